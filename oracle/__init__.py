@@ -1,0 +1,506 @@
+"""ctypes wrapper of the CPU ORACLE (oracle/prost_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under prost_amd/ imports this module.
+
+It consumes the same nested problem descriptions the product's front-end produces
+(prost_amd.problem / .block / .function / .backend -- mirrors of the MATLAB cells).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libprost_oracle.so")
+
+FUNCTIONS = ("zero", "abs", "square", "ind_leq0", "ind_geq0", "ind_eq0", "ind_box01",
+             "max_pos0", "l0", "huber", "lq", "lq_plus_eps", "trunclin", "truncquad")
+FN_ID = {n: i for i, n in enumerate(FUNCTIONS)}
+OP_1D, OP_NORM2 = 0, 1
+STEPSIZE = {"alg1": 0, "alg2": 1, "goldstein": 2, "boyd": 3}
+PROX_G, PROX_F, PROX_GSTAR, PROX_FSTAR = 0, 1, 2, 3
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "prost_oracle.cpp")):
+        subprocess.check_call(["make", "-C", _HERE, "libprost_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class PDHGOpts(C.Structure):
+    _fields_ = [("tau0", C.c_double), ("sigma0", C.c_double), ("residual_iter", C.c_int),
+                ("scale_steps_operator", C.c_int), ("alg2_gamma", C.c_double),
+                ("arg_alpha0", C.c_double), ("arg_nu", C.c_double), ("arg_delta", C.c_double),
+                ("arb_delta", C.c_double), ("arb_tau", C.c_double), ("stepsize", C.c_int)]
+
+
+class ADMMOpts(C.Structure):
+    _fields_ = [("rho0", C.c_double), ("residual_iter", C.c_int), ("arb_delta", C.c_double),
+                ("arb_tau", C.c_double), ("arb_gamma", C.c_double), ("alpha", C.c_double),
+                ("cg_max_iter", C.c_int), ("cg_tol_pow", C.c_double), ("cg_tol_min", C.c_double),
+                ("cg_tol_max", C.c_double)]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [("tol_rel_primal", C.c_double), ("tol_rel_dual", C.c_double),
+                ("tol_abs_primal", C.c_double), ("tol_abs_dual", C.c_double),
+                ("max_iters", C.c_int), ("num_cback_calls", C.c_int), ("verbose", C.c_int),
+                ("solve_dual", C.c_int), ("x0", C.POINTER(C.c_double)), ("nx0", C.c_size_t),
+                ("y0", C.POINTER(C.c_double)), ("ny0", C.c_size_t)]
+
+
+INTERM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_size_t,
+                        C.POINTER(C.c_double), C.c_size_t)
+STOP_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double))
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_last_error.restype = C.c_char_p
+        vp, sz, i32, dbl = C.c_void_p, C.c_size_t, C.c_int, C.c_double
+        L.orc_grad2d.argtypes = [i32, i32, vp, vp, sz, sz, sz, i32]
+        L.orc_grad3d.argtypes = [i32, i32, vp, vp, sz, sz, sz, i32]
+        L.orc_diags_sort.argtypes = [sz, vp, vp]
+        L.orc_diags.argtypes = [i32, i32, vp, vp, sz, sz, sz, vp, vp, i32]
+        L.orc_csr2csc.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.orc_csr_spmv_acc.argtypes = [i32, vp, vp, i32, vp, vp, vp]
+        L.orc_prox_elem.argtypes = [i32, i32, i32, vp, vp, vp, dbl, i32, sz, sz, i32, vp, vp]
+        L.orc_prox_epi_quad.argtypes = [i32, vp, vp, sz, sz, vp, dbl, vp, vp, dbl]
+        L.orc_glibc_rand_fill.argtypes = [C.c_uint, sz, vp]
+        L.orc_glibc_rand_fill.restype = None
+        L.orc_linspace.argtypes = [dbl, dbl, i32, vp]
+        L.orc_set_num_threads.argtypes = [i32]
+        L.orc_set_num_threads.restype = None
+        L.orc_problem_create.argtypes = [i32, sz, sz]
+        L.orc_problem_create.restype = vp
+        L.orc_problem_destroy.argtypes = [vp]
+        L.orc_problem_destroy.restype = None
+        L.orc_problem_add_block_grad.argtypes = [vp, i32, sz, sz, sz, sz, sz, i32]
+        L.orc_problem_add_block_diags.argtypes = [vp, sz, sz, sz, sz, sz, vp, vp]
+        L.orc_problem_add_block_sparse_csc.argtypes = [vp, sz, sz, i32, i32, i32, vp, vp, vp]
+        L.orc_problem_add_block_zero.argtypes = [vp, sz, sz, sz, sz]
+        L.orc_prox_elem_create.argtypes = [i32, i32, sz, sz, sz, i32, i32, vp, vp]
+        L.orc_prox_elem_create.restype = vp
+        L.orc_prox_moreau_create.argtypes = [vp]
+        L.orc_prox_moreau_create.restype = vp
+        L.orc_prox_zero_create.argtypes = [sz, sz]
+        L.orc_prox_zero_create.restype = vp
+        L.orc_prox_epi_quad_create.argtypes = [sz, sz, sz, i32, i32, vp, sz, vp, sz, vp, sz]
+        L.orc_prox_epi_quad_create.restype = vp
+        L.orc_prox_destroy.argtypes = [vp]
+        L.orc_prox_destroy.restype = None
+        L.orc_prox_size.argtypes = [vp]
+        L.orc_prox_size.restype = sz
+        L.orc_prox_eval.argtypes = [vp, i32, vp, vp, vp, dbl]
+        L.orc_problem_add_prox.argtypes = [vp, i32, vp]
+        L.orc_problem_set_scaling_alpha.argtypes = [vp, dbl]
+        L.orc_problem_set_scaling_identity.argtypes = [vp]
+        L.orc_problem_set_scaling_custom.argtypes = [vp, vp, sz, vp, sz]
+        L.orc_problem_initialize.argtypes = [vp]
+        L.orc_problem_get_scaling.argtypes = [vp, vp, vp]
+        L.orc_problem_normest.argtypes = [vp, dbl, i32, vp]
+        L.orc_problem_nrows.argtypes = [vp]
+        L.orc_problem_nrows.restype = sz
+        L.orc_problem_ncols.argtypes = [vp]
+        L.orc_problem_ncols.restype = sz
+        L.orc_linop_eval.argtypes = [vp, i32, vp, vp]
+        L.orc_linop_sums.argtypes = [vp, dbl, vp, vp]
+        L.orc_solver_create_pdhg.argtypes = [vp, C.POINTER(PDHGOpts), C.POINTER(SolverOpts)]
+        L.orc_solver_create_pdhg.restype = vp
+        L.orc_solver_create_admm.argtypes = [vp, C.POINTER(ADMMOpts), C.POINTER(SolverOpts)]
+        L.orc_solver_create_admm.restype = vp
+        L.orc_solver_destroy.argtypes = [vp]
+        L.orc_solver_destroy.restype = None
+        L.orc_solver_set_callbacks.argtypes = [vp, INTERM_CB, STOP_CB, vp]
+        L.orc_solver_set_allreduce.argtypes = [vp, ALLREDUCE_CB, vp, sz, sz]
+        L.orc_solver_initialize.argtypes = [vp]
+        L.orc_solver_iterate.argtypes = [vp, i32]
+        L.orc_solver_solve.argtypes = [vp, vp, vp]
+        L.orc_solver_get.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_solver_scalars.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OracleError(lib().orc_last_error().decode())
+
+
+def _dt(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return 0
+    if dtype == np.float64:
+        return 1
+    raise ValueError("dtype must be float32 or float64")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+# ------------------------------------------------------------------------------------------
+# leaf operators
+# ------------------------------------------------------------------------------------------
+def grad2d(rhs, nx, ny, L, label_first=False, adjoint=False, acc=None):
+    rhs = np.ascontiguousarray(rhs)
+    n = nx * ny * L
+    res = np.zeros(n if adjoint else 2 * n, dtype=rhs.dtype) if acc is None else acc
+    _chk(lib().orc_grad2d(_dt(rhs.dtype), int(adjoint), _p(res), _p(rhs), nx, ny, L, int(label_first)))
+    return res
+
+
+def grad3d(rhs, nx, ny, L, label_first=False, adjoint=False, acc=None):
+    rhs = np.ascontiguousarray(rhs)
+    n = nx * ny * L
+    res = np.zeros(n if adjoint else 3 * n, dtype=rhs.dtype) if acc is None else acc
+    _chk(lib().orc_grad3d(_dt(rhs.dtype), int(adjoint), _p(res), _p(rhs), nx, ny, L, int(label_first)))
+    return res
+
+
+def diags_sort(offsets, factors, dtype):
+    """BlockDiags constructor: double -> real -> float narrowing + bubble sort."""
+    ofs = np.array(offsets, dtype=np.int64).copy()
+    fac = np.array(factors, dtype=np.float64).astype(dtype).astype(np.float32).copy()
+    _chk(lib().orc_diags_sort(len(ofs), _p(ofs), _p(fac)))
+    return ofs, fac
+
+
+def diags(rhs, nrows, ncols, offsets_sorted, factors_f32, adjoint=False, ref_grid_quirk=False, acc=None):
+    rhs = np.ascontiguousarray(rhs)
+    res = np.zeros(ncols if adjoint else nrows, dtype=rhs.dtype) if acc is None else acc
+    _chk(lib().orc_diags(_dt(rhs.dtype), int(adjoint), _p(res), _p(rhs), nrows, ncols, len(offsets_sorted),
+                         _p(offsets_sorted), _p(factors_f32), int(ref_grid_quirk)))
+    return res
+
+
+def csr2csc(n, m, val, col_idx, row_start):
+    val = np.ascontiguousarray(val)
+    nz = len(val)
+    col_idx = np.ascontiguousarray(col_idx, dtype=np.int32)
+    row_start = np.ascontiguousarray(row_start, dtype=np.int32)
+    out_val = np.zeros(nz, dtype=val.dtype)
+    row_idx = np.zeros(nz, dtype=np.int32)
+    col_start = np.zeros(m + 1, dtype=np.int32)
+    _chk(lib().orc_csr2csc(_dt(val.dtype), n, m, nz, _p(val), _p(col_idx), _p(row_start),
+                           _p(out_val), _p(row_idx), _p(col_start)))
+    return out_val, row_idx, col_start
+
+
+def csr_spmv_acc(res, rhs, val, ptr, ind):
+    ptr = np.ascontiguousarray(ptr, dtype=np.int32)
+    ind = np.ascontiguousarray(ind, dtype=np.int32)
+    _chk(lib().orc_csr_spmv_acc(_dt(res.dtype), _p(res), _p(rhs), len(ptr) - 1, _p(val), _p(ptr), _p(ind)))
+    return res
+
+
+def prox_elem(op, fn, arg, tau_diag, tau, count, dim, interleaved, coeffs, invert_tau=False):
+    """coeffs: 7 entries, each scalar or array of length count."""
+    arg = np.ascontiguousarray(arg)
+    tau_diag = np.ascontiguousarray(tau_diag, dtype=arg.dtype)
+    res = np.zeros_like(arg)
+    ptrs = (C.c_void_p * 7)()
+    vals = (C.c_double * 7)()
+    keep = []
+    for i, c in enumerate(coeffs):
+        c = np.atleast_1d(np.asarray(c, dtype=np.float64))
+        if c.size > 1:
+            a = np.ascontiguousarray(c.astype(arg.dtype))
+            keep.append(a)
+            ptrs[i] = a.ctypes.data
+            vals[i] = 0.0
+        else:
+            ptrs[i] = None
+            vals[i] = float(c[0])
+    fn_id = FN_ID[fn] if isinstance(fn, str) else fn
+    _chk(lib().orc_prox_elem(_dt(arg.dtype), op, fn_id, _p(res), _p(arg), _p(tau_diag), float(tau),
+                             int(invert_tau), count, dim, int(interleaved), ptrs, vals))
+    return res
+
+
+def prox_epi_quad(arg, count, dim, a, b, c):
+    arg = np.ascontiguousarray(arg)
+    res = np.zeros_like(arg)
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64)).astype(arg.dtype)
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float64).astype(arg.dtype))
+    c = np.atleast_1d(np.asarray(c, dtype=np.float64)).astype(arg.dtype)
+    _chk(lib().orc_prox_epi_quad(_dt(arg.dtype), _p(res), _p(arg), count, dim,
+                                 _p(a) if a.size > 1 else None, float(a[0]), _p(b),
+                                 _p(c) if c.size > 1 else None, float(c[0])))
+    return res
+
+
+def glibc_rand(seed, n):
+    out = np.zeros(n, dtype=np.int32)
+    lib().orc_glibc_rand_fill(seed, n, _p(out))
+    return out
+
+
+def linspace(start, end, num):
+    out = np.zeros(num + 1)
+    lib().orc_linspace(float(start), float(end), int(num), _p(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# description -> oracle objects
+# ------------------------------------------------------------------------------------------
+def make_prox(desc):
+    """desc = [name, idx, size, diagsteps, data]  (factory.cpp:820-867)"""
+    L = lib()
+    if len(desc) != 5:
+        raise OracleError("Invalid prox description. Dim = %d (should be 5)." % len(desc))
+    name, idx, size, diagsteps, data = desc
+    if name.startswith("elem_operation:"):
+        _, kind, fn = name.split(":")
+        count, dim, interleaved, coeffs = data
+        op = OP_1D if kind == "1d" else OP_NORM2
+        expect = size if op == OP_1D else count          # factory.cpp:326-327 / :341-342
+        arrs = []
+        for c in coeffs:
+            c = np.atleast_1d(np.asarray(c, dtype=np.float64)).ravel()
+            if c.size != 1 and c.size != expect:
+                raise OracleError("Size of coefficients should be either 1 or count.")
+            arrs.append(np.ascontiguousarray(c))
+        ptrs = (C.c_void_p * 7)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * 7)(*[a.size for a in arrs])
+        return L.orc_prox_elem_create(op, FN_ID[fn], idx, int(count), int(dim), int(interleaved),
+                                      int(diagsteps), ptrs, lens)
+    if name == "moreau":
+        return L.orc_prox_moreau_create(make_prox(data[0]))
+    if name == "zero":
+        return L.orc_prox_zero_create(idx, size)
+    if name == "ind_epi_quad":
+        count, dim, interleaved, (a, b, c) = data
+        a, b, c = [np.ascontiguousarray(np.atleast_1d(np.asarray(v, dtype=np.float64)).ravel()) for v in (a, b, c)]
+        return L.orc_prox_epi_quad_create(idx, int(count), int(dim), int(interleaved), int(diagsteps),
+                                          _p(a), a.size, _p(b), b.size, _p(c), c.size)
+    raise OracleError("Creating prox with ID '%s' failed. Reason: Name not registered in ProxFactory." % name)
+
+
+def eval_prox(prox_fn, arg, tau, Tau, dtype=np.float64):
+    """prost.eval_prox (eval_prox.m:7): prox_fn(0, len(arg)) evaluated through Prox::Eval."""
+    arg = np.ascontiguousarray(np.asarray(arg, dtype=np.float64).astype(dtype))
+    Tau = np.ascontiguousarray(np.asarray(Tau, dtype=np.float64).astype(dtype))
+    h = make_prox(prox_fn(0, arg.size))
+    try:
+        if lib().orc_prox_size(h) != arg.size:
+            raise OracleError("Size of input argument doesn't match size of prox!")
+        res = np.zeros_like(arg)
+        _chk(lib().orc_prox_eval(h, _dt(dtype), _p(res), _p(arg), _p(Tau), float(tau)))
+    finally:
+        lib().orc_prox_destroy(h)
+    return res.astype(np.float64)
+
+
+class Problem:
+    def __init__(self, data, nrows, ncols, dtype=np.float64):
+        L = lib()
+        self.dtype = np.dtype(dtype)
+        self.nrows, self.ncols = int(nrows), int(ncols)
+        self.h = L.orc_problem_create(_dt(dtype), self.nrows, self.ncols)
+        for blk in data.get("linop", []):
+            self.add_block(blk)
+        for key, which in (("prox_g", PROX_G), ("prox_f", PROX_F), ("prox_gstar", PROX_GSTAR),
+                           ("prox_fstar", PROX_FSTAR)):
+            for p in data.get(key, []):
+                _chk(L.orc_problem_add_prox(self.h, which, make_prox(p)))
+        sc = data.get("scaling", "alpha")
+        if sc == "alpha":
+            L.orc_problem_set_scaling_alpha(self.h, float(data.get("scaling_alpha", 1)))
+        elif sc == "identity":
+            L.orc_problem_set_scaling_identity(self.h)
+        elif sc == "custom":
+            l = np.ascontiguousarray(data["scaling_left"], dtype=np.float64)
+            r = np.ascontiguousarray(data["scaling_right"], dtype=np.float64)
+            L.orc_problem_set_scaling_custom(self.h, _p(l), l.size, _p(r), r.size)
+        else:
+            raise OracleError("Problem scaling variant not recognized. Options are {'alpha', 'identity', 'custom'}.")
+
+    def add_block(self, blk):
+        L = lib()
+        if len(blk) != 4:
+            raise OracleError("Invalid block description. Dim != 4.")
+        name, row, col, data = blk
+        if name in ("gradient2d", "gradient3d"):
+            nx, ny, Lc, lf = data
+            _chk(L.orc_problem_add_block_grad(self.h, int(name == "gradient3d"), row, col, nx, ny, Lc, int(lf)))
+        elif name == "diags":
+            nrows, ncols, factors, offsets = data
+            f = np.ascontiguousarray(np.atleast_1d(factors), dtype=np.float64)
+            o = np.ascontiguousarray(np.atleast_1d(offsets)).astype(np.int64)
+            if f.size != o.size:
+                raise OracleError("Mismatch of size(factors) and size(offsets).")
+            _chk(L.orc_problem_add_block_diags(self.h, row, col, int(nrows), int(ncols), f.size, _p(o), _p(f)))
+        elif name == "sparse":
+            K = data[0]
+            val = np.ascontiguousarray(K.data, dtype=np.float64)
+            jc = np.ascontiguousarray(K.indptr, dtype=np.int32)
+            ir = np.ascontiguousarray(K.indices, dtype=np.int32)
+            _chk(L.orc_problem_add_block_sparse_csc(self.h, row, col, K.shape[0], K.shape[1], K.nnz,
+                                                    _p(val), _p(jc), _p(ir)))
+        elif name == "zero":
+            _chk(L.orc_problem_add_block_zero(self.h, row, col, int(data[0]), int(data[1])))
+        else:
+            raise OracleError("Creating block with ID '%s' failed. Reason: Name not registered in BlockFactory." % name)
+
+    def initialize(self):
+        _chk(lib().orc_problem_initialize(self.h))
+
+    def scaling(self):
+        l = np.zeros(self.nrows)
+        r = np.zeros(self.ncols)
+        lib().orc_problem_get_scaling(self.h, _p(l), _p(r))
+        return l, r
+
+    def normest(self, tol=1e-6, max_iters=100):
+        out = C.c_double()
+        _chk(lib().orc_problem_normest(self.h, tol, max_iters, C.byref(out)))
+        return out.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_problem_destroy(self.h)
+            self.h = None
+
+
+def eval_linop(linop, rhs, transpose, dtype=np.float64):
+    """prost.eval_linop (prost.cpp:157-224): returns (result, rowsum, colsum)."""
+    P = Problem({"linop": linop}, 0, 0, dtype)
+    rhs = np.ascontiguousarray(np.asarray(rhs, dtype=np.float64).astype(dtype))
+    # sizes of the assembled operator
+    nrows = max(_block_size(b)[0] + b[1] for b in linop)
+    ncols = max(_block_size(b)[1] + b[2] for b in linop)
+    res = np.zeros(ncols if transpose else nrows, dtype=dtype)
+    _chk(lib().orc_linop_eval(P.h, int(transpose), _p(res), _p(rhs)))
+    rowsum = np.zeros(nrows)
+    colsum = np.zeros(ncols)
+    _chk(lib().orc_linop_sums(P.h, 1.0, _p(rowsum), _p(colsum)))
+    return res.astype(np.float64), rowsum, colsum
+
+
+def _block_size(blk):
+    name, row, col, data = blk
+    if name == "gradient2d":
+        n = data[0] * data[1] * data[2]
+        return 2 * n, n
+    if name == "gradient3d":
+        n = data[0] * data[1] * data[2]
+        return 3 * n, n
+    if name == "sparse":
+        return data[0].shape
+    return int(data[0]), int(data[1])
+
+
+class Solver:
+    """Oracle Solver/Backend pair built from (prob.data, nrows, ncols, backend, opts)."""
+
+    def __init__(self, data, nrows, ncols, backend, opts, dtype=np.float64):
+        L = lib()
+        self.problem = Problem(data, nrows, ncols, dtype)
+        self._keep = []
+        so = SolverOpts()
+        for k in ("tol_rel_primal", "tol_rel_dual", "tol_abs_primal", "tol_abs_dual"):
+            setattr(so, k, float(opts[k]))
+        so.max_iters = int(opts["max_iters"])
+        so.num_cback_calls = int(opts["num_cback_calls"])
+        so.verbose = int(bool(opts.get("verbose", False)))
+        so.solve_dual = int(bool(opts.get("solve_dual", False)))
+        for key, pf, nf in (("x0", "x0", "nx0"), ("y0", "y0", "ny0")):
+            v = opts.get(key)
+            if v is not None and len(v) > 0:
+                a = np.ascontiguousarray(v, dtype=np.float64)
+                self._keep.append(a)
+                setattr(so, pf, a.ctypes.data_as(C.POINTER(C.c_double)))
+                setattr(so, nf, a.size)
+        name, bo = backend[0].lower(), backend[1]
+        if name == "pdhg":
+            po = PDHGOpts(float(bo["tau0"]), float(bo["sigma0"]), int(bo["residual_iter"]),
+                          int(bool(bo["scale_steps_operator"])), float(bo["alg2_gamma"]),
+                          float(bo["arg_alpha0"]), float(bo["arg_nu"]), float(bo["arg_delta"]),
+                          float(bo["arb_delta"]), float(bo["arb_tau"]), STEPSIZE[bo["stepsize"]])
+            self.h = L.orc_solver_create_pdhg(self.problem.h, C.byref(po), C.byref(so))
+        elif name == "admm":
+            ao = ADMMOpts(float(bo["rho0"]), int(bo["residual_iter"]), float(bo["arb_delta"]),
+                          float(bo["arb_tau"]), float(bo["arb_gamma"]), float(bo["alpha"]),
+                          int(bo["cg_max_iter"]), float(bo["cg_tol_pow"]), float(bo["cg_tol_min"]),
+                          float(bo["cg_tol_max"]))
+            self.h = L.orc_solver_create_admm(self.problem.h, C.byref(ao), C.byref(so))
+        else:
+            raise OracleError("Creating backend with ID '%s' failed." % name)
+        self.nrows, self.ncols = int(nrows), int(ncols)
+        self.solve_dual = bool(opts.get("solve_dual", False))
+        cb = opts.get("interm_cb")
+        self._icb = self._scb = None
+        if cb is not None:
+            def _icb(user, it, x, nx, y, ny):
+                return int(bool(cb(it, np.ctypeslib.as_array(x, (nx,)).copy(), np.ctypeslib.as_array(y, (ny,)).copy())))
+            self._icb = INTERM_CB(_icb)
+            L.orc_solver_set_callbacks(self.h, self._icb, C.cast(None, STOP_CB), None)
+
+    def set_allreduce(self, fn, global_nrows, global_ncols):
+        def _ar(user, v):
+            a = np.ctypeslib.as_array(v, (4,))
+            a[:] = fn(a.copy())
+        self._ar = ALLREDUCE_CB(_ar)
+        lib().orc_solver_set_allreduce(self.h, self._ar, None, global_nrows, global_ncols)
+
+    def initialize(self):
+        _chk(lib().orc_solver_initialize(self.h))
+
+    def iterate(self, iters=1):
+        _chk(lib().orc_solver_iterate(self.h, iters))
+
+    def solve(self):
+        r, k = C.c_int(), C.c_int()
+        _chk(lib().orc_solver_solve(self.h, C.byref(r), C.byref(k)))
+        return ("Converged.", "Reached maximum iterations.", "Stopped by user.")[r.value], k.value
+
+    def state(self):
+        n, m = self.ncols, self.nrows
+        x, z, y, w = np.zeros(n), np.zeros(m), np.zeros(m), np.zeros(n)
+        _chk(lib().orc_solver_get(self.h, _p(x), _p(z), _p(y), _p(w)))
+        return dict(x=x, z=z, y=y, w=w)
+
+    def scalars(self):
+        o = np.zeros(12)
+        _chk(lib().orc_solver_scalars(self.h, _p(o)))
+        keys = ("tau", "sigma", "theta", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm",
+                "eps_primal", "eps_dual", "iteration", "rho", "delta")
+        return dict(zip(keys, o))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_solver_destroy(self.h)
+            self.h = None
+
+
+def solve(prob, backend, opts, dtype=np.float64):
+    """prost.solve mirror on the oracle (solve.m:5-9)."""
+    prob.finalize()
+    s = Solver(prob.data, prob.nrows, prob.ncols, backend, opts, dtype)
+    s.initialize()
+    result, iters = s.solve()
+    st = s.state()
+    st["result"] = result
+    st["iters"] = iters
+    prob.fill_variables(st)
+    return st

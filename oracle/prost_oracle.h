@@ -1,0 +1,163 @@
+/*
+ * prost_oracle.h -- C interface of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is a from-scratch CPU restatement of
+ * the reference (tum-vision/prost) hot path.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (libprost_hip.so /
+ * libprost.so / prost_amd) never links, loads or calls anything in oracle/.
+ *
+ * Parity status: PINNED -- checked (tests/test_oracle_pinning.py) against
+ *   (i)  the reference's own sources compiled where they lie (oracle/_ref, see
+ *        oracle/Makefile.ref) for every Function1D / ElemOperation1D /
+ *        ElemOperationNorm2 / ProjectEpiQuadNd / PDHG backend / Problem setup,
+ *   (ii) restatements of the reference's MATLAB tests (spmat_gradient2d/3d,
+ *        ball projection, conjugate identities) in tests/test_oracle_*.py,
+ *   (iii) fixtures generated from (i) and committed under tests/golden/.
+ * ADMM/CGLS: the reference needs cuBLAS + cuSPARSE (absent) -> pinned only by
+ * the restated algebraic properties; stated "parity unpinned" for ADMM in DESIGN.md.
+ *
+ * dtype: 0 = float, 1 = double.  All array arguments are host pointers of that
+ * dtype unless typed explicitly.  Every function returns 0 on success; on
+ * failure a message is available from orc_last_error().
+ */
+#ifndef PROST_ORACLE_H_
+#define PROST_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* orc_last_error(void);
+void orc_set_num_threads(int n);   /* OpenMP threads for the hot loops (default 1) */
+
+/* ---- function ids (reference: matlab/+prost/private/factory.cpp:21-48) ---- */
+enum {
+  ORC_FN_ZERO = 0, ORC_FN_ABS, ORC_FN_SQUARE, ORC_FN_IND_LEQ0, ORC_FN_IND_GEQ0,
+  ORC_FN_IND_EQ0, ORC_FN_IND_BOX01, ORC_FN_MAX_POS0, ORC_FN_L0, ORC_FN_HUBER,
+  ORC_FN_LQ, ORC_FN_LQ_PLUS_EPS, ORC_FN_TRUNCLIN, ORC_FN_TRUNCQUAD, ORC_FN_COUNT
+};
+enum { ORC_OP_1D = 0, ORC_OP_NORM2 = 1 };
+
+/* ---- leaf operators (reference seams eval_linop / eval_prox) ---- */
+/* res += K rhs (adjoint=0) or res += K^T rhs (adjoint=1); block_gradient2d.cu:26-139 */
+int orc_grad2d(int dtype, int adjoint, void* res, const void* rhs,
+               size_t nx, size_t ny, size_t L, int label_first);
+/* block_gradient3d.cu:25-150 */
+int orc_grad3d(int dtype, int adjoint, void* res, const void* rhs,
+               size_t nx, size_t ny, size_t L, int label_first);
+/* block_diags.cu:99-119 (constructor bubble sort, factors narrowed to float) */
+int orc_diags_sort(size_t ndiags, int64_t* offsets, float* factors);
+/* block_diags.cu:36-96; ref_grid_quirk=1 reproduces the adjoint launch grid sized
+ * by nrows (block_diags.cu:211): columns >= ceil(nrows/256)*256 are not written. */
+int orc_diags(int dtype, int adjoint, void* res, const void* rhs,
+              size_t nrows, size_t ncols, size_t ndiags,
+              const int64_t* offsets, const float* factors, int ref_grid_quirk);
+/* common.cu:55-82 */
+int orc_csr2csc(int dtype, int n, int m, int nz, const void* a, const int32_t* col_idx,
+                const int32_t* row_start, void* csc_a, int32_t* row_idx, int32_t* col_start);
+/* res += A rhs, CSR; semantics of cusparse<t>csrmv alpha=beta=1 (block_sparse.cu:146-177) */
+int orc_csr_spmv_acc(int dtype, void* res, const void* rhs, int nrows,
+                     const void* val, const int32_t* ptr, const int32_t* ind);
+/* prox_elem_operation.inl:59-94 + elem_operation_1d.hpp:36-59 / elem_operation_norm2.hpp:40-88.
+ * coeff_ptr[i]==NULL -> scalar coeff_val[i] (converted to dtype), else per-element array. */
+int orc_prox_elem(int dtype, int op, int fn, void* res, const void* arg, const void* tau_diag,
+                  double tau, int invert_tau, size_t count, size_t dim, int interleaved,
+                  const void* const* coeff_ptr, const double* coeff_val);
+/* prox_ind_epi_quad.cu:42-79 + helper.hpp:44-105 */
+int orc_prox_epi_quad(int dtype, void* res, const void* arg, size_t count, size_t dim,
+                      const void* a_ptr, double a_val, const void* b_ptr,
+                      const void* c_ptr, double c_val);
+/* glibc rand() restated (TYPE_3 additive feedback); used by normest (problem.cu:435) */
+void orc_glibc_rand_fill(unsigned seed, size_t n, int32_t* out);
+/* common.cu:33-46 ; out must hold num+1 doubles */
+int orc_linspace(double start, double end, int num, double* out);
+
+/* ---- problem object (reference: src/problem.cu, src/linop/linearoperator.cu) ---- */
+typedef struct orc_problem orc_problem;
+typedef struct orc_prox orc_prox;
+typedef struct orc_solver orc_solver;
+
+orc_problem* orc_problem_create(int dtype, size_t nrows, size_t ncols);
+void orc_problem_destroy(orc_problem*);
+int orc_problem_add_block_grad(orc_problem*, int is3d, size_t row, size_t col,
+                               size_t nx, size_t ny, size_t L, int label_first);
+int orc_problem_add_block_diags(orc_problem*, size_t row, size_t col, size_t nrows, size_t ncols,
+                                size_t ndiags, const int64_t* offsets, const double* factors);
+/* MATLAB CSC as handed to factory.cpp:633-655 */
+int orc_problem_add_block_sparse_csc(orc_problem*, size_t row, size_t col, int nrows, int ncols,
+                                     int nnz, const double* val, const int32_t* jc, const int32_t* ir);
+int orc_problem_add_block_zero(orc_problem*, size_t row, size_t col, size_t nrows, size_t ncols);
+
+/* coeff[i] has coeff_len[i] entries (1 or count, resp. size for 1d) */
+orc_prox* orc_prox_elem_create(int op, int fn, size_t idx, size_t count, size_t dim,
+                               int interleaved, int diagsteps,
+                               const double* const* coeff, const size_t* coeff_len);
+orc_prox* orc_prox_moreau_create(orc_prox* child);         /* takes ownership of child */
+orc_prox* orc_prox_zero_create(size_t idx, size_t size);
+orc_prox* orc_prox_epi_quad_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps,
+                                   const double* a, size_t na, const double* b, size_t nb,
+                                   const double* c, size_t nc);
+void orc_prox_destroy(orc_prox*);
+/* Prox::Eval(host vectors) prox.cu:46-71 ; vectors have prox->size entries, offset 0 */
+int orc_prox_eval(orc_prox*, int dtype, void* res, const void* arg, const void* tau_diag, double tau);
+size_t orc_prox_size(const orc_prox*);
+
+enum { ORC_PROX_G = 0, ORC_PROX_F = 1, ORC_PROX_GSTAR = 2, ORC_PROX_FSTAR = 3 };
+int orc_problem_add_prox(orc_problem*, int which, orc_prox*);  /* takes ownership */
+int orc_problem_set_scaling_alpha(orc_problem*, double alpha);
+int orc_problem_set_scaling_identity(orc_problem*);
+int orc_problem_set_scaling_custom(orc_problem*, const double* left, size_t nl, const double* right, size_t nr);
+int orc_problem_initialize(orc_problem*);            /* problem.cu:196-323 */
+int orc_problem_get_scaling(const orc_problem*, double* left, double* right);
+int orc_problem_normest(orc_problem*, double tol, int max_iters, double* out); /* problem.cu:429-500 */
+size_t orc_problem_nrows(const orc_problem*);
+size_t orc_problem_ncols(const orc_problem*);
+/* LinearOperator::Eval / EvalAdjoint with beta = 0 (linearoperator.cu:135-170) */
+int orc_linop_eval(orc_problem*, int adjoint, void* res, const void* rhs);
+int orc_linop_sums(orc_problem*, double alpha, double* rowsum, double* colsum);
+
+/* ---- backends + solver (backend_pdhg.cu, backend_admm.cu, cgls.hpp, solver.cu) ---- */
+enum { ORC_STEP_ALG1 = 0, ORC_STEP_ALG2 = 1, ORC_STEP_GOLDSTEIN = 2, ORC_STEP_BOYD = 3 };
+typedef struct {
+  double tau0, sigma0; int residual_iter; int scale_steps_operator;
+  double alg2_gamma, arg_alpha0, arg_nu, arg_delta, arb_delta, arb_tau; int stepsize;
+} orc_pdhg_opts;
+typedef struct {
+  double rho0; int residual_iter; double arb_delta, arb_tau, arb_gamma, alpha;
+  int cg_max_iter; double cg_tol_pow, cg_tol_min, cg_tol_max;
+} orc_admm_opts;
+typedef struct {
+  double tol_rel_primal, tol_rel_dual, tol_abs_primal, tol_abs_dual;
+  int max_iters, num_cback_calls, verbose, solve_dual;
+  const double* x0; size_t nx0; const double* y0; size_t ny0;
+} orc_solver_opts;
+
+/* interm callback: (user, iteration, x, nx, y, ny) -> nonzero = converged.
+ * stop callback: (user) -> nonzero = stop.  Both may be NULL. */
+typedef int (*orc_interm_cb)(void* user, int it, const double* x, size_t nx, const double* y, size_t ny);
+typedef int (*orc_stop_cb)(void* user);
+/* global residual hook (multi-rank batches): sums the 4 squared sums in place */
+typedef void (*orc_allreduce_cb)(void* user, double* v4);
+
+orc_solver* orc_solver_create_pdhg(orc_problem*, const orc_pdhg_opts*, const orc_solver_opts*);
+orc_solver* orc_solver_create_admm(orc_problem*, const orc_admm_opts*, const orc_solver_opts*);
+void orc_solver_destroy(orc_solver*);
+int orc_solver_set_callbacks(orc_solver*, orc_interm_cb, orc_stop_cb, void* user);
+int orc_solver_set_allreduce(orc_solver*, orc_allreduce_cb, void* user, size_t global_nrows, size_t global_ncols);
+int orc_solver_initialize(orc_solver*);              /* solver.cu:68-120 */
+int orc_solver_iterate(orc_solver*, int iters);      /* PerformIteration x iters, no tests */
+/* solver.cu:123-209 ; *result: 0 converged, 1 max iters, 2 stopped by user */
+int orc_solver_solve(orc_solver*, int* result, int* iters_done);
+/* current_solution (x n, z m, y m, w n) as doubles; any pointer may be NULL */
+int orc_solver_get(orc_solver*, double* x, double* z, double* y, double* w);
+/* out[0..11] = tau, sigma, theta, primal_res, dual_res, primal_var_norm, dual_var_norm,
+ *              eps_primal, eps_dual, iteration, rho, delta */
+int orc_solver_scalars(orc_solver*, double* out12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
