@@ -1,0 +1,238 @@
+/*
+ * prost_hip.h -- thin C ABI of the MI355X (gfx950) kernels behind the prost hot path.
+ *
+ * This is the drop-in boundary of the build: plain pointers and sizes, no C++
+ * types, no exceptions, no hidden synchronisation.  Every entry point
+ *   - returns 0 on success, otherwise a non-zero code; the message is prost_hip_last_error();
+ *   - takes DEVICE pointers unless a parameter is documented as host;
+ *   - enqueues on `stream` (a hipStream_t passed as void*; NULL = the null stream) and returns
+ *     without waiting.
+ * Suffix _f32 / _f64 selects the arithmetic type T (the reference instantiates both:
+ * `template class X<float>; template class X<double>;`).
+ *
+ * Each declaration cites the reference interface (file:line under /root/reference) it replaces.
+ * The host C++ layer (include/prost/ *.hpp, libprost.so) calls only these functions; a cgo /
+ * MEX / ctypes binding would bind exactly these symbols.
+ */
+#ifndef PROST_HIP_H_
+#define PROST_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROST_HIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------ */
+/* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
+/* matlab/+prost/private/prost.cpp:69-72,:299-303; src/backend/backend_pdhg.cu:210-221)        */
+/* ------------------------------------------------------------------------------------------ */
+const char* prost_hip_last_error(void);
+int prost_hip_abi_version(void);
+int prost_hip_device_count(int* count);
+int prost_hip_set_device(int device);
+int prost_hip_get_device(int* device);
+/* name: host buffer of `len` bytes; cu_count/total_mem may be NULL (prost.cpp:84-89, :283-297) */
+int prost_hip_device_info(int device, char* name, size_t len, int* cu_count, size_t* total_mem);
+int prost_hip_mem_info(size_t* free_bytes, size_t* total_bytes);          /* solver.cu:103 */
+int prost_hip_malloc(void** dptr, size_t bytes);
+int prost_hip_free(void* dptr);
+int prost_hip_host_alloc(void** hptr, size_t bytes);                      /* pinned host memory */
+int prost_hip_host_free(void* hptr);
+int prost_hip_memcpy_h2d(void* dst, const void* src_host, size_t bytes, void* stream);
+int prost_hip_memcpy_d2h(void* dst_host, const void* src, size_t bytes, void* stream);
+int prost_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int prost_hip_memset(void* dst, int value, size_t bytes, void* stream);
+int prost_hip_stream_create(void** stream);
+int prost_hip_stream_destroy(void* stream);
+int prost_hip_stream_synchronize(void* stream);
+int prost_hip_device_synchronize(void);
+int prost_hip_event_create(void** event);
+int prost_hip_event_destroy(void* event);
+int prost_hip_event_record(void* event, void* stream);
+int prost_hip_event_synchronize(void* event);
+int prost_hip_event_elapsed_ms(void* start, void* stop, float* ms);
+/* one hipGetLastError per iteration instead of a device sync per prox launch
+ * (prox_elem_operation.inl:128-138) */
+int prost_hip_check_last_error(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* linear operator blocks                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+/* BlockGradient2DKernel / ...Adjoint (src/linop/block_gradient2d.cu:26-78, :81-139; launches
+ * :166-204).  fwd: res[2*nx*ny*L] from rhs[nx*ny*L]; adj: res[nx*ny*L] from rhs[2*nx*ny*L].
+ * acc != 0: res += K rhs (the reference's EvalLocalAdd semantics); acc == 0: res = K rhs
+ * (saves the thrust::fill pass of linearoperator.cu:140-147 when a block owns its rows). */
+int prost_hip_grad2d_fwd_f32(float* res, const float* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+int prost_hip_grad2d_fwd_f64(double* res, const double* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+int prost_hip_grad2d_adj_f32(float* res, const float* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+int prost_hip_grad2d_adj_f64(double* res, const double* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+/* BlockGradient3DKernel / ...Adjoint (src/linop/block_gradient3d.cu:25-81, :83-150; :177-248),
+ * Dirichlet boundary at l = L-1 (:73-76).  fwd res has 3*nx*ny*L entries. */
+int prost_hip_grad3d_fwd_f32(float* res, const float* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+int prost_hip_grad3d_fwd_f64(double* res, const double* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+int prost_hip_grad3d_adj_f32(float* res, const float* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+int prost_hip_grad3d_adj_f64(double* res, const double* rhs, size_t nx, size_t ny, size_t L, int label_first, int acc, void* stream);
+/* BlockDiagsKernel / AdjointKernel (src/linop/block_diags.cu:36-96, launches :187-220).
+ * offsets (sorted ascending, :99-119) and factors (float even for f64, :30,:108) are DEVICE
+ * arrays of ndiags entries (replaces the __constant__ arrays :30-31).  Always accumulates.
+ * ref_grid_quirk != 0 reproduces the adjoint grid sized from nrows (:211): columns
+ * >= ceil(nrows/256)*256 are left untouched. */
+int prost_hip_diags_fwd_f32(float* res, const float* rhs, size_t nrows, size_t ncols, size_t ndiags, const int64_t* offsets, const float* factors, void* stream);
+int prost_hip_diags_fwd_f64(double* res, const double* rhs, size_t nrows, size_t ncols, size_t ndiags, const int64_t* offsets, const float* factors, void* stream);
+int prost_hip_diags_adj_f32(float* res, const float* rhs, size_t nrows, size_t ncols, size_t ndiags, const int64_t* offsets, const float* factors, int ref_grid_quirk, void* stream);
+int prost_hip_diags_adj_f64(double* res, const double* rhs, size_t nrows, size_t ncols, size_t ndiags, const int64_t* offsets, const float* factors, int ref_grid_quirk, void* stream);
+/* res += A rhs, A in CSR with int32 indices: replaces cusparse{S,D}csrmv(alpha=beta=1) at
+ * src/linop/block_sparse.cu:156-168 (forward, K) and :190-202 (adjoint, stored K^T). */
+int prost_hip_csr_spmv_acc_f32(float* res, const float* rhs, size_t nrows, size_t nnz, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_csr_spmv_acc_f64(double* res, const double* rhs, size_t nrows, size_t nnz, const double* val, const int32_t* ptr, const int32_t* ind, void* stream);
+/* x = beta * x (beta == 0 -> zero fill): thrust::fill / transform at linearoperator.cu:140-147 */
+int prost_hip_scale_f32(float* x, size_t n, double beta, void* stream);
+int prost_hip_scale_f64(double* x, size_t n, double beta, void* stream);
+/* x = -x, optionally through a float round trip: thrust::negate<float> at
+ * dual_linearoperator.cu:56-57,:78-79 (via_float reproduces it for f64) */
+int prost_hip_negate_f32(float* x, size_t n, void* stream);
+int prost_hip_negate_f64(double* x, size_t n, int via_float, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* proximal operators                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* function ids, in the order of the registry names of factory.cpp:21-48 */
+enum {
+  PROST_FN_ZERO = 0, PROST_FN_ABS, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, PROST_FN_IND_GEQ0,
+  PROST_FN_IND_EQ0, PROST_FN_IND_BOX01, PROST_FN_MAX_POS0, PROST_FN_L0, PROST_FN_HUBER,
+  PROST_FN_LQ, PROST_FN_LQ_PLUS_EPS, PROST_FN_TRUNCLIN, PROST_FN_TRUNCQUAD, PROST_FN_COUNT
+};
+enum { PROST_OP_1D = 0, PROST_OP_NORM2 = 1 };
+
+/* ProxElemOperationKernel<T, ElemOperation1D|ElemOperationNorm2<T, Function1D*>>
+ * (include/prost/prox/prox_elem_operation.inl:59-94, launch :153-187;
+ * elem_operation_1d.hpp:36-59, elem_operation_norm2.hpp:40-88, function_1d.hpp:34-326).
+ * coeff_ptr: HOST array of 7 DEVICE pointers (NULL entry = use scalar coeff_val[i]);
+ * coeff_val: HOST array of 7 doubles (narrowed to T).  Layout: Vector index
+ * interleaved ? tx*dim+i : tx+count*i (vector.hpp:44-48).  No device sync afterwards. */
+int prost_hip_prox_elem_f32(int op, int fn, float* res, const float* arg, const float* tau_diag, double tau, int invert_tau,
+                            size_t count, size_t dim, int interleaved, const float* const* coeff_ptr, const double* coeff_val, void* stream);
+int prost_hip_prox_elem_f64(int op, int fn, double* res, const double* arg, const double* tau_diag, double tau, int invert_tau,
+                            size_t count, size_t dim, int interleaved, const double* const* coeff_ptr, const double* coeff_val, void* stream);
+/* ProxIndEpiQuadKernel (src/prox/prox_ind_epi_quad.cu:42-79) + helper::ProjectEpiQuadNd
+ * (include/prost/prox/helper.hpp:44-105).  a_ptr/c_ptr NULL -> scalar a_val/c_val. */
+int prost_hip_prox_epi_quad_f32(float* res, const float* arg, size_t count, size_t dim, const float* a_ptr, double a_val, const float* b_ptr, const float* c_ptr, double c_val, void* stream);
+int prost_hip_prox_epi_quad_f64(double* res, const double* arg, size_t count, size_t dim, const double* a_ptr, double a_val, const double* b_ptr, const double* c_ptr, double c_val, void* stream);
+/* MoreauPrescale / MoreauPostscale (src/prox/prox_moreau.cu:29-61, used :110-133) */
+int prost_hip_moreau_prescale_f32(float* scaled, const float* arg, const float* tau_diag, double tau, int invert_tau, size_t n, void* stream);
+int prost_hip_moreau_prescale_f64(double* scaled, const double* arg, const double* tau_diag, double tau, int invert_tau, size_t n, void* stream);
+int prost_hip_moreau_postscale_f32(float* res, const float* arg, const float* tau_diag, double tau, int invert_tau, size_t n, void* stream);
+int prost_hip_moreau_postscale_f64(double* res, const double* arg, const double* tau_diag, double tau, int invert_tau, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* PDHG building blocks, generic path (src/backend/backend_pdhg.cu)                            */
+/* ------------------------------------------------------------------------------------------ */
+/* primal_proxarg_functor (:38-51, used :317-331): temp = x - tau * T .* kty */
+int prost_hip_pdhg_primal_arg_f32(float* temp, const float* x, const float* T, const float* kty, double tau, size_t n, void* stream);
+int prost_hip_pdhg_primal_arg_f64(double* temp, const double* x, const double* T, const double* kty, double tau, size_t n, void* stream);
+/* dual_proxarg_functor (:54-70, used :349-364): temp = y + sigma * S .* ((1+theta) kx - theta kx_prev) */
+int prost_hip_pdhg_dual_arg_f32(float* temp, const float* y, const float* S, const float* kx, const float* kx_prev, double sigma, double theta, size_t m, void* stream);
+int prost_hip_pdhg_dual_arg_f64(double* temp, const double* y, const double* S, const double* kx, const double* kx_prev, double sigma, double theta, size_t m, void* stream);
+/* Residual reductions (primal_residual_transform :97-120, dual_residual_transform :73-94,
+ * thrust::transform_reduce :392-431).  Two-stage deterministic reduction: block partials in
+ * `workspace` (prost_hip_reduce_workspace_bytes() bytes), then one block folds them into
+ * out2[0] = sum diff^2, out2[1] = sum var^2 (DEVICE doubles).  Terms are evaluated in T as the
+ * reference does; the accumulation is in double (the reference's order is unspecified). */
+size_t prost_hip_reduce_workspace_bytes(void);
+int prost_hip_pdhg_residual_primal_f32(double* out2, const float* y_prev, const float* y, const float* S, const float* kx_prev, const float* kx, double sigma, double theta, size_t m, void* workspace, void* stream);
+int prost_hip_pdhg_residual_primal_f64(double* out2, const double* y_prev, const double* y, const double* S, const double* kx_prev, const double* kx, double sigma, double theta, size_t m, void* workspace, void* stream);
+int prost_hip_pdhg_residual_dual_f32(double* out2, const float* x_prev, const float* x, const float* T, const float* kty_prev, const float* kty, double tau, size_t n, void* workspace, void* stream);
+int prost_hip_pdhg_residual_dual_f64(double* out2, const double* x_prev, const double* x, const double* T, const double* kty_prev, const double* kty, double tau, size_t n, void* workspace, void* stream);
+/* compute_w_variable_functor / compute_z_variable_functor (:147-186, used :524-560) */
+int prost_hip_pdhg_w_variable_f32(float* w, const float* x_prev, const float* x, const float* T, const float* kty_prev, double tau, size_t n, void* stream);
+int prost_hip_pdhg_w_variable_f64(double* w, const double* x_prev, const double* x, const double* T, const double* kty_prev, double tau, size_t n, void* stream);
+int prost_hip_pdhg_z_variable_f32(float* z, const float* y_prev, const float* y, const float* S, const float* kx, const float* kx_prev, double sigma, double theta, size_t m, void* stream);
+int prost_hip_pdhg_z_variable_f64(double* z, const double* y_prev, const double* y, const double* S, const double* kx, const double* kx_prev, double sigma, double theta, size_t m, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Fused PDHG passes for K = one gradient2d/gradient3d block (label_first = 0),                */
+/* prox_g = one elem_operation:1d:<fn>, prox_fstar = one elem_operation:norm2:<fn> over the    */
+/* 2L (3 for gradient3d) planar gradient components, uniform preconditioners.                  */
+/* One PerformIteration (backend_pdhg.cu:313-381) = primal pass + dual pass; the vectors kx,   */
+/* kx_prev, kty, kty_prev and temp of the reference are never materialised:                    */
+/*   primal pass: reads y (m), x (n), g-coefficient vectors; writes x_new (n)                  */
+/*   dual pass:   reads y (m), x_new (n), x_old (n);          writes y_new (m)                 */
+/* = 11 floats / pixel / iteration for ROF.                                     */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int is3d;                 /* 0: gradient2d (dual dim 2L), 1: gradient3d (dual dim 3)            */
+  size_t nx, ny, L;
+  int g_fn;                 /* PROST_FN_* of prox_g (elem_operation:1d)                           */
+  const void* g_coeff_ptr[7]; double g_coeff_val[7];
+  int f_fn;                 /* PROST_FN_* of prox_fstar (elem_operation:norm2)                    */
+  const void* f_coeff_ptr[7]; double f_coeff_val[7];
+  double T_val;             /* uniform squared preconditioners (problem.cu:262-287 give           */
+  double S_val;             /*   Sigma = 1/2, Tau = 1/4 (2-D), 1/6 (3-D) for gradient blocks)     */
+} prost_hip_fused_desc;
+
+/* returns 1 if the fused passes support this description for dtype (0 f32, 1 f64) */
+int prost_hip_fused_supported(const prost_hip_fused_desc* desc, int dtype);
+
+/* primal pass of iteration k:  x_new = prox_g(x - tau T K^T y ; T, tau)            (:317-338)
+ * use_kty == 0 reproduces iteration 0, where the reference's kty_ is the zero vector it was
+ * allocated with, not K^T y0 (:213,:377-380).
+ * res_out2 != NULL additionally accumulates the dual residual sums (:73-94, :413-431) with
+ * kty = K^T y (if use_kty) and kty_prev = K^T y_prev (if use_kty_prev); needs `workspace`. */
+int prost_hip_fused_primal_f32(const prost_hip_fused_desc* desc, float* x_new, const float* x, const float* y, const float* y_prev,
+                               double tau, int use_kty, int use_kty_prev, double* res_out2, void* workspace, void* stream);
+int prost_hip_fused_primal_f64(const prost_hip_fused_desc* desc, double* x_new, const double* x, const double* y, const double* y_prev,
+                               double tau, int use_kty, int use_kty_prev, double* res_out2, void* workspace, void* stream);
+/* dual pass of iteration k: y_new = prox_fstar(y + sigma S ((1+theta) K x_new - theta K x_old))
+ * (:341-370).  use_kx_prev == 0 reproduces iteration 0 (kx_prev_ = zero vector, :216).
+ * res_out2 != NULL additionally accumulates the primal residual sums (:97-120, :392-410). */
+int prost_hip_fused_dual_f32(const prost_hip_fused_desc* desc, float* y_new, const float* y, const float* x_new, const float* x_old,
+                             double sigma, double theta, int use_kx_prev, double* res_out2, void* workspace, void* stream);
+int prost_hip_fused_dual_f64(const prost_hip_fused_desc* desc, double* y_new, const double* y, const double* x_new, const double* x_old,
+                             double sigma, double theta, int use_kx_prev, double* res_out2, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* ADMM / CGLS building blocks (src/backend/backend_admm.cu, include/prost/cgls.hpp)           */
+/* ------------------------------------------------------------------------------------------ */
+/* out[0] = sqrt(sum x_i^2), accumulated in double; out is a DEVICE double[2] (out[1] := 0)
+ * (cgls.hpp:152-170 nrm2 via thrust; cublas{S,D}nrm2 at backend_admm.cu:40-50) */
+int prost_hip_nrm2_f32(double* out, const float* x, size_t n, void* workspace, void* stream);
+int prost_hip_nrm2_f64(double* out, const double* x, size_t n, void* workspace, void* stream);
+/* y += alpha x  (cublas{S,D}axpy, cgls.hpp:141-150) */
+int prost_hip_axpy_f32(float* y, const float* x, double alpha, size_t n, void* stream);
+int prost_hip_axpy_f64(double* y, const double* x, double alpha, size_t n, void* stream);
+/* Elementwise ADMM functors (backend_admm.cu:53-196), selected by `op`:
+ *  PROST_ADMM_TEMP1   o = (alpha a + (1-alpha) b + c) / sqrt(d)                 temp1_functor
+ *  PROST_ADMM_TEMP2   o = sqrt(c) (a + b)                                       temp2_functor
+ *  PROST_ADMM_DIFF    o = a - b                                                 difference_functor
+ *  PROST_ADMM_XPROJ   o = sqrt(b) (o + a)                                       x_proj_functor
+ *  PROST_ADMM_XDUAL   o = a sqrt(c) - b                                         x_dual_functor
+ *  PROST_ADMM_ZDUAL   o = a / sqrt(c) - b                                       z_dual_functor
+ *  PROST_ADMM_GEMV1   o = sqrt(a) b                                             gemv_functor1
+ *  PROST_ADMM_GEMV2   o = (beta / (alpha sqrt(a))) b     (alpha, beta scalars)  gemv_functor2
+ *  PROST_ADMM_GEMV3   o = alpha sqrt(a) b                                       gemv_functor3
+ *  PROST_ADMM_GETDUAL o = -alpha pow(d, beta) (a - b + c)   (alpha=rho,beta=expo) get_dual_functor
+ *  PROST_ADMM_SCALE   o = alpha a                                               rescale :650-663 */
+enum { PROST_ADMM_TEMP1 = 0, PROST_ADMM_TEMP2, PROST_ADMM_DIFF, PROST_ADMM_XPROJ, PROST_ADMM_XDUAL, PROST_ADMM_ZDUAL,
+       PROST_ADMM_GEMV1, PROST_ADMM_GEMV2, PROST_ADMM_GEMV3, PROST_ADMM_GETDUAL, PROST_ADMM_SCALE };
+int prost_hip_admm_elem_f32(int op, float* o, const float* a, const float* b, const float* c, const float* d, double alpha, double beta, size_t n, void* stream);
+int prost_hip_admm_elem_f64(int op, double* o, const double* a, const double* b, const double* c, const double* d, double alpha, double beta, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* multi-GPU: global stopping criterion (no counterpart in the reference)        */
+/* ------------------------------------------------------------------------------------------ */
+/* RCCL communicator over the ranks of one node; unique_id is the 128-byte ncclUniqueId made
+ * by rank 0 (prost_hip_comm_unique_id) and broadcast by the launcher. */
+int prost_hip_comm_unique_id(void* id128);
+int prost_hip_comm_create(void** comm, const void* id128, int rank, int world_size);
+int prost_hip_comm_destroy(void* comm);
+/* in-place sum all-reduce of `count` DEVICE doubles (the 4 residual sums) on `stream` */
+int prost_hip_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROST_HIP_H_ */

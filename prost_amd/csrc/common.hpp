@@ -1,0 +1,45 @@
+// common.hpp -- shared plumbing of the gfx950 kernel library (libprost_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "prost_hip.h"
+
+namespace prost_hip {
+
+void set_error(const std::string& msg);
+int fail(hipError_t e, const char* what);
+
+#define PH_CHECK(call)                                              \
+  do {                                                              \
+    hipError_t e_ = (call);                                         \
+    if (e_ != hipSuccess) return ::prost_hip::fail(e_, #call);      \
+  } while (0)
+
+// launch epilogue: surfaces launch-configuration errors without synchronising
+#define PH_LAUNCH_END(name)                                         \
+  do {                                                              \
+    hipError_t e_ = hipGetLastError();                              \
+    if (e_ != hipSuccess) return ::prost_hip::fail(e_, name);       \
+    return 0;                                                       \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 waves, one per SIMD
+constexpr int kMaxGridStride = 256 * 16;   // 256 CUs x 16 blocks: grid-stride cap for streaming kernels
+constexpr int kReduceBlocks = 8192;        // partial slots in the reduction workspace (pairs of doubles)
+
+inline unsigned grid_for(size_t n, int per_thread = 1) {
+  size_t b = (n + (size_t)kBlock * per_thread - 1) / ((size_t)kBlock * per_thread);
+  if (b < 1) b = 1;
+  if (b > (size_t)kMaxGridStride) b = kMaxGridStride;
+  return (unsigned)b;
+}
+
+}  // namespace prost_hip

@@ -1,0 +1,144 @@
+// device_math.hpp -- scalar proximal arithmetic shared by the generic and the fused kernels.
+//
+// Written for gfx950 from the formulas of the reference (cited per function); the fp32 build keeps
+// the reference's implicit promotions to double wherever a double literal appears in its
+// expressions, so results round exactly as the reference's do.  Divisions by a wave-uniform
+// operand that equals 1 are elided (x/1 == x exactly): with scalar coefficients e = 0 and a = 1
+// (the ROF case) this removes every fp64 division but one from the hot loops.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "prost_hip.h"
+
+namespace prost_hip {
+
+template <class T> __device__ __forceinline__ T t_abs(T v) { return v < 0 ? -v : v; }
+template <> __device__ __forceinline__ float t_abs<float>(float v) { return fabsf(v); }
+template <> __device__ __forceinline__ double t_abs<double>(double v) { return fabs(v); }
+__device__ __forceinline__ float t_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double t_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float t_pow(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ double t_pow(double a, double b) { return pow(a, b); }
+__device__ __forceinline__ float t_sin(float v) { return sinf(v); }
+__device__ __forceinline__ double t_sin(double v) { return sin(v); }
+__device__ __forceinline__ float t_cos(float v) { return cosf(v); }
+__device__ __forceinline__ double t_cos(double v) { return cos(v); }
+__device__ __forceinline__ float t_acos(float v) { return acosf(v); }
+__device__ __forceinline__ double t_acos(double v) { return acos(v); }
+
+// x / d with the exact shortcut for d == 1
+__device__ __forceinline__ double div1(double x, double d) { return d == 1.0 ? x : x / d; }
+__device__ __forceinline__ float div1(float x, float d) { return d == 1.0f ? x : x / d; }
+
+// ---- Function1D* (include/prost/prox/elemop/function_1d.hpp) --------------------------------
+template <class T> __device__ __forceinline__ T f1d_abs(T x0, T tau) {            // :47-60
+  if (x0 >= tau) return x0 - tau;
+  if (x0 <= -tau) return x0 + tau;
+  return (T)0;
+}
+template <class T> __device__ __forceinline__ T f1d_square(T x0, T tau) {         // :63-72
+  return (T)div1((double)x0, 1. + (double)tau);
+}
+template <class T> __device__ __forceinline__ T f1d_l0(T x0, T tau) {             // :146-158
+  return (x0 * x0 > 2 * tau) ? x0 : (T)0;
+}
+template <class T> __device__ inline T lq_newton(T t0, T alpha, T q, T eps) {     // :173-191
+  T t = t0, delta = 0;
+  int guard = 0;   // the reference loop has no bound; 200 Newton steps is far past convergence
+  do {
+    const T power = t_pow(t, q);
+    const T dF1 = t - 1 + alpha * q * power / t;
+    const T dF2 = 1 + alpha * q * (q - 1) * power / (t * t);
+    delta = dF1 / dF2;
+    t = t - delta;
+  } while (delta > eps && ++guard < 200);
+  return t;
+}
+template <class T> __device__ inline T lq_half(T alpha) {                          // :195-202
+  const T sqrt3 = t_sqrt((T)3);
+  const T PI_half = (T)1.5707963267948966192313216916397514420985846996875529;
+  const T s = 2 * (t_sin((T)((t_acos((T)(alpha * 3 * sqrt3 / 4)) + PI_half) / 3))) / sqrt3;
+  return s * s;
+}
+template <class T> __device__ __forceinline__ T lq_eps();
+template <> __device__ __forceinline__ float lq_eps<float>() { return (float)1e-5; }   // :263-267
+template <> __device__ __forceinline__ double lq_eps<double>() { return 1e-11; }        // :270-274
+
+template <class T> __device__ inline T f1d_lq(T x0, T tau, T alpha, T beta) {      // :205-260
+  if (alpha == 1) return f1d_abs(x0, tau);
+  if (alpha == 0) return f1d_l0(x0, tau);
+  T t = 0;
+  if (t_abs(x0) > 0) {
+    T factor = tau * t_pow(t_abs(x0), (T)(alpha - 2));
+    if (alpha < 1) {
+      const T t2 = 2 * (alpha - 1) / (alpha - 2);
+      if ((double)factor < 0.5 * (double)(1 - (t2 - 1) * (t2 - 1)) / (double)t_pow(t2, alpha)) {
+        if ((double)alpha == 0.5) t = lq_half<T>(factor);
+        else t = lq_newton<T>((T)1, factor, alpha, lq_eps<T>());
+      }
+    } else {
+      t = lq_newton<T>((T)1, factor, alpha, lq_eps<T>());
+    }
+  }
+  return t * t_abs(x0);
+}
+
+// fn is wave-uniform: a scalar branch, or resolved at compile time when FN >= 0
+template <class T, int FN = -1>
+__device__ __forceinline__ T f1d_apply(int fn_rt, T x0, T tau, T alpha, T beta) {
+  const int fn = FN >= 0 ? FN : fn_rt;
+  switch (fn) {
+    case PROST_FN_ZERO: return x0;                                                   // :34-44
+    case PROST_FN_ABS: return f1d_abs(x0, tau);
+    case PROST_FN_SQUARE: return f1d_square(x0, tau);
+    case PROST_FN_IND_LEQ0: return x0 > (T)0 ? (T)0 : x0;                             // :75-87
+    case PROST_FN_IND_GEQ0: return x0 < (T)0 ? (T)0 : x0;                             // :90-102
+    case PROST_FN_IND_EQ0: return (T)0;                                               // :105-114
+    case PROST_FN_IND_BOX01: return x0 > (T)1 ? (T)1 : (x0 < (T)0 ? (T)0 : x0);       // :117-131
+    case PROST_FN_MAX_POS0: return x0 > tau ? x0 - tau : (x0 < (T)0 ? x0 : (T)0);     // :134-148
+    case PROST_FN_L0: return f1d_l0(x0, tau);
+    case PROST_FN_HUBER: {                                                            // :161-171
+      T r = (T)(((double)(x0 / tau)) / (1. + (double)(alpha / tau)));
+      const T ar = t_abs(r);
+      r /= ((T)1 > ar ? (T)1 : ar);
+      return x0 - tau * r;
+    }
+    case PROST_FN_LQ: return f1d_lq(x0, tau, alpha, beta);
+    case PROST_FN_LQ_PLUS_EPS: return (T)0;                                           // :294-306
+    case PROST_FN_TRUNCQUAD: {                                                        // :277-291
+      const T x_sq = f1d_square<T>(x0, 2 * tau * alpha);
+      const T en_sq = alpha * x_sq * x_sq + (x_sq - x0) * (x_sq - x0) / (2 * tau);
+      return en_sq < beta ? x_sq : x0;
+    }
+    case PROST_FN_TRUNCLIN: {                                                         // :309-323
+      const T x_sh = f1d_abs<T>(x0, tau * alpha);
+      const T en_sh = (x_sh - x0) * (x_sh - x0) / (2 * tau) + alpha * t_abs(x_sh);
+      return en_sh < beta ? x_sh : x0;
+    }
+  }
+  return x0;
+}
+
+// step size of one element: invert_tau ? 1/(tau*td) : tau*td   (elem_operation_1d.hpp:40)
+template <class T> __device__ __forceinline__ T elem_tau(T tau_scal, T td, bool invert_tau) {
+  return invert_tau ? (T)(1. / (double)(tau_scal * td)) : (tau_scal * td);
+}
+
+// the scalar "c f(a x - b) + d x + e/2 x^2" prox on a value v (x itself for 1d, ||x|| for norm2)
+// elem_operation_1d.hpp:45-57 == elem_operation_norm2.hpp:64-74
+template <class T, int FN = -1>
+__device__ __forceinline__ T scaled_prox(int fn, T v, T tau, const T* c) {
+  const double den = 1. + (double)(tau * c[4]);
+  const T prox_arg = (T)(div1((double)(c[0] * (v - c[3] * tau)), den) - (double)c[1]);
+  const T step = (T)div1((double)(c[2] * c[0] * c[0] * tau), den);
+  return div1((T)(f1d_apply<T, FN>(fn, prox_arg, step, c[5], c[6]) + c[1]), c[0]);
+}
+
+// ElemOperation1D::operator() on one value (elem_operation_1d.hpp:36-59)
+template <class T, int FN = -1>
+__device__ __forceinline__ T elem_1d(int fn, T arg, T tau, const T* c) {
+  if (c[0] == 0 || c[2] == 0) return (arg - tau * c[3]) / (1 + tau * c[4]);
+  return scaled_prox<T, FN>(fn, arg, tau, c);
+}
+
+}  // namespace prost_hip

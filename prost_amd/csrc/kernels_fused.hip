@@ -1,0 +1,414 @@
+// kernels_fused.hip -- fused PDHG passes for gradient-regularised problems (ROF-TV, TV-3D).
+//
+// One reference PerformIteration (backend_pdhg.cu:313-381) launches ~8 kernels that move ~35
+// floats per pixel (proxarg, prox_g, fill, K, dual arg, prox_f*, fill, K^T).  Here it is TWO
+// kernels moving 11 (2-D) / 14 (3-D) floats per pixel: neither K x, K^T y nor the prox arguments
+// ever touch HBM.
+//
+// Mapping (gfx950, wave = 64).  Images are column-major, y contiguous (block_gradient2d.cu:50).
+//   * a lane owns VEC = 16 bytes of consecutive rows (float4 / double2): every global access of a
+//     wave is one 1-KiB fully coalesced transaction;
+//   * a workgroup (256 lanes = 1024 fp32 rows) marches over a chunk of columns x0..x1 and keeps
+//     the previous (primal pass: y1[x-1]) / next (dual pass: x[x+1]) column in REGISTERS, so the
+//     +-ny stencil neighbour costs no second load; the +-1 neighbour comes from the adjacent lane
+//     via a 64-lane shuffle (only lane 0/63 of a wave touches memory for it);
+//   * grid = row strips x column chunks x channels >> 256 CUs; chunks are sized so that the single
+//     halo column per chunk is < 7 % of that array's traffic;
+//   * residual iterations add the reduction of backend_pdhg.cu:392-431 to the same passes
+//     (wave shuffles + one LDS slot per wave + one partial per workgroup, folded deterministically).
+#include "common.hpp"
+#include "device_math.hpp"
+#include "reduce.hpp"
+
+namespace prost_hip {
+
+template <class T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; typedef float4 type; };
+template <> struct VecOf<double> { static constexpr int N = 2; typedef double2 type; };
+
+template <class T, int VEC>
+__device__ __forceinline__ void ldv(const T* __restrict__ p, T (&v)[VEC]) {
+  if (VEC == 1) { v[0] = p[0]; return; }
+  typedef typename VecOf<T>::type V;
+  const V t = *reinterpret_cast<const V*>(p);
+  const T* e = reinterpret_cast<const T*>(&t);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) v[j] = e[j];
+}
+template <class T, int VEC>
+__device__ __forceinline__ void stv(T* __restrict__ p, const T (&v)[VEC]) {
+  if (VEC == 1) { p[0] = v[0]; return; }
+  typedef typename VecOf<T>::type V;
+  V t;
+  T* e = reinterpret_cast<T*>(&t);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) e[j] = v[j];
+  *reinterpret_cast<V*>(p) = t;
+}
+
+template <class T>
+struct FusedArgs {
+  size_t nx, ny, L;
+  int cols_per_block;
+  int g_fn, f_fn;
+  const T* g_ptr[7]; T g_val[7];
+  const T* f_ptr[7]; T f_val[7];
+  T Tval, Sval;
+};
+
+// value of the row above the first row of this lane (row0 - 1): neighbour lane's last element
+template <class T, int VEC>
+__device__ __forceinline__ T row_above(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, bool active) {
+  T up = __shfl_up(v[VEC - 1], 1, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0 && active && row0 > 0) up = col_base[row0 - 1];
+  return up;
+}
+// value of the row below the last row of this lane (row0 + VEC)
+template <class T, int VEC>
+__device__ __forceinline__ T row_below(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, size_t ny, bool active) {
+  T dn = __shfl_down(v[0], 1, kWave);
+  if ((threadIdx.x & (kWave - 1)) == kWave - 1 && active && row0 + VEC < ny) dn = col_base[row0 + VEC];
+  return dn;
+}
+
+// ------------------------------------------------------------------------------------------
+// primal pass, gradient2d:  x_new = prox_g(x - tau T K^T y)   [+ dual residual sums]
+// grid: x = row strips, y = column chunks, z = channel l
+// ------------------------------------------------------------------------------------------
+template <class T, int VEC, int GFN, bool RES>
+__global__ void __launch_bounds__(kBlock) fused_primal2d_kernel(T* __restrict__ x_new, const T* __restrict__ x,
+                                                                const T* __restrict__ y, const T* __restrict__ y_prev,
+                                                                FusedArgs<T> a, T tau, bool use_kty, bool use_kty_prev,
+                                                                double* __restrict__ partial) {
+  const size_t nx = a.nx, ny = a.ny;
+  const size_t row0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  const bool active = row0 < ny;
+  const size_t xa = (size_t)blockIdx.y * a.cols_per_block;
+  const size_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const size_t plane = (size_t)blockIdx.z * nx * ny;
+  const size_t N = nx * ny * a.L;
+  const T* y1 = y + plane;          // d/dx components of channel l   (res[idx],       block_gradient2d.cu:76)
+  const T* y2 = y + N + plane;      // d/dy components of channel l   (res[idx + N],   :77)
+  const T* yp1 = RES ? y_prev + plane : nullptr;
+  const T* yp2 = RES ? y_prev + N + plane : nullptr;
+  const T tauT = tau * a.Tval;      // tau_ * T_i              (backend_pdhg.cu:48)
+  const T sqT = t_sqrt(a.Tval);
+  double ra = 0, rb = 0;
+
+  T y1p[VEC], yp1p[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; j++) { y1p[j] = 0; yp1p[j] = 0; }
+  if (active && xa > 0) {
+    ldv<T, VEC>(y1 + (xa - 1) * ny + row0, y1p);
+    if (RES) ldv<T, VEC>(yp1 + (xa - 1) * ny + row0, yp1p);
+  }
+  for (size_t xc = xa; xc < xb; xc++) {
+    const size_t cb = xc * ny;               // column base inside the plane
+    T y1c[VEC], y2c[VEC], xv[VEC], yp1c[VEC], yp2c[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { y1c[j] = 0; y2c[j] = 0; xv[j] = 0; yp1c[j] = 0; yp2c[j] = 0; }
+    if (active) {
+      ldv<T, VEC>(y1 + cb + row0, y1c);
+      ldv<T, VEC>(y2 + cb + row0, y2c);
+      ldv<T, VEC>(x + plane + cb + row0, xv);
+      if (RES) { ldv<T, VEC>(yp1 + cb + row0, yp1c); ldv<T, VEC>(yp2 + cb + row0, yp2c); }
+    }
+    const T up = row_above<T, VEC>(y2c, y2 + cb, row0, active);
+    T upp = 0;
+    if (RES) upp = row_above<T, VEC>(yp2c, yp2 + cb, row0, active);
+    if (active) {
+      T out[VEC], gc[7][VEC];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {       // coefficient k: per-element vector (16-byte load) or scalar
+        if (a.g_ptr[k]) ldv<T, VEC>(a.g_ptr[k] + plane + cb + row0, gc[k]);
+        else {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) gc[k][j] = a.g_val[k];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const size_t row = row0 + j;
+        // BlockGradient2DKernelAdjoint (block_gradient2d.cu:122-138) on a zero-filled result
+        T divy = (row < ny - 1) ? y2c[j] : (T)0;
+        if (row > 0) divy -= (j > 0 ? y2c[j > 0 ? j - 1 : 0] : up);
+        T divx = (xc < nx - 1) ? y1c[j] : (T)0;
+        if (xc > 0) divx -= y1p[j];
+        const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+        const T arg = xv[j] - tauT * kty;                                    // backend_pdhg.cu:38-51
+        T c[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) c[k] = gc[k][j];
+        out[j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, c);                        // elem_operation_1d.hpp:36-59
+        if (RES) {                                                             // dual_residual_transform :73-94
+          T dpy = (row < ny - 1) ? yp2c[j] : (T)0;
+          if (row > 0) dpy -= (j > 0 ? yp2c[j > 0 ? j - 1 : 0] : upp);
+          T dpx = (xc < nx - 1) ? yp1c[j] : (T)0;
+          if (xc > 0) dpx -= yp1p[j];
+          const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
+          const T w_hat = (xv[j] - out[j]) / (tau * sqT) - sqT * ktyp;
+          const T diff = w_hat + sqT * kty;
+          ra += (double)(diff * diff);
+          rb += (double)(w_hat * w_hat);
+        }
+      }
+      stv<T, VEC>(x_new + plane + cb + row0, out);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { y1p[j] = y1c[j]; if (RES) yp1p[j] = yp1c[j]; }
+  }
+  if (RES) block_sum2_store(ra, rb, partial, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+}
+
+// ------------------------------------------------------------------------------------------
+// dual pass, gradient2d:  y_new = prox_f*(y + sigma S ((1+theta) K x_new - theta K x_old))
+// [+ primal residual sums].  All L channels of a pixel are coupled by the 2L-dim norm.
+// grid: x = row strips, y = column chunks
+// ------------------------------------------------------------------------------------------
+template <class T, int VEC, int LCH, int FFN, bool RES>
+__global__ void __launch_bounds__(kBlock) fused_dual2d_kernel(T* __restrict__ y_new, const T* __restrict__ y,
+                                                              const T* __restrict__ xn, const T* __restrict__ xo,
+                                                              FusedArgs<T> a, T sigma, T theta, bool use_kx_prev,
+                                                              double* __restrict__ partial) {
+  const size_t nx = a.nx, ny = a.ny;
+  const size_t row0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  const bool active = row0 < ny;
+  const size_t xa = (size_t)blockIdx.y * a.cols_per_block;
+  const size_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const size_t P = nx * ny;             // one channel plane
+  const size_t N = P * LCH;
+  const T sigS = sigma * a.Sval;        // sigma_ * S_i          (backend_pdhg.cu:64)
+  const T sqS = t_sqrt(a.Sval);
+  double ra = 0, rb = 0;
+
+  T cn[LCH][VEC], co[LCH][VEC];         // current column of x_new / x_old
+#pragma unroll
+  for (int l = 0; l < LCH; l++)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { cn[l][j] = 0; co[l][j] = 0; }
+  if (active) {
+#pragma unroll
+    for (int l = 0; l < LCH; l++) { ldv<T, VEC>(xn + l * P + xa * ny + row0, cn[l]); ldv<T, VEC>(xo + l * P + xa * ny + row0, co[l]); }
+  }
+  for (size_t xc = xa; xc < xb; xc++) {
+    const size_t cb = xc * ny;
+    const bool has_next = xc < nx - 1;
+    T nn[LCH][VEC], no[LCH][VEC], ya[2 * LCH][VEC];
+#pragma unroll
+    for (int l = 0; l < LCH; l++)
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { nn[l][j] = 0; no[l][j] = 0; ya[l][j] = 0; ya[LCH + l][j] = 0; }
+    if (active) {
+#pragma unroll
+      for (int l = 0; l < LCH; l++) {
+        if (has_next) { ldv<T, VEC>(xn + l * P + cb + ny + row0, nn[l]); ldv<T, VEC>(xo + l * P + cb + ny + row0, no[l]); }
+        ldv<T, VEC>(y + l * P + cb + row0, ya[l]);
+        ldv<T, VEC>(y + N + l * P + cb + row0, ya[LCH + l]);
+      }
+    }
+    T dnn[LCH], dno[LCH];
+#pragma unroll
+    for (int l = 0; l < LCH; l++) {
+      dnn[l] = row_below<T, VEC>(cn[l], xn + l * P + cb, row0, ny, active);
+      dno[l] = row_below<T, VEC>(co[l], xo + l * P + cb, row0, ny, active);
+    }
+    if (active) {
+      T out[2 * LCH][VEC], fc[7][VEC];
+#pragma unroll
+      for (int k = 0; k < 7; k++) {
+        if (a.f_ptr[k]) ldv<T, VEC>(a.f_ptr[k] + cb + row0, fc[k]);
+        else {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) fc[k][j] = a.f_val[k];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const size_t row = row0 + j;
+        T arg[2 * LCH], kx[2 * LCH], kxp[2 * LCH];
+#pragma unroll
+        for (int l = 0; l < LCH; l++) {
+          // BlockGradient2DKernel (block_gradient2d.cu:61-77) on a zero-filled result
+          const T belown = (j < VEC - 1) ? cn[l][j < VEC - 1 ? j + 1 : 0] : dnn[l];
+          const T belowo = (j < VEC - 1) ? co[l][j < VEC - 1 ? j + 1 : 0] : dno[l];
+          kx[l] = has_next ? nn[l][j] - cn[l][j] : (T)0;
+          kx[LCH + l] = (row < ny - 1) ? belown - cn[l][j] : (T)0;
+          kxp[l] = (use_kx_prev && has_next) ? no[l][j] - co[l][j] : (T)0;
+          kxp[LCH + l] = (use_kx_prev && row < ny - 1) ? belowo - co[l][j] : (T)0;
+        }
+        T norm = 0;
+#pragma unroll
+        for (int i = 0; i < 2 * LCH; i++) {
+          arg[i] = ya[i][j] + sigS * ((1 + theta) * kx[i] - theta * kxp[i]);   // backend_pdhg.cu:54-70
+          norm += arg[i] * arg[i];                                             // elem_operation_norm2.hpp:48-55
+        }
+        if (norm > 0) {
+          norm = t_sqrt(norm);
+          T c[7];
+#pragma unroll
+          for (int k = 0; k < 7; k++) c[k] = fc[k][j];
+          const T pr = scaled_prox<T, FFN>(a.f_fn, norm, sigS, c);
+#pragma unroll
+          for (int i = 0; i < 2 * LCH; i++) out[i][j] = pr * arg[i] / norm;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2 * LCH; i++) out[i][j] = 0;
+        }
+        if (RES) {                                                             // primal_residual_transform :97-120
+#pragma unroll
+          for (int i = 0; i < 2 * LCH; i++) {
+            const T z_hat = (ya[i][j] - out[i][j]) / (sigma * sqS) + sqS * ((1 + theta) * kx[i] - theta * kxp[i]);
+            const T diff = z_hat - sqS * kx[i];
+            ra += (double)(diff * diff);
+            rb += (double)(z_hat * z_hat);
+          }
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < LCH; l++) {
+        stv<T, VEC>(y_new + l * P + cb + row0, out[l]);
+        stv<T, VEC>(y_new + N + l * P + cb + row0, out[LCH + l]);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < LCH; l++)
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { cn[l][j] = nn[l][j]; co[l][j] = no[l][j]; }
+  }
+  if (RES) block_sum2_store(ra, rb, partial, blockIdx.x + gridDim.x * blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxFusedChannels = 4;
+
+template <class T>
+static bool vec_ok(const prost_hip_fused_desc* d, const void* p0, const void* p1, const void* p2, const void* p3) {
+  const int V = VecOf<T>::N;
+  if (d->ny % V != 0) return false;
+  auto al = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % 16) == 0; };
+  bool ok = al(p0) && al(p1) && al(p2) && al(p3);
+  for (int k = 0; k < 7; k++) ok = ok && al(d->g_coeff_ptr[k]) && al(d->f_coeff_ptr[k]);
+  return ok;
+}
+
+template <class T>
+static FusedArgs<T> make_args(const prost_hip_fused_desc* d) {
+  FusedArgs<T> a;
+  a.nx = d->nx; a.ny = d->ny; a.L = d->L; a.g_fn = d->g_fn; a.f_fn = d->f_fn;
+  for (int k = 0; k < 7; k++) {
+    a.g_ptr[k] = static_cast<const T*>(d->g_coeff_ptr[k]); a.g_val[k] = (T)d->g_coeff_val[k];
+    a.f_ptr[k] = static_cast<const T*>(d->f_coeff_ptr[k]); a.f_val[k] = (T)d->f_coeff_val[k];
+  }
+  a.Tval = (T)d->T_val; a.Sval = (T)d->S_val;
+  a.cols_per_block = 16;
+  return a;
+}
+
+// choose the column chunk so that the grid has >= ~2048 workgroups but no more than the
+// reduction workspace holds (kReduceBlocks partial slots)
+static int pick_cols(size_t nx, size_t row_blocks, size_t planes) {
+  size_t cols = 16;
+  while (cols > 4 && row_blocks * planes * ((nx + cols - 1) / cols) < 2048) cols /= 2;
+  while (row_blocks * planes * ((nx + cols - 1) / cols) > (size_t)kReduceBlocks) cols *= 2;
+  return (int)cols;
+}
+
+static bool desc_ok(const prost_hip_fused_desc* d) {
+  if (!d) return false;
+  if (d->is3d) return false;                              // gradient3d passes: see kernels_fused3d.hip
+  if (d->nx == 0 || d->ny == 0 || d->L == 0 || d->L > (size_t)kMaxFusedChannels) return false;
+  if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
+  const size_t rb = (d->ny + kBlock - 1) / kBlock;        // worst case VEC = 1
+  if (rb * d->L > (size_t)kReduceBlocks || rb > 65535 || d->nx > 65535 * 4) return false;
+  return true;
+}
+
+template <class T>
+static int run_primal(const prost_hip_fused_desc* d, T* x_new, const T* x, const T* y, const T* y_prev, double tau, int use_kty,
+                      int use_kty_prev, double* out2, void* ws, void* stream) {
+  if (!desc_ok(d)) { set_error("fused primal pass: unsupported description"); return 1; }
+  if (out2 && (!ws || !y_prev)) { set_error("fused primal pass: residuals need workspace and y_prev"); return 1; }
+  FusedArgs<T> a = make_args<T>(d);
+  const bool vec = vec_ok<T>(d, x_new, x, y, out2 ? y_prev : nullptr);
+  const int V = vec ? VecOf<T>::N : 1;
+  const size_t rb = (d->ny + (size_t)kBlock * V - 1) / ((size_t)kBlock * V);
+  a.cols_per_block = pick_cols(d->nx, rb, d->L);
+  dim3 grid((unsigned)rb, (unsigned)((d->nx + a.cols_per_block - 1) / a.cols_per_block), (unsigned)d->L), block(kBlock);
+  hipStream_t s = as_stream(stream);
+  double* partial = static_cast<double*>(ws);
+  const bool fast = (d->g_fn == PROST_FN_SQUARE);
+#define GO(VECv, GFNv, RESv) hipLaunchKernelGGL((fused_primal2d_kernel<T, VECv, GFNv, RESv>), grid, block, 0, s, x_new, x, y, y_prev, a, (T)tau, use_kty != 0, use_kty_prev != 0, partial)
+  if (vec) {
+    if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_SQUARE, true); else GO(VecOf<T>::N, PROST_FN_SQUARE, false); }
+    else { if (out2) GO(VecOf<T>::N, -1, true); else GO(VecOf<T>::N, -1, false); }
+  } else {
+    if (out2) GO(1, -1, true); else GO(1, -1, false);
+  }
+#undef GO
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused primal pass"); }
+  if (out2) return launch_fold(out2, partial, grid.x * grid.y * grid.z, false, s);
+  return 0;
+}
+
+template <class T, int LCH>
+static int run_dual_l(const prost_hip_fused_desc* d, T* y_new, const T* y, const T* xn, const T* xo, double sigma, double theta,
+                      int use_kx_prev, double* out2, void* ws, void* stream) {
+  FusedArgs<T> a = make_args<T>(d);
+  const bool vec = vec_ok<T>(d, y_new, y, xn, xo);
+  const int V = vec ? VecOf<T>::N : 1;
+  const size_t rb = (d->ny + (size_t)kBlock * V - 1) / ((size_t)kBlock * V);
+  a.cols_per_block = pick_cols(d->nx, rb, 1);
+  dim3 grid((unsigned)rb, (unsigned)((d->nx + a.cols_per_block - 1) / a.cols_per_block), 1), block(kBlock);
+  hipStream_t s = as_stream(stream);
+  double* partial = static_cast<double*>(ws);
+  const bool fast = (d->f_fn == PROST_FN_IND_LEQ0);
+#define GO(VECv, FFNv, RESv) hipLaunchKernelGGL((fused_dual2d_kernel<T, VECv, LCH, FFNv, RESv>), grid, block, 0, s, y_new, y, xn, xo, a, (T)sigma, (T)theta, use_kx_prev != 0, partial)
+  if (vec) {
+    if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_IND_LEQ0, true); else GO(VecOf<T>::N, PROST_FN_IND_LEQ0, false); }
+    else { if (out2) GO(VecOf<T>::N, -1, true); else GO(VecOf<T>::N, -1, false); }
+  } else {
+    if (out2) GO(1, -1, true); else GO(1, -1, false);
+  }
+#undef GO
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused dual pass"); }
+  if (out2) return launch_fold(out2, partial, grid.x * grid.y, false, s);
+  return 0;
+}
+
+template <class T>
+static int run_dual(const prost_hip_fused_desc* d, T* y_new, const T* y, const T* xn, const T* xo, double sigma, double theta,
+                    int use_kx_prev, double* out2, void* ws, void* stream) {
+  if (!desc_ok(d)) { set_error("fused dual pass: unsupported description"); return 1; }
+  if (out2 && !ws) { set_error("fused dual pass: residuals need a workspace"); return 1; }
+  switch (d->L) {
+    case 1: return run_dual_l<T, 1>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, stream);
+    case 2: return run_dual_l<T, 2>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, stream);
+    case 3: return run_dual_l<T, 3>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, stream);
+    case 4: return run_dual_l<T, 4>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, stream);
+  }
+  set_error("fused dual pass: unsupported channel count");
+  return 1;
+}
+
+}  // namespace prost_hip
+
+using namespace prost_hip;
+
+extern "C" {
+int prost_hip_fused_supported(const prost_hip_fused_desc* desc, int dtype) { (void)dtype; return desc_ok(desc) ? 1 : 0; }
+
+int prost_hip_fused_primal_f32(const prost_hip_fused_desc* d, float* x_new, const float* x, const float* y, const float* y_prev, double tau, int use_kty, int use_kty_prev, double* out2, void* ws, void* s) {
+  return run_primal<float>(d, x_new, x, y, y_prev, tau, use_kty, use_kty_prev, out2, ws, s);
+}
+int prost_hip_fused_primal_f64(const prost_hip_fused_desc* d, double* x_new, const double* x, const double* y, const double* y_prev, double tau, int use_kty, int use_kty_prev, double* out2, void* ws, void* s) {
+  return run_primal<double>(d, x_new, x, y, y_prev, tau, use_kty, use_kty_prev, out2, ws, s);
+}
+int prost_hip_fused_dual_f32(const prost_hip_fused_desc* d, float* y_new, const float* y, const float* xn, const float* xo, double sigma, double theta, int use_kx_prev, double* out2, void* ws, void* s) {
+  return run_dual<float>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, s);
+}
+int prost_hip_fused_dual_f64(const prost_hip_fused_desc* d, double* y_new, const double* y, const double* xn, const double* xo, double sigma, double theta, int use_kx_prev, double* out2, void* ws, void* s) {
+  return run_dual<double>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, s);
+}
+}  // extern "C"

@@ -1,0 +1,100 @@
+// runtime.hip -- device / memory / stream / event plumbing of the C ABI, plus the RCCL
+// communicator used for the global stopping criterion of multi-GPU batches.
+#include "common.hpp"
+
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+namespace prost_hip {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(hipError_t e, const char* what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e == 0 ? 1 : (int)e;
+}
+
+}  // namespace prost_hip
+
+using namespace prost_hip;
+
+extern "C" {
+
+const char* prost_hip_last_error(void) { return g_last_error.c_str(); }
+int prost_hip_abi_version(void) { return PROST_HIP_ABI_VERSION; }
+
+int prost_hip_device_count(int* count) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *count = 0; return fail(e, "hipGetDeviceCount"); }
+  *count = c;
+  return 0;
+}
+int prost_hip_set_device(int device) { PH_CHECK(hipSetDevice(device)); return 0; }
+int prost_hip_get_device(int* device) { PH_CHECK(hipGetDevice(device)); return 0; }
+int prost_hip_device_info(int device, char* name, size_t len, int* cu_count, size_t* total_mem) {
+  hipDeviceProp_t prop;
+  PH_CHECK(hipGetDeviceProperties(&prop, device));
+  if (name && len) { std::strncpy(name, prop.name, len - 1); name[len - 1] = 0; }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (total_mem) *total_mem = prop.totalGlobalMem;
+  return 0;
+}
+int prost_hip_mem_info(size_t* f, size_t* t) { PH_CHECK(hipMemGetInfo(f, t)); return 0; }
+int prost_hip_malloc(void** p, size_t bytes) { *p = nullptr; if (bytes == 0) return 0; PH_CHECK(hipMalloc(p, bytes)); return 0; }
+int prost_hip_free(void* p) { if (p) PH_CHECK(hipFree(p)); return 0; }
+int prost_hip_host_alloc(void** p, size_t bytes) { PH_CHECK(hipHostMalloc(p, bytes, hipHostMallocDefault)); return 0; }
+int prost_hip_host_free(void* p) { if (p) PH_CHECK(hipHostFree(p)); return 0; }
+int prost_hip_memcpy_h2d(void* d, const void* s, size_t n, void* st) { if (n) PH_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st))); return 0; }
+int prost_hip_memcpy_d2h(void* d, const void* s, size_t n, void* st) { if (n) PH_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, as_stream(st))); return 0; }
+int prost_hip_memcpy_d2d(void* d, const void* s, size_t n, void* st) { if (n) PH_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, as_stream(st))); return 0; }
+int prost_hip_memset(void* d, int v, size_t n, void* st) { if (n) PH_CHECK(hipMemsetAsync(d, v, n, as_stream(st))); return 0; }
+int prost_hip_stream_create(void** s) { hipStream_t st; PH_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); *s = st; return 0; }
+int prost_hip_stream_destroy(void* s) { if (s) PH_CHECK(hipStreamDestroy(as_stream(s))); return 0; }
+int prost_hip_stream_synchronize(void* s) { PH_CHECK(hipStreamSynchronize(as_stream(s))); return 0; }
+int prost_hip_device_synchronize(void) { PH_CHECK(hipDeviceSynchronize()); return 0; }
+int prost_hip_event_create(void** e) { hipEvent_t ev; PH_CHECK(hipEventCreate(&ev)); *e = ev; return 0; }
+int prost_hip_event_destroy(void* e) { if (e) PH_CHECK(hipEventDestroy((hipEvent_t)e)); return 0; }
+int prost_hip_event_record(void* e, void* s) { PH_CHECK(hipEventRecord((hipEvent_t)e, as_stream(s))); return 0; }
+int prost_hip_event_synchronize(void* e) { PH_CHECK(hipEventSynchronize((hipEvent_t)e)); return 0; }
+int prost_hip_event_elapsed_ms(void* a, void* b, float* ms) { PH_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
+int prost_hip_check_last_error(void) { PH_CHECK(hipGetLastError()); return 0; }
+
+// ---- RCCL ----
+static int nccl_fail(ncclResult_t r, const char* what) {
+  set_error(std::string(what) + ": " + ncclGetErrorString(r));
+  return 1000 + (int)r;
+}
+int prost_hip_comm_unique_id(void* id128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  if (r != ncclSuccess) return nccl_fail(r, "ncclGetUniqueId");
+  std::memcpy(id128, &id, sizeof(id));
+  return 0;
+}
+int prost_hip_comm_create(void** comm, const void* id128, int rank, int world) {
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  ncclComm_t c;
+  ncclResult_t r = ncclCommInitRank(&c, world, id, rank);
+  if (r != ncclSuccess) return nccl_fail(r, "ncclCommInitRank");
+  *comm = c;
+  return 0;
+}
+int prost_hip_comm_destroy(void* comm) {
+  if (!comm) return 0;
+  ncclResult_t r = ncclCommDestroy((ncclComm_t)comm);
+  if (r != ncclSuccess) return nccl_fail(r, "ncclCommDestroy");
+  return 0;
+}
+int prost_hip_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream) {
+  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)comm, as_stream(stream));
+  if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+"""GPU parity tests of the kernel C ABI (include/prost_hip.h) against the CPU oracle.
+
+Bar: bit-exact for every kernel whose arithmetic is +,-,*,/,sqrt (both sides are compiled without
+FMA contraction and HIP's fp32 divide/sqrt are correctly rounded); <= 4 ulp where libm
+transcendentals (pow/sin/acos/cos) are involved (lq, epi_quad); reductions (different summation
+order) rel 1e-6.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [np.float32, np.float64]
+
+
+def dev(hip, a):
+    return hip.DeviceArray.from_host(a)
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    eps = np.finfo(a.dtype).eps
+    scale = np.maximum(np.maximum(np.abs(a), np.abs(b)), np.finfo(a.dtype).tiny)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)) / (scale.astype(np.float64) * eps)
+    d[np.isnan(a) & np.isnan(b)] = 0
+    return np.nanmax(d) if d.size else 0.0
+
+
+GRAD_SHAPES = [(7, 5, 1, False), (7, 5, 3, False), (7, 5, 3, True), (1, 9, 1, False), (9, 1, 1, False),
+               (33, 130, 2, False), (307, 229, 8, False), (64, 300, 2, True)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", GRAD_SHAPES)
+@pytest.mark.parametrize("d3", [False, True])
+def test_gradient_fwd_adj(hip, dtype, shape, d3):
+    nx, ny, L, lf = shape
+    rng = np.random.default_rng(1)
+    n = nx * ny * L
+    k = 3 if d3 else 2
+    x = rng.standard_normal(n).astype(dtype)
+    y = rng.standard_normal(k * n).astype(dtype)
+    base_r = rng.standard_normal(k * n).astype(dtype)
+    base_c = rng.standard_normal(n).astype(dtype)
+    og = oracle.grad3d if d3 else oracle.grad2d
+    name = "grad3d" if d3 else "grad2d"
+    for acc in (0, 1):
+        ref_f = og(x, nx, ny, L, lf, adjoint=False, acc=base_r.copy() if acc else None)
+        ref_a = og(y, nx, ny, L, lf, adjoint=True, acc=base_c.copy() if acc else None)
+        r = dev(hip, base_r); c = dev(hip, base_c)
+        hip.check(hip.fn(name + "_fwd", dtype)(r.ptr, dev(hip, x).ptr, hip.sz(nx), hip.sz(ny), hip.sz(L), int(lf), acc, None))
+        hip.check(hip.fn(name + "_adj", dtype)(c.ptr, dev(hip, y).ptr, hip.sz(nx), hip.sz(ny), hip.sz(L), int(lf), acc, None))
+        assert np.array_equal(r.to_host(), ref_f)
+        assert np.array_equal(c.to_host(), ref_a)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(5912, 1131), (300, 2000), (64, 64)])
+def test_diags(hip, dtype, shape):
+    nrows, ncols = shape
+    rng = np.random.default_rng(2)
+    nd = 29
+    perm = rng.permutation(nrows + ncols - 2)[:nd]
+    ofs, fac = oracle.diags_sort(perm - nrows + 1, rng.random(nd), dtype)
+    x = rng.standard_normal(ncols).astype(dtype)
+    y = rng.standard_normal(nrows).astype(dtype)
+    d_ofs, d_fac = dev(hip, ofs), dev(hip, fac)
+    r = hip.DeviceArray.zeros(nrows, dtype)
+    hip.check(hip.fn("diags_fwd", dtype)(r.ptr, dev(hip, x).ptr, hip.sz(nrows), hip.sz(ncols), hip.sz(nd), d_ofs.ptr, d_fac.ptr, None))
+    assert np.array_equal(r.to_host(), oracle.diags(x, nrows, ncols, ofs, fac))
+    for quirk in (0, 1):
+        c = hip.DeviceArray.zeros(ncols, dtype)
+        hip.check(hip.fn("diags_adj", dtype)(c.ptr, dev(hip, y).ptr, hip.sz(nrows), hip.sz(ncols), hip.sz(nd), d_ofs.ptr, d_fac.ptr, quirk, None))
+        assert np.array_equal(c.to_host(), oracle.diags(y, nrows, ncols, ofs, fac, adjoint=True, ref_grid_quirk=bool(quirk)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("density", [0.01, 0.2])
+def test_csr_spmv(hip, dtype, density):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    A = sp.random(700, 900, density=density, format="csr", random_state=4, dtype=np.float64).astype(dtype)
+    A.sort_indices()
+    x = rng.standard_normal(900).astype(dtype)
+    base = rng.standard_normal(700).astype(dtype)
+    ref = oracle.csr_spmv_acc(base.copy(), x, A.data, A.indptr, A.indices)
+    r = dev(hip, base)
+    hip.check(hip.fn("csr_spmv_acc", dtype)(r.ptr, dev(hip, x).ptr, hip.sz(700), hip.sz(A.nnz), dev(hip, A.data).ptr,
+                                            dev(hip, A.indptr.astype(np.int32)).ptr, dev(hip, A.indices.astype(np.int32)).ptr, None))
+    got = r.to_host()
+    if A.nnz / 700 <= 6:
+        assert np.array_equal(got, ref)           # row-per-lane path sums in index order
+    else:
+        tol = 1e-5 if dtype == np.float32 else 1e-13
+        assert np.allclose(got, ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("op", [0, 1])
+@pytest.mark.parametrize("fn", oracle.FUNCTIONS)
+def test_prox_elem(hip, dtype, op, fn):
+    rng = np.random.default_rng(5)
+    count = 1000
+    for dim, il, inv, vec in [(1 if op == 0 else 2, False, False, True), (1 if op == 0 else 7, True, True, True),
+                              (1 if op == 0 else 3, False, True, False)]:
+        arg = rng.uniform(-3, 3, count * dim).astype(dtype)
+        if op == 1:   # zero-norm elements
+            idx0 = np.arange(dim) if il else np.arange(dim) * count
+            arg[idx0] = 0
+        td = rng.uniform(0.1, 2, count * dim).astype(dtype)
+        alpha = 0.5 if fn == "lq" else 0.7
+        if vec:
+            coeffs = [rng.uniform(0.5, 2, count), rng.uniform(-1, 1, count), rng.uniform(0.1, 2, count),
+                      rng.uniform(-1, 1, count), rng.uniform(0, 1, count), alpha, 1.3]
+            coeffs[0][:3] = 0; coeffs[2][3:6] = 0        # a == 0 / c == 0 branch (elem_operation_1d.hpp:42-44)
+        else:
+            coeffs = [1.0, 0.25, 2.0, 0.0, 0.0, alpha, 1.3]
+        ref = oracle.prox_elem(op, fn, arg, td, 0.8, count, dim, il, coeffs, inv)
+        ptrs, vals, keep = hip.coeff_args(coeffs, dtype, count)
+        res = hip.DeviceArray.zeros(count * dim, dtype)
+        hip.check(hip.fn("prox_elem", dtype)(op, hip.FN_ID[fn], res.ptr, dev(hip, arg).ptr, dev(hip, td).ptr, hip.dbl(0.8), int(inv),
+                                             hip.sz(count), hip.sz(dim), int(il), ptrs, vals, None))
+        got = res.to_host()
+        if fn == "lq":
+            assert ulp_diff(got, ref) <= 64      # Newton iteration on powf: few-ulp seeds amplify
+        else:
+            assert np.array_equal(got, ref), (fn, op, dim, il, inv, ulp_diff(got, ref))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_epi_quad(hip, dtype):
+    rng = np.random.default_rng(6)
+    count, dim = 2000, 4
+    arg = rng.uniform(-2, 2, count * dim).astype(dtype)
+    a = rng.uniform(0.5, 2, count); b = rng.uniform(-1, 1, count * (dim - 1)); c = rng.uniform(-1, 1, count)
+    b[: count] = 0
+    for av, cv in ((a, c), (1.3, 0.2)):
+        ref = oracle.prox_epi_quad(arg, count, dim, av, b, cv)
+        av_ = np.atleast_1d(av); cv_ = np.atleast_1d(cv)
+        da = dev(hip, av_.astype(dtype)) if av_.size > 1 else None
+        dc = dev(hip, cv_.astype(dtype)) if cv_.size > 1 else None
+        res = hip.DeviceArray.zeros(count * dim, dtype)
+        hip.check(hip.fn("prox_epi_quad", dtype)(res.ptr, dev(hip, arg).ptr, hip.sz(count), hip.sz(dim), da.ptr if da else None,
+                                                 hip.dbl(av_[0]), dev(hip, b.astype(dtype)).ptr, dc.ptr if dc else None, hip.dbl(cv_[0]), None))
+        tol = 2e-5 if dtype == np.float32 else 1e-11
+        assert np.allclose(res.to_host(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_moreau_and_pdhg_elementwise(hip, dtype):
+    rng = np.random.default_rng(7)
+    n = 5000
+    v = [rng.standard_normal(n).astype(dtype) for _ in range(5)]
+    td = rng.uniform(0.1, 2, n).astype(dtype)
+    tau, sigma, theta = dtype(0.37), dtype(1.9), dtype(0.8)
+    d = [dev(hip, a) for a in v]; dtd = dev(hip, td)
+    for inv in (0, 1):
+        out = hip.DeviceArray.zeros(n, dtype)
+        hip.check(hip.fn("moreau_prescale", dtype)(out.ptr, d[0].ptr, dtd.ptr, hip.dbl(tau), inv, hip.sz(n), None))
+        ref = v[0] * (tau * td) if inv else v[0] / (tau * td)
+        assert np.array_equal(out.to_host(), ref.astype(dtype))
+        res = dev(hip, v[1])
+        hip.check(hip.fn("moreau_postscale", dtype)(res.ptr, d[0].ptr, dtd.ptr, hip.dbl(tau), inv, hip.sz(n), None))
+        ref = v[0] - v[1] / (tau * td) if inv else v[0] - tau * td * v[1]
+        assert np.array_equal(res.to_host(), ref.astype(dtype))
+    out = hip.DeviceArray.zeros(n, dtype)
+    hip.check(hip.fn("pdhg_primal_arg", dtype)(out.ptr, d[0].ptr, dtd.ptr, d[1].ptr, hip.dbl(tau), hip.sz(n), None))
+    assert np.array_equal(out.to_host(), (v[0] - tau * td * v[1]).astype(dtype))
+    hip.check(hip.fn("pdhg_dual_arg", dtype)(out.ptr, d[0].ptr, dtd.ptr, d[1].ptr, d[2].ptr, hip.dbl(sigma), hip.dbl(theta), hip.sz(n), None))
+    assert np.array_equal(out.to_host(), (v[0] + sigma * td * ((1 + theta) * v[1] - theta * v[2])).astype(dtype))
+    # residual reductions: terms in T, sums in double
+    ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    out2 = hip.DeviceArray.zeros(2, np.float64)
+    hip.check(hip.fn("pdhg_residual_primal", dtype)(out2.ptr, d[0].ptr, d[1].ptr, dtd.ptr, d[2].ptr, d[3].ptr, hip.dbl(sigma), hip.dbl(theta), hip.sz(n), ws.ptr, None))
+    sq = np.sqrt(td)
+    z_hat = ((v[0] - v[1]) / (sigma * sq) + sq * ((1 + theta) * v[3] - theta * v[2])).astype(dtype)
+    diff = (z_hat - sq * v[3]).astype(dtype)
+    ref = np.array([np.sum((diff * diff).astype(np.float64)), np.sum((z_hat * z_hat).astype(np.float64))])
+    assert np.allclose(out2.to_host(), ref, rtol=1e-12)
+    hip.check(hip.fn("pdhg_residual_dual", dtype)(out2.ptr, d[0].ptr, d[1].ptr, dtd.ptr, d[2].ptr, d[3].ptr, hip.dbl(tau), hip.sz(n), ws.ptr, None))
+    w_hat = ((v[0] - v[1]) / (tau * sq) - sq * v[2]).astype(dtype)
+    diff = (w_hat + sq * v[3]).astype(dtype)
+    ref = np.array([np.sum((diff * diff).astype(np.float64)), np.sum((w_hat * w_hat).astype(np.float64))])
+    assert np.allclose(out2.to_host(), ref, rtol=1e-12)
+    hip.check(hip.fn("nrm2", dtype)(out2.ptr, d[0].ptr, hip.sz(n), ws.ptr, None))
+    assert np.isclose(out2.to_host()[0], np.sqrt(np.sum(v[0].astype(np.float64) ** 2)), rtol=1e-13)
+
+
+def _fused_desc(hip, dtype, nx, ny, L, g_fn, g_coeffs, f_fn, f_coeffs, Tval, Sval):
+    d = hip.FusedDesc()
+    d.is3d = 0; d.nx, d.ny, d.L = nx, ny, L
+    d.g_fn = hip.FN_ID[g_fn]; d.f_fn = hip.FN_ID[f_fn]
+    gp, gv, k1 = hip.coeff_args(g_coeffs, dtype, nx * ny * L)
+    fp, fv, k2 = hip.coeff_args(f_coeffs, dtype, nx * ny)
+    for i in range(7):
+        d.g_coeff_ptr[i] = gp[i]; d.g_coeff_val[i] = gv[i]
+        d.f_coeff_ptr[i] = fp[i]; d.f_coeff_val[i] = fv[i]
+    d.T_val, d.S_val = Tval, Sval
+    return d, (k1, k2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(16, 12, 1), (40, 1028, 1), (33, 130, 2), (9, 7, 3), (5, 2052, 4), (64, 64, 1)])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+def test_fused_passes_match_unfused_oracle(hip, dtype, shape, fns):
+    """One fused primal + dual pass == the reference's unfused sequence evaluated by the oracle
+    (backend_pdhg.cu:313-370), including the residual sums of :392-431."""
+    nx, ny, L = shape
+    g_fn, f_fn = fns
+    rng = np.random.default_rng(8)
+    n, m = nx * ny * L, 2 * nx * ny * L
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    y_prev = rng.uniform(-1, 1, m).astype(dtype); x_old = rng.uniform(0, 1, n).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    tau, sigma, theta = dtype(0.9), dtype(1.1), dtype(0.85)
+    Tval, Sval = dtype(0.25), dtype(0.5)
+    g_coeffs = [1.0, f, 10.0, 0.0, 0.0, 0.3, 0.0]
+    f_coeffs = [1.0, 1.0, 1.0, 0.0, 0.0, 0.3, 0.0]
+    desc, keep = _fused_desc(hip, dtype, nx, ny, L, g_fn, g_coeffs, f_fn, f_coeffs, Tval, Sval)
+    assert hip.lib().prost_hip_fused_supported(C.byref(desc), 0) == 1
+    ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    Td, Sd = np.full(n, Tval, dtype), np.full(m, Sval, dtype)
+    for use_kty, use_prev in ((1, 1), (0, 0), (1, 0)):
+        # ---- oracle, unfused ----
+        kty = oracle.grad2d(y, nx, ny, L, adjoint=True) if use_kty else np.zeros(n, dtype)
+        ktyp = oracle.grad2d(y_prev, nx, ny, L, adjoint=True) if use_prev else np.zeros(n, dtype)
+        temp = (x - tau * Td * kty).astype(dtype)
+        x_ref = oracle.prox_elem(0, g_fn, temp, Td, tau, n, 1, False, g_coeffs)
+        sq = np.sqrt(Td)
+        w_hat = ((x - x_ref) / (tau * sq) - sq * ktyp).astype(dtype); diff = (w_hat + sq * kty).astype(dtype)
+        dres_ref = np.array([np.sum((diff * diff).astype(np.float64)), np.sum((w_hat * w_hat).astype(np.float64))])
+        # ---- fused primal ----
+        x_new = hip.DeviceArray.zeros(n, dtype); out2 = hip.DeviceArray.zeros(2, np.float64)
+        hip.check(hip.fn("fused_primal", dtype)(C.byref(desc), x_new.ptr, dev(hip, x).ptr, dev(hip, y).ptr, dev(hip, y_prev).ptr,
+                                                hip.dbl(tau), use_kty, use_prev, out2.ptr, ws.ptr, None))
+        assert np.array_equal(x_new.to_host(), x_ref)
+        assert np.allclose(out2.to_host(), dres_ref, rtol=1e-11)
+        x_new2 = hip.DeviceArray.zeros(n, dtype)
+        hip.check(hip.fn("fused_primal", dtype)(C.byref(desc), x_new2.ptr, dev(hip, x).ptr, dev(hip, y).ptr, None,
+                                                hip.dbl(tau), use_kty, use_prev, None, None, None))
+        assert np.array_equal(x_new2.to_host(), x_ref)
+    for use_kxp in (1, 0):
+        kx = oracle.grad2d(x, nx, ny, L)
+        kxp = oracle.grad2d(x_old, nx, ny, L) if use_kxp else np.zeros(m, dtype)
+        temp = (y + sigma * Sd * ((1 + theta) * kx - theta * kxp)).astype(dtype)
+        y_ref = oracle.prox_elem(1, f_fn, temp, Sd, sigma, nx * ny, 2 * L, False, f_coeffs)
+        sq = np.sqrt(Sd)
+        z_hat = ((y - y_ref) / (sigma * sq) + sq * ((1 + theta) * kx - theta * kxp)).astype(dtype); diff = (z_hat - sq * kx).astype(dtype)
+        pres_ref = np.array([np.sum((diff * diff).astype(np.float64)), np.sum((z_hat * z_hat).astype(np.float64))])
+        y_new = hip.DeviceArray.zeros(m, dtype); out2 = hip.DeviceArray.zeros(2, np.float64)
+        hip.check(hip.fn("fused_dual", dtype)(C.byref(desc), y_new.ptr, dev(hip, y).ptr, dev(hip, x).ptr, dev(hip, x_old).ptr,
+                                              hip.dbl(sigma), hip.dbl(theta), use_kxp, out2.ptr, ws.ptr, None))
+        assert np.array_equal(y_new.to_host(), y_ref)
+        assert np.allclose(out2.to_host(), pres_ref, rtol=1e-11)
