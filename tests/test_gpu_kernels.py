@@ -17,8 +17,24 @@ pytestmark = pytest.mark.gpu
 DTYPES = [np.float32, np.float64]
 
 
+_KEEP = []
+
+
 def dev(hip, a):
-    return hip.DeviceArray.from_host(a)
+    """host -> device; the buffer is kept alive until the end of the test (kernels are async)."""
+    d = hip.DeviceArray.from_host(a)
+    _KEEP.append(d)
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _release_device_buffers(request):
+    yield
+    if "hip" in request.fixturenames:
+        request.getfixturevalue("hip").sync()
+    for d in _KEEP:
+        d.free()
+    del _KEEP[:]
 
 
 def ulp_diff(a, b):
@@ -126,9 +142,12 @@ def test_prox_elem(hip, dtype, op, fn):
                                              hip.sz(count), hip.sz(dim), int(il), ptrs, vals, None))
         got = res.to_host()
         if fn == "lq":
-            assert ulp_diff(got, ref) <= 64      # Newton iteration on powf: few-ulp seeds amplify
+            # Newton iteration on pow(): stops at |delta| <= 1e-5 (f32) / 1e-11 (f64), function_1d.hpp:173-191,
+            # so device and host libm agree only to about that accuracy
+            tol = 5e-5 if dtype == np.float32 else 1e-10
+            assert np.allclose(got, ref, rtol=tol, atol=tol, equal_nan=True), ulp_diff(got, ref)
         else:
-            assert np.array_equal(got, ref), (fn, op, dim, il, inv, ulp_diff(got, ref))
+            assert np.array_equal(got, ref, equal_nan=True), (fn, op, dim, il, inv, ulp_diff(got, ref))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
