@@ -1,0 +1,62 @@
+// prost/backend/backend.hpp -- algorithm interface (reference include/prost/backend/backend.hpp:37-95).
+#ifndef PROST_BACKEND_BACKEND_HPP_
+#define PROST_BACKEND_BACKEND_HPP_
+#include <cmath>
+
+#include "prost/problem.hpp"
+#include "prost/solver.hpp"
+
+namespace prost {
+
+template <typename T>
+class Backend {
+ public:
+  Backend() : primal_var_norm_(0), dual_var_norm_(0), primal_residual_(0), dual_residual_(0), comm_(nullptr),
+              global_nrows_(0), global_ncols_(0), time_kernels_(false) {}
+  virtual ~Backend() {}
+
+  void SetProblem(shared_ptr<Problem<T>> problem) { problem_ = problem; }
+  void SetOptions(const typename Solver<T>::Options& opts) { solver_opts_ = opts; }
+
+  virtual void Initialize() = 0;
+  virtual void PerformIteration() = 0;
+  virtual void Release() = 0;
+
+  virtual void current_solution(std::vector<T>& primal_sol, std::vector<T>& dual_sol) = 0;
+  virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y,
+                                std::vector<T>& dual_w) = 0;
+
+  virtual T primal_residual() const { return primal_residual_; }
+  virtual T dual_residual() const { return dual_residual_; }
+  virtual T primal_var_norm() const { return primal_var_norm_; }
+  virtual T dual_var_norm() const { return dual_var_norm_; }
+  /// backend.hpp:71-74 ; with a communicator the sizes are the global ones
+  virtual T eps_primal() const {
+    return std::sqrt((double)(global_nrows_ ? global_nrows_ : problem_->nrows())) * solver_opts_.tol_abs_primal + solver_opts_.tol_rel_primal * primal_var_norm();
+  }
+  virtual T eps_dual() const {
+    return std::sqrt((double)(global_ncols_ ? global_ncols_ : problem_->ncols())) * solver_opts_.tol_abs_dual + solver_opts_.tol_rel_dual * dual_var_norm();
+  }
+  virtual size_t gpu_mem_amount() const = 0;
+
+  /// multi-GPU batches: the 4 residual sums are all-reduced over `comm` (an RCCL communicator made
+  /// by prost_hip_comm_create) so every rank takes identical stopping / step-size decisions.
+  void SetCommunicator(void* comm, size_t global_nrows, size_t global_ncols) { comm_ = comm; global_nrows_ = global_nrows; global_ncols_ = global_ncols; }
+  /// record HIP events around the two dominant kernels of every iteration (bench roofline figure)
+  void EnableKernelTiming(bool on) { time_kernels_ = on; }
+  /// mean milliseconds per launch since the last call; returns false if nothing was recorded
+  virtual bool KernelTimes(double* primal_ms, double* dual_ms, size_t* launches) { (void)primal_ms; (void)dual_ms; (void)launches; return false; }
+  /// short description of the execution path ("pdhg:fused-grad2d", "pdhg:generic", "admm:generic")
+  virtual std::string path() const = 0;
+
+ protected:
+  shared_ptr<Problem<T>> problem_;
+  typename Solver<T>::Options solver_opts_;
+  T primal_var_norm_, dual_var_norm_, primal_residual_, dual_residual_;
+  void* comm_;
+  size_t global_nrows_, global_ncols_;
+  bool time_kernels_;
+};
+
+}  // namespace prost
+#endif

@@ -1,0 +1,58 @@
+// prost/backend/backend_admm.hpp -- graph-projection ADMM with a CGLS inner solve
+// (reference backend_admm.hpp:36-112, src/backend/backend_admm.cu, include/prost/cgls.hpp).
+#ifndef PROST_BACKEND_ADMM_HPP_
+#define PROST_BACKEND_ADMM_HPP_
+#include "prost/backend/backend.hpp"
+
+namespace prost {
+
+template <typename T>
+class BackendADMM : public Backend<T> {
+ public:
+  struct Options {
+    double rho0;
+    double alpha;            ///< over-relaxation
+    double cg_tol_pow, cg_tol_min, cg_tol_max;
+    int cg_max_iter;
+    int residual_iter;
+    T arb_delta, arb_tau, arb_gamma;
+    Options() : rho0(1), alpha(1.7), cg_tol_pow(1.3), cg_tol_min(1e-5), cg_tol_max(1e-8), cg_max_iter(10), residual_iter(1),
+                arb_delta(1.05), arb_tau(0.8), arb_gamma(1.01) {}
+  };
+  explicit BackendADMM(const Options& opts) : opts_(opts), scal_dev_(nullptr), scal_host_(nullptr), workspace_(nullptr) {}
+  virtual ~BackendADMM();
+
+  virtual void Initialize();
+  virtual void PerformIteration();
+  virtual void Release();
+  virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
+  virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
+  virtual size_t gpu_mem_amount() const;
+  virtual std::string path() const { return "admm:generic"; }
+  T rho() const { return rho_; }
+  size_t iteration() const { return iteration_; }
+  int last_cg_iterations() const { return last_cg_iters_; }
+
+ private:
+  /// y := alpha op(Sigma^(1/2) K Tau^(1/2)) x + beta y   (GemvPrecondK, backend_admm.cu:199-272)
+  void Gemv(char op, T alpha, const device_vector<T>& x, T beta, device_vector<T>& y);
+  double Nrm2(const device_vector<T>& v, size_t n);
+  int Cgls(const device_vector<T>& b, device_vector<T>& x, double shift, double tol, int maxit, device_vector<T>& p,
+           device_vector<T>& q, device_vector<T>& r, device_vector<T>& s, int& iterations);   // cgls.hpp:222-371
+  void GetDual(device_vector<T>& out, const device_vector<T>& half, const device_vector<T>& proj, const device_vector<T>& dual,
+               const device_vector<T>& scaling, T expo, size_t n);
+
+  Options opts_;
+  device_vector<T> x_half_, z_half_, x_proj_, z_proj_, x_dual_, z_dual_, temp1_, temp2_, temp3_, tmp_n_, tmp_m_;
+  double* scal_dev_;
+  double* scal_host_;
+  void* workspace_;
+  T rho_, delta_;
+  int arb_u_, arb_l_;
+  size_t iteration_;
+  int last_cg_iters_ = 0;
+  std::vector<shared_ptr<Prox<T>>> prox_g_, prox_f_;
+};
+
+}  // namespace prost
+#endif

@@ -1,0 +1,76 @@
+// prost/backend/backend_pdhg.hpp -- preconditioned PDHG (reference backend_pdhg.hpp:36-158,
+// src/backend/backend_pdhg.cu).  Two execution paths with identical arithmetic:
+//   fused    K is one gradient2d/3d block, prox_g one elem_operation:1d, prox_f* one
+//            elem_operation:norm2 over the gradient components, uniform preconditioners ->
+//            two kernels per iteration (prost_hip_fused_primal / _dual), 11 floats/pixel (2-D)
+//   generic  any blocks / proxes: the reference's sequence on the generic kernels
+#ifndef PROST_BACKEND_PDHG_HPP_
+#define PROST_BACKEND_PDHG_HPP_
+#include "prost/backend/backend.hpp"
+#include "prost_hip.h"
+
+namespace prost {
+
+template <typename T>
+class BackendPDHG : public Backend<T> {
+ public:
+  enum StepsizeVariant { kPDHGStepsAlg1 = 1, kPDHGStepsAlg2, kPDHGStepsResidualGoldstein, kPDHGStepsResidualBoyd };
+  struct Options {
+    double tau0, sigma0;
+    int residual_iter;
+    bool scale_steps_operator;
+    T alg2_gamma;
+    T arg_alpha0, arg_nu, arg_delta;
+    T arb_delta, arb_tau;
+    StepsizeVariant stepsize_variant;
+    bool allow_fused;          ///< MI355X addition: set false to force the generic path
+    Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
+                arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
+                allow_fused(true) {}
+  };
+
+  explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), res_dev_(nullptr), res_host_(nullptr),
+                                              workspace_(nullptr), iteration_(0) {}
+  virtual ~BackendPDHG();
+
+  virtual void Initialize();
+  virtual void PerformIteration();
+  virtual void Release();
+  virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
+  virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
+  virtual size_t gpu_mem_amount() const;
+  virtual bool KernelTimes(double* primal_ms, double* dual_ms, size_t* launches);
+  virtual std::string path() const;
+
+  T tau() const { return tau_; }
+  T sigma() const { return sigma_; }
+  T theta() const { return theta_; }
+  size_t iteration() const { return iteration_; }
+
+ private:
+  bool TryFused();
+  void IterationFused(bool residual_iteration);
+  void IterationGeneric(bool residual_iteration);
+  void FinishResiduals();                 // all-reduce, D2H, sqrt, step-size rules (backend_pdhg.cu:433-476)
+  void UpdateAlg2();                      // :483-488
+
+  Options opts_;
+  bool fused_;
+  prost_hip_fused_desc desc_;
+  // state: fused keeps x, x_prev, y, y_prev only; generic adds kx, kx_prev, kty, kty_prev, temp
+  device_vector<T> x_, y_, x_prev_, y_prev_, temp_, kx_, kty_, kx_prev_, kty_prev_;
+  double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
+  double* res_host_;       // pinned
+  void* workspace_;
+  T tau_, sigma_, theta_;
+  size_t iteration_;
+  int arb_l_, arb_u_;
+  T arg_alpha_;
+  std::vector<shared_ptr<Prox<T>>> prox_g_, prox_fstar_;
+  // kernel timing
+  std::vector<void*> ev_;
+  size_t ev_used_ = 0;
+};
+
+}  // namespace prost
+#endif

@@ -1,0 +1,51 @@
+// prost/common.hpp -- small host helpers shared by the solver classes
+// (reference: include/prost/common.hpp, src/common.cu).
+#ifndef PROST_COMMON_HPP_
+#define PROST_COMMON_HPP_
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <list>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "prost/exception.hpp"
+
+namespace prost {
+
+using std::shared_ptr;
+using std::vector;
+
+std::string get_version();
+
+/// num_in equally spaced values from start to end plus a trailing `end` (num_in + 1 entries;
+/// reference src/common.cu:33-46 -- the callback schedule of Solver::Solve relies on the extra one)
+template <typename T> std::list<double> linspace(T start_in, T end_in, int num_in);
+
+/// CSR (n x m) -> CSC, not in place (reference src/common.cu:55-82)
+template <typename T>
+void csr2csc(int n, int m, int nz, const T* a, const int32_t* col_idx, const int32_t* row_start, T* csc_a,
+             int32_t* row_idx, int32_t* col_start);
+
+/// glibc's rand() stream for a given seed.  Problem::normest draws its start vector from
+/// std::rand() with srand never called (reference src/problem.cu:435); every solve here uses the
+/// stream a fresh process would see (seed 1), so repeated solves are reproducible.
+class GlibcRand {
+ public:
+  explicit GlibcRand(unsigned seed = 1);
+  int32_t next();
+
+ private:
+  std::vector<uint32_t> r_;
+};
+
+/// HIP stream all kernels of the calling thread are enqueued on (NULL stream by default)
+void* CurrentStream();
+void SetCurrentStream(void* stream);
+/// throws prost::Exception(prost_hip_last_error()) if rc != 0
+void CheckHip(int rc, const char* what);
+
+}  // namespace prost
+#endif

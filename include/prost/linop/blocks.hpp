@@ -1,0 +1,118 @@
+// prost/linop/blocks.hpp -- the in-tree blocks of the hot path
+// (reference: include/prost/linop/block_{gradient2d,gradient3d,sparse,diags,zero}.hpp).
+#ifndef PROST_LINOP_BLOCKS_HPP_
+#define PROST_LINOP_BLOCKS_HPP_
+#include "prost/device_vector.hpp"
+#include "prost/linop/block.hpp"
+
+namespace prost {
+
+/// forward differences with Neumann boundary, L channels (block_gradient2d.hpp / .cu:141-204)
+template <typename T>
+class BlockGradient2D : public Block<T> {
+ public:
+  BlockGradient2D(size_t row, size_t col, size_t nx, size_t ny, size_t L, bool label_first = false)
+      : Block<T>(row, col, nx * ny * L * 2, nx * ny * L), nx_(nx), ny_(ny), L_(L), label_first_(label_first) {}
+  virtual T row_sum(size_t, T) const { return 2; }     // block_gradient2d.cu:154-157
+  virtual T col_sum(size_t, T) const { return 4; }     // :160-163
+  virtual void row_sums(T* out, T alpha) const;
+  virtual void col_sums(T* out, T alpha) const;
+  virtual size_t gpu_mem_amount() const { return 0; }
+  virtual bool describe(BlockDesc& d) const { d.kind = BlockDesc::kGradient2D; d.nx = nx_; d.ny = ny_; d.L = L_; d.label_first = label_first_; return true; }
+
+ protected:
+  virtual void EvalLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalLocal(T*, T*, const T*, const T*);
+  virtual void EvalAdjointLocal(T*, T*, const T*, const T*);
+  size_t nx_, ny_, L_;
+  bool label_first_;
+};
+
+/// as 2-D plus the label/z difference with Dirichlet boundary at l = L-1 (block_gradient3d.cu:73-76)
+template <typename T>
+class BlockGradient3D : public Block<T> {
+ public:
+  BlockGradient3D(size_t row, size_t col, size_t nx, size_t ny, size_t L, bool label_first = false)
+      : Block<T>(row, col, nx * ny * L * 3, nx * ny * L), nx_(nx), ny_(ny), L_(L), label_first_(label_first) {}
+  virtual T row_sum(size_t, T) const { return 2; }     // block_gradient3d.cu:165-168
+  virtual T col_sum(size_t, T) const { return 6; }     // :171-174
+  virtual void row_sums(T* out, T alpha) const;
+  virtual void col_sums(T* out, T alpha) const;
+  virtual size_t gpu_mem_amount() const { return 0; }
+  virtual bool describe(BlockDesc& d) const { d.kind = BlockDesc::kGradient3D; d.nx = nx_; d.ny = ny_; d.L = L_; d.label_first = label_first_; return true; }
+
+ protected:
+  virtual void EvalLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalLocal(T*, T*, const T*, const T*);
+  virtual void EvalAdjointLocal(T*, T*, const T*, const T*);
+  size_t nx_, ny_, L_;
+  bool label_first_;
+};
+
+/// general sparse block; K as CSR and K^T as CSR (= the CSC arrays handed in) (block_sparse.hpp)
+template <typename T>
+class BlockSparse : public Block<T> {
+ public:
+  /// arrays in MATLAB CSC form: ptr = Jc (ncols+1), ind = Ir (nnz) (block_sparse.cu:34-68)
+  static BlockSparse<T>* CreateFromCSC(size_t row, size_t col, int m, int n, int nnz, const std::vector<T>& val,
+                                       const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind);
+  virtual void Initialize();
+  virtual void Release();
+  virtual T row_sum(size_t row, T alpha) const;
+  virtual T col_sum(size_t col, T alpha) const;
+  virtual size_t gpu_mem_amount() const;
+
+ protected:
+  BlockSparse(size_t row, size_t col, size_t nrows, size_t ncols) : Block<T>(row, col, nrows, ncols), nnz_(0) {}
+  virtual void EvalLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*);
+  size_t nnz_;
+  std::vector<int32_t> host_ind_, host_ind_t_, host_ptr_, host_ptr_t_;
+  std::vector<T> host_val_, host_val_t_;
+  device_vector<int32_t> ind_, ind_t_, ptr_, ptr_t_;
+  device_vector<T> val_, val_t_;
+};
+
+/// constant-coefficient multi-diagonal block; `identity` maps here (block_diags.hpp, identity.m:11-12)
+template <typename T>
+class BlockDiags : public Block<T> {
+ public:
+  BlockDiags(size_t row, size_t col, size_t nrows, size_t ncols, size_t ndiags, const std::vector<int64_t>& offsets,
+             const std::vector<T>& factors);
+  virtual void Initialize();
+  virtual void Release();
+  virtual T row_sum(size_t row, T alpha) const;
+  virtual T col_sum(size_t col, T alpha) const;
+  virtual size_t gpu_mem_amount() const { return ndiags_ * (sizeof(float) + sizeof(int64_t)); }
+  /// reproduce the reference's adjoint launch grid sized from nrows (block_diags.cu:211)?
+  /// default false: every column is written.
+  static void SetReferenceGridQuirk(bool on);
+  static bool ReferenceGridQuirk();
+
+ protected:
+  virtual void EvalLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*);
+  size_t ndiags_;
+  std::vector<int64_t> offsets_;
+  std::vector<float> factors_;      // float regardless of T (block_diags.cu:30,:108)
+  device_vector<int64_t> d_offsets_;
+  device_vector<float> d_factors_;
+};
+
+template <typename T>
+class BlockZero : public Block<T> {
+ public:
+  BlockZero(size_t row, size_t col, size_t nrows, size_t ncols) : Block<T>(row, col, nrows, ncols) {}
+  virtual T row_sum(size_t, T) const { return 0; }
+  virtual T col_sum(size_t, T) const { return 0; }
+  virtual size_t gpu_mem_amount() const { return 0; }
+
+ protected:
+  virtual void EvalLocalAdd(T*, T*, const T*, const T*) {}
+  virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*) {}
+};
+
+}  // namespace prost
+#endif

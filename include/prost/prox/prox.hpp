@@ -1,0 +1,65 @@
+// prost/prox/prox.hpp -- plugin base class of proximal operators.
+//
+// Same contract as the reference's include/prost/prox/prox.hpp:39-135: a prox covers
+// [index, index+size) of its variable; Eval slices result / arg / tau_diag and calls EvalLocal.
+// Ranges are raw HBM pointers instead of thrust iterators; kernels go to prost::CurrentStream()
+// and there is NO device synchronisation after a prox (the reference synchronises after every
+// launch, prox_elem_operation.inl:128,187).
+#ifndef PROST_PROX_PROX_HPP_
+#define PROST_PROX_PROX_HPP_
+#include "prost/common.hpp"
+#include "prost/device_vector.hpp"
+
+namespace prost {
+
+template <typename T> class ProxMoreau;
+
+/// what a backend needs to fuse an elementwise prox into its passes
+struct ProxDesc {
+  enum Kind { kNone = 0, kElem1D, kElemNorm2 } kind = kNone;
+  int fn = 0;
+  size_t count = 0, dim = 0;
+  bool interleaved = false;
+  const void* coeff_ptr[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device, or null
+  double coeff_val[7] = {0, 0, 0, 0, 0, 0, 0};
+};
+
+template <typename T>
+class Prox {
+  friend class ProxMoreau<T>;
+
+ public:
+  Prox(size_t index, size_t size, bool diagsteps) : index_(index), size_(size), diagsteps_(diagsteps) {}
+  Prox(const Prox<T>& other) : index_(other.index_), size_(other.size_), diagsteps_(other.diagsteps_) {}
+  virtual ~Prox() {}
+
+  virtual void Initialize() {}
+  virtual void Release() {}
+
+  /// result[index:index+size] = prox(arg[index:...]; tau * tau_diag[index:...])   (prox.cu:27-43)
+  void Eval(device_vector<T>& result, const device_vector<T>& arg, const device_vector<T>& tau_diag, T tau,
+            bool invert_tau = false);
+  /// host-vector version for debugging / eval_prox; returns milliseconds (prox.cu:46-71)
+  double Eval(std::vector<T>& result, const std::vector<T>& arg, const std::vector<T>& tau_diag, T tau);
+
+  virtual size_t gpu_mem_amount() const = 0;
+  size_t index() const { return index_; }
+  size_t size() const { return size_; }
+  size_t end() const { return index_ + size_ - 1; }
+  bool diagsteps() const { return diagsteps_; }
+
+  /// (start, count, stride) groups over which a preconditioner must be constant (prox.cu:74-78)
+  virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) {
+    sep.push_back(std::tuple<size_t, size_t, size_t>(index_, size_, 1));
+  }
+  virtual bool describe(ProxDesc&) const { return false; }
+
+ protected:
+  virtual void EvalLocal(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg,
+                         const T* tau_end, T tau, bool invert_tau) = 0;
+  size_t index_, size_;
+  bool diagsteps_;
+};
+
+}  // namespace prost
+#endif

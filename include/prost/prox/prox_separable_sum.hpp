@@ -1,0 +1,28 @@
+// prost/prox/prox_separable_sum.hpp -- sum of `count` dim-dimensional functions
+// (reference prox_separable_sum.hpp:47-86; interleaved: x0 y0 x1 y1 ..., else x0 x1 .. y0 y1 ..).
+#ifndef PROST_PROX_SEPARABLE_SUM_HPP_
+#define PROST_PROX_SEPARABLE_SUM_HPP_
+#include "prost/prox/prox.hpp"
+
+namespace prost {
+
+template <typename T>
+class ProxSeparableSum : public Prox<T> {
+ public:
+  ProxSeparableSum(size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps)
+      : Prox<T>(index, count * dim, diagsteps), count_(count), dim_(dim), interleaved_(interleaved) {}
+  size_t dim() const { return dim_; }
+  size_t count() const { return count_; }
+  bool interleaved() const { return interleaved_; }
+  virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) {
+    if (interleaved_) for (size_t i = 0; i < count_; i++) sep.push_back(std::tuple<size_t, size_t, size_t>(this->index_ + i * dim_, dim_, 1));
+    else for (size_t i = 0; i < count_; i++) sep.push_back(std::tuple<size_t, size_t, size_t>(this->index_ + i, dim_, count_));
+  }
+
+ protected:
+  size_t count_, dim_;
+  bool interleaved_;
+};
+
+}  // namespace prost
+#endif

@@ -1,0 +1,109 @@
+/*
+ * prost_c.h -- command-level C ABI of the prost host library (libprost.so).
+ *
+ * Mirror of the reference's MEX gateway (matlab/+prost/private/prost.cpp:305-347): one entry
+ * point, prost_command(cmd, nlhs, plhs, nrhs, prhs), with the same command table
+ *     init, release, solve_problem, eval_linop, eval_prox, list_gpus, set_gpu
+ * and the same argument layout (nested cells / structs / matrices).  MATLAB's mxArray is replaced
+ * by the self-contained prost_value tree below, so that any host language (MATLAB MEX, Python
+ * ctypes, cgo, JNI) can marshal its problem description into it -- see INTEGRATION.md for the
+ * mxArray -> prost_value converter a MEX maintainer would add.
+ *
+ * Extra commands (no reference counterpart, used by the benchmark and the tests):
+ *     set_precision / get_precision   'double' (reference default, config.hpp:7) or 'single'
+ *     problem_info                    host-side problem setup only (no GPU needed)
+ *     solver_create / solver_iterate / solver_state / solver_destroy
+ *                                     persistent solver handle for timing K iterations
+ *     comm_unique_id / comm_init / comm_destroy
+ *                                     RCCL communicator for the global stopping criterion
+ *     set_quirks                      reference bug-compatibility switches
+ *
+ * All functions are thread-compatible but, like the reference gateway, not re-entrant.
+ */
+#ifndef PROST_C_H_
+#define PROST_C_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct prost_value prost_value;
+
+enum {
+  PROST_VALUE_EMPTY = 0,
+  PROST_VALUE_MATRIX = 1,    /* dense real double matrix, column-major (scalars are 1x1)   */
+  PROST_VALUE_STRING = 2,
+  PROST_VALUE_CELL = 3,      /* 1-D list of values                                         */
+  PROST_VALUE_STRUCT = 4,    /* named fields                                               */
+  PROST_VALUE_SPARSE = 5,    /* real double sparse matrix in CSC (MATLAB Ir / Jc layout)   */
+  PROST_VALUE_CALLBACK = 6   /* function handle (opts.interm_cb)                           */
+};
+
+/* interm callback: (user, iteration, x, nx, y, ny) -> non-zero = converged
+ * (factory.cpp:136-158 calls feval(handle, it, x, y)) */
+typedef int (*prost_interm_cb)(void* user, int iteration, const double* x, size_t nx, const double* y, size_t ny);
+/* stop callback polled every iteration (prost.cpp:58-66, utIsInterruptPending) */
+typedef int (*prost_stop_cb)(void* user);
+
+/* ---- constructors (the tree owns its children; free the root with prost_value_free) ---- */
+prost_value* prost_value_scalar(double v);
+prost_value* prost_value_matrix(const double* data, size_t rows, size_t cols);      /* copies */
+prost_value* prost_value_string(const char* s);
+prost_value* prost_value_cell(size_t n);
+int prost_value_cell_set(prost_value* cell, size_t i, prost_value* v);               /* takes ownership of v */
+prost_value* prost_value_struct(void);
+int prost_value_struct_set(prost_value* s, const char* name, prost_value* v);        /* takes ownership of v */
+prost_value* prost_value_sparse(size_t rows, size_t cols, size_t nnz, const double* val, const int64_t* ir, const int64_t* jc);
+prost_value* prost_value_callback(prost_interm_cb fn, void* user);
+void prost_value_free(prost_value* v);
+
+/* ---- accessors (borrowed pointers, valid while the value lives) ---- */
+int prost_value_kind(const prost_value* v);
+size_t prost_value_rows(const prost_value* v);
+size_t prost_value_cols(const prost_value* v);
+const double* prost_value_data(const prost_value* v);
+const char* prost_value_str(const prost_value* v);
+size_t prost_value_count(const prost_value* v);                                      /* cells */
+const prost_value* prost_value_cell_get(const prost_value* v, size_t i);
+const prost_value* prost_value_field(const prost_value* v, const char* name);        /* NULL if absent */
+
+/* ---- the gateway ---- */
+/* Returns 0 on success.  plhs[0..nlhs) receive newly created values the caller must free.
+ * On failure returns non-zero and prost_last_error() holds the message the reference would have
+ * passed to mexErrMsgTxt (prost.cpp:342-346). */
+int prost_command(const char* cmd, int nlhs, prost_value** plhs, int nrhs, const prost_value* const* prhs);
+const char* prost_last_error(void);
+/* user-interrupt hook of solve_problem (the Ctrl-C poll of the MEX gateway) */
+void prost_set_stop_callback(prost_stop_cb fn, void* user);
+
+/*
+ * Command reference (arguments in prhs order, results in plhs order):
+ *   init, release                          -> no results                        (prost.cpp:278-281)
+ *   list_gpus                              -> prints one line per device        (:283-297)
+ *   set_gpu(id)                                                                 (:299-303)
+ *   solve_problem(problem, nrows, ncols, backend, opts) -> struct {x,y,z,w,result[,iters,path]}  (:68-155)
+ *       problem: struct {linop, prox_g, prox_f, prox_gstar, prox_fstar, scaling, scaling_alpha |
+ *                        scaling_left, scaling_right}                           (factory.cpp:950-990)
+ *       backend: cell {name, struct}   name in {pdhg, admm}                     (:914-948)
+ *       opts:    struct of prost.options                                        (:992-1012)
+ *   eval_linop(linop_cells, rhs, transpose) -> result, rowsum, colsum, time_ms  (prost.cpp:157-224)
+ *   eval_prox(prox_cell, arg, tau, Tau[, verbose]) -> result, time_ms           (:226-276)
+ *   set_precision('single'|'double'), get_precision -> string
+ *   problem_info(problem, nrows, ncols) -> struct {scaling_left, scaling_right, nrows, ncols,
+ *                                                   prox_g, prox_f, prox_gstar, prox_fstar}  (index/size/name rows)
+ *   solver_create(problem, nrows, ncols, backend, opts) -> handle (scalar)
+ *   solver_iterate(handle, iters[, time_kernels]) -> struct {ms, primal_kernel_ms, dual_kernel_ms, launches}
+ *   solver_state(handle) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,
+ *                                   dual_var_norm,eps_primal,eps_dual,iteration,path}
+ *   solver_destroy(handle)
+ *   comm_unique_id -> 1x128 matrix of byte values;  comm_init(id, rank, world);  comm_destroy
+ *   set_quirks(struct {diags_adjoint_grid, dual_negate_float})
+ */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROST_C_H_ */

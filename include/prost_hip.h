@@ -215,9 +215,10 @@ int prost_hip_axpy_f64(double* y, const double* x, double alpha, size_t n, void*
  *  PROST_ADMM_GEMV2   o = (beta / (alpha sqrt(a))) b     (alpha, beta scalars)  gemv_functor2
  *  PROST_ADMM_GEMV3   o = alpha sqrt(a) b                                       gemv_functor3
  *  PROST_ADMM_GETDUAL o = -alpha pow(d, beta) (a - b + c)   (alpha=rho,beta=expo) get_dual_functor
- *  PROST_ADMM_SCALE   o = alpha a                                               rescale :650-663 */
+ *  PROST_ADMM_SCALE   o = alpha a                                               rescale :650-663
+ *  PROST_ADMM_DIV     o = a / alpha                                             normest_divide problem.cu:411-421 */
 enum { PROST_ADMM_TEMP1 = 0, PROST_ADMM_TEMP2, PROST_ADMM_DIFF, PROST_ADMM_XPROJ, PROST_ADMM_XDUAL, PROST_ADMM_ZDUAL,
-       PROST_ADMM_GEMV1, PROST_ADMM_GEMV2, PROST_ADMM_GEMV3, PROST_ADMM_GETDUAL, PROST_ADMM_SCALE };
+       PROST_ADMM_GEMV1, PROST_ADMM_GEMV2, PROST_ADMM_GEMV3, PROST_ADMM_GETDUAL, PROST_ADMM_SCALE, PROST_ADMM_DIV };
 int prost_hip_admm_elem_f32(int op, float* o, const float* a, const float* b, const float* c, const float* d, double alpha, double beta, size_t n, void* stream);
 int prost_hip_admm_elem_f64(int op, double* o, const double* a, const double* b, const double* c, const double* d, double alpha, double beta, size_t n, void* stream);
 

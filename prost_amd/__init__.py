@@ -19,7 +19,8 @@ def __getattr__(name):
     # the native command surface is imported lazily so that the pure description builders work
     # without the shared libraries (e.g. when only building problem descriptions)
     if name in ("solve", "eval_linop", "eval_prox", "init", "release", "set_gpu", "list_gpus",
-                "set_precision", "get_precision", "problem_info"):
+                "set_precision", "get_precision", "problem_info", "Solver", "set_quirks", "comm_unique_id",
+                "comm_init", "comm_destroy", "ProstError"):
         from . import _capi
         return getattr(_capi, name)
     raise AttributeError(name)

@@ -1,0 +1,308 @@
+"""ctypes binding of the command-level C ABI (include/prost_c.h -> prost_amd/lib/libprost.so).
+
+Marshals the nested problem descriptions (Python lists / dicts / numpy / scipy.sparse -- the
+MATLAB cells / structs / matrices) into prost_value trees and calls prost_command with the same
+command names and argument order as the reference's MEX gateway (prost.cpp:305-313).
+No compute happens in Python and there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprost.so")
+
+INTERM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.c_size_t)
+STOP_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+(VALUE_EMPTY, VALUE_MATRIX, VALUE_STRING, VALUE_CELL, VALUE_STRUCT, VALUE_SPARSE, VALUE_CALLBACK) = range(7)
+
+
+class ProstError(RuntimeError):
+    """what mexErrMsgTxt would have shown (prost.cpp:342-346)"""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ProstError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(or make -C prost_amd/csrc)" % LIB_PATH)
+        # libprost.so finds libprost_hip.so through its $ORIGIN rpath
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.prost_value_scalar.restype = vp
+        L.prost_value_scalar.argtypes = [C.c_double]
+        L.prost_value_matrix.restype = vp
+        L.prost_value_matrix.argtypes = [vp, C.c_size_t, C.c_size_t]
+        L.prost_value_string.restype = vp
+        L.prost_value_string.argtypes = [C.c_char_p]
+        L.prost_value_cell.restype = vp
+        L.prost_value_cell.argtypes = [C.c_size_t]
+        L.prost_value_cell_set.argtypes = [vp, C.c_size_t, vp]
+        L.prost_value_struct.restype = vp
+        L.prost_value_struct_set.argtypes = [vp, C.c_char_p, vp]
+        L.prost_value_sparse.restype = vp
+        L.prost_value_sparse.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, vp]
+        L.prost_value_callback.restype = vp
+        L.prost_value_callback.argtypes = [INTERM_CB, vp]
+        L.prost_value_free.argtypes = [vp]
+        L.prost_value_free.restype = None
+        L.prost_value_kind.argtypes = [vp]
+        L.prost_value_rows.argtypes = [vp]
+        L.prost_value_rows.restype = C.c_size_t
+        L.prost_value_cols.argtypes = [vp]
+        L.prost_value_cols.restype = C.c_size_t
+        L.prost_value_data.argtypes = [vp]
+        L.prost_value_data.restype = C.POINTER(C.c_double)
+        L.prost_value_str.argtypes = [vp]
+        L.prost_value_str.restype = C.c_char_p
+        L.prost_value_count.argtypes = [vp]
+        L.prost_value_count.restype = C.c_size_t
+        L.prost_value_cell_get.argtypes = [vp, C.c_size_t]
+        L.prost_value_cell_get.restype = vp
+        L.prost_value_field.argtypes = [vp, C.c_char_p]
+        L.prost_value_field.restype = vp
+        L.prost_command.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.prost_last_error.restype = C.c_char_p
+        L.prost_set_stop_callback.argtypes = [STOP_CB, vp]
+        L.prost_set_stop_callback.restype = None
+        _lib = L
+    return _lib
+
+
+# ------------------------------------------------------------------------------------------
+# Python <-> prost_value
+# ------------------------------------------------------------------------------------------
+def to_value(obj, keep):
+    """MATLAB-like conversion: numbers/bools -> 1x1, 1-D arrays -> Nx1, None/[] -> empty matrix,
+    str -> string, list/tuple -> cell, dict -> struct, scipy sparse -> sparse, callable -> handle."""
+    L = lib()
+    if obj is None:
+        return L.prost_value_matrix(None, 0, 0)
+    if isinstance(obj, (bool, np.bool_)):
+        return L.prost_value_scalar(1.0 if obj else 0.0)
+    if isinstance(obj, (int, float, np.integer, np.floating)):
+        return L.prost_value_scalar(float(obj))
+    if isinstance(obj, str):
+        return L.prost_value_string(obj.encode())
+    if isinstance(obj, dict):
+        s = L.prost_value_struct()
+        for k, v in obj.items():
+            L.prost_value_struct_set(s, k.encode(), to_value(v, keep))
+        return s
+    if isinstance(obj, (list, tuple)):
+        c = L.prost_value_cell(len(obj))
+        for i, v in enumerate(obj):
+            L.prost_value_cell_set(c, i, to_value(v, keep))
+        return c
+    if callable(obj):
+        def _cb(user, it, x, nx, y, ny, fn=obj):
+            r = fn(it, np.ctypeslib.as_array(x, (nx,)).copy(), np.ctypeslib.as_array(y, (ny,)).copy())
+            return int(bool(r))
+        cb = INTERM_CB(_cb)
+        keep.append(cb)
+        return L.prost_value_callback(cb, None)
+    try:
+        import scipy.sparse as sp
+        if sp.issparse(obj):
+            K = sp.csc_matrix(obj, dtype=np.float64)
+            K.sort_indices()
+            val = np.ascontiguousarray(K.data, dtype=np.float64)
+            ir = np.ascontiguousarray(K.indices, dtype=np.int64)
+            jc = np.ascontiguousarray(K.indptr, dtype=np.int64)
+            return L.prost_value_sparse(K.shape[0], K.shape[1], K.nnz, val.ctypes.data, ir.ctypes.data, jc.ctypes.data)
+    except ImportError:
+        pass
+    a = np.asarray(obj, dtype=np.float64)
+    if a.ndim == 0:
+        return L.prost_value_scalar(float(a))
+    if a.ndim == 1:
+        a = np.ascontiguousarray(a)
+        return L.prost_value_matrix(a.ctypes.data, a.size, 1 if a.size else 0)
+    if a.ndim == 2:
+        f = np.asfortranarray(a)
+        return L.prost_value_matrix(f.ctypes.data, f.shape[0], f.shape[1])
+    raise ProstError("Cannot handle arrays with dim > 2.")
+
+
+def from_value(v):
+    L = lib()
+    kind = L.prost_value_kind(v)
+    if kind == VALUE_MATRIX:
+        r, c = L.prost_value_rows(v), L.prost_value_cols(v)
+        if r * c == 0:
+            return np.zeros((r, c))
+        a = np.ctypeslib.as_array(L.prost_value_data(v), (r * c,)).copy()
+        if r == 1 and c == 1:
+            return float(a[0])
+        return a if c == 1 else a.reshape((c, r)).T
+    if kind == VALUE_STRING:
+        return L.prost_value_str(v).decode()
+    if kind == VALUE_CELL:
+        return [from_value(L.prost_value_cell_get(v, i)) for i in range(L.prost_value_count(v))]
+    if kind == VALUE_STRUCT:
+        raise ProstError("struct results are read field by field (see _struct_fields)")
+    return None
+
+
+def _struct_fields(v, names):
+    L = lib()
+    out = {}
+    for n in names:
+        f = L.prost_value_field(v, n.encode())
+        if f:
+            out[n] = from_value(f)
+    return out
+
+
+def command(cmd, args=(), nlhs=0, struct_fields=None):
+    """prost_(cmd, args...) -- returns a list of nlhs converted results."""
+    L = lib()
+    keep = []
+    vals = [to_value(a, keep) for a in args]
+    prhs = (C.c_void_p * max(len(vals), 1))(*vals)
+    plhs = (C.c_void_p * max(nlhs, 1))()
+    try:
+        rc = L.prost_command(cmd.encode(), nlhs, plhs, len(vals), prhs)
+        if rc != 0:
+            raise ProstError(L.prost_last_error().decode())
+        out = []
+        for i in range(nlhs):
+            if not plhs[i]:
+                out.append(None)
+            elif L.prost_value_kind(plhs[i]) == VALUE_STRUCT:
+                out.append(_struct_fields(plhs[i], struct_fields or ()))
+            else:
+                out.append(from_value(plhs[i]))
+        return out
+    finally:
+        for v in vals:
+            L.prost_value_free(v)
+        for i in range(nlhs):
+            if plhs[i]:
+                L.prost_value_free(plhs[i])
+
+
+# ------------------------------------------------------------------------------------------
+# the +prost command surface (matlab/+prost/*.m)
+# ------------------------------------------------------------------------------------------
+_RESULT_FIELDS = ("x", "y", "z", "w", "result", "iters", "path")
+_STATE_FIELDS = ("x", "y", "z", "w", "tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res",
+                 "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "path")
+
+
+def _opts_struct(opts):
+    o = dict(opts)
+    for k in ("x0", "y0"):
+        if o.get(k) is None:
+            o[k] = None
+    if o.get("interm_cb") is None:
+        o.pop("interm_cb", None)
+    return o
+
+
+def init():
+    command("init")
+
+
+def release():
+    command("release")
+
+
+def set_gpu(gpu_id):
+    command("set_gpu", [gpu_id])
+
+
+def list_gpus():
+    return int(command("list_gpus", nlhs=1)[0])
+
+
+def set_precision(name):
+    """'double' (the reference's shipped default, config.hpp:7) or 'single'"""
+    command("set_precision", [name])
+
+
+def get_precision():
+    return command("get_precision", nlhs=1)[0]
+
+
+def solve(prob, backend, opts):
+    """prost.solve (solve.m:5-9)"""
+    prob.finalize()
+    result = command("solve_problem", [prob.data, prob.nrows, prob.ncols, backend, _opts_struct(opts)],
+                     nlhs=1, struct_fields=_RESULT_FIELDS)[0]
+    prob.fill_variables(result)
+    return result
+
+
+def eval_linop(linop, rhs, transpose):
+    """prost.eval_linop (eval_linop.m:3) -> (result, rowsum, colsum, time_ms)"""
+    rhs = np.asarray(rhs, dtype=np.float64).reshape(-1, 1)
+    return tuple(command("eval_linop", [list(linop), rhs, bool(transpose)], nlhs=4))
+
+
+def eval_prox(prox, arg, tau, Tau, verbose=False):
+    """prost.eval_prox (eval_prox.m:7): prox is a function builder, evaluated at (0, len(arg))"""
+    arg = np.asarray(arg, dtype=np.float64).reshape(-1, 1)
+    Tau = np.asarray(Tau, dtype=np.float64).reshape(-1, 1)
+    res, ms = command("eval_prox", [prox(0, arg.shape[0]), arg, float(tau), Tau, bool(verbose)], nlhs=2)
+    return np.atleast_1d(res), ms
+
+
+def problem_info(prob):
+    """host-side problem setup (coverage checks, zero-prox filling, preconditioners); no GPU."""
+    prob.finalize()
+    return command("problem_info", [prob.data, prob.nrows, prob.ncols], nlhs=1,
+                   struct_fields=("scaling_left", "scaling_right", "nrows", "ncols", "linop_nrows", "linop_ncols",
+                                  "prox_g", "prox_f", "prox_gstar", "prox_fstar"))[0]
+
+
+def set_quirks(**kw):
+    command("set_quirks", [kw])
+
+
+class Solver:
+    """Persistent solver handle: iterate K times without convergence tests (benchmark / tests)."""
+
+    def __init__(self, prob, backend, opts):
+        prob.finalize()
+        self.prob = prob
+        self.handle = command("solver_create", [prob.data, prob.nrows, prob.ncols, backend, _opts_struct(opts)], nlhs=1)[0]
+
+    def iterate(self, iters, time_kernels=False):
+        return command("solver_iterate", [self.handle, int(iters), bool(time_kernels)], nlhs=1,
+                       struct_fields=("ms", "primal_kernel_ms", "dual_kernel_ms", "launches"))[0]
+
+    def state(self):
+        st = command("solver_state", [self.handle], nlhs=1, struct_fields=_STATE_FIELDS)[0]
+        for k in ("x", "y", "z", "w"):
+            st[k] = np.atleast_1d(st[k])
+        return st
+
+    def destroy(self):
+        if self.handle is not None:
+            command("solver_destroy", [self.handle])
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def comm_unique_id():
+    return np.asarray(command("comm_unique_id", nlhs=1)[0]).reshape(-1)
+
+
+def comm_init(unique_id, rank, world):
+    command("comm_init", [np.asarray(unique_id, dtype=np.float64).reshape(1, -1), rank, world])
+
+
+def comm_destroy():
+    command("comm_destroy")

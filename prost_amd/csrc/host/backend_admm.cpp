@@ -1,0 +1,254 @@
+// backend_admm.cpp -- graph-projection ADMM with CGLS inner solves on the MI355X kernels
+// (behaviour of the reference's src/backend/backend_admm.cu and include/prost/cgls.hpp; the
+// cuBLAS nrm2/axpy and thrust functors are the prost_hip_nrm2 / _axpy / _admm_elem kernels).
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "hipapi.hpp"
+#include "prost/backend/backend_admm.hpp"
+#include "prost/prox/proxes.hpp"
+
+namespace prost {
+
+template <typename T> BackendADMM<T>::~BackendADMM() { Release(); }
+
+template <typename T>
+void BackendADMM<T>::Initialize() {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols(), l = std::max(m, n);
+  x_half_.resize(n); x_proj_.resize(n); x_dual_.resize(n);
+  z_half_.resize(m); z_proj_.resize(m); z_dual_.resize(m);
+  temp1_.resize(n);
+  temp2_.resize(l);      // the reference scales n entries into this m-vector (:586-590); sized max(m,n) here
+  temp3_.resize(l);
+  tmp_n_.resize(n); tmp_m_.resize(m);
+  prox_g_.clear(); prox_f_.clear();
+  if (this->problem_->prox_g().empty()) {
+    if (this->problem_->prox_gstar().empty()) throw Exception("Neither prox_g nor prox_gstar specified.");
+    for (auto& p : this->problem_->prox_gstar()) { auto mo = std::make_shared<ProxMoreau<T>>(p); mo->Initialize(); prox_g_.push_back(mo); }
+  } else prox_g_ = this->problem_->prox_g();
+  if (this->problem_->prox_f().empty()) {
+    if (this->problem_->prox_fstar().empty()) throw Exception("Neither prox_f nor prox_fstar specified.");
+    for (auto& p : this->problem_->prox_fstar()) { auto mo = std::make_shared<ProxMoreau<T>>(p); mo->Initialize(); prox_f_.push_back(mo); }
+  } else prox_f_ = this->problem_->prox_f();
+  delta_ = opts_.arb_delta;
+  rho_ = (T)opts_.rho0;
+  iteration_ = 0;
+  arb_u_ = arb_l_ = 0;
+  // the reference leaves the residual members uninitialised; zero them
+  this->primal_var_norm_ = this->dual_var_norm_ = this->primal_residual_ = this->dual_residual_ = 0;
+  CheckHip(prost_hip_malloc((void**)&scal_dev_, 8 * sizeof(double)), "malloc");
+  CheckHip(prost_hip_host_alloc((void**)&scal_host_, 8 * sizeof(double)), "host_alloc");
+  CheckHip(prost_hip_malloc(&workspace_, prost_hip_reduce_workspace_bytes()), "malloc");
+}
+
+template <typename T>
+void BackendADMM<T>::Release() {
+  if (scal_dev_) { prost_hip_free(scal_dev_); scal_dev_ = nullptr; }
+  if (scal_host_) { prost_hip_host_free(scal_host_); scal_host_ = nullptr; }
+  if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
+  x_half_.clear(); z_half_.clear(); x_proj_.clear(); z_proj_.clear(); x_dual_.clear(); z_dual_.clear(); temp1_.clear(); temp2_.clear(); temp3_.clear(); tmp_n_.clear(); tmp_m_.clear();
+}
+
+template <typename T>
+static void elem(int op, T* o, const T* a, const T* b, const T* c, const T* d, double alpha, double beta, size_t n) {
+  CheckHip(Api<T>::admm_elem(op, o, a, b, c, d, alpha, beta, n, CurrentStream()), "admm_elem");
+}
+
+template <typename T>
+void BackendADMM<T>::Gemv(char op, T alpha, const device_vector<T>& x, T beta, device_vector<T>& y) {
+  const device_vector<T>& Sl = this->problem_->scaling_left();
+  const device_vector<T>& Tr = this->problem_->scaling_right();
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  if (op == 'n') {
+    elem<T>(PROST_ADMM_GEMV1, temp3_.data(), Tr.data(), x.data(), nullptr, nullptr, 0, 0, n);          // temp = Tau^(1/2) x
+    elem<T>(PROST_ADMM_GEMV2, y.data(), Sl.data(), y.data(), nullptr, nullptr, alpha, beta, m);        // y = beta/(alpha Sigma^(1/2)) y
+    this->problem_->linop()->Eval(y, temp3_, 1);                                                       // y += K temp
+    elem<T>(PROST_ADMM_GEMV3, y.data(), Sl.data(), y.data(), nullptr, nullptr, alpha, 0, m);           // y = alpha Sigma^(1/2) y
+  } else {
+    elem<T>(PROST_ADMM_GEMV1, temp3_.data(), Sl.data(), x.data(), nullptr, nullptr, 0, 0, m);
+    elem<T>(PROST_ADMM_GEMV2, y.data(), Tr.data(), y.data(), nullptr, nullptr, alpha, beta, n);
+    this->problem_->linop()->EvalAdjoint(y, temp3_, 1);
+    elem<T>(PROST_ADMM_GEMV3, y.data(), Tr.data(), y.data(), nullptr, nullptr, alpha, 0, n);
+  }
+}
+
+template <typename T>
+double BackendADMM<T>::Nrm2(const device_vector<T>& v, size_t n) {
+  CheckHip(Api<T>::nrm2(scal_dev_, v.data(), n, workspace_, CurrentStream()), "nrm2");
+  CheckHip(prost_hip_memcpy_d2h(scal_host_, scal_dev_, 2 * sizeof(double), CurrentStream()), "memcpy_d2h");
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
+  return scal_host_[0];
+}
+
+/// CGLS for min |Ax - b|^2 + shift |x|^2 with A = Sigma^(1/2) K Tau^(1/2) (cgls.hpp:222-371)
+template <typename T>
+int BackendADMM<T>::Cgls(const device_vector<T>& b, device_vector<T>& x, double shift, double tol, int maxit, device_vector<T>& p,
+                         device_vector<T>& q, device_vector<T>& r, device_vector<T>& s, int& iterations) {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  void* st = CurrentStream();
+  const T kNegShift = (T)(-shift);
+  const double kEps = std::numeric_limits<T>::epsilon();
+  int k = 0, flag = 0, indefinite = 0;
+  CheckHip(prost_hip_memcpy_d2d(r.data(), b.data(), m * sizeof(T), st), "copy");
+  CheckHip(prost_hip_memcpy_d2d(s.data(), x.data(), n * sizeof(T), st), "copy");
+  double normx = Nrm2(x, n);
+  if (normx > 0.) Gemv('n', (T)-1, x, (T)1, r);          // r = b - A x
+  Gemv('t', (T)1, r, kNegShift, s);                      // s = A' r - shift x
+  CheckHip(prost_hip_memcpy_d2d(p.data(), s.data(), n * sizeof(T), st), "copy");
+  double norms = Nrm2(s, n);
+  const double norms0 = norms;
+  double gamma = norms0 * norms0;
+  normx = Nrm2(x, n);
+  double xmax = normx;
+  if (norms < kEps) flag = 1;
+  for (k = 0; k < maxit && !flag; ++k) {
+    Gemv('n', (T)1, p, (T)0, q);                         // q = A p
+    const double normp = Nrm2(p, n), normq = Nrm2(q, m);
+    double dlt = normq * normq + shift * normp * normp;
+    if (dlt <= 0.) indefinite = 1;
+    if (dlt == 0.) dlt = kEps;
+    const T alpha = (T)(gamma / dlt), neg_alpha = (T)(-gamma / dlt);
+    CheckHip(Api<T>::axpy(x.data(), p.data(), (double)alpha, n, st), "axpy");        // x += alpha p
+    CheckHip(Api<T>::axpy(r.data(), q.data(), (double)neg_alpha, m, st), "axpy");    // r -= alpha q
+    CheckHip(prost_hip_memcpy_d2d(s.data(), x.data(), n * sizeof(T), st), "copy");
+    Gemv('t', (T)1, r, kNegShift, s);
+    norms = Nrm2(s, n);
+    const double gamma1 = gamma;
+    gamma = norms * norms;
+    const T beta = (T)(gamma / gamma1);
+    CheckHip(Api<T>::axpy(s.data(), p.data(), (double)beta, n, st), "axpy");         // p = s + beta p
+    CheckHip(prost_hip_memcpy_d2d(p.data(), s.data(), n * sizeof(T), st), "copy");
+    normx = Nrm2(x, n);
+    xmax = std::max(xmax, normx);
+    if ((norms <= norms0 * tol) || (normx * tol >= 1.)) break;
+  }
+  const double shrink = normx / xmax;
+  if (k == maxit) flag = 2;
+  else if (indefinite) flag = 3;
+  else if (shrink * shrink <= tol) flag = 4;
+  iterations = k;
+  return flag;
+}
+
+template <typename T>
+void BackendADMM<T>::GetDual(device_vector<T>& out, const device_vector<T>& half, const device_vector<T>& proj,
+                             const device_vector<T>& dual, const device_vector<T>& scaling, T expo, size_t n) {
+  // out = -rho * scaling^expo * (half - proj + dual)   (get_dual_functor, backend_admm.cu:181-196)
+  elem<T>(PROST_ADMM_GETDUAL, out.data(), half.data(), proj.data(), dual.data(), scaling.data(), (double)rho_, (double)expo, n);
+}
+
+template <typename T>
+void BackendADMM<T>::PerformIteration() {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  const device_vector<T>& Sl = this->problem_->scaling_left();
+  const device_vector<T>& Tr = this->problem_->scaling_right();
+  void* st = CurrentStream();
+
+  elem<T>(PROST_ADMM_TEMP1, temp1_.data(), x_half_.data(), x_proj_.data(), x_dual_.data(), Tr.data(), (double)(T)opts_.alpha, 0, n);   // :358-373
+  elem<T>(PROST_ADMM_TEMP2, temp2_.data(), z_half_.data(), z_dual_.data(), Sl.data(), nullptr, 0, 0, m);                               // :376-389
+  CheckHip(prost_hip_memcpy_d2d(z_dual_.data(), temp2_.data(), m * sizeof(T), st), "copy");          // projection argument lives in z_dual_
+  CheckHip(prost_hip_memcpy_d2d(x_proj_.data(), temp3_.data(), n * sizeof(T), st), "copy");          // CG warm start
+  Gemv('n', (T)-1, temp1_, (T)1, z_dual_);
+
+  double cg_tol = opts_.cg_tol_min / std::pow((double)static_cast<T>(iteration_ + 1), opts_.cg_tol_pow);   // :408-410
+  cg_tol = std::max(cg_tol, opts_.cg_tol_max);
+  Cgls(z_dual_, x_proj_, 1, cg_tol, opts_.cg_max_iter, x_half_, z_half_, z_proj_, x_dual_, last_cg_iters_);
+
+  CheckHip(prost_hip_memcpy_d2d(temp3_.data(), x_proj_.data(), n * sizeof(T), st), "copy");
+  elem<T>(PROST_ADMM_XPROJ, x_proj_.data(), temp1_.data(), Tr.data(), nullptr, nullptr, 0, 0, n);                                       // :447-456
+  this->problem_->linop()->Eval(z_proj_, x_proj_);
+  elem<T>(PROST_ADMM_XDUAL, x_dual_.data(), temp1_.data(), x_proj_.data(), Tr.data(), nullptr, 0, 0, n);                                // :464-477
+  elem<T>(PROST_ADMM_ZDUAL, z_dual_.data(), temp2_.data(), z_proj_.data(), Sl.data(), nullptr, 0, 0, m);                                // :480-493
+  elem<T>(PROST_ADMM_DIFF, temp1_.data(), x_proj_.data(), x_dual_.data(), nullptr, nullptr, 0, 0, n);
+  for (auto& p : prox_g_) p->Eval(x_half_, temp1_, Tr, 1 / rho_);
+  elem<T>(PROST_ADMM_DIFF, temp2_.data(), z_proj_.data(), z_dual_.data(), nullptr, nullptr, 0, 0, m);
+  for (auto& p : prox_f_) p->Eval(z_half_, temp2_, Sl, rho_, true);
+
+  iteration_++;
+
+  if (iteration_ == 0 || (iteration_ % (size_t)opts_.residual_iter) == 0) {                            // :535-663
+    CheckHip(prost_hip_memcpy_d2d(temp2_.data(), z_half_.data(), m * sizeof(T), st), "copy");
+    {   // temp2 = z_half - K x_half  (Eval with beta = -1 on the m-prefix of temp2_)
+      elem<T>(PROST_ADMM_SCALE, temp2_.data(), temp2_.data(), nullptr, nullptr, nullptr, -1.0, 0, m);
+      this->problem_->linop()->Eval(tmp_m_, x_half_);
+      CheckHip(Api<T>::axpy(temp2_.data(), tmp_m_.data(), 1.0, m, st), "axpy");
+    }
+    elem<T>(PROST_ADMM_GEMV1, temp2_.data(), Sl.data(), temp2_.data(), nullptr, nullptr, 0, 0, m);
+    double primal_residual = (double)(T)Nrm2(temp2_, m);
+    elem<T>(PROST_ADMM_GEMV1, temp2_.data(), Sl.data(), z_half_.data(), nullptr, nullptr, 0, 0, m);
+    double primal_var_norm = (double)(T)Nrm2(temp2_, m);
+    GetDual(temp1_, x_half_, x_proj_, x_dual_, Tr, (T)-1, n);                                          // w
+    elem<T>(PROST_ADMM_GEMV1, temp2_.data(), Tr.data(), temp1_.data(), nullptr, nullptr, 0, 0, n);
+    double dual_var_norm = (double)(T)Nrm2(temp2_, n);
+    GetDual(temp2_, z_half_, z_proj_, z_dual_, Sl, (T)1, m);                                           // y
+    {   // temp1 = w + K^T y
+      CheckHip(prost_hip_memcpy_d2d(tmp_m_.data(), temp2_.data(), m * sizeof(T), st), "copy");
+      this->problem_->linop()->EvalAdjoint(tmp_n_, tmp_m_);
+      CheckHip(Api<T>::axpy(temp1_.data(), tmp_n_.data(), 1.0, n, st), "axpy");
+    }
+    elem<T>(PROST_ADMM_GEMV1, temp1_.data(), Tr.data(), temp1_.data(), nullptr, nullptr, 0, 0, n);
+    double dual_residual = (double)(T)Nrm2(temp1_, n);
+
+    if (this->comm_) {
+      scal_host_[0] = primal_residual * primal_residual; scal_host_[1] = primal_var_norm * primal_var_norm;
+      scal_host_[2] = dual_residual * dual_residual; scal_host_[3] = dual_var_norm * dual_var_norm;
+      CheckHip(prost_hip_memcpy_h2d(scal_dev_, scal_host_, 4 * sizeof(double), st), "h2d");
+      CheckHip(prost_hip_allreduce_sum_f64(this->comm_, scal_dev_, 4, st), "allreduce");
+      CheckHip(prost_hip_memcpy_d2h(scal_host_, scal_dev_, 4 * sizeof(double), st), "d2h");
+      CheckHip(prost_hip_stream_synchronize(st), "sync");
+      primal_residual = std::sqrt(scal_host_[0]); primal_var_norm = std::sqrt(scal_host_[1]);
+      dual_residual = std::sqrt(scal_host_[2]); dual_var_norm = std::sqrt(scal_host_[3]);
+    }
+    this->primal_residual_ = (T)primal_residual;
+    this->primal_var_norm_ = (T)primal_var_norm;
+    this->dual_residual_ = (T)dual_residual;
+    this->dual_var_norm_ = (T)dual_var_norm;
+
+    const T eps_primal = this->eps_primal(), eps_dual = this->eps_dual();
+    const T rho_prev = rho_;
+    if ((this->dual_residual_ < eps_dual) && (opts_.arb_tau * iteration_ > arb_l_)) {
+      rho_ *= delta_; delta_ *= opts_.arb_gamma; arb_u_ = (int)iteration_;
+    } else if ((this->primal_residual_ < eps_primal) && (opts_.arb_tau * iteration_ > arb_u_)) {
+      rho_ /= delta_; delta_ *= opts_.arb_gamma; arb_l_ = (int)iteration_;
+    }
+    if (std::abs(rho_ - rho_prev) > 1e-7) {                                                            // :650-663
+      const T f = rho_prev / rho_;
+      elem<T>(PROST_ADMM_SCALE, x_dual_.data(), x_dual_.data(), nullptr, nullptr, nullptr, (double)f, 0, n);
+      elem<T>(PROST_ADMM_SCALE, z_dual_.data(), z_dual_.data(), nullptr, nullptr, nullptr, (double)f, 0, m);
+    }
+    CheckHip(prost_hip_check_last_error(), "ADMM iteration");
+  }
+}
+
+template <typename T>
+void BackendADMM<T>::current_solution(std::vector<T>& primal, std::vector<T>& dual) {
+  const size_t m = this->problem_->nrows();
+  x_half_.copy_to(primal);
+  GetDual(temp2_, z_half_, z_proj_, z_dual_, this->problem_->scaling_left(), (T)1, m);
+  std::vector<T> tmp; temp2_.copy_to(tmp);
+  dual.assign(tmp.begin(), tmp.begin() + m);
+}
+
+template <typename T>
+void BackendADMM<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w) {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  GetDual(temp1_, x_half_, x_proj_, x_dual_, this->problem_->scaling_right(), (T)-1, n);
+  temp1_.copy_to(dual_w);
+  GetDual(temp2_, z_half_, z_proj_, z_dual_, this->problem_->scaling_left(), (T)1, m);
+  std::vector<T> tmp; temp2_.copy_to(tmp);
+  dual_y.assign(tmp.begin(), tmp.begin() + m);
+  x_half_.copy_to(primal_x);
+  z_half_.copy_to(primal_z);
+}
+
+template <typename T>
+size_t BackendADMM<T>::gpu_mem_amount() const {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  return (4 * (n + m) + std::max(m, n)) * sizeof(T);
+}
+
+template class BackendADMM<float>;
+template class BackendADMM<double>;
+
+}  // namespace prost

@@ -1,0 +1,304 @@
+// backend_pdhg.cpp -- preconditioned PDHG on the MI355X kernels.
+//
+// Iteration structure and every scalar update follow the reference (src/backend/backend_pdhg.cu);
+// what differs is where the vector work happens:
+//   fused path   : prost_hip_fused_primal + prost_hip_fused_dual, state = {x, x_prev, y, y_prev}
+//   generic path : the reference's sequence (prox arg, prox, K, dual arg, prox, K^T) on the
+//                  generic kernels, state = the reference's nine vectors
+// Residual sums are produced on the device into res_dev_[0..3]; on residual iterations they are
+// (optionally all-reduced over RCCL and) copied to pinned host memory, which is the only host
+// synchronisation of the loop (the reference synchronises after every prox and twice per
+// residual iteration).
+#include <algorithm>
+#include <cmath>
+#include <iostream>
+
+#include "hipapi.hpp"
+#include "prost/backend/backend_pdhg.hpp"
+#include "prost/prox/proxes.hpp"
+
+namespace prost {
+
+template <typename T>
+BackendPDHG<T>::~BackendPDHG() { Release(); }
+
+template <typename T>
+std::string BackendPDHG<T>::path() const {
+  if (!fused_) return "pdhg:generic";
+  return desc_.is3d ? "pdhg:fused-grad3d" : "pdhg:fused-grad2d";
+}
+
+template <typename T>
+static bool uniform(const std::vector<T>& v, T& value) {
+  if (v.empty()) return false;
+  value = v[0];
+  for (const T& e : v) if (e != value) return false;
+  return true;
+}
+
+/// fused path applies iff: one gradient2d/3d block (not label_first) spanning the whole operator,
+/// one elem_operation:1d prox_g over all primal entries, one elem_operation:norm2 prox_f* whose
+/// groups are the planar gradient components of a pixel, uniform Sigma and Tau.
+template <typename T>
+bool BackendPDHG<T>::TryFused() {
+  if (!opts_.allow_fused) return false;
+  auto& prob = *this->problem_;
+  auto linop = prob.linop();
+  if (linop->blocks().size() != 1 || prox_g_.size() != 1 || prox_fstar_.size() != 1) return false;
+  BlockDesc bd;
+  auto blk = linop->blocks()[0];
+  if (!blk->describe(bd) || bd.label_first) return false;
+  if (blk->row() != 0 || blk->col() != 0 || blk->nrows() != prob.nrows() || blk->ncols() != prob.ncols()) return false;
+  ProxDesc pg, pf;
+  if (!prox_g_[0]->describe(pg) || !prox_fstar_[0]->describe(pf)) return false;
+  if (pg.kind != ProxDesc::kElem1D || pf.kind != ProxDesc::kElemNorm2 || pf.interleaved) return false;
+  if (prox_g_[0]->index() != 0 || prox_g_[0]->size() != prob.ncols()) return false;
+  if (prox_fstar_[0]->index() != 0 || prox_fstar_[0]->size() != prob.nrows()) return false;
+  const bool d3 = bd.kind == BlockDesc::kGradient3D;
+  const size_t pixels = d3 ? bd.nx * bd.ny * bd.L : bd.nx * bd.ny;
+  const size_t comps = d3 ? 3 : 2 * bd.L;
+  if (pf.count != pixels || pf.dim != comps) return false;
+  T tv, sv;
+  if (!uniform(prob.scaling_right_host(), tv) || !uniform(prob.scaling_left_host(), sv)) return false;
+  desc_.is3d = d3 ? 1 : 0; desc_.nx = bd.nx; desc_.ny = bd.ny; desc_.L = bd.L;
+  desc_.g_fn = pg.fn; desc_.f_fn = pf.fn;
+  for (int i = 0; i < 7; i++) {
+    desc_.g_coeff_ptr[i] = pg.coeff_ptr[i]; desc_.g_coeff_val[i] = pg.coeff_val[i];
+    desc_.f_coeff_ptr[i] = pf.coeff_ptr[i]; desc_.f_coeff_val[i] = pf.coeff_val[i];
+  }
+  desc_.T_val = (double)tv; desc_.S_val = (double)sv;
+  return prost_hip_fused_supported(&desc_, dtype_id<T>()) == 1;
+}
+
+template <typename T>
+void BackendPDHG<T>::Initialize() {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols(), l = std::max(m, n);
+
+  iteration_ = 0;
+  tau_ = (T)opts_.tau0;
+  sigma_ = (T)opts_.sigma0;
+  theta_ = 1;
+  arb_l_ = arb_u_ = 0;
+  arg_alpha_ = opts_.arg_alpha0;
+
+  // missing prox_g / prox_f* are derived from the conjugates by Moreau (backend_pdhg.cu:236-266)
+  prox_g_.clear(); prox_fstar_.clear();
+  if (this->problem_->prox_g().empty()) {
+    if (this->problem_->prox_gstar().empty()) throw Exception("Neither prox_g nor prox_gstar specified.");
+    for (auto& p : this->problem_->prox_gstar()) { auto mo = std::make_shared<ProxMoreau<T>>(p); mo->Initialize(); prox_g_.push_back(mo); }
+  } else prox_g_ = this->problem_->prox_g();
+  if (this->problem_->prox_fstar().empty()) {
+    if (this->problem_->prox_f().empty()) throw Exception("Neither prox_f nor prox_fstar specified.");
+    for (auto& p : this->problem_->prox_f()) { auto mo = std::make_shared<ProxMoreau<T>>(p); mo->Initialize(); prox_fstar_.push_back(mo); }
+  } else prox_fstar_ = this->problem_->prox_fstar();
+
+  fused_ = TryFused();
+
+  x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
+  if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
+
+  CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
+  CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
+  CheckHip(prost_hip_host_alloc((void**)&res_host_, 4 * sizeof(double)), "host_alloc");
+  CheckHip(prost_hip_malloc(&workspace_, prost_hip_reduce_workspace_bytes()), "malloc");
+
+  this->primal_var_norm_ = this->dual_var_norm_ = this->primal_residual_ = this->dual_residual_ = 0;
+
+  if (opts_.scale_steps_operator) {                        // backend_pdhg.cu:274-286
+    T norm = this->problem_->normest();
+    if (std::abs(norm - 1) > 0.1) {
+      tau_ /= norm;
+      sigma_ /= norm;
+      if (this->solver_opts_.verbose)
+        std::cout << "|K|=" << norm << " => Rescaled tau=" << tau_ << ", sigma=" << sigma_ << "." << std::endl;
+    }
+  }
+  if (this->solver_opts_.x0.size() > 0) {
+    if (this->solver_opts_.x0.size() != n) throw Exception("Initial primal solution has wrong size.");
+    x_ = this->solver_opts_.x0; x_prev_ = this->solver_opts_.x0;
+  }
+  if (this->solver_opts_.y0.size() > 0) {
+    if (this->solver_opts_.y0.size() != m) throw Exception("Initial dual solution has wrong size.");
+    y_ = this->solver_opts_.y0; y_prev_ = this->solver_opts_.y0;
+  }
+}
+
+template <typename T>
+void BackendPDHG<T>::Release() {
+  if (res_dev_) { prost_hip_free(res_dev_); res_dev_ = nullptr; }
+  if (res_host_) { prost_hip_host_free(res_host_); res_host_ = nullptr; }
+  if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
+  for (void* e : ev_) prost_hip_event_destroy(e);
+  ev_.clear(); ev_used_ = 0;
+  x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
+}
+
+template <typename T>
+void BackendPDHG<T>::PerformIteration() {
+  const bool residual_iteration = (iteration_ == 0) || (iteration_ % (size_t)opts_.residual_iter) == 0;   // backend_pdhg.cu:389
+  if (fused_) IterationFused(residual_iteration); else IterationGeneric(residual_iteration);
+}
+
+/// two kernels: x_ / y_ ping-pong with x_prev_ / y_prev_
+template <typename T>
+void BackendPDHG<T>::IterationFused(bool res) {
+  void* s = CurrentStream();
+  auto stamp = [&]() {
+    if (!this->time_kernels_) return;
+    if (ev_used_ == ev_.size()) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
+    CheckHip(prost_hip_event_record(ev_[ev_used_++], s), "event_record");
+  };
+  // at entry: x_ = x^k, y_ = y^k, y_prev_ = y^(k-1).  The reference's kty_ is K^T y^k except at
+  // k = 0 (zero vector, :213); kty_prev_ is K^T y^(k-1) except at k <= 1 (zero vector).
+  stamp();
+  CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
+                                iteration_ >= 2 ? 1 : 0, res ? res_dev_ + 2 : nullptr, workspace_, s), "fused_primal");
+  stamp();
+  x_.swap(x_prev_);                        // x_ = x^(k+1), x_prev_ = x^k       (:334)
+  // kx_prev_ of the reference is K x^k except at k = 0 (zero vector, :216)
+  CheckHip(Api<T>::fused_dual(&desc_, y_prev_.data(), y_.data(), x_.data(), x_prev_.data(), (double)sigma_, (double)theta_,
+                              iteration_ >= 1 ? 1 : 0, res ? res_dev_ : nullptr, workspace_, s), "fused_dual");
+  stamp();
+  y_.swap(y_prev_);                        // y_ = y^(k+1), y_prev_ = y^k       (:366)
+  if (res) FinishResiduals();
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  iteration_++;
+}
+
+template <typename T>
+void BackendPDHG<T>::IterationGeneric(bool res) {
+  void* s = CurrentStream();
+  const size_t n = this->problem_->ncols(), m = this->problem_->nrows();
+  const device_vector<T>& Tr = this->problem_->scaling_right();
+  const device_vector<T>& Sl = this->problem_->scaling_left();
+  CheckHip(Api<T>::pdhg_primal_arg(temp_.data(), x_.data(), Tr.data(), kty_.data(), (double)tau_, n, s), "primal_arg");   // :317-331
+  x_.swap(x_prev_);
+  for (auto& p : prox_g_) p->Eval(x_, temp_, Tr, tau_);
+  kx_.swap(kx_prev_);
+  this->problem_->linop()->Eval(kx_, x_);
+  CheckHip(Api<T>::pdhg_dual_arg(temp_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "dual_arg");   // :349-364
+  y_.swap(y_prev_);
+  for (auto& p : prox_fstar_) p->Eval(y_, temp_, Sl, sigma_);
+  if (res) {                                                                                                   // :392-431
+    CheckHip(Api<T>::pdhg_residual_primal(res_dev_, y_prev_.data(), y_.data(), Sl.data(), kx_prev_.data(), kx_.data(), (double)sigma_, (double)theta_, m, workspace_, s), "residual_primal");
+    CheckHip(Api<T>::pdhg_residual_dual(res_dev_ + 2, x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), kty_.data(), (double)tau_, n, workspace_, s), "residual_dual");
+    FinishResiduals();
+  }
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  iteration_++;
+  kty_.swap(kty_prev_);
+  this->problem_->linop()->EvalAdjoint(kty_, y_);                                                              // :377-380
+}
+
+template <typename T>
+void BackendPDHG<T>::FinishResiduals() {
+  void* s = CurrentStream();
+  if (this->comm_) CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
+  CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), s), "memcpy_d2h");
+  CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");
+  CheckHip(prost_hip_check_last_error(), "PDHG iteration");
+  // the reference reduces in T and takes std::sqrt of the T sums (:433-436)
+  this->primal_residual_ = std::sqrt((T)res_host_[0]);
+  this->primal_var_norm_ = std::sqrt((T)res_host_[1]);
+  this->dual_residual_ = std::sqrt((T)res_host_[2]);
+  this->dual_var_norm_ = std::sqrt((T)res_host_[3]);
+
+  const T eps_primal = this->eps_primal(), eps_dual = this->eps_dual();
+  switch (opts_.stepsize_variant) {
+    case kPDHGStepsResidualGoldstein: {                       // :443-460 (both branches may fire)
+      const T scale = eps_dual / eps_primal;
+      if (this->dual_residual_ > (scale * this->primal_residual_ * opts_.arg_delta)) {
+        tau_ = tau_ / (1 - arg_alpha_);
+        sigma_ = sigma_ * (1 - arg_alpha_);
+        arg_alpha_ = arg_alpha_ * opts_.arg_nu;
+      }
+      if (this->dual_residual_ < (scale * this->primal_residual_ / opts_.arg_delta)) {
+        tau_ = tau_ * (1 - arg_alpha_);
+        sigma_ = sigma_ / (1 - arg_alpha_);
+        arg_alpha_ = arg_alpha_ * opts_.arg_nu;
+      }
+    } break;
+    case kPDHGStepsResidualBoyd:                              // :462-476
+      if ((this->dual_residual_ < eps_dual) && (opts_.arb_tau * iteration_ > arb_l_)) {
+        tau_ /= opts_.arb_delta;
+        sigma_ *= opts_.arb_delta;
+        arb_u_ = (int)iteration_;
+      } else if ((this->primal_residual_ < eps_primal) && (opts_.arb_tau * iteration_ > arb_u_)) {
+        tau_ *= opts_.arb_delta;
+        sigma_ /= opts_.arb_delta;
+        arb_l_ = (int)iteration_;
+      }
+      break;
+    default: break;
+  }
+}
+
+template <typename T>
+void BackendPDHG<T>::UpdateAlg2() {                           // :483-488, computed in double
+  theta_ = (T)(1. / std::sqrt(1. + 2. * (double)opts_.alg2_gamma * (double)tau_));
+  tau_ = theta_ * tau_;
+  sigma_ = sigma_ / theta_;
+}
+
+template <typename T>
+void BackendPDHG<T>::current_solution(std::vector<T>& primal, std::vector<T>& dual) {
+  x_.copy_to(primal);
+  y_.copy_to(dual);
+}
+
+template <typename T>
+void BackendPDHG<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w) {
+  void* s = CurrentStream();
+  const size_t n = this->problem_->ncols(), m = this->problem_->nrows();
+  x_.copy_to(primal_x);
+  y_.copy_to(dual_y);
+  const device_vector<T>& Tr = this->problem_->scaling_right();
+  const device_vector<T>& Sl = this->problem_->scaling_left();
+  device_vector<T> scratch(std::max(n, m));
+  if (fused_) {
+    // rebuild the operator products the generic path keeps resident (callback iterations only)
+    device_vector<T> ktyp(n), kx(m), kxp(m);
+    if (iteration_ >= 2) this->problem_->linop()->EvalAdjoint(ktyp, y_prev_);      // kty_prev_ = K^T y^(k): zero vector until k = 2
+    this->problem_->linop()->Eval(kx, x_);
+    if (iteration_ >= 2) this->problem_->linop()->Eval(kxp, x_prev_);              // kx_prev_ is the zero vector after the first iteration
+    CheckHip(Api<T>::pdhg_w_variable(scratch.data(), x_prev_.data(), x_.data(), Tr.data(), ktyp.data(), (double)tau_, n, s), "w_variable");
+    scratch.copy_to(primal_z); dual_w.assign(primal_z.begin(), primal_z.begin() + n);
+    CheckHip(Api<T>::pdhg_z_variable(scratch.data(), y_prev_.data(), y_.data(), Sl.data(), kx.data(), kxp.data(), (double)sigma_, (double)theta_, m, s), "z_variable");
+    scratch.copy_to(primal_z); primal_z.resize(m);
+  } else {
+    CheckHip(Api<T>::pdhg_w_variable(scratch.data(), x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), (double)tau_, n, s), "w_variable");   // :147-160
+    scratch.copy_to(primal_z); dual_w.assign(primal_z.begin(), primal_z.begin() + n);
+    CheckHip(Api<T>::pdhg_z_variable(scratch.data(), y_prev_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "z_variable");   // :169-186
+    scratch.copy_to(primal_z); primal_z.resize(m);
+  }
+}
+
+template <typename T>
+size_t BackendPDHG<T>::gpu_mem_amount() const {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  if (fused_) return 2 * (n + m) * sizeof(T);
+  return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511
+}
+
+template <typename T>
+bool BackendPDHG<T>::KernelTimes(double* primal_ms, double* dual_ms, size_t* launches) {
+  if (ev_used_ < 3) return false;
+  CheckHip(prost_hip_event_synchronize(ev_[ev_used_ - 1]), "event_synchronize");
+  double p = 0, d = 0;
+  size_t k = 0;
+  for (size_t i = 0; i + 2 < ev_used_; i += 3, k++) {      // 3 stamps per iteration: | primal | dual |
+    float a = 0, b = 0;
+    CheckHip(prost_hip_event_elapsed_ms(ev_[i], ev_[i + 1], &a), "event_elapsed");
+    CheckHip(prost_hip_event_elapsed_ms(ev_[i + 1], ev_[i + 2], &b), "event_elapsed");
+    p += a; d += b;
+  }
+  if (k == 0) return false;
+  *primal_ms = p / k; *dual_ms = d / k; *launches = k;
+  ev_used_ = 0;
+  return true;
+}
+
+template class BackendPDHG<float>;
+template class BackendPDHG<double>;
+
+}  // namespace prost

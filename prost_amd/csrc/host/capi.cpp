@@ -1,0 +1,670 @@
+// capi.cpp -- prost_value tree, factories/registries and the command table of include/prost_c.h
+// (the MEX gateway of the reference, matlab/+prost/private/{prost,factory}.cpp, without mex.h).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+#include "hipapi.hpp"
+#include "prost/factory.hpp"
+
+using namespace prost;
+
+// ------------------------------------------------------------------------------------------
+// prost_value
+// ------------------------------------------------------------------------------------------
+struct prost_value {
+  int kind = PROST_VALUE_EMPTY;
+  size_t rows = 0, cols = 0;
+  std::vector<double> data;             // matrix values / sparse values
+  std::vector<int64_t> ir, jc;          // sparse
+  std::string str;
+  std::vector<prost_value*> cells;
+  std::vector<std::pair<std::string, prost_value*>> fields;
+  prost_interm_cb cb = nullptr;
+  void* cb_user = nullptr;
+  ~prost_value() {
+    for (auto* c : cells) delete c;
+    for (auto& f : fields) delete f.second;
+  }
+};
+
+static thread_local std::string g_error;
+static prost_stop_cb g_stop_cb = nullptr;
+static void* g_stop_user = nullptr;
+
+extern "C" {
+
+prost_value* prost_value_scalar(double v) { return prost_value_matrix(&v, 1, 1); }
+prost_value* prost_value_matrix(const double* data, size_t rows, size_t cols) {
+  prost_value* v = new prost_value; v->kind = PROST_VALUE_MATRIX; v->rows = rows; v->cols = cols;
+  if (data && rows * cols) v->data.assign(data, data + rows * cols); else v->data.assign(rows * cols, 0.0);
+  return v;
+}
+prost_value* prost_value_string(const char* s) { prost_value* v = new prost_value; v->kind = PROST_VALUE_STRING; v->str = s ? s : ""; v->rows = 1; v->cols = v->str.size(); return v; }
+prost_value* prost_value_cell(size_t n) { prost_value* v = new prost_value; v->kind = PROST_VALUE_CELL; v->cells.assign(n, nullptr); v->rows = n; v->cols = n ? 1 : 0; return v; }
+int prost_value_cell_set(prost_value* cell, size_t i, prost_value* v) {
+  if (!cell || cell->kind != PROST_VALUE_CELL || i >= cell->cells.size()) return 1;
+  delete cell->cells[i]; cell->cells[i] = v; return 0;
+}
+prost_value* prost_value_struct(void) { prost_value* v = new prost_value; v->kind = PROST_VALUE_STRUCT; v->rows = v->cols = 1; return v; }
+int prost_value_struct_set(prost_value* s, const char* name, prost_value* v) {
+  if (!s || s->kind != PROST_VALUE_STRUCT) return 1;
+  for (auto& f : s->fields) if (f.first == name) { delete f.second; f.second = v; return 0; }
+  s->fields.emplace_back(name, v); return 0;
+}
+prost_value* prost_value_sparse(size_t rows, size_t cols, size_t nnz, const double* val, const int64_t* ir, const int64_t* jc) {
+  prost_value* v = new prost_value; v->kind = PROST_VALUE_SPARSE; v->rows = rows; v->cols = cols;
+  v->data.assign(val, val + nnz); v->ir.assign(ir, ir + nnz); v->jc.assign(jc, jc + cols + 1);
+  return v;
+}
+prost_value* prost_value_callback(prost_interm_cb fn, void* user) { prost_value* v = new prost_value; v->kind = PROST_VALUE_CALLBACK; v->cb = fn; v->cb_user = user; return v; }
+void prost_value_free(prost_value* v) { delete v; }
+
+int prost_value_kind(const prost_value* v) { return v ? v->kind : PROST_VALUE_EMPTY; }
+size_t prost_value_rows(const prost_value* v) { return v ? v->rows : 0; }
+size_t prost_value_cols(const prost_value* v) { return v ? v->cols : 0; }
+const double* prost_value_data(const prost_value* v) { return v ? v->data.data() : nullptr; }
+const char* prost_value_str(const prost_value* v) { return v ? v->str.c_str() : ""; }
+size_t prost_value_count(const prost_value* v) { return v ? v->cells.size() : 0; }
+const prost_value* prost_value_cell_get(const prost_value* v, size_t i) { return (v && i < v->cells.size()) ? v->cells[i] : nullptr; }
+const prost_value* prost_value_field(const prost_value* v, const char* name) {
+  if (!v || v->kind != PROST_VALUE_STRUCT) return nullptr;
+  for (auto& f : v->fields) if (f.first == name) return f.second;
+  return nullptr;
+}
+const char* prost_last_error(void) { return g_error.c_str(); }
+void prost_set_stop_callback(prost_stop_cb fn, void* user) { g_stop_cb = fn; g_stop_user = user; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// description helpers (factory.cpp:161-283)
+// ------------------------------------------------------------------------------------------
+namespace prost {
+
+std::vector<double> GetVector(const prost_value* v) {
+  if (!v || v->kind != PROST_VALUE_MATRIX) throw Exception("Argument has to be passed as a vector of type single or double.");
+  if (v->cols != 1 && v->rows != 1) throw Exception("Vector has to be Nx1 or 1xN.");
+  if (v->rows == 0 || v->cols == 0) throw Exception("Empty vector passed.");
+  return v->data;
+}
+static double scalar_of(const prost_value* v) {
+  if (!v || v->kind != PROST_VALUE_MATRIX || v->data.empty()) throw Exception("Scalar expected.");
+  return v->data[0];
+}
+double GetScalarFromCell(const prost_value* cell, size_t index) {
+  if (!cell || cell->kind != PROST_VALUE_CELL || index >= cell->cells.size()) throw Exception("Out-of-bounds access into cell-array.");
+  return scalar_of(cell->cells[index]);
+}
+double GetScalarFromField(const prost_value* s, const std::string& name) {
+  const prost_value* f = prost_value_field(s, name.c_str());
+  if (!f) { std::stringstream ss; ss << "Field with name '" << name << "' not found."; throw Exception(ss.str()); }
+  return scalar_of(f);
+}
+std::string GetString(const prost_value* v) {
+  if (!v || v->kind != PROST_VALUE_STRING) throw Exception("String expected.");
+  return v->str;
+}
+static const prost_value* cell_at(const prost_value* c, size_t i) {
+  if (!c || c->kind != PROST_VALUE_CELL || i >= c->cells.size() || !c->cells[i]) throw Exception("Out-of-bounds access into cell-array.");
+  return c->cells[i];
+}
+static std::vector<const prost_value*> cell_list(const prost_value* c) {
+  std::vector<const prost_value*> out;
+  if (!c) throw Exception("Tried to run GetCellArray on non-existing array.");
+  if (c->kind == PROST_VALUE_EMPTY || (c->kind == PROST_VALUE_MATRIX && c->data.empty())) return out;
+  if (c->kind != PROST_VALUE_CELL) throw Exception("Cell array expected.");
+  for (auto* e : c->cells) out.push_back(e);
+  return out;
+}
+
+static const char* kFunctionNames[PROST_FN_COUNT] = {"zero", "abs", "square", "ind_leq0", "ind_geq0", "ind_eq0", "ind_box01",
+                                                     "max_pos0", "l0", "huber", "lq", "lq_plus_eps", "trunclin", "truncquad"};
+
+template <typename T>
+static void get_coefficients(std::array<std::vector<T>, 7>& coeffs, const prost_value* cell_arr, size_t count) {
+  if (!cell_arr || cell_arr->kind != PROST_VALUE_CELL || cell_arr->cells.size() < 7) throw Exception("Cell array of coefficients is too small.");
+  for (size_t i = 0; i < 7; i++) {
+    std::vector<double> v = GetVector(cell_arr->cells[i]);
+    coeffs[i] = std::vector<T>(v.begin(), v.end());
+    if (coeffs[i].size() != 1 && coeffs[i].size() != count) throw Exception("Size of coefficients should be either 1 or count.");
+  }
+}
+
+template <typename T>
+static Prox<T>* make_elem(int op, int fn, size_t idx, size_t size, bool diagsteps, const prost_value* data) {
+  const size_t count = (size_t)GetScalarFromCell(data, 0), dim = (size_t)GetScalarFromCell(data, 1);
+  const bool interleaved = GetScalarFromCell(data, 2) > 0.;
+  std::array<std::vector<T>, 7> coeffs;
+  get_coefficients<T>(coeffs, cell_at(data, 3), op == PROST_OP_1D ? size : count);     // factory.cpp:326-327 / :341-342
+  return new ProxElemOperation<T>(op, fn, idx, count, dim, interleaved, diagsteps, coeffs);
+}
+
+template <typename T>
+std::map<std::string, typename Factory<T>::ProxFactory>& Factory<T>::prox_reg() {
+  static std::map<std::string, ProxFactory> reg;
+  static bool init = false;
+  if (!init) {
+    init = true;
+    for (int fn = 0; fn < PROST_FN_COUNT; fn++) {
+      reg[std::string("elem_operation:1d:") + kFunctionNames[fn]] = [fn](size_t idx, size_t size, bool ds, const prost_value* d) { return make_elem<T>(PROST_OP_1D, fn, idx, size, ds, d); };
+      reg[std::string("elem_operation:norm2:") + kFunctionNames[fn]] = [fn](size_t idx, size_t size, bool ds, const prost_value* d) { return make_elem<T>(PROST_OP_NORM2, fn, idx, size, ds, d); };
+    }
+    reg["moreau"] = [](size_t, size_t, bool, const prost_value* d) -> Prox<T>* { return new ProxMoreau<T>(Factory<T>::CreateProx(cell_at(d, 0))); };
+    reg["zero"] = [](size_t idx, size_t size, bool, const prost_value*) -> Prox<T>* { return new ProxZero<T>(idx, size); };
+    reg["ind_epi_quad"] = [](size_t idx, size_t, bool ds, const prost_value* d) -> Prox<T>* {
+      const size_t count = (size_t)GetScalarFromCell(d, 0), dim = (size_t)GetScalarFromCell(d, 1);
+      const bool interleaved = GetScalarFromCell(d, 2) > 0.;
+      const prost_value* co = cell_at(d, 3);
+      std::vector<double> a = GetVector(cell_at(co, 0)), b = GetVector(cell_at(co, 1)), c = GetVector(cell_at(co, 2));
+      return new ProxIndEpiQuad<T>(idx, count, dim, interleaved, ds, std::vector<T>(a.begin(), a.end()), std::vector<T>(b.begin(), b.end()), std::vector<T>(c.begin(), c.end()));
+    };
+  }
+  return reg;
+}
+
+template <typename T>
+std::map<std::string, typename Factory<T>::BlockFactory>& Factory<T>::block_reg() {
+  static std::map<std::string, BlockFactory> reg;
+  static bool init = false;
+  if (!init) {
+    init = true;
+    reg["gradient2d"] = [](size_t row, size_t col, const prost_value* d) -> Block<T>* {
+      return new BlockGradient2D<T>(row, col, (size_t)GetScalarFromCell(d, 0), (size_t)GetScalarFromCell(d, 1), (size_t)GetScalarFromCell(d, 2), GetScalarFromCell(d, 3) > 0.);
+    };
+    reg["gradient3d"] = [](size_t row, size_t col, const prost_value* d) -> Block<T>* {
+      return new BlockGradient3D<T>(row, col, (size_t)GetScalarFromCell(d, 0), (size_t)GetScalarFromCell(d, 1), (size_t)GetScalarFromCell(d, 2), GetScalarFromCell(d, 3) > 0.);
+    };
+    reg["zero"] = [](size_t row, size_t col, const prost_value* d) -> Block<T>* {
+      return new BlockZero<T>(row, col, (size_t)GetScalarFromCell(d, 0), (size_t)GetScalarFromCell(d, 1));
+    };
+    reg["diags"] = [](size_t row, size_t col, const prost_value* d) -> Block<T>* {            // factory.cpp:573-588
+      const size_t nrows = (size_t)GetScalarFromCell(d, 0), ncols = (size_t)GetScalarFromCell(d, 1);
+      std::vector<double> f = GetVector(cell_at(d, 2)), o = GetVector(cell_at(d, 3));
+      if (f.size() != o.size()) throw Exception("Mismatch of size(factors) and size(offsets).");
+      std::vector<int64_t> ofs(o.size());
+      for (size_t i = 0; i < o.size(); i++) ofs[i] = (int64_t)o[i];
+      return new BlockDiags<T>(row, col, nrows, ncols, f.size(), ofs, std::vector<T>(f.begin(), f.end()));
+    };
+    reg["sparse"] = [](size_t row, size_t col, const prost_value* d) -> Block<T>* {           // factory.cpp:625-655
+      const prost_value* pm = cell_at(d, 0);
+      if (pm->kind != PROST_VALUE_SPARSE) throw Exception("Matrix must be sparse!");
+      const int nrows = (int)pm->rows, ncols = (int)pm->cols, nnz = (int)pm->jc[ncols];
+      std::vector<T> val(pm->data.begin(), pm->data.begin() + nnz);
+      std::vector<int32_t> ptr(pm->jc.begin(), pm->jc.end()), ind(pm->ir.begin(), pm->ir.begin() + nnz);   // int64 -> int32 narrowing as the reference
+      return BlockSparse<T>::CreateFromCSC(row, col, nrows, ncols, nnz, val, ptr, ind);
+    };
+  }
+  return reg;
+}
+
+template <typename T>
+std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_reg() {
+  static std::map<std::string, BackendFactory> reg;
+  static bool init = false;
+  if (!init) {
+    init = true;
+    reg["pdhg"] = [](const prost_value* d) -> Backend<T>* {                                   // factory.cpp:766-797
+      typename BackendPDHG<T>::Options o;
+      o.tau0 = GetScalarFromField(d, "tau0"); o.sigma0 = GetScalarFromField(d, "sigma0");
+      o.residual_iter = (int)GetScalarFromField(d, "residual_iter");
+      o.scale_steps_operator = GetScalarFromField(d, "scale_steps_operator") > 0.;
+      o.alg2_gamma = (T)GetScalarFromField(d, "alg2_gamma");
+      o.arg_alpha0 = (T)GetScalarFromField(d, "arg_alpha0"); o.arg_nu = (T)GetScalarFromField(d, "arg_nu");
+      o.arg_delta = (T)GetScalarFromField(d, "arg_delta"); o.arb_delta = (T)GetScalarFromField(d, "arb_delta");
+      o.arb_tau = (T)GetScalarFromField(d, "arb_tau");
+      const std::string sv = GetString(prost_value_field(d, "stepsize"));
+      if (sv == "alg1") o.stepsize_variant = BackendPDHG<T>::kPDHGStepsAlg1;
+      else if (sv == "alg2") o.stepsize_variant = BackendPDHG<T>::kPDHGStepsAlg2;
+      else if (sv == "goldstein") o.stepsize_variant = BackendPDHG<T>::kPDHGStepsResidualGoldstein;
+      else if (sv == "boyd") o.stepsize_variant = BackendPDHG<T>::kPDHGStepsResidualBoyd;
+      else throw Exception("Couldn't recognize step-size variant. Valid options are {alg1,alg2,goldstein,boyd}.");
+      if (prost_value_field(d, "allow_fused")) o.allow_fused = GetScalarFromField(d, "allow_fused") > 0.;
+      return new BackendPDHG<T>(o);
+    };
+    reg["admm"] = [](const prost_value* d) -> Backend<T>* {                                   // factory.cpp:799-818
+      typename BackendADMM<T>::Options o;
+      o.rho0 = GetScalarFromField(d, "rho0"); o.residual_iter = (int)GetScalarFromField(d, "residual_iter");
+      o.arb_delta = (T)GetScalarFromField(d, "arb_delta"); o.arb_gamma = (T)GetScalarFromField(d, "arb_gamma");
+      o.arb_tau = (T)GetScalarFromField(d, "arb_tau"); o.alpha = GetScalarFromField(d, "alpha");
+      o.cg_max_iter = (int)GetScalarFromField(d, "cg_max_iter"); o.cg_tol_pow = GetScalarFromField(d, "cg_tol_pow");
+      o.cg_tol_min = GetScalarFromField(d, "cg_tol_min"); o.cg_tol_max = GetScalarFromField(d, "cg_tol_max");
+      return new BackendADMM<T>(o);
+    };
+  }
+  return reg;
+}
+
+template <class Reg>
+static std::string names_of(const Reg& reg) {
+  std::ostringstream ss;
+  bool first = true;
+  for (auto& e : reg) { if (!first) ss << ", "; ss << e.first; first = false; }
+  return ss.str();
+}
+
+template <typename T>
+shared_ptr<Prox<T>> Factory<T>::CreateProx(const prost_value* pm) {
+  if (!pm || pm->kind != PROST_VALUE_CELL || pm->cells.size() != 5) {
+    std::stringstream ss; ss << "Invalid prox description. Dim = " << (pm ? pm->cells.size() : 0) << " (should be 5).";
+    throw Exception(ss.str());
+  }
+  const std::string name = GetString(cell_at(pm, 0));
+  const size_t idx = (size_t)GetScalarFromCell(pm, 1), size = (size_t)GetScalarFromCell(pm, 2);
+  const bool diagsteps = GetScalarFromCell(pm, 3) > 0.;
+  const prost_value* data = pm->cells[4];
+  Prox<T>* prox = nullptr;
+  auto it = prox_reg().find(name);
+  if (it != prox_reg().end()) {
+    try { prox = it->second(idx, size, diagsteps, data); }
+    catch (Exception& e) { throw Exception("Creating prox with ID '" + name + "' failed. Reason: " + e.what()); }
+  }
+  if (!prox) throw Exception("Creating prox with ID '" + name + "' failed. Reason: Name not registered in ProxFactory. Available prox are: { " + names_of(prox_reg()) + " }.\n");
+  return shared_ptr<Prox<T>>(prox);
+}
+
+template <typename T>
+shared_ptr<Block<T>> Factory<T>::CreateBlock(const prost_value* pm) {
+  if (!pm || pm->kind != PROST_VALUE_CELL || pm->cells.size() != 4) throw Exception("Invalid block description. Dim != 4.");
+  const std::string name = GetString(cell_at(pm, 0));
+  const size_t row = (size_t)GetScalarFromCell(pm, 1), col = (size_t)GetScalarFromCell(pm, 2);
+  Block<T>* block = nullptr;
+  auto it = block_reg().find(name);
+  if (it != block_reg().end()) {
+    try { block = it->second(row, col, pm->cells[3]); }
+    catch (Exception& e) { throw Exception("Creating block with ID '" + name + "' failed. Reason: " + e.what()); }
+  }
+  if (!block) throw Exception("Creating block with ID '" + name + "' failed. Reason: Name not registered in BlockFactory. Available blocks are: { " + names_of(block_reg()) + " }.\n");
+  return shared_ptr<Block<T>>(block);
+}
+
+template <typename T>
+shared_ptr<Backend<T>> Factory<T>::CreateBackend(const prost_value* pm) {
+  std::string name = GetString(cell_at(pm, 0));
+  std::transform(name.begin(), name.end(), name.begin(), ::tolower);
+  Backend<T>* backend = nullptr;
+  auto it = backend_reg().find(name);
+  if (it != backend_reg().end()) {
+    try { backend = it->second(cell_at(pm, 1)); }
+    catch (Exception& e) { throw Exception("Creating backend with ID '" + name + "' failed. Reason: " + e.what()); }
+  }
+  if (!backend) throw Exception("Creating backend with ID '" + name + "' failed. Reason: Name not registered in BackendFactory. Available backends are: { " + names_of(backend_reg()) + " }.\n");
+  return shared_ptr<Backend<T>>(backend);
+}
+
+template <typename T>
+shared_ptr<Problem<T>> Factory<T>::CreateProblem(const prost_value* pm, size_t nrows, size_t ncols) {
+  shared_ptr<Problem<T>> prob(new Problem<T>);
+  for (auto* b : cell_list(prost_value_field(pm, "linop"))) prob->AddBlock(CreateBlock(b));
+  for (auto* p : cell_list(prost_value_field(pm, "prox_g"))) prob->AddProx_g(CreateProx(p));
+  for (auto* p : cell_list(prost_value_field(pm, "prox_f"))) prob->AddProx_f(CreateProx(p));
+  for (auto* p : cell_list(prost_value_field(pm, "prox_gstar"))) prob->AddProx_gstar(CreateProx(p));
+  for (auto* p : cell_list(prost_value_field(pm, "prox_fstar"))) prob->AddProx_fstar(CreateProx(p));
+  const std::string scaling = GetString(prost_value_field(pm, "scaling"));
+  if (scaling == "alpha") prob->SetScalingAlpha((T)GetScalarFromField(pm, "scaling_alpha"));
+  else if (scaling == "identity") prob->SetScalingIdentity();
+  else if (scaling == "custom") {
+    std::vector<double> l = GetVector(prost_value_field(pm, "scaling_left")), r = GetVector(prost_value_field(pm, "scaling_right"));
+    prob->SetScalingCustom(std::vector<T>(l.begin(), l.end()), std::vector<T>(r.begin(), r.end()));
+  } else throw Exception("Problem scaling variant not recognized. Options are {'alpha', 'identity', 'custom'}.");
+  prob->SetDimensions(nrows, ncols);
+  return prob;
+}
+
+template <typename T>
+typename Solver<T>::Options Factory<T>::CreateSolverOptions(const prost_value* pm) {
+  typename Solver<T>::Options o;
+  o.tol_rel_primal = (T)GetScalarFromField(pm, "tol_rel_primal"); o.tol_rel_dual = (T)GetScalarFromField(pm, "tol_rel_dual");
+  o.tol_abs_primal = (T)GetScalarFromField(pm, "tol_abs_primal"); o.tol_abs_dual = (T)GetScalarFromField(pm, "tol_abs_dual");
+  o.max_iters = (int)GetScalarFromField(pm, "max_iters"); o.num_cback_calls = (int)GetScalarFromField(pm, "num_cback_calls");
+  o.verbose = GetScalarFromField(pm, "verbose") > 0.; o.solve_dual_problem = GetScalarFromField(pm, "solve_dual") > 0.;
+  const prost_value* x0 = prost_value_field(pm, "x0");
+  const prost_value* y0 = prost_value_field(pm, "y0");
+  if (x0 && x0->kind == PROST_VALUE_MATRIX && x0->rows > 0) { auto v = GetVector(x0); o.x0 = std::vector<T>(v.begin(), v.end()); }
+  if (y0 && y0->kind == PROST_VALUE_MATRIX && y0->rows > 0) { auto v = GetVector(y0); o.y0 = std::vector<T>(v.begin(), v.end()); }
+  return o;
+}
+
+template struct Factory<float>;
+template struct Factory<double>;
+
+}  // namespace prost
+
+// ------------------------------------------------------------------------------------------
+// command table
+// ------------------------------------------------------------------------------------------
+namespace {
+
+int g_device = 0;
+bool g_single = false;       // reference default: typedef double real (matlab/+prost/private/config.hpp:7)
+void* g_comm = nullptr;
+int g_comm_world = 1;
+
+#define CMD_ARGS int nlhs, prost_value** plhs, int nrhs, const prost_value* const* prhs
+
+void select_device() {
+  int n = 0;
+  if (prost_hip_device_count(&n) != 0 || n < 1) throw Exception("Invalid HIP device: no MI355X visible (the prost hot path has no CPU fallback).");
+  if (g_device >= n) throw Exception("Invalid HIP device.");
+  CheckHip(prost_hip_set_device(g_device), "set_device");
+}
+
+prost_value* vec_value(const std::vector<double>& v) { return prost_value_matrix(v.data(), v.size(), 1); }
+template <typename T> prost_value* vec_value_t(const std::vector<T>& v) { std::vector<double> d(v.begin(), v.end()); return vec_value(d); }
+
+template <typename T>
+struct SolverHandle {
+  shared_ptr<Problem<T>> problem;
+  shared_ptr<Backend<T>> backend;
+  shared_ptr<Solver<T>> solver;
+};
+struct AnyHandle { bool single; shared_ptr<void> h; };
+std::map<int, AnyHandle> g_handles;
+int g_next_handle = 1;
+
+template <typename T>
+shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrows, size_t ncols, const prost_value* backend,
+                                         const prost_value* opts, bool with_callbacks) {
+  auto h = std::make_shared<SolverHandle<T>>();
+  h->problem = Factory<T>::CreateProblem(problem, nrows, ncols);
+  h->backend = Factory<T>::CreateBackend(backend);
+  typename Solver<T>::Options o = Factory<T>::CreateSolverOptions(opts);
+  if (o.verbose) {
+    std::cout << "prost v" << get_version() << std::endl;
+    char name[256]; int cus = 0; size_t mem = 0;
+    if (prost_hip_device_info(g_device, name, sizeof(name), &cus, &mem) == 0)
+      std::printf("Running on device number %d: %s (%.1f GB, %d CUs), float precision: %d bit.\n", g_device, name,
+                  (double)mem / (1024. * 1024 * 1024), cus, (int)sizeof(T) * 8);
+  }
+  h->solver = std::make_shared<Solver<T>>(h->problem, h->backend);
+  h->solver->SetOptions(o);
+  if (with_callbacks) {
+    const prost_value* cb = prost_value_field(opts, "interm_cb");
+    if (cb && cb->kind == PROST_VALUE_CALLBACK && cb->cb) {
+      prost_interm_cb fn = cb->cb; void* user = cb->cb_user;
+      h->solver->SetIntermCallback([fn, user](int it, const std::vector<T>& x, const std::vector<T>& y) {
+        std::vector<double> dx(x.begin(), x.end()), dy(y.begin(), y.end());
+        return fn(user, it, dx.data(), dx.size(), dy.data(), dy.size()) != 0;
+      });
+    } else {
+      // options.m's default dummy_cb prints a newline and returns false
+      h->solver->SetIntermCallback([o](int, const std::vector<T>&, const std::vector<T>&) { if (o.verbose) std::cout << std::endl; return false; });
+    }
+    h->solver->SetStoppingCallback([]() { return g_stop_cb ? g_stop_cb(g_stop_user) != 0 : false; });
+  }
+  if (g_comm) {
+    // global sizes for eps_primal / eps_dual: sum over ranks
+    double* d = nullptr; double hbuf[2] = {(double)nrows, (double)ncols};
+    CheckHip(prost_hip_malloc((void**)&d, 2 * sizeof(double)), "malloc");
+    CheckHip(prost_hip_memcpy_h2d(d, hbuf, sizeof(hbuf), nullptr), "h2d");
+    CheckHip(prost_hip_allreduce_sum_f64(g_comm, d, 2, nullptr), "allreduce");
+    CheckHip(prost_hip_memcpy_d2h(hbuf, d, sizeof(hbuf), nullptr), "d2h");
+    CheckHip(prost_hip_stream_synchronize(nullptr), "sync");
+    prost_hip_free(d);
+    h->backend->SetCommunicator(g_comm, (size_t)hbuf[0], (size_t)hbuf[1]);
+  }
+  h->solver->Initialize();
+  return h;
+}
+
+template <typename T>
+void solve_problem_t(CMD_ARGS) {
+  select_device();
+  const size_t nrows = (size_t)prhs[1]->data[0], ncols = (size_t)prhs[2]->data[0];
+  auto h = build_solver<T>(prhs[0], nrows, ncols, prhs[3], prhs[4], true);
+  typename Solver<T>::ConvergenceResult r = h->solver->Solve();
+  prost_value* out = prost_value_struct();
+  prost_value_struct_set(out, "x", vec_value_t(h->solver->cur_primal_sol()));
+  prost_value_struct_set(out, "y", vec_value_t(h->solver->cur_dual_sol()));
+  prost_value_struct_set(out, "z", vec_value_t(h->solver->cur_primal_constr_sol()));
+  prost_value_struct_set(out, "w", vec_value_t(h->solver->cur_dual_constr_sol()));
+  const char* msg = r == Solver<T>::kConverged ? "Converged." : (r == Solver<T>::kStoppedMaxIters ? "Reached maximum iterations." : "Stopped by user.");
+  prost_value_struct_set(out, "result", prost_value_string(msg));
+  prost_value_struct_set(out, "iters", prost_value_scalar(h->solver->iterations_done()));
+  prost_value_struct_set(out, "path", prost_value_string(h->backend->path().c_str()));
+  h->solver->Release();
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
+void cmd_solve_problem(CMD_ARGS) {
+  if (nrhs != 5) throw Exception("solve_problem: five inputs (problem, nrows, ncols, backend, opts) required.");
+  if (g_single) solve_problem_t<float>(nlhs, plhs, nrhs, prhs); else solve_problem_t<double>(nlhs, plhs, nrhs, prhs);
+}
+
+template <typename T>
+void eval_linop_t(CMD_ARGS) {
+  select_device();
+  shared_ptr<LinearOperator<T>> linop(new LinearOperator<T>());
+  for (auto* c : cell_list(prhs[0])) linop->AddBlock(Factory<T>::CreateBlock(c));
+  const bool transpose = prhs[2]->data[0] > 0;
+  if (prhs[1]->cols != 1) throw Exception("Right-hand side input to eval_linop should be a n-times-1 vector!");
+  linop->Initialize();
+  const size_t need = transpose ? linop->nrows() : linop->ncols();
+  if (prhs[1]->data.size() < need) throw Exception("Right-hand side input to eval_linop is too short.");
+  std::vector<T> rhs(prhs[1]->data.begin(), prhs[1]->data.begin() + need), res;
+  const double time = transpose ? linop->EvalAdjoint(res, rhs) : linop->Eval(res, rhs);
+  std::vector<double> rowsum(linop->nrows()), colsum(linop->ncols());
+  for (size_t r = 0; r < linop->nrows(); r++) rowsum[r] = linop->row_sum(r, 1);
+  for (size_t c = 0; c < linop->ncols(); c++) colsum[c] = linop->col_sum(c, 1);
+  linop->Release();
+  plhs[0] = vec_value_t(res); plhs[1] = vec_value(rowsum); plhs[2] = vec_value(colsum);
+  if (nlhs >= 4) plhs[3] = prost_value_scalar(time);
+}
+void cmd_eval_linop(CMD_ARGS) {
+  if (nrhs != 3) throw Exception("eval_lin_op: Three inputs required!");
+  if (nlhs < 3) throw Exception("eval_lin_op: At least three outputs (result, rowsum, colsum) required.");
+  if (g_single) eval_linop_t<float>(nlhs, plhs, nrhs, prhs); else eval_linop_t<double>(nlhs, plhs, nrhs, prhs);
+}
+
+template <typename T>
+void eval_prox_t(CMD_ARGS) {
+  select_device();
+  const size_t n = prhs[1]->rows;
+  if (prhs[1]->cols != 1) throw Exception("Input to prox should be a vector!");
+  shared_ptr<Prox<T>> prox = Factory<T>::CreateProx(prhs[0]);
+  prox->Initialize();
+  if (prox->size() != n) {
+    std::stringstream ss; ss << "Size of input argument (" << n << ") doesn't match size of prox (" << prox->size() << ")!\n";
+    throw Exception(ss.str());
+  }
+  if (prhs[3]->data.size() < n) throw Exception("Diagonal step size vector is too short.");
+  std::vector<T> arg(prhs[1]->data.begin(), prhs[1]->data.end()), tau(prhs[3]->data.begin(), prhs[3]->data.begin() + n), res;
+  const double ms = prox->Eval(res, arg, tau, (T)prhs[2]->data[0]);
+  prox->Release();
+  plhs[0] = vec_value_t(res);
+  if (nlhs >= 2) plhs[1] = prost_value_scalar(ms);
+}
+void cmd_eval_prox(CMD_ARGS) {
+  if (nrhs < 4) throw Exception("eval_prox: At least four inputs required.");
+  if (nlhs == 0) throw Exception("One output (result of prox) required.");
+  if (g_single) eval_prox_t<float>(nlhs, plhs, nrhs, prhs); else eval_prox_t<double>(nlhs, plhs, nrhs, prhs);
+}
+
+void cmd_init(CMD_ARGS) { (void)nlhs; (void)plhs; (void)nrhs; (void)prhs; }
+void cmd_release(CMD_ARGS) { (void)nlhs; (void)plhs; (void)nrhs; (void)prhs; g_handles.clear(); }
+void cmd_list_gpus(CMD_ARGS) {
+  (void)nrhs; (void)prhs;
+  int n = 0; prost_hip_device_count(&n);
+  for (int i = 0; i < n; i++) {
+    char name[256]; int cus = 0; size_t mem = 0;
+    CheckHip(prost_hip_device_info(i, name, sizeof(name), &cus, &mem), "device_info");
+    std::printf("Device number %d: %s (%.1f GB, %d CUs).\n", i, name, (double)mem / (1024. * 1024 * 1024), cus);
+  }
+  if (nlhs >= 1) plhs[0] = prost_value_scalar(n);
+}
+void cmd_set_gpu(CMD_ARGS) { (void)nlhs; (void)plhs; if (nrhs < 1) throw Exception("set_gpu: device id required."); g_device = (int)prhs[0]->data[0]; }
+void cmd_set_precision(CMD_ARGS) {
+  (void)nlhs; (void)plhs;
+  if (nrhs < 1) throw Exception("set_precision: 'single' or 'double' required.");
+  const std::string s = GetString(prhs[0]);
+  if (s == "single" || s == "float") g_single = true;
+  else if (s == "double") g_single = false;
+  else throw Exception("set_precision: 'single' or 'double' required.");
+}
+void cmd_get_precision(CMD_ARGS) { (void)nrhs; (void)prhs; if (nlhs >= 1) plhs[0] = prost_value_string(g_single ? "single" : "double"); }
+
+template <typename T>
+prost_value* prox_rows(const typename Problem<T>::ProxList& l) {
+  std::vector<double> d;
+  for (auto& p : l) { d.push_back((double)p->index()); d.push_back((double)p->size()); d.push_back(p->diagsteps() ? 1 : 0); }
+  return prost_value_matrix(d.data(), 3, l.size());
+}
+template <typename T>
+void problem_info_t(CMD_ARGS) {
+  (void)nrhs;
+  auto prob = Factory<T>::CreateProblem(prhs[0], (size_t)prhs[1]->data[0], (size_t)prhs[2]->data[0]);
+  prob->InitializeHost();
+  prost_value* out = prost_value_struct();
+  prost_value_struct_set(out, "scaling_left", vec_value_t(prob->scaling_left_host()));
+  prost_value_struct_set(out, "scaling_right", vec_value_t(prob->scaling_right_host()));
+  prost_value_struct_set(out, "nrows", prost_value_scalar((double)prob->nrows()));
+  prost_value_struct_set(out, "ncols", prost_value_scalar((double)prob->ncols()));
+  prost_value_struct_set(out, "linop_nrows", prost_value_scalar((double)prob->linop()->nrows()));
+  prost_value_struct_set(out, "linop_ncols", prost_value_scalar((double)prob->linop()->ncols()));
+  prost_value_struct_set(out, "prox_g", prox_rows<T>(prob->prox_g()));
+  prost_value_struct_set(out, "prox_f", prox_rows<T>(prob->prox_f()));
+  prost_value_struct_set(out, "prox_gstar", prox_rows<T>(prob->prox_gstar()));
+  prost_value_struct_set(out, "prox_fstar", prox_rows<T>(prob->prox_fstar()));
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
+void cmd_problem_info(CMD_ARGS) {
+  if (nrhs != 3) throw Exception("problem_info: three inputs (problem, nrows, ncols) required.");
+  if (g_single) problem_info_t<float>(nlhs, plhs, nrhs, prhs); else problem_info_t<double>(nlhs, plhs, nrhs, prhs);
+}
+
+void cmd_solver_create(CMD_ARGS) {
+  if (nrhs != 5) throw Exception("solver_create: five inputs (problem, nrows, ncols, backend, opts) required.");
+  select_device();
+  const size_t nrows = (size_t)prhs[1]->data[0], ncols = (size_t)prhs[2]->data[0];
+  AnyHandle a; a.single = g_single;
+  if (g_single) a.h = build_solver<float>(prhs[0], nrows, ncols, prhs[3], prhs[4], false);
+  else a.h = build_solver<double>(prhs[0], nrows, ncols, prhs[3], prhs[4], false);
+  const int id = g_next_handle++;
+  g_handles[id] = a;
+  if (nlhs >= 1) plhs[0] = prost_value_scalar(id);
+}
+AnyHandle& handle_of(const prost_value* v) {
+  auto it = g_handles.find((int)v->data[0]);
+  if (it == g_handles.end()) throw Exception("Unknown solver handle.");
+  return it->second;
+}
+template <typename T>
+void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int nlhs, prost_value** plhs) {
+  h.backend->EnableKernelTiming(time_kernels);
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+  const auto t0 = std::chrono::steady_clock::now();
+  h.solver->Iterate(iters);
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  CheckHip(prost_hip_check_last_error(), "solver_iterate");
+  double p = 0, d = 0; size_t k = 0;
+  const bool have = h.backend->KernelTimes(&p, &d, &k);
+  h.backend->EnableKernelTiming(false);
+  prost_value* out = prost_value_struct();
+  prost_value_struct_set(out, "ms", prost_value_scalar(ms));
+  prost_value_struct_set(out, "primal_kernel_ms", prost_value_scalar(have ? p : 0));
+  prost_value_struct_set(out, "dual_kernel_ms", prost_value_scalar(have ? d : 0));
+  prost_value_struct_set(out, "launches", prost_value_scalar((double)k));
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
+void cmd_solver_iterate(CMD_ARGS) {
+  if (nrhs < 2) throw Exception("solver_iterate: (handle, iters) required.");
+  AnyHandle& a = handle_of(prhs[0]);
+  const int iters = (int)prhs[1]->data[0];
+  const bool tk = nrhs >= 3 && prhs[2]->data[0] > 0;
+  if (a.single) solver_iterate_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), iters, tk, nlhs, plhs);
+  else solver_iterate_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), iters, tk, nlhs, plhs);
+}
+template <typename T>
+void solver_state_t(SolverHandle<T>& h, int nlhs, prost_value** plhs) {
+  h.solver->FetchSolution();
+  prost_value* out = prost_value_struct();
+  prost_value_struct_set(out, "x", vec_value_t(h.solver->cur_primal_sol()));
+  prost_value_struct_set(out, "y", vec_value_t(h.solver->cur_dual_sol()));
+  prost_value_struct_set(out, "z", vec_value_t(h.solver->cur_primal_constr_sol()));
+  prost_value_struct_set(out, "w", vec_value_t(h.solver->cur_dual_constr_sol()));
+  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0;
+  if (auto* p = dynamic_cast<BackendPDHG<T>*>(h.backend.get())) { tau = p->tau(); sigma = p->sigma(); theta = p->theta(); it = (double)p->iteration(); }
+  if (auto* a = dynamic_cast<BackendADMM<T>*>(h.backend.get())) { rho = a->rho(); it = (double)a->iteration(); }
+  const char* names[] = {"tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual"};
+  const double vals[] = {tau, sigma, theta, rho, it, (double)h.backend->primal_residual(), (double)h.backend->dual_residual(),
+                         (double)h.backend->primal_var_norm(), (double)h.backend->dual_var_norm(), (double)h.backend->eps_primal(), (double)h.backend->eps_dual()};
+  for (int i = 0; i < 11; i++) prost_value_struct_set(out, names[i], prost_value_scalar(vals[i]));
+  prost_value_struct_set(out, "path", prost_value_string(h.backend->path().c_str()));
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
+void cmd_solver_state(CMD_ARGS) {
+  if (nrhs < 1) throw Exception("solver_state: handle required.");
+  AnyHandle& a = handle_of(prhs[0]);
+  if (a.single) solver_state_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), nlhs, plhs);
+  else solver_state_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), nlhs, plhs);
+}
+void cmd_solver_destroy(CMD_ARGS) {
+  (void)nlhs; (void)plhs;
+  if (nrhs < 1) throw Exception("solver_destroy: handle required.");
+  AnyHandle& a = handle_of(prhs[0]);
+  if (a.single) std::static_pointer_cast<SolverHandle<float>>(a.h)->solver->Release();
+  else std::static_pointer_cast<SolverHandle<double>>(a.h)->solver->Release();
+  g_handles.erase((int)prhs[0]->data[0]);
+}
+
+void cmd_comm_unique_id(CMD_ARGS) {
+  (void)nrhs; (void)prhs;
+  unsigned char id[128];
+  CheckHip(prost_hip_comm_unique_id(id), "comm_unique_id");
+  std::vector<double> d(id, id + 128);
+  if (nlhs >= 1) plhs[0] = prost_value_matrix(d.data(), 1, 128);
+}
+void cmd_comm_init(CMD_ARGS) {
+  (void)nlhs; (void)plhs;
+  if (nrhs != 3 || prhs[0]->data.size() != 128) throw Exception("comm_init: (id[128], rank, world) required.");
+  select_device();
+  unsigned char id[128];
+  for (int i = 0; i < 128; i++) id[i] = (unsigned char)prhs[0]->data[i];
+  if (g_comm) { prost_hip_comm_destroy(g_comm); g_comm = nullptr; }
+  CheckHip(prost_hip_comm_create(&g_comm, id, (int)prhs[1]->data[0], (int)prhs[2]->data[0]), "comm_create");
+  g_comm_world = (int)prhs[2]->data[0];
+}
+void cmd_comm_destroy(CMD_ARGS) {
+  (void)nlhs; (void)plhs; (void)nrhs; (void)prhs;
+  if (g_comm) { prost_hip_comm_destroy(g_comm); g_comm = nullptr; g_comm_world = 1; }
+}
+void cmd_set_quirks(CMD_ARGS) {
+  (void)nlhs; (void)plhs;
+  if (nrhs < 1) throw Exception("set_quirks: struct required.");
+  if (prost_value_field(prhs[0], "diags_adjoint_grid")) BlockDiags<double>::SetReferenceGridQuirk(GetScalarFromField(prhs[0], "diags_adjoint_grid") > 0);
+  if (prost_value_field(prhs[0], "dual_negate_float")) DualLinearOperator<double>::SetReferenceNegateQuirk(GetScalarFromField(prhs[0], "dual_negate_float") > 0);
+}
+
+typedef void (*cmd_fn)(CMD_ARGS);
+const std::map<std::string, cmd_fn>& cmd_reg() {
+  static const std::map<std::string, cmd_fn> reg = {
+      {"init", cmd_init}, {"release", cmd_release}, {"solve_problem", cmd_solve_problem}, {"eval_linop", cmd_eval_linop},
+      {"eval_prox", cmd_eval_prox}, {"list_gpus", cmd_list_gpus}, {"set_gpu", cmd_set_gpu},
+      {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info},
+      {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_state", cmd_solver_state},
+      {"solver_destroy", cmd_solver_destroy}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
+      {"comm_destroy", cmd_comm_destroy}, {"set_quirks", cmd_set_quirks}};
+  return reg;
+}
+
+}  // namespace
+
+extern "C" int prost_command(const char* cmd, int nlhs, prost_value** plhs, int nrhs, const prost_value* const* prhs) {
+  for (int i = 0; i < nlhs; i++) plhs[i] = nullptr;
+  try {
+    if (!cmd) throw Exception("Usage: prost_(command, arg1, arg2, ...);");
+    auto it = cmd_reg().find(cmd);
+    if (it == cmd_reg().end()) { std::stringstream msg; msg << "Unknown command '" << cmd << "'."; throw Exception(msg.str()); }
+    for (int i = 0; i < nrhs; i++) if (!prhs[i]) throw Exception("Null argument passed to prost_command.");
+    it->second(nlhs, plhs, nrhs, prhs);
+    return 0;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    for (int i = 0; i < nlhs; i++) { if (plhs[i]) { prost_value_free(plhs[i]); plhs[i] = nullptr; } }
+    return 1;
+  }
+}

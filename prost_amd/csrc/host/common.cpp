@@ -1,0 +1,122 @@
+// common.cpp -- device_vector, stream handling and small host helpers of the prost host library.
+#include <cstring>
+
+#include "hipapi.hpp"
+#include "prost/common.hpp"
+#include "prost/device_vector.hpp"
+
+namespace prost {
+
+static thread_local void* g_stream = nullptr;
+void* CurrentStream() { return g_stream; }
+void SetCurrentStream(void* s) { g_stream = s; }
+
+void CheckHip(int rc, const char* what) {
+  if (rc != 0) throw Exception(std::string(what) + " failed: " + prost_hip_last_error());
+}
+
+std::string get_version() { return "prost-mi355x 0.1 (gfx950)"; }
+
+// ---- device_vector ----
+template <typename T> device_vector<T>::~device_vector() { if (data_) prost_hip_free(data_); }
+template <typename T> void device_vector<T>::clear() { if (data_) prost_hip_free(data_); data_ = nullptr; size_ = 0; }
+template <typename T>
+void device_vector<T>::resize(size_t n) {
+  if (n != size_) {
+    clear();
+    if (n) {
+      void* p = nullptr;
+      int rc = prost_hip_malloc(&p, n * sizeof(T));
+      if (rc != 0) throw Exception(std::string("Out of memory: ") + prost_hip_last_error());
+      data_ = static_cast<T*>(p);
+      size_ = n;
+    }
+  }
+  if (n) CheckHip(prost_hip_memset(data_, 0, n * sizeof(T), CurrentStream()), "memset");
+}
+template <typename T>
+void device_vector<T>::resize(size_t n, T fill) {
+  resize(n);
+  if (n && fill != T(0)) { std::vector<T> h(n, fill); *this = h; }
+}
+template <typename T>
+device_vector<T>& device_vector<T>::operator=(const std::vector<T>& host) {
+  if (host.size() != size_) { clear(); if (!host.empty()) { void* p = nullptr; int rc = prost_hip_malloc(&p, host.size() * sizeof(T)); if (rc != 0) throw Exception(std::string("Out of memory: ") + prost_hip_last_error()); data_ = static_cast<T*>(p); size_ = host.size(); } }
+  if (size_) {
+    CheckHip(prost_hip_memcpy_h2d(data_, host.data(), size_ * sizeof(T), CurrentStream()), "memcpy_h2d");
+    CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");   // host vector may be a temporary
+  }
+  return *this;
+}
+template <typename T>
+void device_vector<T>::copy_to(std::vector<T>& host) const {
+  host.resize(size_);
+  if (size_) {
+    CheckHip(prost_hip_memcpy_d2h(host.data(), data_, size_ * sizeof(T), CurrentStream()), "memcpy_d2h");
+    CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
+  }
+}
+template <typename T>
+void device_vector<T>::copy_from(const device_vector& o) {
+  if (o.size_ != size_) resize(o.size_);
+  if (size_) CheckHip(prost_hip_memcpy_d2d(data_, o.data_, size_ * sizeof(T), CurrentStream()), "memcpy_d2d");
+}
+template class device_vector<float>;
+template class device_vector<double>;
+template class device_vector<int32_t>;
+template class device_vector<int64_t>;
+
+// ---- linspace: num values + a trailing `end` (reference src/common.cu:33-46) ----
+template <typename T>
+std::list<double> linspace(T start_in, T end_in, int num_in) {
+  const double start = static_cast<double>(start_in), end = static_cast<double>(end_in), num = static_cast<double>(num_in);
+  const double delta = (end - start) / (num - 1);
+  std::list<double> out;
+  for (int i = 0; i < num; ++i) out.push_back(start + delta * i);
+  out.push_back(end);
+  return out;
+}
+template std::list<double> linspace<double>(double, double, int);
+template std::list<double> linspace<float>(float, float, int);
+template std::list<double> linspace<size_t>(size_t, size_t, int);
+template std::list<double> linspace<int>(int, int, int);
+
+// ---- CSR (n x m) -> CSC by counting sort on the column index (reference src/common.cu:55-82) ----
+template <typename T>
+void csr2csc(int n, int m, int nz, const T* a, const int32_t* col_idx, const int32_t* row_start, T* csc_a,
+             int32_t* row_idx, int32_t* col_start) {
+  std::vector<int32_t> fill(m + 1, 0);
+  for (int i = 0; i < nz; i++) fill[col_idx[i] + 1]++;
+  for (int c = 0; c < m; c++) fill[c + 1] += fill[c];
+  for (int c = 0; c <= m; c++) col_start[c] = fill[c];
+  for (int r = 0; r < n; r++)
+    for (int32_t j = row_start[r]; j < row_start[r + 1]; j++) {
+      const int32_t dst = fill[col_idx[j]]++;
+      row_idx[dst] = r;
+      if (a) csc_a[dst] = a[j];
+    }
+}
+template void csr2csc<float>(int, int, int, const float*, const int32_t*, const int32_t*, float*, int32_t*, int32_t*);
+template void csr2csc<double>(int, int, int, const double*, const int32_t*, const int32_t*, double*, int32_t*, int32_t*);
+
+// ---- glibc rand(): TYPE_3 additive feedback generator r[i] = r[i-3] + r[i-31] ----
+GlibcRand::GlibcRand(unsigned seed) : r_(344) {
+  if (seed == 0) seed = 1;
+  r_[0] = seed;
+  for (int i = 1; i < 31; i++) {
+    const long long prev = (int32_t)r_[i - 1];
+    long long w = 16807 * (prev % 127773) - 2836 * (prev / 127773);
+    if (w < 0) w += 2147483647;
+    r_[i] = (uint32_t)w;
+  }
+  for (int i = 31; i < 34; i++) r_[i] = r_[i - 31];
+  for (int i = 34; i < 344; i++) r_[i] = r_[i - 31] + r_[i - 3];
+}
+int32_t GlibcRand::next() {
+  const uint32_t v = r_[r_.size() - 31] + r_[r_.size() - 3];
+  r_.push_back(v);
+  if (r_.size() > 8192) r_.erase(r_.begin(), r_.begin() + 4096);
+  return (int32_t)(v >> 1);
+}
+
+}  // namespace prost

@@ -1,0 +1,46 @@
+// hipapi.hpp -- maps the host templates on T to the _f32 / _f64 entry points of prost_hip.h.
+#pragma once
+#include "prost_hip.h"
+
+namespace prost {
+
+template <typename T> struct Api;
+
+#define PROST_API_STRUCT(T, S)                                                    \
+  template <> struct Api<T> {                                                     \
+    static constexpr auto grad2d_fwd = prost_hip_grad2d_fwd_##S;                  \
+    static constexpr auto grad2d_adj = prost_hip_grad2d_adj_##S;                  \
+    static constexpr auto grad3d_fwd = prost_hip_grad3d_fwd_##S;                  \
+    static constexpr auto grad3d_adj = prost_hip_grad3d_adj_##S;                  \
+    static constexpr auto diags_fwd = prost_hip_diags_fwd_##S;                    \
+    static constexpr auto diags_adj = prost_hip_diags_adj_##S;                    \
+    static constexpr auto csr_spmv_acc = prost_hip_csr_spmv_acc_##S;              \
+    static constexpr auto scale = prost_hip_scale_##S;                            \
+    static constexpr auto prox_elem = prost_hip_prox_elem_##S;                    \
+    static constexpr auto prox_epi_quad = prost_hip_prox_epi_quad_##S;            \
+    static constexpr auto moreau_prescale = prost_hip_moreau_prescale_##S;        \
+    static constexpr auto moreau_postscale = prost_hip_moreau_postscale_##S;      \
+    static constexpr auto pdhg_primal_arg = prost_hip_pdhg_primal_arg_##S;        \
+    static constexpr auto pdhg_dual_arg = prost_hip_pdhg_dual_arg_##S;            \
+    static constexpr auto pdhg_residual_primal = prost_hip_pdhg_residual_primal_##S; \
+    static constexpr auto pdhg_residual_dual = prost_hip_pdhg_residual_dual_##S;  \
+    static constexpr auto pdhg_w_variable = prost_hip_pdhg_w_variable_##S;        \
+    static constexpr auto pdhg_z_variable = prost_hip_pdhg_z_variable_##S;        \
+    static constexpr auto fused_primal = prost_hip_fused_primal_##S;              \
+    static constexpr auto fused_dual = prost_hip_fused_dual_##S;                  \
+    static constexpr auto nrm2 = prost_hip_nrm2_##S;                              \
+    static constexpr auto axpy = prost_hip_axpy_##S;                              \
+    static constexpr auto admm_elem = prost_hip_admm_elem_##S;                    \
+  };
+
+PROST_API_STRUCT(float, f32)
+PROST_API_STRUCT(double, f64)
+#undef PROST_API_STRUCT
+
+inline int negate(float* x, size_t n, bool, void* s) { return prost_hip_negate_f32(x, n, s); }
+inline int negate(double* x, size_t n, bool via_float, void* s) { return prost_hip_negate_f64(x, n, via_float ? 1 : 0, s); }
+template <typename T> inline int dtype_id();
+template <> inline int dtype_id<float>() { return 0; }
+template <> inline int dtype_id<double>() { return 1; }
+
+}  // namespace prost

@@ -1,0 +1,271 @@
+// linop.cpp -- blocks and the block container of the prost host library (calls prost_hip.h only).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "hipapi.hpp"
+#include "prost/linop/blocks.hpp"
+#include "prost/linop/linearoperator.hpp"
+
+namespace prost {
+
+// ---- Block defaults: non-accumulating = zero fill + accumulate ----
+template <typename T>
+void Block<T>::EvalLocal(T* rb, T* re, const T* xb, const T* xe) {
+  CheckHip(Api<T>::scale(rb, (size_t)(re - rb), 0.0, CurrentStream()), "scale");
+  EvalLocalAdd(rb, re, xb, xe);
+}
+template <typename T>
+void Block<T>::EvalAdjointLocal(T* rb, T* re, const T* xb, const T* xe) {
+  CheckHip(Api<T>::scale(rb, (size_t)(re - rb), 0.0, CurrentStream()), "scale");
+  EvalAdjointLocalAdd(rb, re, xb, xe);
+}
+template class Block<float>;
+template class Block<double>;
+
+// ---- gradient blocks ----
+#define GRAD_IMPL(CLS, FWD, ADJ, CS)                                                                                   \
+  template <typename T> void CLS<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) { CheckHip(Api<T>::FWD(r, x, nx_, ny_, L_, label_first_, 1, CurrentStream()), #FWD); }          \
+  template <typename T> void CLS<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) { CheckHip(Api<T>::ADJ(r, x, nx_, ny_, L_, label_first_, 1, CurrentStream()), #ADJ); }   \
+  template <typename T> void CLS<T>::EvalLocal(T* r, T*, const T* x, const T*) { CheckHip(Api<T>::FWD(r, x, nx_, ny_, L_, label_first_, 0, CurrentStream()), #FWD); }             \
+  template <typename T> void CLS<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) { CheckHip(Api<T>::ADJ(r, x, nx_, ny_, L_, label_first_, 0, CurrentStream()), #ADJ); }      \
+  template <typename T> void CLS<T>::row_sums(T* out, T) const { for (size_t r = 0; r < this->nrows(); r++) out[r] += 2; }    \
+  template <typename T> void CLS<T>::col_sums(T* out, T) const { for (size_t c = 0; c < this->ncols(); c++) out[c] += CS; }   \
+  template class CLS<float>;                                                                                           \
+  template class CLS<double>;
+GRAD_IMPL(BlockGradient2D, grad2d_fwd, grad2d_adj, 4)
+GRAD_IMPL(BlockGradient3D, grad3d_fwd, grad3d_adj, 6)
+#undef GRAD_IMPL
+
+// ---- sparse block ----
+template <typename T>
+BlockSparse<T>* BlockSparse<T>::CreateFromCSC(size_t row, size_t col, int m, int n, int nnz, const std::vector<T>& val,
+                                              const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind) {
+  BlockSparse<T>* b = new BlockSparse<T>(row, col, m, n);
+  b->nnz_ = nnz;
+  // the CSC arrays of K are the CSR arrays of K^T; K itself in CSR comes from one transposition
+  b->host_ind_t_ = ind; b->host_ptr_t_ = ptr; b->host_val_t_ = val;
+  b->host_ind_.resize(nnz); b->host_val_.resize(nnz); b->host_ptr_.resize(m + 1);
+  csr2csc<T>(n, m, nnz, b->host_val_t_.data(), b->host_ind_t_.data(), b->host_ptr_t_.data(), b->host_val_.data(),
+             b->host_ind_.data(), b->host_ptr_.data());
+  return b;
+}
+template <typename T>
+void BlockSparse<T>::Initialize() {
+  ind_ = host_ind_; ptr_ = host_ptr_; val_ = host_val_;
+  ind_t_ = host_ind_t_; ptr_t_ = host_ptr_t_; val_t_ = host_val_t_;
+}
+template <typename T>
+void BlockSparse<T>::Release() { ind_.clear(); ptr_.clear(); val_.clear(); ind_t_.clear(); ptr_t_.clear(); val_t_.clear(); }
+template <typename T>
+T BlockSparse<T>::row_sum(size_t row, T alpha) const {
+  T sum = 0;
+  for (int32_t i = host_ptr_[row]; i < host_ptr_[row + 1]; i++) sum += std::pow(std::abs(host_val_[i]), alpha);
+  return sum;
+}
+template <typename T>
+T BlockSparse<T>::col_sum(size_t col, T alpha) const {
+  T sum = 0;
+  for (int32_t i = host_ptr_t_[col]; i < host_ptr_t_[col + 1]; i++) sum += std::pow(std::abs(host_val_t_[i]), alpha);
+  return sum;
+}
+template <typename T>
+size_t BlockSparse<T>::gpu_mem_amount() const {
+  return 2 * nnz_ * sizeof(int32_t) + (this->nrows() + this->ncols() + 2) * sizeof(int32_t) + 2 * nnz_ * sizeof(T);
+}
+template <typename T>
+void BlockSparse<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) {
+  if (val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  CheckHip(Api<T>::csr_spmv_acc(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv_acc");
+}
+template <typename T>
+void BlockSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
+  if (val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  CheckHip(Api<T>::csr_spmv_acc(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv_acc");
+}
+template class BlockSparse<float>;
+template class BlockSparse<double>;
+
+// ---- diags block ----
+static bool g_diags_quirk = false;
+template <typename T> void BlockDiags<T>::SetReferenceGridQuirk(bool on) { g_diags_quirk = on; }
+template <typename T> bool BlockDiags<T>::ReferenceGridQuirk() { return g_diags_quirk; }
+template <typename T>
+BlockDiags<T>::BlockDiags(size_t row, size_t col, size_t nrows, size_t ncols, size_t ndiags, const std::vector<int64_t>& offsets,
+                          const std::vector<T>& factors)
+    : Block<T>(row, col, nrows, ncols), ndiags_(ndiags), offsets_(offsets) {
+  factors_ = std::vector<float>(factors.begin(), factors.end());
+  // ascending offsets: the kernels stop at the first diagonal that leaves the matrix.  Selection
+  // by pairwise exchange, which is also the order the reference produces for equal offsets
+  // (block_diags.cu:110-118).
+  for (size_t i = 0; i < ndiags_; i++)
+    for (size_t j = i; j < ndiags_; j++)
+      if (offsets_[i] > offsets_[j]) { std::swap(offsets_[i], offsets_[j]); std::swap(factors_[i], factors_[j]); }
+}
+template <typename T>
+void BlockDiags<T>::Initialize() {
+  if (ndiags_ >= 1024) throw Exception("Out of constant memory. Too many BlockDiags or too many diagonals.");
+  d_offsets_ = offsets_;
+  d_factors_ = factors_;
+}
+template <typename T> void BlockDiags<T>::Release() { d_offsets_.clear(); d_factors_.clear(); }
+template <typename T>
+T BlockDiags<T>::row_sum(size_t row, T alpha) const {
+  T sum = 0;
+  for (size_t i = 0; i < ndiags_; i++) {
+    const long long col = (long long)row + offsets_[i];
+    if (col < 0) continue;
+    if ((size_t)col >= this->ncols()) break;
+    sum += std::pow(std::abs(factors_[i]), alpha);
+  }
+  return sum;
+}
+template <typename T>
+T BlockDiags<T>::col_sum(size_t col, T alpha) const {
+  T sum = 0;
+  const long long sc = (long long)col;
+  for (size_t i = 0; i < ndiags_; i++) {
+    const long long o = offsets_[i];
+    if (o <= sc && (sc - o) < (long long)this->nrows() && (sc - o) >= 0) sum += std::pow(std::abs(factors_[i]), alpha);
+    if (o > sc) break;
+  }
+  return sum;
+}
+template <typename T>
+void BlockDiags<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) {
+  if (d_offsets_.size() != ndiags_) throw Exception("BlockDiags used before Initialize().");
+  CheckHip(Api<T>::diags_fwd(r, x, this->nrows(), this->ncols(), ndiags_, d_offsets_.data(), d_factors_.data(), CurrentStream()), "diags_fwd");
+}
+template <typename T>
+void BlockDiags<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
+  if (d_offsets_.size() != ndiags_) throw Exception("BlockDiags used before Initialize().");
+  CheckHip(Api<T>::diags_adj(r, x, this->nrows(), this->ncols(), ndiags_, d_offsets_.data(), d_factors_.data(), g_diags_quirk ? 1 : 0, CurrentStream()), "diags_adj");
+}
+template class BlockDiags<float>;
+template class BlockDiags<double>;
+template class BlockZero<float>;
+template class BlockZero<double>;
+
+// ---- LinearOperator ----
+static bool ranges_partition(std::vector<std::pair<size_t, size_t>> r, size_t total) {
+  std::sort(r.begin(), r.end());
+  size_t pos = 0;
+  for (auto& p : r) { if (p.first != pos) return false; pos = p.first + p.second; }
+  return pos == total;
+}
+
+template <typename T>
+void LinearOperator<T>::InitializeHost() {
+  nrows_ = ncols_ = 0;
+  bool overlap = false;
+  for (size_t i = 0; i < blocks_.size(); i++) {
+    const Block<T>& a = *blocks_[i];
+    nrows_ = std::max(a.row() + a.nrows(), nrows_);
+    ncols_ = std::max(a.col() + a.ncols(), ncols_);
+    for (size_t j = i + 1; j < blocks_.size(); j++) {
+      const Block<T>& b = *blocks_[j];
+      const bool cols_meet = a.col() <= b.col() + b.ncols() - 1 && a.col() + a.ncols() - 1 >= b.col();
+      const bool rows_meet = a.row() <= b.row() + b.nrows() - 1 && a.row() + a.nrows() - 1 >= b.row();
+      overlap |= cols_meet && rows_meet;
+    }
+  }
+  if (overlap) throw Exception("Blocks are overlapping inside the linear operator. Recheck the indices.");
+  std::vector<std::pair<size_t, size_t>> rr, cc;
+  for (auto& b : blocks_) { rr.emplace_back(b->row(), b->nrows()); cc.emplace_back(b->col(), b->ncols()); }
+  rows_exclusive_ = !blocks_.empty() && ranges_partition(rr, nrows_);
+  cols_exclusive_ = !blocks_.empty() && ranges_partition(cc, ncols_);
+}
+template <typename T>
+void LinearOperator<T>::Initialize() {
+  InitializeHost();
+  for (auto& b : blocks_) b->Initialize();
+}
+template <typename T> void LinearOperator<T>::Release() { for (auto& b : blocks_) b->Release(); }
+
+template <typename T>
+void LinearOperator<T>::ApplyBeta(device_vector<T>& result, T beta, bool negate_beta) {
+  if (beta == 0) CheckHip(Api<T>::scale(result.data(), result.size(), 0.0, CurrentStream()), "scale");
+  else if (beta != 1) CheckHip(Api<T>::scale(result.data(), result.size(), negate_beta ? (double)-beta : (double)beta, CurrentStream()), "scale");
+}
+template <typename T>
+void LinearOperator<T>::Eval(device_vector<T>& result, const device_vector<T>& rhs, T beta) {
+  if (beta == 0 && rows_exclusive_ && result.size() == nrows_) {        // every row has exactly one writer: no fill pass
+    for (auto& b : blocks_) b->Eval(result.data(), rhs.data());
+    return;
+  }
+  ApplyBeta(result, beta, false);
+  for (auto& b : blocks_) b->EvalAdd(result.data(), rhs.data());
+}
+template <typename T>
+void LinearOperator<T>::EvalAdjoint(device_vector<T>& result, const device_vector<T>& rhs, T beta) {
+  if (beta == 0 && cols_exclusive_ && result.size() == ncols_) {
+    for (auto& b : blocks_) b->EvalAdjoint(result.data(), rhs.data());
+    return;
+  }
+  ApplyBeta(result, beta, false);
+  for (auto& b : blocks_) b->EvalAdjointAdd(result.data(), rhs.data());
+}
+template <typename T>
+static double timed_eval(LinearOperator<T>* op, bool adjoint, std::vector<T>& result, const std::vector<T>& rhs) {
+  static const int repeats = 5;                     // linearoperator.cu:178
+  device_vector<T> d_rhs; d_rhs = rhs;
+  device_vector<T> d_res(adjoint ? op->ncols() : op->nrows());
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < repeats; i++) {
+    if (adjoint) op->EvalAdjoint(d_res, d_rhs); else op->Eval(d_res, d_rhs);
+    CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+  }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  d_res.copy_to(result);
+  return ms / repeats;
+}
+template <typename T> double LinearOperator<T>::Eval(std::vector<T>& result, const std::vector<T>& rhs) { return timed_eval(this, false, result, rhs); }
+template <typename T> double LinearOperator<T>::EvalAdjoint(std::vector<T>& result, const std::vector<T>& rhs) { return timed_eval(this, true, result, rhs); }
+
+template <typename T>
+T LinearOperator<T>::row_sum(size_t row, T alpha) const {
+  T sum = 0;
+  for (auto& b : blocks_) { if (row < b->row() || row >= b->row() + b->nrows()) continue; sum += b->row_sum(row - b->row(), alpha); }
+  return sum;
+}
+template <typename T>
+T LinearOperator<T>::col_sum(size_t col, T alpha) const {
+  T sum = 0;
+  for (auto& b : blocks_) { if (col < b->col() || col >= b->col() + b->ncols()) continue; sum += b->col_sum(col - b->col(), alpha); }
+  return sum;
+}
+template <typename T>
+void LinearOperator<T>::row_sums(std::vector<T>& out, T alpha) const {
+  std::fill(out.begin(), out.end(), (T)0);
+  for (auto& b : blocks_) { if (b->row() + b->nrows() <= out.size()) b->row_sums(out.data() + b->row(), alpha); }
+}
+template <typename T>
+void LinearOperator<T>::col_sums(std::vector<T>& out, T alpha) const {
+  std::fill(out.begin(), out.end(), (T)0);
+  for (auto& b : blocks_) { if (b->col() + b->ncols() <= out.size()) b->col_sums(out.data() + b->col(), alpha); }
+}
+template <typename T>
+size_t LinearOperator<T>::gpu_mem_amount() const { size_t m = 0; for (auto& b : blocks_) m += b->gpu_mem_amount(); return m; }
+template class LinearOperator<float>;
+template class LinearOperator<double>;
+
+// ---- DualLinearOperator: -K^T (dual_linearoperator.cu:39-80) ----
+static bool g_negate_quirk = false;
+template <typename T> void DualLinearOperator<T>::SetReferenceNegateQuirk(bool on) { g_negate_quirk = on; }
+template <typename T>
+void DualLinearOperator<T>::Eval(device_vector<T>& result, const device_vector<T>& rhs, T beta) {
+  this->ApplyBeta(result, beta, true);
+  for (auto& b : child_->blocks_) b->EvalAdjointAdd(result.data(), rhs.data());
+  CheckHip(negate(result.data(), result.size(), g_negate_quirk, CurrentStream()), "negate");
+}
+template <typename T>
+void DualLinearOperator<T>::EvalAdjoint(device_vector<T>& result, const device_vector<T>& rhs, T beta) {
+  this->ApplyBeta(result, beta, true);
+  for (auto& b : child_->blocks_) b->EvalAdd(result.data(), rhs.data());
+  CheckHip(negate(result.data(), result.size(), g_negate_quirk, CurrentStream()), "negate");
+}
+template class DualLinearOperator<float>;
+template class DualLinearOperator<double>;
+
+}  // namespace prost

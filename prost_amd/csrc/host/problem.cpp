@@ -1,0 +1,243 @@
+// problem.cpp -- problem assembly, coverage checks, preconditioners and normest
+// (behaviour of the reference's src/problem.cu, written against the MI355X host layer).
+#include <algorithm>
+#include <cmath>
+#include <iostream>
+#include <sstream>
+
+#include "hipapi.hpp"
+#include "prost/problem.hpp"
+#include "prost/prox/proxes.hpp"
+
+namespace prost {
+
+template <typename T>
+static std::vector<shared_ptr<Prox<T>>> sorted_by_index(const std::vector<shared_ptr<Prox<T>>>& l) {
+  std::vector<shared_ptr<Prox<T>>> s = l;
+  std::sort(s.begin(), s.end(), [](const shared_ptr<Prox<T>>& a, const shared_ptr<Prox<T>>& b) { return a->index() < b->index(); });
+  return s;
+}
+
+/// throws unless the prox ranges tile [0, n) exactly (messages as problem.cu:48-89)
+template <typename T>
+static void CheckDomainProx(const typename Problem<T>::ProxList& proxs, size_t n, const std::string& name) {
+  if (proxs.empty()) return;
+  auto s = sorted_by_index<T>(proxs);
+  for (size_t i = 0; i + 1 < s.size(); i++)
+    if (s[i]->end() != s[i + 1]->index() - 1) {
+      std::stringstream ss;
+      ss << name << " (CheckDomainProx): Prox operators are overlapping: [" << s[i]->index() << ", " << s[i]->end() << "] and ["
+         << s[i + 1]->index() << ", " << s[i + 1]->end() << "]." << std::endl;
+      throw Exception(ss.str());
+    }
+  const auto& last = s.back();
+  if (last->end() != n - 1) {
+    std::stringstream ss;
+    ss << name << (last->end() < n - 1 ? " (CheckDomainProx): Last prox operator ends too early: ["
+                                       : " (CheckDomainProx): Last prox operator ends after the domain: [");
+    ss << last->index() << ", " << last->end() << "], end = " << n - 1 << "." << std::endl;
+    throw Exception(ss.str());
+  }
+}
+
+/// fills uncovered ranges of [0, n) with identity proxes (problem.cu:93-158)
+template <typename T>
+static void AddZeroProx(typename Problem<T>::ProxList& proxs, size_t n, const std::string& name) {
+  if (proxs.empty()) return;
+  auto s = sorted_by_index<T>(proxs);
+  if (s[0]->index() > 0) proxs.push_back(shared_ptr<Prox<T>>(new ProxZero<T>(0, s[0]->index())));
+  for (size_t i = 0; i + 1 < s.size(); i++)
+    if (s[i]->end() < s[i + 1]->index() - 1)
+      proxs.push_back(shared_ptr<Prox<T>>(new ProxZero<T>(s[i]->end() + 1, s[i + 1]->index() - s[i]->end() - 1)));
+  const auto& last = s.back();
+  if (last->end() != n - 1) {
+    if (last->end() < n - 1) proxs.push_back(shared_ptr<Prox<T>>(new ProxZero<T>(last->end() + 1, (n - 1) - last->end())));
+    else {
+      std::stringstream ss;
+      ss << name << " (AddZeroProx): Last prox operator ends after the domain: [" << last->index() << ", " << last->end()
+         << "], end = " << n - 1 << "." << std::endl;
+      throw Exception(ss.str());
+    }
+  }
+}
+
+template <typename T>
+Problem<T>::Problem() : nrows_(0), ncols_(0), linop_(new LinearOperator<T>()), scaling_type_(kScalingAlpha), scaling_alpha_(1), host_initialized_(false) {}
+
+template <typename T> void Problem<T>::AddBlock(shared_ptr<Block<T>> block) { linop_->AddBlock(block); }
+
+template <typename T>
+void Problem<T>::SetScalingCustom(const std::vector<T>& left, const std::vector<T>& right) {
+  scaling_type_ = kScalingCustom;
+  scaling_left_host_.resize(left.size());
+  scaling_right_host_.resize(right.size());
+  for (size_t i = 0; i < left.size(); i++) scaling_left_host_[i] = left[i] * left[i];
+  for (size_t i = 0; i < right.size(); i++) scaling_right_host_[i] = right[i] * right[i];
+}
+
+template <typename T>
+void Problem<T>::InitializeHost() {
+  if (host_initialized_) return;
+  linop_->InitializeHost();
+  if (linop_->nrows() != nrows_ || linop_->ncols() != ncols_)
+    std::cout << "Size of linear operator (ncols=" << linop_->ncols() << ", nrows=" << linop_->nrows()
+              << ") doesn't match size of variables. There might be some unnecessary variables in the problem.\n";
+  if (prox_f_.empty() && prox_fstar_.empty()) throw Exception("No proximal operator for f or fstar specified.");
+  if (prox_g_.empty() && prox_gstar_.empty()) throw Exception("No proximal operator for g or gstar specified.");
+  if (!prox_f_.empty() && !prox_fstar_.empty()) throw Exception("Proximal operator for f AND fstar specified. Only set one!");
+  if (!prox_g_.empty() && !prox_gstar_.empty()) throw Exception("Proximal operator for g AND gstar specified. Only set one!");
+
+  if (!prox_f_.empty()) AddZeroProx<T>(prox_f_, nrows_, "prox_f");
+  if (!prox_g_.empty()) AddZeroProx<T>(prox_g_, ncols_, "prox_g");
+  if (!prox_fstar_.empty()) AddZeroProx<T>(prox_fstar_, nrows_, "prox_fstar");
+  if (!prox_gstar_.empty()) AddZeroProx<T>(prox_gstar_, ncols_, "prox_gstar");
+  CheckDomainProx<T>(prox_g_, ncols_, "prox_g");
+  CheckDomainProx<T>(prox_f_, nrows_, "prox_f");
+  CheckDomainProx<T>(prox_gstar_, ncols_, "prox_gstar");
+  CheckDomainProx<T>(prox_fstar_, nrows_, "prox_fstar");
+
+  if (scaling_type_ == kScalingAlpha) {
+    // Sigma_i = 1 / sum_j |K_ij|^alpha ; Tau_j = 1 / sum_i |K_ij|^(2-alpha).  An all-zero row or
+    // column inherits the last positive value seen, and that carry runs from the row sweep on
+    // into the column sweep (problem.cu:262-287).
+    scaling_left_host_.assign(nrows_, 0);
+    scaling_right_host_.assign(ncols_, 0);
+    std::vector<T> sums(nrows_);
+    linop_->row_sums(sums, scaling_alpha_);
+    T value = 1;
+    for (size_t r = 0; r < nrows_; r++) {
+      if (sums[r] > 0) value = (T)(1. / (double)sums[r]);
+      scaling_left_host_[r] = value;
+    }
+    sums.assign(ncols_, 0);
+    linop_->col_sums(sums, (T)(2. - (double)scaling_alpha_));
+    for (size_t c = 0; c < ncols_; c++) {
+      if (sums[c] > 0) value = (T)(1. / (double)sums[c]);
+      scaling_right_host_[c] = value;
+    }
+  } else if (scaling_type_ == kScalingIdentity) {
+    scaling_left_host_.assign(nrows_, 1);
+    scaling_right_host_.assign(ncols_, 1);
+  } else {
+    if (scaling_left_host_.size() != nrows_ || scaling_right_host_.size() != ncols_)
+      throw Exception("Preconditioners/diagonal scaling vectors do not fit the size of linear operator.");
+  }
+  AveragePreconditioners(scaling_right_host_, prox_g_.empty() ? prox_gstar_ : prox_g_);
+  AveragePreconditioners(scaling_left_host_, prox_f_.empty() ? prox_fstar_ : prox_f_);
+  host_initialized_ = true;
+}
+
+template <typename T>
+void Problem<T>::Initialize() {
+  InitializeHost();
+  for (auto& b : linop_->blocks()) b->Initialize();
+  for (auto& p : prox_f_) p->Initialize();
+  for (auto& p : prox_fstar_) p->Initialize();
+  for (auto& p : prox_g_) p->Initialize();
+  for (auto& p : prox_gstar_) p->Initialize();
+  scaling_left_ = scaling_left_host_;
+  scaling_right_ = scaling_right_host_;
+  dual_linop_ = shared_ptr<LinearOperator<T>>(new DualLinearOperator<T>(linop_));
+}
+
+template <typename T>
+void Problem<T>::Release() {
+  linop_->Release();
+  for (auto& p : prox_f_) p->Release();
+  for (auto& p : prox_fstar_) p->Release();
+  for (auto& p : prox_g_) p->Release();
+  for (auto& p : prox_gstar_) p->Release();
+  scaling_left_.clear();
+  scaling_right_.clear();
+}
+
+template <typename T>
+size_t Problem<T>::gpu_mem_amount() const {
+  size_t mem = 0;
+  for (auto& p : prox_f_) mem += p->gpu_mem_amount();
+  for (auto& p : prox_g_) mem += p->gpu_mem_amount();
+  for (auto& p : prox_fstar_) mem += p->gpu_mem_amount();
+  for (auto& p : prox_gstar_) mem += p->gpu_mem_amount();
+  mem += linop_->gpu_mem_amount();
+  mem += sizeof(T) * (nrows() + ncols());
+  return mem;
+}
+
+/// a prox that cannot take a diagonal step size gets the mean preconditioner over each of its
+/// separable groups (problem.cu:503-536)
+template <typename T>
+void Problem<T>::AveragePreconditioners(std::vector<T>& precond, const ProxList& prox) {
+  std::vector<std::tuple<size_t, size_t, size_t>> groups;
+  for (auto& p : prox) if (!p->diagsteps()) p->get_separable_structure(groups);
+  for (auto& g : groups) {
+    const size_t idx = std::get<0>(g), cnt = std::get<1>(g), stride = std::get<2>(g);
+    T avg = 0;
+    for (size_t c = 0; c < cnt; c++) avg += precond[idx + c * stride];
+    avg /= static_cast<T>(cnt);
+    for (size_t c = 0; c < cnt; c++) precond[idx + c * stride] = avg;
+  }
+}
+
+template <typename T>
+void Problem<T>::Dualize() {
+  prox_g_.swap(prox_fstar_);
+  prox_gstar_.swap(prox_f_);
+  std::swap(nrows_, ncols_);
+  std::swap(linop_, dual_linop_);
+  scaling_left_.swap(scaling_right_);
+  std::swap(scaling_left_host_, scaling_right_host_);
+}
+
+/// |Sigma^(1/2) K Tau^(1/2)| by power iteration on the device (problem.cu:429-500).  The start
+/// vector is the std::rand() stream of a fresh process (srand is never called by the reference).
+template <typename T>
+T Problem<T>::normest(T tol, int max_iters) {
+  const size_t n = ncols(), m = nrows();
+  device_vector<T> x(n), Ax(m), x_temp(n), Ax_temp(m);
+  {
+    std::vector<T> x_host(n);
+    GlibcRand rng(1);
+    for (size_t i = 0; i < n; i++) x_host[i] = (T)rng.next() / (T)2147483647;   // RAND_MAX
+    x = x_host;
+  }
+  void* ws = nullptr;
+  double* out_dev = nullptr;
+  CheckHip(prost_hip_malloc(&ws, prost_hip_reduce_workspace_bytes()), "malloc");
+  CheckHip(prost_hip_malloc((void**)&out_dev, 2 * sizeof(double)), "malloc");
+  auto nrm = [&](const device_vector<T>& v) {
+    // sqrt(sum v^2): the reference reduces in T with an unspecified tree order; here in double
+    CheckHip(Api<T>::nrm2(out_dev, v.data(), v.size(), ws, CurrentStream()), "nrm2");
+    double h[2];
+    CheckHip(prost_hip_memcpy_d2h(h, out_dev, 2 * sizeof(double), CurrentStream()), "d2h");
+    CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+    return (T)h[0];
+  };
+  auto mul_sqrt = [&](device_vector<T>& out, const device_vector<T>& scal, const device_vector<T>& v) {
+    CheckHip(Api<T>::admm_elem(PROST_ADMM_GEMV1, out.data(), scal.data(), v.data(), nullptr, nullptr, 0, 0, v.size(), CurrentStream()), "gemv1");
+  };
+  T norm = 0, norm_prev;
+  try {
+    for (int i = 0; i < max_iters; i++) {
+      norm_prev = norm;
+      mul_sqrt(x_temp, scaling_right_, x);
+      linop_->Eval(Ax_temp, x_temp);
+      mul_sqrt(Ax, scaling_left_, Ax_temp);
+      const T norm_Ax = nrm(Ax);
+      mul_sqrt(Ax_temp, scaling_left_, Ax);
+      linop_->EvalAdjoint(x_temp, Ax_temp);
+      mul_sqrt(x, scaling_right_, x_temp);
+      const T norm_x = nrm(x);
+      norm = norm_x / norm_Ax;
+      if (std::abs(norm_prev - norm) < tol * norm) break;
+      CheckHip(Api<T>::admm_elem(PROST_ADMM_DIV, x.data(), x.data(), nullptr, nullptr, nullptr, (double)norm_x, 0, n, CurrentStream()), "divide");
+    }
+  } catch (...) { prost_hip_free(ws); prost_hip_free(out_dev); throw; }
+  prost_hip_free(ws);
+  prost_hip_free(out_dev);
+  return norm;
+}
+
+template class Problem<float>;
+template class Problem<double>;
+
+}  // namespace prost

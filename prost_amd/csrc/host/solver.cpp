@@ -1,0 +1,141 @@
+// solver.cpp -- outer host loop: initialisation, iteration, stopping test, callback schedule
+// (behaviour of the reference's src/solver.cu).
+#include <cmath>
+#include <cstdio>
+#include <iomanip>
+#include <iostream>
+#include <list>
+
+#include "prost/backend/backend.hpp"
+#include "prost/problem.hpp"
+#include "prost/solver.hpp"
+#include "prost_hip.h"
+
+namespace prost {
+
+template <typename T>
+Solver<T>::Solver(shared_ptr<Problem<T>> problem, shared_ptr<Backend<T>> backend)
+    : problem_(problem), backend_(backend), iterations_done_(0), dualized_(false) {}
+
+template <typename T>
+void Solver<T>::Initialize() {
+  try {
+    problem_->Initialize();
+  } catch (Exception& e) {
+    throw Exception(std::string("Failed to initialize the problem. Reason: ") + e.what());
+  }
+  if (opts_.solve_dual_problem) {
+    problem_->Dualize();
+    opts_.x0.swap(opts_.y0);
+    dualized_ = true;
+  }
+  try {
+    backend_->SetProblem(problem_);
+    backend_->SetOptions(opts_);
+    backend_->Initialize();
+  } catch (Exception& e) {
+    throw Exception(std::string("Failed to initialize the backend. Reason: ") + e.what());
+  }
+  if (opts_.verbose) {
+    const size_t mem = problem_->gpu_mem_amount() + backend_->gpu_mem_amount();
+    size_t mem_avail = 0, mem_total = 0;
+    prost_hip_mem_info(&mem_avail, &mem_total);
+    std::cout << "# primal variables: " << problem_->ncols() << std::endl;
+    std::cout << "# dual variables: " << problem_->nrows() << std::endl;
+    std::cout << "Memory requirements: " << mem / (1024 * 1024) << "MB (" << mem_avail / (1024 * 1024) << "/"
+              << mem_total / (1024 * 1024) << "MB available). Path: " << backend_->path() << "." << std::endl;
+  }
+  cur_primal_sol_.resize(problem_->ncols());
+  cur_primal_constr_sol_.resize(problem_->nrows());
+  cur_dual_sol_.resize(problem_->nrows());
+  cur_dual_constr_sol_.resize(problem_->ncols());
+  iterations_done_ = 0;
+}
+
+template <typename T>
+void Solver<T>::Iterate(int iters) {
+  for (int i = 0; i < iters; i++) backend_->PerformIteration();
+  iterations_done_ += iters;
+}
+
+template <typename T>
+void Solver<T>::FetchSolution() {
+  backend_->current_solution(cur_primal_sol_, cur_primal_constr_sol_, cur_dual_sol_, cur_dual_constr_sol_);
+}
+
+template <typename T>
+typename Solver<T>::ConvergenceResult Solver<T>::Solve() {
+  ConvergenceResult result = kStoppedMaxIters;
+
+  // iterations at which the intermediate-solution callback fires: num_cback_calls points from 0
+  // to max_iters-1 (+ the trailing end point linspace appends); fewer than two calls -> only the
+  // convergence / last-iteration triggers remain (solver.cu:128-135)
+  std::list<double> cb_iters;
+  if (opts_.num_cback_calls >= 2) cb_iters = linspace(0, opts_.max_iters - 1, opts_.num_cback_calls);
+  else cb_iters.push_back(1e8);
+
+  for (int i = 0; i < opts_.max_iters; i++) {
+    backend_->PerformIteration();
+    iterations_done_++;
+
+    const T primal_res = backend_->primal_residual(), dual_res = backend_->dual_residual();
+    const T eps_pri = backend_->eps_primal(), eps_dua = backend_->eps_dual();
+    bool is_converged = (primal_res < eps_pri) && (dual_res < eps_dua);
+    const bool is_stopped = stopping_cb_ ? stopping_cb_() : false;
+
+    if (i >= cb_iters.front() || is_converged || is_stopped || i == (opts_.max_iters - 1)) {
+      FetchSolution();
+      if (opts_.num_cback_calls >= 1) {
+        if (opts_.verbose) {
+          const int digits = (int)std::floor(std::log10((double)opts_.max_iters)) + 1;
+          std::cout << "It " << std::setw(digits) << (i + 1) << ": " << std::scientific;
+          std::cout << "Feas_p=" << std::setprecision(2) << primal_res;
+          std::cout << ", Eps_p=" << std::setprecision(2) << eps_pri;
+          std::cout << ", Feas_d=" << std::setprecision(2) << dual_res;
+          std::cout << ", Eps_d=" << std::setprecision(2) << eps_dua << "; ";
+          if (!interm_cb_) std::cout << std::endl;
+        }
+        if (interm_cb_) {
+          if (opts_.solve_dual_problem) is_converged |= interm_cb_(i + 1, cur_dual_sol_, cur_primal_sol_);
+          else is_converged |= interm_cb_(i + 1, cur_primal_sol_, cur_dual_sol_);
+        }
+      }
+      cb_iters.pop_front();
+    }
+    if (is_stopped) {
+      if (opts_.verbose) std::cout << "Stopped by user." << std::endl;
+      result = kStoppedUser;
+      break;
+    }
+    if (is_converged) {
+      if (opts_.verbose) std::cout << "Reached convergence tolerance." << std::endl;
+      result = kConverged;
+      break;
+    }
+  }
+  if (opts_.solve_dual_problem && dualized_) {        // restore the original problem (solver.cu:198-203)
+    problem_->Dualize();
+    opts_.x0.swap(opts_.y0);
+    dualized_ = false;
+  }
+  if (opts_.verbose && result == kStoppedMaxIters)
+    std::cout << "Reached maximum of " << opts_.max_iters << " iterations." << std::endl;
+  return result;
+}
+
+template <typename T>
+void Solver<T>::Release() {
+  problem_->Release();
+  backend_->Release();
+}
+
+// under solve_dual the roles of the solution vectors are exchanged (solver.cu:216-246)
+template <typename T> const std::vector<T>& Solver<T>::cur_primal_sol() const { return opts_.solve_dual_problem ? cur_dual_sol_ : cur_primal_sol_; }
+template <typename T> const std::vector<T>& Solver<T>::cur_dual_sol() const { return opts_.solve_dual_problem ? cur_primal_sol_ : cur_dual_sol_; }
+template <typename T> const std::vector<T>& Solver<T>::cur_primal_constr_sol() const { return opts_.solve_dual_problem ? cur_dual_constr_sol_ : cur_primal_constr_sol_; }
+template <typename T> const std::vector<T>& Solver<T>::cur_dual_constr_sol() const { return opts_.solve_dual_problem ? cur_primal_constr_sol_ : cur_dual_constr_sol_; }
+
+template class Solver<float>;
+template class Solver<double>;
+
+}  // namespace prost

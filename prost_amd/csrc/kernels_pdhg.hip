@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(kBlock) admm_elem_kernel(T* __restrict__ o, co
       case PROST_ADMM_GEMV3: o[i] = alpha * t_sqrt(a[i]) * b[i]; break;
       case PROST_ADMM_GETDUAL: o[i] = -alpha * t_pow(d[i], beta) * (a[i] - b[i] + c[i]); break;
       case PROST_ADMM_SCALE: o[i] = alpha * a[i]; break;
+      case PROST_ADMM_DIV: o[i] = a[i] / alpha; break;
     }
   }
 }
@@ -133,7 +134,7 @@ static int launch_admm(int op, T* o, const T* a, const T* b, const T* c, const T
 #define GO(OPv) case OPv: hipLaunchKernelGGL((admm_elem_kernel<T, OPv>), g, blk, 0, s, o, a, b, c, d, (T)alpha, (T)beta, n); break;
   switch (op) {
     GO(PROST_ADMM_TEMP1) GO(PROST_ADMM_TEMP2) GO(PROST_ADMM_DIFF) GO(PROST_ADMM_XPROJ) GO(PROST_ADMM_XDUAL) GO(PROST_ADMM_ZDUAL)
-    GO(PROST_ADMM_GEMV1) GO(PROST_ADMM_GEMV2) GO(PROST_ADMM_GEMV3) GO(PROST_ADMM_GETDUAL) GO(PROST_ADMM_SCALE)
+    GO(PROST_ADMM_GEMV1) GO(PROST_ADMM_GEMV2) GO(PROST_ADMM_GEMV3) GO(PROST_ADMM_GETDUAL) GO(PROST_ADMM_SCALE) GO(PROST_ADMM_DIV)
     default: set_error("admm_elem: unknown op"); return 1;
   }
 #undef GO
