@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PDHG iterations/second, ROF-TV denoising, 4096 x 4096 grayscale, fp32.
+
+One "step" = one PDHG iteration (BackendPDHG::PerformIteration, backend_pdhg.cu:313-381) of
+matlab/examples/example_rof_primaldual.m on a synthetic 4096^2 image (BASELINE.json configs[1]):
+gradient2d + sum_1d('square', 1, f, 10) + sum_norm2(2, false, 'ind_leq0', 1, 1, 1),
+pdhg(stepsize='alg2', residual_iter=10, alg2_gamma=0.5), tolerances 0 (never stops early).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1: BASELINE config 5 -- N independent 4096^2 problems (seeds 42..42+N-1), one per GPU, weak
+scaling; the 4 residual sums are all-reduced over RCCL every residual iteration so every rank sees
+the global stopping criterion.  value = N * K / max-over-ranks(time).
+
+Inputs are resident in HBM before the timed region.  The JSON line carries
+  roofline     : dominant kernel (fused dual pass, 6 of the 11 floats/pixel/iteration), algorithmic
+                 bytes / mean launch time measured with HIP events on the solver's stream
+  cpu_baseline : the CPU oracle (port of the reference path) timed on this host's cores on a bounded
+                 sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_IMG = 4096
+LAMBDA = 10.0
+ALG_FLOATS_PER_PIXEL = 11          # primal pass 5 + dual pass 6
+DUAL_PASS_FLOATS = 6
+HBM_PEAK_GBPS = 8000.0
+
+
+def cpu_baseline(n_img, threads):
+    """Oracle (CPU restatement of the reference path) on a bounded sample: the same 4096^2 ROF
+    problem, a handful of iterations (about 10-30 s of CPU work)."""
+    import numpy as np
+
+    import oracle
+    import prost_amd as prost
+    from prost_amd import synthetic
+    oracle.set_num_threads(threads)
+    prob, u, q, f = synthetic.rof_problem(n_img, n_img, seed=42)
+    prob.finalize()
+    backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA)
+    opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0,
+                         tol_abs_primal=0, tol_abs_dual=0)
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np.float32)
+    s.initialize()
+    s.iterate(1)
+    iters, t0 = 0, time.time()
+    while True:
+        s.iterate(2)
+        iters += 2
+        el = time.time() - t0
+        if el > 8.0 or iters >= 40:
+            break
+    return {"value": iters / el, "unit": "it/s", "cores": threads, "kind": "port",
+            "sample": "%d PDHG iterations of the same %dx%d fp32 ROF problem, oracle/prost_oracle.cpp with OpenMP" % (iters, n_img, n_img)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=N_IMG, help="image side (default 4096 = the headline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+
+    import prost_amd as prost
+    from prost_amd import synthetic
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the prost hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    prost.set_gpu(local_rank)
+    prost.set_precision("single")
+    if world > 1:
+        # RCCL communicator owned by the native solver: rank 0 creates the id, torch broadcasts it
+        ident = torch.zeros(128, dtype=torch.float64, device="cuda")
+        if rank == 0:
+            ident.copy_(torch.from_numpy(prost.comm_unique_id()))
+        dist.broadcast(ident, src=0)
+        prost.comm_init(ident.cpu().numpy(), rank, world)
+
+    n = args.size
+    prob, u, q, f = synthetic.rof_problem(n, n, lmb=LAMBDA, seed=42 + rank)
+    backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA)
+    opts = prost.options(max_iters=10 ** 9, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0,
+                         tol_abs_primal=0, tol_abs_dual=0)
+    solver = prost.Solver(prob, backend, opts)          # uploads f, allocates x/y ping-pong buffers in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    solver.iterate(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    info = solver.iterate(args.steps, time_kernels=not args.no_kernel_timing)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    st = solver.state()
+    path = st["path"]
+    finite = bool(np.isfinite(st["x"]).all() and np.isfinite(st["y"]).all())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        bytes_per_iter = ALG_FLOATS_PER_PIXEL * 4 * n * n
+        out = {
+            "metric": "PDHG iters/sec, ROF-TV %d^2 fp32" % n,
+            "value": value,
+            "unit": "it/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), "
+                                   "PDHG alg2, residual_iter=10, lambda=10; one independent problem per GPU" % (n, n),
+                       "path": path, "problems": world, "residual_allreduce": "rccl" if world > 1 else "none"},
+            "achieved_hbm_GBps": value * bytes_per_iter / 1e9,
+            "hbm_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world),
+            "iterates_finite": finite,
+        }
+        if info["launches"] > 0 and info["dual_kernel_ms"] > 0:
+            alg_bytes = DUAL_PASS_FLOATS * 4 * n * n
+            achieved = alg_bytes / 1e9 / (info["dual_kernel_ms"] * 1e-3)
+            out["roofline"] = {"bound": "hbm", "kernel": "fused_dual2d_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": info["dual_kernel_ms"],
+                               "launches_timed": int(info["launches"]),
+                               "primal_pass": {"kernel": "fused_primal2d_kernel", "avg_launch_ms": info["primal_kernel_ms"],
+                                               "achieved": 5 * 4 * n * n / 1e9 / (info["primal_kernel_ms"] * 1e-3)}}
+        if not args.no_cpu_baseline and world == 1:
+            threads = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(n, threads)
+        print(json.dumps(out), flush=True)
+
+    solver.destroy()
+    if world > 1:
+        prost.comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,8 +143,11 @@ void BackendPDHG<T>::PerformIteration() {
 template <typename T>
 void BackendPDHG<T>::IterationFused(bool res) {
   void* s = CurrentStream();
+  // kernel timing samples one iteration in eight (never a residual iteration: 8k+1 is odd) so the
+  // event markers do not perturb the pipelining of the other launches
+  const bool sample = this->time_kernels_ && (iteration_ % 8) == 1;
   auto stamp = [&]() {
-    if (!this->time_kernels_) return;
+    if (!sample) return;
     if (ev_used_ == ev_.size()) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
     CheckHip(prost_hip_event_record(ev_[ev_used_++], s), "event_record");
   };

@@ -1,0 +1,106 @@
+"""Generates tests/golden/*.npz from the REAL reference code (oracle/_ref, built from
+/root/reference by oracle/Makefile.ref).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The fixtures are data (inputs + expected outputs); no reference source text is stored.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from oracle import ref  # noqa: E402
+import prost_amd as prost  # noqa: E402
+from prost_amd import synthetic  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def elementwise():
+    rng = np.random.default_rng(20240901)
+    out = {}
+    count = 32
+    for dt in (np.float32, np.float64):
+        for op, dims in ((0, (1,)), (1, (1, 2, 3, 7))):
+            for dim in dims:
+                for il in (False, True):
+                    for inv in (False, True):
+                        arg = rng.uniform(-3, 3, count * dim).astype(dt)
+                        if op == 1:
+                            arg[(np.arange(dim) if il else np.arange(dim) * count)] = 0      # zero-norm element
+                        td = rng.uniform(0.1, 2, count * dim).astype(dt)
+                        a = rng.uniform(0.5, 2, count); a[1] = 0
+                        c = rng.uniform(0.1, 2, count); c[2] = 0
+                        coeffs = [a, rng.uniform(-1, 1, count), c, rng.uniform(-1, 1, count), rng.uniform(0, 1, count)]
+                        key = "%s_op%d_dim%d_il%d_inv%d" % (np.dtype(dt).name, op, dim, il, inv)
+                        out[key + "_arg"] = arg
+                        out[key + "_td"] = td
+                        for i, v in enumerate(coeffs):
+                            out[key + "_c%d" % i] = v
+                        for fn in oracle.FUNCTIONS:
+                            alpha = 0.5 if fn == "lq" else 0.7
+                            out[key + "_" + fn] = ref.prox_elem(op, fn, arg, td, 0.8, count, dim, il, coeffs + [alpha, 1.3], inv)
+    np.savez_compressed(os.path.join(OUT, "elementwise.npz"), **out)
+
+
+def pdhg():
+    out = {}
+    nx, ny, L = 16, 12, 2
+    f = synthetic.rof_image(nx, ny, L, seed=7)
+    out["f"] = f
+    for dt in (np.float32, np.float64):
+        for step in ("alg1", "alg2", "goldstein", "boyd"):
+            for res_iter in (1, 10):
+                prob, u, q, _ = synthetic.rof_problem(nx, ny, L, f=f)
+                prob.finalize()
+                b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5)
+                o = prost.options(max_iters=50, num_cback_calls=0, verbose=False)
+                R = ref.RefProblem(prob.data, prob.nrows, prob.ncols, dt)
+                for k in (1, 2, 10, 50):
+                    r = R.pdhg(b[1], o, k)
+                    key = "%s_%s_r%d_k%d" % (np.dtype(dt).name, step, res_iter, k)
+                    for name in ("x", "y", "z", "w"):
+                        out[key + "_" + name] = r[name].astype(dt)
+                    out[key + "_scal"] = np.array([r[n] for n in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual")])
+                sl, sr = R.scaling()
+                out["%s_scaling_left" % np.dtype(dt).name] = sl
+                out["%s_scaling_right" % np.dtype(dt).name] = sr
+                out["%s_normest" % np.dtype(dt).name] = np.array([R.normest()])
+    # warm start + Moreau-wrapped prox (prox_f given instead of prox_fstar)
+    np.savez_compressed(os.path.join(OUT, "pdhg_rof_16x12x2.npz"), **out)
+
+
+def misc():
+    import scipy.sparse as sp
+    out = {}
+    A = sp.random(23, 31, density=0.15, format="csr", random_state=3, dtype=np.float64)
+    A.sort_indices()
+    v, ri, cs = ref.csr2csc(23, 31, A.data, A.indices, A.indptr)
+    out["csr_val"], out["csr_ind"], out["csr_ptr"] = A.data, A.indices.astype(np.int32), A.indptr.astype(np.int32)
+    out["csc_val"], out["csc_ind"], out["csc_ptr"] = v, ri, cs
+    out["linspace_0_999_10"] = ref.linspace(0, 999, 10)
+    out["linspace_0_9999_250"] = ref.linspace(0, 9999, 250)
+    rng = np.random.default_rng(5)
+    x0 = rng.uniform(-2, 2, (3, 40)); y0 = rng.uniform(-2, 2, 40); al = rng.uniform(0.3, 2, 40)
+    for dt in (np.float32, np.float64):
+        x, y = ref.project_epi_quad(x0.astype(dt), y0.astype(dt), al.astype(dt))
+        out["epi_x_" + np.dtype(dt).name], out["epi_y_" + np.dtype(dt).name] = x, y
+    out["epi_x0"], out["epi_y0"], out["epi_alpha"] = x0, y0, al
+    lib = ref.lib()
+    lib.ref_srand(1)
+    out["glibc_rand_seed1"] = np.array([lib.ref_rand() for _ in range(64)], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+
+
+if __name__ == "__main__":
+    assert ref.available() or ref.build(), "oracle/_ref is not built and /root/reference is absent"
+    elementwise()
+    pdhg()
+    misc()
+    for fn in sorted(os.listdir(OUT)):
+        if fn.endswith(".npz"):
+            print(fn, os.path.getsize(os.path.join(OUT, fn)) // 1024, "KiB")

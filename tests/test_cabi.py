@@ -1,0 +1,149 @@
+"""C-ABI shape checks that need no GPU: both shared libraries load, export every symbol their
+headers declare, and the host-only commands (problem setup, factories, error paths) behave like
+the reference's gateway."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+import prost_amd as prost
+from prost_amd import _capi, _hip, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(prost_[a-z0-9_]+)\s*\(", text)) - {"prost_interm_cb", "prost_stop_cb"})
+
+
+def test_kernel_library_exports_every_declared_symbol():
+    names = declared_functions("prost_hip.h")
+    assert len(names) > 70
+    L = _hip.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.prost_hip_abi_version() == 1
+    assert L.prost_hip_reduce_workspace_bytes() >= 4096
+
+
+def test_host_library_exports_every_declared_symbol():
+    names = declared_functions("prost_c.h")
+    L = _capi.lib()
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_unknown_command_and_factory_errors():
+    with pytest.raises(_capi.ProstError, match="Unknown command 'frobnicate'"):
+        _capi.command("frobnicate")
+    u, q = prost.variable(4), prost.variable(8)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_dual_pair(u, q, prost.block.gradient2d(2, 2, 1))
+    prob.data["prox_g"] = [["no_such_prox", 0, 4, True, []]]
+    with pytest.raises(_capi.ProstError, match="Creating prox with ID 'no_such_prox' failed. Reason: Name not registered in ProxFactory"):
+        prost.problem_info(prob)
+    prob.data["prox_g"] = [["zero", 0, 4, True, []]]
+    prob.data["linop"] = [["no_such_block", 0, 0, []]]
+    with pytest.raises(_capi.ProstError, match="Name not registered in BlockFactory"):
+        prost.problem_info(prob)
+    prob.data["linop"] = [["gradient2d", 0, 0]]
+    with pytest.raises(_capi.ProstError, match="Invalid block description"):
+        prost.problem_info(prob)
+
+
+def test_problem_setup_errors_match_reference_messages():
+    u, q = prost.variable(6), prost.variable(12)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_dual_pair(u, q, prost.block.gradient2d(3, 2, 1))
+    prob.data["prox_g"] = [["zero", 0, 4, True, []], ["zero", 2, 4, True, []]]
+    prob.data["prox_fstar"] = [["zero", 0, 12, True, []]]
+    with pytest.raises(_capi.ProstError, match=r"prox_g \(CheckDomainProx\): Prox operators are overlapping: \[0, 3\] and \[2, 5\]"):
+        prost.problem_info(prob)
+    prob.data["prox_g"] = [["zero", 0, 9, True, []]]
+    with pytest.raises(_capi.ProstError, match="Last prox operator ends after the domain"):
+        prost.problem_info(prob)
+    prob.data["prox_g"] = [["zero", 0, 6, True, []]]
+    prob.data["prox_f"] = [["zero", 0, 12, True, []]]
+    with pytest.raises(_capi.ProstError, match="Proximal operator for f AND fstar specified"):
+        prost.problem_info(prob)
+    prob.data["prox_f"] = []
+    prob.data["linop"].append(["zero", 3, 2, [4, 2]])
+    with pytest.raises(_capi.ProstError, match="Blocks are overlapping inside the linear operator"):
+        prost.problem_info(prob)
+
+
+@pytest.mark.parametrize("precision", ["single", "double"])
+def test_problem_info_matches_oracle_setup(precision):
+    """zero-prox filling, Pock-Chambolle preconditioners with the carried value, averaging over
+    non-diagstep groups (problem.cu:196-323, :503-536) -- host code, compared with the oracle"""
+    import scipy.sparse as sp
+    prost.set_precision(precision)
+    try:
+        dt = np.float32 if precision == "single" else np.float64
+        rng = np.random.default_rng(0)
+        nx, ny = 6, 5
+        n = nx * ny
+        u, w = prost.variable(n), prost.variable(7)
+        q, r = prost.variable(2 * n), prost.variable(9)
+        K = sp.random(9, 7, density=0.3, random_state=1, format="csc")
+        K[3, :] = 0            # an all-zero row: inherits the previous value (problem.cu:267-273)
+        prob = prost.min_max_problem([u, w], [q, r])
+        prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, 1))
+        prob.add_dual_pair(w, r, prost.block.sparse(K))
+        prob.add_dual_pair(u, r, prost.block.diags(9, n, [0.5, -2.0], [0, 3]))
+        prob.add_function(u, prost.function.sum_1d("square", 1, rng.random(n), 10))
+        prob.add_function(q, prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1))
+        for alpha in (1.0, 0.5):
+            prob.set_scaling_alpha(alpha)
+            info = prost.problem_info(prob)
+            P = oracle.Problem(prob.data, prob.nrows, prob.ncols, dt)
+            P.initialize()
+            sl, sr = P.scaling()
+            assert np.array_equal(np.asarray(info["scaling_left"]), sl)
+            assert np.array_equal(np.asarray(info["scaling_right"]), sr)
+        pg = np.asarray(info["prox_g"]).reshape(-1, 3) if np.ndim(info["prox_g"]) == 1 else np.asarray(info["prox_g"]).T
+        assert sorted(pg[:, 0].tolist()) == [0, n] and sorted(pg[:, 1].tolist()) == [7, n]     # zero prox appended for w
+        assert info["nrows"] == 2 * n + 9 and info["ncols"] == n + 7
+    finally:
+        prost.set_precision("double")
+
+
+def test_precision_switch_and_default():
+    assert prost.get_precision() == "double"          # reference default: typedef double real (config.hpp:7)
+    prost.set_precision("single")
+    assert prost.get_precision() == "single"
+    prost.set_precision("double")
+    with pytest.raises(_capi.ProstError):
+        prost.set_precision("half")
+
+
+def test_value_round_trip_through_the_c_tree():
+    L = _capi.lib()
+    keep = []
+    v = _capi.to_value({"a": [1, "two", np.arange(3.0)], "m": np.arange(6.0).reshape(2, 3)}, keep)
+    try:
+        a = L.prost_value_field(v, b"a")
+        assert L.prost_value_kind(a) == _capi.VALUE_CELL and L.prost_value_count(a) == 3
+        assert _capi.from_value(a) [1] == "two" and np.array_equal(_capi.from_value(a)[2], np.arange(3.0))
+        assert np.array_equal(_capi.from_value(L.prost_value_field(v, b"m")), np.arange(6.0).reshape(2, 3))
+        assert not L.prost_value_field(v, b"missing")
+    finally:
+        L.prost_value_free(v)
+
+
+def test_product_fails_loudly_without_a_gpu():
+    """no CPU fallback: on a machine without an MI355X every compute command raises"""
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is present")
+    prob, u, q, f = synthetic.rof_problem(8, 8)
+    with pytest.raises(_capi.ProstError, match="no MI355X|no CPU fallback|Invalid HIP device"):
+        prost.solve(prob, prost.backend.pdhg(), prost.options(max_iters=2, verbose=False))
+    with pytest.raises(_capi.ProstError):
+        prost.eval_prox(prost.function.sum_1d("abs"), np.ones(4), 1.0, np.ones(4))
+    with pytest.raises(_hip.HipError):
+        _hip.require_device()

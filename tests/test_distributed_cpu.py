@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the batch-of-independent-problems scheme with the
+global residual all-reduce (the oracle solver stands in for the GPU solver: same hook contract)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from prost_amd import distributed
+
+
+def test_shard_partitions_problems():
+    for n in (1, 7, 8, 9):
+        for world in (1, 2, 4, 8):
+            ids = [i for r in range(world) for i in distributed.shard(n, r, world)]
+            assert ids == list(range(n))
+            sizes = [len(distributed.shard(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+    assert [distributed.problem_seed(i) for i in range(8)] == list(range(42, 50))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, step, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import oracle
+    import prost_amd as prost
+    from prost_amd import synthetic
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pid = distributed.shard(world, rank, world)[0]
+        prob, u, q, f = synthetic.rof_problem(20, 16, seed=distributed.problem_seed(pid))
+        prob.finalize()
+        b = prost.backend.pdhg(stepsize=step, residual_iter=2, alg2_gamma=0.5)
+        o = prost.options(max_iters=40, num_cback_calls=0, verbose=False)
+        s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float64)
+        s.set_allreduce(distributed.allreduce_hook(dist), world * prob.nrows, world * prob.ncols)
+        s.initialize()
+        s.iterate(40)
+        sc = s.scalars()
+        loc = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float64)
+        loc.initialize(); loc.iterate(40)
+        lsc = loc.scalars()
+        out.put((rank, sc, lsc, float(s.state()["x"].sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("step", ["alg1", "boyd"])
+def test_global_residual_allreduce_gloo(step):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, step, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, l0, x0), (_, g1, l1, x1) = res
+    # every rank sees the same global scalars and takes the same step-size decisions
+    for k in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "tau", "sigma"):
+        assert g0[k] == g1[k], k
+    assert x0 != x1                                    # different problems (seeds 42, 43)
+    if step == "alg1":
+        # iterates do not depend on residuals: global^2 = sum of the local squares
+        for k in ("primal_res", "dual_res", "dual_var_norm"):
+            assert np.isclose(g0[k] ** 2, l0[k] ** 2 + l1[k] ** 2, rtol=1e-12), k
+        # eps uses the GLOBAL sizes: sqrt(sum m) * tol_abs + tol_rel * global norm
+        m = 2 * 2 * 20 * 16
+        assert np.isclose(g0["eps_primal"], np.sqrt(m) * 1e-4 + 1e-4 * g0["primal_var_norm"], rtol=1e-12)

@@ -1,0 +1,93 @@
+"""Front-end description builders (prost_amd = Python mirror of matlab/+prost): index bookkeeping,
+cell layouts and error behaviour must match the MATLAB package (min_max_problem.m, min_problem.m,
+private/add_prox.m, +block/*.m, +function/*.m, options.m, +backend/*.m)."""
+import numpy as np
+import pytest
+
+import prost_amd as prost
+
+
+def test_rof_description_matches_example_rof_primaldual():
+    nx, ny, nc = 5, 4, 3
+    f = np.linspace(0, 1, nx * ny * nc)
+    u = prost.variable(nx * ny * nc)
+    q = prost.variable(2 * nx * ny * nc)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d("square", 1, f, 10))
+    prob.add_function(q, prost.function.sum_norm2(2 * nc, False, "ind_leq0", 1, 1, 1))
+    prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, nc))
+    assert (prob.nrows, prob.ncols) == (2 * nx * ny * nc, nx * ny * nc)
+    name, idx, size, diagsteps, data = prob.data["prox_g"][0]
+    assert (name, idx, size, diagsteps) == ("elem_operation:1d:square", 0, nx * ny * nc, True)      # sum_1d.m:79-80
+    assert data[:3] == [nx * ny * nc, 1, False] and np.array_equal(data[3][1], f) and data[3][2][0] == 10
+    name, idx, size, diagsteps, data = prob.data["prox_fstar"][0]
+    assert (name, idx, size, diagsteps) == ("elem_operation:norm2:ind_leq0", 0, 2 * nx * ny * nc, False)   # sum_norm2.m:85-86
+    assert data[:3] == [nx * ny, 2 * nc, False]
+    assert prob.data["linop"] == [["gradient2d", 0, 0, [nx, ny, nc, False]]]                         # gradient2d.m:12-14
+    assert prob.data["scaling"] == "alpha" and prob.data["scaling_alpha"] == 1                         # problem.m:10
+
+
+def test_variable_offsets_and_sub_variables():
+    a, b = prost.variable(10), prost.variable(6)
+    b1, b2 = prost.sub_variable(b, 2), prost.sub_variable(b, 4)
+    y = prost.variable(7)
+    prob = prost.min_max_problem([a, b], [y])
+    assert (a.idx, b.idx, b1.idx, b2.idx, y.idx) == (0, 10, 10, 12, 0)
+    prob.add_function(b2, prost.function.sum_1d("abs"))
+    assert prob.data["prox_g"][0][1:3] == [12, 4]
+    prob.add_dual_pair(b1, y, prost.block.zero())
+    assert prob.data["linop"][0][:3] == ["zero", 0, 10]
+    bad = prost.variable(5)
+    prost.sub_variable(bad, 2)
+    with pytest.raises(ValueError, match="Size of subvariables"):
+        prost.min_max_problem([bad], [y])
+
+
+def test_add_prox_replaces_same_index_and_block_replaced():
+    u, q = prost.variable(8), prost.variable(8)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d("abs"))
+    prob.add_function(u, prost.function.sum_1d("square"))
+    assert len(prob.data["prox_g"]) == 1 and prob.data["prox_g"][0][0].endswith("square")     # add_prox.m
+    prob.add_dual_pair(u, q, prost.block.identity(2))
+    prob.add_dual_pair(u, q, prost.block.identity(3))
+    assert len(prob.data["linop"]) == 1 and prob.data["linop"][0][3][2][0] == 3               # min_max_problem.m:166-183
+    with pytest.raises(ValueError, match="Size of block"):
+        prob.add_dual_pair(u, q, prost.block.gradient2d(2, 2, 1))
+    with pytest.raises(ValueError, match="not registered"):
+        prob.add_function(prost.variable(3), prost.function.zero())
+
+
+def test_finalize_and_fill_variables():
+    u, q = prost.variable(4), prost.variable(6)
+    s1, s2 = prost.sub_variable(q, 2), prost.sub_variable(q, 4)
+    prob = prost.min_max_problem([u], [q])
+    prob.finalize()
+    assert prob.data["prox_g"] == [["zero", 0, 4, True, []]] and prob.data["prox_fstar"] == [["zero", 0, 6, True, []]]
+    prob.fill_variables({"x": np.arange(4.0), "y": np.arange(6.0) + 10})
+    assert np.array_equal(u.val, np.arange(4.0)) and np.array_equal(s2.val, [12, 13, 14, 15]) and np.array_equal(s1.val, [10, 11])
+    x, z = prost.variable(3), prost.variable(5)
+    mp = prost.min_problem([x], [z])
+    mp.add_function(z, prost.function.sum_1d("abs"))
+    mp.add_constraint(x, z, prost.block.zero())
+    mp.finalize()
+    assert mp.data["prox_f"][0][0].endswith("abs") and mp.data["prox_g"][0][0] == "zero" and not mp.data["prox_fstar"]
+    mp.fill_variables({"x": np.ones(3), "z": np.arange(5.0)})
+    assert np.array_equal(z.val, np.arange(5.0))
+
+
+def test_conjugate_epi_quad_defaults_and_options():
+    f = prost.function.conjugate(prost.function.sum_1d("abs", 1, 0.5))(3, 9)
+    assert f[0] == "moreau" and f[1:4] == [3, 9, True] and f[4][0][0] == "elem_operation:1d:abs"    # conjugate.m:7-15
+    e = prost.function.sum_ind_epi_quad(3, False, 1.0, np.zeros(8), 0.0)(0, 12)
+    assert e[0] == "ind_epi_quad" and e[3] is False and e[4][:3] == [4, 3, False]                   # sum_ind_epi_quad.m:17-20
+    b = prost.backend.pdhg()
+    assert b[0] == "pdhg" and b[1]["stepsize"] == "boyd" and b[1]["residual_iter"] == 1 and b[1]["arb_delta"] == 1.05   # pdhg.m:4-14
+    a = prost.backend.admm(rho0=15)
+    assert a[1]["rho0"] == 15 and a[1]["alpha"] == 1.7 and a[1]["cg_max_iter"] == 10                # admm.m:4-13
+    o = prost.options(max_iters=7)
+    assert o["max_iters"] == 7 and o["tol_rel_primal"] == 1e-4 and o["num_cback_calls"] == 10       # options.m:4-14
+    with pytest.raises(ValueError):
+        prost.options(bogus=1)
+    with pytest.raises(ValueError):
+        prost.backend.pdhg(step="alg1")

@@ -1,0 +1,347 @@
+"""GPU parity tests of the PRODUCT path: Python front-end -> prost_command (libprost.so, host C++)
+-> kernel C ABI (libprost_hip.so) -> MI355X, against the CPU oracle, the golden fixtures produced
+by the real reference, and scipy restatements of the reference's own MATLAB tests.
+
+Bar: PDHG iterates bit-exact with the oracle (both sides evaluate the reference's expressions
+without FMA contraction; HIP fp32 divide/sqrt are correctly rounded).  Residual scalars: rel 1e-5
+(the reference reduces in T with an unspecified order; the kernels accumulate in double).
+ADMM: rel 1e-4 on the iterates after 20 iterations (CG step lengths come from reductions).
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+import prost_amd as prost
+from prost_amd import synthetic
+from reference_matrices import spdiags_const, spmat_gradient2d, spmat_gradient3d
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PRECISIONS = [("single", np.float32), ("double", np.float64)]
+STEPS = ["alg1", "alg2", "goldstein", "boyd"]
+
+
+@pytest.fixture(autouse=True)
+def _gpu(hip):
+    prost.set_gpu(0)
+    yield
+    prost.set_precision("double")
+
+
+def run_product(prob, backend, opts, iters):
+    s = prost.Solver(prob, backend, opts)
+    s.iterate(iters)
+    st = s.state()
+    s.destroy()
+    return st
+
+
+def run_oracle(prob, backend, opts, iters, dtype):
+    prob.finalize()
+    b = [backend[0], {k: v for k, v in backend[1].items() if k != "allow_fused"}]
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
+    s.initialize()
+    s.iterate(iters)
+    st = s.state()
+    st.update(s.scalars())
+    return st
+
+
+def assert_same_iterates(st, ost, exact=True, tol=0.0):
+    for v in "xyzw":
+        if exact:
+            assert np.array_equal(st[v], ost[v]), (v, float(np.abs(st[v] - ost[v]).max()))
+        else:
+            scale = max(1.0, float(np.abs(ost[v]).max()))
+            assert float(np.abs(st[v] - ost[v]).max()) <= tol * scale, (v, float(np.abs(st[v] - ost[v]).max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# PDHG
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", STEPS)
+@pytest.mark.parametrize("fused", [True, False])
+def test_pdhg_iterates_match_oracle(precision, dtype, step, fused):
+    prost.set_precision(precision)
+    for (nx, ny, L), res_iter in (((40, 64, 2), 3), ((33, 30, 1), 1), ((16, 1028, 1), 10)):
+        prob, u, q, f = synthetic.rof_problem(nx, ny, L, seed=5)
+        b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5)
+        b[1]["allow_fused"] = fused
+        o = prost.options(max_iters=60, num_cback_calls=0, verbose=False)
+        for k in (1, 2, 11, 50):
+            st = run_product(prob, b, o, k)
+            assert st["path"] == ("pdhg:fused-grad2d" if fused else "pdhg:generic")
+            ost = run_oracle(prob, b, o, k, dtype)
+            assert_same_iterates(st, ost)
+            for name in ("tau", "sigma", "theta"):
+                assert st[name] == ost[name], name
+            for name in ("primal_res", "dual_res", "dual_var_norm", "eps_primal", "eps_dual"):
+                assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", STEPS)
+def test_pdhg_matches_reference_golden_fixture(precision, dtype, step):
+    """product vs tests/golden/pdhg_rof_16x12x2.npz (iterates of the REAL reference backend)"""
+    prost.set_precision(precision)
+    g = np.load(os.path.join(GOLD, "pdhg_rof_16x12x2.npz"))
+    name = np.dtype(dtype).name
+    for res_iter in (1, 10):
+        prob, u, q, _ = synthetic.rof_problem(16, 12, 2, f=g["f"])
+        b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5)
+        o = prost.options(max_iters=50, num_cback_calls=0, verbose=False)
+        for k in (1, 2, 10, 50):
+            st = run_product(prob, b, o, k)
+            key = "%s_%s_r%d_k%d" % (name, step, res_iter, k)
+            for v in "xyzw":
+                assert np.array_equal(st[v].astype(dtype), g[key + "_" + v]), (key, v)
+            exp = g[key + "_scal"]
+            got = np.array([st[n] for n in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual")])
+            assert np.allclose(got, exp, rtol=1e-5, atol=1e-5 if dtype == np.float32 else 1e-12), key
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_pdhg_warm_start_moreau_and_dual(precision, dtype):
+    prost.set_precision(precision)
+    # warm start: the reference's first iteration ignores K^T y0 and K x0 (kty_, kx_prev_ start as zero vectors)
+    prob, u, q, f = synthetic.rof_problem(24, 20, 1, seed=3)
+    x0, y0 = np.linspace(0, 1, prob.ncols), np.linspace(-0.5, 0.5, prob.nrows)
+    for fused in (True, False):
+        b = prost.backend.pdhg(stepsize="boyd", residual_iter=4)
+        b[1]["allow_fused"] = fused
+        o = prost.options(max_iters=30, num_cback_calls=0, verbose=False, x0=x0, y0=y0)
+        for k in (1, 2, 3, 30):
+            assert_same_iterates(run_product(prob, b, o, k), run_oracle(prob, b, o, k, dtype))
+    # prox_gstar given (conjugate): backend wraps it by Moreau (backend_pdhg.cu:236-250) -> generic path
+    prob, u, q, f = synthetic.rof_problem(9, 14, 3, seed=3)
+    prob.data["prox_gstar"] = [prost.function.conjugate(lambda i, c, p=p: p)(0, 0) for p in prob.data["prox_g"]]
+    prob.data["prox_g"] = []
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=4, alg2_gamma=0.3)
+    o = prost.options(max_iters=30, num_cback_calls=0, verbose=False)
+    st = run_product(prob, b, o, 30)
+    assert st["path"] == "pdhg:generic"
+    assert_same_iterates(st, run_oracle(prob, b, o, 30, dtype))
+    # solve_dual (Problem::Dualize, DualLinearOperator); exact negate on both sides
+    prob, u, q, f = synthetic.rof_problem(12, 10, 1, seed=4)
+    b = prost.backend.pdhg(stepsize="alg1", residual_iter=2)
+    o = prost.options(max_iters=20, num_cback_calls=0, verbose=False, solve_dual=True)
+    if precision == "single":          # thrust::negate<float> is exact for T = float
+        assert_same_iterates(run_product(prob, b, o, 20), run_oracle(prob, b, o, 20, dtype))
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_solve_with_callbacks_matches_oracle(precision, dtype):
+    """prost.solve end to end (example_rof_primaldual.m): convergence iteration, result string,
+    callback schedule (linspace, solver.cu:128-135) and filled variables"""
+    prost.set_precision(precision)
+    seen, seen_o = [], []
+    prob, u, q, f = synthetic.rof_problem(64, 64)
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+    r = prost.solve(prob, b, prost.options(max_iters=2000, num_cback_calls=7, verbose=False, interm_cb=lambda it, x, y: seen.append(it) or False))
+    probo, uo, qo, _ = synthetic.rof_problem(64, 64)
+    ro = oracle.solve(probo, b, prost.options(max_iters=2000, num_cback_calls=7, verbose=False, interm_cb=lambda it, x, y: seen_o.append(it) or False), dtype)
+    assert r["result"] == ro["result"] == "Converged."
+    assert int(r["iters"]) == ro["iters"] and seen == seen_o and len(seen) >= 2
+    assert np.array_equal(np.asarray(r["x"]), ro["x"]) and np.array_equal(u.val, uo.val) and np.array_equal(q.val, qo.val)
+    # max_iters reached + callback that stops the run
+    r = prost.solve(prob, b, prost.options(max_iters=25, num_cback_calls=5, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0))
+    assert r["result"] == "Reached maximum iterations." and int(r["iters"]) == 25
+    r = prost.solve(prob, b, prost.options(max_iters=500, num_cback_calls=50, verbose=False, interm_cb=lambda it, x, y: it >= 100))
+    assert r["result"] == "Converged." and 100 <= int(r["iters"]) <= 112
+
+
+# ---------------------------------------------------------------------------------------------
+# mixed operators (sparse + diags + gradient), generic PDHG and ADMM
+# ---------------------------------------------------------------------------------------------
+def tvl1_like_problem(nx, ny, seed=0):
+    """SURVEY 8(d) C4 shape: primal u in R^(2n); v = W u with W = [diag(Ix) diag(Iy)] (block.sparse),
+    g = gradient2d(nx, ny, 2) u; f(v) = sum_1d('abs', 1, b, lambda), f(g) = sum_norm2(4, false, 'abs')"""
+    n = nx * ny
+    Ix = synthetic.rof_image(nx, ny, 1, seed) - 0.5
+    Iy = synthetic.rof_image(nx, ny, 1, seed + 1) - 0.5
+    bvec = synthetic.rof_image(nx, ny, 1, seed + 2) - 0.5
+    W = sp.hstack([sp.diags(Ix), sp.diags(Iy)]).tocsc()
+    u = prost.variable(2 * n)
+    v, g = prost.variable(n), prost.variable(4 * n)
+    prob = prost.min_problem([u], [v, g])
+    prob.add_function(v, prost.function.sum_1d("abs", 1, bvec, 5.0))
+    prob.add_function(g, prost.function.sum_norm2(4, False, "abs"))
+    prob.add_constraint(u, v, prost.block.sparse(W))
+    prob.add_constraint(u, g, prost.block.gradient2d(nx, ny, 2))
+    return prob
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_generic_pdhg_on_mixed_blocks(precision, dtype):
+    prost.set_precision(precision)
+    prob = tvl1_like_problem(24, 18)
+    b = prost.backend.pdhg(stepsize="boyd", residual_iter=5)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    st = run_product(prob, b, o, 60)
+    assert st["path"] == "pdhg:generic"
+    assert_same_iterates(st, run_oracle(prob, b, o, 60, dtype))
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_admm_matches_oracle(precision, dtype):
+    prost.set_precision(precision)
+    prob = tvl1_like_problem(16, 12)
+    b = prost.backend.admm(rho0=1, residual_iter=2)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    tol = 2e-4 if dtype == np.float32 else 1e-9
+    for k in (1, 5, 20):
+        st = run_product(prob, b, o, k)
+        assert st["path"] == "admm:generic"
+        ost = run_oracle(prob, b, o, k, dtype)
+        assert_same_iterates(st, ost, exact=False, tol=tol)
+        assert np.isclose(st["rho"], ost["rho"], rtol=1e-6)
+        for name in ("primal_res", "dual_res"):
+            assert np.isclose(st[name], ost[name], rtol=1e-3, atol=1e-5), name
+    # ROF through ADMM agrees with PDHG at convergence (the two backends solve the same problem)
+    prob, u, q, f = synthetic.rof_problem(32, 32)
+    r1 = prost.solve(prob, prost.backend.admm(rho0=15), prost.options(max_iters=400, num_cback_calls=0, verbose=False, tol_rel_primal=1e-6, tol_rel_dual=1e-6, tol_abs_primal=1e-6, tol_abs_dual=1e-6))
+    x_admm = np.asarray(r1["x"]).copy()
+    r2 = prost.solve(prob, prost.backend.pdhg(stepsize="alg2", alg2_gamma=0.5, residual_iter=10), prost.options(max_iters=3000, num_cback_calls=0, verbose=False, tol_rel_primal=1e-6, tol_rel_dual=1e-6, tol_abs_primal=1e-6, tol_abs_dual=1e-6))
+    assert np.abs(x_admm - np.asarray(r2["x"])).max() < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# eval_linop / eval_prox: the reference's own MATLAB tests through the product
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_eval_linop_reference_tests(precision, dtype):
+    prost.set_precision(precision)
+    rng = np.random.default_rng(0)
+    # test_linop_gradient2d.m / test_linop_gradient3d.m
+    for d3, (nx, ny, L) in ((False, (307, 229, 8)), (True, (151, 291, 7))):
+        k = 3 if d3 else 2
+        blk = (prost.block.gradient3d if d3 else prost.block.gradient2d)(nx, ny, L, False)
+        linop = [blk(0, 0, nx * ny * k * L, nx * ny * L)[0]]
+        K = (spmat_gradient3d if d3 else spmat_gradient2d)(nx, ny, L)
+        inp, inp2 = rng.random(nx * ny * L), rng.random(nx * ny * L * k)
+        x, _, _, _ = prost.eval_linop(linop, inp, False)
+        y, rowsum, colsum, ms = prost.eval_linop(linop, inp2, True)
+        assert np.linalg.norm(x - K @ inp) <= 1e-3 and np.linalg.norm(y - K.T @ inp2) <= 1e-3
+        assert np.all(rowsum == 2) and np.all(colsum == (6 if d3 else 4)) and ms >= 0
+        xo, _, _ = oracle.eval_linop(linop, inp, False, dtype)
+        yo, _, _ = oracle.eval_linop(linop, inp2, True, dtype)
+        assert np.array_equal(x, xo) and np.array_equal(y, yo)
+    # test_linop_diags.m (smaller grid) and test_linop_sparse_zero.m mixed in one operator
+    nrows, ncols = 1200, 331
+    linop, Krows, row = [], [], 0
+    for i in range(2):
+        col, krow = 0, []
+        for j in range(3):
+            if (i + j) % 3 == 0:
+                Kb = sp.random(nrows, ncols, density=0.01, random_state=i * 3 + j)
+                linop.append(prost.block.sparse(Kb)(row, col, nrows, ncols)[0])
+            elif (i + j) % 3 == 1:
+                fac = rng.random(11); ofs = rng.permutation(nrows + ncols - 2)[:11] - nrows + 1
+                Kb = spdiags_const(nrows, ncols, fac, ofs)
+                linop.append(prost.block.diags(nrows, ncols, fac, ofs)(row, col, nrows, ncols)[0])
+            else:
+                Kb = sp.csr_matrix((nrows, ncols))
+                linop.append(prost.block.zero()(row, col, nrows, ncols)[0])
+            krow.append(Kb); col += ncols
+        Krows.append(sp.hstack(krow)); row += nrows
+    K = sp.vstack(Krows).tocsr()
+    inp, inp2 = rng.standard_normal(K.shape[1]), rng.standard_normal(K.shape[0])
+    x, _, _, _ = prost.eval_linop(linop, inp, False)
+    y, rowsum, colsum, _ = prost.eval_linop(linop, inp2, True)
+    tol = 1e-3 if dtype == np.float64 else 1e-2
+    assert np.linalg.norm(x - K @ inp) <= tol and np.linalg.norm(y - K.T @ inp2) <= tol
+    assert np.allclose(rowsum, np.asarray(abs(K).sum(axis=1)).ravel(), rtol=1e-5, atol=1e-6)
+    assert np.allclose(colsum, np.asarray(abs(K).sum(axis=0)).ravel(), rtol=1e-5, atol=1e-6)
+    xo, _, _ = oracle.eval_linop(linop, inp, False, dtype)
+    assert np.array_equal(x, xo)
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_eval_prox_reference_tests(precision, dtype):
+    prost.set_precision(precision)
+    rng = np.random.default_rng(1)
+    # test_prox_sum_norm2.m
+    N, d = 6000, 7
+    P = -2 + 4 * rng.random((N, d))
+    Q, _ = prost.eval_prox(prost.function.sum_norm2(d, False, "ind_leq0", np.ones(N), 1, np.ones(N), 0, 0, 0, 0), P.reshape(-1, order="F"), 1, np.ones(N * d))
+    nrm = np.sqrt((P ** 2).sum(axis=1, keepdims=True))
+    assert np.abs(Q.reshape((N, d), order="F") - np.where(nrm <= 1, P, P / nrm)).max() < 1e-5
+    # test_prox_conjugate.m
+    N = 5000
+    a, b, c, dd, e, y = (rng.random(N) for _ in range(6))
+    tau, Tau = rng.random(), rng.random(N) + 1e-3
+    f = prost.function.sum_1d("abs", a, b, c, dd, e)
+    x, _ = prost.eval_prox(f, y, tau, Tau)
+    x2, _ = prost.eval_prox(prost.function.conjugate(prost.function.conjugate(f)), y, tau, Tau)
+    assert np.abs(x - x2).max() <= (1e-5 if dtype == np.float64 else 2e-3)
+    assert np.array_equal(x, oracle.eval_prox(f, y, tau, Tau, dtype))
+    assert np.array_equal(x2, oracle.eval_prox(prost.function.conjugate(prost.function.conjugate(f)), y, tau, Tau, dtype))
+    # every registered function through the factory, both elem operations
+    for fn in prost.function.FUNCTIONS_1D:
+        for builder in (prost.function.sum_1d(fn, 1.5, b, 2.0, 0.1, 0.2, 0.5 if fn == "lq" else 0.7, 1.1),
+                        prost.function.sum_norm2(5, False, fn, 1.5, 0.3, 2.0, 0.1, 0.2, 0.5 if fn == "lq" else 0.7, 1.1)):
+            got, _ = prost.eval_prox(builder, y * 4 - 2, tau, Tau)
+            exp = oracle.eval_prox(builder, y * 4 - 2, tau, Tau, dtype)
+            if fn == "lq":
+                assert np.allclose(got, exp, rtol=5e-5, atol=5e-5)
+            else:
+                assert np.array_equal(got, exp), fn
+    # ind_epi_quad (no reference test covers it; oracle pinned by ProjectEpiQuadNd goldens)
+    count, dim = 1000, 3
+    arg = rng.uniform(-2, 2, count * dim)
+    eq = prost.function.sum_ind_epi_quad(dim, False, rng.uniform(0.5, 2, count), rng.uniform(-1, 1, count * (dim - 1)), rng.uniform(-1, 1, count))
+    got, _ = prost.eval_prox(eq, arg, 1.0, np.ones(count * dim))
+    assert np.allclose(got, oracle.eval_prox(eq, arg, 1.0, np.ones(count * dim), dtype), rtol=2e-5, atol=2e-5)
+    from prost_amd import _capi
+    with pytest.raises(_capi.ProstError, match="doesn't match size of prox"):
+        _capi.command("eval_prox", [prost.function.sum_1d("abs")(0, 5), np.ones((4, 1)), 1.0, np.ones((4, 1))], nlhs=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE sizes; the oracle is too slow here, so size-independent checks)
+# ---------------------------------------------------------------------------------------------
+def test_fullsize_fused_equals_generic_and_gap_decreases():
+    prost.set_precision("single")
+    n = 2048
+    prob, u, q, f = synthetic.rof_problem(n, n)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    states = {}
+    for fused in (True, False):
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+        b[1]["allow_fused"] = fused
+        states[fused] = run_product(prob, b, o, 25)
+    for v in "xyzw":
+        assert np.array_equal(states[True][v], states[False][v]), v       # two independent kernel paths, identical bits
+    assert states[True]["primal_res"] == states[False]["primal_res"] or np.isclose(states[True]["primal_res"], states[False]["primal_res"], rtol=1e-6)
+
+
+def test_fullsize_4096_adjointness_and_energy():
+    """<Kx, y> = <x, K^T y> at 4096^2 (double), and the ROF energy decreases along PDHG iterates"""
+    prost.set_precision("double")
+    n = 4096
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal(n * n), rng.standard_normal(2 * n * n)
+    linop = [prost.block.gradient2d(n, n, 1)(0, 0, 2 * n * n, n * n)[0]]
+    kx, _, _, _ = prost.eval_linop(linop, x, False)
+    kty, _, _, _ = prost.eval_linop(linop, y, True)
+    assert np.isclose(np.dot(kx, y), np.dot(x, kty), rtol=1e-9)
+    prost.set_precision("single")
+    prob, u, q, f = synthetic.rof_problem(n, n)
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    s = prost.Solver(prob, b, o)
+    energies = []
+    for it in range(4):
+        s.iterate(40)
+        st = s.state()
+        xx = st["x"].reshape(n, n)            # [x][y], y contiguous
+        gx = np.diff(xx, axis=0, append=xx[-1:, :]); gy = np.diff(xx, axis=1, append=xx[:, -1:])
+        energies.append(0.5 * 10.0 * ((st["x"] - f) ** 2).sum() + np.sqrt(gx ** 2 + gy ** 2).sum())
+        assert np.isfinite(st["x"]).all() and np.abs(st["y"]).max() <= np.sqrt(2) + 1e-4      # dual stays in the unit balls
+    s.destroy()
+    assert energies[-1] < energies[0] and energies[3] <= energies[2] * (1 + 1e-6)
