@@ -121,6 +121,7 @@ def test_pdhg_warm_start_moreau_and_dual(precision, dtype):
     prob, u, q, f = synthetic.rof_problem(9, 14, 3, seed=3)
     prob.data["prox_gstar"] = [prost.function.conjugate(lambda i, c, p=p: p)(0, 0) for p in prob.data["prox_g"]]
     prob.data["prox_g"] = []
+    prob.finalize = lambda: prob      # MATLAB's finalize would add a zero prox_g next to prox_gstar (min_max_problem.m:217-227)
     b = prost.backend.pdhg(stepsize="alg2", residual_iter=4, alg2_gamma=0.3)
     o = prost.options(max_iters=30, num_cback_calls=0, verbose=False)
     st = run_product(prob, b, o, 30)
