@@ -33,6 +33,9 @@ LAMBDA = 10.0
 ALG_FLOATS_PER_PIXEL = 11          # primal pass 5 + dual pass 6
 DUAL_PASS_FLOATS = 6
 HBM_PEAK_GBPS = 8000.0
+# HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE,
+# KiB -> bytes), collected in separate rocprofv3 --pmc passes on the same workload: profiles/r01_pmc_*.txt
+TRAFFIC_BYTES_PER_LAUNCH = {}
 
 
 def cpu_baseline(n_img, threads):
@@ -154,14 +157,25 @@ def main():
             "iterates_finite": finite,
         }
         if info["launches"] > 0 and info["dual_kernel_ms"] > 0:
-            alg_bytes = DUAL_PASS_FLOATS * 4 * n * n
+            single = info["primal_kernel_ms"] < 0.2 * info["dual_kernel_ms"]
+            if single:
+                # one kernel = one whole iteration: the per-unit algorithmic figure is the full
+                # 11 floats/pixel of SURVEY 8(d) although the kernel itself only moves 7
+                alg_bytes = ALG_FLOATS_PER_PIXEL * 4 * n * n
+                kname = "fused_iter2d_kernel"
+            else:
+                alg_bytes = DUAL_PASS_FLOATS * 4 * n * n
+                kname = "fused_dual2d_kernel"
             achieved = alg_bytes / 1e9 / (info["dual_kernel_ms"] * 1e-3)
-            out["roofline"] = {"bound": "hbm", "kernel": "fused_dual2d_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(kname),
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": info["dual_kernel_ms"],
-                               "launches_timed": int(info["launches"]),
-                               "primal_pass": {"kernel": "fused_primal2d_kernel", "avg_launch_ms": info["primal_kernel_ms"],
-                                               "achieved": 5 * 4 * n * n / 1e9 / (info["primal_kernel_ms"] * 1e-3)}}
+                               "launches_timed": int(info["launches"])}
+            if single:
+                out["roofline"]["kernel_moves_bytes_per_launch"] = 7 * 4 * n * n
+            else:
+                out["roofline"]["primal_pass"] = {"kernel": "fused_primal2d_kernel", "avg_launch_ms": info["primal_kernel_ms"],
+                                                  "achieved": 5 * 4 * n * n / 1e9 / (info["primal_kernel_ms"] * 1e-3)}
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(n, threads)

@@ -24,13 +24,15 @@ class BackendPDHG : public Backend<T> {
     T arb_delta, arb_tau;
     StepsizeVariant stepsize_variant;
     bool allow_fused;          ///< MI355X addition: set false to force the generic path
+    bool allow_single_kernel;  ///< MI355X addition: one kernel per non-residual iteration (7 instead of 11 floats/pixel)
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
-                allow_fused(true) {}
+                allow_fused(true), allow_single_kernel(true) {}
   };
 
-  explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), res_dev_(nullptr), res_host_(nullptr),
-                                              workspace_(nullptr), iteration_(0) {}
+  explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), res_dev_(nullptr),
+                                              res_host_(nullptr), workspace_(nullptr), iteration_(0) {}
+  bool single_kernel() const { return single_kernel_; }
   virtual ~BackendPDHG();
 
   virtual void Initialize();
@@ -55,10 +57,11 @@ class BackendPDHG : public Backend<T> {
   void UpdateAlg2();                      // :483-488
 
   Options opts_;
-  bool fused_;
+  bool fused_, single_kernel_;
   prost_hip_fused_desc desc_;
   // state: fused keeps x, x_prev, y, y_prev only; generic adds kx, kx_prev, kty, kty_prev, temp
   device_vector<T> x_, y_, x_prev_, y_prev_, temp_, kx_, kty_, kx_prev_, kty_prev_;
+  device_vector<T> y_spare_;   // third dual buffer: single-kernel residual iterations read y, y_prev and write y_new
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
   double* res_host_;       // pinned
   void* workspace_;

@@ -194,6 +194,21 @@ int prost_hip_fused_dual_f32(const prost_hip_fused_desc* desc, float* y_new, con
 int prost_hip_fused_dual_f64(const prost_hip_fused_desc* desc, double* y_new, const double* y, const double* x_new, const double* x_old,
                              double sigma, double theta, int use_kx_prev, double* res_out2, void* workspace, void* stream);
 
+/* One WHOLE PerformIteration (:313-381) in a single kernel: a wavefront computes x_new one column
+ * ahead of y_new in registers, so x_new never makes the HBM round trip between the two passes:
+ * reads y (m), x (n), g-coefficients; writes x_new (n), y_new (m) = 7 floats / pixel / iteration
+ * for ROF instead of 11.  Results are bit-identical to prost_hip_fused_primal + prost_hip_fused_dual.
+ * cols_per_block <= 0 picks the column chunk.  res_out4 != NULL (residual iterations) also streams
+ * y_prev and writes the four sums of :392-431 to res_out4 = {primal diff^2, primal var^2,
+ * dual diff^2, dual var^2} (DEVICE doubles; needs `workspace`); use_kty_prev as in fused_primal. */
+int prost_hip_fused_iteration_supported(const prost_hip_fused_desc* desc, int dtype);
+int prost_hip_fused_iteration_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
+                                  double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols_per_block,
+                                  double* res_out4, void* workspace, void* stream);
+int prost_hip_fused_iteration_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev,
+                                  double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols_per_block,
+                                  double* res_out4, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* ADMM / CGLS building blocks (src/backend/backend_admm.cu, include/prost/cgls.hpp)           */
 /* ------------------------------------------------------------------------------------------ */

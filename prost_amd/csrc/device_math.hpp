@@ -30,6 +30,34 @@ __device__ __forceinline__ double t_acos(double v) { return acos(v); }
 __device__ __forceinline__ double div1(double x, double d) { return d == 1.0 ? x : x / d; }
 __device__ __forceinline__ float div1(float x, float d) { return d == 1.0f ? x : x / d; }
 
+// ---- exact (float)((double)x / D) for a wave-uniform divisor D ------------------------------
+// The reference's fp32 build divides in double wherever a double literal appears (e.g.
+// Function1DSquare: x0 / (1. + tau)).  A hardware fp64 division is ~35 VALU instructions; with a
+// uniform divisor the reciprocal rD = 1/D is computed once per wave and the quotient costs
+// 2 fma + 1 mul.  q1 below is within 1 ulp(double) of RN_double(x/D); rounding q1 to float gives
+// the reference's float unless q1 lies within 2 ulp(double) of a float rounding boundary -- that
+// case (probability ~2^-27 per element) takes the full division, so the result is ALWAYS
+// identical to (float)((double)x / D).
+struct UniformDiv {
+  double D, rD;
+};
+__device__ __forceinline__ UniformDiv make_uniform_div(double D) { UniformDiv u; u.D = D; u.rD = 1.0 / D; return u; }
+__device__ __forceinline__ float div_to_float_exact(float x, const UniformDiv& u) {
+  if (u.D == 1.0) return x;
+  const double xd = (double)x;
+  const double q0 = xd * u.rD;
+  const double rem = __builtin_fma(-q0, u.D, xd);
+  const double q1 = __builtin_fma(rem, u.rD, q0);
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(q1);
+  const int low = (int)(bits & 0x1FFFFFFFull);                 // the 29 mantissa bits a float drops
+  const int bexp = (int)((bits >> 52) & 0x7FF);                  // biased double exponent
+  const bool near_tie = (low >= (1 << 28) - 2) && (low <= (1 << 28) + 2);
+  const bool normal_float = bexp > 1023 - 126 && bexp < 1023 + 127;
+  if (__builtin_expect((near_tie || !normal_float) && q1 != 0.0, 0)) return (float)(xd / u.D);
+  return (float)q1;
+}
+__device__ __forceinline__ double div_to_float_exact(double x, const UniformDiv& u) { return u.D == 1.0 ? x : x / u.D; }
+
 // ---- Function1D* (include/prost/prox/elemop/function_1d.hpp) --------------------------------
 template <class T> __device__ __forceinline__ T f1d_abs(T x0, T tau) {            // :47-60
   if (x0 >= tau) return x0 - tau;
@@ -132,6 +160,21 @@ __device__ __forceinline__ T scaled_prox(int fn, T v, T tau, const T* c) {
   const T prox_arg = (T)(div1((double)(c[0] * (v - c[3] * tau)), den) - (double)c[1]);
   const T step = (T)div1((double)(c[2] * c[0] * c[0] * tau), den);
   return div1((T)(f1d_apply<T, FN>(fn, prox_arg, step, c[5], c[6]) + c[1]), c[0]);
+}
+
+// ElemOperation1D<Function1DSquare> when a, c, e and tau are wave-uniform: the divisor of
+// Function1DSquare, 1. + step, is uniform.  `u` must be make_uniform_div(1. + (double)step) with
+// step = (T)div1((double)(c2*c0*c0*tau), 1. + (double)(tau*c4)); requires c0 != 0 && c2 != 0.
+template <class T>
+__device__ __forceinline__ T square_step(T tau, const T* c) {
+  return (T)div1((double)(c[2] * c[0] * c[0] * tau), 1. + (double)(tau * c[4]));
+}
+template <class T>
+__device__ __forceinline__ T elem_1d_square_uniform(T arg, T tau, const T* c, const UniformDiv& u) {
+  const double den = 1. + (double)(tau * c[4]);
+  const T prox_arg = (T)(div1((double)(c[0] * (arg - c[3] * tau)), den) - (double)c[1]);
+  const T f = div_to_float_exact(prox_arg, u);
+  return div1((T)(f + c[1]), c[0]);
 }
 
 // ElemOperation1D::operator() on one value (elem_operation_1d.hpp:36-59)

@@ -1,0 +1,74 @@
+// fused_common.hpp -- helpers shared by the fused PDHG kernels (kernels_fused*.hip).
+#pragma once
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace prost_hip {
+
+// a lane owns 16 bytes of consecutive rows: float4 / double2
+template <class T> struct VecOf;
+template <> struct VecOf<float> { static constexpr int N = 4; typedef float4 type; };
+template <> struct VecOf<double> { static constexpr int N = 2; typedef double2 type; };
+
+template <class T, int VEC>
+__device__ __forceinline__ void ldv(const T* __restrict__ p, T (&v)[VEC]) {
+  if (VEC == 1) { v[0] = p[0]; return; }
+  typedef typename VecOf<T>::type V;
+  const V t = *reinterpret_cast<const V*>(p);
+  const T* e = reinterpret_cast<const T*>(&t);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) v[j] = e[j];
+}
+template <class T, int VEC>
+__device__ __forceinline__ void stv(T* __restrict__ p, const T (&v)[VEC]) {
+  if (VEC == 1) { p[0] = v[0]; return; }
+  typedef typename VecOf<T>::type V;
+  V t;
+  T* e = reinterpret_cast<T*>(&t);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) e[j] = v[j];
+  *reinterpret_cast<V*>(p) = t;
+}
+
+template <class T>
+struct FusedArgs {
+  size_t nx, ny, L;
+  int cols_per_block;
+  unsigned chunks;            // column chunks per row strip (single-kernel iteration: 1-D tile grid)
+  int g_fn, f_fn;
+  const T* g_ptr[7]; T g_val[7];
+  const T* f_ptr[7]; T f_val[7];
+  T Tval, Sval;
+};
+
+// value of the row above the first row of this lane (row0 - 1): neighbour lane's last element
+template <class T, int VEC>
+__device__ __forceinline__ T row_above(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, bool active) {
+  T up = __shfl_up(v[VEC - 1], 1, kWave);
+  if ((threadIdx.x & (kWave - 1)) == 0 && active && row0 > 0) up = col_base[row0 - 1];
+  return up;
+}
+// value of the row below the last row of this lane (row0 + VEC)
+template <class T, int VEC>
+__device__ __forceinline__ T row_below(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, size_t ny, bool active) {
+  T dn = __shfl_down(v[0], 1, kWave);
+  if ((threadIdx.x & (kWave - 1)) == kWave - 1 && active && row0 + VEC < ny) dn = col_base[row0 + VEC];
+  return dn;
+}
+
+template <class T>
+inline FusedArgs<T> make_fused_args(const prost_hip_fused_desc* d) {
+  FusedArgs<T> a;
+  a.nx = d->nx; a.ny = d->ny; a.L = d->L; a.g_fn = d->g_fn; a.f_fn = d->f_fn;
+  for (int k = 0; k < 7; k++) {
+    a.g_ptr[k] = static_cast<const T*>(d->g_coeff_ptr[k]); a.g_val[k] = (T)d->g_coeff_val[k];
+    a.f_ptr[k] = static_cast<const T*>(d->f_coeff_ptr[k]); a.f_val[k] = (T)d->f_coeff_val[k];
+  }
+  a.Tval = (T)d->T_val; a.Sval = (T)d->S_val;
+  a.cols_per_block = 16;
+  return a;
+}
+
+inline bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
+
+}  // namespace prost_hip

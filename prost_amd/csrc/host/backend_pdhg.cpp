@@ -93,9 +93,11 @@ void BackendPDHG<T>::Initialize() {
   } else prox_fstar_ = this->problem_->prox_fstar();
 
   fused_ = TryFused();
+  single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
+  if (single_kernel_) y_spare_.resize(m);
 
   CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
   CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
@@ -130,6 +132,7 @@ void BackendPDHG<T>::Release() {
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); ev_used_ = 0;
+  y_spare_.clear();
   x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
 }
 
@@ -153,6 +156,25 @@ void BackendPDHG<T>::IterationFused(bool res) {
   };
   // at entry: x_ = x^k, y_ = y^k, y_prev_ = y^(k-1).  The reference's kty_ is K^T y^k except at
   // k = 0 (zero vector, :213); kty_prev_ is K^T y^(k-1) except at k <= 1 (zero vector).
+  if (single_kernel_) {
+    // ONE kernel per iteration, x_new never round-trips through HBM (7 floats/pixel; residual
+    // iterations add the y_prev stream and the four residual sums).  y_new cannot overwrite
+    // y_prev_ on residual iterations (the kernel still reads it), so it goes to y_spare_.
+    stamp();
+    stamp();
+    T* y_out = res ? y_spare_.data() : y_prev_.data();
+    CheckHip(Api<T>::fused_iteration(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_,
+                                     (double)sigma_, (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0,
+                                     iteration_ >= 2 ? 1 : 0, 0, res ? res_dev_ : nullptr, res ? workspace_ : nullptr, s), "fused_iteration");
+    stamp();
+    x_.swap(x_prev_);
+    if (res) { y_prev_.swap(y_spare_); }     // y_prev_ now holds y^(k+1); swapped into y_ below
+    y_.swap(y_prev_);
+    if (res) FinishResiduals();
+    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+    iteration_++;
+    return;
+  }
   stamp();
   CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
                                 iteration_ >= 2 ? 1 : 0, res ? res_dev_ + 2 : nullptr, workspace_, s), "fused_primal");

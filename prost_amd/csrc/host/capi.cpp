@@ -224,6 +224,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       else if (sv == "boyd") o.stepsize_variant = BackendPDHG<T>::kPDHGStepsResidualBoyd;
       else throw Exception("Couldn't recognize step-size variant. Valid options are {alg1,alg2,goldstein,boyd}.");
       if (prost_value_field(d, "allow_fused")) o.allow_fused = GetScalarFromField(d, "allow_fused") > 0.;
+      if (prost_value_field(d, "allow_single_kernel")) o.allow_single_kernel = GetScalarFromField(d, "allow_single_kernel") > 0.;
       return new BackendPDHG<T>(o);
     };
     reg["admm"] = [](const prost_value* d) -> Backend<T>* {                                   // factory.cpp:799-818

@@ -16,60 +16,10 @@
 //     halo column per chunk is < 7 % of that array's traffic;
 //   * residual iterations add the reduction of backend_pdhg.cu:392-431 to the same passes
 //     (wave shuffles + one LDS slot per wave + one partial per workgroup, folded deterministically).
-#include "common.hpp"
-#include "device_math.hpp"
+#include "fused_common.hpp"
 #include "reduce.hpp"
 
 namespace prost_hip {
-
-template <class T> struct VecOf;
-template <> struct VecOf<float> { static constexpr int N = 4; typedef float4 type; };
-template <> struct VecOf<double> { static constexpr int N = 2; typedef double2 type; };
-
-template <class T, int VEC>
-__device__ __forceinline__ void ldv(const T* __restrict__ p, T (&v)[VEC]) {
-  if (VEC == 1) { v[0] = p[0]; return; }
-  typedef typename VecOf<T>::type V;
-  const V t = *reinterpret_cast<const V*>(p);
-  const T* e = reinterpret_cast<const T*>(&t);
-#pragma unroll
-  for (int j = 0; j < VEC; j++) v[j] = e[j];
-}
-template <class T, int VEC>
-__device__ __forceinline__ void stv(T* __restrict__ p, const T (&v)[VEC]) {
-  if (VEC == 1) { p[0] = v[0]; return; }
-  typedef typename VecOf<T>::type V;
-  V t;
-  T* e = reinterpret_cast<T*>(&t);
-#pragma unroll
-  for (int j = 0; j < VEC; j++) e[j] = v[j];
-  *reinterpret_cast<V*>(p) = t;
-}
-
-template <class T>
-struct FusedArgs {
-  size_t nx, ny, L;
-  int cols_per_block;
-  int g_fn, f_fn;
-  const T* g_ptr[7]; T g_val[7];
-  const T* f_ptr[7]; T f_val[7];
-  T Tval, Sval;
-};
-
-// value of the row above the first row of this lane (row0 - 1): neighbour lane's last element
-template <class T, int VEC>
-__device__ __forceinline__ T row_above(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, bool active) {
-  T up = __shfl_up(v[VEC - 1], 1, kWave);
-  if ((threadIdx.x & (kWave - 1)) == 0 && active && row0 > 0) up = col_base[row0 - 1];
-  return up;
-}
-// value of the row below the last row of this lane (row0 + VEC)
-template <class T, int VEC>
-__device__ __forceinline__ T row_below(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, size_t ny, bool active) {
-  T dn = __shfl_down(v[0], 1, kWave);
-  if ((threadIdx.x & (kWave - 1)) == kWave - 1 && active && row0 + VEC < ny) dn = col_base[row0 + VEC];
-  return dn;
-}
 
 // ------------------------------------------------------------------------------------------
 // primal pass, gradient2d:  x_new = prox_g(x - tau T K^T y)   [+ dual residual sums]

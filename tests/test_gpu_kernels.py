@@ -275,3 +275,48 @@ def test_fused_passes_match_unfused_oracle(hip, dtype, shape, fns):
                                               hip.dbl(sigma), hip.dbl(theta), use_kxp, out2.ptr, ws.ptr, None))
         assert np.array_equal(y_new.to_host(), y_ref)
         assert np.allclose(out2.to_host(), pres_ref, rtol=1e-11)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(16, 12, 1), (40, 1028, 1), (33, 256, 2), (70, 252, 1), (5, 2052, 2), (64, 64, 1), (2, 4, 1)])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+def test_single_kernel_iteration_equals_two_passes(hip, dtype, shape, fns):
+    """prost_hip_fused_iteration (7 floats/pixel) == fused_primal + fused_dual (11 floats/pixel), bit for bit,
+    for every column-chunk size (halo columns) and the iteration-0 flags"""
+    nx, ny, L = shape
+    g_fn, f_fn = fns
+    rng = np.random.default_rng(9)
+    n, m = nx * ny * L, 2 * nx * ny * L
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    tau, sigma, theta = 0.9, 1.1, 0.85
+    for g_coeffs in ([1.0, f, 10.0, 0.0, 0.0, 0.3, 0.0], [1.0, 0.5, 10.0, 0.0, 0.0, 0.3, 0.0], [f + 0.5, f, 10.0, f * 0.1, 0.0, 0.3, 0.0]):
+        desc, keep = _fused_desc(hip, dtype, nx, ny, L, g_fn, g_coeffs, f_fn, [1.0, 1.0, 1.0, 0.0, 0.0, 0.3, 0.0], 0.25, 0.5)
+        if not hip.lib().prost_hip_fused_iteration_supported(C.byref(desc), 0 if dtype == np.float32 else 1):
+            assert ny % (4 if dtype == np.float32 else 2) != 0
+            continue
+        dx, dy = dev(hip, x), dev(hip, y)
+        dyp = dev(hip, rng.uniform(-1, 1, m).astype(dtype))
+        ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+        for use_kty, use_kxp, use_ktyp in ((1, 1, 1), (0, 0, 0), (1, 0, 0)):
+            x_ref = hip.DeviceArray.zeros(n, dtype); y_ref = hip.DeviceArray.zeros(m, dtype)
+            rd = hip.DeviceArray.zeros(2, np.float64); rp = hip.DeviceArray.zeros(2, np.float64)
+            hip.check(hip.fn("fused_primal", dtype)(C.byref(desc), x_ref.ptr, dx.ptr, dy.ptr, dyp.ptr, hip.dbl(tau), use_kty, use_ktyp, rd.ptr, ws.ptr, None))
+            hip.check(hip.fn("fused_dual", dtype)(C.byref(desc), y_ref.ptr, dy.ptr, x_ref.ptr, dx.ptr, hip.dbl(sigma), hip.dbl(theta), use_kxp, rp.ptr, ws.ptr, None))
+            res_ref = np.concatenate([rp.to_host(), rd.to_host()])
+            for cols in (0, 1, 3, 8, 1000):
+                x_new = hip.DeviceArray.zeros(n, dtype); y_new = hip.DeviceArray.zeros(m, dtype)
+                hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), x_new.ptr, y_new.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau), hip.dbl(sigma),
+                                                           hip.dbl(theta), use_kty, use_kxp, 0, cols, None, None, None))
+                assert np.array_equal(x_new.to_host(), x_ref.to_host()), (cols, use_kty)
+                assert np.array_equal(y_new.to_host(), y_ref.to_host()), (cols, use_kxp)
+                # residual variant: same iterates + the four residual sums of the two-pass kernels
+                x_new2 = hip.DeviceArray.zeros(n, dtype); y_new2 = hip.DeviceArray.zeros(m, dtype); r4 = hip.DeviceArray.zeros(4, np.float64)
+                hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), x_new2.ptr, y_new2.ptr, dx.ptr, dy.ptr, dyp.ptr, hip.dbl(tau), hip.dbl(sigma),
+                                                           hip.dbl(theta), use_kty, use_kxp, use_ktyp, cols, r4.ptr, ws.ptr, None))
+                assert np.array_equal(x_new2.to_host(), x_ref.to_host()) and np.array_equal(y_new2.to_host(), y_ref.to_host())
+                assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
+                for d_ in (x_new, y_new, x_new2, y_new2, r4):
+                    d_.free()
+            for d_ in (x_ref, y_ref, rd, rp):
+                d_.free()

@@ -53,3 +53,41 @@ if __name__ == "__main__":
     if len(sys.argv) > 2:
         main(N, dtype=np.float64)
         main(N // 2, L=3)
+
+
+def bench_iter(N=4096, iters=200, dtype=np.float32, L=1, cols_list=(0, 4, 6, 8, 12, 16, 18, 24, 32)):
+    hip.require_device()
+    n, m = N * N * L, 2 * N * N * L
+    rng = np.random.default_rng(0)
+    f = hip.DeviceArray.from_host(rng.random(n).astype(dtype))
+    x = [hip.DeviceArray.from_host(rng.random(n).astype(dtype)), hip.DeviceArray.zeros(n, dtype)]
+    y = [hip.DeviceArray.from_host((rng.random(m) - 0.5).astype(dtype)), hip.DeviceArray.zeros(m, dtype)]
+    d = hip.FusedDesc(); d.is3d = 0; d.nx, d.ny, d.L = N, N, L
+    d.g_fn = hip.FN_ID["square"]; d.f_fn = hip.FN_ID["ind_leq0"]
+    gv = [1, 0, 10, 0, 0, 0, 0]; fv = [1, 1, 1, 0, 0, 0, 0]
+    for i in range(7):
+        d.g_coeff_val[i] = gv[i]; d.f_coeff_val[i] = fv[i]
+    d.g_coeff_ptr[1] = f.ptr.value
+    d.T_val, d.S_val = 0.25, 0.5
+    I = hip.fn("fused_iteration", dtype)
+    L_ = hip.lib()
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev: hip.check(L_.prost_hip_event_create(C.byref(e)))
+    esz = np.dtype(dtype).itemsize
+    for cols in cols_list:
+        def run(k):
+            for i in range(k):
+                a, b = i % 2, (i + 1) % 2
+                hip.check(I(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 0, cols, None, None, None))
+        run(10); hip.sync()
+        hip.check(L_.prost_hip_event_record(ev[0], None)); run(iters); hip.check(L_.prost_hip_event_record(ev[1], None))
+        hip.check(L_.prost_hip_event_synchronize(ev[1]))
+        ms = C.c_float(); hip.check(L_.prost_hip_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+        t = ms.value / iters
+        print("single-kernel iteration N=%d L=%d %s cols=%-3d: %.3f ms/iter  %.1f it/s  actual 7-float traffic %.0f GB/s, algorithmic (11 floats) %.0f GB/s"
+              % (N, L, np.dtype(dtype).name, cols, t, 1e3 / t, 7 * N * N * L * esz / 1e9 / (t * 1e-3), 11 * N * N * L * esz / 1e9 / (t * 1e-3)), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 3:
+    bench_iter(int(sys.argv[1]))
+    bench_iter(int(sys.argv[1]), dtype=np.float64, cols_list=(0, 16))
