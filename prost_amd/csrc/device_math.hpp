@@ -177,6 +177,57 @@ __device__ __forceinline__ T elem_1d_square_uniform(T arg, T tau, const T* c, co
   return div1((T)(f + c[1]), c[0]);
 }
 
+// ---- scaled prox with ALL seven coefficients and the step size wave-uniform --------------------
+// Everything that does not depend on the element (the fp64 denominator 1. + tau*e, the step, the
+// divisor of Function1DSquare and its reciprocal) is evaluated ONCE ON THE HOST with the same
+// expression order, and the "is this divisor exactly 1" decisions become kernel-argument booleans
+// (scalar branches) instead of per-lane selects around a 35-instruction fp64 division.
+template <class T>
+struct UniformProx {
+  T c[7];
+  T tau;
+  double den;          // 1. + (double)(tau * c[4])
+  T step;              // (T)((double)(c2*c0*c0*tau) / den)
+  UniformDiv sq;       // 1. + (double)step and its reciprocal (Function1DSquare)
+  bool den_one, a_one, degenerate;   // den == 1 ; c0 == 1 ; c0 == 0 || c2 == 0 (elem_operation_1d.hpp:42-44)
+};
+template <class T>
+__host__ __device__ inline UniformProx<T> make_uniform_prox(const T* c, T tau) {
+  UniformProx<T> u;
+  for (int k = 0; k < 7; k++) u.c[k] = c[k];
+  u.tau = tau;
+  u.den = 1. + (double)(tau * c[4]);
+  u.den_one = u.den == 1.0;
+  const double num = (double)(c[2] * c[0] * c[0] * tau);
+  u.step = (T)(u.den_one ? num : num / u.den);
+  u.sq.D = 1. + (double)u.step;
+  u.sq.rD = 1.0 / u.sq.D;
+  u.a_one = c[0] == (T)1;
+  u.degenerate = c[0] == (T)0 || c[2] == (T)0;
+  return u;
+}
+// == scaled_prox<T, FN>(fn, v, u.tau, c) bit for bit.  c = this element's coefficients; c[0], c[2],
+// c[4] (a, c, e) must be the uniform ones `u` was built from, the others (b, d, alpha, beta) may
+// vary per element.
+template <class T, int FN = -1>
+__device__ __forceinline__ T scaled_prox_u(int fn, T v, const T* c, const UniformProx<T>& u) {
+  const T num = c[0] * (v - c[3] * u.tau);
+  T prox_arg;
+  if (u.den_one) prox_arg = (T)((double)num - (double)c[1]);
+  else prox_arg = (T)((double)num / u.den - (double)c[1]);
+  T r;
+  if ((FN >= 0 ? FN : fn) == PROST_FN_SQUARE) r = div_to_float_exact(prox_arg, u.sq);
+  else r = f1d_apply<T, FN>(fn, prox_arg, u.step, c[5], c[6]);
+  const T s = (T)(r + c[1]);
+  return u.a_one ? s : s / c[0];
+}
+// == elem_1d<T, FN>(fn, arg, u.tau, c) bit for bit (same requirement on c)
+template <class T, int FN = -1>
+__device__ __forceinline__ T elem_1d_u(int fn, T arg, const T* c, const UniformProx<T>& u) {
+  if (u.degenerate) return (arg - u.tau * c[3]) / (1 + u.tau * c[4]);
+  return scaled_prox_u<T, FN>(fn, arg, c, u);
+}
+
 // ElemOperation1D::operator() on one value (elem_operation_1d.hpp:36-59)
 template <class T, int FN = -1>
 __device__ __forceinline__ T elem_1d(int fn, T arg, T tau, const T* c) {

@@ -7,8 +7,10 @@ namespace prost_hip {
 
 // a lane owns 16 bytes of consecutive rows: float4 / double2
 template <class T> struct VecOf;
-template <> struct VecOf<float> { static constexpr int N = 4; typedef float4 type; };
-template <> struct VecOf<double> { static constexpr int N = 2; typedef double2 type; };
+typedef float native_f4 __attribute__((ext_vector_type(4)));
+typedef double native_d2 __attribute__((ext_vector_type(2)));
+template <> struct VecOf<float> { static constexpr int N = 4; typedef float4 type; typedef native_f4 native; };
+template <> struct VecOf<double> { static constexpr int N = 2; typedef double2 type; typedef native_d2 native; };
 
 template <class T, int VEC>
 __device__ __forceinline__ void ldv(const T* __restrict__ p, T (&v)[VEC]) {
@@ -28,6 +30,26 @@ __device__ __forceinline__ void stv(T* __restrict__ p, const T (&v)[VEC]) {
 #pragma unroll
   for (int j = 0; j < VEC; j++) e[j] = v[j];
   *reinterpret_cast<V*>(p) = t;
+}
+
+// streaming (non-temporal) forms: the PDHG vectors are touched once per iteration and the working
+// set (470 MB at 4096^2) exceeds every cache level
+template <class T, int VEC>
+__device__ __forceinline__ void ldv_nt(const T* __restrict__ p, T (&v)[VEC]) {
+  if (VEC == 1) { v[0] = __builtin_nontemporal_load(p); return; }
+  typedef typename VecOf<T>::native V;
+  const V t = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#pragma unroll
+  for (int j = 0; j < VEC; j++) v[j] = t[j];
+}
+template <class T, int VEC>
+__device__ __forceinline__ void stv_nt(T* __restrict__ p, const T (&v)[VEC]) {
+  if (VEC == 1) { __builtin_nontemporal_store(v[0], p); return; }
+  typedef typename VecOf<T>::native V;
+  V t;
+#pragma unroll
+  for (int j = 0; j < VEC; j++) t[j] = v[j];
+  __builtin_nontemporal_store(t, reinterpret_cast<V*>(p));
 }
 
 template <class T>

@@ -20,6 +20,8 @@
 #include "fused_common.hpp"
 #include "reduce.hpp"
 
+#include <cstdlib>
+
 namespace prost_hip {
 
 // GMASK: bit k set = g-coefficient k is a per-pixel vector (loaded with the column); the other
@@ -34,10 +36,11 @@ struct ColIn {            // everything loaded for one column
   T p1[RES ? LCH : 1][RES ? VEC : 1], p2[RES ? LCH : 1][RES ? VEC : 1], upp[RES ? LCH : 1];   // y_prev (RES only)
 };
 
-template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES>
+template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, int VAR>
 __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
                                                              const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma, T theta,
+                                                             UniformProx<T> ug, UniformProx<T> uf,
                                                              bool use_kty, bool use_kx_prev, bool use_kty_prev,
                                                              double* __restrict__ partial) {
   const size_t nx = a.nx, ny = a.ny;
@@ -61,9 +64,10 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
   // Function1DSquare with scalar a, c, e: its fp64 divisor 1. + step is wave-uniform -> exact
   // reciprocal-based quotient instead of a ~35-instruction fp64 division per pixel (device_math.hpp)
-  constexpr bool kUniformSquare = GFN == PROST_FN_SQUARE && (GMASK & 0x15) == 0;
-  const bool sq_ok = kUniformSquare && a.g_val[0] != 0 && a.g_val[2] != 0;
-  const UniformDiv sq_div = make_uniform_div(1. + (double)square_step<T>(tauT, a.g_val));
+  // scalar a, c, e of prox_g (always the case for prox_f* here): every element-independent part of
+  // the scaled prox (fp64 denominators, step, reciprocal of Function1DSquare's divisor) was
+  // evaluated on the host into ug / uf; see UniformProx in device_math.hpp
+  constexpr bool kUniformG = (GMASK & 0x15) == 0;
   double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
   typedef ColIn<T, VEC, LCH, GMASK, RES> Col;
@@ -71,9 +75,8 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
     for (int l = 0; l < LCH; l++) {
       const size_t o = l * P + c * ny + row0;
-      ldv<T, VEC>(y + o, in.y1[l]);
-      ldv<T, VEC>(y + N + o, in.y2[l]);
-      ldv<T, VEC>(x + o, in.x[l]);
+      if (VAR & 2) { ldv_nt<T, VEC>(y + o, in.y1[l]); ldv_nt<T, VEC>(y + N + o, in.y2[l]); ldv_nt<T, VEC>(x + o, in.x[l]); }
+      else { ldv<T, VEC>(y + o, in.y1[l]); ldv<T, VEC>(y + N + o, in.y2[l]); ldv<T, VEC>(x + o, in.x[l]); }
       // issued together with the column so that the primal step never waits on a second round trip
       in.up[l] = (lane == 0 && row0 > 0) ? y[N + o - 1] : (T)0;
       if (RES) {
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
       for (int k = 0; k < 7; k++) {
         if ((GMASK >> k) & 1) {
-          if (a.g_ptr[k]) ldv<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]);
+          if (a.g_ptr[k]) { if (VAR & 2) ldv_nt<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); else ldv<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); }
           else {
 #pragma unroll
             for (int j = 0; j < VEC; j++) in.gc[l][slot_of(GMASK, k)][j] = a.g_val[k];
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         T cf[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? in.gc[l][slot_of(GMASK, k)][j] : a.g_val[k];
-        if (kUniformSquare && sq_ok) xn[l][j] = elem_1d_square_uniform<T>(arg, tauT, cf, sq_div);
+        if (kUniformG) xn[l][j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
         else xn[l][j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, cf);
         if (RES) {                                          // dual_residual_transform (backend_pdhg.cu:73-94)
           const int jj = RES ? j : 0, ll = RES ? l : 0;
@@ -150,19 +153,19 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
   primal_col(xa, cur, halo, xa > 0, true, xn_c);            // shuffles inside: every lane takes part
   if (owner) {
 #pragma unroll
-    for (int l = 0; l < LCH; l++) stv<T, VEC>(x_new + l * P + xa * ny + row0, xn_c[l]);
+    for (int l = 0; l < LCH; l++) { if (VAR & 1) stv_nt<T, VEC>(x_new + l * P + xa * ny + row0, xn_c[l]); else stv<T, VEC>(x_new + l * P + xa * ny + row0, xn_c[l]); }
   }
 
   for (size_t c = xa; c < xb; c++) {
     const bool has_next = c + 1 < nx;
     Col pre;                                                  // prefetch column c+2 while column c+1 / c are processed
     const bool has_pre = c + 2 < nx && c + 1 < xb;
-    if (active && has_pre) load_col(c + 2, pre);
+    if (!(VAR & 4) && active && has_pre) load_col(c + 2, pre);
     if (has_next) {
       primal_col(c + 1, nxt, cur, true, c + 1 < xb, xn_n);
       if (owner && c + 1 < xb) {
 #pragma unroll
-        for (int l = 0; l < LCH; l++) stv<T, VEC>(x_new + l * P + (c + 1) * ny + row0, xn_n[l]);
+        for (int l = 0; l < LCH; l++) { if (VAR & 1) stv_nt<T, VEC>(x_new + l * P + (c + 1) * ny + row0, xn_n[l]); else stv<T, VEC>(x_new + l * P + (c + 1) * ny + row0, xn_n[l]); }
       }
     }
     // ---- dual step of column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77) ----
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         for (int i = 0; i < 2 * LCH; i++) norm += arg[i] * arg[i];
         if (norm > 0) {
           norm = t_sqrt(norm);
-          const T pr = scaled_prox<T, FFN>(a.f_fn, norm, sigS, a.f_val);
+          const T pr = scaled_prox_u<T, FFN>(a.f_fn, norm, a.f_val, uf);
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) out[i][j] = pr * arg[i] / norm;
         } else {
@@ -214,13 +217,14 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
       }
 #pragma unroll
       for (int l = 0; l < LCH; l++) {
-        stv<T, VEC>(y_new + l * P + c * ny + row0, out[l]);
-        stv<T, VEC>(y_new + N + l * P + c * ny + row0, out[LCH + l]);
+        if (VAR & 1) { stv_nt<T, VEC>(y_new + l * P + c * ny + row0, out[l]); stv_nt<T, VEC>(y_new + N + l * P + c * ny + row0, out[LCH + l]); }
+        else { stv<T, VEC>(y_new + l * P + c * ny + row0, out[l]); stv<T, VEC>(y_new + N + l * P + c * ny + row0, out[LCH + l]); }
       }
     }
     // shift the pipeline
     cur = nxt;
-    if (has_pre) nxt = pre;
+    if (VAR & 4) { if (active && has_pre) load_col(c + 2, nxt); }     // no register prefetch: load after use
+    else if (has_pre) nxt = pre;
 #pragma unroll
     for (int l = 0; l < LCH; l++)
 #pragma unroll
@@ -298,11 +302,19 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   double* partial = static_cast<double*>(ws);
   int mask = 0;
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k]) mask |= 1 << k;
+  // host-side evaluation of everything element-independent, in the kernels' own expression order
+  const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
+  const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   // specialised instance for the ROF shape (square / ind_leq0, only b = f per pixel); generic otherwise
   const bool fast = d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2;
-#define GO(LCHv, G, F, M, R) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
-#define GO_RES(LCHv, G, F, M) do { if (out4) GO(LCHv, G, F, M, true); else GO(LCHv, G, F, M, false); } while (0)
-  if (d->L == 1) { if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(1, -1, -1, 0); else GO_RES(1, -1, -1, 0x7F); }
+#define GO(LCHv, G, F, M, R, VARv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, VARv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO_RES(LCHv, G, F, M) do { if (out4) GO(LCHv, G, F, M, true, 1); else GO(LCHv, G, F, M, false, 1); } while (0)
+#define GO_VAR(VARv) case VARv: if (out4) GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true, VARv); else GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, false, VARv); break;
+  // tuning knob (bit 0: non-temporal stores [default, +4 % at 4096^2], bit 1: non-temporal loads [-15 %],
+  // bit 2: no register prefetch [-8 %]); measured with tools/variant_sweep.sh
+  static const int variant = getenv("PROST_HIP_ITER_VARIANT") ? atoi(getenv("PROST_HIP_ITER_VARIANT")) : 1;
+  if (d->L == 1 && fast && sizeof(T) == 4) { switch (variant) { GO_VAR(0) GO_VAR(1) GO_VAR(2) GO_VAR(3) GO_VAR(4) GO_VAR(5) GO_VAR(6) GO_VAR(7) default: set_error("bad variant"); return 1; } }
+  else if (d->L == 1) { if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(1, -1, -1, 0); else GO_RES(1, -1, -1, 0x7F); }
   else { if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(2, -1, -1, 0); else GO_RES(2, -1, -1, 0x7F); }
 #undef GO_RES
 #undef GO
