@@ -347,18 +347,22 @@ static int run_dual(const prost_hip_fused_desc* d, T* y_new, const T* y, const T
 using namespace prost_hip;
 
 extern "C" {
-int prost_hip_fused_supported(const prost_hip_fused_desc* desc, int dtype) { (void)dtype; return desc_ok(desc) ? 1 : 0; }
+int prost_hip_fused_supported(const prost_hip_fused_desc* desc, int dtype) { (void)dtype; return (desc_ok(desc) || fused3d_desc_ok(desc)) ? 1 : 0; }
 
 int prost_hip_fused_primal_f32(const prost_hip_fused_desc* d, float* x_new, const float* x, const float* y, const float* y_prev, double tau, int use_kty, int use_kty_prev, double* out2, void* ws, void* s) {
+  if (d && d->is3d) return run_primal3d<float>(d, x_new, x, y, y_prev, tau, use_kty, use_kty_prev, out2, ws, s);
   return run_primal<float>(d, x_new, x, y, y_prev, tau, use_kty, use_kty_prev, out2, ws, s);
 }
 int prost_hip_fused_primal_f64(const prost_hip_fused_desc* d, double* x_new, const double* x, const double* y, const double* y_prev, double tau, int use_kty, int use_kty_prev, double* out2, void* ws, void* s) {
+  if (d && d->is3d) return run_primal3d<double>(d, x_new, x, y, y_prev, tau, use_kty, use_kty_prev, out2, ws, s);
   return run_primal<double>(d, x_new, x, y, y_prev, tau, use_kty, use_kty_prev, out2, ws, s);
 }
 int prost_hip_fused_dual_f32(const prost_hip_fused_desc* d, float* y_new, const float* y, const float* xn, const float* xo, double sigma, double theta, int use_kx_prev, double* out2, void* ws, void* s) {
+  if (d && d->is3d) return run_dual3d<float>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, s);
   return run_dual<float>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, s);
 }
 int prost_hip_fused_dual_f64(const prost_hip_fused_desc* d, double* y_new, const double* y, const double* xn, const double* xo, double sigma, double theta, int use_kx_prev, double* out2, void* ws, void* s) {
+  if (d && d->is3d) return run_dual3d<double>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, s);
   return run_dual<double>(d, y_new, y, xn, xo, sigma, theta, use_kx_prev, out2, ws, s);
 }
 }  // extern "C"

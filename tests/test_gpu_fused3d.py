@@ -1,0 +1,89 @@
+"""Fused gradient3d passes (BASELINE config 3: volumetric TV) against the CPU oracle: kernel level
+(one pass == the reference's unfused sequence, bit-exact) and solver level (PDHG iterates)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+import prost_amd as prost
+from prost_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DTYPES = [np.float32, np.float64]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(6, 8, 1), (5, 12, 4), (20, 1028, 3), (9, 7, 2), (33, 64, 5)])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+def test_fused3d_passes_match_unfused_oracle(hip, dtype, shape, fns):
+    nx, ny, L = shape
+    g_fn, f_fn = fns
+    rng = np.random.default_rng(3)
+    n, m = nx * ny * L, 3 * nx * ny * L
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    y_prev = rng.uniform(-1, 1, m).astype(dtype); x_old = rng.uniform(0, 1, n).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    tau, sigma, theta = dtype(0.9), dtype(1.1), dtype(0.85)
+    Tval, Sval = dtype(1.0 / 6.0), dtype(0.5)
+    g_coeffs = [1.0, f, 10.0, 0.0, 0.0, 0.3, 0.0]
+    f_coeffs = [1.0, 1.0, 1.0, 0.0, 0.0, 0.3, 0.0]
+    d = hip.FusedDesc(); d.is3d = 1; d.nx, d.ny, d.L = nx, ny, L
+    d.g_fn = hip.FN_ID[g_fn]; d.f_fn = hip.FN_ID[f_fn]
+    gp, gv, k1 = hip.coeff_args(g_coeffs, dtype, n)
+    fp, fv, k2 = hip.coeff_args(f_coeffs, dtype, n)
+    for i in range(7):
+        d.g_coeff_ptr[i] = gp[i]; d.g_coeff_val[i] = gv[i]; d.f_coeff_ptr[i] = fp[i]; d.f_coeff_val[i] = fv[i]
+    d.T_val, d.S_val = float(Tval), float(Sval)
+    assert hip.lib().prost_hip_fused_supported(C.byref(d), 0) == 1
+    ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    Td, Sd = np.full(n, Tval, dtype), np.full(m, Sval, dtype)
+    dx, dy, dyp, dxo = (hip.DeviceArray.from_host(v) for v in (x, y, y_prev, x_old))
+    for use_kty, use_prev in ((1, 1), (0, 0), (1, 0)):
+        kty = oracle.grad3d(y, nx, ny, L, adjoint=True) if use_kty else np.zeros(n, dtype)
+        ktyp = oracle.grad3d(y_prev, nx, ny, L, adjoint=True) if use_prev else np.zeros(n, dtype)
+        temp = (x - tau * Td * kty).astype(dtype)
+        x_ref = oracle.prox_elem(0, g_fn, temp, Td, tau, n, 1, False, g_coeffs)
+        sq = np.sqrt(Td)
+        w_hat = ((x - x_ref) / (tau * sq) - sq * ktyp).astype(dtype); diff = (w_hat + sq * kty).astype(dtype)
+        dres = np.array([np.sum((diff * diff).astype(np.float64)), np.sum((w_hat * w_hat).astype(np.float64))])
+        x_new = hip.DeviceArray.zeros(n, dtype); out2 = hip.DeviceArray.zeros(2, np.float64)
+        hip.check(hip.fn("fused_primal", dtype)(C.byref(d), x_new.ptr, dx.ptr, dy.ptr, dyp.ptr, hip.dbl(tau), use_kty, use_prev, out2.ptr, ws.ptr, None))
+        assert np.array_equal(x_new.to_host(), x_ref)
+        assert np.allclose(out2.to_host(), dres, rtol=1e-11)
+    for use_kxp in (1, 0):
+        kx = oracle.grad3d(x, nx, ny, L)
+        kxp = oracle.grad3d(x_old, nx, ny, L) if use_kxp else np.zeros(m, dtype)
+        temp = (y + sigma * Sd * ((1 + theta) * kx - theta * kxp)).astype(dtype)
+        y_ref = oracle.prox_elem(1, f_fn, temp, Sd, sigma, n, 3, False, f_coeffs)
+        sq = np.sqrt(Sd)
+        z_hat = ((y - y_ref) / (sigma * sq) + sq * ((1 + theta) * kx - theta * kxp)).astype(dtype); diff = (z_hat - sq * kx).astype(dtype)
+        pres = np.array([np.sum((diff * diff).astype(np.float64)), np.sum((z_hat * z_hat).astype(np.float64))])
+        y_new = hip.DeviceArray.zeros(m, dtype); out2 = hip.DeviceArray.zeros(2, np.float64)
+        hip.check(hip.fn("fused_dual", dtype)(C.byref(d), y_new.ptr, dy.ptr, dx.ptr, dxo.ptr, hip.dbl(sigma), hip.dbl(theta), use_kxp, out2.ptr, ws.ptr, None))
+        assert np.array_equal(y_new.to_host(), y_ref)
+        assert np.allclose(out2.to_host(), pres, rtol=1e-11)
+    hip.sync()
+
+
+@pytest.mark.parametrize("precision,dtype", [("single", np.float32), ("double", np.float64)])
+@pytest.mark.parametrize("step", ["alg2", "boyd"])
+def test_tv3d_pdhg_iterates_match_oracle(hip, precision, dtype, step):
+    prost.set_gpu(0)
+    prost.set_precision(precision)
+    try:
+        for (nx, ny, L) in ((12, 16, 5), (7, 1028, 2)):
+            prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, seed=2)
+            for fused in (True, False):
+                b = prost.backend.pdhg(stepsize=step, residual_iter=3, alg2_gamma=0.5)
+                b[1]["allow_fused"] = fused
+                o = prost.options(max_iters=40, num_cback_calls=0, verbose=False)
+                s = prost.Solver(prob, b, o); s.iterate(40); st = s.state(); s.destroy()
+                assert st["path"] == ("pdhg:fused-grad3d" if fused else "pdhg:generic")
+                bo = prost.backend.pdhg(stepsize=step, residual_iter=3, alg2_gamma=0.5)
+                so = oracle.Solver(prob.data, prob.nrows, prob.ncols, bo, o, dtype); so.initialize(); so.iterate(40)
+                ost = so.state()
+                for v in "xyzw":
+                    assert np.array_equal(st[v], ost[v]), (v, fused, float(np.abs(st[v] - ost[v]).max()))
+    finally:
+        prost.set_precision("double")
