@@ -14,8 +14,9 @@ scaling; the 4 residual sums are all-reduced over RCCL every residual iteration 
 the global stopping criterion.  value = N * K / max-over-ranks(time).
 
 Inputs are resident in HBM before the timed region.  The JSON line carries
-  roofline     : dominant kernel (fused dual pass, 6 of the 11 floats/pixel/iteration), algorithmic
-                 bytes / mean launch time measured with HIP events on the solver's stream
+  roofline     : dominant kernel = fused_iter2d_kernel, one launch = one whole iteration: algorithmic
+                 bytes (11 floats/pixel) / mean launch time measured with HIP events on
+                 the solver's stream (one iteration in eight is sampled); the kernel itself moves 7
   cpu_baseline : the CPU oracle (port of the reference path) timed on this host's cores on a bounded
                  sample of the same workload
 """
@@ -35,7 +36,7 @@ DUAL_PASS_FLOATS = 6
 HBM_PEAK_GBPS = 8000.0
 # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE,
 # KiB -> bytes), collected in separate rocprofv3 --pmc passes on the same workload: profiles/r01_pmc_*.txt
-TRAFFIC_BYTES_PER_LAUNCH = {}
+TRAFFIC_BYTES_PER_LAUNCH = {"fused_iter2d_kernel": (2 * 162173 + 199683) * 1024}   # profiles/r01_pmc_traffic.txt
 
 
 def cpu_baseline(n_img, max_threads):
