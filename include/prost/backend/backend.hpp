@@ -2,6 +2,8 @@
 #ifndef PROST_BACKEND_BACKEND_HPP_
 #define PROST_BACKEND_BACKEND_HPP_
 #include <cmath>
+#include <string>
+#include <vector>
 
 #include "prost/problem.hpp"
 #include "prost/solver.hpp"
@@ -20,6 +22,12 @@ class Backend {
 
   virtual void Initialize() = 0;
   virtual void PerformIteration() = 0;
+  /// MI355X addition: run 1 <= k <= budget iterations and return k.  `budget` counts the iterations
+  /// up to AND INCLUDING the next one after which the caller looks at the backend's state (solution
+  /// read-out, callback, end of the run).  A backend may only fuse iterations whose intermediate
+  /// state nobody observes: it returns k > 1 only if k < budget, so the observed iteration itself is
+  /// always executed by PerformIteration().  Default: one iteration.
+  virtual int PerformIterations(int budget) { (void)budget; PerformIteration(); return 1; }
   virtual void Release() = 0;
 
   virtual void current_solution(std::vector<T>& primal_sol, std::vector<T>& dual_sol) = 0;
@@ -42,10 +50,17 @@ class Backend {
   /// multi-GPU batches: the 4 residual sums are all-reduced over `comm` (an RCCL communicator made
   /// by prost_hip_comm_create) so every rank takes identical stopping / step-size decisions.
   void SetCommunicator(void* comm, size_t global_nrows, size_t global_ncols) { comm_ = comm; global_nrows_ = global_nrows; global_ncols_ = global_ncols; }
-  /// record HIP events around the two dominant kernels of every iteration (bench roofline figure)
+  /// record HIP events around a sample of the iteration kernels' launches (bench roofline figure)
   void EnableKernelTiming(bool on) { time_kernels_ = on; }
-  /// mean milliseconds per launch since the last call; returns false if nothing was recorded
-  virtual bool KernelTimes(double* primal_ms, double* dual_ms, size_t* launches) { (void)primal_ms; (void)dual_ms; (void)launches; return false; }
+  struct KernelTime {
+    std::string name;            ///< kernel symbol as rocprofv3 --kernel-trace reports it
+    double avg_ms;               ///< mean launch duration over the sampled launches
+    size_t sampled;              ///< launches timed (one in eight of each kind)
+    size_t launches;             ///< all launches of this kind while timing was enabled
+    int iterations_per_launch;   ///< PDHG iterations one launch performs (0: a fraction -- one of two passes)
+  };
+  /// mean milliseconds per launch of every kernel kind sampled since the last call
+  virtual void KernelTimes(std::vector<KernelTime>& out) { out.clear(); }
   /// short description of the execution path ("pdhg:fused-grad2d", "pdhg:generic", "admm:generic")
   virtual std::string path() const = 0;
 

@@ -25,23 +25,25 @@ class BackendPDHG : public Backend<T> {
     StepsizeVariant stepsize_variant;
     bool allow_fused;          ///< MI355X addition: set false to force the generic path
     bool allow_single_kernel;  ///< MI355X addition: one kernel per non-residual iteration (7 instead of 11 floats/pixel)
+    bool allow_pair_kernel;    ///< MI355X addition: two iterations per launch where nobody observes the one in between
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
-                allow_fused(true), allow_single_kernel(true) {}
+                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true) {}
   };
 
-  explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), res_dev_(nullptr),
+  explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), pair_kernel_(false), res_dev_(nullptr),
                                               res_host_(nullptr), workspace_(nullptr), iteration_(0) {}
   bool single_kernel() const { return single_kernel_; }
   virtual ~BackendPDHG();
 
   virtual void Initialize();
   virtual void PerformIteration();
+  virtual int PerformIterations(int budget);
   virtual void Release();
   virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
   virtual size_t gpu_mem_amount() const;
-  virtual bool KernelTimes(double* primal_ms, double* dual_ms, size_t* launches);
+  virtual void KernelTimes(std::vector<typename Backend<T>::KernelTime>& out);
   virtual std::string path() const;
 
   T tau() const { return tau_; }
@@ -53,11 +55,13 @@ class BackendPDHG : public Backend<T> {
   bool TryFused();
   void IterationFused(bool residual_iteration);
   void IterationGeneric(bool residual_iteration);
+  void IterationPair();                   // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
+  bool is_residual_iteration(size_t k) const { return k == 0 || (k % (size_t)opts_.residual_iter) == 0; }   // backend_pdhg.cu:389
   void FinishResiduals();                 // all-reduce, D2H, sqrt, step-size rules (backend_pdhg.cu:433-476)
   void UpdateAlg2();                      // :483-488
 
   Options opts_;
-  bool fused_, single_kernel_;
+  bool fused_, single_kernel_, pair_kernel_;
   prost_hip_fused_desc desc_;
   // state: fused keeps x, x_prev, y, y_prev only; generic adds kx, kx_prev, kty, kty_prev, temp
   device_vector<T> x_, y_, x_prev_, y_prev_, temp_, kx_, kty_, kx_prev_, kty_prev_;
@@ -70,9 +74,13 @@ class BackendPDHG : public Backend<T> {
   int arb_l_, arb_u_;
   T arg_alpha_;
   std::vector<shared_ptr<Prox<T>>> prox_g_, prox_fstar_;
-  // kernel timing
-  std::vector<void*> ev_;
-  size_t ev_used_ = 0;
+  // kernel timing: event pairs around one launch in eight of every kernel kind
+  enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelKinds };
+  bool BeginSample(int kind);
+  void EndSample(bool sampled);
+  std::vector<void*> ev_;          // pool, two events per sample
+  std::vector<int> ev_kind_;       // kind of sample i (events 2i, 2i+1)
+  size_t launches_[kKernelKinds] = {0, 0, 0, 0, 0};
 };
 
 }  // namespace prost

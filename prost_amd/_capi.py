@@ -275,8 +275,11 @@ class Solver:
         self.handle = command("solver_create", [prob.data, prob.nrows, prob.ncols, backend, _opts_struct(opts)], nlhs=1)[0]
 
     def iterate(self, iters, time_kernels=False):
-        return command("solver_iterate", [self.handle, int(iters), bool(time_kernels)], nlhs=1,
-                       struct_fields=("ms", "primal_kernel_ms", "dual_kernel_ms", "launches"))[0]
+        """-> {"ms": wall time, "kernels": {kernel name: {"avg_ms", "sampled", "launches", "iterations_per_launch"}}}
+        (kernel launch times from HIP events on the solver's stream; one launch in eight is sampled)"""
+        info = command("solver_iterate", [self.handle, int(iters), bool(time_kernels)], nlhs=1, struct_fields=("ms", "kernels"))[0]
+        info["kernels"] = {k[0]: {"avg_ms": k[1], "sampled": int(k[2]), "iterations_per_launch": int(k[3]), "launches": int(k[4])} for k in info.get("kernels", [])}
+        return info
 
     def state(self):
         st = command("solver_state", [self.handle], nlhs=1, struct_fields=_STATE_FIELDS)[0]

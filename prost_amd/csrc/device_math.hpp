@@ -57,6 +57,36 @@ __device__ __forceinline__ float div_to_float_exact(float x, const UniformDiv& u
   return (float)q1;
 }
 __device__ __forceinline__ double div_to_float_exact(double x, const UniformDiv& u) { return u.D == 1.0 ? x : x / u.D; }
+// the same for VEC values with straight-line code: one (rarely taken) branch per vector instead of
+// one per element, so the independent chains of the elements interleave.  D != 1 required.
+template <int VEC>
+__device__ __forceinline__ void div_to_float_exact_vec(const float (&x)[VEC], const UniformDiv& u, float (&out)[VEC]) {
+  double q1[VEC];
+  bool slow = false;
+#pragma unroll
+  for (int j = 0; j < VEC; j++) {
+    const double xd = (double)x[j];
+    const double q0 = xd * u.rD;
+    const double rem = __builtin_fma(-q0, u.D, xd);
+    q1[j] = __builtin_fma(rem, u.rD, q0);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(q1[j]);
+    const int low = (int)(bits & 0x1FFFFFFFull);
+    const int bexp = (int)((bits >> 52) & 0x7FF);
+    const bool near_tie = (low >= (1 << 28) - 2) && (low <= (1 << 28) + 2);
+    const bool normal_float = bexp > 1023 - 126 && bexp < 1023 + 127;
+    slow = slow || ((near_tie || !normal_float) && q1[j] != 0.0);
+    out[j] = (float)q1[j];
+  }
+  if (__builtin_expect(slow, 0)) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) out[j] = (float)((double)x[j] / u.D);
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void div_to_float_exact_vec(const double (&x)[VEC], const UniformDiv& u, double (&out)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j++) out[j] = x[j] / u.D;
+}
 
 // ---- Function1D* (include/prost/prox/elemop/function_1d.hpp) --------------------------------
 template <class T> __device__ __forceinline__ T f1d_abs(T x0, T tau) {            // :47-60
@@ -213,7 +243,10 @@ template <class T, int FN = -1>
 __device__ __forceinline__ T scaled_prox_u(int fn, T v, const T* c, const UniformProx<T>& u) {
   const T num = c[0] * (v - c[3] * u.tau);
   T prox_arg;
-  if (u.den_one) prox_arg = (T)((double)num - (double)c[1]);
+  // den == 1: (T)((double)num - (double)b) == num - b in T.  For T = float this is Figueroa's theorem
+  // (double rounding through a format of >= 2p+2 = 50 bits is innocuous for +, -, *, /, sqrt of
+  // p = 24-bit operands; double has 53), so no fp64 instruction is needed.
+  if (u.den_one) prox_arg = num - c[1];
   else prox_arg = (T)((double)num / u.den - (double)c[1]);
   T r;
   if ((FN >= 0 ? FN : fn) == PROST_FN_SQUARE) r = div_to_float_exact(prox_arg, u.sq);
@@ -226,6 +259,32 @@ template <class T, int FN = -1>
 __device__ __forceinline__ T elem_1d_u(int fn, T arg, const T* c, const UniformProx<T>& u) {
   if (u.degenerate) return (arg - u.tau * c[3]) / (1 + u.tau * c[4]);
   return scaled_prox_u<T, FN>(fn, arg, c, u);
+}
+
+// ---- scaled prox with two host-decided shortcuts (generic kernels, per-element step sizes) -----
+// e_zero: coefficient e is the scalar 0  -> the fp64 denominator 1. + tau*e is exactly 1
+// a_one : coefficient a is the scalar 1  -> the final division by a is the identity
+// Both are kernel-argument booleans (scalar branches); with them false this is scaled_prox.
+template <class T, int FN = -1>
+__device__ __forceinline__ T scaled_prox_flags(int fn, T v, T tau, const T* c, bool e_zero, bool a_one) {
+  const T num = c[0] * (v - c[3] * tau);
+  const T snum = c[2] * c[0] * c[0] * tau;
+  T prox_arg, step;
+  if (e_zero) {
+    prox_arg = num - c[1];                         // == (T)((double)num - (double)b), see scaled_prox_u
+    step = snum;                                   // (T)((double)snum / 1.) == snum
+  } else {
+    const double den = 1. + (double)(tau * c[4]);
+    prox_arg = (T)((double)num / den - (double)c[1]);
+    step = (T)((double)snum / den);
+  }
+  const T s = (T)(f1d_apply<T, FN>(fn, prox_arg, step, c[5], c[6]) + c[1]);
+  return a_one ? s : s / c[0];
+}
+template <class T, int FN = -1>
+__device__ __forceinline__ T elem_1d_flags(int fn, T arg, T tau, const T* c, bool e_zero, bool a_one) {
+  if (c[0] == 0 || c[2] == 0) return (arg - tau * c[3]) / (1 + tau * c[4]);
+  return scaled_prox_flags<T, FN>(fn, arg, tau, c, e_zero, a_one);
 }
 
 // ElemOperation1D::operator() on one value (elem_operation_1d.hpp:36-59)

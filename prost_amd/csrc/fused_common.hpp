@@ -52,6 +52,17 @@ __device__ __forceinline__ void stv_nt(T* __restrict__ p, const T (&v)[VEC]) {
   __builtin_nontemporal_store(t, reinterpret_cast<V*>(p));
 }
 
+// uniform base + 32-bit per-lane byte offset (global_load/store saddr form)
+template <class T, int VEC>
+__device__ __forceinline__ void ldv_o(const T* base, unsigned byte_off, T (&v)[VEC]) {
+  ldv<T, VEC>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off), v);
+}
+template <class T, int VEC, bool NT>
+__device__ __forceinline__ void stv_o(T* base, unsigned byte_off, const T (&v)[VEC]) {
+  T* p = reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+  if (NT) stv_nt<T, VEC>(p, v); else stv<T, VEC>(p, v);
+}
+
 template <class T>
 struct FusedArgs {
   size_t nx, ny, L;

@@ -98,6 +98,7 @@ void BackendPDHG<T>::Initialize() {
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
   if (single_kernel_) y_spare_.resize(m);
+  pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_supported(&desc_, dtype_id<T>()) == 1;
 
   CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
   CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
@@ -131,42 +132,82 @@ void BackendPDHG<T>::Release() {
   if (res_host_) { prost_hip_host_free(res_host_); res_host_ = nullptr; }
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
-  ev_.clear(); ev_used_ = 0;
+  ev_.clear(); ev_kind_.clear();
   y_spare_.clear();
   x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
 }
 
 template <typename T>
 void BackendPDHG<T>::PerformIteration() {
-  const bool residual_iteration = (iteration_ == 0) || (iteration_ % (size_t)opts_.residual_iter) == 0;   // backend_pdhg.cu:389
+  const bool residual_iteration = is_residual_iteration(iteration_);
   if (fused_) IterationFused(residual_iteration); else IterationGeneric(residual_iteration);
+}
+
+/// Two iterations in one launch when (a) the caller does not look at the state in between
+/// (budget >= 3: neither of the two is the observed iteration), (b) neither is a residual
+/// iteration, (c) the iteration after them is not one either -- it reads y^(k+1) as y_prev, which
+/// the pair kernel never writes -- and (d) k >= 2 (iterations 0 and 1 run with zeroed K^T y / K x
+/// vectors, backend_pdhg.cu:213-216).  The iteration before any observation point is therefore
+/// always a single launch, which leaves x_prev_ / y_prev_ exactly as the reference has them.
+template <typename T>
+int BackendPDHG<T>::PerformIterations(int budget) {
+  if (pair_kernel_ && budget >= 3 && iteration_ >= 2 && !is_residual_iteration(iteration_) &&
+      !is_residual_iteration(iteration_ + 1) && !is_residual_iteration(iteration_ + 2)) {
+    IterationPair();
+    return 2;
+  }
+  PerformIteration();
+  return 1;
+}
+
+template <typename T>
+bool BackendPDHG<T>::BeginSample(int kind) {
+  if (!this->time_kernels_) return false;
+  if ((launches_[kind]++ % 8) != 1) return false;        // one launch in eight: the markers must not serialise the stream
+  const size_t i = 2 * ev_kind_.size();
+  while (ev_.size() < i + 2) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
+  ev_kind_.push_back(kind);
+  CheckHip(prost_hip_event_record(ev_[i], CurrentStream()), "event_record");
+  return true;
+}
+
+template <typename T>
+void BackendPDHG<T>::EndSample(bool sampled) {
+  if (sampled) CheckHip(prost_hip_event_record(ev_[2 * ev_kind_.size() - 1], CurrentStream()), "event_record");
+}
+
+template <typename T>
+void BackendPDHG<T>::IterationPair() {
+  void* s = CurrentStream();
+  double tau[2], sigma[2], theta[2];
+  tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
+  tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
+  const bool t = BeginSample(kKernelPair);
+  CheckHip(Api<T>::fused_iteration2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0, s), "fused_iteration2");
+  EndSample(t);
+  x_.swap(x_prev_);          // x_ = x^(k+2); x_prev_ / y_prev_ hold x^k / y^k until the next single launch rewrites them
+  y_.swap(y_prev_);
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  iteration_ += 2;
 }
 
 /// two kernels: x_ / y_ ping-pong with x_prev_ / y_prev_
 template <typename T>
 void BackendPDHG<T>::IterationFused(bool res) {
   void* s = CurrentStream();
-  // kernel timing samples one iteration in eight (never a residual iteration: 8k+1 is odd) so the
-  // event markers do not perturb the pipelining of the other launches
-  const bool sample = this->time_kernels_ && (iteration_ % 8) == 1;
-  auto stamp = [&]() {
-    if (!sample) return;
-    if (ev_used_ == ev_.size()) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
-    CheckHip(prost_hip_event_record(ev_[ev_used_++], s), "event_record");
-  };
   // at entry: x_ = x^k, y_ = y^k, y_prev_ = y^(k-1).  The reference's kty_ is K^T y^k except at
   // k = 0 (zero vector, :213); kty_prev_ is K^T y^(k-1) except at k <= 1 (zero vector).
   if (single_kernel_) {
     // ONE kernel per iteration, x_new never round-trips through HBM (7 floats/pixel; residual
     // iterations add the y_prev stream and the four residual sums).  y_new cannot overwrite
     // y_prev_ on residual iterations (the kernel still reads it), so it goes to y_spare_.
-    stamp();
-    stamp();
     T* y_out = res ? y_spare_.data() : y_prev_.data();
+    const bool t = BeginSample(res ? kKernelIterRes : kKernelIter);
     CheckHip(Api<T>::fused_iteration(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_,
                                      (double)sigma_, (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0,
                                      iteration_ >= 2 ? 1 : 0, 0, res ? res_dev_ : nullptr, res ? workspace_ : nullptr, s), "fused_iteration");
-    stamp();
+    EndSample(t);
     x_.swap(x_prev_);
     if (res) { y_prev_.swap(y_spare_); }     // y_prev_ now holds y^(k+1); swapped into y_ below
     y_.swap(y_prev_);
@@ -175,15 +216,16 @@ void BackendPDHG<T>::IterationFused(bool res) {
     iteration_++;
     return;
   }
-  stamp();
+  bool t = BeginSample(kKernelPrimal);
   CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
                                 iteration_ >= 2 ? 1 : 0, res ? res_dev_ + 2 : nullptr, workspace_, s), "fused_primal");
-  stamp();
+  EndSample(t);
   x_.swap(x_prev_);                        // x_ = x^(k+1), x_prev_ = x^k       (:334)
   // kx_prev_ of the reference is K x^k except at k = 0 (zero vector, :216)
+  t = BeginSample(kKernelDual);
   CheckHip(Api<T>::fused_dual(&desc_, y_prev_.data(), y_.data(), x_.data(), x_prev_.data(), (double)sigma_, (double)theta_,
                               iteration_ >= 1 ? 1 : 0, res ? res_dev_ : nullptr, workspace_, s), "fused_dual");
-  stamp();
+  EndSample(t);
   y_.swap(y_prev_);                        // y_ = y^(k+1), y_prev_ = y^k       (:366)
   if (res) FinishResiduals();
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
@@ -306,21 +348,25 @@ size_t BackendPDHG<T>::gpu_mem_amount() const {
 }
 
 template <typename T>
-bool BackendPDHG<T>::KernelTimes(double* primal_ms, double* dual_ms, size_t* launches) {
-  if (ev_used_ < 3) return false;
-  CheckHip(prost_hip_event_synchronize(ev_[ev_used_ - 1]), "event_synchronize");
-  double p = 0, d = 0;
-  size_t k = 0;
-  for (size_t i = 0; i + 2 < ev_used_; i += 3, k++) {      // 3 stamps per iteration: | primal | dual |
-    float a = 0, b = 0;
-    CheckHip(prost_hip_event_elapsed_ms(ev_[i], ev_[i + 1], &a), "event_elapsed");
-    CheckHip(prost_hip_event_elapsed_ms(ev_[i + 1], ev_[i + 2], &b), "event_elapsed");
-    p += a; d += b;
+void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& out) {
+  out.clear();
+  if (ev_kind_.empty()) return;
+  CheckHip(prost_hip_event_synchronize(ev_[2 * ev_kind_.size() - 1]), "event_synchronize");
+  double sum[kKernelKinds] = {0, 0, 0, 0, 0};
+  size_t cnt[kKernelKinds] = {0, 0, 0, 0, 0};
+  for (size_t i = 0; i < ev_kind_.size(); i++) {
+    float ms = 0;
+    CheckHip(prost_hip_event_elapsed_ms(ev_[2 * i], ev_[2 * i + 1], &ms), "event_elapsed");
+    sum[ev_kind_[i]] += ms; cnt[ev_kind_[i]]++;
   }
-  if (k == 0) return false;
-  *primal_ms = p / k; *dual_ms = d / k; *launches = k;
-  ev_used_ = 0;
-  return true;
+  const bool d3 = desc_.is3d != 0;
+  const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
+                                     "fused_iter2d_kernel", "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel"};
+  const int iters[kKernelKinds] = {0, 0, 1, 1, 2};
+  for (int k = 0; k < kKernelKinds; k++)
+    if (cnt[k]) out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k]});
+  ev_kind_.clear();
+  for (int k = 0; k < kKernelKinds; k++) launches_[k] = 0;
 }
 
 template class BackendPDHG<float>;

@@ -41,7 +41,7 @@ extern "C" {
 prost_value* prost_value_scalar(double v) { return prost_value_matrix(&v, 1, 1); }
 prost_value* prost_value_matrix(const double* data, size_t rows, size_t cols) {
   prost_value* v = new prost_value; v->kind = PROST_VALUE_MATRIX; v->rows = rows; v->cols = cols;
-  if (data && rows * cols) v->data.assign(data, data + rows * cols); else v->data.assign(rows * cols, 0.0);
+  if (data && rows * cols > 0) v->data.assign(data, data + rows * cols); else v->data.assign(rows * cols, 0.0);
   return v;
 }
 prost_value* prost_value_string(const char* s) { prost_value* v = new prost_value; v->kind = PROST_VALUE_STRING; v->str = s ? s : ""; v->rows = 1; v->cols = v->str.size(); return v; }
@@ -225,6 +225,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       else throw Exception("Couldn't recognize step-size variant. Valid options are {alg1,alg2,goldstein,boyd}.");
       if (prost_value_field(d, "allow_fused")) o.allow_fused = GetScalarFromField(d, "allow_fused") > 0.;
       if (prost_value_field(d, "allow_single_kernel")) o.allow_single_kernel = GetScalarFromField(d, "allow_single_kernel") > 0.;
+      if (prost_value_field(d, "allow_pair_kernel")) o.allow_pair_kernel = GetScalarFromField(d, "allow_pair_kernel") > 0.;
       return new BackendPDHG<T>(o);
     };
     reg["admm"] = [](const prost_value* d) -> Backend<T>* {                                   // factory.cpp:799-818
@@ -561,14 +562,23 @@ void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int nlhs
   CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   CheckHip(prost_hip_check_last_error(), "solver_iterate");
-  double p = 0, d = 0; size_t k = 0;
-  const bool have = h.backend->KernelTimes(&p, &d, &k);
+  std::vector<typename Backend<T>::KernelTime> kt;
+  h.backend->KernelTimes(kt);
   h.backend->EnableKernelTiming(false);
   prost_value* out = prost_value_struct();
   prost_value_struct_set(out, "ms", prost_value_scalar(ms));
-  prost_value_struct_set(out, "primal_kernel_ms", prost_value_scalar(have ? p : 0));
-  prost_value_struct_set(out, "dual_kernel_ms", prost_value_scalar(have ? d : 0));
-  prost_value_struct_set(out, "launches", prost_value_scalar((double)k));
+  // one cell per kernel kind sampled: {name, avg_ms, sampled launches, iterations per launch, all launches}
+  prost_value* ks = prost_value_cell(kt.size());
+  for (size_t i = 0; i < kt.size(); i++) {
+    prost_value* e = prost_value_cell(5);
+    prost_value_cell_set(e, 0, prost_value_string(kt[i].name.c_str()));
+    prost_value_cell_set(e, 1, prost_value_scalar(kt[i].avg_ms));
+    prost_value_cell_set(e, 2, prost_value_scalar((double)kt[i].sampled));
+    prost_value_cell_set(e, 3, prost_value_scalar((double)kt[i].iterations_per_launch));
+    prost_value_cell_set(e, 4, prost_value_scalar((double)kt[i].launches));
+    prost_value_cell_set(ks, i, e);
+  }
+  prost_value_struct_set(out, "kernels", ks);
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 void cmd_solver_iterate(CMD_ARGS) {

@@ -1,5 +1,6 @@
 // solver.cpp -- outer host loop: initialisation, iteration, stopping test, callback schedule
 // (behaviour of the reference's src/solver.cu).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <iomanip>
@@ -54,7 +55,8 @@ void Solver<T>::Initialize() {
 
 template <typename T>
 void Solver<T>::Iterate(int iters) {
-  for (int i = 0; i < iters; i++) backend_->PerformIteration();
+  // the state is observable after the last iteration only: the backend may fuse the ones before it
+  for (int i = 0; i < iters;) i += backend_->PerformIterations(iters - i);
   iterations_done_ += iters;
 }
 
@@ -75,8 +77,17 @@ typename Solver<T>::ConvergenceResult Solver<T>::Solve() {
   else cb_iters.push_back(1e8);
 
   for (int i = 0; i < opts_.max_iters; i++) {
-    backend_->PerformIteration();
-    iterations_done_++;
+    // The loop body below looks at the backend after EVERY iteration in the reference (solver.cu:137-
+    // 196), but only three things can change its outcome: the residuals (which only residual
+    // iterations update -- the backend never fuses those), the callback schedule and the last
+    // iteration (both known here), and a user stop callback (then nothing is fused).  `budget` =
+    // iterations up to and including the next scheduled observation; the backend runs k <= budget of
+    // them and the checks run once for the last of these k, whose index is i afterwards.
+    const int next_observed = std::min((int)std::ceil(cb_iters.front() < 1e8 ? cb_iters.front() : 1e8), opts_.max_iters - 1);
+    const int budget = stopping_cb_ ? 1 : std::max(1, next_observed - i + 1);
+    const int done = backend_->PerformIterations(budget);
+    i += done - 1;
+    iterations_done_ += done;
 
     const T primal_res = backend_->primal_residual(), dual_res = backend_->dual_residual();
     const T eps_pri = backend_->eps_primal(), eps_dua = backend_->eps_dual();

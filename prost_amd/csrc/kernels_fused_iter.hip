@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
     for (int l = 0; l < LCH; l++) {
       const size_t o = l * P + c * ny + row0;
-      if (VAR & 2) { ldv_nt<T, VEC>(y + o, in.y1[l]); ldv_nt<T, VEC>(y + N + o, in.y2[l]); ldv_nt<T, VEC>(x + o, in.x[l]); }
+      if (VAR & 10) { ldv_nt<T, VEC>(y + o, in.y1[l]); ldv_nt<T, VEC>(y + N + o, in.y2[l]); ldv_nt<T, VEC>(x + o, in.x[l]); }
       else { ldv<T, VEC>(y + o, in.y1[l]); ldv<T, VEC>(y + N + o, in.y2[l]); ldv<T, VEC>(x + o, in.x[l]); }
       // issued together with the column so that the primal step never waits on a second round trip
       in.up[l] = (lane == 0 && row0 > 0) ? y[N + o - 1] : (T)0;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
       for (int k = 0; k < 7; k++) {
         if ((GMASK >> k) & 1) {
-          if (a.g_ptr[k]) { if (VAR & 2) ldv_nt<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); else ldv<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); }
+          if (a.g_ptr[k]) { if (VAR & 18) ldv_nt<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); else ldv<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); }
           else {
 #pragma unroll
             for (int j = 0; j < VEC; j++) in.gc[l][slot_of(GMASK, k)][j] = a.g_val[k];
@@ -311,9 +311,9 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
 #define GO_RES(LCHv, G, F, M) do { if (out4) GO(LCHv, G, F, M, true, 1); else GO(LCHv, G, F, M, false, 1); } while (0)
 #define GO_VAR(VARv) case VARv: if (out4) GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true, VARv); else GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, false, VARv); break;
   // tuning knob (bit 0: non-temporal stores [default, +4 % at 4096^2], bit 1: non-temporal loads [-15 %],
-  // bit 2: no register prefetch [-8 %]); measured with tools/variant_sweep.sh
+  // bit 2: no register prefetch [-8 %], bit 3: nt loads of x, y only, bit 4: nt loads of the coefficient vectors only); measured with tools/variant_sweep.sh
   static const int variant = getenv("PROST_HIP_ITER_VARIANT") ? atoi(getenv("PROST_HIP_ITER_VARIANT")) : 1;
-  if (d->L == 1 && fast && sizeof(T) == 4) { switch (variant) { GO_VAR(0) GO_VAR(1) GO_VAR(2) GO_VAR(3) GO_VAR(4) GO_VAR(5) GO_VAR(6) GO_VAR(7) default: set_error("bad variant"); return 1; } }
+  if (d->L == 1 && fast && sizeof(T) == 4) { switch (variant) { GO_VAR(0) GO_VAR(1) GO_VAR(2) GO_VAR(3) GO_VAR(4) GO_VAR(5) GO_VAR(6) GO_VAR(7) GO_VAR(9) GO_VAR(17) default: set_error("bad variant"); return 1; } }
   else if (d->L == 1) { if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(1, -1, -1, 0); else GO_RES(1, -1, -1, 0x7F); }
   else { if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(2, -1, -1, 0); else GO_RES(2, -1, -1, 0x7F); }
 #undef GO_RES

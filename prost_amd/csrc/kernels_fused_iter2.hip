@@ -1,0 +1,286 @@
+// kernels_fused_iter2.hip -- TWO PDHG iterations per kernel launch (temporal blocking) for gradient2d.
+//
+// The single-iteration kernel (kernels_fused_iter.hip) is HBM-bound at 7 floats/pixel/iteration.
+// The only way below that is to keep x^(k+1), y^(k+1) on chip: this kernel reads x^k, y^k and the
+// prox_g coefficient vectors once and writes x^(k+2), y^(k+2) -- 7 floats/pixel per TWO iterations.
+// A wavefront marches over a chunk of columns with a 4-stage software pipeline, all in registers:
+//     A(c+2): x1 = primal step of iteration k    at column c+2   (needs y^k    at c+2, c+1)
+//     B(c+1): y1 = dual   step of iteration k    at column c+1   (needs x1     at c+1, c+2)
+//     C(c+1): x2 = primal step of iteration k+1  at column c+1   (needs y1     at c+1, c)
+//     D(c)  : y2 = dual   step of iteration k+1  at column c     (needs x2     at c,   c+1)
+// Row neighbours come from adjacent lanes (64-lane shuffles).  Lane 0 and lane 63 are HALO lanes:
+// with R the wave's first row, stage A is wrong at row R (no row above), B at R and the last row,
+// C at R, R+1 and the last row, D at R..R+1 and the last two rows -- all inside the halo lanes'
+// VEC rows, which are never stored.  The wave therefore owns 62 x VEC rows; neighbouring strips
+// overlap by two lanes.  Column halo: a
+// chunk starts its pipeline 3 columns early (A(xa-1), B(xa-1) are recomputed) and runs A, B, C one
+// resp. two columns past its end.
+// Every stage evaluates exactly the expressions of the single-iteration kernel, so x^(k+2), y^(k+2)
+// are bit-identical to two single launches.  Intermediate iterates are NOT stored: the host only
+// pairs iterations whose intermediate state nobody reads (see BackendPDHG::PerformIterations).
+#include "fused_common.hpp"
+
+#include <cstdlib>
+
+namespace prost_hip {
+
+constexpr int popcount7b(int m) { int c = 0; for (int k = 0; k < 7; k++) c += (m >> k) & 1; return c; }
+constexpr int slot_ofb(int m, int k) { int c = 0; for (int i = 0; i < k; i++) c += (m >> i) & 1; return c; }
+
+template <class T>
+struct IterParams {           // step sizes of one iteration + the host-evaluated uniform prox terms
+  T tau, sigma, theta;
+  UniformProx<T> ug, uf;
+};
+
+template <class T, int VEC, int GMASK>
+struct Col2 {
+  static constexpr int NG = popcount7b(GMASK) > 0 ? popcount7b(GMASK) : 1;
+  T y1[VEC], y2[VEC], x[VEC], gc[NG][VEC];
+};
+
+template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST>
+__global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
+                                                                const T* __restrict__ x, const T* __restrict__ y,
+                                                                FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2) {
+  const long nx = (long)a.nx, ny = (long)a.ny;
+  const int lane = threadIdx.x;
+  constexpr int kRowsPerWave = (kWave - 2) * VEC;
+  const unsigned total = gridDim.x, chunks = a.chunks;
+  const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;          // XCD-aware tile order (kernels_fused_iter.hip)
+  const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
+  const unsigned strip = tile / chunks, chunk = tile % chunks;
+  const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
+  const bool active = row0 >= 0 && row0 < ny;
+  const bool owner = active && lane > 0 && lane < kWave - 1;
+  const long xa = (long)chunk * a.cols_per_block;
+  const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const size_t N = (size_t)nx * (size_t)ny;
+  constexpr bool kUniformG = (GMASK & 0x15) == 0;
+  typedef Col2<T, VEC, GMASK> Col;
+
+  // one 32-bit byte offset per lane serves every plane (x, y1, y2, coefficients, outputs): the plane
+  // bases are wave-uniform (SGPR pairs), so the loads/stores use the saddr + 32-bit voffset form and
+  // no 64-bit per-lane address arithmetic is left in the loop (host guarantees N * sizeof(T) < 4 GiB)
+  auto off_of = [&](long c) { return (unsigned)((c * ny + row0) * (long)sizeof(T)); };
+  const T* const y2base = y + N;
+  T* const y2out = y_out + N;
+  auto load_col = [&](long c, Col& in) {
+    const unsigned o = off_of(c);
+    ldv_o<T, VEC>(y, o, in.y1); ldv_o<T, VEC>(y2base, o, in.y2); ldv_o<T, VEC>(x, o, in.x);
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      if ((GMASK >> k) & 1) {
+        if (a.g_ptr[k]) ldv_o<T, VEC>(a.g_ptr[k], o, in.gc[slot_ofb(GMASK, k)]);
+        else {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) in.gc[slot_ofb(GMASK, k)][j] = a.g_val[k];
+        }
+      }
+    }
+  };
+  // primal step at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 inlined)
+  auto primal = [&](long c, const T (&y1c)[VEC], const T (&y2c)[VEC], T up, const T (&y1p)[VEC], const T (&xin)[VEC],
+                    const T (&gc)[Col::NG][VEC], const IterParams<T>& P, T (&xn)[VEC]) {
+    const T tauT = P.tau * a.Tval;
+    T parg[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const long row = row0 + j;
+      T divy = (row < ny - 1) ? y2c[j] : (T)0;
+      if (row > 0) divy -= (j > 0) ? y2c[(j + VEC - 1) % VEC] : up;
+      T divx = (c < nx - 1) ? y1c[j] : (T)0;
+      if (c > 0) divx -= y1p[j];
+      const T kty = (T)0 - (divx + divy);
+      const T arg = xin[j] - tauT * kty;
+      if (FAST) {
+        parg[j] = arg - (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
+      } else {
+        T cf[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? gc[slot_ofb(GMASK, k)][j] : a.g_val[k];
+        if (kUniformG) xn[j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, P.ug);
+        else xn[j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, cf);
+      }
+    }
+    if (FAST) {
+      // ElemOperation1D<Function1DSquare> with scalar a = 1, d = 0, e = 0 (host-checked): a (v - d tau) = v
+      // and the fp64 denominator is 1, so the scaled prox is  square_prox(v - b) + b  -- straight-line
+      // code for the VEC elements, one fallback branch per vector inside the exact division
+      T r[VEC];
+      div_to_float_exact_vec<VEC>(parg, P.ug.sq, r);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) xn[j] = r[j] + (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
+    }
+  };
+  // dual step at column c (backend_pdhg.cu:341-370 with block_gradient2d.cu:61-77 inlined)
+  auto dual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+                  const T (&y1c)[VEC], const T (&y2c)[VEC], const IterParams<T>& P, T (&o1)[VEC], T (&o2)[VEC]) {
+    const T sigS = P.sigma * a.Sval, theta = P.theta;
+    const bool has_next = c + 1 < nx;
+    const T bel_n = __shfl_down(xn_c[0], 1, kWave);
+    const T bel_o = __shfl_down(xo_c[0], 1, kWave);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const long row = row0 + j;
+      const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
+      const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
+      const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+      const T kx2 = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
+      const T kp1 = has_next ? xo_n[j] - xo_c[j] : (T)0;
+      const T kp2 = (row < ny - 1) ? below_o - xo_c[j] : (T)0;
+      const T arg1 = y1c[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
+      const T arg2 = y2c[j] + sigS * ((1 + theta) * kx2 - theta * kp2);
+      T norm = 0;
+      norm += arg1 * arg1;
+      norm += arg2 * arg2;
+      if (FAST) {
+        // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked):
+        // pr = min(||v|| - b, 0) + b; branch-free (the quotient of a zero-norm group is replaced by 0)
+        const bool nz = norm > 0;
+        const T nrm = nz ? t_sqrt(norm) : (T)1;
+        const T t = nrm - a.f_val[1];
+        const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+        const T q1 = pr * arg1 / nrm, q2 = pr * arg2 / nrm;
+        o1[j] = nz ? q1 : (T)0;
+        o2[j] = nz ? q2 : (T)0;
+      } else if (norm > 0) {
+        norm = t_sqrt(norm);
+        const T pr = scaled_prox_u<T, FFN>(a.f_fn, norm, a.f_val, P.uf);
+        o1[j] = pr * arg1 / norm;
+        o2[j] = pr * arg2 / norm;
+      } else {
+        o1[j] = 0; o2[j] = 0;
+      }
+    }
+  };
+
+  Col in1 = {}, in2 = {};                       // loaded columns c+1 and c+2
+  T x1_0[VEC], x1_1[VEC], x1_2[VEC];            // x^(k+1) at columns c, c+1, c+2
+  T y1a_0[VEC], y1b_0[VEC], y1a_1[VEC], y1b_1[VEC];   // y^(k+1) (both components) at columns c, c+1
+  T x2_0[VEC], x2_1[VEC];                       // x^(k+2) at columns c, c+1
+#pragma unroll
+  for (int j = 0; j < VEC; j++) {
+    x1_0[j] = x1_1[j] = x1_2[j] = 0; y1a_0[j] = y1b_0[j] = y1a_1[j] = y1b_1[j] = 0; x2_0[j] = x2_1[j] = 0;
+  }
+  if (active) {
+    if (xa - 2 >= 0) ldv_o<T, VEC>(y, off_of(xa - 2), in1.y1);
+    if (xa - 1 >= 0) load_col(xa - 1, in2);
+  }
+  for (long c = xa - 3; c < xb; c++) {
+    Col pre = {};
+    const bool has_pre = c + 3 < nx && c + 3 <= xb + 1;
+    if (active && has_pre) load_col(c + 3, pre);
+    const long ca = c + 2, cb = c + 1;
+    if (ca >= 0 && ca < nx) {                                                                     // stage A
+      // lane 0 gets no row above: its first row is never needed (the top halo is its LAST row)
+      const T up = __shfl_up(in2.y2[VEC - 1], 1, kWave);
+      primal(ca, in2.y1, in2.y2, up, in1.y1, in2.x, in2.gc, p1, x1_2);
+    }
+    if (cb >= 0 && cb >= xa - 1 && cb < nx) dual(cb, x1_1, x1_2, in1.x, in2.x, in1.y1, in1.y2, p1, y1a_1, y1b_1);   // stage B
+    if (cb >= xa && cb < nx) {                                                                    // stage C
+      const T up = __shfl_up(y1b_1[VEC - 1], 1, kWave);          // lane 0: no source, its first row is halo
+      primal(cb, y1a_1, y1b_1, up, y1a_0, x1_1, in1.gc, p2, x2_1);
+      if (owner && cb < xb) stv_o<T, VEC, (VAR & 1) != 0>(x_out, off_of(cb), x2_1);
+    }
+    if (c >= xa) {                                                                                // stage D
+      T o1[VEC], o2[VEC];
+      dual(c, x2_0, x2_1, x1_0, x1_1, y1a_0, y1b_0, p2, o1, o2);
+      if (owner) { stv_o<T, VEC, (VAR & 1) != 0>(y_out, off_of(c), o1); stv_o<T, VEC, (VAR & 1) != 0>(y2out, off_of(c), o2); }
+    }
+    // shift the pipeline by one column
+    in1 = in2;
+    in2 = pre;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      x1_0[j] = x1_1[j]; x1_1[j] = x1_2[j];
+      y1a_0[j] = y1a_1[j]; y1b_0[j] = y1b_1[j];
+      x2_0[j] = x2_1[j];
+    }
+  }
+}
+
+static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
+  if (!d || d->is3d || d->L != 1) return false;
+  if (d->nx < 4 || d->ny < 4) return false;
+  if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
+  const int V = dtype == 0 ? 4 : 2;
+  if (d->ny % V != 0) return false;
+  if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4 : 8) >= 4294967296.0) return false;   // 32-bit byte offsets per plane
+  for (int k = 0; k < 7; k++) {
+    if (d->f_coeff_ptr[k]) return false;
+    if (!aligned16(d->g_coeff_ptr[k])) return false;
+  }
+  return true;
+}
+
+template <class T>
+static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
+                     const double* theta, int cols, void* stream) {
+  constexpr int V = VecOf<T>::N;
+  if (!iter2_desc_ok(d, sizeof(T) == 4 ? 0 : 1) || !aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) {
+    set_error("fused double iteration: unsupported description"); return 1;
+  }
+  FusedArgs<T> a = make_fused_args<T>(d);
+  const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
+  if (cols <= 0) {
+    // The kernel is VALU/latency-bound with 4 resident waves per SIMD (<= 128 VGPRs): 4096 wave slots
+    // on 256 CUs.  Longest chunk (3 warm-up columns are amortised over it) that still fills >= 90 % of
+    // the slots in ONE round -- a second, mostly empty round costs a full chunk time (measured 4096^2:
+    // 18 cols = 3876 waves 0.118 ms, 30 cols = 2329 waves 0.141 ms, 15 cols = 4658 waves 0.125 ms).
+    // Chunk lengths stay off multiples of 16 (HBM channel spread, see kernels_fused_iter.hip).
+    const size_t slots = 256 * 4 * 4;
+    cols = 6;
+    for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
+  }
+  a.cols_per_block = cols;
+  a.chunks = (unsigned)((d->nx + cols - 1) / cols);
+  if (strips * a.chunks > 0x7fffffffull) { set_error("fused double iteration: grid too large"); return 1; }
+  IterParams<T> p[2];
+  for (int i = 0; i < 2; i++) {
+    p[i].tau = (T)tau[i]; p[i].sigma = (T)sigma[i]; p[i].theta = (T)theta[i];
+    p[i].ug = make_uniform_prox<T>(a.g_val, (T)tau[i] * a.Tval);
+    p[i].uf = make_uniform_prox<T>(a.f_val, (T)sigma[i] * a.Sval);
+  }
+  int mask = 0;
+  for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k]) mask |= 1 << k;
+  // straight-line instance for the ROF shape: square / ind_leq0 with scalar a = 1, d = 0, e = 0 on both
+  // sides (so a (v - d tau) = v and the fp64 denominators are exactly 1), b of prox_g per pixel
+  const bool fast = d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2 &&
+                    p[0].ug.a_one && p[0].ug.den_one && !p[0].ug.degenerate && a.g_val[3] == (T)0 &&
+                    p[0].uf.a_one && p[0].uf.den_one && a.f_val[3] == (T)0 &&
+                    p[1].ug.den_one && p[1].uf.den_one;
+  dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
+  hipStream_t s = as_stream(stream);
+  static const int variant = getenv("PROST_HIP_ITER2_VARIANT") ? atoi(getenv("PROST_HIP_ITER2_VARIANT")) : 1;   // bit 0: non-temporal stores, bit 1: 4 waves/SIMD (128 VGPRs)
+#define GO(G, F, M, VARv, FASTv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv>), grid, block, 0, s, x_out, y_out, x, y, a, p[0], p[1])
+  if (fast) {
+    switch (variant & 3) {
+      case 0: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 0, true); break;
+      case 1: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true); break;
+      case 2: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 2, true); break;
+      default: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 3, true); break;
+    }
+  }
+  else if (d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, false);
+  else if (mask == 0) GO(-1, -1, 0, 1, false);
+  else GO(-1, -1, 0x7F, 1, false);
+#undef GO
+  PH_LAUNCH_END("fused double iteration kernel");
+}
+
+}  // namespace prost_hip
+
+using namespace prost_hip;
+
+extern "C" {
+int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) ? 1 : 0; }
+int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
+                                   const double* sigma, const double* theta, int cols_per_block, void* s) {
+  return run_iter2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols_per_block, s);
+}
+int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
+                                   const double* sigma, const double* theta, int cols_per_block, void* s) {
+  return run_iter2<double>(d, x_out, y_out, x, y, tau, sigma, theta, cols_per_block, s);
+}
+}  // extern "C"

@@ -5,7 +5,7 @@
 // contiguous axis is y (resp. (y,l)).  Every kernel maps consecutive lanes to consecutive
 // addresses of that axis: a wave reads/writes 256 contiguous bytes (fp32) per access, and the
 // +-1 / +-ny neighbours of a lane are the same or the adjacent cache lines (served by L1/L2).
-#include "common.hpp"
+#include "elementwise.hpp"
 
 namespace prost_hip {
 
@@ -73,9 +73,159 @@ __global__ void __launch_bounds__(kBlock) grad_adj_kernel(T* __restrict__ res, c
   if (ACC) res[idx] -= s; else res[idx] = (T)0 - s;     // adjoint is minus the divergence
 }
 
+// ---- planar layout, 16 bytes per lane, column marching ------------------------------------------
+// A workgroup owns a strip of kBlock*VEC rows and walks `cols` consecutive image columns of one
+// label slice.  A lane holds VEC consecutive rows (float4 / double2): the x+1 column it needs for
+// the x-difference is the vector it loads for the next step anyway (kept in registers, so every
+// input element is fetched once per workgroup), and the +-1 row neighbour comes from the adjacent
+// lane by a wave shuffle -- only lane 63 (lane 0 for the adjoint) reads one extra scalar.
+// Arithmetic per element is that of the scalar kernels above, so results are bit-identical.
+template <class T, int VEC, bool D3, bool ACC>
+__global__ void __launch_bounds__(kBlock) grad_fwd_vec_kernel(T* __restrict__ res, const T* __restrict__ rhs,
+                                                              size_t nx, size_t ny, size_t L, unsigned strips, unsigned chunks, int cols) {
+  const unsigned strip = blockIdx.x % strips, chunk = (blockIdx.x / strips) % chunks;
+  const size_t l = blockIdx.x / (strips * chunks);
+  const size_t row0 = ((size_t)strip * kBlock + threadIdx.x) * VEC;
+  const bool active = row0 < ny;
+  const size_t x0 = (size_t)chunk * cols, x1 = x0 + cols < nx ? x0 + cols : nx;
+  const size_t N = nx * ny * L, slice = nx * ny;
+  const T* src = rhs + l * slice;
+  T cur[VEC], nxt[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; j++) cur[j] = 0;
+  if (active) ldv<T, VEC>(src + x0 * ny + row0, cur);
+  for (size_t x = x0; x < x1; x++) {
+    const size_t idx = l * slice + x * ny + row0;
+    const bool has_next = x + 1 < nx;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) nxt[j] = 0;
+    if (active && has_next) ldv<T, VEC>(src + (x + 1) * ny + row0, nxt);
+    const T below = row_below<T, VEC>(cur, src + x * ny, row0, ny, active);
+    T gx[VEC], gy[VEC], gl[VEC], up[VEC];
+    if (D3) {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) up[j] = 0;
+      if (active && l + 1 < L) ldv<T, VEC>(rhs + idx + slice, up);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const T val = cur[j];
+      const T dn = (j + 1 < VEC) ? cur[(j + 1) % VEC] : below;
+      gy[j] = (row0 + j < ny - 1) ? dn - val : (T)0;
+      gx[j] = has_next ? nxt[j] - val : (T)0;
+      if (D3) gl[j] = (l + 1 < L) ? up[j] - val : -val;
+    }
+    if (active) {
+      if (ACC) {
+        T o[VEC];
+        ldv<T, VEC>(res + idx, o);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) gx[j] = o[j] + gx[j];
+        ldv<T, VEC>(res + idx + N, o);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) gy[j] = o[j] + gy[j];
+        if (D3) {
+          ldv<T, VEC>(res + idx + 2 * N, o);
+#pragma unroll
+          for (int j = 0; j < VEC; j++) gl[j] = o[j] + gl[j];
+        }
+      }
+      stv<T, VEC>(res + idx, gx);
+      stv<T, VEC>(res + idx + N, gy);
+      if (D3) stv<T, VEC>(res + idx + 2 * N, gl);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
+  }
+}
+
+template <class T, int VEC, bool D3, bool ACC>
+__global__ void __launch_bounds__(kBlock) grad_adj_vec_kernel(T* __restrict__ res, const T* __restrict__ rhs,
+                                                              size_t nx, size_t ny, size_t L, unsigned strips, unsigned chunks, int cols) {
+  const unsigned strip = blockIdx.x % strips, chunk = (blockIdx.x / strips) % chunks;
+  const size_t l = blockIdx.x / (strips * chunks);
+  const size_t row0 = ((size_t)strip * kBlock + threadIdx.x) * VEC;
+  const bool active = row0 < ny;
+  const size_t x0 = (size_t)chunk * cols, x1 = x0 + cols < nx ? x0 + cols : nx;
+  const size_t N = nx * ny * L, slice = nx * ny;
+  const T* px_ = rhs + l * slice;            // x-component plane of this slice
+  const T* py_ = rhs + N + l * slice;        // y-component
+  T prev[VEC], px[VEC], py[VEC], pl[VEC], plm[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; j++) prev[j] = 0;
+  if (active && x0 > 0) ldv<T, VEC>(px_ + (x0 - 1) * ny + row0, prev);
+  for (size_t x = x0; x < x1; x++) {
+    const size_t idx = l * slice + x * ny + row0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { px[j] = 0; py[j] = 0; pl[j] = 0; plm[j] = 0; }
+    if (active) {
+      ldv<T, VEC>(px_ + x * ny + row0, px);
+      ldv<T, VEC>(py_ + x * ny + row0, py);
+      if (D3) {
+        ldv<T, VEC>(rhs + 2 * N + idx, pl);
+        if (l > 0) ldv<T, VEC>(rhs + 2 * N + idx - slice, plm);
+      }
+    }
+    const T above = row_above<T, VEC>(py, py_ + x * ny, row0, active);
+    T o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      T divx, divy;
+      if (row0 + j < ny - 1) divy = py[j]; else divy = 0;
+      if (row0 + j > 0) divy -= (j > 0) ? py[(j + VEC - 1) % VEC] : above;
+      if (x < nx - 1) divx = px[j]; else divx = 0;
+      if (x > 0) divx -= prev[j];
+      T s;
+      if (D3) {
+        T divl = pl[j];
+        if (l > 0) divl -= plm[j];
+        s = divx + divy + divl;
+      } else {
+        s = divx + divy;
+      }
+      o[j] = s;
+    }
+    if (active) {
+      if (ACC) {
+        T r[VEC];
+        ldv<T, VEC>(res + idx, r);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) o[j] = r[j] - o[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) o[j] = (T)0 - o[j];
+      }
+      stv<T, VEC>(res + idx, o);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) prev[j] = px[j];
+  }
+}
+
+// columns per workgroup: non-power-of-two chunks keep concurrently running workgroups on
+// different HBM channels (see kernels_fused_iter.hip); shrink until the grid fills 256 CUs x 4
+static int pick_grad_cols(size_t nx, size_t strips, size_t L) {
+  for (int c : {12, 6, 3}) if (strips * ((nx + c - 1) / c) * L >= 2048) return c;
+  return 1;
+}
+
 template <class T, bool D3>
 static int launch_grad(bool adjoint, T* res, const T* rhs, size_t nx, size_t ny, size_t L, int lf, int acc, void* stream) {
   if (nx == 0 || ny == 0 || L == 0) return 0;
+  constexpr int V = VecOf<T>::N;
+  if (!lf && ny % V == 0 && aligned16(res) && aligned16(rhs)) {
+    const size_t strips = (ny + (size_t)kBlock * V - 1) / ((size_t)kBlock * V);
+    const int cols = pick_grad_cols(nx, strips, L);
+    const size_t chunks = (nx + cols - 1) / cols, blocks = strips * chunks * L;
+    if (blocks < (1ull << 31)) {
+      hipStream_t s = as_stream(stream);
+#define GOV(K, ACCv) hipLaunchKernelGGL((K<T, V, D3, ACCv>), dim3((unsigned)blocks), dim3(kBlock), 0, s, res, rhs, nx, ny, L, (unsigned)strips, (unsigned)chunks, cols)
+      if (!adjoint) { if (acc) GOV(grad_fwd_vec_kernel, true); else GOV(grad_fwd_vec_kernel, false); }
+      else { if (acc) GOV(grad_adj_vec_kernel, true); else GOV(grad_adj_vec_kernel, false); }
+#undef GOV
+      PH_LAUNCH_END("gradient kernel");
+    }
+  }
   if (nx > 65535 || (!lf && L > 65535)) { set_error("gradient: nx and L must be <= 65535"); return 1; }
   dim3 block(kBlock), grid;
   if (lf) grid = dim3((unsigned)((ny * L + kBlock - 1) / kBlock), (unsigned)nx, 1);
@@ -129,6 +279,80 @@ __global__ void __launch_bounds__(kBlock) diags_kernel(T* __restrict__ res, cons
   }
 }
 
+// 16 bytes of consecutive rows per lane.  A workgroup pass covers kBlock*VEC rows; when every
+// diagonal stays inside the operand for the whole pass (all but the first/last few passes) the
+// bounds tests and the 64-bit index arithmetic per (row, diagonal) disappear and each diagonal is
+// one (4-byte aligned) 16-byte load per lane.  Border passes run the scalar formula above.
+template <class T>
+struct __attribute__((packed, aligned(sizeof(T)))) UnalignedVec {
+  T v[VecOf<T>::N];
+};
+
+template <class T, bool ADJ>
+__global__ void __launch_bounds__(kBlock) diags_vec_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nrows,
+                                                           size_t ncols, int ndiags, const int64_t* __restrict__ offsets,
+                                                           const float* __restrict__ factors, size_t limit) {
+  constexpr int VEC = VecOf<T>::N;
+  __shared__ int64_t s_ofs[kMaxDiags];
+  __shared__ float s_fac[kMaxDiags];
+  __shared__ int64_t s_range[2];
+  for (int i = threadIdx.x; i < ndiags; i += kBlock) { s_ofs[i] = offsets[i]; s_fac[i] = factors[i]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t lo = 0, hi = 0;
+    for (int d = 0; d < ndiags; d++) { const int64_t o = s_ofs[d]; if (d == 0 || o < lo) lo = o; if (d == 0 || o > hi) hi = o; }
+    s_range[0] = lo; s_range[1] = hi;
+  }
+  __syncthreads();
+  const long long omin = s_range[0], omax = s_range[1];
+  const size_t span = (size_t)kBlock * VEC;
+  for (size_t base = (size_t)blockIdx.x * span; base < limit; base += (size_t)gridDim.x * span) {
+    const long long lo = (long long)base, hi = (long long)(base + span - 1);
+    const bool interior = hi < (long long)limit &&
+                          (ADJ ? (lo - omax >= 0 && hi - omin < (long long)nrows) : (lo + omin >= 0 && hi + omax < (long long)ncols));
+    const size_t i0 = base + (size_t)threadIdx.x * VEC;
+    if (interior) {
+      T r[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; j++) r[j] = 0;
+      for (int d = 0; d < ndiags; d++) {
+        const long long o = s_ofs[d];
+        const float f = s_fac[d];
+        const UnalignedVec<T> u = *reinterpret_cast<const UnalignedVec<T>*>(rhs + (ADJ ? (long long)i0 - o : (long long)i0 + o));
+#pragma unroll
+        for (int j = 0; j < VEC; j++) r[j] += u.v[j] * f;
+      }
+      T o[VEC];
+      ldv<T, VEC>(res + i0, o);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) o[j] += r[j];
+      stv<T, VEC>(res + i0, o);
+    } else {
+      for (int j = 0; j < VEC; j++) {
+        const size_t i = i0 + j;
+        if (i >= limit) break;
+        T result = 0;
+        if (!ADJ) {
+          for (int d = 0; d < ndiags; d++) {
+            const long long col = (long long)i + s_ofs[d];
+            if (col < 0) continue;
+            if (col >= (long long)ncols) break;
+            result += rhs[col] * s_fac[d];
+          }
+        } else {
+          const long long col = (long long)i;
+          for (int d = 0; d < ndiags; d++) {
+            const long long o = s_ofs[d];
+            if (o <= col && (col - o) < (long long)nrows && (col - o) >= 0) result += rhs[col - o] * s_fac[d];
+            if (o > col) break;
+          }
+        }
+        res[i] += result;
+      }
+    }
+  }
+}
+
 template <class T>
 static int launch_diags(bool adj, T* res, const T* rhs, size_t nrows, size_t ncols, size_t ndiags, const int64_t* ofs,
                         const float* fac, int quirk, void* stream) {
@@ -136,6 +360,14 @@ static int launch_diags(bool adj, T* res, const T* rhs, size_t nrows, size_t nco
   size_t limit = adj ? ncols : nrows;
   if (adj && quirk) { size_t g = ((nrows + 255) / 256) * 256; if (g < limit) limit = g; }   // block_diags.cu:210-211
   if (limit == 0) return 0;
+  constexpr int V = VecOf<T>::N;
+  if (aligned16(res) && ndiags > 0) {
+    unsigned g = grid_for((limit + V - 1) / V);
+    if (ndiags > 16 && g > 8192) g = 8192;     // every workgroup stages the band table: amortise a long one
+    if (adj) hipLaunchKernelGGL((diags_vec_kernel<T, true>), dim3(g), dim3(kBlock), 0, as_stream(stream), res, rhs, nrows, ncols, (int)ndiags, ofs, fac, limit);
+    else hipLaunchKernelGGL((diags_vec_kernel<T, false>), dim3(g), dim3(kBlock), 0, as_stream(stream), res, rhs, nrows, ncols, (int)ndiags, ofs, fac, limit);
+    PH_LAUNCH_END("diags kernel");
+  }
   if (adj) hipLaunchKernelGGL((diags_kernel<T, true>), dim3(grid_for(limit)), dim3(kBlock), 0, as_stream(stream), res, rhs, nrows, ncols, (int)ndiags, ofs, fac, limit);
   else hipLaunchKernelGGL((diags_kernel<T, false>), dim3(grid_for(limit)), dim3(kBlock), 0, as_stream(stream), res, rhs, nrows, ncols, (int)ndiags, ofs, fac, limit);
   PH_LAUNCH_END("diags kernel");
@@ -178,22 +410,14 @@ static int launch_csr(T* res, const T* rhs, size_t nrows, size_t nnz, const T* v
 }
 
 // ------------------------------------------------------------------------------------------
-template <class T>
-__global__ void __launch_bounds__(kBlock) scale_kernel(T* __restrict__ x, size_t n, T beta) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) x[i] = beta * x[i];
-}
-template <class T, bool VIA_FLOAT>
-__global__ void __launch_bounds__(kBlock) negate_kernel(T* __restrict__ x, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
-    x[i] = VIA_FLOAT ? (T)(-(float)x[i]) : -x[i];
-}
+template <class T> struct ScaleF { T beta; __device__ T operator()(const T* a) const { return beta * a[0]; } };
+template <class T, bool VIA_FLOAT> struct NegateF { __device__ T operator()(const T* a) const { return VIA_FLOAT ? (T)(-(float)a[0]) : -a[0]; } };
 
 template <class T>
 static int launch_scale(T* x, size_t n, double beta, void* stream) {
   if (n == 0) return 0;
   if (beta == 0.0) { PH_CHECK(hipMemsetAsync(x, 0, n * sizeof(T), as_stream(stream))); return 0; }
-  hipLaunchKernelGGL((scale_kernel<T>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(stream), x, n, (T)beta);
-  PH_LAUNCH_END("scale kernel");
+  return launch_ew<T, 1>("scale kernel", x, EwIn<T, 1>{{x}}, n, ScaleF<T>{(T)beta}, as_stream(stream));
 }
 
 }  // namespace prost_hip
@@ -221,14 +445,10 @@ int prost_hip_csr_spmv_acc_f64(double* r, const double* x, size_t nrows, size_t 
 int prost_hip_scale_f32(float* x, size_t n, double beta, void* s) { return launch_scale<float>(x, n, beta, s); }
 int prost_hip_scale_f64(double* x, size_t n, double beta, void* s) { return launch_scale<double>(x, n, beta, s); }
 int prost_hip_negate_f32(float* x, size_t n, void* s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL((negate_kernel<float, false>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(s), x, n);
-  PH_LAUNCH_END("negate kernel");
+  return launch_ew<float, 1>("negate kernel", x, EwIn<float, 1>{{x}}, n, NegateF<float, false>{}, as_stream(s));
 }
 int prost_hip_negate_f64(double* x, size_t n, int via_float, void* s) {
-  if (n == 0) return 0;
-  if (via_float) hipLaunchKernelGGL((negate_kernel<double, true>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(s), x, n);
-  else hipLaunchKernelGGL((negate_kernel<double, false>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(s), x, n);
-  PH_LAUNCH_END("negate kernel");
+  if (via_float) return launch_ew<double, 1>("negate kernel", x, EwIn<double, 1>{{x}}, n, NegateF<double, true>{}, as_stream(s));
+  return launch_ew<double, 1>("negate kernel", x, EwIn<double, 1>{{x}}, n, NegateF<double, false>{}, as_stream(s));
 }
 }  // extern "C"

@@ -5,8 +5,7 @@
 // 64 consecutive values per component -> fully coalesced.  The function id is wave-uniform, so
 // the 14-way dispatch is one scalar branch per wave (no per-function template explosion: the
 // reference instantiates 176 kernels, prox_elem_operation.cu:44-256; this file compiles 4).
-#include "common.hpp"
-#include "device_math.hpp"
+#include "elementwise.hpp"
 
 namespace prost_hip {
 
@@ -46,6 +45,91 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
   }
 }
 
+// Vectorised form for the planar layout (and the 1-D operation): a lane owns 16 bytes of
+// consecutive elements per component (float4 / double2), so every access of a wave is one 1-KiB
+// transaction and the per-element coefficient vectors are read with the same width.  DIM > 0 keeps
+// the components in registers; DIM == 0 (any dimension) makes a second pass over arg (L2 hits).
+template <class T, int OP, int DIM>
+__global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ res, const T* __restrict__ arg,
+                                                               const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
+                                                               size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one) {
+  constexpr int VEC = VecOf<T>::N;
+  constexpr int D = DIM > 0 ? DIM : 1;
+  for (size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * VEC; t0 < count; t0 += (size_t)gridDim.x * kBlock * VEC) {
+    T c[7][VEC], td[VEC];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+      if (cf.ptr[k]) ldv<T, VEC>(cf.ptr[k] + t0, c[k]);
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) c[k][j] = cf.val[k];
+      }
+    }
+    ldv<T, VEC>(tau_diag + t0, td);
+    if (OP == PROST_OP_1D) {
+      T a[VEC], out[VEC];
+      ldv<T, VEC>(arg + t0, a);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        T cc[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) cc[k] = c[k][j];
+        out[j] = elem_1d_flags<T>(fn, a[j], elem_tau<T>(tau_scal, td[j], invert_tau), cc, e_zero, a_one);
+      }
+      stv<T, VEC>(res + t0, out);
+    } else {
+      T v[D][VEC], norm[VEC], scale[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; j++) norm[j] = 0;
+      if (DIM > 0) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+          ldv<T, VEC>(arg + t0 + (size_t)i * count, v[i]);
+#pragma unroll
+          for (int j = 0; j < VEC; j++) norm[j] += v[i][j] * v[i][j];
+        }
+      } else {
+        for (size_t i = 0; i < dim; i++) {
+          T w[VEC];
+          ldv<T, VEC>(arg + t0 + i * count, w);
+#pragma unroll
+          for (int j = 0; j < VEC; j++) norm[j] += w[j] * w[j];
+        }
+      }
+      bool pos[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        pos[j] = norm[j] > 0;
+        scale[j] = 0;
+        if (pos[j]) {
+          norm[j] = t_sqrt(norm[j]);
+          T cc[7];
+#pragma unroll
+          for (int k = 0; k < 7; k++) cc[k] = c[k][j];
+          scale[j] = scaled_prox_flags<T>(fn, norm[j], elem_tau<T>(tau_scal, td[j], invert_tau), cc, e_zero, a_one);
+        }
+      }
+      if (DIM > 0) {
+#pragma unroll
+        for (int i = 0; i < D; i++) {
+          T out[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; j++) out[j] = pos[j] ? scale[j] * v[i][j] / norm[j] : (T)0;
+          stv<T, VEC>(res + t0 + (size_t)i * count, out);
+        }
+      } else {
+        for (size_t i = 0; i < dim; i++) {
+          T w[VEC], out[VEC];
+          ldv<T, VEC>(arg + t0 + i * count, w);
+#pragma unroll
+          for (int j = 0; j < VEC; j++) out[j] = pos[j] ? scale[j] * w[j] / norm[j] : (T)0;
+          stv<T, VEC>(res + t0 + i * count, out);
+        }
+      }
+    }
+  }
+}
+
 template <class T>
 static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_diag, double tau, int invert, size_t count,
                             size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
@@ -55,6 +139,22 @@ static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_d
   Coeffs<T> cf;
   for (int i = 0; i < 7; i++) { cf.ptr[i] = coeff_ptr ? coeff_ptr[i] : nullptr; cf.val[i] = (T)coeff_val[i]; }
   hipStream_t s = as_stream(stream);
+  constexpr int V = VecOf<T>::N;
+  bool vec = (op == PROST_OP_1D || !interleaved || dim == 1) && count % V == 0 && aligned16(res) && aligned16(arg) && aligned16(tau_diag);
+  for (int i = 0; i < 7; i++) vec = vec && aligned16(cf.ptr[i]);
+  if (vec) {
+    const bool e_zero = !cf.ptr[4] && cf.val[4] == (T)0, a_one = !cf.ptr[0] && cf.val[0] == (T)1;
+    dim3 g(grid_for(count / V)), b(kBlock);
+#define GO(OPv, DIMv) hipLaunchKernelGGL((prox_elem_vec_kernel<T, OPv, DIMv>), g, b, 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, fn, cf, e_zero, a_one)
+    if (op == PROST_OP_1D) GO(PROST_OP_1D, 1);
+    else if (dim == 1) GO(PROST_OP_NORM2, 1);
+    else if (dim == 2) GO(PROST_OP_NORM2, 2);
+    else if (dim == 3) GO(PROST_OP_NORM2, 3);
+    else if (dim == 4) GO(PROST_OP_NORM2, 4);
+    else GO(PROST_OP_NORM2, 0);
+#undef GO
+    PH_LAUNCH_END("prox_elem kernel");
+  }
   if (op == PROST_OP_1D)
     hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_1D>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, (size_t)1, interleaved != 0, fn, cf);
   else
@@ -122,18 +222,16 @@ __global__ void __launch_bounds__(kBlock) epi_quad_kernel(T* __restrict__ res, c
 // ------------------------------------------------------------------------------------------
 // Moreau pre/post scaling (prox_moreau.cu:29-61)
 // ------------------------------------------------------------------------------------------
-template <class T>
-__global__ void __launch_bounds__(kBlock) moreau_pre_kernel(T* __restrict__ out, const T* __restrict__ arg,
-                                                            const T* __restrict__ td, T tau, bool inv, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
-    out[i] = inv ? arg[i] * (tau * td[i]) : arg[i] / (tau * td[i]);
-}
-template <class T>
-__global__ void __launch_bounds__(kBlock) moreau_post_kernel(T* __restrict__ res, const T* __restrict__ arg,
-                                                             const T* __restrict__ td, T tau, bool inv, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
-    res[i] = inv ? arg[i] - res[i] / (tau * td[i]) : arg[i] - tau * td[i] * res[i];
-}
+// in = arg, tau_diag
+template <class T> struct MoreauPreF {
+  T tau; bool inv;
+  __device__ T operator()(const T* a) const { return inv ? a[0] * (tau * a[1]) : a[0] / (tau * a[1]); }
+};
+// in = arg, tau_diag, res (in place)
+template <class T> struct MoreauPostF {
+  T tau; bool inv;
+  __device__ T operator()(const T* a) const { return inv ? a[0] - a[2] / (tau * a[1]) : a[0] - tau * a[1] * a[2]; }
+};
 
 }  // namespace prost_hip
 
@@ -157,23 +255,15 @@ int prost_hip_prox_epi_quad_f64(double* res, const double* arg, size_t count, si
   PH_LAUNCH_END("epi_quad kernel");
 }
 int prost_hip_moreau_prescale_f32(float* o, const float* a, const float* td, double tau, int inv, size_t n, void* s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL((moreau_pre_kernel<float>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(s), o, a, td, (float)tau, inv != 0, n);
-  PH_LAUNCH_END("moreau prescale");
+  return launch_ew<float, 2>("moreau prescale", o, EwIn<float, 2>{{a, td}}, n, MoreauPreF<float>{(float)tau, inv != 0}, as_stream(s));
 }
 int prost_hip_moreau_prescale_f64(double* o, const double* a, const double* td, double tau, int inv, size_t n, void* s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL((moreau_pre_kernel<double>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(s), o, a, td, tau, inv != 0, n);
-  PH_LAUNCH_END("moreau prescale");
+  return launch_ew<double, 2>("moreau prescale", o, EwIn<double, 2>{{a, td}}, n, MoreauPreF<double>{tau, inv != 0}, as_stream(s));
 }
 int prost_hip_moreau_postscale_f32(float* r, const float* a, const float* td, double tau, int inv, size_t n, void* s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL((moreau_post_kernel<float>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(s), r, a, td, (float)tau, inv != 0, n);
-  PH_LAUNCH_END("moreau postscale");
+  return launch_ew<float, 3>("moreau postscale", r, EwIn<float, 3>{{a, td, r}}, n, MoreauPostF<float>{(float)tau, inv != 0}, as_stream(s));
 }
 int prost_hip_moreau_postscale_f64(double* r, const double* a, const double* td, double tau, int inv, size_t n, void* s) {
-  if (n == 0) return 0;
-  hipLaunchKernelGGL((moreau_post_kernel<double>), dim3(grid_for(n)), dim3(kBlock), 0, as_stream(s), r, a, td, tau, inv != 0, n);
-  PH_LAUNCH_END("moreau postscale");
+  return launch_ew<double, 3>("moreau postscale", r, EwIn<double, 3>{{a, td, r}}, n, MoreauPostF<double>{tau, inv != 0}, as_stream(s));
 }
 }  // extern "C"

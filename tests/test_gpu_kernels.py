@@ -320,3 +320,41 @@ def test_single_kernel_iteration_equals_two_passes(hip, dtype, shape, fns):
                     d_.free()
             for d_ in (x_ref, y_ref, rd, rp):
                 d_.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("shape", [(16, 12), (40, 1028), (33, 256), (70, 248), (70, 252), (5, 2052), (64, 64), (4, 4), (7, 496), (131, 500)])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+def test_double_iteration_kernel_equals_two_single_launches(hip, dtype, shape, fns):
+    """prost_hip_fused_iteration2 (two PDHG iterations, intermediate iterate kept in registers) ==
+    two prost_hip_fused_iteration launches with the step sizes of iteration k and k+1, bit for bit,
+    for every column-chunk size (3-column pipeline warm-up, halo lanes at strip borders)"""
+    nx, ny = shape
+    g_fn, f_fn = fns
+    rng = np.random.default_rng(11)
+    n, m = nx * ny, 2 * nx * ny
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    tau = (C.c_double * 2)(0.9, 0.7); sigma = (C.c_double * 2)(1.1, 1.4); theta = (C.c_double * 2)(0.85, 0.8)
+    for g_coeffs in ([1.0, f, 10.0, 0.0, 0.0, 0.3, 0.0], [1.0, 0.5, 10.0, 0.0, 0.0, 0.3, 0.0], [f + 0.5, f, 10.0, f * 0.1, 0.0, 0.3, 0.0]):
+        desc, keep = _fused_desc(hip, dtype, nx, ny, 1, g_fn, g_coeffs, f_fn, [1.0, 1.0, 1.0, 0.0, 0.0, 0.3, 0.0], 0.25, 0.5)
+        if not hip.lib().prost_hip_fused_iteration2_supported(C.byref(desc), 0 if dtype == np.float32 else 1):
+            assert ny % (4 if dtype == np.float32 else 2) != 0
+            continue
+        dx, dy = dev(hip, x), dev(hip, y)
+        x1 = hip.DeviceArray.zeros(n, dtype); y1 = hip.DeviceArray.zeros(m, dtype)
+        x_ref = hip.DeviceArray.zeros(n, dtype); y_ref = hip.DeviceArray.zeros(m, dtype)
+        hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), x1.ptr, y1.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau[0]), hip.dbl(sigma[0]),
+                                                   hip.dbl(theta[0]), 1, 1, 0, 0, None, None, None))
+        hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), x_ref.ptr, y_ref.ptr, x1.ptr, y1.ptr, None, hip.dbl(tau[1]), hip.dbl(sigma[1]),
+                                                   hip.dbl(theta[1]), 1, 1, 0, 0, None, None, None))
+        xr, yr = x_ref.to_host(), y_ref.to_host()
+        for cols in (0, 1, 2, 3, 5, 8, 1000):
+            x2 = hip.DeviceArray.from_host(np.full(n, 7.0, dtype)); y2 = hip.DeviceArray.from_host(np.full(m, 7.0, dtype))
+            hip.check(hip.fn("fused_iteration2", dtype)(C.byref(desc), x2.ptr, y2.ptr, dx.ptr, dy.ptr, tau, sigma, theta, cols, None))
+            assert np.array_equal(x2.to_host(), xr), (cols, np.flatnonzero(x2.to_host() != xr)[:8])
+            assert np.array_equal(y2.to_host(), yr), (cols, np.flatnonzero(y2.to_host() != yr)[:8])
+            x2.free(); y2.free()
+        for d_ in (x1, y1, x_ref, y_ref):
+            d_.free()

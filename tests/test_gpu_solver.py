@@ -346,3 +346,63 @@ def test_fullsize_4096_adjointness_and_energy():
         assert np.isfinite(st["x"]).all() and np.abs(st["y"]).max() <= np.sqrt(2) + 1e-4      # dual stays in the unit balls
     s.destroy()
     assert energies[-1] < energies[0] and energies[3] <= energies[2] * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("prec,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", STEPS)
+@pytest.mark.parametrize("residual_iter", [1, 2, 3, 4, 7, 10])
+def test_pair_kernel_schedule_is_invisible(prec, dtype, step, residual_iter):
+    """Two iterations per launch (prost_hip_fused_iteration2) where nobody observes the iterate in
+    between: the state after ANY number of iterations -- x, y, the constraint variables z, w (which
+    need x^(k-1), y^(k-1)), the residuals and the step sizes -- is bit-identical to the path that
+    launches every iteration separately, and to the oracle."""
+    prost.set_precision(prec)
+    for (nx, ny) in ((24, 16), (9, 252), (40, 500)):
+        for iters in (1, 2, 3, 5, 8, 9, 10, 11, 23):
+            states = []
+            for pair in (True, False):
+                prob, u, q, f = synthetic.rof_problem(nx, ny, seed=3)
+                b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
+                b[1]["allow_pair_kernel"] = pair
+                o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+                s = prost.Solver(prob, b, o)
+                s.iterate(iters)
+                st = s.state()
+                # a second batch on the same handle: the pairing restarts from an odd/even offset
+                s.iterate(7)
+                st2 = s.state()
+                s.destroy()
+                states.append((st, st2))
+            for a_, b_ in zip(states[0], states[1]):
+                for v in "xyzw":
+                    assert np.array_equal(a_[v], b_[v]), (nx, ny, iters, v)
+                for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):
+                    assert v in a_ and a_[v] == b_[v], (nx, ny, iters, v, a_[v], b_[v])
+        prob, u, q, f = synthetic.rof_problem(nx, ny, seed=3)
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
+        o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+        assert_same_iterates(run_product(prob, b, o, 23), run_oracle(prob, b, o, 23, dtype))
+
+
+@pytest.mark.parametrize("prec,dtype", PRECISIONS)
+def test_pair_kernel_inside_solve_with_callbacks(prec, dtype):
+    """prost.solve with an intermediate-solution callback schedule and a convergence stop: fused
+    pairs never straddle a callback iteration, so the callback sees the same iterates (and the same
+    iteration numbers) with and without the pair kernel."""
+    prost.set_precision(prec)
+    seen = {}
+    for pair in (True, False):
+        prob, u, q, f = synthetic.rof_problem(32, 24, seed=5)
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=5, alg2_gamma=0.5)
+        b[1]["allow_pair_kernel"] = pair
+        log = []
+        o = prost.options(max_iters=97, num_cback_calls=7, verbose=False, tol_rel_primal=1e-30, tol_rel_dual=1e-30, tol_abs_primal=1e-30, tol_abs_dual=1e-30,
+                          interm_cb=lambda it, x, y: log.append((it, np.array(x, copy=True), np.array(y, copy=True))) or False)
+        res = prost.solve(prob, b, o)
+        seen[pair] = (log, res)
+    la, lb = seen[True][0], seen[False][0]
+    assert len(la) == len(lb) and len(la) >= 7
+    for (ia, xa, ya), (ib, xb, yb) in zip(la, lb):
+        assert ia == ib and np.array_equal(xa, xb) and np.array_equal(ya, yb)
+    for v in ("x", "y", "z", "w"):
+        assert np.array_equal(np.asarray(seen[True][1][v]), np.asarray(seen[False][1][v])), v
