@@ -24,9 +24,10 @@ class Backend {
   virtual void PerformIteration() = 0;
   /// MI355X addition: run 1 <= k <= budget iterations and return k.  `budget` counts the iterations
   /// up to AND INCLUDING the next one after which the caller looks at the backend's state (solution
-  /// read-out, callback, end of the run).  A backend may only fuse iterations whose intermediate
-  /// state nobody observes: it returns k > 1 only if k < budget, so the observed iteration itself is
-  /// always executed by PerformIteration().  Default: one iteration.
+  /// read-out, callback, stopping test, end of the run).  A backend may fuse iterations whose
+  /// intermediate state nobody observes; after the call the state must be exactly what k calls of
+  /// PerformIteration() leave (including whatever current_solution() needs of iteration k-1).
+  /// Residual iterations update the residuals as usual.  Default: one iteration.
   virtual int PerformIterations(int budget) { (void)budget; PerformIteration(); return 1; }
   virtual void Release() = 0;
 

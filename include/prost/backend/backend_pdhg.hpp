@@ -55,7 +55,7 @@ class BackendPDHG : public Backend<T> {
   bool TryFused();
   void IterationFused(bool residual_iteration);
   void IterationGeneric(bool residual_iteration);
-  void IterationPair();                   // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
+  void IterationPair(int mode);           // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
   bool is_residual_iteration(size_t k) const { return k == 0 || (k % (size_t)opts_.residual_iter) == 0; }   // backend_pdhg.cu:389
   void FinishResiduals();                 // all-reduce, D2H, sqrt, step-size rules (backend_pdhg.cu:433-476)
   void UpdateAlg2();                      // :483-488
@@ -66,6 +66,7 @@ class BackendPDHG : public Backend<T> {
   // state: fused keeps x, x_prev, y, y_prev only; generic adds kx, kx_prev, kty, kty_prev, temp
   device_vector<T> x_, y_, x_prev_, y_prev_, temp_, kx_, kty_, kx_prev_, kty_prev_;
   device_vector<T> y_spare_;   // third dual buffer: single-kernel residual iterations read y, y_prev and write y_new
+  device_vector<T> x_spare_;   // third primal buffer: pair launches that also store the iterate in between
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
   double* res_host_;       // pinned
   void* workspace_;
@@ -75,12 +76,12 @@ class BackendPDHG : public Backend<T> {
   T arg_alpha_;
   std::vector<shared_ptr<Prox<T>>> prox_g_, prox_fstar_;
   // kernel timing: event pairs around one launch in eight of every kernel kind
-  enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelKinds };
+  enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelPairMid, kKernelPairRes, kKernelKinds };
   bool BeginSample(int kind);
   void EndSample(bool sampled);
   std::vector<void*> ev_;          // pool, two events per sample
   std::vector<int> ev_kind_;       // kind of sample i (events 2i, 2i+1)
-  size_t launches_[kKernelKinds] = {0, 0, 0, 0, 0};
+  size_t launches_[kKernelKinds] = {0};
 };
 
 }  // namespace prost

@@ -214,13 +214,19 @@ int prost_hip_fused_iteration_f64(const prost_hip_fused_desc* desc, double* x_ne
  * reads x^k, y^k, g-coefficients and writes x^(k+2), y^(k+2) -- 7 floats / pixel per two
  * iterations.  tau/sigma/theta are HOST arrays of 2 (the step sizes of iteration k and k+1; alg2
  * changes them every iteration, :483-488).  Bit-identical to two prost_hip_fused_iteration
- * launches.  The intermediate iterate is not written anywhere: callers must not need it
- * (gradient2d with L == 1 only; see _supported). */
+ * launches.  x_mid / y_mid == NULL: the intermediate iterate x^(k+1), y^(k+1) is not written
+ * anywhere, callers must not need it.  x_mid, y_mid != NULL: it is stored there (10 floats/pixel),
+ * leaving the same observable state as two single launches.  res_out4 != NULL (needs x_mid, y_mid
+ * and `workspace`): also the four residual sums of iteration k+1 as prost_hip_fused_iteration
+ * writes them (same terms; the summation order differs, so the sums agree to rounding).
+ * gradient2d with L == 1 only; see _supported. */
 int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype);
 int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y,
-                                   const double* tau, const double* sigma, const double* theta, int cols_per_block, void* stream);
+                                   float* x_mid, float* y_mid, const double* tau, const double* sigma, const double* theta,
+                                   int cols_per_block, double* res_out4, void* workspace, void* stream);
 int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* desc, double* x_out, double* y_out, const double* x, const double* y,
-                                   const double* tau, const double* sigma, const double* theta, int cols_per_block, void* stream);
+                                   double* x_mid, double* y_mid, const double* tau, const double* sigma, const double* theta,
+                                   int cols_per_block, double* res_out4, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* ADMM / CGLS building blocks (src/backend/backend_admm.cu, include/prost/cgls.hpp)           */

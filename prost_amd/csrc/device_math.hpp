@@ -58,24 +58,23 @@ __device__ __forceinline__ float div_to_float_exact(float x, const UniformDiv& u
 }
 __device__ __forceinline__ double div_to_float_exact(double x, const UniformDiv& u) { return u.D == 1.0 ? x : x / u.D; }
 // the same for VEC values with straight-line code: one (rarely taken) branch per vector instead of
-// one per element, so the independent chains of the elements interleave.  D != 1 required.
+// one per element, so the independent chains of the elements interleave.
 template <int VEC>
 __device__ __forceinline__ void div_to_float_exact_vec(const float (&x)[VEC], const UniformDiv& u, float (&out)[VEC]) {
-  double q1[VEC];
-  bool slow = false;
+  unsigned slow = 0;                                   // bitwise, not short-circuit: no branch per element
 #pragma unroll
   for (int j = 0; j < VEC; j++) {
     const double xd = (double)x[j];
     const double q0 = xd * u.rD;
     const double rem = __builtin_fma(-q0, u.D, xd);
-    q1[j] = __builtin_fma(rem, u.rD, q0);
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(q1[j]);
-    const int low = (int)(bits & 0x1FFFFFFFull);
-    const int bexp = (int)((bits >> 52) & 0x7FF);
-    const bool near_tie = (low >= (1 << 28) - 2) && (low <= (1 << 28) + 2);
-    const bool normal_float = bexp > 1023 - 126 && bexp < 1023 + 127;
-    slow = slow || ((near_tie || !normal_float) && q1[j] != 0.0);
-    out[j] = (float)q1[j];
+    const double q1 = __builtin_fma(rem, u.rD, q0);
+    out[j] = (float)q1;
+    // near a float rounding boundary: the 29 dropped mantissa bits within 2 ulp(double) of the tie
+    const unsigned low = (unsigned)((unsigned long long)__double_as_longlong(q1)) & 0x1FFFFFFFu;
+    const unsigned near_tie = (low - ((1u << 28) - 2u)) <= 4u;
+    // result not a normal float (subnormal / overflow range) although x is not zero: take the division too
+    const unsigned odd_range = !__builtin_isnormal(out[j]) && x[j] != 0.0f;
+    slow |= near_tie | odd_range;
   }
   if (__builtin_expect(slow, 0)) {
 #pragma unroll
@@ -87,6 +86,42 @@ __device__ __forceinline__ void div_to_float_exact_vec(const double (&x)[VEC], c
 #pragma unroll
   for (int j = 0; j < VEC; j++) out[j] = x[j] / u.D;
 }
+
+// ---- correctly rounded fp32 division / square root with fewer instructions ---------------------
+// A VALU instruction costs one issue slot of 4 cycles whatever it does, and the compiler's IEEE
+// expansions are long: x / y = 11 instructions (v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas,
+// v_div_fixup), sqrtf = 16 (range scaling + refinement + class fix-up).  The two-iteration kernel
+// is bound by exactly that, so its hot path uses the forms below.  Both return the correctly rounded
+// result, i.e. the same bits as `/` and sqrtf (IEEE results are unique).
+//
+// Division by a shared denominator through ONE double reciprocal: r = 1/(double)d refined to
+// ~2^-52, q = (float)((double)n * r).  |n r - n/d| < 2^-51 |n/d|, while the exact quotient of two
+// 24-bit floats is never within 2^-49 (relative) of a float rounding boundary (n = m d with m a
+// 25-bit midpoint is impossible, and n - m d is a non-zero multiple of the product's last place),
+// so rounding n r gives RN(n/d) -- including subnormal quotients and signed zeros; d = +-0, +-inf
+// or NaN are NOT supported (callers substitute / fall back).
+__device__ __forceinline__ double rcp_refined(float d) {
+  const double dd = (double)d;
+  double r = __builtin_amdgcn_rcp(dd);                     // v_rcp_f64: 2^-23 relative
+  double e = __builtin_fma(-dd, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-dd, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double rcp_refined(double d) { return 1.0 / d; }
+__device__ __forceinline__ float mul_rcp(float n, double r) { return (float)((double)n * r); }
+// sqrtf(x) for x in [2^-96, 2^126]: v_sqrt_f32 (1 ulp) + the compiler's own +-1 ulp residual test,
+// without the 2^32 range scaling and the zero / infinity fix-up that the general expansion carries
+__device__ __forceinline__ float sqrt_midrange(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float s_dn = __int_as_float(__float_as_int(s) - 1), s_up = __int_as_float(__float_as_int(s) + 1);
+  const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+  s = r_dn <= 0.0f ? s_dn : s;
+  s = r_up > 0.0f ? s_up : s;
+  return s;
+}
+__device__ __forceinline__ double sqrt_midrange(double x) { return sqrt(x); }
 
 // ---- Function1D* (include/prost/prox/elemop/function_1d.hpp) --------------------------------
 template <class T> __device__ __forceinline__ T f1d_abs(T x0, T tau) {            // :47-60

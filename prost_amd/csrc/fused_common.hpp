@@ -107,6 +107,9 @@ bool fused3d_desc_ok(const prost_hip_fused_desc* d);
 template <class T> int run_primal3d(const prost_hip_fused_desc* d, T* x_new, const T* x, const T* y, const T* y_prev, double tau, int use_kty, int use_kty_prev, double* out2, void* ws, void* stream);
 template <class T> int run_dual3d(const prost_hip_fused_desc* d, T* y_new, const T* y, const T* xn, const T* xo, double sigma, double theta, int use_kx_prev, double* out2, void* ws, void* stream);
 
+// folds nslots x 4 doubles (one partial per wavefront) in a fixed order -> out4 (kernels_fused_iter.hip)
+int launch_fold4(double* out4, const double* partial, unsigned nslots, hipStream_t s);
+
 inline bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
 }  // namespace prost_hip

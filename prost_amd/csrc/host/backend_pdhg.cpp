@@ -99,6 +99,7 @@ void BackendPDHG<T>::Initialize() {
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
   if (single_kernel_) y_spare_.resize(m);
   pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_supported(&desc_, dtype_id<T>()) == 1;
+  if (pair_kernel_) x_spare_.resize(n);
 
   CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
   CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
@@ -133,7 +134,7 @@ void BackendPDHG<T>::Release() {
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); ev_kind_.clear();
-  y_spare_.clear();
+  y_spare_.clear(); x_spare_.clear();
   x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
 }
 
@@ -143,17 +144,19 @@ void BackendPDHG<T>::PerformIteration() {
   if (fused_) IterationFused(residual_iteration); else IterationGeneric(residual_iteration);
 }
 
-/// Two iterations in one launch when (a) the caller does not look at the state in between
-/// (budget >= 3: neither of the two is the observed iteration), (b) neither is a residual
-/// iteration, (c) the iteration after them is not one either -- it reads y^(k+1) as y_prev, which
-/// the pair kernel never writes -- and (d) k >= 2 (iterations 0 and 1 run with zeroed K^T y / K x
-/// vectors, backend_pdhg.cu:213-216).  The iteration before any observation point is therefore
-/// always a single launch, which leaves x_prev_ / y_prev_ exactly as the reference has them.
+/// Two iterations (k, k+1) in one launch whenever k >= 2 is not a residual iteration (iterations 0
+/// and 1 run with zeroed K^T y / K x vectors, backend_pdhg.cu:213-216; a residual iteration as the
+/// FIRST of a pair would need y^(k-1)).  What the launch leaves behind depends on who looks next:
+///   mode 2  k+1 is a residual iteration: residual sums in-kernel, x^(k+1), y^(k+1) stored
+///   mode 1  k+1 is the iteration the caller observes (budget == 2), or k+2 is a residual iteration
+///           (it reads y^(k+1) as y_prev): x^(k+1), y^(k+1) stored -> x_prev_ / y_prev_ as the reference
+///   mode 0  nobody reads the iterate in between: it never leaves the registers (7 floats/pixel)
 template <typename T>
 int BackendPDHG<T>::PerformIterations(int budget) {
-  if (pair_kernel_ && budget >= 3 && iteration_ >= 2 && !is_residual_iteration(iteration_) &&
-      !is_residual_iteration(iteration_ + 1) && !is_residual_iteration(iteration_ + 2)) {
-    IterationPair();
+  const size_t k = iteration_;
+  if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
+    const int mode = is_residual_iteration(k + 1) ? 2 : ((budget == 2 || is_residual_iteration(k + 2)) ? 1 : 0);
+    IterationPair(mode);
     return 2;
   }
   PerformIteration();
@@ -177,19 +180,30 @@ void BackendPDHG<T>::EndSample(bool sampled) {
 }
 
 template <typename T>
-void BackendPDHG<T>::IterationPair() {
+void BackendPDHG<T>::IterationPair(int mode) {
   void* s = CurrentStream();
   double tau[2], sigma[2], theta[2];
   tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
+  iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
-  const bool t = BeginSample(kKernelPair);
-  CheckHip(Api<T>::fused_iteration2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0, s), "fused_iteration2");
-  EndSample(t);
-  x_.swap(x_prev_);          // x_ = x^(k+2); x_prev_ / y_prev_ hold x^k / y^k until the next single launch rewrites them
-  y_.swap(y_prev_);
+  const bool t = BeginSample(mode == 2 ? kKernelPairRes : (mode == 1 ? kKernelPairMid : kKernelPair));
+  if (mode == 0) {
+    CheckHip(Api<T>::fused_iteration2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
+                                      nullptr, nullptr, s), "fused_iteration2");
+    EndSample(t);
+    x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ hold x^k / y^k until a mode >= 1 pair or a single launch rewrites them
+    y_.swap(y_prev_);
+  } else {
+    CheckHip(Api<T>::fused_iteration2(&desc_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
+                                      theta, 0, mode == 2 ? res_dev_ : nullptr, mode == 2 ? workspace_ : nullptr, s), "fused_iteration2");
+    EndSample(t);
+    x_.swap(x_spare_);       // x_ = x^(k+2), x_prev_ = x^(k+1): the state two single launches leave
+    y_.swap(y_spare_);
+    if (mode == 2) FinishResiduals();                                  // iteration_ == k+1 here, as in the single path
+  }
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
-  iteration_ += 2;
+  iteration_++;
 }
 
 /// two kernels: x_ / y_ ping-pong with x_prev_ / y_prev_
@@ -343,7 +357,7 @@ void BackendPDHG<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& 
 template <typename T>
 size_t BackendPDHG<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
-  if (fused_) return 2 * (n + m) * sizeof(T);
+  if (fused_) return (2 * (n + m) + (single_kernel_ ? m : 0) + (pair_kernel_ ? n : 0)) * sizeof(T);
   return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511
 }
 
@@ -352,8 +366,8 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   out.clear();
   if (ev_kind_.empty()) return;
   CheckHip(prost_hip_event_synchronize(ev_[2 * ev_kind_.size() - 1]), "event_synchronize");
-  double sum[kKernelKinds] = {0, 0, 0, 0, 0};
-  size_t cnt[kKernelKinds] = {0, 0, 0, 0, 0};
+  double sum[kKernelKinds] = {0};
+  size_t cnt[kKernelKinds] = {0};
   for (size_t i = 0; i < ev_kind_.size(); i++) {
     float ms = 0;
     CheckHip(prost_hip_event_elapsed_ms(ev_[2 * i], ev_[2 * i + 1], &ms), "event_elapsed");
@@ -361,8 +375,9 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
-                                     "fused_iter2d_kernel", "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel"};
-  const int iters[kKernelKinds] = {0, 0, 1, 1, 2};
+                                     "fused_iter2d_kernel", "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
+                                     "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+mid+residuals"};
+  const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++)
     if (cnt[k]) out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k]});
   ev_kind_.clear();

@@ -258,6 +258,11 @@ __global__ void __launch_bounds__(kBlock) fold4_kernel(double* __restrict__ out4
   }
 }
 
+int launch_fold4(double* out4, const double* partial, unsigned nslots, hipStream_t s) {
+  hipLaunchKernelGGL(fold4_kernel, dim3(1), dim3(kBlock), 0, s, out4, partial, nslots);
+  PH_LAUNCH_END("fold4 kernel");
+}
+
 static bool iter_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   if (!d || d->is3d) return false;
   if (d->nx < 2 || d->ny < 2 || d->L < 1 || d->L > 2) return false;

@@ -19,8 +19,10 @@
 // are bit-identical to two single launches.  Intermediate iterates are NOT stored: the host only
 // pairs iterations whose intermediate state nobody reads (see BackendPDHG::PerformIterations).
 #include "fused_common.hpp"
+#include "reduce.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace prost_hip {
 
@@ -39,10 +41,16 @@ struct Col2 {
   T y1[VEC], y2[VEC], x[VEC], gc[NG][VEC];
 };
 
-template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST>
-__global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
+// MODE 0: plain.  MODE 1: additionally stores the intermediate iterate x^(k+1), y^(k+1) (x_mid, y_mid)
+// so that the state after the launch is fully observable (10 floats/pixel instead of 7).  MODE 2:
+// MODE 1 + the four residual sums of iteration k+1 (backend_pdhg.cu:392-431) -- everything they need
+// (y^k, y^(k+1), y^(k+2), x^(k+1), x^(k+2), K^T y^k, K^T y^(k+1), K x^(k+1), K x^(k+2)) is in registers.
+template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST, int MODE>
+__global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
-                                                                FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2) {
+                                                                T* __restrict__ x_mid, T* __restrict__ y_mid,
+                                                                FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2,
+                                                                double* __restrict__ partial) {
   const long nx = (long)a.nx, ny = (long)a.ny;
   const int lane = threadIdx.x;
   constexpr int kRowsPerWave = (kWave - 2) * VEC;
@@ -57,7 +65,10 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
   const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t N = (size_t)nx * (size_t)ny;
   constexpr bool kUniformG = (GMASK & 0x15) == 0;
+  constexpr bool kRes = MODE == 2;
   typedef Col2<T, VEC, GMASK> Col;
+  const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
   // one 32-bit byte offset per lane serves every plane (x, y1, y2, coefficients, outputs): the plane
   // bases are wave-uniform (SGPR pairs), so the loads/stores use the saddr + 32-bit voffset form and
@@ -65,6 +76,7 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
   auto off_of = [&](long c) { return (unsigned)((c * ny + row0) * (long)sizeof(T)); };
   const T* const y2base = y + N;
   T* const y2out = y_out + N;
+  T* const y2mid = MODE >= 1 ? y_mid + N : nullptr;
   auto load_col = [&](long c, Col& in) {
     const unsigned o = off_of(c);
     ldv_o<T, VEC>(y, o, in.y1); ldv_o<T, VEC>(y2base, o, in.y2); ldv_o<T, VEC>(x, o, in.x);
@@ -80,18 +92,22 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
     }
   };
   // primal step at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 inlined)
-  auto primal = [&](long c, const T (&y1c)[VEC], const T (&y2c)[VEC], T up, const T (&y1p)[VEC], const T (&xin)[VEC],
-                    const T (&gc)[Col::NG][VEC], const IterParams<T>& P, T (&xn)[VEC]) {
+  // `inner` (a compile-time tag): every row of the wave and the columns c-1 .. c+1 are strictly inside
+  // the image, so the boundary selects of the gradient stencil drop out (identical values otherwise)
+  auto primal = [&](auto inner, long c, const T (&y1c)[VEC], const T (&y2c)[VEC], T up, const T (&y1p)[VEC], const T (&xin)[VEC],
+                    const T (&gc)[Col::NG][VEC], const IterParams<T>& P, T (&xn)[VEC], T (&kt)[VEC]) {
+    constexpr bool I = decltype(inner)::value;
     const T tauT = P.tau * a.Tval;
     T parg[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
-      T divy = (row < ny - 1) ? y2c[j] : (T)0;
-      if (row > 0) divy -= (j > 0) ? y2c[(j + VEC - 1) % VEC] : up;
-      T divx = (c < nx - 1) ? y1c[j] : (T)0;
-      if (c > 0) divx -= y1p[j];
+      T divy = (I || row < ny - 1) ? y2c[j] : (T)0;
+      if (I || row > 0) divy -= (j > 0) ? y2c[(j + VEC - 1) % VEC] : up;
+      T divx = (I || c < nx - 1) ? y1c[j] : (T)0;
+      if (I || c > 0) divx -= y1p[j];
       const T kty = (T)0 - (divx + divy);
+      kt[j] = kty;
       const T arg = xin[j] - tauT * kty;
       if (FAST) {
         parg[j] = arg - (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
@@ -113,37 +129,41 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
       for (int j = 0; j < VEC; j++) xn[j] = r[j] + (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
     }
   };
+  // primal_residual_transform (backend_pdhg.cu:97-120) of one pixel, both components
+  auto residual_terms = [&](int j, T y1o, T y2o, T o1, T o2, T kx1, T kx2, T kp1, T kp2, const IterParams<T>& P) {
+    (void)j;
+    const T z1 = (y1o - o1) / (P.sigma * sqS) + sqS * ((1 + P.theta) * kx1 - P.theta * kp1);
+    const T d1 = z1 - sqS * kx1;
+    r_pd += (double)(d1 * d1); r_pv += (double)(z1 * z1);
+    const T z2 = (y2o - o2) / (P.sigma * sqS) + sqS * ((1 + P.theta) * kx2 - P.theta * kp2);
+    const T d2 = z2 - sqS * kx2;
+    r_pd += (double)(d2 * d2); r_pv += (double)(z2 * z2);
+  };
   // dual step at column c (backend_pdhg.cu:341-370 with block_gradient2d.cu:61-77 inlined)
-  auto dual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
-                  const T (&y1c)[VEC], const T (&y2c)[VEC], const IterParams<T>& P, T (&o1)[VEC], T (&o2)[VEC]) {
+  auto dual = [&](auto inner, long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+                  const T (&y1c)[VEC], const T (&y2c)[VEC], const IterParams<T>& P, T (&o1)[VEC], T (&o2)[VEC], bool acc) {
+    constexpr bool I = decltype(inner)::value;
     const T sigS = P.sigma * a.Sval, theta = P.theta;
-    const bool has_next = c + 1 < nx;
+    const bool has_next = I || c + 1 < nx;
     const T bel_n = __shfl_down(xn_c[0], 1, kWave);
     const T bel_o = __shfl_down(xo_c[0], 1, kWave);
+    T a1v[VEC], a2v[VEC], nv[VEC], k1v[VEC], k2v[VEC], q1v[VEC], q2v[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
       const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
       const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
       const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
-      const T kx2 = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
+      const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
       const T kp1 = has_next ? xo_n[j] - xo_c[j] : (T)0;
-      const T kp2 = (row < ny - 1) ? below_o - xo_c[j] : (T)0;
+      const T kp2 = (I || row < ny - 1) ? below_o - xo_c[j] : (T)0;
       const T arg1 = y1c[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
       const T arg2 = y2c[j] + sigS * ((1 + theta) * kx2 - theta * kp2);
       T norm = 0;
       norm += arg1 * arg1;
       norm += arg2 * arg2;
       if (FAST) {
-        // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked):
-        // pr = min(||v|| - b, 0) + b; branch-free (the quotient of a zero-norm group is replaced by 0)
-        const bool nz = norm > 0;
-        const T nrm = nz ? t_sqrt(norm) : (T)1;
-        const T t = nrm - a.f_val[1];
-        const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-        const T q1 = pr * arg1 / nrm, q2 = pr * arg2 / nrm;
-        o1[j] = nz ? q1 : (T)0;
-        o2[j] = nz ? q2 : (T)0;
+        a1v[j] = arg1; a2v[j] = arg2; nv[j] = norm;
       } else if (norm > 0) {
         norm = t_sqrt(norm);
         const T pr = scaled_prox_u<T, FFN>(a.f_fn, norm, a.f_val, P.uf);
@@ -152,6 +172,50 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
       } else {
         o1[j] = 0; o2[j] = 0;
       }
+      if (!FAST && kRes && acc && owner) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
+      if (FAST) { k1v[j] = kx1; k2v[j] = kx2; q1v[j] = kp1; q2v[j] = kp2; }
+    }
+    if (FAST) {
+      // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked):
+      //   out = pr v / ||v||,  pr = min(||v|| - b, 0) + b,  out = 0 for ||v|| = 0.
+      // Straight-line for the VEC pixels with the short correctly rounded sqrt / division forms of
+      // device_math.hpp.  A zero norm takes the same path with ||v|| := 2^-48: both numerators are
+      // pr * (+-0), the quotient +-0, and "+ 0" makes it the +0 the reference writes (q + 0 == q
+      // for every other q).  Norms outside [2^-96, 2^126] (incl. NaN) take the general expansion.
+      constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
+      unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        tmin = min(tmin, (unsigned)__float_as_int((float)nv[j]) - 1u);     // 0 -> 0xFFFFFFFF: a zero norm is fine
+        nmax = nv[j] > nmax ? nv[j] : nmax;
+      }
+      const bool mid = sizeof(T) == 4 && !(VAR & 4) && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
+      if (__builtin_expect(mid, 1)) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const T nrm = sqrt_midrange(nv[j] > (T)kLo ? nv[j] : (T)kLo);
+          const T t = nrm - a.f_val[1];
+          const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+          const auto r = rcp_refined(nrm);
+          o1[j] = mul_rcp(pr * a1v[j], r) + (T)0;
+          o2[j] = mul_rcp(pr * a2v[j], r) + (T)0;
+        }
+      } else {                                                   // general expansions, still branch-free (the fp64 path)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const bool nz = nv[j] > 0;
+          const T nrm = nz ? t_sqrt(nv[j]) : (T)1;
+          const T t = nrm - a.f_val[1];
+          const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+          const T q1 = pr * a1v[j] / nrm, q2 = pr * a2v[j] / nrm;
+          o1[j] = nz ? q1 : (T)0;
+          o2[j] = nz ? q2 : (T)0;
+        }
+      }
+      if (kRes && acc && owner) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], k1v[j], k2v[j], q1v[j], q2v[j], P);
+      }
     }
   };
 
@@ -159,15 +223,19 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
   T x1_0[VEC], x1_1[VEC], x1_2[VEC];            // x^(k+1) at columns c, c+1, c+2
   T y1a_0[VEC], y1b_0[VEC], y1a_1[VEC], y1b_1[VEC];   // y^(k+1) (both components) at columns c, c+1
   T x2_0[VEC], x2_1[VEC];                       // x^(k+2) at columns c, c+1
+  T kt_1[VEC], kt_2[VEC], kt_c[VEC];            // K^T y^k at columns c+1, c+2; K^T y^(k+1) at c+1 (residuals)
 #pragma unroll
   for (int j = 0; j < VEC; j++) {
     x1_0[j] = x1_1[j] = x1_2[j] = 0; y1a_0[j] = y1b_0[j] = y1a_1[j] = y1b_1[j] = 0; x2_0[j] = x2_1[j] = 0;
+    kt_1[j] = kt_2[j] = kt_c[j] = 0;
   }
   if (active) {
     if (xa - 2 >= 0) ldv_o<T, VEC>(y, off_of(xa - 2), in1.y1);
     if (xa - 1 >= 0) load_col(xa - 1, in2);
   }
-  for (long c = xa - 3; c < xb; c++) {
+  // every lane active and no lane on the first / last image row: the whole strip is interior
+  const bool strip_inner = (long)strip * kRowsPerWave - VEC >= 1 && (long)strip * kRowsPerWave + (long)(kWave - 1) * VEC < ny - 1;
+  auto step = [&](auto inner, long c) {
     Col pre = {};
     const bool has_pre = c + 3 < nx && c + 3 <= xb + 1;
     if (active && has_pre) load_col(c + 3, pre);
@@ -175,18 +243,32 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
     if (ca >= 0 && ca < nx) {                                                                     // stage A
       // lane 0 gets no row above: its first row is never needed (the top halo is its LAST row)
       const T up = __shfl_up(in2.y2[VEC - 1], 1, kWave);
-      primal(ca, in2.y1, in2.y2, up, in1.y1, in2.x, in2.gc, p1, x1_2);
+      primal(inner, ca, in2.y1, in2.y2, up, in1.y1, in2.x, in2.gc, p1, x1_2, kt_2);
     }
-    if (cb >= 0 && cb >= xa - 1 && cb < nx) dual(cb, x1_1, x1_2, in1.x, in2.x, in1.y1, in1.y2, p1, y1a_1, y1b_1);   // stage B
+    if (cb >= 0 && cb >= xa - 1 && cb < nx) dual(inner, cb, x1_1, x1_2, in1.x, in2.x, in1.y1, in1.y2, p1, y1a_1, y1b_1, false);   // stage B
     if (cb >= xa && cb < nx) {                                                                    // stage C
       const T up = __shfl_up(y1b_1[VEC - 1], 1, kWave);          // lane 0: no source, its first row is halo
-      primal(cb, y1a_1, y1b_1, up, y1a_0, x1_1, in1.gc, p2, x2_1);
-      if (owner && cb < xb) stv_o<T, VEC, (VAR & 1) != 0>(x_out, off_of(cb), x2_1);
+      primal(inner, cb, y1a_1, y1b_1, up, y1a_0, x1_1, in1.gc, p2, x2_1, kt_c);
+      if (owner && cb < xb) {
+        stv_o<T, VEC, (VAR & 1) != 0>(x_out, off_of(cb), x2_1);
+        if (MODE >= 1) stv_o<T, VEC, (VAR & 1) != 0>(x_mid, off_of(cb), x1_1);
+        if (kRes) {                                            // dual_residual_transform (backend_pdhg.cu:73-94)
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const T w_hat = (x1_1[j] - x2_1[j]) / (p2.tau * sqT) - sqT * kt_1[j];
+            const T diff = w_hat + sqT * kt_c[j];
+            r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat);
+          }
+        }
+      }
     }
     if (c >= xa) {                                                                                // stage D
       T o1[VEC], o2[VEC];
-      dual(c, x2_0, x2_1, x1_0, x1_1, y1a_0, y1b_0, p2, o1, o2);
-      if (owner) { stv_o<T, VEC, (VAR & 1) != 0>(y_out, off_of(c), o1); stv_o<T, VEC, (VAR & 1) != 0>(y2out, off_of(c), o2); }
+      dual(inner, c, x2_0, x2_1, x1_0, x1_1, y1a_0, y1b_0, p2, o1, o2, true);
+      if (owner) {
+        stv_o<T, VEC, (VAR & 1) != 0>(y_out, off_of(c), o1); stv_o<T, VEC, (VAR & 1) != 0>(y2out, off_of(c), o2);
+        if (MODE >= 1) { stv_o<T, VEC, (VAR & 1) != 0>(y_mid, off_of(c), y1a_0); stv_o<T, VEC, (VAR & 1) != 0>(y2mid, off_of(c), y1b_0); }
+      }
     }
     // shift the pipeline by one column
     in1 = in2;
@@ -196,6 +278,20 @@ __global__ void __launch_bounds__(kWave, (VAR & 2) ? 4 : 1) fused_iter2d_x2_kern
       x1_0[j] = x1_1[j]; x1_1[j] = x1_2[j];
       y1a_0[j] = y1a_1[j]; y1b_0[j] = y1b_1[j];
       x2_0[j] = x2_1[j];
+      kt_1[j] = kt_2[j];
+    }
+  };
+  for (long c = xa - 3; c < xb; c++) {
+    // the stencils of this step touch columns c-1 .. c+3 (stage D reads column c+1, stage A column
+    // c+1 .. c+2 and their left neighbours): all strictly inside, all four stages running
+    if (strip_inner && c >= xa && c >= 2 && c + 3 < nx - 1) step(std::true_type(), c);
+    else step(std::false_type(), c);
+  }
+  if (kRes) {
+    r_pd = wave_sum(r_pd); r_pv = wave_sum(r_pv); r_dd = wave_sum(r_dd); r_dv = wave_sum(r_dv);
+    if (lane == 0) {
+      double* p = partial + 4 * (size_t)blockIdx.x;
+      p[0] = r_pd; p[1] = r_pv; p[2] = r_dd; p[3] = r_dv;
     }
   }
 }
@@ -215,12 +311,14 @@ static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
 }
 
 template <class T>
-static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
-                     const double* theta, int cols, void* stream) {
+static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, T* x_mid, T* y_mid, const double* tau,
+                     const double* sigma, const double* theta, int cols, double* out4, void* ws, void* stream) {
   constexpr int V = VecOf<T>::N;
   if (!iter2_desc_ok(d, sizeof(T) == 4 ? 0 : 1) || !aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) {
     set_error("fused double iteration: unsupported description"); return 1;
   }
+  if ((x_mid == nullptr) != (y_mid == nullptr) || !aligned16(x_mid) || !aligned16(y_mid)) { set_error("fused double iteration: x_mid and y_mid go together"); return 1; }
+  if (out4 && (!ws || !x_mid)) { set_error("fused double iteration: residuals need workspace, x_mid and y_mid"); return 1; }
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
   if (cols <= 0) {
@@ -233,6 +331,8 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
     cols = 6;
     for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
   }
+  // residual launches write one partial (4 doubles) per wavefront: kReduceBlocks / 2 of them fit the workspace
+  while (out4 && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) cols += 6;
   a.cols_per_block = cols;
   a.chunks = (unsigned)((d->nx + cols - 1) / cols);
   if (strips * a.chunks > 0x7fffffffull) { set_error("fused double iteration: grid too large"); return 1; }
@@ -252,21 +352,22 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
                     p[1].ug.den_one && p[1].uf.den_one;
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
   hipStream_t s = as_stream(stream);
-  static const int variant = getenv("PROST_HIP_ITER2_VARIANT") ? atoi(getenv("PROST_HIP_ITER2_VARIANT")) : 1;   // bit 0: non-temporal stores, bit 1: 4 waves/SIMD (128 VGPRs)
-#define GO(G, F, M, VARv, FASTv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv>), grid, block, 0, s, x_out, y_out, x, y, a, p[0], p[1])
+  static const int variant = getenv("PROST_HIP_ITER2_VARIANT") ? atoi(getenv("PROST_HIP_ITER2_VARIANT")) : 1;   // bit 0: non-temporal stores
+  const int mode = out4 ? 2 : (x_mid ? 1 : 0);
+  double* partial = static_cast<double*>(ws);
+#define GO3(G, F, M, VARv, FASTv, MODEv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv, MODEv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
+#define GO(G, F, M, VARv, FASTv) do { if (mode == 0) GO3(G, F, M, VARv, FASTv, 0); else if (mode == 1) GO3(G, F, M, VARv, FASTv, 1); else GO3(G, F, M, VARv, FASTv, 2); } while (0)
   if (fast) {
-    switch (variant & 3) {
-      case 0: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 0, true); break;
-      case 1: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true); break;
-      case 2: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 2, true); break;
-      default: GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 3, true); break;
-    }
+    if (variant & 1) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 0, true);
   }
   else if (d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, false);
   else if (mask == 0) GO(-1, -1, 0, 1, false);
   else GO(-1, -1, 0x7F, 1, false);
 #undef GO
-  PH_LAUNCH_END("fused double iteration kernel");
+#undef GO3
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused double iteration kernel"); }
+  if (out4) return launch_fold4(out4, partial, grid.x, s);
+  return 0;
 }
 
 }  // namespace prost_hip
@@ -275,12 +376,12 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) ? 1 : 0; }
-int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
-                                   const double* sigma, const double* theta, int cols_per_block, void* s) {
-  return run_iter2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols_per_block, s);
+int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, float* x_mid, float* y_mid,
+                                   const double* tau, const double* sigma, const double* theta, int cols_per_block, double* res_out4, void* workspace, void* s) {
+  return run_iter2<float>(d, x_out, y_out, x, y, x_mid, y_mid, tau, sigma, theta, cols_per_block, res_out4, workspace, s);
 }
-int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
-                                   const double* sigma, const double* theta, int cols_per_block, void* s) {
-  return run_iter2<double>(d, x_out, y_out, x, y, tau, sigma, theta, cols_per_block, s);
+int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, double* x_mid, double* y_mid,
+                                   const double* tau, const double* sigma, const double* theta, int cols_per_block, double* res_out4, void* workspace, void* s) {
+  return run_iter2<double>(d, x_out, y_out, x, y, x_mid, y_mid, tau, sigma, theta, cols_per_block, res_out4, workspace, s);
 }
 }  // extern "C"

@@ -349,12 +349,62 @@ def test_double_iteration_kernel_equals_two_single_launches(hip, dtype, shape, f
                                                    hip.dbl(theta[0]), 1, 1, 0, 0, None, None, None))
         hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), x_ref.ptr, y_ref.ptr, x1.ptr, y1.ptr, None, hip.dbl(tau[1]), hip.dbl(sigma[1]),
                                                    hip.dbl(theta[1]), 1, 1, 0, 0, None, None, None))
-        xr, yr = x_ref.to_host(), y_ref.to_host()
+        # residual sums of the SECOND iteration as the single-iteration kernel reports them
+        ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+        r4s = hip.DeviceArray.zeros(4, np.float64); xs = hip.DeviceArray.zeros(n, dtype); ys = hip.DeviceArray.zeros(m, dtype)
+        hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), xs.ptr, ys.ptr, x1.ptr, y1.ptr, dy.ptr, hip.dbl(tau[1]), hip.dbl(sigma[1]),
+                                                   hip.dbl(theta[1]), 1, 1, 1, 0, r4s.ptr, ws.ptr, None))
+        res_ref = r4s.to_host()
+        xr, yr, x1r, y1r = x_ref.to_host(), y_ref.to_host(), x1.to_host(), y1.to_host()
         for cols in (0, 1, 2, 3, 5, 8, 1000):
-            x2 = hip.DeviceArray.from_host(np.full(n, 7.0, dtype)); y2 = hip.DeviceArray.from_host(np.full(m, 7.0, dtype))
-            hip.check(hip.fn("fused_iteration2", dtype)(C.byref(desc), x2.ptr, y2.ptr, dx.ptr, dy.ptr, tau, sigma, theta, cols, None))
-            assert np.array_equal(x2.to_host(), xr), (cols, np.flatnonzero(x2.to_host() != xr)[:8])
-            assert np.array_equal(y2.to_host(), yr), (cols, np.flatnonzero(y2.to_host() != yr)[:8])
-            x2.free(); y2.free()
-        for d_ in (x1, y1, x_ref, y_ref):
+            for mode in (0, 1, 2):
+                x2 = hip.DeviceArray.from_host(np.full(n, 7.0, dtype)); y2 = hip.DeviceArray.from_host(np.full(m, 7.0, dtype))
+                xm = hip.DeviceArray.from_host(np.full(n, 7.0, dtype)); ym = hip.DeviceArray.from_host(np.full(m, 7.0, dtype))
+                r4 = hip.DeviceArray.zeros(4, np.float64)
+                hip.check(hip.fn("fused_iteration2", dtype)(C.byref(desc), x2.ptr, y2.ptr, dx.ptr, dy.ptr, xm.ptr if mode else None, ym.ptr if mode else None,
+                                                            tau, sigma, theta, cols, r4.ptr if mode == 2 else None, ws.ptr if mode == 2 else None, None))
+                assert np.array_equal(x2.to_host(), xr), (cols, mode, np.flatnonzero(x2.to_host() != xr)[:8])
+                assert np.array_equal(y2.to_host(), yr), (cols, mode, np.flatnonzero(y2.to_host() != yr)[:8])
+                if mode:
+                    assert np.array_equal(xm.to_host(), x1r) and np.array_equal(ym.to_host(), y1r), (cols, mode)
+                if mode == 2:
+                    assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
+                for d_ in (x2, y2, xm, ym, r4):
+                    d_.free()
+        for d_ in (x1, y1, x_ref, y_ref, xs, ys, r4s):
             d_.free()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_double_iteration_kernel_special_values(hip, dtype):
+    """The pair kernel's short sqrt / division forms (device_math.hpp: double-reciprocal division,
+    un-scaled sqrt refinement) only run for norms in [2^-96, 2^126]; zero norms, subnormal / tiny /
+    huge magnitudes and signed zeros take the general expansions.  Every regime must reproduce the
+    single-iteration kernel bit for bit."""
+    nx, ny = 24, 1028
+    n, m = nx * ny, 2 * nx * ny
+    rng = np.random.default_rng(23)
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    # flat regions (K x == 0) with y == 0 -> zero norms; tiny, subnormal and huge duals; signed zeros
+    x[: n // 6] = 0.5
+    y[: n // 6] = 0.0; y[n: n + n // 6] = 0.0
+    y[n // 6: n // 5] *= 1e-30; y[n + n // 6: n + n // 5] *= 1e-30
+    y[n // 5: n // 4] *= 1e-42; y[n + n // 5: n + n // 4] = 0.0
+    y[n // 4: n // 3] *= 3e19; y[n + n // 4: n + n // 3] *= 3e19
+    y[n // 3: n // 3 + 500] = -0.0
+    x[n // 2: n // 2 + 300] = 1e-39; x[n // 2 + 300: n // 2 + 600] = -0.0
+    tau = (C.c_double * 2)(0.9, 0.7); sigma = (C.c_double * 2)(1.1, 1.4); theta = (C.c_double * 2)(0.85, 0.8)
+    desc, keep = _fused_desc(hip, dtype, nx, ny, 1, "square", [1.0, f, 10.0, 0.0, 0.0, 0.3, 0.0], "ind_leq0", [1.0, 1.0, 1.0, 0.0, 0.0, 0.3, 0.0], 0.25, 0.5)
+    dx, dy = dev(hip, x), dev(hip, y)
+    x1 = hip.DeviceArray.zeros(n, dtype); y1 = hip.DeviceArray.zeros(m, dtype)
+    x_ref = hip.DeviceArray.zeros(n, dtype); y_ref = hip.DeviceArray.zeros(m, dtype)
+    hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), x1.ptr, y1.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau[0]), hip.dbl(sigma[0]), hip.dbl(theta[0]), 1, 1, 0, 0, None, None, None))
+    hip.check(hip.fn("fused_iteration", dtype)(C.byref(desc), x_ref.ptr, y_ref.ptr, x1.ptr, y1.ptr, None, hip.dbl(tau[1]), hip.dbl(sigma[1]), hip.dbl(theta[1]), 1, 1, 0, 0, None, None, None))
+    for cols in (0, 5):
+        x2 = hip.DeviceArray.zeros(n, dtype); y2 = hip.DeviceArray.zeros(m, dtype); xm = hip.DeviceArray.zeros(n, dtype); ym = hip.DeviceArray.zeros(m, dtype)
+        hip.check(hip.fn("fused_iteration2", dtype)(C.byref(desc), x2.ptr, y2.ptr, dx.ptr, dy.ptr, xm.ptr, ym.ptr, tau, sigma, theta, cols, None, None, None))
+        for got, want, name in ((xm, x1, "x_mid"), (ym, y1, "y_mid"), (x2, x_ref, "x"), (y2, y_ref, "y")):
+            g, w = got.to_host(), want.to_host()
+            assert np.array_equal(g, w, equal_nan=True), (name, cols, np.flatnonzero(g != w)[:8])
+            assert np.array_equal(np.signbit(g), np.signbit(w)), (name, cols, "sign of zero")

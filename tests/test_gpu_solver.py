@@ -376,8 +376,11 @@ def test_pair_kernel_schedule_is_invisible(prec, dtype, step, residual_iter):
             for a_, b_ in zip(states[0], states[1]):
                 for v in "xyzw":
                     assert np.array_equal(a_[v], b_[v]), (nx, ny, iters, v)
-                for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):
+                for v in ("tau", "sigma", "theta", "iteration"):
                     assert v in a_ and a_[v] == b_[v], (nx, ny, iters, v, a_[v], b_[v])
+                # same residual terms, summed in double in a different order (62- vs 63-lane strips)
+                for v in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):
+                    assert np.isclose(a_[v], b_[v], rtol=1e-6, atol=0), (nx, ny, iters, v, a_[v], b_[v])
         prob, u, q, f = synthetic.rof_problem(nx, ny, seed=3)
         b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
         o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)

@@ -24,7 +24,10 @@ d.g_coeff_ptr[1] = f.ptr.value
 d.T_val, d.S_val = 0.25, 0.5
 for i in range(reps):
     a, b = i % 2, (i + 1) % 2
-    if mode == "iter":
+    if mode == "iter2":
+        t2 = (C.c_double * 2)(0.3, 0.29); s2 = (C.c_double * 2)(1.0, 1.03); th2 = (C.c_double * 2)(0.9, 0.91)
+        hip.check(hip.fn("fused_iteration2", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, None, t2, s2, th2, cols, None, None, None))
+    elif mode == "iter":
         hip.check(hip.fn("fused_iteration", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 0, cols, None, None, None))
     else:
         hip.check(hip.fn("fused_primal", dtype)(C.byref(d), x[b].ptr, x[a].ptr, y[a].ptr, None, hip.dbl(0.3), 1, 0, None, None, None))
