@@ -111,6 +111,19 @@ __device__ __forceinline__ double rcp_refined(float d) {
 }
 __device__ __forceinline__ double rcp_refined(double d) { return 1.0 / d; }
 __device__ __forceinline__ float mul_rcp(float n, double r) { return (float)((double)n * r); }
+// n / d for many n and one (typically wave-uniform) d: exact float quotient via the double reciprocal,
+// plain division for double
+template <class T> struct SharedDivisor;
+template <> struct SharedDivisor<float> {
+  double r;
+  __device__ __forceinline__ explicit SharedDivisor(float d) : r(rcp_refined(d)) {}
+  __device__ __forceinline__ float div(float n) const { return mul_rcp(n, r); }
+};
+template <> struct SharedDivisor<double> {
+  double d;
+  __device__ __forceinline__ explicit SharedDivisor(double d_) : d(d_) {}
+  __device__ __forceinline__ double div(double n) const { return n / d; }
+};
 // sqrtf(x) for x in [2^-96, 2^126]: v_sqrt_f32 (1 ulp) + the compiler's own +-1 ulp residual test,
 // without the 2^32 range scaling and the zero / infinity fix-up that the general expansion carries
 __device__ __forceinline__ float sqrt_midrange(float x) {

@@ -130,12 +130,14 @@ __global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || M
     }
   };
   // primal_residual_transform (backend_pdhg.cu:97-120) of one pixel, both components
+  // the residual divisors sigma sqrt(S), tau sqrt(T) are wave-uniform: one double reciprocal each (device_math.hpp)
+  const SharedDivisor<T> div_sigS(p2.sigma * sqS), div_tauT(p2.tau * sqT);
   auto residual_terms = [&](int j, T y1o, T y2o, T o1, T o2, T kx1, T kx2, T kp1, T kp2, const IterParams<T>& P) {
     (void)j;
-    const T z1 = (y1o - o1) / (P.sigma * sqS) + sqS * ((1 + P.theta) * kx1 - P.theta * kp1);
+    const T z1 = div_sigS.div(y1o - o1) + sqS * ((1 + P.theta) * kx1 - P.theta * kp1);
     const T d1 = z1 - sqS * kx1;
     r_pd += (double)(d1 * d1); r_pv += (double)(z1 * z1);
-    const T z2 = (y2o - o2) / (P.sigma * sqS) + sqS * ((1 + P.theta) * kx2 - P.theta * kp2);
+    const T z2 = div_sigS.div(y2o - o2) + sqS * ((1 + P.theta) * kx2 - P.theta * kp2);
     const T d2 = z2 - sqS * kx2;
     r_pd += (double)(d2 * d2); r_pv += (double)(z2 * z2);
   };
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || M
         if (kRes) {                                            // dual_residual_transform (backend_pdhg.cu:73-94)
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
-            const T w_hat = (x1_1[j] - x2_1[j]) / (p2.tau * sqT) - sqT * kt_1[j];
+            const T w_hat = div_tauT.div(x1_1[j] - x2_1[j]) - sqT * kt_1[j];
             const T diff = w_hat + sqT * kt_c[j];
             r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat);
           }
