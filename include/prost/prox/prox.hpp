@@ -24,9 +24,14 @@ struct ProxDesc {
   double coeff_val[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
+template <typename T> class ProxTransform;
+template <typename T> class ProxPermute;
+
 template <typename T>
 class Prox {
   friend class ProxMoreau<T>;
+  friend class ProxTransform<T>;
+  friend class ProxPermute<T>;
 
  public:
   Prox(size_t index, size_t size, bool diagsteps) : index_(index), size_(size), diagsteps_(diagsteps) {}

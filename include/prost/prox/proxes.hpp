@@ -75,5 +75,108 @@ class ProxIndEpiQuad : public ProxSeparableSum<T> {
   device_vector<T> d_a_, d_b_, d_c_;
 };
 
+/// elem_operation:ind_sum -- sum-to-one constraint per group (elem_operation_ind_sum.hpp:41-60)
+template <typename T>
+class ProxElemIndSum : public ProxSeparableSum<T> {
+ public:
+  ProxElemIndSum(size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps)
+      : ProxSeparableSum<T>(index, count, dim, interleaved, diagsteps) {}
+  virtual size_t gpu_mem_amount() const { return 0; }
+
+ protected:
+  virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+};
+
+/// h(x) = c f(ax - b) + dx + (e/2) x^2 around any inner prox (prox_transform.cu:99-221)
+template <typename T>
+class ProxTransform : public Prox<T> {
+ public:
+  ProxTransform(shared_ptr<Prox<T>> inner_fn, const std::vector<T>& a, const std::vector<T>& b, const std::vector<T>& c,
+                const std::vector<T>& d, const std::vector<T>& e)
+      : Prox<T>(*inner_fn), inner_fn_(inner_fn), host_{a, b, c, d, e} {}
+  virtual void Initialize();
+  virtual void Release();
+  virtual size_t gpu_mem_amount() const;
+  virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { inner_fn_->get_separable_structure(sep); }
+
+ protected:
+  virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+  shared_ptr<Prox<T>> inner_fn_;
+  std::array<std::vector<T>, 5> host_;
+  std::array<device_vector<T>, 5> dev_;
+  device_vector<T> scaled_arg_, scaled_tau_;
+};
+
+/// composition with a permutation of the (local) variable order (prox_permute.cu:50-160)
+template <typename T>
+class ProxPermute : public Prox<T> {
+ public:
+  ProxPermute(shared_ptr<Prox<T>> base_prox, const std::vector<int32_t>& perm) : Prox<T>(*base_prox), base_prox_(base_prox), perm_host_(perm) {}
+  virtual void Initialize();
+  virtual void Release();
+  virtual size_t gpu_mem_amount() const { return this->size_ * sizeof(T) + base_prox_->gpu_mem_amount(); }
+  virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { base_prox_->get_separable_structure(sep); }
+
+ protected:
+  virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+  shared_ptr<Prox<T>> base_prox_;
+  std::vector<int32_t> perm_host_;
+  device_vector<int32_t> perm_;
+  device_vector<T> permuted_arg_;
+};
+
+/// projection onto the halfspaces {x | <a, x> <= b} (prox_ind_halfspace.cu:31-153); planar layout always
+template <typename T>
+class ProxIndHalfspace : public ProxSeparableSum<T> {
+ public:
+  ProxIndHalfspace(size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps, const std::vector<T>& a, const std::vector<T>& b)
+      : ProxSeparableSum<T>(index, count, dim, interleaved, diagsteps), a_(a), b_(b) {}
+  virtual void Initialize();
+  virtual void Release() { d_a_.clear(); d_b_.clear(); }
+  virtual size_t gpu_mem_amount() const { return (a_.size() + b_.size()) * sizeof(T); }
+
+ protected:
+  virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+  std::vector<T> a_, b_;
+  device_vector<T> d_a_, d_b_;
+};
+
+/// projection onto the second-order cone alpha ||x|| <= y, alpha == 1 only (prox_ind_soc.cu:30-124)
+template <typename T>
+class ProxIndSOC : public ProxSeparableSum<T> {
+ public:
+  ProxIndSOC(size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps, T alpha)
+      : ProxSeparableSum<T>(index, count, dim, interleaved, diagsteps), alpha_(alpha) {}
+  virtual void Initialize();
+  virtual size_t gpu_mem_amount() const { return 0; }
+
+ protected:
+  virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+  T alpha_;
+};
+
+/// sum constraints over one or two index families, identity elsewhere (prox_ind_sum.cu:30-147)
+template <typename T>
+class ProxIndSum : public Prox<T> {
+ public:
+  ProxIndSum(size_t index, size_t size, size_t count, size_t dim, const std::vector<uint64_t>& inds, T sum)
+      : Prox<T>(index, size, true), dim_(dim), dim_2_(0), count_(count), count_2_(0), inds_(inds), two_(false), sum_(sum), sum_2_(0) {}
+  ProxIndSum(size_t index, size_t size, size_t count, size_t dim, const std::vector<uint64_t>& inds, T sum, size_t count2, size_t dim2,
+             const std::vector<uint64_t>& inds2, T sum2)
+      : Prox<T>(index, size, true), dim_(dim), dim_2_(dim2), count_(count), count_2_(count2), inds_(inds), inds_2_(inds2), two_(true),
+        sum_(sum), sum_2_(sum2) {}
+  virtual void Initialize();
+  virtual void Release() { d_inds_.clear(); d_inds_2_.clear(); }
+  virtual size_t gpu_mem_amount() const { return inds_.size() * sizeof(uint64_t); }
+
+ protected:
+  virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+  size_t dim_, dim_2_, count_, count_2_;
+  std::vector<uint64_t> inds_, inds_2_;
+  device_vector<int64_t> d_inds_, d_inds_2_;
+  bool two_;
+  T sum_, sum_2_;
+};
+
 }  // namespace prost
 #endif

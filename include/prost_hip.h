@@ -128,6 +128,37 @@ int prost_hip_moreau_prescale_f64(double* scaled, const double* arg, const doubl
 int prost_hip_moreau_postscale_f32(float* res, const float* arg, const float* tau_diag, double tau, int invert_tau, size_t n, void* stream);
 int prost_hip_moreau_postscale_f64(double* res, const double* arg, const double* tau_diag, double tau, int invert_tau, size_t n, void* stream);
 
+/* ProxTransform (src/prox/prox_transform.cu), h(x) = c f(ax - b) + dx + (e/2) x^2 around any inner prox:
+ * prescale = ProxTransformPrescaleArgument (:27-52) + ProxTransformPrescaleStepSize (:54-78) in one pass:
+ *   tau2 = tau * tau_diag (or its reciprocal); scaled_arg = a (arg - tau2 d) / (1 + tau2 e) - b;
+ *   scaled_tau = a^2 c tau2 / (1 + tau2 e).
+ * coeff_ptr / coeff_val: a, b, c, d, e as in prost_hip_prox_elem (ptr NULL -> scalar).  The caller then
+ * evaluates the inner prox with (scaled_arg, scaled_tau, tau = 1, invert = 0) and calls postscale
+ * (:80-97): result = (result + b) / a. */
+int prost_hip_transform_prescale_f32(float* scaled_arg, float* scaled_tau, const float* arg, const float* tau_diag, const float* const* coeff_ptr,
+                                     const double* coeff_val, double tau, int invert_tau, size_t n, void* stream);
+int prost_hip_transform_prescale_f64(double* scaled_arg, double* scaled_tau, const double* arg, const double* tau_diag, const double* const* coeff_ptr,
+                                     const double* coeff_val, double tau, int invert_tau, size_t n, void* stream);
+int prost_hip_transform_postscale_f32(float* result, const float* a_ptr, double a_val, const float* b_ptr, double b_val, size_t n, void* stream);
+int prost_hip_transform_postscale_f64(double* result, const double* a_ptr, double a_val, const double* b_ptr, double b_val, size_t n, void* stream);
+/* ProxPermuteKernel (src/prox/prox_permute.cu:31-48): inverse == 0: res[i] = arg[perm[i]]; else res[perm[i]] = arg[i] */
+int prost_hip_permute_f32(float* res, const float* arg, const int32_t* perm, size_t n, int inverse, void* stream);
+int prost_hip_permute_f64(double* res, const double* arg, const int32_t* perm, size_t n, int inverse, void* stream);
+/* ProxIndHalfspaceKernel (src/prox/prox_ind_halfspace.cu:31-86): projection onto {x | <a, x> <= b} per group,
+ * planar layout whatever `interleaved` says; sz_a = count*dim (planar per-group normals) or dim; sz_b = count or 1 */
+int prost_hip_prox_ind_halfspace_f32(float* res, const float* arg, size_t count, size_t dim, const float* a, size_t sz_a, const float* b, size_t sz_b, void* stream);
+int prost_hip_prox_ind_halfspace_f64(double* res, const double* arg, size_t count, size_t dim, const double* a, size_t sz_a, const double* b, size_t sz_b, void* stream);
+/* ProxIndSOCKernel (src/prox/prox_ind_soc.cu:30-77): projection onto ||x|| <= y, (x_1 .. x_{dim-1}, y) planar */
+int prost_hip_prox_ind_soc_f32(float* res, const float* arg, size_t count, size_t dim, void* stream);
+int prost_hip_prox_ind_soc_f64(double* res, const double* arg, size_t count, size_t dim, void* stream);
+/* ProxIndSumKernel (src/prox/prox_ind_sum.cu:30-66): sum over an index family == total_sum; `res` must
+ * already hold a copy of arg (the reference's thrust::copy at :119); inds are local 64-bit indices */
+int prost_hip_prox_ind_sum_f32(float* res, const float* arg, const float* tau_diag, const uint64_t* inds, size_t count, size_t dim, double total_sum, double tau, int invert_tau, void* stream);
+int prost_hip_prox_ind_sum_f64(double* res, const double* arg, const double* tau_diag, const uint64_t* inds, size_t count, size_t dim, double total_sum, double tau, int invert_tau, void* stream);
+/* ElemOperationIndSum (include/prost/prox/elemop/elem_operation_ind_sum.hpp:41-60): sum-to-one per group */
+int prost_hip_prox_elem_ind_sum_f32(float* res, const float* arg, size_t count, size_t dim, int interleaved, void* stream);
+int prost_hip_prox_elem_ind_sum_f64(double* res, const double* arg, size_t count, size_t dim, int interleaved, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* PDHG building blocks, generic path (src/backend/backend_pdhg.cu)                            */
 /* ------------------------------------------------------------------------------------------ */

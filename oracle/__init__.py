@@ -96,6 +96,18 @@ def lib():
         L.orc_prox_zero_create.restype = vp
         L.orc_prox_epi_quad_create.argtypes = [sz, sz, sz, i32, i32, vp, sz, vp, sz, vp, sz]
         L.orc_prox_epi_quad_create.restype = vp
+        L.orc_prox_elem_ind_sum_create.argtypes = [sz, sz, sz, i32, i32]
+        L.orc_prox_elem_ind_sum_create.restype = vp
+        L.orc_prox_transform_create.argtypes = [vp, vp, vp]
+        L.orc_prox_transform_create.restype = vp
+        L.orc_prox_permute_create.argtypes = [vp, vp, sz]
+        L.orc_prox_permute_create.restype = vp
+        L.orc_prox_halfspace_create.argtypes = [sz, sz, sz, i32, i32, vp, sz, vp, sz]
+        L.orc_prox_halfspace_create.restype = vp
+        L.orc_prox_soc_create.argtypes = [sz, sz, sz, i32, i32, dbl]
+        L.orc_prox_soc_create.restype = vp
+        L.orc_prox_ind_sum_create.argtypes = [sz, sz, sz, vp, sz, dbl, sz, vp, sz, dbl]
+        L.orc_prox_ind_sum_create.restype = vp
         L.orc_prox_destroy.argtypes = [vp]
         L.orc_prox_destroy.restype = None
         L.orc_prox_size.argtypes = [vp]
@@ -269,6 +281,36 @@ def make_prox(desc):
     if len(desc) != 5:
         raise OracleError("Invalid prox description. Dim = %d (should be 5)." % len(desc))
     name, idx, size, diagsteps, data = desc
+    if name == "elem_operation:ind_sum":
+        count, dim, interleaved = data
+        return L.orc_prox_elem_ind_sum_create(idx, int(count), int(dim), int(interleaved), int(diagsteps))
+    if name == "transform":                                   # factory.cpp:301-310
+        arrs = []
+        for c in data[:5]:
+            c = np.ascontiguousarray(np.atleast_1d(np.asarray(c, dtype=np.float64)).ravel())
+            if c.size != 1 and c.size != size:
+                raise OracleError("Size of coefficients should be either 1 or count.")
+            arrs.append(c)
+        ptrs = (C.c_void_p * 5)(*[a.ctypes.data for a in arrs])
+        lens = (C.c_size_t * 5)(*[a.size for a in arrs])
+        return L.orc_prox_transform_create(make_prox(data[5]), ptrs, lens)
+    if name == "permute":                                     # factory.cpp:293-299
+        perm = np.ascontiguousarray(np.asarray(data[1], dtype=np.int32).ravel())
+        return L.orc_prox_permute_create(make_prox(data[0]), _p(perm), perm.size)
+    if name == "ind_halfspace":                               # factory.cpp:484-496
+        count, dim, interleaved, (a, b) = data
+        a, b = [np.ascontiguousarray(np.atleast_1d(np.asarray(v, dtype=np.float64)).ravel()) for v in (a, b)]
+        return L.orc_prox_halfspace_create(idx, int(count), int(dim), int(interleaved), int(diagsteps), _p(a), a.size, _p(b), b.size)
+    if name == "ind_soc":                                     # factory.cpp:446-456
+        count, dim, interleaved, alpha = data
+        return L.orc_prox_soc_create(idx, int(count), int(dim), int(interleaved), int(diagsteps), float(alpha))
+    if name == "ind_sum":                                     # factory.cpp:458-481
+        dim, inds, s1 = data[:3]
+        inds = np.ascontiguousarray(np.asarray(inds, dtype=np.uint64).ravel())
+        if len(data) == 6:
+            inds2 = np.ascontiguousarray(np.asarray(data[4], dtype=np.uint64).ravel())
+            return L.orc_prox_ind_sum_create(idx, int(size), int(dim), _p(inds), inds.size, float(s1), int(data[3]), _p(inds2), inds2.size, float(data[5]))
+        return L.orc_prox_ind_sum_create(idx, int(size), int(dim), _p(inds), inds.size, float(s1), 0, None, 0, 0.0)
     if name.startswith("elem_operation:"):
         _, kind, fn = name.split(":")
         count, dim, interleaved, coeffs = data

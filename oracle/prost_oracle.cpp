@@ -484,10 +484,85 @@ struct Block {
   }
 };
 
+// ProxIndHalfspaceKernel + ProjectHalfspace (src/prox/prox_ind_halfspace.cu:31-86): the layout is
+// ALWAYS planar (Vector(count, dim, false, tx, ...), :67-68) whatever `interleaved` says; a is either
+// per group (count*dim, planar) or one normal of dim entries (read as Vector(count, dim, true, 0), :79)
+template <class T>
+void halfspace_run(T* res, const T* arg, size_t count, size_t dim, const T* a, size_t sz_a, const T* b, size_t sz_b) {
+  PAR_FOR
+  for (ssz tx = 0; tx < (ssz)count; tx++) {
+    const T t = (sz_b == count) ? b[tx] : b[0];
+    const bool per_group = sz_a == count * dim;
+    T sq_norm = 0, iprod = 0;
+    for (size_t i = 0; i < dim; i++) {
+      const T n = per_group ? a[tx + count * i] : a[i];
+      sq_norm += n * n;
+      iprod += n * arg[tx + count * i];
+    }
+    for (size_t i = 0; i < dim; i++) {
+      const T n = per_group ? a[tx + count * i] : a[i];
+      res[tx + count * i] = arg[tx + count * i] - (std::max(static_cast<T>(0), iprod - t) / sq_norm) * n;
+    }
+  }
+}
+// ProxIndSOCKernel (src/prox/prox_ind_soc.cu:30-77): (x_1..x_{dim-1}, y) planar, alpha unused (== 1 enforced at Initialize)
+template <class T>
+void soc_run(T* res, const T* arg, size_t count, size_t dim) {
+  PAR_FOR
+  for (ssz tx = 0; tx < (ssz)count; tx++) {
+    const T y0 = arg[count * (dim - 1) + tx];
+    T norm_x0 = 0;
+    for (size_t i = 0; i < dim - 1; i++) norm_x0 += arg[tx + count * i] * arg[tx + count * i];
+    norm_x0 = std::sqrt(norm_x0);
+    if (norm_x0 <= y0) {
+      for (size_t i = 0; i < dim - 1; i++) res[tx + count * i] = arg[tx + count * i];
+      res[count * (dim - 1) + tx] = y0;
+    } else if (norm_x0 <= -y0) {
+      for (size_t i = 0; i < dim - 1; i++) res[tx + count * i] = 0;
+      res[count * (dim - 1) + tx] = 0;
+    } else {
+      const T fac = (y0 + norm_x0) / (2 * norm_x0);
+      for (size_t i = 0; i < dim - 1; i++) res[tx + count * i] = fac * arg[tx + count * i];
+      res[count * (dim - 1) + tx] = fac * norm_x0;
+    }
+  }
+}
+// ProxIndSumKernel (src/prox/prox_ind_sum.cu:30-66); res already holds a copy of arg (:119)
+template <class T>
+void ind_sum_run(T* res, const T* arg, const T* tau_diag, const size_t* inds, size_t count, size_t dim, T total_sum, T tau, bool inv) {
+  for (size_t tx = 0; tx < count; tx++) {       // serial: groups may share indices, the last writer wins as on one stream
+    T sum_arg = 0, sum_tau = 0;
+    for (size_t i = 0; i < dim; i++) {
+      T mytau = tau_diag[inds[tx * dim + i]] * tau;
+      if (inv) mytau = (T)(1. / (double)mytau);
+      sum_arg += arg[inds[tx * dim + i]];
+      sum_tau += mytau;
+    }
+    for (size_t i = 0; i < dim; i++) {
+      T mytau = tau_diag[inds[tx * dim + i]] * tau;
+      if (inv) mytau = (T)(1. / (double)mytau);
+      res[inds[tx * dim + i]] = arg[inds[tx * dim + i]] - mytau * (sum_arg - total_sum) / sum_tau;
+    }
+  }
+}
+// ElemOperationIndSum (include/prost/prox/elemop/elem_operation_ind_sum.hpp:41-60)
+template <class T>
+void elem_ind_sum_run(T* res, const T* arg, size_t count, size_t dim, bool interleaved) {
+  PAR_FOR
+  for (ssz t = 0; t < (ssz)count; t++) {
+    View v{count, dim, interleaved, (size_t)t};
+    T tl = 0;
+    for (size_t i = 0; i < dim; i++) tl += arg[v.at(i)];
+    tl = (T)(((double)tl - 1.) / (double)static_cast<T>(dim));
+    for (size_t i = 0; i < dim; i++) res[v.at(i)] = arg[v.at(i)] - tl;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Prox tree
 // ---------------------------------------------------------------------------------
-enum { PK_ELEM, PK_MOREAU, PK_ZERO, PK_EPI_QUAD };
+enum { PK_ELEM, PK_MOREAU, PK_ZERO, PK_EPI_QUAD, PK_TRANSFORM, PK_PERMUTE, PK_HALFSPACE, PK_SOC, PK_IND_SUM };
+enum { ORC_OP_IND_SUM = 2 };   // elem_operation:ind_sum (no coefficients)
 
 template <class T>
 struct Prox {
@@ -496,11 +571,37 @@ struct Prox {
   std::array<std::vector<T>, 7> coeffs;
   std::vector<T> a, b, c;
   std::unique_ptr<Prox<T>> child;
-  std::vector<T> scaled_arg;
+  std::vector<T> scaled_arg, scaled_tau;
+  std::vector<int> perm;                        // ProxPermute
+  std::vector<size_t> inds, inds2; size_t count2 = 0, dim2 = 0; T sum = 0, sum2 = 0; bool two = false;   // ProxIndSum
+  T alpha = 1;                                  // ProxIndSOC
 
   // Prox::Initialize chain (prox_moreau.cu:73-87, prox_ind_epi_quad.cu:137-169)
   void initialize() {
     if (kind == PK_MOREAU) { scaled_arg.assign(size, 0); child->initialize(); }
+    if (kind == PK_TRANSFORM) {                                       // prox_transform.cu:113-141
+      for (T& v : coeffs[0]) if (v == 0) throw OrcError("ProxTransform: Vector 'a' isn't allowed to contain zero element. (Division by zero)");
+      scaled_arg.assign(size, 0); scaled_tau.assign(size, 0);
+      child->initialize();
+    }
+    if (kind == PK_PERMUTE) {                                         // prox_permute.cu:62-93
+      scaled_arg.assign(size, 0);
+      if (perm.size() != child->size) {
+        std::stringstream ss;
+        ss << "Permutation vector has wrong size (" << perm.size() << ") instead of " << child->size << ".";
+        throw OrcError(ss.str());
+      }
+      child->initialize();
+    }
+    if (kind == PK_HALFSPACE) {                                       // prox_ind_halfspace.cu:130-151
+      if (a.size() != count * dim && a.size() != dim) throw OrcError("Wrong input: Coefficient a has to have dimension count*dim or dim!");
+      if (b.size() != count && b.size() != 1) throw OrcError("Wrong input: Coefficient b has to have dimension count or 1!");
+    }
+    if (kind == PK_SOC && alpha != 1) throw OrcError("ProxIndSOC: Only alpha = 1 implemented right now.");   // prox_ind_soc.cu:118-122
+    if (kind == PK_IND_SUM) {                                         // prox_ind_sum.cu:69-83
+      if (count * dim != inds.size()) throw OrcError("ProxIndSum: dimensions dont fit");
+      if (two && count2 * dim2 != inds2.size()) throw OrcError("ProxIndSum: dimensions dont fit");
+    }
     if (kind == PK_EPI_QUAD) {
       if (a.size() != count && a.size() != 1) throw OrcError("Wrong input: Coefficient a has to have dimension count or 1!");
       for (T& v : a) if (v <= 0) throw OrcError("Wrong input: Coefficient a must be greater 0!");
@@ -512,6 +613,7 @@ struct Prox {
   void eval_local(T* res, const T* arg, const T* tau_diag, T tau, bool invert) {
     switch (kind) {
       case PK_ELEM: {
+        if (op == ORC_OP_IND_SUM) { elem_ind_sum_run<T>(res, arg, count, dim, interleaved); break; }
         const T* cp[7]; T cv[7];
         for (int i = 0; i < 7; i++) {
           if (coeffs[i].size() > 1) { cp[i] = coeffs[i].data(); cv[i] = 0; }     // prox_elem_operation.inl:160-168
@@ -525,6 +627,33 @@ struct Prox {
       case PK_EPI_QUAD:
         epi_quad_run<T>(res, arg, count, dim, a.size() != 1 ? a.data() : nullptr, a[0], b.data(),
                         c.size() != 1 ? c.data() : nullptr, c[0]);
+        break;
+      case PK_TRANSFORM: {                                            // prox_transform.cu:167-221
+        auto co = [&](int k, ssz i) { return coeffs[k].size() > 1 ? coeffs[k][i] : coeffs[k][0]; };
+        PAR_FOR
+        for (ssz i = 0; i < (ssz)size; i++) {                         // PrescaleArgument :27-52, PrescaleStepSize :54-78
+          T tau2 = tau * tau_diag[i];
+          if (invert) tau2 = 1 / tau2;
+          const T a_ = co(0, i), b_ = co(1, i), c_ = co(2, i), d_ = co(3, i), e_ = co(4, i);
+          scaled_arg[i] = (a_ * (arg[i] - tau2 * d_)) / (1 + tau2 * e_) - b_;
+          scaled_tau[i] = (a_ * a_ * c_ * tau2) / (1 + tau2 * e_);
+        }
+        child->eval_local(res, scaled_arg.data(), scaled_tau.data(), 1, false);   // EvalLocal on local ranges: the child's index is not applied
+        PAR_FOR
+        for (ssz i = 0; i < (ssz)size; i++) res[i] = (res[i] + co(1, i)) / co(0, i);   // Postscale :80-97
+      } break;
+      case PK_PERMUTE: {                                              // prox_permute.cu:101-143: tau_diag is NOT permuted
+        const size_t n = perm.size();
+        for (size_t i = 0; i < n; i++) res[i] = arg[perm[i]];
+        child->eval_local(scaled_arg.data(), res, tau_diag, tau, invert);
+        for (size_t i = 0; i < n; i++) res[perm[i]] = scaled_arg[i];
+      } break;
+      case PK_HALFSPACE: halfspace_run<T>(res, arg, count, dim, a.data(), a.size(), b.data(), b.size()); break;
+      case PK_SOC: soc_run<T>(res, arg, count, dim); break;
+      case PK_IND_SUM:
+        if (res != arg) std::memmove(res, arg, size * sizeof(T));     // "zero prox on other indices" :119
+        ind_sum_run<T>(res, arg, tau_diag, inds.data(), count, dim, sum, tau, invert);
+        if (two) ind_sum_run<T>(res, arg, tau_diag, inds2.data(), count2, dim2, sum2, tau, invert);
         break;
       case PK_MOREAU: {                                               // prox_moreau.cu:98-134
         PAR_FOR
@@ -544,8 +673,8 @@ struct Prox {
   }
   // get_separable_structure (prox.cu:74-78, prox_separable_sum.hpp:67-81, prox_moreau.cu:142-147)
   void separable(std::vector<std::tuple<size_t, size_t, size_t>>& sep) const {
-    if (kind == PK_MOREAU) { child->separable(sep); return; }
-    if (kind == PK_ELEM || kind == PK_EPI_QUAD) {
+    if (kind == PK_MOREAU || kind == PK_TRANSFORM || kind == PK_PERMUTE) { child->separable(sep); return; }
+    if (kind == PK_ELEM || kind == PK_EPI_QUAD || kind == PK_HALFSPACE || kind == PK_SOC) {
       if (interleaved) for (size_t i = 0; i < count; i++) sep.emplace_back(index + i * dim, dim, 1);
       else for (size_t i = 0; i < count; i++) sep.emplace_back(index + i, dim, count);
       return;
@@ -820,7 +949,9 @@ struct Solver : SolverBase {
   static Prox<T> clone(const Prox<T>& p) {
     Prox<T> q; q.kind = p.kind; q.index = p.index; q.size = p.size; q.diagsteps = p.diagsteps;
     q.count = p.count; q.dim = p.dim; q.interleaved = p.interleaved; q.op = p.op; q.fn = p.fn;
-    q.coeffs = p.coeffs; q.a = p.a; q.b = p.b; q.c = p.c; q.scaled_arg = p.scaled_arg;
+    q.coeffs = p.coeffs; q.a = p.a; q.b = p.b; q.c = p.c; q.scaled_arg = p.scaled_arg; q.scaled_tau = p.scaled_tau;
+    q.perm = p.perm; q.inds = p.inds; q.inds2 = p.inds2; q.count2 = p.count2; q.dim2 = p.dim2; q.sum = p.sum; q.sum2 = p.sum2;
+    q.two = p.two; q.alpha = p.alpha;
     if (p.child) q.child.reset(new Prox<T>(clone(*p.child)));
     return q;
   }
@@ -1193,6 +1324,7 @@ struct orc_prox {
   int kind = PK_ELEM; size_t index = 0, size = 0; bool diagsteps = true;
   size_t count = 0, dim = 0; bool interleaved = false; int op = 0, fn = 0;
   std::array<std::vector<double>, 7> coeffs; std::vector<double> a, b, c;
+  std::vector<int> perm; std::vector<size_t> inds, inds2; size_t count2 = 0, dim2 = 0; double sum = 0, sum2 = 0, alpha = 1; bool two = false;
   std::unique_ptr<orc_prox> child;
   template <class T> std::shared_ptr<Prox<T>> make() const {
     auto p = std::make_shared<Prox<T>>();
@@ -1200,6 +1332,8 @@ struct orc_prox {
     p->count = count; p->dim = dim; p->interleaved = interleaved; p->op = op; p->fn = fn;
     for (int i = 0; i < 7; i++) p->coeffs[i].assign(coeffs[i].begin(), coeffs[i].end());
     p->a.assign(a.begin(), a.end()); p->b.assign(b.begin(), b.end()); p->c.assign(c.begin(), c.end());
+    p->perm = perm; p->inds = inds; p->inds2 = inds2; p->count2 = count2; p->dim2 = dim2; p->sum = (T)sum; p->sum2 = (T)sum2;
+    p->alpha = (T)alpha; p->two = two;
     if (child) { auto ch = child->make<T>(); p->child.reset(new Prox<T>(Solver<T>::clone(*ch))); }
     return p;
   }
@@ -1355,6 +1489,52 @@ orc_prox* orc_prox_epi_quad_create(size_t idx, size_t count, size_t dim, int int
   p->kind = PK_EPI_QUAD; p->index = idx; p->count = count; p->dim = dim; p->size = count * dim;
   p->interleaved = interleaved; p->diagsteps = diagsteps;
   p->a.assign(a, a + na); p->b.assign(b, b + nb); p->c.assign(c, c + nc);
+  return p;
+}
+orc_prox* orc_prox_elem_ind_sum_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps) {
+  orc_prox* p = new orc_prox;
+  p->kind = PK_ELEM; p->op = ORC_OP_IND_SUM; p->index = idx; p->count = count; p->dim = dim; p->size = count * dim;
+  p->interleaved = interleaved; p->diagsteps = diagsteps;
+  for (int i = 0; i < 7; i++) p->coeffs[i].assign(1, 0.0);
+  return p;
+}
+// ProxTransform copies index/size/diagsteps of the inner prox (prox_transform.cu:107: Prox<T>(*inner_fn))
+orc_prox* orc_prox_transform_create(orc_prox* child, const double* const* coeff, const size_t* coeff_len) {
+  orc_prox* p = new orc_prox;
+  p->kind = PK_TRANSFORM; p->index = child->index; p->size = child->size; p->diagsteps = child->diagsteps;
+  for (int i = 0; i < 5; i++) p->coeffs[i].assign(coeff[i], coeff[i] + coeff_len[i]);
+  for (int i = 5; i < 7; i++) p->coeffs[i].assign(1, 0.0);
+  p->child.reset(child);
+  return p;
+}
+orc_prox* orc_prox_permute_create(orc_prox* child, const int* perm, size_t n) {
+  orc_prox* p = new orc_prox;
+  p->kind = PK_PERMUTE; p->index = child->index; p->size = child->size; p->diagsteps = child->diagsteps;
+  p->perm.assign(perm, perm + n);
+  p->child.reset(child);
+  return p;
+}
+orc_prox* orc_prox_halfspace_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps, const double* a, size_t na,
+                                    const double* b, size_t nb) {
+  orc_prox* p = new orc_prox;
+  p->kind = PK_HALFSPACE; p->index = idx; p->count = count; p->dim = dim; p->size = count * dim;
+  p->interleaved = interleaved; p->diagsteps = diagsteps;
+  p->a.assign(a, a + na); p->b.assign(b, b + nb);
+  return p;
+}
+orc_prox* orc_prox_soc_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps, double alpha) {
+  orc_prox* p = new orc_prox;
+  p->kind = PK_SOC; p->index = idx; p->count = count; p->dim = dim; p->size = count * dim;
+  p->interleaved = interleaved; p->diagsteps = diagsteps; p->alpha = alpha;
+  return p;
+}
+// ProxIndSum: Prox<T>(index, size, true) (prox_ind_sum.hpp:41); count = inds / dim (factory.cpp:466)
+orc_prox* orc_prox_ind_sum_create(size_t idx, size_t size, size_t dim, const size_t* inds, size_t ninds, double sum,
+                                  size_t dim2, const size_t* inds2, size_t ninds2, double sum2) {
+  orc_prox* p = new orc_prox;
+  p->kind = PK_IND_SUM; p->index = idx; p->size = size; p->diagsteps = true;
+  p->dim = dim; p->inds.assign(inds, inds + ninds); p->count = dim ? ninds / dim : 0; p->sum = sum;
+  if (inds2) { p->two = true; p->dim2 = dim2; p->inds2.assign(inds2, inds2 + ninds2); p->count2 = dim2 ? ninds2 / dim2 : 0; p->sum2 = sum2; }
   return p;
 }
 void orc_prox_destroy(orc_prox* p) { delete p; }

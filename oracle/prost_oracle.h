@@ -100,6 +100,18 @@ orc_prox* orc_prox_zero_create(size_t idx, size_t size);
 orc_prox* orc_prox_epi_quad_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps,
                                    const double* a, size_t na, const double* b, size_t nb,
                                    const double* c, size_t nc);
+/* elem_operation:ind_sum (elem_operation_ind_sum.hpp:41-60) */
+orc_prox* orc_prox_elem_ind_sum_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps);
+/* ProxTransform (prox_transform.cu): coeff = a, b, c, d, e each of length 1 or size; takes ownership of child */
+orc_prox* orc_prox_transform_create(orc_prox* child, const double* const* coeff, const size_t* coeff_len);
+/* ProxPermute (prox_permute.cu); takes ownership of child */
+orc_prox* orc_prox_permute_create(orc_prox* child, const int* perm, size_t n);
+/* ProxIndHalfspace (prox_ind_halfspace.cu), ProxIndSOC (prox_ind_soc.cu), ProxIndSum (prox_ind_sum.cu; inds2 may be NULL) */
+orc_prox* orc_prox_halfspace_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps, const double* a, size_t na,
+                                    const double* b, size_t nb);
+orc_prox* orc_prox_soc_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps, double alpha);
+orc_prox* orc_prox_ind_sum_create(size_t idx, size_t size, size_t dim, const size_t* inds, size_t ninds, double sum,
+                                  size_t dim2, const size_t* inds2, size_t ninds2, double sum2);
 void orc_prox_destroy(orc_prox*);
 /* Prox::Eval(host vectors) prox.cu:46-71 ; vectors have prox->size entries, offset 0 */
 int orc_prox_eval(orc_prox*, int dtype, void* res, const void* arg, const void* tau_diag, double tau);

@@ -156,6 +156,49 @@ std::map<std::string, typename Factory<T>::ProxFactory>& Factory<T>::prox_reg() 
     }
     reg["moreau"] = [](size_t, size_t, bool, const prost_value* d) -> Prox<T>* { return new ProxMoreau<T>(Factory<T>::CreateProx(cell_at(d, 0))); };
     reg["zero"] = [](size_t idx, size_t size, bool, const prost_value*) -> Prox<T>* { return new ProxZero<T>(idx, size); };
+    reg["elem_operation:ind_sum"] = [](size_t idx, size_t, bool ds, const prost_value* d) -> Prox<T>* {
+      return new ProxElemIndSum<T>(idx, (size_t)GetScalarFromCell(d, 0), (size_t)GetScalarFromCell(d, 1), GetScalarFromCell(d, 2) > 0., ds);
+    };
+    reg["transform"] = [](size_t, size_t size, bool, const prost_value* d) -> Prox<T>* {          // factory.cpp:301-310
+      std::array<std::vector<T>, 5> co;
+      for (size_t i = 0; i < 5; i++) {
+        std::vector<double> v = GetVector(cell_at(d, i));
+        co[i] = std::vector<T>(v.begin(), v.end());
+        if (co[i].size() != 1 && co[i].size() != size) throw Exception("Size of coefficients should be either 1 or count.");
+      }
+      return new ProxTransform<T>(Factory<T>::CreateProx(cell_at(d, 5)), co[0], co[1], co[2], co[3], co[4]);
+    };
+    reg["permute"] = [](size_t, size_t, bool, const prost_value* d) -> Prox<T>* {                  // factory.cpp:293-299
+      std::vector<double> v = GetVector(cell_at(d, 1));
+      return new ProxPermute<T>(Factory<T>::CreateProx(cell_at(d, 0)), std::vector<int32_t>(v.begin(), v.end()));
+    };
+    reg["ind_halfspace"] = [](size_t idx, size_t, bool ds, const prost_value* d) -> Prox<T>* {     // factory.cpp:484-496
+      const size_t count = (size_t)GetScalarFromCell(d, 0), dim = (size_t)GetScalarFromCell(d, 1);
+      const bool interleaved = GetScalarFromCell(d, 2) > 0.;
+      const prost_value* co = cell_at(d, 3);
+      std::vector<double> a = GetVector(cell_at(co, 0)), b = GetVector(cell_at(co, 1));
+      return new ProxIndHalfspace<T>(idx, count, dim, interleaved, ds, std::vector<T>(a.begin(), a.end()), std::vector<T>(b.begin(), b.end()));
+    };
+    reg["ind_soc"] = [](size_t idx, size_t, bool ds, const prost_value* d) -> Prox<T>* {           // factory.cpp:446-456
+      return new ProxIndSOC<T>(idx, (size_t)GetScalarFromCell(d, 0), (size_t)GetScalarFromCell(d, 1), GetScalarFromCell(d, 2) > 0., ds,
+                               (T)GetScalarFromCell(d, 3));
+    };
+    reg["ind_sum"] = [](size_t idx, size_t size, bool, const prost_value* d) -> Prox<T>* {         // factory.cpp:458-481
+      if (!d || d->kind != PROST_VALUE_CELL) throw Exception("Cell array expected.");
+      const size_t dim = (size_t)GetScalarFromCell(d, 0);
+      std::vector<double> v = GetVector(cell_at(d, 1));
+      std::vector<uint64_t> inds(v.begin(), v.end());
+      const T sum = (T)GetScalarFromCell(d, 2);
+      const size_t count = dim ? inds.size() / dim : 0;     // "hacky" in the reference too (:466)
+      if (d->cells.size() == 3) return new ProxIndSum<T>(idx, size, count, dim, inds, sum);
+      if (d->cells.size() == 6) {
+        const size_t dim2 = (size_t)GetScalarFromCell(d, 3);
+        std::vector<double> v2 = GetVector(cell_at(d, 4));
+        std::vector<uint64_t> inds2(v2.begin(), v2.end());
+        return new ProxIndSum<T>(idx, size, count, dim, inds, sum, dim2 ? inds2.size() / dim2 : 0, dim2, inds2, (T)GetScalarFromCell(d, 5));
+      }
+      throw Exception("ind_sum: 3 or 6 data entries expected.");
+    };
     reg["ind_epi_quad"] = [](size_t idx, size_t, bool ds, const prost_value* d) -> Prox<T>* {
       const size_t count = (size_t)GetScalarFromCell(d, 0), dim = (size_t)GetScalarFromCell(d, 1);
       const bool interleaved = GetScalarFromCell(d, 2) > 0.;

@@ -18,6 +18,13 @@ template <typename T> struct Api;
     static constexpr auto scale = prost_hip_scale_##S;                            \
     static constexpr auto prox_elem = prost_hip_prox_elem_##S;                    \
     static constexpr auto prox_epi_quad = prost_hip_prox_epi_quad_##S;            \
+    static constexpr auto prox_elem_ind_sum = prost_hip_prox_elem_ind_sum_##S;    \
+    static constexpr auto transform_prescale = prost_hip_transform_prescale_##S;  \
+    static constexpr auto transform_postscale = prost_hip_transform_postscale_##S; \
+    static constexpr auto permute = prost_hip_permute_##S;                        \
+    static constexpr auto prox_ind_halfspace = prost_hip_prox_ind_halfspace_##S;  \
+    static constexpr auto prox_ind_soc = prost_hip_prox_ind_soc_##S;              \
+    static constexpr auto prox_ind_sum = prost_hip_prox_ind_sum_##S;              \
     static constexpr auto moreau_prescale = prost_hip_moreau_prescale_##S;        \
     static constexpr auto moreau_postscale = prost_hip_moreau_postscale_##S;      \
     static constexpr auto pdhg_primal_arg = prost_hip_pdhg_primal_arg_##S;        \

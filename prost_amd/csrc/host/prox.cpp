@@ -1,5 +1,6 @@
 // prox.cpp -- proximal operators of the prost host library (calls prost_hip.h only).
 #include <chrono>
+#include <sstream>
 
 #include "hipapi.hpp"
 #include "prost/prox/proxes.hpp"
@@ -118,5 +119,140 @@ void ProxIndEpiQuad<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*, 
 }
 template class ProxIndEpiQuad<float>;
 template class ProxIndEpiQuad<double>;
+
+// ---- elem_operation:ind_sum ----
+template <typename T>
+void ProxElemIndSum<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*, const T*, T, bool) {
+  CheckHip(Api<T>::prox_elem_ind_sum(res, arg, this->count_, this->dim_, this->interleaved_ ? 1 : 0, CurrentStream()), "prox_elem_ind_sum");
+}
+template class ProxElemIndSum<float>;
+template class ProxElemIndSum<double>;
+
+// ---- transform ----
+template <typename T>
+void ProxTransform<T>::Initialize() {
+  for (T& a : host_[0])
+    if (a == 0) throw Exception("ProxTransform: Vector 'a' isn't allowed to contain zero element. (Division by zero)");
+  for (int k = 0; k < 5; k++) {
+    if (host_[k].empty()) throw Exception("Empty vector passed.");
+    if (host_[k].size() > 1) {
+      if (host_[k].size() < this->size_) throw Exception("Size of coefficients should be either 1 or count.");
+      dev_[k] = host_[k];
+    }
+  }
+  scaled_arg_.resize(this->size_);
+  scaled_tau_.resize(this->size_);
+  inner_fn_->Initialize();
+}
+template <typename T>
+void ProxTransform<T>::Release() {
+  inner_fn_->Release();
+  for (int k = 0; k < 5; k++) dev_[k].clear();
+  scaled_arg_.clear(); scaled_tau_.clear();
+}
+template <typename T>
+size_t ProxTransform<T>::gpu_mem_amount() const {
+  size_t mem = inner_fn_->gpu_mem_amount() + 2 * this->size_ * sizeof(T);
+  for (int k = 0; k < 5; k++) if (host_[k].size() > 1) mem += host_[k].size() * sizeof(T);
+  return mem;
+}
+template <typename T>
+void ProxTransform<T>::EvalLocal(T* res, T* res_end, const T* arg, const T*, const T* tau_diag, const T*, T tau, bool invert_tau) {
+  const size_t n = this->size_;
+  if (scaled_arg_.size() != n) throw Exception("ProxTransform used before Initialize().");
+  const T* ptrs[5]; double vals[5];
+  for (int k = 0; k < 5; k++) {
+    ptrs[k] = host_[k].size() > 1 ? dev_[k].data() : nullptr;
+    vals[k] = (double)host_[k][0];
+  }
+  void* s = CurrentStream();
+  CheckHip(Api<T>::transform_prescale(scaled_arg_.data(), scaled_tau_.data(), arg, tau_diag, ptrs, vals, (double)tau, invert_tau ? 1 : 0, n, s), "transform_prescale");
+  // the inner prox sees local ranges: its own index is not applied (prox_transform.cu:202-210)
+  inner_fn_->EvalLocal(res, res_end, scaled_arg_.data(), scaled_arg_.data() + n, scaled_tau_.data(), scaled_tau_.data() + n, (T)1, false);
+  CheckHip(Api<T>::transform_postscale(res, ptrs[0], vals[0], ptrs[1], vals[1], n, s), "transform_postscale");
+}
+template class ProxTransform<float>;
+template class ProxTransform<double>;
+
+// ---- permute ----
+template <typename T>
+void ProxPermute<T>::Initialize() {
+  permuted_arg_.resize(this->size_);
+  perm_ = perm_host_;
+  if (perm_host_.size() != base_prox_->size()) {
+    std::stringstream ss;
+    ss << "Permutation vector has wrong size (" << perm_host_.size() << ") instead of " << base_prox_->size() << ".";
+    throw Exception(ss.str());
+  }
+  for (int32_t v : perm_host_)      // the reference does not check; an out-of-range entry would read / write out of bounds
+    if (v < 0 || (size_t)v >= perm_host_.size()) throw Exception("Permutation vector has an entry outside [0, size).");
+  base_prox_->Initialize();
+}
+template <typename T> void ProxPermute<T>::Release() { base_prox_->Release(); perm_.clear(); permuted_arg_.clear(); }
+template <typename T>
+void ProxPermute<T>::EvalLocal(T* res, T* res_end, const T* arg, const T*, const T* tau_diag, const T* tau_end, T tau, bool invert_tau) {
+  const size_t n = perm_host_.size();
+  if (permuted_arg_.size() != this->size_) throw Exception("ProxPermute used before Initialize().");
+  void* s = CurrentStream();
+  // permuted argument into `res`, prox of it into permuted_arg_, scattered back into `res`; tau_diag is
+  // NOT permuted (prox_permute.cu:113-143)
+  CheckHip(Api<T>::permute(res, arg, perm_.data(), n, 0, s), "permute");
+  base_prox_->EvalLocal(permuted_arg_.data(), permuted_arg_.data() + n, res, res_end, tau_diag, tau_end, tau, invert_tau);
+  CheckHip(Api<T>::permute(res, permuted_arg_.data(), perm_.data(), n, 1, s), "permute");
+}
+template class ProxPermute<float>;
+template class ProxPermute<double>;
+
+// ---- halfspace ----
+template <typename T>
+void ProxIndHalfspace<T>::Initialize() {
+  if (a_.size() != this->count_ * this->dim_ && a_.size() != this->dim_) throw Exception("Wrong input: Coefficient a has to have dimension count*dim or dim!");
+  if (b_.size() != this->count_ && b_.size() != 1) throw Exception("Wrong input: Coefficient b has to have dimension count or 1!");
+  d_a_ = a_; d_b_ = b_;
+}
+template <typename T>
+void ProxIndHalfspace<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*, const T*, T, bool) {
+  if (d_a_.size() != a_.size()) throw Exception("ProxIndHalfspace used before Initialize().");
+  CheckHip(Api<T>::prox_ind_halfspace(res, arg, this->count_, this->dim_, d_a_.data(), a_.size(), d_b_.data(), b_.size(), CurrentStream()), "prox_ind_halfspace");
+}
+template class ProxIndHalfspace<float>;
+template class ProxIndHalfspace<double>;
+
+// ---- second-order cone ----
+template <typename T>
+void ProxIndSOC<T>::Initialize() {
+  if (alpha_ != 1) throw Exception("ProxIndSOC: Only alpha = 1 implemented right now.");
+  if (this->dim_ < 1) throw Exception("ProxIndSOC: dim must be at least 1.");
+}
+template <typename T>
+void ProxIndSOC<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*, const T*, T, bool) {
+  CheckHip(Api<T>::prox_ind_soc(res, arg, this->count_, this->dim_, CurrentStream()), "prox_ind_soc");
+}
+template class ProxIndSOC<float>;
+template class ProxIndSOC<double>;
+
+// ---- index-family sum constraints ----
+template <typename T>
+void ProxIndSum<T>::Initialize() {
+  if (count_ * dim_ != inds_.size()) throw Exception("ProxIndSum: dimensions dont fit");
+  if (two_ && count_2_ * dim_2_ != inds_2_.size()) throw Exception("ProxIndSum: dimensions dont fit");
+  for (uint64_t v : inds_) if (v >= this->size_) throw Exception("ProxIndSum: index outside the prox range.");   // unchecked in the reference
+  for (uint64_t v : inds_2_) if (v >= this->size_) throw Exception("ProxIndSum: index outside the prox range.");
+  d_inds_ = std::vector<int64_t>(inds_.begin(), inds_.end());
+  if (two_) d_inds_2_ = std::vector<int64_t>(inds_2_.begin(), inds_2_.end());
+}
+template <typename T>
+void ProxIndSum<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T* tau_diag, const T*, T tau, bool invert_tau) {
+  if (d_inds_.size() != inds_.size()) throw Exception("ProxIndSum used before Initialize().");
+  void* s = CurrentStream();
+  if (res != arg) CheckHip(prost_hip_memcpy_d2d(res, arg, this->size_ * sizeof(T), s), "memcpy_d2d");       // "zero prox on other indices" :119
+  CheckHip(Api<T>::prox_ind_sum(res, arg, tau_diag, reinterpret_cast<const uint64_t*>(d_inds_.data()), count_, dim_, (double)sum_, (double)tau,
+                                invert_tau ? 1 : 0, s), "prox_ind_sum");
+  if (two_)
+    CheckHip(Api<T>::prox_ind_sum(res, arg, tau_diag, reinterpret_cast<const uint64_t*>(d_inds_2_.data()), count_2_, dim_2_, (double)sum_2_,
+                                  (double)tau, invert_tau ? 1 : 0, s), "prox_ind_sum");
+}
+template class ProxIndSum<float>;
+template class ProxIndSum<double>;
 
 }  // namespace prost

@@ -206,3 +206,110 @@ def test_rof_primal_dual_gap_decreases():
                       tol_abs_primal=0, tol_abs_dual=0)
     r = oracle.solve(prob, b, o, np.float64)
     assert r["result"] == "Converged." and gaps[-1] < 1e-5 and gaps[-1] < gaps[0] * 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_transform(dtype):
+    """test_prox_transform.m:3-36: transform(sum_1d('abs'), a..e) == sum_1d('abs', a..e) under conjugation"""
+    rng = np.random.default_rng(16)
+    for i in range(10):
+        N = 5000
+        a, b, c, d, e, y = (rng.random(N) for _ in range(6))
+        a = a + 1e-3
+        tau, Tau = rng.random() + 1e-3, rng.random(N) + 1e-3
+        x = oracle.eval_prox(prost.function.conjugate(prost.function.sum_1d("abs", a, b, c, d, e)), y, tau, Tau, dtype)
+        x2 = oracle.eval_prox(prost.function.conjugate(prost.function.transform(prost.function.sum_1d("abs", 1, 0, 1, 0, 0), a, b, c, d, e)),
+                              y, tau, Tau, dtype)
+        assert np.abs(x - x2).max() <= (1e-5 if dtype == np.float64 else 5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_conj_trans(dtype):
+    """test_prox_conj_trans.m:3-36: conjugate shifting, (f(. - b))^* = f^* + <b, .>, i.e.
+    conjugate(sum_1d('abs', 1, b, 1, 0, 0)) == transform(conjugate(sum_1d('abs')), 1, 0, 1, b, 0)"""
+    rng = np.random.default_rng(21)
+    for i in range(10):
+        N = 500
+        b, y = rng.random(N), rng.random(N)
+        tau, Tau = rng.random() + 1e-3, rng.random(N) + 1e-3
+        x = oracle.eval_prox(prost.function.conjugate(prost.function.sum_1d("abs", 1, b, 1, 0, 0)), y, tau, Tau, dtype)
+        x2 = oracle.eval_prox(prost.function.transform(prost.function.conjugate(prost.function.sum_1d("abs", 1, 0, 1, 0, 0)), 1, 0, 1, b, 0), y, tau, Tau, dtype)
+        assert np.abs(x - x2).max() <= (1e-5 if dtype == np.float64 else 5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_transform_equals_coefficients(dtype):
+    """transform.m:7-12: transform(sum_1d(fn), a..e) is the same function as sum_1d(fn, a..e), scalar and vector coefficients"""
+    rng = np.random.default_rng(17)
+    N = 3000
+    y = rng.standard_normal(N); Tau = rng.random(N) + 0.1
+    for coeffs in ((2.0, 0.5, 3.0, 0.1, 0.2), tuple(rng.random(N) + 0.2 for _ in range(5))):
+        for fn in ("abs", "square", "huber"):
+            alpha = 0.3
+            x = oracle.eval_prox(prost.function.sum_1d(fn, *coeffs, alpha), y, 0.7, Tau, dtype)
+            x2 = oracle.eval_prox(prost.function.transform(prost.function.sum_1d(fn, 1, 0, 1, 0, 0, alpha), *coeffs), y, 0.7, Tau, dtype)
+            assert np.abs(x - x2).max() <= (1e-9 if dtype == np.float64 else 2e-4), (fn, np.abs(x - x2).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_permute(dtype):
+    """test_prox_permute.m:3-27"""
+    rng = np.random.default_rng(18)
+    n = 34
+    y = 10 * rng.standard_normal(n)
+    perm = rng.permutation(n)
+    inv_perm = np.empty(n, dtype=int); inv_perm[perm] = np.arange(n)
+    f = prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1)
+    x1 = oracle.eval_prox(prost.function.permute(f, perm), y, 0.1, np.ones(n), dtype)
+    x2 = oracle.eval_prox(f, y[perm], 0.1, np.ones(n), dtype)
+    assert np.abs(x1 - x2[inv_perm]).max() <= 1e-5
+    with pytest.raises(oracle.OracleError, match="Permutation vector has wrong size"):
+        oracle.eval_prox(prost.function.permute(f, perm[:-2]), y, 0.1, np.ones(n), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_sum_ind_sum(dtype):
+    """test_prox_sum_ind_sum.m:3-21 (elem_operation:ind_sum) and the index-family form sum_ind_sum2"""
+    rng = np.random.default_rng(19)
+    N, d = 21, 3
+    y = rng.standard_normal(N)
+    x = oracle.eval_prox(prost.function.sum_ind_sum(d, False), y, 1, np.ones(N), dtype).reshape((N // d, d), order="F")
+    assert np.abs(x.sum(axis=1) - 1).max() <= 1e-5
+    xi = oracle.eval_prox(prost.function.sum_ind_sum(d, True), y, 1, np.ones(N), dtype).reshape((N // d, d))
+    assert np.abs(xi.sum(axis=1) - 1).max() <= 1e-5
+    # index families: rows of a 5 x 4 array sum to 2, its first 3 columns (as a second family) to 0.5;
+    # with uniform steps the result is the Euclidean projection, untouched entries stay
+    inds = np.arange(20).reshape(5, 4)
+    Tau = rng.random(24) + 0.5
+    y = rng.standard_normal(24)
+    x = oracle.eval_prox(prost.function.sum_ind_sum2(4, inds.ravel(), 2.0), y, 0.9, Tau, dtype)
+    assert np.abs(x[:20].reshape(5, 4).sum(axis=1) - 2).max() <= 1e-5 and np.array_equal(x[20:], y[20:].astype(dtype).astype(np.float64))
+    x_u = oracle.eval_prox(prost.function.sum_ind_sum2(4, inds.ravel(), 2.0), y, 0.9, np.ones(24), dtype)
+    assert np.abs(x_u[:20].reshape(5, 4) - (y[:20].reshape(5, 4) - (y[:20].reshape(5, 4).sum(axis=1, keepdims=True) - 2) / 4)).max() <= 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_ind_halfspace_and_soc(dtype):
+    """closed forms of prox_ind_halfspace.cu:31-50 and prox_ind_soc.cu:30-77 (no reference test exists for them)"""
+    rng = np.random.default_rng(20)
+    count, dim = 400, 3
+    V = rng.standard_normal((count, dim)); A = rng.standard_normal((count, dim)); b = rng.standard_normal(count)
+    x = oracle.eval_prox(prost.function.sum_ind_halfspace(dim, False, A.reshape(-1, order="F"), b), V.reshape(-1, order="F"), 1, np.ones(count * dim),
+                         dtype).reshape((count, dim), order="F")
+    exc = np.maximum(0, (A * V).sum(axis=1) - b) / (A * A).sum(axis=1)
+    assert np.abs(x - (V - exc[:, None] * A)).max() <= 1e-5
+    assert ((A * x).sum(axis=1) <= b + 1e-4).all()
+    a1 = rng.standard_normal(dim)
+    x1 = oracle.eval_prox(prost.function.sum_ind_halfspace(dim, False, a1, 0.3), V.reshape(-1, order="F"), 1, np.ones(count * dim),
+                          dtype).reshape((count, dim), order="F")
+    assert ((x1 @ a1) <= 0.3 + 1e-4).all()
+    # second-order cone: (x, y) with ||x|| <= y; three regimes
+    W = rng.standard_normal((count, dim)) * 2
+    s = oracle.eval_prox(prost.function.sum_ind_soc(dim, False, 1), W.reshape(-1, order="F"), 1, np.ones(count * dim), dtype).reshape((count, dim), order="F")
+    nx, y0 = np.sqrt((W[:, :-1] ** 2).sum(axis=1)), W[:, -1]
+    fac = np.where(nx <= y0, 1.0, np.where(nx <= -y0, 0.0, (y0 + nx) / (2 * nx)))
+    ref = np.concatenate([fac[:, None] * W[:, :-1], np.where(nx <= y0, y0, fac * nx)[:, None]], axis=1)
+    assert np.abs(s - ref).max() <= 1e-5
+    assert (np.sqrt((s[:, :-1] ** 2).sum(axis=1)) <= s[:, -1] + 1e-4).all()
+    with pytest.raises(oracle.OracleError, match="Only alpha = 1"):
+        oracle.eval_prox(prost.function.sum_ind_soc(dim, False, 2), W.reshape(-1, order="F"), 1, np.ones(count * dim), dtype)
