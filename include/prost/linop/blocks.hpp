@@ -75,6 +75,31 @@ class BlockSparse : public Block<T> {
   device_vector<T> val_, val_t_;
 };
 
+/// kron(K, I_d) (id_first == false, block_sparse_kron_id.cu) or kron(I_d, K) (id_first == true,
+/// block_id_kron_sparse.cu) for a small sparse K, without forming the product; values kept as float
+template <typename T>
+class BlockKronSparse : public Block<T> {
+ public:
+  static BlockKronSparse<T>* CreateFromCSC(bool id_first, size_t row, size_t col, size_t diaglength, int m, int n, int nnz,
+                                           const std::vector<T>& val, const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind);
+  virtual void Initialize();
+  virtual void Release();
+  virtual T row_sum(size_t row, T alpha) const;
+  virtual T col_sum(size_t col, T alpha) const;
+  virtual size_t gpu_mem_amount() const;
+
+ protected:
+  BlockKronSparse(size_t row, size_t col, size_t nrows, size_t ncols) : Block<T>(row, col, nrows, ncols) {}
+  virtual void EvalLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*);
+  bool id_first_ = false;
+  size_t diaglength_ = 0, mat_nnz_ = 0, mat_nrows_ = 0, mat_ncols_ = 0;
+  std::vector<int32_t> host_ind_, host_ind_t_, host_ptr_, host_ptr_t_;
+  std::vector<float> host_val_, host_val_t_;
+  device_vector<int32_t> ind_, ind_t_, ptr_, ptr_t_;
+  device_vector<float> val_, val_t_;
+};
+
 /// constant-coefficient multi-diagonal block; `identity` maps here (block_diags.hpp, identity.m:11-12)
 template <typename T>
 class BlockDiags : public Block<T> {

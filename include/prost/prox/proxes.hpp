@@ -87,6 +87,21 @@ class ProxElemIndSum : public ProxSeparableSum<T> {
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
 };
 
+/// elem_operation:ind_simplex -- projection onto the unit simplex per group (elem_operation_ind_simplex.hpp:40-119)
+template <typename T>
+class ProxElemIndSimplex : public ProxSeparableSum<T> {
+ public:
+  ProxElemIndSimplex(size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps)
+      : ProxSeparableSum<T>(index, count, dim, interleaved, diagsteps) {}
+  virtual void Initialize() { work_.resize(this->count_ * this->dim_); }
+  virtual void Release() { work_.clear(); }
+  virtual size_t gpu_mem_amount() const { return this->count_ * this->dim_ * sizeof(T); }
+
+ protected:
+  virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+  device_vector<T> work_;      // sort workspace, planar like the data
+};
+
 /// h(x) = c f(ax - b) + dx + (e/2) x^2 around any inner prox (prox_transform.cu:99-221)
 template <typename T>
 class ProxTransform : public Prox<T> {

@@ -89,6 +89,14 @@ int prost_hip_diags_adj_f64(double* res, const double* rhs, size_t nrows, size_t
  * src/linop/block_sparse.cu:156-168 (forward, K) and :190-202 (adjoint, stored K^T). */
 int prost_hip_csr_spmv_acc_f32(float* res, const float* rhs, size_t nrows, size_t nnz, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 int prost_hip_csr_spmv_acc_f64(double* res, const double* rhs, size_t nrows, size_t nnz, const double* val, const int32_t* ptr, const int32_t* ind, void* stream);
+/* res += kron(K, I_d) rhs (BlockSparseKronIdKernel, src/linop/block_sparse_kron_id.cu:26-49) and
+ * res += kron(I_d, K) rhs (BlockIdKronSparseKernel, src/linop/block_id_kron_sparse.cu:26-52); K (nrows x ncols)
+ * in CSR with int32 indices and FLOAT values for both T (:36, :79).  The adjoint is the same call
+ * on the stored transpose. */
+int prost_hip_sparse_kron_id_acc_f32(float* res, const float* rhs, size_t diaglength, size_t nrows, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_sparse_kron_id_acc_f64(double* res, const double* rhs, size_t diaglength, size_t nrows, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_id_kron_sparse_acc_f32(float* res, const float* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_id_kron_sparse_acc_f64(double* res, const double* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 /* x = beta * x (beta == 0 -> zero fill): thrust::fill / transform at linearoperator.cu:140-147 */
 int prost_hip_scale_f32(float* x, size_t n, double beta, void* stream);
 int prost_hip_scale_f64(double* x, size_t n, double beta, void* stream);
@@ -158,6 +166,11 @@ int prost_hip_prox_ind_sum_f64(double* res, const double* arg, const double* tau
 /* ElemOperationIndSum (include/prost/prox/elemop/elem_operation_ind_sum.hpp:41-60): sum-to-one per group */
 int prost_hip_prox_elem_ind_sum_f32(float* res, const float* arg, size_t count, size_t dim, int interleaved, void* stream);
 int prost_hip_prox_elem_ind_sum_f64(double* res, const double* arg, size_t count, size_t dim, int interleaved, void* stream);
+/* ElemOperationIndSimplex (include/prost/prox/elemop/elem_operation_ind_simplex.hpp:40-119): projection onto the
+ * unit simplex per group.  `work` is a DEVICE scratch buffer of count*dim entries (the reference uses a
+ * 1024-entry per-thread local array, i.e. dim <= 1024; no such limit here). */
+int prost_hip_prox_elem_ind_simplex_f32(float* res, const float* arg, float* work, size_t count, size_t dim, int interleaved, void* stream);
+int prost_hip_prox_elem_ind_simplex_f64(double* res, const double* arg, double* work, size_t count, size_t dim, int interleaved, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* PDHG building blocks, generic path (src/backend/backend_pdhg.cu)                            */

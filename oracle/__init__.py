@@ -88,6 +88,7 @@ def lib():
         L.orc_problem_add_block_diags.argtypes = [vp, sz, sz, sz, sz, sz, vp, vp]
         L.orc_problem_add_block_sparse_csc.argtypes = [vp, sz, sz, i32, i32, i32, vp, vp, vp]
         L.orc_problem_add_block_zero.argtypes = [vp, sz, sz, sz, sz]
+        L.orc_problem_add_block_kron_csc.argtypes = [vp, i32, sz, sz, sz, i32, i32, i32, vp, vp, vp]
         L.orc_prox_elem_create.argtypes = [i32, i32, sz, sz, sz, i32, i32, vp, vp]
         L.orc_prox_elem_create.restype = vp
         L.orc_prox_moreau_create.argtypes = [vp]
@@ -96,8 +97,8 @@ def lib():
         L.orc_prox_zero_create.restype = vp
         L.orc_prox_epi_quad_create.argtypes = [sz, sz, sz, i32, i32, vp, sz, vp, sz, vp, sz]
         L.orc_prox_epi_quad_create.restype = vp
-        L.orc_prox_elem_ind_sum_create.argtypes = [sz, sz, sz, i32, i32]
-        L.orc_prox_elem_ind_sum_create.restype = vp
+        L.orc_prox_elem_nocoeff_create.argtypes = [i32, sz, sz, sz, i32, i32]
+        L.orc_prox_elem_nocoeff_create.restype = vp
         L.orc_prox_transform_create.argtypes = [vp, vp, vp]
         L.orc_prox_transform_create.restype = vp
         L.orc_prox_permute_create.argtypes = [vp, vp, sz]
@@ -281,9 +282,9 @@ def make_prox(desc):
     if len(desc) != 5:
         raise OracleError("Invalid prox description. Dim = %d (should be 5)." % len(desc))
     name, idx, size, diagsteps, data = desc
-    if name == "elem_operation:ind_sum":
+    if name in ("elem_operation:ind_sum", "elem_operation:ind_simplex"):
         count, dim, interleaved = data
-        return L.orc_prox_elem_ind_sum_create(idx, int(count), int(dim), int(interleaved), int(diagsteps))
+        return L.orc_prox_elem_nocoeff_create(2 if name.endswith("ind_sum") else 3, idx, int(count), int(dim), int(interleaved), int(diagsteps))
     if name == "transform":                                   # factory.cpp:301-310
         arrs = []
         for c in data[:5]:
@@ -399,6 +400,13 @@ class Problem:
             ir = np.ascontiguousarray(K.indices, dtype=np.int32)
             _chk(L.orc_problem_add_block_sparse_csc(self.h, row, col, K.shape[0], K.shape[1], K.nnz,
                                                     _p(val), _p(jc), _p(ir)))
+        elif name in ("sparse_kron_id", "id_kron_sparse"):
+            K, diaglength = data
+            val = np.ascontiguousarray(K.data, dtype=np.float64)
+            jc = np.ascontiguousarray(K.indptr, dtype=np.int32)
+            ir = np.ascontiguousarray(K.indices, dtype=np.int32)
+            _chk(L.orc_problem_add_block_kron_csc(self.h, int(name == "id_kron_sparse"), row, col, int(diaglength), K.shape[0], K.shape[1],
+                                                  K.nnz, _p(val), _p(jc), _p(ir)))
         elif name == "zero":
             _chk(L.orc_problem_add_block_zero(self.h, row, col, int(data[0]), int(data[1])))
         else:
@@ -449,6 +457,8 @@ def _block_size(blk):
         return 3 * n, n
     if name == "sparse":
         return data[0].shape
+    if name in ("sparse_kron_id", "id_kron_sparse"):
+        return data[0].shape[0] * int(data[1]), data[0].shape[1] * int(data[1])
     return int(data[0]), int(data[1])
 
 

@@ -412,7 +412,24 @@ void csr_spmv_acc(T* res, const T* rhs, int nrows, const T* val, const int32_t* 
   }
 }
 
-enum { BK_GRAD2D, BK_GRAD3D, BK_DIAGS, BK_SPARSE, BK_ZERO };
+// BlockSparseKronIdKernel (block_sparse_kron_id.cu:26-49) / BlockIdKronSparseKernel (block_id_kron_sparse.cu:26-52):
+// one output element per thread, matrix values held as float whatever T is
+template <class T>
+void kron_spmv_acc(bool id_first, T* res, const T* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val,
+                   const int32_t* ptr, const int32_t* ind) {
+  PAR_FOR
+  for (ssz tx = 0; tx < (ssz)(diaglength * nrows); tx++) {
+    size_t row, col_ofs;
+    if (id_first) { row = (size_t)tx % nrows; col_ofs = ((size_t)tx / nrows) * ncols; }
+    else { col_ofs = (size_t)tx % diaglength; row = (size_t)tx / diaglength; }
+    T sum = 0;
+    for (int32_t i = ptr[row]; i < ptr[row + 1]; i++)
+      sum += val[i] * rhs[id_first ? (size_t)ind[i] + col_ofs : (size_t)ind[i] * diaglength + col_ofs];
+    res[tx] += sum;
+  }
+}
+
+enum { BK_GRAD2D, BK_GRAD3D, BK_DIAGS, BK_SPARSE, BK_ZERO, BK_SPARSE_KRON_ID, BK_ID_KRON_SPARSE };
 
 template <class T>
 struct Block {
@@ -421,6 +438,7 @@ struct Block {
   size_t ndiags = 0; std::vector<int64_t> ofs; std::vector<float> fac;
   int nnz = 0;
   std::vector<T> val, val_t; std::vector<int32_t> ptr, ind, ptr_t, ind_t;   // K (CSR), K^T (CSR)
+  std::vector<float> fval, fval_t; size_t diaglength = 0; int mat_nrows = 0, mat_ncols = 0;   // Kronecker blocks
 
   void add(T* res, const T* rhs) const {              // EvalLocalAdd
     switch (kind) {
@@ -428,6 +446,8 @@ struct Block {
       case BK_GRAD3D: grad3d_run<T>(false, res, rhs, nx, ny, L, lf); break;
       case BK_DIAGS: diags_run<T>(false, res, rhs, nrows, ncols, ndiags, ofs.data(), fac.data(), false); break;
       case BK_SPARSE: csr_spmv_acc<T>(res, rhs, (int)nrows, val.data(), ptr.data(), ind.data()); break;
+      case BK_SPARSE_KRON_ID: case BK_ID_KRON_SPARSE:
+        kron_spmv_acc<T>(kind == BK_ID_KRON_SPARSE, res, rhs, diaglength, mat_nrows, mat_ncols, fval.data(), ptr.data(), ind.data()); break;
       case BK_ZERO: break;
     }
   }
@@ -437,6 +457,8 @@ struct Block {
       case BK_GRAD3D: grad3d_run<T>(true, res, rhs, nx, ny, L, lf); break;
       case BK_DIAGS: diags_run<T>(true, res, rhs, nrows, ncols, ndiags, ofs.data(), fac.data(), quirk); break;
       case BK_SPARSE: csr_spmv_acc<T>(res, rhs, (int)ncols, val_t.data(), ptr_t.data(), ind_t.data()); break;
+      case BK_SPARSE_KRON_ID: case BK_ID_KRON_SPARSE:
+        kron_spmv_acc<T>(kind == BK_ID_KRON_SPARSE, res, rhs, diaglength, mat_ncols, mat_nrows, fval_t.data(), ptr_t.data(), ind_t.data()); break;
       case BK_ZERO: break;
     }
   }
@@ -458,6 +480,12 @@ struct Block {
         for (int32_t i = ptr[r]; i < ptr[r + 1]; i++) sum += std::pow(std::abs(val[i]), alpha);
         return sum;
       }
+      case BK_SPARSE_KRON_ID: case BK_ID_KRON_SPARSE: {                // block_sparse_kron_id.cu:118-128, block_id_kron_sparse.cu:127-137
+        r = kind == BK_SPARSE_KRON_ID ? r / diaglength : r % (size_t)mat_nrows;
+        T sum = 0;
+        for (int32_t i = ptr[r]; i < ptr[r + 1]; i++) sum += std::pow(std::abs(fval[i]), alpha);
+        return sum;
+      }
     }
     return 0;                                                          // block_zero.cu
   }
@@ -477,6 +505,12 @@ struct Block {
       case BK_SPARSE: {                                                // block_sparse.cu:123-131
         T sum = 0;
         for (int32_t i = ptr_t[c]; i < ptr_t[c + 1]; i++) sum += std::pow(std::abs(val_t[i]), alpha);
+        return sum;
+      }
+      case BK_SPARSE_KRON_ID: case BK_ID_KRON_SPARSE: {                // block_sparse_kron_id.cu:130-140, block_id_kron_sparse.cu:139-149
+        c = kind == BK_SPARSE_KRON_ID ? c / diaglength : c % (size_t)mat_ncols;
+        T sum = 0;
+        for (int32_t i = ptr_t[c]; i < ptr_t[c + 1]; i++) sum += std::pow(std::abs(fval_t[i]), alpha);
         return sum;
       }
     }
@@ -558,11 +592,43 @@ void elem_ind_sum_run(T* res, const T* arg, size_t count, size_t dim, bool inter
   }
 }
 
+// ElemOperationIndSimplex (include/prost/prox/elemop/elem_operation_ind_simplex.hpp:40-119): projection onto
+// the unit simplex by sorting (ShellSort :97-115, descending) and the threshold search of arXiv:1101.6081
+template <class T>
+void elem_ind_simplex_run(T* res, const T* arg, size_t count, size_t dim, bool interleaved) {
+  if (dim > 1024) throw OrcError("ind_simplex: dim exceeds MAX_DIM = 1024 (elem_operation_ind_simplex.hpp:27)");
+  PAR_FOR
+  for (ssz t = 0; t < (ssz)count; t++) {
+    View v{count, dim, interleaved, (size_t)t};
+    std::vector<T> a(dim);
+    for (size_t i = 0; i < dim; i++) a[i] = arg[v.at(i)];
+    const int gaps[6] = {132, 57, 23, 10, 4, 1};
+    for (int k = 0; k < 6; k++) {
+      const int gap = gaps[k];
+      for (int i = gap; i < (int)dim; i++) {
+        const T temp = a[i];
+        int j = i;
+        for (; (j >= gap) && (a[j - gap] <= temp); j -= gap) a[j] = a[j - gap];
+        a[j] = temp;
+      }
+    }
+    bool bget = false;
+    T tmpsum = 0, tmax = 0;
+    for (int ii = 1; ii <= (int)dim - 1; ii++) {
+      tmpsum += a[ii - 1];
+      tmax = (T)(((double)tmpsum - 1.) / (double)(T)ii);
+      if (tmax >= a[ii]) { bget = true; break; }
+    }
+    if (!bget) tmax = (T)(((double)(T)(tmpsum + a[dim - 1]) - 1.0) / (double)(T)dim);
+    for (size_t i = 0; i < dim; i++) res[v.at(i)] = std::max(arg[v.at(i)] - tmax, static_cast<T>(0));
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Prox tree
 // ---------------------------------------------------------------------------------
 enum { PK_ELEM, PK_MOREAU, PK_ZERO, PK_EPI_QUAD, PK_TRANSFORM, PK_PERMUTE, PK_HALFSPACE, PK_SOC, PK_IND_SUM };
-enum { ORC_OP_IND_SUM = 2 };   // elem_operation:ind_sum (no coefficients)
+enum { ORC_OP_IND_SUM = 2, ORC_OP_IND_SIMPLEX = 3 };   // elem_operation:ind_sum / :ind_simplex (no coefficients)
 
 template <class T>
 struct Prox {
@@ -614,6 +680,7 @@ struct Prox {
     switch (kind) {
       case PK_ELEM: {
         if (op == ORC_OP_IND_SUM) { elem_ind_sum_run<T>(res, arg, count, dim, interleaved); break; }
+        if (op == ORC_OP_IND_SIMPLEX) { elem_ind_simplex_run<T>(res, arg, count, dim, interleaved); break; }
         const T* cp[7]; T cv[7];
         for (int i = 0; i < 7; i++) {
           if (coeffs[i].size() > 1) { cp[i] = coeffs[i].data(); cv[i] = 0; }     // prox_elem_operation.inl:160-168
@@ -1459,6 +1526,20 @@ int orc_problem_add_block_sparse_csc(orc_problem* h, size_t row, size_t col, int
             P.blocks.push_back(b);)
   ORC_CATCH
 }
+int orc_problem_add_block_kron_csc(orc_problem* h, int id_first, size_t row, size_t col, size_t diaglength, int nrows, int ncols, int nnz,
+                                   const double* val, const int32_t* jc, const int32_t* ir) {
+  ORC_TRY
+  WITH_PROB(h, Block<T> b; b.kind = id_first ? BK_ID_KRON_SPARSE : BK_SPARSE_KRON_ID; b.row = row; b.col = col;
+            b.nrows = (size_t)nrows * diaglength; b.ncols = (size_t)ncols * diaglength; b.nnz = nnz;
+            b.diaglength = diaglength; b.mat_nrows = nrows; b.mat_ncols = ncols;
+            // CreateFromCSC (block_sparse_kron_id.cu:59-99): double -> real (factory) -> float (:79)
+            std::vector<T> vt(val, val + nnz);
+            b.fval_t.assign(vt.begin(), vt.end()); b.ptr_t.assign(jc, jc + ncols + 1); b.ind_t.assign(ir, ir + nnz);
+            b.fval.resize(nnz); b.ind.resize(nnz); b.ptr.resize(nrows + 1);
+            csr2csc_run<float>(ncols, nrows, nnz, b.fval_t.data(), b.ind_t.data(), b.ptr_t.data(), b.fval.data(), b.ind.data(), b.ptr.data());
+            P.blocks.push_back(b);)
+  ORC_CATCH
+}
 int orc_problem_add_block_zero(orc_problem* h, size_t row, size_t col, size_t nrows, size_t ncols) {
   ORC_TRY
   WITH_PROB(h, Block<T> b; b.kind = BK_ZERO; b.row = row; b.col = col; b.nrows = nrows; b.ncols = ncols; P.blocks.push_back(b);)
@@ -1491,9 +1572,10 @@ orc_prox* orc_prox_epi_quad_create(size_t idx, size_t count, size_t dim, int int
   p->a.assign(a, a + na); p->b.assign(b, b + nb); p->c.assign(c, c + nc);
   return p;
 }
-orc_prox* orc_prox_elem_ind_sum_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps) {
+orc_prox* orc_prox_elem_nocoeff_create(int op, size_t idx, size_t count, size_t dim, int interleaved, int diagsteps) {
+  if (op != ORC_OP_IND_SUM && op != ORC_OP_IND_SIMPLEX) return nullptr;
   orc_prox* p = new orc_prox;
-  p->kind = PK_ELEM; p->op = ORC_OP_IND_SUM; p->index = idx; p->count = count; p->dim = dim; p->size = count * dim;
+  p->kind = PK_ELEM; p->op = op; p->index = idx; p->count = count; p->dim = dim; p->size = count * dim;
   p->interleaved = interleaved; p->diagsteps = diagsteps;
   for (int i = 0; i < 7; i++) p->coeffs[i].assign(1, 0.0);
   return p;

@@ -87,6 +87,9 @@ int orc_problem_add_block_grad(orc_problem*, int is3d, size_t row, size_t col,
 int orc_problem_add_block_diags(orc_problem*, size_t row, size_t col, size_t nrows, size_t ncols,
                                 size_t ndiags, const int64_t* offsets, const double* factors);
 /* MATLAB CSC as handed to factory.cpp:633-655 */
+/* kron(K, I_d) (id_first == 0, block_sparse_kron_id.cu) or kron(I_d, K) (id_first != 0, block_id_kron_sparse.cu); K in CSC */
+int orc_problem_add_block_kron_csc(orc_problem*, int id_first, size_t row, size_t col, size_t diaglength, int nrows, int ncols, int nnz,
+                                   const double* val, const int32_t* jc, const int32_t* ir);
 int orc_problem_add_block_sparse_csc(orc_problem*, size_t row, size_t col, int nrows, int ncols,
                                      int nnz, const double* val, const int32_t* jc, const int32_t* ir);
 int orc_problem_add_block_zero(orc_problem*, size_t row, size_t col, size_t nrows, size_t ncols);
@@ -100,8 +103,8 @@ orc_prox* orc_prox_zero_create(size_t idx, size_t size);
 orc_prox* orc_prox_epi_quad_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps,
                                    const double* a, size_t na, const double* b, size_t nb,
                                    const double* c, size_t nc);
-/* elem_operation:ind_sum (elem_operation_ind_sum.hpp:41-60) */
-orc_prox* orc_prox_elem_ind_sum_create(size_t idx, size_t count, size_t dim, int interleaved, int diagsteps);
+/* op 2: elem_operation:ind_sum (elem_operation_ind_sum.hpp:41-60); op 3: elem_operation:ind_simplex (elem_operation_ind_simplex.hpp:40-119) */
+orc_prox* orc_prox_elem_nocoeff_create(int op, size_t idx, size_t count, size_t dim, int interleaved, int diagsteps);
 /* ProxTransform (prox_transform.cu): coeff = a, b, c, d, e each of length 1 or size; takes ownership of child */
 orc_prox* orc_prox_transform_create(orc_prox* child, const double* const* coeff, const size_t* coeff_len);
 /* ProxPermute (prox_permute.cu); takes ownership of child */

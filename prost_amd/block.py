@@ -27,6 +27,25 @@ def sparse(K):
     return lambda row, col, nrows, ncols: [["sparse", row, col, [K]], sz]
 
 
+def _kron(name, K, diaglength):
+    import scipy.sparse as sp
+    K = sp.csc_matrix(K, dtype=np.float64)
+    K.sort_indices()
+    d = int(diaglength)
+    sz = [K.shape[0] * d, K.shape[1] * d]
+    return lambda row, col, nrows, ncols: [[name, row, col, [K, d]], sz]
+
+
+def sparse_kron_id(K, diaglength):
+    """sparse_kron_id.m:1-14: kron(K, speye(diaglength)) without forming it"""
+    return _kron("sparse_kron_id", K, diaglength)
+
+
+def id_kron_sparse(K, diaglength):
+    """id_kron_sparse.m:1-14: kron(speye(diaglength), K) without forming it"""
+    return _kron("id_kron_sparse", K, diaglength)
+
+
 def diags(nrows, ncols, factors, offsets):
     sz = [nrows, ncols]
     data = [nrows, ncols, np.atleast_1d(np.asarray(factors, dtype=np.float64)),

@@ -159,6 +159,9 @@ std::map<std::string, typename Factory<T>::ProxFactory>& Factory<T>::prox_reg() 
     reg["elem_operation:ind_sum"] = [](size_t idx, size_t, bool ds, const prost_value* d) -> Prox<T>* {
       return new ProxElemIndSum<T>(idx, (size_t)GetScalarFromCell(d, 0), (size_t)GetScalarFromCell(d, 1), GetScalarFromCell(d, 2) > 0., ds);
     };
+    reg["elem_operation:ind_simplex"] = [](size_t idx, size_t, bool ds, const prost_value* d) -> Prox<T>* {
+      return new ProxElemIndSimplex<T>(idx, (size_t)GetScalarFromCell(d, 0), (size_t)GetScalarFromCell(d, 1), GetScalarFromCell(d, 2) > 0., ds);
+    };
     reg["transform"] = [](size_t, size_t size, bool, const prost_value* d) -> Prox<T>* {          // factory.cpp:301-310
       std::array<std::vector<T>, 5> co;
       for (size_t i = 0; i < 5; i++) {
@@ -241,6 +244,16 @@ std::map<std::string, typename Factory<T>::BlockFactory>& Factory<T>::block_reg(
       std::vector<int32_t> ptr(pm->jc.begin(), pm->jc.end()), ind(pm->ir.begin(), pm->ir.begin() + nnz);   // int64 -> int32 narrowing as the reference
       return BlockSparse<T>::CreateFromCSC(row, col, nrows, ncols, nnz, val, ptr, ind);
     };
+    for (int id_first = 0; id_first < 2; id_first++)                                          // factory.cpp:657-755
+      reg[id_first ? "id_kron_sparse" : "sparse_kron_id"] = [id_first](size_t row, size_t col, const prost_value* d) -> Block<T>* {
+        const prost_value* pm = cell_at(d, 0);
+        if (pm->kind != PROST_VALUE_SPARSE) throw Exception("Matrix must be sparse!");
+        const int nrows = (int)pm->rows, ncols = (int)pm->cols, nnz = (int)pm->jc[ncols];
+        const size_t diaglength = (size_t)GetScalarFromCell(d, 1);
+        std::vector<T> val(pm->data.begin(), pm->data.begin() + nnz);
+        std::vector<int32_t> ptr(pm->jc.begin(), pm->jc.end()), ind(pm->ir.begin(), pm->ir.begin() + nnz);
+        return BlockKronSparse<T>::CreateFromCSC(id_first != 0, row, col, diaglength, nrows, ncols, nnz, val, ptr, ind);
+      };
   }
   return reg;
 }

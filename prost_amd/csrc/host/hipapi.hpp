@@ -16,9 +16,12 @@ template <typename T> struct Api;
     static constexpr auto diags_adj = prost_hip_diags_adj_##S;                    \
     static constexpr auto csr_spmv_acc = prost_hip_csr_spmv_acc_##S;              \
     static constexpr auto scale = prost_hip_scale_##S;                            \
+    static constexpr auto sparse_kron_id_acc = prost_hip_sparse_kron_id_acc_##S;  \
+    static constexpr auto id_kron_sparse_acc = prost_hip_id_kron_sparse_acc_##S;  \
     static constexpr auto prox_elem = prost_hip_prox_elem_##S;                    \
     static constexpr auto prox_epi_quad = prost_hip_prox_epi_quad_##S;            \
     static constexpr auto prox_elem_ind_sum = prost_hip_prox_elem_ind_sum_##S;    \
+    static constexpr auto prox_elem_ind_simplex = prost_hip_prox_elem_ind_simplex_##S; \
     static constexpr auto transform_prescale = prost_hip_transform_prescale_##S;  \
     static constexpr auto transform_postscale = prost_hip_transform_postscale_##S; \
     static constexpr auto permute = prost_hip_permute_##S;                        \

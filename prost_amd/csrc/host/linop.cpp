@@ -86,6 +86,58 @@ void BlockSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
 template class BlockSparse<float>;
 template class BlockSparse<double>;
 
+// ---- Kronecker blocks ----
+template <typename T>
+BlockKronSparse<T>* BlockKronSparse<T>::CreateFromCSC(bool id_first, size_t row, size_t col, size_t diaglength, int m, int n, int nnz,
+                                                      const std::vector<T>& val, const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind) {
+  BlockKronSparse<T>* b = new BlockKronSparse<T>(row, col, (size_t)m * diaglength, (size_t)n * diaglength);
+  b->id_first_ = id_first; b->diaglength_ = diaglength; b->mat_nnz_ = nnz; b->mat_nrows_ = m; b->mat_ncols_ = n;
+  b->host_ind_t_ = ind; b->host_ptr_t_ = ptr; b->host_val_t_ = std::vector<float>(val.begin(), val.end());     // block_sparse_kron_id.cu:77-79
+  b->host_ind_.resize(nnz); b->host_val_.resize(nnz); b->host_ptr_.resize(m + 1);
+  csr2csc<float>(n, m, nnz, b->host_val_t_.data(), b->host_ind_t_.data(), b->host_ptr_t_.data(), b->host_val_.data(), b->host_ind_.data(),
+                 b->host_ptr_.data());
+  return b;
+}
+template <typename T>
+void BlockKronSparse<T>::Initialize() {
+  ind_ = host_ind_; ptr_ = host_ptr_; val_ = host_val_;
+  ind_t_ = host_ind_t_; ptr_t_ = host_ptr_t_; val_t_ = host_val_t_;
+}
+template <typename T>
+void BlockKronSparse<T>::Release() { ind_.clear(); ptr_.clear(); val_.clear(); ind_t_.clear(); ptr_t_.clear(); val_t_.clear(); }
+template <typename T>
+T BlockKronSparse<T>::row_sum(size_t row, T alpha) const {
+  row = id_first_ ? row % mat_nrows_ : row / diaglength_;
+  T sum = 0;
+  for (int32_t i = host_ptr_[row]; i < host_ptr_[row + 1]; i++) sum += std::pow(std::abs(host_val_[i]), alpha);
+  return sum;
+}
+template <typename T>
+T BlockKronSparse<T>::col_sum(size_t col, T alpha) const {
+  col = id_first_ ? col % mat_ncols_ : col / diaglength_;
+  T sum = 0;
+  for (int32_t i = host_ptr_t_[col]; i < host_ptr_t_[col + 1]; i++) sum += std::pow(std::abs(host_val_t_[i]), alpha);
+  return sum;
+}
+template <typename T>
+size_t BlockKronSparse<T>::gpu_mem_amount() const {
+  return (host_ind_.size() + host_ind_t_.size() + host_ptr_.size() + host_ptr_t_.size()) * sizeof(int32_t) + (host_val_.size() + host_val_t_.size()) * sizeof(T);
+}
+template <typename T>
+void BlockKronSparse<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) {
+  if (ptr_.size() != host_ptr_.size()) throw Exception("BlockKronSparse used before Initialize().");
+  if (id_first_) CheckHip(Api<T>::id_kron_sparse_acc(r, x, diaglength_, mat_nrows_, mat_ncols_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "id_kron_sparse_acc");
+  else CheckHip(Api<T>::sparse_kron_id_acc(r, x, diaglength_, mat_nrows_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "sparse_kron_id_acc");
+}
+template <typename T>
+void BlockKronSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
+  if (ptr_t_.size() != host_ptr_t_.size()) throw Exception("BlockKronSparse used before Initialize().");
+  if (id_first_) CheckHip(Api<T>::id_kron_sparse_acc(r, x, diaglength_, mat_ncols_, mat_nrows_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "id_kron_sparse_acc");
+  else CheckHip(Api<T>::sparse_kron_id_acc(r, x, diaglength_, mat_ncols_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "sparse_kron_id_acc");
+}
+template class BlockKronSparse<float>;
+template class BlockKronSparse<double>;
+
 // ---- diags block ----
 static bool g_diags_quirk = false;
 template <typename T> void BlockDiags<T>::SetReferenceGridQuirk(bool on) { g_diags_quirk = on; }

@@ -128,6 +128,15 @@ void ProxElemIndSum<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*, 
 template class ProxElemIndSum<float>;
 template class ProxElemIndSum<double>;
 
+// ---- elem_operation:ind_simplex ----
+template <typename T>
+void ProxElemIndSimplex<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*, const T*, T, bool) {
+  if (work_.size() != this->count_ * this->dim_) throw Exception("ProxElemIndSimplex used before Initialize().");
+  CheckHip(Api<T>::prox_elem_ind_simplex(res, arg, work_.data(), this->count_, this->dim_, this->interleaved_ ? 1 : 0, CurrentStream()), "prox_elem_ind_simplex");
+}
+template class ProxElemIndSimplex<float>;
+template class ProxElemIndSimplex<double>;
+
 // ---- transform ----
 template <typename T>
 void ProxTransform<T>::Initialize() {

@@ -410,6 +410,39 @@ static int launch_csr(T* res, const T* rhs, size_t nrows, size_t nnz, const T* v
 }
 
 // ------------------------------------------------------------------------------------------
+// Kronecker blocks: kron(K, I_d) (BlockSparseKronIdKernel, block_sparse_kron_id.cu:26-49) and
+// kron(I_d, K) (BlockIdKronSparseKernel, block_id_kron_sparse.cu:26-52); K in CSR with FLOAT values
+// whatever T is.  One output element per lane.  kron(K, I): the lanes of a wave share the CSR row
+// (ptr / ind / val are wave-uniform broadcasts) and read d-contiguous rhs entries -> fully coalesced.
+// kron(I, K): consecutive lanes own consecutive rows of one K copy (a gather, as in the reference).
+// ------------------------------------------------------------------------------------------
+template <class T, bool ID_FIRST>
+__global__ void __launch_bounds__(kBlock) kron_spmv_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t diaglength, size_t nrows,
+                                                           size_t ncols, const float* __restrict__ val, const int32_t* __restrict__ ptr,
+                                                           const int32_t* __restrict__ ind) {
+  const size_t total = diaglength * nrows;
+  for (size_t tx = (size_t)blockIdx.x * kBlock + threadIdx.x; tx < total; tx += (size_t)gridDim.x * kBlock) {
+    size_t row, col_ofs;
+    if (ID_FIRST) { row = tx % nrows; col_ofs = (tx / nrows) * ncols; }
+    else { col_ofs = tx % diaglength; row = tx / diaglength; }
+    T sum = 0;
+    const int32_t stop = ptr[row + 1];
+    for (int32_t i = ptr[row]; i < stop; i++) sum += val[i] * rhs[ID_FIRST ? (size_t)ind[i] + col_ofs : (size_t)ind[i] * diaglength + col_ofs];
+    res[tx] += sum;
+  }
+}
+
+template <class T>
+static int launch_kron(bool id_first, T* res, const T* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr,
+                       const int32_t* ind, void* stream) {
+  const size_t total = diaglength * nrows;
+  if (total == 0) return 0;
+  if (id_first) hipLaunchKernelGGL((kron_spmv_kernel<T, true>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
+  else hipLaunchKernelGGL((kron_spmv_kernel<T, false>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
+  PH_LAUNCH_END("kronecker spmv kernel");
+}
+
+// ------------------------------------------------------------------------------------------
 template <class T> struct ScaleF { T beta; __device__ T operator()(const T* a) const { return beta * a[0]; } };
 template <class T, bool VIA_FLOAT> struct NegateF { __device__ T operator()(const T* a) const { return VIA_FLOAT ? (T)(-(float)a[0]) : -a[0]; } };
 
@@ -441,6 +474,11 @@ int prost_hip_diags_adj_f64(double* r, const double* x, size_t nr, size_t nc, si
 
 int prost_hip_csr_spmv_acc_f32(float* r, const float* x, size_t nrows, size_t nnz, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<float>(r, x, nrows, nnz, v, p, i, s); }
 int prost_hip_csr_spmv_acc_f64(double* r, const double* x, size_t nrows, size_t nnz, const double* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<double>(r, x, nrows, nnz, v, p, i, s); }
+
+int prost_hip_sparse_kron_id_acc_f32(float* r, const float* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(false, r, x, d, nrows, 0, v, p, i, s); }
+int prost_hip_sparse_kron_id_acc_f64(double* r, const double* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(false, r, x, d, nrows, 0, v, p, i, s); }
+int prost_hip_id_kron_sparse_acc_f32(float* r, const float* x, size_t d, size_t nrows, size_t ncols, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(true, r, x, d, nrows, ncols, v, p, i, s); }
+int prost_hip_id_kron_sparse_acc_f64(double* r, const double* x, size_t d, size_t nrows, size_t ncols, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(true, r, x, d, nrows, ncols, v, p, i, s); }
 
 int prost_hip_scale_f32(float* x, size_t n, double beta, void* s) { return launch_scale<float>(x, n, beta, s); }
 int prost_hip_scale_f64(double* x, size_t n, double beta, void* s) { return launch_scale<double>(x, n, beta, s); }

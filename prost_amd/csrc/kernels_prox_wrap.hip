@@ -169,6 +169,42 @@ __global__ void __launch_bounds__(kBlock) elem_ind_sum_kernel(T* __restrict__ re
   }
 }
 
+// ElemOperationIndSimplex (elem_operation_ind_simplex.hpp:40-119).  The reference sorts in a 1024-entry
+// per-thread local array; here the sort runs in a caller-provided workspace with the same PLANAR
+// layout as the data (entry i of group tx at tx + count*i), so the lanes of a wave touch
+// consecutive addresses whenever they are at the same sort position, and dim is not limited.
+template <class T>
+__global__ void __launch_bounds__(kBlock) elem_ind_simplex_kernel(T* __restrict__ res, const T* __restrict__ arg, T* __restrict__ work,
+                                                                  size_t count, size_t dim, bool interleaved) {
+  for (size_t tx = (size_t)blockIdx.x * kBlock + threadIdx.x; tx < count; tx += (size_t)gridDim.x * kBlock) {
+    const size_t base = interleaved ? tx * dim : tx, stride = interleaved ? 1 : count;
+    T* a = work + tx;                                          // a[i] == a[i * count]
+    for (size_t i = 0; i < dim; i++) a[i * count] = arg[base + i * stride];
+    const int gaps[6] = {132, 57, 23, 10, 4, 1};               // ShellSort :97-115, descending
+    for (int k = 0; k < 6; k++) {
+      const long gap = gaps[k];
+      for (long i = gap; i < (long)dim; i++) {
+        const T temp = a[i * count];
+        long j = i;
+        for (; (j >= gap) && (a[(j - gap) * count] <= temp); j -= gap) a[j * count] = a[(j - gap) * count];
+        a[j * count] = temp;
+      }
+    }
+    bool bget = false;
+    T tmpsum = 0, tmax = 0;
+    for (long ii = 1; ii <= (long)dim - 1; ii++) {
+      tmpsum += a[(ii - 1) * count];
+      tmax = (T)(((double)tmpsum - 1.) / (double)(T)ii);
+      if (tmax >= a[ii * count]) { bget = true; break; }
+    }
+    if (!bget) tmax = (T)(((double)(T)(tmpsum + a[(dim - 1) * count]) - 1.0) / (double)(T)dim);
+    for (size_t i = 0; i < dim; i++) {
+      const T v = arg[base + i * stride] - tmax;
+      res[base + i * stride] = v > (T)0 ? v : (T)0;            // max(val - tmax, 0): first argument wins on NaN
+    }
+  }
+}
+
 }  // namespace prost_hip
 
 using namespace prost_hip;
@@ -207,4 +243,12 @@ int prost_hip_prox_ind_sum_f64(double* res, const double* arg, const double* td,
 }
 int prost_hip_prox_elem_ind_sum_f32(float* res, const float* arg, size_t count, size_t dim, int il, void* s) { GRID_LAUNCH((elem_ind_sum_kernel<float>), count, "elem ind_sum kernel", res, arg, count, dim, il != 0); }
 int prost_hip_prox_elem_ind_sum_f64(double* res, const double* arg, size_t count, size_t dim, int il, void* s) { GRID_LAUNCH((elem_ind_sum_kernel<double>), count, "elem ind_sum kernel", res, arg, count, dim, il != 0); }
+int prost_hip_prox_elem_ind_simplex_f32(float* res, const float* arg, float* work, size_t count, size_t dim, int il, void* s) {
+  if (dim == 0) return 0;
+  GRID_LAUNCH((elem_ind_simplex_kernel<float>), count, "elem ind_simplex kernel", res, arg, work, count, dim, il != 0);
+}
+int prost_hip_prox_elem_ind_simplex_f64(double* res, const double* arg, double* work, size_t count, size_t dim, int il, void* s) {
+  if (dim == 0) return 0;
+  GRID_LAUNCH((elem_ind_simplex_kernel<double>), count, "elem ind_simplex kernel", res, arg, work, count, dim, il != 0);
+}
 }  // extern "C"

@@ -82,6 +82,12 @@ def sum_ind_sum(dim, interleaved):
                                [count // dim, dim, bool(interleaved)]]
 
 
+def sum_ind_simplex(dim, interleaved):
+    """sum_ind_simplex.m:1-9: indicator of the unit simplex per group"""
+    return lambda idx, count: ["elem_operation:ind_simplex", idx, count, False,
+                               [count // dim, dim, bool(interleaved)]]
+
+
 def sum_ind_sum2(dim, inds, s1, dim2=None, inds2=None, s2=None):
     """sum_ind_sum2.m:1-13: sum constraints over index arrays (one or two families)"""
     inds = np.asarray(inds, dtype=np.int64).ravel()

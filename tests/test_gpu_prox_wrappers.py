@@ -125,3 +125,42 @@ def test_rof_through_transform_matches_oracle_and_coefficient_form(prec, dtype):
             assert np.array_equal(st[v], ost[v]), (form, v)
         iters[form] = st
     assert np.abs(iters["transform"]["x"] - iters["coeff"]["x"]).max() <= (1e-10 if dtype == np.float64 else 1e-4)
+
+
+@pytest.mark.parametrize("prec,dtype", PRECISIONS)
+def test_ind_simplex(prec, dtype):
+    prost.set_precision(prec)
+    rng = np.random.default_rng(31)
+    for (N, d, il) in ((300, 289, False), (1000, 5, False), (1000, 5, True), (64, 1, False), (3, 1000, False)):
+        P = -2 + 4 * rng.random(N * d)
+        got, want = both(F.sum_ind_simplex(d, il), P, 1.0, np.ones(N * d), dtype)
+        assert np.array_equal(got, want), (N, d, il)
+        g = got.reshape((N, d), order="C" if il else "F")
+        assert np.abs(g.sum(axis=1) - 1).max() <= 1e-4 and g.min() >= 0
+    got, want = both(F.conjugate(F.sum_ind_simplex(4, False)), rng.standard_normal(400), 0.7, np.full(400, 0.9), dtype)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("prec,dtype", PRECISIONS)
+@pytest.mark.parametrize("name", ["sparse_kron_id", "id_kron_sparse"])
+def test_kronecker_blocks(prec, dtype, name):
+    """product eval_linop (value, transposed value, row / column sums) == oracle bit for bit, and the
+    reference's own check against the explicit Kronecker product (test_linop_sparse_kron_id.m:3-95)"""
+    import scipy.sparse as sp
+    prost.set_precision(prec)
+    rng = np.random.default_rng(32)
+    for (diaglength, nrows, ncols, dens) in ((64 * 12, 81, 64, 0.01), (5, 3, 4, 0.6), (1, 9, 7, 0.3), (700, 2, 2, 1.0)):
+        K_mat = sp.random(nrows, ncols, dens, random_state=5, format="csc")
+        bf = getattr(prost.block, name)(K_mat, diaglength)
+        m, n = nrows * diaglength, ncols * diaglength
+        linop = [bf(0, 0, m, n)[0], bf(m, 0, m, n)[0], bf(m, n, m, n)[0], bf(0, n, m, n)[0]]
+        inp, inp_t = rng.standard_normal(2 * n), rng.standard_normal(2 * m)
+        x, rowsum, colsum, _ = prost.eval_linop(linop, inp, False)
+        x_t = prost.eval_linop(linop, inp_t, True)[0]
+        ox, orow, ocol = oracle.eval_linop(linop, inp, False, dtype)[:3]
+        ox_t = oracle.eval_linop(linop, inp_t, True, dtype)[0]
+        assert np.array_equal(x, ox) and np.array_equal(x_t, ox_t)
+        assert np.allclose(rowsum, orow, rtol=1e-6) and np.allclose(colsum, ocol, rtol=1e-6)
+        full = sp.kron(K_mat, sp.eye(diaglength)) if name == "sparse_kron_id" else sp.kron(sp.eye(diaglength), K_mat)
+        K = sp.bmat([[full, full], [full, full]]).tocsr()
+        assert np.abs(x - K @ inp).max() <= 1e-4 and np.abs(x_t - K.T @ inp_t).max() <= 1e-4

@@ -313,3 +313,46 @@ def test_prox_ind_halfspace_and_soc(dtype):
     assert (np.sqrt((s[:, :-1] ** 2).sum(axis=1)) <= s[:, -1] + 1e-4).all()
     with pytest.raises(oracle.OracleError, match="Only alpha = 1"):
         oracle.eval_prox(prost.function.sum_ind_soc(dim, False, 2), W.reshape(-1, order="F"), 1, np.ones(count * dim), dtype)
+
+
+def _projsplx(y):
+    u = np.sort(y)[::-1]
+    css = np.cumsum(u)
+    rho = np.nonzero(u * np.arange(1, y.size + 1) > (css - 1))[0][-1]
+    return np.maximum(y - (css[rho] - 1) / (rho + 1), 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prox_sum_ind_simplex(dtype):
+    """test_prox_sum_ind_simplex.m:3-36 against the sort-based projection (projsplx)"""
+    rng = np.random.default_rng(22)
+    N, d = 300, 17 * 17
+    P = -2 + 4 * rng.random((N, d))
+    Q = oracle.eval_prox(prost.function.sum_ind_simplex(d, False), P.reshape(-1, order="F"), 1, np.ones(N * d), dtype).reshape((N, d), order="F")
+    Q2 = np.array([_projsplx(P[i]) for i in range(N)])
+    assert np.abs(Q - Q2).max() <= 1e-5
+    Qi = oracle.eval_prox(prost.function.sum_ind_simplex(7, True), P[:, :7].reshape(-1), 1, np.ones(N * 7), dtype).reshape((N, 7))
+    assert np.abs(Qi - np.array([_projsplx(P[i, :7]) for i in range(N)])).max() <= 1e-5
+    one = oracle.eval_prox(prost.function.sum_ind_simplex(1, False), P[:, 0], 1, np.ones(N), dtype)
+    assert np.abs(one - 1).max() <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", ["sparse_kron_id", "id_kron_sparse"])
+def test_linop_kronecker_blocks(dtype, name):
+    """test_linop_sparse_kron_id.m / test_linop_id_kron_sparse.m:3-95: four copies of kron(K, I) resp.
+    kron(I, K) in a 2 x 2 arrangement against the explicit Kronecker product, incl. row / column sums"""
+    rng = np.random.default_rng(23)
+    diaglength, nrows, ncols = 64 * 12, 81, 64
+    K_mat = sp.random(nrows, ncols, 0.01, random_state=3, format="csc")
+    bf = getattr(prost.block, name)(K_mat, diaglength)
+    m, n = nrows * diaglength, ncols * diaglength
+    linop = [bf(0, 0, m, n)[0], bf(m, 0, m, n)[0], bf(m, n, m, n)[0], bf(0, n, m, n)[0]]
+    full = sp.kron(K_mat, sp.eye(diaglength)) if name == "sparse_kron_id" else sp.kron(sp.eye(diaglength), K_mat)
+    K = sp.bmat([[full, full], [full, full]]).tocsr()
+    inp, inp_t = rng.standard_normal(2 * n), rng.standard_normal(2 * m)
+    x, rowsum, colsum = oracle.eval_linop(linop, inp, False, dtype)[:3]
+    x_t = oracle.eval_linop(linop, inp_t, True, dtype)[0]
+    assert np.abs(x - K @ inp).max() <= 1e-4 and np.abs(x_t - K.T @ inp_t).max() <= 1e-4
+    assert np.abs(rowsum - np.asarray(abs(K).sum(axis=1)).ravel()).max() <= 1e-4
+    assert np.abs(colsum - np.asarray(abs(K).sum(axis=0)).ravel()).max() <= 1e-4
