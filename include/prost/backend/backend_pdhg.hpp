@@ -55,7 +55,8 @@ class BackendPDHG : public Backend<T> {
   bool TryFused();
   void IterationFused(bool residual_iteration);
   void IterationGeneric(bool residual_iteration);
-  void IterationPair(int mode);           // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
+  void IterationPair(bool store_mid, bool residuals);   // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
+  void RebuildPrevious();                 // x_prev_ / y_prev_ := x^(k-1) / y^(k-1) after a pair that did not store them
   bool is_residual_iteration(size_t k) const { return k == 0 || (k % (size_t)opts_.residual_iter) == 0; }   // backend_pdhg.cu:389
   void FinishResiduals();                 // all-reduce, D2H, sqrt, step-size rules (backend_pdhg.cu:433-476)
   void UpdateAlg2();                      // :483-488
@@ -67,6 +68,10 @@ class BackendPDHG : public Backend<T> {
   device_vector<T> x_, y_, x_prev_, y_prev_, temp_, kx_, kty_, kx_prev_, kty_prev_;
   device_vector<T> y_spare_;   // third dual buffer: single-kernel residual iterations read y, y_prev and write y_new
   device_vector<T> x_spare_;   // third primal buffer: pair launches that also store the iterate in between
+  // after a pair launch that kept x^(k+1), y^(k+1) in registers, x_prev_ / y_prev_ still hold the pair's
+  // INPUT x^k, y^k; whoever needs the true previous iterate first re-runs iteration k from them
+  bool prev_stale_ = false;
+  T stale_tau_ = 0, stale_sigma_ = 0, stale_theta_ = 0;   // step sizes of that iteration k
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
   double* res_host_;       // pinned
   void* workspace_;
@@ -76,7 +81,7 @@ class BackendPDHG : public Backend<T> {
   T arg_alpha_;
   std::vector<shared_ptr<Prox<T>>> prox_g_, prox_fstar_;
   // kernel timing: event pairs around one launch in eight of every kernel kind
-  enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelPairMid, kKernelPairRes, kKernelKinds };
+  enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelPairMid, kKernelPairRes, kKernelPairMidRes, kKernelKinds };
   bool BeginSample(int kind);
   void EndSample(bool sampled);
   std::vector<void*> ev_;          // pool, two events per sample

@@ -260,9 +260,9 @@ int prost_hip_fused_iteration_f64(const prost_hip_fused_desc* desc, double* x_ne
  * changes them every iteration, :483-488).  Bit-identical to two prost_hip_fused_iteration
  * launches.  x_mid / y_mid == NULL: the intermediate iterate x^(k+1), y^(k+1) is not written
  * anywhere, callers must not need it.  x_mid, y_mid != NULL: it is stored there (10 floats/pixel),
- * leaving the same observable state as two single launches.  res_out4 != NULL (needs x_mid, y_mid
- * and `workspace`): also the four residual sums of iteration k+1 as prost_hip_fused_iteration
- * writes them (same terms; the summation order differs, so the sums agree to rounding).
+ * leaving the same observable state as two single launches.  res_out4 != NULL (needs `workspace`):
+ * also the four residual sums of iteration k+1 as prost_hip_fused_iteration writes them (same
+ * terms; the summation order differs, so the sums agree to rounding) -- with or without x_mid.
  * gradient2d with L == 1 only; see _supported. */
 int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype);
 int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y,

@@ -75,6 +75,7 @@ void BackendPDHG<T>::Initialize() {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols(), l = std::max(m, n);
 
   iteration_ = 0;
+  prev_stale_ = false;
   tau_ = (T)opts_.tau0;
   sigma_ = (T)opts_.sigma0;
   theta_ = 1;
@@ -146,17 +147,17 @@ void BackendPDHG<T>::PerformIteration() {
 
 /// Two iterations (k, k+1) in one launch whenever k >= 2 is not a residual iteration (iterations 0
 /// and 1 run with zeroed K^T y / K x vectors, backend_pdhg.cu:213-216; a residual iteration as the
-/// FIRST of a pair would need y^(k-1)).  What the launch leaves behind depends on who looks next:
-///   mode 2  k+1 is a residual iteration: residual sums in-kernel, x^(k+1), y^(k+1) stored
-///   mode 1  k+1 is the iteration the caller observes (budget == 2), or k+2 is a residual iteration
-///           (it reads y^(k+1) as y_prev): x^(k+1), y^(k+1) stored -> x_prev_ / y_prev_ as the reference
-///   mode 0  nobody reads the iterate in between: it never leaves the registers (7 floats/pixel)
+/// FIRST of a pair would need y^(k-1)).  The iterate in between, x^(k+1) / y^(k+1), stays in
+/// registers: if k+1 is a residual iteration its sums are formed in the kernel, and if somebody
+/// later asks for the previous iterate (current_solution with z / w, i.e. callbacks, convergence,
+/// the end of the run) it is rebuilt by ONE single launch from the pair's inputs (RebuildPrevious).
+/// Only when iteration k+2 is a residual iteration -- it streams y^(k+1) as y_prev -- does the pair
+/// store the intermediate iterate itself.
 template <typename T>
 int BackendPDHG<T>::PerformIterations(int budget) {
   const size_t k = iteration_;
   if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
-    const int mode = is_residual_iteration(k + 1) ? 2 : ((budget == 2 || is_residual_iteration(k + 2)) ? 1 : 0);
-    IterationPair(mode);
+    IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
     return 2;
   }
   PerformIteration();
@@ -180,30 +181,45 @@ void BackendPDHG<T>::EndSample(bool sampled) {
 }
 
 template <typename T>
-void BackendPDHG<T>::IterationPair(int mode) {
+void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
   void* s = CurrentStream();
   double tau[2], sigma[2], theta[2];
   tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
+  stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_;
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
-  const bool t = BeginSample(mode == 2 ? kKernelPairRes : (mode == 1 ? kKernelPairMid : kKernelPair));
-  if (mode == 0) {
+  const bool t = BeginSample(store_mid ? (residuals ? kKernelPairMidRes : kKernelPairMid) : (residuals ? kKernelPairRes : kKernelPair));
+  if (!store_mid) {
     CheckHip(Api<T>::fused_iteration2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
-                                      nullptr, nullptr, s), "fused_iteration2");
+                                      residuals ? res_dev_ : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
     EndSample(t);
-    x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ hold x^k / y^k until a mode >= 1 pair or a single launch rewrites them
+    x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
     y_.swap(y_prev_);
+    prev_stale_ = true;
   } else {
     CheckHip(Api<T>::fused_iteration2(&desc_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
-                                      theta, 0, mode == 2 ? res_dev_ : nullptr, mode == 2 ? workspace_ : nullptr, s), "fused_iteration2");
+                                      theta, 0, residuals ? res_dev_ : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
     EndSample(t);
     x_.swap(x_spare_);       // x_ = x^(k+2), x_prev_ = x^(k+1): the state two single launches leave
     y_.swap(y_spare_);
-    if (mode == 2) FinishResiduals();                                  // iteration_ == k+1 here, as in the single path
+    prev_stale_ = false;
   }
+  if (residuals) FinishResiduals();                                    // iteration_ == k+1 here, as in the single path
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
   iteration_++;
+}
+
+/// x_prev_ / y_prev_ hold x^k, y^k (inputs of the last pair launch), x_ / y_ = x^(k+2), y^(k+2): one
+/// single-iteration launch with the step sizes of iteration k rebuilds x^(k+1), y^(k+1) bit for bit.
+template <typename T>
+void BackendPDHG<T>::RebuildPrevious() {
+  if (!prev_stale_) return;
+  CheckHip(Api<T>::fused_iteration(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
+                                   (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration");
+  x_prev_.swap(x_spare_);
+  y_prev_.swap(y_spare_);
+  prev_stale_ = false;
 }
 
 /// two kernels: x_ / y_ ping-pong with x_prev_ / y_prev_
@@ -213,6 +229,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
   // at entry: x_ = x^k, y_ = y^k, y_prev_ = y^(k-1).  The reference's kty_ is K^T y^k except at
   // k = 0 (zero vector, :213); kty_prev_ is K^T y^(k-1) except at k <= 1 (zero vector).
   if (single_kernel_) {
+    if (res) RebuildPrevious();      // the residual kernel streams y^(k-1)
     // ONE kernel per iteration, x_new never round-trips through HBM (7 floats/pixel; residual
     // iterations add the y_prev stream and the four residual sums).  y_new cannot overwrite
     // y_prev_ on residual iterations (the kernel still reads it), so it goes to y_spare_.
@@ -225,6 +242,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
     x_.swap(x_prev_);
     if (res) { y_prev_.swap(y_spare_); }     // y_prev_ now holds y^(k+1); swapped into y_ below
     y_.swap(y_prev_);
+    prev_stale_ = false;
     if (res) FinishResiduals();
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
@@ -337,6 +355,7 @@ void BackendPDHG<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& 
   const device_vector<T>& Sl = this->problem_->scaling_left();
   device_vector<T> scratch(std::max(n, m));
   if (fused_) {
+    RebuildPrevious();
     // rebuild the operator products the generic path keeps resident (callback iterations only)
     device_vector<T> ktyp(n), kx(m), kxp(m);
     if (iteration_ >= 2) this->problem_->linop()->EvalAdjoint(ktyp, y_prev_);      // kty_prev_ = K^T y^(k): zero vector until k = 2
@@ -376,8 +395,8 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
                                      "fused_iter2d_kernel", "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
-                                     "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+mid+residuals"};
-  const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2};
+                                     "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
+  const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++)
     if (cnt[k]) out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k]});
   ev_kind_.clear();

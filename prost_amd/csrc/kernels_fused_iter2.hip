@@ -41,12 +41,12 @@ struct Col2 {
   T y1[VEC], y2[VEC], x[VEC], gc[NG][VEC];
 };
 
-// MODE 0: plain.  MODE 1: additionally stores the intermediate iterate x^(k+1), y^(k+1) (x_mid, y_mid)
-// so that the state after the launch is fully observable (10 floats/pixel instead of 7).  MODE 2:
-// MODE 1 + the four residual sums of iteration k+1 (backend_pdhg.cu:392-431) -- everything they need
-// (y^k, y^(k+1), y^(k+2), x^(k+1), x^(k+2), K^T y^k, K^T y^(k+1), K x^(k+1), K x^(k+2)) is in registers.
+// MODE bit 0: additionally store the intermediate iterate x^(k+1), y^(k+1) (x_mid, y_mid; 10 floats/pixel
+// instead of 7).  MODE bit 1: the four residual sums of iteration k+1 (backend_pdhg.cu:392-431) --
+// everything they need (y^k, y^(k+1), y^(k+2), x^(k+1), x^(k+2), K^T y^k, K^T y^(k+1), K x^(k+1),
+// K x^(k+2)) is in registers, no extra HBM traffic.
 template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST, int MODE>
-__global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
+__global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 2) || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
                                                                 FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2,
@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || M
   const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t N = (size_t)nx * (size_t)ny;
   constexpr bool kUniformG = (GMASK & 0x15) == 0;
-  constexpr bool kRes = MODE == 2;
+  constexpr bool kRes = (MODE & 2) != 0;
+  constexpr bool kMid = (MODE & 1) != 0;
   typedef Col2<T, VEC, GMASK> Col;
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
   double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || M
   auto off_of = [&](long c) { return (unsigned)((c * ny + row0) * (long)sizeof(T)); };
   const T* const y2base = y + N;
   T* const y2out = y_out + N;
-  T* const y2mid = MODE >= 1 ? y_mid + N : nullptr;
+  T* const y2mid = kMid ? y_mid + N : nullptr;
   auto load_col = [&](long c, Col& in) {
     const unsigned o = off_of(c);
     ldv_o<T, VEC>(y, o, in.y1); ldv_o<T, VEC>(y2base, o, in.y2); ldv_o<T, VEC>(x, o, in.x);
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || M
       primal(inner, cb, y1a_1, y1b_1, up, y1a_0, x1_1, in1.gc, p2, x2_1, kt_c);
       if (owner && cb < xb) {
         stv_o<T, VEC, (VAR & 1) != 0>(x_out, off_of(cb), x2_1);
-        if (MODE >= 1) stv_o<T, VEC, (VAR & 1) != 0>(x_mid, off_of(cb), x1_1);
+        if (kMid) stv_o<T, VEC, (VAR & 1) != 0>(x_mid, off_of(cb), x1_1);
         if (kRes) {                                            // dual_residual_transform (backend_pdhg.cu:73-94)
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (MODE == 2 ? 2 : ((VAR & 2) || M
       dual(inner, c, x2_0, x2_1, x1_0, x1_1, y1a_0, y1b_0, p2, o1, o2, true);
       if (owner) {
         stv_o<T, VEC, (VAR & 1) != 0>(y_out, off_of(c), o1); stv_o<T, VEC, (VAR & 1) != 0>(y2out, off_of(c), o2);
-        if (MODE >= 1) { stv_o<T, VEC, (VAR & 1) != 0>(y_mid, off_of(c), y1a_0); stv_o<T, VEC, (VAR & 1) != 0>(y2mid, off_of(c), y1b_0); }
+        if (kMid) { stv_o<T, VEC, (VAR & 1) != 0>(y_mid, off_of(c), y1a_0); stv_o<T, VEC, (VAR & 1) != 0>(y2mid, off_of(c), y1b_0); }
       }
     }
     // shift the pipeline by one column
@@ -320,7 +321,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
     set_error("fused double iteration: unsupported description"); return 1;
   }
   if ((x_mid == nullptr) != (y_mid == nullptr) || !aligned16(x_mid) || !aligned16(y_mid)) { set_error("fused double iteration: x_mid and y_mid go together"); return 1; }
-  if (out4 && (!ws || !x_mid)) { set_error("fused double iteration: residuals need workspace, x_mid and y_mid"); return 1; }
+  if (out4 && !ws) { set_error("fused double iteration: residuals need the reduction workspace"); return 1; }
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
   if (cols <= 0) {
@@ -355,10 +356,10 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
   hipStream_t s = as_stream(stream);
   static const int variant = getenv("PROST_HIP_ITER2_VARIANT") ? atoi(getenv("PROST_HIP_ITER2_VARIANT")) : 1;   // bit 0: non-temporal stores
-  const int mode = out4 ? 2 : (x_mid ? 1 : 0);
+  const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
   double* partial = static_cast<double*>(ws);
 #define GO3(G, F, M, VARv, FASTv, MODEv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv, MODEv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
-#define GO(G, F, M, VARv, FASTv) do { if (mode == 0) GO3(G, F, M, VARv, FASTv, 0); else if (mode == 1) GO3(G, F, M, VARv, FASTv, 1); else GO3(G, F, M, VARv, FASTv, 2); } while (0)
+#define GO(G, F, M, VARv, FASTv) do { if (mode == 0) GO3(G, F, M, VARv, FASTv, 0); else if (mode == 1) GO3(G, F, M, VARv, FASTv, 1); else if (mode == 2) GO3(G, F, M, VARv, FASTv, 2); else GO3(G, F, M, VARv, FASTv, 3); } while (0)
   if (fast) {
     if (variant & 1) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 0, true);
   }

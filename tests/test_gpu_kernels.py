@@ -357,17 +357,17 @@ def test_double_iteration_kernel_equals_two_single_launches(hip, dtype, shape, f
         res_ref = r4s.to_host()
         xr, yr, x1r, y1r = x_ref.to_host(), y_ref.to_host(), x1.to_host(), y1.to_host()
         for cols in (0, 1, 2, 3, 5, 8, 1000):
-            for mode in (0, 1, 2):
+            for mid, res in ((False, False), (True, False), (False, True), (True, True)):
                 x2 = hip.DeviceArray.from_host(np.full(n, 7.0, dtype)); y2 = hip.DeviceArray.from_host(np.full(m, 7.0, dtype))
                 xm = hip.DeviceArray.from_host(np.full(n, 7.0, dtype)); ym = hip.DeviceArray.from_host(np.full(m, 7.0, dtype))
                 r4 = hip.DeviceArray.zeros(4, np.float64)
-                hip.check(hip.fn("fused_iteration2", dtype)(C.byref(desc), x2.ptr, y2.ptr, dx.ptr, dy.ptr, xm.ptr if mode else None, ym.ptr if mode else None,
-                                                            tau, sigma, theta, cols, r4.ptr if mode == 2 else None, ws.ptr if mode == 2 else None, None))
-                assert np.array_equal(x2.to_host(), xr), (cols, mode, np.flatnonzero(x2.to_host() != xr)[:8])
-                assert np.array_equal(y2.to_host(), yr), (cols, mode, np.flatnonzero(y2.to_host() != yr)[:8])
-                if mode:
-                    assert np.array_equal(xm.to_host(), x1r) and np.array_equal(ym.to_host(), y1r), (cols, mode)
-                if mode == 2:
+                hip.check(hip.fn("fused_iteration2", dtype)(C.byref(desc), x2.ptr, y2.ptr, dx.ptr, dy.ptr, xm.ptr if mid else None, ym.ptr if mid else None,
+                                                            tau, sigma, theta, cols, r4.ptr if res else None, ws.ptr if res else None, None))
+                assert np.array_equal(x2.to_host(), xr), (cols, mid, res, np.flatnonzero(x2.to_host() != xr)[:8])
+                assert np.array_equal(y2.to_host(), yr), (cols, mid, res, np.flatnonzero(y2.to_host() != yr)[:8])
+                if mid:
+                    assert np.array_equal(xm.to_host(), x1r) and np.array_equal(ym.to_host(), y1r), (cols, mid, res)
+                if res:
                     assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
                 for d_ in (x2, y2, xm, ym, r4):
                     d_.free()

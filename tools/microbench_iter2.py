@@ -48,12 +48,12 @@ def main(N=4096, cols_list=(0, 12, 18, 24, 30, 36, 42, 54, 66), iters=200, dtype
           % (N, np.dtype(dtype).name, t, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     xm = hip.DeviceArray.zeros(n, dtype); ym = hip.DeviceArray.zeros(m, dtype); r4 = hip.DeviceArray.zeros(4, np.float64)
     ws = hip.DeviceArray(L_.prost_hip_reduce_workspace_bytes() // 8, np.float64)
-    for cols, mode in [(c, 0) for c in cols_list] + [(cols_list[-1], 1), (cols_list[-1], 2)]:
+    for cols, mode in [(c, 0) for c in cols_list] + [(cols_list[-1], 1), (cols_list[-1], 2), (cols_list[-1], 3)]:
         def run2(k):
             for i in range(k):
                 a, b = i % 2, (i + 1) % 2
-                hip.check(I2(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, xm.ptr if mode else None, ym.ptr if mode else None, tau, sigma, theta, cols,
-                             r4.ptr if mode == 2 else None, ws.ptr if mode == 2 else None, None))
+                hip.check(I2(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, xm.ptr if mode & 1 else None, ym.ptr if mode & 1 else None, tau, sigma, theta, cols,
+                             r4.ptr if mode & 2 else None, ws.ptr if mode & 2 else None, None))
         t = timed(run2)
         print("double  mode=%d N=%d %s cols=%-4d: %.4f ms/launch = %.4f ms/iteration, %.0f it/s, algorithmic (22 floats/launch) %.0f GB/s, kernel moves (7 floats/launch) %.0f GB/s"
               % (mode, N, np.dtype(dtype).name, cols, t, t / 2, 2e3 / t, 22 * n * esz / 1e9 / (t * 1e-3), 7 * n * esz / 1e9 / (t * 1e-3)), flush=True)
