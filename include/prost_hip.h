@@ -272,6 +272,15 @@ int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* desc, double* x_o
                                    double* x_mid, double* y_mid, const double* tau, const double* sigma, const double* theta,
                                    int cols_per_block, double* res_out4, void* workspace, void* stream);
 
+/* Device-side self test of the short correctly rounded forms the fused kernels rely on (csrc/device_math.hpp):
+ * n / d through a refined fp64 reciprocal, sqrtf without range scaling on [2^-96, 2^126], the exact
+ * (float)((double)x / D) of Function1DSquare, and float subtraction == double subtraction rounded to float.
+ * Draws `n` pseudo-random cases (all exponents, subnormal / overflowing quotients, zeros) from `seed` and
+ * writes the number of bit mismatches against the compiler's IEEE expansions to the DEVICE array
+ * mismatches5 = {division, sqrt, exact division, subtraction, control}; `control` counts the cases where
+ * the plain single-precision reciprocal product differs from n / d and must come out > 0. */
+int prost_hip_selftest_math(unsigned long long* mismatches5, uint64_t n, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* ADMM / CGLS building blocks (src/backend/backend_admm.cu, include/prost/cgls.hpp)           */
 /* ------------------------------------------------------------------------------------------ */

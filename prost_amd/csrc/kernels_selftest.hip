@@ -1,0 +1,71 @@
+// kernels_selftest.hip -- exhaustive-style self test of the short correctly rounded forms of
+// device_math.hpp against the compiler's IEEE expansions, ON the device (test infrastructure of
+// the kernel library itself: tests/test_gpu_kernels.py::test_short_division_and_sqrt_forms).
+// The two-iterations kernel relies on  mul_rcp(n, rcp_refined(d)) == n / d,
+// sqrt_midrange(x) == sqrtf(x) on [2^-96, 2^126],  div_to_float_exact(x, u) == (float)((double)x / u.D)
+// and  a - b == (float)((double)a - (double)b)  for ALL inputs in their stated domains.
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace prost_hip {
+
+__device__ __forceinline__ uint32_t mix32(uint64_t v) {
+  v ^= v >> 33; v *= 0xff51afd7ed558ccdull; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ull; v ^= v >> 33;
+  return (uint32_t)v;
+}
+// a float with a uniformly random mantissa and sign, exponent uniform in [elo, ehi] (unbiased)
+__device__ __forceinline__ float rnd_float(uint64_t key, int elo, int ehi) {
+  const uint32_t r = mix32(key), e = mix32(key ^ 0x9e3779b97f4a7c15ull);
+  const int ex = elo + (int)(e % (uint32_t)(ehi - elo + 1));
+  return __uint_as_float((r & 0x807FFFFFu) | ((uint32_t)(ex + 127) << 23));
+}
+
+__global__ void __launch_bounds__(kBlock) selftest_kernel(unsigned long long* bad, uint64_t n, uint64_t seed) {
+  unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t k = seed * 0x100000001b3ull + i * 4;
+    // (0) division through the refined double reciprocal: any normal denominator, numerators over the
+    //     whole float range including subnormal and overflowing quotients, zeros, and n == +-d
+    const int sel = (int)(i % 5);
+    float d = rnd_float(k, -126, 127);
+    if (sel == 3) d = fabsf(d);
+    float nn = sel == 0 ? rnd_float(k + 1, -126, 127) : sel == 1 ? rnd_float(k + 1, -149 + 23, -100) * 1e-10f : sel == 2 ? 0.0f : sel == 3 ? -d : rnd_float(k + 1, -20, 20) * d;
+    const float q = mul_rcp(nn, rcp_refined(d)), qr = nn / d;
+    b0 += (__float_as_uint(q) != __float_as_uint(qr)) && !(q != q && qr != qr);
+    // (4) control: the un-refined single-precision reciprocal is NOT exact -- this count must be > 0
+    b4 += __float_as_uint(nn * __builtin_amdgcn_rcpf(d)) != __float_as_uint(qr);
+    // (1) sqrt without range scaling on its whole domain [2^-96, 2^126]
+    const float x = fabsf(rnd_float(k + 2, -96, 125));
+    const float s = sqrt_midrange(x), sr = sqrtf(x);
+    b1 += __float_as_uint(s) != __float_as_uint(sr);
+    // (2) exact (float)((double)x / D), D = 1 + step as Function1DSquare forms it, steps from tiny to huge
+    const float step = fabsf(rnd_float(k + 3, -30, 30));
+    const UniformDiv u = make_uniform_div(1. + (double)step);
+    const float xv = rnd_float(k + 1, -60, 60);
+    float in4[1] = {xv}, out4[1];
+    div_to_float_exact_vec<1>(in4, u, out4);
+    const float er = (float)((double)xv / u.D);
+    b2 += __float_as_uint(out4[0]) != __float_as_uint(er);
+    b2 += __float_as_uint(div_to_float_exact(xv, u)) != __float_as_uint(er);
+    // (3) float subtraction == double subtraction rounded to float (exponent gaps up to the full range)
+    const float a = rnd_float(k + 1, -126, 127), c = rnd_float(k + 2, -126, 127);
+    const float sf = a - c, sd = (float)((double)a - (double)c);
+    b3 += __float_as_uint(sf) != __float_as_uint(sd);
+  }
+  if (b0) atomicAdd(bad + 0, b0);
+  if (b1) atomicAdd(bad + 1, b1);
+  if (b2) atomicAdd(bad + 2, b2);
+  if (b3) atomicAdd(bad + 3, b3);
+  if (b4) atomicAdd(bad + 4, b4);
+}
+
+}  // namespace prost_hip
+
+using namespace prost_hip;
+
+extern "C" int prost_hip_selftest_math(unsigned long long* mismatches5, uint64_t n, uint64_t seed, void* stream) {
+  PH_CHECK(hipMemsetAsync(mismatches5, 0, 5 * sizeof(unsigned long long), as_stream(stream)));
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(selftest_kernel, dim3(4096), dim3(kBlock), 0, as_stream(stream), mismatches5, n, seed);
+  PH_LAUNCH_END("selftest kernel");
+}
