@@ -46,7 +46,7 @@ struct Col2 {
 // everything they need (y^k, y^(k+1), y^(k+2), x^(k+1), x^(k+2), K^T y^k, K^T y^(k+1), K x^(k+1),
 // K x^(k+2)) is in registers, no extra HBM traffic.
 template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST, int MODE>
-__global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 2) || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
+__global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
                                                                 FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2,
@@ -232,16 +232,22 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 2) || 
     x1_0[j] = x1_1[j] = x1_2[j] = 0; y1a_0[j] = y1b_0[j] = y1a_1[j] = y1b_1[j] = 0; x2_0[j] = x2_1[j] = 0;
     kt_1[j] = kt_2[j] = kt_c[j] = 0;
   }
+  // prefetch depth PF = 1 + (VAR >> 2): columns c+3 .. c+1+PF are in flight / in registers ahead of their use
+  constexpr int PF = 1 + ((VAR >> 2) & 3);
+  Col ahead[PF > 1 ? PF - 1 : 1] = {};
   if (active) {
     if (xa - 2 >= 0) ldv_o<T, VEC>(y, off_of(xa - 2), in1.y1);
     if (xa - 1 >= 0) load_col(xa - 1, in2);
+#pragma unroll
+    for (int k = 0; k < PF - 1; k++) if (xa + k < nx && xa + k <= xb + 1) load_col(xa + k, ahead[k]);
   }
   // every lane active and no lane on the first / last image row: the whole strip is interior
   const bool strip_inner = (long)strip * kRowsPerWave - VEC >= 1 && (long)strip * kRowsPerWave + (long)(kWave - 1) * VEC < ny - 1;
   auto step = [&](auto inner, long c) {
     Col pre = {};
-    const bool has_pre = c + 3 < nx && c + 3 <= xb + 1;
-    if (active && has_pre) load_col(c + 3, pre);
+    constexpr long kAhead = 2 + PF;
+    const bool has_pre = c + kAhead < nx && c + kAhead <= xb + 1;
+    if (active && has_pre) load_col(c + kAhead, pre);
     const long ca = c + 2, cb = c + 1;
     if (ca >= 0 && ca < nx) {                                                                     // stage A
       // lane 0 gets no row above: its first row is never needed (the top halo is its LAST row)
@@ -275,7 +281,12 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 2) || 
     }
     // shift the pipeline by one column
     in1 = in2;
-    in2 = pre;
+    if (PF > 1) {
+      in2 = ahead[0];
+#pragma unroll
+      for (int k = 0; k + 1 < PF - 1; k++) ahead[k] = ahead[k + 1];
+      ahead[PF > 1 ? PF - 2 : 0] = pre;
+    } else in2 = pre;
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       x1_0[j] = x1_1[j]; x1_1[j] = x1_2[j];
@@ -324,13 +335,16 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   if (out4 && !ws) { set_error("fused double iteration: residuals need the reduction workspace"); return 1; }
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
+  static const int variant = getenv("PROST_HIP_ITER2_VARIANT") ? atoi(getenv("PROST_HIP_ITER2_VARIANT")) : 9;
   if (cols <= 0) {
-    // The kernel is VALU/latency-bound with 4 resident waves per SIMD (<= 128 VGPRs): 4096 wave slots
-    // on 256 CUs.  Longest chunk (3 warm-up columns are amortised over it) that still fills >= 90 % of
-    // the slots in ONE round -- a second, mostly empty round costs a full chunk time (measured 4096^2:
-    // 18 cols = 3876 waves 0.118 ms, 30 cols = 2329 waves 0.141 ms, 15 cols = 4658 waves 0.125 ms).
-    // Chunk lengths stay off multiples of 16 (HBM channel spread, see kernels_fused_iter.hip).
-    const size_t slots = 256 * 4 * 4;
+    // The kernel is bound by wave-level latency as much as by HBM: 3 resident waves per SIMD (<= 168
+    // VGPRs) with the loads of three columns in flight per wave beat 4 waves with one (measured same box,
+    // 4096^2: 0.1166 vs 0.1207 ms).  3072 wave slots on 256 CUs: take the longest chunk (3 warm-up
+    // columns are amortised over it) that still fills >= 90 % of the slots in ONE round -- a second,
+    // mostly empty round costs a full chunk time (24 cols = 2907 waves 0.117 ms, 18 cols = 3876 waves
+    // 0.127 ms, 21 cols 0.133 ms).  Chunk lengths stay off multiples of 16 (HBM channel spread).
+    // (the residual instance holds 4 double accumulators and runs 2 waves per SIMD, the mid-storing one 3)
+    const size_t slots = 256 * 4 * (size_t)(out4 ? 2 : (((variant >> 2) & 3) || x_mid ? 3 : 4));
     cols = 6;
     for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
   }
@@ -355,13 +369,12 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
                     p[1].ug.den_one && p[1].uf.den_one;
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
   hipStream_t s = as_stream(stream);
-  static const int variant = getenv("PROST_HIP_ITER2_VARIANT") ? atoi(getenv("PROST_HIP_ITER2_VARIANT")) : 1;   // bit 0: non-temporal stores
   const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
   double* partial = static_cast<double*>(ws);
 #define GO3(G, F, M, VARv, FASTv, MODEv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv, MODEv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
 #define GO(G, F, M, VARv, FASTv) do { if (mode == 0) GO3(G, F, M, VARv, FASTv, 0); else if (mode == 1) GO3(G, F, M, VARv, FASTv, 1); else if (mode == 2) GO3(G, F, M, VARv, FASTv, 2); else GO3(G, F, M, VARv, FASTv, 3); } while (0)
   if (fast) {
-    if (variant & 1) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 0, true);
+    if (variant == 9) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 9, true); else if (variant == 5) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 5, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true);
   }
   else if (d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, false);
   else if (mask == 0) GO(-1, -1, 0, 1, false);

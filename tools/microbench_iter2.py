@@ -61,7 +61,8 @@ def main(N=4096, cols_list=(0, 12, 18, 24, 30, 36, 42, 54, 66), iters=200, dtype
 
 if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    dt = np.float64 if len(sys.argv) > 3 and sys.argv[3] == "f64" else np.float32
     if len(sys.argv) > 2:
-        main(N, tuple(int(c) for c in sys.argv[2].split(",")))
+        main(N, tuple(int(c) for c in sys.argv[2].split(",")), dtype=dt)
     else:
         main(N)
