@@ -409,3 +409,28 @@ def test_pair_kernel_inside_solve_with_callbacks(prec, dtype):
         assert ia == ib and np.array_equal(xa, xb) and np.array_equal(ya, yb)
     for v in ("x", "y", "z", "w"):
         assert np.array_equal(np.asarray(seen[True][1][v]), np.asarray(seen[False][1][v])), v
+
+
+def test_fullsize_4096_pair_launches_equal_single_launches():
+    """the headline configuration itself (4096^2 fp32, alg2, residual_iter 10): 57 iterations run as two-
+    iterations-per-launch kernels (plain, residual and rebuilt-previous-iterate paths all occur) give
+    the same x, y, z, w bit for bit as 57 single launches"""
+    prost.set_precision("single")
+    n = 4096
+    states = {}
+    for pair in (True, False):
+        prob, u, q, f = synthetic.rof_problem(n, n)
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+        b[1]["allow_pair_kernel"] = pair
+        o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+        s = prost.Solver(prob, b, o)
+        s.iterate(57)
+        states[pair] = s.state()
+        s.destroy()
+    for v in "xyzw":
+        assert np.array_equal(states[True][v], states[False][v]), v
+    assert states[True]["iteration"] == states[False]["iteration"] == 57
+    for v in ("tau", "sigma", "theta"):
+        assert states[True][v] == states[False][v]
+    for v in ("primal_res", "dual_res"):
+        assert np.isclose(states[True][v], states[False][v], rtol=1e-6)
