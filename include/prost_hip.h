@@ -265,6 +265,10 @@ int prost_hip_fused_iteration_f64(const prost_hip_fused_desc* desc, double* x_ne
  * terms; the summation order differs, so the sums agree to rounding) -- with or without x_mid.
  * gradient2d with L == 1 only; see _supported. */
 int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype);
+/* 1 iff the launch is also FASTER than two prost_hip_fused_iteration launches: today the ROF / TV-L1 shapes (prox_g
+ * square or abs with scalar a = 1, d = e = 0, prox_f* ind_leq0 with scalar a = 1, d = e = 0), which has a straight-line
+ * instance; other function pairs are supported but register-bound (about 5x slower), so callers pair only here */
+int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int dtype);
 int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y,
                                    float* x_mid, float* y_mid, const double* tau, const double* sigma, const double* theta,
                                    int cols_per_block, double* res_out4, void* workspace, void* stream);

@@ -121,11 +121,16 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       }
     }
     if (FAST) {
-      // ElemOperation1D<Function1DSquare> with scalar a = 1, d = 0, e = 0 (host-checked): a (v - d tau) = v
-      // and the fp64 denominator is 1, so the scaled prox is  square_prox(v - b) + b  -- straight-line
-      // code for the VEC elements, one fallback branch per vector inside the exact division
+      // ElemOperation1D<F> with scalar a = 1, d = 0, e = 0 (host-checked): a (v - d tau) = v and the fp64
+      // denominator is 1, so the scaled prox is  F_prox(v - b; step) + b  -- straight-line code for the
+      // VEC elements.  F = Function1DSquare: the exact division (one fallback branch per vector);
+      // F = Function1DAbs (TV-L1 data term): soft threshold by step = c tau.
       T r[VEC];
-      div_to_float_exact_vec<VEC>(parg, P.ug.sq, r);
+      if (GFN == PROST_FN_SQUARE) div_to_float_exact_vec<VEC>(parg, P.ug.sq, r);
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) r[j] = f1d_apply<T, GFN>(a.g_fn, parg[j], P.ug.step, a.g_val[5], a.g_val[6]);
+      }
 #pragma unroll
       for (int j = 0; j < VEC; j++) xn[j] = r[j] + (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
     }
@@ -324,6 +329,18 @@ static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   return true;
 }
 
+// The straight-line instances exist for the ROF / TV-L1 shapes only: ElemOperation1D<Function1DSquare | Function1DAbs> with scalar
+// a = 1, c != 0, d = 0, e = 0 (b scalar or per pixel) and ElemOperationNorm2<Function1DIndLeq0> with scalar
+// a = 1, d = 0, e = 0.  Every other combination runs through the run-time dispatched instance, whose
+// 4-stage pipeline needs > 240 VGPRs: correct (tests) but ~5x slower than two single launches
+// (measured abs / ind_leq0 at 4096^2: 0.79 vs 0.16 ms per iteration), so callers should not pair there.
+static bool iter2_fast_shape(const prost_hip_fused_desc* d) {
+  if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
+  for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k] && k != 1) return false;
+  return d->g_coeff_val[0] == 1.0 && d->g_coeff_val[2] != 0.0 && d->g_coeff_val[3] == 0.0 && d->g_coeff_val[4] == 0.0 &&
+         d->f_coeff_val[0] == 1.0 && d->f_coeff_val[3] == 0.0 && d->f_coeff_val[4] == 0.0;
+}
+
 template <class T>
 static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, T* x_mid, T* y_mid, const double* tau,
                      const double* sigma, const double* theta, int cols, double* out4, void* ws, void* stream) {
@@ -363,9 +380,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k]) mask |= 1 << k;
   // straight-line instance for the ROF shape: square / ind_leq0 with scalar a = 1, d = 0, e = 0 on both
   // sides (so a (v - d tau) = v and the fp64 denominators are exactly 1), b of prox_g per pixel
-  const bool fast = d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2 &&
-                    p[0].ug.a_one && p[0].ug.den_one && !p[0].ug.degenerate && a.g_val[3] == (T)0 &&
-                    p[0].uf.a_one && p[0].uf.den_one && a.f_val[3] == (T)0 &&
+  const bool fast = iter2_fast_shape(d) && p[0].ug.a_one && p[0].ug.den_one && !p[0].ug.degenerate && p[0].uf.a_one && p[0].uf.den_one &&
                     p[1].ug.den_one && p[1].uf.den_one;
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
   hipStream_t s = as_stream(stream);
@@ -373,9 +388,11 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   double* partial = static_cast<double*>(ws);
 #define GO3(G, F, M, VARv, FASTv, MODEv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv, MODEv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
 #define GO(G, F, M, VARv, FASTv) do { if (mode == 0) GO3(G, F, M, VARv, FASTv, 0); else if (mode == 1) GO3(G, F, M, VARv, FASTv, 1); else if (mode == 2) GO3(G, F, M, VARv, FASTv, 2); else GO3(G, F, M, VARv, FASTv, 3); } while (0)
-  if (fast) {
+  if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 9, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 9, true); }
+  else if (fast && mask == 0x2) {
     if (variant == 9) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 9, true); else if (variant == 5) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 5, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true);
   }
+  else if (fast) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0, 9, true);                 // b of prox_g is a scalar too
   else if (d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, false);
   else if (mask == 0) GO(-1, -1, 0, 1, false);
   else GO(-1, -1, 0x7F, 1, false);
@@ -392,6 +409,7 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) ? 1 : 0; }
+int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) && iter2_fast_shape(desc) ? 1 : 0; }
 int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, float* x_mid, float* y_mid,
                                    const double* tau, const double* sigma, const double* theta, int cols_per_block, double* res_out4, void* workspace, void* s) {
   return run_iter2<float>(d, x_out, y_out, x, y, x_mid, y_mid, tau, sigma, theta, cols_per_block, res_out4, workspace, s);

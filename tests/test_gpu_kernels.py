@@ -325,7 +325,7 @@ def test_single_kernel_iteration_equals_two_passes(hip, dtype, shape, fns):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("shape", [(16, 12), (40, 1028), (33, 256), (70, 248), (70, 252), (5, 2052), (64, 64), (4, 4), (7, 496), (131, 500)])
-@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "ind_leq0"), ("abs", "huber")])
 def test_double_iteration_kernel_equals_two_single_launches(hip, dtype, shape, fns):
     """prost_hip_fused_iteration2 (two PDHG iterations, intermediate iterate kept in registers) ==
     two prost_hip_fused_iteration launches with the step sizes of iteration k and k+1, bit for bit,

@@ -10,7 +10,7 @@ import numpy as np
 from prost_amd import _hip as hip
 
 
-def main(N=4096, cols_list=(0, 12, 18, 24, 30, 36, 42, 54, 66), iters=200, dtype=np.float32):
+def main(N=4096, cols_list=(0, 12, 18, 24, 30, 36, 42, 54, 66), iters=200, dtype=np.float32, gfn="square", ffn="ind_leq0"):
     hip.require_device()
     n, m = N * N, 2 * N * N
     rng = np.random.default_rng(0)
@@ -18,7 +18,7 @@ def main(N=4096, cols_list=(0, 12, 18, 24, 30, 36, 42, 54, 66), iters=200, dtype
     x = [hip.DeviceArray.from_host(rng.random(n).astype(dtype)), hip.DeviceArray.zeros(n, dtype)]
     y = [hip.DeviceArray.from_host((rng.random(m) - 0.5).astype(dtype)), hip.DeviceArray.zeros(m, dtype)]
     d = hip.FusedDesc(); d.is3d = 0; d.nx, d.ny, d.L = N, N, 1
-    d.g_fn = hip.FN_ID["square"]; d.f_fn = hip.FN_ID["ind_leq0"]
+    d.g_fn = hip.FN_ID[gfn]; d.f_fn = hip.FN_ID[ffn]
     gv = [1, 0, 10, 0, 0, 0, 0]; fv = [1, 1, 1, 0, 0, 0, 0]
     for i in range(7):
         d.g_coeff_val[i] = gv[i]; d.f_coeff_val[i] = fv[i]
@@ -63,6 +63,7 @@ if __name__ == "__main__":
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     dt = np.float64 if len(sys.argv) > 3 and sys.argv[3] == "f64" else np.float32
     if len(sys.argv) > 2:
-        main(N, tuple(int(c) for c in sys.argv[2].split(",")), dtype=dt)
+        main(N, tuple(int(c) for c in sys.argv[2].split(",")), dtype=dt, gfn=sys.argv[4] if len(sys.argv) > 4 else "square",
+             ffn=sys.argv[5] if len(sys.argv) > 5 else "ind_leq0")
     else:
         main(N)
