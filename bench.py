@@ -94,6 +94,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # PROST_BENCH_FORCE_DIST=1 runs the multi-rank code path (torch.distributed + the native RCCL communicator +
+    # residual all-reduce) even with one rank: the only way to exercise it on a 1-GPU box
+    multi = world > 1 or os.environ.get("PROST_BENCH_FORCE_DIST", "0") == "1"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
@@ -106,13 +109,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the prost hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     prost.set_gpu(local_rank)
     prost.set_precision("single")
-    if world > 1:
+    if multi:
         # RCCL communicator owned by the native solver: rank 0 creates the id, torch broadcasts it
         ident = torch.zeros(128, dtype=torch.float64, device="cuda")
         if rank == 0:
@@ -166,7 +169,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), "
                                    "PDHG alg2, residual_iter=10, lambda=10; one independent problem per GPU" % (n, n),
-                       "path": path, "problems": world, "residual_allreduce": "rccl" if world > 1 else "none"},
+                       "path": path, "problems": world, "residual_allreduce": "rccl" if multi else "none"},
             "achieved_hbm_GBps": value * bytes_per_iter / 1e9,
             "hbm_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world),
             "iterates_finite": finite,
@@ -195,7 +198,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     solver.destroy()
-    if world > 1:
+    if multi:
         prost.comm_destroy()
         dist.destroy_process_group()
 
