@@ -39,7 +39,7 @@ HBM_PEAK_GBPS = 8000.0
 # HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE,
 # KiB -> bytes), collected in separate rocprofv3 --pmc passes on the same workload: profiles/r01_pmc_*.txt
 TRAFFIC_BYTES_PER_LAUNCH = {"fused_iter2d_kernel": (2 * 162173 + 199683) * 1024,         # profiles/r01_pmc_traffic.txt
-                            "fused_iter2d_x2_kernel": (2 * 185786 + 204376) * 1024}
+                            "fused_iter2d_x2_kernel": (2 * 168755 + 196609) * 1024}
 
 
 def cpu_baseline(n_img, max_threads):
