@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
     const bool has_next = I || c + 1 < nx;
     const T bel_n = __shfl_down(xn_c[0], 1, kWave);
     const T bel_o = __shfl_down(xo_c[0], 1, kWave);
-    T a1v[VEC], a2v[VEC], nv[VEC], k1v[VEC], k2v[VEC], q1v[VEC], q2v[VEC];
+    T a1v[VEC], a2v[VEC], nv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
@@ -181,7 +181,6 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
         o1[j] = 0; o2[j] = 0;
       }
       if (!FAST && kRes && acc && owner) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
-      if (FAST) { k1v[j] = kx1; k2v[j] = kx2; q1v[j] = kp1; q2v[j] = kp2; }
     }
     if (FAST) {
       // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked):
@@ -222,7 +221,16 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       }
       if (kRes && acc && owner) {
 #pragma unroll
-        for (int j = 0; j < VEC; j++) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], k1v[j], k2v[j], q1v[j], q2v[j], P);
+        for (int j = 0; j < VEC; j++) {                          // K x^(k+2), K x^(k+1) again: cheaper than keeping them in registers
+          const long row = row0 + j;
+          const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
+          const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
+          const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+          const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
+          const T kp1 = has_next ? xo_n[j] - xo_c[j] : (T)0;
+          const T kp2 = (I || row < ny - 1) ? below_o - xo_c[j] : (T)0;
+          residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
+        }
       }
     }
   };
@@ -360,7 +368,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
     // columns are amortised over it) that still fills >= 90 % of the slots in ONE round -- a second,
     // mostly empty round costs a full chunk time (24 cols = 2907 waves 0.117 ms, 18 cols = 3876 waves
     // 0.127 ms, 21 cols 0.133 ms).  Chunk lengths stay off multiples of 16 (HBM channel spread).
-    // (the residual instance holds 4 double accumulators and runs 2 waves per SIMD, the mid-storing one 3)
+    // (the residual instance holds 4 double accumulators and runs 2 waves per SIMD, the others 3)
     const size_t slots = 256 * 4 * (size_t)(out4 ? 2 : (((variant >> 2) & 3) || x_mid ? 3 : 4));
     cols = 6;
     for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
