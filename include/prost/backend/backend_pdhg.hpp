@@ -46,6 +46,15 @@ class BackendPDHG : public Backend<T> {
   virtual void KernelTimes(std::vector<typename Backend<T>::KernelTime>& out);
   virtual std::string path() const;
 
+  /// Column-sharded images (one slab of columns + halo columns per GPU): only the image columns
+  /// [x0, x1) of this backend's problem count in the residual sums (x1 == 0: all).  Call before
+  /// Initialize(); needs the single-kernel path (gradient2d, L <= 2).
+  void SetOwnedColumns(size_t x0, size_t x1) { owned_x0_ = x0; owned_x1_ = x1; }
+  /// device pointers of the current iterate, for halo exchange between slabs: x (n), y (m)
+  T* x_data() { return x_.data(); }
+  T* y_data() { return y_.data(); }
+  bool single_kernel_path() const { return single_kernel_; }
+
   T tau() const { return tau_; }
   T sigma() const { return sigma_; }
   T theta() const { return theta_; }
@@ -71,6 +80,7 @@ class BackendPDHG : public Backend<T> {
   // after a pair launch that kept x^(k+1), y^(k+1) in registers, x_prev_ / y_prev_ still hold the pair's
   // INPUT x^k, y^k; whoever needs the true previous iterate first re-runs iteration k from them
   bool prev_stale_ = false;
+  size_t owned_x0_ = 0, owned_x1_ = 0;
   T stale_tau_ = 0, stale_sigma_ = 0, stale_theta_ = 0;   // step sizes of that iteration k
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
   double* res_host_;       // pinned

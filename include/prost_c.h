@@ -94,8 +94,15 @@ void prost_set_stop_callback(prost_stop_cb fn, void* user);
  *   set_precision('single'|'double'), get_precision -> string
  *   problem_info(problem, nrows, ncols) -> struct {scaling_left, scaling_right, nrows, ncols,
  *                                                   prox_g, prox_f, prox_gstar, prox_fstar}  (index/size/name rows)
- *   solver_create(problem, nrows, ncols, backend, opts) -> handle (scalar)
- *   solver_iterate(handle, iters[, time_kernels]) -> struct {ms, primal_kernel_ms, dual_kernel_ms, launches}
+ *   solver_create(problem, nrows, ncols, backend, opts[, [x0 x1 nx]]) -> handle (scalar); the optional
+ *       1x3 matrix marks image columns [x0, x1) of nx as OWNED (column-sharded images: the rest are halo
+ *       columns that do not count in the residual sums); pdhg single-kernel gradient2d path only
+ *   solver_iterate(handle, iters[, time_kernels]) -> struct {ms, kernels}; kernels = cell of
+ *       {name, avg_ms, sampled launches, iterations per launch, all launches}
+ *   solver_halo_exchange(handle, ny, halo, left_halo, right_halo, left_rank, right_rank): swap `halo` image
+ *       columns of x and y with the neighbouring ranks over the comm_init communicator (rank < 0: none)
+ *   solver_copy_columns(dst_handle, dst_col, src_handle, src_col, ncols, ny): the same transfer between two
+ *       solvers of one process
  *   solver_state(handle) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,
  *                                   dual_var_norm,eps_primal,eps_dual,iteration,path}
  *   solver_destroy(handle)

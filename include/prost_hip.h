@@ -216,6 +216,9 @@ typedef struct {
   const void* f_coeff_ptr[7]; double f_coeff_val[7];
   double T_val;             /* uniform squared preconditioners (problem.cu:262-287 give           */
   double S_val;             /*   Sigma = 1/2, Tau = 1/4 (2-D), 1/6 (3-D) for gradient blocks)     */
+  size_t res_x0, res_x1;    /* residual sums only over image columns [res_x0, res_x1); res_x1 == 0: all  */
+                            /* (column-sharded images: the halo columns of a slab are not counted;        */
+                            /*  honoured by prost_hip_fused_iteration / _iteration2)                      */
 } prost_hip_fused_desc;
 
 /* returns 1 if the fused passes support this description for dtype (0 f32, 1 f64) */
@@ -323,6 +326,14 @@ int prost_hip_comm_create(void** comm, const void* id128, int rank, int world_si
 int prost_hip_comm_destroy(void* comm);
 /* in-place sum all-reduce of `count` DEVICE doubles (the 4 residual sums) on `stream` */
 int prost_hip_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream);
+/* point-to-point transfers of `bytes` bytes of device memory with rank `peer` of the communicator (RCCL
+ * ncclSend / ncclRecv over xGMI).  Issue the sends and receives of one exchange step between group_start
+ * and group_end: they then complete as ONE group, so both neighbours can be served without deadlock.
+ * Used for the halo columns of column-sharded images. */
+int prost_hip_comm_group_start(void);
+int prost_hip_comm_group_end(void);
+int prost_hip_comm_send(void* comm, const void* buf, size_t bytes, int peer, void* stream);
+int prost_hip_comm_recv(void* comm, void* buf, size_t bytes, int peer, void* stream);
 
 #ifdef __cplusplus
 }

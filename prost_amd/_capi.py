@@ -269,10 +269,20 @@ def set_quirks(**kw):
 class Solver:
     """Persistent solver handle: iterate K times without convergence tests (benchmark / tests)."""
 
-    def __init__(self, prob, backend, opts):
+    def __init__(self, prob, backend, opts, owned_columns=None):
+        """owned_columns = (x0, x1, nx): column-sharded images, see prost_amd.distributed.ColumnShardedSolver"""
         prob.finalize()
         self.prob = prob
-        self.handle = command("solver_create", [prob.data, prob.nrows, prob.ncols, backend, _opts_struct(opts)], nlhs=1)[0]
+        args = [prob.data, prob.nrows, prob.ncols, backend, _opts_struct(opts)]
+        if owned_columns is not None:
+            args.append(np.asarray(owned_columns, dtype=np.float64).reshape(1, 3))
+        self.handle = command("solver_create", args, nlhs=1)[0]
+
+    def halo_exchange(self, ny, halo, left_halo, right_halo, left_rank, right_rank):
+        command("solver_halo_exchange", [self.handle, int(ny), int(halo), int(left_halo), int(right_halo), int(left_rank), int(right_rank)])
+
+    def copy_columns_from(self, dst_col, src, src_col, ncols, ny):
+        command("solver_copy_columns", [self.handle, int(dst_col), src.handle, int(src_col), int(ncols), int(ny)])
 
     def iterate(self, iters, time_kernels=False):
         """-> {"ms": wall time, "kernels": {kernel name: {"avg_ms", "sampled", "launches", "iterations_per_launch"}}}

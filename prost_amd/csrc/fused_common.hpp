@@ -72,6 +72,7 @@ struct FusedArgs {
   const T* g_ptr[7]; T g_val[7];
   const T* f_ptr[7]; T f_val[7];
   T Tval, Sval;
+  size_t rx0, rx1;            // columns whose residual terms are counted (single-kernel / pair kernels)
 };
 
 // value of the row above the first row of this lane (row0 - 1): neighbour lane's last element
@@ -98,6 +99,7 @@ inline FusedArgs<T> make_fused_args(const prost_hip_fused_desc* d) {
     a.f_ptr[k] = static_cast<const T*>(d->f_coeff_ptr[k]); a.f_val[k] = (T)d->f_coeff_val[k];
   }
   a.Tval = (T)d->T_val; a.Sval = (T)d->S_val;
+  a.rx0 = d->res_x1 ? d->res_x0 : 0; a.rx1 = d->res_x1 ? d->res_x1 : d->nx;
   a.cols_per_block = 16;
   return a;
 }

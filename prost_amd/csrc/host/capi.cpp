@@ -426,7 +426,7 @@ int g_next_handle = 1;
 
 template <typename T>
 shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrows, size_t ncols, const prost_value* backend,
-                                         const prost_value* opts, bool with_callbacks) {
+                                         const prost_value* opts, bool with_callbacks, const prost_value* owned = nullptr) {
   auto h = std::make_shared<SolverHandle<T>>();
   h->problem = Factory<T>::CreateProblem(problem, nrows, ncols);
   h->backend = Factory<T>::CreateBackend(backend);
@@ -454,9 +454,19 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
     }
     h->solver->SetStoppingCallback([]() { return g_stop_cb ? g_stop_cb(g_stop_user) != 0 : false; });
   }
+  // column-sharded images: only the owned columns of this slab count (residual sums, global sizes)
+  double own_frac = 1.0;
+  if (owned && owned->kind == PROST_VALUE_MATRIX && owned->data.size() >= 3) {
+    auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
+    if (!pd) throw Exception("Owned columns are only supported by the pdhg backend.");
+    const size_t x0 = (size_t)owned->data[0], x1 = (size_t)owned->data[1], nx = (size_t)owned->data[2];
+    if (x1 <= x0 || x1 > nx) throw Exception("Owned column range must satisfy x0 < x1 <= nx.");
+    pd->SetOwnedColumns(x0, x1);
+    own_frac = (double)(x1 - x0) / (double)nx;
+  }
   if (g_comm) {
     // global sizes for eps_primal / eps_dual: sum over ranks
-    double* d = nullptr; double hbuf[2] = {(double)nrows, (double)ncols};
+    double* d = nullptr; double hbuf[2] = {(double)nrows * own_frac, (double)ncols * own_frac};
     CheckHip(prost_hip_malloc((void**)&d, 2 * sizeof(double)), "malloc");
     CheckHip(prost_hip_memcpy_h2d(d, hbuf, sizeof(hbuf), nullptr), "h2d");
     CheckHip(prost_hip_allreduce_sum_f64(g_comm, d, 2, nullptr), "allreduce");
@@ -466,6 +476,10 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
     h->backend->SetCommunicator(g_comm, (size_t)hbuf[0], (size_t)hbuf[1]);
   }
   h->solver->Initialize();
+  if (own_frac != 1.0) {
+    auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
+    if (!pd->single_kernel_path()) throw Exception("Column sharding needs the single-kernel gradient2d path (one gradient2d block with L <= 2, ny % 4 == 0).");
+  }
   return h;
 }
 
@@ -594,12 +608,13 @@ void cmd_problem_info(CMD_ARGS) {
 }
 
 void cmd_solver_create(CMD_ARGS) {
-  if (nrhs != 5) throw Exception("solver_create: five inputs (problem, nrows, ncols, backend, opts) required.");
+  if (nrhs != 5 && nrhs != 6) throw Exception("solver_create: five inputs (problem, nrows, ncols, backend, opts) [+ owned columns {x0, x1, nx}] required.");
   select_device();
   const size_t nrows = (size_t)prhs[1]->data[0], ncols = (size_t)prhs[2]->data[0];
+  const prost_value* owned = nrhs == 6 ? prhs[5] : nullptr;
   AnyHandle a; a.single = g_single;
-  if (g_single) a.h = build_solver<float>(prhs[0], nrows, ncols, prhs[3], prhs[4], false);
-  else a.h = build_solver<double>(prhs[0], nrows, ncols, prhs[3], prhs[4], false);
+  if (g_single) a.h = build_solver<float>(prhs[0], nrows, ncols, prhs[3], prhs[4], false, owned);
+  else a.h = build_solver<double>(prhs[0], nrows, ncols, prhs[3], prhs[4], false, owned);
   const int id = g_next_handle++;
   g_handles[id] = a;
   if (nlhs >= 1) plhs[0] = prost_value_scalar(id);
@@ -669,6 +684,70 @@ void cmd_solver_state(CMD_ARGS) {
   if (a.single) solver_state_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), nlhs, plhs);
   else solver_state_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), nlhs, plhs);
 }
+// ---- column-sharded images: halo columns of the current iterate (x: n, y: two planes of n; column c of a
+// plane = ny contiguous entries at c * ny) ----
+template <typename T>
+static BackendPDHG<T>& pdhg_of(AnyHandle& a) {
+  auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
+  auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
+  if (!pd || !pd->single_kernel_path()) throw Exception("Halo exchange needs a pdhg solver on the single-kernel gradient2d path.");
+  return *pd;
+}
+/// solver_halo_exchange(handle, ny, halo, left_halo, right_halo, left_rank, right_rank): over the RCCL
+/// communicator of comm_init.  left_halo / right_halo = number of halo columns this slab has on that side
+/// (0 at the image border); a negative rank means no neighbour on that side.
+template <typename T>
+static void halo_exchange_t(AnyHandle& a, size_t ny, size_t H, size_t HL, size_t HR, int left, int right) {
+  if (left < 0 && right < 0) return;
+  if (!g_comm) throw Exception("solver_halo_exchange: comm_init first.");
+  BackendPDHG<T>& pd = pdhg_of<T>(a);
+  auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
+  const size_t n = h->problem->ncols(), nl = n / ny;
+  if (nl * ny != n || HL + HR + 2 * H > nl + (HL ? 0 : H) + (HR ? 0 : H)) throw Exception("solver_halo_exchange: slab too narrow for the halo width.");
+  T* planes[3] = {pd.x_data(), pd.y_data(), pd.y_data() + n};
+  const size_t bytes = H * ny * sizeof(T);
+  void* st = CurrentStream();
+  CheckHip(prost_hip_comm_group_start(), "group_start");
+  for (T* p : planes) {
+    if (left >= 0) {
+      CheckHip(prost_hip_comm_send(g_comm, p + HL * ny, bytes, left, st), "send");              // my first owned columns
+      CheckHip(prost_hip_comm_recv(g_comm, p, bytes, left, st), "recv");                        // -> my left halo
+    }
+    if (right >= 0) {
+      CheckHip(prost_hip_comm_send(g_comm, p + (nl - HR - H) * ny, bytes, right, st), "send");  // my last owned columns
+      CheckHip(prost_hip_comm_recv(g_comm, p + (nl - HR) * ny, bytes, right, st), "recv");      // -> my right halo
+    }
+  }
+  CheckHip(prost_hip_comm_group_end(), "group_end");
+}
+void cmd_solver_halo_exchange(CMD_ARGS) {
+  (void)nlhs; (void)plhs;
+  if (nrhs != 7) throw Exception("solver_halo_exchange: (handle, ny, halo, left_halo, right_halo, left_rank, right_rank) required.");
+  AnyHandle& a = handle_of(prhs[0]);
+  const size_t ny = (size_t)prhs[1]->data[0], H = (size_t)prhs[2]->data[0], HL = (size_t)prhs[3]->data[0], HR = (size_t)prhs[4]->data[0];
+  const int left = (int)prhs[5]->data[0], right = (int)prhs[6]->data[0];
+  if (a.single) halo_exchange_t<float>(a, ny, H, HL, HR, left, right); else halo_exchange_t<double>(a, ny, H, HL, HR, left, right);
+}
+/// solver_copy_columns(dst_handle, dst_col, src_handle, src_col, ncols, ny): the same transfer between two
+/// solvers of ONE process (several slabs on one GPU: tests, or images larger than fit one solver's tiling)
+template <typename T>
+static void copy_columns_t(AnyHandle& dst, size_t dcol, AnyHandle& src, size_t scol, size_t ncols, size_t ny) {
+  BackendPDHG<T>& pd = pdhg_of<T>(dst); BackendPDHG<T>& ps = pdhg_of<T>(src);
+  const size_t nd = std::static_pointer_cast<SolverHandle<T>>(dst.h)->problem->ncols(), ns = std::static_pointer_cast<SolverHandle<T>>(src.h)->problem->ncols();
+  if ((dcol + ncols) * ny > nd || (scol + ncols) * ny > ns) throw Exception("solver_copy_columns: column range outside the slab.");
+  T* d[3] = {pd.x_data(), pd.y_data(), pd.y_data() + nd};
+  T* s[3] = {ps.x_data(), ps.y_data(), ps.y_data() + ns};
+  for (int k = 0; k < 3; k++)
+    CheckHip(prost_hip_memcpy_d2d(d[k] + dcol * ny, s[k] + scol * ny, ncols * ny * sizeof(T), CurrentStream()), "memcpy_d2d");
+}
+void cmd_solver_copy_columns(CMD_ARGS) {
+  (void)nlhs; (void)plhs;
+  if (nrhs != 6) throw Exception("solver_copy_columns: (dst_handle, dst_col, src_handle, src_col, ncols, ny) required.");
+  AnyHandle& d = handle_of(prhs[0]); AnyHandle& s = handle_of(prhs[2]);
+  if (d.single != s.single) throw Exception("solver_copy_columns: both solvers must have the same precision.");
+  const size_t dcol = (size_t)prhs[1]->data[0], scol = (size_t)prhs[3]->data[0], nc = (size_t)prhs[4]->data[0], ny = (size_t)prhs[5]->data[0];
+  if (d.single) copy_columns_t<float>(d, dcol, s, scol, nc, ny); else copy_columns_t<double>(d, dcol, s, scol, nc, ny);
+}
 void cmd_solver_destroy(CMD_ARGS) {
   (void)nlhs; (void)plhs;
   if (nrhs < 1) throw Exception("solver_destroy: handle required.");
@@ -713,7 +792,7 @@ const std::map<std::string, cmd_fn>& cmd_reg() {
       {"eval_prox", cmd_eval_prox}, {"list_gpus", cmd_list_gpus}, {"set_gpu", cmd_set_gpu},
       {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info},
       {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_state", cmd_solver_state},
-      {"solver_destroy", cmd_solver_destroy}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
+      {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_copy_columns", cmd_solver_copy_columns}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
       {"comm_destroy", cmd_comm_destroy}, {"set_quirks", cmd_set_quirks}};
   return reg;
 }

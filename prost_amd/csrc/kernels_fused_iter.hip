@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
           const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
           const T w_hat = (in.x[l][j] - xn[l][j]) / (tau * sqT) - sqT * ktyp;
           const T diff = w_hat + sqT * kty;
-          if (owner && owned) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
+          if (owner && owned && c >= a.rx0 && c < a.rx1) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
         }
       }
     }
@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) out[i][j] = 0;
         }
-        if (RES) {                                          // primal_residual_transform (backend_pdhg.cu:97-120)
+        if (RES && c >= a.rx0 && c < a.rx1) {              // primal_residual_transform (backend_pdhg.cu:97-120)
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) {
             const T yo = i < LCH ? cur.y1[i < LCH ? i : 0][j] : cur.y2[i < LCH ? 0 : i - LCH][j];

@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
     constexpr bool I = decltype(inner)::value;
     const T sigS = P.sigma * a.Sval, theta = P.theta;
     const bool has_next = I || c + 1 < nx;
+    const bool counted = (size_t)c >= a.rx0 && (size_t)c < a.rx1;       // residual terms of this column count (column-sharded images)
     const T bel_n = __shfl_down(xn_c[0], 1, kWave);
     const T bel_o = __shfl_down(xo_c[0], 1, kWave);
     T a1v[VEC], a2v[VEC], nv[VEC];
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       } else {
         o1[j] = 0; o2[j] = 0;
       }
-      if (!FAST && kRes && acc && owner) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
+      if (!FAST && kRes && acc && owner && counted) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
     }
     if (FAST) {
       // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked):
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
           o2[j] = nz ? q2 : (T)0;
         }
       }
-      if (kRes && acc && owner) {
+      if (kRes && acc && owner && counted) {
 #pragma unroll
         for (int j = 0; j < VEC; j++) {                          // K x^(k+2), K x^(k+1) again: cheaper than keeping them in registers
           const long row = row0 + j;
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       if (owner && cb < xb) {
         stv_o<T, VEC, (VAR & 1) != 0>(x_out, off_of(cb), x2_1);
         if (kMid) stv_o<T, VEC, (VAR & 1) != 0>(x_mid, off_of(cb), x1_1);
-        if (kRes) {                                            // dual_residual_transform (backend_pdhg.cu:73-94)
+        if (kRes && (size_t)cb >= a.rx0 && (size_t)cb < a.rx1) {   // dual_residual_transform (backend_pdhg.cu:73-94)
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
             const T w_hat = div_tauT.div(x1_1[j] - x2_1[j]) - sqT * kt_1[j];

@@ -91,6 +91,28 @@ int prost_hip_comm_destroy(void* comm) {
   if (r != ncclSuccess) return nccl_fail(r, "ncclCommDestroy");
   return 0;
 }
+// point-to-point over xGMI (halo columns of column-sharded images); calls between group_start / group_end
+// are issued as one RCCL group, so a rank can send to and receive from both neighbours without deadlock
+int prost_hip_comm_group_start(void) {
+  ncclResult_t r = ncclGroupStart();
+  if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
+  return 0;
+}
+int prost_hip_comm_group_end(void) {
+  ncclResult_t r = ncclGroupEnd();
+  if (r != ncclSuccess) return nccl_fail(r, "ncclGroupEnd");
+  return 0;
+}
+int prost_hip_comm_send(void* comm, const void* buf, size_t bytes, int peer, void* stream) {
+  ncclResult_t r = ncclSend(buf, bytes, ncclChar, peer, (ncclComm_t)comm, as_stream(stream));
+  if (r != ncclSuccess) return nccl_fail(r, "ncclSend");
+  return 0;
+}
+int prost_hip_comm_recv(void* comm, void* buf, size_t bytes, int peer, void* stream) {
+  ncclResult_t r = ncclRecv(buf, bytes, ncclChar, peer, (ncclComm_t)comm, as_stream(stream));
+  if (r != ncclSuccess) return nccl_fail(r, "ncclRecv");
+  return 0;
+}
 int prost_hip_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream) {
   ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)comm, as_stream(stream));
   if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");

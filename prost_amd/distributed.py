@@ -40,3 +40,109 @@ def allreduce_hook(dist):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.numpy()
     return hook
+
+
+# ------------------------------------------------------------------------------------------
+# ONE image sharded over ranks by column slabs
+# ------------------------------------------------------------------------------------------
+def column_slab(nx, rank, world, halo):
+    """Owned image columns [c0, c1) of `rank` and its halo widths (left, right): contiguous slabs whose
+    sizes differ by at most one; no halo at the image border."""
+    base, extra = divmod(nx, world)
+    c0 = rank * base + min(rank, extra)
+    c1 = c0 + base + (1 if rank < extra else 0)
+    return c0, c1, (halo if rank > 0 else 0), (halo if rank < world - 1 else 0)
+
+
+class ColumnShardedSolver:
+    """PDHG on ONE gradient2d image split into column slabs, one slab (+ `halo` columns per inner side)
+    per solver.  Every slab runs the unmodified single-image kernels on its extended slab; the wrong
+    boundary condition at an artificial edge contaminates one more column per iteration, so after at
+    most halo - 2 iterations the halo columns of x and y are refreshed from the neighbours' owned
+    columns (communication-avoiding: one exchange of 3 * halo * ny values per side every halo - 2
+    iterations instead of one per operator application).  Owned columns are then bit-identical to the
+    single-GPU iterates.  Residual sums count owned columns only and are all-reduced through the native
+    communicator when there is one, so step sizes and stopping agree on all ranks.
+
+    make_problem(col_lo, col_hi) must build the problem restricted to image columns [col_lo, col_hi)
+    (an nx' = col_hi - col_lo wide image); the backend must not rescale the step sizes from a LOCAL
+    operator norm, so `scale_steps_operator` is forced off (for gradient operators the reference's
+    rescaling branch |norm - 1| > 0.1 never fires anyway).
+
+    transport: "rccl" (one slab per rank, prost.comm_init done) or a list of ColumnShardedSolver objects
+    of the same process (several slabs on one GPU)."""
+
+    def __init__(self, make_problem, nx, ny, backend, opts, rank, world, halo=8, transport="rccl"):
+        from . import _capi
+        if halo < 3:
+            raise ValueError("halo must be at least 3 columns")
+        self.nx, self.ny, self.rank, self.world, self.halo = nx, ny, rank, world, halo
+        self.c0, self.c1, self.hl, self.hr = column_slab(nx, rank, world, halo)
+        if self.c1 - self.c0 < halo:
+            raise ValueError("slab of %d columns is narrower than the halo" % (self.c1 - self.c0))
+        lo, hi = self.c0 - self.hl, self.c1 + self.hr
+        self.nl = hi - lo
+        prob = make_problem(lo, hi)
+        backend = [backend[0], dict(backend[1], scale_steps_operator=False)]
+        self.solver = _capi.Solver(prob, backend, opts, owned_columns=(self.hl, self.hl + (self.c1 - self.c0), self.nl))
+        self.transport = transport
+        self.since_exchange = 0
+
+    def exchange(self, peers=None):
+        h, ny = self.halo, self.ny
+        if self.transport == "rccl":
+            if self.hl or self.hr:
+                self.solver.halo_exchange(ny, h, self.hl, self.hr, self.rank - 1 if self.hl else -1, self.rank + 1 if self.hr else -1)
+        else:
+            peers = peers if peers is not None else self.transport
+            if self.hl:                       # left halo <- left neighbour's last owned columns
+                src = peers[self.rank - 1]
+                self.solver.copy_columns_from(0, src.solver, src.nl - src.hr - h, h, ny)
+            if self.hr:                       # right halo <- right neighbour's first owned columns
+                src = peers[self.rank + 1]
+                self.solver.copy_columns_from(self.nl - self.hr, src.solver, src.hl, h, ny)
+        self.since_exchange = 0
+
+    def steps_until_exchange(self):
+        return (self.halo - 2) - self.since_exchange
+
+    def iterate_local(self, k):
+        self.solver.iterate(k)
+        self.since_exchange += k
+
+    def iterate(self, iters):
+        """rccl transport: runs `iters` iterations with the exchanges in between (collective: every rank
+        calls it with the same count)"""
+        if self.transport != "rccl":
+            raise RuntimeError("in-process slabs are driven by iterate_group()")
+        done = 0
+        while done < iters:
+            if self.steps_until_exchange() <= 0:
+                self.exchange()
+            k = min(iters - done, self.steps_until_exchange())
+            self.iterate_local(k)
+            done += k
+
+    def owned_state(self):
+        st = self.solver.state()
+        n, ny = self.nl * self.ny, self.ny
+        a, b = self.hl * ny, (self.hl + self.c1 - self.c0) * ny
+        y = np.asarray(st["y"])
+        return {"x": np.asarray(st["x"])[a:b], "y1": y[a:b], "y2": y[n + a:n + b], "iteration": st["iteration"],
+                "primal_res": st["primal_res"], "dual_res": st["dual_res"]}
+
+    def destroy(self):
+        self.solver.destroy()
+
+
+def iterate_group(slabs, iters):
+    """several slabs in one process: lock-step iterations with in-process halo copies"""
+    done = 0
+    while done < iters:
+        if slabs[0].steps_until_exchange() <= 0:
+            for s in slabs:
+                s.exchange(slabs)
+        k = min(iters - done, slabs[0].steps_until_exchange())
+        for s in slabs:
+            s.iterate_local(k)
+        done += k

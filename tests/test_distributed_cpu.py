@@ -79,3 +79,20 @@ def test_global_residual_allreduce_gloo(step):
         # eps uses the GLOBAL sizes: sqrt(sum m) * tol_abs + tol_rel * global norm
         m = 2 * 2 * 20 * 16
         assert np.isclose(g0["eps_primal"], np.sqrt(m) * 1e-4 + 1e-4 * g0["primal_var_norm"], rtol=1e-12)
+
+
+def test_column_slabs_partition_the_image():
+    """prost_amd.distributed.column_slab: contiguous slabs covering [0, nx) exactly, sizes differing by at
+    most one, halo columns only on inner sides"""
+    from prost_amd.distributed import column_slab
+    for nx in (7, 96, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            if nx < world:
+                continue
+            slabs = [column_slab(nx, r, world, 8) for r in range(world)]
+            assert slabs[0][0] == 0 and slabs[-1][1] == nx
+            assert all(slabs[r][1] == slabs[r + 1][0] for r in range(world - 1))
+            sizes = [c1 - c0 for c0, c1, _, _ in slabs]
+            assert max(sizes) - min(sizes) <= 1
+            assert slabs[0][2] == 0 and slabs[-1][3] == 0
+            assert all(s[2] == 8 for s in slabs[1:]) and all(s[3] == 8 for s in slabs[:-1])
