@@ -52,15 +52,56 @@ __device__ __forceinline__ void stv_nt(T* __restrict__ p, const T (&v)[VEC]) {
   __builtin_nontemporal_store(t, reinterpret_cast<V*>(p));
 }
 
-// uniform base + 32-bit per-lane byte offset (global_load/store saddr form)
-template <class T, int VEC>
-__device__ __forceinline__ void ldv_o(const T* base, unsigned byte_off, T (&v)[VEC]) {
-  ldv<T, VEC>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off), v);
+// ---- image heights that are not a multiple of VEC ------------------------------------------------
+// Columns then start at addresses that are only sizeof(T)-aligned and the last lane of a column holds
+// fewer than VEC valid rows.  gfx950 serves 16-byte global accesses at any 4-byte aligned address
+// (unaligned access mode), so the full vectors stay ONE load / store each; only the lane with the
+// ragged end falls back to element accesses (it must neither read past the allocation nor write
+// into the next column).  nvalid = number of rows of this lane inside the image (VEC for all but one).
+typedef float native_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef double native_d2u __attribute__((ext_vector_type(2), aligned(8)));
+template <class T> struct UVecOf;
+template <> struct UVecOf<float> { typedef native_f4u type; };
+template <> struct UVecOf<double> { typedef native_d2u type; };
+
+template <class T, int VEC, bool RAG>
+__device__ __forceinline__ void ldv_n(const T* p, T (&v)[VEC], int nvalid) {
+  if (VEC == 1) { v[0] = p[0]; return; }
+  if (!RAG) { ldv<T, VEC>(p, v); return; }                   // heights that are a multiple of VEC: the aligned form, unchanged
+  if (nvalid >= VEC) {
+    typedef typename UVecOf<T>::type V;
+    const V t = *reinterpret_cast<const V*>(p);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) v[j] = t[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) v[j] = j < nvalid ? p[j] : (T)0;
+  }
 }
-template <class T, int VEC, bool NT>
-__device__ __forceinline__ void stv_o(T* base, unsigned byte_off, const T (&v)[VEC]) {
-  T* p = reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
-  if (NT) stv_nt<T, VEC>(p, v); else stv<T, VEC>(p, v);
+template <class T, int VEC, bool NT, bool RAG>
+__device__ __forceinline__ void stv_n(T* p, const T (&v)[VEC], int nvalid) {
+  if (VEC == 1) { if (NT) __builtin_nontemporal_store(v[0], p); else p[0] = v[0]; return; }
+  if (!RAG) { if (NT) stv_nt<T, VEC>(p, v); else stv<T, VEC>(p, v); return; }
+  if (nvalid >= VEC) {
+    typedef typename UVecOf<T>::type V;
+    V t;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) t[j] = v[j];
+    if (NT) __builtin_nontemporal_store(t, reinterpret_cast<V*>(p)); else *reinterpret_cast<V*>(p) = t;
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) if (j < nvalid) p[j] = v[j];
+  }
+}
+
+// uniform base + 32-bit per-lane byte offset (global_load/store saddr form)
+template <class T, int VEC, bool RAG>
+__device__ __forceinline__ void ldv_o(const T* base, unsigned byte_off, T (&v)[VEC], int nvalid) {
+  ldv_n<T, VEC, RAG>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off), v, nvalid);
+}
+template <class T, int VEC, bool NT, bool RAG>
+__device__ __forceinline__ void stv_o(T* base, unsigned byte_off, const T (&v)[VEC], int nvalid) {
+  stv_n<T, VEC, NT, RAG>(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v, nvalid);
 }
 
 template <class T>

@@ -36,7 +36,8 @@ struct ColIn {            // everything loaded for one column
   T p1[RES ? LCH : 1][RES ? VEC : 1], p2[RES ? LCH : 1][RES ? VEC : 1], upp[RES ? LCH : 1];   // y_prev (RES only)
 };
 
-template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, int VAR>
+// RAG: the image height is not a multiple of VEC (fused_common.hpp, ldv_n / stv_n)
+template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, int VAR, bool RAG>
 __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
                                                              const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma, T theta,
@@ -57,6 +58,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
   const size_t row0 = (size_t)strip * kRowsPerWave + (size_t)lane * VEC;
   const bool active = row0 < ny;                       // loads + primal step
   const bool owner = active && lane < kWave - 1;       // stores + residual terms
+  const int nvalid = !RAG ? VEC : (active ? (ny - row0 < (size_t)VEC ? (int)(ny - row0) : VEC) : 0);   // rows of this lane inside the image
   const size_t xa = (size_t)chunk * a.cols_per_block;
   const size_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t P = nx * ny, N = P * LCH;
@@ -75,19 +77,18 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
     for (int l = 0; l < LCH; l++) {
       const size_t o = l * P + c * ny + row0;
-      if (VAR & 10) { ldv_nt<T, VEC>(y + o, in.y1[l]); ldv_nt<T, VEC>(y + N + o, in.y2[l]); ldv_nt<T, VEC>(x + o, in.x[l]); }
-      else { ldv<T, VEC>(y + o, in.y1[l]); ldv<T, VEC>(y + N + o, in.y2[l]); ldv<T, VEC>(x + o, in.x[l]); }
+      ldv_n<T, VEC, RAG>(y + o, in.y1[l], nvalid); ldv_n<T, VEC, RAG>(y + N + o, in.y2[l], nvalid); ldv_n<T, VEC, RAG>(x + o, in.x[l], nvalid);
       // issued together with the column so that the primal step never waits on a second round trip
       in.up[l] = (lane == 0 && row0 > 0) ? y[N + o - 1] : (T)0;
       if (RES) {
-        ldv<T, RES ? VEC : 1>(y_prev + o, in.p1[RES ? l : 0]);
-        ldv<T, RES ? VEC : 1>(y_prev + N + o, in.p2[RES ? l : 0]);
+        ldv_n<T, RES ? VEC : 1, RAG>(y_prev + o, in.p1[RES ? l : 0], nvalid);
+        ldv_n<T, RES ? VEC : 1, RAG>(y_prev + N + o, in.p2[RES ? l : 0], nvalid);
         in.upp[RES ? l : 0] = (lane == 0 && row0 > 0) ? y_prev[N + o - 1] : (T)0;
       }
 #pragma unroll
       for (int k = 0; k < 7; k++) {
         if ((GMASK >> k) & 1) {
-          if (a.g_ptr[k]) { if (VAR & 18) ldv_nt<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); else ldv<T, VEC>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)]); }
+          if (a.g_ptr[k]) ldv_n<T, VEC, RAG>(a.g_ptr[k] + o, in.gc[l][slot_of(GMASK, k)], nvalid);
           else {
 #pragma unroll
             for (int j = 0; j < VEC; j++) in.gc[l][slot_of(GMASK, k)][j] = a.g_val[k];
@@ -127,7 +128,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
           const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
           const T w_hat = (in.x[l][j] - xn[l][j]) / (tau * sqT) - sqT * ktyp;
           const T diff = w_hat + sqT * kty;
-          if (owner && owned && c >= a.rx0 && c < a.rx1) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
+          if (owner && owned && j < nvalid && c >= a.rx0 && c < a.rx1) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
         }
       }
     }
@@ -144,8 +145,8 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
     if (xa > 0) {
 #pragma unroll
       for (int l = 0; l < LCH; l++) {
-        ldv<T, VEC>(y + l * P + (xa - 1) * ny + row0, halo.y1[l]);
-        if (RES) ldv<T, RES ? VEC : 1>(y_prev + l * P + (xa - 1) * ny + row0, halo.p1[RES ? l : 0]);
+        ldv_n<T, VEC, RAG>(y + l * P + (xa - 1) * ny + row0, halo.y1[l], nvalid);
+        if (RES) ldv_n<T, RES ? VEC : 1, RAG>(y_prev + l * P + (xa - 1) * ny + row0, halo.p1[RES ? l : 0], nvalid);
       }
     }
     if (xa + 1 < nx) load_col(xa + 1, nxt);
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
   primal_col(xa, cur, halo, xa > 0, true, xn_c);            // shuffles inside: every lane takes part
   if (owner) {
 #pragma unroll
-    for (int l = 0; l < LCH; l++) { if (VAR & 1) stv_nt<T, VEC>(x_new + l * P + xa * ny + row0, xn_c[l]); else stv<T, VEC>(x_new + l * P + xa * ny + row0, xn_c[l]); }
+    for (int l = 0; l < LCH; l++) stv_n<T, VEC, (VAR & 1) != 0, RAG>(x_new + l * P + xa * ny + row0, xn_c[l], nvalid);
   }
 
   for (size_t c = xa; c < xb; c++) {
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
       primal_col(c + 1, nxt, cur, true, c + 1 < xb, xn_n);
       if (owner && c + 1 < xb) {
 #pragma unroll
-        for (int l = 0; l < LCH; l++) { if (VAR & 1) stv_nt<T, VEC>(x_new + l * P + (c + 1) * ny + row0, xn_n[l]); else stv<T, VEC>(x_new + l * P + (c + 1) * ny + row0, xn_n[l]); }
+        for (int l = 0; l < LCH; l++) stv_n<T, VEC, (VAR & 1) != 0, RAG>(x_new + l * P + (c + 1) * ny + row0, xn_n[l], nvalid);
       }
     }
     // ---- dual step of column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77) ----
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) out[i][j] = 0;
         }
-        if (RES && c >= a.rx0 && c < a.rx1) {              // primal_residual_transform (backend_pdhg.cu:97-120)
+        if (RES && j < nvalid && c >= a.rx0 && c < a.rx1) { // primal_residual_transform (backend_pdhg.cu:97-120)
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) {
             const T yo = i < LCH ? cur.y1[i < LCH ? i : 0][j] : cur.y2[i < LCH ? 0 : i - LCH][j];
@@ -217,8 +218,8 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
       }
 #pragma unroll
       for (int l = 0; l < LCH; l++) {
-        if (VAR & 1) { stv_nt<T, VEC>(y_new + l * P + c * ny + row0, out[l]); stv_nt<T, VEC>(y_new + N + l * P + c * ny + row0, out[LCH + l]); }
-        else { stv<T, VEC>(y_new + l * P + c * ny + row0, out[l]); stv<T, VEC>(y_new + N + l * P + c * ny + row0, out[LCH + l]); }
+        stv_n<T, VEC, (VAR & 1) != 0, RAG>(y_new + l * P + c * ny + row0, out[l], nvalid);
+        stv_n<T, VEC, (VAR & 1) != 0, RAG>(y_new + N + l * P + c * ny + row0, out[LCH + l], nvalid);
       }
     }
     // shift the pipeline
@@ -268,7 +269,6 @@ static bool iter_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->nx < 2 || d->ny < 2 || d->L < 1 || d->L > 2) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   const int V = dtype == 0 ? 4 : 2;
-  if (d->ny % V != 0) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;                 // per-pixel norm2 coefficients: two-pass kernels
     if (!aligned16(d->g_coeff_ptr[k])) return false;
@@ -307,22 +307,25 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   double* partial = static_cast<double*>(ws);
   int mask = 0;
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k]) mask |= 1 << k;
+  const bool rag = d->ny % V != 0;
   // host-side evaluation of everything element-independent, in the kernels' own expression order
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   // specialised instance for the ROF shape (square / ind_leq0, only b = f per pixel); generic otherwise
   const bool fast = d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2;
-#define GO(LCHv, G, F, M, R, VARv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, VARv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO2(LCHv, G, F, M, R, VARv, RAGv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, VARv, RAGv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO(LCHv, G, F, M, R, VARv) do { if (rag) GO2(LCHv, G, F, M, R, VARv, true); else GO2(LCHv, G, F, M, R, VARv, false); } while (0)
 #define GO_RES(LCHv, G, F, M) do { if (out4) GO(LCHv, G, F, M, true, 1); else GO(LCHv, G, F, M, false, 1); } while (0)
 #define GO_VAR(VARv) case VARv: if (out4) GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true, VARv); else GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, false, VARv); break;
   // tuning knob (bit 0: non-temporal stores [default, +4 % at 4096^2], bit 1: non-temporal loads [-15 %],
   // bit 2: no register prefetch [-8 %], bit 3: nt loads of x, y only, bit 4: nt loads of the coefficient vectors only); measured with tools/variant_sweep.sh
   static const int variant = getenv("PROST_HIP_ITER_VARIANT") ? atoi(getenv("PROST_HIP_ITER_VARIANT")) : 1;
-  if (d->L == 1 && fast && sizeof(T) == 4) { switch (variant) { GO_VAR(0) GO_VAR(1) GO_VAR(2) GO_VAR(3) GO_VAR(4) GO_VAR(5) GO_VAR(6) GO_VAR(7) GO_VAR(9) GO_VAR(17) default: set_error("bad variant"); return 1; } }
+  if (d->L == 1 && fast && sizeof(T) == 4) { switch (variant) { GO_VAR(0) GO_VAR(1) GO_VAR(4) default: set_error("bad variant"); return 1; } }
   else if (d->L == 1) { if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(1, -1, -1, 0); else GO_RES(1, -1, -1, 0x7F); }
   else { if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(2, -1, -1, 0); else GO_RES(2, -1, -1, 0x7F); }
 #undef GO_RES
 #undef GO
+#undef GO2
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused iteration kernel"); }
   if (out4) {
     hipLaunchKernelGGL(fold4_kernel, dim3(1), dim3(kBlock), 0, s, out4, partial, grid.x);

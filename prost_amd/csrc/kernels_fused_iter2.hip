@@ -45,7 +45,7 @@ struct Col2 {
 // instead of 7).  MODE bit 1: the four residual sums of iteration k+1 (backend_pdhg.cu:392-431) --
 // everything they need (y^k, y^(k+1), y^(k+2), x^(k+1), x^(k+2), K^T y^k, K^T y^(k+1), K x^(k+1),
 // K x^(k+2)) is in registers, no extra HBM traffic.
-template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST, int MODE>
+template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST, int MODE, bool RAG>
 __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
@@ -61,6 +61,8 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
   const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
   const bool active = row0 >= 0 && row0 < ny;
   const bool owner = active && lane > 0 && lane < kWave - 1;
+  // RAG: the image height is not a multiple of VEC (fused_common.hpp, ldv_n / stv_n)
+  const int nvalid = !RAG ? VEC : (active ? (ny - row0 < (long)VEC ? (int)(ny - row0) : VEC) : 0);   // rows of this lane inside the image
   const long xa = (long)chunk * a.cols_per_block;
   const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t N = (size_t)nx * (size_t)ny;
@@ -80,11 +82,11 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
   T* const y2mid = kMid ? y_mid + N : nullptr;
   auto load_col = [&](long c, Col& in) {
     const unsigned o = off_of(c);
-    ldv_o<T, VEC>(y, o, in.y1); ldv_o<T, VEC>(y2base, o, in.y2); ldv_o<T, VEC>(x, o, in.x);
+    ldv_o<T, VEC, RAG>(y, o, in.y1, nvalid); ldv_o<T, VEC, RAG>(y2base, o, in.y2, nvalid); ldv_o<T, VEC, RAG>(x, o, in.x, nvalid);
 #pragma unroll
     for (int k = 0; k < 7; k++) {
       if ((GMASK >> k) & 1) {
-        if (a.g_ptr[k]) ldv_o<T, VEC>(a.g_ptr[k], o, in.gc[slot_ofb(GMASK, k)]);
+        if (a.g_ptr[k]) ldv_o<T, VEC, RAG>(a.g_ptr[k], o, in.gc[slot_ofb(GMASK, k)], nvalid);
         else {
 #pragma unroll
           for (int j = 0; j < VEC; j++) in.gc[slot_ofb(GMASK, k)][j] = a.g_val[k];
@@ -181,7 +183,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       } else {
         o1[j] = 0; o2[j] = 0;
       }
-      if (!FAST && kRes && acc && owner && counted) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
+      if (!FAST && kRes && acc && owner && counted && j < nvalid) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
     }
     if (FAST) {
       // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked):
@@ -230,7 +232,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
           const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
           const T kp1 = has_next ? xo_n[j] - xo_c[j] : (T)0;
           const T kp2 = (I || row < ny - 1) ? below_o - xo_c[j] : (T)0;
-          residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
+          if (j < nvalid) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
         }
       }
     }
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
   constexpr int PF = 1 + ((VAR >> 2) & 3);
   Col ahead[PF > 1 ? PF - 1 : 1] = {};
   if (active) {
-    if (xa - 2 >= 0) ldv_o<T, VEC>(y, off_of(xa - 2), in1.y1);
+    if (xa - 2 >= 0) ldv_o<T, VEC, RAG>(y, off_of(xa - 2), in1.y1, nvalid);
     if (xa - 1 >= 0) load_col(xa - 1, in2);
 #pragma unroll
     for (int k = 0; k < PF - 1; k++) if (xa + k < nx && xa + k <= xb + 1) load_col(xa + k, ahead[k]);
@@ -273,14 +275,14 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       const T up = __shfl_up(y1b_1[VEC - 1], 1, kWave);          // lane 0: no source, its first row is halo
       primal(inner, cb, y1a_1, y1b_1, up, y1a_0, x1_1, in1.gc, p2, x2_1, kt_c);
       if (owner && cb < xb) {
-        stv_o<T, VEC, (VAR & 1) != 0>(x_out, off_of(cb), x2_1);
-        if (kMid) stv_o<T, VEC, (VAR & 1) != 0>(x_mid, off_of(cb), x1_1);
+        stv_o<T, VEC, (VAR & 1) != 0, RAG>(x_out, off_of(cb), x2_1, nvalid);
+        if (kMid) stv_o<T, VEC, (VAR & 1) != 0, RAG>(x_mid, off_of(cb), x1_1, nvalid);
         if (kRes && (size_t)cb >= a.rx0 && (size_t)cb < a.rx1) {   // dual_residual_transform (backend_pdhg.cu:73-94)
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
             const T w_hat = div_tauT.div(x1_1[j] - x2_1[j]) - sqT * kt_1[j];
             const T diff = w_hat + sqT * kt_c[j];
-            r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat);
+            if (j < nvalid) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
           }
         }
       }
@@ -289,8 +291,8 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       T o1[VEC], o2[VEC];
       dual(inner, c, x2_0, x2_1, x1_0, x1_1, y1a_0, y1b_0, p2, o1, o2, true);
       if (owner) {
-        stv_o<T, VEC, (VAR & 1) != 0>(y_out, off_of(c), o1); stv_o<T, VEC, (VAR & 1) != 0>(y2out, off_of(c), o2);
-        if (kMid) { stv_o<T, VEC, (VAR & 1) != 0>(y_mid, off_of(c), y1a_0); stv_o<T, VEC, (VAR & 1) != 0>(y2mid, off_of(c), y1b_0); }
+        stv_o<T, VEC, (VAR & 1) != 0, RAG>(y_out, off_of(c), o1, nvalid); stv_o<T, VEC, (VAR & 1) != 0, RAG>(y2out, off_of(c), o2, nvalid);
+        if (kMid) { stv_o<T, VEC, (VAR & 1) != 0, RAG>(y_mid, off_of(c), y1a_0, nvalid); stv_o<T, VEC, (VAR & 1) != 0, RAG>(y2mid, off_of(c), y1b_0, nvalid); }
       }
     }
     // shift the pipeline by one column
@@ -328,8 +330,6 @@ static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   if (!d || d->is3d || d->L != 1) return false;
   if (d->nx < 4 || d->ny < 4) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
-  const int V = dtype == 0 ? 4 : 2;
-  if (d->ny % V != 0) return false;
   if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4 : 8) >= 4294967296.0) return false;   // 32-bit byte offsets per plane
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;
@@ -394,12 +394,14 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
   hipStream_t s = as_stream(stream);
   const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
+  const bool rag = d->ny % V != 0;
   double* partial = static_cast<double*>(ws);
-#define GO3(G, F, M, VARv, FASTv, MODEv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv, MODEv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
+#define GO4(G, F, M, VARv, FASTv, MODEv, RAGv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv, MODEv, RAGv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
+#define GO3(G, F, M, VARv, FASTv, MODEv) do { if (rag) GO4(G, F, M, VARv, FASTv, MODEv, true); else GO4(G, F, M, VARv, FASTv, MODEv, false); } while (0)
 #define GO(G, F, M, VARv, FASTv) do { if (mode == 0) GO3(G, F, M, VARv, FASTv, 0); else if (mode == 1) GO3(G, F, M, VARv, FASTv, 1); else if (mode == 2) GO3(G, F, M, VARv, FASTv, 2); else GO3(G, F, M, VARv, FASTv, 3); } while (0)
   if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 9, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 9, true); }
   else if (fast && mask == 0x2) {
-    if (variant == 9) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 9, true); else if (variant == 5) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 5, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true);
+    if (variant == 1) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 9, true);
   }
   else if (fast) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0, 9, true);                 // b of prox_g is a scalar too
   else if (d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, false);
@@ -407,6 +409,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   else GO(-1, -1, 0x7F, 1, false);
 #undef GO
 #undef GO3
+#undef GO4
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused double iteration kernel"); }
   if (out4) return launch_fold4(out4, partial, grid.x, s);
   return 0;

@@ -28,7 +28,7 @@ def _maker(f_full, ny):
 
 
 @pytest.mark.parametrize("prec,dtype", PRECISIONS)
-@pytest.mark.parametrize("world,halo,nx,ny", [(3, 8, 96, 64), (2, 5, 41, 252), (4, 12, 130, 500)])
+@pytest.mark.parametrize("world,halo,nx,ny", [(3, 8, 96, 64), (2, 5, 41, 252), (4, 12, 130, 500), (3, 6, 60, 249)])
 def test_slabs_reproduce_the_single_image_iterates(prec, dtype, world, halo, nx, ny):
     prost.set_precision(prec)
     f = np.asarray(synthetic.rof_image(nx, ny, 1, 9)).ravel()

@@ -357,7 +357,7 @@ def test_pair_kernel_schedule_is_invisible(prec, dtype, step, residual_iter):
     need x^(k-1), y^(k-1)), the residuals and the step sizes -- is bit-identical to the path that
     launches every iteration separately, and to the oracle."""
     prost.set_precision(prec)
-    for (nx, ny) in ((24, 16), (9, 252), (40, 500)):
+    for (nx, ny) in ((24, 16), (9, 252), (40, 500), (24, 18), (9, 251)):
         for iters in (1, 2, 3, 5, 8, 9, 10, 11, 23):
             states = []
             for pair in (True, False):
