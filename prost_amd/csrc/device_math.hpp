@@ -240,21 +240,6 @@ __device__ __forceinline__ T scaled_prox(int fn, T v, T tau, const T* c) {
   return div1((T)(f1d_apply<T, FN>(fn, prox_arg, step, c[5], c[6]) + c[1]), c[0]);
 }
 
-// ElemOperation1D<Function1DSquare> when a, c, e and tau are wave-uniform: the divisor of
-// Function1DSquare, 1. + step, is uniform.  `u` must be make_uniform_div(1. + (double)step) with
-// step = (T)div1((double)(c2*c0*c0*tau), 1. + (double)(tau*c4)); requires c0 != 0 && c2 != 0.
-template <class T>
-__device__ __forceinline__ T square_step(T tau, const T* c) {
-  return (T)div1((double)(c[2] * c[0] * c[0] * tau), 1. + (double)(tau * c[4]));
-}
-template <class T>
-__device__ __forceinline__ T elem_1d_square_uniform(T arg, T tau, const T* c, const UniformDiv& u) {
-  const double den = 1. + (double)(tau * c[4]);
-  const T prox_arg = (T)(div1((double)(c[0] * (arg - c[3] * tau)), den) - (double)c[1]);
-  const T f = div_to_float_exact(prox_arg, u);
-  return div1((T)(f + c[1]), c[0]);
-}
-
 // ---- scaled prox with ALL seven coefficients and the step size wave-uniform --------------------
 // Everything that does not depend on the element (the fp64 denominator 1. + tau*e, the step, the
 // divisor of Function1DSquare and its reciprocal) is evaluated ONCE ON THE HOST with the same

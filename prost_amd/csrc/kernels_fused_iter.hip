@@ -20,7 +20,6 @@
 #include "fused_common.hpp"
 #include "reduce.hpp"
 
-#include <cstdlib>
 
 namespace prost_hip {
 
@@ -37,7 +36,7 @@ struct ColIn {            // everything loaded for one column
 };
 
 // RAG: the image height is not a multiple of VEC (fused_common.hpp, ldv_n / stv_n)
-template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, int VAR, bool RAG>
+template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, bool RAG>
 __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
                                                              const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma, T theta,
@@ -154,19 +153,19 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
   primal_col(xa, cur, halo, xa > 0, true, xn_c);            // shuffles inside: every lane takes part
   if (owner) {
 #pragma unroll
-    for (int l = 0; l < LCH; l++) stv_n<T, VEC, (VAR & 1) != 0, RAG>(x_new + l * P + xa * ny + row0, xn_c[l], nvalid);
+    for (int l = 0; l < LCH; l++) stv_n<T, VEC, true, RAG>(x_new + l * P + xa * ny + row0, xn_c[l], nvalid);
   }
 
   for (size_t c = xa; c < xb; c++) {
     const bool has_next = c + 1 < nx;
     Col pre;                                                  // prefetch column c+2 while column c+1 / c are processed
     const bool has_pre = c + 2 < nx && c + 1 < xb;
-    if (!(VAR & 4) && active && has_pre) load_col(c + 2, pre);
+    if (active && has_pre) load_col(c + 2, pre);
     if (has_next) {
       primal_col(c + 1, nxt, cur, true, c + 1 < xb, xn_n);
       if (owner && c + 1 < xb) {
 #pragma unroll
-        for (int l = 0; l < LCH; l++) stv_n<T, VEC, (VAR & 1) != 0, RAG>(x_new + l * P + (c + 1) * ny + row0, xn_n[l], nvalid);
+        for (int l = 0; l < LCH; l++) stv_n<T, VEC, true, RAG>(x_new + l * P + (c + 1) * ny + row0, xn_n[l], nvalid);
       }
     }
     // ---- dual step of column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77) ----
@@ -218,14 +217,13 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
       }
 #pragma unroll
       for (int l = 0; l < LCH; l++) {
-        stv_n<T, VEC, (VAR & 1) != 0, RAG>(y_new + l * P + c * ny + row0, out[l], nvalid);
-        stv_n<T, VEC, (VAR & 1) != 0, RAG>(y_new + N + l * P + c * ny + row0, out[LCH + l], nvalid);
+        stv_n<T, VEC, true, RAG>(y_new + l * P + c * ny + row0, out[l], nvalid);
+        stv_n<T, VEC, true, RAG>(y_new + N + l * P + c * ny + row0, out[LCH + l], nvalid);
       }
     }
     // shift the pipeline
     cur = nxt;
-    if (VAR & 4) { if (active && has_pre) load_col(c + 2, nxt); }     // no register prefetch: load after use
-    else if (has_pre) nxt = pre;
+    if (has_pre) nxt = pre;
 #pragma unroll
     for (int l = 0; l < LCH; l++)
 #pragma unroll
@@ -313,15 +311,11 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   // specialised instance for the ROF shape (square / ind_leq0, only b = f per pixel); generic otherwise
   const bool fast = d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2;
-#define GO2(LCHv, G, F, M, R, VARv, RAGv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, VARv, RAGv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
-#define GO(LCHv, G, F, M, R, VARv) do { if (rag) GO2(LCHv, G, F, M, R, VARv, true); else GO2(LCHv, G, F, M, R, VARv, false); } while (0)
-#define GO_RES(LCHv, G, F, M) do { if (out4) GO(LCHv, G, F, M, true, 1); else GO(LCHv, G, F, M, false, 1); } while (0)
-#define GO_VAR(VARv) case VARv: if (out4) GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true, VARv); else GO(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, false, VARv); break;
-  // tuning knob (bit 0: non-temporal stores [default, +4 % at 4096^2], bit 1: non-temporal loads [-15 %],
-  // bit 2: no register prefetch [-8 %], bit 3: nt loads of x, y only, bit 4: nt loads of the coefficient vectors only); measured with tools/variant_sweep.sh
-  static const int variant = getenv("PROST_HIP_ITER_VARIANT") ? atoi(getenv("PROST_HIP_ITER_VARIANT")) : 1;
-  if (d->L == 1 && fast && sizeof(T) == 4) { switch (variant) { GO_VAR(0) GO_VAR(1) GO_VAR(4) default: set_error("bad variant"); return 1; } }
-  else if (d->L == 1) { if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(1, -1, -1, 0); else GO_RES(1, -1, -1, 0x7F); }
+#define GO2(LCHv, G, F, M, R, RAGv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO(LCHv, G, F, M, R) do { if (rag) GO2(LCHv, G, F, M, R, true); else GO2(LCHv, G, F, M, R, false); } while (0)
+#define GO_RES(LCHv, G, F, M) do { if (out4) GO(LCHv, G, F, M, true); else GO(LCHv, G, F, M, false); } while (0)
+  // measured (4096^2 fp32): non-temporal stores +4 %, non-temporal loads -15 %, no register prefetch -8 %
+  if (d->L == 1) { if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(1, -1, -1, 0); else GO_RES(1, -1, -1, 0x7F); }
   else { if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(2, -1, -1, 0); else GO_RES(2, -1, -1, 0x7F); }
 #undef GO_RES
 #undef GO

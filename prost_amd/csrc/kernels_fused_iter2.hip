@@ -21,7 +21,6 @@
 #include "fused_common.hpp"
 #include "reduce.hpp"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace prost_hip {
@@ -45,8 +44,9 @@ struct Col2 {
 // instead of 7).  MODE bit 1: the four residual sums of iteration k+1 (backend_pdhg.cu:392-431) --
 // everything they need (y^k, y^(k+1), y^(k+2), x^(k+1), x^(k+2), K^T y^k, K^T y^(k+1), K x^(k+1),
 // K x^(k+2)) is in registers, no extra HBM traffic.
-template <class T, int VEC, int GFN, int FFN, int GMASK, int VAR, bool FAST, int MODE, bool RAG>
-__global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
+// PF: columns of loads kept in flight per wave (3 for the straight-line instances at 3 waves/SIMD, 1 otherwise)
+template <class T, int VEC, int GFN, int FFN, int GMASK, int PF, bool FAST, int MODE, bool RAG>
+__global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
                                                                 FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2,
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
         tmin = min(tmin, (unsigned)__float_as_int((float)nv[j]) - 1u);     // 0 -> 0xFFFFFFFF: a zero norm is fine
         nmax = nv[j] > nmax ? nv[j] : nmax;
       }
-      const bool mid = sizeof(T) == 4 && !(VAR & 4) && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
+      const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
       if (__builtin_expect(mid, 1)) {
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
@@ -248,8 +248,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
     x1_0[j] = x1_1[j] = x1_2[j] = 0; y1a_0[j] = y1b_0[j] = y1a_1[j] = y1b_1[j] = 0; x2_0[j] = x2_1[j] = 0;
     kt_1[j] = kt_2[j] = kt_c[j] = 0;
   }
-  // prefetch depth PF = 1 + (VAR >> 2): columns c+3 .. c+1+PF are in flight / in registers ahead of their use
-  constexpr int PF = 1 + ((VAR >> 2) & 3);
+  // prefetch depth PF: columns c+3 .. c+1+PF are in flight / in registers ahead of their use
   Col ahead[PF > 1 ? PF - 1 : 1] = {};
   if (active) {
     if (xa - 2 >= 0) ldv_o<T, VEC, RAG>(y, off_of(xa - 2), in1.y1, nvalid);
@@ -275,8 +274,8 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       const T up = __shfl_up(y1b_1[VEC - 1], 1, kWave);          // lane 0: no source, its first row is halo
       primal(inner, cb, y1a_1, y1b_1, up, y1a_0, x1_1, in1.gc, p2, x2_1, kt_c);
       if (owner && cb < xb) {
-        stv_o<T, VEC, (VAR & 1) != 0, RAG>(x_out, off_of(cb), x2_1, nvalid);
-        if (kMid) stv_o<T, VEC, (VAR & 1) != 0, RAG>(x_mid, off_of(cb), x1_1, nvalid);
+        stv_o<T, VEC, true, RAG>(x_out, off_of(cb), x2_1, nvalid);
+        if (kMid) stv_o<T, VEC, true, RAG>(x_mid, off_of(cb), x1_1, nvalid);
         if (kRes && (size_t)cb >= a.rx0 && (size_t)cb < a.rx1) {   // dual_residual_transform (backend_pdhg.cu:73-94)
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
@@ -291,8 +290,8 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : ((VAR & 14) ||
       T o1[VEC], o2[VEC];
       dual(inner, c, x2_0, x2_1, x1_0, x1_1, y1a_0, y1b_0, p2, o1, o2, true);
       if (owner) {
-        stv_o<T, VEC, (VAR & 1) != 0, RAG>(y_out, off_of(c), o1, nvalid); stv_o<T, VEC, (VAR & 1) != 0, RAG>(y2out, off_of(c), o2, nvalid);
-        if (kMid) { stv_o<T, VEC, (VAR & 1) != 0, RAG>(y_mid, off_of(c), y1a_0, nvalid); stv_o<T, VEC, (VAR & 1) != 0, RAG>(y2mid, off_of(c), y1b_0, nvalid); }
+        stv_o<T, VEC, true, RAG>(y_out, off_of(c), o1, nvalid); stv_o<T, VEC, true, RAG>(y2out, off_of(c), o2, nvalid);
+        if (kMid) { stv_o<T, VEC, true, RAG>(y_mid, off_of(c), y1a_0, nvalid); stv_o<T, VEC, true, RAG>(y2mid, off_of(c), y1b_0, nvalid); }
       }
     }
     // shift the pipeline by one column
@@ -361,7 +360,6 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   if (out4 && !ws) { set_error("fused double iteration: residuals need the reduction workspace"); return 1; }
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
-  static const int variant = getenv("PROST_HIP_ITER2_VARIANT") ? atoi(getenv("PROST_HIP_ITER2_VARIANT")) : 9;
   if (cols <= 0) {
     // The kernel is bound by wave-level latency as much as by HBM: 3 resident waves per SIMD (<= 168
     // VGPRs) with the loads of three columns in flight per wave beat 4 waves with one (measured same box,
@@ -370,7 +368,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
     // mostly empty round costs a full chunk time (24 cols = 2907 waves 0.117 ms, 18 cols = 3876 waves
     // 0.127 ms, 21 cols 0.133 ms).  Chunk lengths stay off multiples of 16 (HBM channel spread).
     // (the residual instance holds 4 double accumulators and runs 2 waves per SIMD, the others 3)
-    const size_t slots = 256 * 4 * (size_t)(out4 ? 2 : (((variant >> 2) & 3) || x_mid ? 3 : 4));
+    const size_t slots = 256 * 4 * (size_t)(out4 ? 2 : 3);
     cols = 6;
     for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
   }
@@ -396,14 +394,14 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
   const bool rag = d->ny % V != 0;
   double* partial = static_cast<double*>(ws);
-#define GO4(G, F, M, VARv, FASTv, MODEv, RAGv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, VARv, FASTv, MODEv, RAGv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
-#define GO3(G, F, M, VARv, FASTv, MODEv) do { if (rag) GO4(G, F, M, VARv, FASTv, MODEv, true); else GO4(G, F, M, VARv, FASTv, MODEv, false); } while (0)
-#define GO(G, F, M, VARv, FASTv) do { if (mode == 0) GO3(G, F, M, VARv, FASTv, 0); else if (mode == 1) GO3(G, F, M, VARv, FASTv, 1); else if (mode == 2) GO3(G, F, M, VARv, FASTv, 2); else GO3(G, F, M, VARv, FASTv, 3); } while (0)
-  if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 9, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 9, true); }
+#define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
+#define GO3(G, F, M, PFv, FASTv, MODEv) do { if (rag) GO4(G, F, M, PFv, FASTv, MODEv, true); else GO4(G, F, M, PFv, FASTv, MODEv, false); } while (0)
+#define GO(G, F, M, PFv, FASTv) do { if (mode == 0) GO3(G, F, M, PFv, FASTv, 0); else if (mode == 1) GO3(G, F, M, PFv, FASTv, 1); else if (mode == 2) GO3(G, F, M, PFv, FASTv, 2); else GO3(G, F, M, PFv, FASTv, 3); } while (0)
+  if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 3, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 3, true); }
   else if (fast && mask == 0x2) {
-    if (variant == 1) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 9, true);
+    GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 3, true);
   }
-  else if (fast) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0, 9, true);                 // b of prox_g is a scalar too
+  else if (fast) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0, 3, true);                 // b of prox_g is a scalar too
   else if (d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 1, false);
   else if (mask == 0) GO(-1, -1, 0, 1, false);
   else GO(-1, -1, 0x7F, 1, false);
