@@ -294,6 +294,16 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
     // 0.121 ms, 12 or 18 cols 0.102 ms).
     cols = 18;
     while (cols > 6 && strips * ((d->nx + cols - 1) / cols) < 4096) cols -= 6;
+    if (strips * ((d->nx + cols - 1) / cols) < 2048) {
+      // small images: the launch lasts as long as one wave needs for its chunk (c + 1 steps); shortest
+      // chunk that still fits one round of the 4096 wave slots
+      double best = 1e30;
+      for (int c : {6, 4, 3, 2, 1}) {
+        const size_t waves = strips * ((d->nx + c - 1) / c);
+        const double cost = (c + 1.5) * (double)((waves + 4095) / 4096);
+        if (cost < best) { best = cost; cols = c; }
+      }
+    }
   }
   // residual launches write one partial (4 doubles) per wavefront: 2 * kReduceBlocks pairs fit the workspace
   while (out4 && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) cols += 6;

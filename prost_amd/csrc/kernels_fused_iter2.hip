@@ -369,8 +369,19 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
     // 0.127 ms, 21 cols 0.133 ms).  Chunk lengths stay off multiples of 16 (HBM channel spread).
     // (the residual instance holds 4 double accumulators and runs 2 waves per SIMD, the others 3)
     const size_t slots = 256 * 4 * (size_t)(out4 ? 2 : 3);
-    cols = 6;
+    cols = 0;
     for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
+    if (cols == 0) {
+      // small images cannot fill the chip: the launch then lasts as long as ONE wave needs for its chunk
+      // (c + 3 pipeline steps), so the shortest chunk that still fits one round wins (256^2: 1 column
+      // 0.009 ms, 6 columns 0.019 ms; 1024^2: 2-3 columns)
+      double best = 1e30;
+      for (int c : {6, 4, 3, 2, 1}) {
+        const size_t waves = strips * ((d->nx + c - 1) / c);
+        const double cost = (c + 3.5) * (double)((waves + slots - 1) / slots);
+        if (cost < best) { best = cost; cols = c; }
+      }
+    }
   }
   // residual launches write one partial (4 doubles) per wavefront: kReduceBlocks / 2 of them fit the workspace
   while (out4 && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) cols += 6;
