@@ -376,9 +376,9 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
       // (c + 3 pipeline steps), so the shortest chunk that still fits one round wins (256^2: 1 column
       // 0.009 ms, 6 columns 0.019 ms; 1024^2: 2-3 columns)
       double best = 1e30;
-      for (int c : {6, 4, 3, 2, 1}) {
-        const size_t waves = strips * ((d->nx + c - 1) / c);
-        const double cost = (c + 3.5) * (double)((waves + slots - 1) / slots);
+      for (int c : {18, 12, 9, 6, 4, 3, 2, 1}) {
+        const double waves = (double)(strips * ((d->nx + c - 1) / c));
+        const double cost = (c + 3.5) * (waves > (double)slots ? waves / (double)slots : 1.0);
         if (cost < best) { best = cost; cols = c; }
       }
     }
