@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--size", type=int, default=N_IMG, help="image side (default 4096 = the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
+    ap.add_argument("--no-pair", action="store_true", help="one kernel launch per iteration (allow_pair_kernel = false); not the default configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +127,8 @@ def main():
     n = args.size
     prob, u, q, f = synthetic.rof_problem(n, n, lmb=LAMBDA, seed=42 + rank)
     backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA)
+    if args.no_pair:
+        backend[1]["allow_pair_kernel"] = False
     opts = prost.options(max_iters=10 ** 9, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0,
                          tol_abs_primal=0, tol_abs_dual=0)
     solver = prost.Solver(prob, backend, opts)          # uploads f, allocates x/y ping-pong buffers in HBM

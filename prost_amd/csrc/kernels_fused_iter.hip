@@ -36,7 +36,9 @@ struct ColIn {            // everything loaded for one column
 };
 
 // RAG: the image height is not a multiple of VEC (fused_common.hpp, ldv_n / stv_n)
-template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, bool RAG>
+// FAST: straight-line instance for the ROF shape (host-checked: prox_g square with scalar a = 1, d = e = 0,
+// prox_f* ind_leq0 with scalar a = 1, d = e = 0), same forms as kernels_fused_iter2.hip
+template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, bool RAG, bool FAST>
 __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
                                                              const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma, T theta,
@@ -72,6 +74,8 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
   double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
   typedef ColIn<T, VEC, LCH, GMASK, RES> Col;
+  // the residual divisors tau sqrt(T), sigma sqrt(S) are wave-uniform: exact quotients through one double reciprocal each
+  const SharedDivisor<T> div_tauT(tau * sqT), div_sigS(sigma * sqS);
   auto load_col = [&](size_t c, Col& in) {
 #pragma unroll
     for (int l = 0; l < LCH; l++) {
@@ -104,6 +108,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
       if (lane == 0) up = in.up[l];
       T upp = 0;
       if (RES) { upp = __shfl_up(in.p2[RES ? l : 0][RES ? VEC - 1 : 0], 1, kWave); if (lane == 0) upp = in.upp[RES ? l : 0]; }
+      T ktyv[VEC], parg[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         const size_t row = row0 + j;
@@ -112,21 +117,36 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         T divx = (c < nx - 1) ? in.y1[l][j] : (T)0;
         if (have_prev) divx -= prev.y1[l][j];
         const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+        ktyv[j] = kty;
         const T arg = in.x[l][j] - tauT * kty;
-        T cf[7];
+        if (FAST) {
+          parg[j] = arg - (((GMASK >> 1) & 1) ? in.gc[l][slot_of(GMASK, 1)][j] : a.g_val[1]);
+        } else {
+          T cf[7];
 #pragma unroll
-        for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? in.gc[l][slot_of(GMASK, k)][j] : a.g_val[k];
-        if (kUniformG) xn[l][j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
-        else xn[l][j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, cf);
-        if (RES) {                                          // dual_residual_transform (backend_pdhg.cu:73-94)
+          for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? in.gc[l][slot_of(GMASK, k)][j] : a.g_val[k];
+          if (kUniformG) xn[l][j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
+          else xn[l][j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, cf);
+        }
+      }
+      if (FAST) {      // a (v - d tau) = v, fp64 denominator 1: square_prox(v - b) + b, one fallback branch per vector
+        T r[VEC];
+        div_to_float_exact_vec<VEC>(parg, ug.sq, r);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) xn[l][j] = r[j] + (((GMASK >> 1) & 1) ? in.gc[l][slot_of(GMASK, 1)][j] : a.g_val[1]);
+      }
+      if (RES) {                                            // dual_residual_transform (backend_pdhg.cu:73-94)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const size_t row = row0 + j;
           const int jj = RES ? j : 0, ll = RES ? l : 0;
           T dpy = (row < ny - 1) ? in.p2[ll][jj] : (T)0;
           if (row > 0) dpy -= (j > 0 ? in.p2[ll][RES && j > 0 ? j - 1 : 0] : upp);
           T dpx = (c < nx - 1) ? in.p1[ll][jj] : (T)0;
           if (have_prev) dpx -= prev.p1[ll][jj];
           const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
-          const T w_hat = (in.x[l][j] - xn[l][j]) / (tau * sqT) - sqT * ktyp;
-          const T diff = w_hat + sqT * kty;
+          const T w_hat = div_tauT.div(in.x[l][j] - xn[l][j]) - sqT * ktyp;
+          const T diff = w_hat + sqT * ktyv[j];
           if (owner && owned && j < nvalid && c >= a.rx0 && c < a.rx1) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
         }
       }
@@ -177,6 +197,8 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
     }
     if (owner) {
       T out[2 * LCH][VEC];
+      T av[FAST ? 2 * LCH : 1][FAST ? VEC : 1], nv[FAST ? VEC : 1];
+      T kxv[RES ? 2 * LCH : 1][RES ? VEC : 1], kpv[RES ? 2 * LCH : 1][RES ? VEC : 1];
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         const size_t row = row0 + j;
@@ -195,7 +217,15 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         }
 #pragma unroll
         for (int i = 0; i < 2 * LCH; i++) norm += arg[i] * arg[i];
-        if (norm > 0) {
+        if (RES) {
+#pragma unroll
+          for (int i = 0; i < 2 * LCH; i++) { kxv[RES ? i : 0][RES ? j : 0] = kx[i]; kpv[RES ? i : 0][RES ? j : 0] = kp[i]; }
+        }
+        if (FAST) {
+          nv[FAST ? j : 0] = norm;
+#pragma unroll
+          for (int i = 0; i < 2 * LCH; i++) av[FAST ? i : 0][FAST ? j : 0] = arg[i];
+        } else if (norm > 0) {
           norm = t_sqrt(norm);
           const T pr = scaled_prox_u<T, FFN>(a.f_fn, norm, a.f_val, uf);
 #pragma unroll
@@ -204,14 +234,51 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) out[i][j] = 0;
         }
-        if (RES && j < nvalid && c >= a.rx0 && c < a.rx1) { // primal_residual_transform (backend_pdhg.cu:97-120)
+      }
+      if (FAST) {
+        // out = pr v / ||v||, pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0: the short correctly rounded sqrt and
+        // shared-reciprocal division of device_math.hpp for norms in [2^-96, 2^126] (zero handled inline),
+        // the general expansions otherwise; see kernels_fused_iter2.hip
+        constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
+        unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          tmin = min(tmin, (unsigned)__float_as_int((float)nv[FAST ? j : 0]) - 1u);
+          nmax = nv[FAST ? j : 0] > nmax ? nv[FAST ? j : 0] : nmax;
+        }
+        const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
+        if (__builtin_expect(mid, 1)) {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const T nrm = sqrt_midrange(nv[FAST ? j : 0] > (T)kLo ? nv[FAST ? j : 0] : (T)kLo);
+            const T t = nrm - a.f_val[1];
+            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+            const auto r = rcp_refined(nrm);
+#pragma unroll
+            for (int i = 0; i < 2 * LCH; i++) out[i][j] = mul_rcp(pr * av[FAST ? i : 0][FAST ? j : 0], r) + (T)0;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const bool nz = nv[FAST ? j : 0] > 0;
+            const T nrm = nz ? t_sqrt(nv[FAST ? j : 0]) : (T)1;
+            const T t = nrm - a.f_val[1];
+            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+#pragma unroll
+            for (int i = 0; i < 2 * LCH; i++) { const T q = pr * av[FAST ? i : 0][FAST ? j : 0] / nrm; out[i][j] = nz ? q : (T)0; }
+          }
+        }
+      }
+      if (RES && c >= a.rx0 && c < a.rx1) {                // primal_residual_transform (backend_pdhg.cu:97-120)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) {
             const T yo = i < LCH ? cur.y1[i < LCH ? i : 0][j] : cur.y2[i < LCH ? 0 : i - LCH][j];
-            const T z_hat = (yo - out[i][j]) / (sigma * sqS) + sqS * ((1 + theta) * kx[i] - theta * kp[i]);
-            const T diff = z_hat - sqS * kx[i];
-            r_pd += (double)(diff * diff);
-            r_pv += (double)(z_hat * z_hat);
+            const T kxi = kxv[RES ? i : 0][RES ? j : 0], kpi = kpv[RES ? i : 0][RES ? j : 0];
+            const T z_hat = div_sigS.div(yo - out[i][j]) + sqS * ((1 + theta) * kxi - theta * kpi);
+            const T diff = z_hat - sqS * kxi;
+            if (j < nvalid) { r_pd += (double)(diff * diff); r_pv += (double)(z_hat * z_hat); }
           }
         }
       }
@@ -319,14 +386,22 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   // host-side evaluation of everything element-independent, in the kernels' own expression order
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
-  // specialised instance for the ROF shape (square / ind_leq0, only b = f per pixel); generic otherwise
-  const bool fast = d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && mask == 0x2;
-#define GO2(LCHv, G, F, M, R, RAGv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
-#define GO(LCHv, G, F, M, R) do { if (rag) GO2(LCHv, G, F, M, R, true); else GO2(LCHv, G, F, M, R, false); } while (0)
-#define GO_RES(LCHv, G, F, M) do { if (out4) GO(LCHv, G, F, M, true); else GO(LCHv, G, F, M, false); } while (0)
+  // straight-line instance for the ROF shape (square / ind_leq0 with scalar a = 1, d = e = 0 on both sides); run-time
+  // dispatched otherwise
+  bool fast = d->g_fn == PROST_FN_SQUARE && d->f_fn == PROST_FN_IND_LEQ0 && (mask == 0x2 || (mask == 0 && d->L == 1)) &&
+              ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
+#define GO2(LCHv, G, F, M, R, RAGv, FASTv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO(LCHv, G, F, M, R, FASTv) do { if (rag) GO2(LCHv, G, F, M, R, true, FASTv); else GO2(LCHv, G, F, M, R, false, FASTv); } while (0)
+#define GO_RES(LCHv, G, F, M, FASTv) do { if (out4) GO(LCHv, G, F, M, true, FASTv); else GO(LCHv, G, F, M, false, FASTv); } while (0)
   // measured (4096^2 fp32): non-temporal stores +4 %, non-temporal loads -15 %, no register prefetch -8 %
-  if (d->L == 1) { if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(1, -1, -1, 0); else GO_RES(1, -1, -1, 0x7F); }
-  else { if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2); else if (mask == 0) GO_RES(2, -1, -1, 0); else GO_RES(2, -1, -1, 0x7F); }
+  if (d->L == 1) {
+    if (fast && mask == 0x2) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true);
+    else if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0, true);
+    else if (mask == 0) GO_RES(1, -1, -1, 0, false);
+    else GO_RES(1, -1, -1, 0x7F, false);
+  } else {
+    if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true); else if (mask == 0) GO_RES(2, -1, -1, 0, false); else GO_RES(2, -1, -1, 0x7F, false);
+  }
 #undef GO_RES
 #undef GO
 #undef GO2
