@@ -25,10 +25,12 @@ namespace prost_hip {
 // primal pass, gradient2d:  x_new = prox_g(x - tau T K^T y)   [+ dual residual sums]
 // grid: x = row strips, y = column chunks, z = channel l
 // ------------------------------------------------------------------------------------------
-template <class T, int VEC, int GFN, bool RES>
+// FAST: straight-line instance for the ROF shape (host-checked: prox_g square with scalar a = 1, c, d = e = 0; b scalar
+// or per pixel), the exact division of device_math.hpp with one fallback branch per vector (see kernels_fused_iter2.hip)
+template <class T, int VEC, int GFN, bool RES, bool FAST>
 __global__ void __launch_bounds__(kBlock) fused_primal2d_kernel(T* __restrict__ x_new, const T* __restrict__ x,
                                                                 const T* __restrict__ y, const T* __restrict__ y_prev,
-                                                                FusedArgs<T> a, T tau, bool use_kty, bool use_kty_prev,
+                                                                FusedArgs<T> a, T tau, UniformDiv sq, bool use_kty, bool use_kty_prev,
                                                                 double* __restrict__ partial) {
   const size_t nx = a.nx, ny = a.ny;
   const size_t row0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * VEC;
@@ -67,13 +69,14 @@ __global__ void __launch_bounds__(kBlock) fused_primal2d_kernel(T* __restrict__ 
     T upp = 0;
     if (RES) upp = row_above<T, VEC>(yp2c, yp2 + cb, row0, active);
     if (active) {
-      T out[VEC], gc[7][VEC];
+      T out[VEC], gc[FAST ? 1 : 7][VEC], ktyv[VEC], parg[VEC];
 #pragma unroll
       for (int k = 0; k < 7; k++) {       // coefficient k: per-element vector (16-byte load) or scalar
-        if (a.g_ptr[k]) ldv<T, VEC>(a.g_ptr[k] + plane + cb + row0, gc[k]);
+        if (FAST && k != 1) continue;     // the straight-line instance only needs b
+        if (a.g_ptr[k]) ldv<T, VEC>(a.g_ptr[k] + plane + cb + row0, gc[FAST ? 0 : k]);
         else {
 #pragma unroll
-          for (int j = 0; j < VEC; j++) gc[k][j] = a.g_val[k];
+          for (int j = 0; j < VEC; j++) gc[FAST ? 0 : k][j] = a.g_val[k];
         }
       }
 #pragma unroll
@@ -85,19 +88,33 @@ __global__ void __launch_bounds__(kBlock) fused_primal2d_kernel(T* __restrict__ 
         T divx = (xc < nx - 1) ? y1c[j] : (T)0;
         if (xc > 0) divx -= y1p[j];
         const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+        ktyv[j] = kty;
         const T arg = xv[j] - tauT * kty;                                    // backend_pdhg.cu:38-51
-        T c[7];
+        if (FAST) parg[j] = arg - gc[0][j];
+        else {
+          T c[7];
 #pragma unroll
-        for (int k = 0; k < 7; k++) c[k] = gc[k][j];
-        out[j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, c);                        // elem_operation_1d.hpp:36-59
-        if (RES) {                                                             // dual_residual_transform :73-94
+          for (int k = 0; k < 7; k++) c[k] = gc[FAST ? 0 : k][j];
+          out[j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, c);                      // elem_operation_1d.hpp:36-59
+        }
+      }
+      if (FAST) {
+        T r[VEC];
+        div_to_float_exact_vec<VEC>(parg, sq, r);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) out[j] = r[j] + gc[0][j];
+      }
+      if (RES) {                                                               // dual_residual_transform :73-94
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const size_t row = row0 + j;
           T dpy = (row < ny - 1) ? yp2c[j] : (T)0;
           if (row > 0) dpy -= (j > 0 ? yp2c[j > 0 ? j - 1 : 0] : upp);
           T dpx = (xc < nx - 1) ? yp1c[j] : (T)0;
           if (xc > 0) dpx -= yp1p[j];
           const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
           const T w_hat = (xv[j] - out[j]) / (tau * sqT) - sqT * ktyp;
-          const T diff = w_hat + sqT * kty;
+          const T diff = w_hat + sqT * ktyv[j];
           ra += (double)(diff * diff);
           rb += (double)(w_hat * w_hat);
         }
@@ -115,7 +132,9 @@ __global__ void __launch_bounds__(kBlock) fused_primal2d_kernel(T* __restrict__ 
 // [+ primal residual sums].  All L channels of a pixel are coupled by the 2L-dim norm.
 // grid: x = row strips, y = column chunks
 // ------------------------------------------------------------------------------------------
-template <class T, int VEC, int LCH, int FFN, bool RES>
+// FAST: straight-line instance (host-checked: prox_f* ind_leq0 with scalar a = 1, b, d = e = 0): short sqrt / shared-
+// reciprocal division forms of device_math.hpp, see kernels_fused_iter2.hip
+template <class T, int VEC, int LCH, int FFN, bool RES, bool FAST>
 __global__ void __launch_bounds__(kBlock) fused_dual2d_kernel(T* __restrict__ y_new, const T* __restrict__ y,
                                                               const T* __restrict__ xn, const T* __restrict__ xo,
                                                               FusedArgs<T> a, T sigma, T theta, bool use_kx_prev,
@@ -163,13 +182,17 @@ __global__ void __launch_bounds__(kBlock) fused_dual2d_kernel(T* __restrict__ y_
       dno[l] = row_below<T, VEC>(co[l], xo + l * P + cb, row0, ny, active);
     }
     if (active) {
-      T out[2 * LCH][VEC], fc[7][VEC];
+      T out[2 * LCH][VEC], fc[FAST ? 1 : 7][FAST ? 1 : VEC];
+      T av[FAST ? 2 * LCH : 1][FAST ? VEC : 1], nv[FAST ? VEC : 1];
+      T kxv[RES ? 2 * LCH : 1][RES ? VEC : 1], kpv[RES ? 2 * LCH : 1][RES ? VEC : 1];
+      if (!FAST) {
 #pragma unroll
-      for (int k = 0; k < 7; k++) {
-        if (a.f_ptr[k]) ldv<T, VEC>(a.f_ptr[k] + cb + row0, fc[k]);
-        else {
+        for (int k = 0; k < 7; k++) {
+          if (a.f_ptr[k]) ldv<T, FAST ? 1 : VEC>(a.f_ptr[k] + cb + row0, fc[FAST ? 0 : k]);
+          else {
 #pragma unroll
-          for (int j = 0; j < VEC; j++) fc[k][j] = a.f_val[k];
+            for (int j = 0; j < (FAST ? 1 : VEC); j++) fc[FAST ? 0 : k][j] = a.f_val[k];
+          }
         }
       }
 #pragma unroll
@@ -192,11 +215,19 @@ __global__ void __launch_bounds__(kBlock) fused_dual2d_kernel(T* __restrict__ y_
           arg[i] = ya[i][j] + sigS * ((1 + theta) * kx[i] - theta * kxp[i]);   // backend_pdhg.cu:54-70
           norm += arg[i] * arg[i];                                             // elem_operation_norm2.hpp:48-55
         }
-        if (norm > 0) {
+        if (RES) {
+#pragma unroll
+          for (int i = 0; i < 2 * LCH; i++) { kxv[RES ? i : 0][RES ? j : 0] = kx[i]; kpv[RES ? i : 0][RES ? j : 0] = kxp[i]; }
+        }
+        if (FAST) {
+          nv[FAST ? j : 0] = norm;
+#pragma unroll
+          for (int i = 0; i < 2 * LCH; i++) av[FAST ? i : 0][FAST ? j : 0] = arg[i];
+        } else if (norm > 0) {
           norm = t_sqrt(norm);
           T c[7];
 #pragma unroll
-          for (int k = 0; k < 7; k++) c[k] = fc[k][j];
+          for (int k = 0; k < 7; k++) c[k] = fc[FAST ? 0 : k][FAST ? 0 : j];
           const T pr = scaled_prox<T, FFN>(a.f_fn, norm, sigS, c);
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) out[i][j] = pr * arg[i] / norm;
@@ -204,11 +235,46 @@ __global__ void __launch_bounds__(kBlock) fused_dual2d_kernel(T* __restrict__ y_
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) out[i][j] = 0;
         }
-        if (RES) {                                                             // primal_residual_transform :97-120
+      }
+      if (FAST) {
+        constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
+        unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          tmin = min(tmin, (unsigned)__float_as_int((float)nv[FAST ? j : 0]) - 1u);
+          nmax = nv[FAST ? j : 0] > nmax ? nv[FAST ? j : 0] : nmax;
+        }
+        const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
+        if (__builtin_expect(mid, 1)) {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const T nrm = sqrt_midrange(nv[FAST ? j : 0] > (T)kLo ? nv[FAST ? j : 0] : (T)kLo);
+            const T t = nrm - a.f_val[1];
+            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+            const auto r = rcp_refined(nrm);
+#pragma unroll
+            for (int i = 0; i < 2 * LCH; i++) out[i][j] = mul_rcp(pr * av[FAST ? i : 0][FAST ? j : 0], r) + (T)0;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const bool nz = nv[FAST ? j : 0] > 0;
+            const T nrm = nz ? t_sqrt(nv[FAST ? j : 0]) : (T)1;
+            const T t = nrm - a.f_val[1];
+            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+#pragma unroll
+            for (int i = 0; i < 2 * LCH; i++) { const T q = pr * av[FAST ? i : 0][FAST ? j : 0] / nrm; out[i][j] = nz ? q : (T)0; }
+          }
+        }
+      }
+      if (RES) {                                                               // primal_residual_transform :97-120
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) {
-            const T z_hat = (ya[i][j] - out[i][j]) / (sigma * sqS) + sqS * ((1 + theta) * kx[i] - theta * kxp[i]);
-            const T diff = z_hat - sqS * kx[i];
+            const T kxi = kxv[RES ? i : 0][RES ? j : 0], kpi = kpv[RES ? i : 0][RES ? j : 0];
+            const T z_hat = (ya[i][j] - out[i][j]) / (sigma * sqS) + sqS * ((1 + theta) * kxi - theta * kpi);
+            const T diff = z_hat - sqS * kxi;
             ra += (double)(diff * diff);
             rb += (double)(z_hat * z_hat);
           }
@@ -288,13 +354,18 @@ static int run_primal(const prost_hip_fused_desc* d, T* x_new, const T* x, const
   dim3 grid((unsigned)rb, (unsigned)((d->nx + a.cols_per_block - 1) / a.cols_per_block), (unsigned)d->L), block(kBlock);
   hipStream_t s = as_stream(stream);
   double* partial = static_cast<double*>(ws);
-  const bool fast = (d->g_fn == PROST_FN_SQUARE);
-#define GO(VECv, GFNv, RESv) hipLaunchKernelGGL((fused_primal2d_kernel<T, VECv, GFNv, RESv>), grid, block, 0, s, x_new, x, y, y_prev, a, (T)tau, use_kty != 0, use_kty_prev != 0, partial)
+  const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
+  bool coeff_vec_other = false;
+  for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k] && k != 1) coeff_vec_other = true;
+  // straight-line instance: square with scalar a = 1, c != 0, d = e = 0 (b scalar or per pixel)
+  const bool fast = d->g_fn == PROST_FN_SQUARE && !coeff_vec_other && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0;
+#define GO(VECv, GFNv, RESv, FASTv) hipLaunchKernelGGL((fused_primal2d_kernel<T, VECv, GFNv, RESv, FASTv>), grid, block, 0, s, x_new, x, y, y_prev, a, (T)tau, ug.sq, use_kty != 0, use_kty_prev != 0, partial)
   if (vec) {
-    if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_SQUARE, true); else GO(VecOf<T>::N, PROST_FN_SQUARE, false); }
-    else { if (out2) GO(VecOf<T>::N, -1, true); else GO(VecOf<T>::N, -1, false); }
+    if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_SQUARE, true, true); else GO(VecOf<T>::N, PROST_FN_SQUARE, false, true); }
+    else if (d->g_fn == PROST_FN_SQUARE) { if (out2) GO(VecOf<T>::N, PROST_FN_SQUARE, true, false); else GO(VecOf<T>::N, PROST_FN_SQUARE, false, false); }
+    else { if (out2) GO(VecOf<T>::N, -1, true, false); else GO(VecOf<T>::N, -1, false, false); }
   } else {
-    if (out2) GO(1, -1, true); else GO(1, -1, false);
+    if (out2) GO(1, -1, true, false); else GO(1, -1, false, false);
   }
 #undef GO
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused primal pass"); }
@@ -313,13 +384,17 @@ static int run_dual_l(const prost_hip_fused_desc* d, T* y_new, const T* y, const
   dim3 grid((unsigned)rb, (unsigned)((d->nx + a.cols_per_block - 1) / a.cols_per_block), 1), block(kBlock);
   hipStream_t s = as_stream(stream);
   double* partial = static_cast<double*>(ws);
-  const bool fast = (d->f_fn == PROST_FN_IND_LEQ0);
-#define GO(VECv, FFNv, RESv) hipLaunchKernelGGL((fused_dual2d_kernel<T, VECv, LCH, FFNv, RESv>), grid, block, 0, s, y_new, y, xn, xo, a, (T)sigma, (T)theta, use_kx_prev != 0, partial)
+  bool f_vec = false;
+  for (int k = 0; k < 7; k++) if (d->f_coeff_ptr[k]) f_vec = true;
+  // straight-line instance: ind_leq0 with scalar coefficients a = 1, d = e = 0
+  const bool fast = d->f_fn == PROST_FN_IND_LEQ0 && !f_vec && a.f_val[0] == (T)1 && a.f_val[3] == (T)0 && a.f_val[4] == (T)0;
+#define GO(VECv, FFNv, RESv, FASTv) hipLaunchKernelGGL((fused_dual2d_kernel<T, VECv, LCH, FFNv, RESv, FASTv>), grid, block, 0, s, y_new, y, xn, xo, a, (T)sigma, (T)theta, use_kx_prev != 0, partial)
   if (vec) {
-    if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_IND_LEQ0, true); else GO(VecOf<T>::N, PROST_FN_IND_LEQ0, false); }
-    else { if (out2) GO(VecOf<T>::N, -1, true); else GO(VecOf<T>::N, -1, false); }
+    if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_IND_LEQ0, true, true); else GO(VecOf<T>::N, PROST_FN_IND_LEQ0, false, true); }
+    else if (d->f_fn == PROST_FN_IND_LEQ0) { if (out2) GO(VecOf<T>::N, PROST_FN_IND_LEQ0, true, false); else GO(VecOf<T>::N, PROST_FN_IND_LEQ0, false, false); }
+    else { if (out2) GO(VecOf<T>::N, -1, true, false); else GO(VecOf<T>::N, -1, false, false); }
   } else {
-    if (out2) GO(1, -1, true); else GO(1, -1, false);
+    if (out2) GO(1, -1, true, false); else GO(1, -1, false, false);
   }
 #undef GO
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused dual pass"); }
