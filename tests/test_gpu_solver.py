@@ -434,3 +434,21 @@ def test_fullsize_4096_pair_launches_equal_single_launches():
         assert states[True][v] == states[False][v]
     for v in ("primal_res", "dual_res"):
         assert np.isclose(states[True][v], states[False][v], rtol=1e-6)
+
+
+@pytest.mark.parametrize("prec,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", ["alg2", "boyd"])
+def test_pair_kernel_convergence_stop_is_identical(prec, dtype, step):
+    """prost.solve stopping on the residual criterion: the run with pair launches stops at the same iteration
+    with the same x, y and constraint variables z, w (rebuilt previous iterate) as the run without"""
+    prost.set_precision(prec)
+    out = {}
+    for pair in (True, False):
+        prob, u, q, f = synthetic.rof_problem(40, 36, seed=8)
+        b = prost.backend.pdhg(stepsize=step, residual_iter=6, alg2_gamma=0.5)
+        b[1]["allow_pair_kernel"] = pair
+        o = prost.options(max_iters=5000, num_cback_calls=3, verbose=False, tol_rel_primal=2e-3, tol_rel_dual=2e-3, tol_abs_primal=2e-3, tol_abs_dual=2e-3)
+        out[pair] = prost.solve(prob, b, o)
+    assert out[True]["iters"] == out[False]["iters"] and out[True]["iters"] < 5000 and out[True]["result"] == out[False]["result"]
+    for v in "xyzw":
+        assert np.array_equal(np.asarray(out[True][v]), np.asarray(out[False][v])), v
