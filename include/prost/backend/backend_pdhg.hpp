@@ -83,6 +83,9 @@ class BackendPDHG : public Backend<T> {
   size_t owned_x0_ = 0, owned_x1_ = 0;
   T stale_tau_ = 0, stale_sigma_ = 0, stale_theta_ = 0;   // step sizes of that iteration k
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
+  /// where the reduction kernels put the four sums: the pinned (device-visible) host buffer, or the device
+  /// buffer when an RCCL all-reduce has to run on them first
+  double* res_target() { return this->comm_ ? res_dev_ : res_host_; }
   double* res_host_;       // pinned
   void* workspace_;
   T tau_, sigma_, theta_;

@@ -193,14 +193,14 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
   const bool t = BeginSample(store_mid ? (residuals ? kKernelPairMidRes : kKernelPairMid) : (residuals ? kKernelPairRes : kKernelPair));
   if (!store_mid) {
     CheckHip(Api<T>::fused_iteration2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
-                                      residuals ? res_dev_ : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
+                                      residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
     EndSample(t);
     x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
     y_.swap(y_prev_);
     prev_stale_ = true;
   } else {
     CheckHip(Api<T>::fused_iteration2(&desc_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
-                                      theta, 0, residuals ? res_dev_ : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
+                                      theta, 0, residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
     EndSample(t);
     x_.swap(x_spare_);       // x_ = x^(k+2), x_prev_ = x^(k+1): the state two single launches leave
     y_.swap(y_spare_);
@@ -238,7 +238,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
     const bool t = BeginSample(res ? kKernelIterRes : kKernelIter);
     CheckHip(Api<T>::fused_iteration(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_,
                                      (double)sigma_, (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0,
-                                     iteration_ >= 2 ? 1 : 0, 0, res ? res_dev_ : nullptr, res ? workspace_ : nullptr, s), "fused_iteration");
+                                     iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration");
     EndSample(t);
     x_.swap(x_prev_);
     if (res) { y_prev_.swap(y_spare_); }     // y_prev_ now holds y^(k+1); swapped into y_ below
@@ -251,13 +251,13 @@ void BackendPDHG<T>::IterationFused(bool res) {
   }
   bool t = BeginSample(kKernelPrimal);
   CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
-                                iteration_ >= 2 ? 1 : 0, res ? res_dev_ + 2 : nullptr, workspace_, s), "fused_primal");
+                                iteration_ >= 2 ? 1 : 0, res ? res_target() + 2 : nullptr, workspace_, s), "fused_primal");
   EndSample(t);
   x_.swap(x_prev_);                        // x_ = x^(k+1), x_prev_ = x^k       (:334)
   // kx_prev_ of the reference is K x^k except at k = 0 (zero vector, :216)
   t = BeginSample(kKernelDual);
   CheckHip(Api<T>::fused_dual(&desc_, y_prev_.data(), y_.data(), x_.data(), x_prev_.data(), (double)sigma_, (double)theta_,
-                              iteration_ >= 1 ? 1 : 0, res ? res_dev_ : nullptr, workspace_, s), "fused_dual");
+                              iteration_ >= 1 ? 1 : 0, res ? res_target() : nullptr, workspace_, s), "fused_dual");
   EndSample(t);
   y_.swap(y_prev_);                        // y_ = y^(k+1), y_prev_ = y^k       (:366)
   if (res) FinishResiduals();
@@ -280,8 +280,8 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   y_.swap(y_prev_);
   for (auto& p : prox_fstar_) p->Eval(y_, temp_, Sl, sigma_);
   if (res) {                                                                                                   // :392-431
-    CheckHip(Api<T>::pdhg_residual_primal(res_dev_, y_prev_.data(), y_.data(), Sl.data(), kx_prev_.data(), kx_.data(), (double)sigma_, (double)theta_, m, workspace_, s), "residual_primal");
-    CheckHip(Api<T>::pdhg_residual_dual(res_dev_ + 2, x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), kty_.data(), (double)tau_, n, workspace_, s), "residual_dual");
+    CheckHip(Api<T>::pdhg_residual_primal(res_target(), y_prev_.data(), y_.data(), Sl.data(), kx_prev_.data(), kx_.data(), (double)sigma_, (double)theta_, m, workspace_, s), "residual_primal");
+    CheckHip(Api<T>::pdhg_residual_dual(res_target() + 2, x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), kty_.data(), (double)tau_, n, workspace_, s), "residual_dual");
     FinishResiduals();
   }
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
@@ -293,8 +293,12 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
 template <typename T>
 void BackendPDHG<T>::FinishResiduals() {
   void* s = CurrentStream();
-  if (this->comm_) CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
-  CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), s), "memcpy_d2h");
+  // without a communicator the reduction kernels wrote the four sums straight into the pinned host buffer
+  // (device-visible): no D2H copy, the stream synchronisation below is all that is needed
+  if (this->comm_) {
+    CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
+    CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), s), "memcpy_d2h");
+  }
   CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   // the reference reduces in T and takes std::sqrt of the T sums (:433-436)
