@@ -198,12 +198,17 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(n, threads)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
 
     solver.destroy()
     if multi:
         prost.comm_destroy()
         dist.destroy_process_group()
+    if out is not None:
+        # the ONE JSON line, last thing on stdout (RCCL prints its version banner while the communicators are created)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
