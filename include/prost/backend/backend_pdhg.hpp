@@ -55,6 +55,12 @@ class BackendPDHG : public Backend<T> {
   T* y_data() { return y_.data(); }
   bool single_kernel_path() const { return single_kernel_; }
 
+  // residual accessors pick up sums that are still in flight (see FinishResiduals)
+  virtual T primal_residual() const { const_cast<BackendPDHG<T>*>(this)->ResolveResiduals(); return this->primal_residual_; }
+  virtual T dual_residual() const { const_cast<BackendPDHG<T>*>(this)->ResolveResiduals(); return this->dual_residual_; }
+  virtual T primal_var_norm() const { const_cast<BackendPDHG<T>*>(this)->ResolveResiduals(); return this->primal_var_norm_; }
+  virtual T dual_var_norm() const { const_cast<BackendPDHG<T>*>(this)->ResolveResiduals(); return this->dual_var_norm_; }
+
   T tau() const { return tau_; }
   T sigma() const { return sigma_; }
   T theta() const { return theta_; }
@@ -67,7 +73,8 @@ class BackendPDHG : public Backend<T> {
   void IterationPair(bool store_mid, bool residuals);   // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
   void RebuildPrevious();                 // x_prev_ / y_prev_ := x^(k-1) / y^(k-1) after a pair that did not store them
   bool is_residual_iteration(size_t k) const { return k == 0 || (k % (size_t)opts_.residual_iter) == 0; }   // backend_pdhg.cu:389
-  void FinishResiduals();                 // all-reduce, D2H, sqrt, step-size rules (backend_pdhg.cu:433-476)
+  void FinishResiduals();                 // all-reduce + D2H enqueued; resolved at once only for residual-driven step rules
+  void ResolveResiduals();                // wait, sqrt, step-size rules (backend_pdhg.cu:433-476)
   void UpdateAlg2();                      // :483-488
 
   Options opts_;
@@ -80,6 +87,7 @@ class BackendPDHG : public Backend<T> {
   // after a pair launch that kept x^(k+1), y^(k+1) in registers, x_prev_ / y_prev_ still hold the pair's
   // INPUT x^k, y^k; whoever needs the true previous iterate first re-runs iteration k from them
   bool prev_stale_ = false;
+  bool residuals_pending_ = false;   // four sums enqueued (device -> pinned host), not yet waited for
   size_t owned_x0_ = 0, owned_x1_ = 0;
   T stale_tau_ = 0, stale_sigma_ = 0, stale_theta_ = 0;   // step sizes of that iteration k
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)

@@ -77,6 +77,7 @@ void BackendPDHG<T>::Initialize() {
 
   iteration_ = 0;
   prev_stale_ = false;
+  residuals_pending_ = false;
   tau_ = (T)opts_.tau0;
   sigma_ = (T)opts_.sigma0;
   theta_ = 1;
@@ -290,16 +291,29 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   this->problem_->linop()->EvalAdjoint(kty_, y_);                                                              // :377-380
 }
 
+/// Residual iteration, device side done: all-reduce the four sums if there is a communicator and bring them
+/// to the host.  The residual-driven step rules (goldstein, boyd) need the values before the next launch;
+/// alg1 / alg2 do not, so there the host does NOT wait: the sums are picked up (ResolveResiduals) when
+/// somebody asks for a residual -- Solver::Solve after every iteration (same behaviour as before),
+/// Solver::Iterate never, solver_state / current_solution at the end.
 template <typename T>
 void BackendPDHG<T>::FinishResiduals() {
   void* s = CurrentStream();
   // without a communicator the reduction kernels wrote the four sums straight into the pinned host buffer
-  // (device-visible): no D2H copy, the stream synchronisation below is all that is needed
+  // (device-visible): no D2H copy, a stream synchronisation is all that is needed before reading them
   if (this->comm_) {
     CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
     CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), s), "memcpy_d2h");
   }
-  CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");
+  residuals_pending_ = true;
+  if (opts_.stepsize_variant == kPDHGStepsResidualGoldstein || opts_.stepsize_variant == kPDHGStepsResidualBoyd) ResolveResiduals();
+}
+
+template <typename T>
+void BackendPDHG<T>::ResolveResiduals() {
+  if (!residuals_pending_) return;
+  residuals_pending_ = false;
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   // the reference reduces in T and takes std::sqrt of the T sums (:433-436)
   this->primal_residual_ = std::sqrt((T)res_host_[0]);
