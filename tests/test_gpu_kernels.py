@@ -280,7 +280,7 @@ def test_fused_passes_match_unfused_oracle(hip, dtype, shape, fns):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(16, 12, 1), (40, 1028, 1), (33, 256, 2), (70, 252, 1), (5, 2052, 2), (64, 64, 1), (2, 4, 1),
                                    (16, 13, 1), (40, 1030, 1), (33, 255, 2), (70, 250, 1), (9, 501, 1), (3, 5, 2)])
-@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "ind_leq0"), ("abs", "huber")])
 def test_single_kernel_iteration_equals_two_passes(hip, dtype, shape, fns):
     """prost_hip_fused_iteration (7 floats/pixel) == fused_primal + fused_dual (11 floats/pixel), bit for bit,
     for every column-chunk size (halo columns) and the iteration-0 flags"""
