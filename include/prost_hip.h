@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define PROST_HIP_ABI_VERSION 1
+/* 2: prost_hip_fused_desc gained res_x0 / res_x1; fused_iteration2, comm send/recv, wrapper proxes, Kronecker blocks */
+#define PROST_HIP_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
