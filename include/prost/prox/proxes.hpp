@@ -23,6 +23,8 @@ class ProxElemOperation : public ProxSeparableSum<T> {
   virtual bool describe(ProxDesc& d) const;
   int op() const { return op_; }
   int fn() const { return fn_; }
+  /// prox of the conjugate (Moreau) of this elem operation in one fused pass; same ranges as EvalLocal
+  void EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau);
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
@@ -35,6 +37,8 @@ class ProxElemOperation : public ProxSeparableSum<T> {
 template <typename T>
 class ProxMoreau : public Prox<T> {
  public:
+  /// MI355X addition: a conjugated elem operation runs as ONE kernel (default on)
+  static void SetFuseElemOperations(bool on);
   explicit ProxMoreau(shared_ptr<Prox<T>> conjugate) : Prox<T>(*conjugate), conjugate_(conjugate) {}
   virtual void Initialize();
   virtual void Release();

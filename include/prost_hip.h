@@ -127,6 +127,14 @@ int prost_hip_prox_elem_f32(int op, int fn, float* res, const float* arg, const 
                             size_t count, size_t dim, int interleaved, const float* const* coeff_ptr, const double* coeff_val, void* stream);
 int prost_hip_prox_elem_f64(int op, int fn, double* res, const double* arg, const double* tau_diag, double tau, int invert_tau,
                             size_t count, size_t dim, int interleaved, const double* const* coeff_ptr, const double* coeff_val, void* stream);
+/* The prox of the CONJUGATE of the same elem operation in one pass: ProxMoreau::EvalLocal (src/prox/prox_moreau.cu:98-134)
+ * = MoreauPrescale (:29-43) + the elem operation with the inverted step flag + MoreauPostscale (:45-61), bit-identical
+ * to prost_hip_moreau_prescale + prost_hip_prox_elem(!invert_tau) + prost_hip_moreau_postscale; 3 instead of 9 values
+ * per element through HBM.  invert_tau is the flag the Moreau wrapper itself is called with. */
+int prost_hip_prox_elem_moreau_f32(int op, int fn, float* res, const float* arg, const float* tau_diag, double tau, int invert_tau,
+                                   size_t count, size_t dim, int interleaved, const float* const* coeff_ptr, const double* coeff_val, void* stream);
+int prost_hip_prox_elem_moreau_f64(int op, int fn, double* res, const double* arg, const double* tau_diag, double tau, int invert_tau,
+                                   size_t count, size_t dim, int interleaved, const double* const* coeff_ptr, const double* coeff_val, void* stream);
 /* ProxIndEpiQuadKernel (src/prox/prox_ind_epi_quad.cu:42-79) + helper::ProjectEpiQuadNd
  * (include/prost/prox/helper.hpp:44-105).  a_ptr/c_ptr NULL -> scalar a_val/c_val. */
 int prost_hip_prox_epi_quad_f32(float* res, const float* arg, size_t count, size_t dim, const float* a_ptr, double a_val, const float* b_ptr, const float* c_ptr, double c_val, void* stream);

@@ -782,6 +782,7 @@ void cmd_set_quirks(CMD_ARGS) {
   (void)nlhs; (void)plhs;
   if (nrhs < 1) throw Exception("set_quirks: struct required.");
   if (prost_value_field(prhs[0], "diags_adjoint_grid")) BlockDiags<double>::SetReferenceGridQuirk(GetScalarFromField(prhs[0], "diags_adjoint_grid") > 0);
+  if (prost_value_field(prhs[0], "fuse_moreau")) { const bool on = GetScalarFromField(prhs[0], "fuse_moreau") > 0; ProxMoreau<float>::SetFuseElemOperations(on); ProxMoreau<double>::SetFuseElemOperations(on); }
   if (prost_value_field(prhs[0], "dual_negate_float")) DualLinearOperator<double>::SetReferenceNegateQuirk(GetScalarFromField(prhs[0], "dual_negate_float") > 0);
 }
 

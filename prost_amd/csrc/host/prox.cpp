@@ -76,15 +76,35 @@ void ProxElemOperation<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T
   CheckHip(Api<T>::prox_elem(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
                              this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem");
 }
+template <typename T>
+void ProxElemOperation<T>::EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau) {
+  const T* ptrs[7]; double vals[7];
+  for (int i = 0; i < 7; i++) {
+    if (coeffs_[i].size() > 1) {
+      if (d_coeffs_[i].size() != coeffs_[i].size()) throw Exception("ProxElemOperation used before Initialize().");
+      ptrs[i] = d_coeffs_[i].data(); vals[i] = 0;
+    } else { ptrs[i] = nullptr; vals[i] = (double)coeffs_[i][0]; }
+  }
+  CheckHip(Api<T>::prox_elem_moreau(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
+                                    this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem_moreau");
+}
 template class ProxElemOperation<float>;
 template class ProxElemOperation<double>;
 
 // ---- Moreau ----
 template <typename T> void ProxMoreau<T>::Initialize() { scaled_arg_.resize(this->size_); conjugate_->Initialize(); }
 template <typename T> void ProxMoreau<T>::Release() { conjugate_->Release(); scaled_arg_.clear(); }
+static bool g_moreau_fuse = true;
+template <typename T> void ProxMoreau<T>::SetFuseElemOperations(bool on) { g_moreau_fuse = on; }
 template <typename T>
 void ProxMoreau<T>::EvalLocal(T* res, T* res_end, const T* arg, const T* arg_end, const T* tau_diag, const T* tau_end, T tau, bool invert_tau) {
   const size_t n = this->size_;
+  if (g_moreau_fuse && res != arg) {
+    if (auto* e = dynamic_cast<ProxElemOperation<T>*>(conjugate_.get())) {        // pre-scale, elem operation and post-scale in one kernel
+      e->EvalMoreauLocal(res, arg, tau_diag, tau, invert_tau);
+      return;
+    }
+  }
   CheckHip(Api<T>::moreau_prescale(scaled_arg_.data(), arg, tau_diag, (double)tau, invert_tau ? 1 : 0, n, CurrentStream()), "moreau_prescale");
   conjugate_->EvalLocal(res, res_end, scaled_arg_.data(), scaled_arg_.data() + n, tau_diag, tau_end, tau, !invert_tau);
   CheckHip(Api<T>::moreau_postscale(res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, n, CurrentStream()), "moreau_postscale");

@@ -15,31 +15,50 @@ struct Coeffs {
   T val[7];
 };
 
-template <class T, int OP>
+// MOREAU: the prox of the CONJUGATE in the same pass (ProxMoreau::EvalLocal, prox_moreau.cu:98-134, around an
+// elem operation): arg is pre-scaled per element (MoreauPrescale :29-43), the elem operation runs with the inverted
+// step, and the result is post-scaled (MoreauPostscale :45-61) -- 3 values per element through HBM instead of 9.
+// `invert_tau` is then the flag the Moreau wrapper itself was called with.
+template <class T> __device__ __forceinline__ T moreau_pre(T a, T tau, T td, bool inv) { return inv ? a * (tau * td) : a / (tau * td); }
+template <class T> __device__ __forceinline__ T moreau_post(T a, T r, T tau, T td, bool inv) { return inv ? a - r / (tau * td) : a - tau * td * r; }
+
+template <class T, int OP, bool MOREAU>
 __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, const T* __restrict__ arg,
                                                            const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                            size_t count, size_t dim, bool interleaved, int fn, Coeffs<T> cf) {
+  const bool inner_inv = MOREAU ? !invert_tau : invert_tau;      // step flag the elem operation sees
   for (size_t tx = (size_t)blockIdx.x * kBlock + threadIdx.x; tx < count; tx += (size_t)gridDim.x * kBlock) {
     T c[7];
 #pragma unroll
     for (int i = 0; i < 7; i++) c[i] = cf.ptr[i] ? cf.ptr[i][tx] : cf.val[i];
     if (OP == PROST_OP_1D) {
       // Vector index with dim = 1: both layouts give tx (vector.hpp:44-48)
-      const T tau = elem_tau<T>(tau_scal, tau_diag[tx], invert_tau);
-      res[tx] = elem_1d<T>(fn, arg[tx], tau, c);
+      const T td = tau_diag[tx], a = arg[tx];
+      const T tau = elem_tau<T>(tau_scal, td, inner_inv);
+      const T r = elem_1d<T>(fn, MOREAU ? moreau_pre<T>(a, tau_scal, td, invert_tau) : a, tau, c);
+      res[tx] = MOREAU ? moreau_post<T>(a, r, tau_scal, td, invert_tau) : r;
     } else {
       // ElemOperationNorm2 (elem_operation_norm2.hpp:40-88)
       const size_t base = interleaved ? tx * dim : tx;
       const size_t stride = interleaved ? 1 : count;
       T norm = 0;
-      for (size_t i = 0; i < dim; i++) { const T v = arg[base + i * stride]; norm += v * v; }
+      for (size_t i = 0; i < dim; i++) {
+        T v = arg[base + i * stride];
+        if (MOREAU) v = moreau_pre<T>(v, tau_scal, tau_diag[base + i * stride], invert_tau);
+        norm += v * v;
+      }
+      T pr = 0;
       if (norm > 0) {
         norm = t_sqrt(norm);
-        const T tau = elem_tau<T>(tau_scal, tau_diag[base], invert_tau);   // tau_diag[0] only (:61)
-        const T pr = scaled_prox<T>(fn, norm, tau, c);
-        for (size_t i = 0; i < dim; i++) res[base + i * stride] = pr * arg[base + i * stride] / norm;
-      } else {
-        for (size_t i = 0; i < dim; i++) res[base + i * stride] = 0;
+        const T tau = elem_tau<T>(tau_scal, tau_diag[base], inner_inv);   // tau_diag[0] only (:61)
+        pr = scaled_prox<T>(fn, norm, tau, c);
+      }
+      for (size_t i = 0; i < dim; i++) {
+        const T a = arg[base + i * stride];
+        const T td = MOREAU ? tau_diag[base + i * stride] : (T)0;
+        const T v = MOREAU ? moreau_pre<T>(a, tau_scal, td, invert_tau) : a;
+        const T r = norm > 0 ? pr * v / norm : (T)0;
+        res[base + i * stride] = MOREAU ? moreau_post<T>(a, r, tau_scal, td, invert_tau) : r;
       }
     }
   }
@@ -49,7 +68,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
 // consecutive elements per component (float4 / double2), so every access of a wave is one 1-KiB
 // transaction and the per-element coefficient vectors are read with the same width.  DIM > 0 keeps
 // the components in registers; DIM == 0 (any dimension) makes a second pass over arg (L2 hits).
-template <class T, int OP, int DIM>
+template <class T, int OP, int DIM, bool MOREAU>
 __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ res, const T* __restrict__ arg,
                                                                const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                                size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one) {
@@ -66,6 +85,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
       }
     }
     ldv<T, VEC>(tau_diag + t0, td);
+    const bool inner_inv = MOREAU ? !invert_tau : invert_tau;
     if (OP == PROST_OP_1D) {
       T a[VEC], out[VEC];
       ldv<T, VEC>(arg + t0, a);
@@ -74,26 +94,40 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
         T cc[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) cc[k] = c[k][j];
-        out[j] = elem_1d_flags<T>(fn, a[j], elem_tau<T>(tau_scal, td[j], invert_tau), cc, e_zero, a_one);
+        const T r = elem_1d_flags<T>(fn, MOREAU ? moreau_pre<T>(a[j], tau_scal, td[j], invert_tau) : a[j], elem_tau<T>(tau_scal, td[j], inner_inv), cc, e_zero, a_one);
+        out[j] = MOREAU ? moreau_post<T>(a[j], r, tau_scal, td[j], invert_tau) : r;
       }
       stv<T, VEC>(res + t0, out);
     } else {
-      T v[D][VEC], norm[VEC], scale[VEC];
+      T v[D][VEC], tdv[MOREAU ? D : 1][VEC], norm[VEC], scale[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; j++) norm[j] = 0;
       if (DIM > 0) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
           ldv<T, VEC>(arg + t0 + (size_t)i * count, v[i]);
+          if (MOREAU) {
+            if (i == 0) {
 #pragma unroll
-          for (int j = 0; j < VEC; j++) norm[j] += v[i][j] * v[i][j];
+              for (int j = 0; j < VEC; j++) tdv[0][j] = td[j];
+            } else ldv<T, VEC>(tau_diag + t0 + (size_t)i * count, tdv[MOREAU ? i : 0]);
+          }
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const T sv = MOREAU ? moreau_pre<T>(v[i][j], tau_scal, tdv[MOREAU ? i : 0][j], invert_tau) : v[i][j];
+            norm[j] += sv * sv;
+          }
         }
       } else {
         for (size_t i = 0; i < dim; i++) {
-          T w[VEC];
+          T w[VEC], tw[VEC];
           ldv<T, VEC>(arg + t0 + i * count, w);
+          if (MOREAU) ldv<T, VEC>(tau_diag + t0 + i * count, tw);
 #pragma unroll
-          for (int j = 0; j < VEC; j++) norm[j] += w[j] * w[j];
+          for (int j = 0; j < VEC; j++) {
+            const T sv = MOREAU ? moreau_pre<T>(w[j], tau_scal, tw[j], invert_tau) : w[j];
+            norm[j] += sv * sv;
+          }
         }
       }
       bool pos[VEC];
@@ -106,7 +140,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
           T cc[7];
 #pragma unroll
           for (int k = 0; k < 7; k++) cc[k] = c[k][j];
-          scale[j] = scaled_prox_flags<T>(fn, norm[j], elem_tau<T>(tau_scal, td[j], invert_tau), cc, e_zero, a_one);
+          scale[j] = scaled_prox_flags<T>(fn, norm[j], elem_tau<T>(tau_scal, td[j], inner_inv), cc, e_zero, a_one);
         }
       }
       if (DIM > 0) {
@@ -114,15 +148,26 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
         for (int i = 0; i < D; i++) {
           T out[VEC];
 #pragma unroll
-          for (int j = 0; j < VEC; j++) out[j] = pos[j] ? scale[j] * v[i][j] / norm[j] : (T)0;
+          for (int j = 0; j < VEC; j++) {
+            const T tdi = MOREAU ? tdv[MOREAU ? i : 0][j] : (T)0;
+            const T sv = MOREAU ? moreau_pre<T>(v[i][j], tau_scal, tdi, invert_tau) : v[i][j];
+            const T r = pos[j] ? scale[j] * sv / norm[j] : (T)0;
+            out[j] = MOREAU ? moreau_post<T>(v[i][j], r, tau_scal, tdi, invert_tau) : r;
+          }
           stv<T, VEC>(res + t0 + (size_t)i * count, out);
         }
       } else {
         for (size_t i = 0; i < dim; i++) {
-          T w[VEC], out[VEC];
+          T w[VEC], tw[VEC], out[VEC];
           ldv<T, VEC>(arg + t0 + i * count, w);
+          if (MOREAU) ldv<T, VEC>(tau_diag + t0 + i * count, tw);
 #pragma unroll
-          for (int j = 0; j < VEC; j++) out[j] = pos[j] ? scale[j] * w[j] / norm[j] : (T)0;
+          for (int j = 0; j < VEC; j++) {
+            const T tdi = MOREAU ? tw[j] : (T)0;
+            const T sv = MOREAU ? moreau_pre<T>(w[j], tau_scal, tdi, invert_tau) : w[j];
+            const T r = pos[j] ? scale[j] * sv / norm[j] : (T)0;
+            out[j] = MOREAU ? moreau_post<T>(w[j], r, tau_scal, tdi, invert_tau) : r;
+          }
           stv<T, VEC>(res + t0 + i * count, out);
         }
       }
@@ -130,7 +175,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
   }
 }
 
-template <class T>
+template <class T, bool MOREAU>
 static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_diag, double tau, int invert, size_t count,
                             size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
   if (fn < 0 || fn >= PROST_FN_COUNT) { set_error("prox_elem: unknown function id"); return 1; }
@@ -145,7 +190,7 @@ static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_d
   if (vec) {
     const bool e_zero = !cf.ptr[4] && cf.val[4] == (T)0, a_one = !cf.ptr[0] && cf.val[0] == (T)1;
     dim3 g(grid_for(count / V)), b(kBlock);
-#define GO(OPv, DIMv) hipLaunchKernelGGL((prox_elem_vec_kernel<T, OPv, DIMv>), g, b, 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, fn, cf, e_zero, a_one)
+#define GO(OPv, DIMv) hipLaunchKernelGGL((prox_elem_vec_kernel<T, OPv, DIMv, MOREAU>), g, b, 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, fn, cf, e_zero, a_one)
     if (op == PROST_OP_1D) GO(PROST_OP_1D, 1);
     else if (dim == 1) GO(PROST_OP_NORM2, 1);
     else if (dim == 2) GO(PROST_OP_NORM2, 2);
@@ -156,9 +201,9 @@ static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_d
     PH_LAUNCH_END("prox_elem kernel");
   }
   if (op == PROST_OP_1D)
-    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_1D>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, (size_t)1, interleaved != 0, fn, cf);
+    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_1D, MOREAU>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, (size_t)1, interleaved != 0, fn, cf);
   else
-    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_NORM2>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, interleaved != 0, fn, cf);
+    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_NORM2, MOREAU>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, interleaved != 0, fn, cf);
   PH_LAUNCH_END("prox_elem kernel");
 }
 
@@ -239,10 +284,16 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_prox_elem_f32(int op, int fn, float* res, const float* arg, const float* td, double tau, int inv, size_t count, size_t dim, int il, const float* const* cp, const double* cv, void* s) {
-  return launch_prox_elem<float>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
+  return launch_prox_elem<float, false>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
 }
 int prost_hip_prox_elem_f64(int op, int fn, double* res, const double* arg, const double* td, double tau, int inv, size_t count, size_t dim, int il, const double* const* cp, const double* cv, void* s) {
-  return launch_prox_elem<double>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
+  return launch_prox_elem<double, false>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
+}
+int prost_hip_prox_elem_moreau_f32(int op, int fn, float* res, const float* arg, const float* td, double tau, int inv, size_t count, size_t dim, int il, const float* const* cp, const double* cv, void* s) {
+  return launch_prox_elem<float, true>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
+}
+int prost_hip_prox_elem_moreau_f64(int op, int fn, double* res, const double* arg, const double* td, double tau, int inv, size_t count, size_t dim, int il, const double* const* cp, const double* cv, void* s) {
+  return launch_prox_elem<double, true>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
 }
 int prost_hip_prox_epi_quad_f32(float* res, const float* arg, size_t count, size_t dim, const float* a_ptr, double a_val, const float* b_ptr, const float* c_ptr, double c_val, void* s) {
   if (count == 0) return 0;

@@ -164,3 +164,31 @@ def test_kronecker_blocks(prec, dtype, name):
         full = sp.kron(K_mat, sp.eye(diaglength)) if name == "sparse_kron_id" else sp.kron(sp.eye(diaglength), K_mat)
         K = sp.bmat([[full, full], [full, full]]).tocsr()
         assert np.abs(x - K @ inp).max() <= 1e-4 and np.abs(x_t - K.T @ inp_t).max() <= 1e-4
+
+
+@pytest.mark.parametrize("prec,dtype", PRECISIONS)
+def test_fused_moreau_equals_three_kernel_sequence(prec, dtype):
+    """conjugate(elem operation) as ONE kernel (prost_hip_prox_elem_moreau) == MoreauPrescale + elem operation +
+    MoreauPostscale (prox_moreau.cu:98-134) bit for bit, and both == the oracle; every function, both
+    operations, both layouts, per-element coefficients, and the doubly conjugated (inverted step) form"""
+    prost.set_precision(prec)
+    rng = np.random.default_rng(77)
+    fns = [f for f in F.FUNCTIONS_1D if f not in ("lq", "lq_plus_eps")]
+    for n, dim in ((6, 1), (1027, 1), (4096, 2), (3000, 3), (35, 7)):
+        arg = rng.standard_normal(n); Tau = rng.random(n) + 0.2
+        vec = [rng.random(n // dim) + 0.3 for _ in range(3)]
+        for fn in fns:
+            if dim == 1:
+                cases = [F.sum_1d(fn, 1.5, 0.2, 2.0, 0.1, 0.3, 0.4, 0.6), F.sum_1d(fn, rng.random(n) + 0.3, rng.random(n), 2.0, 0.0, 0.0, 0.4, 0.6)]
+            else:
+                cases = [F.sum_norm2(dim, il, fn, vec[0], 0.2, vec[2], 0.0, 0.1, 0.4, 0.6) for il in (False, True)]
+            for f in cases:
+                for g in (F.conjugate(f), F.conjugate(F.conjugate(f))):
+                    prost.set_quirks(fuse_moreau=1)
+                    fused, _ = prost.eval_prox(g, arg, 0.8, Tau)
+                    prost.set_quirks(fuse_moreau=0)
+                    plain, _ = prost.eval_prox(g, arg, 0.8, Tau)
+                    prost.set_quirks(fuse_moreau=1)
+                    assert np.array_equal(fused, plain, equal_nan=True), (fn, n, dim)
+                    want = oracle.eval_prox(g, arg, 0.8, Tau, dtype)
+                    assert np.array_equal(np.asarray(fused, dtype=np.float64), want, equal_nan=True), (fn, n, dim)
