@@ -16,10 +16,12 @@ class BackendADMM : public Backend<T> {
     int cg_max_iter;
     int residual_iter;
     T arb_delta, arb_tau, arb_gamma;
+    bool device_cg;          ///< fused passes + CG scalars resident on the device (default); false = the reference's launch sequence, one blocking nrm2 per scalar
     Options() : rho0(1), alpha(1.7), cg_tol_pow(1.3), cg_tol_min(1e-5), cg_tol_max(1e-8), cg_max_iter(10), residual_iter(1),
-                arb_delta(1.05), arb_tau(0.8), arb_gamma(1.01) {}
+                arb_delta(1.05), arb_tau(0.8), arb_gamma(1.01), device_cg(true) {}
   };
-  explicit BackendADMM(const Options& opts) : opts_(opts), scal_dev_(nullptr), scal_host_(nullptr), workspace_(nullptr) {}
+  explicit BackendADMM(const Options& opts)
+      : opts_(opts), scal_dev_(nullptr), scal_host_(nullptr), workspace_(nullptr), cg_state_(nullptr), cg_workspace_(nullptr), cg_done_host_(nullptr) {}
   virtual ~BackendADMM();
 
   virtual void Initialize();
@@ -31,7 +33,7 @@ class BackendADMM : public Backend<T> {
   virtual std::string path() const { return "admm:generic"; }
   T rho() const { return rho_; }
   size_t iteration() const { return iteration_; }
-  int last_cg_iterations() const { return last_cg_iters_; }
+  int last_cg_iterations();                 ///< iterations taken by the most recent CGLS solve (reads the device record)
 
  private:
   /// y := alpha op(Sigma^(1/2) K Tau^(1/2)) x + beta y   (GemvPrecondK, backend_admm.cu:199-272)
@@ -39,6 +41,11 @@ class BackendADMM : public Backend<T> {
   double Nrm2(const device_vector<T>& v, size_t n);
   int Cgls(const device_vector<T>& b, device_vector<T>& x, double shift, double tol, int maxit, device_vector<T>& p,
            device_vector<T>& q, device_vector<T>& r, device_vector<T>& s, int& iterations);   // cgls.hpp:222-371
+  void CglsDevice(const device_vector<T>& b, device_vector<T>& x, double shift, double tol, int maxit, device_vector<T>& p,
+                  device_vector<T>& q, device_vector<T>& r, device_vector<T>& s);
+  void PerformIterationFused();
+  void PerformIterationUnfused();
+  void FinishResiduals(double primal_residual, double primal_var_norm, double dual_residual, double dual_var_norm);
   void GetDual(device_vector<T>& out, const device_vector<T>& half, const device_vector<T>& proj, const device_vector<T>& dual,
                const device_vector<T>& scaling, T expo, size_t n);
 
@@ -47,6 +54,11 @@ class BackendADMM : public Backend<T> {
   double* scal_dev_;
   double* scal_host_;
   void* workspace_;
+  void* cg_state_;          ///< device record of the CG scalars (prost_hip_cgls_state_bytes)
+  void* cg_workspace_;      ///< per-workgroup partial sums of the fused stages (prost_hip_cgls_workspace_bytes)
+  int* cg_done_host_;       ///< pinned word the device stores the solve's epoch to when the stopping test fires
+  int cg_epoch_ = 0;
+  bool cg_iters_valid_ = true;
   T rho_, delta_;
   int arb_u_, arb_l_;
   size_t iteration_;

@@ -68,6 +68,8 @@ class BlockSparse : public Block<T> {
   BlockSparse(size_t row, size_t col, size_t nrows, size_t ncols) : Block<T>(row, col, nrows, ncols), nnz_(0) {}
   virtual void EvalLocalAdd(T*, T*, const T*, const T*);
   virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalLocal(T*, T*, const T*, const T*);            ///< non-accumulating product in one pass (no separate zero fill)
+  virtual void EvalAdjointLocal(T*, T*, const T*, const T*);
   size_t nnz_;
   std::vector<int32_t> host_ind_, host_ind_t_, host_ptr_, host_ptr_t_;
   std::vector<T> host_val_, host_val_t_;

@@ -90,6 +90,9 @@ int prost_hip_diags_adj_f64(double* res, const double* rhs, size_t nrows, size_t
  * src/linop/block_sparse.cu:156-168 (forward, K) and :190-202 (adjoint, stored K^T). */
 int prost_hip_csr_spmv_acc_f32(float* res, const float* rhs, size_t nrows, size_t nnz, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 int prost_hip_csr_spmv_acc_f64(double* res, const double* rhs, size_t nrows, size_t nnz, const double* val, const int32_t* ptr, const int32_t* ind, void* stream);
+/* res = K rhs (non-accumulating form: the zero fill of Block::EvalLocal folded into the product) */
+int prost_hip_csr_spmv_f32(float* res, const float* rhs, size_t nrows, size_t nnz, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_csr_spmv_f64(double* res, const double* rhs, size_t nrows, size_t nnz, const double* val, const int32_t* ptr, const int32_t* ind, void* stream);
 /* res += kron(K, I_d) rhs (BlockSparseKronIdKernel, src/linop/block_sparse_kron_id.cu:26-49) and
  * res += kron(I_d, K) rhs (BlockIdKronSparseKernel, src/linop/block_id_kron_sparse.cu:26-52); K (nrows x ncols)
  * in CSR with int32 indices and FLOAT values for both T (:36, :79).  The adjoint is the same call
@@ -324,6 +327,70 @@ enum { PROST_ADMM_TEMP1 = 0, PROST_ADMM_TEMP2, PROST_ADMM_DIFF, PROST_ADMM_XPROJ
        PROST_ADMM_GEMV1, PROST_ADMM_GEMV2, PROST_ADMM_GEMV3, PROST_ADMM_GETDUAL, PROST_ADMM_SCALE, PROST_ADMM_DIV };
 int prost_hip_admm_elem_f32(int op, float* o, const float* a, const float* b, const float* c, const float* d, double alpha, double beta, size_t n, void* stream);
 int prost_hip_admm_elem_f64(int op, double* o, const double* a, const double* b, const double* c, const double* d, double alpha, double beta, size_t n, void* stream);
+
+/* Device-resident CGLS (include/prost/cgls.hpp:222-371 on the preconditioned operator
+ * A = Sigma^(1/2) K Tau^(1/2) of GemvPrecondK, backend_admm.cu:199-272).  The CG scalars live in a device
+ * record (`state`, prost_hip_cgls_state_bytes() bytes); each stage is one fused pass over the vectors
+ * and the caller applies K / K^T between stages:
+ *
+ *   INIT_X ; INIT_R ; r += K t ; INIT_R2 ; s += K^T t ; INIT_S ;
+ *   repeat maxit times:  q = K t ; STEP_Q ; STEP_XR ; s += K^T t ; STEP_S ; STEP_P
+ *
+ * After the stopping test of cgls.hpp:355-360 fires the STEP stages return without touching x, so the
+ * host may launch all maxit rounds without waiting; STEP_S additionally stores `epoch` to the pinned
+ * host word `host_done` (may be NULL) so that a host that is not running ahead can stop launching.
+ * b, r, q: m elements; x, p, s: n elements; t: max(m, n) scratch; sigma (m) / tau (n) are the
+ * preconditioner diagonals (the stages take the square roots, as gemv_functor1-3 do). */
+typedef struct prost_hip_cgls_desc {
+  void* state;
+  void* workspace;          /* prost_hip_cgls_workspace_bytes() */
+  const void* b;
+  void* x; void* p; void* q; void* r; void* s; void* t;
+  const void* sigma; const void* tau;
+  uint64_t m, n;
+  double shift, tol;
+  int* host_done;
+  int epoch;
+} prost_hip_cgls_desc;
+typedef struct prost_hip_cgls_result_t {
+  int iterations, converged, indefinite, flag;     /* flag 1: initial |s| < eps (cgls.hpp:283) */
+  double norms, norms0, normx, xmax;
+} prost_hip_cgls_result_t;
+enum { PROST_CGLS_INIT_X = 0, PROST_CGLS_INIT_R, PROST_CGLS_INIT_R2, PROST_CGLS_INIT_S,
+       PROST_CGLS_STEP_Q, PROST_CGLS_STEP_XR, PROST_CGLS_STEP_S, PROST_CGLS_STEP_P };
+size_t prost_hip_cgls_state_bytes(void);
+size_t prost_hip_cgls_workspace_bytes(void);
+int prost_hip_cgls_stage_f32(int stage, const prost_hip_cgls_desc* d, void* stream);
+int prost_hip_cgls_stage_f64(int stage, const prost_hip_cgls_desc* d, void* stream);
+/* blocking read-back of the scalar record (synchronises `stream`) */
+int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void* stream);
+
+/* Fused passes of the ADMM outer iteration (BackendADMM::PerformIteration, backend_admm.cu:355-665): each
+ * stage applies, per element, the reference functors that touch that element (same expressions, same
+ * order) and replaces the device-to-device copies between them.  The caller applies K / K^T in between:
+ *
+ *   PRE_X ; PRE_Z ; z_dual += K temp3 ; PRE_Z2 ; [CGLS on b = z_dual, x = x_proj] ;
+ *   POST_X ; z_proj = K x_proj ; POST_XZ ; prox_g(temp1) -> x_half ; prox_f(temp2) -> z_half ;
+ *   residuals (:535-616):  kx = K x_half ; RES_Z (overwrites kx with the dual variable y) ;
+ *                          kty = K^T kx ; RES_X -> out4 = {primal residual, primal variable norm,
+ *                          dual residual, dual variable norm} (doubles; out4 may be pinned host memory)
+ * x_*: n elements, z_*: m elements, temp1: n, temp2: m, temp3: max(m, n), kx: m, kty: n. */
+typedef struct prost_hip_admm_desc {
+  void* workspace;          /* prost_hip_cgls_workspace_bytes() */
+  void* x_half; void* x_proj; void* x_dual;
+  void* z_half; void* z_proj; void* z_dual;
+  void* temp1; void* temp2; void* temp3;
+  void* kx; void* kty;
+  const void* sigma; const void* tau;
+  uint64_t m, n;
+  double alpha;             /* over-relaxation */
+  double rho;
+  double* out4;
+} prost_hip_admm_desc;
+enum { PROST_ADMM_STAGE_PRE_X = 0, PROST_ADMM_STAGE_PRE_Z, PROST_ADMM_STAGE_PRE_Z2, PROST_ADMM_STAGE_POST_X,
+       PROST_ADMM_STAGE_POST_XZ, PROST_ADMM_STAGE_RES_Z, PROST_ADMM_STAGE_RES_X };
+int prost_hip_admm_stage_f32(int stage, const prost_hip_admm_desc* d, void* stream);
+int prost_hip_admm_stage_f64(int stage, const prost_hip_admm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* multi-GPU: global stopping criterion (no counterpart in the reference)        */

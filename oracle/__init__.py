@@ -533,10 +533,10 @@ class Solver:
         return dict(x=x, z=z, y=y, w=w)
 
     def scalars(self):
-        o = np.zeros(12)
+        o = np.zeros(13)
         _chk(lib().orc_solver_scalars(self.h, _p(o)))
         keys = ("tau", "sigma", "theta", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm",
-                "eps_primal", "eps_dual", "iteration", "rho", "delta")
+                "eps_primal", "eps_dual", "iteration", "rho", "delta", "cg_iterations")
         return dict(zip(keys, o))
 
     def __del__(self):

@@ -1263,7 +1263,7 @@ struct Solver : SolverBase {
     gemv('n', (T)-1, temp1, (T)1, z_dual);
     double cg_tol = ao.cg_tol_min / std::pow((double)static_cast<T>(iteration + 1), ao.cg_tol_pow);   // :408-410
     cg_tol = std::max(cg_tol, ao.cg_tol_max);
-    int taken;
+    int& taken = last_cg_iters;
     cgls_solve((int)m, (int)n, z_dual, x_proj, 1, cg_tol, ao.cg_max_iter, x_half, z_half, z_proj, x_dual, taken);
     std::copy(x_proj.begin(), x_proj.end(), temp3.begin());
     for (size_t i = 0; i < n; i++) x_proj[i] = std::sqrt(Tr[i]) * (x_proj[i] + temp1[i]);     // x_proj_functor :96-105
@@ -1374,9 +1374,10 @@ struct Solver : SolverBase {
     if (oy) std::copy(dy.begin(), dy.end(), oy);
     if (ow) std::copy(dw.begin(), dw.end(), ow);
   }
+  int last_cg_iters = 0;
   void scalars(double* o) override {
     o[0] = tau; o[1] = sigma; o[2] = theta; o[3] = primal_res; o[4] = dual_res; o[5] = primal_var_norm;
-    o[6] = dual_var_norm; o[7] = eps_primal(); o[8] = eps_dual(); o[9] = (double)iteration; o[10] = rho; o[11] = delta;
+    o[6] = dual_var_norm; o[7] = eps_primal(); o[8] = eps_dual(); o[9] = (double)iteration; o[10] = rho; o[11] = delta; o[12] = last_cg_iters;
   }
 };
 

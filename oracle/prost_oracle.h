@@ -170,7 +170,7 @@ int orc_solver_solve(orc_solver*, int* result, int* iters_done);
 int orc_solver_get(orc_solver*, double* x, double* z, double* y, double* w);
 /* out[0..11] = tau, sigma, theta, primal_res, dual_res, primal_var_norm, dual_var_norm,
  *              eps_primal, eps_dual, iteration, rho, delta */
-int orc_solver_scalars(orc_solver*, double* out12);
+int orc_solver_scalars(orc_solver*, double* out13);   /* ..., rho, delta, iterations of the last CGLS solve */
 
 #ifdef __cplusplus
 }

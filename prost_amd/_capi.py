@@ -193,7 +193,7 @@ def command(cmd, args=(), nlhs=0, struct_fields=None):
 # ------------------------------------------------------------------------------------------
 _RESULT_FIELDS = ("x", "y", "z", "w", "result", "iters", "path")
 _STATE_FIELDS = ("x", "y", "z", "w", "tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res",
-                 "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "path")
+                 "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "cg_iterations", "path")
 
 
 def _opts_struct(opts):

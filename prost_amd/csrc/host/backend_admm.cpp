@@ -40,6 +40,13 @@ void BackendADMM<T>::Initialize() {
   CheckHip(prost_hip_malloc((void**)&scal_dev_, 8 * sizeof(double)), "malloc");
   CheckHip(prost_hip_host_alloc((void**)&scal_host_, 8 * sizeof(double)), "host_alloc");
   CheckHip(prost_hip_malloc(&workspace_, prost_hip_reduce_workspace_bytes()), "malloc");
+  CheckHip(prost_hip_malloc(&cg_state_, prost_hip_cgls_state_bytes()), "malloc");
+  CheckHip(prost_hip_memset(cg_state_, 0, prost_hip_cgls_state_bytes(), CurrentStream()), "memset");
+  CheckHip(prost_hip_malloc(&cg_workspace_, prost_hip_cgls_workspace_bytes()), "malloc");
+  CheckHip(prost_hip_host_alloc((void**)&cg_done_host_, sizeof(int)), "host_alloc");
+  *cg_done_host_ = 0;
+  cg_epoch_ = 0;
+  cg_iters_valid_ = true;
 }
 
 template <typename T>
@@ -47,6 +54,9 @@ void BackendADMM<T>::Release() {
   if (scal_dev_) { prost_hip_free(scal_dev_); scal_dev_ = nullptr; }
   if (scal_host_) { prost_hip_host_free(scal_host_); scal_host_ = nullptr; }
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
+  if (cg_state_) { prost_hip_free(cg_state_); cg_state_ = nullptr; }
+  if (cg_workspace_) { prost_hip_free(cg_workspace_); cg_workspace_ = nullptr; }
+  if (cg_done_host_) { prost_hip_host_free(cg_done_host_); cg_done_host_ = nullptr; }
   x_half_.clear(); z_half_.clear(); x_proj_.clear(); z_proj_.clear(); x_dual_.clear(); z_dual_.clear(); temp1_.clear(); temp2_.clear(); temp3_.clear(); tmp_n_.clear(); tmp_m_.clear();
 }
 
@@ -131,6 +141,52 @@ int BackendADMM<T>::Cgls(const device_vector<T>& b, device_vector<T>& x, double 
   return flag;
 }
 
+
+/// The same solve with the CG scalars resident on the device (prost_hip_cgls_stage_*): no host round
+/// trip per iteration.  All maxit rounds are queued unless the pinned stop word shows that the device
+/// already met the stopping test; rounds queued after that point return immediately on the device.
+template <typename T>
+void BackendADMM<T>::CglsDevice(const device_vector<T>& b, device_vector<T>& x, double shift, double tol, int maxit,
+                                device_vector<T>& p, device_vector<T>& q, device_vector<T>& r, device_vector<T>& s) {
+  void* st = CurrentStream();
+  prost_hip_cgls_desc d;
+  d.state = cg_state_; d.workspace = cg_workspace_;
+  d.b = b.data(); d.x = x.data(); d.p = p.data(); d.q = q.data(); d.r = r.data(); d.s = s.data(); d.t = temp3_.data();
+  d.sigma = this->problem_->scaling_left().data(); d.tau = this->problem_->scaling_right().data();
+  d.m = this->problem_->nrows(); d.n = this->problem_->ncols();
+  d.shift = shift; d.tol = tol;
+  d.host_done = cg_done_host_; d.epoch = ++cg_epoch_;
+  auto stage = [&](int which) { CheckHip(Api<T>::cgls_stage(which, &d, st), "cgls_stage"); };
+  LinearOperator<T>* K = this->problem_->linop().get();
+  stage(PROST_CGLS_INIT_X);
+  stage(PROST_CGLS_INIT_R);
+  K->Eval(r, temp3_, 1);
+  stage(PROST_CGLS_INIT_R2);
+  K->EvalAdjoint(s, temp3_, 1);
+  stage(PROST_CGLS_INIT_S);
+  for (int k = 0; k < maxit; ++k) {
+    if (*static_cast<volatile int*>(cg_done_host_) == d.epoch) break;
+    K->Eval(q, temp3_, 0);
+    stage(PROST_CGLS_STEP_Q);
+    stage(PROST_CGLS_STEP_XR);
+    K->EvalAdjoint(s, temp3_, 1);
+    stage(PROST_CGLS_STEP_S);
+    stage(PROST_CGLS_STEP_P);
+  }
+  cg_iters_valid_ = false;
+}
+
+template <typename T>
+int BackendADMM<T>::last_cg_iterations() {
+  if (!cg_iters_valid_ && cg_state_) {
+    prost_hip_cgls_result_t res;
+    CheckHip(prost_hip_cgls_result(cg_state_, &res, CurrentStream()), "cgls_result");
+    last_cg_iters_ = res.iterations;
+    cg_iters_valid_ = true;
+  }
+  return last_cg_iters_;
+}
+
 template <typename T>
 void BackendADMM<T>::GetDual(device_vector<T>& out, const device_vector<T>& half, const device_vector<T>& proj,
                              const device_vector<T>& dual, const device_vector<T>& scaling, T expo, size_t n) {
@@ -140,6 +196,97 @@ void BackendADMM<T>::GetDual(device_vector<T>& out, const device_vector<T>& half
 
 template <typename T>
 void BackendADMM<T>::PerformIteration() {
+  if (opts_.device_cg) PerformIterationFused(); else PerformIterationUnfused();
+}
+
+/// residual bookkeeping shared by both paths: all-reduce over ranks, rho adaptation (:618-663)
+template <typename T>
+void BackendADMM<T>::FinishResiduals(double primal_residual, double primal_var_norm, double dual_residual, double dual_var_norm) {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  void* st = CurrentStream();
+  if (this->comm_) {
+    scal_host_[0] = primal_residual * primal_residual; scal_host_[1] = primal_var_norm * primal_var_norm;
+    scal_host_[2] = dual_residual * dual_residual; scal_host_[3] = dual_var_norm * dual_var_norm;
+    CheckHip(prost_hip_memcpy_h2d(scal_dev_, scal_host_, 4 * sizeof(double), st), "h2d");
+    CheckHip(prost_hip_allreduce_sum_f64(this->comm_, scal_dev_, 4, st), "allreduce");
+    CheckHip(prost_hip_memcpy_d2h(scal_host_, scal_dev_, 4 * sizeof(double), st), "d2h");
+    CheckHip(prost_hip_stream_synchronize(st), "sync");
+    primal_residual = std::sqrt(scal_host_[0]); primal_var_norm = std::sqrt(scal_host_[1]);
+    dual_residual = std::sqrt(scal_host_[2]); dual_var_norm = std::sqrt(scal_host_[3]);
+  }
+  this->primal_residual_ = (T)primal_residual;
+  this->primal_var_norm_ = (T)primal_var_norm;
+  this->dual_residual_ = (T)dual_residual;
+  this->dual_var_norm_ = (T)dual_var_norm;
+
+  const T eps_primal = this->eps_primal(), eps_dual = this->eps_dual();
+  const T rho_prev = rho_;
+  if ((this->dual_residual_ < eps_dual) && (opts_.arb_tau * iteration_ > arb_l_)) {
+    rho_ *= delta_; delta_ *= opts_.arb_gamma; arb_u_ = (int)iteration_;
+  } else if ((this->primal_residual_ < eps_primal) && (opts_.arb_tau * iteration_ > arb_u_)) {
+    rho_ /= delta_; delta_ *= opts_.arb_gamma; arb_l_ = (int)iteration_;
+  }
+  if (std::abs(rho_ - rho_prev) > 1e-7) {                                                            // :650-663
+    const T f = rho_prev / rho_;
+    elem<T>(PROST_ADMM_SCALE, x_dual_.data(), x_dual_.data(), nullptr, nullptr, nullptr, (double)f, 0, n);
+    elem<T>(PROST_ADMM_SCALE, z_dual_.data(), z_dual_.data(), nullptr, nullptr, nullptr, (double)f, 0, m);
+  }
+  CheckHip(prost_hip_check_last_error(), "ADMM iteration");
+}
+
+/// The iteration on the fused passes of prost_hip_admm_stage_* with the device-resident CGLS: the same
+/// per-element expressions as PerformIterationUnfused, 7 passes + 2 prox + 5 operator applications
+/// outside the CG solve instead of ~45 launches, and ONE host synchronisation (the four residual norms).
+template <typename T>
+void BackendADMM<T>::PerformIterationFused() {
+  const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
+  const device_vector<T>& Sl = this->problem_->scaling_left();
+  const device_vector<T>& Tr = this->problem_->scaling_right();
+  void* st = CurrentStream();
+  LinearOperator<T>* K = this->problem_->linop().get();
+  prost_hip_admm_desc d;
+  d.workspace = cg_workspace_;
+  d.x_half = x_half_.data(); d.x_proj = x_proj_.data(); d.x_dual = x_dual_.data();
+  d.z_half = z_half_.data(); d.z_proj = z_proj_.data(); d.z_dual = z_dual_.data();
+  d.temp1 = temp1_.data(); d.temp2 = temp2_.data(); d.temp3 = temp3_.data();
+  d.kx = tmp_m_.data(); d.kty = tmp_n_.data();
+  d.sigma = Sl.data(); d.tau = Tr.data();
+  d.m = m; d.n = n;
+  d.alpha = (double)(T)opts_.alpha; d.rho = (double)rho_;
+  d.out4 = scal_host_;
+  auto stage = [&](int which) { CheckHip(Api<T>::admm_stage(which, &d, st), "admm_stage"); };
+
+  stage(PROST_ADMM_STAGE_PRE_X);
+  stage(PROST_ADMM_STAGE_PRE_Z);
+  K->Eval(z_dual_, temp3_, 1);
+  stage(PROST_ADMM_STAGE_PRE_Z2);
+
+  double cg_tol = opts_.cg_tol_min / std::pow((double)static_cast<T>(iteration_ + 1), opts_.cg_tol_pow);   // :408-410
+  cg_tol = std::max(cg_tol, opts_.cg_tol_max);
+  CglsDevice(z_dual_, x_proj_, 1, cg_tol, opts_.cg_max_iter, x_half_, z_half_, z_proj_, x_dual_);
+
+  stage(PROST_ADMM_STAGE_POST_X);
+  K->Eval(z_proj_, x_proj_);
+  stage(PROST_ADMM_STAGE_POST_XZ);
+  for (auto& p : prox_g_) p->Eval(x_half_, temp1_, Tr, 1 / rho_);
+  for (auto& p : prox_f_) p->Eval(z_half_, temp2_, Sl, rho_, true);
+
+  iteration_++;
+
+  if (iteration_ == 0 || (iteration_ % (size_t)opts_.residual_iter) == 0) {                            // :535-616
+    K->Eval(tmp_m_, x_half_);
+    stage(PROST_ADMM_STAGE_RES_Z);
+    K->EvalAdjoint(tmp_n_, tmp_m_);
+    stage(PROST_ADMM_STAGE_RES_X);                       // the fold writes the four norms to pinned host memory
+    CheckHip(prost_hip_stream_synchronize(st), "sync");
+    FinishResiduals((double)(T)scal_host_[0], (double)(T)scal_host_[1], (double)(T)scal_host_[2], (double)(T)scal_host_[3]);
+  }
+}
+
+/// The reference's own sequence, one launch per functor and one blocking copy per norm
+/// (kept selectable -- backend option device_cg = false -- as the A/B for the fused path).
+template <typename T>
+void BackendADMM<T>::PerformIterationUnfused() {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
   const device_vector<T>& Sl = this->problem_->scaling_left();
   const device_vector<T>& Tr = this->problem_->scaling_right();
@@ -154,6 +301,7 @@ void BackendADMM<T>::PerformIteration() {
   double cg_tol = opts_.cg_tol_min / std::pow((double)static_cast<T>(iteration_ + 1), opts_.cg_tol_pow);   // :408-410
   cg_tol = std::max(cg_tol, opts_.cg_tol_max);
   Cgls(z_dual_, x_proj_, 1, cg_tol, opts_.cg_max_iter, x_half_, z_half_, z_proj_, x_dual_, last_cg_iters_);
+  cg_iters_valid_ = true;
 
   CheckHip(prost_hip_memcpy_d2d(temp3_.data(), x_proj_.data(), n * sizeof(T), st), "copy");
   elem<T>(PROST_ADMM_XPROJ, x_proj_.data(), temp1_.data(), Tr.data(), nullptr, nullptr, 0, 0, n);                                       // :447-456
@@ -190,34 +338,7 @@ void BackendADMM<T>::PerformIteration() {
     elem<T>(PROST_ADMM_GEMV1, temp1_.data(), Tr.data(), temp1_.data(), nullptr, nullptr, 0, 0, n);
     double dual_residual = (double)(T)Nrm2(temp1_, n);
 
-    if (this->comm_) {
-      scal_host_[0] = primal_residual * primal_residual; scal_host_[1] = primal_var_norm * primal_var_norm;
-      scal_host_[2] = dual_residual * dual_residual; scal_host_[3] = dual_var_norm * dual_var_norm;
-      CheckHip(prost_hip_memcpy_h2d(scal_dev_, scal_host_, 4 * sizeof(double), st), "h2d");
-      CheckHip(prost_hip_allreduce_sum_f64(this->comm_, scal_dev_, 4, st), "allreduce");
-      CheckHip(prost_hip_memcpy_d2h(scal_host_, scal_dev_, 4 * sizeof(double), st), "d2h");
-      CheckHip(prost_hip_stream_synchronize(st), "sync");
-      primal_residual = std::sqrt(scal_host_[0]); primal_var_norm = std::sqrt(scal_host_[1]);
-      dual_residual = std::sqrt(scal_host_[2]); dual_var_norm = std::sqrt(scal_host_[3]);
-    }
-    this->primal_residual_ = (T)primal_residual;
-    this->primal_var_norm_ = (T)primal_var_norm;
-    this->dual_residual_ = (T)dual_residual;
-    this->dual_var_norm_ = (T)dual_var_norm;
-
-    const T eps_primal = this->eps_primal(), eps_dual = this->eps_dual();
-    const T rho_prev = rho_;
-    if ((this->dual_residual_ < eps_dual) && (opts_.arb_tau * iteration_ > arb_l_)) {
-      rho_ *= delta_; delta_ *= opts_.arb_gamma; arb_u_ = (int)iteration_;
-    } else if ((this->primal_residual_ < eps_primal) && (opts_.arb_tau * iteration_ > arb_u_)) {
-      rho_ /= delta_; delta_ *= opts_.arb_gamma; arb_l_ = (int)iteration_;
-    }
-    if (std::abs(rho_ - rho_prev) > 1e-7) {                                                            // :650-663
-      const T f = rho_prev / rho_;
-      elem<T>(PROST_ADMM_SCALE, x_dual_.data(), x_dual_.data(), nullptr, nullptr, nullptr, (double)f, 0, n);
-      elem<T>(PROST_ADMM_SCALE, z_dual_.data(), z_dual_.data(), nullptr, nullptr, nullptr, (double)f, 0, m);
-    }
-    CheckHip(prost_hip_check_last_error(), "ADMM iteration");
+    FinishResiduals(primal_residual, primal_var_norm, dual_residual, dual_var_norm);
   }
 }
 

@@ -291,6 +291,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       o.arb_tau = (T)GetScalarFromField(d, "arb_tau"); o.alpha = GetScalarFromField(d, "alpha");
       o.cg_max_iter = (int)GetScalarFromField(d, "cg_max_iter"); o.cg_tol_pow = GetScalarFromField(d, "cg_tol_pow");
       o.cg_tol_min = GetScalarFromField(d, "cg_tol_min"); o.cg_tol_max = GetScalarFromField(d, "cg_tol_max");
+      if (prost_value_field(d, "device_cg")) o.device_cg = GetScalarFromField(d, "device_cg") > 0.;
       return new BackendADMM<T>(o);
     };
   }
@@ -668,13 +669,14 @@ void solver_state_t(SolverHandle<T>& h, int nlhs, prost_value** plhs) {
   prost_value_struct_set(out, "y", vec_value_t(h.solver->cur_dual_sol()));
   prost_value_struct_set(out, "z", vec_value_t(h.solver->cur_primal_constr_sol()));
   prost_value_struct_set(out, "w", vec_value_t(h.solver->cur_dual_constr_sol()));
-  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0;
+  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0;
   if (auto* p = dynamic_cast<BackendPDHG<T>*>(h.backend.get())) { tau = p->tau(); sigma = p->sigma(); theta = p->theta(); it = (double)p->iteration(); }
-  if (auto* a = dynamic_cast<BackendADMM<T>*>(h.backend.get())) { rho = a->rho(); it = (double)a->iteration(); }
+  if (auto* a = dynamic_cast<BackendADMM<T>*>(h.backend.get())) { rho = a->rho(); it = (double)a->iteration(); cg_its = a->last_cg_iterations(); }
   const char* names[] = {"tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual"};
   const double vals[] = {tau, sigma, theta, rho, it, (double)h.backend->primal_residual(), (double)h.backend->dual_residual(),
                          (double)h.backend->primal_var_norm(), (double)h.backend->dual_var_norm(), (double)h.backend->eps_primal(), (double)h.backend->eps_dual()};
   for (int i = 0; i < 11; i++) prost_value_struct_set(out, names[i], prost_value_scalar(vals[i]));
+  prost_value_struct_set(out, "cg_iterations", prost_value_scalar(cg_its));
   prost_value_struct_set(out, "path", prost_value_string(h.backend->path().c_str()));
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }

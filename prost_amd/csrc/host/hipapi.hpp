@@ -15,6 +15,7 @@ template <typename T> struct Api;
     static constexpr auto diags_fwd = prost_hip_diags_fwd_##S;                    \
     static constexpr auto diags_adj = prost_hip_diags_adj_##S;                    \
     static constexpr auto csr_spmv_acc = prost_hip_csr_spmv_acc_##S;              \
+    static constexpr auto csr_spmv = prost_hip_csr_spmv_##S;                      \
     static constexpr auto scale = prost_hip_scale_##S;                            \
     static constexpr auto sparse_kron_id_acc = prost_hip_sparse_kron_id_acc_##S;  \
     static constexpr auto id_kron_sparse_acc = prost_hip_id_kron_sparse_acc_##S;  \
@@ -44,6 +45,8 @@ template <typename T> struct Api;
     static constexpr auto nrm2 = prost_hip_nrm2_##S;                              \
     static constexpr auto axpy = prost_hip_axpy_##S;                              \
     static constexpr auto admm_elem = prost_hip_admm_elem_##S;                    \
+    static constexpr auto cgls_stage = prost_hip_cgls_stage_##S;                  \
+    static constexpr auto admm_stage = prost_hip_admm_stage_##S;                  \
   };
 
 PROST_API_STRUCT(float, f32)

@@ -83,6 +83,16 @@ void BlockSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
   if (val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv_acc");
 }
+template <typename T>
+void BlockSparse<T>::EvalLocal(T* r, T*, const T* x, const T*) {
+  if (val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  CheckHip(Api<T>::csr_spmv(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv");
+}
+template <typename T>
+void BlockSparse<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) {
+  if (val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  CheckHip(Api<T>::csr_spmv(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv");
+}
 template class BlockSparse<float>;
 template class BlockSparse<double>;
 

@@ -378,7 +378,7 @@ static int launch_diags(bool adj, T* res, const T* rhs, size_t nrows, size_t nco
 // LANES lanes cooperate on one row (1 = row per lane, strictly sequential sum; 64 = one
 // wavefront per row) chosen from the mean row length; partial sums fold with wave shuffles.
 // ------------------------------------------------------------------------------------------
-template <class T, int LANES>
+template <class T, int LANES, bool ACC>
 __global__ void __launch_bounds__(kBlock) csr_spmv_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nrows,
                                                           const T* __restrict__ val, const int32_t* __restrict__ ptr,
                                                           const int32_t* __restrict__ ind) {
@@ -393,19 +393,19 @@ __global__ void __launch_bounds__(kBlock) csr_spmv_kernel(T* __restrict__ res, c
 #pragma unroll
       for (int o = LANES / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, LANES);
     }
-    if (lane == 0) res[row] += sum;
+    if (lane == 0) res[row] = (ACC ? res[row] : (T)0) + sum;       // ACC = false: the zero fill + accumulate of Block::EvalLocal in one pass
   }
 }
 
-template <class T>
+template <class T, bool ACC>
 static int launch_csr(T* res, const T* rhs, size_t nrows, size_t nnz, const T* val, const int32_t* ptr, const int32_t* ind, void* stream) {
   if (nrows == 0) return 0;
   const double mean = (double)nnz / (double)nrows;
   hipStream_t s = as_stream(stream);
-  if (mean <= 6.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 1>), dim3(grid_for(nrows)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
-  else if (mean <= 24.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 4>), dim3(grid_for(nrows * 4)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
-  else if (mean <= 96.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 16>), dim3(grid_for(nrows * 16)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
-  else hipLaunchKernelGGL((csr_spmv_kernel<T, 64>), dim3(grid_for(nrows * 64)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
+  if (mean <= 6.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 1, ACC>), dim3(grid_for(nrows)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
+  else if (mean <= 24.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 4, ACC>), dim3(grid_for(nrows * 4)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
+  else if (mean <= 96.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 16, ACC>), dim3(grid_for(nrows * 16)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
+  else hipLaunchKernelGGL((csr_spmv_kernel<T, 64, ACC>), dim3(grid_for(nrows * 64)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
   PH_LAUNCH_END("csr spmv kernel");
 }
 
@@ -472,8 +472,10 @@ int prost_hip_diags_fwd_f64(double* r, const double* x, size_t nr, size_t nc, si
 int prost_hip_diags_adj_f32(float* r, const float* x, size_t nr, size_t nc, size_t nd, const int64_t* o, const float* f, int q, void* s) { return launch_diags<float>(true, r, x, nr, nc, nd, o, f, q, s); }
 int prost_hip_diags_adj_f64(double* r, const double* x, size_t nr, size_t nc, size_t nd, const int64_t* o, const float* f, int q, void* s) { return launch_diags<double>(true, r, x, nr, nc, nd, o, f, q, s); }
 
-int prost_hip_csr_spmv_acc_f32(float* r, const float* x, size_t nrows, size_t nnz, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<float>(r, x, nrows, nnz, v, p, i, s); }
-int prost_hip_csr_spmv_acc_f64(double* r, const double* x, size_t nrows, size_t nnz, const double* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<double>(r, x, nrows, nnz, v, p, i, s); }
+int prost_hip_csr_spmv_acc_f32(float* r, const float* x, size_t nrows, size_t nnz, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<float, true>(r, x, nrows, nnz, v, p, i, s); }
+int prost_hip_csr_spmv_acc_f64(double* r, const double* x, size_t nrows, size_t nnz, const double* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<double, true>(r, x, nrows, nnz, v, p, i, s); }
+int prost_hip_csr_spmv_f32(float* r, const float* x, size_t nrows, size_t nnz, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<float, false>(r, x, nrows, nnz, v, p, i, s); }
+int prost_hip_csr_spmv_f64(double* r, const double* x, size_t nrows, size_t nnz, const double* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<double, false>(r, x, nrows, nnz, v, p, i, s); }
 
 int prost_hip_sparse_kron_id_acc_f32(float* r, const float* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(false, r, x, d, nrows, 0, v, p, i, s); }
 int prost_hip_sparse_kron_id_acc_f64(double* r, const double* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(false, r, x, d, nrows, 0, v, p, i, s); }

@@ -42,7 +42,7 @@ def run_product(prob, backend, opts, iters):
 
 def run_oracle(prob, backend, opts, iters, dtype):
     prob.finalize()
-    b = [backend[0], {k: v for k, v in backend[1].items() if k != "allow_fused"}]
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg")}]
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
     s.initialize()
     s.iterate(iters)
@@ -189,10 +189,14 @@ def test_generic_pdhg_on_mixed_blocks(precision, dtype):
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
-def test_admm_matches_oracle(precision, dtype):
+@pytest.mark.parametrize("device_cg", [True, False])
+def test_admm_matches_oracle(precision, dtype, device_cg):
+    """device_cg=True: CG scalars resident on the device (fused stages, no host round trip);
+    False: host-driven CGLS with one blocking nrm2 per scalar, as the reference does it."""
     prost.set_precision(precision)
     prob = tvl1_like_problem(16, 12)
     b = prost.backend.admm(rho0=1, residual_iter=2)
+    b[1]["device_cg"] = device_cg
     o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
     tol = 2e-4 if dtype == np.float32 else 1e-9
     for k in (1, 5, 20):
@@ -201,8 +205,32 @@ def test_admm_matches_oracle(precision, dtype):
         ost = run_oracle(prob, b, o, k, dtype)
         assert_same_iterates(st, ost, exact=False, tol=tol)
         assert np.isclose(st["rho"], ost["rho"], rtol=1e-6)
+        assert st["cg_iterations"] == ost["cg_iterations"]
         for name in ("primal_res", "dual_res"):
             assert np.isclose(st[name], ost[name], rtol=1e-3, atol=1e-5), name
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("cg_tol_min,cg_max_iter", [(0.3, 10), (1e-2, 25), (1e-5, 3)])
+def test_admm_device_cg_stopping_rules(precision, dtype, cg_tol_min, cg_max_iter):
+    """Early convergence (rounds queued after the stopping test must not touch x), the iteration cap,
+    and odd sizes (vector tails) -- iterates and CG iteration counts against the oracle."""
+    prost.set_precision(precision)
+    prob = tvl1_like_problem(23, 19, seed=3)
+    b = prost.backend.admm(rho0=2, residual_iter=1, cg_tol_min=cg_tol_min, cg_tol_max=cg_tol_min * 1e-3, cg_max_iter=cg_max_iter)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    tol = 5e-4 if dtype == np.float32 else 1e-9
+    seen = set()
+    for k in (1, 2, 7, 15):
+        st = run_product(prob, b, o, k)
+        ost = run_oracle(prob, b, o, k, dtype)
+        assert_same_iterates(st, ost, exact=False, tol=tol)
+        assert st["cg_iterations"] == ost["cg_iterations"], (k, st["cg_iterations"], ost["cg_iterations"])
+        seen.add(int(st["cg_iterations"]))
+    if cg_max_iter == 3:
+        assert 3 in seen and seen <= {0, 3}     # 0: the very first solve starts from x = 0 with |A'b| < eps
+    if cg_tol_min == 0.3:
+        assert min(seen) < cg_max_iter          # the early-exit path was taken
     # ROF through ADMM agrees with PDHG at convergence (the two backends solve the same problem)
     prob, u, q, f = synthetic.rof_problem(32, 32)
     r1 = prost.solve(prob, prost.backend.admm(rho0=15), prost.options(max_iters=400, num_cback_calls=0, verbose=False, tol_rel_primal=1e-6, tol_rel_dual=1e-6, tol_abs_primal=1e-6, tol_abs_dual=1e-6))
