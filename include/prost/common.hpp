@@ -47,5 +47,17 @@ void SetCurrentStream(void* stream);
 /// throws prost::Exception(prost_hip_last_error()) if rc != 0
 void CheckHip(int rc, const char* what);
 
+/// Wall-clock of a setup stage, printed to stderr at scope exit when the environment variable
+/// PROST_TIMING is set (the stream is synchronised first so device work is attributed to its stage).
+class StageTimer {
+ public:
+  explicit StageTimer(const char* name);
+  ~StageTimer();
+ private:
+  const char* name_;
+  double t0_;
+  bool on_;
+};
+
 }  // namespace prost
 #endif

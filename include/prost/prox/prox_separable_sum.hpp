@@ -18,6 +18,23 @@ class ProxSeparableSum : public Prox<T> {
     if (interleaved_) for (size_t i = 0; i < count_; i++) sep.push_back(std::tuple<size_t, size_t, size_t>(this->index_ + i * dim_, dim_, 1));
     else for (size_t i = 0; i < count_; i++) sep.push_back(std::tuple<size_t, size_t, size_t>(this->index_ + i, dim_, count_));
   }
+  virtual void average_preconditioner(std::vector<T>& precond) {
+    T* base = precond.data() + this->index_;
+    if (interleaved_) {
+      for (size_t i = 0; i < count_; i++) {
+        T avg = 0;
+        for (size_t c = 0; c < dim_; c++) avg += base[i * dim_ + c];
+        avg /= static_cast<T>(dim_);
+        for (size_t c = 0; c < dim_; c++) base[i * dim_ + c] = avg;
+      }
+    } else {                                    // planar: component c of element i at i + c * count
+      std::vector<T> avg(count_, (T)0);
+      for (size_t c = 0; c < dim_; c++) { const T* src = base + c * count_; for (size_t i = 0; i < count_; i++) avg[i] += src[i]; }
+      const T cnt = static_cast<T>(dim_);
+      for (size_t i = 0; i < count_; i++) avg[i] /= cnt;
+      for (size_t c = 0; c < dim_; c++) { T* dst = base + c * count_; for (size_t i = 0; i < count_; i++) dst[i] = avg[i]; }
+    }
+  }
 
  protected:
   size_t count_, dim_;

@@ -44,6 +44,7 @@ class ProxMoreau : public Prox<T> {
   virtual void Release();
   virtual size_t gpu_mem_amount() const { return this->size_ * sizeof(T) + conjugate_->gpu_mem_amount(); }
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { conjugate_->get_separable_structure(sep); }
+  virtual void average_preconditioner(std::vector<T>& precond) { conjugate_->average_preconditioner(precond); }
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
@@ -117,6 +118,7 @@ class ProxTransform : public Prox<T> {
   virtual void Release();
   virtual size_t gpu_mem_amount() const;
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { inner_fn_->get_separable_structure(sep); }
+  virtual void average_preconditioner(std::vector<T>& precond) { inner_fn_->average_preconditioner(precond); }
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
@@ -135,6 +137,7 @@ class ProxPermute : public Prox<T> {
   virtual void Release();
   virtual size_t gpu_mem_amount() const { return this->size_ * sizeof(T) + base_prox_->gpu_mem_amount(); }
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { base_prox_->get_separable_structure(sep); }
+  virtual void average_preconditioner(std::vector<T>& precond) { base_prox_->average_preconditioner(precond); }
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);

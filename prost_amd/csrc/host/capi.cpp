@@ -413,7 +413,12 @@ void select_device() {
 }
 
 prost_value* vec_value(const std::vector<double>& v) { return prost_value_matrix(v.data(), v.size(), 1); }
-template <typename T> prost_value* vec_value_t(const std::vector<T>& v) { std::vector<double> d(v.begin(), v.end()); return vec_value(d); }
+// widens straight into the value's storage (one pass; these are the 10^7..10^8-element result vectors)
+template <typename T> prost_value* vec_value_t(const std::vector<T>& v) {
+  prost_value* out = new prost_value; out->kind = PROST_VALUE_MATRIX; out->rows = v.size(); out->cols = 1;
+  out->data.assign(v.begin(), v.end());
+  return out;
+}
 
 template <typename T>
 struct SolverHandle {
@@ -429,7 +434,7 @@ template <typename T>
 shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrows, size_t ncols, const prost_value* backend,
                                          const prost_value* opts, bool with_callbacks, const prost_value* owned = nullptr) {
   auto h = std::make_shared<SolverHandle<T>>();
-  h->problem = Factory<T>::CreateProblem(problem, nrows, ncols);
+  { StageTimer t("factory: CreateProblem"); h->problem = Factory<T>::CreateProblem(problem, nrows, ncols); }
   h->backend = Factory<T>::CreateBackend(backend);
   typename Solver<T>::Options o = Factory<T>::CreateSolverOptions(opts);
   if (o.verbose) {
@@ -476,7 +481,7 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
     prost_hip_free(d);
     h->backend->SetCommunicator(g_comm, (size_t)hbuf[0], (size_t)hbuf[1]);
   }
-  h->solver->Initialize();
+  { StageTimer t("Solver::Initialize (total)"); h->solver->Initialize(); }
   if (own_frac != 1.0) {
     auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
     if (!pd->single_kernel_path()) throw Exception("Column sharding needs the single-kernel gradient2d path (one gradient2d block with L <= 2, ny % 4 == 0).");
@@ -663,7 +668,8 @@ void cmd_solver_iterate(CMD_ARGS) {
 }
 template <typename T>
 void solver_state_t(SolverHandle<T>& h, int nlhs, prost_value** plhs) {
-  h.solver->FetchSolution();
+  { StageTimer t("FetchSolution"); h.solver->FetchSolution(); }
+  StageTimer t2("solver_state: value tree");
   prost_value* out = prost_value_struct();
   prost_value_struct_set(out, "x", vec_value_t(h.solver->cur_primal_sol()));
   prost_value_struct_set(out, "y", vec_value_t(h.solver->cur_dual_sol()));

@@ -1,4 +1,7 @@
 // common.cpp -- device_vector, stream handling and small host helpers of the prost host library.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "hipapi.hpp"
@@ -117,6 +120,16 @@ int32_t GlibcRand::next() {
   r_.push_back(v);
   if (r_.size() > 8192) r_.erase(r_.begin(), r_.begin() + 4096);
   return (int32_t)(v >> 1);
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+StageTimer::StageTimer(const char* name) : name_(name), t0_(0), on_(std::getenv("PROST_TIMING") != nullptr) {
+  if (on_) t0_ = now_ms();
+}
+StageTimer::~StageTimer() {
+  if (!on_) return;
+  prost_hip_stream_synchronize(CurrentStream());
+  std::fprintf(stderr, "[prost timing] %-40s %9.3f ms\n", name_, now_ms() - t0_);
 }
 
 }  // namespace prost

@@ -78,6 +78,7 @@ void Problem<T>::SetScalingCustom(const std::vector<T>& left, const std::vector<
 template <typename T>
 void Problem<T>::InitializeHost() {
   if (host_initialized_) return;
+  StageTimer timer("Problem::InitializeHost");
   linop_->InitializeHost();
   if (linop_->nrows() != nrows_ || linop_->ncols() != ncols_)
     std::cout << "Size of linear operator (ncols=" << linop_->ncols() << ", nrows=" << linop_->nrows()
@@ -103,16 +104,18 @@ void Problem<T>::InitializeHost() {
     scaling_left_host_.assign(nrows_, 0);
     scaling_right_host_.assign(ncols_, 0);
     std::vector<T> sums(nrows_);
+    StageTimer t_pre("  preconditioner sums");
     linop_->row_sums(sums, scaling_alpha_);
-    T value = 1;
+    // (the reciprocal is only re-evaluated when the sum changes: stencil operators repeat one value 10^7 times)
+    T value = 1, last_sum = 0;
     for (size_t r = 0; r < nrows_; r++) {
-      if (sums[r] > 0) value = (T)(1. / (double)sums[r]);
+      if (sums[r] > 0 && sums[r] != last_sum) { last_sum = sums[r]; value = (T)(1. / (double)sums[r]); }
       scaling_left_host_[r] = value;
     }
     sums.assign(ncols_, 0);
     linop_->col_sums(sums, (T)(2. - (double)scaling_alpha_));
     for (size_t c = 0; c < ncols_; c++) {
-      if (sums[c] > 0) value = (T)(1. / (double)sums[c]);
+      if (sums[c] > 0 && sums[c] != last_sum) { last_sum = sums[c]; value = (T)(1. / (double)sums[c]); }
       scaling_right_host_[c] = value;
     }
   } else if (scaling_type_ == kScalingIdentity) {
@@ -122,6 +125,7 @@ void Problem<T>::InitializeHost() {
     if (scaling_left_host_.size() != nrows_ || scaling_right_host_.size() != ncols_)
       throw Exception("Preconditioners/diagonal scaling vectors do not fit the size of linear operator.");
   }
+  StageTimer t_avg("  AveragePreconditioners");
   AveragePreconditioners(scaling_right_host_, prox_g_.empty() ? prox_gstar_ : prox_g_);
   AveragePreconditioners(scaling_left_host_, prox_f_.empty() ? prox_fstar_ : prox_f_);
   host_initialized_ = true;
@@ -130,6 +134,7 @@ void Problem<T>::InitializeHost() {
 template <typename T>
 void Problem<T>::Initialize() {
   InitializeHost();
+  StageTimer timer("Problem::Initialize uploads");
   for (auto& b : linop_->blocks()) b->Initialize();
   for (auto& p : prox_f_) p->Initialize();
   for (auto& p : prox_fstar_) p->Initialize();
@@ -167,15 +172,7 @@ size_t Problem<T>::gpu_mem_amount() const {
 /// separable groups (problem.cu:503-536)
 template <typename T>
 void Problem<T>::AveragePreconditioners(std::vector<T>& precond, const ProxList& prox) {
-  std::vector<std::tuple<size_t, size_t, size_t>> groups;
-  for (auto& p : prox) if (!p->diagsteps()) p->get_separable_structure(groups);
-  for (auto& g : groups) {
-    const size_t idx = std::get<0>(g), cnt = std::get<1>(g), stride = std::get<2>(g);
-    T avg = 0;
-    for (size_t c = 0; c < cnt; c++) avg += precond[idx + c * stride];
-    avg /= static_cast<T>(cnt);
-    for (size_t c = 0; c < cnt; c++) precond[idx + c * stride] = avg;
-  }
+  for (auto& p : prox) if (!p->diagsteps()) p->average_preconditioner(precond);
 }
 
 template <typename T>

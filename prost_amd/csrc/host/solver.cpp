@@ -33,6 +33,7 @@ void Solver<T>::Initialize() {
   try {
     backend_->SetProblem(problem_);
     backend_->SetOptions(opts_);
+    StageTimer timer("Backend::Initialize");
     backend_->Initialize();
   } catch (Exception& e) {
     throw Exception(std::string("Failed to initialize the backend. Reason: ") + e.what());
