@@ -93,7 +93,12 @@ class BackendPDHG : public Backend<T> {
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
   /// where the reduction kernels put the four sums: the pinned (device-visible) host buffer, or the device
   /// buffer when an RCCL all-reduce has to run on them first
-  double* res_target() { return this->comm_ ? res_dev_ : res_host_; }
+  double* res_target();
+  // all-reduce of the sums on a side stream (alg1 / alg2 with a communicator): the iteration stream never waits for the other ranks
+  void* side_stream_ = nullptr;
+  void* ev_res_ready_ = nullptr;
+  void* ev_res_done_ = nullptr;
+  bool side_inflight_ = false, resolve_on_side_ = false;
   double* res_host_;       // pinned
   void* workspace_;
   T tau_, sigma_, theta_;

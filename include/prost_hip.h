@@ -55,6 +55,7 @@ int prost_hip_event_create(void** event);
 int prost_hip_event_destroy(void* event);
 int prost_hip_event_record(void* event, void* stream);
 int prost_hip_event_synchronize(void* event);
+int prost_hip_stream_wait_event(void* stream, void* event);      /* later work on `stream` waits for `event` (no host wait) */
 int prost_hip_event_elapsed_ms(void* start, void* stop, float* ms);
 /* one hipGetLastError per iteration instead of a device sync per prox launch
  * (prox_elem_operation.inl:128-138) */

@@ -108,6 +108,13 @@ void BackendPDHG<T>::Initialize() {
   CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
   CheckHip(prost_hip_host_alloc((void**)&res_host_, 4 * sizeof(double)), "host_alloc");
   CheckHip(prost_hip_malloc(&workspace_, prost_hip_reduce_workspace_bytes()), "malloc");
+  side_inflight_ = resolve_on_side_ = false;
+  const bool deferred_rule = opts_.stepsize_variant != kPDHGStepsResidualGoldstein && opts_.stepsize_variant != kPDHGStepsResidualBoyd;
+  if (this->comm_ && deferred_rule && owned_x1_ == 0) {     // column-sharded slabs also exchange halos on this communicator: keep one stream there
+    CheckHip(prost_hip_stream_create(&side_stream_), "stream_create");
+    CheckHip(prost_hip_event_create(&ev_res_ready_), "event_create");
+    CheckHip(prost_hip_event_create(&ev_res_done_), "event_create");
+  }
 
   this->primal_var_norm_ = this->dual_var_norm_ = this->primal_residual_ = this->dual_residual_ = 0;
 
@@ -135,6 +142,9 @@ void BackendPDHG<T>::Release() {
   if (res_dev_) { prost_hip_free(res_dev_); res_dev_ = nullptr; }
   if (res_host_) { prost_hip_host_free(res_host_); res_host_ = nullptr; }
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
+  if (side_stream_) { prost_hip_stream_synchronize(side_stream_); prost_hip_stream_destroy(side_stream_); side_stream_ = nullptr; }
+  if (ev_res_ready_) { prost_hip_event_destroy(ev_res_ready_); ev_res_ready_ = nullptr; }
+  if (ev_res_done_) { prost_hip_event_destroy(ev_res_done_); ev_res_done_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); ev_kind_.clear();
   y_spare_.clear(); x_spare_.clear();
@@ -291,6 +301,20 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   this->problem_->linop()->EvalAdjoint(kty_, y_);                                                              // :377-380
 }
 
+/// where the reduction kernels put the four sums: the pinned (device-visible) host buffer, or the device
+/// buffer when an RCCL all-reduce has to run on them first.  Called right before a residual launch is
+/// enqueued: if the previous all-reduce is still in flight on the side stream, the iteration stream is
+/// made to wait for it (device-side) before the buffer is overwritten.
+template <typename T>
+double* BackendPDHG<T>::res_target() {
+  if (!this->comm_) return res_host_;
+  if (side_inflight_) {
+    CheckHip(prost_hip_stream_wait_event(CurrentStream(), ev_res_done_), "stream_wait_event");
+    side_inflight_ = false;
+  }
+  return res_dev_;
+}
+
 /// Residual iteration, device side done: all-reduce the four sums if there is a communicator and bring them
 /// to the host.  The residual-driven step rules (goldstein, boyd) need the values before the next launch;
 /// alg1 / alg2 do not, so there the host does NOT wait: the sums are picked up (ResolveResiduals) when
@@ -302,8 +326,19 @@ void BackendPDHG<T>::FinishResiduals() {
   // without a communicator the reduction kernels wrote the four sums straight into the pinned host buffer
   // (device-visible): no D2H copy, a stream synchronisation is all that is needed before reading them
   if (this->comm_) {
-    CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
-    CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), s), "memcpy_d2h");
+    if (side_stream_) {
+      // alg1 / alg2: nothing on the iteration stream depends on the global sums, so the collective (which
+      // waits for the slowest rank) and the copy run beside the next iterations instead of between them
+      CheckHip(prost_hip_event_record(ev_res_ready_, s), "event_record");
+      CheckHip(prost_hip_stream_wait_event(side_stream_, ev_res_ready_), "stream_wait_event");
+      CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, side_stream_), "allreduce");
+      CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), side_stream_), "memcpy_d2h");
+      CheckHip(prost_hip_event_record(ev_res_done_, side_stream_), "event_record");
+      side_inflight_ = resolve_on_side_ = true;
+    } else {
+      CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
+      CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), s), "memcpy_d2h");
+    }
   }
   residuals_pending_ = true;
   if (opts_.stepsize_variant == kPDHGStepsResidualGoldstein || opts_.stepsize_variant == kPDHGStepsResidualBoyd) ResolveResiduals();
@@ -313,7 +348,8 @@ template <typename T>
 void BackendPDHG<T>::ResolveResiduals() {
   if (!residuals_pending_) return;
   residuals_pending_ = false;
-  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
+  if (resolve_on_side_) { CheckHip(prost_hip_event_synchronize(ev_res_done_), "event_synchronize"); resolve_on_side_ = false; }
+  else CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   // the reference reduces in T and takes std::sqrt of the T sums (:433-436)
   this->primal_residual_ = std::sqrt((T)res_host_[0]);

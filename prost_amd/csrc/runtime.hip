@@ -59,6 +59,7 @@ int prost_hip_device_synchronize(void) { PH_CHECK(hipDeviceSynchronize()); retur
 int prost_hip_event_create(void** e) { hipEvent_t ev; PH_CHECK(hipEventCreate(&ev)); *e = ev; return 0; }
 int prost_hip_event_destroy(void* e) { if (e) PH_CHECK(hipEventDestroy((hipEvent_t)e)); return 0; }
 int prost_hip_event_record(void* e, void* s) { PH_CHECK(hipEventRecord((hipEvent_t)e, as_stream(s))); return 0; }
+int prost_hip_stream_wait_event(void* s, void* e) { PH_CHECK(hipStreamWaitEvent(as_stream(s), (hipEvent_t)e, 0)); return 0; }
 int prost_hip_event_synchronize(void* e) { PH_CHECK(hipEventSynchronize((hipEvent_t)e)); return 0; }
 int prost_hip_event_elapsed_ms(void* a, void* b, float* ms) { PH_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 int prost_hip_check_last_error(void) { PH_CHECK(hipGetLastError()); return 0; }

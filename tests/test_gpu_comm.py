@@ -10,12 +10,15 @@ from prost_amd import synthetic
 pytestmark = pytest.mark.gpu
 
 
-def test_world1_communicator_gives_identical_solve(hip):
+@pytest.mark.parametrize("stepsize", ["boyd", "alg2"])
+def test_world1_communicator_gives_identical_solve(hip, stepsize):
+    """boyd: the all-reduce runs on the iteration stream (the step rule needs the global sums at once);
+    alg2: on the side stream, overlapped with the next iterations, resolved when the state is read."""
     prost.set_gpu(0)
     prost.set_precision("single")
     try:
         prob, u, q, f = synthetic.rof_problem(64, 48)
-        b = prost.backend.pdhg(stepsize="boyd", residual_iter=2)
+        b = prost.backend.pdhg(stepsize=stepsize, residual_iter=2, alg2_gamma=0.5)
         o = prost.options(max_iters=60, num_cback_calls=0, verbose=False)
         s = prost.Solver(prob, b, o); s.iterate(60); ref = s.state(); s.destroy()
         ident = prost.comm_unique_id()
