@@ -26,9 +26,10 @@ class BackendPDHG : public Backend<T> {
     bool allow_fused;          ///< MI355X addition: set false to force the generic path
     bool allow_single_kernel;  ///< MI355X addition: one kernel per non-residual iteration (7 instead of 11 floats/pixel)
     bool allow_pair_kernel;    ///< MI355X addition: two iterations per launch where nobody observes the one in between
+    bool allow_arg_fusion;     ///< MI355X addition (generic path): proxes form their argument on the fly, no argument pass
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
-                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true) {}
+                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true) {}
   };
 
   explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), pair_kernel_(false), res_dev_(nullptr),
@@ -93,6 +94,7 @@ class BackendPDHG : public Backend<T> {
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
   /// where the reduction kernels put the four sums: the pinned (device-visible) host buffer, or the device
   /// buffer when an RCCL all-reduce has to run on them first
+  bool arg_fused_g_ = false, arg_fused_f_ = false;     // every prox of prox_g_ / prox_fstar_ evaluates from an argument source
   double* res_target();
   // all-reduce of the sums on a side stream (alg1 / alg2 with a communicator): the iteration stream never waits for the other ranks
   void* side_stream_ = nullptr;

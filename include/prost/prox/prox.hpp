@@ -73,6 +73,22 @@ class Prox {
   }
   virtual bool describe(ProxDesc&) const { return false; }
 
+  /// A prox argument that is not materialised: the backend names the vectors and scalars it is made of
+  /// (prost_hip_arg_spec modes; pointers to element 0 of the whole variable) and a prox that can form it on the
+  /// fly evaluates straight from them -- the separate argument pass of the PDHG iteration disappears.
+  struct ArgSource {
+    int mode;               ///< PROST_ARG_PDHG_PRIMAL (x, T, K^T y; tau) or PROST_ARG_PDHG_DUAL (y, Sigma, K x, K x_prev; sigma, theta)
+    const T* v[4];
+    T s[2];
+  };
+  /// true if EvalFromSource is implemented; a backend only skips its argument pass when EVERY prox of the list is
+  virtual bool supports_arg_source() const { return false; }
+  /// result[index:index+size) = prox(source[index:index+size); tau * tau_diag[...]); result must not alias source.v[0]
+  virtual void EvalFromSource(device_vector<T>& result, const ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false) {
+    (void)result; (void)src; (void)tau_diag; (void)tau; (void)invert_tau;
+    throw Exception("This prox cannot evaluate from an argument source.");
+  }
+
  protected:
   virtual void EvalLocal(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg,
                          const T* tau_end, T tau, bool invert_tau) = 0;

@@ -25,6 +25,12 @@ class ProxElemOperation : public ProxSeparableSum<T> {
   int fn() const { return fn_; }
   /// prox of the conjugate (Moreau) of this elem operation in one fused pass; same ranges as EvalLocal
   void EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau);
+  virtual bool supports_arg_source() const { return true; }
+  virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false) {
+    EvalSourceLocal(false, result, src, tau_diag, tau, invert_tau);
+  }
+  /// moreau = true: the conjugate's prox from the source (used by ProxMoreau::EvalFromSource)
+  void EvalSourceLocal(bool moreau, device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau);
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
@@ -44,6 +50,8 @@ class ProxMoreau : public Prox<T> {
   virtual void Release();
   virtual size_t gpu_mem_amount() const { return this->size_ * sizeof(T) + conjugate_->gpu_mem_amount(); }
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { conjugate_->get_separable_structure(sep); }
+  virtual bool supports_arg_source() const;
+  virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
   virtual void average_preconditioner(std::vector<T>& precond) { conjugate_->average_preconditioner(precond); }
 
  protected:
@@ -58,6 +66,9 @@ class ProxZero : public Prox<T> {
  public:
   ProxZero(size_t index, size_t size) : Prox<T>(index, size, true) {}
   virtual size_t gpu_mem_amount() const { return 0; }
+  virtual bool supports_arg_source() const { return true; }
+  /// the identity prox of a source IS the argument pass, written straight into the result
+  virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);

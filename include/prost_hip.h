@@ -139,6 +139,20 @@ int prost_hip_prox_elem_moreau_f32(int op, int fn, float* res, const float* arg,
                                    size_t count, size_t dim, int interleaved, const float* const* coeff_ptr, const double* coeff_val, void* stream);
 int prost_hip_prox_elem_moreau_f64(int op, int fn, double* res, const double* arg, const double* tau_diag, double tau, int invert_tau,
                                    size_t count, size_t dim, int interleaved, const double* const* coeff_ptr, const double* coeff_val, void* stream);
+/* The same operations with the argument formed on the fly (no separate argument pass):
+ *   PROST_ARG_PLAIN        arg = v[0]
+ *   PROST_ARG_PDHG_PRIMAL  arg = v[0] - s[0] v[1] v[2]                          primal_proxarg_functor, backend_pdhg.cu:38-51
+ *                          (x, T, K^T y; tau)
+ *   PROST_ARG_PDHG_DUAL    arg = v[0] + s[0] v[1] ((1 + s[1]) v[2] - s[1] v[3])  dual_proxarg_functor, backend_pdhg.cu:54-70
+ *                          (y, Sigma, K x, K x_prev; sigma, theta)
+ * v[] are device pointers to the FIRST element of the prox's range in each vector; res must not alias v[0].
+ * moreau != 0 evaluates the conjugate as prost_hip_prox_elem_moreau does. */
+typedef struct prost_hip_arg_spec { int mode; const void* v[4]; double s[2]; } prost_hip_arg_spec;
+enum { PROST_ARG_PLAIN = 0, PROST_ARG_PDHG_PRIMAL = 1, PROST_ARG_PDHG_DUAL = 2 };
+int prost_hip_prox_elem_arg_f32(int op, int fn, int moreau, float* res, const prost_hip_arg_spec* arg, const float* tau_diag, double tau, int invert_tau,
+                                size_t count, size_t dim, int interleaved, const float* const* coeff_ptr, const double* coeff_val, void* stream);
+int prost_hip_prox_elem_arg_f64(int op, int fn, int moreau, double* res, const prost_hip_arg_spec* arg, const double* tau_diag, double tau, int invert_tau,
+                                size_t count, size_t dim, int interleaved, const double* const* coeff_ptr, const double* coeff_val, void* stream);
 /* ProxIndEpiQuadKernel (src/prox/prox_ind_epi_quad.cu:42-79) + helper::ProjectEpiQuadNd
  * (include/prost/prox/helper.hpp:44-105).  a_ptr/c_ptr NULL -> scalar a_val/c_val. */
 int prost_hip_prox_epi_quad_f32(float* res, const float* arg, size_t count, size_t dim, const float* a_ptr, double a_val, const float* b_ptr, const float* c_ptr, double c_val, void* stream);

@@ -96,6 +96,9 @@ void BackendPDHG<T>::Initialize() {
   } else prox_fstar_ = this->problem_->prox_fstar();
 
   fused_ = TryFused();
+  arg_fused_g_ = arg_fused_f_ = opts_.allow_arg_fusion;
+  for (auto& p : prox_g_) arg_fused_g_ = arg_fused_g_ && p->supports_arg_source();
+  for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
   single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
@@ -282,14 +285,29 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   const size_t n = this->problem_->ncols(), m = this->problem_->nrows();
   const device_vector<T>& Tr = this->problem_->scaling_right();
   const device_vector<T>& Sl = this->problem_->scaling_left();
-  CheckHip(Api<T>::pdhg_primal_arg(temp_.data(), x_.data(), Tr.data(), kty_.data(), (double)tau_, n, s), "primal_arg");   // :317-331
-  x_.swap(x_prev_);
-  for (auto& p : prox_g_) p->Eval(x_, temp_, Tr, tau_);
+  // When every prox of a list can form its argument on the fly (elem operations, their conjugates, the identity),
+  // the argument pass of :317-331 / :349-364 is folded into the prox kernels: same expressions, one vector less
+  // written and re-read per prox.
+  if (arg_fused_g_) {
+    x_.swap(x_prev_);
+    const typename Prox<T>::ArgSource src{PROST_ARG_PDHG_PRIMAL, {x_prev_.data(), Tr.data(), kty_.data(), nullptr}, {tau_, (T)0}};
+    for (auto& p : prox_g_) p->EvalFromSource(x_, src, Tr, tau_);
+  } else {
+    CheckHip(Api<T>::pdhg_primal_arg(temp_.data(), x_.data(), Tr.data(), kty_.data(), (double)tau_, n, s), "primal_arg");   // :317-331
+    x_.swap(x_prev_);
+    for (auto& p : prox_g_) p->Eval(x_, temp_, Tr, tau_);
+  }
   kx_.swap(kx_prev_);
   this->problem_->linop()->Eval(kx_, x_);
-  CheckHip(Api<T>::pdhg_dual_arg(temp_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "dual_arg");   // :349-364
-  y_.swap(y_prev_);
-  for (auto& p : prox_fstar_) p->Eval(y_, temp_, Sl, sigma_);
+  if (arg_fused_f_) {
+    y_.swap(y_prev_);
+    const typename Prox<T>::ArgSource src{PROST_ARG_PDHG_DUAL, {y_prev_.data(), Sl.data(), kx_.data(), kx_prev_.data()}, {sigma_, theta_}};
+    for (auto& p : prox_fstar_) p->EvalFromSource(y_, src, Sl, sigma_);
+  } else {
+    CheckHip(Api<T>::pdhg_dual_arg(temp_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "dual_arg");   // :349-364
+    y_.swap(y_prev_);
+    for (auto& p : prox_fstar_) p->Eval(y_, temp_, Sl, sigma_);
+  }
   if (res) {                                                                                                   // :392-431
     CheckHip(Api<T>::pdhg_residual_primal(res_target(), y_prev_.data(), y_.data(), Sl.data(), kx_prev_.data(), kx_.data(), (double)sigma_, (double)theta_, m, workspace_, s), "residual_primal");
     CheckHip(Api<T>::pdhg_residual_dual(res_target() + 2, x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), kty_.data(), (double)tau_, n, workspace_, s), "residual_dual");

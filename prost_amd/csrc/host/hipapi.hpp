@@ -21,6 +21,7 @@ template <typename T> struct Api;
     static constexpr auto id_kron_sparse_acc = prost_hip_id_kron_sparse_acc_##S;  \
     static constexpr auto prox_elem = prost_hip_prox_elem_##S;                    \
     static constexpr auto prox_elem_moreau = prost_hip_prox_elem_moreau_##S;      \
+    static constexpr auto prox_elem_arg = prost_hip_prox_elem_arg_##S;            \
     static constexpr auto prox_epi_quad = prost_hip_prox_epi_quad_##S;            \
     static constexpr auto prox_elem_ind_sum = prost_hip_prox_elem_ind_sum_##S;    \
     static constexpr auto prox_elem_ind_simplex = prost_hip_prox_elem_ind_simplex_##S; \

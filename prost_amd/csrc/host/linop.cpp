@@ -255,6 +255,12 @@ void LinearOperator<T>::Eval(device_vector<T>& result, const device_vector<T>& r
     for (auto& b : blocks_) b->Eval(result.data(), rhs.data());
     return;
   }
+  if (beta == 0 && !blocks_.empty() && blocks_[0]->row() == 0 && blocks_[0]->nrows() == nrows_ && result.size() == nrows_) {
+    // the first block writes every row: it replaces the fill, the others accumulate in the same order as before
+    blocks_[0]->Eval(result.data(), rhs.data());
+    for (size_t i = 1; i < blocks_.size(); i++) blocks_[i]->EvalAdd(result.data(), rhs.data());
+    return;
+  }
   ApplyBeta(result, beta, false);
   for (auto& b : blocks_) b->EvalAdd(result.data(), rhs.data());
 }
@@ -262,6 +268,11 @@ template <typename T>
 void LinearOperator<T>::EvalAdjoint(device_vector<T>& result, const device_vector<T>& rhs, T beta) {
   if (beta == 0 && cols_exclusive_ && result.size() == ncols_) {
     for (auto& b : blocks_) b->EvalAdjoint(result.data(), rhs.data());
+    return;
+  }
+  if (beta == 0 && !blocks_.empty() && blocks_[0]->col() == 0 && blocks_[0]->ncols() == ncols_ && result.size() == ncols_) {
+    blocks_[0]->EvalAdjoint(result.data(), rhs.data());
+    for (size_t i = 1; i < blocks_.size(); i++) blocks_[i]->EvalAdjointAdd(result.data(), rhs.data());
     return;
   }
   ApplyBeta(result, beta, false);

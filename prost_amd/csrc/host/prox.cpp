@@ -88,6 +88,23 @@ void ProxElemOperation<T>::EvalMoreauLocal(T* res, const T* arg, const T* tau_di
   CheckHip(Api<T>::prox_elem_moreau(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
                                     this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem_moreau");
 }
+template <typename T>
+void ProxElemOperation<T>::EvalSourceLocal(bool moreau, device_vector<T>& result, const typename Prox<T>::ArgSource& src,
+                                           const device_vector<T>& tau_diag, T tau, bool invert_tau) {
+  const T* ptrs[7]; double vals[7];
+  for (int i = 0; i < 7; i++) {
+    if (coeffs_[i].size() > 1) {
+      if (d_coeffs_[i].size() != coeffs_[i].size()) throw Exception("ProxElemOperation used before Initialize().");
+      ptrs[i] = d_coeffs_[i].data(); vals[i] = 0;
+    } else { ptrs[i] = nullptr; vals[i] = (double)coeffs_[i][0]; }
+  }
+  prost_hip_arg_spec a;
+  a.mode = src.mode;
+  for (int k = 0; k < 4; k++) a.v[k] = src.v[k] ? src.v[k] + this->index_ : nullptr;
+  a.s[0] = (double)src.s[0]; a.s[1] = (double)src.s[1];
+  CheckHip(Api<T>::prox_elem_arg(op_, fn_, moreau ? 1 : 0, result.data() + this->index_, &a, tau_diag.data() + this->index_, (double)tau,
+                                 invert_tau ? 1 : 0, this->count_, this->dim_, this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem_arg");
+}
 template class ProxElemOperation<float>;
 template class ProxElemOperation<double>;
 
@@ -110,10 +127,28 @@ void ProxMoreau<T>::EvalLocal(T* res, T* res_end, const T* arg, const T* arg_end
   CheckHip(Api<T>::moreau_postscale(res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, n, CurrentStream()), "moreau_postscale");
   (void)arg_end;
 }
+template <typename T>
+bool ProxMoreau<T>::supports_arg_source() const { return g_moreau_fuse && dynamic_cast<ProxElemOperation<T>*>(conjugate_.get()) != nullptr; }
+template <typename T>
+void ProxMoreau<T>::EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau) {
+  auto* e = dynamic_cast<ProxElemOperation<T>*>(conjugate_.get());
+  if (!e) throw Exception("ProxMoreau: only a conjugated elem operation evaluates from an argument source.");
+  e->EvalSourceLocal(true, result, src, tau_diag, tau, invert_tau);
+}
 template class ProxMoreau<float>;
 template class ProxMoreau<double>;
 
 // ---- zero ----
+template <typename T>
+void ProxZero<T>::EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>&, T, bool) {
+  const size_t i = this->index_;
+  void* s = CurrentStream();
+  if (src.mode == PROST_ARG_PDHG_PRIMAL)
+    CheckHip(Api<T>::pdhg_primal_arg(result.data() + i, src.v[0] + i, src.v[1] + i, src.v[2] + i, (double)src.s[0], this->size_, s), "primal_arg");
+  else if (src.mode == PROST_ARG_PDHG_DUAL)
+    CheckHip(Api<T>::pdhg_dual_arg(result.data() + i, src.v[0] + i, src.v[1] + i, src.v[2] + i, src.v[3] + i, (double)src.s[0], (double)src.s[1], this->size_, s), "dual_arg");
+  else throw Exception("ProxZero: unknown argument source.");
+}
 template <typename T>
 void ProxZero<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*, const T*, T, bool) {
   if (res != arg) CheckHip(prost_hip_memcpy_d2d(res, arg, this->size_ * sizeof(T), CurrentStream()), "memcpy_d2d");

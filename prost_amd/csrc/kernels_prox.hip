@@ -15,6 +15,35 @@ struct Coeffs {
   T val[7];
 };
 
+// Where the prox argument comes from.  ARG = 0: the `arg` vector.  ARG = 1 / 2: the PDHG prox arguments are formed
+// on the fly from the iterate and the operator product, with the expressions of primal_proxarg_functor /
+// dual_proxarg_functor (backend_pdhg.cu:38-70) -- the separate argument pass (write + re-read of one vector per
+// prox) disappears, the values are bit-identical.
+template <class T>
+struct ArgSrc {
+  const T* v0; const T* v1; const T* v2; const T* v3;      // ARG 0: v0 = arg.  1: x, T, K^T y.  2: y, Sigma, K x, K x_prev
+  T s0, s1;                                                //                   1: tau          2: sigma, theta
+};
+template <class T, int ARG>
+__device__ __forceinline__ T arg_formula(const ArgSrc<T>& a, T p0, T p1, T p2, T p3) {
+  if (ARG == 1) return p0 - a.s0 * p1 * p2;
+  return p0 + a.s0 * p1 * ((1 + a.s1) * p2 - a.s1 * p3);
+}
+template <class T, int VEC, int ARG>
+__device__ __forceinline__ void load_arg(const ArgSrc<T>& a, size_t off, T (&out)[VEC]) {
+  if (ARG == 0) { ldv<T, VEC>(a.v0 + off, out); return; }
+  T p0[VEC], p1[VEC], p2[VEC], p3[VEC];
+  ldv<T, VEC>(a.v0 + off, p0); ldv<T, VEC>(a.v1 + off, p1); ldv<T, VEC>(a.v2 + off, p2);
+  if (ARG == 2) ldv<T, VEC>(a.v3 + off, p3);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) out[j] = arg_formula<T, ARG>(a, p0[j], p1[j], p2[j], ARG == 2 ? p3[j] : (T)0);
+}
+template <class T, int ARG>
+__device__ __forceinline__ T load_arg1(const ArgSrc<T>& a, size_t off) {
+  if (ARG == 0) return a.v0[off];
+  return arg_formula<T, ARG>(a, a.v0[off], a.v1[off], a.v2[off], ARG == 2 ? a.v3[off] : (T)0);
+}
+
 // MOREAU: the prox of the CONJUGATE in the same pass (ProxMoreau::EvalLocal, prox_moreau.cu:98-134, around an
 // elem operation): arg is pre-scaled per element (MoreauPrescale :29-43), the elem operation runs with the inverted
 // step, and the result is post-scaled (MoreauPostscale :45-61) -- 3 values per element through HBM instead of 9.
@@ -22,8 +51,8 @@ struct Coeffs {
 template <class T> __device__ __forceinline__ T moreau_pre(T a, T tau, T td, bool inv) { return inv ? a * (tau * td) : a / (tau * td); }
 template <class T> __device__ __forceinline__ T moreau_post(T a, T r, T tau, T td, bool inv) { return inv ? a - r / (tau * td) : a - tau * td * r; }
 
-template <class T, int OP, bool MOREAU>
-__global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, const T* __restrict__ arg,
+template <class T, int OP, bool MOREAU, int ARG>
+__global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, ArgSrc<T> arg,
                                                            const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                            size_t count, size_t dim, bool interleaved, int fn, Coeffs<T> cf) {
   const bool inner_inv = MOREAU ? !invert_tau : invert_tau;      // step flag the elem operation sees
@@ -33,7 +62,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
     for (int i = 0; i < 7; i++) c[i] = cf.ptr[i] ? cf.ptr[i][tx] : cf.val[i];
     if (OP == PROST_OP_1D) {
       // Vector index with dim = 1: both layouts give tx (vector.hpp:44-48)
-      const T td = tau_diag[tx], a = arg[tx];
+      const T td = tau_diag[tx], a = load_arg1<T, ARG>(arg, tx);
       const T tau = elem_tau<T>(tau_scal, td, inner_inv);
       const T r = elem_1d<T>(fn, MOREAU ? moreau_pre<T>(a, tau_scal, td, invert_tau) : a, tau, c);
       res[tx] = MOREAU ? moreau_post<T>(a, r, tau_scal, td, invert_tau) : r;
@@ -43,7 +72,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
       const size_t stride = interleaved ? 1 : count;
       T norm = 0;
       for (size_t i = 0; i < dim; i++) {
-        T v = arg[base + i * stride];
+        T v = load_arg1<T, ARG>(arg, base + i * stride);
         if (MOREAU) v = moreau_pre<T>(v, tau_scal, tau_diag[base + i * stride], invert_tau);
         norm += v * v;
       }
@@ -54,7 +83,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
         pr = scaled_prox<T>(fn, norm, tau, c);
       }
       for (size_t i = 0; i < dim; i++) {
-        const T a = arg[base + i * stride];
+        const T a = load_arg1<T, ARG>(arg, base + i * stride);
         const T td = MOREAU ? tau_diag[base + i * stride] : (T)0;
         const T v = MOREAU ? moreau_pre<T>(a, tau_scal, td, invert_tau) : a;
         const T r = norm > 0 ? pr * v / norm : (T)0;
@@ -68,8 +97,8 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
 // consecutive elements per component (float4 / double2), so every access of a wave is one 1-KiB
 // transaction and the per-element coefficient vectors are read with the same width.  DIM > 0 keeps
 // the components in registers; DIM == 0 (any dimension) makes a second pass over arg (L2 hits).
-template <class T, int OP, int DIM, bool MOREAU>
-__global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ res, const T* __restrict__ arg,
+template <class T, int OP, int DIM, bool MOREAU, int ARG>
+__global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ res, ArgSrc<T> arg,
                                                                const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                                size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one) {
   constexpr int VEC = VecOf<T>::N;
@@ -88,7 +117,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
     const bool inner_inv = MOREAU ? !invert_tau : invert_tau;
     if (OP == PROST_OP_1D) {
       T a[VEC], out[VEC];
-      ldv<T, VEC>(arg + t0, a);
+      load_arg<T, VEC, ARG>(arg, t0, a);
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         T cc[7];
@@ -105,7 +134,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
       if (DIM > 0) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
-          ldv<T, VEC>(arg + t0 + (size_t)i * count, v[i]);
+          load_arg<T, VEC, ARG>(arg, t0 + (size_t)i * count, v[i]);
           if (MOREAU) {
             if (i == 0) {
 #pragma unroll
@@ -121,7 +150,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
       } else {
         for (size_t i = 0; i < dim; i++) {
           T w[VEC], tw[VEC];
-          ldv<T, VEC>(arg + t0 + i * count, w);
+          load_arg<T, VEC, ARG>(arg, t0 + i * count, w);
           if (MOREAU) ldv<T, VEC>(tau_diag + t0 + i * count, tw);
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
@@ -159,7 +188,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
       } else {
         for (size_t i = 0; i < dim; i++) {
           T w[VEC], tw[VEC], out[VEC];
-          ldv<T, VEC>(arg + t0 + i * count, w);
+          load_arg<T, VEC, ARG>(arg, t0 + i * count, w);
           if (MOREAU) ldv<T, VEC>(tau_diag + t0 + i * count, tw);
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
@@ -175,8 +204,8 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
   }
 }
 
-template <class T, bool MOREAU>
-static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_diag, double tau, int invert, size_t count,
+template <class T, bool MOREAU, int ARG>
+static int launch_prox_elem(int op, int fn, T* res, const ArgSrc<T>& arg, const T* tau_diag, double tau, int invert, size_t count,
                             size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
   if (fn < 0 || fn >= PROST_FN_COUNT) { set_error("prox_elem: unknown function id"); return 1; }
   if (op != PROST_OP_1D && op != PROST_OP_NORM2) { set_error("prox_elem: unknown elem operation"); return 1; }
@@ -185,12 +214,14 @@ static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_d
   for (int i = 0; i < 7; i++) { cf.ptr[i] = coeff_ptr ? coeff_ptr[i] : nullptr; cf.val[i] = (T)coeff_val[i]; }
   hipStream_t s = as_stream(stream);
   constexpr int V = VecOf<T>::N;
-  bool vec = (op == PROST_OP_1D || !interleaved || dim == 1) && count % V == 0 && aligned16(res) && aligned16(arg) && aligned16(tau_diag);
+  bool vec = (op == PROST_OP_1D || !interleaved || dim == 1) && count % V == 0 && aligned16(res) && aligned16(arg.v0) && aligned16(tau_diag);
+  if (ARG >= 1) vec = vec && aligned16(arg.v1) && aligned16(arg.v2);
+  if (ARG == 2) vec = vec && aligned16(arg.v3);
   for (int i = 0; i < 7; i++) vec = vec && aligned16(cf.ptr[i]);
   if (vec) {
     const bool e_zero = !cf.ptr[4] && cf.val[4] == (T)0, a_one = !cf.ptr[0] && cf.val[0] == (T)1;
     dim3 g(grid_for(count / V)), b(kBlock);
-#define GO(OPv, DIMv) hipLaunchKernelGGL((prox_elem_vec_kernel<T, OPv, DIMv, MOREAU>), g, b, 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, fn, cf, e_zero, a_one)
+#define GO(OPv, DIMv) hipLaunchKernelGGL((prox_elem_vec_kernel<T, OPv, DIMv, MOREAU, ARG>), g, b, 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, fn, cf, e_zero, a_one)
     if (op == PROST_OP_1D) GO(PROST_OP_1D, 1);
     else if (dim == 1) GO(PROST_OP_NORM2, 1);
     else if (dim == 2) GO(PROST_OP_NORM2, 2);
@@ -201,10 +232,34 @@ static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_d
     PH_LAUNCH_END("prox_elem kernel");
   }
   if (op == PROST_OP_1D)
-    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_1D, MOREAU>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, (size_t)1, interleaved != 0, fn, cf);
+    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_1D, MOREAU, ARG>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, (size_t)1, interleaved != 0, fn, cf);
   else
-    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_NORM2, MOREAU>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, interleaved != 0, fn, cf);
+    hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_NORM2, MOREAU, ARG>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, interleaved != 0, fn, cf);
   PH_LAUNCH_END("prox_elem kernel");
+}
+
+template <class T, bool MOREAU>
+static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_diag, double tau, int invert, size_t count,
+                            size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
+  return launch_prox_elem<T, MOREAU, 0>(op, fn, res, ArgSrc<T>{arg, nullptr, nullptr, nullptr, (T)0, (T)0}, tau_diag, tau, invert, count, dim, interleaved,
+                                        coeff_ptr, coeff_val, stream);
+}
+
+template <class T>
+static int launch_prox_elem_arg(int op, int fn, int moreau, T* res, const prost_hip_arg_spec* a, const T* tau_diag, double tau, int invert, size_t count,
+                                size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
+  if (!a) { set_error("prox_elem_arg: argument source required"); return 1; }
+  const ArgSrc<T> src{static_cast<const T*>(a->v[0]), static_cast<const T*>(a->v[1]), static_cast<const T*>(a->v[2]), static_cast<const T*>(a->v[3]),
+                      (T)a->s[0], (T)a->s[1]};
+  if (src.v0 == res) { set_error("prox_elem_arg: the result must not alias the argument source"); return 1; }
+#define GO(M, A) return launch_prox_elem<T, M, A>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream)
+  switch (a->mode) {
+    case PROST_ARG_PLAIN: if (moreau) GO(true, 0); else GO(false, 0);
+    case PROST_ARG_PDHG_PRIMAL: if (moreau) GO(true, 1); else GO(false, 1);
+    case PROST_ARG_PDHG_DUAL: if (moreau) GO(true, 2); else GO(false, 2);
+    default: set_error("prox_elem_arg: unknown argument mode"); return 1;
+  }
+#undef GO
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,6 +349,12 @@ int prost_hip_prox_elem_moreau_f32(int op, int fn, float* res, const float* arg,
 }
 int prost_hip_prox_elem_moreau_f64(int op, int fn, double* res, const double* arg, const double* td, double tau, int inv, size_t count, size_t dim, int il, const double* const* cp, const double* cv, void* s) {
   return launch_prox_elem<double, true>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
+}
+int prost_hip_prox_elem_arg_f32(int op, int fn, int moreau, float* res, const prost_hip_arg_spec* a, const float* td, double tau, int inv, size_t count, size_t dim, int il, const float* const* cp, const double* cv, void* s) {
+  return launch_prox_elem_arg<float>(op, fn, moreau, res, a, td, tau, inv, count, dim, il, cp, cv, s);
+}
+int prost_hip_prox_elem_arg_f64(int op, int fn, int moreau, double* res, const prost_hip_arg_spec* a, const double* td, double tau, int inv, size_t count, size_t dim, int il, const double* const* cp, const double* cv, void* s) {
+  return launch_prox_elem_arg<double>(op, fn, moreau, res, a, td, tau, inv, count, dim, il, cp, cv, s);
 }
 int prost_hip_prox_epi_quad_f32(float* res, const float* arg, size_t count, size_t dim, const float* a_ptr, double a_val, const float* b_ptr, const float* c_ptr, double c_val, void* s) {
   if (count == 0) return 0;

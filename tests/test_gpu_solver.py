@@ -42,7 +42,7 @@ def run_product(prob, backend, opts, iters):
 
 def run_oracle(prob, backend, opts, iters, dtype):
     prob.finalize()
-    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg")}]
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion")}]
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
     s.initialize()
     s.iterate(iters)
@@ -178,14 +178,49 @@ def tvl1_like_problem(nx, ny, seed=0):
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
-def test_generic_pdhg_on_mixed_blocks(precision, dtype):
+@pytest.mark.parametrize("arg_fusion", [True, False])
+def test_generic_pdhg_on_mixed_blocks(precision, dtype, arg_fusion):
+    """arg_fusion: the proxes form the PDHG prox arguments on the fly (prost_hip_prox_elem_arg_*) instead of reading
+    a separately written argument vector -- same bits either way."""
     prost.set_precision(precision)
     prob = tvl1_like_problem(24, 18)
     b = prost.backend.pdhg(stepsize="boyd", residual_iter=5)
+    b[1]["allow_arg_fusion"] = arg_fusion
     o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
     st = run_product(prob, b, o, 60)
     assert st["path"] == "pdhg:generic"
     assert_same_iterates(st, run_oracle(prob, b, o, 60, dtype))
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("arg_fusion", [True, False])
+def test_generic_pdhg_arg_sources_cover_every_prox_kind(precision, dtype, arg_fusion):
+    """Generic path (allow_fused off) on ROF-like problems whose prox lists mix the kinds that evaluate from an
+    argument source: elem 1d with vector coefficients, norm2 of dims 2 / 3 / 7 (register and two-pass kernels),
+    conjugated elem operations (prox_f given -> Moreau), the identity prox of an uncovered range, ragged counts
+    (scalar kernels).  Against the oracle, bit for bit."""
+    prost.set_precision(precision)
+    rng = np.random.default_rng(11)
+    cases = []
+    for (nx, ny, L) in ((20, 16, 1), (9, 7, 3)):            # 9*7*3 = 189 elements: not a multiple of the vector width
+        prob, u, q, f = synthetic.rof_problem(nx, ny, L, seed=3)
+        cases.append(prob)
+    # uncovered primal range (identity prox inserted by the problem) + prox_f (Moreau) on a 7-component norm
+    n = 28
+    u = prost.variable(n + 5); q = prost.variable(7 * 8)
+    prob = prost.min_max_problem([u], [q])
+    A = sp.random(7 * 8, n + 5, density=0.3, random_state=5, format="csc")
+    prob.add_dual_pair(u, q, prost.block.sparse(A))
+    prob.add_function(q, prost.function.conjugate(prost.function.sum_norm2(7, False, "huber", 1, 0, 1, 0, 0, 0.3)))
+    cases.append(prob)
+    for prob in cases:
+        b = prost.backend.pdhg(stepsize="alg1", residual_iter=3)
+        b[1]["allow_fused"] = False
+        b[1]["allow_arg_fusion"] = arg_fusion
+        o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+        st = run_product(prob, b, o, 30)
+        assert st["path"] == "pdhg:generic"
+        assert_same_iterates(st, run_oracle(prob, b, o, 30, dtype))
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)

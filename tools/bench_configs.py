@@ -3,7 +3,7 @@
   c3  : 2048x2048x64 volumetric TV (gradient3d + sum_norm2(3) + sum_1d square), PDHG alg2
   c4  : TV-L1 flow-like (block.sparse W + gradient2d(L=2), sum_1d abs + sum_norm2(4) abs), ADMM
   c1  : 256x256 ROF (plumbing size)
-usage: python tools/bench_configs.py c3 [nx ny L] | c4 [N [device|host]] | c1
+usage: python tools/bench_configs.py c3 [nx ny L] | c4 [N [device|host|pdhg]] | c1
 """
 import json
 import os
@@ -55,11 +55,12 @@ def main():
         prob.add_function(g, prost.function.sum_norm2(4, False, "abs"))
         prob.add_constraint(u, v, prost.block.sparse(W))
         prob.add_constraint(u, g, prost.block.gradient2d(N, N, 2))
-        for device_cg in ((True, False) if len(sys.argv) <= 3 else (sys.argv[3] == "device",)):
+        modes = (True, False) if len(sys.argv) <= 3 else () if sys.argv[3] == "pdhg" else (sys.argv[3] == "device",)
+        for device_cg in modes:
             b = prost.backend.admm(rho0=1)
             b[1]["device_cg"] = device_cg
             run(prob, b, 100, 5, None, n, "TV-L1 flow-like %dx%d fp32 ADMM (block.sparse + gradient2d L=2), %s CG scalars" % (N, N, "device" if device_cg else "host"))
-        if len(sys.argv) <= 3:
+        if len(sys.argv) <= 3 or sys.argv[3] == "pdhg":
             run(prob, prost.backend.pdhg(stepsize="boyd", residual_iter=10), 200, 10, None, n, "TV-L1 flow-like %dx%d fp32 PDHG generic path" % (N, N))
     else:
         prob, u, q, f = synthetic.rof_problem(256, 256)
