@@ -34,6 +34,7 @@ class ProxElemOperation : public ProxSeparableSum<T> {
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
+  void CoeffArgs(const T* (&ptrs)[7], double (&vals)[7]) const;
   int op_, fn_;
   std::array<std::vector<T>, 7> coeffs_;
   std::array<device_vector<T>, 7> d_coeffs_;

@@ -64,27 +64,27 @@ bool ProxElemOperation<T>::describe(ProxDesc& d) const {
   }
   return true;
 }
+/// device pointer (per-element coefficient) or scalar value of each of the seven coefficients, as the kernels take them
 template <typename T>
-void ProxElemOperation<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T* tau_diag, const T*, T tau, bool invert_tau) {
-  const T* ptrs[7]; double vals[7];
+void ProxElemOperation<T>::CoeffArgs(const T* (&ptrs)[7], double (&vals)[7]) const {
   for (int i = 0; i < 7; i++) {
     if (coeffs_[i].size() > 1) {
       if (d_coeffs_[i].size() != coeffs_[i].size()) throw Exception("ProxElemOperation used before Initialize().");
       ptrs[i] = d_coeffs_[i].data(); vals[i] = 0;
     } else { ptrs[i] = nullptr; vals[i] = (double)coeffs_[i][0]; }
   }
+}
+template <typename T>
+void ProxElemOperation<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T* tau_diag, const T*, T tau, bool invert_tau) {
+  const T* ptrs[7]; double vals[7];
+  CoeffArgs(ptrs, vals);
   CheckHip(Api<T>::prox_elem(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
                              this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem");
 }
 template <typename T>
 void ProxElemOperation<T>::EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau) {
   const T* ptrs[7]; double vals[7];
-  for (int i = 0; i < 7; i++) {
-    if (coeffs_[i].size() > 1) {
-      if (d_coeffs_[i].size() != coeffs_[i].size()) throw Exception("ProxElemOperation used before Initialize().");
-      ptrs[i] = d_coeffs_[i].data(); vals[i] = 0;
-    } else { ptrs[i] = nullptr; vals[i] = (double)coeffs_[i][0]; }
-  }
+  CoeffArgs(ptrs, vals);
   CheckHip(Api<T>::prox_elem_moreau(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
                                     this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem_moreau");
 }
@@ -92,12 +92,7 @@ template <typename T>
 void ProxElemOperation<T>::EvalSourceLocal(bool moreau, device_vector<T>& result, const typename Prox<T>::ArgSource& src,
                                            const device_vector<T>& tau_diag, T tau, bool invert_tau) {
   const T* ptrs[7]; double vals[7];
-  for (int i = 0; i < 7; i++) {
-    if (coeffs_[i].size() > 1) {
-      if (d_coeffs_[i].size() != coeffs_[i].size()) throw Exception("ProxElemOperation used before Initialize().");
-      ptrs[i] = d_coeffs_[i].data(); vals[i] = 0;
-    } else { ptrs[i] = nullptr; vals[i] = (double)coeffs_[i][0]; }
-  }
+  CoeffArgs(ptrs, vals);
   prost_hip_arg_spec a;
   a.mode = src.mode;
   for (int k = 0; k < 4; k++) a.v[k] = src.v[k] ? src.v[k] + this->index_ : nullptr;
