@@ -51,6 +51,12 @@ int prost_hip_stream_create(void** stream);
 int prost_hip_stream_destroy(void* stream);
 int prost_hip_stream_synchronize(void* stream);
 int prost_hip_device_synchronize(void);
+/* HIP graphs: the launches enqueued on `stream` between begin and end are recorded instead of executed;
+ * end returns an executable graph that replays them with one host call (launch-bound inner loops). */
+int prost_hip_stream_begin_capture(void* stream);
+int prost_hip_stream_end_capture(void* stream, void** graph_exec);
+int prost_hip_graph_launch(void* graph_exec, void* stream);
+int prost_hip_graph_destroy(void* graph_exec);
 int prost_hip_event_create(void** event);
 int prost_hip_event_destroy(void* event);
 int prost_hip_event_record(void* event, void* stream);
@@ -354,6 +360,8 @@ int prost_hip_admm_elem_f64(int op, double* o, const double* a, const double* b,
  * After the stopping test of cgls.hpp:355-360 fires the STEP stages return without touching x, so the
  * host may launch all maxit rounds without waiting; STEP_S additionally stores `epoch` to the pinned
  * host word `host_done` (may be NULL) so that a host that is not running ahead can stop launching.
+ * `tol` and `epoch` are read by INIT_X only (kept in the device record afterwards): the STEP launches of
+ * one solver are argument-identical from solve to solve and can be replayed from a captured HIP graph.
  * b, r, q: m elements; x, p, s: n elements; t: max(m, n) scratch; sigma (m) / tau (n) are the
  * preconditioner diagonals (the stages take the square roots, as gemv_functor1-3 do). */
 typedef struct prost_hip_cgls_desc {

@@ -28,6 +28,8 @@ namespace prost_hip {
 
 struct CgState {
   double gamma, norms0, norms, normx, xmax, alpha, neg_alpha, beta;
+  double tol;                      // stopping tolerance and epoch of the current solve: set by INIT_X, so that the
+  int epoch;                       // STEP launches take no per-solve argument (they can be replayed from a HIP graph)
   int done, k, indefinite, flag;
 };
 
@@ -86,6 +88,7 @@ __global__ void __launch_bounds__(kBlock) cg_scalar_kernel(CgState* stp, const d
   if (WHICH == kScalarsInitX) {                        // cgls.hpp:243-249, :281-282
     st.normx = sqrt(s0); st.xmax = st.normx;
     st.done = 0; st.k = 0; st.indefinite = 0; st.flag = 0;
+    st.tol = a.tol; st.epoch = a.epoch;
   } else if (WHICH == kScalarsInitS) {                 // :263-283
     st.norms = sqrt(s0); st.norms0 = st.norms;
     st.gamma = st.norms0 * st.norms0;
@@ -104,9 +107,9 @@ __global__ void __launch_bounds__(kBlock) cg_scalar_kernel(CgState* stp, const d
     st.beta = (double)(T)(st.gamma / gamma1);
     st.normx = sqrt(s1);
     st.xmax = st.xmax > st.normx ? st.xmax : st.normx;
-    if ((st.norms <= st.norms0 * a.tol) || (st.normx * a.tol >= 1.)) {
+    if ((st.norms <= st.norms0 * st.tol) || (st.normx * st.tol >= 1.)) {
       st.done = 1;
-      if (a.host_done) __hip_atomic_store(a.host_done, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (a.host_done) __hip_atomic_store(a.host_done, st.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
       st.k = st.k + 1;
     }

@@ -62,6 +62,20 @@ int prost_hip_event_record(void* e, void* s) { PH_CHECK(hipEventRecord((hipEvent
 int prost_hip_stream_wait_event(void* s, void* e) { PH_CHECK(hipStreamWaitEvent(as_stream(s), (hipEvent_t)e, 0)); return 0; }
 int prost_hip_event_synchronize(void* e) { PH_CHECK(hipEventSynchronize((hipEvent_t)e)); return 0; }
 int prost_hip_event_elapsed_ms(void* a, void* b, float* ms) { PH_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
+// ---- graphs: a captured launch sequence replayed with one host call ----
+int prost_hip_stream_begin_capture(void* s) { PH_CHECK(hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeThreadLocal)); return 0; }
+int prost_hip_stream_end_capture(void* s, void** exec) {
+  hipGraph_t g = nullptr;
+  PH_CHECK(hipStreamEndCapture(as_stream(s), &g));
+  hipGraphExec_t e = nullptr;
+  const hipError_t r = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (r != hipSuccess) return fail(r, "hipGraphInstantiate");
+  *exec = e;
+  return 0;
+}
+int prost_hip_graph_launch(void* exec, void* s) { PH_CHECK(hipGraphLaunch((hipGraphExec_t)exec, as_stream(s))); return 0; }
+int prost_hip_graph_destroy(void* exec) { if (exec) PH_CHECK(hipGraphExecDestroy((hipGraphExec_t)exec)); return 0; }
 int prost_hip_check_last_error(void) { PH_CHECK(hipGetLastError()); return 0; }
 
 // ---- RCCL ----

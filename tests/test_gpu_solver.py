@@ -42,7 +42,7 @@ def run_product(prob, backend, opts, iters):
 
 def run_oracle(prob, backend, opts, iters, dtype):
     prob.finalize()
-    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion")}]
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph")}]
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
     s.initialize()
     s.iterate(iters)
@@ -246,13 +246,15 @@ def test_admm_matches_oracle(precision, dtype, device_cg):
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("cg_graph", [False, True])
 @pytest.mark.parametrize("cg_tol_min,cg_max_iter", [(0.3, 10), (1e-2, 25), (1e-5, 3)])
-def test_admm_device_cg_stopping_rules(precision, dtype, cg_tol_min, cg_max_iter):
+def test_admm_device_cg_stopping_rules(precision, dtype, cg_tol_min, cg_max_iter, cg_graph):
     """Early convergence (rounds queued after the stopping test must not touch x), the iteration cap,
     and odd sizes (vector tails) -- iterates and CG iteration counts against the oracle."""
     prost.set_precision(precision)
     prob = tvl1_like_problem(23, 19, seed=3)
     b = prost.backend.admm(rho0=2, residual_iter=1, cg_tol_min=cg_tol_min, cg_tol_max=cg_tol_min * 1e-3, cg_max_iter=cg_max_iter)
+    b[1]["cg_graph"] = cg_graph          # the CG rounds replayed from a captured HIP graph (opt-in) or launched directly
     o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
     tol = 5e-4 if dtype == np.float32 else 1e-9
     seen = set()

@@ -59,6 +59,7 @@ def main():
         for device_cg in modes:
             b = prost.backend.admm(rho0=1)
             b[1]["device_cg"] = device_cg
+            b[1]["cg_graph"] = os.environ.get("PROST_CG_GRAPH", "0") == "1"
             run(prob, b, 100, 5, None, n, "TV-L1 flow-like %dx%d fp32 ADMM (block.sparse + gradient2d L=2), %s CG scalars" % (N, N, "device" if device_cg else "host"))
         if len(sys.argv) <= 3 or sys.argv[3] == "pdhg":
             run(prob, prost.backend.pdhg(stepsize="boyd", residual_iter=10), 200, 10, None, n, "TV-L1 flow-like %dx%d fp32 PDHG generic path" % (N, N))
