@@ -305,6 +305,18 @@ int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int d
  * square or abs with scalar a = 1, d = e = 0, prox_f* ind_leq0 with scalar a = 1, d = e = 0), which has a straight-line
  * instance; other function pairs are supported but register-bound (about 5x slower), so callers pair only here */
 int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int dtype);
+
+/* ONE kernel per iteration for gradient3d problems (kernels_fused_iter3d.hip): x_new = prox_g(x - tau T K^T y),
+ * y_new = prox_f*(y + sigma S K(x_new + theta (x_new - x))) with x_new of plane l+1 recomputed in registers
+ * (BackendPDHG::PerformIteration, backend_pdhg.cu:313-381, with BlockGradient3D, block_gradient3d.cu:25-150).
+ * Outputs must not alias inputs.  Supported when ny is a multiple of the vector width (4 floats / 2 doubles), the
+ * coefficients of prox_f* are scalars and at most b of prox_g is a per-voxel vector; no residual sums (residual
+ * iterations use prost_hip_fused_primal / _dual).  cols = columns per wavefront chunk (0 = automatic). */
+int prost_hip_fused_iteration3d_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
+int prost_hip_fused_iteration3d_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, double tau, double sigma,
+                                    double theta, int use_kty, int use_kx_prev, int cols, void* stream);
+int prost_hip_fused_iteration3d_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
+                                    double theta, int use_kty, int use_kx_prev, int cols, void* stream);
 int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y,
                                    float* x_mid, float* y_mid, const double* tau, const double* sigma, const double* theta,
                                    int cols_per_block, double* res_out4, void* workspace, void* stream);

@@ -100,6 +100,7 @@ void BackendPDHG<T>::Initialize() {
   for (auto& p : prox_g_) arg_fused_g_ = arg_fused_g_ && p->supports_arg_source();
   for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
   single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
+  single3d_ = fused_ && !single_kernel_ && opts_.allow_single_kernel && prost_hip_fused_iteration3d_supported(&desc_, dtype_id<T>()) == 1;
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
@@ -259,6 +260,19 @@ void BackendPDHG<T>::IterationFused(bool res) {
     y_.swap(y_prev_);
     prev_stale_ = false;
     if (res) FinishResiduals();
+    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+    iteration_++;
+    return;
+  }
+  if (single3d_ && !res) {
+    // gradient3d, no residual sums wanted: one kernel, x_new stays in registers (9 instead of 14 values per voxel);
+    // outputs go to the previous-iterate buffers, which this iteration does not read
+    const bool t3 = BeginSample(kKernelIter);
+    CheckHip(Api<T>::fused_iteration3d(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
+                                       iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, s), "fused_iteration3d");
+    EndSample(t3);
+    x_.swap(x_prev_);
+    y_.swap(y_prev_);
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
     return;
@@ -467,7 +481,7 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
-                                     "fused_iter2d_kernel", "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
+                                     d3 ? "fused_iter3d_kernel" : "fused_iter2d_kernel", "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
                                      "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++)

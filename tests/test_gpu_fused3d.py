@@ -74,9 +74,12 @@ def test_tv3d_pdhg_iterates_match_oracle(hip, precision, dtype, step):
     try:
         for (nx, ny, L) in ((12, 16, 5), (7, 1028, 2)):
             prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, seed=2)
-            for fused in (True, False):
+            for fused, single in ((True, True), (True, False), (False, False)):
+                # fused + single: one kernel per non-residual iteration (x_new of plane l+1 recomputed), two passes on residual
+                # iterations; fused only: two passes always; neither: the generic nine-vector path
                 b = prost.backend.pdhg(stepsize=step, residual_iter=3, alg2_gamma=0.5)
                 b[1]["allow_fused"] = fused
+                b[1]["allow_single_kernel"] = single
                 o = prost.options(max_iters=40, num_cback_calls=0, verbose=False)
                 s = prost.Solver(prob, b, o); s.iterate(40); st = s.state(); s.destroy()
                 assert st["path"] == ("pdhg:fused-grad3d" if fused else "pdhg:generic")
@@ -100,7 +103,7 @@ def test_tv3d_large_fused_equals_generic(hip):
         st = {}
         for fused in (True, False):
             b = prost.backend.pdhg(stepsize="alg2", residual_iter=4, alg2_gamma=0.5)
-            b[1]["allow_fused"] = fused
+            b[1]["allow_fused"] = fused           # True: one kernel per non-residual iteration, two passes on residual iterations
             s = prost.Solver(prob, b, o); s.iterate(12); st[fused] = s.state(); s.destroy()
         assert st[True]["path"] == "pdhg:fused-grad3d" and st[False]["path"] == "pdhg:generic"
         for v in "xyzw":
@@ -109,3 +112,47 @@ def test_tv3d_large_fused_equals_generic(hip):
         assert np.isclose(st[True]["primal_res"], st[False]["primal_res"], rtol=1e-5)
     finally:
         prost.set_precision("double")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(6, 8, 1), (5, 12, 4), (20, 1028, 3), (33, 64, 5), (3, 256, 2), (40, 508, 3)])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+@pytest.mark.parametrize("vector_b", [True, False])
+def test_single_kernel_3d_iteration_equals_two_passes(hip, dtype, shape, fns, vector_b):
+    """prost_hip_fused_iteration3d (x_new of plane l+1 recomputed in registers) against the two-pass kernels, which are
+    pinned to the oracle above: same bits for x_new and all three components of y_new, for every chunk width,
+    flag combination, plane count (incl. L = 1: no upper plane) and strip layout (1028 rows: five wavefront strips)."""
+    nx, ny, L = shape
+    g_fn, f_fn = fns
+    rng = np.random.default_rng(5)
+    n, m = nx * ny * L, 3 * nx * ny * L
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    tau, sigma, theta = dtype(0.9), dtype(1.1), dtype(0.85)
+    g_coeffs = [1.0, f if vector_b else 0.4, 10.0, 0.0, 0.0, 0.3, 0.0]
+    f_coeffs = [1.0, 1.0, 1.0, 0.0, 0.0, 0.3, 0.0]
+    d = hip.FusedDesc(); d.is3d = 1; d.nx, d.ny, d.L = nx, ny, L
+    d.g_fn = hip.FN_ID[g_fn]; d.f_fn = hip.FN_ID[f_fn]
+    gp, gv, k1 = hip.coeff_args(g_coeffs, dtype, n)
+    fp, fv, k2 = hip.coeff_args(f_coeffs, dtype, n)
+    for i in range(7):
+        d.g_coeff_ptr[i] = gp[i]; d.g_coeff_val[i] = gv[i]; d.f_coeff_ptr[i] = fp[i]; d.f_coeff_val[i] = fv[i]
+    d.T_val, d.S_val = 1.0 / 6.0, 0.5
+    dt = 0 if dtype == np.float32 else 1
+    vecw = 4 if dtype == np.float32 else 2
+    assert hip.lib().prost_hip_fused_iteration3d_supported(C.byref(d), dt) == (1 if ny % vecw == 0 else 0)
+    if ny % vecw:
+        return
+    ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    dx, dy = hip.DeviceArray.from_host(x), hip.DeviceArray.from_host(y)
+    for use_kty, use_kxp in ((1, 1), (0, 0), (1, 0)):
+        x_ref = hip.DeviceArray.zeros(n, dtype); y_ref = hip.DeviceArray.zeros(m, dtype)
+        hip.check(hip.fn("fused_primal", dtype)(C.byref(d), x_ref.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau), use_kty, 0, None, ws.ptr, None))
+        hip.check(hip.fn("fused_dual", dtype)(C.byref(d), y_ref.ptr, dy.ptr, x_ref.ptr, dx.ptr, hip.dbl(sigma), hip.dbl(theta), use_kxp, None, ws.ptr, None))
+        for cols in (0, 1, 2, 5, 64):
+            x_new = hip.DeviceArray.zeros(n, dtype); y_new = hip.DeviceArray.zeros(m, dtype)
+            hip.check(hip.fn("fused_iteration3d", dtype)(C.byref(d), x_new.ptr, y_new.ptr, dx.ptr, dy.ptr, hip.dbl(tau), hip.dbl(sigma), hip.dbl(theta),
+                                                         use_kty, use_kxp, cols, None))
+            assert np.array_equal(x_new.to_host(), x_ref.to_host()), (cols, use_kty)
+            assert np.array_equal(y_new.to_host(), y_ref.to_host()), (cols, use_kty, use_kxp)
+    hip.sync()
