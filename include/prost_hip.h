@@ -310,13 +310,17 @@ int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int 
  * y_new = prox_f*(y + sigma S K(x_new + theta (x_new - x))) with x_new of plane l+1 recomputed in registers
  * (BackendPDHG::PerformIteration, backend_pdhg.cu:313-381, with BlockGradient3D, block_gradient3d.cu:25-150).
  * Outputs must not alias inputs.  Supported when ny is a multiple of the vector width (4 floats / 2 doubles), the
- * coefficients of prox_f* are scalars and at most b of prox_g is a per-voxel vector; no residual sums (residual
- * iterations use prost_hip_fused_primal / _dual).  cols = columns per wavefront chunk (0 = automatic). */
+ * coefficients of prox_f* are scalars and at most b of prox_g is a per-voxel vector.  res_out4 != NULL (residual
+ * iterations): y_prev = y^(k-1) is streamed too and res_out4 receives {primal diff^2, primal var^2, dual diff^2,
+ * dual var^2} as prost_hip_fused_iteration does (workspace: prost_hip_reduce_workspace_bytes(); y_new must then not
+ * alias y_prev).  cols = columns per wavefront chunk (0 = automatic). */
 int prost_hip_fused_iteration3d_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
-int prost_hip_fused_iteration3d_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, double tau, double sigma,
-                                    double theta, int use_kty, int use_kx_prev, int cols, void* stream);
-int prost_hip_fused_iteration3d_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
-                                    double theta, int use_kty, int use_kx_prev, int cols, void* stream);
+int prost_hip_fused_iteration3d_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
+                                    double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,
+                                    void* workspace, void* stream);
+int prost_hip_fused_iteration3d_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev,
+                                    double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,
+                                    void* workspace, void* stream);
 int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y,
                                    float* x_mid, float* y_mid, const double* tau, const double* sigma, const double* theta,
                                    int cols_per_block, double* res_out4, void* workspace, void* stream);

@@ -104,7 +104,7 @@ void BackendPDHG<T>::Initialize() {
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
-  if (single_kernel_) y_spare_.resize(m);
+  if (single_kernel_ || single3d_) y_spare_.resize(m);
   pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_profitable(&desc_, dtype_id<T>()) == 1;
   if (pair_kernel_) x_spare_.resize(n);
 
@@ -264,15 +264,20 @@ void BackendPDHG<T>::IterationFused(bool res) {
     iteration_++;
     return;
   }
-  if (single3d_ && !res) {
-    // gradient3d, no residual sums wanted: one kernel, x_new stays in registers (9 instead of 14 values per voxel);
-    // outputs go to the previous-iterate buffers, which this iteration does not read
-    const bool t3 = BeginSample(kKernelIter);
-    CheckHip(Api<T>::fused_iteration3d(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
-                                       iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, s), "fused_iteration3d");
+  if (single3d_) {
+    // gradient3d: one kernel, x_new stays in registers (9 instead of 14 values per voxel; residual iterations add the
+    // y_prev stream of the own plane and the four sums).  Outputs go to the previous-iterate buffers, which a
+    // non-residual iteration does not read; on residual iterations y_new goes to y_spare_ (the kernel still reads y_prev_).
+    T* y_out = res ? y_spare_.data() : y_prev_.data();
+    const bool t3 = BeginSample(res ? kKernelIterRes : kKernelIter);
+    CheckHip(Api<T>::fused_iteration3d(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
+                                       (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
+                                       res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration3d");
     EndSample(t3);
     x_.swap(x_prev_);
+    if (res) y_prev_.swap(y_spare_);
     y_.swap(y_prev_);
+    if (res) FinishResiduals();
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
     return;
@@ -481,7 +486,7 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
-                                     d3 ? "fused_iter3d_kernel" : "fused_iter2d_kernel", "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
+                                     d3 ? "fused_iter3d_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
                                      "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++)

@@ -39,7 +39,7 @@ __host__ __device__ inline double* region(double* ws, int r) { return ws + (size
 template <class T, int VEC, class F>
 __global__ void __launch_bounds__(kBlock) cg_stage_kernel(F f, size_t n0, size_t n1, const CgState* st, double* ws) {
   if (F::kSkipWhenDone && st->done) return;
-  f.load(*st);
+  f.load(st);
   double sa = 0, sb = 0;
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, stride = (size_t)gridDim.x * kBlock;
   {
@@ -123,7 +123,7 @@ template <class T> struct InitX {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = kRegionX, kRegion2 = -1;
   const T* x; const T* tau; T* t; T* s; T negshift;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double& sa, double&) const {
     T xv[V], dv[V], tv[V], sv[V];
     ldv<T, V>(x + i, xv); ldv<T, V>(tau + i, dv);
@@ -143,7 +143,7 @@ template <class T> struct InitR {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* b; const T* sigma; T* r;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T bv[V], dv[V], rv[V];
     ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv);
@@ -159,7 +159,7 @@ template <class T> struct InitR2 {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* b; const T* sigma; T* r; T* t; bool nonzero;
-  __device__ void load(const CgState& st) { nonzero = st.normx > 0.; }
+  __device__ void load(const CgState* st) { nonzero = st->normx > 0.; }
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T bv[V], dv[V], rv[V], tv[V];
     ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv); ldv<T, V>(r + i, rv);
@@ -179,7 +179,7 @@ template <class T> struct InitS {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = kRegionS, kRegion2 = kRegionP;
   T* s; T* p; T* t; const T* tau;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double& sa, double&) const {
     T sv[V], dv[V], tv[V];
     ldv<T, V>(s + i, sv); ldv<T, V>(tau + i, dv);
@@ -199,7 +199,7 @@ template <class T> struct StepQ {
   static constexpr bool kSkipWhenDone = true, kTwoRanges = false;
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
   T* q; const T* sigma;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double& sa, double&) const {
     T qv[V], dv[V];
     ldv<T, V>(q + i, qv); ldv<T, V>(sigma + i, dv);
@@ -219,7 +219,7 @@ template <class T> struct StepXR {
   static constexpr int kRegion = kRegionX, kRegion2 = -1;
   T* x; const T* p; T* s; const T* tau; T* r; const T* q; const T* sigma; T* t; T negshift;
   T alpha, neg_alpha;
-  __device__ void load(const CgState& st) { alpha = (T)st.alpha; neg_alpha = (T)st.neg_alpha; }
+  __device__ void load(const CgState* st) { alpha = (T)st->alpha; neg_alpha = (T)st->neg_alpha; }
   template <int V> __device__ void range0(size_t i, double& sa, double&) const {
     T xv[V], pv[V], dv[V], sv[V];
     ldv<T, V>(x + i, xv); ldv<T, V>(p + i, pv); ldv<T, V>(tau + i, dv);
@@ -247,7 +247,7 @@ template <class T> struct StepS {
   static constexpr bool kSkipWhenDone = true, kTwoRanges = false;
   static constexpr int kRegion = kRegionS, kRegion2 = -1;
   T* s; const T* tau;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double& sa, double&) const {
     T sv[V], dv[V];
     ldv<T, V>(s + i, sv); ldv<T, V>(tau + i, dv);
@@ -265,7 +265,7 @@ template <class T> struct StepP {
   static constexpr bool kSkipWhenDone = true, kTwoRanges = false;
   static constexpr int kRegion = kRegionP, kRegion2 = -1;
   T* p; const T* s; T* t; const T* tau; T beta;
-  __device__ void load(const CgState& st) { beta = (T)st.beta; }
+  __device__ void load(const CgState* st) { beta = (T)st->beta; }
   template <int V> __device__ void range0(size_t i, double& sa, double&) const {
     T pv[V], sv[V], dv[V], tv[V];
     ldv<T, V>(p + i, pv); ldv<T, V>(s + i, sv); ldv<T, V>(tau + i, dv);
@@ -291,7 +291,7 @@ template <class T> struct AdmmPreX {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* x_half; T* x_proj; const T* x_dual; const T* tau; T* temp1; T* temp3; T alpha;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T a[V], b[V], c[V], d[V], w[V], o[V], t[V];
     ldv<T, V>(x_half + i, a); ldv<T, V>(x_proj + i, b); ldv<T, V>(x_dual + i, c); ldv<T, V>(tau + i, d); ldv<T, V>(temp3 + i, w);
@@ -311,7 +311,7 @@ template <class T> struct AdmmPreZ {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* z_half; T* z_dual; const T* sigma; T* temp2;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T a[V], b[V], d[V], o[V], z[V];
     ldv<T, V>(z_half + i, a); ldv<T, V>(z_dual + i, b); ldv<T, V>(sigma + i, d);
@@ -330,7 +330,7 @@ template <class T> struct AdmmPreZ2 {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   T* z_dual; const T* sigma;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T z[V], d[V];
     ldv<T, V>(z_dual + i, z); ldv<T, V>(sigma + i, d);
@@ -345,7 +345,7 @@ template <class T> struct AdmmPostX {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   T* x_proj; const T* temp1; const T* tau; T* temp3;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T x[V], a[V], d[V], o[V];
     ldv<T, V>(x_proj + i, x); ldv<T, V>(temp1 + i, a); ldv<T, V>(tau + i, d);
@@ -362,7 +362,7 @@ template <class T> struct AdmmPostXZ {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = true;
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* x_proj; T* x_dual; T* temp1; const T* tau; const T* z_proj; T* z_dual; T* temp2; const T* sigma;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T a[V], b[V], d[V], u[V], o[V];
     ldv<T, V>(temp1 + i, a); ldv<T, V>(x_proj + i, b); ldv<T, V>(tau + i, d);
@@ -396,7 +396,7 @@ template <class T> struct AdmmResZ {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
   T* kx; const T* z_half; const T* z_proj; const T* z_dual; const T* sigma; T rho;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double& sa, double& sb) const {
     T k[V], h[V], pj[V], du[V], d[V], y[V];
     ldv<T, V>(kx + i, k); ldv<T, V>(z_half + i, h); ldv<T, V>(z_proj + i, pj); ldv<T, V>(z_dual + i, du); ldv<T, V>(sigma + i, d);
@@ -419,7 +419,7 @@ template <class T> struct AdmmResX {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = kRegionP, kRegion2 = -1;
   const T* kty; const T* x_half; const T* x_proj; const T* x_dual; const T* tau; T rho;
-  __device__ void load(const CgState&) {}
+  __device__ void load(const CgState*) {}
   template <int V> __device__ void range0(size_t i, double& sa, double& sb) const {
     T k[V], h[V], pj[V], du[V], d[V];
     ldv<T, V>(kty + i, k); ldv<T, V>(x_half + i, h); ldv<T, V>(x_proj + i, pj); ldv<T, V>(x_dual + i, du); ldv<T, V>(tau + i, d);
@@ -519,8 +519,8 @@ static int admm_stage(int stage, const prost_hip_admm_desc* d, void* stream) {
   bool vn = aligned16(x_half) && aligned16(x_proj) && aligned16(x_dual) && aligned16(temp1) && aligned16(temp3) && aligned16(tau) && aligned16(kty) &&
             n >= (size_t)VecOf<T>::N;
   bool vm = aligned16(z_half) && aligned16(z_proj) && aligned16(z_dual) && aligned16(temp2) && aligned16(sigma) && aligned16(kx) && m >= (size_t)VecOf<T>::N;
-  prost_hip_cgls_desc c{};                   // launch_stage only reads state / workspace
-  c.state = d->workspace; c.workspace = d->workspace;      // `state` is never dereferenced by these stages (kSkipWhenDone = false, empty load)
+  prost_hip_cgls_desc c{};                   // launch_stage only reads state / workspace; these stages have no scalar record
+  c.state = nullptr; c.workspace = d->workspace;
   int rc;
   switch (stage) {
     case PROST_ADMM_STAGE_PRE_X:

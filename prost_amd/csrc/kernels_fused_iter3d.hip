@@ -13,17 +13,19 @@
 //     read y1, y2, y3, x, f of plane l once;  write x_new, y1, y2, y3   = 9 floats / voxel / iteration (vs 14).
 // Per-element arithmetic is that of kernels_fused3d.hip (block_gradient3d.cu:57-80, :127-149 inlined; prox
 // expressions of device_math.hpp): the iterates are bit-identical to the two-pass path and to the oracle.
-// Residual iterations run the two-pass kernels (they also stream y_prev).
+// Residual iterations (RES) additionally stream y_prev of the wavefront's own plane and accumulate the four residual sums.
 #include "fused_common.hpp"
+#include "reduce.hpp"
 
 namespace prost_hip {
 
-template <class T, int VEC, bool GB>
+template <class T, int VEC, bool GB, bool RES>
 struct Col3 {
   T y1[VEC], y2[VEC], y3[VEC], x[VEC], b[GB ? VEC : 1];        // plane l
   T zy1[VEC], zy2[VEC], zy3[VEC], zx[VEC], zb[GB ? VEC : 1];   // plane l+1 (zero when l is the last plane)
   T y3m[VEC];                                                  // y3 of plane l-1
   T up, zup;                                                   // y2 of the row above the wave's first row (lane 0)
+  T p1[RES ? VEC : 1], p2[RES ? VEC : 1], p3[RES ? VEC : 1], p3m[RES ? VEC : 1], pup;   // y_prev of plane l (and y_prev3 of l-1): RES only
 };
 
 // GB: the coefficient b of prox_g (the data term f of ROF) is a per-voxel vector; a, c, d, e, alpha, beta of
@@ -32,10 +34,13 @@ struct Col3 {
 // ind_leq0 with scalar a = 1, d = e = 0): the correctly rounded short forms of device_math.hpp instead of the IEEE
 // division / sqrt expansions (3 divisions + 1 sqrt per voxel and one fp64 division per primal step otherwise) --
 // the generic instance is VALU-bound at ~250 instructions per voxel.
-template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST>
+// RES = true (residual iterations) additionally streams y_prev of plane l and accumulates the four residual sums of
+// backend_pdhg.cu:392-431 for the wavefront's own plane (one partial of 4 doubles per wavefront, folded by fold4).
+template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, bool RES>
 __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_new, T* __restrict__ y_new, const T* __restrict__ x,
-                                                             const T* __restrict__ y, FusedArgs<T> a, T tau, T sigma, T theta,
-                                                             UniformProx<T> ug, UniformProx<T> uf, bool use_kty, bool use_kx_prev) {
+                                                             const T* __restrict__ y, const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma,
+                                                             T theta, UniformProx<T> ug, UniformProx<T> uf, bool use_kty, bool use_kx_prev,
+                                                             bool use_kty_prev, double* __restrict__ partial) {
   const size_t nx = a.nx, ny = a.ny, L = a.L;
   const int lane = threadIdx.x;
   constexpr int kRowsPerWave = (kWave - 1) * VEC;
@@ -58,8 +63,12 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
   const T* y1 = y + plane; const T* y2 = y + N + plane; const T* y3 = y + 2 * N + plane;
   const T* xp = x + plane;
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
+  const T* q1 = RES ? y_prev + plane : nullptr; const T* q2 = RES ? y_prev + N + plane : nullptr; const T* q3 = RES ? y_prev + 2 * N + plane : nullptr;
+  const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  const SharedDivisor<T> div_tauT(tau * sqT), div_sigS(sigma * sqS);        // wave-uniform residual divisors: exact quotients through one double reciprocal each
+  double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
-  typedef Col3<T, VEC, GB> Col;
+  typedef Col3<T, VEC, GB, RES> Col;
   auto load_col = [&](size_t c, Col& in) {
     const size_t o = c * ny + row0;
     ldv<T, VEC>(y1 + o, in.y1); ldv<T, VEC>(y2 + o, in.y2); ldv<T, VEC>(y3 + o, in.y3); ldv<T, VEC>(xp + o, in.x);
@@ -71,10 +80,16 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
       in.zup = (lane == 0 && row0 > 0) ? y2[P + o - 1] : (T)0;
     }
     if (l > 0) ldv<T, VEC>(y3 - P + o, in.y3m);
+    if (RES) {
+      ldv<T, RES ? VEC : 1>(q1 + o, in.p1); ldv<T, RES ? VEC : 1>(q2 + o, in.p2); ldv<T, RES ? VEC : 1>(q3 + o, in.p3);
+      if (l > 0) ldv<T, RES ? VEC : 1>(q3 - P + o, in.p3m);
+      in.pup = (lane == 0 && row0 > 0) ? q2[o - 1] : (T)0;
+    }
   };
   // x_new of one plane at column c (backend_pdhg.cu:317-338 with block_gradient3d.cu:127-149 on a zero-filled result)
   auto primal_col = [&](size_t c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&v3m)[VEC], bool has_below_plane,
-                        const T (&p1)[VEC], bool have_prev, T upv, const T (&xv)[VEC], const T (&bv)[GB ? VEC : 1], T (&xn)[VEC]) {
+                        const T (&p1)[VEC], bool have_prev, T upv, const T (&xv)[VEC], const T (&bv)[GB ? VEC : 1], T (&xn)[VEC],
+                        T (&ktyv)[RES ? VEC : 1]) {
     T up = __shfl_up(v2[VEC - 1], 1, kWave);
     if (lane == 0) up = upv;
     T parg[VEC];
@@ -88,6 +103,7 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
       T divl = v3[j];
       if (has_below_plane) divl -= v3m[j];
       const T kty = use_kty ? (T)0 - (divx + divy + divl) : (T)0;
+      if (RES) ktyv[RES ? j : 0] = kty;
       const T arg = xv[j] - tauT * kty;
       if (FAST) {
         parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
@@ -107,7 +123,30 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
     }
   };
 
+  // dual_residual_transform (backend_pdhg.cu:73-94) for the own plane at column c
+  auto dual_residual = [&](size_t c, const Col& in, const T (&pp1)[RES ? VEC : 1], bool have_prev, const T (&xn)[VEC], const T (&ktyv)[RES ? VEC : 1], bool counted) {
+    T upp = __shfl_up(in.p2[RES ? VEC - 1 : 0], 1, kWave);
+    if (lane == 0) upp = in.pup;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const size_t row = row0 + j;
+      const int jj = RES ? j : 0;
+      T dpy = (row < ny - 1) ? in.p2[jj] : (T)0;
+      if (row > 0) dpy -= (j > 0 ? in.p2[RES && j > 0 ? j - 1 : 0] : upp);
+      T dpx = (c < nx - 1) ? in.p1[jj] : (T)0;
+      if (have_prev) dpx -= pp1[jj];
+      T dpl = in.p3[jj];
+      if (l > 0) dpl -= in.p3m[jj];
+      const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy + dpl) : (T)0;
+      const T w_hat = div_tauT.div(in.x[j] - xn[j]) - sqT * ktyp;
+      const T diff = w_hat + sqT * ktyv[jj];
+      if (owner && counted) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
+    }
+  };
+
   Col cur = {}, nxt = {};
+  T hp1[RES ? VEC : 1];                                  // y_prev1 of column xa-1
+  T kt_c[RES ? VEC : 1], kt_n[RES ? VEC : 1], kt_z[RES ? VEC : 1];
   T h1[VEC], hz1[VEC];                                  // y1 of column xa-1, planes l and l+1
   T xn_c[VEC], xn_n[VEC], xz_c[VEC], xz_n[VEC];          // x_new of plane l / l+1 at columns c / c+1
 #pragma unroll
@@ -117,11 +156,15 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
     if (xa > 0) {
       ldv<T, VEC>(y1 + (xa - 1) * ny + row0, h1);
       if (has_above) ldv<T, VEC>(y1 + P + (xa - 1) * ny + row0, hz1);
+      if (RES) ldv<T, RES ? VEC : 1>(q1 + (xa - 1) * ny + row0, hp1);
     }
     if (xa + 1 < nx) load_col(xa + 1, nxt);
   }
-  primal_col(xa, cur.y1, cur.y2, cur.y3, cur.y3m, l > 0, h1, xa > 0, cur.up, cur.x, cur.b, xn_c);      // shuffles inside: every lane takes part
-  if (has_above) primal_col(xa, cur.zy1, cur.zy2, cur.zy3, cur.y3, true, hz1, xa > 0, cur.zup, cur.zx, cur.zb, xz_c);
+#pragma unroll
+  for (int j = 0; j < (RES ? VEC : 1); j++) { if (!(active && xa > 0)) hp1[j] = 0; kt_c[j] = 0; kt_n[j] = 0; kt_z[j] = 0; }
+  primal_col(xa, cur.y1, cur.y2, cur.y3, cur.y3m, l > 0, h1, xa > 0, cur.up, cur.x, cur.b, xn_c, kt_c);      // shuffles inside: every lane takes part
+  if (RES) dual_residual(xa, cur, hp1, xa > 0, xn_c, kt_c, true);
+  if (has_above) primal_col(xa, cur.zy1, cur.zy2, cur.zy3, cur.y3, true, hz1, xa > 0, cur.zup, cur.zx, cur.zb, xz_c, kt_z);
   if (owner) stv_nt<T, VEC>(x_new + plane + xa * ny + row0, xn_c);
 
   for (size_t c = xa; c < xb; c++) {
@@ -130,8 +173,9 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
     const bool has_pre = c + 2 < nx && c + 1 < xb;
     if (active && has_pre) load_col(c + 2, pre);
     if (has_next) {
-      primal_col(c + 1, nxt.y1, nxt.y2, nxt.y3, nxt.y3m, l > 0, cur.y1, true, nxt.up, nxt.x, nxt.b, xn_n);
-      if (has_above && c + 1 < xb) primal_col(c + 1, nxt.zy1, nxt.zy2, nxt.zy3, nxt.y3, true, cur.zy1, true, nxt.zup, nxt.zx, nxt.zb, xz_n);
+      primal_col(c + 1, nxt.y1, nxt.y2, nxt.y3, nxt.y3m, l > 0, cur.y1, true, nxt.up, nxt.x, nxt.b, xn_n, kt_n);
+      if (RES) dual_residual(c + 1, nxt, cur.p1, true, xn_n, kt_n, c + 1 < xb);
+      if (has_above && c + 1 < xb) primal_col(c + 1, nxt.zy1, nxt.zy2, nxt.zy3, nxt.y3, true, cur.zy1, true, nxt.zup, nxt.zx, nxt.zb, xz_n, kt_z);
       if (owner && c + 1 < xb) stv_nt<T, VEC>(x_new + plane + (c + 1) * ny + row0, xn_n);
     }
     // ---- dual step of column c (backend_pdhg.cu:341-370 with block_gradient3d.cu:62-80) ----
@@ -140,6 +184,7 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
     if (owner) {
       T out[3][VEC];
       T av[FAST ? 3 : 1][FAST ? VEC : 1], nv[FAST ? VEC : 1];
+      T kxv[RES ? 3 : 1][RES ? VEC : 1], kpv[RES ? 3 : 1][RES ? VEC : 1];
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         const size_t row = row0 + j;
@@ -158,6 +203,7 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
         for (int i = 0; i < 3; i++) {
           arg[i] = yv[i] + sigS * ((1 + theta) * kx[i] - theta * kp[i]);         // backend_pdhg.cu:54-70
           norm += arg[i] * arg[i];
+          if (RES) { kxv[RES ? i : 0][RES ? j : 0] = kx[i]; kpv[RES ? i : 0][RES ? j : 0] = kp[i]; }
         }
         if (FAST) {
           nv[FAST ? j : 0] = norm;
@@ -208,6 +254,19 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
           }
         }
       }
+      if (RES) {                                            // primal_residual_transform (backend_pdhg.cu:97-120)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const T yo = i == 0 ? cur.y1[j] : i == 1 ? cur.y2[j] : cur.y3[j];
+            const T kxi = kxv[RES ? i : 0][RES ? j : 0], kpi = kpv[RES ? i : 0][RES ? j : 0];
+            const T z_hat = div_sigS.div(yo - out[i][j]) + sqS * ((1 + theta) * kxi - theta * kpi);
+            const T diff = z_hat - sqS * kxi;
+            r_pd += (double)(diff * diff); r_pv += (double)(z_hat * z_hat);
+          }
+        }
+      }
       const size_t o = plane + c * ny + row0;
       stv_nt<T, VEC>(y_new + o, out[0]);
       stv_nt<T, VEC>(y_new + N + o, out[1]);
@@ -218,6 +277,13 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
     if (has_pre) nxt = pre;
 #pragma unroll
     for (int j = 0; j < VEC; j++) { xn_c[j] = xn_n[j]; xz_c[j] = xz_n[j]; }
+  }
+  if (RES) {
+    r_pd = wave_sum(r_pd); r_pv = wave_sum(r_pv); r_dd = wave_sum(r_dd); r_dv = wave_sum(r_dv);
+    if (lane == 0) {
+      double* p = partial + 4 * (size_t)blockIdx.x;
+      p[0] = r_pd; p[1] = r_pv; p[2] = r_dd; p[3] = r_dv;
+    }
   }
 }
 
@@ -238,32 +304,42 @@ static bool iter3d_ok(const prost_hip_fused_desc* d) {
 }
 
 template <class T>
-static int run_iter3d(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, double tau, double sigma, double theta,
-                      int use_kty, int use_kx_prev, int cols, void* stream) {
+static int run_iter3d(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
+                      int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream) {
   if (!iter3d_ok<T>(d)) { set_error("fused 3-D iteration: unsupported description (see prost_hip_fused_iteration3d_supported)"); return 1; }
-  if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y)) { set_error("fused 3-D iteration: vectors must be 16-byte aligned"); return 1; }
-  if (x_new == x || y_new == y) { set_error("fused 3-D iteration: outputs must not alias inputs (planes l-1 / l+1 are read by other wavefronts)"); return 1; }
+  if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y) || !aligned16(y_prev)) { set_error("fused 3-D iteration: vectors must be 16-byte aligned"); return 1; }
+  if (x_new == x || y_new == y || (out4 && y_new == y_prev)) { set_error("fused 3-D iteration: outputs must not alias inputs (planes l-1 / l+1 are read by other wavefronts)"); return 1; }
+  if (out4 && (!ws || !y_prev)) { set_error("fused 3-D iteration: residuals need the reduction workspace and y_prev"); return 1; }
   constexpr int V = VecOf<T>::N;
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t strips = (d->ny + (size_t)(kWave - 1) * V - 1) / ((size_t)(kWave - 1) * V);
   size_t c = cols > 0 ? (size_t)cols : 18;
   if (cols <= 0) while (c > 6 && strips * d->L * ((d->nx + c - 1) / c) < 8192) c -= 3;     // enough wavefronts to fill the chip
+  // residual launches: one partial of 4 doubles per wavefront must fit the reduction workspace
+  const size_t max_waves = (size_t)kReduceBlocks / 2;
+  if (out4) while (c < d->nx && strips * d->L * ((d->nx + c - 1) / c) > max_waves) c += 6;
   if (c > d->nx) c = d->nx;
+  if (out4 && strips * d->L * ((d->nx + c - 1) / c) > max_waves) { set_error("fused 3-D iteration: grid exceeds the reduction workspace"); return 1; }
   a.cols_per_block = (unsigned)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
   const unsigned grid = (unsigned)(strips * a.chunks * d->L);
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   hipStream_t s = as_stream(stream);
+  double* partial = static_cast<double*>(ws);
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO(G, F, B, FASTv) hipLaunchKernelGGL((fused_iter3d_kernel<T, V, G, F, B, FASTv>), dim3(grid), dim3(kWave), 0, s, x_new, y_new, x, y, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0)
+#define GO2(G, F, B, FASTv, R) hipLaunchKernelGGL((fused_iter3d_kernel<T, V, G, F, B, FASTv, R>), dim3(grid), dim3(kWave), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO(G, F, B, FASTv) do { if (out4) GO2(G, F, B, FASTv, true); else GO2(G, F, B, FASTv, false); } while (0)
   if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
   else if (gsq && fle) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, false); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, false); }
   else { if (gb) GO(-1, -1, true, false); else GO(-1, -1, false, false); }
 #undef GO
-  PH_LAUNCH_END("fused 3-D iteration kernel");
+#undef GO2
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused 3-D iteration kernel"); }
+  if (out4) return launch_fold4(out4, partial, grid, s);
+  return 0;
 }
 
 }  // namespace prost_hip
@@ -272,12 +348,14 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration3d_supported(const prost_hip_fused_desc* d, int dtype) { return (dtype == 0 ? iter3d_ok<float>(d) : iter3d_ok<double>(d)) ? 1 : 0; }
-int prost_hip_fused_iteration3d_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, double tau, double sigma,
-                                    double theta, int use_kty, int use_kx_prev, int cols, void* stream) {
-  return run_iter3d<float>(d, x_new, y_new, x, y, tau, sigma, theta, use_kty, use_kx_prev, cols, stream);
+int prost_hip_fused_iteration3d_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
+                                    double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,
+                                    void* workspace, void* stream) {
+  return run_iter3d<float>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream);
 }
-int prost_hip_fused_iteration3d_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
-                                    double theta, int use_kty, int use_kx_prev, int cols, void* stream) {
-  return run_iter3d<double>(d, x_new, y_new, x, y, tau, sigma, theta, use_kty, use_kx_prev, cols, stream);
+int prost_hip_fused_iteration3d_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev,
+                                    double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,
+                                    void* workspace, void* stream) {
+  return run_iter3d<double>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream);
 }
 }  // extern "C"
