@@ -130,13 +130,42 @@ def to_value(obj, keep):
     raise ProstError("Cannot handle arrays with dim > 2.")
 
 
-def from_value(v):
+_VIEW_THRESHOLD = 1 << 20     # elements; larger result matrices are handed out without a copy
+
+
+class _ValueOwner:
+    """Frees a prost_value tree when the last numpy view into it is gone."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+        self.used = False
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().prost_value_free(self.ptr)
+        except Exception:          # interpreter shutdown
+            pass
+        self.ptr = None
+
+
+def from_value(v, owner=None):
+    """Converts a prost_value to Python.  With `owner` (a _ValueOwner of the tree's root) large matrices are returned
+    as numpy views of the value's storage -- the 10^7..10^8-element result vectors are not copied a second time;
+    the tree is freed when the last view is collected."""
     L = lib()
     kind = L.prost_value_kind(v)
     if kind == VALUE_MATRIX:
         r, c = L.prost_value_rows(v), L.prost_value_cols(v)
         if r * c == 0:
             return np.zeros((r, c))
+        if owner is not None and r * c >= _VIEW_THRESHOLD:
+            addr = C.cast(L.prost_value_data(v), C.c_void_p).value
+            buf = (C.c_double * (r * c)).from_address(addr)
+            buf._prost_owner = owner          # numpy keeps `buf` (the buffer exporter) alive for every view
+            owner.used = True
+            a = np.frombuffer(buf, dtype=np.float64)
+            return a if c == 1 else a.reshape((c, r)).T
         a = np.ctypeslib.as_array(L.prost_value_data(v), (r * c,)).copy()
         if r == 1 and c == 1:
             return float(a[0])
@@ -144,19 +173,19 @@ def from_value(v):
     if kind == VALUE_STRING:
         return L.prost_value_str(v).decode()
     if kind == VALUE_CELL:
-        return [from_value(L.prost_value_cell_get(v, i)) for i in range(L.prost_value_count(v))]
+        return [from_value(L.prost_value_cell_get(v, i), owner) for i in range(L.prost_value_count(v))]
     if kind == VALUE_STRUCT:
         raise ProstError("struct results are read field by field (see _struct_fields)")
     return None
 
 
-def _struct_fields(v, names):
+def _struct_fields(v, names, owner=None):
     L = lib()
     out = {}
     for n in names:
         f = L.prost_value_field(v, n.encode())
         if f:
-            out[n] = from_value(f)
+            out[n] = from_value(f, owner)
     return out
 
 
@@ -175,10 +204,18 @@ def command(cmd, args=(), nlhs=0, struct_fields=None):
         for i in range(nlhs):
             if not plhs[i]:
                 out.append(None)
-            elif L.prost_value_kind(plhs[i]) == VALUE_STRUCT:
-                out.append(_struct_fields(plhs[i], struct_fields or ()))
-            else:
-                out.append(from_value(plhs[i]))
+                continue
+            owner = _ValueOwner(plhs[i])
+            try:
+                if L.prost_value_kind(plhs[i]) == VALUE_STRUCT:
+                    out.append(_struct_fields(plhs[i], struct_fields or (), owner))
+                else:
+                    out.append(from_value(plhs[i], owner))
+            finally:
+                if owner.used:
+                    plhs[i] = None            # the views own the tree now
+                else:
+                    owner.ptr = None          # nothing references it: freed below
         return out
     finally:
         for v in vals:

@@ -91,3 +91,28 @@ def test_conjugate_epi_quad_defaults_and_options():
         prost.options(bogus=1)
     with pytest.raises(ValueError):
         prost.backend.pdhg(step="alg1")
+
+
+def test_large_results_are_views_that_keep_their_value_alive():
+    """Result matrices above the view threshold are numpy views of the prost_value's storage (no second copy of the
+    10^7..10^8-element result vectors); the value tree lives until the last view is gone."""
+    import gc
+    from prost_amd import _capi
+    L = _capi.lib()
+    n = _capi._VIEW_THRESHOLD + 17
+    src = np.arange(n, dtype=np.float64)
+    keep = []
+    v = _capi.to_value([src, "tag", np.ones(3)], keep)
+    owner = _capi._ValueOwner(v)
+    out = _capi.from_value(v, owner)
+    assert owner.used and out[1] == "tag" and np.array_equal(out[2], np.ones(3))
+    big = out[0]
+    assert not big.flags.owndata and np.array_equal(big, src)
+    tail = big[-5:]
+    del out, big, owner
+    gc.collect()
+    assert np.array_equal(tail, src[-5:])          # the view keeps the tree alive
+    del tail
+    gc.collect()
+    small = _capi.from_value(_capi.to_value(np.ones(4), keep))
+    assert small.flags.owndata
