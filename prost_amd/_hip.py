@@ -28,6 +28,23 @@ class FusedDesc(C.Structure):
                 ("T_val", C.c_double), ("S_val", C.c_double), ("res_x0", C.c_size_t), ("res_x1", C.c_size_t)]
 
 
+class ArgSpec(C.Structure):
+    """prost_hip_arg_spec: how a prox obtains its argument (PROST_ARG_PLAIN / PDHG_PRIMAL / PDHG_DUAL)"""
+    _fields_ = [("mode", C.c_int), ("v", C.c_void_p * 4), ("s", C.c_double * 2)]
+
+
+class CglsDesc(C.Structure):
+    """prost_hip_cgls_desc"""
+    _fields_ = [("state", C.c_void_p), ("workspace", C.c_void_p), ("b", C.c_void_p), ("x", C.c_void_p), ("p", C.c_void_p), ("q", C.c_void_p),
+                ("r", C.c_void_p), ("s", C.c_void_p), ("t", C.c_void_p), ("sigma", C.c_void_p), ("tau", C.c_void_p), ("m", C.c_uint64), ("n", C.c_uint64),
+                ("shift", C.c_double), ("tol", C.c_double), ("host_done", C.c_void_p), ("epoch", C.c_int)]
+
+
+class CglsResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("indefinite", C.c_int), ("flag", C.c_int),
+                ("norms", C.c_double), ("norms0", C.c_double), ("normx", C.c_double), ("xmax", C.c_double)]
+
+
 _lib = None
 
 
@@ -43,6 +60,8 @@ def lib():
         if L.prost_hip_abi_version() != 2:
             raise HipError("libprost_hip.so has ABI version %d, this binding needs 2: rebuild (make -C prost_amd/csrc)" % L.prost_hip_abi_version())
         L.prost_hip_reduce_workspace_bytes.restype = C.c_size_t
+        L.prost_hip_cgls_state_bytes.restype = C.c_size_t
+        L.prost_hip_cgls_workspace_bytes.restype = C.c_size_t
         _lib = L
     return _lib
 

@@ -151,6 +151,132 @@ def test_prox_elem(hip, dtype, op, fn):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("op,fn", [(0, "square"), (0, "abs"), (0, "huber"), (1, "ind_leq0"), (1, "abs"), (1, "l0")])
+@pytest.mark.parametrize("moreau", [0, 1])
+def test_prox_elem_with_argument_source_equals_argument_pass_plus_prox(hip, dtype, op, fn, moreau):
+    """prost_hip_prox_elem_arg (argument formed in the load path of the prox kernel) against the separate argument
+    pass + prost_hip_prox_elem / _moreau on the same operands: identical bits for both PDHG argument modes, the
+    vector kernels (dims 1-4 in registers, 7 in two passes), the interleaved / unaligned element-per-lane kernel."""
+    rng = np.random.default_rng(9)
+    L_ = hip.lib()
+    for count, dim, il, off in ((1000, 1 if op == 0 else 2, False, 0), (1000, 1 if op == 0 else 7, False, 0), (996, 1 if op == 0 else 3, True, 0),
+                                (1001, 1 if op == 0 else 4, False, 0), (1000, 1 if op == 0 else 3, False, 1)):
+        n = count * dim
+        coeffs = [rng.uniform(0.5, 2, count), rng.uniform(-1, 1, count), rng.uniform(0.1, 2, count), 0.1, 0.2, 0.7, 1.3]
+        ptrs, vals, keep = hip.coeff_args(coeffs, dtype, count)
+        v0, v1, v2, v3 = (hip.DeviceArray.from_host(rng.uniform(lo, hi, n + off).astype(dtype)) for lo, hi in ((-2, 2), (0.2, 1.5), (-1, 1), (-1, 1)))
+        td = hip.DeviceArray.from_host(rng.uniform(0.2, 1.5, n + off).astype(dtype))
+        esz = np.dtype(dtype).itemsize
+        at = lambda d: C.c_void_p(d.ptr.value + off * esz)          # off = 1: pointers that are not 16-byte aligned
+        for mode in (1, 2):
+            temp = hip.DeviceArray.zeros(n + off, dtype); ref = hip.DeviceArray.zeros(n + off, dtype); got = hip.DeviceArray.zeros(n + off, dtype)
+            if mode == 1:
+                hip.check(hip.fn("pdhg_primal_arg", dtype)(at(temp), at(v0), at(v1), at(v2), hip.dbl(0.37), hip.sz(n), None))
+            else:
+                hip.check(hip.fn("pdhg_dual_arg", dtype)(at(temp), at(v0), at(v1), at(v2), at(v3), hip.dbl(0.37), hip.dbl(0.8), hip.sz(n), None))
+            plain = hip.fn("prox_elem_moreau" if moreau else "prox_elem", dtype)
+            hip.check(plain(op, hip.FN_ID[fn], at(ref), at(temp), at(td), hip.dbl(0.9), 0, hip.sz(count), hip.sz(dim), int(il), ptrs, vals, None))
+            spec = hip.ArgSpec(); spec.mode = mode
+            for k, d in enumerate((v0, v1, v2, v3)):
+                spec.v[k] = d.ptr.value + off * esz
+            spec.s[0], spec.s[1] = 0.37, 0.8
+            hip.check(hip.fn("prox_elem_arg", dtype)(op, hip.FN_ID[fn], moreau, at(got), C.byref(spec), at(td), hip.dbl(0.9), 0, hip.sz(count), hip.sz(dim), int(il),
+                                                     ptrs, vals, None))
+            assert np.array_equal(got.to_host()[off:], ref.to_host()[off:], equal_nan=True), (count, dim, il, off, mode)
+    # the result must not alias the first operand
+    spec = hip.ArgSpec(); spec.mode = 1
+    for k in range(3):
+        spec.v[k] = v0.ptr.value
+    assert hip.fn("prox_elem_arg", dtype)(0, hip.FN_ID["abs"], 0, v0.ptr, C.byref(spec), td.ptr, hip.dbl(1.0), 0, hip.sz(8), hip.sz(1), 0, ptrs, vals, None) != 0
+    assert b"alias" in L_.prost_hip_last_error()
+
+
+def _cgls_reference(A, b, x, sig, tau, shift, tol, maxit, dtype):
+    """cgls::Solve (cgls.hpp:222-371) on S^(1/2) A T^(1/2) in numpy: vectors in `dtype`, scalars in double."""
+    T = dtype
+    sq_s, sq_t = np.sqrt(sig).astype(T), np.sqrt(tau).astype(T)
+    ATr = A.T.tocsr()
+
+    def gemv(op, alpha, xv, beta, yv):            # GemvPrecondK (backend_admm.cu:199-272), functor by functor
+        if op == "n":
+            t = (sq_t * xv).astype(T); yv = ((T(beta) / (T(alpha) * sq_s)) * yv).astype(T)
+            yv = (yv + (A @ t).astype(T)).astype(T)
+            return (T(alpha) * sq_s * yv).astype(T)
+        t = (sq_s * xv).astype(T); yv = ((T(beta) / (T(alpha) * sq_t)) * yv).astype(T)
+        yv = (yv + (ATr @ t).astype(T)).astype(T)
+        return (T(alpha) * sq_t * yv).astype(T)
+    Aop = lambda v: gemv("n", 1, v, 0, np.zeros(A.shape[0], T))
+    nrm = lambda v: float(np.sqrt(np.sum(v.astype(np.float64) ** 2)))
+    x = x.copy(); r = b.copy()
+    if nrm(x) > 0:
+        r = gemv("n", -1, x, 1, r)
+    s = gemv("t", 1, r, -shift, x.copy())
+    p = s.copy()
+    norms0 = norms = nrm(s); gamma = norms0 ** 2; normx = xmax = nrm(x)
+    k = 0
+    if norms < np.finfo(T).eps:
+        return x, 0
+    while k < maxit:
+        q = Aop(p)
+        dlt = nrm(q) ** 2 + shift * nrm(p) ** 2
+        alpha = T(gamma / dlt)
+        x = (alpha * p + x).astype(T); r = (T(-gamma / dlt) * q + r).astype(T)
+        s = gemv("t", 1, r, -shift, x.copy())
+        norms = nrm(s); gamma1 = gamma; gamma = norms ** 2
+        p = (T(gamma / gamma1) * p + s).astype(T)
+        normx = nrm(x); xmax = max(xmax, normx)
+        if norms <= norms0 * tol or normx * tol >= 1:
+            break
+        k += 1
+    return x, k
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m,n,tol,zero_start", [(300, 200, 1e-3, False), (301, 203, 1e-10, True), (64, 1000, 0.2, False)])
+def test_cgls_stages_at_the_c_abi(hip, dtype, m, n, tol, zero_start):
+    """The device-resident CGLS driven stage by stage through prost_hip_cgls_stage_* with a CSR operator
+    (prost_hip_csr_spmv*), against a numpy restatement of cgls.hpp: same iteration count, same x to round-off;
+    rounds queued after the stopping test must leave x untouched."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    L_ = hip.lib()
+    A = sp.random(m, n, density=0.05, random_state=4, format="csr", dtype=np.float64).astype(dtype); A.sort_indices()
+    At = A.T.tocsr(); At.sort_indices()
+    sig = rng.uniform(0.3, 2, m).astype(dtype); tau = rng.uniform(0.3, 2, n).astype(dtype)
+    b = rng.standard_normal(m).astype(dtype)
+    x0 = np.zeros(n, dtype) if zero_start else rng.standard_normal(n).astype(dtype)
+    # CG amplifies round-off differences (here: the association order of the norm reductions) from iteration to iteration:
+    # fp32 agrees to 2e-4 for 8 iterations (5e-3 after 12), fp64 to 1e-10 for 12
+    maxit = 8 if dtype == np.float32 else 12
+    x_ref, k_ref = _cgls_reference(A, b, x0, sig, tau, 1.0, tol, maxit, dtype)
+    dev_ = lambda a: hip.DeviceArray.from_host(np.ascontiguousarray(a))
+    dA = [dev_(A.data), dev_(A.indptr.astype(np.int32)), dev_(A.indices.astype(np.int32))]
+    dAt = [dev_(At.data), dev_(At.indptr.astype(np.int32)), dev_(At.indices.astype(np.int32))]
+    vec = {k: hip.DeviceArray.zeros(sz, dtype) for k, sz in (("p", n), ("q", m), ("r", m), ("s", n), ("t", max(m, n)))}
+    db, dx, dsig, dtau = dev_(b), dev_(x0), dev_(sig), dev_(tau)
+    state = hip.DeviceArray.zeros(L_.prost_hip_cgls_state_bytes() // 8 + 1, np.float64)
+    ws = hip.DeviceArray(L_.prost_hip_cgls_workspace_bytes() // 8, np.float64)
+    d = hip.CglsDesc()
+    d.state, d.workspace, d.b, d.x = state.ptr.value, ws.ptr.value, db.ptr.value, dx.ptr.value
+    d.p, d.q, d.r, d.s, d.t = (vec[k].ptr.value for k in "pqrst")
+    d.sigma, d.tau, d.m, d.n, d.shift, d.tol, d.host_done, d.epoch = dsig.ptr.value, dtau.ptr.value, m, n, 1.0, tol, None, 1
+    stage = lambda which: hip.check(hip.fn("cgls_stage", dtype)(which, C.byref(d), None))
+    K = lambda res, rhs, acc: hip.check(hip.fn("csr_spmv_acc" if acc else "csr_spmv", dtype)(res.ptr, rhs.ptr, hip.sz(m), hip.sz(A.nnz), dA[0].ptr, dA[1].ptr, dA[2].ptr, None))
+    Kt = lambda res, rhs: hip.check(hip.fn("csr_spmv_acc", dtype)(res.ptr, rhs.ptr, hip.sz(n), hip.sz(A.nnz), dAt[0].ptr, dAt[1].ptr, dAt[2].ptr, None))
+    INIT_X, INIT_R, INIT_R2, INIT_S, STEP_Q, STEP_XR, STEP_S, STEP_P = range(8)
+    stage(INIT_X); stage(INIT_R); K(vec["r"], vec["t"], True); stage(INIT_R2); Kt(vec["s"], vec["t"]); stage(INIT_S)
+    for _ in range(maxit):
+        K(vec["q"], vec["t"], False); stage(STEP_Q); stage(STEP_XR); Kt(vec["s"], vec["t"]); stage(STEP_S); stage(STEP_P)
+    res = hip.CglsResult()
+    hip.check(L_.prost_hip_cgls_result(state.ptr, C.byref(res), None))
+    assert res.iterations == k_ref, (res.iterations, k_ref)
+    assert res.converged == (1 if k_ref < maxit else 0)
+    rtol = 2e-4 if dtype == np.float32 else 1e-10
+    err = float(np.abs(dx.to_host() - x_ref).max()) / max(1.0, float(np.abs(x_ref).max()))
+    assert err <= rtol, (err, res.iterations)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_prox_epi_quad(hip, dtype):
     rng = np.random.default_rng(6)
     count, dim = 2000, 4
