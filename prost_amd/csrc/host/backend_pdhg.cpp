@@ -101,6 +101,7 @@ void BackendPDHG<T>::Initialize() {
   for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
   single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
   single3d_ = fused_ && !single_kernel_ && opts_.allow_single_kernel && prost_hip_fused_iteration3d_supported(&desc_, dtype_id<T>()) == 1;
+  single_mc_ = fused_ && !single_kernel_ && !single3d_ && opts_.allow_single_kernel && prost_hip_fused_iteration_mc_supported(&desc_, dtype_id<T>()) == 1;
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
@@ -278,6 +279,19 @@ void BackendPDHG<T>::IterationFused(bool res) {
     if (res) y_prev_.swap(y_spare_);
     y_.swap(y_prev_);
     if (res) FinishResiduals();
+    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+    iteration_++;
+    return;
+  }
+  if (single_mc_ && !res) {
+    // gradient2d with 3 / 4 channels, no residual sums wanted: one kernel, the channels on the wavefronts of a workgroup
+    // (7 instead of 11 values per pixel and channel); residual iterations take the two passes below
+    const bool tm = BeginSample(kKernelIter);
+    CheckHip(Api<T>::fused_iteration_mc(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
+                                        iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, s), "fused_iteration_mc");
+    EndSample(tm);
+    x_.swap(x_prev_);
+    y_.swap(y_prev_);
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
     return;
@@ -486,7 +500,7 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
-                                     d3 ? "fused_iter3d_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
+                                     d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
                                      "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++)

@@ -1,0 +1,259 @@
+// kernels_fused_iter_mc.hip -- ONE kernel per PDHG iteration for gradient2d problems with L = 3 or 4 channels
+// (vectorial TV of RGB images: example_rof_primaldual.m builds sum_norm2(2 * nc, ...) over all channel gradients).
+//
+// kernels_fused_iter.hip keeps all channels of a pixel in one lane (LCH <= 2); with three channels that is 289
+// VGPRs and slower than the two passes.  Here the channels go ACROSS THE WAVEFRONTS OF A WORKGROUP: wavefront w
+// marches over the same (row strip, column chunk) as its siblings but on channel w, with the single-channel
+// register pipeline (x_new of column c+1 one step ahead of y_new of column c, row neighbours by wave shuffle,
+// lane 63 a halo lane).  The only coupling between channels is the norm over the 2 L gradient components of a
+// pixel: every wavefront writes the squares of its two dual arguments to LDS, one workgroup barrier per column,
+// and every wavefront adds the 2 L squares in the reference's component order (all d/dx, then all d/dy; channel
+// order inside) -- the same float additions as `norm += arg[i] * arg[i]`, so the result is bit-identical to the
+// two-pass kernels and the oracle.  LDS: 2 buffers x 2 L components x 256 pixels x 4 B (6 KiB for RGB fp32),
+// double-buffered so that one barrier per column suffices.
+//     per channel and column: load y1, y2, x, f of column c+1; store x_new[c+1], y1_new[c], y2_new[c]
+//     = 7 floats / pixel / channel / iteration (two passes: 11).
+// No residual variant: residual iterations run the two-pass kernels.
+#include "fused_common.hpp"
+
+namespace prost_hip {
+
+template <class T, int VEC, bool GB>
+struct ColMc {
+  T y1[VEC], y2[VEC], x[VEC], b[GB ? VEC : 1];
+  T up;              // y2 of the row above the wave's first row (lane 0)
+};
+
+// GB: coefficient b of prox_g is a per-pixel vector; every other coefficient of prox_g and all of prox_f* are scalars.
+// FAST: straight-line ROF instance (square / ind_leq0 with scalar a = 1, d = e = 0), forms of device_math.hpp.
+template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, int LW>
+__global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restrict__ x_new, T* __restrict__ y_new, const T* __restrict__ x,
+                                                                    const T* __restrict__ y, FusedArgs<T> a, T tau, T sigma, T theta,
+                                                                    UniformProx<T> ug, UniformProx<T> uf, bool use_kty, bool use_kx_prev) {
+  constexpr int kRowsPerWave = (kWave - 1) * VEC;
+  constexpr int kPix = kWave * VEC;
+  __shared__ T s_sq[2][2 * LW][kPix];
+  const size_t nx = a.nx, ny = a.ny;
+  const int lane = threadIdx.x & (kWave - 1), ch = threadIdx.x / kWave;
+  const unsigned total = gridDim.x, chunks = a.chunks;
+  const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // XCD-aware tile order, see kernels_fused_iter.hip
+  const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
+  const unsigned strip = tile / chunks, chunk = tile % chunks;
+  const size_t row0 = (size_t)strip * kRowsPerWave + (size_t)lane * VEC;
+  const bool active = row0 < ny;
+  const bool owner = active && lane < kWave - 1;
+  const size_t xa = (size_t)chunk * a.cols_per_block;
+  const size_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const size_t P = nx * ny, N = P * LW, plane = (size_t)ch * P;
+  const T tauT = tau * a.Tval, sigS = sigma * a.Sval;
+  const T* y1 = y + plane; const T* y2 = y + N + plane;
+  const T* xp = x + plane;
+  const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
+
+  typedef ColMc<T, VEC, GB> Col;
+  auto load_col = [&](size_t c, Col& in) {
+    const size_t o = c * ny + row0;
+    ldv<T, VEC>(y1 + o, in.y1); ldv<T, VEC>(y2 + o, in.y2); ldv<T, VEC>(xp + o, in.x);
+    if (GB) ldv<T, GB ? VEC : 1>(bp + o, in.b);
+    in.up = (lane == 0 && row0 > 0) ? y2[o - 1] : (T)0;
+  };
+  // x_new of this channel at column c (backend_pdhg.cu:317-338, block_gradient2d.cu:122-138 on a zero-filled result)
+  auto primal_col = [&](size_t c, const Col& in, const T (&p1)[VEC], bool have_prev, T (&xn)[VEC]) {
+    T up = __shfl_up(in.y2[VEC - 1], 1, kWave);
+    if (lane == 0) up = in.up;
+    T parg[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const size_t row = row0 + j;
+      T divy = (row < ny - 1) ? in.y2[j] : (T)0;
+      if (row > 0) divy -= (j > 0 ? in.y2[j > 0 ? j - 1 : 0] : up);
+      T divx = (c < nx - 1) ? in.y1[j] : (T)0;
+      if (have_prev) divx -= p1[j];
+      const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+      const T arg = in.x[j] - tauT * kty;
+      if (FAST) {
+        parg[j] = arg - (GB ? in.b[GB ? j : 0] : a.g_val[1]);
+      } else {
+        T cf[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) cf[k] = a.g_val[k];
+        if (GB) cf[1] = in.b[GB ? j : 0];
+        xn[j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
+      }
+    }
+    if (FAST) {
+      T r[VEC];
+      div_to_float_exact_vec<VEC>(parg, ug.sq, r);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? in.b[GB ? j : 0] : a.g_val[1]);
+    }
+  };
+
+  Col cur = {}, nxt = {};
+  T h1[VEC], xn_c[VEC], xn_n[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; j++) { h1[j] = 0; xn_c[j] = 0; xn_n[j] = 0; }
+  if (active) {
+    load_col(xa, cur);
+    if (xa > 0) ldv<T, VEC>(y1 + (xa - 1) * ny + row0, h1);
+    if (xa + 1 < nx) load_col(xa + 1, nxt);
+  }
+  primal_col(xa, cur, h1, xa > 0, xn_c);
+  if (owner) stv_nt<T, VEC>(x_new + plane + xa * ny + row0, xn_c);
+
+  for (size_t c = xa; c < xb; c++) {
+    const bool has_next = c + 1 < nx;
+    Col pre;
+    const bool has_pre = c + 2 < nx && c + 1 < xb;
+    if (active && has_pre) load_col(c + 2, pre);
+    if (has_next) {
+      primal_col(c + 1, nxt, cur.y1, true, xn_n);
+      if (owner && c + 1 < xb) stv_nt<T, VEC>(x_new + plane + (c + 1) * ny + row0, xn_n);
+    }
+    // ---- dual step of column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77) ----
+    const T bel_n = __shfl_down(xn_c[0], 1, kWave);
+    const T bel_o = __shfl_down(cur.x[0], 1, kWave);
+    T av[2][VEC];
+    const int buf = (int)(c & 1);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const size_t row = row0 + j;
+      const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
+      const T below_o = (j < VEC - 1) ? cur.x[j < VEC - 1 ? j + 1 : 0] : bel_o;
+      const T kx0 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+      const T kx1 = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
+      const T kp0 = (use_kx_prev && has_next) ? nxt.x[j] - cur.x[j] : (T)0;
+      const T kp1 = (use_kx_prev && row < ny - 1) ? below_o - cur.x[j] : (T)0;
+      av[0][j] = cur.y1[j] + sigS * ((1 + theta) * kx0 - theta * kp0);       // backend_pdhg.cu:54-70
+      av[1][j] = cur.y2[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
+      s_sq[buf][ch][j * kWave + lane] = av[0][j] * av[0][j];             // [j][lane]: conflict-free banks
+      s_sq[buf][LW + ch][j * kWave + lane] = av[1][j] * av[1][j];
+    }
+    __syncthreads();                                        // every wavefront of the workgroup runs the same column loop
+    T nv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      T norm = 0;
+#pragma unroll
+      for (int i = 0; i < 2 * LW; i++) norm += s_sq[buf][i][j * kWave + lane];   // component order of ElemOperationNorm2: d/dx of all channels, then d/dy
+      nv[j] = norm;
+    }
+    if (owner) {
+      T out[2][VEC];
+      if (FAST) {
+        constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96, see kernels_fused_iter.hip
+        unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          tmin = min(tmin, (unsigned)__float_as_int((float)nv[j]) - 1u);
+          nmax = nv[j] > nmax ? nv[j] : nmax;
+        }
+        const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
+        if (__builtin_expect(mid, 1)) {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const T nrm = sqrt_midrange(nv[j] > (T)kLo ? nv[j] : (T)kLo);
+            const T t = nrm - a.f_val[1];
+            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+            const auto r = rcp_refined(nrm);
+#pragma unroll
+            for (int i = 0; i < 2; i++) out[i][j] = mul_rcp(pr * av[i][j], r) + (T)0;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const bool nz = nv[j] > 0;
+            const T nrm = nz ? t_sqrt(nv[j]) : (T)1;
+            const T t = nrm - a.f_val[1];
+            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
+#pragma unroll
+            for (int i = 0; i < 2; i++) { const T qv = pr * av[i][j] / nrm; out[i][j] = nz ? qv : (T)0; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          if (nv[j] > 0) {
+            const T nrm = t_sqrt(nv[j]);
+            const T pr = scaled_prox_u<T, FFN>(a.f_fn, nrm, a.f_val, uf);
+#pragma unroll
+            for (int i = 0; i < 2; i++) out[i][j] = pr * av[i][j] / nrm;
+          } else {
+            out[0][j] = 0; out[1][j] = 0;
+          }
+        }
+      }
+      const size_t o = plane + c * ny + row0;
+      stv_nt<T, VEC>(y_new + o, out[0]);
+      stv_nt<T, VEC>(y_new + N + o, out[1]);
+    }
+    cur = nxt;
+    if (has_pre) nxt = pre;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) xn_c[j] = xn_n[j];
+  }
+}
+
+template <class T>
+static bool iter_mc_ok(const prost_hip_fused_desc* d) {
+  if (!d || d->is3d || (d->L != 3 && d->L != 4)) return false;
+  if (d->nx == 0 || d->ny == 0) return false;
+  if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
+  if (d->ny % VecOf<T>::N != 0) return false;
+  for (int k = 0; k < 7; k++) {
+    if (d->f_coeff_ptr[k]) return false;
+    if (k != 1 && d->g_coeff_ptr[k]) return false;
+  }
+  if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
+  if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
+  const size_t strips = (d->ny + (size_t)(kWave - 1) * VecOf<T>::N - 1) / ((size_t)(kWave - 1) * VecOf<T>::N);
+  return strips * d->nx < (size_t)1 << 31;
+}
+
+template <class T>
+static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, double tau, double sigma, double theta,
+                       int use_kty, int use_kx_prev, int cols, void* stream) {
+  if (!iter_mc_ok<T>(d)) { set_error("fused multi-channel iteration: unsupported description (see prost_hip_fused_iteration_mc_supported)"); return 1; }
+  if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y)) { set_error("fused multi-channel iteration: vectors must be 16-byte aligned"); return 1; }
+  if (x_new == x || y_new == y) { set_error("fused multi-channel iteration: outputs must not alias inputs"); return 1; }
+  constexpr int V = VecOf<T>::N;
+  FusedArgs<T> a = make_fused_args<T>(d);
+  const size_t strips = (d->ny + (size_t)(kWave - 1) * V - 1) / ((size_t)(kWave - 1) * V);
+  // measured 4096^2 x 3 fp32: 6 columns 0.302 ms, 12: 0.306, 18: 0.314, 36: 0.329 (shorter chunks = more workgroups in flight
+  // to hide the per-column barrier; one halo column each)
+  size_t c = cols > 0 ? (size_t)cols : 12;
+  if (cols <= 0) while (c > 3 && strips * ((d->nx + c - 1) / c) * d->L < 4096) c -= 3;
+  if (c > d->nx) c = d->nx;
+  a.cols_per_block = (unsigned)c;
+  a.chunks = (unsigned)((d->nx + c - 1) / c);
+  const unsigned grid = (unsigned)(strips * a.chunks);
+  const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
+  const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
+  hipStream_t s = as_stream(stream);
+  const bool gb = d->g_coeff_ptr[1] != nullptr;
+  const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
+  const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
+#define GO2(G, F, B, FASTv, LWv) hipLaunchKernelGGL((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0)
+#define GO(G, F, B, FASTv) do { if (d->L == 3) GO2(G, F, B, FASTv, 3); else GO2(G, F, B, FASTv, 4); } while (0)
+  if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
+  else { if (gb) GO(-1, -1, true, false); else GO(-1, -1, false, false); }
+#undef GO
+#undef GO2
+  PH_LAUNCH_END("fused multi-channel iteration kernel");
+}
+
+}  // namespace prost_hip
+
+using namespace prost_hip;
+
+extern "C" {
+int prost_hip_fused_iteration_mc_supported(const prost_hip_fused_desc* d, int dtype) { return (dtype == 0 ? iter_mc_ok<float>(d) : iter_mc_ok<double>(d)) ? 1 : 0; }
+int prost_hip_fused_iteration_mc_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, double tau, double sigma,
+                                     double theta, int use_kty, int use_kx_prev, int cols, void* stream) {
+  return run_iter_mc<float>(d, x_new, y_new, x, y, tau, sigma, theta, use_kty, use_kx_prev, cols, stream);
+}
+int prost_hip_fused_iteration_mc_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
+                                     double theta, int use_kty, int use_kx_prev, int cols, void* stream) {
+  return run_iter_mc<double>(d, x_new, y_new, x, y, tau, sigma, theta, use_kty, use_kx_prev, cols, stream);
+}
+}  // extern "C"

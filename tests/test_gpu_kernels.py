@@ -545,3 +545,49 @@ def test_short_division_and_sqrt_forms(hip):
     assert total[:4].tolist() == [0, 0, 0, 0], dict(zip(("division", "sqrt", "exact_division", "subtraction"), total.tolist()))
     assert total[4] > 1000, "control: the harness must see the approximate reciprocal fail"
     print("selftest control mismatches:", int(total[4]), "of", 8 << 28)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(6, 8, 3), (21, 1028, 3), (33, 64, 4), (3, 256, 4), (40, 508, 3)])
+@pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
+@pytest.mark.parametrize("vector_b", [True, False])
+def test_multichannel_single_kernel_equals_two_passes(hip, dtype, shape, fns, vector_b):
+    """prost_hip_fused_iteration_mc (3 / 4 channels on the wavefronts of one workgroup, the norm over the 2 L gradient
+    components assembled in LDS in the reference's component order) against the two-pass kernels: same bits for
+    x_new and y_new for every chunk width and flag combination."""
+    nx, ny, L = shape
+    g_fn, f_fn = fns
+    rng = np.random.default_rng(7)
+    n, m = nx * ny * L, 2 * nx * ny * L
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    tau, sigma, theta = dtype(0.9), dtype(1.1), dtype(0.85)
+    g_coeffs = [1.0, f if vector_b else 0.4, 10.0, 0.0, 0.0, 0.3, 0.0]
+    f_coeffs = [1.0, 1.0, 1.0, 0.0, 0.0, 0.3, 0.0]
+    d = hip.FusedDesc(); d.is3d = 0; d.nx, d.ny, d.L = nx, ny, L
+    d.g_fn = hip.FN_ID[g_fn]; d.f_fn = hip.FN_ID[f_fn]
+    gp, gv, k1 = hip.coeff_args(g_coeffs, dtype, n)
+    fp, fv, k2 = hip.coeff_args(f_coeffs, dtype, n)
+    for i in range(7):
+        d.g_coeff_ptr[i] = gp[i]; d.g_coeff_val[i] = gv[i]; d.f_coeff_ptr[i] = fp[i]; d.f_coeff_val[i] = fv[i]
+    d.T_val, d.S_val = 0.25, 0.5
+    dt = 0 if dtype == np.float32 else 1
+    vecw = 4 if dtype == np.float32 else 2
+    assert hip.lib().prost_hip_fused_iteration_mc_supported(C.byref(d), dt) == (1 if ny % vecw == 0 else 0)
+    d1 = hip.FusedDesc(); d1.is3d = 0; d1.nx, d1.ny, d1.L = nx, ny, 1
+    assert hip.lib().prost_hip_fused_iteration_mc_supported(C.byref(d1), dt) == 0          # L = 1, 2: kernels_fused_iter.hip
+    if ny % vecw:
+        return
+    ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    dx, dy = hip.DeviceArray.from_host(x), hip.DeviceArray.from_host(y)
+    for use_kty, use_kxp in ((1, 1), (0, 0), (1, 0)):
+        x_ref = hip.DeviceArray.zeros(n, dtype); y_ref = hip.DeviceArray.zeros(m, dtype)
+        hip.check(hip.fn("fused_primal", dtype)(C.byref(d), x_ref.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau), use_kty, 0, None, ws.ptr, None))
+        hip.check(hip.fn("fused_dual", dtype)(C.byref(d), y_ref.ptr, dy.ptr, x_ref.ptr, dx.ptr, hip.dbl(sigma), hip.dbl(theta), use_kxp, None, ws.ptr, None))
+        for cols in (0, 1, 2, 5, 64):
+            x_new = hip.DeviceArray.zeros(n, dtype); y_new = hip.DeviceArray.zeros(m, dtype)
+            hip.check(hip.fn("fused_iteration_mc", dtype)(C.byref(d), x_new.ptr, y_new.ptr, dx.ptr, dy.ptr, hip.dbl(tau), hip.dbl(sigma), hip.dbl(theta),
+                                                          use_kty, use_kxp, cols, None))
+            assert np.array_equal(x_new.to_host(), x_ref.to_host()), (cols, use_kty)
+            assert np.array_equal(y_new.to_host(), y_ref.to_host()), (cols, use_kty, use_kxp)
+    hip.sync()

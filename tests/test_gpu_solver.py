@@ -85,6 +85,24 @@ def test_pdhg_iterates_match_oracle(precision, dtype, step, fused):
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("single", [True, False])
+def test_pdhg_multichannel_iterates_match_oracle(precision, dtype, single):
+    """RGB / 4-channel ROF (the shape of example_rof_primaldual.m: sum_norm2(2 * nc, ...)).  single = True: one kernel per
+    non-residual iteration with the channels on the wavefronts of a workgroup (kernels_fused_iter_mc.hip), two passes on
+    residual iterations; False: two passes always.  Bit for bit against the oracle."""
+    prost.set_precision(precision)
+    for (nx, ny, L), res_iter in (((24, 16, 3), 3), ((9, 260, 4), 1), ((13, 1028, 3), 10)):
+        prob, u, q, f = synthetic.rof_problem(nx, ny, L, seed=9)
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=res_iter, alg2_gamma=0.5)
+        b[1]["allow_single_kernel"] = single
+        o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+        st = run_product(prob, b, o, 25)
+        assert st["path"] == "pdhg:fused-grad2d"
+        bo = prost.backend.pdhg(stepsize="alg2", residual_iter=res_iter, alg2_gamma=0.5)
+        assert_same_iterates(st, run_oracle(prob, bo, o, 25, dtype))
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("step", STEPS)
 def test_pdhg_matches_reference_golden_fixture(precision, dtype, step):
     """product vs tests/golden/pdhg_rof_16x12x2.npz (iterates of the REAL reference backend)"""

@@ -1,0 +1,65 @@
+"""Micro-benchmark at the kernel C ABI: RGB (L = 3) ROF, two-pass kernels vs the multi-channel one-kernel iteration.
+usage: microbench_iter_mc.py [N L] [cols,cols,...]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from prost_amd import _hip as hip
+
+
+def main(N=4096, Lc=3, cols_list=(0, 6, 12, 18, 24, 36), iters=50, dtype=np.float32):
+    hip.require_device()
+    n, m = N * N * Lc, 2 * N * N * Lc
+    rng = np.random.default_rng(0)
+    f = hip.DeviceArray.from_host(rng.random(n, dtype=np.float32).astype(dtype))
+    x = [hip.DeviceArray.from_host(rng.random(n, dtype=np.float32).astype(dtype)), hip.DeviceArray.zeros(n, dtype)]
+    y = [hip.DeviceArray.from_host((rng.random(m, dtype=np.float32) - 0.5).astype(dtype)), hip.DeviceArray.zeros(m, dtype)]
+    d = hip.FusedDesc(); d.is3d = 0; d.nx, d.ny, d.L = N, N, Lc
+    d.g_fn = hip.FN_ID["square"]; d.f_fn = hip.FN_ID["ind_leq0"]
+    gv = [1, 0, 10, 0, 0, 0, 0]; fv = [1, 1, 1, 0, 0, 0, 0]
+    for i in range(7):
+        d.g_coeff_val[i] = gv[i]; d.f_coeff_val[i] = fv[i]
+    d.g_coeff_ptr[1] = f.ptr.value
+    d.T_val, d.S_val = 0.25, 0.5
+    L_ = hip.lib()
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        hip.check(L_.prost_hip_event_create(C.byref(e)))
+    ws = hip.DeviceArray(L_.prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    esz = np.dtype(dtype).itemsize
+
+    def timed(run):
+        run(5); hip.sync()
+        hip.check(L_.prost_hip_event_record(ev[0], None)); run(iters); hip.check(L_.prost_hip_event_record(ev[1], None))
+        hip.check(L_.prost_hip_event_synchronize(ev[1]))
+        ms = C.c_float(); hip.check(L_.prost_hip_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
+        return ms.value / iters
+
+    P, D, MC = hip.fn("fused_primal", dtype), hip.fn("fused_dual", dtype), hip.fn("fused_iteration_mc", dtype)
+
+    def run2(k):
+        for i in range(k):
+            a, b = i % 2, (i + 1) % 2
+            hip.check(P(C.byref(d), x[b].ptr, x[a].ptr, y[a].ptr, None, hip.dbl(0.3), 1, 0, None, ws.ptr, None))
+            hip.check(D(C.byref(d), y[b].ptr, y[a].ptr, x[b].ptr, x[a].ptr, hip.dbl(1.0), hip.dbl(0.9), 1, None, ws.ptr, None))
+    t = timed(run2)
+    print("two-pass   %dx%dx%d %s: %.4f ms/iteration, %.1f it/s, algorithmic (11 values/pixel/channel) %.0f GB/s" % (N, N, Lc, np.dtype(dtype).name, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3)), flush=True)
+    for cols in cols_list:
+        def run1(k):
+            for i in range(k):
+                a, b = i % 2, (i + 1) % 2
+                hip.check(MC(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, None))
+        t = timed(run1)
+        print("one-kernel cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s, kernel moves (7 values) %.0f GB/s"
+              % (cols, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3), 7 * n * esz / 1e9 / (t * 1e-3)), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 3:
+        cl = tuple(int(c) for c in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 6, 12, 18, 24, 36)
+        main(int(sys.argv[1]), int(sys.argv[2]), cols_list=cl)
+    else:
+        main()
