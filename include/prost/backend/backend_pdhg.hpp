@@ -95,6 +95,7 @@ class BackendPDHG : public Backend<T> {
   /// where the reduction kernels put the four sums: the pinned (device-visible) host buffer, or the device
   /// buffer when an RCCL all-reduce has to run on them first
   bool single_mc_ = false;           // gradient2d, 3 / 4 channels: one kernel per non-residual iteration (prost_hip_fused_iteration_mc_*)
+  bool single3d_pw_ = false;         // ... with the planes across the wavefronts of a workgroup on non-residual iterations
   bool single3d_ = false;            // gradient3d: one kernel per non-residual iteration (prost_hip_fused_iteration3d_*)
   bool arg_fused_g_ = false, arg_fused_f_ = false;     // every prox of prox_g_ / prox_fstar_ evaluates from an argument source
   double* res_target();

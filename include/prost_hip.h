@@ -306,6 +306,16 @@ int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int d
  * instance; other function pairs are supported but register-bound (about 5x slower), so callers pair only here */
 int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int dtype);
 
+/* The same iteration with the PLANES ACROSS THE WAVEFRONTS of a workgroup (kernels_fused_iter3d_pw.hip): `waves` - 1
+ * consecutive planes per workgroup exchange x_new through LDS, one helper wavefront recomputes the plane above the
+ * group (waves = 4 or 8; 0 = automatic).  No residual variant.  Needs L >= 2; otherwise the contract of
+ * prost_hip_fused_iteration3d. */
+int prost_hip_fused_iteration3d_pw_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
+int prost_hip_fused_iteration3d_pw_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, double tau, double sigma,
+                                       double theta, int use_kty, int use_kx_prev, int cols, int waves, void* stream);
+int prost_hip_fused_iteration3d_pw_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
+                                       double theta, int use_kty, int use_kx_prev, int cols, int waves, void* stream);
+
 /* ONE kernel per iteration for gradient2d problems with L = 3 or 4 channels (kernels_fused_iter_mc.hip): the channels
  * run on the wavefronts of one workgroup and meet in LDS for the norm over the 2 L gradient components of a pixel
  * (sum_norm2(2 * nc, ...) of example_rof_primaldual.m).  Same contract as prost_hip_fused_iteration3d without the

@@ -101,6 +101,7 @@ void BackendPDHG<T>::Initialize() {
   for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
   single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
   single3d_ = fused_ && !single_kernel_ && opts_.allow_single_kernel && prost_hip_fused_iteration3d_supported(&desc_, dtype_id<T>()) == 1;
+  single3d_pw_ = single3d_ && prost_hip_fused_iteration3d_pw_supported(&desc_, dtype_id<T>()) == 1;
   single_mc_ = fused_ && !single_kernel_ && !single3d_ && opts_.allow_single_kernel && prost_hip_fused_iteration_mc_supported(&desc_, dtype_id<T>()) == 1;
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
@@ -271,6 +272,10 @@ void BackendPDHG<T>::IterationFused(bool res) {
     // non-residual iteration does not read; on residual iterations y_new goes to y_spare_ (the kernel still reads y_prev_).
     T* y_out = res ? y_spare_.data() : y_prev_.data();
     const bool t3 = BeginSample(res ? kKernelIterRes : kKernelIter);
+    if (single3d_pw_ && !res)        // planes across the wavefronts of a workgroup: x_new of the plane above comes through LDS
+      CheckHip(Api<T>::fused_iteration3d_pw(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
+                                            iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, 0, s), "fused_iteration3d_pw");
+    else
     CheckHip(Api<T>::fused_iteration3d(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
                                        (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
                                        res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration3d");

@@ -115,7 +115,7 @@ def test_tv3d_large_fused_equals_generic(hip):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(6, 8, 1), (5, 12, 4), (20, 1028, 3), (33, 64, 5), (3, 256, 2), (40, 508, 3)])
+@pytest.mark.parametrize("shape", [(6, 8, 1), (5, 12, 4), (20, 1028, 3), (33, 64, 5), (3, 256, 2), (40, 508, 3), (7, 16, 9), (5, 24, 15)])
 @pytest.mark.parametrize("fns", [("square", "ind_leq0"), ("abs", "huber")])
 @pytest.mark.parametrize("vector_b", [True, False])
 def test_single_kernel_3d_iteration_equals_two_passes(hip, dtype, shape, fns, vector_b):
@@ -161,4 +161,13 @@ def test_single_kernel_3d_iteration_equals_two_passes(hip, dtype, shape, fns, ve
                 assert np.array_equal(y_new.to_host(), y_ref.to_host()), (cols, use_kty, use_kxp, res)
                 if res:
                     assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
+            # planes across the wavefronts of a workgroup (x_new exchanged through LDS, one helper wavefront per group)
+            if L >= 2:
+                assert hip.lib().prost_hip_fused_iteration3d_pw_supported(C.byref(d), dt) == 1
+                for waves in (4, 8):
+                    x_new = hip.DeviceArray.zeros(n, dtype); y_new = hip.DeviceArray.zeros(m, dtype)
+                    hip.check(hip.fn("fused_iteration3d_pw", dtype)(C.byref(d), x_new.ptr, y_new.ptr, dx.ptr, dy.ptr, hip.dbl(tau), hip.dbl(sigma), hip.dbl(theta),
+                                                                    use_kty, use_kxp, cols, waves, None))
+                    assert np.array_equal(x_new.to_host(), x_ref.to_host()), ("pw", waves, cols, use_kty)
+                    assert np.array_equal(y_new.to_host(), y_ref.to_host()), ("pw", waves, cols, use_kty, use_kxp)
     hip.sync()

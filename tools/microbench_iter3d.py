@@ -55,6 +55,15 @@ def main(nx=2048, ny=2048, Lp=64, cols_list=(0, 6, 12, 18, 24, 36, 48), iters=30
         t = timed(run1)
         print("one-kernel cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s, kernel moves (9 values/voxel) %.0f GB/s"
               % (cols, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3), 9 * n * esz / 1e9 / (t * 1e-3)), flush=True)
+    PW = hip.fn("fused_iteration3d_pw", dtype)
+    for waves in (4, 8):
+        for cols in (6, 12, 18):
+            def runp(k):
+                for i in range(k):
+                    a, b = i % 2, (i + 1) % 2
+                    hip.check(PW(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, waves, None))
+            t = timed(runp)
+            print("planes-across-waves waves=%d cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s" % (waves, cols, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     yp = hip.DeviceArray.from_host((rng.random(m, dtype=np.float32) - 0.5).astype(dtype)); r4 = hip.DeviceArray.zeros(4, np.float64)
 
     def run_res2(k):
