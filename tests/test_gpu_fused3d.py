@@ -171,3 +171,42 @@ def test_single_kernel_3d_iteration_equals_two_passes(hip, dtype, shape, fns, ve
                     assert np.array_equal(x_new.to_host(), x_ref.to_host()), ("pw", waves, cols, use_kty)
                     assert np.array_equal(y_new.to_host(), y_ref.to_host()), ("pw", waves, cols, use_kty, use_kxp)
     hip.sync()
+
+
+@pytest.mark.parametrize("kernel", ["fused_iteration3d", "fused_iteration3d_pw", "fused_iteration_mc"])
+def test_single_kernel_iterations_write_only_their_outputs(hip, kernel):
+    """Canary words around the output vectors of the one-kernel iterations (halo lanes, halo columns, helper and idle
+    wavefronts must not store anything): shapes whose last row strip, last column chunk and last plane group are
+    partial."""
+    dtype = np.float32
+    rng = np.random.default_rng(17)
+    pad, sentinel = 256, np.float32(-123456.75)
+    for (nx, ny, L) in ((11, 260, 5), (7, 1028, 2), (19, 16, 4), (5, 508, 3)):
+        is3d = kernel != "fused_iteration_mc"
+        if not is3d and L not in (3, 4):
+            continue
+        comps = 3 if is3d else 2
+        n, m = nx * ny * L, comps * nx * ny * L
+        d = hip.FusedDesc(); d.is3d = 1 if is3d else 0; d.nx, d.ny, d.L = nx, ny, L
+        d.g_fn = hip.FN_ID["square"]; d.f_fn = hip.FN_ID["ind_leq0"]
+        f = hip.DeviceArray.from_host(rng.uniform(0, 1, n).astype(dtype))
+        gv = [1, 0, 10, 0, 0, 0, 0]; fv = [1, 1, 1, 0, 0, 0, 0]
+        for i in range(7):
+            d.g_coeff_val[i] = gv[i]; d.f_coeff_val[i] = fv[i]
+        d.g_coeff_ptr[1] = f.ptr.value
+        d.T_val, d.S_val = (1.0 / 6.0 if is3d else 0.25), 0.5
+        dx = hip.DeviceArray.from_host(rng.uniform(0, 1, n).astype(dtype)); dy = hip.DeviceArray.from_host(rng.uniform(-1, 1, m).astype(dtype))
+        for cols in (0, 3):
+            bx = hip.DeviceArray.from_host(np.full(n + 2 * pad, sentinel, dtype)); by = hip.DeviceArray.from_host(np.full(m + 2 * pad, sentinel, dtype))
+            xo = C.c_void_p(bx.ptr.value + pad * 4); yo = C.c_void_p(by.ptr.value + pad * 4)
+            fn = hip.fn(kernel, dtype)
+            if kernel == "fused_iteration3d":
+                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, cols, None, None, None))
+            elif kernel == "fused_iteration3d_pw":
+                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, 0, None))
+            else:
+                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, None))
+            hx, hy = bx.to_host(), by.to_host()
+            for h, k in ((hx, n), (hy, m)):
+                assert np.all(h[:pad] == sentinel) and np.all(h[pad + k:] == sentinel), (kernel, nx, ny, L, cols)
+                assert np.all(h[pad:pad + k] != sentinel)          # and every output element was written
