@@ -47,6 +47,13 @@ void SetCurrentStream(void* stream);
 /// throws prost::Exception(prost_hip_last_error()) if rc != 0
 void CheckHip(int rc, const char* what);
 
+/// fn(begin, end) over disjoint sub-ranges of [0, n) on up to 8 host threads (the one-off setup passes over 10^7..10^8
+/// host entries are memory-bound loops); runs inline when n is small.  fn must only touch its own range.
+void ParallelFor(size_t n, const std::function<void(size_t, size_t)>& fn);
+/// number of sub-ranges ParallelFor(n, ...) uses, and the i-th of them (for two-phase scans with a carried value)
+size_t ParallelChunks(size_t n);
+void ParallelChunkRange(size_t n, size_t i, size_t& begin, size_t& end);
+
 /// Wall-clock of a setup stage, printed to stderr at scope exit when the environment variable
 /// PROST_TIMING is set (the stream is synchronised first so device work is attributed to its stage).
 class StageTimer {

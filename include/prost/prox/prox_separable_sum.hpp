@@ -28,11 +28,14 @@ class ProxSeparableSum : public Prox<T> {
         for (size_t c = 0; c < dim_; c++) base[i * dim_ + c] = avg;
       }
     } else {                                    // planar: component c of element i at i + c * count
-      std::vector<T> avg(count_, (T)0);
-      for (size_t c = 0; c < dim_; c++) { const T* src = base + c * count_; for (size_t i = 0; i < count_; i++) avg[i] += src[i]; }
+      std::vector<T> avg(count_);
       const T cnt = static_cast<T>(dim_);
-      for (size_t i = 0; i < count_; i++) avg[i] /= cnt;
-      for (size_t c = 0; c < dim_; c++) { T* dst = base + c * count_; for (size_t i = 0; i < count_; i++) dst[i] = avg[i]; }
+      ParallelFor(count_, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) avg[i] = 0;
+        for (size_t c = 0; c < dim_; c++) { const T* src = base + c * count_; for (size_t i = b; i < e; i++) avg[i] += src[i]; }
+        for (size_t i = b; i < e; i++) avg[i] /= cnt;
+        for (size_t c = 0; c < dim_; c++) { T* dst = base + c * count_; for (size_t i = b; i < e; i++) dst[i] = avg[i]; }
+      });
     }
   }
 

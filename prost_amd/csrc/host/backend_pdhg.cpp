@@ -10,6 +10,7 @@
 // synchronisation of the loop (the reference synchronises after every prox and twice per
 // residual iteration).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <iostream>
 
@@ -32,8 +33,12 @@ template <typename T>
 static bool uniform(const std::vector<T>& v, T& value) {
   if (v.empty()) return false;
   value = v[0];
-  for (const T& e : v) if (e != value) return false;
-  return true;
+  const T first = value;
+  std::atomic<bool> same(true);
+  ParallelFor(v.size(), [&](size_t b, size_t e) {
+    for (size_t i = b; i < e && same.load(std::memory_order_relaxed); i++) if (v[i] != first) { same.store(false); return; }
+  });
+  return same.load();
 }
 
 /// fused path applies iff: one gradient2d/3d block (not label_first) spanning the whole operator,

@@ -1,5 +1,10 @@
 // common.cpp -- device_vector, stream handling and small host helpers of the prost host library.
+#include <algorithm>
 #include <chrono>
+#include <exception>
+#include <mutex>
+#include <thread>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -120,6 +125,34 @@ int32_t GlibcRand::next() {
   r_.push_back(v);
   if (r_.size() > 8192) r_.erase(r_.begin(), r_.begin() + 4096);
   return (int32_t)(v >> 1);
+}
+
+size_t ParallelChunks(size_t n) {
+  const size_t kMinChunk = (size_t)1 << 20;
+  size_t hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 1;
+  const size_t t = std::min<size_t>(std::min<size_t>(8, hw), (n + kMinChunk - 1) / kMinChunk);
+  return t < 1 ? 1 : t;
+}
+void ParallelChunkRange(size_t n, size_t i, size_t& begin, size_t& end) {
+  const size_t t = ParallelChunks(n), per = (n + t - 1) / t;
+  begin = std::min(n, i * per);
+  end = std::min(n, begin + per);
+}
+void ParallelFor(size_t n, const std::function<void(size_t, size_t)>& fn) {
+  const size_t t = ParallelChunks(n);
+  if (t <= 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  std::exception_ptr err = nullptr;
+  std::mutex mu;
+  for (size_t i = 1; i < t; i++) {
+    size_t b, e; ParallelChunkRange(n, i, b, e);
+    th.emplace_back([&, b, e]() { try { fn(b, e); } catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); } });
+  }
+  size_t b0, e0; ParallelChunkRange(n, 0, b0, e0);
+  try { fn(b0, e0); } catch (...) { std::lock_guard<std::mutex> g(mu); err = std::current_exception(); }
+  for (auto& x : th) x.join();
+  if (err) std::rethrow_exception(err);
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

@@ -29,8 +29,8 @@ template class Block<double>;
   template <typename T> void CLS<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) { CheckHip(Api<T>::ADJ(r, x, nx_, ny_, L_, label_first_, 1, CurrentStream()), #ADJ); }   \
   template <typename T> void CLS<T>::EvalLocal(T* r, T*, const T* x, const T*) { CheckHip(Api<T>::FWD(r, x, nx_, ny_, L_, label_first_, 0, CurrentStream()), #FWD); }             \
   template <typename T> void CLS<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) { CheckHip(Api<T>::ADJ(r, x, nx_, ny_, L_, label_first_, 0, CurrentStream()), #ADJ); }      \
-  template <typename T> void CLS<T>::row_sums(T* out, T) const { for (size_t r = 0; r < this->nrows(); r++) out[r] += 2; }    \
-  template <typename T> void CLS<T>::col_sums(T* out, T) const { for (size_t c = 0; c < this->ncols(); c++) out[c] += CS; }   \
+  template <typename T> void CLS<T>::row_sums(T* out, T) const { ParallelFor(this->nrows(), [&](size_t b, size_t e) { for (size_t r = b; r < e; r++) out[r] += 2; }); }    \
+  template <typename T> void CLS<T>::col_sums(T* out, T) const { ParallelFor(this->ncols(), [&](size_t b, size_t e) { for (size_t c = b; c < e; c++) out[c] += CS; }); }   \
   template class CLS<float>;                                                                                           \
   template class CLS<double>;
 GRAD_IMPL(BlockGradient2D, grad2d_fwd, grad2d_adj, 4)

@@ -75,6 +75,33 @@ void Problem<T>::SetScalingCustom(const std::vector<T>& left, const std::vector<
   for (size_t i = 0; i < right.size(); i++) scaling_right_host_[i] = right[i] * right[i];
 }
 
+/// out[i] = 1 / sums[i] where sums[i] > 0, else the last value written before it (`carry` before the first entry);
+/// returns the value carried out of the sweep.  Same results as the sequential sweep of problem.cu:262-287.
+template <typename T>
+static T CarriedReciprocals(const std::vector<T>& sums, std::vector<T>& out, T carry) {
+  const size_t n = sums.size(), chunks = ParallelChunks(n);
+  std::vector<T> last(chunks);            // reciprocal of the last positive sum of each sub-range (or 0: none)
+  ParallelFor(n, [&](size_t b, size_t e) {
+    size_t ci = 0;
+    for (size_t i = 0; i < chunks; i++) { size_t cb, ce; ParallelChunkRange(n, i, cb, ce); if (cb == b) { ci = i; break; } }
+    T v = 0;
+    for (size_t i = e; i > b; i--) if (sums[i - 1] > 0) { v = (T)(1. / (double)sums[i - 1]); break; }
+    last[ci] = v;
+  });
+  std::vector<T> carry_in(chunks);
+  for (size_t i = 0; i < chunks; i++) { carry_in[i] = carry; if (last[i] > 0) carry = last[i]; }
+  ParallelFor(n, [&](size_t b, size_t e) {
+    size_t ci = 0;
+    for (size_t i = 0; i < chunks; i++) { size_t cb, ce; ParallelChunkRange(n, i, cb, ce); if (cb == b) { ci = i; break; } }
+    T value = carry_in[ci], last_sum = 0;
+    for (size_t r = b; r < e; r++) {
+      if (sums[r] > 0 && sums[r] != last_sum) { last_sum = sums[r]; value = (T)(1. / (double)sums[r]); }
+      out[r] = value;
+    }
+  });
+  return carry;
+}
+
 template <typename T>
 void Problem<T>::InitializeHost() {
   if (host_initialized_) return;
@@ -106,18 +133,13 @@ void Problem<T>::InitializeHost() {
     std::vector<T> sums(nrows_);
     StageTimer t_pre("  preconditioner sums");
     linop_->row_sums(sums, scaling_alpha_);
-    // (the reciprocal is only re-evaluated when the sum changes: stencil operators repeat one value 10^7 times)
-    T value = 1, last_sum = 0;
-    for (size_t r = 0; r < nrows_; r++) {
-      if (sums[r] > 0 && sums[r] != last_sum) { last_sum = sums[r]; value = (T)(1. / (double)sums[r]); }
-      scaling_left_host_[r] = value;
-    }
+    // (the reciprocal is only re-evaluated when the sum changes: stencil operators repeat one value 10^7 times; the sweep
+    // runs on several host threads -- a sub-range starts from the value the sweep carries into it, found in a first pass)
+    T value = 1;
+    value = CarriedReciprocals(sums, scaling_left_host_, value);
     sums.assign(ncols_, 0);
     linop_->col_sums(sums, (T)(2. - (double)scaling_alpha_));
-    for (size_t c = 0; c < ncols_; c++) {
-      if (sums[c] > 0 && sums[c] != last_sum) { last_sum = sums[c]; value = (T)(1. / (double)sums[c]); }
-      scaling_right_host_[c] = value;
-    }
+    value = CarriedReciprocals(sums, scaling_right_host_, value);
   } else if (scaling_type_ == kScalingIdentity) {
     scaling_left_host_.assign(nrows_, 1);
     scaling_right_host_.assign(ncols_, 1);
