@@ -1,9 +1,9 @@
 #!/bin/bash
 # On the GPU box: bench line + rocprofv3 kernel stats + HBM traffic counters (separate --pmc passes).
 R=$PWD; mkdir -p $R/gpurun_out/prof
-python bench.py --steps 500 --warmup 20 2>/dev/null | tail -1 > $R/gpurun_out/bench_r01.json
+python bench.py 2>/dev/null | tail -1 > $R/gpurun_out/bench_r01.json
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python3 $R/bench.py --steps 500 --warmup 20 --no-cpu-baseline > $R/gpurun_out/prof/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof/bench_under_rocprof.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof -o pmc_fetch -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof -o pmc_write -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 python3 - <<PY
