@@ -60,12 +60,12 @@ def main():
             b = prost.backend.admm(rho0=1)
             b[1]["device_cg"] = device_cg
             b[1]["cg_graph"] = os.environ.get("PROST_CG_GRAPH", "0") == "1"
-            run(prob, b, 100, 5, None, n, "TV-L1 flow-like %dx%d fp32 ADMM (block.sparse + gradient2d L=2), %s CG scalars" % (N, N, "device" if device_cg else "host"))
+            run(prob, b, 300, 50, None, n, "TV-L1 flow-like %dx%d fp32 ADMM (block.sparse + gradient2d L=2), %s CG scalars" % (N, N, "device" if device_cg else "host"))
         if len(sys.argv) <= 3 or sys.argv[3] == "pdhg":
-            run(prob, prost.backend.pdhg(stepsize="boyd", residual_iter=10), 200, 10, None, n, "TV-L1 flow-like %dx%d fp32 PDHG generic path" % (N, N))
+            run(prob, prost.backend.pdhg(stepsize="boyd", residual_iter=10), 5000, 1000, None, n, "TV-L1 flow-like %dx%d fp32 PDHG generic path" % (N, N))
     else:
         prob, u, q, f = synthetic.rof_problem(256, 256)
-        run(prob, prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5), 2000, 50, 11, 256 * 256, "ROF 256x256 fp32 PDHG alg2")
+        run(prob, prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5), 50000, 10000, 11, 256 * 256, "ROF 256x256 fp32 PDHG alg2")
 
 
 if __name__ == "__main__":
