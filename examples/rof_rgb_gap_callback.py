@@ -4,7 +4,7 @@ The MATLAB script reads images/lion.png (700 x 464 RGB); no image file travels w
 image of the same size stands in (prost_amd.synthetic.rof_image).  Everything from `u = prost.variable(...)` on is the
 reference's problem description unchanged; the primal-dual gap callback is example_rof_pdgap.m with the sparse
 gradient matrix of +test/private/spmat_gradient2d.m.
-usage: python examples/example_rof_primaldual.py [nx ny nc]"""
+usage: python examples/rof_rgb_gap_callback.py [nx ny nc]"""
 import os
 import sys
 import time

@@ -1,6 +1,6 @@
 """matlab/examples/example_tvl1.m on the MI355X build: TV-L1 denoising of an image with 25 % salt & pepper noise
 (sum_1d('abs') data term, vectorial TV), PDHG with Boyd's residual balancing.  Synthetic image instead of images/fisch.jpg.
-usage: python examples/example_tvl1.py [nx ny nc]"""
+usage: python examples/tvl1_salt_and_pepper.py [nx ny nc]"""
 import os
 import sys
 import time

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_example_rof_primaldual_converges_by_its_own_gap_callback():
-    import example_rof_primaldual as ex
+    import rof_rgb_gap_callback as ex
     prost.set_gpu(0)
     prost.set_precision("double")          # the MEX default (config.hpp:7)
     result, gaps, img = ex.main(nx=70, ny=48, nc=3, max_iters=10000, verbose=False)
@@ -22,7 +22,7 @@ def test_example_rof_primaldual_converges_by_its_own_gap_callback():
 
 
 def test_example_tvl1_removes_salt_and_pepper_noise():
-    import example_tvl1 as ex
+    import tvl1_salt_and_pepper as ex
     prost.set_gpu(0)
     prost.set_precision("double")
     result, err_noisy, err_denoised = ex.main(nx=96, ny=64, nc=1, max_iters=20000, verbose=False)
