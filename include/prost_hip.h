@@ -318,14 +318,16 @@ int prost_hip_fused_iteration3d_pw_f64(const prost_hip_fused_desc* desc, double*
 
 /* ONE kernel per iteration for gradient2d problems with L = 3 or 4 channels (kernels_fused_iter_mc.hip): the channels
  * run on the wavefronts of one workgroup and meet in LDS for the norm over the 2 L gradient components of a pixel
- * (sum_norm2(2 * nc, ...) of example_rof_primaldual.m).  Same contract as prost_hip_fused_iteration3d without the
- * residual variant: outputs must not alias inputs, ny a multiple of the vector width, scalar coefficients except b
- * of prox_g. */
+ * (sum_norm2(2 * nc, ...) of example_rof_primaldual.m).  Same contract as prost_hip_fused_iteration3d (incl. the
+ * residual variant: y_prev, res_out4, workspace): outputs must not alias inputs, ny a multiple of the vector width,
+ * scalar coefficients except b of prox_g. */
 int prost_hip_fused_iteration_mc_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
-int prost_hip_fused_iteration_mc_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, double tau, double sigma,
-                                     double theta, int use_kty, int use_kx_prev, int cols, void* stream);
-int prost_hip_fused_iteration_mc_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
-                                     double theta, int use_kty, int use_kx_prev, int cols, void* stream);
+int prost_hip_fused_iteration_mc_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
+                                     double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,
+                                     void* workspace, void* stream);
+int prost_hip_fused_iteration_mc_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev,
+                                     double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,
+                                     void* workspace, void* stream);
 
 /* ONE kernel per iteration for gradient3d problems (kernels_fused_iter3d.hip): x_new = prox_g(x - tau T K^T y),
  * y_new = prox_f*(y + sigma S K(x_new + theta (x_new - x))) with x_new of plane l+1 recomputed in registers

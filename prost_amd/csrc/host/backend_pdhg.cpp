@@ -111,7 +111,7 @@ void BackendPDHG<T>::Initialize() {
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
-  if (single_kernel_ || single3d_) y_spare_.resize(m);
+  if (single_kernel_ || single3d_ || single_mc_) y_spare_.resize(m);
   pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_profitable(&desc_, dtype_id<T>()) == 1;
   if (pair_kernel_) x_spare_.resize(n);
 
@@ -293,15 +293,19 @@ void BackendPDHG<T>::IterationFused(bool res) {
     iteration_++;
     return;
   }
-  if (single_mc_ && !res) {
-    // gradient2d with 3 / 4 channels, no residual sums wanted: one kernel, the channels on the wavefronts of a workgroup
-    // (7 instead of 11 values per pixel and channel); residual iterations take the two passes below
-    const bool tm = BeginSample(kKernelIter);
-    CheckHip(Api<T>::fused_iteration_mc(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
-                                        iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, s), "fused_iteration_mc");
+  if (single_mc_) {
+    // gradient2d with 3 / 4 channels: one kernel, the channels on the wavefronts of a workgroup (7 instead of 11 values per
+    // pixel and channel; residual iterations add the y_prev stream and the four sums, y_new then goes to y_spare_)
+    T* y_out = res ? y_spare_.data() : y_prev_.data();
+    const bool tm = BeginSample(res ? kKernelIterRes : kKernelIter);
+    CheckHip(Api<T>::fused_iteration_mc(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
+                                        (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
+                                        res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration_mc");
     EndSample(tm);
     x_.swap(x_prev_);
+    if (res) y_prev_.swap(y_spare_);
     y_.swap(y_prev_);
+    if (res) FinishResiduals();
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
     return;

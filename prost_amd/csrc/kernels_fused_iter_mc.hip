@@ -13,23 +13,27 @@
 // double-buffered so that one barrier per column suffices.
 //     per channel and column: load y1, y2, x, f of column c+1; store x_new[c+1], y1_new[c], y2_new[c]
 //     = 7 floats / pixel / channel / iteration (two passes: 11).
-// No residual variant: residual iterations run the two-pass kernels.
+// RES = true (residual iterations) additionally streams y_prev of the channel and accumulates the four residual sums of
+// backend_pdhg.cu:392-431 (one partial of 4 doubles per wavefront, folded by fold4).
 #include "fused_common.hpp"
+#include "reduce.hpp"
 
 namespace prost_hip {
 
-template <class T, int VEC, bool GB>
+template <class T, int VEC, bool GB, bool RES>
 struct ColMc {
   T y1[VEC], y2[VEC], x[VEC], b[GB ? VEC : 1];
   T up;              // y2 of the row above the wave's first row (lane 0)
+  T p1[RES ? VEC : 1], p2[RES ? VEC : 1], pup;      // y_prev of this channel (RES only)
 };
 
 // GB: coefficient b of prox_g is a per-pixel vector; every other coefficient of prox_g and all of prox_f* are scalars.
 // FAST: straight-line ROF instance (square / ind_leq0 with scalar a = 1, d = e = 0), forms of device_math.hpp.
-template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, int LW>
+template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, int LW, bool RES>
 __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restrict__ x_new, T* __restrict__ y_new, const T* __restrict__ x,
-                                                                    const T* __restrict__ y, FusedArgs<T> a, T tau, T sigma, T theta,
-                                                                    UniformProx<T> ug, UniformProx<T> uf, bool use_kty, bool use_kx_prev) {
+                                                                    const T* __restrict__ y, const T* __restrict__ y_prev, FusedArgs<T> a, T tau,
+                                                                    T sigma, T theta, UniformProx<T> ug, UniformProx<T> uf, bool use_kty,
+                                                                    bool use_kx_prev, bool use_kty_prev, double* __restrict__ partial) {
   constexpr int kRowsPerWave = (kWave - 1) * VEC;
   constexpr int kPix = kWave * VEC;
   __shared__ T s_sq[2][2 * LW][kPix];
@@ -49,19 +53,27 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
   const T* y1 = y + plane; const T* y2 = y + N + plane;
   const T* xp = x + plane;
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
+  const T* q1 = RES ? y_prev + plane : nullptr; const T* q2 = RES ? y_prev + N + plane : nullptr;
+  const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  const SharedDivisor<T> div_tauT(tau * sqT), div_sigS(sigma * sqS);        // wave-uniform residual divisors
+  double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
-  typedef ColMc<T, VEC, GB> Col;
+  typedef ColMc<T, VEC, GB, RES> Col;
   auto load_col = [&](size_t c, Col& in) {
     const size_t o = c * ny + row0;
     ldv<T, VEC>(y1 + o, in.y1); ldv<T, VEC>(y2 + o, in.y2); ldv<T, VEC>(xp + o, in.x);
     if (GB) ldv<T, GB ? VEC : 1>(bp + o, in.b);
     in.up = (lane == 0 && row0 > 0) ? y2[o - 1] : (T)0;
+    if (RES) {
+      ldv<T, RES ? VEC : 1>(q1 + o, in.p1); ldv<T, RES ? VEC : 1>(q2 + o, in.p2);
+      in.pup = (lane == 0 && row0 > 0) ? q2[o - 1] : (T)0;
+    }
   };
   // x_new of this channel at column c (backend_pdhg.cu:317-338, block_gradient2d.cu:122-138 on a zero-filled result)
-  auto primal_col = [&](size_t c, const Col& in, const T (&p1)[VEC], bool have_prev, T (&xn)[VEC]) {
+  auto primal_col = [&](size_t c, const Col& in, const T (&p1)[VEC], bool have_prev, T (&xn)[VEC], const T (&pp1)[RES ? VEC : 1], bool counted) {
     T up = __shfl_up(in.y2[VEC - 1], 1, kWave);
     if (lane == 0) up = in.up;
-    T parg[VEC];
+    T parg[VEC], ktyv[RES ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const size_t row = row0 + j;
@@ -70,6 +82,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       T divx = (c < nx - 1) ? in.y1[j] : (T)0;
       if (have_prev) divx -= p1[j];
       const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+      if (RES) ktyv[RES ? j : 0] = kty;
       const T arg = in.x[j] - tauT * kty;
       if (FAST) {
         parg[j] = arg - (GB ? in.b[GB ? j : 0] : a.g_val[1]);
@@ -87,18 +100,40 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
 #pragma unroll
       for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? in.b[GB ? j : 0] : a.g_val[1]);
     }
+    if (RES) {                                              // dual_residual_transform (backend_pdhg.cu:73-94)
+      T upp = __shfl_up(in.p2[RES ? VEC - 1 : 0], 1, kWave);
+      if (lane == 0) upp = in.pup;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const size_t row = row0 + j;
+        const int jj = RES ? j : 0;
+        T dpy = (row < ny - 1) ? in.p2[jj] : (T)0;
+        if (row > 0) dpy -= (j > 0 ? in.p2[RES && j > 0 ? j - 1 : 0] : upp);
+        T dpx = (c < nx - 1) ? in.p1[jj] : (T)0;
+        if (have_prev) dpx -= pp1[jj];
+        const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
+        const T w_hat = div_tauT.div(in.x[j] - xn[j]) - sqT * ktyp;
+        const T diff = w_hat + sqT * ktyv[jj];
+        if (owner && counted) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
+      }
+    }
   };
 
   Col cur = {}, nxt = {};
-  T h1[VEC], xn_c[VEC], xn_n[VEC];
+  T h1[VEC], xn_c[VEC], xn_n[VEC], hp1[RES ? VEC : 1];
 #pragma unroll
   for (int j = 0; j < VEC; j++) { h1[j] = 0; xn_c[j] = 0; xn_n[j] = 0; }
+#pragma unroll
+  for (int j = 0; j < (RES ? VEC : 1); j++) hp1[j] = 0;
   if (active) {
     load_col(xa, cur);
-    if (xa > 0) ldv<T, VEC>(y1 + (xa - 1) * ny + row0, h1);
+    if (xa > 0) {
+      ldv<T, VEC>(y1 + (xa - 1) * ny + row0, h1);
+      if (RES) ldv<T, RES ? VEC : 1>(q1 + (xa - 1) * ny + row0, hp1);
+    }
     if (xa + 1 < nx) load_col(xa + 1, nxt);
   }
-  primal_col(xa, cur, h1, xa > 0, xn_c);
+  primal_col(xa, cur, h1, xa > 0, xn_c, hp1, true);
   if (owner) stv_nt<T, VEC>(x_new + plane + xa * ny + row0, xn_c);
 
   for (size_t c = xa; c < xb; c++) {
@@ -107,13 +142,14 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
     const bool has_pre = c + 2 < nx && c + 1 < xb;
     if (active && has_pre) load_col(c + 2, pre);
     if (has_next) {
-      primal_col(c + 1, nxt, cur.y1, true, xn_n);
+      primal_col(c + 1, nxt, cur.y1, true, xn_n, cur.p1, c + 1 < xb);
       if (owner && c + 1 < xb) stv_nt<T, VEC>(x_new + plane + (c + 1) * ny + row0, xn_n);
     }
     // ---- dual step of column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77) ----
     const T bel_n = __shfl_down(xn_c[0], 1, kWave);
     const T bel_o = __shfl_down(cur.x[0], 1, kWave);
     T av[2][VEC];
+    T kxv[RES ? 2 : 1][RES ? VEC : 1], kpv[RES ? 2 : 1][RES ? VEC : 1];
     const int buf = (int)(c & 1);
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
@@ -126,6 +162,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       const T kp1 = (use_kx_prev && row < ny - 1) ? below_o - cur.x[j] : (T)0;
       av[0][j] = cur.y1[j] + sigS * ((1 + theta) * kx0 - theta * kp0);       // backend_pdhg.cu:54-70
       av[1][j] = cur.y2[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
+      if (RES) { kxv[0][RES ? j : 0] = kx0; kxv[RES ? 1 : 0][RES ? j : 0] = kx1; kpv[0][RES ? j : 0] = kp0; kpv[RES ? 1 : 0][RES ? j : 0] = kp1; }
       s_sq[buf][ch][j * kWave + lane] = av[0][j] * av[0][j];             // [j][lane]: conflict-free banks
       s_sq[buf][LW + ch][j * kWave + lane] = av[1][j] * av[1][j];
     }
@@ -183,6 +220,19 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
           }
         }
       }
+      if (RES) {                                            // primal_residual_transform (backend_pdhg.cu:97-120)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const T yo = i == 0 ? cur.y1[j] : cur.y2[j];
+            const T kxi = kxv[RES ? i : 0][RES ? j : 0], kpi = kpv[RES ? i : 0][RES ? j : 0];
+            const T z_hat = div_sigS.div(yo - out[i][j]) + sqS * ((1 + theta) * kxi - theta * kpi);
+            const T diff = z_hat - sqS * kxi;
+            r_pd += (double)(diff * diff); r_pv += (double)(z_hat * z_hat);
+          }
+        }
+      }
       const size_t o = plane + c * ny + row0;
       stv_nt<T, VEC>(y_new + o, out[0]);
       stv_nt<T, VEC>(y_new + N + o, out[1]);
@@ -191,6 +241,13 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
     if (has_pre) nxt = pre;
 #pragma unroll
     for (int j = 0; j < VEC; j++) xn_c[j] = xn_n[j];
+  }
+  if (RES) {
+    r_pd = wave_sum(r_pd); r_pv = wave_sum(r_pv); r_dd = wave_sum(r_dd); r_dv = wave_sum(r_dv);
+    if (lane == 0) {
+      double* p = partial + 4 * ((size_t)blockIdx.x * LW + ch);
+      p[0] = r_pd; p[1] = r_pv; p[2] = r_dd; p[3] = r_dv;
+    }
   }
 }
 
@@ -211,11 +268,12 @@ static bool iter_mc_ok(const prost_hip_fused_desc* d) {
 }
 
 template <class T>
-static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, double tau, double sigma, double theta,
-                       int use_kty, int use_kx_prev, int cols, void* stream) {
+static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
+                       int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream) {
   if (!iter_mc_ok<T>(d)) { set_error("fused multi-channel iteration: unsupported description (see prost_hip_fused_iteration_mc_supported)"); return 1; }
-  if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y)) { set_error("fused multi-channel iteration: vectors must be 16-byte aligned"); return 1; }
-  if (x_new == x || y_new == y) { set_error("fused multi-channel iteration: outputs must not alias inputs"); return 1; }
+  if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y) || !aligned16(y_prev)) { set_error("fused multi-channel iteration: vectors must be 16-byte aligned"); return 1; }
+  if (x_new == x || y_new == y || (out4 && y_new == y_prev)) { set_error("fused multi-channel iteration: outputs must not alias inputs"); return 1; }
+  if (out4 && (!ws || !y_prev)) { set_error("fused multi-channel iteration: residuals need the reduction workspace and y_prev"); return 1; }
   constexpr int V = VecOf<T>::N;
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t strips = (d->ny + (size_t)(kWave - 1) * V - 1) / ((size_t)(kWave - 1) * V);
@@ -223,23 +281,32 @@ static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const 
   // to hide the per-column barrier; one halo column each)
   size_t c = cols > 0 ? (size_t)cols : 12;
   if (cols <= 0) while (c > 3 && strips * ((d->nx + c - 1) / c) * d->L < 4096) c -= 3;
+  // residual launches: one partial of 4 doubles per wavefront must fit the reduction workspace
+  const size_t max_waves = (size_t)kReduceBlocks / 2;
+  if (out4) while (c < d->nx && strips * ((d->nx + c - 1) / c) * d->L > max_waves) c += 6;
   if (c > d->nx) c = d->nx;
+  if (out4 && strips * ((d->nx + c - 1) / c) * d->L > max_waves) { set_error("fused multi-channel iteration: grid exceeds the reduction workspace"); return 1; }
   a.cols_per_block = (unsigned)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
   const unsigned grid = (unsigned)(strips * a.chunks);
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   hipStream_t s = as_stream(stream);
+  double* partial = static_cast<double*>(ws);
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO2(G, F, B, FASTv, LWv) hipLaunchKernelGGL((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0)
+#define GO3(G, F, B, FASTv, LWv, R) hipLaunchKernelGGL((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO2(G, F, B, FASTv, LWv) do { if (out4) GO3(G, F, B, FASTv, LWv, true); else GO3(G, F, B, FASTv, LWv, false); } while (0)
 #define GO(G, F, B, FASTv) do { if (d->L == 3) GO2(G, F, B, FASTv, 3); else GO2(G, F, B, FASTv, 4); } while (0)
   if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
   else { if (gb) GO(-1, -1, true, false); else GO(-1, -1, false, false); }
 #undef GO
 #undef GO2
-  PH_LAUNCH_END("fused multi-channel iteration kernel");
+#undef GO3
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel iteration kernel"); }
+  if (out4) return launch_fold4(out4, partial, grid * (unsigned)d->L, s);
+  return 0;
 }
 
 }  // namespace prost_hip
@@ -248,12 +315,14 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration_mc_supported(const prost_hip_fused_desc* d, int dtype) { return (dtype == 0 ? iter_mc_ok<float>(d) : iter_mc_ok<double>(d)) ? 1 : 0; }
-int prost_hip_fused_iteration_mc_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, double tau, double sigma,
-                                     double theta, int use_kty, int use_kx_prev, int cols, void* stream) {
-  return run_iter_mc<float>(d, x_new, y_new, x, y, tau, sigma, theta, use_kty, use_kx_prev, cols, stream);
+int prost_hip_fused_iteration_mc_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev, double tau,
+                                     double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace,
+                                     void* stream) {
+  return run_iter_mc<float>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream);
 }
-int prost_hip_fused_iteration_mc_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
-                                     double theta, int use_kty, int use_kx_prev, int cols, void* stream) {
-  return run_iter_mc<double>(d, x_new, y_new, x, y, tau, sigma, theta, use_kty, use_kx_prev, cols, stream);
+int prost_hip_fused_iteration_mc_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev, double tau,
+                                     double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace,
+                                     void* stream) {
+  return run_iter_mc<double>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream);
 }
 }  // extern "C"

@@ -205,7 +205,7 @@ def test_single_kernel_iterations_write_only_their_outputs(hip, kernel):
             elif kernel == "fused_iteration3d_pw":
                 hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, 0, None))
             else:
-                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, None))
+                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, cols, None, None, None))
             hx, hy = bx.to_host(), by.to_host()
             for h, k in ((hx, n), (hy, m)):
                 assert np.all(h[:pad] == sentinel) and np.all(h[pad + k:] == sentinel), (kernel, nx, ny, L, cols)

@@ -580,14 +580,20 @@ def test_multichannel_single_kernel_equals_two_passes(hip, dtype, shape, fns, ve
         return
     ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
     dx, dy = hip.DeviceArray.from_host(x), hip.DeviceArray.from_host(y)
-    for use_kty, use_kxp in ((1, 1), (0, 0), (1, 0)):
+    dyp = hip.DeviceArray.from_host(rng.uniform(-1, 1, m).astype(dtype))
+    for use_kty, use_kxp, use_ktyp in ((1, 1, 1), (0, 0, 0), (1, 0, 0), (1, 1, 0)):
         x_ref = hip.DeviceArray.zeros(n, dtype); y_ref = hip.DeviceArray.zeros(m, dtype)
-        hip.check(hip.fn("fused_primal", dtype)(C.byref(d), x_ref.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau), use_kty, 0, None, ws.ptr, None))
-        hip.check(hip.fn("fused_dual", dtype)(C.byref(d), y_ref.ptr, dy.ptr, x_ref.ptr, dx.ptr, hip.dbl(sigma), hip.dbl(theta), use_kxp, None, ws.ptr, None))
+        rd = hip.DeviceArray.zeros(2, np.float64); rp = hip.DeviceArray.zeros(2, np.float64)
+        hip.check(hip.fn("fused_primal", dtype)(C.byref(d), x_ref.ptr, dx.ptr, dy.ptr, dyp.ptr, hip.dbl(tau), use_kty, use_ktyp, rd.ptr, ws.ptr, None))
+        hip.check(hip.fn("fused_dual", dtype)(C.byref(d), y_ref.ptr, dy.ptr, x_ref.ptr, dx.ptr, hip.dbl(sigma), hip.dbl(theta), use_kxp, rp.ptr, ws.ptr, None))
+        res_ref = np.concatenate([rp.to_host(), rd.to_host()])      # {primal diff^2, primal var^2, dual diff^2, dual var^2}
         for cols in (0, 1, 2, 5, 64):
-            x_new = hip.DeviceArray.zeros(n, dtype); y_new = hip.DeviceArray.zeros(m, dtype)
-            hip.check(hip.fn("fused_iteration_mc", dtype)(C.byref(d), x_new.ptr, y_new.ptr, dx.ptr, dy.ptr, hip.dbl(tau), hip.dbl(sigma), hip.dbl(theta),
-                                                          use_kty, use_kxp, cols, None))
-            assert np.array_equal(x_new.to_host(), x_ref.to_host()), (cols, use_kty)
-            assert np.array_equal(y_new.to_host(), y_ref.to_host()), (cols, use_kty, use_kxp)
+            for res in (False, True):
+                x_new = hip.DeviceArray.zeros(n, dtype); y_new = hip.DeviceArray.zeros(m, dtype); r4 = hip.DeviceArray.zeros(4, np.float64)
+                hip.check(hip.fn("fused_iteration_mc", dtype)(C.byref(d), x_new.ptr, y_new.ptr, dx.ptr, dy.ptr, dyp.ptr if res else None, hip.dbl(tau), hip.dbl(sigma),
+                                                              hip.dbl(theta), use_kty, use_kxp, use_ktyp, cols, r4.ptr if res else None, ws.ptr if res else None, None))
+                assert np.array_equal(x_new.to_host(), x_ref.to_host()), (cols, use_kty, res)
+                assert np.array_equal(y_new.to_host(), y_ref.to_host()), (cols, use_kty, use_kxp, res)
+                if res:
+                    assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
     hip.sync()

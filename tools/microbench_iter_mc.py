@@ -51,10 +51,22 @@ def main(N=4096, Lc=3, cols_list=(0, 6, 12, 18, 24, 36), iters=50, dtype=np.floa
         def run1(k):
             for i in range(k):
                 a, b = i % 2, (i + 1) % 2
-                hip.check(MC(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, None))
+                hip.check(MC(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, cols, None, None, None))
         t = timed(run1)
         print("one-kernel cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s, kernel moves (7 values) %.0f GB/s"
               % (cols, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3), 7 * n * esz / 1e9 / (t * 1e-3)), flush=True)
+    yp = hip.DeviceArray.from_host((rng.random(m, dtype=np.float32) - 0.5).astype(dtype)); r4 = hip.DeviceArray.zeros(4, np.float64)
+
+    def run_res2(k):
+        for i in range(k):
+            hip.check(P(C.byref(d), x[1].ptr, x[0].ptr, y[0].ptr, yp.ptr, hip.dbl(0.3), 1, 1, r4.ptr, ws.ptr, None))
+            hip.check(D(C.byref(d), y[1].ptr, y[0].ptr, x[1].ptr, x[0].ptr, hip.dbl(1.0), hip.dbl(0.9), 1, r4.ptr, ws.ptr, None))
+    print("residual iteration: two-pass %.4f ms" % timed(run_res2), flush=True)
+    for cols in (0, 12, 18, 24, 36):
+        def run_res1(k):
+            for i in range(k):
+                hip.check(MC(C.byref(d), x[1].ptr, y[1].ptr, x[0].ptr, y[0].ptr, yp.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, cols, r4.ptr, ws.ptr, None))
+        print("residual iteration: one-kernel cols=%d %.4f ms" % (cols, timed(run_res1)), flush=True)
 
 
 if __name__ == "__main__":
