@@ -113,6 +113,37 @@ def test_problem_info_matches_oracle_setup(precision):
         prost.set_precision("double")
 
 
+def test_problem_setup_on_several_host_threads_matches_oracle():
+    """The preconditioner sweeps run on up to 8 host threads above ~10^6 entries (ParallelFor): a 1300 x 1100 image
+    (1.43 M pixels, 2.86 M rows) plus a sparse block with long runs of empty rows / columns, so that the value the
+    sequential sweep carries over empty rows (problem.cu:262-287) has to cross sub-range boundaries."""
+    import scipy.sparse as sp
+    prost.set_precision("single")
+    try:
+        nx, ny = 1300, 1100
+        n = nx * ny
+        kr, kc = 2_400_000, 1_300_000
+        rows = np.array([5, 17, 1_200_000, 1_200_001, 2_399_990]); cols = np.array([3, 600_000, 600_001, 1_299_999, 7])
+        K = sp.csc_matrix((np.array([0.5, -2.0, 3.0, 0.25, 1.5]), (rows, cols)), shape=(kr, kc))
+        u, w = prost.variable(n), prost.variable(kc)
+        q, r = prost.variable(2 * n), prost.variable(kr)
+        prob = prost.min_max_problem([u, w], [q, r])
+        prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, 1))
+        prob.add_dual_pair(w, r, prost.block.sparse(K))
+        prob.add_function(u, prost.function.sum_1d("square", 1, 0.5, 10))
+        prob.add_function(q, prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1))
+        prob.set_scaling_alpha(1.0)
+        info = prost.problem_info(prob)
+        P = oracle.Problem(prob.data, prob.nrows, prob.ncols, np.float32)
+        P.initialize()
+        sl, sr = P.scaling()
+        assert np.array_equal(np.asarray(info["scaling_left"]), sl)
+        assert np.array_equal(np.asarray(info["scaling_right"]), sr)
+        assert len(np.unique(sl)) >= 4 and len(np.unique(sr)) >= 4          # carried values differ along the sweep
+    finally:
+        prost.set_precision("double")
+
+
 def test_precision_switch_and_default():
     assert prost.get_precision() == "double"          # reference default: typedef double real (config.hpp:7)
     prost.set_precision("single")
