@@ -24,8 +24,10 @@
 extern "C" {
 #endif
 
-/* 2: prost_hip_fused_desc gained res_x0 / res_x1; fused_iteration2, comm send/recv, wrapper proxes, Kronecker blocks */
-#define PROST_HIP_ABI_VERSION 2
+/* 2: prost_hip_fused_desc gained res_x0 / res_x1; fused_iteration2, comm send/recv, wrapper proxes, Kronecker blocks
+ * 3: additions only -- device-resident CGLS / ADMM stages, prox_elem_arg, csr_spmv (non-accumulating), fused_iteration3d,
+ *    fused_iteration3d_pw, fused_iteration_mc, stream_wait_event, graph capture */
+#define PROST_HIP_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
