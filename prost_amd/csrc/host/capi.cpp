@@ -16,10 +16,21 @@ using namespace prost;
 // ------------------------------------------------------------------------------------------
 // prost_value
 // ------------------------------------------------------------------------------------------
+// value storage without the zero fill of std::vector::resize: the 10^7..10^8-element result vectors are written once, by
+// several host threads (vec_value_t)
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+  template <class U> struct rebind { typedef default_init_allocator<U> other; };
+  using std::allocator<T>::allocator;
+  template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+typedef std::vector<double, default_init_allocator<double>> value_vector;
+
 struct prost_value {
   int kind = PROST_VALUE_EMPTY;
   size_t rows = 0, cols = 0;
-  std::vector<double> data;             // matrix values / sparse values
+  value_vector data;                    // matrix values / sparse values
   std::vector<int64_t> ir, jc;          // sparse
   std::string str;
   std::vector<prost_value*> cells;
@@ -90,7 +101,7 @@ std::vector<double> GetVector(const prost_value* v) {
   if (!v || v->kind != PROST_VALUE_MATRIX) throw Exception("Argument has to be passed as a vector of type single or double.");
   if (v->cols != 1 && v->rows != 1) throw Exception("Vector has to be Nx1 or 1xN.");
   if (v->rows == 0 || v->cols == 0) throw Exception("Empty vector passed.");
-  return v->data;
+  return std::vector<double>(v->data.begin(), v->data.end());
 }
 static double scalar_of(const prost_value* v) {
   if (!v || v->kind != PROST_VALUE_MATRIX || v->data.empty()) throw Exception("Scalar expected.");
@@ -418,7 +429,10 @@ prost_value* vec_value(const std::vector<double>& v) { return prost_value_matrix
 // widens straight into the value's storage (one pass; these are the 10^7..10^8-element result vectors)
 template <typename T> prost_value* vec_value_t(const std::vector<T>& v) {
   prost_value* out = new prost_value; out->kind = PROST_VALUE_MATRIX; out->rows = v.size(); out->cols = 1;
-  out->data.assign(v.begin(), v.end());
+  out->data.resize(v.size());           // no zero fill (default_init_allocator)
+  double* dst = out->data.data();
+  const T* src = v.data();
+  ParallelFor(v.size(), [&](size_t b, size_t e) { for (size_t i = b; i < e; i++) dst[i] = (double)src[i]; });
   return out;
 }
 
