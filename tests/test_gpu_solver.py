@@ -404,6 +404,25 @@ def test_fullsize_fused_equals_generic_and_gap_decreases():
     assert states[True]["primal_res"] == states[False]["primal_res"] or np.isclose(states[True]["primal_res"], states[False]["primal_res"], rtol=1e-6)
 
 
+def test_large_rgb_single_kernel_equals_generic():
+    """RGB 1536 x 1024 (the multi-channel one-kernel iteration at a size where thousands of workgroups with their
+    per-column LDS barriers are in flight) against the generic nine-vector path: identical bits after 23 iterations,
+    residual iterations included."""
+    prost.set_precision("single")
+    prob, u, q, f = synthetic.rof_problem(1536, 1024, 3, seed=6)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    states = {}
+    for fused in (True, False):
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=5, alg2_gamma=0.5)
+        b[1]["allow_fused"] = fused
+        states[fused] = run_product(prob, b, o, 23)
+    assert states[True]["path"] == "pdhg:fused-grad2d" and states[False]["path"] == "pdhg:generic"
+    for v in "xyzw":
+        assert np.array_equal(states[True][v], states[False][v]), v
+    assert np.isclose(states[True]["primal_res"], states[False]["primal_res"], rtol=1e-5)
+    prost.set_precision("double")
+
+
 def test_fullsize_4096_adjointness_and_energy():
     """<Kx, y> = <x, K^T y> at 4096^2 (double), and the ROF energy decreases along PDHG iterates"""
     prost.set_precision("double")
