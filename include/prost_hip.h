@@ -456,6 +456,23 @@ enum { PROST_ADMM_STAGE_PRE_X = 0, PROST_ADMM_STAGE_PRE_Z, PROST_ADMM_STAGE_PRE_
 int prost_hip_admm_stage_f32(int stage, const prost_hip_admm_desc* d, void* stream);
 int prost_hip_admm_stage_f64(int stage, const prost_hip_admm_desc* d, void* stream);
 
+/* Fused passes of the operator-norm power iteration (Problem::normest, problem.cu:429-500), one round:
+ *   NORMEST_A: x_temp = sqrt(tau) (x / norm_x)        (norm_x = 0: no divide -- first round)
+ *   ax = K x_temp ; NORMEST_B: a = sqrt(sigma) ax, out[0] = |a|, ax = sqrt(sigma) a
+ *   x_temp = K^T ax ; NORMEST_C: x = sqrt(tau) x_temp, out[1] = |x|
+ * x, x_temp: n elements; ax: m; out: two doubles (device or pinned host); workspace: prost_hip_cgls_workspace_bytes(). */
+typedef struct prost_hip_normest_desc {
+  void* workspace;
+  void* x; void* x_temp; void* ax;
+  const void* sigma; const void* tau;
+  uint64_t m, n;
+  double norm_x;
+  double* out;
+} prost_hip_normest_desc;
+enum { PROST_NORMEST_A = 0, PROST_NORMEST_B, PROST_NORMEST_C };
+int prost_hip_normest_stage_f32(int stage, const prost_hip_normest_desc* d, void* stream);
+int prost_hip_normest_stage_f64(int stage, const prost_hip_normest_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* multi-GPU: global stopping criterion (no counterpart in the reference)        */
 /* ------------------------------------------------------------------------------------------ */

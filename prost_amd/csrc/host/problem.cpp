@@ -212,47 +212,42 @@ void Problem<T>::Dualize() {
 template <typename T>
 T Problem<T>::normest(T tol, int max_iters) {
   const size_t n = ncols(), m = nrows();
-  device_vector<T> x(n), Ax(m), x_temp(n), Ax_temp(m);
+  device_vector<T> x(n), x_temp(n), Ax_temp(m);
   {
     std::vector<T> x_host(n);
     GlibcRand rng(1);
     for (size_t i = 0; i < n; i++) x_host[i] = (T)rng.next() / (T)2147483647;   // RAND_MAX
     x = x_host;
   }
+  // Per round the reference runs four scaling passes, two nrm2 (each with a blocking read-back) and a divide around K
+  // and K^T; here three fused passes (prost_hip_normest_stage_*: same expressions and roundings), the two norms land in
+  // pinned host memory and ONE synchronisation per round reads them.
   void* ws = nullptr;
-  double* out_dev = nullptr;
-  CheckHip(prost_hip_malloc(&ws, prost_hip_reduce_workspace_bytes()), "malloc");
-  CheckHip(prost_hip_malloc((void**)&out_dev, 2 * sizeof(double)), "malloc");
-  auto nrm = [&](const device_vector<T>& v) {
-    // sqrt(sum v^2): the reference reduces in T with an unspecified tree order; here in double
-    CheckHip(Api<T>::nrm2(out_dev, v.data(), v.size(), ws, CurrentStream()), "nrm2");
-    double h[2];
-    CheckHip(prost_hip_memcpy_d2h(h, out_dev, 2 * sizeof(double), CurrentStream()), "d2h");
-    CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
-    return (T)h[0];
-  };
-  auto mul_sqrt = [&](device_vector<T>& out, const device_vector<T>& scal, const device_vector<T>& v) {
-    CheckHip(Api<T>::admm_elem(PROST_ADMM_GEMV1, out.data(), scal.data(), v.data(), nullptr, nullptr, 0, 0, v.size(), CurrentStream()), "gemv1");
-  };
+  double* out_host = nullptr;
+  CheckHip(prost_hip_malloc(&ws, prost_hip_cgls_workspace_bytes()), "malloc");
+  CheckHip(prost_hip_host_alloc((void**)&out_host, 2 * sizeof(double)), "host_alloc");
+  prost_hip_normest_desc d;
+  d.workspace = ws; d.x = x.data(); d.x_temp = x_temp.data(); d.ax = Ax_temp.data();
+  d.sigma = scaling_left_.data(); d.tau = scaling_right_.data(); d.m = m; d.n = n; d.norm_x = 0; d.out = out_host;
   T norm = 0, norm_prev;
   try {
     for (int i = 0; i < max_iters; i++) {
       norm_prev = norm;
-      mul_sqrt(x_temp, scaling_right_, x);
+      CheckHip(Api<T>::normest_stage(PROST_NORMEST_A, &d, CurrentStream()), "normest_stage");
       linop_->Eval(Ax_temp, x_temp);
-      mul_sqrt(Ax, scaling_left_, Ax_temp);
-      const T norm_Ax = nrm(Ax);
-      mul_sqrt(Ax_temp, scaling_left_, Ax);
+      CheckHip(Api<T>::normest_stage(PROST_NORMEST_B, &d, CurrentStream()), "normest_stage");
       linop_->EvalAdjoint(x_temp, Ax_temp);
-      mul_sqrt(x, scaling_right_, x_temp);
-      const T norm_x = nrm(x);
+      CheckHip(Api<T>::normest_stage(PROST_NORMEST_C, &d, CurrentStream()), "normest_stage");
+      CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+      // the reference reduces in T with an unspecified tree order; here in double, narrowed to T
+      const T norm_Ax = (T)out_host[0], norm_x = (T)out_host[1];
       norm = norm_x / norm_Ax;
       if (std::abs(norm_prev - norm) < tol * norm) break;
-      CheckHip(Api<T>::admm_elem(PROST_ADMM_DIV, x.data(), x.data(), nullptr, nullptr, nullptr, (double)norm_x, 0, n, CurrentStream()), "divide");
+      d.norm_x = (double)norm_x;                       // x := x / norm_x is folded into the next round's first pass
     }
-  } catch (...) { prost_hip_free(ws); prost_hip_free(out_dev); throw; }
+  } catch (...) { prost_hip_free(ws); prost_hip_host_free(out_host); throw; }
   prost_hip_free(ws);
-  prost_hip_free(out_dev);
+  prost_hip_host_free(out_host);
   return norm;
 }
 

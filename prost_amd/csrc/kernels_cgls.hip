@@ -445,6 +445,65 @@ __global__ void __launch_bounds__(kBlock) admm_residual_fold_kernel(double* out4
   if (threadIdx.x == 0) { out4[0] = sqrt(a); out4[1] = sqrt(b); out4[2] = sqrt(c); out4[3] = sqrt(d); }
 }
 
+// ---- normest power iteration (Problem::normest, problem.cu:429-500) --------------------------------
+// |Sigma^(1/2) K Tau^(1/2)| by power iteration: per round the reference runs four scaling passes, two nrm2 and a divide
+// around K and K^T; fused here into three passes (same expressions, same roundings):
+// NORMEST_A (n):  x_temp = sqrt(Tau) (x / norm_x)     [the divide of the previous round folded in; norm_x = 0: first round, no divide]
+template <class T> struct NormestA {
+  static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
+  static constexpr int kRegion = -1, kRegion2 = -1;
+  const T* x; const T* tau; T* x_temp; T norm_x; bool divide;
+  __device__ void load(const CgState*) {}
+  template <int V> __device__ void range0(size_t i, double&, double&) const {
+    T xv[V], dv[V], o[V];
+    ldv<T, V>(x + i, xv); ldv<T, V>(tau + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) { const T t = divide ? xv[j] / norm_x : xv[j]; o[j] = t_sqrt(dv[j]) * t; }
+    stv<T, V>(x_temp + i, o);
+  }
+  template <int V> __device__ void range1(size_t, double&, double&) const {}
+};
+// NORMEST_B (m), after ax = K x_temp:  a = sqrt(Sigma) ax;  partials of |a|^2;  ax = sqrt(Sigma) a
+template <class T> struct NormestB {
+  static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
+  static constexpr int kRegion = kRegionQ, kRegion2 = -1;
+  T* ax; const T* sigma;
+  __device__ void load(const CgState*) {}
+  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+    T v[V], dv[V];
+    ldv<T, V>(ax + i, v); ldv<T, V>(sigma + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(dv[j]);
+      const T a = sq * v[j];
+      sa += (double)a * (double)a;
+      v[j] = sq * a;
+    }
+    stv<T, V>(ax + i, v);
+  }
+  template <int V> __device__ void range1(size_t, double&, double&) const {}
+};
+// NORMEST_C (n), after x_temp = K^T ax:  x = sqrt(Tau) x_temp;  partials of |x|^2
+template <class T> struct NormestC {
+  static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
+  static constexpr int kRegion = kRegionP, kRegion2 = -1;
+  T* x; const T* x_temp; const T* tau;
+  __device__ void load(const CgState*) {}
+  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+    T v[V], dv[V];
+    ldv<T, V>(x_temp + i, v); ldv<T, V>(tau + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) { v[j] = t_sqrt(dv[j]) * v[j]; sa += (double)v[j] * (double)v[j]; }
+    stv<T, V>(x + i, v);
+  }
+  template <int V> __device__ void range1(size_t, double&, double&) const {}
+};
+// out[0] = sqrt(sum of the first components of g partial pairs of region r); out may be pinned host memory
+__global__ void __launch_bounds__(kBlock) sqrt_fold_kernel(double* out, const double* ws, int r, unsigned g) {
+  const double a = fold_region(region(const_cast<double*>(ws), r), g);
+  if (threadIdx.x == 0) out[0] = sqrt(a);
+}
+
 template <class T>
 static unsigned stage_grid(size_t nmax, bool vec) {
   unsigned g = grid_for(vec ? nmax / VecOf<T>::N : nmax, 2);
@@ -541,6 +600,35 @@ static int admm_stage(int stage, const prost_hip_admm_desc* d, void* stream) {
   }
 }
 
+template <class T>
+static int normest_stage(int stage, const prost_hip_normest_desc* d, void* stream) {
+  if (!d || !d->workspace) { set_error("normest_stage: workspace is required"); return 1; }
+  hipStream_t st = as_stream(stream);
+  T* x = static_cast<T*>(d->x); T* x_temp = static_cast<T*>(d->x_temp); T* ax = static_cast<T*>(d->ax);
+  const T* sigma = static_cast<const T*>(d->sigma); const T* tau = static_cast<const T*>(d->tau);
+  const size_t m = d->m, n = d->n;
+  const bool vn = aligned16(x) && aligned16(x_temp) && aligned16(tau) && n >= (size_t)VecOf<T>::N;
+  const bool vm = aligned16(ax) && aligned16(sigma) && m >= (size_t)VecOf<T>::N;
+  prost_hip_cgls_desc c{};
+  c.state = nullptr; c.workspace = d->workspace;
+  int rc;
+  switch (stage) {
+    case PROST_NORMEST_A:
+      return launch_stage<T>("normest a", NormestA<T>{x, tau, x_temp, (T)d->norm_x, d->norm_x != 0.0}, n, 0, vn, &c, st);
+    case PROST_NORMEST_B:
+      if (!d->out) { set_error("normest_stage: out is required"); return 1; }
+      if ((rc = launch_stage<T>("normest b", NormestB<T>{ax, sigma}, m, 0, vm, &c, st))) return rc;
+      hipLaunchKernelGGL(sqrt_fold_kernel, dim3(1), dim3(kBlock), 0, st, d->out, static_cast<const double*>(d->workspace), (int)kRegionQ, stage_grid<T>(m, vm));
+      PH_LAUNCH_END("normest fold");
+    case PROST_NORMEST_C:
+      if (!d->out) { set_error("normest_stage: out is required"); return 1; }
+      if ((rc = launch_stage<T>("normest c", NormestC<T>{x, x_temp, tau}, n, 0, vn, &c, st))) return rc;
+      hipLaunchKernelGGL(sqrt_fold_kernel, dim3(1), dim3(kBlock), 0, st, d->out + 1, static_cast<const double*>(d->workspace), (int)kRegionP, stage_grid<T>(n, vn));
+      PH_LAUNCH_END("normest fold");
+    default: set_error("normest_stage: unknown stage"); return 1;
+  }
+}
+
 }  // namespace prost_hip
 
 using namespace prost_hip;
@@ -554,6 +642,9 @@ int prost_hip_cgls_stage_f64(int stage, const prost_hip_cgls_desc* d, void* stre
 
 int prost_hip_admm_stage_f32(int stage, const prost_hip_admm_desc* d, void* stream) { return admm_stage<float>(stage, d, stream); }
 int prost_hip_admm_stage_f64(int stage, const prost_hip_admm_desc* d, void* stream) { return admm_stage<double>(stage, d, stream); }
+
+int prost_hip_normest_stage_f32(int stage, const prost_hip_normest_desc* d, void* stream) { return normest_stage<float>(stage, d, stream); }
+int prost_hip_normest_stage_f64(int stage, const prost_hip_normest_desc* d, void* stream) { return normest_stage<double>(stage, d, stream); }
 
 int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void* stream) {
   CgState h;
