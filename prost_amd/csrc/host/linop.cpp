@@ -310,12 +310,12 @@ T LinearOperator<T>::col_sum(size_t col, T alpha) const {
 }
 template <typename T>
 void LinearOperator<T>::row_sums(std::vector<T>& out, T alpha) const {
-  std::fill(out.begin(), out.end(), (T)0);
+  ParallelFor(out.size(), [&](size_t b, size_t e) { std::fill(out.begin() + b, out.begin() + e, (T)0); });
   for (auto& b : blocks_) { if (b->row() + b->nrows() <= out.size()) b->row_sums(out.data() + b->row(), alpha); }
 }
 template <typename T>
 void LinearOperator<T>::col_sums(std::vector<T>& out, T alpha) const {
-  std::fill(out.begin(), out.end(), (T)0);
+  ParallelFor(out.size(), [&](size_t b, size_t e) { std::fill(out.begin() + b, out.begin() + e, (T)0); });
   for (auto& b : blocks_) { if (b->col() + b->ncols() <= out.size()) b->col_sums(out.data() + b->col(), alpha); }
 }
 template <typename T>

@@ -128,18 +128,18 @@ void Problem<T>::InitializeHost() {
     // Sigma_i = 1 / sum_j |K_ij|^alpha ; Tau_j = 1 / sum_i |K_ij|^(2-alpha).  An all-zero row or
     // column inherits the last positive value seen, and that carry runs from the row sweep on
     // into the column sweep (problem.cu:262-287).
-    scaling_left_host_.assign(nrows_, 0);
-    scaling_right_host_.assign(ncols_, 0);
-    std::vector<T> sums(nrows_);
+    // the sums are accumulated straight into the preconditioner vectors and inverted in place (at 10^9 entries every extra
+    // host vector is seconds of page faults)
     StageTimer t_pre("  preconditioner sums");
-    linop_->row_sums(sums, scaling_alpha_);
+    scaling_left_host_.resize(nrows_);
+    scaling_right_host_.resize(ncols_);
+    linop_->row_sums(scaling_left_host_, scaling_alpha_);
     // (the reciprocal is only re-evaluated when the sum changes: stencil operators repeat one value 10^7 times; the sweep
     // runs on several host threads -- a sub-range starts from the value the sweep carries into it, found in a first pass)
     T value = 1;
-    value = CarriedReciprocals(sums, scaling_left_host_, value);
-    sums.assign(ncols_, 0);
-    linop_->col_sums(sums, (T)(2. - (double)scaling_alpha_));
-    value = CarriedReciprocals(sums, scaling_right_host_, value);
+    value = CarriedReciprocals(scaling_left_host_, scaling_left_host_, value);
+    linop_->col_sums(scaling_right_host_, (T)(2. - (double)scaling_alpha_));
+    value = CarriedReciprocals(scaling_right_host_, scaling_right_host_, value);
   } else if (scaling_type_ == kScalingIdentity) {
     scaling_left_host_.assign(nrows_, 1);
     scaling_right_host_.assign(ncols_, 1);

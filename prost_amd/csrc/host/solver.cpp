@@ -47,10 +47,9 @@ void Solver<T>::Initialize() {
     std::cout << "Memory requirements: " << mem / (1024 * 1024) << "MB (" << mem_avail / (1024 * 1024) << "/"
               << mem_total / (1024 * 1024) << "MB available). Path: " << backend_->path() << "." << std::endl;
   }
-  cur_primal_sol_.resize(problem_->ncols());
-  cur_primal_constr_sol_.resize(problem_->nrows());
-  cur_dual_sol_.resize(problem_->nrows());
-  cur_dual_constr_sol_.resize(problem_->ncols());
+  // the host copies of the solution (solver.cu:110-113 sizes them here) are sized by the first FetchSolution instead: at
+  // 10^9 entries zero-filling 2 (m + n) host values is more than a second of page faults before the first iteration
+  cur_primal_sol_.clear(); cur_primal_constr_sol_.clear(); cur_dual_sol_.clear(); cur_dual_constr_sol_.clear();
   iterations_done_ = 0;
 }
 
