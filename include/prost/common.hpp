@@ -36,6 +36,9 @@ class GlibcRand {
  public:
   explicit GlibcRand(unsigned seed = 1);
   int32_t next();
+  /// out[i] = (T)next() / (T)RAND_MAX for i < n -- the same stream as n calls of next(), generated in one tight loop and
+  /// narrowed on several host threads (normest draws one value per primal entry)
+  template <typename T> void fill_unit(T* out, size_t n);
 
  private:
   std::vector<uint32_t> r_;

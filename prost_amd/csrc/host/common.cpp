@@ -127,6 +127,18 @@ int32_t GlibcRand::next() {
   return (int32_t)(v >> 1);
 }
 
+template <typename T>
+void GlibcRand::fill_unit(T* out, size_t n) {
+  std::vector<uint32_t> buf(n + 31);
+  std::copy(r_.end() - 31, r_.end(), buf.begin());
+  uint32_t* b = buf.data();
+  for (size_t i = 31; i < n + 31; i++) b[i] = b[i - 31] + b[i - 3];
+  ParallelFor(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) out[i] = (T)(int32_t)(b[i + 31] >> 1) / (T)2147483647; });
+  r_.assign(buf.end() - 31, buf.end());
+}
+template void GlibcRand::fill_unit<float>(float*, size_t);
+template void GlibcRand::fill_unit<double>(double*, size_t);
+
 size_t ParallelChunks(size_t n) {
   const size_t kMinChunk = (size_t)1 << 20;
   size_t hw = std::thread::hardware_concurrency();

@@ -214,9 +214,10 @@ T Problem<T>::normest(T tol, int max_iters) {
   const size_t n = ncols(), m = nrows();
   device_vector<T> x(n), x_temp(n), Ax_temp(m);
   {
+    StageTimer t_rng("  normest: start vector (glibc rand stream)");
     std::vector<T> x_host(n);
     GlibcRand rng(1);
-    for (size_t i = 0; i < n; i++) x_host[i] = (T)rng.next() / (T)2147483647;   // RAND_MAX
+    rng.fill_unit(x_host.data(), n);                     // x[i] = (T)rand() / (T)RAND_MAX (problem.cu:441-444)
     x = x_host;
   }
   // Per round the reference runs four scaling passes, two nrm2 (each with a blocking read-back) and a divide around K
@@ -226,6 +227,7 @@ T Problem<T>::normest(T tol, int max_iters) {
   double* out_host = nullptr;
   CheckHip(prost_hip_malloc(&ws, prost_hip_cgls_workspace_bytes()), "malloc");
   CheckHip(prost_hip_host_alloc((void**)&out_host, 2 * sizeof(double)), "host_alloc");
+  StageTimer t_rounds("  normest: power iteration");
   prost_hip_normest_desc d;
   d.workspace = ws; d.x = x.data(); d.x_temp = x_temp.data(); d.ax = Ax_temp.data();
   d.sigma = scaling_left_.data(); d.tau = scaling_right_.data(); d.m = m; d.n = n; d.norm_x = 0; d.out = out_host;
