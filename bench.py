@@ -13,14 +13,27 @@ N > 1: BASELINE config 5 -- N independent 4096^2 problems (seeds 42..42+N-1), on
 scaling; the 4 residual sums are all-reduced over RCCL every residual iteration so every rank sees
 the global stopping criterion.  value = N * K / max-over-ranks(time).
 
-Inputs are resident in HBM before the timed region.  The JSON line carries
+Inputs are resident in HBM before the timed region.  Timed region = K iterations of the loop a caller
+of prost.solve runs (Solver::IterateChecked: the stopping test of solver.cu:141-150 after every observable
+iteration, i.e. the host waits for the residual sums of every residual iteration); the rate of the bare
+iteration loop (Solver::Iterate, no host wait) is reported beside it as `iterate_only_it_per_s`.
+Before the W warm-up steps an untimed clock-ramp prelude runs 1500 of the same iterations (~90 ms;
+`prelude_iterations`): the part needs tens of milliseconds of load to reach its steady clocks and the
+driver's `--steps 20 --warmup 5` would otherwise measure the ramp.  The JSON line carries
   roofline     : dominant kernel = fused_iter2d_x2_kernel, one launch = TWO whole iterations with the
-                 iterate in between kept in registers: algorithmic bytes (2 x 11 floats/pixel, SURVEY
-                 8d) / mean launch time measured with HIP events on the solver's stream (one launch in
-                 eight is sampled); the kernel itself moves 7 floats/pixel per launch, so `frac` can
-                 exceed 1 -- it is measured against what the reference's algorithm must move
+                 iterate in between kept in registers.
+                 `achieved` / `frac`: ALGORITHMIC bytes (2 x 11 floats/pixel) / mean launch time
+                 measured with HIP events on the solver's stream inside the timed region.  The kernel moves
+                 only 7 floats/pixel per launch, so this figure can exceed 1: it is measured against what the
+                 reference's two-pass algorithm must move, not against what this kernel moves.
+                 `traffic` / `frac_hbm_traffic`: the PHYSICAL figure -- HBM bytes per launch from the PMC
+                 counters (profiles/traffic_table.json: FETCH_SIZE doubled per MI355X_MICROARCH.md +
+                 WRITE_SIZE, separate --pmc passes), looked up by kernel instance, image size and chunk
+                 length of the launch that was timed (null if that geometry was never profiled), divided by
+                 the same launch time and the 8 TB/s peak.
   cpu_baseline : the CPU oracle (port of the reference path) timed on this host's cores on a bounded
-                 sample of the same workload
+                 sample of the same workload; `reference_build` = the REAL reference's CPU build
+                 (oracle/_ref, single-threaded thrust host backend) timed beside the port at 1024^2
 """
 import argparse
 import json
@@ -36,10 +49,22 @@ LAMBDA = 10.0
 ALG_FLOATS_PER_PIXEL = 11          # primal pass 5 + dual pass 6
 DUAL_PASS_FLOATS = 6
 HBM_PEAK_GBPS = 8000.0
-# HBM bytes per launch from the PMC counters (FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE,
-# KiB -> bytes), collected in separate rocprofv3 --pmc passes on the same workload: profiles/r01_pmc_*.txt
-TRAFFIC_BYTES_PER_LAUNCH = {"fused_iter2d_kernel": (2 * 162173 + 199683) * 1024,         # profiles/r01_pmc_traffic.txt
-                            "fused_iter2d_x2_kernel": (2 * 168755 + 196609) * 1024}
+TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "traffic_table.json")
+
+
+def traffic_bytes(kernel, size, chunk_cols):
+    """HBM bytes per launch of `kernel` (name as KernelTimes reports it) at image side `size` with `chunk_cols` columns
+    per wavefront, from the PMC passes recorded in profiles/traffic_table.json (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md + WRITE_SIZE, KiB).  None when this launch geometry was never profiled."""
+    try:
+        with open(TRAFFIC_TABLE) as fh:
+            rows = json.load(fh)["launches"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    for r in rows:
+        if r["kernel"] == kernel and r["size"] == size and r["chunk_cols"] == chunk_cols:
+            return (2 * r["fetch_size_kib"] + r["write_size_kib"]) * 1024, r.get("source")
+    return None, None
 
 
 def cpu_baseline(n_img, max_threads):
@@ -81,9 +106,49 @@ def cpu_baseline(n_img, max_threads):
     t1 = time.time()
     s.iterate(3)
     single = 3 / (time.time() - t1)
-    return {"value": iters / el, "unit": "it/s", "cores": best, "kind": "port", "single_thread_value": single,
-            "sample": "%d PDHG iterations of the same %dx%d fp32 ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads "
-                      "(best of a probe over 8/16/32/64 threads on %d logical cores)" % (iters, n_img, n_img, best, max_threads)}
+    out = {"value": iters / el, "unit": "it/s", "cores": best, "kind": "port", "single_thread_value": single,
+           "sample": "%d PDHG iterations of the same %dx%d fp32 ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads "
+                     "(best of a probe over 8/16/32/64 threads on %d logical cores)" % (iters, n_img, n_img, best, max_threads)}
+    del s
+    out["reference_build"] = reference_build_rate(backend, opts)
+    return out
+
+
+def reference_build_rate(backend, opts, n_ref=1024):
+    """The REAL reference's CPU build (oracle/_ref/libprost_ref.so: backend_pdhg.cu, problem.cu, prox functors compiled from
+    /root/reference where it lies, thrust host backend = ONE thread) on this host, next to the port on one thread, on the same
+    ROF problem at 1024^2 (at 4096^2 its one-virtual-call-per-row setup alone exceeds the time budget of a bench run).
+    Rate = (k2 - k1) / (t(k2) - t(k1)) over two runs, which removes the setup.  None where the prebuilt library is absent."""
+    import numpy as np
+
+    import oracle
+    from oracle import ref
+    from prost_amd import synthetic
+    if not ref.available():
+        return None
+    try:
+        prob, u, q, f = synthetic.rof_problem(n_ref, n_ref, seed=42)
+        prob.finalize()
+        R = ref.RefProblem(prob.data, prob.nrows, prob.ncols, np.float32)
+        times = {}
+        for k in (2, 22):
+            t0 = time.time()
+            R.pdhg(backend[1], opts, k)
+            times[k] = time.time() - t0
+        rate_ref = 20.0 / max(times[22] - times[2], 1e-9)
+        oracle.set_num_threads(1)
+        s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np.float32)
+        s.initialize()
+        s.iterate(2)
+        t0 = time.time()
+        s.iterate(20)
+        rate_port = 20.0 / (time.time() - t0)
+        return {"value": rate_ref, "unit": "it/s", "cores": 1, "kind": "reference", "port_one_thread_same_size": rate_port,
+                "sample": "20 PDHG iterations of the fp32 ROF problem at %dx%d (difference of a 22- and a 2-iteration run: setup removed), "
+                          "oracle/_ref/libprost_ref.so = the reference's own backend_pdhg.cu / problem.cu / prox functors, thrust host backend"
+                          % (n_ref, n_ref)}
+    except Exception as e:          # the baseline must never take the bench line down
+        return {"error": str(e)}
 
 
 def main():
@@ -94,6 +159,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--size", type=int, default=N_IMG, help="image side (default 4096 = the headline config)")
+    ap.add_argument("--prelude-iters", type=int, default=1500, help="untimed clock-ramp prelude before the warm-up steps: this many of the same iterations (0: none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--no-pair", action="store_true", help="one kernel launch per iteration (allow_pair_kernel = false); not the default configuration")
@@ -151,17 +217,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    solver.iterate(args.warmup)
+    # untimed clock-ramp prelude on the real problem: a FIXED number of the same iterations (about 90 ms at the headline
+    # size; every rank must run the same count -- the residual all-reduces pair up across ranks)
+    prelude_iters, t_pre = args.prelude_iters, time.perf_counter()
+    if prelude_iters > 0:
+        solver.iterate(prelude_iters)
+    prelude_ms = (time.perf_counter() - t_pre) * 1e3
+    # short runs bracket every launch with events (>= 5 samples of the dominant kernel at --steps 20), long runs one in eight
+    # (the markers cost launch pipelining)
+    every = 1 if args.steps <= 40 else 2 if args.steps <= 80 else 4 if args.steps <= 160 else 8
+
+    solver.iterate(args.warmup, checked=True)
     barrier()
     t0 = time.perf_counter()
-    info = solver.iterate(args.steps, time_kernels=not args.no_kernel_timing)
+    info = solver.iterate(args.steps, time_kernels=not args.no_kernel_timing, sample_every=every, checked=True)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    # the bare iteration loop (Solver::Iterate: nobody waits for the residual sums), same K, untimed markers off
+    barrier()
+    t1 = time.perf_counter()
+    solver.iterate(args.steps)
+    barrier()
+    elapsed_iterate = time.perf_counter() - t1
+
+    t = torch.tensor([elapsed, elapsed_iterate], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, elapsed_iterate = float(t[0].item()), float(t[1].item())
     st = solver.state()
     path = st["path"]
     finite = bool(np.isfinite(st["x"]).all() and np.isfinite(st["y"]).all())
@@ -184,7 +267,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), "
                                    "PDHG alg2, residual_iter=10, lambda=10; one independent problem per GPU" % (n, n),
-                       "path": path, "problems": world, "residual_allreduce": "rccl" if multi else "none"},
+                       "path": path, "problems": world, "residual_allreduce": "rccl" if multi else "none",
+                       "timed_loop": "Solver::IterateChecked = the loop of prost.solve (stopping test after every observable iteration; "
+                                     "tolerances 0, so it never fires)"},
+            "iterate_only_it_per_s": world * args.steps / elapsed_iterate,
+            "prelude_iterations": prelude_iters,
+            "prelude_ms": prelude_ms,
             "achieved_hbm_GBps": value * bytes_per_iter / 1e9,
             "hbm_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world),
             "iterates_finite": finite,
@@ -200,12 +288,24 @@ def main():
             floats = ALG_FLOATS_PER_PIXEL * ipl if ipl else (DUAL_PASS_FLOATS if "dual" in kname else ALG_FLOATS_PER_PIXEL - DUAL_PASS_FLOATS)
             alg_bytes = floats * 4 * n * n
             achieved = alg_bytes / 1e9 / (k["avg_ms"] * 1e-3)
+            traffic, traffic_src = traffic_bytes(kname, n, k["chunk_cols"])
+            phys = traffic / 1e9 / (k["avg_ms"] * 1e-3) if traffic else None
             out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(kname),
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                               "frac_hbm_traffic": phys / HBM_PEAK_GBPS if phys else None,
+                               "achieved_hbm_traffic": phys, "traffic_source": traffic_src,
+                               "note": "frac = ALGORITHMIC bytes (SURVEY 8d: 11 floats/pixel/iteration x %s iterations per launch) / launch time / peak; "
+                                       "it exceeds 1 because one launch performs two iterations with the iterate in between kept in registers and "
+                                       "physically moves 7 floats/pixel, not 22.  The physical HBM fraction is frac_hbm_traffic = PMC traffic "
+                                       "(FETCH_SIZE x 2 + WRITE_SIZE) / launch time / peak.  That the work is done: bit-exact against the CPU oracle at this "
+                                       "very size and launch geometry (tests/test_gpu_fullsize.py) and against single-iteration launches "
+                                       "(tests/test_gpu_solver.py::test_fullsize_4096_pair_launches_equal_single_launches)." % (ipl if ipl else "1/2"),
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k["avg_ms"],
-                               "launches_timed": k["sampled"], "iterations_per_launch": ipl,
+                               "launches_timed": k["sampled"], "iterations_per_launch": ipl, "chunk_cols": k["chunk_cols"],
+                               "sample_every": every,
                                "kernel_moves_bytes_per_launch": 7 * 4 * n * n if ipl else None,
-                               "all_kernels": {name: {"avg_launch_ms": v["avg_ms"], "launches": v["launches"], "iterations_per_launch": v["iterations_per_launch"]}
+                               "all_kernels": {name: {"avg_launch_ms": v["avg_ms"], "launches": v["launches"], "launches_timed": v["sampled"],
+                                                      "iterations_per_launch": v["iterations_per_launch"], "chunk_cols": v["chunk_cols"]}
                                                for name, v in kern.items()}}
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1

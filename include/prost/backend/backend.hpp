@@ -14,7 +14,7 @@ template <typename T>
 class Backend {
  public:
   Backend() : primal_var_norm_(0), dual_var_norm_(0), primal_residual_(0), dual_residual_(0), comm_(nullptr),
-              global_nrows_(0), global_ncols_(0), time_kernels_(false) {}
+              global_nrows_(0), global_ncols_(0), time_kernels_(false), sample_every_(8) {}
   virtual ~Backend() {}
 
   void SetProblem(shared_ptr<Problem<T>> problem) { problem_ = problem; }
@@ -51,14 +51,19 @@ class Backend {
   /// multi-GPU batches: the 4 residual sums are all-reduced over `comm` (an RCCL communicator made
   /// by prost_hip_comm_create) so every rank takes identical stopping / step-size decisions.
   void SetCommunicator(void* comm, size_t global_nrows, size_t global_ncols) { comm_ = comm; global_nrows_ = global_nrows; global_ncols_ = global_ncols; }
+  /// Problem::Dualize() exchanges rows and columns; the global sizes follow (called by Solver when it dualizes)
+  void SwapGlobalSizes() { const size_t t = global_nrows_; global_nrows_ = global_ncols_; global_ncols_ = t; }
   /// record HIP events around a sample of the iteration kernels' launches (bench roofline figure)
-  void EnableKernelTiming(bool on) { time_kernels_ = on; }
+  /// `every`: one launch in `every` of each kernel kind is bracketed (1 = all of them: short runs; the markers cost
+  /// launch pipelining, so long runs sample one in eight)
+  void EnableKernelTiming(bool on, int every = 8) { time_kernels_ = on; sample_every_ = every < 1 ? 1 : every; }
   struct KernelTime {
     std::string name;            ///< kernel symbol as rocprofv3 --kernel-trace reports it
     double avg_ms;               ///< mean launch duration over the sampled launches
-    size_t sampled;              ///< launches timed (one in eight of each kind)
+    size_t sampled;              ///< launches timed
     size_t launches;             ///< all launches of this kind while timing was enabled
     int iterations_per_launch;   ///< PDHG iterations one launch performs (0: a fraction -- one of two passes)
+    int chunk_cols;              ///< image columns per wavefront of this launch geometry (0: not applicable / unknown)
   };
   /// mean milliseconds per launch of every kernel kind sampled since the last call
   virtual void KernelTimes(std::vector<KernelTime>& out) { out.clear(); }
@@ -72,6 +77,7 @@ class Backend {
   void* comm_;
   size_t global_nrows_, global_ncols_;
   bool time_kernels_;
+  int sample_every_;
 };
 
 }  // namespace prost

@@ -55,6 +55,13 @@ class BackendPDHG : public Backend<T> {
   T* x_data() { return x_.data(); }
   T* y_data() { return y_.data(); }
   bool single_kernel_path() const { return single_kernel_; }
+  size_t fused_channels() const { return fused_ ? desc_.L : 0; }
+  /// verification entry (solver_compare / solver_read): device pointers of the current and the previous iterate; a previous
+  /// iterate that a pair launch kept in registers is rebuilt first
+  void device_iterates(T*& x, T*& y, T*& x_prev, T*& y_prev) {
+    if (fused_) RebuildPrevious();
+    x = x_.data(); y = y_.data(); x_prev = x_prev_.data(); y_prev = y_prev_.data();
+  }
 
   // residual accessors pick up sums that are still in flight (see FinishResiduals)
   virtual T primal_residual() const { const_cast<BackendPDHG<T>*>(this)->ResolveResiduals(); return this->primal_residual_; }

@@ -36,6 +36,10 @@ class Solver {
   void Release();
   /// `iters` backend iterations without convergence tests / callbacks (benchmark + test entry)
   void Iterate(int iters);
+  /// The loop of Solve() -- backend iterations with the convergence test of solver.cu:141-150 after every observable
+  /// iteration -- for exactly `iters` iterations or until the test fires; no callbacks, no read-out of the solution.
+  /// What a caller of prost.solve pays per iteration (benchmark entry).  Returns true iff converged.
+  bool IterateChecked(int iters);
   /// refreshes cur_*_sol from the device (Backend::current_solution)
   void FetchSolution();
   int iterations_done() const { return iterations_done_; }

@@ -97,14 +97,21 @@ void prost_set_stop_callback(prost_stop_cb fn, void* user);
  *   solver_create(problem, nrows, ncols, backend, opts[, [x0 x1 nx]]) -> handle (scalar); the optional
  *       1x3 matrix marks image columns [x0, x1) of nx as OWNED (column-sharded images: the rest are halo
  *       columns that do not count in the residual sums); pdhg single-kernel gradient2d path only
- *   solver_iterate(handle, iters[, time_kernels]) -> struct {ms, kernels}; kernels = cell of
- *       {name, avg_ms, sampled launches, iterations per launch, all launches}
+ *   solver_iterate(handle, iters[, time_kernels[, sample_every[, checked]]]) -> struct {ms, converged, kernels};
+ *       kernels = cell of {name, avg_ms, sampled launches, iterations per launch, all launches, chunk columns};
+ *       sample_every: one launch in that many is bracketed by events (default 8; 1 = every launch);
+ *       checked != 0 runs the loop of solve_problem (stopping test of solver.cu:141-150 after every observable
+ *       iteration, stops when it fires) without callbacks or solution read-out
  *   solver_halo_exchange(handle, ny, halo, left_halo, right_halo, left_rank, right_rank): swap `halo` image
  *       columns of x and y with the neighbouring ranks over the comm_init communicator (rank < 0: none)
  *   solver_copy_columns(dst_handle, dst_col, src_handle, src_col, ncols, ny): the same transfer between two
  *       solvers of one process
- *   solver_state(handle) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,
- *                                   dual_var_norm,eps_primal,eps_dual,iteration,path}
+ *   solver_state(handle[, with_vectors = 1]) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,
+ *                                   dual_var_norm,eps_primal,eps_dual,iteration,path}; with_vectors = 0 leaves out x,y,z,w
+ *   solver_compare(handle_a, handle_b) -> 4x2 matrix, rows x, y, x_prev, y_prev: {elements whose bits differ,
+ *       sum |a - b|}, formed on the device (verification of states too large to read back; pdhg only)
+ *   solver_read(handle, 'x'|'y'|'x_prev'|'y_prev', offsets, count) -> count x numel(offsets) matrix: `count`
+ *       consecutive entries of that device vector from every offset (partial read-back; pdhg only)
  *   solver_destroy(handle)
  *   comm_unique_id -> 1x128 matrix of byte values;  comm_init(id, rank, world);  comm_destroy
  *   set_quirks(struct {diags_adjoint_grid, dual_negate_float})

@@ -307,6 +307,9 @@ int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int d
  * square or abs with scalar a = 1, d = e = 0, prox_f* ind_leq0 with scalar a = 1, d = e = 0), which has a straight-line
  * instance; other function pairs are supported but register-bound (about 5x slower), so callers pair only here */
 int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int dtype);
+/* columns per wavefront (chunk length) a launch with cols_per_block <= 0 uses for this description; 0 if unsupported.
+ * Measurement key: the HBM traffic of a launch depends on it (3 warm-up columns are re-read per chunk). */
+int prost_hip_fused_iteration2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals);
 
 /* The same iteration with the PLANES ACROSS THE WAVEFRONTS of a workgroup (kernels_fused_iter3d_pw.hip): `waves` - 1
  * consecutive planes per workgroup exchange x_new through LDS, one helper wavefront recomputes the plane above the
@@ -361,6 +364,12 @@ int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* desc, double* x_o
  * mismatches5 = {division, sqrt, exact division, subtraction, control}; `control` counts the cases where
  * the plain single-precision reciprocal product differs from n / d and must come out > 0. */
 int prost_hip_selftest_math(unsigned long long* mismatches5, uint64_t n, uint64_t seed, void* stream);
+/* Verification entry: bitwise comparison of two device vectors without a read-back (the 2048 x 2048 x 64 state is
+ * 8 GB per vector set).  out2 (DEVICE double[2]) = {number of elements whose bit patterns differ, sum |a_i - b_i| over
+ * them}; workspace: prost_hip_reduce_workspace_bytes().  The reference compares iterates on the host after
+ * thrust::copy (backend_pdhg.cu:491-502); there is no device-side counterpart. */
+int prost_hip_compare_f32(double* out2, const float* a, const float* b, size_t n, void* workspace, void* stream);
+int prost_hip_compare_f64(double* out2, const double* a, const double* b, size_t n, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* ADMM / CGLS building blocks (src/backend/backend_admm.cu, include/prost/cgls.hpp)           */

@@ -321,17 +321,36 @@ class Solver:
     def copy_columns_from(self, dst_col, src, src_col, ncols, ny):
         command("solver_copy_columns", [self.handle, int(dst_col), src.handle, int(src_col), int(ncols), int(ny)])
 
-    def iterate(self, iters, time_kernels=False):
-        """-> {"ms": wall time, "kernels": {kernel name: {"avg_ms", "sampled", "launches", "iterations_per_launch"}}}
-        (kernel launch times from HIP events on the solver's stream; one launch in eight is sampled)"""
-        info = command("solver_iterate", [self.handle, int(iters), bool(time_kernels)], nlhs=1, struct_fields=("ms", "kernels"))[0]
-        info["kernels"] = {k[0]: {"avg_ms": k[1], "sampled": int(k[2]), "iterations_per_launch": int(k[3]), "launches": int(k[4])} for k in info.get("kernels", [])}
+    def compare(self, other):
+        """bitwise comparison with another solver's iterates ON THE DEVICE (no read-back):
+        {"x" | "y" | "x_prev" | "y_prev": (elements whose bits differ, sum |a - b|)}"""
+        m = np.asarray(command("solver_compare", [self.handle, other.handle], nlhs=1)[0]).reshape(4, 2)
+        return {k: (int(m[i, 0]), float(m[i, 1])) for i, k in enumerate(("x", "y", "x_prev", "y_prev"))}
+
+    def read(self, which, offsets, count):
+        """`count` consecutive entries of the device vector `which` ("x", "y", "x_prev", "y_prev") from each offset
+        -> array (len(offsets), count); partial read-back for states too large to fetch whole"""
+        offsets = np.asarray(offsets, dtype=np.float64).reshape(-1)
+        out = np.asarray(command("solver_read", [self.handle, which, offsets, int(count)], nlhs=1)[0], dtype=np.float64)
+        return out.T if out.ndim == 2 else out.reshape(1, -1)      # (count, segments) -> (segments, count)
+
+    def iterate(self, iters, time_kernels=False, sample_every=8, checked=False):
+        """-> {"ms": wall time, "converged", "kernels": {kernel name: {"avg_ms", "sampled", "launches",
+        "iterations_per_launch", "chunk_cols"}}} (kernel launch times from HIP events on the solver's stream; one launch
+        in `sample_every` is bracketed).  checked=True runs the loop of prost.solve -- the stopping test after every
+        observable iteration -- without callbacks or read-out, and stops when the test fires."""
+        info = command("solver_iterate", [self.handle, int(iters), bool(time_kernels), int(sample_every), bool(checked)], nlhs=1,
+                       struct_fields=("ms", "converged", "kernels"))[0]
+        info["kernels"] = {k[0]: {"avg_ms": k[1], "sampled": int(k[2]), "iterations_per_launch": int(k[3]), "launches": int(k[4]),
+                                  "chunk_cols": int(k[5])} for k in info.get("kernels", [])}
         return info
 
-    def state(self):
-        st = command("solver_state", [self.handle], nlhs=1, struct_fields=_STATE_FIELDS)[0]
+    def state(self, vectors=True):
+        """vectors=False: step sizes, iteration count and residuals only (no read-back of x, y, z, w)"""
+        st = command("solver_state", [self.handle, bool(vectors)], nlhs=1, struct_fields=_STATE_FIELDS)[0]
         for k in ("x", "y", "z", "w"):
-            st[k] = np.atleast_1d(st[k])
+            if k in st:
+                st[k] = np.atleast_1d(st[k])
         return st
 
     def destroy(self):

@@ -190,7 +190,8 @@ int BackendPDHG<T>::PerformIterations(int budget) {
 template <typename T>
 bool BackendPDHG<T>::BeginSample(int kind) {
   if (!this->time_kernels_) return false;
-  if ((launches_[kind]++ % 8) != 1) return false;        // one launch in eight: the markers must not serialise the stream
+  // one launch in `sample_every_`: the markers must not serialise the stream of a long run
+  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) return false;
   const size_t i = 2 * ev_kind_.size();
   while (ev_.size() < i + 2) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
   ev_kind_.push_back(kind);
@@ -517,8 +518,11 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
                                      d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
                                      "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
-  for (int k = 0; k < kKernelKinds; k++)
-    if (cnt[k]) out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k]});
+  for (int k = 0; k < kKernelKinds; k++) {
+    if (!cnt[k]) continue;
+    const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes) : 0;
+    out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k], cols});
+  }
   ev_kind_.clear();
   for (int k = 0; k < kKernelKinds; k++) launches_[k] = 0;
 }

@@ -500,7 +500,8 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
   { StageTimer t("Solver::Initialize (total)"); h->solver->Initialize(); }
   if (own_frac != 1.0) {
     auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
-    if (!pd->single_kernel_path()) throw Exception("Column sharding needs the single-kernel gradient2d path (one gradient2d block with L <= 2, ny % 4 == 0).");
+    // halo exchange / column copies move the planes x, y1, y2 of ONE channel
+    if (!pd->single_kernel_path() || pd->fused_channels() != 1) throw Exception("Column sharding needs the single-kernel gradient2d path (one gradient2d block with L = 1).");
   }
   return h;
 }
@@ -647,11 +648,12 @@ AnyHandle& handle_of(const prost_value* v) {
   return it->second;
 }
 template <typename T>
-void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int nlhs, prost_value** plhs) {
-  h.backend->EnableKernelTiming(time_kernels);
+void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int sample_every, bool checked, int nlhs, prost_value** plhs) {
+  h.backend->EnableKernelTiming(time_kernels, sample_every);
   CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
   const auto t0 = std::chrono::steady_clock::now();
-  h.solver->Iterate(iters);
+  bool converged = false;
+  if (checked) converged = h.solver->IterateChecked(iters); else h.solver->Iterate(iters);
   CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   CheckHip(prost_hip_check_last_error(), "solver_iterate");
@@ -660,10 +662,12 @@ void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int nlhs
   h.backend->EnableKernelTiming(false);
   prost_value* out = prost_value_struct();
   prost_value_struct_set(out, "ms", prost_value_scalar(ms));
-  // one cell per kernel kind sampled: {name, avg_ms, sampled launches, iterations per launch, all launches}
+  prost_value_struct_set(out, "converged", prost_value_scalar(converged ? 1 : 0));
+  // one cell per kernel kind sampled: {name, avg_ms, sampled launches, iterations per launch, all launches, chunk columns}
   prost_value* ks = prost_value_cell(kt.size());
   for (size_t i = 0; i < kt.size(); i++) {
-    prost_value* e = prost_value_cell(5);
+    prost_value* e = prost_value_cell(6);
+    prost_value_cell_set(e, 5, prost_value_scalar((double)kt[i].chunk_cols));
     prost_value_cell_set(e, 0, prost_value_string(kt[i].name.c_str()));
     prost_value_cell_set(e, 1, prost_value_scalar(kt[i].avg_ms));
     prost_value_cell_set(e, 2, prost_value_scalar((double)kt[i].sampled));
@@ -679,18 +683,22 @@ void cmd_solver_iterate(CMD_ARGS) {
   AnyHandle& a = handle_of(prhs[0]);
   const int iters = (int)prhs[1]->data[0];
   const bool tk = nrhs >= 3 && prhs[2]->data[0] > 0;
-  if (a.single) solver_iterate_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), iters, tk, nlhs, plhs);
-  else solver_iterate_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), iters, tk, nlhs, plhs);
+  const int every = nrhs >= 4 ? (int)prhs[3]->data[0] : 8;
+  const bool checked = nrhs >= 5 && prhs[4]->data[0] > 0;
+  if (a.single) solver_iterate_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), iters, tk, every, checked, nlhs, plhs);
+  else solver_iterate_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), iters, tk, every, checked, nlhs, plhs);
 }
 template <typename T>
-void solver_state_t(SolverHandle<T>& h, int nlhs, prost_value** plhs) {
-  { StageTimer t("FetchSolution"); h.solver->FetchSolution(); }
+void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** plhs) {
+  if (vectors) { StageTimer t("FetchSolution"); h.solver->FetchSolution(); }
   StageTimer t2("solver_state: value tree");
   prost_value* out = prost_value_struct();
-  prost_value_struct_set(out, "x", vec_value_t(h.solver->cur_primal_sol()));
-  prost_value_struct_set(out, "y", vec_value_t(h.solver->cur_dual_sol()));
-  prost_value_struct_set(out, "z", vec_value_t(h.solver->cur_primal_constr_sol()));
-  prost_value_struct_set(out, "w", vec_value_t(h.solver->cur_dual_constr_sol()));
+  if (vectors) {
+    prost_value_struct_set(out, "x", vec_value_t(h.solver->cur_primal_sol()));
+    prost_value_struct_set(out, "y", vec_value_t(h.solver->cur_dual_sol()));
+    prost_value_struct_set(out, "z", vec_value_t(h.solver->cur_primal_constr_sol()));
+    prost_value_struct_set(out, "w", vec_value_t(h.solver->cur_dual_constr_sol()));
+  }
   double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0;
   if (auto* p = dynamic_cast<BackendPDHG<T>*>(h.backend.get())) { tau = p->tau(); sigma = p->sigma(); theta = p->theta(); it = (double)p->iteration(); }
   if (auto* a = dynamic_cast<BackendADMM<T>*>(h.backend.get())) { rho = a->rho(); it = (double)a->iteration(); cg_its = a->last_cg_iterations(); }
@@ -703,10 +711,11 @@ void solver_state_t(SolverHandle<T>& h, int nlhs, prost_value** plhs) {
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 void cmd_solver_state(CMD_ARGS) {
-  if (nrhs < 1) throw Exception("solver_state: handle required.");
+  if (nrhs < 1) throw Exception("solver_state: handle [, with_vectors = 1] required.");
   AnyHandle& a = handle_of(prhs[0]);
-  if (a.single) solver_state_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), nlhs, plhs);
-  else solver_state_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), nlhs, plhs);
+  const bool vectors = nrhs < 2 || prhs[1]->data[0] > 0;      // 0: step sizes / residuals only (states too large to read back)
+  if (a.single) solver_state_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), vectors, nlhs, plhs);
+  else solver_state_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), vectors, nlhs, plhs);
 }
 // ---- column-sharded images: halo columns of the current iterate (x: n, y: two planes of n; column c of a
 // plane = ny contiguous entries at c * ny) ----
@@ -714,7 +723,7 @@ template <typename T>
 static BackendPDHG<T>& pdhg_of(AnyHandle& a) {
   auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
   auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
-  if (!pd || !pd->single_kernel_path()) throw Exception("Halo exchange needs a pdhg solver on the single-kernel gradient2d path.");
+  if (!pd || !pd->single_kernel_path() || pd->fused_channels() != 1) throw Exception("Halo exchange needs a pdhg solver on the single-kernel gradient2d path (L = 1).");
   return *pd;
 }
 /// solver_halo_exchange(handle, ny, halo, left_halo, right_halo, left_rank, right_rank): over the RCCL
@@ -772,6 +781,72 @@ void cmd_solver_copy_columns(CMD_ARGS) {
   const size_t dcol = (size_t)prhs[1]->data[0], scol = (size_t)prhs[3]->data[0], nc = (size_t)prhs[4]->data[0], ny = (size_t)prhs[5]->data[0];
   if (d.single) copy_columns_t<float>(d, dcol, s, scol, nc, ny); else copy_columns_t<double>(d, dcol, s, scol, nc, ny);
 }
+// ---- verification without a full read-back (the 2048 x 2048 x 64 state is ~8 GB per solver) ----
+/// solver_compare(handle_a, handle_b) -> 4 x 2 matrix, rows x, y, x_prev, y_prev: {elements whose bits differ, sum |a - b|},
+/// computed on the device (prost_hip_compare_*)
+template <typename T>
+static prost_value* solver_compare_t(AnyHandle& a, AnyHandle& b) {
+  auto ha = std::static_pointer_cast<SolverHandle<T>>(a.h); auto hb = std::static_pointer_cast<SolverHandle<T>>(b.h);
+  auto* pa = dynamic_cast<BackendPDHG<T>*>(ha->backend.get()); auto* pb = dynamic_cast<BackendPDHG<T>*>(hb->backend.get());
+  if (!pa || !pb) throw Exception("solver_compare: both solvers must use the pdhg backend.");
+  const size_t n = ha->problem->ncols(), m = ha->problem->nrows();
+  if (n != hb->problem->ncols() || m != hb->problem->nrows()) throw Exception("solver_compare: problem sizes differ.");
+  T* va[4]; T* vb[4];
+  pa->device_iterates(va[0], va[1], va[2], va[3]);
+  pb->device_iterates(vb[0], vb[1], vb[2], vb[3]);
+  const size_t len[4] = {n, m, n, m};
+  double* out = nullptr; void* ws = nullptr;
+  CheckHip(prost_hip_malloc((void**)&out, 8 * sizeof(double)), "malloc");
+  CheckHip(prost_hip_malloc(&ws, prost_hip_reduce_workspace_bytes()), "malloc");
+  for (int k = 0; k < 4; k++) CheckHip(Api<T>::compare(out + 2 * k, va[k], vb[k], len[k], ws, CurrentStream()), "compare");
+  double host[8];
+  CheckHip(prost_hip_memcpy_d2h(host, out, sizeof(host), CurrentStream()), "d2h");
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+  prost_hip_free(out); prost_hip_free(ws);
+  double t[8];
+  for (int k = 0; k < 4; k++) { t[k] = host[2 * k]; t[4 + k] = host[2 * k + 1]; }      // column-major 4 x 2
+  return prost_value_matrix(t, 4, 2);
+}
+void cmd_solver_compare(CMD_ARGS) {
+  if (nrhs != 2) throw Exception("solver_compare: (handle_a, handle_b) required.");
+  AnyHandle& a = handle_of(prhs[0]); AnyHandle& b = handle_of(prhs[1]);
+  if (a.single != b.single) throw Exception("solver_compare: both solvers must have the same precision.");
+  prost_value* out = a.single ? solver_compare_t<float>(a, b) : solver_compare_t<double>(a, b);
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
+/// solver_read(handle, which, offsets, count) -> count x #offsets matrix: `count` consecutive entries of vector `which`
+/// ("x", "y", "x_prev", "y_prev") starting at each offset
+template <typename T>
+static prost_value* solver_read_t(AnyHandle& a, const std::string& which, const prost_value* offs, size_t count) {
+  auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
+  auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
+  if (!pd) throw Exception("solver_read: pdhg backend required.");
+  T* v[4];
+  pd->device_iterates(v[0], v[1], v[2], v[3]);
+  const size_t n = h->problem->ncols(), m = h->problem->nrows();
+  const int k = which == "x" ? 0 : which == "y" ? 1 : which == "x_prev" ? 2 : which == "y_prev" ? 3 : -1;
+  if (k < 0) throw Exception("solver_read: vector must be one of x, y, x_prev, y_prev.");
+  const size_t len = (k & 1) ? m : n, segs = offs->data.size();
+  std::vector<T> buf(count * segs);
+  for (size_t s = 0; s < segs; s++) {
+    const size_t o = (size_t)offs->data[s];
+    if (o + count > len) throw Exception("solver_read: segment outside the vector.");
+    CheckHip(prost_hip_memcpy_d2h(buf.data() + s * count, v[k] + o, count * sizeof(T), CurrentStream()), "d2h");
+  }
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+  prost_value* out = prost_value_matrix(nullptr, count, segs);
+  for (size_t i = 0; i < buf.size(); i++) out->data[i] = (double)buf[i];
+  return out;
+}
+void cmd_solver_read(CMD_ARGS) {
+  if (nrhs != 4) throw Exception("solver_read: (handle, vector name, offsets, count) required.");
+  AnyHandle& a = handle_of(prhs[0]);
+  const std::string which = GetString(prhs[1]);
+  if (prhs[2]->kind != PROST_VALUE_MATRIX) throw Exception("solver_read: offsets must be a numeric vector.");
+  const size_t count = (size_t)prhs[3]->data[0];
+  prost_value* out = a.single ? solver_read_t<float>(a, which, prhs[2], count) : solver_read_t<double>(a, which, prhs[2], count);
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
 void cmd_solver_destroy(CMD_ARGS) {
   (void)nlhs; (void)plhs;
   if (nrhs < 1) throw Exception("solver_destroy: handle required.");
@@ -817,7 +892,8 @@ const std::map<std::string, cmd_fn>& cmd_reg() {
       {"eval_prox", cmd_eval_prox}, {"list_gpus", cmd_list_gpus}, {"set_gpu", cmd_set_gpu},
       {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info},
       {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_state", cmd_solver_state},
-      {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_copy_columns", cmd_solver_copy_columns}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
+      {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_copy_columns", cmd_solver_copy_columns},
+      {"solver_compare", cmd_solver_compare}, {"solver_read", cmd_solver_read}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
       {"comm_destroy", cmd_comm_destroy}, {"set_quirks", cmd_set_quirks}};
   return reg;
 }

@@ -27,6 +27,7 @@ void Solver<T>::Initialize() {
   }
   if (opts_.solve_dual_problem) {
     problem_->Dualize();
+    backend_->SwapGlobalSizes();
     opts_.x0.swap(opts_.y0);
     dualized_ = true;
   }
@@ -58,6 +59,19 @@ void Solver<T>::Iterate(int iters) {
   // the state is observable after the last iteration only: the backend may fuse the ones before it
   for (int i = 0; i < iters;) i += backend_->PerformIterations(iters - i);
   iterations_done_ += iters;
+}
+
+template <typename T>
+bool Solver<T>::IterateChecked(int iters) {
+  for (int i = 0; i < iters;) {
+    const int done = backend_->PerformIterations(iters - i);
+    i += done;
+    iterations_done_ += done;
+    // residual accessors wait for the sums of a residual iteration (the only host synchronisation of the loop)
+    const T primal_res = backend_->primal_residual(), dual_res = backend_->dual_residual();
+    if ((primal_res < backend_->eps_primal()) && (dual_res < backend_->eps_dual())) return true;
+  }
+  return false;
 }
 
 template <typename T>
@@ -126,6 +140,7 @@ typename Solver<T>::ConvergenceResult Solver<T>::Solve() {
   }
   if (opts_.solve_dual_problem && dualized_) {        // restore the original problem (solver.cu:198-203)
     problem_->Dualize();
+    backend_->SwapGlobalSizes();
     opts_.x0.swap(opts_.y0);
     dualized_ = false;
   }

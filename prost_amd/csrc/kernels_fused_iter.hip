@@ -343,7 +343,9 @@ static bool iter_desc_ok(const prost_hip_fused_desc* d, int dtype) {
     if (!aligned16(d->g_coeff_ptr[k])) return false;
   }
   const size_t strips = (d->ny + 63 * V - 1) / (63 * V);
-  return strips <= 65535 && d->nx <= 65535 * 4;
+  // residual launches write one partial (4 doubles) per wavefront into the reduction workspace: with ONE chunk per strip
+  // (the widest choice the launcher can make) the strips alone must fit it, otherwise the two-pass kernels run
+  return strips <= (size_t)kReduceBlocks / 2 && d->nx <= 65535 * 4;
 }
 
 template <class T>
@@ -377,7 +379,8 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
     }
   }
   // residual launches write one partial (4 doubles) per wavefront: 2 * kReduceBlocks pairs fit the workspace
-  while (out4 && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) cols += 6;
+  while (out4 && (size_t)cols < d->nx && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) cols += 6;
+  if (out4 && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) { set_error("fused iteration: grid exceeds the reduction workspace"); return 1; }
   a.cols_per_block = cols;
   a.chunks = (unsigned)((d->nx + cols - 1) / cols);
   if (strips * a.chunks > 0x7fffffffull) { set_error("fused iteration: grid too large"); return 1; }

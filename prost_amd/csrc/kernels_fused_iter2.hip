@@ -330,6 +330,8 @@ static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->nx < 4 || d->ny < 4) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4 : 8) >= 4294967296.0) return false;   // 32-bit byte offsets per plane
+  // one partial per wavefront of a residual launch must fit the reduction workspace even with one chunk per strip
+  if ((d->ny + 62 * (dtype == 0 ? 4 : 2) - 1) / (62 * (dtype == 0 ? 4 : 2)) > (size_t)kReduceBlocks / 2) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;
     if (!aligned16(d->g_coeff_ptr[k])) return false;
@@ -349,26 +351,18 @@ static bool iter2_fast_shape(const prost_hip_fused_desc* d) {
          d->f_coeff_val[0] == 1.0 && d->f_coeff_val[3] == 0.0 && d->f_coeff_val[4] == 0.0;
 }
 
-template <class T>
-static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, T* x_mid, T* y_mid, const double* tau,
-                     const double* sigma, const double* theta, int cols, double* out4, void* ws, void* stream) {
-  constexpr int V = VecOf<T>::N;
-  if (!iter2_desc_ok(d, sizeof(T) == 4 ? 0 : 1) || !aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) {
-    set_error("fused double iteration: unsupported description"); return 1;
-  }
-  if ((x_mid == nullptr) != (y_mid == nullptr) || !aligned16(x_mid) || !aligned16(y_mid)) { set_error("fused double iteration: x_mid and y_mid go together"); return 1; }
-  if (out4 && !ws) { set_error("fused double iteration: residuals need the reduction workspace"); return 1; }
-  FusedArgs<T> a = make_fused_args<T>(d);
+// chunk length (columns per wavefront) of a launch; `res`: the launch also forms the residual sums
+static int iter2_chunk_cols(const prost_hip_fused_desc* d, int V, bool res, int cols) {
   const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
   if (cols <= 0) {
     // The kernel is bound by wave-level latency as much as by HBM: 3 resident waves per SIMD (<= 168
     // VGPRs) with the loads of three columns in flight per wave beat 4 waves with one (measured same box,
-    // 4096^2: 0.1166 vs 0.1207 ms).  3072 wave slots on 256 CUs: take the longest chunk (3 warm-up
+    // 4096^2: 0.1166 vs 0.1207 ms).  256 CUs x 4 SIMDs x 3 wave slots: take the longest chunk (3 warm-up
     // columns are amortised over it) that still fills >= 90 % of the slots in ONE round -- a second,
     // mostly empty round costs a full chunk time (24 cols = 2907 waves 0.117 ms, 18 cols = 3876 waves
     // 0.127 ms, 21 cols 0.133 ms).  Chunk lengths stay off multiples of 16 (HBM channel spread).
     // (the residual instance holds 4 double accumulators and runs 2 waves per SIMD, the others 3)
-    const size_t slots = 256 * 4 * (size_t)(out4 ? 2 : 3);
+    const size_t slots = 256 * 4 * (size_t)(res ? 2 : 3);
     cols = 0;
     for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
     if (cols == 0) {
@@ -384,7 +378,23 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
     }
   }
   // residual launches write one partial (4 doubles) per wavefront: kReduceBlocks / 2 of them fit the workspace
-  while (out4 && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) cols += 6;
+  while (res && (size_t)cols < d->nx && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) cols += 6;
+  return cols;
+}
+
+template <class T>
+static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, T* x_mid, T* y_mid, const double* tau,
+                     const double* sigma, const double* theta, int cols, double* out4, void* ws, void* stream) {
+  constexpr int V = VecOf<T>::N;
+  if (!iter2_desc_ok(d, sizeof(T) == 4 ? 0 : 1) || !aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) {
+    set_error("fused double iteration: unsupported description"); return 1;
+  }
+  if ((x_mid == nullptr) != (y_mid == nullptr) || !aligned16(x_mid) || !aligned16(y_mid)) { set_error("fused double iteration: x_mid and y_mid go together"); return 1; }
+  if (out4 && !ws) { set_error("fused double iteration: residuals need the reduction workspace"); return 1; }
+  FusedArgs<T> a = make_fused_args<T>(d);
+  const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
+  cols = iter2_chunk_cols(d, V, out4 != nullptr, cols);
+  if (out4 && strips * ((d->nx + cols - 1) / cols) > (size_t)kReduceBlocks / 2) { set_error("fused double iteration: grid exceeds the reduction workspace"); return 1; }
   a.cols_per_block = cols;
   a.chunks = (unsigned)((d->nx + cols - 1) / cols);
   if (strips * a.chunks > 0x7fffffffull) { set_error("fused double iteration: grid too large"); return 1; }
@@ -431,6 +441,9 @@ using namespace prost_hip;
 extern "C" {
 int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) ? 1 : 0; }
 int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) && iter2_fast_shape(desc) ? 1 : 0; }
+int prost_hip_fused_iteration2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals) {
+  return iter2_desc_ok(desc, dtype) ? iter2_chunk_cols(desc, dtype == 0 ? 4 : 2, with_residuals != 0, 0) : 0;
+}
 int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, float* x_mid, float* y_mid,
                                    const double* tau, const double* sigma, const double* theta, int cols_per_block, double* res_out4, void* workspace, void* s) {
   return run_iter2<float>(d, x_out, y_out, x, y, x_mid, y_mid, tau, sigma, theta, cols_per_block, res_out4, workspace, s);

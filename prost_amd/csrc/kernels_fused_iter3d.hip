@@ -300,6 +300,9 @@ static bool iter3d_ok(const prost_hip_fused_desc* d) {
   if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
   if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
   const size_t strips = (d->ny + (size_t)(kWave - 1) * VecOf<T>::N - 1) / ((size_t)(kWave - 1) * VecOf<T>::N);
+  // residual launches: one partial per wavefront, at best one chunk per (strip, plane), must fit the reduction workspace --
+  // otherwise BackendPDHG takes the two-pass kernels (e.g. 1024^3, or ny = 4096 with 256 planes)
+  if (strips * d->L > (size_t)kReduceBlocks / 2) return false;
   return strips * d->L * ((d->nx + 5) / 6) < (size_t)1 << 31;
 }
 

@@ -264,6 +264,7 @@ static bool iter_mc_ok(const prost_hip_fused_desc* d) {
   if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
   if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
   const size_t strips = (d->ny + (size_t)(kWave - 1) * VecOf<T>::N - 1) / ((size_t)(kWave - 1) * VecOf<T>::N);
+  if (strips * d->L > (size_t)kReduceBlocks / 2) return false;     // residual launches: one partial per wavefront must fit the workspace
   return strips * d->nx < (size_t)1 << 31;
 }
 

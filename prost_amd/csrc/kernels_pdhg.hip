@@ -64,6 +64,20 @@ template <class T> struct ZVarF {                                               
   __device__ T operator()(const T* a) const { return (a[0] - a[1]) / (sigma * a[2]) + (1 + theta) * a[3] - theta * a[4]; }
 };
 
+// bitwise comparison of two vectors (test / verification entry: prost_hip_compare_*): a = elements whose bit patterns
+// differ, b = sum |a - b| over the differing elements (+-0 and NaN payloads count as different bits)
+template <class T> struct CompareF;
+template <> struct CompareF<float> {
+  __device__ void operator()(const float* v, double& a, double& b) const {
+    if (__float_as_uint(v[0]) != __float_as_uint(v[1])) { a += 1.0; b += fabs((double)v[0] - (double)v[1]); }
+  }
+};
+template <> struct CompareF<double> {
+  __device__ void operator()(const double* v, double& a, double& b) const {
+    if (__double_as_longlong(v[0]) != __double_as_longlong(v[1])) { a += 1.0; b += fabs(v[0] - v[1]); }
+  }
+};
+
 // ---- ADMM / CGLS ----
 template <class T> struct Nrm2F { __device__ void operator()(const T* v, double& a, double&) const { a += (double)v[0] * (double)v[0]; } };
 template <class T> struct AxpyF { T alpha; __device__ T operator()(const T* a) const { return alpha * a[0] + a[1]; } };   // x, y
@@ -158,6 +172,13 @@ int prost_hip_pdhg_z_variable_f32(float* z, const float* yp, const float* y, con
 }
 int prost_hip_pdhg_z_variable_f64(double* z, const double* yp, const double* y, const double* S, const double* kx, const double* kxp, double sg, double th, size_t m, void* s) {
   return launch_ew<double, 5>("z_variable", z, EwIn<double, 5>{{yp, y, S, kx, kxp}}, m, ZVarF<double>{sg, th}, as_stream(s));
+}
+
+int prost_hip_compare_f32(double* out2, const float* a, const float* b, size_t n, void* ws, void* s) {
+  return reduce_to<float, 2>(out2, ws, EwIn<float, 2>{{a, b}}, n, CompareF<float>{}, false, s);
+}
+int prost_hip_compare_f64(double* out2, const double* a, const double* b, size_t n, void* ws, void* s) {
+  return reduce_to<double, 2>(out2, ws, EwIn<double, 2>{{a, b}}, n, CompareF<double>{}, false, s);
 }
 
 // fold writes out[0] = sqrt(sum), out[1] = 0 -> `out` must have room for 2 doubles

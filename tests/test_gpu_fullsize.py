@@ -1,0 +1,139 @@
+"""Parity at the BASELINE sizes themselves (configs C2 and C3), against the CPU oracle.
+
+The size-dependent code of the headline path -- the launch geometry `run_iter2` derives from the image
+size (3876-wave grid, 18..36-column chunks, XCD tile order: kernels_fused_iter2.hip), 32-bit byte offsets
+per plane, the > 2^31-byte dual vector of the 2048 x 2048 x 64 volume -- is not exercised by the small
+oracle comparisons of test_gpu_solver.py / test_gpu_fused3d.py.  Here:
+
+  C2  4096 x 4096 fp32, alg2, residual_iter 10: product (default path: pair launches) == oracle.Solver,
+      bit for bit, on x, y, z, w after 12 iterations (iterations 0 and 10 are residual iterations, 2..9 and
+      11 run as pairs / singles, z and w need the rebuilt previous iterate).
+  C3  2048 x 2048 x 64 fp32: (a) fused path (one-kernel iterations, `_pw` layout + residual variant) ==
+      generic nine-vector path, compared ON THE DEVICE (prost_hip_compare_*: no 8 GB read-back);
+      (b) sub-volumes of the full-size run == oracle runs on the cropped volume.  One PDHG iteration moves
+      information by one voxel (K^T reads p - e, K reads p + e), the alg2 step sizes do not depend on the
+      data and the preconditioners are the constants 1/2, 1/6, so after k iterations every voxel further
+      than k from the crop's artificial faces carries the bits of the full-size run.  The crops sit in the
+      far corner (faces that coincide with the true volume faces are exact) and mid-volume; the third
+      gradient component of ANY voxel lies beyond byte 2^31 of y.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import prost_amd as prost
+from prost_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+ZERO_TOL = dict(tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+
+
+@pytest.fixture(autouse=True)
+def _gpu(hip):
+    prost.set_gpu(0)
+    prost.set_precision("single")
+    yield
+    prost.set_precision("double")
+
+
+def test_c2_4096_default_path_matches_oracle_bit_for_bit():
+    n, k = 4096, 12
+    prob, u, q, f = synthetic.rof_problem(n, n)
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    s = prost.Solver(prob, b, o)
+    info = s.iterate(k, time_kernels=True)
+    st = s.state()
+    s.destroy()
+    assert st["path"] == "pdhg:fused-grad2d"
+    # the launch kinds the headline run consists of all occurred: plain pairs, a pair carrying the residual sums
+    # or storing the middle iterate, single launches (iterations 0, 1 and the residual iteration 10)
+    assert any(name.startswith("fused_iter2d_x2_kernel") for name in info["kernels"]), info["kernels"]
+    oracle.set_num_threads(16)
+    os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float32)
+    os_.initialize()
+    os_.iterate(k)
+    ost = os_.state()
+    sc = os_.scalars()
+    for v in "xyzw":
+        assert st[v].shape == ost[v].shape
+        assert np.array_equal(st[v], ost[v]), (v, int((st[v] != ost[v]).sum()), float(np.abs(st[v] - ost[v]).max()))
+    for v in ("tau", "sigma", "theta"):
+        assert st[v] == sc[v], v
+    # residual scalars: double accumulation here, T-precision sums in the oracle (tolerance as in test_gpu_solver.py)
+    for v in ("primal_res", "dual_res"):
+        assert np.isclose(st[v], sc[v], rtol=1e-5), (v, st[v], sc[v])
+
+
+def _crop(f, nx, ny, L, x0, x1, y0, y1, l0, l1):
+    return np.ascontiguousarray(f.reshape(L, nx, ny)[l0:l1, x0:x1, y0:y1]).reshape(-1)
+
+
+def _read_block(solver, which, comps, nx, ny, L, x0, x1, y0, y1, l0, l1):
+    """sub-volume [l0:l1, x0:x1, y0:y1] of every component plane of device vector `which` -> (comps, l, x, y)"""
+    n = nx * ny * L
+    offs = [c * n + l * nx * ny + x * ny + y0 for c in range(comps) for l in range(l0, l1) for x in range(x0, x1)]
+    seg = solver.read(which, offs, y1 - y0)
+    return seg.reshape(comps, l1 - l0, x1 - x0, y1 - y0)
+
+
+def test_c3_2048x2048x64_fused_equals_generic_on_device_and_subvolumes_match_oracle():
+    nx, ny, L, k = 2048, 2048, 64, 12
+    f = synthetic.rof_image(nx, ny, L, 42)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    solvers = {}
+    for fused in (True, False):
+        prob, u, q, _ = synthetic.tv3d_problem(nx, ny, L, f=f)
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+        b[1]["allow_fused"] = fused
+        s = prost.Solver(prob, b, o)
+        s.iterate(k)
+        solvers[fused] = s
+        del prob
+    # (a) two independent kernel paths, every bit of x, y and the previous iterate equal -- compared on the device
+    diff = solvers[True].compare(solvers[False])
+    for v, (count, total) in diff.items():
+        assert count == 0, (v, count, total)
+    # negative control of the comparison entry: one more iteration on one side must show up
+    solvers[False].iterate(1)
+    moved = solvers[True].compare(solvers[False])
+    assert moved["x"][0] > nx * ny * L // 2 and moved["y"][0] > nx * ny * L // 2, moved
+    solvers[False].destroy()
+    s = solvers[True]
+    scal = s.state(vectors=False)
+    assert scal["path"] == "pdhg:fused-grad3d" and scal["iteration"] == k
+    # (b) sub-volumes against the oracle on the cropped volume
+    oracle.set_num_threads(16)
+    margin = k + 1
+    crops = [  # (x0, x1, y0, y1, l0, l1): far corner (three true faces), mid-volume, first planes / last columns
+        (nx - 44, nx, ny - 72, ny, L - 36, L),
+        (1000, 1044, 1990, 2048, 20, 56),
+        (0, 40, 0, 64, 0, 34),
+    ]
+    for (x0, x1, y0, y1, l0, l1) in crops:
+        cx, cy, cl = x1 - x0, y1 - y0, l1 - l0
+        cprob, _, _, _ = synthetic.tv3d_problem(cx, cy, cl, f=_crop(f, nx, ny, L, x0, x1, y0, y1, l0, l1))
+        cprob.finalize()
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+        osv = oracle.Solver(cprob.data, cprob.nrows, cprob.ncols, b, o, np.float32)
+        osv.initialize()
+        osv.iterate(k)
+        ost = osv.state()
+        osc = osv.scalars()
+        assert (osc["tau"], osc["sigma"], osc["theta"]) == (scal["tau"], scal["sigma"], scal["theta"])     # data-independent steps
+        # voxels further than k from an ARTIFICIAL face (a face that is also a face of the full volume is exact)
+        lo = lambda a0: 0 if a0 == 0 else margin
+        hi = lambda a1, full, c: c if a1 == full else c - margin
+        sx, sy, sl = slice(lo(x0), hi(x1, nx, cx)), slice(lo(y0), hi(y1, ny, cy)), slice(lo(l0), hi(l1, L, cl))
+        assert (sx.stop - sx.start) * (sy.stop - sy.start) * (sl.stop - sl.start) > 4000
+        got_x = _read_block(s, "x", 1, nx, ny, L, x0, x1, y0, y1, l0, l1)
+        got_y = _read_block(s, "y", 3, nx, ny, L, x0, x1, y0, y1, l0, l1)
+        exp_x = ost["x"].reshape(1, cl, cx, cy)
+        exp_y = ost["y"].reshape(3, cl, cx, cy)
+        assert np.array_equal(got_x[:, sl, sx, sy], exp_x[:, sl, sx, sy]), ("x", (x0, y0, l0))
+        assert np.array_equal(got_y[:, sl, sx, sy], exp_y[:, sl, sx, sy]), ("y", (x0, y0, l0))
+        # the margin is needed: right at an artificial face the crop's boundary condition differs
+        if x0 > 0:
+            assert not np.array_equal(got_x[:, :, :2, :], exp_x[:, :, :2, :])
+    s.destroy()

@@ -1,20 +1,30 @@
 #!/bin/bash
-# On the GPU box: bench line + rocprofv3 kernel stats + HBM traffic counters (separate --pmc passes).
-R=$PWD; mkdir -p $R/gpurun_out/prof
-python bench.py 2>/dev/null | tail -1 > $R/gpurun_out/bench_r01.json
+# On the GPU box: bench lines (driver invocation + default) + rocprofv3 kernel stats + HBM traffic counters (separate --pmc passes).
+# usage: tools/profile_bench.sh <tag>      (outputs under gpurun_out/prof_<tag>/, copy the summaries to profiles/)
+R=$PWD; TAG=${1:-r02}; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
+python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_invocation.json
+python3 bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_default.json
+python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_driver_invocation_2.json
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof -o pmc_fetch -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof -o pmc_write -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
-python3 - <<PY
-import csv, collections
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats_short -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_short_under_rocprof.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O -o pmc_fetch -- python3 $R/bench.py --steps 60 --warmup 10 --prelude-iters 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O -o pmc_write -- python3 $R/bench.py --steps 60 --warmup 10 --prelude-iters 0 --no-cpu-baseline > /dev/null 2>&1
+python3 - <<PY > $O/pmc_traffic_summary.txt
+import csv, collections, glob
 for tag in ("pmc_fetch", "pmc_write"):
     agg = collections.defaultdict(float); n = collections.Counter()
-    for r in csv.DictReader(open("$R/gpurun_out/prof/%s_counter_collection.csv" % tag)):
-        k = r["Kernel_Name"].split("(")[0]
-        agg[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+    for f in glob.glob("$O/**/%s_counter_collection.csv" % tag, recursive=True) + glob.glob("$O/%s_counter_collection.csv" % tag):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            agg[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
+        break
     for (k, c), v in sorted(agg.items()):
-        if "fused" in k: print(tag, k[-60:], c, "mean per launch = %.6g KiB over %d launches" % (v / n[(k, c)], n[(k, c)]))
+        if "fused" in k: print(tag, k[-70:], c, "mean per launch = %.6g KiB over %d launches" % (v / n[(k, c)], n[(k, c)]))
 PY
-head -6 $R/gpurun_out/prof/r01_kernel_stats.csv | cut -c1-200
-python3 -c "import json; d=json.load(open('$R/gpurun_out/bench_r01.json')); print(d['value'], d['ms_per_step'], d['roofline'], d['cpu_baseline'])"
+cat $O/pmc_traffic_summary.txt
+for f in $(find $O -name "stats_kernel_stats.csv" -o -name "stats_short_kernel_stats.csv"); do echo $f; head -8 $f | cut -c1-220; done
+for f in bench_driver_invocation bench_driver_invocation_2 bench_default; do python3 -c "
+import json; d=json.load(open('$O/$f.json')); r=d['roofline']
+print('$f', 'value', round(d['value']), 'iterate_only', round(d['iterate_only_it_per_s']), 'ms/step', d['ms_per_step'], 'kernel', r['kernel'], 'avg_ms', r['avg_launch_ms'], 'timed', r['launches_timed'], 'frac', round(r['frac'],3), 'phys', r['frac_hbm_traffic'], 'cols', r['chunk_cols'])
+print('   all', {k:(round(v['avg_launch_ms'],4), v['launches_timed']) for k,v in r['all_kernels'].items()}, d.get('cpu_baseline'))"; done
