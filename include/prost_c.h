@@ -97,11 +97,13 @@ void prost_set_stop_callback(prost_stop_cb fn, void* user);
  *   solver_create(problem, nrows, ncols, backend, opts[, [x0 x1 nx]]) -> handle (scalar); the optional
  *       1x3 matrix marks image columns [x0, x1) of nx as OWNED (column-sharded images: the rest are halo
  *       columns that do not count in the residual sums); pdhg single-kernel gradient2d path only
- *   solver_iterate(handle, iters[, time_kernels[, sample_every[, checked]]]) -> struct {ms, converged, kernels};
+ *   solver_kernel_times(handle) -> the `kernels` cell of solver_iterate for the events recorded since the last evaluation
+ *   solver_iterate(handle, iters[, time_kernels[, sample_every[, checked[, defer_times]]]]) -> struct {ms, converged, kernels};
  *       kernels = cell of {name, avg_ms, sampled launches, iterations per launch, all launches, chunk columns};
  *       sample_every: one launch in that many is bracketed by events (default 8; 1 = every launch);
  *       checked != 0 runs the loop of solve_problem (stopping test of solver.cu:141-150 after every observable
- *       iteration, stops when it fires) without callbacks or solution read-out
+ *       iteration, stops when it fires) without callbacks or solution read-out; defer_times != 0 leaves `kernels`
+ *       empty and the recorded events to solver_kernel_times
  *   solver_halo_exchange(handle, ny, halo, left_halo, right_halo, left_rank, right_rank): swap `halo` image
  *       columns of x and y with the neighbouring ranks over the comm_init communicator (rank < 0: none)
  *   solver_copy_columns(dst_handle, dst_col, src_handle, src_col, ncols, ny): the same transfer between two

@@ -334,16 +334,25 @@ class Solver:
         out = np.asarray(command("solver_read", [self.handle, which, offsets, int(count)], nlhs=1)[0], dtype=np.float64)
         return out.T if out.ndim == 2 else out.reshape(1, -1)      # (count, segments) -> (segments, count)
 
-    def iterate(self, iters, time_kernels=False, sample_every=8, checked=False):
+    @staticmethod
+    def _kernel_dict(cells):
+        return {k[0]: {"avg_ms": k[1], "sampled": int(k[2]), "iterations_per_launch": int(k[3]), "launches": int(k[4]),
+                       "chunk_cols": int(k[5])} for k in cells or []}
+
+    def iterate(self, iters, time_kernels=False, sample_every=8, checked=False, defer_times=False):
         """-> {"ms": wall time, "converged", "kernels": {kernel name: {"avg_ms", "sampled", "launches",
         "iterations_per_launch", "chunk_cols"}}} (kernel launch times from HIP events on the solver's stream; one launch
         in `sample_every` is bracketed).  checked=True runs the loop of prost.solve -- the stopping test after every
-        observable iteration -- without callbacks or read-out, and stops when the test fires."""
-        info = command("solver_iterate", [self.handle, int(iters), bool(time_kernels), int(sample_every), bool(checked)], nlhs=1,
-                       struct_fields=("ms", "converged", "kernels"))[0]
-        info["kernels"] = {k[0]: {"avg_ms": k[1], "sampled": int(k[2]), "iterations_per_launch": int(k[3]), "launches": int(k[4]),
-                                  "chunk_cols": int(k[5])} for k in info.get("kernels", [])}
+        observable iteration -- without callbacks or read-out, and stops when the test fires.  defer_times=True leaves
+        the recorded events to a later kernel_times() call (keeps their evaluation out of a caller's timed region)."""
+        info = command("solver_iterate", [self.handle, int(iters), bool(time_kernels), int(sample_every), bool(checked), bool(defer_times)],
+                       nlhs=1, struct_fields=("ms", "converged", "kernels"))[0]
+        info["kernels"] = self._kernel_dict(info.get("kernels"))
         return info
+
+    def kernel_times(self):
+        """evaluates the event pairs recorded by iterate(..., time_kernels=True, defer_times=True)"""
+        return self._kernel_dict(command("solver_kernel_times", [self.handle], nlhs=1)[0])
 
     def state(self, vectors=True):
         """vectors=False: step sizes, iteration count and residuals only (no read-back of x, y, z, w)"""

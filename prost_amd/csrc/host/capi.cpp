@@ -648,7 +648,25 @@ AnyHandle& handle_of(const prost_value* v) {
   return it->second;
 }
 template <typename T>
-void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int sample_every, bool checked, int nlhs, prost_value** plhs) {
+static prost_value* kernel_times_value(Backend<T>& backend) {
+  std::vector<typename Backend<T>::KernelTime> kt;
+  backend.KernelTimes(kt);
+  // one cell per kernel kind sampled: {name, avg_ms, sampled launches, iterations per launch, all launches, chunk columns}
+  prost_value* ks = prost_value_cell(kt.size());
+  for (size_t i = 0; i < kt.size(); i++) {
+    prost_value* e = prost_value_cell(6);
+    prost_value_cell_set(e, 0, prost_value_string(kt[i].name.c_str()));
+    prost_value_cell_set(e, 1, prost_value_scalar(kt[i].avg_ms));
+    prost_value_cell_set(e, 2, prost_value_scalar((double)kt[i].sampled));
+    prost_value_cell_set(e, 3, prost_value_scalar((double)kt[i].iterations_per_launch));
+    prost_value_cell_set(e, 4, prost_value_scalar((double)kt[i].launches));
+    prost_value_cell_set(e, 5, prost_value_scalar((double)kt[i].chunk_cols));
+    prost_value_cell_set(ks, i, e);
+  }
+  return ks;
+}
+template <typename T>
+void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int sample_every, bool checked, bool defer_times, int nlhs, prost_value** plhs) {
   h.backend->EnableKernelTiming(time_kernels, sample_every);
   CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
   const auto t0 = std::chrono::steady_clock::now();
@@ -657,25 +675,12 @@ void solver_iterate_t(SolverHandle<T>& h, int iters, bool time_kernels, int samp
   CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   CheckHip(prost_hip_check_last_error(), "solver_iterate");
-  std::vector<typename Backend<T>::KernelTime> kt;
-  h.backend->KernelTimes(kt);
   h.backend->EnableKernelTiming(false);
   prost_value* out = prost_value_struct();
   prost_value_struct_set(out, "ms", prost_value_scalar(ms));
   prost_value_struct_set(out, "converged", prost_value_scalar(converged ? 1 : 0));
-  // one cell per kernel kind sampled: {name, avg_ms, sampled launches, iterations per launch, all launches, chunk columns}
-  prost_value* ks = prost_value_cell(kt.size());
-  for (size_t i = 0; i < kt.size(); i++) {
-    prost_value* e = prost_value_cell(6);
-    prost_value_cell_set(e, 5, prost_value_scalar((double)kt[i].chunk_cols));
-    prost_value_cell_set(e, 0, prost_value_string(kt[i].name.c_str()));
-    prost_value_cell_set(e, 1, prost_value_scalar(kt[i].avg_ms));
-    prost_value_cell_set(e, 2, prost_value_scalar((double)kt[i].sampled));
-    prost_value_cell_set(e, 3, prost_value_scalar((double)kt[i].iterations_per_launch));
-    prost_value_cell_set(e, 4, prost_value_scalar((double)kt[i].launches));
-    prost_value_cell_set(ks, i, e);
-  }
-  prost_value_struct_set(out, "kernels", ks);
+  // defer_times: the event pairs stay recorded and are evaluated by solver_kernel_times (outside a caller's timed region)
+  prost_value_struct_set(out, "kernels", defer_times ? prost_value_cell(0) : kernel_times_value<T>(*h.backend));
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 void cmd_solver_iterate(CMD_ARGS) {
@@ -685,8 +690,16 @@ void cmd_solver_iterate(CMD_ARGS) {
   const bool tk = nrhs >= 3 && prhs[2]->data[0] > 0;
   const int every = nrhs >= 4 ? (int)prhs[3]->data[0] : 8;
   const bool checked = nrhs >= 5 && prhs[4]->data[0] > 0;
-  if (a.single) solver_iterate_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), iters, tk, every, checked, nlhs, plhs);
-  else solver_iterate_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), iters, tk, every, checked, nlhs, plhs);
+  const bool defer = nrhs >= 6 && prhs[5]->data[0] > 0;
+  if (a.single) solver_iterate_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), iters, tk, every, checked, defer, nlhs, plhs);
+  else solver_iterate_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), iters, tk, every, checked, defer, nlhs, plhs);
+}
+void cmd_solver_kernel_times(CMD_ARGS) {
+  if (nrhs < 1) throw Exception("solver_kernel_times: handle required.");
+  AnyHandle& a = handle_of(prhs[0]);
+  prost_value* out = a.single ? kernel_times_value<float>(*std::static_pointer_cast<SolverHandle<float>>(a.h)->backend)
+                              : kernel_times_value<double>(*std::static_pointer_cast<SolverHandle<double>>(a.h)->backend);
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 template <typename T>
 void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** plhs) {
@@ -891,7 +904,7 @@ const std::map<std::string, cmd_fn>& cmd_reg() {
       {"init", cmd_init}, {"release", cmd_release}, {"solve_problem", cmd_solve_problem}, {"eval_linop", cmd_eval_linop},
       {"eval_prox", cmd_eval_prox}, {"list_gpus", cmd_list_gpus}, {"set_gpu", cmd_set_gpu},
       {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info},
-      {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_state", cmd_solver_state},
+      {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_kernel_times", cmd_solver_kernel_times}, {"solver_state", cmd_solver_state},
       {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_copy_columns", cmd_solver_copy_columns},
       {"solver_compare", cmd_solver_compare}, {"solver_read", cmd_solver_read}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
       {"comm_destroy", cmd_comm_destroy}, {"set_quirks", cmd_set_quirks}};

@@ -11,16 +11,23 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats_short -- pyt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O -o pmc_fetch -- python3 $R/bench.py --steps 60 --warmup 10 --prelude-iters 0 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O -o pmc_write -- python3 $R/bench.py --steps 60 --warmup 10 --prelude-iters 0 --no-cpu-baseline > /dev/null 2>&1
 python3 - <<PY > $O/pmc_traffic_summary.txt
+# mean counter value per launch, FULL-SIZE launches only (bench.py first runs the same kernels on a 64 x 64 problem to load the
+# code objects: those launches have a smaller grid and are left out)
 import csv, collections, glob
 for tag in ("pmc_fetch", "pmc_write"):
+    files = glob.glob("$O/**/%s_counter_collection.csv" % tag, recursive=True)
+    rows = [r for f in files[:1] for r in csv.DictReader(open(f)) if "fused" in r["Kernel_Name"]]
+    big = collections.defaultdict(int)
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0]
+        big[k] = max(big[k], int(r["Grid_Size"]))
     agg = collections.defaultdict(float); n = collections.Counter()
-    for f in glob.glob("$O/**/%s_counter_collection.csv" % tag, recursive=True) + glob.glob("$O/%s_counter_collection.csv" % tag):
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
-            agg[(k, r["Counter_Name"])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
-        break
-    for (k, c), v in sorted(agg.items()):
-        if "fused" in k: print(tag, k[-70:], c, "mean per launch = %.6g KiB over %d launches" % (v / n[(k, c)], n[(k, c)]))
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0]
+        if int(r["Grid_Size"]) != big[k]: continue
+        agg[(k, r["Counter_Name"], big[k])] += float(r["Counter_Value"]); n[(k, r["Counter_Name"], big[k])] += 1
+    for (k, c, g), v in sorted(agg.items()):
+        print(tag, k[-70:], "grid %d work-items" % g, c, "mean per launch = %.6g KiB over %d launches" % (v / n[(k, c, g)], n[(k, c, g)]))
 PY
 cat $O/pmc_traffic_summary.txt
 for f in $(find $O -name "stats_kernel_stats.csv" -o -name "stats_short_kernel_stats.csv"); do echo $f; head -8 $f | cut -c1-220; done
