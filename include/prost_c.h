@@ -110,7 +110,7 @@ void prost_set_stop_callback(prost_stop_cb fn, void* user);
  *       solvers of one process
  *   solver_state(handle[, with_vectors = 1]) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,
  *                                   dual_var_norm,eps_primal,eps_dual,iteration,path}; with_vectors = 0 leaves out x,y,z,w
- *   solver_compare(handle_a, handle_b) -> 4x2 matrix, rows x, y, x_prev, y_prev: {elements whose bits differ,
+ *   solver_compare(handle_a, handle_b) -> 4x2 matrix, rows x, y, x_prev, y_prev: {elements that differ in value,
  *       sum |a - b|}, formed on the device (verification of states too large to read back; pdhg only)
  *   solver_read(handle, 'x'|'y'|'x_prev'|'y_prev', offsets, count) -> count x numel(offsets) matrix: `count`
  *       consecutive entries of that device vector from every offset (partial read-back; pdhg only)

@@ -361,12 +361,13 @@ int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* desc, double* x_o
  * (float)((double)x / D) of Function1DSquare, and float subtraction == double subtraction rounded to float.
  * Draws `n` pseudo-random cases (all exponents, subnormal / overflowing quotients, zeros) from `seed` and
  * writes the number of bit mismatches against the compiler's IEEE expansions to the DEVICE array
- * mismatches5 = {division, sqrt, exact division, subtraction, control}; `control` counts the cases where
+ * mismatches8 = {division, sqrt, exact division, subtraction, control, division with the product rounded through
+ * fma(n, r, +0) against n / d + 0, min0(t) against t > 0 ? 0 : t, unused}; `control` counts the cases where
  * the plain single-precision reciprocal product differs from n / d and must come out > 0. */
-int prost_hip_selftest_math(unsigned long long* mismatches5, uint64_t n, uint64_t seed, void* stream);
-/* Verification entry: bitwise comparison of two device vectors without a read-back (the 2048 x 2048 x 64 state is
- * 8 GB per vector set).  out2 (DEVICE double[2]) = {number of elements whose bit patterns differ, sum |a_i - b_i| over
- * them}; workspace: prost_hip_reduce_workspace_bytes().  The reference compares iterates on the host after
+int prost_hip_selftest_math(unsigned long long* mismatches8, uint64_t n, uint64_t seed, void* stream);
+/* Verification entry: comparison of two device vectors without a read-back (the 2048 x 2048 x 64 state is
+ * 8 GB per vector set).  out2 (DEVICE double[2]) = {number of elements that differ in value (+0 == -0, NaN == NaN: what
+ * numpy.array_equal(a, b, equal_nan=True) counts), sum |a_i - b_i| over them}; workspace: prost_hip_reduce_workspace_bytes().  The reference compares iterates on the host after
  * thrust::copy (backend_pdhg.cu:491-502); there is no device-side counterpart. */
 int prost_hip_compare_f32(double* out2, const float* a, const float* b, size_t n, void* workspace, void* stream);
 int prost_hip_compare_f64(double* out2, const double* a, const double* b, size_t n, void* workspace, void* stream);

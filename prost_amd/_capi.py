@@ -322,8 +322,8 @@ class Solver:
         command("solver_copy_columns", [self.handle, int(dst_col), src.handle, int(src_col), int(ncols), int(ny)])
 
     def compare(self, other):
-        """bitwise comparison with another solver's iterates ON THE DEVICE (no read-back):
-        {"x" | "y" | "x_prev" | "y_prev": (elements whose bits differ, sum |a - b|)}"""
+        """comparison with another solver's iterates ON THE DEVICE (no read-back):
+        {"x" | "y" | "x_prev" | "y_prev": (elements that differ in value, sum |a - b|)}"""
         m = np.asarray(command("solver_compare", [self.handle, other.handle], nlhs=1)[0]).reshape(4, 2)
         return {k: (int(m[i, 0]), float(m[i, 1])) for i, k in enumerate(("x", "y", "x_prev", "y_prev"))}
 

@@ -57,28 +57,37 @@ __device__ __forceinline__ float div_to_float_exact(float x, const UniformDiv& u
   return (float)q1;
 }
 __device__ __forceinline__ double div_to_float_exact(double x, const UniformDiv& u) { return u.D == 1.0 ? x : x / u.D; }
-// the same for VEC values with straight-line code: one (rarely taken) branch per vector instead of
-// one per element, so the independent chains of the elements interleave.
+// The same for VEC values with straight-line code, the guards evaluated as WAVE MASKS (the compares write SGPR pairs,
+// the OR runs on the scalar unit: no v_cndmask / v_or per element) and without the residual correction step: q0 = RN(x * rD) with rD = RN(1/D) is within
+// 2^-52 |q| < 2 ulp(double) of x / D, the reference's RN_double(x / D) within 1/2 ulp, so the two doubles differ by at
+// most 2 ulp and round to the same float unless a float rounding boundary lies within 4 ulp of q0 (window below:
+// +-4 ulp, probability 2^-26 per element) -- those elements, and results that are not normal floats, take the division.
+// The fallback is taken by the whole wave (the mask is wave-uniform); recomputing an element whose fast result was
+// already right gives the same bits.
 template <int VEC>
 __device__ __forceinline__ void div_to_float_exact_vec(const float (&x)[VEC], const UniformDiv& u, float (&out)[VEC]) {
-  unsigned slow = 0;                                   // bitwise, not short-circuit: no branch per element
+  unsigned long long odd = 0;
 #pragma unroll
   for (int j = 0; j < VEC; j++) {
-    const double xd = (double)x[j];
-    const double q0 = xd * u.rD;
-    const double rem = __builtin_fma(-q0, u.D, xd);
-    const double q1 = __builtin_fma(rem, u.rD, q0);
-    out[j] = (float)q1;
-    // near a float rounding boundary: the 29 dropped mantissa bits within 2 ulp(double) of the tie
-    const unsigned low = (unsigned)((unsigned long long)__double_as_longlong(q1)) & 0x1FFFFFFFu;
-    const unsigned near_tie = (low - ((1u << 28) - 2u)) <= 4u;
-    // result not a normal float (subnormal / overflow range) although x is not zero: take the division too
-    const unsigned odd_range = !__builtin_isnormal(out[j]) && x[j] != 0.0f;
-    slow |= near_tie | odd_range;
+    const double q0 = (double)x[j] * u.rD;
+    out[j] = (float)q0;
+    const unsigned low = (unsigned)((unsigned long long)__double_as_longlong(q0)) & 0x1FFFFFFFu;
+    odd |= __builtin_amdgcn_ballot_w64((low - ((1u << 28) - 4u)) <= 8u);
+    odd |= __builtin_amdgcn_ballot_w64(!__builtin_isnormal(out[j]));
   }
-  if (__builtin_expect(slow, 0)) {
+  if (__builtin_expect(odd != 0, 0)) {
+    // second look (rare; always taken by waves with padding lanes, whose x is 0): a zero result of a zero x is exact
+    unsigned long long slow = 0;
 #pragma unroll
-    for (int j = 0; j < VEC; j++) out[j] = (float)((double)x[j] / u.D);
+    for (int j = 0; j < VEC; j++) {
+      const double q0 = (double)x[j] * u.rD;
+      const unsigned low = (unsigned)((unsigned long long)__double_as_longlong(q0)) & 0x1FFFFFFFu;
+      slow |= __builtin_amdgcn_ballot_w64((low - ((1u << 28) - 4u)) <= 8u || (!__builtin_isnormal(out[j]) && x[j] != 0.0f));
+    }
+    if (slow != 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) out[j] = (float)((double)x[j] / u.D);
+    }
   }
 }
 template <int VEC>
@@ -110,7 +119,42 @@ __device__ __forceinline__ double rcp_refined(float d) {
   return r;
 }
 __device__ __forceinline__ double rcp_refined(double d) { return 1.0 / d; }
+// the same from the single-precision reciprocal estimate (v_rcp_f32, 1 ulp, converted) instead of v_rcp_f64: two Newton
+// steps take 2^-22.4 to below 2^-52 all the same
+__device__ __forceinline__ double rcp_refined_s(float d) {
+  const double dd = (double)d;
+  double r = (double)__builtin_amdgcn_rcpf(d);
+  double e = __builtin_fma(-dd, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-dd, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double rcp_refined_s(double d) { return 1.0 / d; }
 __device__ __forceinline__ float mul_rcp(float n, double r) { return (float)((double)n * r); }
+// mul_rcp(n, r) with the quotient of a zero numerator forced to +0, in one instruction less than "+ 0.0f" afterwards:
+// fma(n, r, +0.0) rounds exactly like the product and turns a -0 product (n = +-0) into +0 already in double.  (A
+// non-zero quotient that underflows to zero keeps its sign, like n / d itself.)
+__device__ __forceinline__ float mul_rcp_pz(float n, double r) { return (float)__builtin_fma((double)n, r, 0.0); }
+__device__ __forceinline__ double mul_rcp_pz(double n, double r) { return n * r + 0.0; }
+// min(t, 0) for t that is not NaN (callers: the range-checked fast paths): == (t > 0 ? 0 : t) including t = +-0
+__device__ __forceinline__ float min0(float t) { return __builtin_fminf(t, 0.0f); }
+__device__ __forceinline__ double min0(double t) { return t > 0.0 ? 0.0 : t; }
+// value of the neighbouring lane of the 64-lane wavefront: ONE v_mov_b32 with a DPP wavefront shift instead of a
+// ds_bpermute (address VALU + LDS round trip).  lane_up: lane i reads lane i - 1 (lane 0 gets 0); lane_down: lane i
+// reads lane i + 1 (lane 63 gets 0).
+__device__ __forceinline__ float lane_up(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false)); }
+__device__ __forceinline__ float lane_down(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, false)); }
+__device__ __forceinline__ double lane_up(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x138, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x138, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lane_down(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x130, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x130, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 // n / d for many n and one (typically wave-uniform) d: exact float quotient via the double reciprocal,
 // plain division for double
 template <class T> struct SharedDivisor;
@@ -124,6 +168,32 @@ template <> struct SharedDivisor<double> {
   __device__ __forceinline__ explicit SharedDivisor(double d_) : d(d_) {}
   __device__ __forceinline__ double div(double n) const { return n / d; }
 };
+// ---- the same quotient in single precision only -------------------------------------------------
+// fp64 instructions and the f32 <-> f64 conversions issue at half the fp32 rate on this part (16 vs 32 lanes per
+// cycle and SIMD), v_rcp_f64 far below that; the double-reciprocal form above spends ~70 of its issue cycles there.
+// This is the compiler's own IEEE expansion of `/` (v_rcp_f32, one Newton step on the reciprocal, quotient estimate,
+// two residual corrections) WITHOUT its v_div_scale / v_div_fmas / v_div_fixup range handling: identical bits whenever
+// that handling would be the identity -- d and 1/d normal, the quotient not subnormal, exponent(n) - exponent(d) < 96,
+// |n| >= 2^-103 -- and for n = +-0 (result +0: the callers want the sign of a zero quotient dropped).  Callers keep
+// d in [2^-48, 2^63] and check the QUOTIENT: |q| >= 2^-55 implies |n| >= 2^-103 and a normal quotient.
+struct RcpF32 { float d, y; };
+__device__ __forceinline__ RcpF32 rcp_f32_newton(float d) {
+  RcpF32 r;
+  r.d = d;
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, y0, 1.0f);
+  r.y = __builtin_fmaf(e, y0, y0);
+  return r;
+}
+__device__ __forceinline__ float div_f32_unscaled(float n, const RcpF32& r) {
+  const float q0 = n * r.y;
+  const float r0 = __builtin_fmaf(-r.d, q0, n);
+  const float q1 = __builtin_fmaf(r0, r.y, q0);
+  const float r1 = __builtin_fmaf(-r.d, q1, n);
+  return __builtin_fmaf(r1, r.y, q1);
+}
+constexpr float kDivF32MinQuotient = 2.7755575615628914e-17f;      // 2^-55
+
 // sqrtf(x) for x in [2^-96, 2^126]: v_sqrt_f32 (1 ulp) + the compiler's own +-1 ulp residual test,
 // without the 2^32 range scaling and the zero / infinity fix-up that the general expansion carries
 __device__ __forceinline__ float sqrt_midrange(float x) {
@@ -135,6 +205,55 @@ __device__ __forceinline__ float sqrt_midrange(float x) {
   return s;
 }
 __device__ __forceinline__ double sqrt_midrange(double x) { return sqrt(x); }
+
+// ---- the dual step's prox of the ROF / TV shapes, straight-line --------------------------------
+// ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked; elem_operation_norm2.hpp:40-88,
+// function_1d.hpp:75-87) on the NC gradient components of VEC pixels:
+//     out_i = pr v_i / ||v||,  pr = min(||v|| - b, 0) + b;   ||v|| = 0 -> 0
+// nv = the squared norms as the reference accumulates them, av = the components.  Norms up to 2^126 take the short
+// correctly rounded forms above (sqrt without range scaling, ONE refined double reciprocal per pixel, the products
+// rounded through fma(n, r, +0) so that zero quotients come out as +0).  A zero norm runs the same code with
+// ||v|| := 2^-48: then pr = RN(RN(2^-48 - b) + b) = 0 for every radius b >= 2^-20, the numerators are +-0 and the
+// results +0, the value the reference writes.  The same holds for non-zero norms below 2^-96 (squares of
+// subnormal-range components): the reference computes pr = 0 and quotients +-0 there as well, so with
+// `tiny_is_zero` (= b >= 2^-20, wave-uniform) they need no separate path; results are equal in value to the
+// reference's, zeros may differ in sign.  Without it such norms, like norms above 2^126 and NaNs, take the general
+// expansions.
+template <class T, int NC, int VEC>
+__device__ __forceinline__ void norm2_leq0_fast(const T (&nv)[VEC], const T (&av)[NC][VEC], T b, bool tiny_is_zero, T (&out)[NC][VEC]) {
+  constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
+  T nmax = 0;
+#pragma unroll
+  for (int j = 0; j < VEC; j++) nmax = nv[j] > nmax ? nv[j] : nmax;
+  bool mid = sizeof(T) == 4 && nmax <= (T)8.507059173023462e37f;
+  if (!tiny_is_zero) {
+    unsigned tmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) tmin = min(tmin, (unsigned)__float_as_int((float)nv[j]) - 1u);     // 0 -> 0xFFFFFFFF: a zero norm is fine
+    mid = mid && tmin >= (unsigned)__float_as_int(kLo) - 1u;
+  }
+  if (__builtin_expect(mid, 1)) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const T nrm = sqrt_midrange(nv[j] > (T)kLo ? nv[j] : (T)kLo);
+      const T pr = min0(nrm - b) + b;
+      const auto r = rcp_refined(nrm);
+#pragma unroll
+      for (int i = 0; i < NC; i++) out[i][j] = mul_rcp_pz(pr * av[i][j], r);
+    }
+  } else {                                                   // general expansions, still branch-free (the fp64 instantiation)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const bool nz = nv[j] > 0;
+      const T nrm = nz ? t_sqrt(nv[j]) : (T)1;
+      const T t = nrm - b;
+      const T pr = (t > (T)0 ? (T)0 : t) + b;
+#pragma unroll
+      for (int i = 0; i < NC; i++) { const T q = pr * av[i][j] / nrm; out[i][j] = nz ? q : (T)0; }
+    }
+  }
+}
+constexpr float kTinyIsZeroRadius = 9.5367431640625e-07f;     // 2^-20
 
 // ---- Function1D* (include/prost/prox/elemop/function_1d.hpp) --------------------------------
 template <class T> __device__ __forceinline__ T f1d_abs(T x0, T tau) {            // :47-60

@@ -795,7 +795,7 @@ void cmd_solver_copy_columns(CMD_ARGS) {
   if (d.single) copy_columns_t<float>(d, dcol, s, scol, nc, ny); else copy_columns_t<double>(d, dcol, s, scol, nc, ny);
 }
 // ---- verification without a full read-back (the 2048 x 2048 x 64 state is ~8 GB per solver) ----
-/// solver_compare(handle_a, handle_b) -> 4 x 2 matrix, rows x, y, x_prev, y_prev: {elements whose bits differ, sum |a - b|},
+/// solver_compare(handle_a, handle_b) -> 4 x 2 matrix, rows x, y, x_prev, y_prev: {elements that differ in value, sum |a - b|},
 /// computed on the device (prost_hip_compare_*)
 template <typename T>
 static prost_value* solver_compare_t(AnyHandle& a, AnyHandle& b) {

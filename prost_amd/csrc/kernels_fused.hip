@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(kBlock) fused_dual2d_kernel(T* __restrict__ y_
   const size_t N = P * LCH;
   const T sigS = sigma * a.Sval;        // sigma_ * S_i          (backend_pdhg.cu:64)
   const T sqS = t_sqrt(a.Sval);
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
   double ra = 0, rb = 0;
 
   T cn[LCH][VEC], co[LCH][VEC];         // current column of x_new / x_old
@@ -236,36 +237,9 @@ __global__ void __launch_bounds__(kBlock) fused_dual2d_kernel(T* __restrict__ y_
           for (int i = 0; i < 2 * LCH; i++) out[i][j] = 0;
         }
       }
-      if (FAST) {
-        constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
-        unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          tmin = min(tmin, (unsigned)__float_as_int((float)nv[FAST ? j : 0]) - 1u);
-          nmax = nv[FAST ? j : 0] > nmax ? nv[FAST ? j : 0] : nmax;
-        }
-        const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
-        if (__builtin_expect(mid, 1)) {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const T nrm = sqrt_midrange(nv[FAST ? j : 0] > (T)kLo ? nv[FAST ? j : 0] : (T)kLo);
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-            const auto r = rcp_refined(nrm);
-#pragma unroll
-            for (int i = 0; i < 2 * LCH; i++) out[i][j] = mul_rcp(pr * av[FAST ? i : 0][FAST ? j : 0], r) + (T)0;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const bool nz = nv[FAST ? j : 0] > 0;
-            const T nrm = nz ? t_sqrt(nv[FAST ? j : 0]) : (T)1;
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-#pragma unroll
-            for (int i = 0; i < 2 * LCH; i++) { const T q = pr * av[FAST ? i : 0][FAST ? j : 0] / nrm; out[i][j] = nz ? q : (T)0; }
-          }
-        }
+      if constexpr (FAST) {
+        // out = pr v / ||v||, pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0: device_math.hpp
+        norm2_leq0_fast<T, 2 * LCH, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
       }
       if (RES) {                                                               // primal_residual_transform :97-120
 #pragma unroll

@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
   constexpr bool kMid = (MODE & 1) != 0;
   typedef Col2<T, VEC, GMASK> Col;
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;
   double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
   // one 32-bit byte offset per lane serves every plane (x, y1, y2, coefficients, outputs): the plane
@@ -156,9 +157,9 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
     const T sigS = P.sigma * a.Sval, theta = P.theta;
     const bool has_next = I || c + 1 < nx;
     const bool counted = (size_t)c >= a.rx0 && (size_t)c < a.rx1;       // residual terms of this column count (column-sharded images)
-    const T bel_n = __shfl_down(xn_c[0], 1, kWave);
-    const T bel_o = __shfl_down(xo_c[0], 1, kWave);
-    T a1v[VEC], a2v[VEC], nv[VEC];
+    const T bel_n = lane_down(xn_c[0]);                         // lane 63: no source, its last row is halo
+    const T bel_o = lane_down(xo_c[0]);
+    T av[2][VEC], nv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
       norm += arg1 * arg1;
       norm += arg2 * arg2;
       if (FAST) {
-        a1v[j] = arg1; a2v[j] = arg2; nv[j] = norm;
+        av[0][j] = arg1; av[1][j] = arg2; nv[j] = norm;
       } else if (norm > 0) {
         norm = t_sqrt(norm);
         const T pr = scaled_prox_u<T, FFN>(a.f_fn, norm, a.f_val, P.uf);
@@ -186,42 +187,12 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
       if (!FAST && kRes && acc && owner && counted && j < nvalid) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
     }
     if (FAST) {
-      // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked):
-      //   out = pr v / ||v||,  pr = min(||v|| - b, 0) + b,  out = 0 for ||v|| = 0.
-      // Straight-line for the VEC pixels with the short correctly rounded sqrt / division forms of
-      // device_math.hpp.  A zero norm takes the same path with ||v|| := 2^-48: both numerators are
-      // pr * (+-0), the quotient +-0, and "+ 0" makes it the +0 the reference writes (q + 0 == q
-      // for every other q).  Norms outside [2^-96, 2^126] (incl. NaN) take the general expansion.
-      constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
-      unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
+      // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked): out = pr v / ||v||,
+      // pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0 -- straight-line for the VEC pixels (device_math.hpp)
+      T out[2][VEC];
+      norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
 #pragma unroll
-      for (int j = 0; j < VEC; j++) {
-        tmin = min(tmin, (unsigned)__float_as_int((float)nv[j]) - 1u);     // 0 -> 0xFFFFFFFF: a zero norm is fine
-        nmax = nv[j] > nmax ? nv[j] : nmax;
-      }
-      const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
-      if (__builtin_expect(mid, 1)) {
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          const T nrm = sqrt_midrange(nv[j] > (T)kLo ? nv[j] : (T)kLo);
-          const T t = nrm - a.f_val[1];
-          const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-          const auto r = rcp_refined(nrm);
-          o1[j] = mul_rcp(pr * a1v[j], r) + (T)0;
-          o2[j] = mul_rcp(pr * a2v[j], r) + (T)0;
-        }
-      } else {                                                   // general expansions, still branch-free (the fp64 path)
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          const bool nz = nv[j] > 0;
-          const T nrm = nz ? t_sqrt(nv[j]) : (T)1;
-          const T t = nrm - a.f_val[1];
-          const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-          const T q1 = pr * a1v[j] / nrm, q2 = pr * a2v[j] / nrm;
-          o1[j] = nz ? q1 : (T)0;
-          o2[j] = nz ? q2 : (T)0;
-        }
-      }
+      for (int j = 0; j < VEC; j++) { o1[j] = out[0][j]; o2[j] = out[1][j]; }
       if (kRes && acc && owner && counted) {
 #pragma unroll
         for (int j = 0; j < VEC; j++) {                          // K x^(k+2), K x^(k+1) again: cheaper than keeping them in registers
@@ -266,12 +237,12 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
     const long ca = c + 2, cb = c + 1;
     if (ca >= 0 && ca < nx) {                                                                     // stage A
       // lane 0 gets no row above: its first row is never needed (the top halo is its LAST row)
-      const T up = __shfl_up(in2.y2[VEC - 1], 1, kWave);
+      const T up = lane_up(in2.y2[VEC - 1]);
       primal(inner, ca, in2.y1, in2.y2, up, in1.y1, in2.x, in2.gc, p1, x1_2, kt_2);
     }
     if (cb >= 0 && cb >= xa - 1 && cb < nx) dual(inner, cb, x1_1, x1_2, in1.x, in2.x, in1.y1, in1.y2, p1, y1a_1, y1b_1, false);   // stage B
     if (cb >= xa && cb < nx) {                                                                    // stage C
-      const T up = __shfl_up(y1b_1[VEC - 1], 1, kWave);          // lane 0: no source, its first row is halo
+      const T up = lane_up(y1b_1[VEC - 1]);                      // lane 0: no source, its first row is halo
       primal(inner, cb, y1a_1, y1b_1, up, y1a_0, x1_1, in1.gc, p2, x2_1, kt_c);
       if (owner && cb < xb) {
         stv_o<T, VEC, true, RAG>(x_out, off_of(cb), x2_1, nvalid);

@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
   const T* q1 = RES ? y_prev + plane : nullptr; const T* q2 = RES ? y_prev + N + plane : nullptr; const T* q3 = RES ? y_prev + 2 * N + plane : nullptr;
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
   const SharedDivisor<T> div_tauT(tau * sqT), div_sigS(sigma * sqS);        // wave-uniform residual divisors: exact quotients through one double reciprocal each
   double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
@@ -219,40 +220,9 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
           for (int i = 0; i < 3; i++) out[i][j] = 0;
         }
       }
-      if (FAST) {
-        // out = pr v / ||v||, pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0: short correctly rounded sqrt and ONE refined
-        // reciprocal for the three components when every norm of the vector lies in [2^-96, 2^126] (a zero norm runs
-        // the same path with ||v|| := 2^-96: numerators pr * (+-0), "+ 0" makes the +0 the reference writes); the
-        // general expansions otherwise.  Same forms as kernels_fused_iter.hip / kernels_fused_iter2.hip.
-        constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
-        unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          tmin = min(tmin, (unsigned)__float_as_int((float)nv[FAST ? j : 0]) - 1u);
-          nmax = nv[FAST ? j : 0] > nmax ? nv[FAST ? j : 0] : nmax;
-        }
-        const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
-        if (__builtin_expect(mid, 1)) {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const T nrm = sqrt_midrange(nv[FAST ? j : 0] > (T)kLo ? nv[FAST ? j : 0] : (T)kLo);
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-            const auto r = rcp_refined(nrm);
-#pragma unroll
-            for (int i = 0; i < 3; i++) out[i][j] = mul_rcp(pr * av[FAST ? i : 0][FAST ? j : 0], r) + (T)0;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const bool nz = nv[FAST ? j : 0] > 0;
-            const T nrm = nz ? t_sqrt(nv[FAST ? j : 0]) : (T)1;
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-#pragma unroll
-            for (int i = 0; i < 3; i++) { const T q = pr * av[FAST ? i : 0][FAST ? j : 0] / nrm; out[i][j] = nz ? q : (T)0; }
-          }
-        }
+      if constexpr (FAST) {
+        // out = pr v / ||v||, pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0: device_math.hpp
+        norm2_leq0_fast<T, 3, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
       }
       if (RES) {                                            // primal_residual_transform (backend_pdhg.cu:97-120)
 #pragma unroll

@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(kWave * WT) fused_iter3d_pw_kernel(T* __restri
   const size_t P = nx * ny, N = P * L, plane = (plane_ok ? l : 0) * P;
   const bool has_above = l + 1 < L;
   const T tauT = tau * a.Tval, sigS = sigma * a.Sval;
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
   const T* y1 = y + plane; const T* y2 = y + N + plane; const T* y3 = y + 2 * N + plane;
   const T* xp = x + plane;
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
@@ -174,36 +175,9 @@ __global__ void __launch_bounds__(kWave * WT) fused_iter3d_pw_kernel(T* __restri
           for (int i = 0; i < 3; i++) out[i][j] = 0;
         }
       }
-      if (FAST) {                                                  // see kernels_fused_iter3d.hip
-        constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96
-        unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          tmin = min(tmin, (unsigned)__float_as_int((float)nv[FAST ? j : 0]) - 1u);
-          nmax = nv[FAST ? j : 0] > nmax ? nv[FAST ? j : 0] : nmax;
-        }
-        const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
-        if (__builtin_expect(mid, 1)) {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const T nrm = sqrt_midrange(nv[FAST ? j : 0] > (T)kLo ? nv[FAST ? j : 0] : (T)kLo);
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-            const auto r = rcp_refined(nrm);
-#pragma unroll
-            for (int i = 0; i < 3; i++) out[i][j] = mul_rcp(pr * av[FAST ? i : 0][FAST ? j : 0], r) + (T)0;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const bool nz = nv[FAST ? j : 0] > 0;
-            const T nrm = nz ? t_sqrt(nv[FAST ? j : 0]) : (T)1;
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-#pragma unroll
-            for (int i = 0; i < 3; i++) { const T qv = pr * av[FAST ? i : 0][FAST ? j : 0] / nrm; out[i][j] = nz ? qv : (T)0; }
-          }
-        }
+      if constexpr (FAST) {
+        // out = pr v / ||v||, pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0: device_math.hpp
+        norm2_leq0_fast<T, 3, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
       }
       const size_t o = plane + c * ny + row0;
       stv_nt<T, VEC>(y_new + o, out[0]);

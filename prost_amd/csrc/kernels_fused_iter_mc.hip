@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
   const T* q1 = RES ? y_prev + plane : nullptr; const T* q2 = RES ? y_prev + N + plane : nullptr;
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
   const SharedDivisor<T> div_tauT(tau * sqT), div_sigS(sigma * sqS);        // wave-uniform residual divisors
   double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
@@ -178,35 +179,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
     if (owner) {
       T out[2][VEC];
       if (FAST) {
-        constexpr float kLo = 1.2621774483536189e-29f;             // 2^-96, see kernels_fused_iter.hip
-        unsigned tmin = 0xFFFFFFFFu; T nmax = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          tmin = min(tmin, (unsigned)__float_as_int((float)nv[j]) - 1u);
-          nmax = nv[j] > nmax ? nv[j] : nmax;
-        }
-        const bool mid = sizeof(T) == 4 && tmin >= (unsigned)__float_as_int(kLo) - 1u && nmax <= (T)8.507059173023462e37f;
-        if (__builtin_expect(mid, 1)) {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const T nrm = sqrt_midrange(nv[j] > (T)kLo ? nv[j] : (T)kLo);
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-            const auto r = rcp_refined(nrm);
-#pragma unroll
-            for (int i = 0; i < 2; i++) out[i][j] = mul_rcp(pr * av[i][j], r) + (T)0;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const bool nz = nv[j] > 0;
-            const T nrm = nz ? t_sqrt(nv[j]) : (T)1;
-            const T t = nrm - a.f_val[1];
-            const T pr = (t > (T)0 ? (T)0 : t) + a.f_val[1];
-#pragma unroll
-            for (int i = 0; i < 2; i++) { const T qv = pr * av[i][j] / nrm; out[i][j] = nz ? qv : (T)0; }
-          }
-        }
+        norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
       } else {
 #pragma unroll
         for (int j = 0; j < VEC; j++) {

@@ -64,17 +64,12 @@ template <class T> struct ZVarF {                                               
   __device__ T operator()(const T* a) const { return (a[0] - a[1]) / (sigma * a[2]) + (1 + theta) * a[3] - theta * a[4]; }
 };
 
-// bitwise comparison of two vectors (test / verification entry: prost_hip_compare_*): a = elements whose bit patterns
-// differ, b = sum |a - b| over the differing elements (+-0 and NaN payloads count as different bits)
-template <class T> struct CompareF;
-template <> struct CompareF<float> {
-  __device__ void operator()(const float* v, double& a, double& b) const {
-    if (__float_as_uint(v[0]) != __float_as_uint(v[1])) { a += 1.0; b += fabs((double)v[0] - (double)v[1]); }
-  }
-};
-template <> struct CompareF<double> {
-  __device__ void operator()(const double* v, double& a, double& b) const {
-    if (__double_as_longlong(v[0]) != __double_as_longlong(v[1])) { a += 1.0; b += fabs(v[0] - v[1]); }
+// comparison of two vectors (test / verification entry: prost_hip_compare_*): a = elements that differ in VALUE (what
+// numpy.array_equal(..., equal_nan=True) counts: +0 == -0, NaN == NaN), b = sum |a - b| over them
+template <class T> struct CompareF {
+  __device__ void operator()(const T* v, double& a, double& b) const {
+    const bool same = v[0] == v[1] || (v[0] != v[0] && v[1] != v[1]);
+    if (!same) { a += 1.0; const double d = fabs((double)v[0] - (double)v[1]); b += d == d ? d : 0.0; }
   }
 };
 

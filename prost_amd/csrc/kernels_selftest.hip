@@ -21,7 +21,7 @@ __device__ __forceinline__ float rnd_float(uint64_t key, int elo, int ehi) {
 }
 
 __global__ void __launch_bounds__(kBlock) selftest_kernel(unsigned long long* bad, uint64_t n, uint64_t seed) {
-  unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+  unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const uint64_t k = seed * 0x100000001b3ull + i * 4;
     // (0) division through the refined double reciprocal: any normal denominator, numerators over the
@@ -32,6 +32,13 @@ __global__ void __launch_bounds__(kBlock) selftest_kernel(unsigned long long* ba
     float nn = sel == 0 ? rnd_float(k + 1, -126, 127) : sel == 1 ? rnd_float(k + 1, -149 + 23, -100) * 1e-10f : sel == 2 ? 0.0f : sel == 3 ? -d : rnd_float(k + 1, -20, 20) * d;
     const float q = mul_rcp(nn, rcp_refined(d)), qr = nn / d;
     b0 += (__float_as_uint(q) != __float_as_uint(qr)) && !(q != q && qr != qr);
+    // the same product rounded through fma(n, r, +0): the quotient of a ZERO numerator becomes +0, everything else is
+    // unchanged (a non-zero quotient that underflows to zero keeps its sign, as n / d does)
+    const float qz = mul_rcp_pz(nn, rcp_refined(d)), qzr = nn == 0.0f ? nn / d + 0.0f : nn / d;
+    b5 += (__float_as_uint(qz) != __float_as_uint(qzr)) && !(qz != qz && qzr != qzr);
+    // min0(t) == (t > 0 ? 0 : t) for every t that is not NaN, signed zeros included
+    const float t0 = sel == 2 ? (i & 8 ? -0.0f : 0.0f) : nn;
+    b6 += __float_as_uint(min0(t0)) != __float_as_uint(t0 > 0.0f ? 0.0f : t0);
     // (4) control: the un-refined single-precision reciprocal is NOT exact -- this count must be > 0
     b4 += __float_as_uint(nn * __builtin_amdgcn_rcpf(d)) != __float_as_uint(qr);
     // (1) sqrt without range scaling on its whole domain [2^-96, 2^126]
@@ -57,15 +64,17 @@ __global__ void __launch_bounds__(kBlock) selftest_kernel(unsigned long long* ba
   if (b2) atomicAdd(bad + 2, b2);
   if (b3) atomicAdd(bad + 3, b3);
   if (b4) atomicAdd(bad + 4, b4);
+  if (b5) atomicAdd(bad + 5, b5);
+  if (b6) atomicAdd(bad + 6, b6);
 }
 
 }  // namespace prost_hip
 
 using namespace prost_hip;
 
-extern "C" int prost_hip_selftest_math(unsigned long long* mismatches5, uint64_t n, uint64_t seed, void* stream) {
-  PH_CHECK(hipMemsetAsync(mismatches5, 0, 5 * sizeof(unsigned long long), as_stream(stream)));
+extern "C" int prost_hip_selftest_math(unsigned long long* mismatches8, uint64_t n, uint64_t seed, void* stream) {
+  PH_CHECK(hipMemsetAsync(mismatches8, 0, 8 * sizeof(unsigned long long), as_stream(stream)));
   if (n == 0) return 0;
-  hipLaunchKernelGGL(selftest_kernel, dim3(4096), dim3(kBlock), 0, as_stream(stream), mismatches5, n, seed);
+  hipLaunchKernelGGL(selftest_kernel, dim3(4096), dim3(kBlock), 0, as_stream(stream), mismatches8, n, seed);
   PH_LAUNCH_END("selftest kernel");
 }

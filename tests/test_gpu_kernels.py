@@ -537,12 +537,13 @@ def test_double_iteration_kernel_special_values(hip, dtype):
 def test_short_division_and_sqrt_forms(hip):
     """device_math.hpp's short correctly rounded forms (used by the two-iterations kernel) against the
     compiler's IEEE expansions on 2^31 pseudo-random cases per form, evaluated on the device."""
-    bad = hip.DeviceArray.zeros(5, np.uint64)
-    total = np.zeros(5, dtype=np.uint64)
+    bad = hip.DeviceArray.zeros(8, np.uint64)
+    total = np.zeros(8, dtype=np.uint64)
     for seed in range(8):
         hip.check(hip.lib().prost_hip_selftest_math(bad.ptr, C.c_uint64(1 << 28), C.c_uint64(seed), None))
         total += bad.to_host()
-    assert total[:4].tolist() == [0, 0, 0, 0], dict(zip(("division", "sqrt", "exact_division", "subtraction"), total.tolist()))
+    names = ("division", "sqrt", "exact_division", "subtraction", "control", "division_plus_zero", "min0", "unused")
+    assert total[:4].tolist() == [0, 0, 0, 0] and total[5:].tolist() == [0, 0, 0], dict(zip(names, total.tolist()))
     assert total[4] > 1000, "control: the harness must see the approximate reciprocal fail"
     print("selftest control mismatches:", int(total[4]), "of", 8 << 28)
 
