@@ -15,6 +15,8 @@ namespace prost_hip {
 template <class T> __device__ __forceinline__ T t_abs(T v) { return v < 0 ? -v : v; }
 template <> __device__ __forceinline__ float t_abs<float>(float v) { return fabsf(v); }
 template <> __device__ __forceinline__ double t_abs<double>(double v) { return fabs(v); }
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float t_sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ double t_sqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float t_pow(float a, float b) { return powf(a, b); }

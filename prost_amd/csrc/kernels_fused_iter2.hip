@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
   // primal_residual_transform (backend_pdhg.cu:97-120) of one pixel, both components
   // the residual divisors sigma sqrt(S), tau sqrt(T) are wave-uniform: one double reciprocal each (device_math.hpp)
   const SharedDivisor<T> div_sigS(p2.sigma * sqS), div_tauT(p2.tau * sqT);
+  const T inv_sigS = (T)1 / (p2.sigma * sqS), inv_tauT = (T)1 / (p2.tau * sqT);
   auto residual_terms = [&](int j, T y1o, T y2o, T o1, T o2, T kx1, T kx2, T kp1, T kp2, const IterParams<T>& P) {
     (void)j;
     const T z1 = div_sigS.div(y1o - o1) + sqS * ((1 + P.theta) * kx1 - P.theta * kp1);
@@ -194,17 +195,24 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
 #pragma unroll
       for (int j = 0; j < VEC; j++) { o1[j] = out[0][j]; o2[j] = out[1][j]; }
       if (kRes && acc && owner && counted) {
+        // primal_residual_transform (backend_pdhg.cu:97-120): z_hat = (y_old - y_new) / (sigma sqrt(S)) + sqrt(S) ((1 + theta) K x_new
+        // - theta K x_old).  With the prox argument above, arg = y_old + sigma S ((1 + theta) K x_new - theta K x_old), that is
+        // (arg - y_new) / (sigma sqrt(S)): one subtraction and one product with the wave-uniform reciprocal.  The residual SUMS are
+        // compared with a relative tolerance (they steer step sizes and the stopping test; the reference reduces them in T in an
+        // unspecified order), so this block -- unlike the iterates -- uses plain fp32 with fused multiply-adds, summed per column
+        // in T and across columns in double.
+        T spd = 0, spv = 0;
 #pragma unroll
-        for (int j = 0; j < VEC; j++) {                          // K x^(k+2), K x^(k+1) again: cheaper than keeping them in registers
+        for (int j = 0; j < VEC; j++) {
           const long row = row0 + j;
           const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
-          const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
-          const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+          const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;     // K x^(k+2) again: cheaper than keeping it in registers
           const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
-          const T kp1 = has_next ? xo_n[j] - xo_c[j] : (T)0;
-          const T kp2 = (I || row < ny - 1) ? below_o - xo_c[j] : (T)0;
-          if (j < nvalid) residual_terms(j, y1c[j], y2c[j], o1[j], o2[j], kx1, kx2, kp1, kp2, P);
+          const T z1 = (av[0][j] - o1[j]) * inv_sigS, z2 = (av[1][j] - o2[j]) * inv_sigS;
+          const T d1 = t_fma(-sqS, kx1, z1), d2 = t_fma(-sqS, kx2, z2);
+          if (j < nvalid) { spd = t_fma(d1, d1, spd); spd = t_fma(d2, d2, spd); spv = t_fma(z1, z1, spv); spv = t_fma(z2, z2, spv); }
         }
+        r_pd += (double)spd; r_pv += (double)spv;
       }
     }
   };
@@ -248,11 +256,22 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
         stv_o<T, VEC, true, RAG>(x_out, off_of(cb), x2_1, nvalid);
         if (kMid) stv_o<T, VEC, true, RAG>(x_mid, off_of(cb), x1_1, nvalid);
         if (kRes && (size_t)cb >= a.rx0 && (size_t)cb < a.rx1) {   // dual_residual_transform (backend_pdhg.cu:73-94)
+          if (FAST) {                             // tolerance-compared sums: plain fp32 with fused multiply-adds (see dual)
+            T sdd = 0, sdv = 0;
 #pragma unroll
-          for (int j = 0; j < VEC; j++) {
-            const T w_hat = div_tauT.div(x1_1[j] - x2_1[j]) - sqT * kt_1[j];
-            const T diff = w_hat + sqT * kt_c[j];
-            if (j < nvalid) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
+            for (int j = 0; j < VEC; j++) {
+              const T w_hat = t_fma(-sqT, kt_1[j], (x1_1[j] - x2_1[j]) * inv_tauT);
+              const T diff = t_fma(sqT, kt_c[j], w_hat);
+              if (j < nvalid) { sdd = t_fma(diff, diff, sdd); sdv = t_fma(w_hat, w_hat, sdv); }
+            }
+            r_dd += (double)sdd; r_dv += (double)sdv;
+          } else {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+              const T w_hat = div_tauT.div(x1_1[j] - x2_1[j]) - sqT * kt_1[j];
+              const T diff = w_hat + sqT * kt_c[j];
+              if (j < nvalid) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
+            }
           }
         }
       }

@@ -492,7 +492,13 @@ def test_double_iteration_kernel_equals_two_single_launches(hip, dtype, shape, f
                 if mid:
                     assert np.array_equal(xm.to_host(), x1r) and np.array_equal(ym.to_host(), y1r), (cols, mid, res)
                 if res:
-                    assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
+                    # the straight-line fp32 instances form the residual TERMS with fused multiply-adds (tolerance-compared sums,
+                    # kernels_fused_iter2.hip); every other instance evaluates the reference's expressions and only the order differs
+                    # (a sum that is pure round-off -- 1e-15 beside sums of order 1 -- is compared on the scale of the largest one)
+                    fast = fns[1] == "ind_leq0"
+                    eps = 1e-9 if dtype == np.float32 else 1e-15
+                    assert np.allclose(r4.to_host(), res_ref, rtol=2e-6 if fast and dtype == np.float32 else 1e-11,
+                                       atol=eps * np.abs(res_ref).max() if fast else 1e-300), (cols, r4.to_host(), res_ref)
                 for d_ in (x2, y2, xm, ym, r4):
                     d_.free()
         for d_ in (x1, y1, x_ref, y_ref, xs, ys, r4s):

@@ -22,9 +22,14 @@ for i, (g, fv) in enumerate(zip([1, 0, 10, 0, 0, 0, 0], [1, 1, 1, 0, 0, 0, 0])):
     d.g_coeff_val[i] = g; d.f_coeff_val[i] = fv
 d.g_coeff_ptr[1] = f.ptr.value
 d.T_val, d.S_val = 0.25, 0.5
+r4 = hip.DeviceArray.zeros(4, np.float64)
+ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
 for i in range(reps):
     a, b = i % 2, (i + 1) % 2
-    if mode == "iter2":
+    if mode == "iter2res":
+        t2 = (C.c_double * 2)(0.3, 0.29); s2 = (C.c_double * 2)(1.0, 1.03); th2 = (C.c_double * 2)(0.9, 0.91)
+        hip.check(hip.fn("fused_iteration2", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, None, t2, s2, th2, cols, r4.ptr, ws.ptr, None))
+    elif mode == "iter2":
         t2 = (C.c_double * 2)(0.3, 0.29); s2 = (C.c_double * 2)(1.0, 1.03); th2 = (C.c_double * 2)(0.9, 0.91)
         hip.check(hip.fn("fused_iteration2", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, None, t2, s2, th2, cols, None, None, None))
     elif mode == "iter":
