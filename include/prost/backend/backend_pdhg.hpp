@@ -122,8 +122,13 @@ class BackendPDHG : public Backend<T> {
   enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelPairMid, kKernelPairRes, kKernelPairMidRes, kKernelKinds };
   bool BeginSample(int kind);
   void EndSample(bool sampled);
-  std::vector<void*> ev_;          // pool, two events per sample
-  std::vector<int> ev_kind_;       // kind of sample i (events 2i, 2i+1)
+  static constexpr size_t kNoEvent = ~(size_t)0;
+  struct Sample { int kind; size_t start, end; };   // indices into ev_
+  size_t NewEvent();               // records the next event of the pool on the solver's stream
+  std::vector<void*> ev_;          // event pool
+  size_t ev_used_ = 0;
+  size_t last_end_ = kNoEvent;     // end event of the previous launch while nothing else has been enqueued since
+  std::vector<Sample> samples_;
   size_t launches_[kKernelKinds] = {0};
 };
 

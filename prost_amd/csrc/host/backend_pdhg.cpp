@@ -157,7 +157,7 @@ void BackendPDHG<T>::Release() {
   if (ev_res_ready_) { prost_hip_event_destroy(ev_res_ready_); ev_res_ready_ = nullptr; }
   if (ev_res_done_) { prost_hip_event_destroy(ev_res_done_); ev_res_done_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
-  ev_.clear(); ev_kind_.clear();
+  ev_.clear(); samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;
   y_spare_.clear(); x_spare_.clear();
   x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
 }
@@ -188,20 +188,29 @@ int BackendPDHG<T>::PerformIterations(int budget) {
 }
 
 template <typename T>
+size_t BackendPDHG<T>::NewEvent() {
+  if (ev_used_ == ev_.size()) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
+  CheckHip(prost_hip_event_record(ev_[ev_used_], CurrentStream()), "event_record");
+  return ev_used_++;
+}
+
+/// Event pair around a launch.  When EVERY launch is sampled (short runs) consecutive launches share their boundary
+/// event -- a marker costs about 4 us of launch pipelining, so this halves the price; the chain is broken wherever
+/// something else sits between two launches (fold / all-reduce after a residual launch, a host wait, a rebuild launch).
+template <typename T>
 bool BackendPDHG<T>::BeginSample(int kind) {
   if (!this->time_kernels_) return false;
   // one launch in `sample_every_`: the markers must not serialise the stream of a long run
-  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) return false;
-  const size_t i = 2 * ev_kind_.size();
-  while (ev_.size() < i + 2) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
-  ev_kind_.push_back(kind);
-  CheckHip(prost_hip_event_record(ev_[i], CurrentStream()), "event_record");
+  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) { last_end_ = kNoEvent; return false; }
+  const size_t start = (this->sample_every_ == 1 && last_end_ != kNoEvent) ? last_end_ : NewEvent();
+  samples_.push_back({kind, start, kNoEvent});
   return true;
 }
 
 template <typename T>
 void BackendPDHG<T>::EndSample(bool sampled) {
-  if (sampled) CheckHip(prost_hip_event_record(ev_[2 * ev_kind_.size() - 1], CurrentStream()), "event_record");
+  if (!sampled) return;
+  samples_.back().end = last_end_ = NewEvent();
 }
 
 template <typename T>
@@ -239,6 +248,7 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
 template <typename T>
 void BackendPDHG<T>::RebuildPrevious() {
   if (!prev_stale_) return;
+  last_end_ = kNoEvent;
   CheckHip(Api<T>::fused_iteration(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
                                    (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration");
   x_prev_.swap(x_spare_);
@@ -389,6 +399,7 @@ double* BackendPDHG<T>::res_target() {
 template <typename T>
 void BackendPDHG<T>::FinishResiduals() {
   void* s = CurrentStream();
+  last_end_ = kNoEvent;            // kernel timing: the fold (and what follows here) sits between this launch and the next
   // without a communicator the reduction kernels wrote the four sums straight into the pinned host buffer
   // (device-visible): no D2H copy, a stream synchronisation is all that is needed before reading them
   if (this->comm_) {
@@ -504,14 +515,15 @@ size_t BackendPDHG<T>::gpu_mem_amount() const {
 template <typename T>
 void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& out) {
   out.clear();
-  if (ev_kind_.empty()) return;
-  CheckHip(prost_hip_event_synchronize(ev_[2 * ev_kind_.size() - 1]), "event_synchronize");
+  if (samples_.empty()) return;
+  CheckHip(prost_hip_event_synchronize(ev_[ev_used_ - 1]), "event_synchronize");
   double sum[kKernelKinds] = {0};
   size_t cnt[kKernelKinds] = {0};
-  for (size_t i = 0; i < ev_kind_.size(); i++) {
+  for (const Sample& sm : samples_) {
+    if (sm.end == kNoEvent) continue;
     float ms = 0;
-    CheckHip(prost_hip_event_elapsed_ms(ev_[2 * i], ev_[2 * i + 1], &ms), "event_elapsed");
-    sum[ev_kind_[i]] += ms; cnt[ev_kind_[i]]++;
+    CheckHip(prost_hip_event_elapsed_ms(ev_[sm.start], ev_[sm.end], &ms), "event_elapsed");
+    sum[sm.kind] += ms; cnt[sm.kind]++;
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
@@ -523,7 +535,7 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
     const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes) : 0;
     out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k], cols});
   }
-  ev_kind_.clear();
+  samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;
   for (int k = 0; k < kKernelKinds; k++) launches_[k] = 0;
 }
 
