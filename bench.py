@@ -172,6 +172,10 @@ def main():
     # PROST_BENCH_FORCE_DIST=1 runs the multi-rank code path (torch.distributed + the native RCCL communicator +
     # residual all-reduce) even with one rank: the only way to exercise it on a 1-GPU box
     multi = world > 1 or os.environ.get("PROST_BENCH_FORCE_DIST", "0") == "1"
+    # PROST_BENCH_TRANSPORT=host: every rank on GPU 0, gloo between the processes, the native communicator on the
+    # host-callback transport (RCCL refuses two ranks on one device) -- runs the N > 1 code of this file and of the
+    # solver on a one-GPU box (tests/test_gpu_multirank.py); not a performance configuration
+    host_transport = multi and os.environ.get("PROST_BENCH_TRANSPORT", "rccl") == "host"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
@@ -182,15 +186,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the prost hot path has no CPU fallback")
+    if host_transport:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if multi:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if host_transport:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     prost.set_gpu(local_rank)
     prost.set_precision("single")
-    if multi:
+    if host_transport:
+        prost.comm_init_host(lambda a: dist.all_reduce(torch.from_numpy(a)), world)
+    elif multi:
         # RCCL communicator owned by the native solver: rank 0 creates the id, torch broadcasts it
         ident = torch.zeros(128, dtype=torch.float64, device="cuda")
         if rank == 0:
@@ -244,7 +255,7 @@ def main():
     # the timed region proper: the K iterations between the two stream synchronisations INSIDE the native command
     # (info["ms"]); `elapsed` additionally holds the Python -> C marshalling of the call on both sides (~35 us, 3 % of a
     # 20-step run) and is reported as wall_ms_python_side
-    t = torch.tensor([info["ms"] * 1e-3, elapsed_iterate, elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([info["ms"] * 1e-3, elapsed_iterate, elapsed], dtype=torch.float64, device="cpu" if host_transport else "cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, elapsed_iterate, elapsed_py = float(t[0].item()), float(t[1].item()), float(t[2].item())
@@ -270,7 +281,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), "
                                    "PDHG alg2, residual_iter=10, lambda=10; one independent problem per GPU" % (n, n),
-                       "path": path, "problems": world, "residual_allreduce": "rccl" if multi else "none",
+                       "path": path, "problems": world, "residual_allreduce": "host-callback (gloo)" if host_transport else "rccl" if multi else "none",
                        "timed_loop": "Solver::IterateChecked = the loop of prost.solve (stopping test after every observable iteration; "
                                      "tolerances 0, so it never fires)"},
             "iterate_only_it_per_s": world * args.steps / elapsed_iterate,

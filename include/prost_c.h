@@ -78,6 +78,12 @@ int prost_command(const char* cmd, int nlhs, prost_value** plhs, int nrhs, const
 const char* prost_last_error(void);
 /* user-interrupt hook of solve_problem (the Ctrl-C poll of the MEX gateway) */
 void prost_set_stop_callback(prost_stop_cb fn, void* user);
+/* Multi-rank runs without RCCL (several ranks on one GPU, or a host-side fabric): makes `fn(user, values, count)` -- an
+ * in-place sum over the ranks of `count` doubles in pinned host memory -- the communicator of the solvers created
+ * afterwards, exactly as comm_init does with an RCCL communicator (prost_hip_comm_create_host).  Returns 0 / 1
+ * (prost_last_error); undone by the comm_destroy command. */
+typedef void (*prost_allreduce_cb)(void* user, double* values, size_t count);
+int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size);
 
 /*
  * Command reference (arguments in prhs order, results in plhs order):

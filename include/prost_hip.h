@@ -491,6 +491,14 @@ int prost_hip_normest_stage_f64(int stage, const prost_hip_normest_desc* d, void
 int prost_hip_comm_unique_id(void* id128);
 int prost_hip_comm_create(void** comm, const void* id128, int rank, int world_size);
 int prost_hip_comm_destroy(void* comm);
+/* Host-callback transport: a communicator whose all-reduce is `fn(user, values, count)` -- sum `values` (pinned host
+ * memory, in place) over the ranks, e.g. with gloo or MPI on the host.  prost_hip_allreduce_sum_f64 on it enqueues a
+ * D2H copy, the function (hipLaunchHostFunc: it runs on a runtime thread and must not call HIP) and the H2D copy on the
+ * given stream, i.e. it keeps the enqueue-and-return contract of the RCCL call, so the callers' stream / event logic is
+ * the same on both.  For running several ranks on ONE GPU (RCCL refuses duplicate devices): tests of the N > 1 host
+ * logic on a single-GPU box.  The reference has no multi-process path at all (prost.cpp:299-303: set_gpu). */
+typedef void (*prost_hip_host_allreduce_fn)(void* user, double* values, size_t count);
+int prost_hip_comm_create_host(void** comm, prost_hip_host_allreduce_fn fn, void* user);
 /* in-place sum all-reduce of `count` DEVICE doubles (the 4 residual sums) on `stream` */
 int prost_hip_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream);
 /* point-to-point transfers of `bytes` bytes of device memory with rank `peer` of the communicator (RCCL

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libprost.so")
 
 INTERM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.c_size_t)
 STOP_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
 
 (VALUE_EMPTY, VALUE_MATRIX, VALUE_STRING, VALUE_CELL, VALUE_STRUCT, VALUE_SPARSE, VALUE_CALLBACK) = range(7)
 
@@ -71,6 +72,7 @@ def lib():
         L.prost_last_error.restype = C.c_char_p
         L.prost_set_stop_callback.argtypes = [STOP_CB, vp]
         L.prost_set_stop_callback.restype = None
+        L.prost_comm_init_host.argtypes = [ALLREDUCE_CB, vp, C.c_int]
         _lib = L
     return _lib
 
@@ -380,6 +382,21 @@ def comm_unique_id():
 
 def comm_init(unique_id, rank, world):
     command("comm_init", [np.asarray(unique_id, dtype=np.float64).reshape(1, -1), rank, world])
+
+
+_host_allreduce_keep = []
+
+
+def comm_init_host(allreduce, world):
+    """Communicator with a host-side all-reduce: `allreduce(a)` sums the float64 numpy array `a` (a view of pinned host
+    memory) over the ranks IN PLACE, e.g. `dist.all_reduce(torch.from_numpy(a))` on a gloo group.  It is called from a
+    runtime thread, in stream order, wherever an RCCL all-reduce would run.  For several ranks on one GPU."""
+    def _cb(user, ptr, count, fn=allreduce):
+        fn(np.ctypeslib.as_array(ptr, (count,)))
+    cb = ALLREDUCE_CB(_cb)
+    _host_allreduce_keep.append(cb)
+    if lib().prost_comm_init_host(cb, None, int(world)) != 0:
+        raise ProstError(lib().prost_last_error().decode())
 
 
 def comm_destroy():

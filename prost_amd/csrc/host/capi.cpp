@@ -898,6 +898,17 @@ void cmd_set_quirks(CMD_ARGS) {
   if (prost_value_field(prhs[0], "dual_negate_float")) DualLinearOperator<double>::SetReferenceNegateQuirk(GetScalarFromField(prhs[0], "dual_negate_float") > 0);
 }
 
+}  // namespace
+extern "C" int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size) {
+  try {
+    select_device();
+    if (g_comm) { prost_hip_comm_destroy(g_comm); g_comm = nullptr; }
+    CheckHip(prost_hip_comm_create_host(&g_comm, fn, user), "comm_create_host");
+    g_comm_world = world_size;
+    return 0;
+  } catch (const std::exception& e) { g_error = e.what(); return 1; }
+}
+namespace {
 typedef void (*cmd_fn)(CMD_ARGS);
 const std::map<std::string, cmd_fn>& cmd_reg() {
   static const std::map<std::string, cmd_fn> reg = {

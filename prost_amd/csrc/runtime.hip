@@ -78,11 +78,29 @@ int prost_hip_graph_launch(void* exec, void* s) { PH_CHECK(hipGraphLaunch((hipGr
 int prost_hip_graph_destroy(void* exec) { if (exec) PH_CHECK(hipGraphExecDestroy((hipGraphExec_t)exec)); return 0; }
 int prost_hip_check_last_error(void) { PH_CHECK(hipGetLastError()); return 0; }
 
-// ---- RCCL ----
+// ---- communicators: RCCL over xGMI, or a host-callback transport ----
+// A communicator handle is a Comm*: either an RCCL communicator (one rank per GPU, the production path) or a HOST
+// transport whose all-reduce is a caller-supplied function working on pinned host memory (gloo / MPI on the host).  The
+// host transport keeps the stream semantics of the RCCL call -- it is ENQUEUED (D2H copy, host function, H2D copy) and
+// ordered by the stream like any other work -- so the callers' stream / event choreography runs unchanged; it exists to
+// run the multi-rank logic where RCCL cannot (several ranks on ONE GPU: tests on a single-GPU box).
+struct Comm {
+  ncclComm_t nccl = nullptr;
+  prost_hip_host_allreduce_fn host_fn = nullptr;
+  void* host_user = nullptr;
+  double* staging = nullptr;      // pinned, kHostStaging doubles
+  size_t count = 0;               // doubles of the call in flight (read by the host function)
+};
+constexpr size_t kHostStaging = 64;
+static void host_allreduce_trampoline(void* p) {
+  Comm* c = static_cast<Comm*>(p);
+  c->host_fn(c->host_user, c->staging, c->count);
+}
 static int nccl_fail(ncclResult_t r, const char* what) {
   set_error(std::string(what) + ": " + ncclGetErrorString(r));
   return 1000 + (int)r;
 }
+static int host_only(const char* what) { set_error(std::string(what) + ": not available on a host-callback communicator"); return 1; }
 int prost_hip_comm_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   ncclUniqueId id;
@@ -97,14 +115,28 @@ int prost_hip_comm_create(void** comm, const void* id128, int rank, int world) {
   ncclComm_t c;
   ncclResult_t r = ncclCommInitRank(&c, world, id, rank);
   if (r != ncclSuccess) return nccl_fail(r, "ncclCommInitRank");
-  *comm = c;
+  Comm* h = new Comm;
+  h->nccl = c;
+  *comm = h;
+  return 0;
+}
+int prost_hip_comm_create_host(void** comm, prost_hip_host_allreduce_fn fn, void* user) {
+  if (!fn) { set_error("prost_hip_comm_create_host: all-reduce function required"); return 1; }
+  Comm* h = new Comm;
+  h->host_fn = fn; h->host_user = user;
+  const hipError_t e = hipHostMalloc((void**)&h->staging, kHostStaging * sizeof(double), hipHostMallocDefault);
+  if (e != hipSuccess) { delete h; return fail(e, "hipHostMalloc"); }
+  *comm = h;
   return 0;
 }
 int prost_hip_comm_destroy(void* comm) {
   if (!comm) return 0;
-  ncclResult_t r = ncclCommDestroy((ncclComm_t)comm);
-  if (r != ncclSuccess) return nccl_fail(r, "ncclCommDestroy");
-  return 0;
+  Comm* h = static_cast<Comm*>(comm);
+  int rc = 0;
+  if (h->nccl) { ncclResult_t r = ncclCommDestroy(h->nccl); if (r != ncclSuccess) rc = nccl_fail(r, "ncclCommDestroy"); }
+  if (h->staging) (void)hipHostFree(h->staging);
+  delete h;
+  return rc;
 }
 // point-to-point over xGMI (halo columns of column-sharded images); calls between group_start / group_end
 // are issued as one RCCL group, so a rank can send to and receive from both neighbours without deadlock
@@ -119,17 +151,31 @@ int prost_hip_comm_group_end(void) {
   return 0;
 }
 int prost_hip_comm_send(void* comm, const void* buf, size_t bytes, int peer, void* stream) {
-  ncclResult_t r = ncclSend(buf, bytes, ncclChar, peer, (ncclComm_t)comm, as_stream(stream));
+  if (!static_cast<Comm*>(comm)->nccl) return host_only("prost_hip_comm_send");
+  ncclResult_t r = ncclSend(buf, bytes, ncclChar, peer, static_cast<Comm*>(comm)->nccl, as_stream(stream));
   if (r != ncclSuccess) return nccl_fail(r, "ncclSend");
   return 0;
 }
 int prost_hip_comm_recv(void* comm, void* buf, size_t bytes, int peer, void* stream) {
-  ncclResult_t r = ncclRecv(buf, bytes, ncclChar, peer, (ncclComm_t)comm, as_stream(stream));
+  if (!static_cast<Comm*>(comm)->nccl) return host_only("prost_hip_comm_recv");
+  ncclResult_t r = ncclRecv(buf, bytes, ncclChar, peer, static_cast<Comm*>(comm)->nccl, as_stream(stream));
   if (r != ncclSuccess) return nccl_fail(r, "ncclRecv");
   return 0;
 }
 int prost_hip_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream) {
-  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, (ncclComm_t)comm, as_stream(stream));
+  Comm* h = static_cast<Comm*>(comm);
+  if (!h->nccl) {
+    // host transport: the same enqueue-and-return contract.  One call in flight per communicator (the staging buffer and
+    // `count` belong to it): callers serialise their all-reduces by stream order / events, as they must for RCCL.
+    if (count > kHostStaging) { set_error("prost_hip_allreduce_sum_f64: host transport moves at most 64 values"); return 1; }
+    hipStream_t s = as_stream(stream);
+    h->count = count;
+    PH_CHECK(hipMemcpyAsync(h->staging, buf, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    PH_CHECK(hipLaunchHostFunc(s, host_allreduce_trampoline, h));
+    PH_CHECK(hipMemcpyAsync(buf, h->staging, count * sizeof(double), hipMemcpyHostToDevice, s));
+    return 0;
+  }
+  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, h->nccl, as_stream(stream));
   if (r != ncclSuccess) return nccl_fail(r, "ncclAllReduce");
   return 0;
 }

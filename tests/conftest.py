@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A clean process factory, started BEFORE anything initialises the GPU: the multi-rank GPU tests get their worker
+    # processes from this fork server (a process that has touched the GPU must not fork / exec others on the GPU boxes).
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    mp.get_context("forkserver")
+    forkserver.ensure_running()
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,80 @@
+"""Worker processes of the multi-rank GPU tests (tests/test_gpu_multirank.py).
+
+They are started by the fork server that tests/conftest.py launches BEFORE anything initialises the GPU: a process
+that has touched the GPU must not fork / exec others on the GPU boxes.  Every worker is one rank: its own process, its
+own HIP context on GPU 0, gloo between the ranks, and the native solver's communicator on the host-callback transport
+(prost_comm_init_host) -- the N > 1 logic of BackendPDHG (global sizes, side-stream all-reduce, buffer hand-over,
+identical step-size decisions) with two real ranks on a one-GPU box.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+
+def _init(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return torch, dist
+
+
+def pdhg_rank(rank, world, port, step, precision, out):
+    """one rank of a batch of independent ROF problems (seeds 42 + rank) with the global residual all-reduce:
+    product (host-callback communicator) next to the oracle (same gloo group), iterate / state and a full solve"""
+    try:
+        torch, dist = _init(rank, world, port)
+        import oracle
+        import prost_amd as prost
+        from prost_amd import distributed, synthetic
+        dtype = np.float32 if precision == "single" else np.float64
+        prost.set_gpu(0)
+        prost.set_precision(precision)
+        calls = []
+
+        def allreduce(a):                      # runs on a HIP runtime thread, in stream order
+            calls.append(a.copy())
+            dist.all_reduce(torch.from_numpy(a))
+
+        prost.comm_init_host(allreduce, world)
+        prob, u, q, f = synthetic.rof_problem(64, 48, seed=42 + rank)
+        b = prost.backend.pdhg(stepsize=step, residual_iter=2, alg2_gamma=0.5)
+        o = prost.options(max_iters=60, num_cback_calls=0, verbose=False)
+        s = prost.Solver(prob, b, o)
+        s.iterate(37)                          # odd count: ends between residual iterations
+        mid = s.state(vectors=False)
+        s.iterate(23)
+        st = s.state()
+        s.destroy()
+        n_calls = len(calls)
+        # the oracle under the same all-reduce (tests/test_distributed_cpu.py)
+        prob.finalize()
+        os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, dtype)
+        os_.set_allreduce(distributed.allreduce_hook(dist), world * prob.nrows, world * prob.ncols)
+        os_.initialize()
+        os_.iterate(60)
+        ost, osc = os_.state(), os_.scalars()
+        same = {v: bool(np.array_equal(st[v], ost[v])) for v in "xyzw"}
+        # a complete solve that stops on the GLOBAL criterion: same iteration count on every rank
+        o2 = prost.options(max_iters=4000, num_cback_calls=0, verbose=False, tol_rel_primal=2e-3, tol_rel_dual=2e-3, tol_abs_primal=2e-3, tol_abs_dual=2e-3)
+        res = prost.solve(prob, b, o2)
+        prost.comm_destroy()
+        out.put(dict(rank=rank, same=same, scal={k: float(st[k]) for k in ("tau", "sigma", "theta", "primal_res", "dual_res", "eps_primal", "eps_dual", "primal_var_norm", "dual_var_norm")},
+                     oscal={k: float(osc[k]) for k in ("tau", "sigma", "theta", "primal_res", "dual_res", "eps_primal", "eps_dual", "primal_var_norm", "dual_var_norm")},
+                     mid_iteration=float(mid["iteration"]), n_calls=n_calls, path=st["path"], xsum=float(st["x"].sum()),
+                     solve_iters=int(res["iters"]), solve_result=res["result"], nrows=prob.nrows, ncols=prob.ncols))
+        dist.destroy_process_group()
+    except Exception as e:                      # never leave the parent waiting
+        import traceback
+        out.put(dict(rank=rank, error=traceback.format_exc() + repr(e)))
+
+
+def run_command(cmd, env, cwd, out):
+    """runs a launcher (torchrun) from a process that has never touched the GPU"""
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run(cmd, env=e, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    out.put((p.returncode, p.stdout[-6000:], p.stderr[-3000:]))
