@@ -116,3 +116,24 @@ def test_large_results_are_views_that_keep_their_value_alive():
     gc.collect()
     small = _capi.from_value(_capi.to_value(np.ones(4), keep))
     assert small.flags.owndata
+
+
+def test_mex_gateway_source_compiles_against_the_mex_api_declarations():
+    """mex/prost_mex.cpp (the MATLAB gateway over libprost.so; reference matlab/+prost/private/prost.cpp:305-347) cannot be
+    linked here -- no MATLAB, no mex.h -- but it must stay a compilable translation unit: g++ -fsyntax-only against
+    tests/mex_decl.h (declarations of the MEX API functions it calls) and the real include/prost_c.h."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "mex", "prost_mex.cpp")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-include", os.path.join(root, "tests", "mex_decl.h"),
+                        "-I", os.path.join(root, "include"), src], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(src).read()
+    # both directions of the marshalling and the three callbacks of the reference gateway are defined, not just declared
+    for needle in ("prost_value* convert(const mxArray* a) {", "mxArray* back(const prost_value* v) {", "int stop_cb(void*) {",
+                   "int interm_cb(void* user", "void mexFunction(int nlhs, mxArray** plhs, int nrhs, const mxArray** prhs) {"):
+        assert needle in text, needle
+    # the declarations header stays declarations: no function bodies
+    decl = open(os.path.join(root, "tests", "mex_decl.h")).read()
+    assert "{" not in decl.split('extern "C" {', 1)[1].rsplit("}", 1)[0]
