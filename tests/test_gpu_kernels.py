@@ -276,6 +276,50 @@ def test_cgls_stages_at_the_c_abi(hip, dtype, m, n, tol, zero_start):
     assert err <= rtol, (err, res.iterations)
 
 
+def test_cgls_converges_to_the_damped_least_squares_solution(hip):
+    """What cgls::Solve (cgls.hpp:222-371) computes on GemvPrecondK (backend_admm.cu:199-272) is the minimiser of
+    |A' x - b|^2 + shift |x|^2 with A' = sqrt(Sigma) A sqrt(Tau): the device-resident CG (prost_hip_cgls_stage_*), run to a tight
+    tolerance in fp64, must reach the solution scipy computes -- lsqr with damp = sqrt(shift) and the normal equations solved
+    directly.  Pins the stage kernels to the mathematical definition where no reference vector exists."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    dtype = np.float64
+    rng = np.random.default_rng(33)
+    L_ = hip.lib()
+    m, n, shift = 400, 260, 1.0
+    A = sp.random(m, n, density=0.04, random_state=9, format="csr", dtype=np.float64); A.sort_indices()
+    At = A.T.tocsr(); At.sort_indices()
+    sig = rng.uniform(0.3, 2, m); tau = rng.uniform(0.3, 2, n)
+    b = rng.standard_normal(m)
+    Abar = sp.diags(np.sqrt(sig)) @ A @ sp.diags(np.sqrt(tau))
+    x_direct = spla.spsolve((Abar.T @ Abar + shift * sp.identity(n)).tocsc(), Abar.T @ b)
+    x_lsqr = spla.lsqr(Abar, b, damp=np.sqrt(shift), atol=1e-14, btol=1e-14, iter_lim=5000)[0]
+    assert np.allclose(x_lsqr, x_direct, rtol=1e-8, atol=1e-10)
+    dev_ = lambda a: hip.DeviceArray.from_host(np.ascontiguousarray(a))
+    dA = [dev_(A.data), dev_(A.indptr.astype(np.int32)), dev_(A.indices.astype(np.int32))]
+    dAt = [dev_(At.data), dev_(At.indptr.astype(np.int32)), dev_(At.indices.astype(np.int32))]
+    vec = {k: hip.DeviceArray.zeros(sz, dtype) for k, sz in (("p", n), ("q", m), ("r", m), ("s", n), ("t", max(m, n)))}
+    db, dx, dsig, dtau = dev_(b), dev_(np.zeros(n)), dev_(sig), dev_(tau)
+    state = hip.DeviceArray.zeros(L_.prost_hip_cgls_state_bytes() // 8 + 1, np.float64)
+    ws = hip.DeviceArray(L_.prost_hip_cgls_workspace_bytes() // 8, np.float64)
+    d = hip.CglsDesc()
+    d.state, d.workspace, d.b, d.x = state.ptr.value, ws.ptr.value, db.ptr.value, dx.ptr.value
+    d.p, d.q, d.r, d.s, d.t = (vec[k].ptr.value for k in "pqrst")
+    d.sigma, d.tau, d.m, d.n, d.shift, d.tol, d.host_done, d.epoch = dsig.ptr.value, dtau.ptr.value, m, n, shift, 1e-13, None, 1
+    stage = lambda which: hip.check(hip.fn("cgls_stage", dtype)(which, C.byref(d), None))
+    K = lambda res, rhs, acc: hip.check(hip.fn("csr_spmv_acc" if acc else "csr_spmv", dtype)(res.ptr, rhs.ptr, hip.sz(m), hip.sz(A.nnz), dA[0].ptr, dA[1].ptr, dA[2].ptr, None))
+    Kt = lambda res, rhs: hip.check(hip.fn("csr_spmv_acc", dtype)(res.ptr, rhs.ptr, hip.sz(n), hip.sz(A.nnz), dAt[0].ptr, dAt[1].ptr, dAt[2].ptr, None))
+    INIT_X, INIT_R, INIT_R2, INIT_S, STEP_Q, STEP_XR, STEP_S, STEP_P = range(8)
+    stage(INIT_X); stage(INIT_R); K(vec["r"], vec["t"], True); stage(INIT_R2); Kt(vec["s"], vec["t"]); stage(INIT_S)
+    for _ in range(400):
+        K(vec["q"], vec["t"], False); stage(STEP_Q); stage(STEP_XR); Kt(vec["s"], vec["t"]); stage(STEP_S); stage(STEP_P)
+    res = hip.CglsResult()
+    hip.check(L_.prost_hip_cgls_result(state.ptr, C.byref(res), None))
+    assert res.converged == 1 and res.iterations < 400
+    x = dx.to_host()
+    assert np.allclose(x, x_direct, rtol=1e-8, atol=1e-10), float(np.abs(x - x_direct).max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_prox_epi_quad(hip, dtype):
     rng = np.random.default_rng(6)

@@ -263,6 +263,29 @@ def test_admm_matches_oracle(precision, dtype, device_cg):
             assert np.isclose(st[name], ost[name], rtol=1e-3, atol=1e-5), name
 
 
+def test_admm_and_pdhg_agree_at_convergence_on_the_c4_shape():
+    """the PRODUCT's two backends on the C4 shape (block.sparse + gradient2d(L = 2), sum_1d abs + sum_norm2(4) abs), fp64: ADMM
+    (device-resident CGLS graph projection; no reference-held vector pins it) and generic PDHG (bit-exact
+    against the oracle, which the real reference build pins) converge to the same energy and the same sum(x) -- the check the
+    survey ran on the reference itself (sum x = 465.796 vs 465.885 on a 32 x 32 TV-L1 problem) -- and both match the oracle's
+    ADMM run"""
+    from test_oracle_reference_tests import c4_shape_problem
+    prost.set_precision("double")
+    prob, energy = c4_shape_problem(32, 32)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    out = {}
+    for name, b, its in (("admm", prost.backend.admm(rho0=1), 1500), ("pdhg", prost.backend.pdhg(stepsize="boyd", residual_iter=10), 4000)):
+        st = run_product(prob, b, o, its)
+        assert st["path"] == ("admm:generic" if name == "admm" else "pdhg:generic"), st["path"]
+        out[name] = (energy(st["x"]), st["x"].sum(), st["x"])
+    (ea, sa, xa), (ep, sp_, xp) = out["admm"], out["pdhg"]
+    assert abs(ea - ep) / ep < 1e-3, (ea, ep)
+    assert abs(sa - sp_) / abs(sp_) < 1e-4, (sa, sp_)
+    ost = run_oracle(prob, prost.backend.admm(rho0=1), o, 1500, np.float64)
+    assert abs(energy(ost["x"]) - ea) / ea < 1e-6
+    assert float(np.abs(ost["x"] - xa).max()) < 1e-6 * max(1.0, float(np.abs(xa).max()))
+
+
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("cg_graph", [False, True])
 @pytest.mark.parametrize("cg_tol_min,cg_max_iter", [(0.3, 10), (1e-2, 25), (1e-5, 3)])

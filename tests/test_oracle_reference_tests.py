@@ -356,3 +356,53 @@ def test_linop_kronecker_blocks(dtype, name):
     assert np.abs(x - K @ inp).max() <= 1e-4 and np.abs(x_t - K.T @ inp_t).max() <= 1e-4
     assert np.abs(rowsum - np.asarray(abs(K).sum(axis=1)).ravel()).max() <= 1e-4
     assert np.abs(colsum - np.asarray(abs(K).sum(axis=0)).ravel()).max() <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# ADMM / CGLS (backend_admm.cu:355-665, cgls.hpp:222-371): the reference's own code needs cuBLAS + cuSPARSE and cannot be
+# compiled here, and the reference holds no test or golden vector for it -- PARITY UNPINNED.  What can
+# be checked is that the restatement solves the problems it claims to solve.
+# ---------------------------------------------------------------------------------------------
+def c4_shape_problem(nx, ny, seed=0):
+    """SURVEY 8(d) C4 shape (TV-L1 flow-like): v = W u, W = [diag(Ix) diag(Iy)] (block.sparse); g = gradient2d(nx, ny, 2) u;
+    f(v) = 5 |v - b|_1, f(g) = sum of 4-norms"""
+    from prost_amd import synthetic
+    n = nx * ny
+    Ix = synthetic.rof_image(nx, ny, 1, seed) - 0.5
+    Iy = synthetic.rof_image(nx, ny, 1, seed + 1) - 0.5
+    bvec = synthetic.rof_image(nx, ny, 1, seed + 2) - 0.5
+    W = sp.hstack([sp.diags(Ix), sp.diags(Iy)]).tocsc()
+    u = prost.variable(2 * n)
+    v, g = prost.variable(n), prost.variable(4 * n)
+    prob = prost.min_problem([u], [v, g])
+    prob.add_function(v, prost.function.sum_1d("abs", 1, bvec, 5.0))
+    prob.add_function(g, prost.function.sum_norm2(4, False, "abs"))
+    prob.add_constraint(u, v, prost.block.sparse(W))
+    prob.add_constraint(u, g, prost.block.gradient2d(nx, ny, 2))
+    G = spmat_gradient2d(nx, ny, 2)
+
+    def energy(x):
+        return 5.0 * np.abs(W @ x - bvec).sum() + np.sqrt(((G @ x).reshape(4, -1) ** 2).sum(0)).sum()
+    return prob, energy
+
+
+def test_admm_and_pdhg_agree_at_convergence_on_the_c4_shape():
+    """two different algorithms, one minimiser: the oracle's ADMM (graph projection by CGLS on the preconditioned operator)
+    and its PDHG (pinned bit-exactly by the real reference build) reach the same energy on the C4 shape -- the survey's
+    own probe of the reference saw sum(x) = 465.796 (ADMM) vs 465.885 (PDHG-boyd) on a 32 x 32 TV-L1 problem"""
+    prob, energy = c4_shape_problem(32, 32)
+    prob.finalize()
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    out = {}
+    for name, b, its in (("admm", prost.backend.admm(rho0=1), 1500), ("pdhg", prost.backend.pdhg(stepsize="boyd", residual_iter=10), 4000)):
+        s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float64)
+        s.initialize()
+        s.iterate(50)
+        e_early = energy(s.state()["x"])
+        s.iterate(its - 50)
+        x = s.state()["x"]
+        out[name] = (energy(x), x.sum(), e_early)
+        assert out[name][0] < e_early                               # the energy falls
+    (ea, sa, _), (ep, sp_, _) = out["admm"], out["pdhg"]
+    assert abs(ea - ep) / ep < 1e-3, (ea, ep)
+    assert abs(sa - sp_) / abs(sp_) < 1e-4, (sa, sp_)
