@@ -55,6 +55,8 @@ class BackendPDHG : public Backend<T> {
   T* x_data() { return x_.data(); }
   T* y_data() { return y_.data(); }
   bool single_kernel_path() const { return single_kernel_; }
+  /// one kernel per iteration with residual sums restricted to owned columns: gradient2d with L <= 2 or L = 3 / 4 channels
+  bool sharded_path() const { return single_kernel_ || single_mc_; }
   size_t fused_channels() const { return fused_ ? desc_.L : 0; }
   /// verification entry (solver_compare / solver_read): device pointers of the current and the previous iterate; a previous
   /// iterate that a pair launch kept in registers is rebuilt first

@@ -102,7 +102,7 @@ int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size);
  *                                                   prox_g, prox_f, prox_gstar, prox_fstar}  (index/size/name rows)
  *   solver_create(problem, nrows, ncols, backend, opts[, [x0 x1 nx]]) -> handle (scalar); the optional
  *       1x3 matrix marks image columns [x0, x1) of nx as OWNED (column-sharded images: the rest are halo
- *       columns that do not count in the residual sums); pdhg single-kernel gradient2d path only
+ *       columns that do not count in the residual sums); pdhg one-kernel gradient2d paths (L <= 4 channels) only
  *   solver_kernel_times(handle) -> the `kernels` cell of solver_iterate for the events recorded since the last evaluation
  *   solver_iterate(handle, iters[, time_kernels[, sample_every[, checked[, defer_times]]]]) -> struct {ms, converged, kernels};
  *       kernels = cell of {name, avg_ms, sampled launches, iterations per launch, all launches, chunk columns};
@@ -112,6 +112,9 @@ int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size);
  *       empty and the recorded events to solver_kernel_times
  *   solver_halo_exchange(handle, ny, halo, left_halo, right_halo, left_rank, right_rank): swap `halo` image
  *       columns of x and y with the neighbouring ranks over the comm_init communicator (rank < 0: none)
+ *   solver_iterate_sharded(handle, iters, ny, halo, left_halo, right_halo, left_rank, right_rank, since_exchange) ->
+ *       since_exchange: `iters` iterations of a column slab with the halo refresh every halo - 2 iterations, the loop
+ *       inside the native solver (collective over the communicator)
  *   solver_copy_columns(dst_handle, dst_col, src_handle, src_col, ncols, ny): the same transfer between two
  *       solvers of one process
  *   solver_state(handle[, with_vectors = 1]) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,

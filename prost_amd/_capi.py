@@ -320,6 +320,11 @@ class Solver:
     def halo_exchange(self, ny, halo, left_halo, right_halo, left_rank, right_rank):
         command("solver_halo_exchange", [self.handle, int(ny), int(halo), int(left_halo), int(right_halo), int(left_rank), int(right_rank)])
 
+    def iterate_sharded(self, iters, ny, halo, left_halo, right_halo, left_rank, right_rank, since_exchange):
+        """`iters` iterations with the halo refresh every halo - 2 iterations, looped natively -> new since_exchange"""
+        return int(command("solver_iterate_sharded", [self.handle, int(iters), int(ny), int(halo), int(left_halo), int(right_halo), int(left_rank),
+                                                      int(right_rank), int(since_exchange)], nlhs=1)[0])
+
     def copy_columns_from(self, dst_col, src, src_col, ncols, ny):
         command("solver_copy_columns", [self.handle, int(dst_col), src.handle, int(src_col), int(ncols), int(ny)])
 

@@ -500,8 +500,7 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
   { StageTimer t("Solver::Initialize (total)"); h->solver->Initialize(); }
   if (own_frac != 1.0) {
     auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
-    // halo exchange / column copies move the planes x, y1, y2 of ONE channel
-    if (!pd->single_kernel_path() || pd->fused_channels() != 1) throw Exception("Column sharding needs the single-kernel gradient2d path (one gradient2d block with L = 1).");
+    if (!pd->sharded_path()) throw Exception("Column sharding needs a one-kernel gradient2d path (one gradient2d block with L <= 4 channels).");
   }
   return h;
 }
@@ -730,14 +729,23 @@ void cmd_solver_state(CMD_ARGS) {
   if (a.single) solver_state_t(*std::static_pointer_cast<SolverHandle<float>>(a.h), vectors, nlhs, plhs);
   else solver_state_t(*std::static_pointer_cast<SolverHandle<double>>(a.h), vectors, nlhs, plhs);
 }
-// ---- column-sharded images: halo columns of the current iterate (x: n, y: two planes of n; column c of a
-// plane = ny contiguous entries at c * ny) ----
+// ---- column-sharded images: halo columns of the current iterate.  gradient2d with L channels keeps 3 L image planes of
+// nl * ny entries: x (L planes) and y (2 L planes: d/dx of every channel, then d/dy); column c of a plane = ny contiguous
+// entries at c * ny ----
 template <typename T>
 static BackendPDHG<T>& pdhg_of(AnyHandle& a) {
   auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
   auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
-  if (!pd || !pd->single_kernel_path() || pd->fused_channels() != 1) throw Exception("Halo exchange needs a pdhg solver on the single-kernel gradient2d path (L = 1).");
+  if (!pd || !pd->sharded_path()) throw Exception("Halo exchange needs a pdhg solver on a one-kernel gradient2d path (L <= 4).");
   return *pd;
+}
+template <typename T>
+static std::vector<T*> image_planes(BackendPDHG<T>& pd, size_t n) {
+  const size_t L = pd.fused_channels(), P = n / L;
+  std::vector<T*> planes;
+  for (size_t l = 0; l < L; l++) planes.push_back(pd.x_data() + l * P);
+  for (size_t k = 0; k < 2 * L; k++) planes.push_back(pd.y_data() + k * P);
+  return planes;
 }
 /// solver_halo_exchange(handle, ny, halo, left_halo, right_halo, left_rank, right_rank): over the RCCL
 /// communicator of comm_init.  left_halo / right_halo = number of halo columns this slab has on that side
@@ -748,13 +756,12 @@ static void halo_exchange_t(AnyHandle& a, size_t ny, size_t H, size_t HL, size_t
   if (!g_comm) throw Exception("solver_halo_exchange: comm_init first.");
   BackendPDHG<T>& pd = pdhg_of<T>(a);
   auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
-  const size_t n = h->problem->ncols(), nl = n / ny;
-  if (nl * ny != n || HL + HR + 2 * H > nl + (HL ? 0 : H) + (HR ? 0 : H)) throw Exception("solver_halo_exchange: slab too narrow for the halo width.");
-  T* planes[3] = {pd.x_data(), pd.y_data(), pd.y_data() + n};
+  const size_t n = h->problem->ncols(), P = n / pd.fused_channels(), nl = P / ny;
+  if (nl * ny != P || HL + HR + 2 * H > nl + (HL ? 0 : H) + (HR ? 0 : H)) throw Exception("solver_halo_exchange: slab too narrow for the halo width.");
   const size_t bytes = H * ny * sizeof(T);
   void* st = CurrentStream();
   CheckHip(prost_hip_comm_group_start(), "group_start");
-  for (T* p : planes) {
+  for (T* p : image_planes<T>(pd, n)) {
     if (left >= 0) {
       CheckHip(prost_hip_comm_send(g_comm, p + HL * ny, bytes, left, st), "send");              // my first owned columns
       CheckHip(prost_hip_comm_recv(g_comm, p, bytes, left, st), "recv");                        // -> my left halo
@@ -765,6 +772,32 @@ static void halo_exchange_t(AnyHandle& a, size_t ny, size_t H, size_t HL, size_t
     }
   }
   CheckHip(prost_hip_comm_group_end(), "group_end");
+}
+/// solver_iterate_sharded(handle, iters, ny, halo, left_halo, right_halo, left_rank, right_rank, since_exchange) ->
+/// since_exchange: `iters` iterations of a column slab with the halo refresh every halo - 2 iterations, all inside the
+/// native solver (collective: every rank calls it with the same counts) -- no host language between the exchanges
+template <typename T>
+static size_t iterate_sharded_t(AnyHandle& a, int iters, size_t ny, size_t H, size_t HL, size_t HR, int left, int right, size_t since) {
+  auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
+  if (H < 3) throw Exception("solver_iterate_sharded: the halo must be at least 3 columns.");
+  const size_t period = H - 2;
+  for (int done = 0; done < iters;) {
+    if (since >= period) { halo_exchange_t<T>(a, ny, H, HL, HR, left, right); since = 0; }
+    const int k = (int)std::min<size_t>((size_t)(iters - done), period - since);
+    h->solver->Iterate(k);
+    done += k; since += (size_t)k;
+  }
+  return since;
+}
+void cmd_solver_iterate_sharded(CMD_ARGS) {
+  if (nrhs != 9) throw Exception("solver_iterate_sharded: (handle, iters, ny, halo, left_halo, right_halo, left_rank, right_rank, since_exchange) required.");
+  AnyHandle& a = handle_of(prhs[0]);
+  const int iters = (int)prhs[1]->data[0];
+  const size_t ny = (size_t)prhs[2]->data[0], H = (size_t)prhs[3]->data[0], HL = (size_t)prhs[4]->data[0], HR = (size_t)prhs[5]->data[0];
+  const int left = (int)prhs[6]->data[0], right = (int)prhs[7]->data[0];
+  const size_t since = (size_t)prhs[8]->data[0];
+  const size_t out = a.single ? iterate_sharded_t<float>(a, iters, ny, H, HL, HR, left, right, since) : iterate_sharded_t<double>(a, iters, ny, H, HL, HR, left, right, since);
+  if (nlhs >= 1) plhs[0] = prost_value_scalar((double)out);
 }
 void cmd_solver_halo_exchange(CMD_ARGS) {
   (void)nlhs; (void)plhs;
@@ -780,10 +813,11 @@ template <typename T>
 static void copy_columns_t(AnyHandle& dst, size_t dcol, AnyHandle& src, size_t scol, size_t ncols, size_t ny) {
   BackendPDHG<T>& pd = pdhg_of<T>(dst); BackendPDHG<T>& ps = pdhg_of<T>(src);
   const size_t nd = std::static_pointer_cast<SolverHandle<T>>(dst.h)->problem->ncols(), ns = std::static_pointer_cast<SolverHandle<T>>(src.h)->problem->ncols();
-  if ((dcol + ncols) * ny > nd || (scol + ncols) * ny > ns) throw Exception("solver_copy_columns: column range outside the slab.");
-  T* d[3] = {pd.x_data(), pd.y_data(), pd.y_data() + nd};
-  T* s[3] = {ps.x_data(), ps.y_data(), ps.y_data() + ns};
-  for (int k = 0; k < 3; k++)
+  if (pd.fused_channels() != ps.fused_channels()) throw Exception("solver_copy_columns: the slabs have different channel counts.");
+  const size_t L = pd.fused_channels();
+  if ((dcol + ncols) * ny > nd / L || (scol + ncols) * ny > ns / L) throw Exception("solver_copy_columns: column range outside the slab.");
+  const std::vector<T*> d = image_planes<T>(pd, nd), s = image_planes<T>(ps, ns);
+  for (size_t k = 0; k < d.size(); k++)
     CheckHip(prost_hip_memcpy_d2d(d[k] + dcol * ny, s[k] + scol * ny, ncols * ny * sizeof(T), CurrentStream()), "memcpy_d2d");
 }
 void cmd_solver_copy_columns(CMD_ARGS) {
@@ -916,7 +950,7 @@ const std::map<std::string, cmd_fn>& cmd_reg() {
       {"eval_prox", cmd_eval_prox}, {"list_gpus", cmd_list_gpus}, {"set_gpu", cmd_set_gpu},
       {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info},
       {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_kernel_times", cmd_solver_kernel_times}, {"solver_state", cmd_solver_state},
-      {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_copy_columns", cmd_solver_copy_columns},
+      {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_iterate_sharded", cmd_solver_iterate_sharded}, {"solver_copy_columns", cmd_solver_copy_columns},
       {"solver_compare", cmd_solver_compare}, {"solver_read", cmd_solver_read}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
       {"comm_destroy", cmd_comm_destroy}, {"set_quirks", cmd_set_quirks}};
   return reg;

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
         const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
         const T w_hat = div_tauT.div(in.x[j] - xn[j]) - sqT * ktyp;
         const T diff = w_hat + sqT * ktyv[jj];
-        if (owner && counted) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
+        if (owner && counted && c >= a.rx0 && c < a.rx1) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
       }
     }
   };
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
           }
         }
       }
-      if (RES) {                                            // primal_residual_transform (backend_pdhg.cu:97-120)
+      if (RES && c >= a.rx0 && c < a.rx1) {                  // primal_residual_transform (backend_pdhg.cu:97-120); owned columns only
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
 #pragma unroll
@@ -235,7 +235,6 @@ static bool iter_mc_ok(const prost_hip_fused_desc* d) {
     if (k != 1 && d->g_coeff_ptr[k]) return false;
   }
   if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
-  if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
   const size_t strips = (d->ny + (size_t)(kWave - 1) * VecOf<T>::N - 1) / ((size_t)(kWave - 1) * VecOf<T>::N);
   if (strips * d->L > (size_t)kReduceBlocks / 2) return false;     // residual launches: one partial per wavefront must fit the workspace
   return strips * d->nx < (size_t)1 << 31;

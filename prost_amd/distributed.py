@@ -115,21 +115,21 @@ class ColumnShardedSolver:
         calls it with the same count)"""
         if self.transport != "rccl":
             raise RuntimeError("in-process slabs are driven by iterate_group()")
-        done = 0
-        while done < iters:
-            if self.steps_until_exchange() <= 0:
-                self.exchange()
-            k = min(iters - done, self.steps_until_exchange())
-            self.iterate_local(k)
-            done += k
+        # the exchange / iterate loop runs inside the native solver (solver_iterate_sharded): no Python between exchanges
+        self.since_exchange = self.solver.iterate_sharded(iters, self.ny, self.halo, self.hl, self.hr, self.rank - 1 if self.hl else -1,
+                                                          self.rank + 1 if self.hr else -1, self.since_exchange)
 
     def owned_state(self):
         st = self.solver.state()
-        n, ny = self.nl * self.ny, self.ny
+        P, ny = self.nl * self.ny, self.ny
         a, b = self.hl * ny, (self.hl + self.c1 - self.c0) * ny
-        y = np.asarray(st["y"])
-        return {"x": np.asarray(st["x"])[a:b], "y1": y[a:b], "y2": y[n + a:n + b], "iteration": st["iteration"],
-                "primal_res": st["primal_res"], "dual_res": st["dual_res"]}
+        x, y = np.asarray(st["x"]), np.asarray(st["y"])
+        L = x.size // P
+        out = {"x": np.concatenate([x[l * P + a:l * P + b] for l in range(L)]),
+               "y1": np.concatenate([y[l * P + a:l * P + b] for l in range(L)]),
+               "y2": np.concatenate([y[(L + l) * P + a:(L + l) * P + b] for l in range(L)]),
+               "iteration": st["iteration"], "primal_res": st["primal_res"], "dual_res": st["dual_res"]}
+        return out
 
     def destroy(self):
         self.solver.destroy()
