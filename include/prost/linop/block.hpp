@@ -44,6 +44,10 @@ class Block {
   /// sum_j |K_ij|^alpha of LOCAL row / column (host)
   virtual T row_sum(size_t row, T alpha) const = 0;
   virtual T col_sum(size_t col, T alpha) const = 0;
+  /// MI355X addition: true iff EVERY row sum is `row` and EVERY column sum is `col` (stencil blocks: the gradient blocks
+  /// report 2 and 4 / 6 for every row and column, block_gradient2d.cu:154-163) -- the preconditioners are then two
+  /// constants and no per-entry sweep, host vector or upload is needed
+  virtual bool uniform_sums(T alpha_row, T alpha_col, T& row, T& col) const { (void)alpha_row; (void)alpha_col; (void)row; (void)col; return false; }
   virtual void row_sums(T* out, T alpha) const { for (size_t r = 0; r < nrows_; r++) out[r] += row_sum(r, alpha); }
   virtual void col_sums(T* out, T alpha) const { for (size_t c = 0; c < ncols_; c++) out[c] += col_sum(c, alpha); }
 

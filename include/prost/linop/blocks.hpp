@@ -15,6 +15,7 @@ class BlockGradient2D : public Block<T> {
       : Block<T>(row, col, nx * ny * L * 2, nx * ny * L), nx_(nx), ny_(ny), L_(L), label_first_(label_first) {}
   virtual T row_sum(size_t, T) const { return 2; }     // block_gradient2d.cu:154-157
   virtual T col_sum(size_t, T) const { return 4; }     // :160-163
+  virtual bool uniform_sums(T, T, T& row, T& col) const { row = 2; col = 4; return true; }
   virtual void row_sums(T* out, T alpha) const;
   virtual void col_sums(T* out, T alpha) const;
   virtual size_t gpu_mem_amount() const { return 0; }
@@ -37,6 +38,7 @@ class BlockGradient3D : public Block<T> {
       : Block<T>(row, col, nx * ny * L * 3, nx * ny * L), nx_(nx), ny_(ny), L_(L), label_first_(label_first) {}
   virtual T row_sum(size_t, T) const { return 2; }     // block_gradient3d.cu:165-168
   virtual T col_sum(size_t, T) const { return 6; }     // :171-174
+  virtual bool uniform_sums(T, T, T& row, T& col) const { row = 2; col = 6; return true; }
   virtual void row_sums(T* out, T alpha) const;
   virtual void col_sums(T* out, T alpha) const;
   virtual size_t gpu_mem_amount() const { return 0; }

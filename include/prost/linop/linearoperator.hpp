@@ -33,6 +33,12 @@ class LinearOperator {
   /// bulk: out[r] = sum over blocks; out must hold nrows() / ncols() entries
   virtual void row_sums(std::vector<T>& out, T alpha) const;
   virtual void col_sums(std::vector<T>& out, T alpha) const;
+  /// true iff the operator is ONE block that spans it and reports constant row and column sums (Block::uniform_sums)
+  virtual bool uniform_sums(T alpha_row, T alpha_col, T& row, T& col) const {
+    if (blocks_.size() != 1) return false;
+    const auto& b = blocks_[0];
+    return b->row() == 0 && b->col() == 0 && b->nrows() == nrows_ && b->ncols() == ncols_ && b->uniform_sums(alpha_row, alpha_col, row, col);
+  }
 
   virtual size_t nrows() const { return nrows_; }
   virtual size_t ncols() const { return ncols_; }
@@ -62,6 +68,7 @@ class DualLinearOperator : public LinearOperator<T> {
   virtual T col_sum(size_t col, T alpha) const { return child_->row_sum(col, alpha); }
   virtual void row_sums(std::vector<T>& out, T alpha) const { child_->col_sums(out, alpha); }
   virtual void col_sums(std::vector<T>& out, T alpha) const { child_->row_sums(out, alpha); }
+  virtual bool uniform_sums(T alpha_row, T alpha_col, T& row, T& col) const { return child_->uniform_sums(alpha_col, alpha_row, col, row); }
   virtual size_t nrows() const { return child_->ncols(); }
   virtual size_t ncols() const { return child_->nrows(); }
   virtual size_t gpu_mem_amount() const { return 0; }

@@ -42,8 +42,13 @@ class Problem {
   shared_ptr<LinearOperator<T>> linop() const { return linop_; }
   const device_vector<T>& scaling_left() const { return scaling_left_; }
   const device_vector<T>& scaling_right() const { return scaling_right_; }
-  const std::vector<T>& scaling_left_host() const { return scaling_left_host_; }
-  const std::vector<T>& scaling_right_host() const { return scaling_right_host_; }
+  /// host copies; when the preconditioner is one constant (uniform_left / uniform_right) they are only filled on first use
+  const std::vector<T>& scaling_left_host() const { MaterializeHost(); return scaling_left_host_; }
+  const std::vector<T>& scaling_right_host() const { MaterializeHost(); return scaling_right_host_; }
+  /// MI355X addition: Sigma (left) / Tau (right) known to be ONE value (a single stencil block with constant row and
+  /// column sums): nothing is swept, stored or uploaded per entry -- at 10^9 entries that is seconds of setup
+  bool uniform_left(T& v) const { v = left_value_; return left_uniform_; }
+  bool uniform_right(T& v) const { v = right_value_; return right_uniform_; }
   const ProxList& prox_f() const { return prox_f_; }
   const ProxList& prox_g() const { return prox_g_; }
   const ProxList& prox_fstar() const { return prox_fstar_; }
@@ -54,12 +59,15 @@ class Problem {
 
  protected:
   void AveragePreconditioners(std::vector<T>& precond, const ProxList& prox);
+  void MaterializeHost() const;
 
   size_t nrows_, ncols_;
   shared_ptr<LinearOperator<T>> linop_, dual_linop_;
   Scaling scaling_type_;
   device_vector<T> scaling_left_, scaling_right_;           // squared preconditioners Sigma, Tau
-  std::vector<T> scaling_left_host_, scaling_right_host_;
+  mutable std::vector<T> scaling_left_host_, scaling_right_host_;
+  bool left_uniform_ = false, right_uniform_ = false;
+  T left_value_ = 0, right_value_ = 0;
   T scaling_alpha_;
   ProxList prox_f_, prox_g_, prox_fstar_, prox_gstar_;
   bool host_initialized_;

@@ -71,6 +71,10 @@ class Prox {
       for (size_t c = 0; c < cnt; c++) precond[idx + c * stride] = avg;
     }
   }
+  /// MI355X addition: the preconditioner over this prox's range is the ONE value `value`; if averaging leaves it one value,
+  /// store it (the mean as average_preconditioner forms it) and return true.  false = unknown: the caller materialises the
+  /// vector and calls average_preconditioner.
+  virtual bool average_uniform(T& value) const { (void)value; return false; }
   virtual bool describe(ProxDesc&) const { return false; }
 
   /// A prox argument that is not materialised: the backend names the vectors and scalars it is made of

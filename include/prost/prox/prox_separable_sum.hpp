@@ -18,6 +18,13 @@ class ProxSeparableSum : public Prox<T> {
     if (interleaved_) for (size_t i = 0; i < count_; i++) sep.push_back(std::tuple<size_t, size_t, size_t>(this->index_ + i * dim_, dim_, 1));
     else for (size_t i = 0; i < count_; i++) sep.push_back(std::tuple<size_t, size_t, size_t>(this->index_ + i, dim_, count_));
   }
+  virtual bool average_uniform(T& value) const {           // every group: dim_ copies of `value`, summed in order, divided
+    T avg = 0;
+    for (size_t c = 0; c < dim_; c++) avg += value;
+    avg /= static_cast<T>(dim_);
+    value = avg;
+    return true;
+  }
   virtual void average_preconditioner(std::vector<T>& precond) {
     T* base = precond.data() + this->index_;
     if (interleaved_) {

@@ -54,6 +54,7 @@ class ProxMoreau : public Prox<T> {
   virtual bool supports_arg_source() const;
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
   virtual void average_preconditioner(std::vector<T>& precond) { conjugate_->average_preconditioner(precond); }
+  virtual bool average_uniform(T& value) const { return conjugate_->average_uniform(value); }
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
@@ -131,6 +132,7 @@ class ProxTransform : public Prox<T> {
   virtual size_t gpu_mem_amount() const;
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { inner_fn_->get_separable_structure(sep); }
   virtual void average_preconditioner(std::vector<T>& precond) { inner_fn_->average_preconditioner(precond); }
+  virtual bool average_uniform(T& value) const { return inner_fn_->average_uniform(value); }
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);
@@ -150,6 +152,7 @@ class ProxPermute : public Prox<T> {
   virtual size_t gpu_mem_amount() const { return this->size_ * sizeof(T) + base_prox_->gpu_mem_amount(); }
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { base_prox_->get_separable_structure(sep); }
   virtual void average_preconditioner(std::vector<T>& precond) { base_prox_->average_preconditioner(precond); }
+  virtual bool average_uniform(T& value) const { return base_prox_->average_uniform(value); }
 
  protected:
   virtual void EvalLocal(T*, T*, const T*, const T*, const T*, const T*, T tau, bool invert_tau);

@@ -111,6 +111,10 @@ int prost_hip_sparse_kron_id_acc_f64(double* res, const double* rhs, size_t diag
 int prost_hip_id_kron_sparse_acc_f32(float* res, const float* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 int prost_hip_id_kron_sparse_acc_f64(double* res, const double* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 /* x = beta * x (beta == 0 -> zero fill): thrust::fill / transform at linearoperator.cu:140-147 */
+/* x[i] = value (thrust::fill, linearoperator.cu:140-147; also used for preconditioners that are one constant: the
+ * gradient blocks' row / column sums are, block_gradient2d.cu:154-163, so nothing is uploaded for them) */
+int prost_hip_fill_f32(float* x, double value, size_t n, void* stream);
+int prost_hip_fill_f64(double* x, double value, size_t n, void* stream);
 int prost_hip_scale_f32(float* x, size_t n, double beta, void* stream);
 int prost_hip_scale_f64(double* x, size_t n, double beta, void* stream);
 /* x = -x, optionally through a float round trip: thrust::negate<float> at
@@ -478,6 +482,8 @@ typedef struct prost_hip_normest_desc {
   uint64_t m, n;
   double norm_x;
   double* out;
+  const double* norm_x_from;   /* NORMEST_A: if not NULL the divisor is read from here (device-visible memory, e.g. the out[1] a
+                                * previous round wrote) instead of norm_x -- rounds can be queued without a host round trip */
 } prost_hip_normest_desc;
 enum { PROST_NORMEST_A = 0, PROST_NORMEST_B, PROST_NORMEST_C };
 int prost_hip_normest_stage_f32(int stage, const prost_hip_normest_desc* d, void* stream);

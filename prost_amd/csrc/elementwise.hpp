@@ -14,7 +14,7 @@ namespace prost_hip {
 
 template <class T, int NIN>
 struct EwIn {
-  const T* p[NIN];
+  const T* p[NIN > 0 ? NIN : 1];
 };
 
 // out[i] = f(in[0][i], ..., in[NIN-1][i]); `out` may alias an input (all loads of an element
@@ -23,12 +23,12 @@ template <class T, int VEC, int NIN, class F>
 __global__ void __launch_bounds__(kBlock) ew_kernel(T* out, EwIn<T, NIN> in, size_t n, F f) {
   const size_t nv = n / VEC;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
-    T v[NIN][VEC], o[VEC];
+    T v[NIN > 0 ? NIN : 1][VEC], o[VEC];
 #pragma unroll
     for (int k = 0; k < NIN; k++) ldv<T, VEC>(in.p[k] + i * VEC, v[k]);
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      T a[NIN];
+      T a[NIN > 0 ? NIN : 1];
 #pragma unroll
       for (int k = 0; k < NIN; k++) a[k] = v[k][j];
       o[j] = f(a);
@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(kBlock) ew_kernel(T* out, EwIn<T, NIN> in, siz
   }
   if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < n - nv * VEC) {
     const size_t i = nv * VEC + threadIdx.x;
-    T a[NIN];
+    T a[NIN > 0 ? NIN : 1];
 #pragma unroll
     for (int k = 0; k < NIN; k++) a[k] = in.p[k][i];
     out[i] = f(a);

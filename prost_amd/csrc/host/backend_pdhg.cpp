@@ -64,7 +64,8 @@ bool BackendPDHG<T>::TryFused() {
   const size_t comps = d3 ? 3 : 2 * bd.L;
   if (pf.count != pixels || pf.dim != comps) return false;
   T tv, sv;
-  if (!uniform(prob.scaling_right_host(), tv) || !uniform(prob.scaling_left_host(), sv)) return false;
+  if (!prob.uniform_right(tv) && !uniform(prob.scaling_right_host(), tv)) return false;
+  if (!prob.uniform_left(sv) && !uniform(prob.scaling_left_host(), sv)) return false;
   desc_.res_x0 = owned_x0_; desc_.res_x1 = owned_x1_;
   desc_.is3d = d3 ? 1 : 0; desc_.nx = bd.nx; desc_.ny = bd.ny; desc_.L = bd.L;
   desc_.g_fn = pg.fn; desc_.f_fn = pf.fn;

@@ -52,7 +52,13 @@ extern "C" {
 prost_value* prost_value_scalar(double v) { return prost_value_matrix(&v, 1, 1); }
 prost_value* prost_value_matrix(const double* data, size_t rows, size_t cols) {
   prost_value* v = new prost_value; v->kind = PROST_VALUE_MATRIX; v->rows = rows; v->cols = cols;
-  if (data && rows * cols > 0) v->data.assign(data, data + rows * cols); else v->data.assign(rows * cols, 0.0);
+  const size_t n = rows * cols;
+  if (data && n >= ((size_t)1 << 20)) {       // large vectors (per-pixel coefficients): storage not zero-filled, copied on several host threads
+    v->data.resize(n);
+    double* dst = v->data.data();
+    prost::ParallelFor(n, [&](size_t b, size_t e) { std::memcpy(dst + b, data + b, (e - b) * sizeof(double)); });
+  } else if (data && n > 0) v->data.assign(data, data + n);
+  else v->data.assign(n, 0.0);
   return v;
 }
 prost_value* prost_value_string(const char* s) { prost_value* v = new prost_value; v->kind = PROST_VALUE_STRING; v->str = s ? s : ""; v->rows = 1; v->cols = v->str.size(); return v; }
@@ -140,8 +146,16 @@ template <typename T>
 static void get_coefficients(std::array<std::vector<T>, 7>& coeffs, const prost_value* cell_arr, size_t count) {
   if (!cell_arr || cell_arr->kind != PROST_VALUE_CELL || cell_arr->cells.size() < 7) throw Exception("Cell array of coefficients is too small.");
   for (size_t i = 0; i < 7; i++) {
-    std::vector<double> v = GetVector(cell_arr->cells[i]);
-    coeffs[i] = std::vector<T>(v.begin(), v.end());
+    const prost_value* cv = cell_arr->cells[i];
+    if (!cv || cv->kind != PROST_VALUE_MATRIX) throw Exception("Argument has to be passed as a vector of type single or double.");
+    if (cv->cols != 1 && cv->rows != 1) throw Exception("Vector has to be Nx1 or 1xN.");
+    if (cv->rows == 0 || cv->cols == 0) throw Exception("Empty vector passed.");
+    // narrowed to T straight from the value's storage on several host threads (a per-pixel coefficient of a 2048 x 2048 x 64
+    // volume is 2 GB of doubles: no intermediate copy)
+    coeffs[i].resize(cv->data.size());
+    const double* src = cv->data.data();
+    T* dst = coeffs[i].data();
+    ParallelFor(coeffs[i].size(), [&](size_t b, size_t e) { for (size_t k = b; k < e; k++) dst[k] = (T)src[k]; });
     if (coeffs[i].size() != 1 && coeffs[i].size() != count) throw Exception("Size of coefficients should be either 1 or count.");
   }
 }
@@ -629,6 +643,18 @@ void cmd_problem_info(CMD_ARGS) {
   if (g_single) problem_info_t<float>(nlhs, plhs, nrhs, prhs); else problem_info_t<double>(nlhs, plhs, nrhs, prhs);
 }
 
+/// glibc_rand_unit(n[, skip]) -> n x 1: (T)rand() / (T)RAND_MAX of a fresh process after `skip` draws -- the start vector of
+/// Problem::normest (problem.cu:441-444) as GlibcRand::fill_unit generates it (chunk-parallel by jump-ahead); host only
+void cmd_glibc_rand_unit(CMD_ARGS) {
+  if (nrhs < 1) throw Exception("glibc_rand_unit: n required.");
+  const size_t n = (size_t)prhs[0]->data[0], skip = nrhs >= 2 ? (size_t)prhs[1]->data[0] : 0;
+  GlibcRand rng(1);
+  for (size_t i = 0; i < skip; i++) rng.next();
+  prost_value* out = prost_value_matrix(nullptr, n, 1);
+  if (g_single) { std::vector<float> v(n); rng.fill_unit(v.data(), n); for (size_t i = 0; i < n; i++) out->data[i] = v[i]; }
+  else rng.fill_unit(out->data.data(), n);
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
 void cmd_solver_create(CMD_ARGS) {
   if (nrhs != 5 && nrhs != 6) throw Exception("solver_create: five inputs (problem, nrows, ncols, backend, opts) [+ owned columns {x0, x1, nx}] required.");
   select_device();
@@ -948,7 +974,7 @@ const std::map<std::string, cmd_fn>& cmd_reg() {
   static const std::map<std::string, cmd_fn> reg = {
       {"init", cmd_init}, {"release", cmd_release}, {"solve_problem", cmd_solve_problem}, {"eval_linop", cmd_eval_linop},
       {"eval_prox", cmd_eval_prox}, {"list_gpus", cmd_list_gpus}, {"set_gpu", cmd_set_gpu},
-      {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info},
+      {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info}, {"glibc_rand_unit", cmd_glibc_rand_unit},
       {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_kernel_times", cmd_solver_kernel_times}, {"solver_state", cmd_solver_state},
       {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_iterate_sharded", cmd_solver_iterate_sharded}, {"solver_copy_columns", cmd_solver_copy_columns},
       {"solver_compare", cmd_solver_compare}, {"solver_read", cmd_solver_read}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <iostream>
+#include <memory>
 #include <sstream>
 
 #include "hipapi.hpp"
@@ -124,6 +125,32 @@ void Problem<T>::InitializeHost() {
   CheckDomainProx<T>(prox_gstar_, ncols_, "prox_gstar");
   CheckDomainProx<T>(prox_fstar_, nrows_, "prox_fstar");
 
+  left_uniform_ = right_uniform_ = false;
+  T urow = 0, ucol = 0;
+  if (scaling_type_ == kScalingAlpha && linop_->uniform_sums(scaling_alpha_, (T)(2. - (double)scaling_alpha_), urow, ucol) && urow > 0 && ucol > 0) {
+    // ONE stencil block with constant row / column sums (gradient2d / 3d): Sigma and Tau are one value each -- the reciprocal
+    // sweep of problem.cu:262-287 would write it into every entry.  The averaging over separable groups (problem.cu:503-536)
+    // maps a constant vector to a constant vector when every prox of the list agrees on the mean; then nothing is swept,
+    // stored or uploaded per entry (2048 x 2048 x 64: 1.07e9 entries).  Otherwise fall through to the vectors.
+    T lv = (T)(1. / (double)urow), rv = (T)(1. / (double)ucol);
+    auto uniform_average = [](T& v, const ProxList& list) {
+      bool first = true; T out = v;
+      for (auto& p : list) {
+        T pv = v;
+        if (!p->diagsteps() && !p->average_uniform(pv)) return false;
+        if (first) { out = pv; first = false; } else if (pv != out) return false;
+      }
+      v = out;
+      return true;
+    };
+    if (uniform_average(rv, prox_g_.empty() ? prox_gstar_ : prox_g_) && uniform_average(lv, prox_f_.empty() ? prox_fstar_ : prox_f_)) {
+      left_uniform_ = right_uniform_ = true;
+      left_value_ = lv; right_value_ = rv;
+      scaling_left_host_.clear(); scaling_right_host_.clear();
+      host_initialized_ = true;
+      return;
+    }
+  }
   if (scaling_type_ == kScalingAlpha) {
     // Sigma_i = 1 / sum_j |K_ij|^alpha ; Tau_j = 1 / sum_i |K_ij|^(2-alpha).  An all-zero row or
     // column inherits the last positive value seen, and that carry runs from the row sweep on
@@ -162,8 +189,14 @@ void Problem<T>::Initialize() {
   for (auto& p : prox_fstar_) p->Initialize();
   for (auto& p : prox_g_) p->Initialize();
   for (auto& p : prox_gstar_) p->Initialize();
-  scaling_left_ = scaling_left_host_;
-  scaling_right_ = scaling_right_host_;
+  if (left_uniform_ && right_uniform_) {            // constants: filled on the device, nothing crosses PCIe
+    scaling_left_.resize(nrows_); scaling_right_.resize(ncols_);
+    CheckHip(Api<T>::fill(scaling_left_.data(), (double)left_value_, nrows_, CurrentStream()), "fill");
+    CheckHip(Api<T>::fill(scaling_right_.data(), (double)right_value_, ncols_, CurrentStream()), "fill");
+  } else {
+    scaling_left_ = scaling_left_host_;
+    scaling_right_ = scaling_right_host_;
+  }
   dual_linop_ = shared_ptr<LinearOperator<T>>(new DualLinearOperator<T>(linop_));
 }
 
@@ -205,6 +238,20 @@ void Problem<T>::Dualize() {
   std::swap(linop_, dual_linop_);
   scaling_left_.swap(scaling_right_);
   std::swap(scaling_left_host_, scaling_right_host_);
+  std::swap(left_uniform_, right_uniform_);
+  std::swap(left_value_, right_value_);
+}
+
+template <typename T>
+void Problem<T>::MaterializeHost() const {
+  if (left_uniform_ && scaling_left_host_.size() != nrows_) {
+    scaling_left_host_.resize(nrows_);
+    ParallelFor(nrows_, [&](size_t b, size_t e) { std::fill(scaling_left_host_.begin() + b, scaling_left_host_.begin() + e, left_value_); });
+  }
+  if (right_uniform_ && scaling_right_host_.size() != ncols_) {
+    scaling_right_host_.resize(ncols_);
+    ParallelFor(ncols_, [&](size_t b, size_t e) { std::fill(scaling_right_host_.begin() + b, scaling_right_host_.begin() + e, right_value_); });
+  }
 }
 
 /// |Sigma^(1/2) K Tau^(1/2)| by power iteration on the device (problem.cu:429-500).  The start
@@ -215,10 +262,12 @@ T Problem<T>::normest(T tol, int max_iters) {
   device_vector<T> x(n), x_temp(n), Ax_temp(m);
   {
     StageTimer t_rng("  normest: start vector (glibc rand stream)");
-    std::vector<T> x_host(n);
+    // not value-initialised: the pages are first touched by the generating threads, not by a serial zero fill
+    std::unique_ptr<T[]> x_host(new T[n]);
     GlibcRand rng(1);
-    rng.fill_unit(x_host.data(), n);                     // x[i] = (T)rand() / (T)RAND_MAX (problem.cu:441-444)
-    x = x_host;
+    rng.fill_unit(x_host.get(), n);                      // x[i] = (T)rand() / (T)RAND_MAX (problem.cu:441-444)
+    CheckHip(prost_hip_memcpy_h2d(x.data(), x_host.get(), n * sizeof(T), CurrentStream()), "memcpy_h2d");
+    CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
   }
   // Per round the reference runs four scaling passes, two nrm2 (each with a blocking read-back) and a divide around K
   // and K^T; here three fused passes (prost_hip_normest_stage_*: same expressions and roundings), the two norms land in
@@ -226,26 +275,38 @@ T Problem<T>::normest(T tol, int max_iters) {
   void* ws = nullptr;
   double* out_host = nullptr;
   CheckHip(prost_hip_malloc(&ws, prost_hip_cgls_workspace_bytes()), "malloc");
-  CheckHip(prost_hip_host_alloc((void**)&out_host, 2 * sizeof(double)), "host_alloc");
+  CheckHip(prost_hip_host_alloc((void**)&out_host, 2 * (size_t)std::max(max_iters, 1) * sizeof(double)), "host_alloc");
   StageTimer t_rounds("  normest: power iteration");
   prost_hip_normest_desc d;
   d.workspace = ws; d.x = x.data(); d.x_temp = x_temp.data(); d.ax = Ax_temp.data();
-  d.sigma = scaling_left_.data(); d.tau = scaling_right_.data(); d.m = m; d.n = n; d.norm_x = 0; d.out = out_host;
+  d.sigma = scaling_left_.data(); d.tau = scaling_right_.data(); d.m = m; d.n = n; d.norm_x = 0; d.out = out_host; d.norm_x_from = nullptr;
+  // Only the norm leaves this function, so rounds beyond the one at which the reference's loop stops are harmless: the rounds
+  // are queued in batches without a host round trip in between -- round i writes its two norms to slot i of a pinned array,
+  // round i + 1 reads its divisor from there (norm_x_from) -- and the stopping test of problem.cu:493-496 is replayed on the
+  // host over the recorded norms, in order.
   T norm = 0, norm_prev;
+  bool stop = false;
+  const int kBatch = 20;
   try {
-    for (int i = 0; i < max_iters; i++) {
-      norm_prev = norm;
-      CheckHip(Api<T>::normest_stage(PROST_NORMEST_A, &d, CurrentStream()), "normest_stage");
-      linop_->Eval(Ax_temp, x_temp);
-      CheckHip(Api<T>::normest_stage(PROST_NORMEST_B, &d, CurrentStream()), "normest_stage");
-      linop_->EvalAdjoint(x_temp, Ax_temp);
-      CheckHip(Api<T>::normest_stage(PROST_NORMEST_C, &d, CurrentStream()), "normest_stage");
+    for (int i0 = 0; i0 < max_iters && !stop; i0 += kBatch) {
+      const int i1 = std::min(max_iters, i0 + kBatch);
+      for (int i = i0; i < i1; i++) {
+        d.out = out_host + 2 * i;
+        d.norm_x_from = i > 0 ? out_host + 2 * (i - 1) + 1 : nullptr;
+        CheckHip(Api<T>::normest_stage(PROST_NORMEST_A, &d, CurrentStream()), "normest_stage");
+        linop_->Eval(Ax_temp, x_temp);
+        CheckHip(Api<T>::normest_stage(PROST_NORMEST_B, &d, CurrentStream()), "normest_stage");
+        linop_->EvalAdjoint(x_temp, Ax_temp);
+        CheckHip(Api<T>::normest_stage(PROST_NORMEST_C, &d, CurrentStream()), "normest_stage");
+      }
       CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
-      // the reference reduces in T with an unspecified tree order; here in double, narrowed to T
-      const T norm_Ax = (T)out_host[0], norm_x = (T)out_host[1];
-      norm = norm_x / norm_Ax;
-      if (std::abs(norm_prev - norm) < tol * norm) break;
-      d.norm_x = (double)norm_x;                       // x := x / norm_x is folded into the next round's first pass
+      for (int i = i0; i < i1 && !stop; i++) {
+        norm_prev = norm;
+        // the reference reduces in T with an unspecified tree order; here in double, narrowed to T
+        const T norm_Ax = (T)out_host[2 * i], norm_x = (T)out_host[2 * i + 1];
+        norm = norm_x / norm_Ax;
+        if (std::abs(norm_prev - norm) < tol * norm) stop = true;
+      }
     }
   } catch (...) { prost_hip_free(ws); prost_hip_host_free(out_host); throw; }
   prost_hip_free(ws);

@@ -452,8 +452,8 @@ __global__ void __launch_bounds__(kBlock) admm_residual_fold_kernel(double* out4
 template <class T> struct NormestA {
   static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
-  const T* x; const T* tau; T* x_temp; T norm_x; bool divide;
-  __device__ void load(const CgState*) {}
+  const T* x; const T* tau; T* x_temp; T norm_x; bool divide; const double* norm_from;
+  __device__ void load(const CgState*) { if (norm_from) { norm_x = (T)*norm_from; divide = *norm_from != 0.0; } }
   template <int V> __device__ void range0(size_t i, double&, double&) const {
     T xv[V], dv[V], o[V];
     ldv<T, V>(x + i, xv); ldv<T, V>(tau + i, dv);
@@ -614,7 +614,7 @@ static int normest_stage(int stage, const prost_hip_normest_desc* d, void* strea
   int rc;
   switch (stage) {
     case PROST_NORMEST_A:
-      return launch_stage<T>("normest a", NormestA<T>{x, tau, x_temp, (T)d->norm_x, d->norm_x != 0.0}, n, 0, vn, &c, st);
+      return launch_stage<T>("normest a", NormestA<T>{x, tau, x_temp, (T)d->norm_x, d->norm_x != 0.0, d->norm_x_from}, n, 0, vn, &c, st);
     case PROST_NORMEST_B:
       if (!d->out) { set_error("normest_stage: out is required"); return 1; }
       if ((rc = launch_stage<T>("normest b", NormestB<T>{ax, sigma}, m, 0, vm, &c, st))) return rc;

@@ -73,6 +73,8 @@ template <class T> struct CompareF {
   }
 };
 
+template <class T> struct FillF { T v; __device__ T operator()(const T*) const { return v; } };
+
 // ---- ADMM / CGLS ----
 template <class T> struct Nrm2F { __device__ void operator()(const T* v, double& a, double&) const { a += (double)v[0] * (double)v[0]; } };
 template <class T> struct AxpyF { T alpha; __device__ T operator()(const T* a) const { return alpha * a[0] + a[1]; } };   // x, y
@@ -169,6 +171,8 @@ int prost_hip_pdhg_z_variable_f64(double* z, const double* yp, const double* y, 
   return launch_ew<double, 5>("z_variable", z, EwIn<double, 5>{{yp, y, S, kx, kxp}}, m, ZVarF<double>{sg, th}, as_stream(s));
 }
 
+int prost_hip_fill_f32(float* x, double value, size_t n, void* s) { return launch_ew<float, 0>("fill", x, EwIn<float, 0>{}, n, FillF<float>{(float)value}, as_stream(s)); }
+int prost_hip_fill_f64(double* x, double value, size_t n, void* s) { return launch_ew<double, 0>("fill", x, EwIn<double, 0>{}, n, FillF<double>{value}, as_stream(s)); }
 int prost_hip_compare_f32(double* out2, const float* a, const float* b, size_t n, void* ws, void* s) {
   return reduce_to<float, 2>(out2, ws, EwIn<float, 2>{{a, b}}, n, CompareF<float>{}, false, s);
 }

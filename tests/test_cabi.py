@@ -178,3 +178,24 @@ def test_product_fails_loudly_without_a_gpu():
         prost.eval_prox(prost.function.sum_1d("abs"), np.ones(4), 1.0, np.ones(4))
     with pytest.raises(_hip.HipError):
         _hip.require_device()
+
+
+def test_glibc_rand_stream_is_generated_chunk_parallel_and_stays_exact():
+    """Problem::normest starts from (T)rand() / (T)RAND_MAX of a fresh process (problem.cu:441-444).  The host library generates
+    that stream on several threads by jump-ahead of the additive-feedback recurrence (GlibcRand::fill_unit); it must equal the
+    sequential stream -- the oracle's GlibcRand, pinned against the real std::rand() by tests/test_oracle_pinning.py -- for
+    lengths below, at and across the chunk boundaries, and after a prefix drawn one by one."""
+    import oracle
+    from prost_amd import _capi
+    prost.set_precision("single")
+    try:
+        for n, skip in ((1, 0), (30, 0), (31, 5), (1000, 0), ((1 << 21) + 7, 0), (5 * (1 << 20) + 3, 17)):
+            got = np.asarray(_capi.command("glibc_rand_unit", [n, skip], nlhs=1)[0]).reshape(-1)
+            ref = oracle.glibc_rand(1, n + skip)[skip:].astype(np.float32) / np.float32(2147483647)
+            assert got.shape == (n,) and np.array_equal(got.astype(np.float32), ref), (n, skip, int((got.astype(np.float32) != ref).sum()))
+        prost.set_precision("double")
+        n = 3 * (1 << 20) + 11
+        got = np.asarray(_capi.command("glibc_rand_unit", [n], nlhs=1)[0]).reshape(-1)
+        assert np.array_equal(got, oracle.glibc_rand(1, n).astype(np.float64) / 2147483647.0)
+    finally:
+        prost.set_precision("double")
