@@ -34,6 +34,11 @@ struct IterParams {           // step sizes of one iteration + the host-evaluate
   UniformProx<T> ug, uf;
 };
 
+// PF == 0 selects the LDS prefetch ring (see the kernel): resident wavefronts per SIMD of that instance
+constexpr int kRingWaves = 4;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
 template <class T, int VEC, int GMASK>
 struct Col2 {
   static constexpr int NG = popcount7b(GMASK) > 0 ? popcount7b(GMASK) : 1;
@@ -46,7 +51,7 @@ struct Col2 {
 // K x^(k+2)) is in registers, no extra HBM traffic.
 // PF: columns of loads kept in flight per wave (3 for the straight-line instances at 3 waves/SIMD, 1 otherwise)
 template <class T, int VEC, int GFN, int FFN, int GMASK, int PF, bool FAST, int MODE, bool RAG>
-__global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
+__global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRingWaves) : (MODE & 2) ? 2 : (PF > 1 || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
                                                                 FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2,
@@ -78,6 +83,18 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
   // bases are wave-uniform (SGPR pairs), so the loads/stores use the saddr + 32-bit voffset form and
   // no 64-bit per-lane address arithmetic is left in the loop (host guarantees N * sizeof(T) < 4 GiB)
   auto off_of = [&](long c) { return (unsigned)((c * ny + row0) * (long)sizeof(T)); };
+  // ---- PF == 0: prefetch through an LDS ring instead of a register ring --------------------------------------------------
+  // The register version keeps the columns c+1 .. c+2+PF of the four input streams in VGPRs (80 registers at PF = 3) and
+  // moves them one slot per step (64 v_mov per column).  Here a column is fetched by four LDS-DMA loads
+  // (global_load_lds_dwordx4: no VGPR, wave-uniform LDS base + lane * 16) two steps before it is used, lands in one of two
+  // 4-KiB slots of the wave's own LDS ring and is read into the `in2` registers when its step comes; only in1 <- in2 is
+  // still a register copy.  ~48 VGPRs and ~48 moves per column less, which fits four resident wavefronts per SIMD.
+  // Nothing orders an LDS read behind a pending LDS-DMA except the issuing wave's vmcnt, and hipcc drains vmcnt(0) before
+  // any LDS read it can see, so the ring is read with inline-asm ds_read_b128 behind a COUNTED s_waitcnt: at the top of a
+  // step the batch of column c+3 (NB loads, issued one step ago) may still be in flight, whatever stores lie in between.
+  constexpr bool kRing = PF == 0;
+  constexpr int NB = 3 + ((GMASK >> 1) & 1);                    // LDS-DMA loads per column: y1, y2, x (, b of prox_g)
+  __shared__ __attribute__((aligned(16))) char ring_mem[kRing ? 2 * 4096 : 16];
   const T* const y2base = y + N;
   T* const y2out = y_out + N;
   T* const y2mid = kMid ? y_mid + N : nullptr;
@@ -94,6 +111,31 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
         }
       }
     }
+  };
+  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
+  auto ring_issue = [&](long k) {                                // column k -> slot k & 1
+    if (active) {
+      const unsigned o = off_of(k);
+      char* slot = ring_mem + (k & 1) * 4096;
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(y) + o), (lds_void_t*)(slot), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(y2base) + o), (lds_void_t*)(slot + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(x) + o), (lds_void_t*)(slot + 2048), 16, 0, 0);
+      if ((GMASK >> 1) & 1) __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(a.g_ptr[1]) + o), (lds_void_t*)(slot + 3072), 16, 0, 0);
+    }
+  };
+  auto ring_fetch = [&](long k, bool next_in_flight, Col& in) {
+    typedef typename VecOf<T>::native V4;
+    if (next_in_flight) { if (NB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned addr = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ring_mem) + (unsigned)(k & 1) * 4096u + (unsigned)lane * 16u;
+    V4 v0, v1, v2, v3 = {};
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(addr) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v1) : "v"(addr) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(v2) : "v"(addr) : "memory");
+    if ((GMASK >> 1) & 1) asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(v3) : "v"(addr) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) :: "memory");
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { in.y1[j] = v0[j]; in.y2[j] = v1[j]; in.x[j] = v2[j]; if ((GMASK >> 1) & 1) in.gc[slot_ofb(GMASK, 1)][j] = v3[j]; }
   };
   // primal step at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 inlined)
   // `inner` (a compile-time tag): every row of the wave and the columns c-1 .. c+1 are strictly inside
@@ -229,7 +271,18 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
   }
   // prefetch depth PF: columns c+3 .. c+1+PF are in flight / in registers ahead of their use
   Col ahead[PF > 1 ? PF - 1 : 1] = {};
-  if (active) {
+  if (kRing) {
+    // lanes outside the image never receive LDS-DMA data: their slices of both slots read as zeros, like the register version's
+    typedef typename VecOf<T>::native V4;
+    V4* rz = reinterpret_cast<V4*>(ring_mem);
+    const V4 zero = {};
+#pragma unroll
+    for (int k = 0; k < 8; k++) rz[k * kWave + lane] = zero;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (active && xa - 2 >= 0) ldv_o<T, VEC, RAG>(y, off_of(xa - 2), in2.y1, nvalid);     // becomes in1.y1 at the top of the first step
+    if (has_col(xa - 1)) ring_issue(xa - 1);
+    ring_issue(xa);
+  } else if (active) {
     if (xa - 2 >= 0) ldv_o<T, VEC, RAG>(y, off_of(xa - 2), in1.y1, nvalid);
     if (xa - 1 >= 0) load_col(xa - 1, in2);
 #pragma unroll
@@ -240,9 +293,14 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
   auto step = [&](auto inner, long c) {
     Col pre = {};
     constexpr long kAhead = 2 + PF;
-    const bool has_pre = c + kAhead < nx && c + kAhead <= xb + 1;
+    const bool has_pre = !kRing && c + kAhead < nx && c + kAhead <= xb + 1;
     if (active && has_pre) load_col(c + kAhead, pre);
     const long ca = c + 2, cb = c + 1;
+    if (kRing) {
+      in1 = in2;
+      if (has_col(ca)) ring_fetch(ca, has_col(ca + 1), in2); else in2 = Col{};
+      if (has_col(ca + 2)) ring_issue(ca + 2);                 // into the slot just read (the reads above have completed)
+    }
     if (ca >= 0 && ca < nx) {                                                                     // stage A
       // lane 0 gets no row above: its first row is never needed (the top halo is its LAST row)
       const T up = lane_up(in2.y2[VEC - 1]);
@@ -285,8 +343,9 @@ __global__ void __launch_bounds__(kWave, FAST ? ((MODE & 2) ? 2 : (PF > 1 || MOD
       }
     }
     // shift the pipeline by one column
-    in1 = in2;
-    if (PF > 1) {
+    if (!kRing) in1 = in2;
+    if (kRing) {
+    } else if (PF > 1) {
       in2 = ahead[0];
 #pragma unroll
       for (int k = 0; k + 1 < PF - 1; k++) ahead[k] = ahead[k + 1];
@@ -344,15 +403,17 @@ static bool iter2_fast_shape(const prost_hip_fused_desc* d) {
 // chunk length (columns per wavefront) of a launch; `res`: the launch also forms the residual sums
 static int iter2_chunk_cols(const prost_hip_fused_desc* d, int V, bool res, int cols) {
   const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
+  // resident wavefronts per SIMD of the instance that will run: LDS-ring instances 4 (3 with the residual sums), register-ring
+  // instances 3 (2)
+  static const bool no_ring = []() { const char* e = getenv("PROST_ITER2_NO_RING"); return e && atoi(e) != 0; }();
+  const bool ring = !no_ring && iter2_fast_shape(d) && d->ny % (size_t)V == 0;
   if (cols <= 0) {
-    // The kernel is bound by wave-level latency as much as by HBM: 3 resident waves per SIMD (<= 168
-    // VGPRs) with the loads of three columns in flight per wave beat 4 waves with one (measured same box,
-    // 4096^2: 0.1166 vs 0.1207 ms).  256 CUs x 4 SIMDs x 3 wave slots: take the longest chunk (3 warm-up
-    // columns are amortised over it) that still fills >= 90 % of the slots in ONE round -- a second,
-    // mostly empty round costs a full chunk time (24 cols = 2907 waves 0.117 ms, 18 cols = 3876 waves
-    // 0.127 ms, 21 cols 0.133 ms).  Chunk lengths stay off multiples of 16 (HBM channel spread).
-    // (the residual instance holds 4 double accumulators and runs 2 waves per SIMD, the others 3)
-    const size_t slots = 256 * 4 * (size_t)(res ? 2 : 3);
+    // The kernel is bound by wave-level latency as much as by HBM.  256 CUs x 4 SIMDs x resident waves: take the longest
+    // chunk (3 warm-up columns are amortised over it) that still fills >= 90 % of the slots in ONE round -- a second,
+    // mostly empty round costs a full chunk time (register ring, 3 waves / SIMD: 24 cols = 2907 waves 0.117 ms, 18 cols =
+    // 3876 waves 0.127 ms; LDS ring, 4 waves / SIMD: 18 and 24 cols 0.100 ms, 36 cols 0.117; with the residual sums, 3
+    // waves: 24 cols 0.116 ms, 18 cols 0.121, 36 cols 0.122).  Chunk lengths stay off multiples of 16 (HBM channel spread).
+    const size_t slots = 256 * 4 * (size_t)(ring ? (res ? 3 : 4) : (res ? 2 : 3));
     cols = 0;
     for (int c : {36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
     if (cols == 0) {
@@ -406,7 +467,11 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   const bool rag = d->ny % V != 0;
   double* partial = static_cast<double*>(ws);
 #define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
-#define GO3(G, F, M, PFv, FASTv, MODEv) do { if (rag) GO4(G, F, M, PFv, FASTv, MODEv, true); else GO4(G, F, M, PFv, FASTv, MODEv, false); } while (0)
+// straight-line instances of heights that are a multiple of the vector width prefetch through the LDS ring (PF = 0); ragged
+// heights (4-byte aligned column starts) keep the register ring
+// (PROST_ITER2_NO_RING=1 forces the register ring everywhere: A/B measurements)
+  static const bool no_ring = []() { const char* e = getenv("PROST_ITER2_NO_RING"); return e && atoi(e) != 0; }();
+#define GO3(G, F, M, PFv, FASTv, MODEv) do { if (rag) GO4(G, F, M, PFv, FASTv, MODEv, true); else if (no_ring) GO4(G, F, M, PFv, FASTv, MODEv, false); else GO4(G, F, M, (FASTv ? 0 : PFv), FASTv, MODEv, false); } while (0)
 #define GO(G, F, M, PFv, FASTv) do { if (mode == 0) GO3(G, F, M, PFv, FASTv, 0); else if (mode == 1) GO3(G, F, M, PFv, FASTv, 1); else if (mode == 2) GO3(G, F, M, PFv, FASTv, 2); else GO3(G, F, M, PFv, FASTv, 3); } while (0)
   if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 3, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 3, true); }
   else if (fast && mask == 0x2) {
