@@ -119,14 +119,14 @@ struct FusedArgs {
 // value of the row above the first row of this lane (row0 - 1): neighbour lane's last element
 template <class T, int VEC>
 __device__ __forceinline__ T row_above(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, bool active) {
-  T up = __shfl_up(v[VEC - 1], 1, kWave);
+  T up = lane_up(v[VEC - 1]);
   if ((threadIdx.x & (kWave - 1)) == 0 && active && row0 > 0) up = col_base[row0 - 1];
   return up;
 }
 // value of the row below the last row of this lane (row0 + VEC)
 template <class T, int VEC>
 __device__ __forceinline__ T row_below(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, size_t ny, bool active) {
-  T dn = __shfl_down(v[0], 1, kWave);
+  T dn = lane_down(v[0]);
   if ((threadIdx.x & (kWave - 1)) == kWave - 1 && active && row0 + VEC < ny) dn = col_base[row0 + VEC];
   return dn;
 }

@@ -105,10 +105,10 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
   auto primal_col = [&](size_t c, const Col& in, const Col& prev, bool have_prev, bool owned, T (&xn)[LCH][VEC]) {
 #pragma unroll
     for (int l = 0; l < LCH; l++) {
-      T up = __shfl_up(in.y2[l][VEC - 1], 1, kWave);
+      T up = lane_up(in.y2[l][VEC - 1]);
       if (lane == 0) up = in.up[l];
       T upp = 0;
-      if (RES) { upp = __shfl_up(in.p2[RES ? l : 0][RES ? VEC - 1 : 0], 1, kWave); if (lane == 0) upp = in.upp[RES ? l : 0]; }
+      if (RES) { upp = lane_up(in.p2[RES ? l : 0][RES ? VEC - 1 : 0]); if (lane == 0) upp = in.upp[RES ? l : 0]; }
       T ktyv[VEC], parg[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
     T bel_n[LCH], bel_o[LCH];
 #pragma unroll
     for (int l = 0; l < LCH; l++) {
-      bel_n[l] = __shfl_down(xn_c[l][0], 1, kWave);
-      bel_o[l] = __shfl_down(cur.x[l][0], 1, kWave);
+      bel_n[l] = lane_down(xn_c[l][0]);
+      bel_o[l] = lane_down(cur.x[l][0]);
     }
     if (owner) {
       T out[2 * LCH][VEC];

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
   auto primal_col = [&](size_t c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&v3m)[VEC], bool has_below_plane,
                         const T (&p1)[VEC], bool have_prev, T upv, const T (&xv)[VEC], const T (&bv)[GB ? VEC : 1], T (&xn)[VEC],
                         T (&ktyv)[RES ? VEC : 1]) {
-    T up = __shfl_up(v2[VEC - 1], 1, kWave);
+    T up = lane_up(v2[VEC - 1]);
     if (lane == 0) up = upv;
     T parg[VEC];
 #pragma unroll
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
 
   // dual_residual_transform (backend_pdhg.cu:73-94) for the own plane at column c
   auto dual_residual = [&](size_t c, const Col& in, const T (&pp1)[RES ? VEC : 1], bool have_prev, const T (&xn)[VEC], const T (&ktyv)[RES ? VEC : 1], bool counted) {
-    T upp = __shfl_up(in.p2[RES ? VEC - 1 : 0], 1, kWave);
+    T upp = lane_up(in.p2[RES ? VEC - 1 : 0]);
     if (lane == 0) upp = in.pup;
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_n
       if (owner && c + 1 < xb) stv_nt<T, VEC>(x_new + plane + (c + 1) * ny + row0, xn_n);
     }
     // ---- dual step of column c (backend_pdhg.cu:341-370 with block_gradient3d.cu:62-80) ----
-    const T bel_n = __shfl_down(xn_c[0], 1, kWave);
-    const T bel_o = __shfl_down(cur.x[0], 1, kWave);
+    const T bel_n = lane_down(xn_c[0]);
+    const T bel_o = lane_down(cur.x[0]);
     if (owner) {
       T out[3][VEC];
       T av[FAST ? 3 : 1][FAST ? VEC : 1], nv[FAST ? VEC : 1];

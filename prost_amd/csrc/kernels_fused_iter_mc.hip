@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
   };
   // x_new of this channel at column c (backend_pdhg.cu:317-338, block_gradient2d.cu:122-138 on a zero-filled result)
   auto primal_col = [&](size_t c, const Col& in, const T (&p1)[VEC], bool have_prev, T (&xn)[VEC], const T (&pp1)[RES ? VEC : 1], bool counted) {
-    T up = __shfl_up(in.y2[VEC - 1], 1, kWave);
+    T up = lane_up(in.y2[VEC - 1]);
     if (lane == 0) up = in.up;
     T parg[VEC], ktyv[RES ? VEC : 1];
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? in.b[GB ? j : 0] : a.g_val[1]);
     }
     if (RES) {                                              // dual_residual_transform (backend_pdhg.cu:73-94)
-      T upp = __shfl_up(in.p2[RES ? VEC - 1 : 0], 1, kWave);
+      T upp = lane_up(in.p2[RES ? VEC - 1 : 0]);
       if (lane == 0) upp = in.pup;
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       if (owner && c + 1 < xb) stv_nt<T, VEC>(x_new + plane + (c + 1) * ny + row0, xn_n);
     }
     // ---- dual step of column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77) ----
-    const T bel_n = __shfl_down(xn_c[0], 1, kWave);
-    const T bel_o = __shfl_down(cur.x[0], 1, kWave);
+    const T bel_n = lane_down(xn_c[0]);
+    const T bel_o = lane_down(cur.x[0]);
     T av[2][VEC];
     T kxv[RES ? 2 : 1][RES ? VEC : 1], kpv[RES ? 2 : 1][RES ? VEC : 1];
     const int buf = (int)(c & 1);
