@@ -192,6 +192,9 @@ def main():
     dist = None
     if multi:
         import torch.distributed as dist
+        # PROST_BENCH_FORCE_DIST without a launcher: a one-rank rendezvous on the loopback interface
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
+            os.environ.setdefault(k, v)
         if host_transport:
             dist.init_process_group(backend="gloo")
         else:
@@ -333,8 +336,14 @@ def main():
         prost.comm_destroy()
         dist.destroy_process_group()
     if out is not None:
-        # the ONE JSON line, last thing on stdout (RCCL prints its version banner while the communicators are created)
+        # the ONE JSON line, last thing on stdout: RCCL prints its version banner through C stdio while the communicators are
+        # created, which sits in the C buffer until the process exits when stdout is a pipe -- flush it first
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
 
