@@ -199,3 +199,37 @@ def test_glibc_rand_stream_is_generated_chunk_parallel_and_stays_exact():
         assert np.array_equal(got, oracle.glibc_rand(1, n).astype(np.float64) / 2147483647.0)
     finally:
         prost.set_precision("double")
+
+
+@pytest.mark.parametrize("precision", ["single", "double"])
+def test_constant_preconditioners_of_a_single_stencil_block_match_the_oracle_sweep(precision):
+    """A problem whose operator is ONE gradient block takes the constant-preconditioner path (Block::uniform_sums,
+    Prox::average_uniform: no sweep, no per-entry averaging); the vectors it stands for must be what the oracle's sweep and
+    group averaging (problem.cu:262-287, :503-536) produce: gray / RGB gradient2d with sum_norm2 over 2 / 6 components,
+    gradient3d with 3, every alpha, and a conjugated (Moreau-wrapped) f"""
+    from prost_amd import synthetic
+    prost.set_precision(precision)
+    try:
+        dt = np.float32 if precision == "single" else np.float64
+        cases = []
+        for L in (1, 3):
+            cases.append(synthetic.rof_problem(7, 5, L, seed=3)[0])
+        cases.append(synthetic.tv3d_problem(6, 5, 4, seed=3)[0])
+        u, q = prost.variable(7 * 5), prost.variable(2 * 7 * 5)
+        p = prost.min_max_problem([u], [q])
+        p.add_dual_pair(u, q, prost.block.gradient2d(7, 5, 1))
+        p.add_function(u, prost.function.sum_1d("square", 1, np.linspace(0, 1, 35), 10))
+        p.add_function(q, prost.function.conjugate(prost.function.sum_norm2(2, False, "abs", 1, 0, 1)))
+        cases.append(p)
+        for prob in cases:
+            for alpha in (1.0, 0.5, 2.0, 0.0):
+                prob.set_scaling_alpha(alpha)
+                info = prost.problem_info(prob)
+                P = oracle.Problem(prob.data, prob.nrows, prob.ncols, dt)
+                P.initialize()
+                sl, sr = P.scaling()
+                assert np.array_equal(np.asarray(info["scaling_left"]), sl), alpha
+                assert np.array_equal(np.asarray(info["scaling_right"]), sr), alpha
+                assert np.unique(sl).size == 1 and np.unique(sr).size == 1
+    finally:
+        prost.set_precision("double")
