@@ -1,0 +1,330 @@
+// kernels_fused_iter3d_x2.hip -- gradient3d, TWO PDHG iterations per kernel launch (temporal blocking in 3-D).
+//
+// fused_iter3d_pw_kernel (one iteration per launch, planes across the wavefronts of a workgroup) is memory-bound: 2.19 ms at
+// 2048 x 2048 x 64 against 1.28 ms with every access served from cache.  Here a workgroup of WT wavefronts owns P = WT - 3
+// consecutive planes of one (row strip, column chunk) and every wavefront runs the 4-stage column pipeline of the 2-D pair
+// kernel (kernels_fused_iter2.hip) on ITS plane, one column further apart:
+//     A(c+2): x1 = primal step of iteration k            B(c+1): y1 = dual step of iteration k
+//     C(c)  : x2 = primal step of iteration k+1          D(c-1): y2 = dual step of iteration k+1
+// What a stage needs from a neighbouring plane -- x1(l+1) for B, the third component of y1(l-1) for C, x2(l+1) for D -- was
+// published through double-buffered LDS in the PREVIOUS column step by the wavefront of that plane, so ONE workgroup barrier
+// per column orders everything.  Planes l0 .. l0+P-1 are owned (x^(k+2), y^(k+2) stored); the wavefront of plane l0-1 runs A
+// and B only, that of plane l0+P runs A, B, C, that of plane l0+P+1 runs A only (helper planes: 4P+6 stage units per P planes).
+// Row neighbours come from adjacent lanes, lanes 0 and 63 are halo lanes exactly as in the 2-D pair kernel.
+// Every stage evaluates the expressions of kernels_fused_iter3d_pw.hip / kernels_fused3d.hip, so x^(k+2), y^(k+2) are
+// bit-identical to two single launches (tests/test_gpu_fused3d.py).  Straight-line ROF shape only (prox_g square with scalar
+// a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), fp32, heights that are a multiple of
+// the vector width; no residual sums, no stored intermediate iterate: BackendPDHG pairs only iterations nobody observes.
+#include "fused_common.hpp"
+
+namespace prost_hip {
+
+template <class T>
+struct IterParams3 {           // step sizes of one iteration + the host-evaluated divisor of Function1DSquare
+  T tau, sigma, theta;
+  UniformDiv sq;
+};
+
+// VEC consecutive rows per lane (4: 16-byte accesses, 2: 8-byte accesses)
+template <class T, int VEC>
+__device__ __forceinline__ void ldx(const T* __restrict__ p, T (&v)[VEC]) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  const V t = *reinterpret_cast<const V*>(p);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) v[j] = t[j];
+}
+template <class T, int VEC>
+__device__ __forceinline__ void stx_nt(T* __restrict__ p, const T (&v)[VEC]) {
+  typedef T V __attribute__((ext_vector_type(VEC)));
+  V t;
+#pragma unroll
+  for (int j = 0; j < VEC; j++) t[j] = v[j];
+  __builtin_nontemporal_store(t, reinterpret_cast<V*>(p));
+}
+
+template <class T, int VEC, bool GB>
+struct ColX2 {
+  T y1[VEC], y2[VEC], y3[VEC], x[VEC], b[GB ? VEC : 1];   // own plane
+  T zx[VEC];                                              // x of the plane above (old iterate, for K x_prev of stage B)
+  T y3m[VEC];                                             // y3 of the plane below (stage A)
+};
+
+template <class T, int VEC, bool GB, int WT>
+__global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
+                                                                       const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2) {
+  constexpr int kRowsPerWave = (kWave - 2) * VEC;
+  constexpr int kPix = kWave * VEC;
+  constexpr int P = WT - 3;                            // planes a workgroup owns
+  __shared__ T s_x1[2][WT][kPix], s_y3[2][WT][kPix], s_x2[2][WT][kPix];
+  const long nx = (long)a.nx, ny = (long)a.ny, L = (long)a.L;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const unsigned groups = (unsigned)((L + P - 1) / P);
+  const unsigned total = gridDim.x, chunks = a.chunks;
+  const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // XCD-aware tile order: plane group fastest
+  const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
+  // row strip fastest: the workgroups that run side by side read whole columns (8 KB at 2048 rows) and share the lines their halo
+  // lanes touch; then the plane group (neighbouring groups share their helper planes), then the column chunk
+  // (2048 x 2048 x 64, same box: 1.55 ms per iteration against 1.69 ms with the plane group fastest and the strip slowest)
+  const unsigned strips_n = total / (groups * chunks);
+  const unsigned strip = tile % strips_n, grp = (tile / strips_n) % groups, chunk = tile / (strips_n * groups);
+  const long pl = (long)grp * P - 1 + wv;              // this wavefront's plane (may lie outside the volume: idle, still takes part in the barriers)
+  const bool exists = pl >= 0 && pl < L;
+  const long l = exists ? pl : 0;
+  const bool do_y1 = exists && wv <= P + 1;
+  const bool do_x2 = exists && wv >= 1 && wv <= P + 1;
+  const bool do_y2 = exists && wv >= 1 && wv <= P;
+  const bool has_above = exists && l + 1 < L, has_below = exists && l > 0;
+  const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
+  const bool active = exists && row0 >= 0 && row0 < ny;
+  const bool owner = active && lane > 0 && lane < kWave - 1;
+  const long xa = (long)chunk * a.cols_per_block;
+  const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const size_t Pn = (size_t)nx * (size_t)ny, N = Pn * (size_t)L, plane = (size_t)l * Pn;
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
+  const T* y1p = y + plane; const T* y2p = y + N + plane; const T* y3p = y + 2 * N + plane;
+  const T* xp = x + plane;
+  const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
+
+  typedef ColX2<T, VEC, GB> Col;
+  auto load_col = [&](long c, Col& in) {
+    const size_t o = (size_t)c * (size_t)ny + (size_t)row0;
+    ldx<T, VEC>(y1p + o, in.y1); ldx<T, VEC>(y2p + o, in.y2); ldx<T, VEC>(y3p + o, in.y3); ldx<T, VEC>(xp + o, in.x);
+    if constexpr (GB) ldx<T, VEC>(bp + o, in.b);
+    if (has_above) ldx<T, VEC>(xp + Pn + o, in.zx);
+    if (has_below) ldx<T, VEC>(y3p - Pn + o, in.y3m);
+  };
+  // primal step at column c of this plane (backend_pdhg.cu:317-338 with block_gradient3d.cu:127-149 on a zero-filled result);
+  // v1 / v2 / v3: the dual variable at column c, p1c: its first component at column c-1, v3m: its third component one plane below
+  auto primal = [&](long c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&p1c)[VEC], const T (&v3m)[VEC],
+                    const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1], const IterParams3<T>& Pm, T (&xn)[VEC]) {
+    const T tauT = Pm.tau * a.Tval;
+    const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
+    T parg[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const long row = row0 + j;
+      T divy = (row < ny - 1) ? v2[j] : (T)0;
+      if (row > 0) divy -= (j > 0 ? v2[j > 0 ? j - 1 : 0] : up);
+      T divx = (c < nx - 1) ? v1[j] : (T)0;
+      if (c > 0) divx -= p1c[j];
+      T divl = v3[j];
+      if (has_below) divl -= v3m[j];
+      const T kty = (T)0 - (divx + divy + divl);
+      const T arg = xin[j] - tauT * kty;
+      parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
+    }
+    T r[VEC];
+    div_to_float_exact_vec<VEC>(parg, Pm.sq, r);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? bv[GB ? j : 0] : a.g_val[1]);
+  };
+  // dual step at column c of this plane (backend_pdhg.cu:341-370 with block_gradient3d.cu:62-80): xn_* the new primal iterate at
+  // columns c / c+1 / one plane above, xo_* the old one, v* the dual variable at column c
+  auto dual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+                  const T (&xo_z)[VEC], const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const IterParams3<T>& Pm,
+                  T (&out)[3][VEC]) {
+    const T sigS = Pm.sigma * a.Sval, theta = Pm.theta;
+    const bool has_next = c + 1 < nx;
+    const T bel_n = lane_down(xn_c[0]);                // lane 63: no source, its last row is halo
+    const T bel_o = lane_down(xo_c[0]);
+    T av[3][VEC], nv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const long row = row0 + j;
+      const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
+      const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
+      T kx[3], kp[3];
+      kx[0] = has_next ? xn_n[j] - xn_c[j] : (T)0;
+      kx[1] = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
+      kx[2] = has_above ? xn_z[j] - xn_c[j] : -xn_c[j];                        // Dirichlet (:73-76)
+      kp[0] = has_next ? xo_n[j] - xo_c[j] : (T)0;
+      kp[1] = (row < ny - 1) ? below_o - xo_c[j] : (T)0;
+      kp[2] = has_above ? xo_z[j] - xo_c[j] : -xo_c[j];
+      const T yv[3] = {v1[j], v2[j], v3[j]};
+      T norm = 0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const T arg = yv[i] + sigS * ((1 + theta) * kx[i] - theta * kp[i]);     // backend_pdhg.cu:54-70
+        norm += arg * arg;
+        av[i][j] = arg;
+      }
+      nv[j] = norm;
+    }
+    norm2_leq0_fast<T, 3, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+  };
+  auto publish = [&](T (&buf)[WT][kPix], const T (&v)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) buf[wv][j * kWave + lane] = v[j];             // [j][lane]: conflict-free banks
+  };
+  auto fetch = [&](const T (&buf)[WT][kPix], int w, T (&v)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) v[j] = buf[w][j * kWave + lane];
+  };
+
+  Col in1 = {}, in2 = {};                              // raw columns c+1 and c+2
+  T b_c[GB ? VEC : 1];                                 // b of prox_g at column c (stage C)
+  T x1_m[VEC], x1_0[VEC], x1_1[VEC], x1_2[VEC];        // x^(k+1) at columns c-1 .. c+2
+  T xz1_m[VEC], xz1_0[VEC], xz1_1[VEC];                // x^(k+1) one plane above at columns c-1 .. c+1 (from LDS)
+  T ya_m[VEC], yb_m[VEC], yc_m[VEC], ya_0[VEC], yb_0[VEC], yc_0[VEC], ya_1[VEC], yb_1[VEC], yc_1[VEC];   // y^(k+1) at columns c-1, c, c+1
+  T x2_m[VEC], x2_0[VEC];                              // x^(k+2) at columns c-1, c
+  T xz2_m[VEC];                                        // x^(k+2) one plane above at column c-1 (from LDS)
+  T ym3_0[VEC];                                        // third component of y^(k+1) one plane below at column c (from LDS)
+#pragma unroll
+  for (int j = 0; j < VEC; j++) {
+    x1_m[j] = x1_0[j] = x1_1[j] = x1_2[j] = 0; xz1_m[j] = xz1_0[j] = xz1_1[j] = 0;
+    ya_m[j] = yb_m[j] = yc_m[j] = ya_0[j] = yb_0[j] = yc_0[j] = ya_1[j] = yb_1[j] = yc_1[j] = 0;
+    x2_m[j] = x2_0[j] = 0; xz2_m[j] = 0; ym3_0[j] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = 0;
+  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
+  if (active) {
+    if (xa - 2 >= 0) ldx<T, VEC>(y1p + (size_t)(xa - 2) * (size_t)ny + (size_t)row0, in2.y1);   // becomes in1.y1 for A(xa-1)
+  }
+  Col pre = {};
+  if (active && has_col(xa - 1)) load_col(xa - 1, pre);
+
+  for (long c = xa - 3; c <= xb; c++) {
+    const int wr = (int)((c + 4) & 1), rd = wr ^ 1;
+    // raw columns: in1 <- in2 <- pre, prefetch column c+3
+    in1 = in2; in2 = pre;
+    pre = Col{};
+    if (active && has_col(c + 3)) load_col(c + 3, pre);
+    // neighbour-plane values published in the previous step
+    if (has_above && wv + 1 < WT) { fetch(s_x1[rd], wv + 1, xz1_1); fetch(s_x2[rd], wv + 1, xz2_m); }
+    if (has_below && wv >= 1) fetch(s_y3[rd], wv - 1, ym3_0);
+    const long ca = c + 2, cb = c + 1, cd = c - 1;
+    if (exists && ca >= (xa - 1 > 0 ? xa - 1 : 0) && ca < nx && ca <= xb + 1) {                    // stage A
+      primal(ca, in2.y1, in2.y2, in2.y3, in1.y1, in2.y3m, in2.x, in2.b, p1, x1_2);
+      publish(s_x1[wr], x1_2);
+    }
+    if (do_y1 && cb >= (xa - 1 > 0 ? xa - 1 : 0) && cb < nx && cb <= xb) {                         // stage B
+      T o[3][VEC];
+      dual(cb, x1_1, x1_2, xz1_1, in1.x, in2.x, in1.zx, in1.y1, in1.y2, in1.y3, p1, o);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { ya_1[j] = o[0][j]; yb_1[j] = o[1][j]; yc_1[j] = o[2][j]; }
+      publish(s_y3[wr], yc_1);
+    }
+    if (do_x2 && c >= xa && c < nx && c <= xb) {                                                  // stage C
+      primal(c, ya_0, yb_0, yc_0, ya_m, ym3_0, x1_0, b_c, p2, x2_0);
+      publish(s_x2[wr], x2_0);
+      if (do_y2 && owner && c < xb) stx_nt<T, VEC>(x_out + plane + (size_t)c * (size_t)ny + (size_t)row0, x2_0);
+    }
+    if (do_y2 && cd >= xa && cd < xb) {                                                           // stage D
+      T o[3][VEC];
+      dual(cd, x2_m, x2_0, xz2_m, x1_m, x1_0, xz1_m, ya_m, yb_m, yc_m, p2, o);
+      if (owner) {
+        const size_t off = plane + (size_t)cd * (size_t)ny + (size_t)row0;
+        stx_nt<T, VEC>(y_out + off, o[0]); stx_nt<T, VEC>(y_out + N + off, o[1]); stx_nt<T, VEC>(y_out + 2 * N + off, o[2]);
+      }
+    }
+    __syncthreads();                                   // one barrier per column: the buffers written now are read in the next step
+    // shift the pipeline by one column
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      x1_m[j] = x1_0[j]; x1_0[j] = x1_1[j]; x1_1[j] = x1_2[j];
+      xz1_m[j] = xz1_0[j]; xz1_0[j] = xz1_1[j];
+      ya_m[j] = ya_0[j]; yb_m[j] = yb_0[j]; yc_m[j] = yc_0[j];
+      ya_0[j] = ya_1[j]; yb_0[j] = yb_1[j]; yc_0[j] = yc_1[j];
+      x2_m[j] = x2_0[j];
+    }
+#pragma unroll
+    for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = in1.b[j];
+  }
+}
+
+bool fused3d_desc_ok(const prost_hip_fused_desc* d);
+
+// rows per lane / wavefronts per workgroup of the instance that runs (see the header of this file)
+constexpr int kX2Vec = 2, kX2Waves = 16;
+
+// straight-line ROF shape, fp32, heights that are a multiple of the vector width
+static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
+  if (dtype != 0 || !fused3d_desc_ok(d)) return false;
+  if (d->ny % kX2Vec != 0 || d->ny < 4 || d->nx < 4) return false;
+  if (d->g_fn != PROST_FN_SQUARE || d->f_fn != PROST_FN_IND_LEQ0) return false;
+  for (int k = 0; k < 7; k++) {
+    if (d->f_coeff_ptr[k]) return false;
+    if (k != 1 && d->g_coeff_ptr[k]) return false;
+  }
+  if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
+  if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
+  if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
+  if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
+  const size_t strips = (d->ny + 62 * kX2Vec - 1) / (62 * kX2Vec);
+  return strips * ((d->L + kX2Waves - 4) / (kX2Waves - 3)) * d->nx < (size_t)1 << 31;
+}
+
+static int compute_units() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount; else n = 256;
+  }
+  return n;
+}
+
+// One workgroup per compute unit is resident (16 wavefronts x 126 VGPRs) and all workgroups take equally long, so a launch lasts
+// (rounds of workgroups) x (column steps of a workgroup): pick the number of column chunks that minimises
+// ceil(strips * groups * chunks / CUs) * (columns per chunk + 4 warm-up steps).  2048 x 2048 x 64 on 256 CUs: 17 x 5 x 3 = 255
+// workgroups, ONE round of 687 steps (64-column chunks: 11 rounds of 68 steps = 748).
+static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int cols) {
+  if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
+  constexpr int P = kX2Waves - 3;
+  const size_t tiles = ((d->ny + (size_t)(kWave - 2) * kX2Vec - 1) / ((size_t)(kWave - 2) * kX2Vec)) * ((d->L + P - 1) / P);
+  const size_t cus = (size_t)compute_units();
+  size_t best_c = d->nx, best_cost = (size_t)-1;
+  for (size_t n = 1; n <= d->nx; n++) {
+    const size_t c = (d->nx + n - 1) / n;
+    if (c < 8 && n > 1) break;
+    const size_t cost = ((tiles * ((d->nx + c - 1) / c) + cus - 1) / cus) * (c + 4);
+    if (cost < best_cost) { best_cost = cost; best_c = c; }
+  }
+  return best_c;
+}
+
+template <class T, int V, int WT>
+static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const IterParams3<T> (&p)[2], int cols, hipStream_t s) {
+  constexpr int P = WT - 3;
+  FusedArgs<T> a = make_fused_args<T>(d);
+  const size_t groups = (d->L + P - 1) / P;
+  const size_t strips = (d->ny + (size_t)(kWave - 2) * V - 1) / ((size_t)(kWave - 2) * V);
+  const size_t c = x2_chunk_cols(d, cols);
+  a.cols_per_block = (int)c;
+  a.chunks = (unsigned)((d->nx + c - 1) / c);
+  const unsigned grid = (unsigned)(strips * a.chunks * groups);
+  if (d->g_coeff_ptr[1]) hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, true, WT>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1]);
+  else hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, false, WT>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1]);
+  PH_LAUNCH_END("fused 3-D double iteration kernel");
+}
+
+template <class T>
+static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
+                         const double* theta, int cols, void* stream) {
+  if (!iter3d_x2_ok(d, 0)) { set_error("fused 3-D double iteration: unsupported description (see prost_hip_fused_iteration3d_x2_supported)"); return 1; }
+  if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused 3-D double iteration: vectors must be 16-byte aligned"); return 1; }
+  if (x_out == x || y_out == y) { set_error("fused 3-D double iteration: outputs must not alias inputs"); return 1; }
+  FusedArgs<T> a = make_fused_args<T>(d);
+  IterParams3<T> p[2];
+  for (int i = 0; i < 2; i++) {
+    p[i].tau = (T)tau[i]; p[i].sigma = (T)sigma[i]; p[i].theta = (T)theta[i];
+    const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau[i] * a.Tval);
+    const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma[i] * a.Sval);
+    if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused 3-D double iteration: not the straight-line ROF shape"); return 1; }
+    p[i].sq = ug.sq;
+  }
+  return launch_iter3d_x2<T, kX2Vec, kX2Waves>(d, x_out, y_out, x, y, p, cols, as_stream(stream));
+}
+
+}  // namespace prost_hip
+
+using namespace prost_hip;
+
+extern "C" {
+int prost_hip_fused_iteration3d_x2_supported(const prost_hip_fused_desc* d, int dtype) { return iter3d_x2_ok(d, dtype) ? 1 : 0; }
+int prost_hip_fused_iteration3d_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype) { return iter3d_x2_ok(d, dtype) ? (int)x2_chunk_cols(d, 0) : 0; }
+int prost_hip_fused_iteration3d_x2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
+                                       const double* sigma, const double* theta, int cols, void* stream) {
+  return run_iter3d_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, stream);
+}
+}  // extern "C"

@@ -173,7 +173,55 @@ def test_single_kernel_3d_iteration_equals_two_passes(hip, dtype, shape, fns, ve
     hip.sync()
 
 
-@pytest.mark.parametrize("kernel", ["fused_iteration3d", "fused_iteration3d_pw", "fused_iteration_mc"])
+@pytest.mark.parametrize("shape", [(6, 8, 1), (5, 12, 4), (20, 1028, 3), (33, 64, 5), (4, 256, 2), (40, 508, 6), (7, 16, 9), (5, 24, 15), (64, 252, 11), (9, 248, 7), (9, 250, 14), (5, 6, 29), (12, 130, 13), (70, 126, 27)])
+@pytest.mark.parametrize("vector_b", [True, False])
+@pytest.mark.parametrize("radius", [1.0, 1e-7])
+def test_double_3d_iteration_equals_two_single_launches(hip, shape, vector_b, radius):
+    """prost_hip_fused_iteration3d_x2 (two iterations per launch, planes across wavefronts, stages meeting in LDS) against two
+    iterations of the two-pass kernels, which are pinned to the oracle above: same bits for
+    x^(k+2) and all three components of y^(k+2), for every chunk width (1: every column a chunk border; 64: one chunk), plane
+    counts below / equal to / above the 13 planes a workgroup owns (helper planes outside the volume, several plane groups),
+    strip layouts (126 = one strip + 2 rows, 1028 rows: nine strips) and step sizes that change between the two iterations (alg2)."""
+    dtype = np.float32
+    nx, ny, L = shape
+    rng = np.random.default_rng(11)
+    n, m = nx * ny * L, 3 * nx * ny * L
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    g_coeffs = [1.0, f if vector_b else 0.4, 10.0, 0.0, 0.0, 0.3, 0.0]
+    f_coeffs = [1.0, radius, 1.0, 0.0, 0.0, 0.3, 0.0]
+    d = hip.FusedDesc(); d.is3d = 1; d.nx, d.ny, d.L = nx, ny, L
+    d.g_fn = hip.FN_ID["square"]; d.f_fn = hip.FN_ID["ind_leq0"]
+    gp, gv, k1 = hip.coeff_args(g_coeffs, dtype, n)
+    fp, fv, k2 = hip.coeff_args(f_coeffs, dtype, n)
+    for i in range(7):
+        d.g_coeff_ptr[i] = gp[i]; d.g_coeff_val[i] = gv[i]; d.f_coeff_ptr[i] = fp[i]; d.f_coeff_val[i] = fv[i]
+    d.T_val, d.S_val = 1.0 / 6.0, 0.5
+    assert hip.lib().prost_hip_fused_iteration3d_x2_supported(C.byref(d), 0) == 1
+    assert hip.lib().prost_hip_fused_iteration3d_x2_supported(C.byref(d), 1) == 0           # fp32 only
+    tau, sigma, theta = [0.9, 0.61], [1.1, 1.63], [0.85, 0.67]
+    dx, dy = hip.DeviceArray.from_host(x), hip.DeviceArray.from_host(y)
+    x1 = hip.DeviceArray.zeros(n, dtype); y1 = hip.DeviceArray.zeros(m, dtype)
+    x2 = hip.DeviceArray.zeros(n, dtype); y2 = hip.DeviceArray.zeros(m, dtype)
+    P, D = hip.fn("fused_primal", dtype), hip.fn("fused_dual", dtype)          # the two-pass kernels (any height), pinned to the oracle above
+    ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    hip.check(P(C.byref(d), x1.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau[0]), 1, 0, None, ws.ptr, None))
+    hip.check(D(C.byref(d), y1.ptr, dy.ptr, x1.ptr, dx.ptr, hip.dbl(sigma[0]), hip.dbl(theta[0]), 1, None, ws.ptr, None))
+    hip.check(P(C.byref(d), x2.ptr, x1.ptr, y1.ptr, None, hip.dbl(tau[1]), 1, 0, None, ws.ptr, None))
+    hip.check(D(C.byref(d), y2.ptr, y1.ptr, x2.ptr, x1.ptr, hip.dbl(sigma[1]), hip.dbl(theta[1]), 1, None, ws.ptr, None))
+    x_ref, y_ref = x2.to_host(), y2.to_host()
+    arr = lambda v: (C.c_double * 2)(*v)
+    for cols in (0, 1, 2, 5, 7, 64):
+        xo = hip.DeviceArray.zeros(n, dtype); yo = hip.DeviceArray.zeros(m, dtype)
+        hip.check(hip.lib().prost_hip_fused_iteration3d_x2_f32(C.byref(d), xo.ptr, yo.ptr, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols, None))
+        hx, hy = xo.to_host(), yo.to_host()
+        assert np.array_equal(hx, x_ref), (cols, np.flatnonzero(hx != x_ref)[:8])
+        for k in range(3):
+            assert np.array_equal(hy[k * n:(k + 1) * n], y_ref[k * n:(k + 1) * n]), (cols, k, np.flatnonzero(hy[k * n:(k + 1) * n] != y_ref[k * n:(k + 1) * n])[:8])
+    hip.sync()
+
+
+@pytest.mark.parametrize("kernel", ["fused_iteration3d", "fused_iteration3d_pw", "fused_iteration3d_x2", "fused_iteration_mc"])
 def test_single_kernel_iterations_write_only_their_outputs(hip, kernel):
     """Canary words around the output vectors of the one-kernel iterations (halo lanes, halo columns, helper and idle
     wavefronts must not store anything): shapes whose last row strip, last column chunk and last plane group are
@@ -204,6 +252,9 @@ def test_single_kernel_iterations_write_only_their_outputs(hip, kernel):
                 hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, cols, None, None, None))
             elif kernel == "fused_iteration3d_pw":
                 hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, 0, None))
+            elif kernel == "fused_iteration3d_x2":
+                two = lambda a, b: (C.c_double * 2)(a, b)
+                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, two(0.3, 0.25), two(1.0, 1.2), two(0.9, 0.8), cols, None))
             else:
                 hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, cols, None, None, None))
             hx, hy = bx.to_host(), by.to_host()

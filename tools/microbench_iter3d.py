@@ -45,7 +45,10 @@ def main(nx=2048, ny=2048, Lp=64, cols_list=(0, 6, 12, 18, 24, 36, 48), iters=30
             a, b = i % 2, (i + 1) % 2
             hip.check(P(C.byref(d), x[b].ptr, x[a].ptr, y[a].ptr, None, hip.dbl(0.3), 1, 0, None, ws.ptr, None))
             hip.check(D(C.byref(d), y[b].ptr, y[a].ptr, x[b].ptr, x[a].ptr, hip.dbl(1.0), hip.dbl(0.9), 1, None, ws.ptr, None))
-    t = timed(run2)
+    only = os.environ.get("X2_ONLY") == "1"
+    if only:
+        cols_list = ()
+    t = 1.0 if only else timed(run2)
     print("two-pass   %dx%dx%d %s: %.4f ms/iteration, %.1f it/s, algorithmic (14 values/voxel) %.0f GB/s" % (nx, ny, Lp, np.dtype(dtype).name, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     for cols in cols_list:
         def run1(k):
@@ -56,7 +59,7 @@ def main(nx=2048, ny=2048, Lp=64, cols_list=(0, 6, 12, 18, 24, 36, 48), iters=30
         print("one-kernel cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s, kernel moves (9 values/voxel) %.0f GB/s"
               % (cols, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3), 9 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     PW = hip.fn("fused_iteration3d_pw", dtype)
-    for waves in (4, 8):
+    for waves in (() if only else (4, 8)):
         for cols in (6, 12, 18):
             def runp(k):
                 for i in range(k):
@@ -64,6 +67,15 @@ def main(nx=2048, ny=2048, Lp=64, cols_list=(0, 6, 12, 18, 24, 36, 48), iters=30
                     hip.check(PW(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, waves, None))
             t = timed(runp)
             print("planes-across-waves waves=%d cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s" % (waves, cols, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3)), flush=True)
+    if dtype == np.float32 and L_.prost_hip_fused_iteration3d_x2_supported(C.byref(d), 0) == 1:
+        two = lambda v: (C.c_double * 2)(v, v)
+        for cols in tuple(int(c) for c in os.environ.get("X2_COLS", "0,8,16,24,32,48,64").split(",")):
+            def runx(k):
+                for i in range(k):
+                    a, b = i % 2, (i + 1) % 2
+                    hip.check(L_.prost_hip_fused_iteration3d_x2_f32(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, two(0.3), two(1.0), two(0.9), cols, None))
+            t = timed(runx) / 2
+            print("two iterations per launch cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s" % (cols, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     yp = hip.DeviceArray.from_host((rng.random(m, dtype=np.float32) - 0.5).astype(dtype)); r4 = hip.DeviceArray.zeros(4, np.float64)
 
     def run_res2(k):
@@ -74,6 +86,8 @@ def main(nx=2048, ny=2048, Lp=64, cols_list=(0, 6, 12, 18, 24, 36, 48), iters=30
     def run_res1(k):
         for i in range(k):
             hip.check(I3(C.byref(d), x[1].ptr, y[1].ptr, x[0].ptr, y[0].ptr, yp.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, 0, r4.ptr, ws.ptr, None))
+    if only:
+        return
     print("residual iteration: two-pass %.4f ms, one-kernel %.4f ms" % (timed(run_res2), timed(run_res1)), flush=True)
 
 
