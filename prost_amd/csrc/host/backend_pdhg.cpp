@@ -10,6 +10,7 @@
 // synchronisation of the loop (the reference synchronises after every prox and twice per
 // residual iteration).
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include <cmath>
 #include <iostream>
@@ -112,9 +113,12 @@ void BackendPDHG<T>::Initialize() {
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
-  if (single_kernel_ || single3d_ || single_mc_) y_spare_.resize(m);
   pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_profitable(&desc_, dtype_id<T>()) == 1;
-  if (pair_kernel_) x_spare_.resize(n);
+  pair3d_ = false;
+  if constexpr (std::is_same<T, float>::value)
+    pair3d_ = fused_ && desc_.is3d && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, 0) == 1;
+  if (pair_kernel_ || pair3d_) x_spare_.resize(n);
+  if (single_kernel_ || single3d_ || single_mc_ || pair3d_) y_spare_.resize(m);
 
   CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
   CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
@@ -184,6 +188,12 @@ int BackendPDHG<T>::PerformIterations(int budget) {
     IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
     return 2;
   }
+  // gradient3d: the double-iteration kernel has neither residual sums nor a stored intermediate iterate, so it runs where
+  // none of k, k+1 (its sums) and k+2 (streams y^(k+1)) is a residual iteration: 8 of 10 iterations at residual_iter = 10
+  if (pair3d_ && budget >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 1) && !is_residual_iteration(k + 2)) {
+    IterationPair3D();
+    return 2;
+  }
   PerformIteration();
   return 1;
 }
@@ -244,12 +254,44 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
   iteration_++;
 }
 
+template <typename T>
+void BackendPDHG<T>::IterationPair3D() {
+  if constexpr (std::is_same<T, float>::value) {
+    double tau[2], sigma[2], theta[2];
+    tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
+    stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_;
+    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
+    iteration_++;
+    tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
+    const bool t = BeginSample(kKernelPair);
+    CheckHip(prost_hip_fused_iteration3d_x2_f32(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0, CurrentStream()),
+             "fused_iteration3d_x2");
+    EndSample(t);
+    x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
+    y_.swap(y_prev_);
+    prev_stale_ = true;
+    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+    iteration_++;
+  } else {
+    throw Exception("IterationPair3D: fp32 only");
+  }
+}
+
 /// x_prev_ / y_prev_ hold x^k, y^k (inputs of the last pair launch), x_ / y_ = x^(k+2), y^(k+2): one
 /// single-iteration launch with the step sizes of iteration k rebuilds x^(k+1), y^(k+1) bit for bit.
 template <typename T>
 void BackendPDHG<T>::RebuildPrevious() {
   if (!prev_stale_) return;
   last_end_ = kNoEvent;
+  if (pair3d_ && single3d_)
+    CheckHip(Api<T>::fused_iteration3d(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
+                                       (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration3d");
+  else if (pair3d_) {        // heights the one-kernel iteration does not take (ny % 4 != 0): the two passes
+    CheckHip(Api<T>::fused_primal(&desc_, x_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_, 1, 0, nullptr, workspace_,
+                                  CurrentStream()), "fused_primal");
+    CheckHip(Api<T>::fused_dual(&desc_, y_spare_.data(), y_prev_.data(), x_spare_.data(), x_prev_.data(), (double)stale_sigma_, (double)stale_theta_, 1,
+                                nullptr, workspace_, CurrentStream()), "fused_dual");
+  } else
   CheckHip(Api<T>::fused_iteration(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
                                    (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration");
   x_prev_.swap(x_spare_);
@@ -287,6 +329,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
     // gradient3d: one kernel, x_new stays in registers (9 instead of 14 values per voxel; residual iterations add the
     // y_prev stream of the own plane and the four sums).  Outputs go to the previous-iterate buffers, which a
     // non-residual iteration does not read; on residual iterations y_new goes to y_spare_ (the kernel still reads y_prev_).
+    if (res) RebuildPrevious();      // the residual kernel streams y^(k-1)
     T* y_out = res ? y_spare_.data() : y_prev_.data();
     const bool t3 = BeginSample(res ? kKernelIterRes : kKernelIter);
     if (single3d_pw_ && !res)        // planes across the wavefronts of a workgroup: x_new of the plane above comes through LDS
@@ -300,6 +343,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
     x_.swap(x_prev_);
     if (res) y_prev_.swap(y_spare_);
     y_.swap(y_prev_);
+    prev_stale_ = false;
     if (res) FinishResiduals();
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
@@ -322,6 +366,8 @@ void BackendPDHG<T>::IterationFused(bool res) {
     iteration_++;
     return;
   }
+  if (res) RebuildPrevious();        // the residual primal pass streams y^(k-1)
+  prev_stale_ = false;
   bool t = BeginSample(kKernelPrimal);
   CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
                                 iteration_ >= 2 ? 1 : 0, res ? res_target() + 2 : nullptr, workspace_, s), "fused_primal");
@@ -509,7 +555,7 @@ void BackendPDHG<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& 
 template <typename T>
 size_t BackendPDHG<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
-  if (fused_) return (2 * (n + m) + (single_kernel_ ? m : 0) + (pair_kernel_ ? n : 0)) * sizeof(T);
+  if (fused_) return (2 * (n + m) + (single_kernel_ || single3d_ || single_mc_ || pair3d_ ? m : 0) + (pair_kernel_ || pair3d_ ? n : 0)) * sizeof(T);
   return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511
 }
 
@@ -528,12 +574,13 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
-                                     d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", "fused_iter2d_x2_kernel",
+                                     d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", d3 ? "fused_iter3d_x2_kernel" : "fused_iter2d_x2_kernel",
                                      "fused_iter2d_x2_kernel+mid", "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++) {
     if (!cnt[k]) continue;
-    const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes) : 0;
+    const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes)
+                     : k == kKernelPair && pair3d_ ? prost_hip_fused_iteration3d_x2_chunk_cols(&desc_, dtype_id<T>()) : 0;
     out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k], cols});
   }
   samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;

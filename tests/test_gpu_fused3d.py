@@ -92,6 +92,53 @@ def test_tv3d_pdhg_iterates_match_oracle(hip, precision, dtype, step):
         prost.set_precision("double")
 
 
+@pytest.mark.parametrize("step", ["alg1", "alg2", "boyd"])
+@pytest.mark.parametrize("residual_iter", [1, 3, 4, 5, 10])
+def test_tv3d_pair_schedule_is_invisible(hip, step, residual_iter):
+    """fp32 volumetric TV with two iterations per launch (prost_hip_fused_iteration3d_x2) wherever none of k, k+1, k+2 is a
+    residual iteration: the state after ANY number of iterations -- x, y, the constraint variables z, w (which need the
+    previous iterate, rebuilt by one single launch after a pair), residuals, step sizes -- is bit-identical to the path
+    that launches every iteration separately, and the iterates equal the oracle's."""
+    prost.set_gpu(0)
+    prost.set_precision("single")
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    try:
+        for (nx, ny, L) in ((12, 16, 5), (9, 250, 14), (6, 128, 30)):
+            prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, seed=2)
+            for iters in (2, 3, 4, 5, 9, 10, 11, 23):
+                states = []
+                for pair in (True, False):
+                    b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
+                    b[1]["allow_pair_kernel"] = pair
+                    s = prost.Solver(prob, b, o)
+                    info = s.iterate(iters, time_kernels=True, sample_every=1)
+                    names = list(info["kernels"])
+                    st = s.state()
+                    s.iterate(7)              # a second batch: the pairing restarts from another offset
+                    st2 = s.state()
+                    s.destroy()
+                    assert st["path"] == "pdhg:fused-grad3d"
+                    # residual_iter >= 4 leaves room for a pair (iterations k, k+1, k+2 free of residual iterations) once k >= 2
+                    if residual_iter >= 4 and iters >= 8:
+                        assert ("fused_iter3d_x2_kernel" in names) == pair, (names, pair)
+                    elif not pair:
+                        assert "fused_iter3d_x2_kernel" not in names
+                    states.append((st, st2))
+                for a_, b_ in zip(states[0], states[1]):
+                    for v in "xyzw":
+                        assert np.array_equal(a_[v], b_[v]), (nx, ny, L, iters, v)
+                    for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):
+                        assert a_[v] == b_[v], (nx, ny, L, iters, v, a_[v], b_[v])     # residual iterations run the same kernel on both paths
+            bo = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
+            so = oracle.Solver(prob.data, prob.nrows, prob.ncols, bo, o, np.float32); so.initialize(); so.iterate(23)
+            ost = so.state()
+            s = prost.Solver(prob, bo, o); s.iterate(23); st = s.state(); s.destroy()
+            for v in "xyzw":
+                assert np.array_equal(st[v], ost[v]), (nx, ny, L, v)
+    finally:
+        prost.set_precision("double")
+
+
 def test_tv3d_large_fused_equals_generic(hip):
     """512 x 512 x 32 (8.4 M voxels, the C3 shape scaled to what the host can read back): the fused gradient3d
     passes and the generic nine-vector path are two independent kernel paths -- identical bits after 12 iterations."""
