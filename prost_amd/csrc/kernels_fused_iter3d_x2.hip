@@ -16,6 +16,7 @@
 // a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), fp32, heights that are a multiple of
 // the vector width; no residual sums, no stored intermediate iterate: BackendPDHG pairs only iterations nobody observes.
 #include "fused_common.hpp"
+#include "reduce.hpp"
 
 namespace prost_hip {
 
@@ -42,6 +43,17 @@ __device__ __forceinline__ void stx_nt(T* __restrict__ p, const T (&v)[VEC]) {
   __builtin_nontemporal_store(t, reinterpret_cast<V*>(p));
 }
 
+// wave-uniform base + 32-bit per-lane byte offset: the global_load / global_store SADDR form, no 64-bit address VGPRs
+// (128 -> 111 VGPRs)
+template <class T, int VEC>
+__device__ __forceinline__ void ldx_o(const T* __restrict__ base, unsigned byte_off, T (&v)[VEC]) {
+  ldx<T, VEC>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off), v);
+}
+template <class T, int VEC>
+__device__ __forceinline__ void stx_o(T* __restrict__ base, unsigned byte_off, const T (&v)[VEC]) {
+  stx_nt<T, VEC>(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
+}
+
 template <class T, int VEC, bool GB>
 struct ColX2 {
   T y1[VEC], y2[VEC], y3[VEC], x[VEC], b[GB ? VEC : 1];   // own plane
@@ -49,15 +61,24 @@ struct ColX2 {
   T y3m[VEC];                                             // y3 of the plane below (stage A)
 };
 
-template <class T, int VEC, bool GB, int WT>
+// RES: additionally the four residual sums of the SECOND iteration (primal_residual_transform / dual_residual_transform,
+// backend_pdhg.cu:73-120), term by term the expressions of fused_iter3d_kernel: K^T y^k at column c comes from stage A two
+// steps earlier, everything else is in registers when stages C and D run.  One partial (4 doubles) per workgroup.
+template <class T, int VEC, bool GB, int WT, bool RES>
 __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
-                                                                       const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2) {
+                                                                       const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2,
+                                                                       double* __restrict__ partial) {
   constexpr int kRowsPerWave = (kWave - 2) * VEC;
   constexpr int kPix = kWave * VEC;
   constexpr int P = WT - 3;                            // planes a workgroup owns
   __shared__ T s_x1[2][WT][kPix], s_y3[2][WT][kPix], s_x2[2][WT][kPix];
+  // RES: K^T y^k of the own plane waits two steps between stages A and C, and the four sums are added up once per step --
+  // both live in LDS (own lanes only, no synchronisation), the instance stays within the 128 VGPRs of 16 wavefronts per CU
+  __shared__ T s_kt[RES ? 3 : 1][RES ? WT : 1][RES ? kPix : 1];
+  __shared__ double s_acc[RES ? 4 : 1][RES ? WT : 1][RES ? kWave : 1];
   const long nx = (long)a.nx, ny = (long)a.ny, L = (long)a.L;
-  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // wave-uniform: plane, roles and base pointers live in SGPRs
   const unsigned groups = (unsigned)((L + P - 1) / P);
   const unsigned total = gridDim.x, chunks = a.chunks;
   const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // XCD-aware tile order: plane group fastest
@@ -86,17 +107,18 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
 
   typedef ColX2<T, VEC, GB> Col;
+  const unsigned voff = (unsigned)(row0 * (long)sizeof(T));          // meaningful in active lanes only (the others do not access memory)
   auto load_col = [&](long c, Col& in) {
-    const size_t o = (size_t)c * (size_t)ny + (size_t)row0;
-    ldx<T, VEC>(y1p + o, in.y1); ldx<T, VEC>(y2p + o, in.y2); ldx<T, VEC>(y3p + o, in.y3); ldx<T, VEC>(xp + o, in.x);
-    if constexpr (GB) ldx<T, VEC>(bp + o, in.b);
-    if (has_above) ldx<T, VEC>(xp + Pn + o, in.zx);
-    if (has_below) ldx<T, VEC>(y3p - Pn + o, in.y3m);
+    const size_t o = (size_t)c * (size_t)ny;                          // wave-uniform
+    ldx_o<T, VEC>(y1p + o, voff, in.y1); ldx_o<T, VEC>(y2p + o, voff, in.y2); ldx_o<T, VEC>(y3p + o, voff, in.y3); ldx_o<T, VEC>(xp + o, voff, in.x);
+    if constexpr (GB) ldx_o<T, VEC>(bp + o, voff, in.b);
+    if (has_above) ldx_o<T, VEC>(xp + Pn + o, voff, in.zx);
+    if (has_below) ldx_o<T, VEC>(y3p - Pn + o, voff, in.y3m);
   };
   // primal step at column c of this plane (backend_pdhg.cu:317-338 with block_gradient3d.cu:127-149 on a zero-filled result);
   // v1 / v2 / v3: the dual variable at column c, p1c: its first component at column c-1, v3m: its third component one plane below
   auto primal = [&](long c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&p1c)[VEC], const T (&v3m)[VEC],
-                    const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1], const IterParams3<T>& Pm, T (&xn)[VEC]) {
+                    const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1], const IterParams3<T>& Pm, T (&xn)[VEC], T (&ktv)[VEC]) {
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
     T parg[VEC];
@@ -110,6 +132,7 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
       T divl = v3[j];
       if (has_below) divl -= v3m[j];
       const T kty = (T)0 - (divx + divy + divl);
+      ktv[j] = kty;
       const T arg = xin[j] - tauT * kty;
       parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
     }
@@ -118,28 +141,33 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
 #pragma unroll
     for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? bv[GB ? j : 0] : a.g_val[1]);
   };
-  // dual step at column c of this plane (backend_pdhg.cu:341-370 with block_gradient3d.cu:62-80): xn_* the new primal iterate at
-  // columns c / c+1 / one plane above, xo_* the old one, v* the dual variable at column c
+  // K x (new iterate) and K x_prev (old iterate) of pixel j at column c (block_gradient3d.cu:62-80)
+  auto gradients = [&](long c, int j, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+                       const T (&xo_z)[VEC], T bel_n, T bel_o, T (&kx)[3], T (&kp)[3]) {
+    const long row = row0 + j;
+    const bool has_next = c + 1 < nx;
+    const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
+    const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
+    kx[0] = has_next ? xn_n[j] - xn_c[j] : (T)0;
+    kx[1] = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
+    kx[2] = has_above ? xn_z[j] - xn_c[j] : -xn_c[j];                          // Dirichlet (:73-76)
+    kp[0] = has_next ? xo_n[j] - xo_c[j] : (T)0;
+    kp[1] = (row < ny - 1) ? below_o - xo_c[j] : (T)0;
+    kp[2] = has_above ? xo_z[j] - xo_c[j] : -xo_c[j];
+  };
+  // dual step at column c of this plane (backend_pdhg.cu:341-370): xn_* the new primal iterate at columns c / c+1 / one plane
+  // above, xo_* the old one, v* the dual variable at column c
   auto dual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
                   const T (&xo_z)[VEC], const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const IterParams3<T>& Pm,
                   T (&out)[3][VEC]) {
     const T sigS = Pm.sigma * a.Sval, theta = Pm.theta;
-    const bool has_next = c + 1 < nx;
     const T bel_n = lane_down(xn_c[0]);                // lane 63: no source, its last row is halo
     const T bel_o = lane_down(xo_c[0]);
     T av[3][VEC], nv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const long row = row0 + j;
-      const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
-      const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
       T kx[3], kp[3];
-      kx[0] = has_next ? xn_n[j] - xn_c[j] : (T)0;
-      kx[1] = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
-      kx[2] = has_above ? xn_z[j] - xn_c[j] : -xn_c[j];                        // Dirichlet (:73-76)
-      kp[0] = has_next ? xo_n[j] - xo_c[j] : (T)0;
-      kp[1] = (row < ny - 1) ? below_o - xo_c[j] : (T)0;
-      kp[2] = has_above ? xo_z[j] - xo_c[j] : -xo_c[j];
+      gradients(c, j, xn_c, xn_n, xn_z, xo_c, xo_n, xo_z, bel_n, bel_o, kx, kp);
       const T yv[3] = {v1[j], v2[j], v3[j]};
       T norm = 0;
 #pragma unroll
@@ -151,6 +179,46 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
       nv[j] = norm;
     }
     norm2_leq0_fast<T, 3, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+  };
+  // residual sums of the second iteration (RES): the terms of fused_iter3d_kernel
+  const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  const SharedDivisor<T> div_tauT(p2.tau * sqT), div_sigS(p2.sigma * sqS);   // wave-uniform: exact quotients through one double reciprocal each
+  if (RES) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_acc[RES ? k : 0][RES ? wv : 0][RES ? lane : 0] = 0;   // primal diff^2, primal var^2, dual diff^2, dual var^2
+  }
+  auto accumulate = [&](int k, double v) { s_acc[RES ? k : 0][RES ? wv : 0][RES ? lane : 0] += v; };
+  // dual_residual_transform (backend_pdhg.cu:73-94) at a column of stage C: xo / xn = x^(k+1) / x^(k+2), kt_prev = K^T y^k, kt = K^T y^(k+1)
+  auto dual_residual = [&](const T (&xo)[VEC], const T (&xn)[VEC], const T (&kt_prev)[VEC], const T (&kt)[VEC]) {
+    double dd = 0, dv = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const T w_hat = div_tauT.div(xo[j] - xn[j]) - sqT * kt_prev[j];
+      const T diff = w_hat + sqT * kt[j];
+      dd += (double)(diff * diff); dv += (double)(w_hat * w_hat);
+    }
+    if (owner) { accumulate(2, dd); accumulate(3, dv); }
+  };
+  // primal_residual_transform (backend_pdhg.cu:97-120) at the column of stage D: v* = y^(k+1), out = y^(k+2)
+  auto primal_residual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+                             const T (&xo_z)[VEC], const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&out)[3][VEC]) {
+    const T theta = p2.theta;
+    const T bel_n = lane_down(xn_c[0]);
+    const T bel_o = lane_down(xo_c[0]);
+    double pd = 0, pv = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      T kx[3], kp[3];
+      gradients(c, j, xn_c, xn_n, xn_z, xo_c, xo_n, xo_z, bel_n, bel_o, kx, kp);
+      const T yv[3] = {v1[j], v2[j], v3[j]};
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const T z_hat = div_sigS.div(yv[i] - out[i][j]) + sqS * ((1 + theta) * kx[i] - theta * kp[i]);
+        const T diff = z_hat - sqS * kx[i];
+        pd += (double)(diff * diff); pv += (double)(z_hat * z_hat);
+      }
+    }
+    if (owner) { accumulate(0, pd); accumulate(1, pv); }
   };
   auto publish = [&](T (&buf)[WT][kPix], const T (&v)[VEC]) {
 #pragma unroll
@@ -179,11 +247,12 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = 0;
   auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
   if (active) {
-    if (xa - 2 >= 0) ldx<T, VEC>(y1p + (size_t)(xa - 2) * (size_t)ny + (size_t)row0, in2.y1);   // becomes in1.y1 for A(xa-1)
+    if (xa - 2 >= 0) ldx_o<T, VEC>(y1p + (size_t)(xa - 2) * (size_t)ny, voff, in2.y1);   // becomes in1.y1 for A(xa-1)
   }
   Col pre = {};
   if (active && has_col(xa - 1)) load_col(xa - 1, pre);
 
+  int k3 = 0;                                          // slot of s_kt that stage A writes in this step
   for (long c = xa - 3; c <= xb; c++) {
     const int wr = (int)((c + 4) & 1), rd = wr ^ 1;
     // raw columns: in1 <- in2 <- pre, prefetch column c+3
@@ -195,7 +264,12 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     if (has_below && wv >= 1) fetch(s_y3[rd], wv - 1, ym3_0);
     const long ca = c + 2, cb = c + 1, cd = c - 1;
     if (exists && ca >= (xa - 1 > 0 ? xa - 1 : 0) && ca < nx && ca <= xb + 1) {                    // stage A
-      primal(ca, in2.y1, in2.y2, in2.y3, in1.y1, in2.y3m, in2.x, in2.b, p1, x1_2);
+      T kt_a[VEC];
+      primal(ca, in2.y1, in2.y2, in2.y3, in1.y1, in2.y3m, in2.x, in2.b, p1, x1_2, kt_a);
+      if (RES) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) s_kt[RES ? k3 : 0][RES ? wv : 0][RES ? j * kWave + lane : 0] = kt_a[j];       // K^T y^k at column c+2: read by stage C two steps later
+      }
       publish(s_x1[wr], x1_2);
     }
     if (do_y1 && cb >= (xa - 1 > 0 ? xa - 1 : 0) && cb < nx && cb <= xb) {                         // stage B
@@ -206,16 +280,24 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
       publish(s_y3[wr], yc_1);
     }
     if (do_x2 && c >= xa && c < nx && c <= xb) {                                                  // stage C
-      primal(c, ya_0, yb_0, yc_0, ya_m, ym3_0, x1_0, b_c, p2, x2_0);
+      T kt_c[VEC];
+      primal(c, ya_0, yb_0, yc_0, ya_m, ym3_0, x1_0, b_c, p2, x2_0, kt_c);
       publish(s_x2[wr], x2_0);
-      if (do_y2 && owner && c < xb) stx_nt<T, VEC>(x_out + plane + (size_t)c * (size_t)ny + (size_t)row0, x2_0);
+      if (RES && do_y2 && c < xb) {
+        T kt_0[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) kt_0[j] = s_kt[RES ? (k3 + 1) % 3 : 0][RES ? wv : 0][RES ? j * kWave + lane : 0];     // written two steps ago
+        dual_residual(x1_0, x2_0, kt_0, kt_c);
+      }
+      if (do_y2 && owner && c < xb) stx_o<T, VEC>(x_out + plane + (size_t)c * (size_t)ny, voff, x2_0);
     }
     if (do_y2 && cd >= xa && cd < xb) {                                                           // stage D
       T o[3][VEC];
       dual(cd, x2_m, x2_0, xz2_m, x1_m, x1_0, xz1_m, ya_m, yb_m, yc_m, p2, o);
+      if (RES) primal_residual(cd, x2_m, x2_0, xz2_m, x1_m, x1_0, xz1_m, ya_m, yb_m, yc_m, o);
       if (owner) {
-        const size_t off = plane + (size_t)cd * (size_t)ny + (size_t)row0;
-        stx_nt<T, VEC>(y_out + off, o[0]); stx_nt<T, VEC>(y_out + N + off, o[1]); stx_nt<T, VEC>(y_out + 2 * N + off, o[2]);
+        const size_t off = plane + (size_t)cd * (size_t)ny;           // wave-uniform
+        stx_o<T, VEC>(y_out + off, voff, o[0]); stx_o<T, VEC>(y_out + N + off, voff, o[1]); stx_o<T, VEC>(y_out + 2 * N + off, voff, o[2]);
       }
     }
     __syncthreads();                                   // one barrier per column: the buffers written now are read in the next step
@@ -230,6 +312,20 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     }
 #pragma unroll
     for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = in1.b[j];
+    k3 = k3 == 2 ? 0 : k3 + 1;
+  }
+  if (RES) {                                           // the last barrier of the loop has passed: the exchange buffers are free
+    double* sred = reinterpret_cast<double*>(&s_x1[0][0][0]);
+    double r_pd = s_acc[0][RES ? wv : 0][RES ? lane : 0], r_pv = s_acc[RES ? 1 : 0][RES ? wv : 0][RES ? lane : 0], r_dd = s_acc[RES ? 2 : 0][RES ? wv : 0][RES ? lane : 0],
+           r_dv = s_acc[RES ? 3 : 0][RES ? wv : 0][RES ? lane : 0];
+    r_pd = wave_sum(r_pd); r_pv = wave_sum(r_pv); r_dd = wave_sum(r_dd); r_dv = wave_sum(r_dv);
+    if (lane == 0) { sred[4 * wv + 0] = r_pd; sred[4 * wv + 1] = r_pv; sred[4 * wv + 2] = r_dd; sred[4 * wv + 3] = r_dv; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double t = 0;
+      for (int w = 0; w < WT; w++) t += sred[4 * w + threadIdx.x];       // fixed order: run-to-run deterministic
+      partial[4 * (size_t)blockIdx.x + threadIdx.x] = t;
+    }
   }
 }
 
@@ -252,7 +348,9 @@ static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
   if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
   const size_t strips = (d->ny + 62 * kX2Vec - 1) / (62 * kX2Vec);
-  return strips * ((d->L + kX2Waves - 4) / (kX2Waves - 3)) * d->nx < (size_t)1 << 31;
+  // (residual launches write one partial per workgroup: with one chunk per tile the tiles alone must fit the reduction workspace)
+  const size_t tiles = strips * ((d->L + kX2Waves - 4) / (kX2Waves - 3));
+  return tiles <= (size_t)kReduceBlocks / 2 && tiles * d->nx < (size_t)1 << 31;
 }
 
 static int compute_units() {
@@ -268,15 +366,17 @@ static int compute_units() {
 // (rounds of workgroups) x (column steps of a workgroup): pick the number of column chunks that minimises
 // ceil(strips * groups * chunks / CUs) * (columns per chunk + 4 warm-up steps).  2048 x 2048 x 64 on 256 CUs: 17 x 5 x 3 = 255
 // workgroups, ONE round of 687 steps (64-column chunks: 11 rounds of 68 steps = 748).
-static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int cols) {
-  if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
+static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int cols, bool res) {
   constexpr int P = kX2Waves - 3;
   const size_t tiles = ((d->ny + (size_t)(kWave - 2) * kX2Vec - 1) / ((size_t)(kWave - 2) * kX2Vec)) * ((d->L + P - 1) / P);
+  const size_t max_groups = res ? (size_t)kReduceBlocks / 2 : (size_t)1 << 31;     // residual launches: one partial (4 doubles) per workgroup
+  if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
   const size_t cus = (size_t)compute_units();
   size_t best_c = d->nx, best_cost = (size_t)-1;
   for (size_t n = 1; n <= d->nx; n++) {
     const size_t c = (d->nx + n - 1) / n;
     if (c < 8 && n > 1) break;
+    if (tiles * ((d->nx + c - 1) / c) > max_groups && n > 1) break;
     const size_t cost = ((tiles * ((d->nx + c - 1) / c) + cus - 1) / cus) * (c + 4);
     if (cost < best_cost) { best_cost = cost; best_c = c; }
   }
@@ -284,26 +384,34 @@ static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int cols) {
 }
 
 template <class T, int V, int WT>
-static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const IterParams3<T> (&p)[2], int cols, hipStream_t s) {
+static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const IterParams3<T> (&p)[2], int cols,
+                            double* out4, void* ws, hipStream_t s) {
   constexpr int P = WT - 3;
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t groups = (d->L + P - 1) / P;
   const size_t strips = (d->ny + (size_t)(kWave - 2) * V - 1) / ((size_t)(kWave - 2) * V);
-  const size_t c = x2_chunk_cols(d, cols);
+  const size_t c = x2_chunk_cols(d, cols, out4 != nullptr);
   a.cols_per_block = (int)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
   const unsigned grid = (unsigned)(strips * a.chunks * groups);
-  if (d->g_coeff_ptr[1]) hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, true, WT>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1]);
-  else hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, false, WT>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1]);
-  PH_LAUNCH_END("fused 3-D double iteration kernel");
+  if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused 3-D double iteration: grid exceeds the reduction workspace"); return 1; }
+  double* partial = static_cast<double*>(ws);
+#define GO(B, R) hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, B, WT, R>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+  if (d->g_coeff_ptr[1]) { if (out4) GO(true, true); else GO(true, false); }
+  else { if (out4) GO(false, true); else GO(false, false); }
+#undef GO
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused 3-D double iteration kernel"); }
+  if (out4) return launch_fold4(out4, partial, grid, s);
+  return 0;
 }
 
 template <class T>
 static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
-                         const double* theta, int cols, void* stream) {
+                         const double* theta, int cols, double* out4, void* ws, void* stream) {
   if (!iter3d_x2_ok(d, 0)) { set_error("fused 3-D double iteration: unsupported description (see prost_hip_fused_iteration3d_x2_supported)"); return 1; }
   if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused 3-D double iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_out == x || y_out == y) { set_error("fused 3-D double iteration: outputs must not alias inputs"); return 1; }
+  if (out4 && !ws) { set_error("fused 3-D double iteration: residuals need the reduction workspace"); return 1; }
   FusedArgs<T> a = make_fused_args<T>(d);
   IterParams3<T> p[2];
   for (int i = 0; i < 2; i++) {
@@ -313,7 +421,7 @@ static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, cons
     if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused 3-D double iteration: not the straight-line ROF shape"); return 1; }
     p[i].sq = ug.sq;
   }
-  return launch_iter3d_x2<T, kX2Vec, kX2Waves>(d, x_out, y_out, x, y, p, cols, as_stream(stream));
+  return launch_iter3d_x2<T, kX2Vec, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
 }
 
 }  // namespace prost_hip
@@ -322,9 +430,11 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration3d_x2_supported(const prost_hip_fused_desc* d, int dtype) { return iter3d_x2_ok(d, dtype) ? 1 : 0; }
-int prost_hip_fused_iteration3d_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype) { return iter3d_x2_ok(d, dtype) ? (int)x2_chunk_cols(d, 0) : 0; }
+int prost_hip_fused_iteration3d_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int with_residuals) {
+  return iter3d_x2_ok(d, dtype) ? (int)x2_chunk_cols(d, 0, with_residuals != 0) : 0;
+}
 int prost_hip_fused_iteration3d_x2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
-                                       const double* sigma, const double* theta, int cols, void* stream) {
-  return run_iter3d_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, stream);
+                                       const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
+  return run_iter3d_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
 }
 }  // extern "C"

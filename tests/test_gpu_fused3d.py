@@ -95,8 +95,8 @@ def test_tv3d_pdhg_iterates_match_oracle(hip, precision, dtype, step):
 @pytest.mark.parametrize("step", ["alg1", "alg2", "boyd"])
 @pytest.mark.parametrize("residual_iter", [1, 3, 4, 5, 10])
 def test_tv3d_pair_schedule_is_invisible(hip, step, residual_iter):
-    """fp32 volumetric TV with two iterations per launch (prost_hip_fused_iteration3d_x2) wherever none of k, k+1, k+2 is a
-    residual iteration: the state after ANY number of iterations -- x, y, the constraint variables z, w (which need the
+    """fp32 volumetric TV with two iterations per launch (prost_hip_fused_iteration3d_x2) wherever neither k nor k+2 is a
+    residual iteration (k+1 may be one: the kernel forms its sums): the state after ANY number of iterations -- x, y, the constraint variables z, w (which need the
     previous iterate, rebuilt by one single launch after a pair), residuals, step sizes -- is bit-identical to the path
     that launches every iteration separately, and the iterates equal the oracle's."""
     prost.set_gpu(0)
@@ -118,17 +118,20 @@ def test_tv3d_pair_schedule_is_invisible(hip, step, residual_iter):
                     st2 = s.state()
                     s.destroy()
                     assert st["path"] == "pdhg:fused-grad3d"
-                    # residual_iter >= 4 leaves room for a pair (iterations k, k+1, k+2 free of residual iterations) once k >= 2
-                    if residual_iter >= 4 and iters >= 8:
-                        assert ("fused_iter3d_x2_kernel" in names) == pair, (names, pair)
+                    # a pair starts at k >= 2 unless k or k + 2 is a residual iteration
+                    x2 = [k for k in names if k.startswith("fused_iter3d_x2_kernel")]
+                    if residual_iter >= 3 and iters >= 8:
+                        assert bool(x2) == pair, (names, pair)
                     elif not pair:
-                        assert "fused_iter3d_x2_kernel" not in names
+                        assert not x2
                     states.append((st, st2))
                 for a_, b_ in zip(states[0], states[1]):
                     for v in "xyzw":
                         assert np.array_equal(a_[v], b_[v]), (nx, ny, L, iters, v)
-                    for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):
-                        assert a_[v] == b_[v], (nx, ny, L, iters, v, a_[v], b_[v])     # residual iterations run the same kernel on both paths
+                    for v in ("tau", "sigma", "theta", "iteration"):
+                        assert a_[v] == b_[v], (nx, ny, L, iters, v, a_[v], b_[v])
+                    for v in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):       # same terms, another summation order
+                        assert np.isclose(a_[v], b_[v], rtol=1e-9, atol=0), (nx, ny, L, iters, v, a_[v], b_[v])
             bo = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
             so = oracle.Solver(prob.data, prob.nrows, prob.ncols, bo, o, np.float32); so.initialize(); so.iterate(23)
             ost = so.state()
@@ -228,7 +231,8 @@ def test_double_3d_iteration_equals_two_single_launches(hip, shape, vector_b, ra
     iterations of the two-pass kernels, which are pinned to the oracle above: same bits for
     x^(k+2) and all three components of y^(k+2), for every chunk width (1: every column a chunk border; 64: one chunk), plane
     counts below / equal to / above the 13 planes a workgroup owns (helper planes outside the volume, several plane groups),
-    strip layouts (126 = one strip + 2 rows, 1028 rows: nine strips) and step sizes that change between the two iterations (alg2)."""
+    strip layouts (126 = one strip + 2 rows, 1028 rows: nine strips) and step sizes that change between the two iterations (alg2);
+    with residual sums: the four sums of the second iteration against the two-pass kernels' for that iteration."""
     dtype = np.float32
     nx, ny, L = shape
     rng = np.random.default_rng(11)
@@ -254,17 +258,23 @@ def test_double_3d_iteration_equals_two_single_launches(hip, shape, vector_b, ra
     ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
     hip.check(P(C.byref(d), x1.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau[0]), 1, 0, None, ws.ptr, None))
     hip.check(D(C.byref(d), y1.ptr, dy.ptr, x1.ptr, dx.ptr, hip.dbl(sigma[0]), hip.dbl(theta[0]), 1, None, ws.ptr, None))
-    hip.check(P(C.byref(d), x2.ptr, x1.ptr, y1.ptr, None, hip.dbl(tau[1]), 1, 0, None, ws.ptr, None))
-    hip.check(D(C.byref(d), y2.ptr, y1.ptr, x2.ptr, x1.ptr, hip.dbl(sigma[1]), hip.dbl(theta[1]), 1, None, ws.ptr, None))
+    rd = hip.DeviceArray.zeros(2, np.float64); rp = hip.DeviceArray.zeros(2, np.float64)      # the second iteration as a residual iteration (y_prev = y^k)
+    hip.check(P(C.byref(d), x2.ptr, x1.ptr, y1.ptr, dy.ptr, hip.dbl(tau[1]), 1, 1, rd.ptr, ws.ptr, None))
+    hip.check(D(C.byref(d), y2.ptr, y1.ptr, x2.ptr, x1.ptr, hip.dbl(sigma[1]), hip.dbl(theta[1]), 1, rp.ptr, ws.ptr, None))
+    res_ref = np.concatenate([rp.to_host(), rd.to_host()])      # {primal diff^2, primal var^2, dual diff^2, dual var^2}
     x_ref, y_ref = x2.to_host(), y2.to_host()
     arr = lambda v: (C.c_double * 2)(*v)
     for cols in (0, 1, 2, 5, 7, 64):
-        xo = hip.DeviceArray.zeros(n, dtype); yo = hip.DeviceArray.zeros(m, dtype)
-        hip.check(hip.lib().prost_hip_fused_iteration3d_x2_f32(C.byref(d), xo.ptr, yo.ptr, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols, None))
-        hx, hy = xo.to_host(), yo.to_host()
-        assert np.array_equal(hx, x_ref), (cols, np.flatnonzero(hx != x_ref)[:8])
-        for k in range(3):
-            assert np.array_equal(hy[k * n:(k + 1) * n], y_ref[k * n:(k + 1) * n]), (cols, k, np.flatnonzero(hy[k * n:(k + 1) * n] != y_ref[k * n:(k + 1) * n])[:8])
+        for res in (False, True):
+            xo = hip.DeviceArray.zeros(n, dtype); yo = hip.DeviceArray.zeros(m, dtype); r4 = hip.DeviceArray.zeros(4, np.float64)
+            hip.check(hip.lib().prost_hip_fused_iteration3d_x2_f32(C.byref(d), xo.ptr, yo.ptr, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols,
+                                                                   r4.ptr if res else None, ws.ptr if res else None, None))
+            hx, hy = xo.to_host(), yo.to_host()
+            assert np.array_equal(hx, x_ref), (cols, res, np.flatnonzero(hx != x_ref)[:8])
+            for k in range(3):
+                assert np.array_equal(hy[k * n:(k + 1) * n], y_ref[k * n:(k + 1) * n]), (cols, res, k, np.flatnonzero(hy[k * n:(k + 1) * n] != y_ref[k * n:(k + 1) * n])[:8])
+            if res:          # the same terms as the two-pass kernels, summed in double in another order
+                assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
     hip.sync()
 
 
@@ -301,7 +311,7 @@ def test_single_kernel_iterations_write_only_their_outputs(hip, kernel):
                 hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, 0, None))
             elif kernel == "fused_iteration3d_x2":
                 two = lambda a, b: (C.c_double * 2)(a, b)
-                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, two(0.3, 0.25), two(1.0, 1.2), two(0.9, 0.8), cols, None))
+                hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, two(0.3, 0.25), two(1.0, 1.2), two(0.9, 0.8), cols, None, None, None))
             else:
                 hip.check(fn(C.byref(d), xo, yo, dx.ptr, dy.ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 1, cols, None, None, None))
             hx, hy = bx.to_host(), by.to_host()
