@@ -26,7 +26,7 @@ extern "C" {
 
 /* 2: prost_hip_fused_desc gained res_x0 / res_x1; fused_iteration2, comm send/recv, wrapper proxes, Kronecker blocks
  * 3: additions only -- device-resident CGLS / ADMM stages, prox_elem_arg, csr_spmv (non-accumulating), fused_iteration3d,
- *    fused_iteration3d_pw, fused_iteration_mc, stream_wait_event, graph capture */
+ *    fused_iteration3d_pw, fused_iteration3d_x2, fused_iteration_mc, stream_wait_event, graph capture */
 #define PROST_HIP_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------------------------ */

@@ -1,20 +1,27 @@
 // kernels_fused_iter3d_x2.hip -- gradient3d, TWO PDHG iterations per kernel launch (temporal blocking in 3-D).
 //
-// fused_iter3d_pw_kernel (one iteration per launch, planes across the wavefronts of a workgroup) is memory-bound: 2.19 ms at
-// 2048 x 2048 x 64 against 1.28 ms with every access served from cache.  Here a workgroup of WT wavefronts owns P = WT - 3
-// consecutive planes of one (row strip, column chunk) and every wavefront runs the 4-stage column pipeline of the 2-D pair
-// kernel (kernels_fused_iter2.hip) on ITS plane, one column further apart:
+// fused_iter3d_pw_kernel (one iteration per launch, planes across the wavefronts of a workgroup) is memory-bound: 2.0-2.7 ms
+// between boxes at 2048 x 2048 x 64 against 1.28 ms with every access served from cache.  Here a workgroup of WT = 16
+// wavefronts owns P = WT - 3 = 13 consecutive planes of one (row strip, column chunk) and every wavefront runs the 4-stage
+// column pipeline of the 2-D pair kernel (kernels_fused_iter2.hip) on ITS plane:
 //     A(c+2): x1 = primal step of iteration k            B(c+1): y1 = dual step of iteration k
 //     C(c)  : x2 = primal step of iteration k+1          D(c-1): y2 = dual step of iteration k+1
 // What a stage needs from a neighbouring plane -- x1(l+1) for B, the third component of y1(l-1) for C, x2(l+1) for D -- was
 // published through double-buffered LDS in the PREVIOUS column step by the wavefront of that plane, so ONE workgroup barrier
 // per column orders everything.  Planes l0 .. l0+P-1 are owned (x^(k+2), y^(k+2) stored); the wavefront of plane l0-1 runs A
-// and B only, that of plane l0+P runs A, B, C, that of plane l0+P+1 runs A only (helper planes: 4P+6 stage units per P planes).
-// Row neighbours come from adjacent lanes, lanes 0 and 63 are halo lanes exactly as in the 2-D pair kernel.
+// and B only, that of plane l0+P runs A, B, C, that of plane l0+P+1 runs A only (helper planes: 4P+6 = 58 stage units per 52
+// useful ones).  Row neighbours come from adjacent lanes (DPP), lanes 0 and 63 are halo lanes as in the 2-D pair kernel.
+//
+// Shape of the instance (measured at 2048 x 2048 x 64 fp32, per iteration):
+//   4 rows per lane x 8 wavefronts (5 owned planes, 212 VGPRs, 2 waves per SIMD): 2.22 ms -- arithmetic alone 1.69 ms, 30 % of
+//   it on helper planes, the barrier 0.39 ms;
+//   2 rows per lane x 16 wavefronts (13 owned planes, 111 VGPRs, 4 waves per SIMD): arithmetic alone 1.15 ms, memory alone
+//   1.2 ms, together 1.5-1.6 ms.  The HBM traffic of a launch is 11.15 GB (rocprofv3 counters: 6.62 GB read + 4.53 GB written;
+//   ideal 5 + 4 floats per voxel = 9.66 GB) for TWO iterations, against 11.3 GB for ONE of the single-iteration kernel.
 // Every stage evaluates the expressions of kernels_fused_iter3d_pw.hip / kernels_fused3d.hip, so x^(k+2), y^(k+2) are
 // bit-identical to two single launches (tests/test_gpu_fused3d.py).  Straight-line ROF shape only (prox_g square with scalar
-// a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), fp32, heights that are a multiple of
-// the vector width; no residual sums, no stored intermediate iterate: BackendPDHG pairs only iterations nobody observes.
+// a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), fp32, even heights.  The
+// intermediate iterate is stored nowhere; the residual sums of the second iteration are available (RES).
 #include "fused_common.hpp"
 #include "reduce.hpp"
 
@@ -81,13 +88,13 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // wave-uniform: plane, roles and base pointers live in SGPRs
   const unsigned groups = (unsigned)((L + P - 1) / P);
   const unsigned total = gridDim.x, chunks = a.chunks;
-  const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // XCD-aware tile order: plane group fastest
+  const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // consecutive tiles on one XCD (its L2 serves what neighbours share)
   const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
-  // row strip fastest: the workgroups that run side by side read whole columns (8 KB at 2048 rows) and share the lines their halo
-  // lanes touch; then the plane group (neighbouring groups share their helper planes), then the column chunk
-  // (2048 x 2048 x 64, same box: 1.55 ms per iteration against 1.69 ms with the plane group fastest and the strip slowest)
+  // plane group fastest, then the row strip, then the column chunk: the workgroups that run side by side on an XCD share their
+  // helper planes and the lines their halo lanes touch through its L2 (2048 x 2048 x 64: 6.2 GB read per launch; 6.6 GB with
+  // the strip fastest, and 9 % more time with the strip slowest)
   const unsigned strips_n = total / (groups * chunks);
-  const unsigned strip = tile % strips_n, grp = (tile / strips_n) % groups, chunk = tile / (strips_n * groups);
+  const unsigned grp = tile % groups, strip = (tile / groups) % strips_n, chunk = tile / (strips_n * groups);
   const long pl = (long)grp * P - 1 + wv;              // this wavefront's plane (may lie outside the volume: idle, still takes part in the barriers)
   const bool exists = pl >= 0 && pl < L;
   const long l = exists ? pl : 0;
