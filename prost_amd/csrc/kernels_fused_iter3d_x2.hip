@@ -259,6 +259,10 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   Col pre = {};
   if (active && has_col(xa - 1)) load_col(xa - 1, pre);
 
+  // nothing of the prologue may still be in flight when the loop starts: the compiler's wait-count insertion otherwise carries
+  // the prologue's pending loads around the loop and drains vmcnt to 0 INSIDE every step -- which also waits for the column that
+  // was just prefetched
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
   int k3 = 0;                                          // slot of s_kt that stage A writes in this step
   for (long c = xa - 3; c <= xb; c++) {
     const int wr = (int)((c + 4) & 1), rd = wr ^ 1;
