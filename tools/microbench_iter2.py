@@ -9,6 +9,9 @@ import numpy as np
 
 from prost_amd import _hip as hip
 
+if os.environ.get("PROST_HIP_LIB"):          # A/B runs of kernel variants on one box
+    hip.LIB_PATH = os.environ["PROST_HIP_LIB"]
+
 
 def main(N=4096, cols_list=(0, 12, 18, 24, 30, 36, 42, 54, 66), iters=200, dtype=np.float32, gfn="square", ffn="ind_leq0", quick=False):
     hip.require_device()
