@@ -34,6 +34,13 @@ class Backend {
   virtual void current_solution(std::vector<T>& primal_sol, std::vector<T>& dual_sol) = 0;
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y,
                                 std::vector<T>& dual_w) = 0;
+  /// The same four vectors left ON THE DEVICE (pointers valid until the next iteration or Release): lets the caller stream a
+  /// large result to wherever it is needed instead of passing through four host vectors.  false: not provided, call
+  /// current_solution.
+  virtual bool current_solution_device(const T*& primal_x, const T*& primal_z, const T*& dual_y, const T*& dual_w) {
+    (void)primal_x; (void)primal_z; (void)dual_y; (void)dual_w;
+    return false;
+  }
 
   virtual T primal_residual() const { return primal_residual_; }
   virtual T dual_residual() const { return dual_residual_; }

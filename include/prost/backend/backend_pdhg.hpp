@@ -43,6 +43,7 @@ class BackendPDHG : public Backend<T> {
   virtual void Release();
   virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
+  virtual bool current_solution_device(const T*& primal_x, const T*& primal_z, const T*& dual_y, const T*& dual_w);
   virtual size_t gpu_mem_amount() const;
   virtual void KernelTimes(std::vector<typename Backend<T>::KernelTime>& out);
   virtual std::string path() const;
@@ -99,6 +100,8 @@ class BackendPDHG : public Backend<T> {
   // after a pair launch that kept x^(k+1), y^(k+1) in registers, x_prev_ / y_prev_ still hold the pair's
   // INPUT x^k, y^k; whoever needs the true previous iterate first re-runs iteration k from them
   bool prev_stale_ = false;
+  device_vector<T> sol_z_, sol_w_;        // constraint variables z, w of current_solution (built on demand)
+  void ConstraintVariables();             // sol_z_, sol_w_ := z, w of the current iterate (backend_pdhg.cu:147-186)
   bool residuals_pending_ = false;   // four sums enqueued (device -> pinned host), not yet waited for
   size_t owned_x0_ = 0, owned_x1_ = 0;
   T stale_tau_ = 0, stale_sigma_ = 0, stale_theta_ = 0;   // step sizes of that iteration k

@@ -45,8 +45,15 @@ class Solver {
   int iterations_done() const { return iterations_done_; }
 
   void SetOptions(const Options& opts) { opts_ = opts; }
+  const Options& options() const { return opts_; }
   void SetStoppingCallback(const StoppingCallback& cb) { stopping_cb_ = cb; }
   void SetIntermCallback(const IntermCallback& cb) { interm_cb_ = cb; }
+  /// Called by Solve() INSTEAD of the read-out into cur_*_sol at the observation that ends the run (convergence, stop, last
+  /// iteration) when no intermediate-solution callback is installed: the caller takes the result straight from the backend
+  /// (Backend::current_solution_device) while the problem is still in the state it was solved in.  Returns false to decline
+  /// (the usual read-out follows).
+  typedef std::function<bool()> FinalReadout;
+  void SetFinalReadout(const FinalReadout& f) { final_readout_ = f; }
 
   const std::vector<T>& cur_primal_sol() const;          // x
   const std::vector<T>& cur_dual_sol() const;            // y
@@ -62,6 +69,7 @@ class Solver {
   std::vector<T> cur_primal_sol_, cur_dual_sol_, cur_primal_constr_sol_, cur_dual_constr_sol_;
   IntermCallback interm_cb_;
   StoppingCallback stopping_cb_;
+  FinalReadout final_readout_;
   int iterations_done_;
   bool dualized_;
 };

@@ -163,7 +163,7 @@ void BackendPDHG<T>::Release() {
   if (ev_res_done_) { prost_hip_event_destroy(ev_res_done_); ev_res_done_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;
-  y_spare_.clear(); x_spare_.clear();
+  y_spare_.clear(); x_spare_.clear(); sol_z_.clear(); sol_w_.clear();
   x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
 }
 
@@ -527,14 +527,13 @@ void BackendPDHG<T>::current_solution(std::vector<T>& primal, std::vector<T>& du
 }
 
 template <typename T>
-void BackendPDHG<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w) {
+void BackendPDHG<T>::ConstraintVariables() {
   void* s = CurrentStream();
   const size_t n = this->problem_->ncols(), m = this->problem_->nrows();
-  x_.copy_to(primal_x);
-  y_.copy_to(dual_y);
   const device_vector<T>& Tr = this->problem_->scaling_right();
   const device_vector<T>& Sl = this->problem_->scaling_left();
-  device_vector<T> scratch(std::max(n, m));
+  if (sol_w_.size() != n) sol_w_.resize(n);
+  if (sol_z_.size() != m) sol_z_.resize(m);
   if (fused_) {
     RebuildPrevious();
     // rebuild the operator products the generic path keeps resident (callback iterations only)
@@ -542,16 +541,29 @@ void BackendPDHG<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& 
     if (iteration_ >= 2) this->problem_->linop()->EvalAdjoint(ktyp, y_prev_);      // kty_prev_ = K^T y^(k): zero vector until k = 2
     this->problem_->linop()->Eval(kx, x_);
     if (iteration_ >= 2) this->problem_->linop()->Eval(kxp, x_prev_);              // kx_prev_ is the zero vector after the first iteration
-    CheckHip(Api<T>::pdhg_w_variable(scratch.data(), x_prev_.data(), x_.data(), Tr.data(), ktyp.data(), (double)tau_, n, s), "w_variable");
-    scratch.copy_to(primal_z); dual_w.assign(primal_z.begin(), primal_z.begin() + n);
-    CheckHip(Api<T>::pdhg_z_variable(scratch.data(), y_prev_.data(), y_.data(), Sl.data(), kx.data(), kxp.data(), (double)sigma_, (double)theta_, m, s), "z_variable");
-    scratch.copy_to(primal_z); primal_z.resize(m);
+    CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), ktyp.data(), (double)tau_, n, s), "w_variable");
+    CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx.data(), kxp.data(), (double)sigma_, (double)theta_, m, s), "z_variable");
+    CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");             // the temporaries above go out of scope
   } else {
-    CheckHip(Api<T>::pdhg_w_variable(scratch.data(), x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), (double)tau_, n, s), "w_variable");   // :147-160
-    scratch.copy_to(primal_z); dual_w.assign(primal_z.begin(), primal_z.begin() + n);
-    CheckHip(Api<T>::pdhg_z_variable(scratch.data(), y_prev_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "z_variable");   // :169-186
-    scratch.copy_to(primal_z); primal_z.resize(m);
+    CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), (double)tau_, n, s), "w_variable");   // :147-160
+    CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "z_variable");   // :169-186
   }
+}
+
+template <typename T>
+void BackendPDHG<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w) {
+  x_.copy_to(primal_x);
+  y_.copy_to(dual_y);
+  ConstraintVariables();
+  sol_w_.copy_to(dual_w);
+  sol_z_.copy_to(primal_z);
+}
+
+template <typename T>
+bool BackendPDHG<T>::current_solution_device(const T*& primal_x, const T*& primal_z, const T*& dual_y, const T*& dual_w) {
+  ConstraintVariables();
+  primal_x = x_.data(); primal_z = sol_z_.data(); dual_y = y_.data(); dual_w = sol_w_.data();
+  return true;
 }
 
 template <typename T>

@@ -2,6 +2,7 @@
 // (the MEX gateway of the reference, matlab/+prost/private/{prost,factory}.cpp, without mex.h).
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -484,10 +485,9 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
         std::vector<double> dx(x.begin(), x.end()), dy(y.begin(), y.end());
         return fn(user, it, dx.data(), dx.size(), dy.data(), dy.size()) != 0;
       });
-    } else {
-      // options.m's default dummy_cb prints a newline and returns false
-      h->solver->SetIntermCallback([o](int, const std::vector<T>&, const std::vector<T>&) { if (o.verbose) std::cout << std::endl; return false; });
     }
+    // (options.m's default dummy_cb prints a newline and returns false: exactly what Solver::Solve does by itself when no
+    // callback is installed, so none is -- and the final read-out can stream the result, see solve_problem_t)
     h->solver->SetStoppingCallback([]() { return g_stop_cb ? g_stop_cb(g_stop_user) != 0 : false; });
   }
   // column-sharded images: only the owned columns of this slab count (residual sums, global sizes)
@@ -523,13 +523,51 @@ template <typename T>
 void solve_problem_t(CMD_ARGS) {
   select_device();
   const size_t nrows = (size_t)prhs[1]->data[0], ncols = (size_t)prhs[2]->data[0];
+  // PROST_TRACE_SOLVE=1: wall time of the stages of a solve on stderr (tools/time_to_solution.py)
+  const bool trace = std::getenv("PROST_TRACE_SOLVE") != nullptr;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const auto t0 = now();
   auto h = build_solver<T>(prhs[0], nrows, ncols, prhs[3], prhs[4], true);
-  typename Solver<T>::ConvergenceResult r = h->solver->Solve();
+  const auto t1 = now();
+  // The result goes from the device straight into the double-precision values the caller gets (pinned staging, widened by
+  // the copying threads) instead of through four host vectors of T and a widening pass -- unless an intermediate-solution
+  // callback needs those vectors anyway, or the backend keeps no device-resident solution.
+  prost_value* streamed[4] = {nullptr, nullptr, nullptr, nullptr};        // x, z, y, w of the solved (possibly dualised) problem
+  h->solver->SetFinalReadout([&]() {
+    const T* dev[4];
+    const auto r0 = now();
+    if (!h->backend->current_solution_device(dev[0], dev[1], dev[2], dev[3])) return false;
+    const auto r1 = now();
+    const size_t n = h->problem->ncols(), m = h->problem->nrows();
+    const size_t len[4] = {n, m, m, n};
+    for (int k = 0; k < 4; k++) {
+      prost_value* v = new prost_value; v->kind = PROST_VALUE_MATRIX; v->rows = len[k]; v->cols = 1;
+      v->data.resize(len[k]);             // no zero fill (default_init_allocator)
+      streamed[k] = v;
+      DownloadAs<double, T>(v->data.data(), dev[k], len[k]);
+    }
+    if (trace) std::fprintf(stderr, "solve_problem: read-out: constraint variables %.3f s, download + widening of x, z, y, w %.3f s\n", secs(r0, r1), secs(r1, now()));
+    return true;
+  });
+  typename Solver<T>::ConvergenceResult r;
+  try { r = h->solver->Solve(); } catch (...) { for (auto* v : streamed) if (v) prost_value_free(v); throw; }
+  const auto t2 = now();
   prost_value* out = prost_value_struct();
+  if (streamed[0]) {
+    // under solve_dual the roles of the solution vectors are exchanged (solver.cu:216-246)
+    const bool dual = h->solver->options().solve_dual_problem;
+    prost_value_struct_set(out, "x", streamed[dual ? 2 : 0]);
+    prost_value_struct_set(out, "y", streamed[dual ? 0 : 2]);
+    prost_value_struct_set(out, "z", streamed[dual ? 3 : 1]);
+    prost_value_struct_set(out, "w", streamed[dual ? 1 : 3]);
+  } else {
   prost_value_struct_set(out, "x", vec_value_t(h->solver->cur_primal_sol()));
   prost_value_struct_set(out, "y", vec_value_t(h->solver->cur_dual_sol()));
   prost_value_struct_set(out, "z", vec_value_t(h->solver->cur_primal_constr_sol()));
   prost_value_struct_set(out, "w", vec_value_t(h->solver->cur_dual_constr_sol()));
+  }
+  if (trace) std::fprintf(stderr, "solve_problem: build + initialize %.3f s, Solve (iterations + final read-out) %.3f s, widening the result %.3f s\n", secs(t0, t1), secs(t1, t2), secs(t2, now()));
   const char* msg = r == Solver<T>::kConverged ? "Converged." : (r == Solver<T>::kStoppedMaxIters ? "Reached maximum iterations." : "Stopped by user.");
   prost_value_struct_set(out, "result", prost_value_string(msg));
   prost_value_struct_set(out, "iters", prost_value_scalar(h->solver->iterations_done()));

@@ -4,6 +4,7 @@
 #include <exception>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +60,9 @@ device_vector<T>& device_vector<T>::operator=(const std::vector<T>& host) {
 template <typename T>
 void device_vector<T>::copy_to(std::vector<T>& host) const {
   host.resize(size_);
-  if (size_) {
+  if (size_ * sizeof(T) >= ((size_t)4 << 20)) {
+    DownloadAs<T, T>(host.data(), data_, size_);        // pinned staging, chunks overlapped with the host copy
+  } else if (size_) {
     CheckHip(prost_hip_memcpy_d2h(host.data(), data_, size_ * sizeof(T), CurrentStream()), "memcpy_d2h");
     CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
   }
@@ -219,6 +222,52 @@ void ParallelFor(size_t n, const std::function<void(size_t, size_t)>& fn) {
   for (auto& x : th) x.join();
   if (err) std::rethrow_exception(err);
 }
+
+namespace {
+struct DownloadStage {
+  static constexpr size_t kBytes = (size_t)32 << 20;
+  void* buf[2] = {nullptr, nullptr};
+  void* ev[2] = {nullptr, nullptr};
+  std::mutex mu;
+  void ensure() {
+    for (int i = 0; i < 2; i++) {
+      if (!buf[i]) CheckHip(prost_hip_host_alloc(&buf[i], kBytes), "host_alloc");
+      if (!ev[i]) CheckHip(prost_hip_event_create(&ev[i]), "event_create");
+    }
+  }
+};
+DownloadStage g_download;
+}  // namespace
+
+template <class D, class T>
+void DownloadAs(D* dst, const T* dev, size_t n) {
+  if (n == 0) return;
+  void* st = CurrentStream();
+  std::lock_guard<std::mutex> lock(g_download.mu);
+  g_download.ensure();
+  const size_t ce = DownloadStage::kBytes / sizeof(T), chunks = (n + ce - 1) / ce;
+  auto issue = [&](size_t k) {
+    const size_t b = k * ce, len = std::min(ce, n - b);
+    CheckHip(prost_hip_memcpy_d2h(g_download.buf[k & 1], dev + b, len * sizeof(T), st), "memcpy_d2h");
+    CheckHip(prost_hip_event_record(g_download.ev[k & 1], st), "event_record");
+  };
+  issue(0);
+  for (size_t k = 0; k < chunks; k++) {
+    if (k + 1 < chunks) issue(k + 1);                   // into the buffer whose contents were moved out in the previous round
+    CheckHip(prost_hip_event_synchronize(g_download.ev[k & 1]), "event_synchronize");
+    const size_t b = k * ce, len = std::min(ce, n - b);
+    const T* src = static_cast<const T*>(g_download.buf[k & 1]);
+    D* out = dst + b;
+    ParallelFor(len, [&](size_t lo, size_t hi) {
+      if (std::is_same<D, T>::value) std::memcpy(static_cast<void*>(out + lo), static_cast<const void*>(src + lo), (hi - lo) * sizeof(T));
+      else for (size_t i = lo; i < hi; i++) out[i] = (D)src[i];
+    });
+  }
+}
+template void DownloadAs<float, float>(float*, const float*, size_t);
+template void DownloadAs<double, double>(double*, const double*, size_t);
+template void DownloadAs<double, float>(double*, const float*, size_t);
+template void DownloadAs<int32_t, int32_t>(int32_t*, const int32_t*, size_t);
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 StageTimer::StageTimer(const char* name) : name_(name), t0_(0), on_(std::getenv("PROST_TIMING") != nullptr) {

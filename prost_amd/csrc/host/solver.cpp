@@ -109,7 +109,9 @@ typename Solver<T>::ConvergenceResult Solver<T>::Solve() {
     const bool is_stopped = stopping_cb_ ? stopping_cb_() : false;
 
     if (i >= cb_iters.front() || is_converged || is_stopped || i == (opts_.max_iters - 1)) {
-      FetchSolution();
+      // the observation that ends the run, nobody to show intermediate solutions to: the caller may take the result directly
+      const bool last = is_converged || is_stopped || i == (opts_.max_iters - 1);
+      if (!(last && !interm_cb_ && final_readout_ && final_readout_())) FetchSolution();
       if (opts_.num_cback_calls >= 1) {
         if (opts_.verbose) {
           const int digits = (int)std::floor(std::log10((double)opts_.max_iters)) + 1;
