@@ -50,7 +50,7 @@ void SetCurrentStream(void* stream);
 /// throws prost::Exception(prost_hip_last_error()) if rc != 0
 void CheckHip(int rc, const char* what);
 
-/// fn(begin, end) over disjoint sub-ranges of [0, n) on up to 8 host threads (the one-off setup passes over 10^7..10^8
+/// fn(begin, end) over disjoint sub-ranges of [0, n) on up to 16 host threads (the one-off setup passes over 10^7..10^8
 /// host entries are memory-bound loops); runs inline when n is small.  fn must only touch its own range.
 void ParallelFor(size_t n, const std::function<void(size_t, size_t)>& fn);
 /// number of sub-ranges ParallelFor(n, ...) uses, and the i-th of them (for two-phase scans with a carried value)
@@ -62,6 +62,10 @@ void ParallelChunkRange(size_t n, size_t i, size_t& begin, size_t& end);
 /// plain copy).  `dst` may be pageable, untouched memory -- its pages are first touched by the copying threads.  Synchronous.
 /// (400 MB of results at 4096^2: a pageable hipMemcpy into zero-filled std::vectors + a widening pass took 0.22 s.)
 template <class D, class T> void DownloadAs(D* dst, const T* dev, size_t n);
+/// The other direction for data that is GENERATED on the host: gen(p, len) fills consecutive pieces of the sequence straight
+/// into the pinned staging buffers, each piece is on its way to `dev` while the next one is generated (no pageable copy of the
+/// whole vector, no page faults on it).  Synchronous.
+template <class T> void UploadGenerated(T* dev, size_t n, const std::function<void(T*, size_t)>& gen);
 
 /// Wall-clock of a setup stage, printed to stderr at scope exit when the environment variable
 /// PROST_TIMING is set (the stream is synchronised first so device work is attributed to its stage).

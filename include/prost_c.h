@@ -100,7 +100,7 @@ int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size);
  *   set_precision('single'|'double'), get_precision -> string
  *   problem_info(problem, nrows, ncols) -> struct {scaling_left, scaling_right, nrows, ncols,
  *                                                   prox_g, prox_f, prox_gstar, prox_fstar}  (index/size/name rows)
- *   glibc_rand_unit(n[, skip]) -> n x 1: (T)rand() / (T)RAND_MAX of a fresh process after `skip` draws (the start vector
+ *   glibc_rand_unit(n[, skip[, piece]]) -> n x 1 (drawn in consecutive pieces of `piece` values when given): (T)rand() / (T)RAND_MAX of a fresh process after `skip` draws (the start vector
  *       of Problem::normest, problem.cu:441-444; host only)
  *   solver_create(problem, nrows, ncols, backend, opts[, [x0 x1 nx]]) -> handle (scalar); the optional
  *       1x3 matrix marks image columns [x0, x1) of nx as OWNED (column-sharded images: the rest are halo

@@ -505,6 +505,23 @@ enum { PROST_NORMEST_A = 0, PROST_NORMEST_B, PROST_NORMEST_C };
 int prost_hip_normest_stage_f32(int stage, const prost_hip_normest_desc* d, void* stream);
 int prost_hip_normest_stage_f64(int stage, const prost_hip_normest_desc* d, void* stream);
 
+/* The whole round in ONE kernel when the operator is a single gradient2d / gradient3d block (not label_first) under constant
+ * preconditioners tau, sigma (kernels_normest_grad.hip): x_out = sqrt(tau) K^T sigma K sqrt(tau) (x_in / norm), out[0] = |a|,
+ * out[1] = |x_out| as the three stages above report them.  x_out is bit-identical to the staged round (every intermediate
+ * value is formed by the same expression); the norms sum the same terms in another order.  x_in != x_out (n = nx ny L
+ * elements each); norm_x_from: NULL or 0.0 there = first round, no divide; workspace: prost_hip_cgls_workspace_bytes(). */
+typedef struct prost_hip_normest_grad_desc {
+  int is3d;
+  uint64_t nx, ny, L;
+  const void* x_in; void* x_out;
+  double tau, sigma;
+  const double* norm_x_from;
+  double* out;
+  void* workspace;
+} prost_hip_normest_grad_desc;
+int prost_hip_normest_grad_round_f32(const prost_hip_normest_grad_desc* d, void* stream);
+int prost_hip_normest_grad_round_f64(const prost_hip_normest_grad_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* multi-GPU: global stopping criterion (no counterpart in the reference)        */
 /* ------------------------------------------------------------------------------------------ */

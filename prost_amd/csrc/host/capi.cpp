@@ -681,16 +681,22 @@ void cmd_problem_info(CMD_ARGS) {
   if (g_single) problem_info_t<float>(nlhs, plhs, nrhs, prhs); else problem_info_t<double>(nlhs, plhs, nrhs, prhs);
 }
 
-/// glibc_rand_unit(n[, skip]) -> n x 1: (T)rand() / (T)RAND_MAX of a fresh process after `skip` draws -- the start vector of
+/// glibc_rand_unit(n[, skip[, piece]]) -> n x 1: (T)rand() / (T)RAND_MAX of a fresh process after `skip` draws -- the start vector of
 /// Problem::normest (problem.cu:441-444) as GlibcRand::fill_unit generates it (chunk-parallel by jump-ahead); host only
 void cmd_glibc_rand_unit(CMD_ARGS) {
   if (nrhs < 1) throw Exception("glibc_rand_unit: n required.");
   const size_t n = (size_t)prhs[0]->data[0], skip = nrhs >= 2 ? (size_t)prhs[1]->data[0] : 0;
+  const size_t piece = nrhs >= 3 && prhs[2]->data[0] > 0 ? (size_t)prhs[2]->data[0] : n;     // consecutive fill_unit calls of this length
   GlibcRand rng(1);
   for (size_t i = 0; i < skip; i++) rng.next();
   prost_value* out = prost_value_matrix(nullptr, n, 1);
-  if (g_single) { std::vector<float> v(n); rng.fill_unit(v.data(), n); for (size_t i = 0; i < n; i++) out->data[i] = v[i]; }
-  else rng.fill_unit(out->data.data(), n);
+  if (g_single) {
+    std::vector<float> v(n);
+    for (size_t b = 0; b < n; b += piece) rng.fill_unit(v.data() + b, std::min(piece, n - b));
+    for (size_t i = 0; i < n; i++) out->data[i] = v[i];
+  } else {
+    for (size_t b = 0; b < n; b += piece) rng.fill_unit(out->data.data() + b, std::min(piece, n - b));
+  }
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 void cmd_solver_create(CMD_ARGS) {

@@ -51,7 +51,16 @@ void device_vector<T>::resize(size_t n, T fill) {
 template <typename T>
 device_vector<T>& device_vector<T>::operator=(const std::vector<T>& host) {
   if (host.size() != size_) { clear(); if (!host.empty()) { void* p = nullptr; int rc = prost_hip_malloc(&p, host.size() * sizeof(T)); if (rc != 0) throw Exception(std::string("Out of memory: ") + prost_hip_last_error()); data_ = static_cast<T*>(p); size_ = host.size(); } }
-  if (size_) {
+  if (size_ * sizeof(T) >= ((size_t)4 << 20)) {
+    // through the pinned staging buffers: host threads copy piece k + 1 while piece k is on the bus
+    size_t off = 0;
+    const T* src = host.data();
+    UploadGenerated<T>(data_, size_, [&](T* p, size_t len) {
+      const T* from = src + off;
+      ParallelFor(len, [&](size_t lo, size_t hi) { std::memcpy(static_cast<void*>(p + lo), static_cast<const void*>(from + lo), (hi - lo) * sizeof(T)); });
+      off += len;
+    });
+  } else if (size_) {
     CheckHip(prost_hip_memcpy_h2d(data_, host.data(), size_ * sizeof(T), CurrentStream()), "memcpy_h2d");
     CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");   // host vector may be a temporary
   }
@@ -199,7 +208,7 @@ size_t ParallelChunks(size_t n) {
   const size_t kMinChunk = (size_t)1 << 20;
   size_t hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 1;
-  const size_t t = std::min<size_t>(std::min<size_t>(8, hw), (n + kMinChunk - 1) / kMinChunk);
+  const size_t t = std::min<size_t>(std::min<size_t>(16, hw), (n + kMinChunk - 1) / kMinChunk);
   return t < 1 ? 1 : t;
 }
 void ParallelChunkRange(size_t n, size_t i, size_t& begin, size_t& end) {
@@ -264,6 +273,27 @@ void DownloadAs(D* dst, const T* dev, size_t n) {
     });
   }
 }
+template <class T>
+void UploadGenerated(T* dev, size_t n, const std::function<void(T*, size_t)>& gen) {
+  if (n == 0) return;
+  void* st = CurrentStream();
+  std::lock_guard<std::mutex> lock(g_download.mu);
+  g_download.ensure();
+  const size_t ce = DownloadStage::kBytes / sizeof(T), chunks = (n + ce - 1) / ce;
+  for (size_t k = 0; k < chunks; k++) {
+    if (k >= 2) CheckHip(prost_hip_event_synchronize(g_download.ev[k & 1]), "event_synchronize");     // the copy that last read this buffer
+    const size_t b = k * ce, len = std::min(ce, n - b);
+    T* p = static_cast<T*>(g_download.buf[k & 1]);
+    gen(p, len);
+    CheckHip(prost_hip_memcpy_h2d(dev + b, p, len * sizeof(T), st), "memcpy_h2d");
+    CheckHip(prost_hip_event_record(g_download.ev[k & 1], st), "event_record");
+  }
+  CheckHip(prost_hip_stream_synchronize(st), "stream_synchronize");
+}
+template void UploadGenerated<float>(float*, size_t, const std::function<void(float*, size_t)>&);
+template void UploadGenerated<double>(double*, size_t, const std::function<void(double*, size_t)>&);
+template void UploadGenerated<int32_t>(int32_t*, size_t, const std::function<void(int32_t*, size_t)>&);
+
 template void DownloadAs<float, float>(float*, const float*, size_t);
 template void DownloadAs<double, double>(double*, const double*, size_t);
 template void DownloadAs<double, float>(double*, const float*, size_t);

@@ -54,6 +54,7 @@ template <typename T> struct Api;
     static constexpr auto cgls_stage = prost_hip_cgls_stage_##S;                  \
     static constexpr auto admm_stage = prost_hip_admm_stage_##S;                  \
     static constexpr auto normest_stage = prost_hip_normest_stage_##S;            \
+    static constexpr auto normest_grad_round = prost_hip_normest_grad_round_##S;  \
   };
 
 PROST_API_STRUCT(float, f32)

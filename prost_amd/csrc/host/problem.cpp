@@ -259,15 +259,22 @@ void Problem<T>::MaterializeHost() const {
 template <typename T>
 T Problem<T>::normest(T tol, int max_iters) {
   const size_t n = ncols(), m = nrows();
-  device_vector<T> x(n), x_temp(n), Ax_temp(m);
+  // ONE gradient block under constant preconditioners (the ROF / TV problems): the whole round is one stencil kernel and K x
+  // is never stored (prost_hip_normest_grad_round: 2 instead of 23 values per voxel through HBM per round)
+  BlockDesc bd;
+  bool grad_round = dynamic_cast<DualLinearOperator<T>*>(linop_.get()) == nullptr && linop_->blocks().size() == 1 && left_uniform_ && right_uniform_;
+  if (grad_round) {
+    auto blk = linop_->blocks()[0];
+    grad_round = blk->describe(bd) && !bd.label_first && (bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D) &&
+                 blk->row() == 0 && blk->col() == 0 && blk->nrows() == m && blk->ncols() == n &&
+                 n == bd.nx * bd.ny * bd.L && m == (bd.kind == BlockDesc::kGradient3D ? 3 : 2) * n;
+  }
+  device_vector<T> x(n), x_temp(n), Ax_temp(grad_round ? 0 : m);
   {
     StageTimer t_rng("  normest: start vector (glibc rand stream)");
-    // not value-initialised: the pages are first touched by the generating threads, not by a serial zero fill
-    std::unique_ptr<T[]> x_host(new T[n]);
+    // generated piecewise into pinned staging buffers, every piece on its way to the device while the next one is drawn
     GlibcRand rng(1);
-    rng.fill_unit(x_host.get(), n);                      // x[i] = (T)rand() / (T)RAND_MAX (problem.cu:441-444)
-    CheckHip(prost_hip_memcpy_h2d(x.data(), x_host.get(), n * sizeof(T), CurrentStream()), "memcpy_h2d");
-    CheckHip(prost_hip_stream_synchronize(CurrentStream()), "sync");
+    UploadGenerated<T>(x.data(), n, [&](T* p, size_t len) { rng.fill_unit(p, len); });      // x[i] = (T)rand() / (T)RAND_MAX (problem.cu:441-444)
   }
   // Per round the reference runs four scaling passes, two nrm2 (each with a blocking read-back) and a divide around K
   // and K^T; here three fused passes (prost_hip_normest_stage_*: same expressions and roundings), the two norms land in
@@ -293,6 +300,15 @@ T Problem<T>::normest(T tol, int max_iters) {
       for (int i = i0; i < i1; i++) {
         d.out = out_host + 2 * i;
         d.norm_x_from = i > 0 ? out_host + 2 * (i - 1) + 1 : nullptr;
+        if (grad_round) {
+          prost_hip_normest_grad_desc g;
+          g.is3d = bd.kind == BlockDesc::kGradient3D ? 1 : 0; g.nx = bd.nx; g.ny = bd.ny; g.L = bd.L;
+          g.x_in = (i & 1) ? x_temp.data() : x.data(); g.x_out = (i & 1) ? x.data() : x_temp.data();     // ping-pong (stencil)
+          g.tau = (double)right_value_; g.sigma = (double)left_value_;
+          g.norm_x_from = d.norm_x_from; g.out = d.out; g.workspace = ws;
+          CheckHip(Api<T>::normest_grad_round(&g, CurrentStream()), "normest_grad_round");
+          continue;
+        }
         CheckHip(Api<T>::normest_stage(PROST_NORMEST_A, &d, CurrentStream()), "normest_stage");
         linop_->Eval(Ax_temp, x_temp);
         CheckHip(Api<T>::normest_stage(PROST_NORMEST_B, &d, CurrentStream()), "normest_stage");

@@ -193,6 +193,11 @@ def test_glibc_rand_stream_is_generated_chunk_parallel_and_stays_exact():
             got = np.asarray(_capi.command("glibc_rand_unit", [n, skip], nlhs=1)[0]).reshape(-1)
             ref = oracle.glibc_rand(1, n + skip)[skip:].astype(np.float32) / np.float32(2147483647)
             assert got.shape == (n,) and np.array_equal(got.astype(np.float32), ref), (n, skip, int((got.astype(np.float32) != ref).sum()))
+        # consecutive calls continue the stream (Problem::normest draws the start vector piece by piece into pinned staging buffers)
+        for n, skip, piece in ((100, 0, 7), (5 * (1 << 20) + 3, 3, (1 << 21) + 5), (3 * (1 << 20), 0, 1 << 20), (40, 2, 31)):
+            got = np.asarray(_capi.command("glibc_rand_unit", [n, skip, piece], nlhs=1)[0]).reshape(-1)
+            ref = oracle.glibc_rand(1, n + skip)[skip:].astype(np.float32) / np.float32(2147483647)
+            assert np.array_equal(got.astype(np.float32), ref), (n, skip, piece, int((got.astype(np.float32) != ref).sum()))
         prost.set_precision("double")
         n = 3 * (1 << 20) + 11
         got = np.asarray(_capi.command("glibc_rand_unit", [n], nlhs=1)[0]).reshape(-1)

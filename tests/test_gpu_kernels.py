@@ -648,3 +648,51 @@ def test_multichannel_single_kernel_equals_two_passes(hip, dtype, shape, fns, ve
                 if res:
                     assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
     hip.sync()
+
+
+class _NormestDesc(C.Structure):
+    _fields_ = [("workspace", C.c_void_p), ("x", C.c_void_p), ("x_temp", C.c_void_p), ("ax", C.c_void_p), ("sigma", C.c_void_p), ("tau", C.c_void_p),
+                ("m", C.c_uint64), ("n", C.c_uint64), ("norm_x", C.c_double), ("out", C.c_void_p), ("norm_x_from", C.c_void_p)]
+
+
+class _NormestGradDesc(C.Structure):
+    _fields_ = [("is3d", C.c_int), ("nx", C.c_uint64), ("ny", C.c_uint64), ("L", C.c_uint64), ("x_in", C.c_void_p), ("x_out", C.c_void_p),
+                ("tau", C.c_double), ("sigma", C.c_double), ("norm_x_from", C.c_void_p), ("out", C.c_void_p), ("workspace", C.c_void_p)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(9, 16, 1, False), (33, 250, 3, False), (7, 1028, 2, False), (12, 16, 5, True), (5, 251, 9, True), (40, 512, 3, True), (1, 8, 1, True), (6, 1, 4, False)])
+def test_normest_gradient_round_equals_the_staged_round(hip, dtype, shape):
+    """prost_hip_normest_grad_round (the whole power-iteration round of Problem::normest in one stencil kernel, for a single
+    gradient block under constant preconditioners) against the staged round NORMEST_A, K, NORMEST_B, K^T, NORMEST_C it replaces:
+    same bits in the new x, the two norms to summation order -- first round (no divide) and a later one (x / |x|)."""
+    nx, ny, L, d3 = shape
+    n = nx * ny * L
+    m = (3 if d3 else 2) * n
+    rng = np.random.default_rng(8)
+    tau, sigma = dtype(1.0 / (6 if d3 else 4)), dtype(0.5)
+    lib = hip.lib()
+    ws = hip.DeviceArray(lib.prost_hip_cgls_workspace_bytes() // 8, np.float64)
+    name = "grad3d" if d3 else "grad2d"
+    for norm_prev in (0.0, 37.25):
+        x0 = rng.uniform(0, 1, n).astype(dtype)
+        # staged
+        x = dev(hip, x0); xt = hip.DeviceArray.zeros(n, dtype); ax = hip.DeviceArray.zeros(m, dtype)
+        sig = dev(hip, np.full(m, sigma, dtype)); ta = dev(hip, np.full(n, tau, dtype))
+        out = hip.DeviceArray.zeros(2, np.float64); nf = dev(hip, np.array([norm_prev]))
+        d = _NormestDesc(ws.ptr.value, x.ptr.value, xt.ptr.value, ax.ptr.value, sig.ptr.value, ta.ptr.value, m, n, 0.0, out.ptr.value, nf.ptr.value)
+        stage = hip.fn("normest_stage", dtype)
+        hip.check(stage(0, C.byref(d), None))
+        hip.check(hip.fn(name + "_fwd", dtype)(ax.ptr, xt.ptr, hip.sz(nx), hip.sz(ny), hip.sz(L), 0, 0, None))
+        hip.check(stage(1, C.byref(d), None))
+        hip.check(hip.fn(name + "_adj", dtype)(xt.ptr, ax.ptr, hip.sz(nx), hip.sz(ny), hip.sz(L), 0, 0, None))
+        hip.check(stage(2, C.byref(d), None))
+        x_ref, out_ref = x.to_host(), out.to_host()
+        # one kernel
+        xi = dev(hip, x0); xo = hip.DeviceArray.zeros(n, dtype); out2 = hip.DeviceArray.zeros(2, np.float64)
+        g = _NormestGradDesc(1 if d3 else 0, nx, ny, L, xi.ptr.value, xo.ptr.value, float(tau), float(sigma), nf.ptr.value, out2.ptr.value, ws.ptr.value)
+        hip.check(hip.fn("normest_grad_round", dtype)(C.byref(g), None))
+        assert np.array_equal(xo.to_host(), x_ref), (norm_prev, np.flatnonzero(xo.to_host() != x_ref)[:8])
+        assert np.allclose(out2.to_host(), out_ref, rtol=1e-12, atol=0), (out2.to_host(), out_ref)
+        assert np.all(out_ref > 0)
+    hip.sync()
