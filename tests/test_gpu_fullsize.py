@@ -64,6 +64,14 @@ def test_c2_4096_default_path_matches_oracle_bit_for_bit():
     # residual scalars: double accumulation here, T-precision sums in the oracle (tolerance as in test_gpu_solver.py)
     for v in ("primal_res", "dual_res"):
         assert np.isclose(st[v], sc[v], rtol=1e-5), (v, st[v], sc[v])
+    # the same 12 iterations through prost.solve: the result is streamed from the device into the caller's double arrays in
+    # 32 MiB pieces (x: 2, y and z: 4 each, w: 2) through the pinned staging buffers -- every element must arrive, in place
+    r = prost.solve(prob, b, prost.options(max_iters=k, num_cback_calls=0, verbose=False, **ZERO_TOL))
+    assert r["result"] == "Reached maximum iterations." and r["iters"] == k
+    for v in "xyzw":
+        got = np.asarray(r[v]).reshape(-1)
+        assert got.dtype == np.float64 and got.shape == ost[v].shape
+        assert np.array_equal(got, ost[v].astype(np.float64)), (v, int((got != ost[v]).sum()))
 
 
 def _crop(f, nx, ny, L, x0, x1, y0, y1, l0, l1):
