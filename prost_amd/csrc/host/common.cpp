@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <chrono>
 #include <exception>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <type_traits>
@@ -237,7 +238,6 @@ struct DownloadStage {
   static constexpr size_t kBytes = (size_t)32 << 20;
   void* buf[2] = {nullptr, nullptr};
   void* ev[2] = {nullptr, nullptr};
-  std::mutex mu;
   void ensure() {
     for (int i = 0; i < 2; i++) {
       if (!buf[i]) CheckHip(prost_hip_host_alloc(&buf[i], kBytes), "host_alloc");
@@ -245,27 +245,36 @@ struct DownloadStage {
     }
   }
 };
-DownloadStage g_download;
+// one stage per device (events belong to the device they were created on); all transfers of the process serialise on one lock
+std::mutex g_stage_mu;
+std::map<int, DownloadStage> g_stages;
+DownloadStage& stage_of_current_device() {
+  int dev = 0;
+  CheckHip(prost_hip_get_device(&dev), "get_device");
+  DownloadStage& st = g_stages[dev];
+  st.ensure();
+  return st;
+}
 }  // namespace
 
 template <class D, class T>
 void DownloadAs(D* dst, const T* dev, size_t n) {
   if (n == 0) return;
   void* st = CurrentStream();
-  std::lock_guard<std::mutex> lock(g_download.mu);
-  g_download.ensure();
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  DownloadStage& stg = stage_of_current_device();
   const size_t ce = DownloadStage::kBytes / sizeof(T), chunks = (n + ce - 1) / ce;
   auto issue = [&](size_t k) {
     const size_t b = k * ce, len = std::min(ce, n - b);
-    CheckHip(prost_hip_memcpy_d2h(g_download.buf[k & 1], dev + b, len * sizeof(T), st), "memcpy_d2h");
-    CheckHip(prost_hip_event_record(g_download.ev[k & 1], st), "event_record");
+    CheckHip(prost_hip_memcpy_d2h(stg.buf[k & 1], dev + b, len * sizeof(T), st), "memcpy_d2h");
+    CheckHip(prost_hip_event_record(stg.ev[k & 1], st), "event_record");
   };
   issue(0);
   for (size_t k = 0; k < chunks; k++) {
     if (k + 1 < chunks) issue(k + 1);                   // into the buffer whose contents were moved out in the previous round
-    CheckHip(prost_hip_event_synchronize(g_download.ev[k & 1]), "event_synchronize");
+    CheckHip(prost_hip_event_synchronize(stg.ev[k & 1]), "event_synchronize");
     const size_t b = k * ce, len = std::min(ce, n - b);
-    const T* src = static_cast<const T*>(g_download.buf[k & 1]);
+    const T* src = static_cast<const T*>(stg.buf[k & 1]);
     D* out = dst + b;
     ParallelFor(len, [&](size_t lo, size_t hi) {
       if (std::is_same<D, T>::value) std::memcpy(static_cast<void*>(out + lo), static_cast<const void*>(src + lo), (hi - lo) * sizeof(T));
@@ -277,16 +286,16 @@ template <class T>
 void UploadGenerated(T* dev, size_t n, const std::function<void(T*, size_t)>& gen) {
   if (n == 0) return;
   void* st = CurrentStream();
-  std::lock_guard<std::mutex> lock(g_download.mu);
-  g_download.ensure();
+  std::lock_guard<std::mutex> lock(g_stage_mu);
+  DownloadStage& stg = stage_of_current_device();
   const size_t ce = DownloadStage::kBytes / sizeof(T), chunks = (n + ce - 1) / ce;
   for (size_t k = 0; k < chunks; k++) {
-    if (k >= 2) CheckHip(prost_hip_event_synchronize(g_download.ev[k & 1]), "event_synchronize");     // the copy that last read this buffer
+    if (k >= 2) CheckHip(prost_hip_event_synchronize(stg.ev[k & 1]), "event_synchronize");     // the copy that last read this buffer
     const size_t b = k * ce, len = std::min(ce, n - b);
-    T* p = static_cast<T*>(g_download.buf[k & 1]);
+    T* p = static_cast<T*>(stg.buf[k & 1]);
     gen(p, len);
     CheckHip(prost_hip_memcpy_h2d(dev + b, p, len * sizeof(T), st), "memcpy_h2d");
-    CheckHip(prost_hip_event_record(g_download.ev[k & 1], st), "event_record");
+    CheckHip(prost_hip_event_record(stg.ev[k & 1], st), "event_record");
   }
   CheckHip(prost_hip_stream_synchronize(st), "stream_synchronize");
 }

@@ -19,8 +19,8 @@
 //   1.2 ms, together 1.5-1.6 ms.  The HBM traffic of a launch is 11.15 GB (rocprofv3 counters: 6.62 GB read + 4.53 GB written;
 //   ideal 5 + 4 floats per voxel = 9.66 GB) for TWO iterations, against 11.3 GB for ONE of the single-iteration kernel.
 // Every stage evaluates the expressions of kernels_fused_iter3d_pw.hip / kernels_fused3d.hip, so x^(k+2), y^(k+2) are
-// bit-identical to two single launches (tests/test_gpu_fused3d.py).  Straight-line ROF shape only (prox_g square with scalar
-// a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), fp32, even heights.  The
+// bit-identical to two single launches (tests/test_gpu_fused3d.py).  Straight-line ROF / TV-L1 shapes only (prox_g square or abs with
+// scalar a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), fp32, even heights.  The
 // intermediate iterate is stored nowhere; the residual sums of the second iteration are available (RES).
 #include "fused_common.hpp"
 #include "reduce.hpp"
@@ -28,8 +28,9 @@
 namespace prost_hip {
 
 template <class T>
-struct IterParams3 {           // step sizes of one iteration + the host-evaluated divisor of Function1DSquare
+struct IterParams3 {           // step sizes of one iteration + the host-evaluated step c tau and divisor 1 + step of Function1DSquare
   T tau, sigma, theta;
+  T step;
   UniformDiv sq;
 };
 
@@ -71,7 +72,7 @@ struct ColX2 {
 // RES: additionally the four residual sums of the SECOND iteration (primal_residual_transform / dual_residual_transform,
 // backend_pdhg.cu:73-120), term by term the expressions of fused_iter3d_kernel: K^T y^k at column c comes from stage A two
 // steps earlier, everything else is in registers when stages C and D run.  One partial (4 doubles) per workgroup.
-template <class T, int VEC, bool GB, int WT, bool RES>
+template <class T, int VEC, int GFN, bool GB, int WT, bool RES>
 __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                        const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2,
                                                                        double* __restrict__ partial) {
@@ -143,8 +144,14 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
       const T arg = xin[j] - tauT * kty;
       parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
     }
+    // ElemOperation1D<F> with scalar a = 1, d = e = 0 (host-checked): the scaled prox is F_prox(v - b; step) + b.
+    // F = Function1DSquare: the exact division; F = Function1DAbs (TV-L1 data term): soft threshold by step = c tau
     T r[VEC];
-    div_to_float_exact_vec<VEC>(parg, Pm.sq, r);
+    if (GFN == PROST_FN_SQUARE) div_to_float_exact_vec<VEC>(parg, Pm.sq, r);
+    else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) r[j] = f1d_apply<T, GFN>(a.g_fn, parg[j], Pm.step, a.g_val[5], a.g_val[6]);
+    }
 #pragma unroll
     for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? bv[GB ? j : 0] : a.g_val[1]);
   };
@@ -349,7 +356,7 @@ constexpr int kX2Vec = 2, kX2Waves = 16;
 static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (dtype != 0 || !fused3d_desc_ok(d)) return false;
   if (d->ny % kX2Vec != 0 || d->ny < 4 || d->nx < 4) return false;
-  if (d->g_fn != PROST_FN_SQUARE || d->f_fn != PROST_FN_IND_LEQ0) return false;
+  if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;
     if (k != 1 && d->g_coeff_ptr[k]) return false;
@@ -407,10 +414,12 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
   const unsigned grid = (unsigned)(strips * a.chunks * groups);
   if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused 3-D double iteration: grid exceeds the reduction workspace"); return 1; }
   double* partial = static_cast<double*>(ws);
-#define GO(B, R) hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, B, WT, R>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+#define GO2(G, B, R) hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, G, B, WT, R>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+#define GO(B, R) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B, R); else GO2(PROST_FN_SQUARE, B, R); } while (0)
   if (d->g_coeff_ptr[1]) { if (out4) GO(true, true); else GO(true, false); }
   else { if (out4) GO(false, true); else GO(false, false); }
 #undef GO
+#undef GO2
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused 3-D double iteration kernel"); }
   if (out4) return launch_fold4(out4, partial, grid, s);
   return 0;
@@ -430,7 +439,7 @@ static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, cons
     const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau[i] * a.Tval);
     const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma[i] * a.Sval);
     if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused 3-D double iteration: not the straight-line ROF shape"); return 1; }
-    p[i].sq = ug.sq;
+    p[i].sq = ug.sq; p[i].step = ug.step;
   }
   return launch_iter3d_x2<T, kX2Vec, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
 }

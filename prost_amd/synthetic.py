@@ -49,8 +49,8 @@ def rof_problem(nx, ny, L=1, lmb=10.0, seed=42, f=None):
     return prob, u, q, f
 
 
-def tv3d_problem(nx, ny, L, lmb=10.0, seed=42, f=None):
-    """BASELINE config 3: volumetric TV, gradient3d + sum_norm2(3) + sum_1d('square')."""
+def tv3d_problem(nx, ny, L, lmb=10.0, seed=42, f=None, data_term="square"):
+    """BASELINE config 3: volumetric TV, gradient3d + sum_norm2(3) + sum_1d('square'); data_term='abs': volumetric TV-L1."""
     from . import block, function
     from .problem import variable, min_max_problem
     if f is None:
@@ -58,7 +58,7 @@ def tv3d_problem(nx, ny, L, lmb=10.0, seed=42, f=None):
     u = variable(nx * ny * L)
     q = variable(3 * nx * ny * L)
     prob = min_max_problem([u], [q])
-    prob.add_function(u, function.sum_1d("square", 1, f, lmb))
+    prob.add_function(u, function.sum_1d(data_term, 1, f, lmb))
     prob.add_function(q, function.sum_norm2(3, False, "ind_leq0", 1, 1, 1))
     prob.add_dual_pair(u, q, block.gradient3d(nx, ny, L))
     return prob, u, q, f

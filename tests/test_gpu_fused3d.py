@@ -93,8 +93,8 @@ def test_tv3d_pdhg_iterates_match_oracle(hip, precision, dtype, step):
 
 
 @pytest.mark.parametrize("step", ["alg1", "alg2", "boyd"])
-@pytest.mark.parametrize("residual_iter", [1, 3, 4, 5, 10])
-def test_tv3d_pair_schedule_is_invisible(hip, step, residual_iter):
+@pytest.mark.parametrize("residual_iter,data_term", [(1, "square"), (3, "square"), (4, "square"), (5, "square"), (10, "square"), (10, "abs"), (3, "abs")])
+def test_tv3d_pair_schedule_is_invisible(hip, step, residual_iter, data_term):
     """fp32 volumetric TV with two iterations per launch (prost_hip_fused_iteration3d_x2) wherever neither k nor k+2 is a
     residual iteration (k+1 may be one: the kernel forms its sums): the state after ANY number of iterations -- x, y, the constraint variables z, w (which need the
     previous iterate, rebuilt by one single launch after a pair), residuals, step sizes -- is bit-identical to the path
@@ -104,7 +104,7 @@ def test_tv3d_pair_schedule_is_invisible(hip, step, residual_iter):
     o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
     try:
         for (nx, ny, L) in ((12, 16, 5), (9, 250, 14), (6, 128, 30)):
-            prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, seed=2)
+            prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, seed=2, data_term=data_term, lmb=10.0 if data_term == "square" else 0.7)
             for iters in (2, 3, 4, 5, 9, 10, 11, 23):
                 states = []
                 for pair in (True, False):
@@ -225,8 +225,8 @@ def test_single_kernel_3d_iteration_equals_two_passes(hip, dtype, shape, fns, ve
 
 @pytest.mark.parametrize("shape", [(6, 8, 1), (5, 12, 4), (20, 1028, 3), (33, 64, 5), (4, 256, 2), (40, 508, 6), (7, 16, 9), (5, 24, 15), (64, 252, 11), (9, 248, 7), (9, 250, 14), (5, 6, 29), (12, 130, 13), (70, 126, 27)])
 @pytest.mark.parametrize("vector_b", [True, False])
-@pytest.mark.parametrize("radius", [1.0, 1e-7])
-def test_double_3d_iteration_equals_two_single_launches(hip, shape, vector_b, radius):
+@pytest.mark.parametrize("radius,g_fn", [(1.0, "square"), (1e-7, "square"), (1.0, "abs")])
+def test_double_3d_iteration_equals_two_single_launches(hip, shape, vector_b, radius, g_fn):
     """prost_hip_fused_iteration3d_x2 (two iterations per launch, planes across wavefronts, stages meeting in LDS) against two
     iterations of the two-pass kernels, which are pinned to the oracle above: same bits for
     x^(k+2) and all three components of y^(k+2), for every chunk width (1: every column a chunk border; 64: one chunk), plane
@@ -242,7 +242,7 @@ def test_double_3d_iteration_equals_two_single_launches(hip, shape, vector_b, ra
     g_coeffs = [1.0, f if vector_b else 0.4, 10.0, 0.0, 0.0, 0.3, 0.0]
     f_coeffs = [1.0, radius, 1.0, 0.0, 0.0, 0.3, 0.0]
     d = hip.FusedDesc(); d.is3d = 1; d.nx, d.ny, d.L = nx, ny, L
-    d.g_fn = hip.FN_ID["square"]; d.f_fn = hip.FN_ID["ind_leq0"]
+    d.g_fn = hip.FN_ID[g_fn]; d.f_fn = hip.FN_ID["ind_leq0"]          # abs: the TV-L1 data term (soft threshold around b)
     gp, gv, k1 = hip.coeff_args(g_coeffs, dtype, n)
     fp, fv, k2 = hip.coeff_args(f_coeffs, dtype, n)
     for i in range(7):
