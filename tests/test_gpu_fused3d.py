@@ -92,7 +92,7 @@ def test_tv3d_pdhg_iterates_match_oracle(hip, precision, dtype, step):
         prost.set_precision("double")
 
 
-@pytest.mark.parametrize("step", ["alg1", "alg2", "boyd"])
+@pytest.mark.parametrize("step", ["alg1", "alg2", "boyd", "goldstein"])
 @pytest.mark.parametrize("residual_iter,data_term", [(1, "square"), (3, "square"), (4, "square"), (5, "square"), (10, "square"), (10, "abs"), (3, "abs")])
 def test_tv3d_pair_schedule_is_invisible(hip, step, residual_iter, data_term):
     """fp32 volumetric TV with two iterations per launch (prost_hip_fused_iteration3d_x2) wherever neither k nor k+2 is a
