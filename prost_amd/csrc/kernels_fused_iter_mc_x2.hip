@@ -1,0 +1,272 @@
+// kernels_fused_iter_mc_x2.hip -- gradient2d with L = 2, 3 or 4 channels (vectorial TV: RGB images, flow fields), TWO PDHG
+// iterations per kernel launch.
+//
+// The channels run on the wavefronts of a workgroup as in kernels_fused_iter_mc.hip; every wavefront runs the 4-stage column
+// pipeline of the gray-value pair kernel (kernels_fused_iter2.hip) on ITS channel:
+//     A(c+2): x1 = primal step of iteration k            B(c+1): y1 = dual step of iteration k
+//     C(c)  : x2 = primal step of iteration k+1          D(c-1): y2 = dual step of iteration k+1
+// The only coupling between channels is the norm over the 2 L gradient components of a pixel in the two dual steps: stages B
+// and D first form their dual arguments and publish the squares in LDS, ONE workgroup barrier per column step, then every
+// wavefront adds the 2 L squares of both stages in the reference's component order (all d/dx, then all d/dy; channel order
+// inside: the float additions of `norm += arg[i] * arg[i]`) and finishes the two projections.  Double-buffered LDS
+// (2 x 2 stages x 2 L x 256 floats = 32 KiB for L = 4), so that the barrier of the next step is the only other fence.
+// Row neighbours come from adjacent lanes (DPP), lanes 0 and 63 are halo lanes as in the gray-value pair kernel.
+// Per channel: 7 floats per pixel per TWO iterations (y1, y2, x, b read; x, y1, y2 written) against 2 x 7 for the
+// single-iteration kernel.  x^(k+2), y^(k+2) are bit-identical to two single launches (tests/test_gpu_kernels.py).
+// Straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0, b scalar or per pixel; prox_f*
+// ind_leq0 with scalar a = 1, d = e = 0), fp32, heights that are a multiple of 4; the intermediate iterate is stored nowhere
+// and there are no residual sums: BackendPDHG pairs only iterations k, k+1 with no residual iteration among k, k+1, k+2.
+#include "fused_common.hpp"
+
+namespace prost_hip {
+
+template <class T>
+struct IterParamsMc {          // step sizes of one iteration + the host-evaluated step c tau and divisor 1 + step of Function1DSquare
+  T tau, sigma, theta;
+  T step;
+  UniformDiv sq;
+};
+
+template <class T, int VEC, bool GB>
+struct ColMcX2 {
+  T y1[VEC], y2[VEC], x[VEC], b[GB ? VEC : 1];
+};
+
+template <class T, int VEC>
+__device__ __forceinline__ void ldm_o(const T* __restrict__ base, unsigned byte_off, T (&v)[VEC]) {      // wave-uniform base + lane offset (SADDR form)
+  ldv<T, VEC>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off), v);
+}
+template <class T, int VEC>
+__device__ __forceinline__ void stm_o(T* __restrict__ base, unsigned byte_off, const T (&v)[VEC]) {
+  stv_nt<T, VEC>(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
+}
+
+template <class T, int VEC, int GFN, bool GB, int LW>
+__global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
+                                                                                const T* __restrict__ y, FusedArgs<T> a, IterParamsMc<T> p1,
+                                                                                IterParamsMc<T> p2) {
+  constexpr int kRowsPerWave = (kWave - 2) * VEC;
+  constexpr int kPix = kWave * VEC;
+  __shared__ T s_sq[2][2][2 * LW][kPix];               // [buffer][stage B / D][component][pixel]
+  const long nx = (long)a.nx, ny = (long)a.ny;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // wave-uniform: base pointers live in SGPRs
+  const unsigned total = gridDim.x, chunks = a.chunks;
+  const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // XCD-aware tile order, see kernels_fused_iter.hip
+  const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
+  const unsigned strip = tile / chunks, chunk = tile % chunks;
+  const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
+  const bool active = row0 >= 0 && row0 < ny;
+  const bool owner = active && lane > 0 && lane < kWave - 1;
+  const long xa = (long)chunk * a.cols_per_block;
+  const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const size_t P = (size_t)nx * (size_t)ny, N = P * LW, plane = (size_t)ch * P;
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
+  const T* y1p = y + plane; const T* y2p = y + N + plane;
+  const T* xp = x + plane;
+  const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
+  const unsigned voff = (unsigned)(row0 * (long)sizeof(T));          // meaningful in active lanes only
+
+  typedef ColMcX2<T, VEC, GB> Col;
+  auto load_col = [&](long c, Col& in) {
+    const size_t o = (size_t)c * (size_t)ny;                          // wave-uniform
+    ldm_o<T, VEC>(y1p + o, voff, in.y1); ldm_o<T, VEC>(y2p + o, voff, in.y2); ldm_o<T, VEC>(xp + o, voff, in.x);
+    if constexpr (GB) ldm_o<T, VEC>(bp + o, voff, in.b);
+  };
+  // primal step of this channel at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 on a zero-filled result);
+  // v1 / v2: the dual variable at column c, p1c: its first component at column c-1
+  auto primal = [&](long c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&p1c)[VEC], const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1],
+                    const IterParamsMc<T>& Pm, T (&xn)[VEC]) {
+    const T tauT = Pm.tau * a.Tval;
+    const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
+    T parg[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const long row = row0 + j;
+      T divy = (row < ny - 1) ? v2[j] : (T)0;
+      if (row > 0) divy -= (j > 0 ? v2[j > 0 ? j - 1 : 0] : up);
+      T divx = (c < nx - 1) ? v1[j] : (T)0;
+      if (c > 0) divx -= p1c[j];
+      const T kty = (T)0 - (divx + divy);
+      const T arg = xin[j] - tauT * kty;
+      parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
+    }
+    T r[VEC];
+    if (GFN == PROST_FN_SQUARE) div_to_float_exact_vec<VEC>(parg, Pm.sq, r);
+    else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) r[j] = f1d_apply<T, GFN>(a.g_fn, parg[j], Pm.step, a.g_val[5], a.g_val[6]);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? bv[GB ? j : 0] : a.g_val[1]);
+  };
+  // first half of the dual step at column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77): the two dual arguments of this
+  // channel, their squares published for the norm over all channels
+  auto dual_args = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC], const T (&v1)[VEC],
+                       const T (&v2)[VEC], const IterParamsMc<T>& Pm, T (&av)[2][VEC], T (&sq)[2 * LW][kPix]) {
+    const T sigS = Pm.sigma * a.Sval, theta = Pm.theta;
+    const bool has_next = c + 1 < nx;
+    const T bel_n = lane_down(xn_c[0]);                // lane 63: no source, its last row is halo
+    const T bel_o = lane_down(xo_c[0]);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const long row = row0 + j;
+      const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
+      const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
+      const T kx0 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+      const T kx1 = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
+      const T kp0 = has_next ? xo_n[j] - xo_c[j] : (T)0;
+      const T kp1 = (row < ny - 1) ? below_o - xo_c[j] : (T)0;
+      av[0][j] = v1[j] + sigS * ((1 + theta) * kx0 - theta * kp0);              // backend_pdhg.cu:54-70
+      av[1][j] = v2[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
+      sq[ch][j * kWave + lane] = av[0][j] * av[0][j];                           // [j][lane]: conflict-free banks
+      sq[LW + ch][j * kWave + lane] = av[1][j] * av[1][j];
+    }
+  };
+  // second half, after the barrier: the norm in the component order of ElemOperationNorm2 (d/dx of all channels, then d/dy), the projection
+  auto dual_finish = [&](const T (&av)[2][VEC], const T (&sq)[2 * LW][kPix], T (&out)[2][VEC]) {
+    T nv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      T norm = 0;
+#pragma unroll
+      for (int i = 0; i < 2 * LW; i++) norm += sq[i][j * kWave + lane];
+      nv[j] = norm;
+    }
+    norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+  };
+
+  Col in1 = {}, in2 = {};                              // raw columns c+1 and c+2
+  T b_c[GB ? VEC : 1];                                 // b of prox_g at column c (stage C)
+  T x1_m[VEC], x1_0[VEC], x1_1[VEC], x1_2[VEC];        // x^(k+1) at columns c-1 .. c+2
+  T ya_m[VEC], yb_m[VEC], ya_0[VEC], yb_0[VEC], ya_1[VEC], yb_1[VEC];   // y^(k+1) at columns c-1, c, c+1
+  T x2_m[VEC], x2_0[VEC];                              // x^(k+2) at columns c-1, c
+#pragma unroll
+  for (int j = 0; j < VEC; j++) {
+    x1_m[j] = x1_0[j] = x1_1[j] = x1_2[j] = 0;
+    ya_m[j] = yb_m[j] = ya_0[j] = yb_0[j] = ya_1[j] = yb_1[j] = 0;
+    x2_m[j] = x2_0[j] = 0;
+  }
+#pragma unroll
+  for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = 0;
+  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
+  if (active && xa - 2 >= 0) ldm_o<T, VEC>(y1p + (size_t)(xa - 2) * (size_t)ny, voff, in2.y1);   // becomes in1.y1 for A(xa-1)
+  Col pre = {};
+  if (active && has_col(xa - 1)) load_col(xa - 1, pre);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): nothing of the prologue in flight when the loop starts (see kernels_fused_iter3d_x2.hip)
+
+  for (long c = xa - 3; c <= xb; c++) {
+    const int buf = (int)((c + 4) & 1);
+    in1 = in2; in2 = pre;
+    pre = Col{};
+    if (active && has_col(c + 3)) load_col(c + 3, pre);
+    const long ca = c + 2, cb = c + 1, cd = c - 1;
+    const bool runA = ca >= (xa - 1 > 0 ? xa - 1 : 0) && ca < nx && ca <= xb + 1;
+    const bool runB = cb >= (xa - 1 > 0 ? xa - 1 : 0) && cb < nx && cb <= xb;
+    const bool runC = c >= xa && c < nx && c <= xb;
+    const bool runD = cd >= xa && cd < xb;
+    T avB[2][VEC], avD[2][VEC];
+    if (runA) primal(ca, in2.y1, in2.y2, in1.y1, in2.x, in2.b, p1, x1_2);                          // stage A
+    if (runB) dual_args(cb, x1_1, x1_2, in1.x, in2.x, in1.y1, in1.y2, p1, avB, s_sq[buf][0]);      // stage B, first half
+    if (runC) primal(c, ya_0, yb_0, ya_m, x1_0, b_c, p2, x2_0);                                    // stage C
+    if (runD) dual_args(cd, x2_m, x2_0, x1_m, x1_0, ya_m, yb_m, p2, avD, s_sq[buf][1]);            // stage D, first half
+    __syncthreads();                                   // one barrier per column step (every wavefront runs the same stages)
+    if (runB) {
+      T o[2][VEC];
+      dual_finish(avB, s_sq[buf][0], o);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { ya_1[j] = o[0][j]; yb_1[j] = o[1][j]; }
+    }
+    if (runD) {
+      T o[2][VEC];
+      dual_finish(avD, s_sq[buf][1], o);
+      if (owner) {
+        const size_t off = plane + (size_t)cd * (size_t)ny;           // wave-uniform
+        stm_o<T, VEC>(y_out + off, voff, o[0]); stm_o<T, VEC>(y_out + N + off, voff, o[1]);
+      }
+    }
+    if (runC && owner && c < xb) stm_o<T, VEC>(x_out + plane + (size_t)c * (size_t)ny, voff, x2_0);
+    // shift the pipeline by one column
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      x1_m[j] = x1_0[j]; x1_0[j] = x1_1[j]; x1_1[j] = x1_2[j];
+      ya_m[j] = ya_0[j]; yb_m[j] = yb_0[j];
+      ya_0[j] = ya_1[j]; yb_0[j] = yb_1[j];
+      x2_m[j] = x2_0[j];
+    }
+#pragma unroll
+    for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = in1.b[j];
+  }
+}
+
+static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
+  if (dtype != 0 || !d || d->is3d || d->L < 2 || d->L > 4) return false;
+  if (d->nx < 4 || d->ny < 4 || d->ny % 4 != 0) return false;
+  if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
+  for (int k = 0; k < 7; k++) {
+    if (d->f_coeff_ptr[k]) return false;
+    if (k != 1 && d->g_coeff_ptr[k]) return false;
+  }
+  if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
+  if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
+  if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
+  if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
+  if ((double)d->nx * (double)d->ny * 4.0 >= 4294967296.0) return false;              // 32-bit byte offsets per plane
+  const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
+  return strips * d->nx < (size_t)1 << 31;
+}
+
+// chunk length: the longest one that still fills >= 90 % of the resident wave slots (3 per SIMD) in ONE round -- 3 warm-up
+// columns are amortised over it, a second, mostly empty round would cost a full chunk time (cf. kernels_fused_iter2.hip)
+static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols) {
+  if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
+  const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
+  const size_t slots = 256 * 4 * 3;
+  for (size_t c : {96, 72, 60, 48, 36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * d->L * 10 >= slots * 9) return c < d->nx ? c : d->nx;
+  return d->nx < 9 ? d->nx : 9;
+}
+
+template <class T>
+static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
+                          const double* theta, int cols, void* stream) {
+  if (!iter_mc_x2_ok(d, 0)) { set_error("fused multi-channel double iteration: unsupported description (see prost_hip_fused_iteration_mc_x2_supported)"); return 1; }
+  if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused multi-channel double iteration: vectors must be 16-byte aligned"); return 1; }
+  if (x_out == x || y_out == y) { set_error("fused multi-channel double iteration: outputs must not alias inputs"); return 1; }
+  constexpr int V = 4;
+  FusedArgs<T> a = make_fused_args<T>(d);
+  IterParamsMc<T> p[2];
+  for (int i = 0; i < 2; i++) {
+    p[i].tau = (T)tau[i]; p[i].sigma = (T)sigma[i]; p[i].theta = (T)theta[i];
+    const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau[i] * a.Tval);
+    const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma[i] * a.Sval);
+    if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused multi-channel double iteration: not the straight-line ROF / TV-L1 shape"); return 1; }
+    p[i].sq = ug.sq; p[i].step = ug.step;
+  }
+  const size_t strips = (d->ny + (size_t)(kWave - 2) * V - 1) / ((size_t)(kWave - 2) * V);
+  const size_t c = mc_x2_chunk_cols(d, cols);
+  a.cols_per_block = (int)c;
+  a.chunks = (unsigned)((d->nx + c - 1) / c);
+  const unsigned grid = (unsigned)(strips * a.chunks);
+  hipStream_t s = as_stream(stream);
+#define GO3(G, B, LWv) hipLaunchKernelGGL((fused_iter2d_mc_x2_kernel<T, V, G, B, LWv>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1])
+#define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)
+#define GO(B) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B); else GO2(PROST_FN_SQUARE, B); } while (0)
+  if (d->g_coeff_ptr[1]) GO(true); else GO(false);
+#undef GO
+#undef GO2
+#undef GO3
+  PH_LAUNCH_END("fused multi-channel double iteration kernel");
+}
+
+}  // namespace prost_hip
+
+using namespace prost_hip;
+
+extern "C" {
+int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* d, int dtype) { return iter_mc_x2_ok(d, dtype) ? 1 : 0; }
+int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype) { return iter_mc_x2_ok(d, dtype) ? (int)mc_x2_chunk_cols(d, 0) : 0; }
+int prost_hip_fused_iteration_mc_x2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
+                                        const double* sigma, const double* theta, int cols, void* stream) {
+  return run_iter_mc_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, stream);
+}
+}  // extern "C"

@@ -696,3 +696,55 @@ def test_normest_gradient_round_equals_the_staged_round(hip, dtype, shape):
         assert np.allclose(out2.to_host(), out_ref, rtol=1e-12, atol=0), (out2.to_host(), out_ref)
         assert np.all(out_ref > 0)
     hip.sync()
+
+
+@pytest.mark.parametrize("shape", [(6, 8, 3), (5, 12, 4), (20, 1028, 3), (33, 64, 2), (4, 256, 4), (40, 508, 3), (64, 252, 2), (9, 248, 4), (130, 16, 3)])
+@pytest.mark.parametrize("vector_b", [True, False])
+@pytest.mark.parametrize("radius,g_fn", [(1.0, "square"), (1e-7, "square"), (1.0, "abs")])
+def test_double_multichannel_iteration_equals_two_iterations_of_the_two_pass_kernels(hip, shape, vector_b, radius, g_fn):
+    """prost_hip_fused_iteration_mc_x2 (two iterations per launch, one channel per wavefront, the squares of both dual steps
+    meeting in LDS for the norm over the 2 L components of a pixel) against two iterations of the two-pass kernels, which are
+    pinned to the oracle (test_fused_passes_match_unfused_oracle): same bits for x^(k+2) and all 2 L components of y^(k+2), for
+    every chunk width (1: every column a chunk border; 200: one chunk), 2 / 3 / 4 channels, strip layouts (252 = one strip + 4
+    rows, 1028 rows: five strips) and step sizes that change between the two iterations (alg2)."""
+    dtype = np.float32
+    nx, ny, L = shape
+    rng = np.random.default_rng(13)
+    n, m = nx * ny * L, 2 * nx * ny * L
+    x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
+    f = rng.uniform(0, 1, n)
+    g_coeffs = [1.0, f if vector_b else 0.4, 10.0 if g_fn == "square" else 0.6, 0.0, 0.0, 0.3, 0.0]
+    f_coeffs = [1.0, radius, 1.0, 0.0, 0.0, 0.3, 0.0]
+    d = hip.FusedDesc(); d.is3d = 0; d.nx, d.ny, d.L = nx, ny, L
+    d.g_fn = hip.FN_ID[g_fn]; d.f_fn = hip.FN_ID["ind_leq0"]
+    gp, gv, k1 = hip.coeff_args(g_coeffs, dtype, n)
+    fp, fv, k2 = hip.coeff_args(f_coeffs, dtype, n)
+    for i in range(7):
+        d.g_coeff_ptr[i] = gp[i]; d.g_coeff_val[i] = gv[i]; d.f_coeff_ptr[i] = fp[i]; d.f_coeff_val[i] = fv[i]
+    d.T_val, d.S_val = 0.25, 0.5
+    assert hip.lib().prost_hip_fused_iteration_mc_x2_supported(C.byref(d), 0) == 1
+    assert hip.lib().prost_hip_fused_iteration_mc_x2_supported(C.byref(d), 1) == 0           # fp32 only
+    tau, sigma, theta = [0.9, 0.61], [1.1, 1.63], [0.85, 0.67]
+    dx, dy = dev(hip, x), dev(hip, y)
+    x1 = hip.DeviceArray.zeros(n, dtype); y1 = hip.DeviceArray.zeros(m, dtype)
+    x2 = hip.DeviceArray.zeros(n, dtype); y2 = hip.DeviceArray.zeros(m, dtype)
+    P, D = hip.fn("fused_primal", dtype), hip.fn("fused_dual", dtype)
+    ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
+    hip.check(P(C.byref(d), x1.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau[0]), 1, 0, None, ws.ptr, None))
+    hip.check(D(C.byref(d), y1.ptr, dy.ptr, x1.ptr, dx.ptr, hip.dbl(sigma[0]), hip.dbl(theta[0]), 1, None, ws.ptr, None))
+    hip.check(P(C.byref(d), x2.ptr, x1.ptr, y1.ptr, None, hip.dbl(tau[1]), 1, 0, None, ws.ptr, None))
+    hip.check(D(C.byref(d), y2.ptr, y1.ptr, x2.ptr, x1.ptr, hip.dbl(sigma[1]), hip.dbl(theta[1]), 1, None, ws.ptr, None))
+    x_ref, y_ref = x2.to_host(), y2.to_host()
+    arr = lambda v: (C.c_double * 2)(*v)
+    pad, sentinel = 256, np.float32(-123456.75)
+    for cols in (0, 1, 2, 5, 7, 200):
+        bx = dev(hip, np.full(n + 2 * pad, sentinel, dtype)); by = dev(hip, np.full(m + 2 * pad, sentinel, dtype))      # canaries around the outputs
+        xo = C.c_void_p(bx.ptr.value + pad * 4); yo = C.c_void_p(by.ptr.value + pad * 4)
+        hip.check(hip.lib().prost_hip_fused_iteration_mc_x2_f32(C.byref(d), xo, yo, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols, None))
+        hx, hy = bx.to_host(), by.to_host()
+        assert np.all(hx[:pad] == sentinel) and np.all(hx[pad + n:] == sentinel) and np.all(hy[:pad] == sentinel) and np.all(hy[pad + m:] == sentinel), cols
+        assert np.array_equal(hx[pad:pad + n], x_ref), (cols, np.flatnonzero(hx[pad:pad + n] != x_ref)[:8])
+        for k in range(2 * L):
+            got = hy[pad + k * nx * ny: pad + (k + 1) * nx * ny]
+            assert np.array_equal(got, y_ref[k * nx * ny:(k + 1) * nx * ny]), (cols, k, np.flatnonzero(got != y_ref[k * nx * ny:(k + 1) * nx * ny])[:8])
+    hip.sync()
