@@ -117,7 +117,10 @@ void BackendPDHG<T>::Initialize() {
   pair3d_ = false;
   if constexpr (std::is_same<T, float>::value)
     pair3d_ = fused_ && desc_.is3d && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, 0) == 1;
-  if (pair_kernel_ || pair3d_) x_spare_.resize(n);
+  pair_mc_ = false;
+  if constexpr (std::is_same<T, float>::value)        // 2-4 channels: the channels on the wavefronts of a workgroup, two iterations per launch
+    pair_mc_ = (single_mc_ || (single_kernel_ && desc_.L == 2)) && opts_.allow_pair_kernel && prost_hip_fused_iteration_mc_x2_supported(&desc_, 0) == 1;
+  if (pair_kernel_ || pair3d_ || pair_mc_) x_spare_.resize(n);
   if (single_kernel_ || single3d_ || single_mc_ || pair3d_) y_spare_.resize(m);
 
   CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
@@ -193,6 +196,12 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   // residual iterations are always the second of a pair
   if (pair3d_ && budget >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {
     IterationPair3D(is_residual_iteration(k + 1));
+    return 2;
+  }
+  // 2-4 channels: no residual sums and no stored intermediate iterate in that kernel, so none of k, k+1 (its sums) and k+2
+  // (streams y^(k+1)) may be a residual iteration: 8 of 10 iterations at residual_iter = 10
+  if (pair_mc_ && budget >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 1) && !is_residual_iteration(k + 2)) {
+    IterationPairMc();
     return 2;
   }
   PerformIteration();
@@ -279,13 +288,39 @@ void BackendPDHG<T>::IterationPair3D(bool residuals) {
   }
 }
 
+template <typename T>
+void BackendPDHG<T>::IterationPairMc() {
+  if constexpr (std::is_same<T, float>::value) {
+    double tau[2], sigma[2], theta[2];
+    tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
+    stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_;
+    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
+    iteration_++;
+    tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
+    const bool t = BeginSample(kKernelPair);
+    CheckHip(prost_hip_fused_iteration_mc_x2_f32(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0, CurrentStream()),
+             "fused_iteration_mc_x2");
+    EndSample(t);
+    x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
+    y_.swap(y_prev_);
+    prev_stale_ = true;
+    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+    iteration_++;
+  } else {
+    throw Exception("IterationPairMc: fp32 only");
+  }
+}
+
 /// x_prev_ / y_prev_ hold x^k, y^k (inputs of the last pair launch), x_ / y_ = x^(k+2), y^(k+2): one
 /// single-iteration launch with the step sizes of iteration k rebuilds x^(k+1), y^(k+1) bit for bit.
 template <typename T>
 void BackendPDHG<T>::RebuildPrevious() {
   if (!prev_stale_) return;
   last_end_ = kNoEvent;
-  if (pair3d_ && single3d_)
+  if (pair_mc_ && single_mc_)
+    CheckHip(Api<T>::fused_iteration_mc(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
+                                        (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration_mc");
+  else if (pair3d_ && single3d_)
     CheckHip(Api<T>::fused_iteration3d(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
                                        (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration3d");
   else if (pair3d_) {        // heights the one-kernel iteration does not take (ny % 4 != 0): the two passes
@@ -354,6 +389,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
   if (single_mc_) {
     // gradient2d with 3 / 4 channels: one kernel, the channels on the wavefronts of a workgroup (7 instead of 11 values per
     // pixel and channel; residual iterations add the y_prev stream and the four sums, y_new then goes to y_spare_)
+    if (res) RebuildPrevious();      // the residual kernel streams y^(k-1)
     T* y_out = res ? y_spare_.data() : y_prev_.data();
     const bool tm = BeginSample(res ? kKernelIterRes : kKernelIter);
     CheckHip(Api<T>::fused_iteration_mc(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
@@ -363,6 +399,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
     x_.swap(x_prev_);
     if (res) y_prev_.swap(y_spare_);
     y_.swap(y_prev_);
+    prev_stale_ = false;
     if (res) FinishResiduals();
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
@@ -569,7 +606,7 @@ bool BackendPDHG<T>::current_solution_device(const T*& primal_x, const T*& prima
 template <typename T>
 size_t BackendPDHG<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
-  if (fused_) return (2 * (n + m) + (single_kernel_ || single3d_ || single_mc_ || pair3d_ ? m : 0) + (pair_kernel_ || pair3d_ ? n : 0)) * sizeof(T);
+  if (fused_) return (2 * (n + m) + (single_kernel_ || single3d_ || single_mc_ || pair3d_ ? m : 0) + (pair_kernel_ || pair3d_ || pair_mc_ ? n : 0)) * sizeof(T);
   return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511
 }
 
@@ -588,13 +625,14 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
-                                     d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", d3 ? "fused_iter3d_x2_kernel" : "fused_iter2d_x2_kernel",
+                                     d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", d3 ? "fused_iter3d_x2_kernel" : pair_mc_ ? "fused_iter2d_mc_x2_kernel" : "fused_iter2d_x2_kernel",
                                      "fused_iter2d_x2_kernel+mid", d3 ? "fused_iter3d_x2_kernel+residuals" : "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++) {
     if (!cnt[k]) continue;
     const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes)
-                     : (k == kKernelPair || k == kKernelPairRes) && pair3d_ ? prost_hip_fused_iteration3d_x2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes) : 0;
+                     : (k == kKernelPair || k == kKernelPairRes) && pair3d_ ? prost_hip_fused_iteration3d_x2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes)
+                     : k == kKernelPair && pair_mc_ ? prost_hip_fused_iteration_mc_x2_chunk_cols(&desc_, dtype_id<T>()) : 0;
     out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k], cols});
   }
   samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;

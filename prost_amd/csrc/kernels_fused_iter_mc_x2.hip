@@ -210,20 +210,27 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
   if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
-  if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
+  // (res_x0 / res_x1 -- the owned columns of a sharded slab -- only restrict residual sums, which this kernel does not form)
   if ((double)d->nx * (double)d->ny * 4.0 >= 4294967296.0) return false;              // 32-bit byte offsets per plane
   const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
   return strips * d->nx < (size_t)1 << 31;
 }
 
-// chunk length: the longest one that still fills >= 90 % of the resident wave slots (3 per SIMD) in ONE round -- 3 warm-up
-// columns are amortised over it, a second, mostly empty round would cost a full chunk time (cf. kernels_fused_iter2.hip)
+// chunk length: a launch lasts about (rounds of wavefronts on the 3 resident slots per SIMD) x (column steps of a wavefront), so
+// the chunk length minimises ceil(strips * chunks * L / slots) * (columns + 3 warm-up steps): long chunks once the image fills
+// the chip (4096^2 RGB: 72 columns, one round), short ones for small images, where every wavefront gets a slot anyway and only
+// the number of steps counts (700 x 464 RGB: 3 columns = 6 steps per two iterations)
 static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols) {
   if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
   const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
   const size_t slots = 256 * 4 * 3;
-  for (size_t c : {96, 72, 60, 48, 36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * d->L * 10 >= slots * 9) return c < d->nx ? c : d->nx;
-  return d->nx < 9 ? d->nx : 9;
+  size_t best_c = 3, best_cost = (size_t)-1;
+  for (size_t c = 3; c <= 128 && c <= d->nx; c++) {
+    const size_t waves = strips * ((d->nx + c - 1) / c) * d->L;
+    const size_t cost = ((waves + slots - 1) / slots) * (c + 3);
+    if (cost <= best_cost) { best_cost = cost; best_c = c; }         // ties: the longer chunk (less redundant arithmetic)
+  }
+  return best_c < d->nx ? best_c : d->nx;
 }
 
 template <class T>

@@ -34,8 +34,8 @@ def rof_image(nx, ny, L=1, seed=42, dtype=np.float64):
     return out
 
 
-def rof_problem(nx, ny, L=1, lmb=10.0, seed=42, f=None):
-    """The problem of matlab/examples/example_rof_primaldual.m:15-28 on synthetic data."""
+def rof_problem(nx, ny, L=1, lmb=10.0, seed=42, f=None, data_term="square"):
+    """The problem of matlab/examples/example_rof_primaldual.m:15-28 on synthetic data (data_term='abs': TV-L1, example_tvl1.m)."""
     from . import block, function
     from .problem import variable, min_max_problem
     if f is None:
@@ -43,7 +43,7 @@ def rof_problem(nx, ny, L=1, lmb=10.0, seed=42, f=None):
     u = variable(nx * ny * L)
     q = variable(2 * nx * ny * L)
     prob = min_max_problem([u], [q])
-    prob.add_function(u, function.sum_1d("square", 1, f, lmb))
+    prob.add_function(u, function.sum_1d(data_term, 1, f, lmb))
     prob.add_function(q, function.sum_norm2(2 * L, False, "ind_leq0", 1, 1, 1))
     prob.add_dual_pair(u, q, block.gradient2d(nx, ny, L))
     return prob, u, q, f

@@ -537,6 +537,44 @@ def test_pair_kernel_schedule_is_invisible(prec, dtype, step, residual_iter):
         assert_same_iterates(run_product(prob, b, o, 23), run_oracle(prob, b, o, 23, dtype))
 
 
+@pytest.mark.parametrize("step", STEPS)
+@pytest.mark.parametrize("L,residual_iter,data_term", [(3, 10, "square"), (3, 4, "square"), (3, 3, "square"), (4, 10, "square"), (2, 10, "square"), (2, 5, "square"), (3, 10, "abs"), (2, 10, "abs")])
+def test_multichannel_pair_schedule_is_invisible(step, L, residual_iter, data_term):
+    """fp32 vectorial TV with 2 / 3 / 4 channels: two iterations per launch (prost_hip_fused_iteration_mc_x2) wherever none of k,
+    k+1, k+2 is a residual iteration.  The state after ANY number of iterations -- x, y, the constraint variables z, w (which need
+    the previous iterate, rebuilt by one single launch after a pair), residuals, step sizes -- is bit-identical to the path that
+    launches every iteration separately, and the iterates equal the oracle's."""
+    prost.set_precision("single")
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    for (nx, ny) in ((12, 16), (9, 252), (40, 500)):
+        prob, u, q, f = synthetic.rof_problem(nx, ny, L, seed=3, data_term=data_term, lmb=10.0 if data_term == "square" else 0.7)
+        for iters in (2, 3, 4, 5, 9, 10, 11, 23):
+            states = []
+            for pair in (True, False):
+                b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
+                b[1]["allow_pair_kernel"] = pair
+                s = prost.Solver(prob, b, o)
+                info = s.iterate(iters, time_kernels=True, sample_every=1)
+                names = list(info["kernels"])
+                st = s.state()
+                s.iterate(7)              # a second batch: the pairing restarts from another offset
+                st2 = s.state()
+                s.destroy()
+                x2 = [k for k in names if k.startswith("fused_iter2d_mc_x2_kernel")]
+                if residual_iter >= 4 and iters >= 9:
+                    assert bool(x2) == pair, (names, pair)
+                elif not pair:
+                    assert not x2
+                states.append((st, st2))
+            for a_, b_ in zip(states[0], states[1]):
+                for v in "xyzw":
+                    assert np.array_equal(a_[v], b_[v]), (nx, ny, L, iters, v)
+                for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):
+                    assert a_[v] == b_[v], (nx, ny, L, iters, v, a_[v], b_[v])     # residual iterations run the same kernel on both paths
+        bo = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
+        assert_same_iterates(run_product(prob, bo, o, 23), run_oracle(prob, bo, o, 23, np.float32))
+
+
 @pytest.mark.parametrize("prec,dtype", PRECISIONS)
 def test_pair_kernel_inside_solve_with_callbacks(prec, dtype):
     """prost.solve with an intermediate-solution callback schedule and a convergence stop: fused
