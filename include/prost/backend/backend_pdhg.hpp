@@ -82,7 +82,7 @@ class BackendPDHG : public Backend<T> {
   void IterationFused(bool residual_iteration);
   void IterationGeneric(bool residual_iteration);
   void IterationPair(bool store_mid, bool residuals);   // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
-  void IterationPairMc();                 // the same for gradient2d with 2-4 channels (prost_hip_fused_iteration_mc_x2): no residual iteration among k, k+1, k+2
+  void IterationPairMc(bool residuals);   // the same for gradient2d with 2-4 channels (prost_hip_fused_iteration_mc_x2): k + 2 is not a residual iteration
   void IterationPair3D(bool residuals);   // the same for gradient3d (prost_hip_fused_iteration3d_x2): k + 2 is not a residual iteration
   void RebuildPrevious();                 // x_prev_ / y_prev_ := x^(k-1) / y^(k-1) after a pair that did not store them
   bool is_residual_iteration(size_t k) const { return k == 0 || (k % (size_t)opts_.residual_iter) == 0; }   // backend_pdhg.cu:389

@@ -328,14 +328,16 @@ int prost_hip_fused_iteration3d_pw_f64(const prost_hip_fused_desc* desc, double*
 /* TWO iterations of a gradient2d problem with L = 2, 3 or 4 channels per launch (kernels_fused_iter_mc_x2.hip;
  * backend_pdhg.cu:317-370 twice): the channels on the wavefronts of a workgroup, each running the 4-stage column pipeline of
  * prost_hip_fused_iteration2, the squares of the dual arguments of both dual steps meeting in LDS for the norm over the
- * 2 L components of a pixel.  Reads x^k, y^k and b, writes x^(k+2), y^(k+2); no intermediate iterate, no residual sums.
+ * 2 L components of a pixel.  Reads x^k, y^k and b, writes x^(k+2), y^(k+2); the intermediate iterate is stored nowhere.
  * tau/sigma/theta: HOST arrays of 2.  Bit-identical to two prost_hip_fused_iteration_mc launches (resp. two
  * prost_hip_fused_iteration launches for L = 2).  fp32, straight-line ROF / TV-L1 shapes (prox_g square or abs with
  * scalar a = 1, d = e = 0, b scalar or per pixel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), ny % 4 == 0. */
 int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
-int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* desc, int dtype);
+int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals);
+/* res_out4 != NULL (needs `workspace`): also the four residual sums of the SECOND iteration, as prost_hip_fused_iteration_mc
+ * writes them for that iteration (same terms, restricted to the owned columns res_x0 / res_x1; the summation order differs) */
 int prost_hip_fused_iteration_mc_x2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
-                                        const double* sigma, const double* theta, int cols, void* stream);
+                                        const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream);
 
 /* TWO iterations of a gradient3d problem per launch (kernels_fused_iter3d_x2.hip; backend_pdhg.cu:317-370 twice): the
  * planes of a group run on the wavefronts of one workgroup, every wavefront runs the 4-stage column pipeline of

@@ -198,10 +198,9 @@ int BackendPDHG<T>::PerformIterations(int budget) {
     IterationPair3D(is_residual_iteration(k + 1));
     return 2;
   }
-  // 2-4 channels: no residual sums and no stored intermediate iterate in that kernel, so none of k, k+1 (its sums) and k+2
-  // (streams y^(k+1)) may be a residual iteration: 8 of 10 iterations at residual_iter = 10
-  if (pair_mc_ && budget >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 1) && !is_residual_iteration(k + 2)) {
-    IterationPairMc();
+  // 2-4 channels: the same rule (residual sums of the second iteration in the kernel, no stored intermediate iterate)
+  if (pair_mc_ && budget >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {
+    IterationPairMc(is_residual_iteration(k + 1));
     return 2;
   }
   PerformIteration();
@@ -289,7 +288,7 @@ void BackendPDHG<T>::IterationPair3D(bool residuals) {
 }
 
 template <typename T>
-void BackendPDHG<T>::IterationPairMc() {
+void BackendPDHG<T>::IterationPairMc(bool residuals) {
   if constexpr (std::is_same<T, float>::value) {
     double tau[2], sigma[2], theta[2];
     tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
@@ -297,13 +296,14 @@ void BackendPDHG<T>::IterationPairMc() {
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
     iteration_++;
     tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
-    const bool t = BeginSample(kKernelPair);
-    CheckHip(prost_hip_fused_iteration_mc_x2_f32(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0, CurrentStream()),
-             "fused_iteration_mc_x2");
+    const bool t = BeginSample(residuals ? kKernelPairRes : kKernelPair);
+    CheckHip(prost_hip_fused_iteration_mc_x2_f32(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
+                                                 residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration_mc_x2");
     EndSample(t);
     x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
     y_.swap(y_prev_);
     prev_stale_ = true;
+    if (residuals) FinishResiduals();                                    // iteration_ == k+1 here, as in the single path
     if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
     iteration_++;
   } else {
@@ -626,13 +626,13 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
                                      d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", d3 ? "fused_iter3d_x2_kernel" : pair_mc_ ? "fused_iter2d_mc_x2_kernel" : "fused_iter2d_x2_kernel",
-                                     "fused_iter2d_x2_kernel+mid", d3 ? "fused_iter3d_x2_kernel+residuals" : "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
+                                     "fused_iter2d_x2_kernel+mid", d3 ? "fused_iter3d_x2_kernel+residuals" : pair_mc_ ? "fused_iter2d_mc_x2_kernel+residuals" : "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++) {
     if (!cnt[k]) continue;
     const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes)
                      : (k == kKernelPair || k == kKernelPairRes) && pair3d_ ? prost_hip_fused_iteration3d_x2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes)
-                     : k == kKernelPair && pair_mc_ ? prost_hip_fused_iteration_mc_x2_chunk_cols(&desc_, dtype_id<T>()) : 0;
+                     : (k == kKernelPair || k == kKernelPairRes) && pair_mc_ ? prost_hip_fused_iteration_mc_x2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes) : 0;
     out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k], cols});
   }
   samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;

@@ -14,9 +14,11 @@
 // Per channel: 7 floats per pixel per TWO iterations (y1, y2, x, b read; x, y1, y2 written) against 2 x 7 for the
 // single-iteration kernel.  x^(k+2), y^(k+2) are bit-identical to two single launches (tests/test_gpu_kernels.py).
 // Straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0, b scalar or per pixel; prox_f*
-// ind_leq0 with scalar a = 1, d = e = 0), fp32, heights that are a multiple of 4; the intermediate iterate is stored nowhere
-// and there are no residual sums: BackendPDHG pairs only iterations k, k+1 with no residual iteration among k, k+1, k+2.
+// ind_leq0 with scalar a = 1, d = e = 0), fp32, heights that are a multiple of 4; the intermediate iterate is stored nowhere,
+// the residual sums of the second iteration are available (RES): BackendPDHG pairs iterations k, k+1 unless k or k+2 is a
+// residual iteration.
 #include "fused_common.hpp"
+#include "reduce.hpp"
 
 namespace prost_hip {
 
@@ -41,13 +43,18 @@ __device__ __forceinline__ void stm_o(T* __restrict__ base, unsigned byte_off, c
   stv_nt<T, VEC>(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
 }
 
-template <class T, int VEC, int GFN, bool GB, int LW>
+// RES: additionally the four residual sums of the SECOND iteration (backend_pdhg.cu:73-120), term by term the expressions of
+// fused_iter2d_mc_kernel; K^T y^k of a column waits two steps between stages A and C in LDS, the sums are accumulated in LDS
+// (own lanes, no synchronisation) -- as in kernels_fused_iter3d_x2.hip.  One partial (4 doubles) per workgroup.
+template <class T, int VEC, int GFN, bool GB, int LW, bool RES>
 __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                                 const T* __restrict__ y, FusedArgs<T> a, IterParamsMc<T> p1,
-                                                                                IterParamsMc<T> p2) {
+                                                                                IterParamsMc<T> p2, double* __restrict__ partial) {
   constexpr int kRowsPerWave = (kWave - 2) * VEC;
   constexpr int kPix = kWave * VEC;
   __shared__ T s_sq[2][2][2 * LW][kPix];               // [buffer][stage B / D][component][pixel]
+  __shared__ T s_kt[RES ? 3 : 1][RES ? LW : 1][RES ? kPix : 1];
+  __shared__ double s_acc[RES ? 4 : 1][RES ? LW : 1][RES ? kWave : 1];
   const long nx = (long)a.nx, ny = (long)a.ny;
   const int lane = threadIdx.x & (kWave - 1);
   const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // wave-uniform: base pointers live in SGPRs
@@ -76,7 +83,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   // primal step of this channel at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 on a zero-filled result);
   // v1 / v2: the dual variable at column c, p1c: its first component at column c-1
   auto primal = [&](long c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&p1c)[VEC], const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1],
-                    const IterParamsMc<T>& Pm, T (&xn)[VEC]) {
+                    const IterParamsMc<T>& Pm, T (&xn)[VEC], T (&ktv)[VEC]) {
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
     T parg[VEC];
@@ -88,6 +95,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
       T divx = (c < nx - 1) ? v1[j] : (T)0;
       if (c > 0) divx -= p1c[j];
       const T kty = (T)0 - (divx + divy);
+      ktv[j] = kty;
       const T arg = xin[j] - tauT * kty;
       parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
     }
@@ -136,6 +144,51 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
   };
 
+  // residual sums of the second iteration (RES): the terms of fused_iter2d_mc_kernel
+  const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
+  const SharedDivisor<T> div_tauT(p2.tau * sqT), div_sigS(p2.sigma * sqS);   // wave-uniform: exact quotients through one double reciprocal each
+  if (RES) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_acc[RES ? k : 0][RES ? ch : 0][RES ? lane : 0] = 0;   // primal diff^2, primal var^2, dual diff^2, dual var^2
+  }
+  auto accumulate = [&](int k, double v) { s_acc[RES ? k : 0][RES ? ch : 0][RES ? lane : 0] += v; };
+  // dual_residual_transform (backend_pdhg.cu:73-94) at the column of stage C: xo / xn = x^(k+1) / x^(k+2), kt_prev = K^T y^k, kt = K^T y^(k+1)
+  auto dual_residual = [&](const T (&xo)[VEC], const T (&xn)[VEC], const T (&kt_prev)[VEC], const T (&kt)[VEC]) {
+    double dd = 0, dv = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const T w_hat = div_tauT.div(xo[j] - xn[j]) - sqT * kt_prev[j];
+      const T diff = w_hat + sqT * kt[j];
+      dd += (double)(diff * diff); dv += (double)(w_hat * w_hat);
+    }
+    if (owner) { accumulate(2, dd); accumulate(3, dv); }
+  };
+  // primal_residual_transform (backend_pdhg.cu:97-120) at the column of stage D: v* = y^(k+1), out = y^(k+2); K x, K x_prev formed again
+  auto primal_residual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC], const T (&v1)[VEC],
+                             const T (&v2)[VEC], const T (&out)[2][VEC]) {
+    const T theta = p2.theta;
+    const bool has_next = c + 1 < nx;
+    const T bel_n = lane_down(xn_c[0]);
+    const T bel_o = lane_down(xo_c[0]);
+    double pd = 0, pv = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const long row = row0 + j;
+      const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
+      const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
+      const T kx[2] = {has_next ? xn_n[j] - xn_c[j] : (T)0, (row < ny - 1) ? below_n - xn_c[j] : (T)0};
+      const T kp[2] = {has_next ? xo_n[j] - xo_c[j] : (T)0, (row < ny - 1) ? below_o - xo_c[j] : (T)0};
+      const T yv[2] = {v1[j], v2[j]};
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const T z_hat = div_sigS.div(yv[i] - out[i][j]) + sqS * ((1 + theta) * kx[i] - theta * kp[i]);
+        const T diff = z_hat - sqS * kx[i];
+        pd += (double)(diff * diff); pv += (double)(z_hat * z_hat);
+      }
+    }
+    if (owner) { accumulate(0, pd); accumulate(1, pv); }
+  };
+
   Col in1 = {}, in2 = {};                              // raw columns c+1 and c+2
   T b_c[GB ? VEC : 1];                                 // b of prox_g at column c (stage C)
   T x1_m[VEC], x1_0[VEC], x1_1[VEC], x1_2[VEC];        // x^(k+1) at columns c-1 .. c+2
@@ -155,6 +208,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   if (active && has_col(xa - 1)) load_col(xa - 1, pre);
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): nothing of the prologue in flight when the loop starts (see kernels_fused_iter3d_x2.hip)
 
+  int k3 = 0;                                          // slot of s_kt that stage A writes in this step
   for (long c = xa - 3; c <= xb; c++) {
     const int buf = (int)((c + 4) & 1);
     in1 = in2; in2 = pre;
@@ -166,9 +220,25 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     const bool runC = c >= xa && c < nx && c <= xb;
     const bool runD = cd >= xa && cd < xb;
     T avB[2][VEC], avD[2][VEC];
-    if (runA) primal(ca, in2.y1, in2.y2, in1.y1, in2.x, in2.b, p1, x1_2);                          // stage A
+    if (runA) {                                                                                    // stage A
+      T kt_a[VEC];
+      primal(ca, in2.y1, in2.y2, in1.y1, in2.x, in2.b, p1, x1_2, kt_a);
+      if (RES) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) s_kt[RES ? k3 : 0][RES ? ch : 0][RES ? j * kWave + lane : 0] = kt_a[j];     // K^T y^k at column c+2: read by stage C two steps later
+      }
+    }
     if (runB) dual_args(cb, x1_1, x1_2, in1.x, in2.x, in1.y1, in1.y2, p1, avB, s_sq[buf][0]);      // stage B, first half
-    if (runC) primal(c, ya_0, yb_0, ya_m, x1_0, b_c, p2, x2_0);                                    // stage C
+    if (runC) {                                                                                    // stage C
+      T kt_c[VEC];
+      primal(c, ya_0, yb_0, ya_m, x1_0, b_c, p2, x2_0, kt_c);
+      if (RES && c < xb && (size_t)c >= a.rx0 && (size_t)c < a.rx1) {
+        T kt_0[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) kt_0[j] = s_kt[RES ? (k3 + 1) % 3 : 0][RES ? ch : 0][RES ? j * kWave + lane : 0];     // written two steps ago
+        dual_residual(x1_0, x2_0, kt_0, kt_c);
+      }
+    }
     if (runD) dual_args(cd, x2_m, x2_0, x1_m, x1_0, ya_m, yb_m, p2, avD, s_sq[buf][1]);            // stage D, first half
     __syncthreads();                                   // one barrier per column step (every wavefront runs the same stages)
     if (runB) {
@@ -180,6 +250,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     if (runD) {
       T o[2][VEC];
       dual_finish(avD, s_sq[buf][1], o);
+      if (RES && (size_t)cd >= a.rx0 && (size_t)cd < a.rx1) primal_residual(cd, x2_m, x2_0, x1_m, x1_0, ya_m, yb_m, o);
       if (owner) {
         const size_t off = plane + (size_t)cd * (size_t)ny;           // wave-uniform
         stm_o<T, VEC>(y_out + off, voff, o[0]); stm_o<T, VEC>(y_out + N + off, voff, o[1]);
@@ -196,6 +267,21 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     }
 #pragma unroll
     for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = in1.b[j];
+    k3 = k3 == 2 ? 0 : k3 + 1;
+  }
+  if (RES) {
+    __syncthreads();                                   // every wavefront has finished reading the squares: the buffer is free
+    double* sred = reinterpret_cast<double*>(&s_sq[0][0][0][0]);
+    double r_pd = s_acc[0][RES ? ch : 0][RES ? lane : 0], r_pv = s_acc[RES ? 1 : 0][RES ? ch : 0][RES ? lane : 0], r_dd = s_acc[RES ? 2 : 0][RES ? ch : 0][RES ? lane : 0],
+           r_dv = s_acc[RES ? 3 : 0][RES ? ch : 0][RES ? lane : 0];
+    r_pd = wave_sum(r_pd); r_pv = wave_sum(r_pv); r_dd = wave_sum(r_dd); r_dv = wave_sum(r_dv);
+    if (lane == 0) { sred[4 * ch + 0] = r_pd; sred[4 * ch + 1] = r_pv; sred[4 * ch + 2] = r_dd; sred[4 * ch + 3] = r_dv; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double t = 0;
+      for (int w = 0; w < LW; w++) t += sred[4 * w + threadIdx.x];       // fixed order: run-to-run deterministic
+      partial[4 * (size_t)blockIdx.x + threadIdx.x] = t;
+    }
   }
 }
 
@@ -213,6 +299,7 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   // (res_x0 / res_x1 -- the owned columns of a sharded slab -- only restrict residual sums, which this kernel does not form)
   if ((double)d->nx * (double)d->ny * 4.0 >= 4294967296.0) return false;              // 32-bit byte offsets per plane
   const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
+  if (strips > (size_t)kReduceBlocks / 2) return false;              // residual launches: one partial per workgroup, at best one chunk per strip
   return strips * d->nx < (size_t)1 << 31;
 }
 
@@ -220,13 +307,14 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
 // the chunk length minimises ceil(strips * chunks * L / slots) * (columns + 3 warm-up steps): long chunks once the image fills
 // the chip (4096^2 RGB: 72 columns, one round), short ones for small images, where every wavefront gets a slot anyway and only
 // the number of steps counts (700 x 464 RGB: 3 columns = 6 steps per two iterations)
-static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols) {
+static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols, bool res) {
   if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
   const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
   const size_t slots = 256 * 4 * 3;
   size_t best_c = 3, best_cost = (size_t)-1;
   for (size_t c = 3; c <= 128 && c <= d->nx; c++) {
     const size_t waves = strips * ((d->nx + c - 1) / c) * d->L;
+    if (res && strips * ((d->nx + c - 1) / c) > (size_t)kReduceBlocks / 2) continue;      // residual launches: one partial (4 doubles) per workgroup
     const size_t cost = ((waves + slots - 1) / slots) * (c + 3);
     if (cost <= best_cost) { best_cost = cost; best_c = c; }         // ties: the longer chunk (less redundant arithmetic)
   }
@@ -235,10 +323,11 @@ static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols) {
 
 template <class T>
 static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
-                          const double* theta, int cols, void* stream) {
+                          const double* theta, int cols, double* out4, void* ws, void* stream) {
   if (!iter_mc_x2_ok(d, 0)) { set_error("fused multi-channel double iteration: unsupported description (see prost_hip_fused_iteration_mc_x2_supported)"); return 1; }
   if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused multi-channel double iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_out == x || y_out == y) { set_error("fused multi-channel double iteration: outputs must not alias inputs"); return 1; }
+  if (out4 && !ws) { set_error("fused multi-channel double iteration: residuals need the reduction workspace"); return 1; }
   constexpr int V = 4;
   FusedArgs<T> a = make_fused_args<T>(d);
   IterParamsMc<T> p[2];
@@ -250,19 +339,25 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
     p[i].sq = ug.sq; p[i].step = ug.step;
   }
   const size_t strips = (d->ny + (size_t)(kWave - 2) * V - 1) / ((size_t)(kWave - 2) * V);
-  const size_t c = mc_x2_chunk_cols(d, cols);
+  const size_t c = mc_x2_chunk_cols(d, cols, out4 != nullptr);
   a.cols_per_block = (int)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
   const unsigned grid = (unsigned)(strips * a.chunks);
   hipStream_t s = as_stream(stream);
-#define GO3(G, B, LWv) hipLaunchKernelGGL((fused_iter2d_mc_x2_kernel<T, V, G, B, LWv>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1])
+  if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused multi-channel double iteration: grid exceeds the reduction workspace"); return 1; }
+  double* partial = static_cast<double*>(ws);
+#define GO4(G, B, LWv, R) hipLaunchKernelGGL((fused_iter2d_mc_x2_kernel<T, V, G, B, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+#define GO3(G, B, LWv) do { if (out4) GO4(G, B, LWv, true); else GO4(G, B, LWv, false); } while (0)
 #define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)
 #define GO(B) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B); else GO2(PROST_FN_SQUARE, B); } while (0)
   if (d->g_coeff_ptr[1]) GO(true); else GO(false);
 #undef GO
 #undef GO2
 #undef GO3
-  PH_LAUNCH_END("fused multi-channel double iteration kernel");
+#undef GO4
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel double iteration kernel"); }
+  if (out4) return launch_fold4(out4, partial, grid, s);
+  return 0;
 }
 
 }  // namespace prost_hip
@@ -271,9 +366,11 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* d, int dtype) { return iter_mc_x2_ok(d, dtype) ? 1 : 0; }
-int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype) { return iter_mc_x2_ok(d, dtype) ? (int)mc_x2_chunk_cols(d, 0) : 0; }
+int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int with_residuals) {
+  return iter_mc_x2_ok(d, dtype) ? (int)mc_x2_chunk_cols(d, 0, with_residuals != 0) : 0;
+}
 int prost_hip_fused_iteration_mc_x2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
-                                        const double* sigma, const double* theta, int cols, void* stream) {
-  return run_iter_mc_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, stream);
+                                        const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
+  return run_iter_mc_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
 }
 }  // extern "C"

@@ -706,7 +706,8 @@ def test_double_multichannel_iteration_equals_two_iterations_of_the_two_pass_ker
     meeting in LDS for the norm over the 2 L components of a pixel) against two iterations of the two-pass kernels, which are
     pinned to the oracle (test_fused_passes_match_unfused_oracle): same bits for x^(k+2) and all 2 L components of y^(k+2), for
     every chunk width (1: every column a chunk border; 200: one chunk), 2 / 3 / 4 channels, strip layouts (252 = one strip + 4
-    rows, 1028 rows: five strips) and step sizes that change between the two iterations (alg2)."""
+    rows, 1028 rows: five strips) and step sizes that change between the two iterations (alg2); with residual sums: the four sums
+    of the second iteration against the two-pass kernels' for that iteration."""
     dtype = np.float32
     nx, ny, L = shape
     rng = np.random.default_rng(13)
@@ -732,15 +733,21 @@ def test_double_multichannel_iteration_equals_two_iterations_of_the_two_pass_ker
     ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
     hip.check(P(C.byref(d), x1.ptr, dx.ptr, dy.ptr, None, hip.dbl(tau[0]), 1, 0, None, ws.ptr, None))
     hip.check(D(C.byref(d), y1.ptr, dy.ptr, x1.ptr, dx.ptr, hip.dbl(sigma[0]), hip.dbl(theta[0]), 1, None, ws.ptr, None))
-    hip.check(P(C.byref(d), x2.ptr, x1.ptr, y1.ptr, None, hip.dbl(tau[1]), 1, 0, None, ws.ptr, None))
-    hip.check(D(C.byref(d), y2.ptr, y1.ptr, x2.ptr, x1.ptr, hip.dbl(sigma[1]), hip.dbl(theta[1]), 1, None, ws.ptr, None))
+    rd = hip.DeviceArray.zeros(2, np.float64); rp = hip.DeviceArray.zeros(2, np.float64)      # the second iteration as a residual iteration (y_prev = y^k)
+    hip.check(P(C.byref(d), x2.ptr, x1.ptr, y1.ptr, dy.ptr, hip.dbl(tau[1]), 1, 1, rd.ptr, ws.ptr, None))
+    hip.check(D(C.byref(d), y2.ptr, y1.ptr, x2.ptr, x1.ptr, hip.dbl(sigma[1]), hip.dbl(theta[1]), 1, rp.ptr, ws.ptr, None))
+    res_ref = np.concatenate([rp.to_host(), rd.to_host()])      # {primal diff^2, primal var^2, dual diff^2, dual var^2}
     x_ref, y_ref = x2.to_host(), y2.to_host()
     arr = lambda v: (C.c_double * 2)(*v)
     pad, sentinel = 256, np.float32(-123456.75)
-    for cols in (0, 1, 2, 5, 7, 200):
+    for cols, res in ((0, False), (0, True), (1, True), (2, False), (5, True), (7, False), (200, True)):
         bx = dev(hip, np.full(n + 2 * pad, sentinel, dtype)); by = dev(hip, np.full(m + 2 * pad, sentinel, dtype))      # canaries around the outputs
         xo = C.c_void_p(bx.ptr.value + pad * 4); yo = C.c_void_p(by.ptr.value + pad * 4)
-        hip.check(hip.lib().prost_hip_fused_iteration_mc_x2_f32(C.byref(d), xo, yo, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols, None))
+        r4 = hip.DeviceArray.zeros(4, np.float64)
+        hip.check(hip.lib().prost_hip_fused_iteration_mc_x2_f32(C.byref(d), xo, yo, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols,
+                                                                r4.ptr if res else None, ws.ptr if res else None, None))
+        if res:      # the same terms as the two-pass kernels, summed in double in another order
+            assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)
         hx, hy = bx.to_host(), by.to_host()
         assert np.all(hx[:pad] == sentinel) and np.all(hx[pad + n:] == sentinel) and np.all(hy[:pad] == sentinel) and np.all(hy[pad + m:] == sentinel), cols
         assert np.array_equal(hx[pad:pad + n], x_ref), (cols, np.flatnonzero(hx[pad:pad + n] != x_ref)[:8])

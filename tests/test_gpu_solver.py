@@ -540,8 +540,8 @@ def test_pair_kernel_schedule_is_invisible(prec, dtype, step, residual_iter):
 @pytest.mark.parametrize("step", STEPS)
 @pytest.mark.parametrize("L,residual_iter,data_term", [(3, 10, "square"), (3, 4, "square"), (3, 3, "square"), (4, 10, "square"), (2, 10, "square"), (2, 5, "square"), (3, 10, "abs"), (2, 10, "abs")])
 def test_multichannel_pair_schedule_is_invisible(step, L, residual_iter, data_term):
-    """fp32 vectorial TV with 2 / 3 / 4 channels: two iterations per launch (prost_hip_fused_iteration_mc_x2) wherever none of k,
-    k+1, k+2 is a residual iteration.  The state after ANY number of iterations -- x, y, the constraint variables z, w (which need
+    """fp32 vectorial TV with 2 / 3 / 4 channels: two iterations per launch (prost_hip_fused_iteration_mc_x2) wherever neither k
+    nor k+2 is a residual iteration (k+1 may be one: the kernel forms its sums).  The state after ANY number of iterations -- x, y, the constraint variables z, w (which need
     the previous iterate, rebuilt by one single launch after a pair), residuals, step sizes -- is bit-identical to the path that
     launches every iteration separately, and the iterates equal the oracle's."""
     prost.set_precision("single")
@@ -561,7 +561,7 @@ def test_multichannel_pair_schedule_is_invisible(step, L, residual_iter, data_te
                 st2 = s.state()
                 s.destroy()
                 x2 = [k for k in names if k.startswith("fused_iter2d_mc_x2_kernel")]
-                if residual_iter >= 4 and iters >= 9:
+                if residual_iter >= 3 and iters >= 8:        # a pair starts at k >= 2 unless k or k + 2 is a residual iteration
                     assert bool(x2) == pair, (names, pair)
                 elif not pair:
                     assert not x2
@@ -569,8 +569,10 @@ def test_multichannel_pair_schedule_is_invisible(step, L, residual_iter, data_te
             for a_, b_ in zip(states[0], states[1]):
                 for v in "xyzw":
                     assert np.array_equal(a_[v], b_[v]), (nx, ny, L, iters, v)
-                for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):
-                    assert a_[v] == b_[v], (nx, ny, L, iters, v, a_[v], b_[v])     # residual iterations run the same kernel on both paths
+                for v in ("tau", "sigma", "theta", "iteration"):
+                    assert a_[v] == b_[v], (nx, ny, L, iters, v, a_[v], b_[v])
+                for v in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):       # same terms, another summation order
+                    assert np.isclose(a_[v], b_[v], rtol=1e-9, atol=0), (nx, ny, L, iters, v, a_[v], b_[v])
         bo = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
         assert_same_iterates(run_product(prob, bo, o, 23), run_oracle(prob, bo, o, 23, np.float32))
 

@@ -57,13 +57,15 @@ def main(N=4096, Lc=3, cols_list=(0, 6, 12, 18, 24, 36), iters=50, dtype=np.floa
               % (cols, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3), 7 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     if dtype == np.float32 and L_.prost_hip_fused_iteration_mc_x2_supported(C.byref(d), 0) == 1:
         two = lambda v: (C.c_double * 2)(v, v)
-        for cols in tuple(int(c) for c in os.environ.get("X2_COLS", "0,24,36,48,72,96").split(",")):
+        r4x = hip.DeviceArray.zeros(4, np.float64)
+        for xres, cols in [(False, int(c)) for c in os.environ.get("X2_COLS", "0,24,36,48,72,96").split(",")] + [(True, 0)]:
             def runx(k):
                 for i in range(k):
                     a, b = i % 2, (i + 1) % 2
-                    hip.check(L_.prost_hip_fused_iteration_mc_x2_f32(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, two(0.3), two(1.0), two(0.9), cols, None))
+                    hip.check(L_.prost_hip_fused_iteration_mc_x2_f32(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, two(0.3), two(1.0), two(0.9), cols, r4x.ptr if xres else None, ws.ptr if xres else None, None))
             t = timed(runx) / 2
-            print("two iterations per launch cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s" % (cols, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3)), flush=True)
+            print("two iterations per launch%s cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s"
+                  % (" + residual sums" if xres else "", cols, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     yp = hip.DeviceArray.from_host((rng.random(m, dtype=np.float32) - 0.5).astype(dtype)); r4 = hip.DeviceArray.zeros(4, np.float64)
 
     def run_res2(k):
