@@ -240,7 +240,12 @@ struct DownloadStage {
   void* ev[2] = {nullptr, nullptr};
   void ensure() {
     for (int i = 0; i < 2; i++) {
-      if (!buf[i]) CheckHip(prost_hip_host_alloc(&buf[i], kBytes), "host_alloc");
+      if (!buf[i] && prost_hip_host_alloc(&buf[i], kBytes) != 0) {
+        // no pinned memory to be had (locked-memory limit): a pageable buffer keeps every transfer correct -- the copies
+        // are then staged by the runtime and the event waits below still order them -- only the overlap is lost
+        buf[i] = std::malloc(kBytes);
+        if (!buf[i]) throw Exception("Out of host memory for the transfer staging buffers.");
+      }
       if (!ev[i]) CheckHip(prost_hip_event_create(&ev[i]), "event_create");
     }
   }
