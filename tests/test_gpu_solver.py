@@ -153,6 +153,31 @@ def test_pdhg_warm_start_moreau_and_dual(precision, dtype):
         assert_same_iterates(run_product(prob, b, o, 20), run_oracle(prob, b, o, 20, dtype))
 
 
+@pytest.mark.parametrize("solve_dual", [False, True])
+def test_solve_streams_the_same_result_it_hands_to_callbacks(solve_dual):
+    """Without an intermediate-solution callback prost.solve takes x, y, z, w straight from the device
+    (Backend::current_solution_device, widened while they arrive); with one it goes through the host vectors the callback
+    sees.  Same values either way, equal to the oracle's, also under solve_dual (roles of the four vectors exchanged,
+    solver.cu:216-246) and for a backend that keeps no device-resident solution (ADMM: the vector path)."""
+    prost.set_precision("single")
+    prob, u, q, f = synthetic.rof_problem(40, 36, 1, seed=6)
+    b = prost.backend.pdhg(stepsize="alg1", residual_iter=5)
+    kw = dict(max_iters=30, verbose=False, solve_dual=solve_dual, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    streamed = prost.solve(prob, b, prost.options(num_cback_calls=0, **kw))
+    seen = []
+    via_vectors = prost.solve(prob, b, prost.options(num_cback_calls=3, interm_cb=lambda it, x, y: seen.append((it, len(x), len(y))) or False, **kw))
+    assert seen and streamed["result"] == via_vectors["result"] == "Reached maximum iterations."
+    ro = oracle.solve(synthetic.rof_problem(40, 36, 1, seed=6)[0], b, prost.options(num_cback_calls=0, **kw), np.float32)
+    for v in "xyzw":
+        a_, b_ = np.asarray(streamed[v]).reshape(-1), np.asarray(via_vectors[v]).reshape(-1)
+        assert a_.shape == b_.shape == ro[v].shape, (v, a_.shape, b_.shape, ro[v].shape)
+        assert np.array_equal(a_, b_), v
+        assert np.array_equal(a_, ro[v]), (v, float(np.abs(a_ - ro[v]).max()))
+    # ADMM keeps no device-resident solution: prost.solve falls back to the host vectors
+    ra = prost.solve(prob, prost.backend.admm(rho0=1), prost.options(num_cback_calls=0, max_iters=5, verbose=False))
+    assert np.isfinite(np.asarray(ra["x"])).all() and np.asarray(ra["x"]).size == prob.ncols
+
+
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 def test_solve_with_callbacks_matches_oracle(precision, dtype):
     """prost.solve end to end (example_rof_primaldual.m): convergence iteration, result string,
