@@ -116,7 +116,9 @@ void BackendPDHG<T>::Initialize() {
   pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_profitable(&desc_, dtype_id<T>()) == 1;
   pair3d_ = false;
   if constexpr (std::is_same<T, float>::value)
-    pair3d_ = fused_ && desc_.is3d && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, 0) == 1;
+    // (volumes of fewer than 4 planes leave 13 of the 16 wavefronts of a workgroup idle: 2048^2 x 2 runs 0.125 ms per iteration in pairs,
+    // 0.086 ms in single launches; from 4 planes on the pairs win, 0.127 against 0.206 ms)
+    pair3d_ = fused_ && desc_.is3d && desc_.L >= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, 0) == 1;
   pair_mc_ = false;
   if constexpr (std::is_same<T, float>::value)        // 2-4 channels: the channels on the wavefronts of a workgroup, two iterations per launch
     pair_mc_ = (single_mc_ || (single_kernel_ && desc_.L == 2)) && opts_.allow_pair_kernel && prost_hip_fused_iteration_mc_x2_supported(&desc_, 0) == 1;
