@@ -333,6 +333,9 @@ int prost_hip_fused_iteration3d_pw_f64(const prost_hip_fused_desc* desc, double*
  * prost_hip_fused_iteration launches for L = 2).  fp32, straight-line ROF / TV-L1 shapes (prox_g square or abs with
  * scalar a = 1, d = e = 0, b scalar or per pixel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), ny % 4 == 0. */
 int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
+/* 1 iff the launch is also faster than two single launches (tiny images: one launch instead of two; large ones: half the HBM
+ * traffic; in between -- about 384^2 to 700^2 RGB -- the single-iteration kernel is up to 9 % faster) */
+int prost_hip_fused_iteration_mc_x2_profitable(const prost_hip_fused_desc* desc, int dtype);
 int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals);
 /* res_out4 != NULL (needs `workspace`): also the four residual sums of the SECOND iteration, as prost_hip_fused_iteration_mc
  * writes them for that iteration (same terms, restricted to the owned columns res_x0 / res_x1; the summation order differs) */

@@ -121,7 +121,7 @@ void BackendPDHG<T>::Initialize() {
     pair3d_ = fused_ && desc_.is3d && desc_.L >= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, 0) == 1;
   pair_mc_ = false;
   if constexpr (std::is_same<T, float>::value)        // 2-4 channels: the channels on the wavefronts of a workgroup, two iterations per launch
-    pair_mc_ = (single_mc_ || (single_kernel_ && desc_.L == 2)) && opts_.allow_pair_kernel && prost_hip_fused_iteration_mc_x2_supported(&desc_, 0) == 1;
+    pair_mc_ = (single_mc_ || (single_kernel_ && desc_.L == 2)) && opts_.allow_pair_kernel && prost_hip_fused_iteration_mc_x2_profitable(&desc_, 0) == 1;
   if (pair_kernel_ || pair3d_ || pair_mc_) x_spare_.resize(n);
   if (single_kernel_ || single3d_ || single_mc_ || pair3d_) y_spare_.resize(m);
 

@@ -306,15 +306,15 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
 // chunk length: a launch lasts about (rounds of wavefronts on the 3 resident slots per SIMD) x (column steps of a wavefront), so
 // the chunk length minimises ceil(strips * chunks * L / slots) * (columns + 3 warm-up steps): long chunks once the image fills
 // the chip, short ones for small images, where every wavefront gets a slot anyway and only
-// the number of steps counts (700 x 464 RGB: 3 columns = 6 steps per two iterations)
+// the number of steps counts (512^2 RGB: 2 columns = 5 steps per two iterations)
 static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols, bool res) {
   if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
   const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
   const size_t slots = 256 * 4 * 3;
-  size_t best_c = 3, best_cost = (size_t)-1;
+  size_t best_c = 1, best_cost = (size_t)-1;
   // (capped at 24 columns: beyond the point where every slot is taken, MORE and shorter workgroups hide the per-column barrier
   // better than fewer warm-up columns pay -- 4096^2 RGB: 24 columns 0.186 ms per iteration, 72 columns 0.198, 96 columns 0.220)
-  for (size_t c = 3; c <= 24 && c <= d->nx; c++) {
+  for (size_t c = 1; c <= 24 && c <= d->nx; c++) {
     const size_t waves = strips * ((d->nx + c - 1) / c) * d->L;
     if (res && strips * ((d->nx + c - 1) / c) > (size_t)kReduceBlocks / 2) continue;      // residual launches: one partial (4 doubles) per workgroup
     const size_t cost = ((waves + slots - 1) / slots) * (c + 3);
@@ -368,6 +368,15 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* d, int dtype) { return iter_mc_x2_ok(d, dtype) ? 1 : 0; }
+// 1 iff the launch is also FASTER than two single launches.  Measured per iteration, RGB: 256^2 6.4 vs 8.5 us (launch-bound: one
+// launch instead of two), 384^2 8.0 vs 7.3, 512^2 10.6 vs 10.5, 700 x 464 10.5 vs 10.0 (latency-bound: a column step of the pair
+// pipeline issues twice the instructions of a single step and there are too few wavefronts to hide it), 768^2 14.8 vs 15.2,
+// 1024^2 21.9 vs 25.3, 2048^2 56 vs 87, 4096^2 187 vs 301 (throughput-bound: half the HBM traffic).
+int prost_hip_fused_iteration_mc_x2_profitable(const prost_hip_fused_desc* d, int dtype) {
+  if (!iter_mc_x2_ok(d, dtype)) return 0;
+  const double values = (double)d->nx * (double)d->ny * (double)d->L;
+  return values <= 3.0e5 || values >= 1.5e6 ? 1 : 0;
+}
 int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int with_residuals) {
   return iter_mc_x2_ok(d, dtype) ? (int)mc_x2_chunk_cols(d, 0, with_residuals != 0) : 0;
 }
