@@ -42,6 +42,9 @@ class Backend {
     return false;
   }
 
+  /// launches that ran two iterations at once so far (diagnostics: 0 for backends that never fuse iterations)
+  virtual size_t pair_launches() const { return 0; }
+
   virtual T primal_residual() const { return primal_residual_; }
   virtual T dual_residual() const { return dual_residual_; }
   virtual T primal_var_norm() const { return primal_var_norm_; }

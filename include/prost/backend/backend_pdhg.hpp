@@ -56,6 +56,7 @@ class BackendPDHG : public Backend<T> {
   T* x_data() { return x_.data(); }
   T* y_data() { return y_.data(); }
   bool single_kernel_path() const { return single_kernel_; }
+  virtual size_t pair_launches() const { return pair_launches_; }
   /// one kernel per iteration with residual sums restricted to owned columns: gradient2d with L <= 2 or L = 3 / 4 channels
   bool sharded_path() const { return single_kernel_ || single_mc_; }
   size_t fused_channels() const { return fused_ ? desc_.L : 0; }
@@ -93,6 +94,7 @@ class BackendPDHG : public Backend<T> {
   Options opts_;
   bool fused_, single_kernel_, pair_kernel_;
   bool pair3d_ = false, pair_mc_ = false;
+  size_t pair_launches_ = 0;
   prost_hip_fused_desc desc_;
   // state: fused keeps x, x_prev, y, y_prev only; generic adds kx, kx_prev, kty, kty_prev, temp
   device_vector<T> x_, y_, x_prev_, y_prev_, temp_, kx_, kty_, kx_prev_, kty_prev_;

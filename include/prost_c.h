@@ -76,7 +76,8 @@ const prost_value* prost_value_field(const prost_value* v, const char* name);   
  * passed to mexErrMsgTxt (prost.cpp:342-346). */
 int prost_command(const char* cmd, int nlhs, prost_value** plhs, int nrhs, const prost_value* const* prhs);
 const char* prost_last_error(void);
-/* user-interrupt hook of solve_problem (the Ctrl-C poll of the MEX gateway) */
+/* user-interrupt hook of solve_problem (the Ctrl-C poll of the MEX gateway), asked after EVERY iteration: while one is registered
+ * the solver hands out iterations one by one (no two iterations per launch).  fn = NULL removes it. */
 void prost_set_stop_callback(prost_stop_cb fn, void* user);
 /* Multi-rank runs without RCCL (several ranks on one GPU, or a host-side fabric): makes `fn(user, values, count)` -- an
  * in-place sum over the ranks of `count` doubles in pinned host memory -- the communicator of the solvers created
@@ -90,7 +91,7 @@ int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size);
  *   init, release                          -> no results                        (prost.cpp:278-281)
  *   list_gpus                              -> prints one line per device        (:283-297)
  *   set_gpu(id)                                                                 (:299-303)
- *   solve_problem(problem, nrows, ncols, backend, opts) -> struct {x,y,z,w,result[,iters,path]}  (:68-155)
+ *   solve_problem(problem, nrows, ncols, backend, opts) -> struct {x,y,z,w,result[,iters,path,pair_launches]}  (:68-155)
  *       problem: struct {linop, prox_g, prox_f, prox_gstar, prox_fstar, scaling, scaling_alpha |
  *                        scaling_left, scaling_right}                           (factory.cpp:950-990)
  *       backend: cell {name, struct}   name in {pdhg, admm}                     (:914-948)

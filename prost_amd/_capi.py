@@ -230,7 +230,7 @@ def command(cmd, args=(), nlhs=0, struct_fields=None):
 # ------------------------------------------------------------------------------------------
 # the +prost command surface (matlab/+prost/*.m)
 # ------------------------------------------------------------------------------------------
-_RESULT_FIELDS = ("x", "y", "z", "w", "result", "iters", "path")
+_RESULT_FIELDS = ("x", "y", "z", "w", "result", "iters", "path", "pair_launches")
 _STATE_FIELDS = ("x", "y", "z", "w", "tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res",
                  "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "cg_iterations", "path")
 
@@ -402,6 +402,22 @@ def comm_init_host(allreduce, world):
     _host_allreduce_keep.append(cb)
     if lib().prost_comm_init_host(cb, None, int(world)) != 0:
         raise ProstError(lib().prost_last_error().decode())
+
+
+_stop_cb_keep = []
+
+
+def set_stop_callback(fn):
+    """Registers `fn() -> bool` (True = stop) as the stopping callback of prost.solve -- the MEX gateway's Ctrl-C poll
+    (prost.cpp:58-66).  It is asked after EVERY iteration, so a solve with a stopping callback launches every iteration on its
+    own; None removes it."""
+    if fn is None:
+        lib().prost_set_stop_callback(STOP_CB(), None)
+        del _stop_cb_keep[:]
+        return
+    cb = STOP_CB(lambda user, f=fn: 1 if f() else 0)
+    _stop_cb_keep.append(cb)
+    lib().prost_set_stop_callback(cb, None)
 
 
 def comm_destroy():

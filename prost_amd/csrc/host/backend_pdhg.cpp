@@ -83,6 +83,7 @@ void BackendPDHG<T>::Initialize() {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols(), l = std::max(m, n);
 
   iteration_ = 0;
+  pair_launches_ = 0;
   prev_stale_ = false;
   residuals_pending_ = false;
   tau_ = (T)opts_.tau0;
@@ -191,6 +192,7 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   const size_t k = iteration_;
   if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
     IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
+    pair_launches_++;
     return 2;
   }
   // gradient3d: the double-iteration kernel forms the residual sums of its second iteration but stores no intermediate
@@ -198,11 +200,13 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   // residual iterations are always the second of a pair
   if (pair3d_ && budget >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {
     IterationPair3D(is_residual_iteration(k + 1));
+    pair_launches_++;
     return 2;
   }
   // 2-4 channels: the same rule (residual sums of the second iteration in the kernel, no stored intermediate iterate)
   if (pair_mc_ && budget >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {
     IterationPairMc(is_residual_iteration(k + 1));
+    pair_launches_++;
     return 2;
   }
   PerformIteration();

@@ -488,7 +488,9 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
     }
     // (options.m's default dummy_cb prints a newline and returns false: exactly what Solver::Solve does by itself when no
     // callback is installed, so none is -- and the final read-out can stream the result, see solve_problem_t)
-    h->solver->SetStoppingCallback([]() { return g_stop_cb ? g_stop_cb(g_stop_user) != 0 : false; });
+    // only when the front end registered one (the MEX gateway polls Ctrl-C, prost.cpp:58-66): a stopping callback is asked after
+    // EVERY iteration, so the solver then hands out iterations one by one and no two of them share a launch
+    if (g_stop_cb) h->solver->SetStoppingCallback([]() { return g_stop_cb ? g_stop_cb(g_stop_user) != 0 : false; });
   }
   // column-sharded images: only the owned columns of this slab count (residual sums, global sizes)
   double own_frac = 1.0;
@@ -572,6 +574,7 @@ void solve_problem_t(CMD_ARGS) {
   prost_value_struct_set(out, "result", prost_value_string(msg));
   prost_value_struct_set(out, "iters", prost_value_scalar(h->solver->iterations_done()));
   prost_value_struct_set(out, "path", prost_value_string(h->backend->path().c_str()));
+  prost_value_struct_set(out, "pair_launches", prost_value_scalar((double)h->backend->pair_launches()));
   h->solver->Release();
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }

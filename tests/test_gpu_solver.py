@@ -153,6 +153,30 @@ def test_pdhg_warm_start_moreau_and_dual(precision, dtype):
         assert_same_iterates(run_product(prob, b, o, 20), run_oracle(prob, b, o, 20, dtype))
 
 
+def test_solve_pairs_iterations_unless_a_stopping_callback_polls_every_one():
+    """prost.solve launches two iterations at once where nobody looks in between (row a1: the budget of Solver::Solve); a
+    registered stopping callback (the MEX gateway's Ctrl-C poll, solver.cu:151) is asked after EVERY iteration, which rules pairs
+    out, and ends the run at exactly the iteration where it fires -- with the iterates the uninterrupted run had there."""
+    prost.set_precision("single")
+    prob, u, q, f = synthetic.rof_problem(64, 48, 1, seed=8)
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+    kw = dict(verbose=False, num_cback_calls=0, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    r = prost.solve(prob, b, prost.options(max_iters=40, **kw))
+    assert r["result"] == "Reached maximum iterations." and int(r["pair_launches"]) >= 15, r["pair_launches"]
+    polls = []
+    prost.set_stop_callback(lambda: polls.append(1) or len(polls) >= 17)
+    try:
+        rs = prost.solve(prob, b, prost.options(max_iters=40, **kw))
+    finally:
+        prost.set_stop_callback(None)
+    assert rs["result"] == "Stopped by user." and int(rs["iters"]) == 17 == len(polls) and int(rs["pair_launches"]) == 0
+    r17 = prost.solve(prob, b, prost.options(max_iters=17, **kw))
+    for v in "xyzw":
+        assert np.array_equal(np.asarray(rs[v]), np.asarray(r17[v])), v
+    r2 = prost.solve(prob, b, prost.options(max_iters=40, **kw))          # the callback is gone again
+    assert int(r2["pair_launches"]) == int(r["pair_launches"]) and np.array_equal(np.asarray(r2["x"]), np.asarray(r["x"]))
+
+
 @pytest.mark.parametrize("solve_dual", [False, True])
 def test_solve_streams_the_same_result_it_hands_to_callbacks(solve_dual):
     """Without an intermediate-solution callback prost.solve takes x, y, z, w straight from the device
