@@ -76,8 +76,9 @@ const prost_value* prost_value_field(const prost_value* v, const char* name);   
  * passed to mexErrMsgTxt (prost.cpp:342-346). */
 int prost_command(const char* cmd, int nlhs, prost_value** plhs, int nrhs, const prost_value* const* prhs);
 const char* prost_last_error(void);
-/* user-interrupt hook of solve_problem (the Ctrl-C poll of the MEX gateway), asked after EVERY iteration: while one is registered
- * the solver hands out iterations one by one (no two iterations per launch).  fn = NULL removes it. */
+/* user-interrupt hook of solve_problem (the Ctrl-C poll of the MEX gateway), asked once per kernel launch -- after every
+ * iteration or every second one where two iterations share a launch, so a stop request is honoured at most one iteration
+ * later than by the reference (solver.cu:151 polls after each).  fn = NULL removes it. */
 void prost_set_stop_callback(prost_stop_cb fn, void* user);
 /* Multi-rank runs without RCCL (several ranks on one GPU, or a host-side fabric): makes `fn(user, values, count)` -- an
  * in-place sum over the ranks of `count` doubles in pinned host memory -- the communicator of the solvers created

@@ -409,8 +409,7 @@ _stop_cb_keep = []
 
 def set_stop_callback(fn):
     """Registers `fn() -> bool` (True = stop) as the stopping callback of prost.solve -- the MEX gateway's Ctrl-C poll
-    (prost.cpp:58-66).  It is asked after EVERY iteration, so a solve with a stopping callback launches every iteration on its
-    own; None removes it."""
+    (prost.cpp:58-66).  It is asked once per kernel launch, i.e. after every iteration or every second one; None removes it."""
     if fn is None:
         lib().prost_set_stop_callback(STOP_CB(), None)
         del _stop_cb_keep[:]

@@ -488,8 +488,7 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
     }
     // (options.m's default dummy_cb prints a newline and returns false: exactly what Solver::Solve does by itself when no
     // callback is installed, so none is -- and the final read-out can stream the result, see solve_problem_t)
-    // only when the front end registered one (the MEX gateway polls Ctrl-C, prost.cpp:58-66): a stopping callback is asked after
-    // EVERY iteration, so the solver then hands out iterations one by one and no two of them share a launch
+    // only when the front end registered one (the MEX gateway polls Ctrl-C, prost.cpp:58-66): it is asked once per launch
     if (g_stop_cb) h->solver->SetStoppingCallback([]() { return g_stop_cb ? g_stop_cb(g_stop_user) != 0 : false; });
   }
   // column-sharded images: only the owned columns of this slab count (residual sums, global sizes)

@@ -95,10 +95,12 @@ typename Solver<T>::ConvergenceResult Solver<T>::Solve() {
     // 196), but only three things can change its outcome: the residuals (which only residual
     // iterations update -- the backend never fuses those), the callback schedule and the last
     // iteration (both known here), and a user stop callback (then nothing is fused).  `budget` =
-    // iterations up to and including the next scheduled observation; the backend runs k <= budget of
-    // them and the checks run once for the last of these k, whose index is i afterwards.
+    // iterations up to and including the next scheduled observation (at most 2 with a stopping callback); the backend runs
+    // k <= budget of them and the checks run once for the last of these k, whose index is i afterwards.
     const int next_observed = std::min((int)std::ceil(cb_iters.front() < 1e8 ? cb_iters.front() : 1e8), opts_.max_iters - 1);
-    const int budget = stopping_cb_ ? 1 : std::max(1, next_observed - i + 1);
+    // A stopping callback (the MEX gateway's Ctrl-C poll) is asked once per LAUNCH, i.e. after every iteration or every second
+    // one: a stop request is honoured at most one iteration later than in the reference, which polls after each (solver.cu:151).
+    const int budget = std::max(1, std::min(stopping_cb_ ? 2 : opts_.max_iters, next_observed - i + 1));
     const int done = backend_->PerformIterations(budget);
     i += done - 1;
     iterations_done_ += done;
