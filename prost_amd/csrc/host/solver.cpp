@@ -113,7 +113,11 @@ typename Solver<T>::ConvergenceResult Solver<T>::Solve() {
     if (i >= cb_iters.front() || is_converged || is_stopped || i == (opts_.max_iters - 1)) {
       // the observation that ends the run, nobody to show intermediate solutions to: the caller may take the result directly
       const bool last = is_converged || is_stopped || i == (opts_.max_iters - 1);
-      if (!(last && !interm_cb_ && final_readout_ && final_readout_())) FetchSolution();
+      // scheduled observations without a callback only print the residual line: the solution vectors are read when somebody
+      // can see them (an installed callback, or the end of the run) -- not 10 times by default (options.m: num_cback_calls = 10)
+      if (interm_cb_ || last) {
+        if (!(last && !interm_cb_ && final_readout_ && final_readout_())) FetchSolution();
+      }
       if (opts_.num_cback_calls >= 1) {
         if (opts_.verbose) {
           const int digits = (int)std::floor(std::log10((double)opts_.max_iters)) + 1;
