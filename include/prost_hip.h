@@ -330,8 +330,8 @@ int prost_hip_fused_iteration3d_pw_f64(const prost_hip_fused_desc* desc, double*
  * prost_hip_fused_iteration2, the squares of the dual arguments of both dual steps meeting in LDS for the norm over the
  * 2 L components of a pixel.  Reads x^k, y^k and b, writes x^(k+2), y^(k+2); the intermediate iterate is stored nowhere.
  * tau/sigma/theta: HOST arrays of 2.  Bit-identical to two prost_hip_fused_iteration_mc launches (resp. two
- * prost_hip_fused_iteration launches for L = 2).  fp32, straight-line ROF / TV-L1 shapes (prox_g square or abs with
- * scalar a = 1, d = e = 0, b scalar or per pixel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), ny % 4 == 0. */
+ * prost_hip_fused_iteration launches for L = 2).  Straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar
+ * a = 1, d = e = 0, b scalar or per pixel; prox_f* ind_leq0 with scalar a = 1, d = e = 0); ny % 4 == 0 (fp32) / ny % 2 == 0 (fp64). */
 int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
 /* 1 iff the launch is also faster than two single launches (tiny images: one launch instead of two; large ones: half the HBM
  * traffic; in between -- about 384^2 to 700^2 RGB -- the single-iteration kernel is up to 9 % faster) */
@@ -340,6 +340,8 @@ int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* desc,
 /* res_out4 != NULL (needs `workspace`): also the four residual sums of the SECOND iteration, as prost_hip_fused_iteration_mc
  * writes them for that iteration (same terms, restricted to the owned columns res_x0 / res_x1; the summation order differs) */
 int prost_hip_fused_iteration_mc_x2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
+                                        const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream);
+int prost_hip_fused_iteration_mc_x2_f64(const prost_hip_fused_desc* desc, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
                                         const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream);
 
 /* TWO iterations of a gradient3d problem per launch (kernels_fused_iter3d_x2.hip; backend_pdhg.cu:317-370 twice): the

@@ -14,11 +14,12 @@
 // Per channel: 7 floats per pixel per TWO iterations (y1, y2, x, b read; x, y1, y2 written) against 2 x 7 for the
 // single-iteration kernel.  x^(k+2), y^(k+2) are bit-identical to two single launches (tests/test_gpu_kernels.py).
 // Straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0, b scalar or per pixel; prox_f*
-// ind_leq0 with scalar a = 1, d = e = 0), fp32, heights that are a multiple of 4; the intermediate iterate is stored nowhere,
+// ind_leq0 with scalar a = 1, d = e = 0), fp32 (4 rows per lane) and fp64 (2 rows per lane), heights that are a multiple of that; the intermediate iterate is stored nowhere,
 // the residual sums of the second iteration are available (RES): BackendPDHG pairs iterations k, k+1 unless k or k+2 is a
 // residual iteration.
 #include "fused_common.hpp"
 #include "reduce.hpp"
+#include <type_traits>
 
 namespace prost_hip {
 
@@ -286,8 +287,9 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
 }
 
 static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
-  if (dtype != 0 || !d || d->is3d || d->L < 2 || d->L > 4) return false;
-  if (d->nx < 4 || d->ny < 4 || d->ny % 4 != 0) return false;
+  if ((dtype != 0 && dtype != 1) || !d || d->is3d || d->L < 2 || d->L > 4) return false;
+  const size_t V = dtype == 0 ? 4 : 2;                 // rows per lane: 16 bytes
+  if (d->nx < 4 || d->ny < 4 || d->ny % V != 0) return false;
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;
@@ -297,8 +299,8 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
   // (res_x0 / res_x1 -- the owned columns of a sharded slab -- only restrict residual sums, which this kernel does not form)
-  if ((double)d->nx * (double)d->ny * 4.0 >= 4294967296.0) return false;              // 32-bit byte offsets per plane
-  const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
+  if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4.0 : 8.0) >= 4294967296.0) return false;              // 32-bit byte offsets per plane
+  const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
   if (strips > (size_t)kReduceBlocks / 2) return false;              // residual launches: one partial per workgroup, at best one chunk per strip
   return strips * d->nx < (size_t)1 << 31;
 }
@@ -307,9 +309,10 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
 // the chunk length minimises ceil(strips * chunks * L / slots) * (columns + 3 warm-up steps): long chunks once the image fills
 // the chip, short ones for small images, where every wavefront gets a slot anyway and only
 // the number of steps counts (512^2 RGB: 2 columns = 5 steps per two iterations)
-static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols, bool res) {
+static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int cols, bool res) {
   if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
-  const size_t strips = (d->ny + 62 * 4 - 1) / (62 * 4);
+  const size_t V = dtype == 0 ? 4 : 2;
+  const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
   const size_t slots = 256 * 4 * 3;
   size_t best_c = 1, best_cost = (size_t)-1;
   // (capped at 24 columns: beyond the point where every slot is taken, MORE and shorter workgroups hide the per-column barrier
@@ -326,11 +329,12 @@ static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int cols, bool res
 template <class T>
 static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
                           const double* theta, int cols, double* out4, void* ws, void* stream) {
-  if (!iter_mc_x2_ok(d, 0)) { set_error("fused multi-channel double iteration: unsupported description (see prost_hip_fused_iteration_mc_x2_supported)"); return 1; }
+  constexpr int kDtype = std::is_same<T, float>::value ? 0 : 1;
+  if (!iter_mc_x2_ok(d, kDtype)) { set_error("fused multi-channel double iteration: unsupported description (see prost_hip_fused_iteration_mc_x2_supported)"); return 1; }
   if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused multi-channel double iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_out == x || y_out == y) { set_error("fused multi-channel double iteration: outputs must not alias inputs"); return 1; }
   if (out4 && !ws) { set_error("fused multi-channel double iteration: residuals need the reduction workspace"); return 1; }
-  constexpr int V = 4;
+  constexpr int V = VecOf<T>::N;
   FusedArgs<T> a = make_fused_args<T>(d);
   IterParamsMc<T> p[2];
   for (int i = 0; i < 2; i++) {
@@ -341,7 +345,7 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
     p[i].sq = ug.sq; p[i].step = ug.step;
   }
   const size_t strips = (d->ny + (size_t)(kWave - 2) * V - 1) / ((size_t)(kWave - 2) * V);
-  const size_t c = mc_x2_chunk_cols(d, cols, out4 != nullptr);
+  const size_t c = mc_x2_chunk_cols(d, kDtype, cols, out4 != nullptr);
   a.cols_per_block = (int)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
   const unsigned grid = (unsigned)(strips * a.chunks);
@@ -378,10 +382,14 @@ int prost_hip_fused_iteration_mc_x2_profitable(const prost_hip_fused_desc* d, in
   return values <= 3.0e5 || values >= 1.5e6 ? 1 : 0;
 }
 int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int with_residuals) {
-  return iter_mc_x2_ok(d, dtype) ? (int)mc_x2_chunk_cols(d, 0, with_residuals != 0) : 0;
+  return iter_mc_x2_ok(d, dtype) ? (int)mc_x2_chunk_cols(d, dtype, 0, with_residuals != 0) : 0;
 }
 int prost_hip_fused_iteration_mc_x2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
                                         const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
   return run_iter_mc_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
+}
+int prost_hip_fused_iteration_mc_x2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
+                                        const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
+  return run_iter_mc_x2<double>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
 }
 }  // extern "C"

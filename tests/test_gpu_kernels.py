@@ -698,18 +698,24 @@ def test_normest_gradient_round_equals_the_staged_round(hip, dtype, shape):
     hip.sync()
 
 
-@pytest.mark.parametrize("shape", [(6, 8, 3), (5, 12, 4), (20, 1028, 3), (33, 64, 2), (4, 256, 4), (40, 508, 3), (64, 252, 2), (9, 248, 4), (130, 16, 3)])
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(6, 8, 3), (5, 12, 4), (20, 1028, 3), (33, 64, 2), (4, 256, 4), (40, 508, 3), (64, 252, 2), (9, 248, 4), (130, 16, 3), (11, 126, 3)])
 @pytest.mark.parametrize("vector_b", [True, False])
 @pytest.mark.parametrize("radius,g_fn", [(1.0, "square"), (1e-7, "square"), (1.0, "abs")])
-def test_double_multichannel_iteration_equals_two_iterations_of_the_two_pass_kernels(hip, shape, vector_b, radius, g_fn):
+def test_double_multichannel_iteration_equals_two_iterations_of_the_two_pass_kernels(hip, dtype, shape, vector_b, radius, g_fn):
     """prost_hip_fused_iteration_mc_x2 (two iterations per launch, one channel per wavefront, the squares of both dual steps
     meeting in LDS for the norm over the 2 L components of a pixel) against two iterations of the two-pass kernels, which are
     pinned to the oracle (test_fused_passes_match_unfused_oracle): same bits for x^(k+2) and all 2 L components of y^(k+2), for
     every chunk width (1: every column a chunk border; 200: one chunk), 2 / 3 / 4 channels, strip layouts (252 = one strip + 4
     rows, 1028 rows: five strips) and step sizes that change between the two iterations (alg2); with residual sums: the four sums
     of the second iteration against the two-pass kernels' for that iteration."""
-    dtype = np.float32
     nx, ny, L = shape
+    dt = 0 if dtype == np.float32 else 1
+    if ny % (4 if dt == 0 else 2):
+        d0 = hip.FusedDesc(); d0.is3d = 0; d0.nx, d0.ny, d0.L = nx, ny, L
+        d0.g_fn = hip.FN_ID[g_fn]; d0.f_fn = hip.FN_ID["ind_leq0"]
+        assert hip.lib().prost_hip_fused_iteration_mc_x2_supported(C.byref(d0), dt) == 0      # 16 bytes of rows per lane
+        return
     rng = np.random.default_rng(13)
     n, m = nx * ny * L, 2 * nx * ny * L
     x = rng.uniform(0, 1, n).astype(dtype); y = rng.uniform(-1, 1, m).astype(dtype)
@@ -723,8 +729,7 @@ def test_double_multichannel_iteration_equals_two_iterations_of_the_two_pass_ker
     for i in range(7):
         d.g_coeff_ptr[i] = gp[i]; d.g_coeff_val[i] = gv[i]; d.f_coeff_ptr[i] = fp[i]; d.f_coeff_val[i] = fv[i]
     d.T_val, d.S_val = 0.25, 0.5
-    assert hip.lib().prost_hip_fused_iteration_mc_x2_supported(C.byref(d), 0) == 1
-    assert hip.lib().prost_hip_fused_iteration_mc_x2_supported(C.byref(d), 1) == 0           # fp32 only
+    assert hip.lib().prost_hip_fused_iteration_mc_x2_supported(C.byref(d), dt) == 1
     tau, sigma, theta = [0.9, 0.61], [1.1, 1.63], [0.85, 0.67]
     dx, dy = dev(hip, x), dev(hip, y)
     x1 = hip.DeviceArray.zeros(n, dtype); y1 = hip.DeviceArray.zeros(m, dtype)
@@ -739,12 +744,13 @@ def test_double_multichannel_iteration_equals_two_iterations_of_the_two_pass_ker
     res_ref = np.concatenate([rp.to_host(), rd.to_host()])      # {primal diff^2, primal var^2, dual diff^2, dual var^2}
     x_ref, y_ref = x2.to_host(), y2.to_host()
     arr = lambda v: (C.c_double * 2)(*v)
-    pad, sentinel = 256, np.float32(-123456.75)
+    pad, sentinel = 256, dtype(-123456.75)
     for cols, res in ((0, False), (0, True), (1, True), (2, False), (5, True), (7, False), (200, True)):
         bx = dev(hip, np.full(n + 2 * pad, sentinel, dtype)); by = dev(hip, np.full(m + 2 * pad, sentinel, dtype))      # canaries around the outputs
-        xo = C.c_void_p(bx.ptr.value + pad * 4); yo = C.c_void_p(by.ptr.value + pad * 4)
+        esz = np.dtype(dtype).itemsize
+        xo = C.c_void_p(bx.ptr.value + pad * esz); yo = C.c_void_p(by.ptr.value + pad * esz)
         r4 = hip.DeviceArray.zeros(4, np.float64)
-        hip.check(hip.lib().prost_hip_fused_iteration_mc_x2_f32(C.byref(d), xo, yo, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols,
+        hip.check(hip.fn("fused_iteration_mc_x2", dtype)(C.byref(d), xo, yo, dx.ptr, dy.ptr, arr(tau), arr(sigma), arr(theta), cols,
                                                                 r4.ptr if res else None, ws.ptr if res else None, None))
         if res:      # the same terms as the two-pass kernels, summed in double in another order
             assert np.allclose(r4.to_host(), res_ref, rtol=1e-11, atol=1e-300), (cols, r4.to_host(), res_ref)

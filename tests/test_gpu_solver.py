@@ -588,14 +588,15 @@ def test_pair_kernel_schedule_is_invisible(prec, dtype, step, residual_iter):
         assert_same_iterates(run_product(prob, b, o, 23), run_oracle(prob, b, o, 23, dtype))
 
 
+@pytest.mark.parametrize("prec,dtype", PRECISIONS)
 @pytest.mark.parametrize("step", STEPS)
 @pytest.mark.parametrize("L,residual_iter,data_term", [(3, 10, "square"), (3, 4, "square"), (3, 3, "square"), (4, 10, "square"), (2, 10, "square"), (2, 5, "square"), (3, 10, "abs"), (2, 10, "abs")])
-def test_multichannel_pair_schedule_is_invisible(step, L, residual_iter, data_term):
-    """fp32 vectorial TV with 2 / 3 / 4 channels: two iterations per launch (prost_hip_fused_iteration_mc_x2) wherever neither k
+def test_multichannel_pair_schedule_is_invisible(prec, dtype, step, L, residual_iter, data_term):
+    """Vectorial TV with 2 / 3 / 4 channels, fp32 and fp64: two iterations per launch (prost_hip_fused_iteration_mc_x2) wherever neither k
     nor k+2 is a residual iteration (k+1 may be one: the kernel forms its sums).  The state after ANY number of iterations -- x, y, the constraint variables z, w (which need
     the previous iterate, rebuilt by one single launch after a pair), residuals, step sizes -- is bit-identical to the path that
     launches every iteration separately, and the iterates equal the oracle's."""
-    prost.set_precision("single")
+    prost.set_precision(prec)
     o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
     for (nx, ny) in ((12, 16), (9, 252), (40, 500)):
         prob, u, q, f = synthetic.rof_problem(nx, ny, L, seed=3, data_term=data_term, lmb=10.0 if data_term == "square" else 0.7)
@@ -625,7 +626,7 @@ def test_multichannel_pair_schedule_is_invisible(step, L, residual_iter, data_te
                 for v in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm"):       # same terms, another summation order
                     assert np.isclose(a_[v], b_[v], rtol=1e-9, atol=0), (nx, ny, L, iters, v, a_[v], b_[v])
         bo = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
-        assert_same_iterates(run_product(prob, bo, o, 23), run_oracle(prob, bo, o, 23, np.float32))
+        assert_same_iterates(run_product(prob, bo, o, 23), run_oracle(prob, bo, o, 23, dtype))
 
 
 @pytest.mark.parametrize("prec,dtype", PRECISIONS)

@@ -55,14 +55,14 @@ def main(N=4096, Lc=3, cols_list=(0, 6, 12, 18, 24, 36), iters=50, dtype=np.floa
         t = timed(run1)
         print("one-kernel cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s, kernel moves (7 values) %.0f GB/s"
               % (cols, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3), 7 * n * esz / 1e9 / (t * 1e-3)), flush=True)
-    if dtype == np.float32 and L_.prost_hip_fused_iteration_mc_x2_supported(C.byref(d), 0) == 1:
+    if L_.prost_hip_fused_iteration_mc_x2_supported(C.byref(d), 0 if dtype == np.float32 else 1) == 1:
         two = lambda v: (C.c_double * 2)(v, v)
         r4x = hip.DeviceArray.zeros(4, np.float64)
         for xres, cols in [(False, int(c)) for c in os.environ.get("X2_COLS", "0,24,36,48,72,96").split(",")] + [(True, 0)]:
             def runx(k):
                 for i in range(k):
                     a, b = i % 2, (i + 1) % 2
-                    hip.check(L_.prost_hip_fused_iteration_mc_x2_f32(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, two(0.3), two(1.0), two(0.9), cols, r4x.ptr if xres else None, ws.ptr if xres else None, None))
+                    hip.check(hip.fn("fused_iteration_mc_x2", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, two(0.3), two(1.0), two(0.9), cols, r4x.ptr if xres else None, ws.ptr if xres else None, None))
             t = timed(runx) / 2
             print("two iterations per launch%s cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s"
                   % (" + residual sums" if xres else "", cols, t, 1e3 / t, 11 * n * esz / 1e9 / (t * 1e-3)), flush=True)
@@ -83,6 +83,6 @@ def main(N=4096, Lc=3, cols_list=(0, 6, 12, 18, 24, 36), iters=50, dtype=np.floa
 if __name__ == "__main__":
     if len(sys.argv) >= 3:
         cl = tuple(int(c) for c in sys.argv[3].split(",")) if len(sys.argv) > 3 else (0, 6, 12, 18, 24, 36)
-        main(int(sys.argv[1]), int(sys.argv[2]), cols_list=cl)
+        main(int(sys.argv[1]), int(sys.argv[2]), cols_list=cl, dtype=np.float64 if len(sys.argv) > 4 and sys.argv[4] == "f64" else np.float32)
     else:
         main()
