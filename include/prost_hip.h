@@ -348,8 +348,8 @@ int prost_hip_fused_iteration_mc_x2_f64(const prost_hip_fused_desc* desc, double
  * planes of a group run on the wavefronts of one workgroup, every wavefront runs the 4-stage column pipeline of
  * prost_hip_fused_iteration2 on its plane and the stages meet in LDS.  Reads x^k, y^k and b, writes x^(k+2), y^(k+2);
  * the intermediate iterate is stored nowhere, so callers pair only iterations whose intermediate state nobody observes.  tau/sigma/theta: HOST arrays of 2.  Bit-identical to two prost_hip_fused_iteration3d
- * launches (use_kty = use_kx_prev = 1).  fp32, straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0,
- * b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), even ny: see _supported.
+ * launches (use_kty = use_kx_prev = 1).  fp32 (even ny) and fp64, straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0,
+ * b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0): see _supported.
  * cols <= 0: automatic chunk length. */
 int prost_hip_fused_iteration3d_x2_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
 /* columns per chunk a launch with cols <= 0 uses (0 if unsupported): chosen so that the rounds of workgroups on the
@@ -358,6 +358,8 @@ int prost_hip_fused_iteration3d_x2_chunk_cols(const prost_hip_fused_desc* desc, 
 /* res_out4 != NULL (needs `workspace`): also the four residual sums of the SECOND iteration, as
  * prost_hip_fused_iteration3d writes them for that iteration (same terms; the summation order differs) */
 int prost_hip_fused_iteration3d_x2_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
+                                       const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream);
+int prost_hip_fused_iteration3d_x2_f64(const prost_hip_fused_desc* desc, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
                                        const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream);
 
 /* ONE kernel per iteration for gradient2d problems with L = 3 or 4 channels (kernels_fused_iter_mc.hip): the channels

@@ -115,11 +115,9 @@ void BackendPDHG<T>::Initialize() {
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
   pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_profitable(&desc_, dtype_id<T>()) == 1;
-  pair3d_ = false;
-  if constexpr (std::is_same<T, float>::value)
-    // (volumes of fewer than 4 planes leave 13 of the 16 wavefronts of a workgroup idle: 2048^2 x 2 runs 0.125 ms per iteration in pairs,
-    // 0.086 ms in single launches; from 4 planes on the pairs win, 0.127 against 0.206 ms)
-    pair3d_ = fused_ && desc_.is3d && desc_.L >= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, 0) == 1;
+  // (volumes of fewer than 4 planes leave 13 of the 16 wavefronts of a workgroup idle: 2048^2 x 2 runs 0.125 ms per iteration in pairs,
+  // 0.086 ms in single launches; from 4 planes on the pairs win, 0.127 against 0.206 ms)
+  pair3d_ = fused_ && desc_.is3d && desc_.L >= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, dtype_id<T>()) == 1;
   // 2-4 channels: the channels on the wavefronts of a workgroup, two iterations per launch
   pair_mc_ = (single_mc_ || (single_kernel_ && desc_.L == 2)) && opts_.allow_pair_kernel && prost_hip_fused_iteration_mc_x2_profitable(&desc_, dtype_id<T>()) == 1;
   if (pair_kernel_ || pair3d_ || pair_mc_) x_spare_.resize(n);
@@ -270,26 +268,22 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
 
 template <typename T>
 void BackendPDHG<T>::IterationPair3D(bool residuals) {
-  if constexpr (std::is_same<T, float>::value) {
-    double tau[2], sigma[2], theta[2];
-    tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
-    stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_;
-    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
-    iteration_++;
-    tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
-    const bool t = BeginSample(residuals ? kKernelPairRes : kKernelPair);
-    CheckHip(prost_hip_fused_iteration3d_x2_f32(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
-                                                residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration3d_x2");
-    EndSample(t);
-    x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
-    y_.swap(y_prev_);
-    prev_stale_ = true;
-    if (residuals) FinishResiduals();                                    // iteration_ == k+1 here, as in the single path
-    if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
-    iteration_++;
-  } else {
-    throw Exception("IterationPair3D: fp32 only");
-  }
+  double tau[2], sigma[2], theta[2];
+  tau[0] = (double)tau_; sigma[0] = (double)sigma_; theta[0] = (double)theta_;
+  stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_;
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
+  iteration_++;
+  tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
+  const bool t = BeginSample(residuals ? kKernelPairRes : kKernelPair);
+  CheckHip(Api<T>::fused_iteration3d_x2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
+                                        residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration3d_x2");
+  EndSample(t);
+  x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
+  y_.swap(y_prev_);
+  prev_stale_ = true;
+  if (residuals) FinishResiduals();                                    // iteration_ == k+1 here, as in the single path
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  iteration_++;
 }
 
 template <typename T>

@@ -48,6 +48,7 @@ template <typename T> struct Api;
     static constexpr auto fused_iteration_mc = prost_hip_fused_iteration_mc_##S;  \
     static constexpr auto fused_iteration_mc_x2 = prost_hip_fused_iteration_mc_x2_##S; \
     static constexpr auto fused_iteration3d_pw = prost_hip_fused_iteration3d_pw_##S; \
+    static constexpr auto fused_iteration3d_x2 = prost_hip_fused_iteration3d_x2_##S; \
     static constexpr auto compare = prost_hip_compare_##S;                        \
     static constexpr auto nrm2 = prost_hip_nrm2_##S;                              \
     static constexpr auto axpy = prost_hip_axpy_##S;                              \

@@ -20,10 +20,12 @@
 //   ideal 5 + 4 floats per voxel = 9.66 GB) for TWO iterations, against 11.3 GB for ONE of the single-iteration kernel.
 // Every stage evaluates the expressions of kernels_fused_iter3d_pw.hip / kernels_fused3d.hip, so x^(k+2), y^(k+2) are
 // bit-identical to two single launches (tests/test_gpu_fused3d.py).  Straight-line ROF / TV-L1 shapes only (prox_g square or abs with
-// scalar a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0), fp32, even heights.  The
+// scalar a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0); fp32 with 2 rows per lane (even heights)
+// and fp64 with 1 row per lane and two halo lanes on either side.  The
 // intermediate iterate is stored nowhere; the residual sums of the second iteration are available (RES).
 #include "fused_common.hpp"
 #include "reduce.hpp"
+#include <type_traits>
 
 namespace prost_hip {
 
@@ -37,14 +39,16 @@ struct IterParams3 {           // step sizes of one iteration + the host-evaluat
 // VEC consecutive rows per lane (4: 16-byte accesses, 2: 8-byte accesses)
 template <class T, int VEC>
 __device__ __forceinline__ void ldx(const T* __restrict__ p, T (&v)[VEC]) {
-  typedef T V __attribute__((ext_vector_type(VEC)));
+  if constexpr (VEC == 1) { v[0] = p[0]; return; }
+  typedef T V __attribute__((ext_vector_type(VEC > 1 ? VEC : 2)));
   const V t = *reinterpret_cast<const V*>(p);
 #pragma unroll
   for (int j = 0; j < VEC; j++) v[j] = t[j];
 }
 template <class T, int VEC>
 __device__ __forceinline__ void stx_nt(T* __restrict__ p, const T (&v)[VEC]) {
-  typedef T V __attribute__((ext_vector_type(VEC)));
+  if constexpr (VEC == 1) { __builtin_nontemporal_store(v[0], p); return; }
+  typedef T V __attribute__((ext_vector_type(VEC > 1 ? VEC : 2)));
   V t;
 #pragma unroll
   for (int j = 0; j < VEC; j++) t[j] = v[j];
@@ -76,7 +80,10 @@ template <class T, int VEC, int GFN, bool GB, int WT, bool RES>
 __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                        const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2,
                                                                        double* __restrict__ partial) {
-  constexpr int kRowsPerWave = (kWave - 2) * VEC;
+  // two iterations need TWO valid rows beyond the owned ones on either side (x^(k+2) of a row needs y^(k+1) of the row above, that
+  // x^(k+1) of the same row, that the raw y of the row above it): one halo lane of >= 2 rows, or two halo lanes of one row (fp64)
+  constexpr int kHalo = VEC >= 2 ? 1 : 2;
+  constexpr int kRowsPerWave = (kWave - 2 * kHalo) * VEC;
   constexpr int kPix = kWave * VEC;
   constexpr int P = WT - 3;                            // planes a workgroup owns
   __shared__ T s_x1[2][WT][kPix], s_y3[2][WT][kPix], s_x2[2][WT][kPix];
@@ -103,9 +110,9 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   const bool do_x2 = exists && wv >= 1 && wv <= P + 1;
   const bool do_y2 = exists && wv >= 1 && wv <= P;
   const bool has_above = exists && l + 1 < L, has_below = exists && l > 0;
-  const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
+  const long row0 = (long)strip * kRowsPerWave + ((long)lane - kHalo) * VEC;
   const bool active = exists && row0 >= 0 && row0 < ny;
-  const bool owner = active && lane > 0 && lane < kWave - 1;
+  const bool owner = active && lane >= kHalo && lane < kWave - kHalo;
   const long xa = (long)chunk * a.cols_per_block;
   const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t Pn = (size_t)nx * (size_t)ny, N = Pn * (size_t)L, plane = (size_t)l * Pn;
@@ -350,11 +357,15 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
 bool fused3d_desc_ok(const prost_hip_fused_desc* d);
 
 // rows per lane / wavefronts per workgroup of the instance that runs (see the header of this file)
-constexpr int kX2Vec = 2, kX2Waves = 16;
+// (8 bytes of rows per lane: 2 floats or 1 double)
+constexpr int kX2Waves = 16;
+static constexpr int x2_vec(int dtype) { return dtype == 0 ? 2 : 1; }
+static constexpr size_t x2_rows_per_wave(int dtype) { return dtype == 0 ? (size_t)(kWave - 2) * 2 : (size_t)(kWave - 4); }      // owned rows: one halo lane of 2 rows / two of 1 row on either side
 
-// straight-line ROF shape, fp32, heights that are a multiple of the vector width
+// straight-line ROF / TV-L1 shapes; fp32: even heights
 static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
-  if (dtype != 0 || !fused3d_desc_ok(d)) return false;
+  if ((dtype != 0 && dtype != 1) || !fused3d_desc_ok(d)) return false;
+  const size_t kX2Vec = (size_t)x2_vec(dtype);
   if (d->ny % kX2Vec != 0 || d->ny < 4 || d->nx < 4) return false;
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   for (int k = 0; k < 7; k++) {
@@ -365,7 +376,7 @@ static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
   if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
-  const size_t strips = (d->ny + 62 * kX2Vec - 1) / (62 * kX2Vec);
+  const size_t strips = (d->ny + x2_rows_per_wave(dtype) - 1) / x2_rows_per_wave(dtype);
   // (residual launches write one partial per workgroup: with one chunk per tile the tiles alone must fit the reduction workspace)
   const size_t tiles = strips * ((d->L + kX2Waves - 4) / (kX2Waves - 3));
   return tiles <= (size_t)kReduceBlocks / 2 && tiles * d->nx < (size_t)1 << 31;
@@ -384,9 +395,9 @@ static int compute_units() {
 // (rounds of workgroups) x (column steps of a workgroup): pick the number of column chunks that minimises
 // ceil(strips * groups * chunks / CUs) * (columns per chunk + 4 warm-up steps).  2048 x 2048 x 64 on 256 CUs: 17 x 5 x 3 = 255
 // workgroups, ONE round of 687 steps (64-column chunks: 11 rounds of 68 steps = 748).
-static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int cols, bool res) {
+static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int cols, bool res) {
   constexpr int P = kX2Waves - 3;
-  const size_t tiles = ((d->ny + (size_t)(kWave - 2) * kX2Vec - 1) / ((size_t)(kWave - 2) * kX2Vec)) * ((d->L + P - 1) / P);
+  const size_t tiles = ((d->ny + x2_rows_per_wave(dtype) - 1) / x2_rows_per_wave(dtype)) * ((d->L + P - 1) / P);
   const size_t max_groups = res ? (size_t)kReduceBlocks / 2 : (size_t)1 << 31;     // residual launches: one partial (4 doubles) per workgroup
   if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
   const size_t cus = (size_t)compute_units();
@@ -407,8 +418,8 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
   constexpr int P = WT - 3;
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t groups = (d->L + P - 1) / P;
-  const size_t strips = (d->ny + (size_t)(kWave - 2) * V - 1) / ((size_t)(kWave - 2) * V);
-  const size_t c = x2_chunk_cols(d, cols, out4 != nullptr);
+  const size_t strips = (d->ny + x2_rows_per_wave(V == 2 ? 0 : 1) - 1) / x2_rows_per_wave(V == 2 ? 0 : 1);
+  const size_t c = x2_chunk_cols(d, std::is_same<T, float>::value ? 0 : 1, cols, out4 != nullptr);
   a.cols_per_block = (int)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
   const unsigned grid = (unsigned)(strips * a.chunks * groups);
@@ -428,7 +439,8 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
 template <class T>
 static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
                          const double* theta, int cols, double* out4, void* ws, void* stream) {
-  if (!iter3d_x2_ok(d, 0)) { set_error("fused 3-D double iteration: unsupported description (see prost_hip_fused_iteration3d_x2_supported)"); return 1; }
+  constexpr int kDtype = std::is_same<T, float>::value ? 0 : 1;
+  if (!iter3d_x2_ok(d, kDtype)) { set_error("fused 3-D double iteration: unsupported description (see prost_hip_fused_iteration3d_x2_supported)"); return 1; }
   if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused 3-D double iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_out == x || y_out == y) { set_error("fused 3-D double iteration: outputs must not alias inputs"); return 1; }
   if (out4 && !ws) { set_error("fused 3-D double iteration: residuals need the reduction workspace"); return 1; }
@@ -441,7 +453,7 @@ static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, cons
     if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused 3-D double iteration: not the straight-line ROF shape"); return 1; }
     p[i].sq = ug.sq; p[i].step = ug.step;
   }
-  return launch_iter3d_x2<T, kX2Vec, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
+  return launch_iter3d_x2<T, x2_vec(kDtype), kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
 }
 
 }  // namespace prost_hip
@@ -451,10 +463,14 @@ using namespace prost_hip;
 extern "C" {
 int prost_hip_fused_iteration3d_x2_supported(const prost_hip_fused_desc* d, int dtype) { return iter3d_x2_ok(d, dtype) ? 1 : 0; }
 int prost_hip_fused_iteration3d_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int with_residuals) {
-  return iter3d_x2_ok(d, dtype) ? (int)x2_chunk_cols(d, 0, with_residuals != 0) : 0;
+  return iter3d_x2_ok(d, dtype) ? (int)x2_chunk_cols(d, dtype, 0, with_residuals != 0) : 0;
 }
 int prost_hip_fused_iteration3d_x2_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
                                        const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
   return run_iter3d_x2<float>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
+}
+int prost_hip_fused_iteration3d_x2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
+                                       const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
+  return run_iter3d_x2<double>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
 }
 }  // extern "C"

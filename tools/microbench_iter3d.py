@@ -70,14 +70,14 @@ def main(nx=2048, ny=2048, Lp=64, cols_list=(0, 6, 12, 18, 24, 36, 48), iters=30
                     hip.check(PW(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, cols, waves, None))
             t = timed(runp)
             print("planes-across-waves waves=%d cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s" % (waves, cols, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3)), flush=True)
-    if dtype == np.float32 and L_.prost_hip_fused_iteration3d_x2_supported(C.byref(d), 0) == 1:
+    if L_.prost_hip_fused_iteration3d_x2_supported(C.byref(d), 0 if dtype == np.float32 else 1) == 1:
         two = lambda v: (C.c_double * 2)(v, v)
         r4x = hip.DeviceArray.zeros(4, np.float64)
         for xres, cols in [(False, int(c)) for c in os.environ.get("X2_COLS", "0,8,16,24,32,48,64").split(",")] + [(True, 0)]:
             def runx(k):
                 for i in range(k):
                     a, b = i % 2, (i + 1) % 2
-                    hip.check(L_.prost_hip_fused_iteration3d_x2_f32(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, two(0.3), two(1.0), two(0.9), cols, r4x.ptr if xres else None, ws.ptr if xres else None, None))
+                    hip.check(hip.fn("fused_iteration3d_x2", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, two(0.3), two(1.0), two(0.9), cols, r4x.ptr if xres else None, ws.ptr if xres else None, None))
             t = timed(runx) / 2
             print("two iterations per launch%s cols=%-3d: %.4f ms/iteration, %.1f it/s, algorithmic %.0f GB/s" % (" + residual sums" if xres else "", cols, t, 1e3 / t, 14 * n * esz / 1e9 / (t * 1e-3)), flush=True)
     yp = hip.DeviceArray.from_host((rng.random(m, dtype=np.float32) - 0.5).astype(dtype)); r4 = hip.DeviceArray.zeros(4, np.float64)
@@ -99,6 +99,6 @@ if __name__ == "__main__":
     if len(sys.argv) >= 4:
         shape = tuple(int(v) for v in sys.argv[1:4])
         cl = tuple(int(c) for c in sys.argv[4].split(",")) if len(sys.argv) > 4 else (0, 6, 12, 18, 24, 36, 48)
-        main(*shape, cols_list=cl)
+        main(*shape, cols_list=cl, dtype=np.float64 if len(sys.argv) > 5 and sys.argv[5] == "f64" else np.float32)
     else:
         main()
