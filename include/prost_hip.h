@@ -348,7 +348,7 @@ int prost_hip_fused_iteration_mc_x2_f64(const prost_hip_fused_desc* desc, double
  * planes of a group run on the wavefronts of one workgroup, every wavefront runs the 4-stage column pipeline of
  * prost_hip_fused_iteration2 on its plane and the stages meet in LDS.  Reads x^k, y^k and b, writes x^(k+2), y^(k+2);
  * the intermediate iterate is stored nowhere, so callers pair only iterations whose intermediate state nobody observes.  tau/sigma/theta: HOST arrays of 2.  Bit-identical to two prost_hip_fused_iteration3d
- * launches (use_kty = use_kx_prev = 1).  fp32 (even ny) and fp64, straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0,
+ * launches (use_kty = use_kx_prev = 1).  fp32 and fp64, any height, straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0,
  * b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0): see _supported.
  * cols <= 0: automatic chunk length. */
 int prost_hip_fused_iteration3d_x2_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);

@@ -20,8 +20,8 @@
 //   ideal 5 + 4 floats per voxel = 9.66 GB) for TWO iterations, against 11.3 GB for ONE of the single-iteration kernel.
 // Every stage evaluates the expressions of kernels_fused_iter3d_pw.hip / kernels_fused3d.hip, so x^(k+2), y^(k+2) are
 // bit-identical to two single launches (tests/test_gpu_fused3d.py).  Straight-line ROF / TV-L1 shapes only (prox_g square or abs with
-// scalar a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0); fp32 with 2 rows per lane (even heights)
-// and fp64 with 1 row per lane and two halo lanes on either side.  The
+// scalar a = 1, d = e = 0, b scalar or per voxel; prox_f* ind_leq0 with scalar a = 1, d = e = 0); fp32 with 2 rows per lane (even heights); fp64
+// and fp32 at odd heights with 1 row per lane and two halo lanes on either side.  The
 // intermediate iterate is stored nowhere; the residual sums of the second iteration are available (RES).
 #include "fused_common.hpp"
 #include "reduce.hpp"
@@ -359,14 +359,14 @@ bool fused3d_desc_ok(const prost_hip_fused_desc* d);
 // rows per lane / wavefronts per workgroup of the instance that runs (see the header of this file)
 // (8 bytes of rows per lane: 2 floats or 1 double)
 constexpr int kX2Waves = 16;
-static constexpr int x2_vec(int dtype) { return dtype == 0 ? 2 : 1; }
-static constexpr size_t x2_rows_per_wave(int dtype) { return dtype == 0 ? (size_t)(kWave - 2) * 2 : (size_t)(kWave - 4); }      // owned rows: one halo lane of 2 rows / two of 1 row on either side
+// rows per lane: 2 floats where the height is even, otherwise (and for doubles) 1
+static int x2_vec(int dtype, size_t ny) { return dtype == 0 && ny % 2 == 0 ? 2 : 1; }
+static size_t x2_rows_per_wave(int vec) { return vec == 2 ? (size_t)(kWave - 2) * 2 : (size_t)(kWave - 4); }      // owned rows: one halo lane of 2 rows / two of 1 row on either side
 
-// straight-line ROF / TV-L1 shapes; fp32: even heights
+// straight-line ROF / TV-L1 shapes
 static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if ((dtype != 0 && dtype != 1) || !fused3d_desc_ok(d)) return false;
-  const size_t kX2Vec = (size_t)x2_vec(dtype);
-  if (d->ny % kX2Vec != 0 || d->ny < 4 || d->nx < 4) return false;
+  if (d->ny < 4 || d->nx < 4) return false;
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;
@@ -376,7 +376,8 @@ static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
   if (d->res_x1 != 0 && !(d->res_x0 == 0 && d->res_x1 >= d->nx)) return false;
-  const size_t strips = (d->ny + x2_rows_per_wave(dtype) - 1) / x2_rows_per_wave(dtype);
+  const size_t rows = x2_rows_per_wave(x2_vec(dtype, d->ny));
+  const size_t strips = (d->ny + rows - 1) / rows;
   // (residual launches write one partial per workgroup: with one chunk per tile the tiles alone must fit the reduction workspace)
   const size_t tiles = strips * ((d->L + kX2Waves - 4) / (kX2Waves - 3));
   return tiles <= (size_t)kReduceBlocks / 2 && tiles * d->nx < (size_t)1 << 31;
@@ -397,7 +398,8 @@ static int compute_units() {
 // workgroups, ONE round of 687 steps (64-column chunks: 11 rounds of 68 steps = 748).
 static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int cols, bool res) {
   constexpr int P = kX2Waves - 3;
-  const size_t tiles = ((d->ny + x2_rows_per_wave(dtype) - 1) / x2_rows_per_wave(dtype)) * ((d->L + P - 1) / P);
+  const size_t rows = x2_rows_per_wave(x2_vec(dtype, d->ny));
+  const size_t tiles = ((d->ny + rows - 1) / rows) * ((d->L + P - 1) / P);
   const size_t max_groups = res ? (size_t)kReduceBlocks / 2 : (size_t)1 << 31;     // residual launches: one partial (4 doubles) per workgroup
   if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
   const size_t cus = (size_t)compute_units();
@@ -418,7 +420,7 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
   constexpr int P = WT - 3;
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t groups = (d->L + P - 1) / P;
-  const size_t strips = (d->ny + x2_rows_per_wave(V == 2 ? 0 : 1) - 1) / x2_rows_per_wave(V == 2 ? 0 : 1);
+  const size_t strips = (d->ny + x2_rows_per_wave(V) - 1) / x2_rows_per_wave(V);
   const size_t c = x2_chunk_cols(d, std::is_same<T, float>::value ? 0 : 1, cols, out4 != nullptr);
   a.cols_per_block = (int)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
@@ -453,7 +455,10 @@ static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, cons
     if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused 3-D double iteration: not the straight-line ROF shape"); return 1; }
     p[i].sq = ug.sq; p[i].step = ug.step;
   }
-  return launch_iter3d_x2<T, x2_vec(kDtype), kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
+  if constexpr (std::is_same<T, float>::value) {
+    if (x2_vec(kDtype, d->ny) == 2) return launch_iter3d_x2<T, 2, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
+  }
+  return launch_iter3d_x2<T, 1, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
 }
 
 }  // namespace prost_hip
