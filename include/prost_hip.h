@@ -331,7 +331,8 @@ int prost_hip_fused_iteration3d_pw_f64(const prost_hip_fused_desc* desc, double*
  * 2 L components of a pixel.  Reads x^k, y^k and b, writes x^(k+2), y^(k+2); the intermediate iterate is stored nowhere.
  * tau/sigma/theta: HOST arrays of 2.  Bit-identical to two prost_hip_fused_iteration_mc launches (resp. two
  * prost_hip_fused_iteration launches for L = 2).  Straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar
- * a = 1, d = e = 0, b scalar or per pixel; prox_f* ind_leq0 with scalar a = 1, d = e = 0); ny % 4 == 0 (fp32) / ny % 2 == 0 (fp64). */
+ * a = 1, d = e = 0, b scalar or per pixel; prox_f* ind_leq0 with scalar a = 1, d = e = 0); any height (16 bytes of rows per lane
+ * where it is a multiple of that, else one row). */
 int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
 /* 1 iff the launch is also faster than two single launches (tiny images: one launch instead of two; large ones: half the HBM
  * traffic; in between -- about 384^2 to 700^2 RGB -- the single-iteration kernel is up to 9 % faster) */

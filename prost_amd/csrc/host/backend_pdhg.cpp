@@ -119,9 +119,11 @@ void BackendPDHG<T>::Initialize() {
   // 0.086 ms in single launches; from 4 planes on the pairs win, 0.127 against 0.206 ms)
   pair3d_ = fused_ && desc_.is3d && desc_.L >= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, dtype_id<T>()) == 1;
   // 2-4 channels: the channels on the wavefronts of a workgroup, two iterations per launch
-  pair_mc_ = (single_mc_ || (single_kernel_ && desc_.L == 2)) && opts_.allow_pair_kernel && prost_hip_fused_iteration_mc_x2_profitable(&desc_, dtype_id<T>()) == 1;
+  // (also at heights the single-iteration kernels do not take: the other iterations then run the two passes)
+  pair_mc_ = fused_ && !desc_.is3d && desc_.L >= 2 && desc_.L <= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel &&
+             prost_hip_fused_iteration_mc_x2_profitable(&desc_, dtype_id<T>()) == 1;
   if (pair_kernel_ || pair3d_ || pair_mc_) x_spare_.resize(n);
-  if (single_kernel_ || single3d_ || single_mc_ || pair3d_) y_spare_.resize(m);
+  if (single_kernel_ || single3d_ || single_mc_ || pair3d_ || pair_mc_) y_spare_.resize(m);
 
   CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
   CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
@@ -318,7 +320,7 @@ void BackendPDHG<T>::RebuildPrevious() {
   else if (pair3d_ && single3d_)
     CheckHip(Api<T>::fused_iteration3d(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
                                        (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration3d");
-  else if (pair3d_) {        // heights the one-kernel iteration does not take (ny % 4 != 0): the two passes
+  else if (pair3d_ || (pair_mc_ && !single_kernel_)) {        // heights the one-kernel iterations do not take: the two passes
     CheckHip(Api<T>::fused_primal(&desc_, x_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_, 1, 0, nullptr, workspace_,
                                   CurrentStream()), "fused_primal");
     CheckHip(Api<T>::fused_dual(&desc_, y_spare_.data(), y_prev_.data(), x_spare_.data(), x_prev_.data(), (double)stale_sigma_, (double)stale_theta_, 1,
@@ -601,7 +603,7 @@ bool BackendPDHG<T>::current_solution_device(const T*& primal_x, const T*& prima
 template <typename T>
 size_t BackendPDHG<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
-  if (fused_) return (2 * (n + m) + (single_kernel_ || single3d_ || single_mc_ || pair3d_ ? m : 0) + (pair_kernel_ || pair3d_ || pair_mc_ ? n : 0)) * sizeof(T);
+  if (fused_) return (2 * (n + m) + (single_kernel_ || single3d_ || single_mc_ || pair3d_ || pair_mc_ ? m : 0) + (pair_kernel_ || pair3d_ || pair_mc_ ? n : 0)) * sizeof(T);
   return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511
 }
 

@@ -14,7 +14,7 @@
 // Per channel: 7 floats per pixel per TWO iterations (y1, y2, x, b read; x, y1, y2 written) against 2 x 7 for the
 // single-iteration kernel.  x^(k+2), y^(k+2) are bit-identical to two single launches (tests/test_gpu_kernels.py).
 // Straight-line ROF / TV-L1 shapes (prox_g square or abs with scalar a = 1, d = e = 0, b scalar or per pixel; prox_f*
-// ind_leq0 with scalar a = 1, d = e = 0), fp32 (4 rows per lane) and fp64 (2 rows per lane), heights that are a multiple of that; the intermediate iterate is stored nowhere,
+// ind_leq0 with scalar a = 1, d = e = 0), fp32 (4 rows per lane) and fp64 (2 rows per lane), 1 row per lane at other heights; the intermediate iterate is stored nowhere,
 // the residual sums of the second iteration are available (RES): BackendPDHG pairs iterations k, k+1 unless k or k+2 is a
 // residual iteration.
 #include "fused_common.hpp"
@@ -51,7 +51,10 @@ template <class T, int VEC, int GFN, bool GB, int LW, bool RES>
 __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                                 const T* __restrict__ y, FusedArgs<T> a, IterParamsMc<T> p1,
                                                                                 IterParamsMc<T> p2, double* __restrict__ partial) {
-  constexpr int kRowsPerWave = (kWave - 2) * VEC;
+  // two iterations need two valid rows beyond the owned ones on either side: one halo lane of >= 2 rows, or two halo lanes of one row
+  // (heights that are not a multiple of 16 bytes of rows: 1 row per lane)
+  constexpr int kHalo = VEC >= 2 ? 1 : 2;
+  constexpr int kRowsPerWave = (kWave - 2 * kHalo) * VEC;
   constexpr int kPix = kWave * VEC;
   __shared__ T s_sq[2][2][2 * LW][kPix];               // [buffer][stage B / D][component][pixel]
   __shared__ T s_kt[RES ? 3 : 1][RES ? LW : 1][RES ? kPix : 1];
@@ -63,9 +66,9 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // XCD-aware tile order, see kernels_fused_iter.hip
   const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
   const unsigned strip = tile / chunks, chunk = tile % chunks;
-  const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
+  const long row0 = (long)strip * kRowsPerWave + ((long)lane - kHalo) * VEC;
   const bool active = row0 >= 0 && row0 < ny;
-  const bool owner = active && lane > 0 && lane < kWave - 1;
+  const bool owner = active && lane >= kHalo && lane < kWave - kHalo;
   const long xa = (long)chunk * a.cols_per_block;
   const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t P = (size_t)nx * (size_t)ny, N = P * LW, plane = (size_t)ch * P;
@@ -286,10 +289,13 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   }
 }
 
+// rows per lane: 16 bytes where the height allows, otherwise 1; owned rows of a wavefront (one halo lane of >= 2 rows or two of 1 row on either side)
+static int mc_x2_vec(int dtype, size_t ny) { const int full = dtype == 0 ? 4 : 2; return ny % (size_t)full == 0 ? full : 1; }
+static size_t mc_x2_rows(int dtype, size_t ny) { const int v = mc_x2_vec(dtype, ny); return v >= 2 ? (size_t)(kWave - 2) * v : (size_t)(kWave - 4); }
+
 static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if ((dtype != 0 && dtype != 1) || !d || d->is3d || d->L < 2 || d->L > 4) return false;
-  const size_t V = dtype == 0 ? 4 : 2;                 // rows per lane: 16 bytes
-  if (d->nx < 4 || d->ny < 4 || d->ny % V != 0) return false;
+  if (d->nx < 4 || d->ny < 4) return false;
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;
@@ -300,7 +306,7 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
   // (res_x0 / res_x1 -- the owned columns of a sharded slab -- only restrict residual sums, which this kernel does not form)
   if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4.0 : 8.0) >= 4294967296.0) return false;              // 32-bit byte offsets per plane
-  const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
+  const size_t strips = (d->ny + mc_x2_rows(dtype, d->ny) - 1) / mc_x2_rows(dtype, d->ny);
   if (strips > (size_t)kReduceBlocks / 2) return false;              // residual launches: one partial per workgroup, at best one chunk per strip
   return strips * d->nx < (size_t)1 << 31;
 }
@@ -311,8 +317,7 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
 // the number of steps counts (512^2 RGB: 2 columns = 5 steps per two iterations)
 static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int cols, bool res) {
   if (cols > 0) return (size_t)cols < d->nx ? (size_t)cols : d->nx;
-  const size_t V = dtype == 0 ? 4 : 2;
-  const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
+  const size_t strips = (d->ny + mc_x2_rows(dtype, d->ny) - 1) / mc_x2_rows(dtype, d->ny);
   const size_t slots = 256 * 4 * 3;
   size_t best_c = 1, best_cost = (size_t)-1;
   // (capped at 24 columns: beyond the point where every slot is taken, MORE and shorter workgroups hide the per-column barrier
@@ -334,7 +339,6 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
   if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused multi-channel double iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_out == x || y_out == y) { set_error("fused multi-channel double iteration: outputs must not alias inputs"); return 1; }
   if (out4 && !ws) { set_error("fused multi-channel double iteration: residuals need the reduction workspace"); return 1; }
-  constexpr int V = VecOf<T>::N;
   FusedArgs<T> a = make_fused_args<T>(d);
   IterParamsMc<T> p[2];
   for (int i = 0; i < 2; i++) {
@@ -344,7 +348,8 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
     if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused multi-channel double iteration: not the straight-line ROF / TV-L1 shape"); return 1; }
     p[i].sq = ug.sq; p[i].step = ug.step;
   }
-  const size_t strips = (d->ny + (size_t)(kWave - 2) * V - 1) / ((size_t)(kWave - 2) * V);
+  const size_t rows = mc_x2_rows(kDtype, d->ny);
+  const size_t strips = (d->ny + rows - 1) / rows;
   const size_t c = mc_x2_chunk_cols(d, kDtype, cols, out4 != nullptr);
   a.cols_per_block = (int)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
@@ -352,7 +357,9 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
   hipStream_t s = as_stream(stream);
   if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused multi-channel double iteration: grid exceeds the reduction workspace"); return 1; }
   double* partial = static_cast<double*>(ws);
-#define GO4(G, B, LWv, R) hipLaunchKernelGGL((fused_iter2d_mc_x2_kernel<T, V, G, B, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+  const bool full = mc_x2_vec(kDtype, d->ny) > 1;
+#define GO5(VV, G, B, LWv, R) hipLaunchKernelGGL((fused_iter2d_mc_x2_kernel<T, VV, G, B, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+#define GO4(G, B, LWv, R) do { if (full) GO5(VecOf<T>::N, G, B, LWv, R); else GO5(1, G, B, LWv, R); } while (0)
 #define GO3(G, B, LWv) do { if (out4) GO4(G, B, LWv, true); else GO4(G, B, LWv, false); } while (0)
 #define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)
 #define GO(B) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B); else GO2(PROST_FN_SQUARE, B); } while (0)
@@ -361,6 +368,7 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
 #undef GO2
 #undef GO3
 #undef GO4
+#undef GO5
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel double iteration kernel"); }
   if (out4) return launch_fold4(out4, partial, grid, s);
   return 0;

@@ -598,7 +598,7 @@ def test_multichannel_pair_schedule_is_invisible(prec, dtype, step, L, residual_
     launches every iteration separately, and the iterates equal the oracle's."""
     prost.set_precision(prec)
     o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
-    for (nx, ny) in ((12, 16), (9, 252), (40, 500)):
+    for (nx, ny) in ((12, 16), (9, 252), (40, 500), (10, 67)):
         prob, u, q, f = synthetic.rof_problem(nx, ny, L, seed=3, data_term=data_term, lmb=10.0 if data_term == "square" else 0.7)
         for iters in (2, 3, 4, 5, 9, 10, 11, 23):
             states = []
