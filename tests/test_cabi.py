@@ -238,3 +238,40 @@ def test_constant_preconditioners_of_a_single_stencil_block_match_the_oracle_swe
                 assert np.unique(sl).size == 1 and np.unique(sr).size == 1
     finally:
         prost.set_precision("double")
+
+
+def test_support_predicates_and_launch_geometry_of_the_double_iteration_kernels():
+    """Host-only entry points of the kernel library (no launch): which problem shapes the two-iterations-per-launch kernels take,
+    and the column-chunk lengths their launchers pick -- rounds of workgroups x column steps minimal (3-D: 2048 x 2048 x 64 ->
+    17 strips x 5 plane groups x 3 chunks = 255 workgroups on 256 compute units, 683 columns each), 24 columns at most for the
+    multi-channel kernel, one partial per workgroup within the reduction workspace for the residual variants."""
+    from prost_amd import _hip as hip
+    L = hip.lib()
+
+    def desc(is3d, nx, ny, nl, g_fn="square", f_fn="ind_leq0"):
+        d = hip.FusedDesc(); d.is3d = is3d; d.nx, d.ny, d.L = nx, ny, nl
+        d.g_fn = hip.FN_ID[g_fn]; d.f_fn = hip.FN_ID[f_fn]
+        for i, (g, f) in enumerate(zip([1, 0.3, 10, 0, 0, 0, 0], [1, 1, 1, 0, 0, 0, 0])):
+            d.g_coeff_val[i] = g; d.f_coeff_val[i] = f
+        d.T_val, d.S_val = (1 / 6.0, 0.5) if is3d else (0.25, 0.5)
+        return d
+
+    c3 = desc(1, 2048, 2048, 64)
+    for dt in (0, 1):
+        assert L.prost_hip_fused_iteration3d_x2_supported(C.byref(c3), dt) == 1
+        assert L.prost_hip_fused_iteration3d_x2_supported(C.byref(desc(1, 64, 63, 8)), dt) == 1          # any height
+        assert L.prost_hip_fused_iteration3d_x2_supported(C.byref(desc(1, 64, 64, 8, g_fn="huber")), dt) == 0
+        assert L.prost_hip_fused_iteration3d_x2_supported(C.byref(desc(0, 64, 64, 3)), dt) == 0          # not gradient3d
+        assert L.prost_hip_fused_iteration_mc_x2_supported(C.byref(desc(0, 64, 63, 3)), dt) == 1
+        assert L.prost_hip_fused_iteration_mc_x2_supported(C.byref(desc(0, 64, 64, 1)), dt) == 0          # gray: prost_hip_fused_iteration2
+        assert L.prost_hip_fused_iteration_mc_x2_supported(C.byref(desc(0, 64, 64, 5)), dt) == 0
+        assert L.prost_hip_fused_iteration_mc_x2_supported(C.byref(desc(0, 64, 64, 3, f_fn="huber")), dt) == 0
+    # without a device the launcher assumes the 256 compute units of an MI355X
+    assert L.prost_hip_fused_iteration3d_x2_chunk_cols(C.byref(c3), 0, 0) == 683
+    assert L.prost_hip_fused_iteration3d_x2_chunk_cols(C.byref(c3), 0, 1) == 683
+    assert L.prost_hip_fused_iteration3d_x2_chunk_cols(C.byref(desc(1, 64, 64, 8, g_fn="huber")), 0, 0) == 0
+    assert 20 <= L.prost_hip_fused_iteration_mc_x2_chunk_cols(C.byref(desc(0, 4096, 4096, 3)), 0, 0) <= 24
+    assert L.prost_hip_fused_iteration_mc_x2_chunk_cols(C.byref(desc(0, 512, 512, 3)), 0, 0) == 2
+    assert 1 <= L.prost_hip_fused_iteration_mc_x2_chunk_cols(C.byref(desc(0, 700, 464, 3)), 0, 1) <= 24
+    # profitable: tiny (launch-bound) and large (throughput-bound) images, not the latency-bound middle
+    assert [L.prost_hip_fused_iteration_mc_x2_profitable(C.byref(desc(0, n, n, 3)), 0) for n in (256, 512, 1024, 4096)] == [1, 0, 1, 1]
