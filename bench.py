@@ -8,6 +8,7 @@ pdhg(stepsize='alg2', residual_iter=10, alg2_gamma=0.5), tolerances 0 (never sto
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...      (no launcher: starts the N ranks itself as a child torch.distributed.run job)
 
 N > 1: BASELINE config 5 -- N independent 4096^2 problems (seeds 42..42+N-1), one per GPU, weak
 scaling; the 4 residual sums are all-reduced over RCCL every residual iteration so every rank sees
@@ -151,6 +152,37 @@ def reference_build_rate(backend, opts, n_ref=1024):
         return {"error": str(e)}
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run job (this process has
+    not touched the GPU and never does), pass the child's rank-0 JSON line through and exit with the child's code.  A process
+    that has initialised the GPU is never re-executed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    other = [l for l in p.stdout.splitlines() if not l.startswith("{")]
+    if other:
+        sys.stderr.write("\n".join(other) + "\n")
+    if p.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank child job failed (exit code %d)\n" % (n_ranks, p.returncode))
+        raise SystemExit(p.returncode or 1)
+    d = json.loads(lines[-1])
+    if d.get("n_gpus") != n_ranks:
+        sys.stderr.write("bench.py: asked for %d ranks, the job reports n_gpus = %r\n" % (n_ranks, d.get("n_gpus")))
+        raise SystemExit(1)
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,9 +198,16 @@ def main():
     ap.add_argument("--no-pair", action="store_true", help="one kernel launch per iteration (allow_pair_kernel = false); not the default configuration")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)          # does not return
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE = %d ranks: n_gpus would not be what was asked for" % (args.gpus, world))
     # PROST_BENCH_FORCE_DIST=1 runs the multi-rank code path (torch.distributed + the native RCCL communicator +
     # residual all-reduce) even with one rank: the only way to exercise it on a 1-GPU box
     multi = world > 1 or os.environ.get("PROST_BENCH_FORCE_DIST", "0") == "1"
@@ -188,6 +227,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the prost hot path has no CPU fallback")
     if host_transport:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d, this node has %d (one rank per GPU; PROST_BENCH_TRANSPORT=host puts every "
+                         "rank on GPU 0 for tests)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if multi:
@@ -211,6 +253,9 @@ def main():
             ident.copy_(torch.from_numpy(prost.comm_unique_id()))
         dist.broadcast(ident, src=0)
         prost.comm_init(ident.cpu().numpy(), rank, world)
+    comm_info = prost.comm_info() if multi else {"nranks": 0, "transport": "none"}
+    if multi and int(comm_info["nranks"]) != world:
+        raise SystemExit("bench.py: the communicator counts %d ranks, WORLD_SIZE is %d" % (int(comm_info["nranks"]), world))
 
     n = args.size
     prob, u, q, f = synthetic.rof_problem(n, n, lmb=LAMBDA, seed=42 + rank)
@@ -284,7 +329,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), "
                                    "PDHG alg2, residual_iter=10, lambda=10; one independent problem per GPU" % (n, n),
-                       "path": path, "problems": world, "residual_allreduce": "host-callback (gloo)" if host_transport else "rccl" if multi else "none",
+                       "path": path, "problems": world, "rccl_nranks": int(comm_info["nranks"]) if comm_info["transport"] == "rccl" else None,
+                       "comm_nranks": int(comm_info["nranks"]), "residual_allreduce": "host-callback (gloo)" if host_transport else "rccl" if multi else "none",
                        "timed_loop": "Solver::IterateChecked = the loop of prost.solve (stopping test after every observable iteration; "
                                      "tolerances 0, so it never fires)"},
             "iterate_only_it_per_s": world * args.steps / elapsed_iterate,

@@ -133,6 +133,7 @@ class BackendPDHG : public Backend<T> {
   bool BeginSample(int kind);
   void EndSample(bool sampled);
   static constexpr size_t kNoEvent = ~(size_t)0;
+  static constexpr size_t kMaxSamples = 16384;
   struct Sample { int kind; size_t start, end; };   // indices into ev_
   size_t NewEvent();               // records the next event of the pool on the solver's stream
   std::vector<void*> ev_;          // event pool

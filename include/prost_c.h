@@ -69,6 +69,8 @@ const char* prost_value_str(const prost_value* v);
 size_t prost_value_count(const prost_value* v);                                      /* cells */
 const prost_value* prost_value_cell_get(const prost_value* v, size_t i);
 const prost_value* prost_value_field(const prost_value* v, const char* name);        /* NULL if absent */
+size_t prost_value_field_count(const prost_value* v);                                /* struct fields, in insertion order  */
+const char* prost_value_field_name(const prost_value* v, size_t i);                  /* NULL if i >= field_count           */
 
 /* ---- the gateway ---- */
 /* Returns 0 on success.  plhs[0..nlhs) receive newly created values the caller must free.
@@ -76,6 +78,12 @@ const prost_value* prost_value_field(const prost_value* v, const char* name);   
  * passed to mexErrMsgTxt (prost.cpp:342-346). */
 int prost_command(const char* cmd, int nlhs, prost_value** plhs, int nrhs, const prost_value* const* prhs);
 const char* prost_last_error(void);
+/* Text the library prints (std::cout: the verbose header and the "It k: Feas_p=..." lines of solve_problem, list_gpus, the
+ * |K| rescale note) goes to `fn(user, text, n)` -- n bytes, not NUL-terminated -- instead of the process's stdout: the
+ * mexstream / scoped_redirect_cout of the MEX gateway (prost.cpp:15-44), which hands it to mexPrintf.  fn = NULL restores
+ * stdout. */
+typedef void (*prost_output_cb)(void* user, const char* text, size_t n);
+void prost_set_output_callback(prost_output_cb fn, void* user);
 /* user-interrupt hook of solve_problem (the Ctrl-C poll of the MEX gateway), asked once per kernel launch -- after every
  * iteration or every second one where two iterations share a launch, so a stop request is honoured at most one iteration
  * later than by the reference (solver.cu:151 polls after each).  fn = NULL removes it. */
@@ -86,6 +94,12 @@ void prost_set_stop_callback(prost_stop_cb fn, void* user);
  * (prost_last_error); undone by the comm_destroy command. */
 typedef void (*prost_allreduce_cb)(void* user, double* values, size_t count);
 int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size);
+/* Point-to-point function of that communicator (halo columns of column-sharded images between the ranks:
+ * solver_halo_exchange / solver_iterate_sharded): `fn(user, nops, is_send, peers, bufs, bytes)` performs all the transfers
+ * of one exchange on pinned host buffers and returns when they are complete (prost_hip_comm_host_configure).  Call after
+ * prost_comm_init_host. */
+typedef void (*prost_p2p_cb)(void* user, int nops, const int* is_send, const int* peers, void* const* bufs, const size_t* bytes);
+int prost_comm_set_host_p2p(prost_p2p_cb fn, void* user);
 
 /*
  * Command reference (arguments in prhs order, results in plhs order):
@@ -129,6 +143,11 @@ int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world_size);
  *       consecutive entries of that device vector from every offset (partial read-back; pdhg only)
  *   solver_destroy(handle)
  *   comm_unique_id -> 1x128 matrix of byte values;  comm_init(id, rank, world);  comm_destroy
+ *   comm_info -> struct {nranks, transport}: ranks as the communicator counts them (ncclCommCount), 'rccl' | 'host' | 'none'
+ *   load_plugin(path): dlopen a shared library of user-defined prost::Block / Prox / Backend subclasses that register
+ *       themselves in Factory<T>::block_reg() / prox_reg() / backend_reg() from static initialisers (custom.cpp:11-28;
+ *       the reference compiles such sources into the MEX file, cmake/CustomSources.cmake.example:1-26)
+ *   registered -> struct {prox, block, backend}: cells of the registered names
  *   set_quirks(struct {diags_adjoint_grid, dual_negate_float})
  */
 

@@ -26,8 +26,12 @@ extern "C" {
 
 /* 2: prost_hip_fused_desc gained res_x0 / res_x1; fused_iteration2, comm send/recv, wrapper proxes, Kronecker blocks
  * 3: additions only -- device-resident CGLS / ADMM stages, prox_elem_arg, csr_spmv (non-accumulating), fused_iteration3d,
- *    fused_iteration3d_pw, fused_iteration3d_x2, fused_iteration_mc, fused_iteration_mc_x2, normest_grad_round, stream_wait_event, graph capture */
-#define PROST_HIP_ABI_VERSION 3
+ *    fused_iteration3d_pw, fused_iteration3d_x2, fused_iteration_mc, fused_iteration_mc_x2, normest_grad_round, stream_wait_event, graph capture
+ * 4: prost_hip_selftest_math writes EIGHT counters (it wrote five up to an early v3 header: a caller built against that
+ *    header passes a too short buffer -- check prost_hip_abi_version() >= 4 before relying on the 8-slot layout);
+ *    additions: comm_count, comm_is_host, comm_host_configure (point-to-point on the host-callback transport),
+ *    fused operator entry points of the ADMM graph projection */
+#define PROST_HIP_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
@@ -560,10 +564,24 @@ int prost_hip_comm_destroy(void* comm);
  * logic on a single-GPU box.  The reference has no multi-process path at all (prost.cpp:299-303: set_gpu). */
 typedef void (*prost_hip_host_allreduce_fn)(void* user, double* values, size_t count);
 int prost_hip_comm_create_host(void** comm, prost_hip_host_allreduce_fn fn, void* user);
+/* Point-to-point on the host-callback transport: `p2p(user, nops, is_send, peers, bufs, bytes)` performs ALL transfers of one
+ * group -- operation i sends (is_send[i] != 0) or receives bytes[i] bytes of pinned host memory bufs[i] to / from rank
+ * peers[i] -- and returns when every one of them is complete (e.g. gloo isend / irecv + wait).  prost_hip_comm_send / recv
+ * on such a communicator collect the operations of a group; group_end (or the call itself outside a group) enqueues the D2H
+ * copies of what is sent, the function (hipLaunchHostFunc: runtime thread, no HIP calls) and the H2D copies of what is
+ * received on the stream -- the enqueue-and-return contract of an RCCL group.  One communicator and one stream per group;
+ * consecutive groups of a communicator must be ordered by their stream (they share a staging area).  world_size is what
+ * prost_hip_comm_count reports for the communicator.  p2p may be NULL (all-reduce only). */
+typedef void (*prost_hip_host_p2p_fn)(void* user, int nops, const int* is_send, const int* peers, void* const* bufs, const size_t* bytes);
+int prost_hip_comm_host_configure(void* comm, int world_size, prost_hip_host_p2p_fn p2p, void* p2p_user);
+/* number of ranks of the communicator (ncclCommCount; the configured world size of a host-callback communicator) */
+int prost_hip_comm_count(void* comm, int* nranks);
+/* 1 for a host-callback communicator, 0 for RCCL */
+int prost_hip_comm_is_host(void* comm);
 /* in-place sum all-reduce of `count` DEVICE doubles (the 4 residual sums) on `stream` */
 int prost_hip_allreduce_sum_f64(void* comm, double* buf, size_t count, void* stream);
 /* point-to-point transfers of `bytes` bytes of device memory with rank `peer` of the communicator (RCCL
- * ncclSend / ncclRecv over xGMI).  Issue the sends and receives of one exchange step between group_start
+ * ncclSend / ncclRecv over xGMI; the p2p function of a host-callback communicator).  Issue the sends and receives of one exchange step between group_start
  * and group_end: they then complete as ONE group, so both neighbours can be served without deadlock.
  * Used for the halo columns of column-sharded images. */
 int prost_hip_comm_group_start(void);

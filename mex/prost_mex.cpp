@@ -10,6 +10,10 @@
 //                                           (the intermediate-solution callback, factory.cpp:136-158)
 //     back()      prost_value -> mxArray  : matrices, strings, cells and the {x, y, z, w, result} struct of prost.cpp:138-152
 //     stop_cb()   Ctrl-C polling          : prost.cpp:58-66
+//     print_cb()  library output          : what libprost.so prints (verbose header, "It k: Feas_p=..." lines, list_gpus) arrives
+//                                           through prost_set_output_callback and goes to mexPrintf, with the pause(.001) after
+//                                           a newline that lets MATLAB flush its command window (prost.cpp:15-44 mexstream /
+//                                           scoped_redirect_cout); installed for the duration of one mexFunction call
 // Errors: prost_command returns non-zero, the message goes to mexErrMsgTxt (prost.cpp:342-346).
 //
 // Build (replaces matlab/CMakeLists.txt:46-57):  mex mex/prost_mex.cpp -Iinclude -Lprost_amd/lib -lprost -output prost_
@@ -39,6 +43,18 @@ int stop_cb(void*) {                                         // prost.cpp:58-66 
   }
   return 0;
 }
+
+// prost.cpp:15-33 mexstream: text to the MATLAB command window; after a newline MATLAB gets the chance to flush it
+void print_cb(void*, const char* text, size_t n) {
+  if (n == 0) return;
+  mexPrintf("%.*s", static_cast<int>(n), text);
+  if (text[n - 1] == '\n') mexEvalString("pause(.001);");
+}
+
+struct ScopedOutputRedirect {            // prost.cpp:35-44 scoped_redirect_cout
+  ScopedOutputRedirect() { prost_set_output_callback(print_cb, nullptr); }
+  ~ScopedOutputRedirect() { prost_set_output_callback(nullptr, nullptr); }
+};
 
 // factory.cpp:136-158 SolverIntermCallback: feval(handle, iter, primal, dual) -> is_converged
 int interm_cb(void* user, int iteration, const double* x, size_t nx, const double* y, size_t ny) {
@@ -114,14 +130,9 @@ prost_value* convert(const mxArray* a) {
   return nullptr;
 }
 
-// Results.  solve_problem returns the struct of prost.cpp:138-152 ({x, y, z, w, result}; this library adds iters and
-// path): the names are fixed by the command, a prost_value struct is read field by field through prost_value_field.
-const char* const kResultFields[] = {"x", "y", "z", "w", "result", "iters", "path",
-                                     // solver_state / solver_iterate / problem_info (persistent-solver commands of prost_c.h)
-                                     "tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm",
-                                     "eps_primal", "eps_dual", "cg_iterations", "ms", "converged", "kernels", "scaling_left", "scaling_right",
-                                     "nrows", "ncols", "linop_nrows", "linop_ncols", "prox_g", "prox_f", "prox_gstar", "prox_fstar"};
-
+// Results.  solve_problem returns the struct of prost.cpp:138-152 ({x, y, z, w, result}; this library adds iters, path,
+// pair_launches); every struct a command returns is copied field by field, whatever the command put into it
+// (prost_value_field_count / prost_value_field_name).
 mxArray* back(const prost_value* v) {
   switch (prost_value_kind(v)) {
     case PROST_VALUE_MATRIX: {
@@ -141,7 +152,7 @@ mxArray* back(const prost_value* v) {
     }
     case PROST_VALUE_STRUCT: {
       std::vector<const char*> names;
-      for (const char* f : kResultFields) if (prost_value_field(v, f)) names.push_back(f);
+      for (size_t i = 0; i < prost_value_field_count(v); i++) names.push_back(prost_value_field_name(v, i));
       mxArray* s = mxCreateStructMatrix(1, 1, static_cast<int>(names.size()), names.data());
       for (size_t i = 0; i < names.size(); i++) mxSetFieldByNumber(s, 0, static_cast<int>(i), back(prost_value_field(v, names[i])));
       return s;
@@ -168,6 +179,7 @@ void mexFunction(int nlhs, mxArray** plhs, int nrhs, const mxArray** prhs) {
   const int nout = std::max(nlhs, 1);
   {
     ValueList in, out;
+    ScopedOutputRedirect redirect;                            // the library's std::cout -> mexPrintf while the command runs
     for (int i = 1; i < nrhs; i++) in.v.push_back(convert(prhs[i]));
     out.v.assign(static_cast<size_t>(nout), nullptr);
     prost_set_stop_callback(stop_cb, nullptr);

@@ -20,7 +20,7 @@ def __getattr__(name):
     # without the shared libraries (e.g. when only building problem descriptions)
     if name in ("solve", "eval_linop", "eval_prox", "init", "release", "set_gpu", "list_gpus",
                 "set_precision", "get_precision", "problem_info", "Solver", "set_quirks", "comm_unique_id",
-                "comm_init", "comm_init_host", "comm_destroy", "set_stop_callback", "ProstError"):
+                "comm_init", "comm_init_host", "comm_destroy", "comm_info", "gloo_p2p", "load_plugin", "registered", "set_stop_callback", "set_output_callback", "ProstError"):
         from . import _capi
         return getattr(_capi, name)
     raise AttributeError(name)

@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libprost.so")
 INTERM_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.c_size_t)
 STOP_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
+OUTPUT_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_char), C.c_size_t)
+P2P_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 
 (VALUE_EMPTY, VALUE_MATRIX, VALUE_STRING, VALUE_CELL, VALUE_STRUCT, VALUE_SPARSE, VALUE_CALLBACK) = range(7)
 
@@ -72,7 +74,14 @@ def lib():
         L.prost_last_error.restype = C.c_char_p
         L.prost_set_stop_callback.argtypes = [STOP_CB, vp]
         L.prost_set_stop_callback.restype = None
+        L.prost_value_field_count.argtypes = [vp]
+        L.prost_value_field_count.restype = C.c_size_t
+        L.prost_value_field_name.argtypes = [vp, C.c_size_t]
+        L.prost_value_field_name.restype = C.c_char_p
+        L.prost_set_output_callback.argtypes = [OUTPUT_CB, vp]
+        L.prost_set_output_callback.restype = None
         L.prost_comm_init_host.argtypes = [ALLREDUCE_CB, vp, C.c_int]
+        L.prost_comm_set_host_p2p.argtypes = [P2P_CB, vp]
         _lib = L
     return _lib
 
@@ -177,7 +186,8 @@ def from_value(v, owner=None):
     if kind == VALUE_CELL:
         return [from_value(L.prost_value_cell_get(v, i), owner) for i in range(L.prost_value_count(v))]
     if kind == VALUE_STRUCT:
-        raise ProstError("struct results are read field by field (see _struct_fields)")
+        names = [L.prost_value_field_name(v, i).decode() for i in range(L.prost_value_field_count(v))]
+        return _struct_fields(v, names, owner)
     return None
 
 
@@ -209,9 +219,9 @@ def command(cmd, args=(), nlhs=0, struct_fields=None):
                 continue
             owner = _ValueOwner(plhs[i])
             try:
-                if L.prost_value_kind(plhs[i]) == VALUE_STRUCT:
-                    out.append(_struct_fields(plhs[i], struct_fields or (), owner))
-                else:
+                if L.prost_value_kind(plhs[i]) == VALUE_STRUCT and struct_fields is not None:
+                    out.append(_struct_fields(plhs[i], struct_fields, owner))
+                else:                         # structs: every field, enumerated through prost_value_field_name
                     out.append(from_value(plhs[i], owner))
             finally:
                 if owner.used:
@@ -299,6 +309,16 @@ def problem_info(prob):
     return command("problem_info", [prob.data, prob.nrows, prob.ncols], nlhs=1,
                    struct_fields=("scaling_left", "scaling_right", "nrows", "ncols", "linop_nrows", "linop_ncols",
                                   "prox_g", "prox_f", "prox_gstar", "prox_fstar"))[0]
+
+
+def load_plugin(path):
+    """loads a shared library of user-defined blocks / proxes / backends (custom.cpp:11-28); they register themselves"""
+    command("load_plugin", [os.path.abspath(path)])
+
+
+def registered():
+    """{'prox': [...], 'block': [...], 'backend': [...]}: the names in the factory registries"""
+    return command("registered", nlhs=1)[0]
 
 
 def set_quirks(**kw):
@@ -392,16 +412,44 @@ def comm_init(unique_id, rank, world):
 _host_allreduce_keep = []
 
 
-def comm_init_host(allreduce, world):
+def comm_init_host(allreduce, world, p2p=None):
     """Communicator with a host-side all-reduce: `allreduce(a)` sums the float64 numpy array `a` (a view of pinned host
     memory) over the ranks IN PLACE, e.g. `dist.all_reduce(torch.from_numpy(a))` on a gloo group.  It is called from a
-    runtime thread, in stream order, wherever an RCCL all-reduce would run.  For several ranks on one GPU."""
+    runtime thread, in stream order, wherever an RCCL all-reduce would run.  For several ranks on one GPU.
+
+    p2p (optional): `p2p(ops)` with ops = [(is_send, peer, uint8 array view of pinned host memory), ...] performs ALL
+    transfers of one halo exchange and returns when they are complete (gloo: isend / irecv on every entry, then wait) --
+    what ncclSend / ncclRecv inside one group do on the RCCL transport (solver_halo_exchange, solver_iterate_sharded)."""
     def _cb(user, ptr, count, fn=allreduce):
         fn(np.ctypeslib.as_array(ptr, (count,)))
     cb = ALLREDUCE_CB(_cb)
     _host_allreduce_keep.append(cb)
     if lib().prost_comm_init_host(cb, None, int(world)) != 0:
         raise ProstError(lib().prost_last_error().decode())
+    if p2p is not None:
+        def _p2p(user, nops, is_send, peers, bufs, nbytes, fn=p2p):
+            fn([(bool(is_send[i]), int(peers[i]), np.ctypeslib.as_array(C.cast(bufs[i], C.POINTER(C.c_uint8)), (nbytes[i],)))
+                for i in range(nops)])
+        pcb = P2P_CB(_p2p)
+        _host_allreduce_keep.append(pcb)
+        if lib().prost_comm_set_host_p2p(pcb, None) != 0:
+            raise ProstError(lib().prost_last_error().decode())
+
+
+def gloo_p2p(dist):
+    """the p2p function of comm_init_host over a torch.distributed (gloo) process group"""
+    import torch
+
+    def p2p(ops):
+        reqs = [dist.isend(torch.from_numpy(a), peer) if send else dist.irecv(torch.from_numpy(a), peer) for send, peer, a in ops]
+        for r in reqs:
+            r.wait()
+    return p2p
+
+
+def comm_info():
+    """{'nranks': ranks as the communicator counts them (ncclCommCount), 'transport': 'rccl' | 'host' | 'none'}"""
+    return command("comm_info", nlhs=1)[0]
 
 
 _stop_cb_keep = []
@@ -417,6 +465,21 @@ def set_stop_callback(fn):
     cb = STOP_CB(lambda user, f=fn: 1 if f() else 0)
     _stop_cb_keep.append(cb)
     lib().prost_set_stop_callback(cb, None)
+
+
+_output_cb_keep = []
+
+
+def set_output_callback(fn):
+    """`fn(text)` receives what the library prints (verbose header, "It k: Feas_p=..." lines, list_gpus) instead of the
+    process's stdout -- the mexPrintf redirect of the MEX gateway (prost.cpp:15-44); None restores stdout."""
+    if fn is None:
+        lib().prost_set_output_callback(OUTPUT_CB(), None)
+        del _output_cb_keep[:]
+        return
+    cb = OUTPUT_CB(lambda user, text, n, f=fn: f(C.string_at(text, n).decode(errors="replace")))
+    _output_cb_keep.append(cb)
+    lib().prost_set_output_callback(cb, None)
 
 
 def comm_destroy():

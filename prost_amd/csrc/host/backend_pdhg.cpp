@@ -120,10 +120,16 @@ void BackendPDHG<T>::Initialize() {
   pair3d_ = fused_ && desc_.is3d && desc_.L >= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, dtype_id<T>()) == 1;
   // 2-4 channels: the channels on the wavefronts of a workgroup, two iterations per launch
   // (also at heights the single-iteration kernels do not take: the other iterations then run the two passes)
-  pair_mc_ = fused_ && !desc_.is3d && desc_.L >= 2 && desc_.L <= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel &&
+  // (L = 2 at heights the gray-value pair kernel takes: PerformIterations launches that one, so only one of the two flags is set --
+  // the kernel names and chunk lengths KernelTimes reports then belong to the kernel that ran)
+  pair_mc_ = fused_ && !pair_kernel_ && !desc_.is3d && desc_.L >= 2 && desc_.L <= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel &&
              prost_hip_fused_iteration_mc_x2_profitable(&desc_, dtype_id<T>()) == 1;
-  if (pair_kernel_ || pair3d_ || pair_mc_) x_spare_.resize(n);
-  if (single_kernel_ || single3d_ || single_mc_ || pair3d_ || pair_mc_) y_spare_.resize(m);
+  // third buffers: where every residual iteration (single-kernel paths) or every other pair (pair_kernel_: stored intermediate
+  // iterate) uses them they are allocated here; the 3-D / multi-channel pair paths without them need a third buffer only to
+  // rebuild the previous iterate (RebuildPrevious: read-out, callbacks) and allocate it there -- 4 n + 4 m values less resident
+  // at the 2048 x 2048 x 64 size until somebody reads the solution
+  if (pair_kernel_) x_spare_.resize(n);
+  if (single_kernel_ || single3d_ || single_mc_) y_spare_.resize(m);
 
   CheckHip(prost_hip_malloc((void**)&res_dev_, 4 * sizeof(double)), "malloc");
   CheckHip(prost_hip_memset(res_dev_, 0, 4 * sizeof(double), CurrentStream()), "memset");
@@ -189,6 +195,9 @@ void BackendPDHG<T>::PerformIteration() {
 template <typename T>
 int BackendPDHG<T>::PerformIterations(int budget) {
   const size_t k = iteration_;
+  // z, w of the last read-out (n + m values; the reference keeps no such copies): large ones are released when the iteration
+  // goes on, small ones stay for the next callback
+  if (!sol_z_.empty() && (sol_z_.size() + sol_w_.size()) * sizeof(T) > ((size_t)1 << 30)) { sol_z_.clear(); sol_w_.clear(); }
   if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
     IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
     pair_launches_++;
@@ -224,7 +233,9 @@ size_t BackendPDHG<T>::NewEvent() {
 /// something else sits between two launches (fold / all-reduce after a residual launch, a host wait, a rebuild launch).
 template <typename T>
 bool BackendPDHG<T>::BeginSample(int kind) {
-  if (!this->time_kernels_) return false;
+  // (an untimed launch breaks the chain of shared boundary events; the pool is bounded: at most kMaxSamples launches are
+  // bracketed between two KernelTimes calls, later ones run unmarked)
+  if (!this->time_kernels_ || samples_.size() >= kMaxSamples) { last_end_ = kNoEvent; return false; }
   // one launch in `sample_every_`: the markers must not serialise the stream of a long run
   if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) { last_end_ = kNoEvent; return false; }
   const size_t start = (this->sample_every_ == 1 && last_end_ != kNoEvent) ? last_end_ : NewEvent();
@@ -314,6 +325,8 @@ template <typename T>
 void BackendPDHG<T>::RebuildPrevious() {
   if (!prev_stale_) return;
   last_end_ = kNoEvent;
+  if (x_spare_.size() != x_.size()) x_spare_.resize(x_.size());
+  if (y_spare_.size() != y_.size()) y_spare_.resize(y_.size());
   if (pair_mc_ && single_mc_)
     CheckHip(Api<T>::fused_iteration_mc(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
                                         (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration_mc");

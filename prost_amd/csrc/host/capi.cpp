@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <iostream>
 #include <map>
 #include <sstream>
@@ -27,6 +28,23 @@ struct default_init_allocator : std::allocator<T> {
   template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
 };
 typedef std::vector<double, default_init_allocator<double>> value_vector;
+
+// std::cout of the library (the verbose header and "It k: Feas_p=..." lines of Solver::Solve, list_gpus, the |K| rescale
+// note) handed to a front end's print function: the mexstream of prost.cpp:15-44 behind the C ABI
+namespace {
+prost_output_cb g_out_fn = nullptr;
+void* g_out_user = nullptr;
+std::streambuf* g_cout_saved = nullptr;
+class CallbackStreambuf : public std::streambuf {
+ protected:
+  std::streamsize xsputn(const char* s, std::streamsize n) override { if (g_out_fn && n > 0) g_out_fn(g_out_user, s, (size_t)n); return n; }
+  int overflow(int c = EOF) override {
+    if (c != EOF) { const char ch = (char)c; if (g_out_fn) g_out_fn(g_out_user, &ch, 1); }
+    return 1;
+  }
+};
+CallbackStreambuf g_out_buf;
+}  // namespace
 
 struct prost_value {
   int kind = PROST_VALUE_EMPTY;
@@ -94,7 +112,16 @@ const prost_value* prost_value_field(const prost_value* v, const char* name) {
   for (auto& f : v->fields) if (f.first == name) return f.second;
   return nullptr;
 }
+size_t prost_value_field_count(const prost_value* v) { return (v && v->kind == PROST_VALUE_STRUCT) ? v->fields.size() : 0; }
+const char* prost_value_field_name(const prost_value* v, size_t i) {
+  return (v && v->kind == PROST_VALUE_STRUCT && i < v->fields.size()) ? v->fields[i].first.c_str() : nullptr;
+}
 const char* prost_last_error(void) { return g_error.c_str(); }
+void prost_set_output_callback(prost_output_cb fn, void* user) {
+  g_out_fn = fn; g_out_user = user;
+  if (fn) { if (!g_cout_saved) g_cout_saved = std::cout.rdbuf(&g_out_buf); }
+  else if (g_cout_saved) { std::cout.rdbuf(g_cout_saved); g_cout_saved = nullptr; }
+}
 void prost_set_stop_callback(prost_stop_cb fn, void* user) { g_stop_cb = fn; g_stop_user = user; }
 
 }  // extern "C"
@@ -992,9 +1019,52 @@ void cmd_comm_init(CMD_ARGS) {
   CheckHip(prost_hip_comm_create(&g_comm, id, (int)prhs[1]->data[0], (int)prhs[2]->data[0]), "comm_create");
   g_comm_world = (int)prhs[2]->data[0];
 }
+/// comm_info() -> struct {nranks, transport}: nranks as the communicator itself counts them (ncclCommCount), 0 / "none"
+/// without a communicator
+void cmd_comm_info(CMD_ARGS) {
+  (void)nrhs; (void)prhs;
+  prost_value* out = prost_value_struct();
+  int n = 0;
+  if (g_comm) CheckHip(prost_hip_comm_count(g_comm, &n), "comm_count");
+  prost_value_struct_set(out, "nranks", prost_value_scalar((double)n));
+  prost_value_struct_set(out, "transport", prost_value_string(!g_comm ? "none" : prost_hip_comm_is_host(g_comm) ? "host" : "rccl"));
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
+}
 void cmd_comm_destroy(CMD_ARGS) {
   (void)nlhs; (void)plhs; (void)nrhs; (void)prhs;
   if (g_comm) { prost_hip_comm_destroy(g_comm); g_comm = nullptr; g_comm_world = 1; }
+}
+/// load_plugin(path): dlopen()s a shared library of user-defined prost::Block / prost::Prox / prost::Backend subclasses whose
+/// static initialisers insert `name -> factory` into Factory<T>::block_reg() / prox_reg() / backend_reg() -- what compiling
+/// user sources into the MEX file does for the reference (custom.cpp:11-28, cmake/CustomSources.cmake.example:1-26).  The
+/// library stays loaded for the life of the process.
+void cmd_load_plugin(CMD_ARGS) {
+  (void)nlhs; (void)plhs;
+  if (nrhs != 1) throw Exception("load_plugin: (path) required.");
+  const std::string path = GetString(prhs[0]);
+  if (!dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL)) {
+    const char* why = dlerror();
+    throw Exception("load_plugin: cannot load '" + path + "': " + (why ? why : "unknown error"));
+  }
+}
+/// registered() -> struct {prox, block, backend}: cells of the names in the registries of the current precision
+void cmd_registered(CMD_ARGS) {
+  (void)nrhs; (void)prhs;
+  auto names = [](auto& reg) {
+    prost_value* c = prost_value_cell(reg.size());
+    size_t i = 0;
+    for (auto& e : reg) prost_value_cell_set(c, i++, prost_value_string(e.first.c_str()));
+    return c;
+  };
+  prost_value* out = prost_value_struct();
+  if (g_single) {
+    prost_value_struct_set(out, "prox", names(Factory<float>::prox_reg())); prost_value_struct_set(out, "block", names(Factory<float>::block_reg()));
+    prost_value_struct_set(out, "backend", names(Factory<float>::backend_reg()));
+  } else {
+    prost_value_struct_set(out, "prox", names(Factory<double>::prox_reg())); prost_value_struct_set(out, "block", names(Factory<double>::block_reg()));
+    prost_value_struct_set(out, "backend", names(Factory<double>::backend_reg()));
+  }
+  if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 void cmd_set_quirks(CMD_ARGS) {
   (void)nlhs; (void)plhs;
@@ -1010,7 +1080,15 @@ extern "C" int prost_comm_init_host(prost_allreduce_cb fn, void* user, int world
     select_device();
     if (g_comm) { prost_hip_comm_destroy(g_comm); g_comm = nullptr; }
     CheckHip(prost_hip_comm_create_host(&g_comm, fn, user), "comm_create_host");
+    CheckHip(prost_hip_comm_host_configure(g_comm, world_size, nullptr, nullptr), "comm_host_configure");
     g_comm_world = world_size;
+    return 0;
+  } catch (const std::exception& e) { g_error = e.what(); return 1; }
+}
+extern "C" int prost_comm_set_host_p2p(prost_p2p_cb fn, void* user) {
+  try {
+    if (!g_comm || !prost_hip_comm_is_host(g_comm)) throw Exception("prost_comm_set_host_p2p: prost_comm_init_host first.");
+    CheckHip(prost_hip_comm_host_configure(g_comm, g_comm_world, fn, user), "comm_host_configure");
     return 0;
   } catch (const std::exception& e) { g_error = e.what(); return 1; }
 }
@@ -1024,7 +1102,7 @@ const std::map<std::string, cmd_fn>& cmd_reg() {
       {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_kernel_times", cmd_solver_kernel_times}, {"solver_state", cmd_solver_state},
       {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_iterate_sharded", cmd_solver_iterate_sharded}, {"solver_copy_columns", cmd_solver_copy_columns},
       {"solver_compare", cmd_solver_compare}, {"solver_read", cmd_solver_read}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
-      {"comm_destroy", cmd_comm_destroy}, {"set_quirks", cmd_set_quirks}};
+      {"comm_destroy", cmd_comm_destroy}, {"comm_info", cmd_comm_info}, {"set_quirks", cmd_set_quirks}, {"load_plugin", cmd_load_plugin}, {"registered", cmd_registered}};
   return reg;
 }
 

@@ -301,7 +301,7 @@ static FusedArgs<T> make_args(const prost_hip_fused_desc* d) {
 static int pick_cols(size_t nx, size_t row_blocks, size_t planes) {
   size_t cols = 16;
   while (cols > 4 && row_blocks * planes * ((nx + cols - 1) / cols) < 2048) cols /= 2;
-  while (row_blocks * planes * ((nx + cols - 1) / cols) > (size_t)kReduceBlocks) cols *= 2;
+  while (cols < nx && row_blocks * planes * ((nx + cols - 1) / cols) > (size_t)kReduceBlocks) cols *= 2;      // desc_ok: one chunk always fits
   return (int)cols;
 }
 

@@ -218,7 +218,10 @@ bool fused3d_desc_ok(const prost_hip_fused_desc* d) {
   if (!d || !d->is3d) return false;
   if (d->nx == 0 || d->ny == 0 || d->L == 0 || d->L > 65535) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
-  const size_t rb = (d->ny + kBlock - 1) / kBlock;
+  const size_t rb = (d->ny + kBlock - 1) / kBlock;        // worst case VEC = 1
+  // residual launches keep one partial per workgroup: even with one column chunk (the widest pick_cols3d can choose) the grid
+  // of row blocks x planes must fit the reduction workspace -- larger volumes take the generic path
+  if (rb * d->L > (size_t)kReduceBlocks) return false;
   return rb <= 65535 && d->nx <= 65535 * 4;
 }
 
@@ -235,7 +238,7 @@ static bool vec3_ok(const prost_hip_fused_desc* d, const void* p0, const void* p
 static int pick_cols3d(size_t nx, size_t row_blocks, size_t planes, bool res) {
   size_t cols = 12;
   while (cols > 6 && row_blocks * planes * ((nx + cols - 1) / cols) < 2048) cols -= 3;
-  while (res && row_blocks * planes * ((nx + cols - 1) / cols) > (size_t)kReduceBlocks) cols += 6;
+  while (res && cols < nx && row_blocks * planes * ((nx + cols - 1) / cols) > (size_t)kReduceBlocks) cols += 6;      // ends at one chunk
   return (int)cols;
 }
 

@@ -304,7 +304,7 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
   if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
-  // (res_x0 / res_x1 -- the owned columns of a sharded slab -- only restrict residual sums, which this kernel does not form)
+  // (res_x0 / res_x1 -- the owned columns of a sharded slab -- restrict the residual sums of the RES instances)
   if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4.0 : 8.0) >= 4294967296.0) return false;              // 32-bit byte offsets per plane
   const size_t strips = (d->ny + mc_x2_rows(dtype, d->ny) - 1) / mc_x2_rows(dtype, d->ny);
   if (strips > (size_t)kReduceBlocks / 2) return false;              // residual launches: one partial per workgroup, at best one chunk per strip
@@ -322,9 +322,14 @@ static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int col
   size_t best_c = 1, best_cost = (size_t)-1;
   // (capped at 24 columns: beyond the point where every slot is taken, MORE and shorter workgroups hide the per-column barrier
   // better than fewer warm-up columns pay -- 4096^2 RGB: 24 columns 0.186 ms per iteration, 72 columns 0.198, 96 columns 0.220)
-  for (size_t c = 1; c <= 24 && c <= d->nx; c++) {
+  // residual launches: one partial (4 doubles) per workgroup -- where 24 columns leave more workgroups than the workspace holds
+  // (4096^2 in fp64: 34 strips of 124 rows), the cap moves to the shortest chunk that fits (iter_mc_x2_ok: one chunk always does)
+  const size_t max_groups = (size_t)kReduceBlocks / 2;
+  size_t cap = 24;
+  if (res && strips * ((d->nx + cap - 1) / cap) > max_groups) cap = (d->nx + max_groups / strips - 1) / (max_groups / strips);
+  for (size_t c = 1; c <= cap && c <= d->nx; c++) {
     const size_t waves = strips * ((d->nx + c - 1) / c) * d->L;
-    if (res && strips * ((d->nx + c - 1) / c) > (size_t)kReduceBlocks / 2) continue;      // residual launches: one partial (4 doubles) per workgroup
+    if (res && strips * ((d->nx + c - 1) / c) > max_groups) continue;
     const size_t cost = ((waves + slots - 1) / slots) * (c + 3);
     if (cost <= best_cost) { best_cost = cost; best_c = c; }         // ties: the longer chunk (less redundant arithmetic)
   }

@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace prost_hip {
 
@@ -90,7 +91,71 @@ struct Comm {
   void* host_user = nullptr;
   double* staging = nullptr;      // pinned, kHostStaging doubles
   size_t count = 0;               // doubles of the call in flight (read by the host function)
+  // host transport, point-to-point: `p2p_fn` performs ALL transfers of one group (pinned host buffers) and returns when
+  // they are complete; the staging area is reused by consecutive groups, which stream order keeps apart
+  int host_world = 1;
+  prost_hip_host_p2p_fn p2p_fn = nullptr;
+  void* p2p_user = nullptr;
+  char* p2p_staging = nullptr;    // pinned
+  size_t p2p_capacity = 0;
 };
+// one group of sends / receives on a host communicator, handed to the host function through the stream
+struct HostGroupJob {
+  Comm* comm;
+  std::vector<int> is_send, peers;
+  std::vector<void*> bufs;        // pinned staging slices
+  std::vector<size_t> bytes;
+};
+struct HostPendingOp { Comm* comm; bool send; void* dev; size_t bytes; int peer; hipStream_t stream; };
+static thread_local int g_group_depth = 0;
+static thread_local std::vector<HostPendingOp> g_pending;
+static void host_p2p_trampoline(void* p) {
+  HostGroupJob* j = static_cast<HostGroupJob*>(p);
+  j->comm->p2p_fn(j->comm->p2p_user, (int)j->is_send.size(), j->is_send.data(), j->peers.data(), j->bufs.data(), j->bytes.data());
+  delete j;
+}
+// Enqueues the pending operations of one host communicator as ONE exchange: D2H copies of everything that is sent, the host
+// function (all transfers of the group, so both neighbours are served whatever order they post in), H2D copies of
+// everything received.  Same enqueue-and-return contract as an RCCL group.
+static int flush_host_group() {
+  std::vector<HostPendingOp> ops;
+  ops.swap(g_pending);
+  if (ops.empty()) return 0;
+  Comm* c = ops[0].comm;
+  hipStream_t s = ops[0].stream;
+  size_t total = 0;
+  for (const HostPendingOp& o : ops) {
+    if (o.comm != c || o.stream != s) { set_error("prost_hip_comm_group_end: one host communicator and one stream per group"); return 1; }
+    total += (o.bytes + 63) & ~(size_t)63;
+  }
+  if (total > c->p2p_capacity) {
+    // a previous group may still be using the old area: drain the stream before it is replaced
+    PH_CHECK(hipStreamSynchronize(s));
+    if (c->p2p_staging) (void)hipHostFree(c->p2p_staging);
+    c->p2p_staging = nullptr; c->p2p_capacity = 0;
+    PH_CHECK(hipHostMalloc((void**)&c->p2p_staging, total, hipHostMallocDefault));
+    c->p2p_capacity = total;
+  }
+  HostGroupJob* job = new HostGroupJob;
+  job->comm = c;
+  size_t off = 0;
+  for (const HostPendingOp& o : ops) {
+    char* h = c->p2p_staging + off;
+    off += (o.bytes + 63) & ~(size_t)63;
+    job->is_send.push_back(o.send ? 1 : 0); job->peers.push_back(o.peer); job->bufs.push_back(h); job->bytes.push_back(o.bytes);
+    if (o.send) { const hipError_t e = hipMemcpyAsync(h, o.dev, o.bytes, hipMemcpyDeviceToHost, s); if (e != hipSuccess) { delete job; return fail(e, "hipMemcpyAsync"); } }
+  }
+  const std::vector<void*> bufs = job->bufs;            // the job is deleted by the host function
+  { const hipError_t e = hipLaunchHostFunc(s, host_p2p_trampoline, job); if (e != hipSuccess) { delete job; return fail(e, "hipLaunchHostFunc"); } }
+  for (size_t i = 0; i < ops.size(); i++)
+    if (!ops[i].send) PH_CHECK(hipMemcpyAsync(ops[i].dev, bufs[i], ops[i].bytes, hipMemcpyHostToDevice, s));
+  return 0;
+}
+static int host_p2p(Comm* c, bool send, void* dev, size_t bytes, int peer, void* stream, const char* what) {
+  if (!c->p2p_fn) { set_error(std::string(what) + ": this host-callback communicator has no point-to-point function (prost_hip_comm_host_configure)"); return 1; }
+  g_pending.push_back({c, send, dev, bytes, peer, as_stream(stream)});
+  return g_group_depth > 0 ? 0 : flush_host_group();
+}
 constexpr size_t kHostStaging = 64;
 static void host_allreduce_trampoline(void* p) {
   Comm* c = static_cast<Comm*>(p);
@@ -100,7 +165,6 @@ static int nccl_fail(ncclResult_t r, const char* what) {
   set_error(std::string(what) + ": " + ncclGetErrorString(r));
   return 1000 + (int)r;
 }
-static int host_only(const char* what) { set_error(std::string(what) + ": not available on a host-callback communicator"); return 1; }
 int prost_hip_comm_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   ncclUniqueId id;
@@ -129,12 +193,29 @@ int prost_hip_comm_create_host(void** comm, prost_hip_host_allreduce_fn fn, void
   *comm = h;
   return 0;
 }
+int prost_hip_comm_host_configure(void* comm, int world_size, prost_hip_host_p2p_fn p2p, void* p2p_user) {
+  Comm* h = static_cast<Comm*>(comm);
+  if (!h || h->nccl) { set_error("prost_hip_comm_host_configure: host-callback communicator required"); return 1; }
+  if (world_size < 1) { set_error("prost_hip_comm_host_configure: world_size must be positive"); return 1; }
+  h->host_world = world_size; h->p2p_fn = p2p; h->p2p_user = p2p_user;
+  return 0;
+}
+int prost_hip_comm_count(void* comm, int* nranks) {
+  Comm* h = static_cast<Comm*>(comm);
+  if (!h) { set_error("prost_hip_comm_count: no communicator"); return 1; }
+  if (!h->nccl) { *nranks = h->host_world; return 0; }
+  ncclResult_t r = ncclCommCount(h->nccl, nranks);
+  if (r != ncclSuccess) return nccl_fail(r, "ncclCommCount");
+  return 0;
+}
+int prost_hip_comm_is_host(void* comm) { return comm && !static_cast<Comm*>(comm)->nccl ? 1 : 0; }
 int prost_hip_comm_destroy(void* comm) {
   if (!comm) return 0;
   Comm* h = static_cast<Comm*>(comm);
   int rc = 0;
   if (h->nccl) { ncclResult_t r = ncclCommDestroy(h->nccl); if (r != ncclSuccess) rc = nccl_fail(r, "ncclCommDestroy"); }
   if (h->staging) (void)hipHostFree(h->staging);
+  if (h->p2p_staging) (void)hipHostFree(h->p2p_staging);
   delete h;
   return rc;
 }
@@ -143,21 +224,23 @@ int prost_hip_comm_destroy(void* comm) {
 int prost_hip_comm_group_start(void) {
   ncclResult_t r = ncclGroupStart();
   if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
+  g_group_depth++;
   return 0;
 }
 int prost_hip_comm_group_end(void) {
+  if (g_group_depth > 0) g_group_depth--;
   ncclResult_t r = ncclGroupEnd();
-  if (r != ncclSuccess) return nccl_fail(r, "ncclGroupEnd");
-  return 0;
+  if (r != ncclSuccess) { g_pending.clear(); return nccl_fail(r, "ncclGroupEnd"); }
+  return g_group_depth == 0 ? flush_host_group() : 0;
 }
 int prost_hip_comm_send(void* comm, const void* buf, size_t bytes, int peer, void* stream) {
-  if (!static_cast<Comm*>(comm)->nccl) return host_only("prost_hip_comm_send");
+  if (!static_cast<Comm*>(comm)->nccl) return host_p2p(static_cast<Comm*>(comm), true, const_cast<void*>(buf), bytes, peer, stream, "prost_hip_comm_send");
   ncclResult_t r = ncclSend(buf, bytes, ncclChar, peer, static_cast<Comm*>(comm)->nccl, as_stream(stream));
   if (r != ncclSuccess) return nccl_fail(r, "ncclSend");
   return 0;
 }
 int prost_hip_comm_recv(void* comm, void* buf, size_t bytes, int peer, void* stream) {
-  if (!static_cast<Comm*>(comm)->nccl) return host_only("prost_hip_comm_recv");
+  if (!static_cast<Comm*>(comm)->nccl) return host_p2p(static_cast<Comm*>(comm), false, buf, bytes, peer, stream, "prost_hip_comm_recv");
   ncclResult_t r = ncclRecv(buf, bytes, ncclChar, peer, static_cast<Comm*>(comm)->nccl, as_stream(stream));
   if (r != ncclSuccess) return nccl_fail(r, "ncclRecv");
   return 0;

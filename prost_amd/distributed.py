@@ -69,10 +69,11 @@ class ColumnShardedSolver:
     operator norm, so `scale_steps_operator` is forced off (for gradient operators the reference's
     rescaling branch |norm - 1| > 0.1 never fires anyway).
 
-    transport: "rccl" (one slab per rank, prost.comm_init done) or a list of ColumnShardedSolver objects
-    of the same process (several slabs on one GPU)."""
+    transport: "comm" / "rccl" (one slab per rank through the native communicator: prost.comm_init = RCCL over xGMI, or
+    prost.comm_init_host with a p2p function = host transport, several ranks on one GPU) or a list of ColumnShardedSolver
+    objects of the same process (several slabs on one GPU)."""
 
-    def __init__(self, make_problem, nx, ny, backend, opts, rank, world, halo=8, transport="rccl"):
+    def __init__(self, make_problem, nx, ny, backend, opts, rank, world, halo=8, transport="comm"):
         from . import _capi
         if halo < 3:
             raise ValueError("halo must be at least 3 columns")
@@ -85,12 +86,12 @@ class ColumnShardedSolver:
         prob = make_problem(lo, hi)
         backend = [backend[0], dict(backend[1], scale_steps_operator=False)]
         self.solver = _capi.Solver(prob, backend, opts, owned_columns=(self.hl, self.hl + (self.c1 - self.c0), self.nl))
-        self.transport = transport
+        self.transport = "comm" if transport == "rccl" else transport
         self.since_exchange = 0
 
     def exchange(self, peers=None):
         h, ny = self.halo, self.ny
-        if self.transport == "rccl":
+        if self.transport == "comm":
             if self.hl or self.hr:
                 self.solver.halo_exchange(ny, h, self.hl, self.hr, self.rank - 1 if self.hl else -1, self.rank + 1 if self.hr else -1)
         else:
@@ -111,9 +112,9 @@ class ColumnShardedSolver:
         self.since_exchange += k
 
     def iterate(self, iters):
-        """rccl transport: runs `iters` iterations with the exchanges in between (collective: every rank
+        """communicator transport: runs `iters` iterations with the exchanges in between (collective: every rank
         calls it with the same count)"""
-        if self.transport != "rccl":
+        if self.transport != "comm":
             raise RuntimeError("in-process slabs are driven by iterate_group()")
         # the exchange / iterate loop runs inside the native solver (solver_iterate_sharded): no Python between exchanges
         self.since_exchange = self.solver.iterate_sharded(iters, self.ny, self.halo, self.hl, self.hr, self.rank - 1 if self.hl else -1,

@@ -13,6 +13,8 @@ typedef bool mxLogical;
 typedef enum { mxREAL, mxCOMPLEX } mxComplexity;
 extern "C" {
 void mexErrMsgTxt(const char* msg);
+int mexPrintf(const char* fmt, ...);
+int mexEvalString(const char* command);
 int mexCallMATLAB(int nlhs, mxArray* plhs[], int nrhs, mxArray* prhs[], const char* name);
 mxArray* mxCreateDoubleScalar(double v);
 mxArray* mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);

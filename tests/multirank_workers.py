@@ -72,6 +72,68 @@ def pdhg_rank(rank, world, port, step, precision, out):
         out.put(dict(rank=rank, error=traceback.format_exc() + repr(e)))
 
 
+def sharded_rank(rank, world, port, precision, L, nx, ny, halo, iters, out):
+    """one rank of ONE image cut into column slabs: the native exchange / iterate loop (solver_iterate_sharded)
+    with the halo columns travelling BETWEEN PROCESSES through the host-callback transport's point-to-point function (gloo
+    isend / irecv), the residual sums through its all-reduce.  Owned columns are compared with the oracle's iterates of the
+    whole image."""
+    try:
+        torch, dist = _init(rank, world, port)
+        import oracle
+        import prost_amd as prost
+        from prost_amd import distributed, synthetic
+        dtype = np.float32 if precision == "single" else np.float64
+        prost.set_gpu(0)
+        prost.set_precision(precision)
+        moved = []
+
+        gloo = prost.gloo_p2p(dist)
+
+        def p2p(ops):                          # runs on a HIP runtime thread, in stream order
+            moved.append(sum(a.size for s, peer, a in ops if s))
+            gloo(ops)
+
+        prost.comm_init_host(lambda a: dist.all_reduce(torch.from_numpy(a)), world, p2p=p2p)
+        info = prost.comm_info()
+        f_full = np.asarray(synthetic.rof_image(nx, ny, L, 9)).ravel()
+
+        def make(lo, hi):
+            f = np.concatenate([f_full[l * nx * ny + lo * ny: l * nx * ny + hi * ny] for l in range(L)])
+            return synthetic.rof_problem(hi - lo, ny, L, f=f)[0]
+
+        backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+        opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+        s = distributed.ColumnShardedSolver(make, nx, ny, backend, opts, rank, world, halo, transport="comm")
+        s.iterate(iters[0])
+        s.iterate(iters[1] - iters[0])         # the exchange phase carries over between calls
+        st = s.owned_state()
+        path = s.solver.state(vectors=False)["path"]
+        c0, c1 = s.c0, s.c1
+        s.destroy()
+        prost.comm_destroy()
+        whole = make(0, nx)
+        whole.finalize()
+        noscale = [backend[0], dict(backend[1], scale_steps_operator=False)]
+        orc = oracle.Solver(whole.data, whole.nrows, whole.ncols, noscale, opts, dtype)
+        orc.initialize()
+        orc.iterate(iters[1])
+        ost, osc = orc.state(), orc.scalars()
+
+        def owned(v, planes):
+            return np.concatenate([v[k * nx * ny + c0 * ny: k * nx * ny + c1 * ny] for k in planes])
+
+        same = {"x": bool(np.array_equal(st["x"], owned(ost["x"], range(L)))),
+                "y1": bool(np.array_equal(st["y1"], owned(ost["y"], range(L)))),
+                "y2": bool(np.array_equal(st["y2"], owned(ost["y"], range(L, 2 * L))))}
+        out.put(dict(rank=rank, same=same, iteration=int(st["iteration"]), primal_res=float(st["primal_res"]), dual_res=float(st["dual_res"]),
+                     o_primal_res=float(osc["primal_res"]), o_dual_res=float(osc["dual_res"]), exchanges=len(moved), bytes_sent=moved,
+                     nranks=int(info["nranks"]), transport=info["transport"], path=path, itemsize=np.dtype(dtype).itemsize))
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        out.put(dict(rank=rank, error=traceback.format_exc() + repr(e)))
+
+
 def run_command(cmd, env, cwd, out):
     """runs a launcher (torchrun) from a process that has never touched the GPU"""
     e = dict(os.environ)

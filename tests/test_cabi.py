@@ -27,7 +27,7 @@ def test_kernel_library_exports_every_declared_symbol():
     L = _hip.lib()
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.prost_hip_abi_version() == 3
+    assert L.prost_hip_abi_version() == 4
     assert L.prost_hip_reduce_workspace_bytes() >= 4096
 
 
@@ -275,3 +275,17 @@ def test_support_predicates_and_launch_geometry_of_the_double_iteration_kernels(
     assert 1 <= L.prost_hip_fused_iteration_mc_x2_chunk_cols(C.byref(desc(0, 700, 464, 3)), 0, 1) <= 24
     # profitable: tiny (launch-bound) and large (throughput-bound) images, not the latency-bound middle
     assert [L.prost_hip_fused_iteration_mc_x2_profitable(C.byref(desc(0, n, n, 3)), 0) for n in (256, 512, 1024, 4096)] == [1, 0, 1, 1]
+    # residual variants: one partial per workgroup must fit the reduction workspace (4096 workgroups).  4096^2 in fp64 has 34
+    # strips of 124 rows, 24-column chunks would make 5814 workgroups: the chunk grows to the shortest length that fits
+    for n, dt in ((4096, 1), (4096, 0), (8192, 1), (16384, 1)):
+        rows = 62 * (4 if dt == 0 else 2)
+        c = L.prost_hip_fused_iteration_mc_x2_chunk_cols(C.byref(desc(0, n, n, 3)), dt, 1)
+        assert c >= 1 and -(-n // rows) * -(-n // c) <= 4096, (n, dt, c)
+    assert L.prost_hip_fused_iteration_mc_x2_chunk_cols(C.byref(desc(0, 4096, 4096, 3)), 1, 1) == 35
+    # gradient3d two-pass fallback: (row blocks of 256) x planes partials per residual launch even with ONE column chunk -- volumes
+    # beyond the workspace are not taken by the fused path at all (they run the generic kernels) instead of looping for a chunk
+    # length that does not exist
+    assert L.prost_hip_fused_supported(C.byref(desc(1, 64, 4096, 512)), 0) == 1
+    assert L.prost_hip_fused_supported(C.byref(desc(1, 64, 4096, 513)), 0) == 0
+    assert L.prost_hip_fused_supported(C.byref(desc(1, 64, 4096, 2049)), 0) == 0
+    assert L.prost_hip_fused_iteration3d_x2_supported(C.byref(desc(1, 64, 4096, 2049)), 0) == 0

@@ -132,8 +132,13 @@ def test_mex_gateway_source_compiles_against_the_mex_api_declarations():
     text = open(src).read()
     # both directions of the marshalling and the three callbacks of the reference gateway are defined, not just declared
     for needle in ("prost_value* convert(const mxArray* a) {", "mxArray* back(const prost_value* v) {", "int stop_cb(void*) {",
-                   "int interm_cb(void* user", "void mexFunction(int nlhs, mxArray** plhs, int nrhs, const mxArray** prhs) {"):
+                   "int interm_cb(void* user", "void mexFunction(int nlhs, mxArray** plhs, int nrhs, const mxArray** prhs) {",
+                   # library output -> mexPrintf with the pause(.001) flush (prost.cpp:15-44), installed per call
+                   "void print_cb(void*, const char* text, size_t n) {", 'mexEvalString("pause(.001);")', "ScopedOutputRedirect redirect;",
+                   # result structs are copied field by field, whatever the command returns (pair_launches, comm_info, ...)
+                   "prost_value_field_count(v)", "prost_value_field_name(v, i)"):
         assert needle in text, needle
+    assert "kResultFields" not in text          # no hard-coded field list that a new result field could fall through
     # the declarations header stays declarations: no function bodies
     decl = open(os.path.join(root, "tests", "mex_decl.h")).read()
     assert "{" not in decl.split('extern "C" {', 1)[1].rsplit("}", 1)[0]

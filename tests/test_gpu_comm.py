@@ -23,8 +23,10 @@ def test_world1_communicator_gives_identical_solve(hip, stepsize):
         s = prost.Solver(prob, b, o); s.iterate(60); ref = s.state(); s.destroy()
         ident = prost.comm_unique_id()
         assert ident.shape == (128,)
+        assert prost.comm_info() == {"nranks": 0.0, "transport": "none"}
         prost.comm_init(ident, 0, 1)
         try:
+            assert prost.comm_info() == {"nranks": 1.0, "transport": "rccl"}       # ncclCommCount
             s = prost.Solver(prob, b, o); s.iterate(60); st = s.state(); s.destroy()
         finally:
             prost.comm_destroy()

@@ -37,7 +37,11 @@ def _gpu(hip):
     prost.set_precision("double")
 
 
-def test_c2_4096_default_path_matches_oracle_bit_for_bit():
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_c2_4096_default_path_matches_oracle_bit_for_bit(prec, dtype):
+    """double = the precision the reference front end ships with (config.hpp:7): the fp64 instance of the pair kernel
+    (2 rows per lane, its own chunk geometry) at the headline size"""
+    prost.set_precision(prec)
     n, k = 4096, 12
     prob, u, q, f = synthetic.rof_problem(n, n)
     b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
@@ -51,11 +55,12 @@ def test_c2_4096_default_path_matches_oracle_bit_for_bit():
     # or storing the middle iterate, single launches (iterations 0, 1 and the residual iteration 10)
     assert any(name.startswith("fused_iter2d_x2_kernel") for name in info["kernels"]), info["kernels"]
     oracle.set_num_threads(16)
-    os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float32)
+    os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, dtype)
     os_.initialize()
     os_.iterate(k)
     ost = os_.state()
     sc = os_.scalars()
+    del os_
     for v in "xyzw":
         assert st[v].shape == ost[v].shape
         assert np.array_equal(st[v], ost[v]), (v, int((st[v] != ost[v]).sum()), float(np.abs(st[v] - ost[v]).max()))
@@ -64,6 +69,8 @@ def test_c2_4096_default_path_matches_oracle_bit_for_bit():
     # residual scalars: double accumulation here, T-precision sums in the oracle (tolerance as in test_gpu_solver.py)
     for v in ("primal_res", "dual_res"):
         assert np.isclose(st[v], sc[v], rtol=1e-5), (v, st[v], sc[v])
+    if prec == "double":
+        return
     # the same 12 iterations through prost.solve: the result is streamed from the device into the caller's double arrays in
     # 32 MiB pieces (x: 2, y and z: 4 each, w: 2) through the pinned staging buffers -- every element must arrive, in place
     r = prost.solve(prob, b, prost.options(max_iters=k, num_cback_calls=0, verbose=False, **ZERO_TOL))
@@ -86,7 +93,11 @@ def _read_block(solver, which, comps, nx, ny, L, x0, x1, y0, y1, l0, l1):
     return seg.reshape(comps, l1 - l0, x1 - x0, y1 - y0)
 
 
-def test_c3_2048x2048x64_fused_equals_generic_on_device_and_subvolumes_match_oracle():
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_c3_2048x2048x64_fused_equals_generic_on_device_and_subvolumes_match_oracle(prec, dtype):
+    """double: the one-row-per-lane, two-halo-lane geometry of the double-iteration kernel, planes of 32 MiB, 6.4 GB dual
+    vector; one oracle crop (single: three)"""
+    prost.set_precision(prec)
     nx, ny, L, k = 2048, 2048, 64, 12
     f = synthetic.rof_image(nx, ny, L, 42)
     o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
@@ -119,12 +130,14 @@ def test_c3_2048x2048x64_fused_equals_generic_on_device_and_subvolumes_match_ora
         (1000, 1044, 1990, 2048, 20, 56),
         (0, 40, 0, 64, 0, 34),
     ]
+    if prec == "double":
+        crops = crops[:1]
     for (x0, x1, y0, y1, l0, l1) in crops:
         cx, cy, cl = x1 - x0, y1 - y0, l1 - l0
         cprob, _, _, _ = synthetic.tv3d_problem(cx, cy, cl, f=_crop(f, nx, ny, L, x0, x1, y0, y1, l0, l1))
         cprob.finalize()
         b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
-        osv = oracle.Solver(cprob.data, cprob.nrows, cprob.ncols, b, o, np.float32)
+        osv = oracle.Solver(cprob.data, cprob.nrows, cprob.ncols, b, o, dtype)
         osv.initialize()
         osv.iterate(k)
         ost = osv.state()
@@ -145,3 +158,98 @@ def test_c3_2048x2048x64_fused_equals_generic_on_device_and_subvolumes_match_ora
         if x0 > 0:
             assert not np.array_equal(got_x[:, :, :2, :], exp_x[:, :, :2, :])
     s.destroy()
+
+
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_rgb_4096_pair_path_equals_generic_on_device(prec):
+    """the vectorial TV of example_rof_primaldual.m (RGB, sum_norm2(6, ...)) at 4096^2: the multi-channel double-iteration
+    kernel (fused_iter2d_mc_x2_kernel, its RES variant, the single-iteration kernel on the remaining iterations) against
+    the generic nine-vector path, every element of x, y and the previous iterate compared on the device"""
+    prost.set_precision(prec)
+    n, L, k = 4096, 3, 12
+    f = synthetic.rof_image(n, n, L, 42)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    solvers = {}
+    for fused in (True, False):
+        prob, u, q, _ = synthetic.rof_problem(n, n, L, f=f)
+        b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+        b[1]["allow_fused"] = fused
+        s = prost.Solver(prob, b, o)
+        info = s.iterate(k, time_kernels=fused)
+        if fused:
+            assert any(name.startswith("fused_iter2d_mc_x2_kernel") for name in info["kernels"]), info["kernels"]
+        solvers[fused] = s
+        del prob
+    assert solvers[True].state(vectors=False)["path"] == "pdhg:fused-grad2d" and solvers[False].state(vectors=False)["path"] == "pdhg:generic"
+    for v, (count, total) in solvers[True].compare(solvers[False]).items():
+        assert count == 0, (v, count, total)
+    sa, sb = solvers[True].state(vectors=False), solvers[False].state(vectors=False)
+    for v in ("tau", "sigma", "theta"):
+        assert sa[v] == sb[v], v
+    for v in ("primal_res", "dual_res"):
+        assert np.isclose(sa[v], sb[v], rtol=1e-5), v
+    solvers[False].iterate(1)          # negative control
+    assert solvers[True].compare(solvers[False])["x"][0] > n * n
+    for s in solvers.values():
+        s.destroy()
+
+
+def test_c4_1024_admm_matches_oracle():
+    """C4 at its BASELINE size (TV-L1 flow-like, 1024^2, block.sparse + gradient2d(L = 2), ADMM with the device-resident CGLS
+    graph projection) against oracle.Solver after 5 outer iterations at the tolerance of row a5 (2e-4 of the vector's scale in
+    fp32, equal CG iteration counts).  ADMM / CGLS are parity-unpinned by the reference: this compares the
+    product with the restatement at full size."""
+    from test_gpu_solver import tvl1_like_problem
+    n, k = 1024, 5
+    prob = tvl1_like_problem(n, n)
+    b = prost.backend.admm(rho0=1)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    s = prost.Solver(prob, b, o)
+    s.iterate(k)
+    st = s.state()
+    s.destroy()
+    assert st["path"] == "admm:generic"
+    prob.finalize()
+    oracle.set_num_threads(16)
+    os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float32)
+    os_.initialize()
+    os_.iterate(k)
+    ost = os_.state()
+    ost.update(os_.scalars())
+    for v in "xyzw":
+        scale = max(1.0, float(np.abs(ost[v]).max()))
+        assert float(np.abs(st[v] - ost[v]).max()) <= 2e-4 * scale, (v, float(np.abs(st[v] - ost[v]).max()), scale)
+    assert st["cg_iterations"] == ost["cg_iterations"]
+    assert np.isclose(st["rho"], ost["rho"], rtol=1e-6)
+
+
+def test_c2_4096_boyd_pair_and_single_launches_take_the_same_decisions():
+    """residual-driven steps (boyd) at 4096^2, 30 iterations, residual_iter 5, tolerances 1e-2 (so that the rule's
+    comparisons `residual < eps` flip during the run: no change at iterations 0 and 5, tau /= 1.05 from iteration 10 on, where
+    the dual residual is within 10 % of eps_dual): the run with two iterations per launch -- whose straight-line instance forms
+    the residual SUMS in fp32 with FMAs -- takes the same six decisions as the run with single launches (tau, sigma
+    identical), so the iterates stay identical bit for bit"""
+    n, k = 4096, 30
+    tol = dict(tol_rel_primal=1e-2, tol_rel_dual=1e-2, tol_abs_primal=1e-2, tol_abs_dual=1e-2)
+    solvers = {}
+    for pair in (True, False):
+        prob, u, q, f = synthetic.rof_problem(n, n)
+        b = prost.backend.pdhg(stepsize="boyd", residual_iter=5)
+        b[1]["allow_pair_kernel"] = pair
+        o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **tol)
+        s = prost.Solver(prob, b, o)
+        info = s.iterate(k, time_kernels=True)
+        assert any(name.startswith("fused_iter2d_x2_kernel") for name in info["kernels"]) == pair, info["kernels"]
+        solvers[pair] = s
+        del prob
+    for v, (count, total) in solvers[True].compare(solvers[False]).items():
+        assert count == 0, (v, count, total)
+    sa, sb = solvers[True].state(vectors=False), solvers[False].state(vectors=False)
+    assert sa["iteration"] == sb["iteration"] == k
+    for v in ("tau", "sigma"):
+        assert sa[v] == sb[v], (v, sa[v], sb[v])
+    assert 0.75 < sa["tau"] < 0.9 and sa["sigma"] > 1.1    # boyd rebalanced three or four times (1.05^-4 = 0.823)
+    for v in ("primal_res", "dual_res"):
+        assert np.isclose(sa[v], sb[v], rtol=1e-5), v
+    for s in solvers.values():
+        s.destroy()

@@ -67,6 +67,71 @@ def test_two_ranks_on_one_gpu_match_the_oracle_under_the_same_allreduce(hip, ste
     assert a["solve_iters"] == b["solve_iters"] and a["solve_iters"] < 4000 and a["solve_result"] == b["solve_result"] == "Converged."
 
 
+@pytest.mark.parametrize("world,precision,L,nx,ny,halo", [(2, "single", 1, 64, 252, 6), (3, "double", 1, 96, 64, 8), (2, "single", 3, 48, 128, 7), (3, "single", 2, 66, 64, 5)])
+def test_column_slabs_on_real_ranks_exchange_halos_between_processes(hip, world, precision, L, nx, ny, halo):
+    """SURVEY 8f.4 with REAL ranks: every rank owns one column slab in its own process and HIP context (all on GPU 0), the
+    native loop solver_iterate_sharded exchanges the halo columns through prost_hip_comm_send / recv on the host-callback
+    transport (D2H, gloo isend / irecv of the whole group, H2D -- where RCCL would run ncclSend / ncclRecv) and the residual
+    sums through its all-reduce.  Owned columns of every rank == the oracle's iterates of the WHOLE image, bit for bit; the
+    all-reduced residuals == the oracle's residuals of the whole image."""
+    ctx = mp.get_context("forkserver")
+    out = ctx.Queue()
+    port = _free_port()
+    iters = (13, 45)
+    procs = [ctx.Process(target=workers.sharded_rank, args=(r, world, port, precision, L, nx, ny, halo, iters, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=60)
+    for d in res:
+        assert "error" not in d, d.get("error")
+    exchanges = (iters[1] - 1) // (halo - 2)           # one refresh every halo - 2 iterations, none before the first
+    for d in res:
+        assert all(d["same"].values()), (d["rank"], d["same"])
+        assert d["iteration"] == iters[1] and d["nranks"] == world and d["transport"] == "host"
+        assert d["path"].startswith("pdhg:fused-grad2d"), d["path"]
+        assert d["exchanges"] == exchanges, (d["exchanges"], exchanges)
+        sides = (1 if d["rank"] > 0 else 0) + (1 if d["rank"] < world - 1 else 0)
+        assert all(b == sides * 3 * L * halo * ny * d["itemsize"] for b in d["bytes_sent"]), d["bytes_sent"]
+        # every rank reports the residuals of the WHOLE image (owned columns only, summed over the ranks)
+        assert np.isclose(d["primal_res"], d["o_primal_res"], rtol=2e-5) and np.isclose(d["dual_res"], d["o_dual_res"], rtol=2e-5)
+    assert len({(d["primal_res"], d["dual_res"]) for d in res}) == 1
+
+
+def _run_bench(cmd, env):
+    ctx = mp.get_context("forkserver")
+    out = ctx.Queue()
+    p = ctx.Process(target=workers.run_command, args=(cmd, env, ROOT, out))
+    p.start()
+    rc, stdout, stderr = out.get(timeout=600)
+    p.join(timeout=60)
+    return rc, stdout, stderr
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher(hip):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py itself starts the two ranks (a child
+    torch.distributed.run job created before anything touches the GPU) and prints the rank-0 line with n_gpus == 2;
+    a launcher whose WORLD_SIZE disagrees with --gpus is refused instead of silently reporting another n_gpus."""
+    env = {"PROST_BENCH_TRANSPORT": "host", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        assert k not in os.environ
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--size", "1024", "--prelude-iters", "100", "--no-cpu-baseline"]
+    rc, stdout, stderr = _run_bench(cmd, env)
+    assert rc == 0, stderr
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["problems"] == 2 and d["config"]["comm_nranks"] == 2 and d["config"]["rccl_nranks"] is None
+    assert d["value"] > 0 and d["iterates_finite"]
+    # WORLD_SIZE = 1 from a launcher, --gpus 2 on the command line: refused
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--size", "256", "--prelude-iters", "0", "--no-cpu-baseline"]
+    rc, stdout, stderr = _run_bench(cmd, env)
+    assert rc != 0 and "WORLD_SIZE = 1" in stderr, (rc, stderr[-500:])
+    assert not [l for l in stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_two_ranks_under_torchrun_on_one_gpu(hip):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on GPU 0
     over the host-callback transport (PROST_BENCH_TRANSPORT=host): rank-0 JSON assembly, barrier and max-over-ranks

@@ -179,6 +179,34 @@ def test_solve_pairs_iterations_and_polls_the_stopping_callback_once_per_launch(
     assert int(r2["pair_launches"]) == int(r["pair_launches"]) and np.array_equal(np.asarray(r2["x"]), np.asarray(r["x"]))
 
 
+def test_verbose_output_reaches_the_front_end_print_function():
+    """prost_set_output_callback (the MEX gateway's std::cout -> mexPrintf redirect, prost.cpp:15-44): a verbose solve hands
+    its header, the scheduled "It k: Feas_p=..." lines (solver.cu:161-171: num_cback_calls + 1 of them, scientific with two
+    digits) and the closing line to the registered function; afterwards the library prints to stdout again."""
+    import re
+    prost.set_precision("single")
+    prob, u, q, f = synthetic.rof_problem(48, 40, 1, seed=8)
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=5, alg2_gamma=0.5)
+    o = prost.options(max_iters=100, num_cback_calls=4, verbose=True, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    chunks = []
+    prost.set_output_callback(chunks.append)
+    try:
+        r = prost.solve(prob, b, o)
+    finally:
+        prost.set_output_callback(None)
+    text = "".join(chunks)
+    assert r["result"] == "Reached maximum iterations."
+    assert text.startswith("prost v") and "# primal variables: %d" % (48 * 40) in text and "# dual variables: %d" % (2 * 48 * 40) in text
+    lines = [l for l in text.splitlines() if l.startswith("It ")]
+    assert [int(l[3:6]) for l in lines] == [1, 34, 67, 100], lines                   # common.cu:33-46: linspace(0, max_iters - 1, 4) = 0, 33, 66, 99 (, 99)
+    for l in lines:
+        assert re.fullmatch(r"It +\d+: Feas_p=\d\.\d\de[+-]\d\d, Eps_p=\d\.\d\de[+-]\d\d, Feas_d=\d\.\d\de[+-]\d\d, Eps_d=\d\.\d\de[+-]\d\d; ", l), l
+    assert text.rstrip().endswith("Reached maximum of 100 iterations.")
+    n = len(chunks)
+    prost.solve(prob, b, prost.options(max_iters=10, num_cback_calls=0, verbose=False))
+    assert len(chunks) == n
+
+
 @pytest.mark.parametrize("solve_dual", [False, True])
 def test_solve_streams_the_same_result_it_hands_to_callbacks(solve_dual):
     """Without an intermediate-solution callback prost.solve takes x, y, z, w straight from the device
