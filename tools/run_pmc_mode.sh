@@ -8,7 +8,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rm -rf /tmp/pmcm_$TAG_$i
+  rm -rf /tmp/pmcm_${TAG}_$i
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmcm_${TAG}_$i -o p -- python3 $R/tools/pmc_iter.py 4096 $MODE $COLS 12 > /dev/null 2>&1
 done
 python3 - <<PY
