@@ -3,6 +3,7 @@
 #ifndef PROST_BACKEND_ADMM_HPP_
 #define PROST_BACKEND_ADMM_HPP_
 #include "prost/backend/backend.hpp"
+#include "prost_hip.h"
 
 namespace prost {
 
@@ -18,9 +19,11 @@ class BackendADMM : public Backend<T> {
     T arb_delta, arb_tau, arb_gamma;
     bool cg_graph;           ///< replay the CG rounds of a solve from one captured HIP graph (needs device_cg); off by default:
                              ///< measured 10-25 % SLOWER than the direct launches on ROCm 7.2
+    bool fused_rounds;       ///< CG rounds of four launches with the operator applied inside them (needs device_cg and an operator of
+                             ///< CSR / gradient blocks); false: the staged rounds with LinearOperator::Eval between the stages
     bool device_cg;          ///< fused passes + CG scalars resident on the device (default); false = the reference's launch sequence, one blocking nrm2 per scalar
     Options() : rho0(1), alpha(1.7), cg_tol_pow(1.3), cg_tol_min(1e-5), cg_tol_max(1e-8), cg_max_iter(10), residual_iter(1),
-                arb_delta(1.05), arb_tau(0.8), arb_gamma(1.01), cg_graph(false), device_cg(true) {}
+                arb_delta(1.05), arb_tau(0.8), arb_gamma(1.01), cg_graph(false), fused_rounds(true), device_cg(true) {}
   };
   explicit BackendADMM(const Options& opts)
       : opts_(opts), scal_dev_(nullptr), scal_host_(nullptr), workspace_(nullptr), cg_state_(nullptr), cg_workspace_(nullptr), cg_done_host_(nullptr) {}
@@ -45,6 +48,7 @@ class BackendADMM : public Backend<T> {
            device_vector<T>& q, device_vector<T>& r, device_vector<T>& s, int& iterations);   // cgls.hpp:222-371
   void CglsDevice(const device_vector<T>& b, device_vector<T>& x, double shift, double tol, int maxit, device_vector<T>& p,
                   device_vector<T>& q, device_vector<T>& r, device_vector<T>& s);
+  void DescribeOperator();
   void PerformIterationFused();
   void PerformIterationUnfused();
   void FinishResiduals(double primal_residual, double primal_var_norm, double dual_residual, double dual_var_norm);
@@ -64,6 +68,11 @@ class BackendADMM : public Backend<T> {
   void* cg_ev_[2] = {nullptr, nullptr};
   int cg_epoch_ = 0;
   bool cg_iters_valid_ = true;
+  // CG rounds in four launches (prost_hip_cgls_round_*): the operator as a table of CSR / gradient blocks, one scalar record
+  // per round; fused_op_.nblocks == 0: the operator has other blocks (plugins, diags, Kronecker, ...) -> staged rounds
+  prost_hip_fused_op fused_op_;
+  bool fused_rounds_ = false;
+  int cg_result_index_ = 0;      ///< record that holds the result of the most recent device solve
   T rho_, delta_;
   int arb_u_, arb_l_;
   size_t iteration_;

@@ -20,9 +20,13 @@
 namespace prost {
 
 struct BlockDesc {
-  enum Kind { kNone = 0, kGradient2D, kGradient3D } kind = kNone;
+  enum Kind { kNone = 0, kGradient2D, kGradient3D, kSparse } kind = kNone;
   size_t nx = 0, ny = 0, L = 0;
   bool label_first = false;
+  // kSparse (valid after Initialize()): K and K^T as CSR in device memory, values of type T
+  size_t nnz = 0;
+  const void* val = nullptr; const int32_t* ptr = nullptr; const int32_t* ind = nullptr;
+  const void* val_t = nullptr; const int32_t* ptr_t = nullptr; const int32_t* ind_t = nullptr;
 };
 
 template <typename T>

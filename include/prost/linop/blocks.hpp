@@ -65,6 +65,13 @@ class BlockSparse : public Block<T> {
   virtual T row_sum(size_t row, T alpha) const;
   virtual T col_sum(size_t col, T alpha) const;
   virtual size_t gpu_mem_amount() const;
+  virtual bool describe(BlockDesc& d) const {
+    if (val_.size() != nnz_ || nnz_ == 0) return false;      // before Initialize()
+    d.kind = BlockDesc::kSparse; d.nnz = nnz_;
+    d.val = val_.data(); d.ptr = ptr_.data(); d.ind = ind_.data();
+    d.val_t = val_t_.data(); d.ptr_t = ptr_t_.data(); d.ind_t = ind_t_.data();
+    return true;
+  }
 
  protected:
   BlockSparse(size_t row, size_t col, size_t nrows, size_t ncols) : Block<T>(row, col, nrows, ncols), nnz_(0) {}

@@ -485,6 +485,46 @@ int prost_hip_cgls_stage_f64(int stage, const prost_hip_cgls_desc* d, void* stre
 /* blocking read-back of the scalar record (synchronises `stream`) */
 int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void* stream);
 
+/* A CG round in FOUR launches for operators made of CSR and gradient blocks (the shapes of block_sparse.cu:146-211 and
+ * block_gradient2d.cu:26-139 / block_gradient3d.cu:25-150): the operator of GemvPrecondK is applied by one kernel per
+ * direction -- the thread that owns an output element evaluates its CSR row / stencil row for every block that covers it, in
+ * block order, as LinearOperator::Eval / EvalAdjoint accumulate them (linearoperator.cu:135-170) -- with the stage that follows
+ * the product as its epilogue, and the two scalar kernels of the round above are folded into the kernels that consume their
+ * results (every workgroup forms alpha / beta / the stopping test of cgls.hpp:297-360 from the partial sums itself):
+ *
+ *   round j:  q = sqrt(Sigma) K t, |q|^2 ; alpha, x += alpha p, r -= alpha q, s = -shift x / sqrt(Tau), t = sqrt(Sigma) r, |x|^2 ;
+ *             s = sqrt(Tau) (s + K^T t), |s|^2 ; beta, stopping test, p = beta p + s, t = sqrt(Tau) p, |p|^2
+ *
+ * `state` is an ARRAY of records here (prost_hip_cgls_state_bytes() each): the INIT stages of prost_hip_cgls_stage write
+ * record 0, round j reads record j and writes record j + 1 (rounds after the stopping test fired only hand the record on), so
+ * a solve of at most R rounds needs R + 1 records and its result is record R (prost_hip_cgls_result_at).  Same per-element
+ * expressions and roundings as the staged round; the partial sums are grouped differently (sums in double).
+ * CSR blocks: one thread per row, sequential sum -- what prost_hip_csr_spmv does for rows of up to 6 entries on average.
+ * Gradient blocks: planar layout (label_first = false). */
+enum { PROST_OP_CSR = 1, PROST_OP_GRAD2D = 2, PROST_OP_GRAD3D = 3 };
+typedef struct prost_hip_op_block {
+  int kind;
+  uint64_t row, col, nrows, ncols;          /* position and size inside the operator (Block::row() ...) */
+  uint64_t nx, ny, L;                       /* gradient blocks */
+  const void* val; const int32_t* ptr; const int32_t* ind;          /* CSR of K   (T values, nrows + 1 row starts) */
+  const void* val_t; const int32_t* ptr_t; const int32_t* ind_t;    /* CSR of K^T (ncols + 1 row starts) */
+} prost_hip_op_block;
+#define PROST_HIP_OP_MAX_BLOCKS 4
+typedef struct prost_hip_fused_op {
+  int nblocks;
+  prost_hip_op_block block[PROST_HIP_OP_MAX_BLOCKS];
+} prost_hip_fused_op;
+/* 1 if the rounds take this operator of m rows and n columns (host-only check, no launch) */
+int prost_hip_fused_op_supported(const prost_hip_fused_op* op, uint64_t m, uint64_t n);
+int prost_hip_cgls_round_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream);
+int prost_hip_cgls_round_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream);
+/* blocking read-back of record `index` of a record array */
+int prost_hip_cgls_result_at(const void* state, int index, prost_hip_cgls_result_t* out, void* stream);
+/* The start of a solve the same way: INIT_X ; [INIT_R ; r += K t ; INIT_R2] ; [s += K^T (sqrt(Sigma) r) ; INIT_S], each bracket
+ * one kernel; sqrt(Sigma) r passes through q (which the first round overwrites).  Writes record 0. */
+int prost_hip_cgls_init_fused_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream);
+int prost_hip_cgls_init_fused_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream);
+
 /* Fused passes of the ADMM outer iteration (BackendADMM::PerformIteration, backend_admm.cu:355-665): each
  * stage applies, per element, the reference functors that touch that element (same expressions, same
  * order) and replaces the device-to-device copies between them.  The caller applies K / K^T in between:
@@ -511,6 +551,14 @@ enum { PROST_ADMM_STAGE_PRE_X = 0, PROST_ADMM_STAGE_PRE_Z, PROST_ADMM_STAGE_PRE_
        PROST_ADMM_STAGE_POST_XZ, PROST_ADMM_STAGE_RES_Z, PROST_ADMM_STAGE_RES_X };
 int prost_hip_admm_stage_f32(int stage, const prost_hip_admm_desc* d, void* stream);
 int prost_hip_admm_stage_f64(int stage, const prost_hip_admm_desc* d, void* stream);
+/* The ADMM outer iteration with the operator inside the stages (prost_hip_admm_stage: same expressions, the caller applies
+ * K between the stages there).  Each bracket is one kernel:
+ *   PRE : PRE_X ; [PRE_Z ; z_dual += K temp3 ; PRE_Z2]
+ *   POST: [POST_X ; the n half of POST_XZ] ; [z_proj = K x_proj ; the m half of POST_XZ]
+ *   RES : [kx = K x_half ; RES_Z] ; [K^T kx (not stored) ; RES_X] ; fold -> out4 */
+enum { PROST_ADMM_FUSED_PRE = 0, PROST_ADMM_FUSED_POST, PROST_ADMM_FUSED_RES };
+int prost_hip_admm_fused_stage_f32(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream);
+int prost_hip_admm_fused_stage_f64(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream);
 
 /* Fused passes of the operator-norm power iteration (Problem::normest, problem.cu:429-500), one round:
  *   NORMEST_A: x_temp = sqrt(tau) (x / norm_x)        (norm_x = 0: no divide -- first round)

@@ -40,6 +40,21 @@ class CglsDesc(C.Structure):
                 ("shift", C.c_double), ("tol", C.c_double), ("host_done", C.c_void_p), ("epoch", C.c_int)]
 
 
+class OpBlock(C.Structure):
+    """prost_hip_op_block"""
+    _fields_ = [("kind", C.c_int), ("row", C.c_uint64), ("col", C.c_uint64), ("nrows", C.c_uint64), ("ncols", C.c_uint64),
+                ("nx", C.c_uint64), ("ny", C.c_uint64), ("L", C.c_uint64),
+                ("val", C.c_void_p), ("ptr", C.c_void_p), ("ind", C.c_void_p), ("val_t", C.c_void_p), ("ptr_t", C.c_void_p), ("ind_t", C.c_void_p)]
+
+
+class FusedOp(C.Structure):
+    """prost_hip_fused_op"""
+    _fields_ = [("nblocks", C.c_int), ("block", OpBlock * 4)]
+
+
+OP_CSR, OP_GRAD2D, OP_GRAD3D = 1, 2, 3
+
+
 class CglsResult(C.Structure):
     _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("indefinite", C.c_int), ("flag", C.c_int),
                 ("norms", C.c_double), ("norms0", C.c_double), ("normx", C.c_double), ("xmax", C.c_double)]

@@ -40,8 +40,14 @@ void BackendADMM<T>::Initialize() {
   CheckHip(prost_hip_malloc((void**)&scal_dev_, 8 * sizeof(double)), "malloc");
   CheckHip(prost_hip_host_alloc((void**)&scal_host_, 8 * sizeof(double)), "host_alloc");
   CheckHip(prost_hip_malloc(&workspace_, prost_hip_reduce_workspace_bytes()), "malloc");
-  CheckHip(prost_hip_malloc(&cg_state_, prost_hip_cgls_state_bytes()), "malloc");
-  CheckHip(prost_hip_memset(cg_state_, 0, prost_hip_cgls_state_bytes(), CurrentStream()), "memset");
+  // one scalar record per CG round + the initial one (prost_hip_cgls_round_*); the staged rounds use record 0 only
+  const size_t records = (size_t)std::max(opts_.cg_max_iter, 0) + 2;
+  CheckHip(prost_hip_malloc(&cg_state_, records * prost_hip_cgls_state_bytes()), "malloc");
+  CheckHip(prost_hip_memset(cg_state_, 0, records * prost_hip_cgls_state_bytes(), CurrentStream()), "memset");
+  fused_rounds_ = false;
+  fused_op_.nblocks = 0;
+  cg_result_index_ = 0;
+  if (opts_.device_cg && opts_.fused_rounds && !opts_.cg_graph) DescribeOperator();
   CheckHip(prost_hip_malloc(&cg_workspace_, prost_hip_cgls_workspace_bytes()), "malloc");
   CheckHip(prost_hip_host_alloc((void**)&cg_done_host_, sizeof(int)), "host_alloc");
   *cg_done_host_ = 0;
@@ -150,6 +156,40 @@ int BackendADMM<T>::Cgls(const device_vector<T>& b, device_vector<T>& x, double 
 }
 
 
+/// The operator as a table of CSR / gradient blocks for prost_hip_cgls_round_*: every block must describe itself as one of
+/// those (plugin blocks, diags, Kronecker blocks, label_first gradients and dualized operators do not), CSR blocks must be the
+/// short-row kind the one-thread-per-row product is meant for (what prost_hip_csr_spmv itself picks up to 6 entries per row).
+template <typename T>
+void BackendADMM<T>::DescribeOperator() {
+  auto linop = this->problem_->linop();
+  if (dynamic_cast<DualLinearOperator<T>*>(linop.get())) return;
+  const auto& blocks = linop->blocks();
+  if (blocks.empty() || blocks.size() > (size_t)PROST_HIP_OP_MAX_BLOCKS) return;
+  prost_hip_fused_op op;
+  op.nblocks = 0;
+  for (const auto& b : blocks) {
+    BlockDesc bd;
+    if (!b->describe(bd)) return;
+    prost_hip_op_block& o = op.block[op.nblocks++];
+    o.row = b->row(); o.col = b->col(); o.nrows = b->nrows(); o.ncols = b->ncols();
+    o.nx = o.ny = o.L = 0;
+    o.val = o.val_t = nullptr; o.ptr = o.ind = o.ptr_t = o.ind_t = nullptr;
+    if (bd.kind == BlockDesc::kSparse) {
+      if ((double)bd.nnz > 6.0 * (double)b->nrows() || (double)bd.nnz > 6.0 * (double)b->ncols()) return;
+      o.kind = PROST_OP_CSR;
+      o.val = bd.val; o.ptr = bd.ptr; o.ind = bd.ind; o.val_t = bd.val_t; o.ptr_t = bd.ptr_t; o.ind_t = bd.ind_t;
+    } else if ((bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D) && !bd.label_first) {
+      o.kind = bd.kind == BlockDesc::kGradient2D ? PROST_OP_GRAD2D : PROST_OP_GRAD3D;
+      o.nx = bd.nx; o.ny = bd.ny; o.L = bd.L;
+    } else {
+      return;
+    }
+  }
+  if (prost_hip_fused_op_supported(&op, this->problem_->nrows(), this->problem_->ncols()) != 1) return;
+  fused_op_ = op;
+  fused_rounds_ = true;
+}
+
 /// The same solve with the CG scalars resident on the device (prost_hip_cgls_stage_*): no host round
 /// trip per iteration.  All maxit rounds are queued unless the pinned stop word shows that the device
 /// already met the stopping test; rounds queued after that point return immediately on the device.
@@ -174,6 +214,21 @@ void BackendADMM<T>::CglsDevice(const device_vector<T>& b, device_vector<T>& x, 
     stage(PROST_CGLS_STEP_S);
     stage(PROST_CGLS_STEP_P);
   };
+  cg_result_index_ = 0;
+  if (fused_rounds_) {
+    // the operator inside the kernels: three launches + two scalar kernels to start, four launches per round; record j + 1
+    // is written by round j
+    CheckHip(Api<T>::cgls_init_fused(&d, &fused_op_, st), "cgls_init_fused");
+    int queued = 0;
+    for (int k = 0; k < maxit; ++k) {
+      if (*static_cast<volatile int*>(cg_done_host_) == d.epoch) break;
+      CheckHip(Api<T>::cgls_round(&d, &fused_op_, k, st), "cgls_round");
+      queued++;
+    }
+    cg_result_index_ = queued;
+    cg_iters_valid_ = false;
+    return;
+  }
   stage(PROST_CGLS_INIT_X);
   stage(PROST_CGLS_INIT_R);
   K->Eval(r, temp3_, 1);
@@ -215,7 +270,7 @@ template <typename T>
 int BackendADMM<T>::last_cg_iterations() {
   if (!cg_iters_valid_ && cg_state_) {
     prost_hip_cgls_result_t res;
-    CheckHip(prost_hip_cgls_result(cg_state_, &res, CurrentStream()), "cgls_result");
+    CheckHip(prost_hip_cgls_result_at(cg_state_, cg_result_index_, &res, CurrentStream()), "cgls_result");
     last_cg_iters_ = res.iterations;
     cg_iters_valid_ = true;
   }
@@ -291,28 +346,44 @@ void BackendADMM<T>::PerformIterationFused() {
   d.out4 = scal_host_;
   auto stage = [&](int which) { CheckHip(Api<T>::admm_stage(which, &d, st), "admm_stage"); };
 
-  stage(PROST_ADMM_STAGE_PRE_X);
-  stage(PROST_ADMM_STAGE_PRE_Z);
-  K->Eval(z_dual_, temp3_, 1);
-  stage(PROST_ADMM_STAGE_PRE_Z2);
+  auto fused = [&](int which) { CheckHip(Api<T>::admm_fused_stage(which, &d, &fused_op_, st), "admm_fused_stage"); };
+  if (fused_rounds_) fused(PROST_ADMM_FUSED_PRE);
+  else {
+    stage(PROST_ADMM_STAGE_PRE_X);
+    stage(PROST_ADMM_STAGE_PRE_Z);
+    K->Eval(z_dual_, temp3_, 1);
+    stage(PROST_ADMM_STAGE_PRE_Z2);
+  }
 
   double cg_tol = opts_.cg_tol_min / std::pow((double)static_cast<T>(iteration_ + 1), opts_.cg_tol_pow);   // :408-410
   cg_tol = std::max(cg_tol, opts_.cg_tol_max);
   CglsDevice(z_dual_, x_proj_, 1, cg_tol, opts_.cg_max_iter, x_half_, z_half_, z_proj_, x_dual_);
 
-  stage(PROST_ADMM_STAGE_POST_X);
-  K->Eval(z_proj_, x_proj_);
-  stage(PROST_ADMM_STAGE_POST_XZ);
-  for (auto& p : prox_g_) p->Eval(x_half_, temp1_, Tr, 1 / rho_);
+  if (fused_rounds_) fused(PROST_ADMM_FUSED_POST);
+  else {
+    stage(PROST_ADMM_STAGE_POST_X);
+    K->Eval(z_proj_, x_proj_);
+    stage(PROST_ADMM_STAGE_POST_XZ);
+  }
+  // an identity prox over the whole variable (prox_zero.cu:37-48: a device copy of the argument) is a buffer exchange here:
+  // temp1 is rewritten from scratch by the next PRE stage (not under a captured graph, which holds the buffer addresses)
+  if (!opts_.cg_graph && prox_g_.size() == 1 && dynamic_cast<ProxZero<T>*>(prox_g_[0].get()) && prox_g_[0]->index() == 0 && prox_g_[0]->size() == n)
+    x_half_.swap(temp1_);
+  else
+    for (auto& p : prox_g_) p->Eval(x_half_, temp1_, Tr, 1 / rho_);
   for (auto& p : prox_f_) p->Eval(z_half_, temp2_, Sl, rho_, true);
 
   iteration_++;
 
   if (iteration_ == 0 || (iteration_ % (size_t)opts_.residual_iter) == 0) {                            // :535-616
-    K->Eval(tmp_m_, x_half_);
-    stage(PROST_ADMM_STAGE_RES_Z);
-    K->EvalAdjoint(tmp_n_, tmp_m_);
-    stage(PROST_ADMM_STAGE_RES_X);                       // the fold writes the four norms to pinned host memory
+    d.x_half = x_half_.data(); d.temp1 = temp1_.data();
+    if (fused_rounds_) fused(PROST_ADMM_FUSED_RES);
+    else {
+      K->Eval(tmp_m_, x_half_);
+      stage(PROST_ADMM_STAGE_RES_Z);
+      K->EvalAdjoint(tmp_n_, tmp_m_);
+      stage(PROST_ADMM_STAGE_RES_X);                     // the fold writes the four norms to pinned host memory
+    }
     CheckHip(prost_hip_stream_synchronize(st), "sync");
     FinishResiduals((double)(T)scal_host_[0], (double)(T)scal_host_[1], (double)(T)scal_host_[2], (double)(T)scal_host_[3]);
   }

@@ -347,6 +347,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       o.cg_tol_min = GetScalarFromField(d, "cg_tol_min"); o.cg_tol_max = GetScalarFromField(d, "cg_tol_max");
       if (prost_value_field(d, "device_cg")) o.device_cg = GetScalarFromField(d, "device_cg") > 0.;
       if (prost_value_field(d, "cg_graph")) o.cg_graph = GetScalarFromField(d, "cg_graph") > 0.;
+      if (prost_value_field(d, "fused_rounds")) o.fused_rounds = GetScalarFromField(d, "fused_rounds") > 0.;
       return new BackendADMM<T>(o);
     };
   }

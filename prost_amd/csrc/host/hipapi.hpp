@@ -54,6 +54,9 @@ template <typename T> struct Api;
     static constexpr auto axpy = prost_hip_axpy_##S;                              \
     static constexpr auto admm_elem = prost_hip_admm_elem_##S;                    \
     static constexpr auto cgls_stage = prost_hip_cgls_stage_##S;                  \
+    static constexpr auto cgls_round = prost_hip_cgls_round_##S;                  \
+    static constexpr auto cgls_init_fused = prost_hip_cgls_init_fused_##S;        \
+    static constexpr auto admm_fused_stage = prost_hip_admm_fused_stage_##S;      \
     static constexpr auto admm_stage = prost_hip_admm_stage_##S;                  \
     static constexpr auto normest_stage = prost_hip_normest_stage_##S;            \
     static constexpr auto normest_grad_round = prost_hip_normest_grad_round_##S;  \

@@ -59,10 +59,22 @@ __global__ void __launch_bounds__(kBlock) cg_stage_kernel(F f, size_t n0, size_t
 }
 
 // one workgroup: sum of the first component of `g` partial pairs, fixed association order
-__device__ __forceinline__ double fold_region(const double* part, unsigned g) {
-  __shared__ double s_w[kBlock / kWave];
+// (loads in batches of eight per thread, all issued before the first add: a loop of load-add-load-add pays one cache latency
+// per iteration, and every workgroup of the consuming kernels sits in this fold before it can start)
+__device__ __forceinline__ double fold_strided(const double* __restrict__ part, unsigned g, unsigned stride) {
   double a = 0;
-  for (unsigned i = threadIdx.x; i < g; i += kBlock) a += part[2 * i];
+  for (unsigned base = threadIdx.x; base < g; base += 8 * kBlock) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const unsigned i = base + k * kBlock; v[k] = i < g ? part[(size_t)stride * i] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) a += v[k];
+  }
+  return a;
+}
+__device__ __forceinline__ double fold_region(const double* part, unsigned g, unsigned stride = 2) {
+  __shared__ double s_w[kBlock / kWave];
+  double a = fold_strided(part, g, stride);
   a = wave_sum(a);
   __syncthreads();
   if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = a;
@@ -73,14 +85,52 @@ __device__ __forceinline__ double fold_region(const double* part, unsigned g) {
   return t;
 }
 
+// the same for two COMPACT arrays (one double per workgroup) at once: one pass, both sets of loads in flight together, one pair
+// of barriers; association order per array as in fold_region
+__device__ __forceinline__ void fold_region2(const double* __restrict__ pa, unsigned ga, const double* __restrict__ pb, unsigned gb, double& ra, double& rb) {
+  __shared__ double s_a[kBlock / kWave], s_b[kBlock / kWave];
+  double a = 0, b = 0;
+  const unsigned gmax = ga > gb ? ga : gb;
+  for (unsigned base = threadIdx.x; base < gmax; base += 8 * kBlock) {
+    double va[8], vb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const unsigned i = base + k * kBlock; va[k] = i < ga ? pa[i] : 0.0; vb[k] = i < gb ? pb[i] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) { a += va[k]; b += vb[k]; }
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_a[threadIdx.x / kWave] = a; s_b[threadIdx.x / kWave] = b; }
+  __syncthreads();
+  double ta = 0, tb = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; w++) { ta += s_a[w]; tb += s_b[w]; }
+  ra = ta; rb = tb;
+}
+
+// one double per workgroup, compact (the sums the fused rounds fold in every workgroup of the next kernel)
+__device__ __forceinline__ void block_sum1_store(double a, double* __restrict__ partial, unsigned slot) {
+  __shared__ double s_c[kBlock / kWave];
+  a = wave_sum(a);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_c[threadIdx.x / kWave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; w++) t += s_c[w];
+    partial[slot] = t;
+  }
+}
+
 enum { kScalarsInitX = 0, kScalarsInitS, kScalarsAlpha, kScalarsBeta };
-struct ScalarArgs { double shift, tol, eps; unsigned g0, g1; int* host_done; int epoch; };
+struct ScalarArgs { double shift, tol, eps; unsigned g0, g1; int* host_done; int epoch; unsigned stride; };   // stride 2: partial pairs, 1: compact
 
 // the scalar recurrences of cgls.hpp, in double, values narrowed to T where the reference narrows them
 template <class T, int WHICH>
 __global__ void __launch_bounds__(kBlock) cg_scalar_kernel(CgState* stp, const double* ws, ScalarArgs a) {
   if (WHICH >= kScalarsAlpha && stp->done) return;
-  const double s0 = fold_region(region(const_cast<double*>(ws), WHICH == kScalarsInitX ? kRegionX : WHICH == kScalarsAlpha ? kRegionQ : kRegionS), a.g0);
+  const double s0 = fold_region(region(const_cast<double*>(ws), WHICH == kScalarsInitX ? kRegionX : WHICH == kScalarsAlpha ? kRegionQ : kRegionS), a.g0, a.stride);
   const double s1 = WHICH == kScalarsAlpha ? fold_region(region(const_cast<double*>(ws), kRegionP), a.g1)
                   : WHICH == kScalarsBeta ? fold_region(region(const_cast<double*>(ws), kRegionX), a.g1) : 0.;
   if (threadIdx.x != 0) return;
@@ -217,7 +267,7 @@ template <class T> struct StepQ {
 template <class T> struct StepXR {
   static constexpr bool kSkipWhenDone = true, kTwoRanges = true;
   static constexpr int kRegion = kRegionX, kRegion2 = -1;
-  T* x; const T* p; T* s; const T* tau; T* r; const T* q; const T* sigma; T* t; T negshift;
+  T* x; const T* p; T* s; const T* tau; T* r; const T* q; const T* sigma; T* t; T negshift;     // s == nullptr: the consumer forms it from x
   T alpha, neg_alpha;
   __device__ void load(const CgState* st) { alpha = (T)st->alpha; neg_alpha = (T)st->neg_alpha; }
   template <int V> __device__ void range0(size_t i, double& sa, double&) const {
@@ -229,7 +279,8 @@ template <class T> struct StepXR {
       sv[j] = (negshift / ((T)1 * t_sqrt(dv[j]))) * xv[j];
       sa += (double)xv[j] * (double)xv[j];
     }
-    stv<T, V>(x + i, xv); stv<T, V>(s + i, sv);
+    stv<T, V>(x + i, xv);
+    if (s) stv<T, V>(s + i, sv);
   }
   template <int V> __device__ void range1(size_t i, double&, double&) const {
     T rv[V], qv[V], dv[V], tv[V];
@@ -522,8 +573,8 @@ static int launch_stage(const char* name, F f, size_t n0, size_t n1, bool vec, c
 }
 
 template <class T, int WHICH>
-static int launch_scalars(const prost_hip_cgls_desc* d, unsigned g0, unsigned g1, hipStream_t st) {
-  ScalarArgs a{d->shift, d->tol, (double)std::numeric_limits<T>::epsilon(), g0, g1, d->host_done, d->epoch};
+static int launch_scalars(const prost_hip_cgls_desc* d, unsigned g0, unsigned g1, hipStream_t st, unsigned stride = 2) {
+  ScalarArgs a{d->shift, d->tol, (double)std::numeric_limits<T>::epsilon(), g0, g1, d->host_done, d->epoch, stride};
   hipLaunchKernelGGL((cg_scalar_kernel<T, WHICH>), dim3(1), dim3(kBlock), 0, st, static_cast<CgState*>(d->state),
                      static_cast<const double*>(d->workspace), a);
   PH_LAUNCH_END("cgls scalars");
@@ -629,6 +680,676 @@ static int normest_stage(int stage, const prost_hip_normest_desc* d, void* strea
   }
 }
 
+
+// ---- fused operator: CG rounds in FOUR launches, ADMM outer stages with the operator inside -------------------
+// Kernel durations, not launch gaps, are what the staged sequence above is made of at the C4 size (n = 2 Mi, m = 5 Mi:
+// profiles/r01_c4_admm_kernel_stats.csv -- per CG round 90 us in ten kernels, the device never idle): STEP_XR moves its
+// 140 MB at 6.1 TB/s, but the operator is four small kernels at ~3.2 TB/s, each product is written unscaled and re-read by
+// the stage that scales it, and two one-workgroup scalar kernels cost 5.8 us each.  Here
+//   * the operator is applied by ONE kernel per direction whatever its blocks are: the thread that owns VEC consecutive
+//     output elements evaluates their CSR rows / gradient stencil rows for every block that covers them, in block order,
+//     with the expressions of csr_spmv_kernel<., 1, .> / grad_fwd_kernel / grad_adj_kernel (LinearOperator::Eval: zero
+//     fill, then EvalAdd per block), and the stage that follows the product is its EPILOGUE -- the product never reaches
+//     memory unscaled;
+//   * the scalar kernels are gone: every workgroup of the CONSUMING kernel folds the partial sums itself (at most 2048
+//     values, identical order in every workgroup, hence identical results) and forms alpha / beta / the stopping test in
+//     double exactly as cg_scalar_kernel does; workgroup 0 records the result;
+//   * the scalar record is an ARRAY: round j reads record j and writes record j + 1, so no kernel reads a field that
+//     another workgroup of the same launch writes.
+// Round:  OP_FWD<FwdQ>  |  STEP_XR2 (alpha)  |  OP_ADJ<AdjS>  |  STEP_P2 (beta, stopping test)
+struct OpBlockDev {
+  int kind;
+  unsigned long long row, col, nrows, ncols, nx, ny, L;
+  const void* val; const int32_t* ptr; const int32_t* ind;
+  const void* val_t; const int32_t* ptr_t; const int32_t* ind_t;
+};
+struct FusedOpDev { int nblocks; OpBlockDev b[PROST_HIP_OP_MAX_BLOCKS]; };
+
+// a[j] belongs to element j * 64 + lane of a 64 VEC-element range; out[c] := element VEC * lane + c (all 64 lanes active)
+template <class T, int VEC>
+__device__ __forceinline__ void wave_untranspose(const T (&a)[VEC], T (&out)[VEC], unsigned lane) {
+  const unsigned src_j = (VEC * lane) / kWave;          // the same for the VEC elements of a lane: VEC divides 64
+#pragma unroll
+  for (int c = 0; c < VEC; c++) {
+    const int src_lane = (int)((VEC * lane + c) & (kWave - 1));
+    T v = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { const T tmp = __shfl(a[j], src_lane, kWave); if ((unsigned)j == src_j) v = tmp; }
+    out[c] = v;
+  }
+}
+
+// sum[j] = (A rhs)_(r_j), j < VEC, for VEC rows of a CSR matrix -- ONE loop over the entry positions with the VEC rows side
+// by side, so that the loads of the VEC rows (row starts, then values / indices, then gathered operands: three dependent
+// levels) are in flight together instead of one row after the other.  Per row the entries are summed in order, as
+// csr_spmv_kernel<T, 1, .> does.
+template <class T, int VEC>
+__device__ __forceinline__ void csr_rows(const T* __restrict__ val, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ind,
+                                         const T* __restrict__ rhs, const size_t (&r)[VEC], T (&sum)[VEC]) {
+  int32_t b[VEC], e[VEC], len = 0;
+#pragma unroll
+  for (int j = 0; j < VEC; j++) { b[j] = ptr[r[j]]; e[j] = ptr[r[j] + 1]; }
+#pragma unroll
+  for (int j = 0; j < VEC; j++) { sum[j] = 0; len = e[j] - b[j] > len ? e[j] - b[j] : len; }
+  for (int32_t st = 0; st < len; st++) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const int32_t k = b[j] + st;
+      if (k < e[j]) sum[j] += val[k] * rhs[ind[k]];
+    }
+  }
+}
+// the contribution of one CSR block (or its transpose) to the VEC elements starting at local index r0 of this lane; `wave0`: local
+// index of lane 0's first element, `whole`: the wavefront's 64 VEC elements all lie inside the block -- then the lanes take the rows
+// transposed (lane, lane + 64, ...: neighbouring lanes load neighbouring rows) and the sums are shuffled back
+template <class T, int VEC>
+__device__ __forceinline__ void csr_contrib(const T* __restrict__ val, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ind,
+                                            const T* __restrict__ rhs, size_t r0, size_t wave0, bool whole, T (&sum)[VEC]) {
+  size_t r[VEC];
+  if (VEC > 1 && whole) {
+    const unsigned lane = threadIdx.x & (kWave - 1);
+    T st[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) r[j] = wave0 + (size_t)j * kWave + lane;
+    csr_rows<T, VEC>(val, ptr, ind, rhs, r, st);
+    wave_untranspose<T, VEC>(st, sum, lane);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) r[j] = r0 + j;
+    csr_rows<T, VEC>(val, ptr, ind, rhs, r, sum);
+  }
+}
+
+// kv[0..VEC) = (K rhs)_(i .. i+VEC).  VEC > 1: i, every block's row / col / nrows and every gradient block's ny and plane
+// size are multiples of VEC (host-checked), so the VEC rows lie in the same blocks, the same component plane and image column.
+// w0 = the i of lane 0 (wave-uniform); VEC > 1 callers guarantee that all 64 lanes are active.
+template <class T, int VEC>
+__device__ __forceinline__ void op_fwd_rows(const FusedOpDev& op, size_t i, size_t w0, const T* __restrict__ t, T (&kv)[VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j++) kv[j] = 0;
+  for (int b = 0; b < op.nblocks; b++) {
+    const OpBlockDev& B = op.b[b];
+    if (i < B.row || i >= B.row + B.nrows) continue;
+    const size_t r = i - B.row;
+    const T* rhs = t + B.col;
+    if (B.kind == PROST_OP_CSR) {
+      const bool whole = VEC > 1 && w0 >= B.row && w0 + (size_t)kWave * VEC <= B.row + B.nrows;
+      T sum[VEC];
+      csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, rhs, r, w0 - B.row, whole, sum);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) kv[j] = kv[j] + sum[j];
+    } else {
+      const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, N = slice * (unsigned)B.L;
+      const unsigned r32 = (unsigned)r;
+      const unsigned c = r32 / N, idx = r32 - c * N;
+      T cur[VEC], g[VEC];
+      ldv<T, VEC>(rhs + idx, cur);
+      if (c == 0) {
+        const unsigned x = (idx / ny) % nx;
+        T nb[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) nb[j] = 0;
+        if (x < nx - 1) ldv<T, VEC>(rhs + idx + ny, nb);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) g[j] = x < nx - 1 ? nb[j] - cur[j] : (T)0;
+      } else if (c == 1) {
+        const unsigned y = idx % ny;
+        const T below = y + VEC < ny ? rhs[idx + VEC] : (T)0;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const T dn = j + 1 < VEC ? cur[(j + 1) % VEC] : below;
+          g[j] = y + j < ny - 1 ? dn - cur[j] : (T)0;
+        }
+      } else {
+        const unsigned l = idx / slice;
+        T up[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) up[j] = 0;
+        if (l < (unsigned)B.L - 1) ldv<T, VEC>(rhs + idx + slice, up);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) g[j] = l < (unsigned)B.L - 1 ? up[j] - cur[j] : -cur[j];      // Dirichlet (block_gradient3d.cu:73-76)
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; j++) kv[j] = kv[j] + g[j];
+    }
+  }
+}
+// v[0..VEC) += (K^T rhs)_(j .. j+VEC), blocks in order (EvalAdjointAdd per block)
+template <class T, int VEC>
+__device__ __forceinline__ void op_adj_cols(const FusedOpDev& op, size_t jg, size_t w0, const T* __restrict__ t, T (&v)[VEC]) {
+  for (int b = 0; b < op.nblocks; b++) {
+    const OpBlockDev& B = op.b[b];
+    if (jg < B.col || jg >= B.col + B.ncols) continue;
+    const size_t cidx = jg - B.col;
+    const T* rhs = t + B.row;
+    if (B.kind == PROST_OP_CSR) {
+      const bool whole = VEC > 1 && w0 >= B.col && w0 + (size_t)kWave * VEC <= B.col + B.ncols;
+      T sum[VEC];
+      csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - B.col, whole, sum);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) v[j] = v[j] + sum[j];
+    } else {
+      const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, idx = (unsigned)cidx;
+      const size_t N = (size_t)slice * B.L;
+      const unsigned y = idx % ny, x = (idx / ny) % nx;
+      T px[VEC], pxm[VEC], py[VEC];
+      ldv<T, VEC>(rhs + idx, px);
+      ldv<T, VEC>(rhs + N + idx, py);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) pxm[j] = 0;
+      if (x > 0) ldv<T, VEC>(rhs + idx - ny, pxm);
+      const T above = y > 0 ? rhs[N + idx - 1] : (T)0;
+      T pl[VEC], plm[VEC];
+      unsigned l = 0;
+      if (B.kind == PROST_OP_GRAD3D) {
+        l = idx / slice;
+        ldv<T, VEC>(rhs + 2 * N + idx, pl);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) plm[j] = 0;
+        if (l > 0) ldv<T, VEC>(rhs + 2 * N + idx - slice, plm);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        T divx, divy;
+        if (y + j < ny - 1) divy = py[j]; else divy = 0;
+        if (y + j > 0) divy -= j > 0 ? py[(j + VEC - 1) % VEC] : above;
+        if (x < nx - 1) divx = px[j]; else divx = 0;
+        if (x > 0) divx -= pxm[j];
+        T sdiv;
+        if (B.kind == PROST_OP_GRAD3D) {
+          T divl = pl[j];
+          if (l > 0) divl -= plm[j];
+          sdiv = divx + divy + divl;
+        } else {
+          sdiv = divx + divy;
+        }
+        v[j] = v[j] - sdiv;                     // adjoint is minus the divergence
+      }
+    }
+  }
+}
+
+// out = E(K in) / out = E(v0 + K^T in) with the stage functor E as epilogue; `count` output elements; E::kRegion >= 0: one
+// partial (pair) per workgroup.  E::prologue runs in every thread of every workgroup before the loop (block-wide folds).
+// A wavefront takes 64 VEC consecutive elements per step, lane l the VEC elements from (w0 + l) VEC; the last, partly filled
+// step of the range and the count % VEC tail run one element per lane.
+template <class T, int VEC, bool ADJ, class E>
+__global__ void __launch_bounds__(kBlock) op_stage_kernel(FusedOpDev op, E e, const T* __restrict__ in, size_t count, const CgState* cur, double* ws) {
+  if (E::kSkipWhenDone && cur->done) return;
+  e.prologue(cur, ws);
+  double sa = 0, sb = 0;
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  const size_t nv = VEC > 1 ? (count / ((size_t)VEC * kWave)) * kWave : count;          // vector groups in full wavefront steps
+  for (size_t i0 = (size_t)blockIdx.x * kBlock + (threadIdx.x - lane); i0 < nv; i0 += (size_t)gridDim.x * kBlock) {
+    const size_t i = (i0 + lane) * VEC;
+    T kv[VEC];
+    if (VEC > 1 || i < count) {
+      if constexpr (ADJ) { e.template init<VEC>(i, kv); op_adj_cols<T, VEC>(op, i, i0 * VEC, in, kv); }
+      else op_fwd_rows<T, VEC>(op, i, i0 * VEC, in, kv);
+      e.template apply<VEC>(i, kv, sa, sb);
+    }
+  }
+  if (VEC > 1) {
+    for (size_t i = nv * VEC + (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) {
+      T kv[1];
+      if constexpr (ADJ) { e.template init<1>(i, kv); op_adj_cols<T, 1>(op, i, i, in, kv); }
+      else op_fwd_rows<T, 1>(op, i, i, in, kv);
+      e.template apply<1>(i, kv, sa, sb);
+    }
+  }
+  if (E::kRegion >= 0) {
+    if (E::kPairs) {
+      block_sum2_store(sa, sb, region(ws, E::kRegion), blockIdx.x);
+    } else {
+      block_sum1_store(sa, region(ws, E::kRegion), blockIdx.x);
+      if (E::kRegion2 >= 0 && threadIdx.x == 0) region(ws, E::kRegion2)[blockIdx.x] = region(ws, E::kRegion)[blockIdx.x];
+    }
+  }
+}
+
+// ---- epilogues (the stage structs above, fed with the product instead of reading it back) ----
+// FWD_Q (m):  q = 1 sqrt(Sigma) (K t);  |q|^2                                   [K->Eval(q, t, 0) ; STEP_Q]
+template <class T> struct EpiFwdQ {
+  static constexpr bool kPairs = false;
+  static constexpr bool kSkipWhenDone = true;
+  static constexpr int kRegion = kRegionQ, kRegion2 = -1;
+  T* q; const T* sigma;
+  __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double&) const {
+    T dv[V], qv[V];
+    ldv<T, V>(sigma + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) { qv[j] = (T)1 * t_sqrt(dv[j]) * kv[j]; sa += (double)qv[j] * (double)qv[j]; }
+    stv<T, V>(q + i, qv);
+  }
+};
+// ADJ_S (n):  s = 1 sqrt(Tau) (s0 + K^T t) with s0 = (-shift / (1 sqrt(Tau))) x formed here (STEP_XR's expression: the vector
+//             STEP_XR would write and this kernel read back);  |s|^2            [K->EvalAdjoint(s, t, 1) ; STEP_S]
+template <class T> struct EpiAdjS {
+  static constexpr bool kPairs = false;
+  static constexpr bool kSkipWhenDone = true;
+  static constexpr int kRegion = kRegionS, kRegion2 = -1;
+  T* s; const T* tau; const T* x; T negshift;
+  __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void init(size_t i, T (&v)[V]) const {
+    T xv[V], dv[V];
+    ldv<T, V>(x + i, xv); ldv<T, V>(tau + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) v[j] = (negshift / ((T)1 * t_sqrt(dv[j]))) * xv[j];
+  }
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double&) const {
+    T dv[V], sv[V];
+    ldv<T, V>(tau + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) { sv[j] = (T)1 * t_sqrt(dv[j]) * kv[j]; sa += (double)sv[j] * (double)sv[j]; }
+    stv<T, V>(s + i, sv);
+  }
+};
+// INIT_RK (m):  r = (1 / (-1 sqrt(Sigma))) b ; r += K t ; r = normx > 0 ? -1 sqrt(Sigma) r : b ; tm = sqrt(Sigma) r
+//               [INIT_R ; K->Eval(r, t, 1) ; INIT_R2 -- tm goes to its own buffer: t is being read by other threads]
+template <class T> struct EpiInitRK {
+  static constexpr bool kPairs = false;
+  static constexpr bool kSkipWhenDone = false;
+  static constexpr int kRegion = -1, kRegion2 = -1;
+  const T* b; const T* sigma; T* r; T* tm; bool nonzero;
+  __device__ void prologue(const CgState* st, double*) { nonzero = st->normx > 0.; }
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double&, double&) const {
+    T bv[V], dv[V], rv[V], tv[V];
+    ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(dv[j]);
+      T rr = ((T)1 / ((T)-1 * sq)) * bv[j];
+      rr = rr + kv[j];
+      rr = nonzero ? (T)-1 * sq * rr : bv[j];
+      rv[j] = rr;
+      tv[j] = sq * rr;
+    }
+    stv<T, V>(r + i, rv); stv<T, V>(tm + i, tv);
+  }
+};
+// INIT_SK (n):  s = 1 sqrt(Tau) (s + K^T tm) ; p = s ; t = sqrt(Tau) p ; |s|^2 = |p|^2       [K->EvalAdjoint(s, tm, 1) ; INIT_S]
+template <class T> struct EpiInitSK {
+  static constexpr bool kPairs = false;
+  static constexpr bool kSkipWhenDone = false;
+  static constexpr int kRegion = kRegionS, kRegion2 = kRegionP;
+  T* s; T* p; T* t; const T* tau;
+  __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void init(size_t i, T (&v)[V]) const { ldv<T, V>(s + i, v); }
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double&) const {
+    T dv[V], sv[V], tv[V];
+    ldv<T, V>(tau + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(dv[j]);
+      sv[j] = (T)1 * sq * kv[j];
+      tv[j] = sq * sv[j];
+      sa += (double)sv[j] * (double)sv[j];
+    }
+    stv<T, V>(s + i, sv); stv<T, V>(p + i, sv); stv<T, V>(t + i, tv);
+  }
+};
+// PRE_ZK (m):  temp2 = sqrt(Sigma) (z_half + z_dual) ; z_dual = (1 / (-1 sqrt(Sigma))) temp2 ; z_dual += K temp3 ;
+//              z_dual = -1 sqrt(Sigma) z_dual                                    [PRE_Z ; K->Eval(z_dual, temp3, 1) ; PRE_Z2]
+template <class T> struct EpiPreZK {
+  static constexpr bool kPairs = false;
+  static constexpr bool kSkipWhenDone = false;
+  static constexpr int kRegion = -1, kRegion2 = -1;
+  const T* z_half; T* z_dual; const T* sigma; T* temp2;
+  __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double&, double&) const {
+    T a[V], bb[V], d[V], o[V], z[V];
+    ldv<T, V>(z_half + i, a); ldv<T, V>(z_dual + i, bb); ldv<T, V>(sigma + i, d);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(d[j]);
+      o[j] = sq * (a[j] + bb[j]);
+      T zz = ((T)1 / ((T)-1 * sq)) * o[j];
+      zz = zz + kv[j];
+      z[j] = (T)-1 * sq * zz;
+    }
+    stv<T, V>(temp2 + i, o); stv<T, V>(z_dual + i, z);
+  }
+};
+// POST_ZK (m):  z_proj = K x_proj ; z_dual = temp2 / sqrt(Sigma) - z_proj ; temp2 = z_proj - z_dual
+//               [K->Eval(z_proj, x_proj) ; the m half of POST_XZ]
+template <class T> struct EpiPostZK {
+  static constexpr bool kPairs = false;
+  static constexpr bool kSkipWhenDone = false;
+  static constexpr int kRegion = -1, kRegion2 = -1;
+  T* z_proj; T* z_dual; T* temp2; const T* sigma;
+  __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double&, double&) const {
+    T a[V], d[V], u[V], o[V];
+    ldv<T, V>(temp2 + i, a); ldv<T, V>(sigma + i, d);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      u[j] = a[j] / t_sqrt(d[j]) - kv[j];
+      o[j] = kv[j] - u[j];
+    }
+    stv<T, V>(z_proj + i, kv); stv<T, V>(z_dual + i, u); stv<T, V>(temp2 + i, o);
+  }
+};
+// POST_X2 (n, elementwise):  temp3 = x_proj ; x_proj = sqrt(Tau) (x_proj + temp1) ; x_dual = temp1 sqrt(Tau) - x_proj ;
+//               temp1 = x_proj - x_dual                                          [POST_X ; the n half of POST_XZ]
+template <class T> struct AdmmPostX2 {
+  static constexpr bool kSkipWhenDone = false, kTwoRanges = false;
+  static constexpr int kRegion = -1, kRegion2 = -1;
+  T* x_proj; T* temp1; const T* tau; T* temp3; T* x_dual;
+  __device__ void load(const CgState*) {}
+  template <int V> __device__ void range0(size_t i, double&, double&) const {
+    T x[V], a[V], d[V], o[V], u[V], w[V];
+    ldv<T, V>(x_proj + i, x); ldv<T, V>(temp1 + i, a); ldv<T, V>(tau + i, d);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(d[j]);
+      o[j] = sq * (x[j] + a[j]);
+      u[j] = a[j] * sq - o[j];
+      w[j] = o[j] - u[j];
+    }
+    stv<T, V>(temp3 + i, x); stv<T, V>(x_proj + i, o); stv<T, V>(x_dual + i, u); stv<T, V>(temp1 + i, w);
+  }
+  template <int V> __device__ void range1(size_t, double&, double&) const {}
+};
+// RES_ZK (m):  kx = K x_half ; RES_Z (primal residual / variable norm sums; y = get_dual(...) stored in kx)
+template <class T> struct EpiResZK {
+  static constexpr bool kPairs = true;
+  static constexpr bool kSkipWhenDone = false;
+  static constexpr int kRegion = kRegionQ, kRegion2 = -1;
+  T* kx; const T* z_half; const T* z_proj; const T* z_dual; const T* sigma; T rho;
+  __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double& sb) const {
+    T h[V], pj[V], du[V], d[V], y[V];
+    ldv<T, V>(z_half + i, h); ldv<T, V>(z_proj + i, pj); ldv<T, V>(z_dual + i, du); ldv<T, V>(sigma + i, d);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(d[j]);
+      const T pr = sq * ((T)1.0 * kv[j] + (T)-1.0 * h[j]);
+      const T pv = sq * h[j];
+      sa += (double)pr * (double)pr;
+      sb += (double)pv * (double)pv;
+      y[j] = get_dual<T>(rho, d[j], (T)1, h[j], pj[j], du[j]);
+    }
+    stv<T, V>(kx + i, y);
+  }
+};
+// RES_XK (n):  kty = K^T y (not stored) ; RES_X (dual residual / variable norm sums)
+template <class T> struct EpiResXK {
+  static constexpr bool kPairs = true;
+  static constexpr bool kSkipWhenDone = false;
+  static constexpr int kRegion = kRegionP, kRegion2 = -1;
+  const T* x_half; const T* x_proj; const T* x_dual; const T* tau; T rho;
+  __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void init(size_t, T (&v)[V]) const {
+#pragma unroll
+    for (int j = 0; j < V; j++) v[j] = 0;
+  }
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double& sb) const {
+    T h[V], pj[V], du[V], d[V];
+    ldv<T, V>(x_half + i, h); ldv<T, V>(x_proj + i, pj); ldv<T, V>(x_dual + i, du); ldv<T, V>(tau + i, d);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(d[j]);
+      const T w = get_dual<T>(rho, d[j], (T)-1, h[j], pj[j], du[j]);
+      const T dv = sq * w;
+      const T dr = sq * ((T)1.0 * kv[j] + w);
+      sa += (double)dr * (double)dr;
+      sb += (double)dv * (double)dv;
+    }
+  }
+};
+
+struct RoundScalars { double shift, eps; unsigned g_a, g_b; int* host_done; };
+
+// STEP_XR with alpha formed here from the partials of |q|^2 (g_a pairs) and |p|^2 (g_b pairs)   (cgls.hpp:297-325)
+template <class T, int VEC>
+__global__ void __launch_bounds__(kBlock) cg_step_xr2_kernel(StepXR<T> f, size_t n, size_t m, const CgState* cur, CgState* nxt, double* ws, RoundScalars a) {
+  if (cur->done) return;
+  // operands of the first element group requested before the fold (see cg_step_p2_kernel)
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, stride = (size_t)gridDim.x * kBlock;
+  const size_t nvn = n / VEC;
+  T xv[VEC], pv[VEC], dv[VEC];
+  const bool first = tid < nvn;
+  if (first) { ldv<T, VEC>(f.x + tid * VEC, xv); ldv<T, VEC>(f.p + tid * VEC, pv); ldv<T, VEC>(f.tau + tid * VEC, dv); }
+  double s0, s1;
+  fold_region2(region(ws, kRegionQ), a.g_a, region(ws, kRegionP), a.g_b, s0, s1);
+  const double normq = sqrt(s0), normp = sqrt(s1);
+  double dlt = normq * normq + a.shift * normp * normp;
+  const int indefinite = dlt <= 0. ? 1 : 0;
+  if (dlt == 0.) dlt = a.eps;
+  f.alpha = (T)(cur->gamma / dlt);
+  f.neg_alpha = (T)(-cur->gamma / dlt);
+  if (blockIdx.x == 0 && threadIdx.x == 0) nxt->indefinite = cur->indefinite | indefinite;
+  double sa = 0, sb = 0;
+  if (first) {                                       // StepXR::range0 on the prefetched operands
+    T sv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      xv[j] = f.alpha * pv[j] + xv[j];
+      sv[j] = (f.negshift / ((T)1 * t_sqrt(dv[j]))) * xv[j];
+      sa += (double)xv[j] * (double)xv[j];
+    }
+    stv<T, VEC>(f.x + tid * VEC, xv);
+    if (f.s) stv<T, VEC>(f.s + tid * VEC, sv);
+  }
+  for (size_t i = tid + stride; i < nvn; i += stride) f.template range0<VEC>(i * VEC, sa, sb);
+  if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < n - nvn * VEC) f.template range0<1>(nvn * VEC + threadIdx.x, sa, sb);
+  {
+    const size_t nv = m / VEC;
+    for (size_t i = tid; i < nv; i += stride) f.template range1<VEC>(i * VEC, sa, sb);
+    if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < m - nv * VEC) f.template range1<1>(nv * VEC + threadIdx.x, sa, sb);
+  }
+  block_sum1_store(sa, region(ws, kRegionX), blockIdx.x);
+}
+// STEP_P with beta and the stopping test formed here from the partials of |s|^2 (g_a) and |x|^2 (g_b)   (cgls.hpp:326-360);
+// workgroup 0 writes the next record.  A round that finds the solve finished only hands the record on.
+template <class T, int VEC>
+__global__ void __launch_bounds__(kBlock) cg_step_p2_kernel(StepP<T> f, size_t n, const CgState* cur, CgState* nxt, double* ws, RoundScalars a) {
+  if (cur->done) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nxt = *cur;
+    return;
+  }
+  // the operands of this thread's first element group are requested BEFORE the fold: they do not depend on beta, and the fold
+  // (a cache latency + two barriers in every workgroup) would otherwise sit in front of the first byte this kernel streams
+  const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, stride = (size_t)gridDim.x * kBlock;
+  const size_t nv = n / VEC;
+  T pv[VEC], sv[VEC], dv[VEC];
+  const bool first = tid < nv;
+  if (first) { ldv<T, VEC>(f.p + tid * VEC, pv); ldv<T, VEC>(f.s + tid * VEC, sv); ldv<T, VEC>(f.tau + tid * VEC, dv); }
+  double s0, s1;
+  fold_region2(region(ws, kRegionS), a.g_a, region(ws, kRegionX), a.g_b, s0, s1);
+  const double norms = sqrt(s0), gamma = norms * norms, normx = sqrt(s1);
+  f.beta = (T)(gamma / cur->gamma);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int indefinite = nxt->indefinite;          // written by this round's STEP_XR2
+    CgState r = *cur;
+    r.indefinite = indefinite;
+    r.norms = norms; r.gamma = gamma; r.beta = (double)f.beta; r.normx = normx;
+    r.xmax = cur->xmax > normx ? cur->xmax : normx;
+    if ((norms <= cur->norms0 * cur->tol) || (normx * cur->tol >= 1.)) {
+      r.done = 1;
+      if (a.host_done) __hip_atomic_store(a.host_done, cur->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      r.k = cur->k + 1;
+    }
+    *nxt = r;
+  }
+  double sa = 0, sb = 0;
+  if (first) {                                       // StepP::range0 on the prefetched operands
+    T tv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      pv[j] = f.beta * pv[j] + sv[j];
+      tv[j] = t_sqrt(dv[j]) * pv[j];
+      sa += (double)pv[j] * (double)pv[j];
+    }
+    stv<T, VEC>(f.p + tid * VEC, pv); stv<T, VEC>(f.t + tid * VEC, tv);
+  }
+  for (size_t i = tid + stride; i < nv; i += stride) f.template range0<VEC>(i * VEC, sa, sb);
+  if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < n - nv * VEC) f.template range0<1>(nv * VEC + threadIdx.x, sa, sb);
+  block_sum1_store(sa, region(ws, kRegionP), blockIdx.x);
+}
+
+static bool fused_op_ok(const prost_hip_fused_op* op, uint64_t m, uint64_t n) {
+  if (!op || op->nblocks < 1 || op->nblocks > PROST_HIP_OP_MAX_BLOCKS) return false;
+  for (int b = 0; b < op->nblocks; b++) {
+    const prost_hip_op_block& B = op->block[b];
+    if (B.nrows == 0 || B.ncols == 0 || B.row + B.nrows > m || B.col + B.ncols > n) return false;
+    if (B.kind == PROST_OP_CSR) {
+      if (!B.val || !B.ptr || !B.ind || !B.val_t || !B.ptr_t || !B.ind_t) return false;
+    } else if (B.kind == PROST_OP_GRAD2D || B.kind == PROST_OP_GRAD3D) {
+      const uint64_t N = B.nx * B.ny * B.L, comps = B.kind == PROST_OP_GRAD2D ? 2 : 3;
+      if (B.nx == 0 || B.ny == 0 || B.L == 0 || N != B.ncols || comps * N != B.nrows) return false;
+      if (comps * N >= ((uint64_t)1 << 32)) return false;                // 32-bit element offsets inside a block
+    } else {
+      return false;
+    }
+  }
+  return true;
+}
+// VEC rows / columns per thread need every block boundary, gradient height and plane size on a multiple of VEC
+static bool fused_op_vec_ok(const prost_hip_fused_op* op, unsigned V) {
+  for (int b = 0; b < op->nblocks; b++) {
+    const prost_hip_op_block& B = op->block[b];
+    if (B.row % V || B.col % V || B.nrows % V || B.ncols % V) return false;
+    if (B.kind != PROST_OP_CSR && (B.ny % V || (B.nx * B.ny * B.L) % V)) return false;
+  }
+  return true;
+}
+static FusedOpDev make_op(const prost_hip_fused_op* op) {
+  FusedOpDev o;
+  o.nblocks = op->nblocks;
+  for (int b = 0; b < op->nblocks; b++) {
+    const prost_hip_op_block& B = op->block[b];
+    o.b[b] = OpBlockDev{B.kind, B.row, B.col, B.nrows, B.ncols, B.nx, B.ny, B.L, B.val, B.ptr, B.ind, B.val_t, B.ptr_t, B.ind_t};
+  }
+  return o;
+}
+// Workgroups of a kernel whose partial sums every workgroup of the NEXT kernel folds itself.  A fold costs one memory latency
+// plus g / 256 loads per thread whatever g is (the partial array stays in L1 / L2), so the PRODUCING kernels may use as many
+// workgroups as the workspace has slots: the operator kernels -- chains of dependent loads (row start -> value, index ->
+// gathered operand) -- run one VEC-row group per thread; the streaming stages cap at kFoldBlocks workgroups.
+constexpr unsigned kFoldBlocks = 2048;
+constexpr unsigned kOpBlocks = 2048;
+static unsigned fold_grid(size_t elements, unsigned per_thread, unsigned cap = kFoldBlocks) {
+  const size_t need = (elements / per_thread + kBlock - 1) / kBlock;
+  return (unsigned)(need < 1 ? 1 : need > cap ? cap : need);
+}
+static unsigned op_grid(size_t elements, unsigned per_thread) { return fold_grid(elements, per_thread, (unsigned)kReduceBlocks); }
+
+template <class T, bool ADJ, class E>
+static void launch_op(const prost_hip_fused_op* op, const E& e, const T* in, size_t count, bool vec, unsigned grid, const CgState* cur, double* ws, hipStream_t st) {
+  constexpr int V = VecOf<T>::N;
+  const FusedOpDev dev = make_op(op);
+  if (vec) hipLaunchKernelGGL((op_stage_kernel<T, V, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
+  else hipLaunchKernelGGL((op_stage_kernel<T, 1, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
+}
+
+template <class T>
+struct CgPtrs {
+  const T* b; T *x, *p, *q, *r, *s, *t; const T *sigma, *tau; size_t m, n; bool vn, vm, vop;
+  CgPtrs(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op)
+      : b(static_cast<const T*>(d->b)), x(static_cast<T*>(d->x)), p(static_cast<T*>(d->p)), q(static_cast<T*>(d->q)), r(static_cast<T*>(d->r)),
+        s(static_cast<T*>(d->s)), t(static_cast<T*>(d->t)), sigma(static_cast<const T*>(d->sigma)), tau(static_cast<const T*>(d->tau)), m(d->m), n(d->n) {
+    constexpr int V = VecOf<T>::N;
+    vn = aligned16(x) && aligned16(p) && aligned16(s) && aligned16(t) && aligned16(tau) && n >= (size_t)V;
+    vm = aligned16(b) && aligned16(q) && aligned16(r) && aligned16(t) && aligned16(sigma) && m >= (size_t)V;
+    vop = vn && vm && fused_op_vec_ok(op, V);
+  }
+};
+
+template <class T>
+static int cgls_round(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream) {
+  if (!d || !d->state || !d->workspace) { set_error("cgls_round: state and workspace are required"); return 1; }
+  if (round < 0) { set_error("cgls_round: negative round"); return 1; }
+  if (!fused_op_ok(op, d->m, d->n)) { set_error("cgls_round: unsupported operator description (prost_hip_fused_op_supported)"); return 1; }
+  hipStream_t st = as_stream(stream);
+  constexpr int V = VecOf<T>::N;
+  const CgPtrs<T> c(d, op);
+  const unsigned gq = fold_grid(c.m, c.vop ? V : 1, kOpBlocks), gs = fold_grid(c.n, c.vop ? V : 1, kOpBlocks);
+  // (STEP_P2 moves a quarter of what STEP_XR2 moves: half as many workgroups fold the partial sums in front of it)
+  const unsigned gx = fold_grid(c.n > c.m ? c.n : c.m, c.vn && c.vm ? V : 1), gpp = fold_grid(c.n, c.vn ? V : 1, kFoldBlocks / 2);
+  const unsigned gp = round == 0 ? gs : gpp;          // |p|^2 of round 0 comes from INIT_SK (grid gs)
+  const CgState* cur = static_cast<const CgState*>(d->state) + round;
+  CgState* nxt = static_cast<CgState*>(d->state) + round + 1;
+  double* ws = static_cast<double*>(d->workspace);
+  const double eps = (double)std::numeric_limits<T>::epsilon();
+  launch_op<T, false>(op, EpiFwdQ<T>{c.q, c.sigma}, c.t, c.m, c.vop, gq, cur, ws, st);
+  const StepXR<T> fx{c.x, c.p, nullptr, c.tau, c.r, c.q, c.sigma, c.t, (T)(-d->shift), (T)0, (T)0};
+  const RoundScalars ax{d->shift, eps, gq, gp, nullptr};
+  if (c.vn && c.vm) hipLaunchKernelGGL((cg_step_xr2_kernel<T, V>), dim3(gx), dim3(kBlock), 0, st, fx, c.n, c.m, cur, nxt, ws, ax);
+  else hipLaunchKernelGGL((cg_step_xr2_kernel<T, 1>), dim3(gx), dim3(kBlock), 0, st, fx, c.n, c.m, cur, nxt, ws, ax);
+  launch_op<T, true>(op, EpiAdjS<T>{c.s, c.tau, c.x, (T)(-d->shift)}, c.t, c.n, c.vop, gs, cur, ws, st);
+  const StepP<T> fp{c.p, c.s, c.t, c.tau, (T)0};
+  const RoundScalars ap{d->shift, eps, gs, gx, d->host_done};
+  if (c.vn) hipLaunchKernelGGL((cg_step_p2_kernel<T, V>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
+  else hipLaunchKernelGGL((cg_step_p2_kernel<T, 1>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
+  PH_LAUNCH_END("cgls round");
+}
+
+// INIT_X ; [INIT_R ; r += K t ; INIT_R2] ; [s += K^T tm ; INIT_S] with the two operator applications inside their stages;
+// tm (= sqrt(Sigma) r) passes through q, which the first round overwrites
+template <class T>
+static int cgls_init_fused(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream) {
+  if (!d || !d->state || !d->workspace) { set_error("cgls_init_fused: state and workspace are required"); return 1; }
+  if (!fused_op_ok(op, d->m, d->n)) { set_error("cgls_init_fused: unsupported operator description (prost_hip_fused_op_supported)"); return 1; }
+  hipStream_t st = as_stream(stream);
+  constexpr int V = VecOf<T>::N;
+  const CgPtrs<T> c(d, op);
+  int rc;
+  if ((rc = cgls_stage<T>(PROST_CGLS_INIT_X, d, stream))) return rc;               // t = sqrt(Tau) x, s = -shift x / sqrt(Tau), record 0
+  const CgState* cur = static_cast<const CgState*>(d->state);
+  double* ws = static_cast<double*>(d->workspace);
+  launch_op<T, false>(op, EpiInitRK<T>{c.b, c.sigma, c.r, c.q, false}, c.t, c.m, c.vop, op_grid(c.m, c.vop ? V : 1), cur, ws, st);
+  const unsigned gs = fold_grid(c.n, c.vop ? V : 1, kOpBlocks);          // = the grid round 0 expects for |p|^2
+  launch_op<T, true>(op, EpiInitSK<T>{c.s, c.p, c.t, c.tau}, c.q, c.n, c.vop, gs, cur, ws, st);
+  return launch_scalars<T, kScalarsInitS>(d, gs, 0, st, 1);
+}
+
+// ADMM outer iteration with the operator inside the stages (the caller runs the CG solve and the proxes in between):
+//   PRE : PRE_X ; [PRE_Z ; z_dual += K temp3 ; PRE_Z2]
+//   POST: [POST_X ; n half of POST_XZ] ; [z_proj = K x_proj ; m half of POST_XZ]
+//   RES : [kx = K x_half ; RES_Z] ; [K^T kx ; RES_X] ; fold -> out4
+template <class T>
+static int admm_fused_stage(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream) {
+  if (!d || !d->workspace) { set_error("admm_fused_stage: workspace is required"); return 1; }
+  if (!fused_op_ok(op, d->m, d->n)) { set_error("admm_fused_stage: unsupported operator description (prost_hip_fused_op_supported)"); return 1; }
+  hipStream_t st = as_stream(stream);
+  constexpr int V = VecOf<T>::N;
+  T* x_half = static_cast<T*>(d->x_half); T* x_proj = static_cast<T*>(d->x_proj); T* x_dual = static_cast<T*>(d->x_dual);
+  T* z_half = static_cast<T*>(d->z_half); T* z_proj = static_cast<T*>(d->z_proj); T* z_dual = static_cast<T*>(d->z_dual);
+  T* temp1 = static_cast<T*>(d->temp1); T* temp2 = static_cast<T*>(d->temp2); T* temp3 = static_cast<T*>(d->temp3);
+  T* kx = static_cast<T*>(d->kx);
+  const T* sigma = static_cast<const T*>(d->sigma); const T* tau = static_cast<const T*>(d->tau);
+  const size_t m = d->m, n = d->n;
+  const bool vn = aligned16(x_half) && aligned16(x_proj) && aligned16(x_dual) && aligned16(temp1) && aligned16(temp3) && aligned16(tau) && n >= (size_t)V;
+  const bool vm = aligned16(z_half) && aligned16(z_proj) && aligned16(z_dual) && aligned16(temp2) && aligned16(sigma) && aligned16(kx) && m >= (size_t)V;
+  const bool vop = vn && vm && fused_op_vec_ok(op, V);
+  double* ws = static_cast<double*>(d->workspace);
+  prost_hip_cgls_desc c{};
+  c.state = nullptr; c.workspace = d->workspace;
+  int rc;
+  switch (stage) {
+    case PROST_ADMM_FUSED_PRE:
+      if ((rc = launch_stage<T>("admm pre_x", AdmmPreX<T>{x_half, x_proj, x_dual, tau, temp1, temp3, (T)d->alpha}, n, 0, vn, &c, st))) return rc;
+      launch_op<T, false>(op, EpiPreZK<T>{z_half, z_dual, sigma, temp2}, temp3, m, vop, grid_for(vop ? m / V : m), nullptr, ws, st);
+      PH_LAUNCH_END("admm pre_zk");
+    case PROST_ADMM_FUSED_POST:
+      if ((rc = launch_stage<T>("admm post_x2", AdmmPostX2<T>{x_proj, temp1, tau, temp3, x_dual}, n, 0, vn, &c, st))) return rc;
+      launch_op<T, false>(op, EpiPostZK<T>{z_proj, z_dual, temp2, sigma}, x_proj, m, vop, grid_for(vop ? m / V : m), nullptr, ws, st);
+      PH_LAUNCH_END("admm post_zk");
+    case PROST_ADMM_FUSED_RES: {
+      if (!d->out4) { set_error("admm_fused_stage: RES needs out4"); return 1; }
+      const unsigned gz = fold_grid(m, vop ? V : 1, 2048), gx = fold_grid(n, vop ? V : 1, 2048);
+      launch_op<T, false>(op, EpiResZK<T>{kx, z_half, z_proj, z_dual, sigma, (T)d->rho}, x_half, m, vop, gz, nullptr, ws, st);
+      launch_op<T, true>(op, EpiResXK<T>{x_half, x_proj, x_dual, tau, (T)d->rho}, kx, n, vop, gx, nullptr, ws, st);
+      hipLaunchKernelGGL(admm_residual_fold_kernel, dim3(1), dim3(kBlock), 0, st, d->out4, static_cast<const double*>(d->workspace), gz, gx);
+      PH_LAUNCH_END("admm residual fold");
+    }
+    default: set_error("admm_fused_stage: unknown stage"); return 1;
+  }
+}
+
 }  // namespace prost_hip
 
 using namespace prost_hip;
@@ -646,8 +1367,19 @@ int prost_hip_admm_stage_f64(int stage, const prost_hip_admm_desc* d, void* stre
 int prost_hip_normest_stage_f32(int stage, const prost_hip_normest_desc* d, void* stream) { return normest_stage<float>(stage, d, stream); }
 int prost_hip_normest_stage_f64(int stage, const prost_hip_normest_desc* d, void* stream) { return normest_stage<double>(stage, d, stream); }
 
-int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void* stream) {
+int prost_hip_fused_op_supported(const prost_hip_fused_op* op, uint64_t m, uint64_t n) { return fused_op_ok(op, m, n) ? 1 : 0; }
+int prost_hip_cgls_round_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream) { return cgls_round<float>(d, op, round, stream); }
+int prost_hip_cgls_round_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream) { return cgls_round<double>(d, op, round, stream); }
+int prost_hip_cgls_init_fused_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream) { return cgls_init_fused<float>(d, op, stream); }
+int prost_hip_cgls_init_fused_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream) { return cgls_init_fused<double>(d, op, stream); }
+int prost_hip_admm_fused_stage_f32(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream) { return admm_fused_stage<float>(stage, d, op, stream); }
+int prost_hip_admm_fused_stage_f64(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream) { return admm_fused_stage<double>(stage, d, op, stream); }
+
+int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void* stream) { return prost_hip_cgls_result_at(state, 0, out, stream); }
+int prost_hip_cgls_result_at(const void* state, int index, prost_hip_cgls_result_t* out, void* stream) {
   CgState h;
+  if (index < 0) { set_error("prost_hip_cgls_result_at: negative index"); return 1; }
+  state = static_cast<const CgState*>(state) + index;
   PH_CHECK(hipMemcpyAsync(&h, state, sizeof(CgState), hipMemcpyDeviceToHost, as_stream(stream)));
   PH_CHECK(hipStreamSynchronize(as_stream(stream)));
   out->iterations = h.k; out->converged = h.done; out->indefinite = h.indefinite; out->flag = h.flag;

@@ -276,6 +276,123 @@ def test_cgls_stages_at_the_c_abi(hip, dtype, m, n, tol, zero_start):
     assert err <= rtol, (err, res.iterations)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", ["c4", "side_by_side_3d", "uncovered_rows"])
+def test_cgls_fused_rounds_at_the_c_abi(hip, dtype, shape):
+    """prost_hip_cgls_round_*: a CG round in four launches -- the operator (CSR and gradient blocks, evaluated by the thread that
+    owns the output element, blocks in order) applied inside the kernels, alpha / beta / the stopping test formed by the
+    consuming kernels, one scalar record per round -- against (a) the numpy restatement of cgls.hpp on the assembled scipy
+    matrix and (b) the staged rounds of prost_hip_cgls_stage_* with the separate operator kernels: same iteration counts,
+    same x to round-off (only the grouping of the partial sums differs).
+    c4: K = [W; grad2d] as in BASELINE config 4; side_by_side_3d: K = [A B; grad3d 0]; uncovered_rows: rows no block writes."""
+    import scipy.sparse as sp
+    from reference_matrices import spmat_gradient2d, spmat_gradient3d
+    rng = np.random.default_rng(5)
+    L_ = hip.lib()
+    dev_ = lambda a: hip.DeviceArray.from_host(np.ascontiguousarray(a))
+    keep, blocks = [], []
+
+    def csr_block(M, row, col):
+        M = sp.csr_matrix(M).astype(dtype); M.sort_indices()
+        Mt = sp.csr_matrix(M.T).astype(dtype); Mt.sort_indices()
+        arrs = [dev_(M.data), dev_(M.indptr.astype(np.int32)), dev_(M.indices.astype(np.int32)),
+                dev_(Mt.data), dev_(Mt.indptr.astype(np.int32)), dev_(Mt.indices.astype(np.int32))]
+        keep.append(arrs)
+        blocks.append(dict(kind=hip.OP_CSR, row=row, col=col, nrows=M.shape[0], ncols=M.shape[1], M=M, arrs=arrs, dims=(0, 0, 0)))
+
+    def grad_block(nx, ny, L, d3, row, col):
+        G = (spmat_gradient3d if d3 else spmat_gradient2d)(nx, ny, L)
+        blocks.append(dict(kind=hip.OP_GRAD3D if d3 else hip.OP_GRAD2D, row=row, col=col, nrows=G.shape[0], ncols=G.shape[1], M=sp.csr_matrix(G), arrs=None, dims=(nx, ny, L)))
+
+    if shape == "c4":
+        nx, ny = 24, 36
+        npx = nx * ny
+        W = sp.hstack([sp.diags(rng.uniform(-0.5, 0.5, npx)), sp.diags(rng.uniform(-0.5, 0.5, npx))])
+        csr_block(W, 0, 0); grad_block(nx, ny, 2, False, npx, 0)
+        m, n = npx + 4 * npx, 2 * npx
+    elif shape == "side_by_side_3d":
+        nx, ny, L = 9, 14, 5
+        npx = nx * ny * L
+        csr_block(sp.random(300, npx, density=0.004, random_state=1), 0, 0)
+        csr_block(sp.random(300, 120, density=0.03, random_state=2), 0, npx)
+        grad_block(nx, ny, L, True, 300, 0)
+        m, n = 300 + 3 * npx, npx + 120
+    else:
+        nx, ny = 10, 12
+        npx = nx * ny
+        csr_block(sp.random(50, npx, density=0.02, random_state=3), 7, 0)
+        grad_block(nx, ny, 1, False, 64, 0)
+        m, n = 64 + 2 * npx + 5, npx
+    K = sp.lil_matrix((m, n))
+    for b in blocks:
+        K[b["row"]:b["row"] + b["nrows"], b["col"]:b["col"] + b["ncols"]] = b["M"]
+    K = sp.csr_matrix(K).astype(dtype)
+    op = hip.FusedOp(); op.nblocks = len(blocks)
+    for i, b in enumerate(blocks):
+        o = op.block[i]
+        o.kind, o.row, o.col, o.nrows, o.ncols = b["kind"], b["row"], b["col"], b["nrows"], b["ncols"]
+        o.nx, o.ny, o.L = b["dims"]
+        if b["arrs"]:
+            o.val, o.ptr, o.ind, o.val_t, o.ptr_t, o.ind_t = (a.ptr.value for a in b["arrs"])
+    assert L_.prost_hip_fused_op_supported(C.byref(op), C.c_uint64(m), C.c_uint64(n)) == 1
+    last_row = max(b["row"] + b["nrows"] for b in blocks)
+    assert L_.prost_hip_fused_op_supported(C.byref(op), C.c_uint64(last_row - 1), C.c_uint64(n)) == 0   # a block sticks out
+
+    sig = rng.uniform(0.3, 2, m).astype(dtype); tau = rng.uniform(0.3, 2, n).astype(dtype)
+    bvec = rng.standard_normal(m).astype(dtype)
+    x0 = rng.standard_normal(n).astype(dtype)
+    maxit, tol = (8 if dtype == np.float32 else 12), 1e-3
+    x_ref, k_ref = _cgls_reference(K, bvec, x0, sig, tau, 1.0, tol, maxit, dtype)
+    Kt = sp.csr_matrix(K.T); Kt.sort_indices(); K.sort_indices()
+    dK = [dev_(K.data), dev_(K.indptr.astype(np.int32)), dev_(K.indices.astype(np.int32))]
+    dKt = [dev_(Kt.data), dev_(Kt.indptr.astype(np.int32)), dev_(Kt.indices.astype(np.int32))]
+    INIT_X, INIT_R, INIT_R2, INIT_S, STEP_Q, STEP_XR, STEP_S, STEP_P = range(8)
+    results = {}
+    for mode in ("fused", "staged"):
+        vec = {k: hip.DeviceArray.zeros(sz, dtype) for k, sz in (("p", n), ("q", m), ("r", m), ("s", n), ("t", max(m, n)))}
+        db, dx, dsig, dtau = dev_(bvec), dev_(x0), dev_(sig), dev_(tau)
+        rec = L_.prost_hip_cgls_state_bytes()
+        state = hip.DeviceArray.zeros((maxit + 6) * rec // 8 + 1, np.float64)
+        ws = hip.DeviceArray(L_.prost_hip_cgls_workspace_bytes() // 8, np.float64)
+        d = hip.CglsDesc()
+        d.state, d.workspace, d.b, d.x = state.ptr.value, ws.ptr.value, db.ptr.value, dx.ptr.value
+        d.p, d.q, d.r, d.s, d.t = (vec[k].ptr.value for k in "pqrst")
+        d.sigma, d.tau, d.m, d.n, d.shift, d.tol, d.host_done, d.epoch = dsig.ptr.value, dtau.ptr.value, m, n, 1.0, tol, None, 1
+        stage = lambda which: hip.check(hip.fn("cgls_stage", dtype)(which, C.byref(d), None))
+        Kf = lambda res, rhs, acc: hip.check(hip.fn("csr_spmv_acc" if acc else "csr_spmv", dtype)(res.ptr, rhs.ptr, hip.sz(m), hip.sz(K.nnz), dK[0].ptr, dK[1].ptr, dK[2].ptr, None))
+        Ka = lambda res, rhs: hip.check(hip.fn("csr_spmv_acc", dtype)(res.ptr, rhs.ptr, hip.sz(n), hip.sz(K.nnz), dKt[0].ptr, dKt[1].ptr, dKt[2].ptr, None))
+        rounds = maxit + 3               # rounds queued after the stopping test only hand the record on
+        res = hip.CglsResult()
+        if mode == "fused":
+            hip.check(hip.fn("cgls_init_fused", dtype)(C.byref(d), C.byref(op), None))
+        else:
+            stage(INIT_X); stage(INIT_R); Kf(vec["r"], vec["t"], True); stage(INIT_R2); Ka(vec["s"], vec["t"]); stage(INIT_S)
+        if mode == "fused":
+            for j in range(rounds):
+                hip.check(hip.fn("cgls_round", dtype)(C.byref(d), C.byref(op), j, None))
+                if j + 1 == maxit:
+                    hip.check(L_.prost_hip_cgls_result_at(state.ptr, maxit, C.byref(res), None))
+                    x_at_maxit = dx.to_host()
+            last = hip.CglsResult()
+            hip.check(L_.prost_hip_cgls_result_at(state.ptr, rounds, C.byref(last), None))
+            if res.converged:            # the extra rounds changed nothing
+                assert (last.iterations, last.converged) == (res.iterations, res.converged) and np.array_equal(dx.to_host(), x_at_maxit)
+            results[mode] = (x_at_maxit, res.iterations, res.converged)
+        else:
+            for j in range(maxit):
+                Kf(vec["q"], vec["t"], False); stage(STEP_Q); stage(STEP_XR); Ka(vec["s"], vec["t"]); stage(STEP_S); stage(STEP_P)
+            hip.check(L_.prost_hip_cgls_result(state.ptr, C.byref(res), None))
+            results[mode] = (dx.to_host(), res.iterations, res.converged)
+    rtol = 2e-4 if dtype == np.float32 else 1e-10
+    scale = max(1.0, float(np.abs(x_ref).max()))
+    for mode, (x, its, conv) in results.items():
+        assert its == k_ref, (mode, its, k_ref)
+        assert conv == (1 if k_ref < maxit else 0), mode
+        assert float(np.abs(x - x_ref).max()) / scale <= rtol, (mode, float(np.abs(x - x_ref).max()) / scale)
+    # fused against staged: the same arithmetic per element, different grouping of the partial sums only
+    assert float(np.abs(results["fused"][0] - results["staged"][0]).max()) / scale <= (2e-5 if dtype == np.float32 else 1e-12)
+
+
 def test_cgls_converges_to_the_damped_least_squares_solution(hip):
     """What cgls::Solve (cgls.hpp:222-371) computes on GemvPrecondK (backend_admm.cu:199-272) is the minimiser of
     |A' x - b|^2 + shift |x|^2 with A' = sqrt(Sigma) A sqrt(Tau): the device-resident CG (prost_hip_cgls_stage_*), run to a tight

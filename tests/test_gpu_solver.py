@@ -42,7 +42,7 @@ def run_product(prob, backend, opts, iters):
 
 def run_oracle(prob, backend, opts, iters, dtype):
     prob.finalize()
-    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph")}]
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds")}]
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
     s.initialize()
     s.iterate(iters)
@@ -321,14 +321,16 @@ def test_generic_pdhg_arg_sources_cover_every_prox_kind(precision, dtype, arg_fu
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
-@pytest.mark.parametrize("device_cg", [True, False])
-def test_admm_matches_oracle(precision, dtype, device_cg):
-    """device_cg=True: CG scalars resident on the device (fused stages, no host round trip);
-    False: host-driven CGLS with one blocking nrm2 per scalar, as the reference does it."""
+@pytest.mark.parametrize("device_cg,fused_rounds", [(True, True), (True, False), (False, False)])
+def test_admm_matches_oracle(precision, dtype, device_cg, fused_rounds):
+    """device_cg=True: CG scalars resident on the device (no host round trip) -- fused_rounds: a CG round in four launches with
+    the operator [W; grad] applied inside them (prost_hip_cgls_round_*), else the staged rounds around LinearOperator::Eval;
+    device_cg=False: host-driven CGLS with one blocking nrm2 per scalar, as the reference does it."""
     prost.set_precision(precision)
     prob = tvl1_like_problem(16, 12)
     b = prost.backend.admm(rho0=1, residual_iter=2)
     b[1]["device_cg"] = device_cg
+    b[1]["fused_rounds"] = fused_rounds
     o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
     tol = 2e-4 if dtype == np.float32 else 1e-9
     for k in (1, 5, 20):
