@@ -9,6 +9,12 @@ pdhg(stepsize='alg2', residual_iter=10, alg2_gamma=0.5), tolerances 0 (never sto
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
   python bench.py --gpus N ...      (no launcher: starts the N ranks itself as a child torch.distributed.run job)
+  python bench.py --config c3|c4    the other single-GPU BASELINE configs with the same JSON schema (default c2 = the headline):
+      c3  2048 x 2048 x 64 volumetric TV (gradient3d + sum_norm2(3) + sum_1d square), PDHG alg2, residual_iter 10;
+          14 floats/voxel/iteration algorithmic, dominant kernel fused_iter3d_x2_kernel (two iterations per launch)
+      c4  TV-L1 flow-like 1024^2 (block.sparse W + gradient2d(L = 2), sum_1d abs + sum_norm2(4) abs), ADMM defaults (10 CG
+          iterations per outer iteration); a step = one ADMM iteration; the roofline object is that of the dominant kernel of
+          the CG round (its compulsory bytes, SURVEY 8d "generic kernels ... with their own compulsory bytes")
 
 N > 1: BASELINE config 5 -- N independent 4096^2 problems (seeds 42..42+N-1), one per GPU, weak
 scaling; the 4 residual sums are all-reduced over RCCL every residual iteration so every rank sees
@@ -66,6 +72,140 @@ def traffic_bytes(kernel, size, chunk_cols):
         if r["kernel"] == kernel and r["size"] == size and r["chunk_cols"] == chunk_cols:
             return (2 * r["fetch_size_kib"] + r["write_size_kib"]) * 1024, r.get("source")
     return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the BASELINE configs: problem, backend, metric text, algorithmic bytes, CPU baseline sample
+# ------------------------------------------------------------------------------------------------------------------
+ZERO_TOL = dict(tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+
+
+def c4_problem(N):
+    """SURVEY 8(d) C4: primal u in R^(2n); v = W u with W = [diag(Ix) diag(Iy)] (block.sparse, 2 nnz per row), g = gradient2d(N, N, 2) u;
+    f(v) = sum_1d('abs', 1, b, lambda), f(g) = sum_norm2(4, false, 'abs'); min_problem"""
+    import scipy.sparse as sp
+
+    import prost_amd as prost
+    from prost_amd import synthetic
+    n = N * N
+    Ix = synthetic.rof_image(N, N, 1, 1) - 0.5
+    Iy = synthetic.rof_image(N, N, 1, 2) - 0.5
+    bvec = synthetic.rof_image(N, N, 1, 3) - 0.5
+    W = sp.hstack([sp.diags(Ix), sp.diags(Iy)]).tocsc()
+    u = prost.variable(2 * n)
+    v, g = prost.variable(n), prost.variable(4 * n)
+    prob = prost.min_problem([u], [v, g])
+    prob.add_function(v, prost.function.sum_1d("abs", 1, bvec, 5.0))
+    prob.add_function(g, prost.function.sum_norm2(4, False, "abs"))
+    prob.add_constraint(u, v, prost.block.sparse(W))
+    prob.add_constraint(u, g, prost.block.gradient2d(N, N, 2))
+    return prob
+
+
+def make_config(name, size, volume, seed):
+    """-> dict(prob, backend, metric, workload, units (pixels / voxels of one problem), alg_floats_per_unit (per iteration; None where
+    SURVEY 8d defines no per-iteration figure), size_key (traffic-table key), prelude (default clock-ramp iterations))"""
+    import prost_amd as prost
+    from prost_amd import synthetic
+    if name == "c2":
+        prob, u, q, f = synthetic.rof_problem(size, size, lmb=LAMBDA, seed=seed)
+        return dict(prob=prob, backend=prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA),
+                    metric="PDHG iters/sec, ROF-TV %d^2 fp32" % size, units=size * size, alg_floats_per_unit=ALG_FLOATS_PER_PIXEL, size_key=size,
+                    workload="ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), PDHG alg2, residual_iter=10, "
+                             "lambda=10; one independent problem per GPU" % (size, size), prelude=1500,
+                    tiny=lambda: synthetic.rof_problem(64, 64, lmb=LAMBDA, seed=1)[0])
+    if name == "c3":
+        nx, ny, L = volume
+        prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, lmb=LAMBDA, seed=seed)
+        return dict(prob=prob, backend=prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA),
+                    metric="PDHG iters/sec, TV-3D %dx%dx%d fp32" % (nx, ny, L), units=nx * ny * L, alg_floats_per_unit=14, size_key="%dx%dx%d" % (nx, ny, L),
+                    workload="volumetric TV %dx%dx%d (gradient3d + sum_1d square + sum_norm2(3) ind_leq0), PDHG alg2, residual_iter=10, lambda=10; "
+                             "one independent problem per GPU" % (nx, ny, L), prelude=60,
+                    tiny=lambda: synthetic.tv3d_problem(32, 32, 8, lmb=LAMBDA, seed=1)[0])
+    if name == "c4":
+        return dict(prob=c4_problem(size), backend=prost.backend.admm(rho0=1), metric="ADMM iters/sec, TV-L1 flow-like %d^2 fp32" % size,
+                    units=size * size, alg_floats_per_unit=None, size_key=size,
+                    workload="TV-L1 flow-like %dx%d (block.sparse W = [diag(Ix) diag(Iy)] + gradient2d L=2, sum_1d abs + sum_norm2(4) abs), ADMM rho0=1 with the "
+                             "reference defaults (cg_max_iter=10, residual_iter=1); a step = one ADMM iteration = one graph projection (CGLS) + two proxes; "
+                             "one independent problem per GPU" % (size, size), prelude=100,
+                    tiny=lambda: c4_problem(32))
+    raise SystemExit("bench.py: unknown --config %r (c2, c3, c4)" % name)
+
+
+def c4_kernel_bytes(kname, n_px, itemsize=4):
+    """compulsory bytes of the four kernels of a CG round at the C4 shape (n = 2 px primal, m = 5 px rows, W: 2 px entries, two per
+    row; W^T one per row): every vector the kernel has to read or write once, CSR arrays included (generic kernels)"""
+    n, m, nnz = 2 * n_px, 5 * n_px, 2 * n_px
+    if kname == "cg_step_xr2_kernel":            # x, p, tau -> x ; r, q, sigma -> r, t
+        return (4 * n + 5 * m) * itemsize
+    if kname == "op_stage_kernel<EpiFwdQ>":      # t (n) through W (val, ind, row starts) and the stencil ; sigma -> q
+        return (n + 2 * m) * itemsize + nnz * (itemsize + 4) + (n_px + 1) * 4
+    if kname == "op_stage_kernel<EpiAdjS>":      # t (m) through W^T and the stencil ; x, tau -> s
+        return (m + 3 * n) * itemsize + nnz * (itemsize + 4) + (n + 1) * 4
+    if kname == "cg_step_p2_kernel":             # p, s, tau -> p, t
+        return 5 * n * itemsize
+    return None
+
+
+def cpu_baseline_c3(volume, max_threads):
+    """oracle (OpenMP port of the reference path) on a CROP of the volume: 256 x 256 x L voxels of the same synthetic data generator, the
+    same backend options (scale_steps_operator off: the port's power iteration alone would take a minute; for gradient operators the
+    rescale never fires), about 10 s of iterations; reported in voxel-iterations/s and as the equivalent full-volume rate"""
+    import numpy as np
+
+    import oracle
+    import prost_amd as prost
+    from prost_amd import synthetic
+    nx, ny, L = volume
+    cx, cy = min(nx, 256), min(ny, 256)
+    prob, u, q, f = synthetic.tv3d_problem(cx, cy, L, lmb=LAMBDA, seed=42)
+    prob.finalize()
+    backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA, scale_steps_operator=False)
+    opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    threads = min(16, max_threads)
+    oracle.set_num_threads(threads)
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np.float32)
+    s.initialize()
+    s.iterate(2)
+    iters, t0 = 0, time.time()
+    while True:
+        s.iterate(5)
+        iters += 5
+        el = time.time() - t0
+        if el > 10.0 or iters >= 400:
+            break
+    rate = iters / el
+    return {"value": rate * cx * cy * L / (nx * ny * L), "unit": "it/s", "cores": threads, "kind": "port",
+            "voxel_iterations_per_s": rate * cx * cy * L, "crop_it_per_s": rate,
+            "sample": "%d PDHG iterations of a %dx%dx%d crop of the volume (same generator, same options), oracle/prost_oracle.cpp with %d OpenMP "
+                      "threads; value = the crop's voxel-iteration rate divided by the %dx%dx%d voxels of the full volume" % (iters, cx, cy, L, threads, nx, ny, L)}
+
+
+def cpu_baseline_c4(size, backend, max_threads):
+    """oracle ADMM (restatement of backend_admm.cu + cgls.hpp; parity-unpinned by the reference) on the SAME problem,
+    about 10 s of outer iterations"""
+    import numpy as np
+
+    import oracle
+    import prost_amd as prost
+    prob = c4_problem(size)
+    prob.finalize()
+    opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    threads = min(16, max_threads)
+    oracle.set_num_threads(threads)
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np.float32)
+    s.initialize()
+    s.iterate(1)
+    iters, t0 = 0, time.time()
+    while True:
+        s.iterate(2)
+        iters += 2
+        el = time.time() - t0
+        if el > 10.0 or iters >= 200:
+            break
+    return {"value": iters / el, "unit": "it/s", "cores": threads, "kind": "port",
+            "sample": "%d ADMM iterations (10 CG iterations each) of the same %dx%d fp32 problem, oracle/prost_oracle.cpp with %d OpenMP threads"
+                      % (iters, size, size, threads)}
 
 
 def cpu_baseline(n_img, max_threads):
@@ -188,10 +328,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 1000 + 5000 iterations = 0.4 s of GPU time.  The part needs ~10 ms of load to reach its steady clocks:
     # with --warmup 20 --steps 500 (a 35 ms run) the pair kernel measures 0.124 ms per launch, in steady state 0.115 ms
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=1000)
-    ap.add_argument("--size", type=int, default=N_IMG, help="image side (default 4096 = the headline config)")
-    ap.add_argument("--prelude-iters", type=int, default=1500, help="untimed clock-ramp prelude before the warm-up steps: this many of the same iterations (0: none)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"], help="BASELINE config (default c2 = the headline: ROF-TV 4096^2)")
+    ap.add_argument("--steps", type=int, default=None, help="timed iterations (default: 5000 for c2, 200 for c3, 1000 for c4)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up iterations (default: 1000 / 20 / 100)")
+    ap.add_argument("--size", type=int, default=None, help="image side (default 4096 for c2, 1024 for c4)")
+    ap.add_argument("--volume", type=int, nargs=3, default=[2048, 2048, 64], metavar=("NX", "NY", "L"), help="c3: the volume (default 2048 2048 64)")
+    ap.add_argument("--prelude-iters", type=int, default=None, help="untimed clock-ramp prelude before the warm-up steps: this many of the same iterations (0: none; default ~100 ms worth)")
     ap.add_argument("--sample-every", type=int, default=0, help="bracket one launch in this many with HIP events (0: chosen from --steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
@@ -200,6 +342,10 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
+    dflt = {"c2": (5000, 1000, N_IMG), "c3": (200, 20, None), "c4": (1000, 100, 1024)}[args.config]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+    args.size = dflt[2] if args.size is None else args.size
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)          # does not return
 
@@ -258,18 +404,20 @@ def main():
         raise SystemExit("bench.py: the communicator counts %d ranks, WORLD_SIZE is %d" % (int(comm_info["nranks"]), world))
 
     n = args.size
-    prob, u, q, f = synthetic.rof_problem(n, n, lmb=LAMBDA, seed=42 + rank)
-    backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA)
+    cfg = make_config(args.config, args.size, tuple(args.volume), 42 + rank)
+    prob, backend = cfg["prob"], cfg["backend"]
     if args.no_pair:
+        if backend[0] != "pdhg":
+            raise SystemExit("bench.py: --no-pair applies to the pdhg configs")
         backend[1]["allow_pair_kernel"] = False
     opts = prost.options(max_iters=10 ** 9, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0,
                          tol_abs_primal=0, tol_abs_dual=0)
     # code objects are loaded on a kernel's first launch (milliseconds each): run the same kernel instances once on a
-    # 64 x 64 problem so that a short --warmup does not pay for that inside or right before the timed region
-    tiny = prost.Solver(synthetic.rof_problem(64, 64, lmb=LAMBDA, seed=1)[0], backend, opts)
+    # tiny problem so that a short --warmup does not pay for that inside or right before the timed region
+    tiny = prost.Solver(cfg["tiny"](), backend, opts)
     tiny.iterate(24)
     tiny.destroy()
-    solver = prost.Solver(prob, backend, opts)          # uploads f, allocates x/y ping-pong buffers in HBM
+    solver = prost.Solver(prob, backend, opts)          # uploads the data, allocates the state in HBM
 
     def barrier():
         torch.cuda.synchronize()
@@ -279,7 +427,7 @@ def main():
 
     # untimed clock-ramp prelude on the real problem: a FIXED number of the same iterations (about 90 ms at the headline
     # size; every rank must run the same count -- the residual all-reduces pair up across ranks)
-    prelude_iters, t_pre = args.prelude_iters, time.perf_counter()
+    prelude_iters, t_pre = (cfg["prelude"] if args.prelude_iters is None else args.prelude_iters), time.perf_counter()
     if prelude_iters > 0:
         solver.iterate(prelude_iters)
     prelude_ms = (time.perf_counter() - t_pre) * 1e3
@@ -307,15 +455,24 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, elapsed_iterate, elapsed_py = float(t[0].item()), float(t[1].item()), float(t[2].item())
-    st = solver.state()
+    units = cfg["units"]
+    if args.config == "c3":
+        # the state is 8 GB at the full size: scalars only, finiteness on three 64 Ki-element windows of x and y read from the device
+        st = solver.state(vectors=False)
+        seg = min(65536, units)
+        probes = [np.asarray(solver.read(v, [0, (ln - seg) // 2, ln - seg], seg)) for v, ln in (("x", units), ("y", 3 * units))]
+        finite = bool(all(np.isfinite(p).all() for p in probes))
+    else:
+        st = solver.state()
+        finite = bool(np.isfinite(st["x"]).all() and np.isfinite(st["y"]).all())
     path = st["path"]
-    finite = bool(np.isfinite(st["x"]).all() and np.isfinite(st["y"]).all())
 
     if rank == 0:
         value = world * args.steps / elapsed
-        bytes_per_iter = ALG_FLOATS_PER_PIXEL * 4 * n * n
+        afu = cfg["alg_floats_per_unit"]
+        bytes_per_iter = afu * 4 * units if afu else None
         out = {
-            "metric": "PDHG iters/sec, ROF-TV %d^2 fp32" % n,
+            "metric": cfg["metric"],
             "value": value,
             "unit": "it/s",
             "n_gpus": world,
@@ -327,8 +484,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), "
-                                   "PDHG alg2, residual_iter=10, lambda=10; one independent problem per GPU" % (n, n),
+            "config": {"workload": cfg["workload"], "name": args.config,
                        "path": path, "problems": world, "rccl_nranks": int(comm_info["nranks"]) if comm_info["transport"] == "rccl" else None,
                        "comm_nranks": int(comm_info["nranks"]), "residual_allreduce": "host-callback (gloo)" if host_transport else "rccl" if multi else "none",
                        "timed_loop": "Solver::IterateChecked = the loop of prost.solve (stopping test after every observable iteration; "
@@ -337,43 +493,68 @@ def main():
             "wall_ms_python_side": 1e3 * elapsed_py,     # barrier -> command -> barrier as seen from Python
             "prelude_iterations": prelude_iters,
             "prelude_ms": prelude_ms,
-            "achieved_hbm_GBps": value * bytes_per_iter / 1e9,
-            "hbm_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world),
+            "achieved_hbm_GBps": value * bytes_per_iter / 1e9 if bytes_per_iter else None,
+            "hbm_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world) if bytes_per_iter else None,
             "iterates_finite": finite,
         }
+        if args.config == "c4":
+            out["cg_iterations_last_solve"] = st.get("cg_iterations")
         kern = info.get("kernels", {})
         if kern:
             # dominant kernel = largest share of the timed region (mean launch time x launches)
             kname = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
             k = kern[kname]
             ipl = k["iterations_per_launch"]
-            # algorithmic bytes per launch = SURVEY 8(d)'s 11 floats/pixel/iteration x the iterations one
-            # launch performs (two-pass kernels: the pass's own share, 5 primal / 6 dual)
-            floats = ALG_FLOATS_PER_PIXEL * ipl if ipl else (DUAL_PASS_FLOATS if "dual" in kname else ALG_FLOATS_PER_PIXEL - DUAL_PASS_FLOATS)
-            alg_bytes = floats * 4 * n * n
-            achieved = alg_bytes / 1e9 / (k["avg_ms"] * 1e-3)
-            traffic, traffic_src = traffic_bytes(kname, n, k["chunk_cols"])
+            if args.config == "c4":
+                # ADMM: the kernels of the CG round, each against its own compulsory bytes (generic kernels)
+                alg_bytes = c4_kernel_bytes(kname, units)
+                moves = alg_bytes
+                note = ("ADMM has no per-iteration byte figure in SURVEY 8d; frac = COMPULSORY bytes of the dominant kernel of the CG round (every operand read "
+                        "or written once, CSR arrays included: %s) / its launch time / peak.  The working set of a solve (~160 MB at 1024^2) exceeds the 32 MB of "
+                        "L2, so the round's kernels stream from HBM / Infinity Cache: the path is bandwidth-bound kernel by kernel, not launch-bound -- "
+                        "profiles/r03_c4_admm_kernel_stats.csv shows the device busy back to back." % kname)
+            else:
+                # algorithmic bytes per launch = SURVEY 8(d)'s floats/unit/iteration x the iterations one launch performs
+                # (two-pass kernels: the pass's own share, 5 primal / 6 dual of 11 in 2-D, 6 / 8 of 14 in 3-D)
+                if ipl:
+                    floats = afu * ipl
+                elif args.config == "c3":
+                    floats = 8 if "dual" in kname else 6
+                else:
+                    floats = DUAL_PASS_FLOATS if "dual" in kname else ALG_FLOATS_PER_PIXEL - DUAL_PASS_FLOATS
+                alg_bytes = floats * 4 * units
+                moves = (7 if args.config == "c2" else 9) * 4 * units if ipl else None
+                note = ("frac = ALGORITHMIC bytes (SURVEY 8d: %d floats/%s/iteration x %s iterations per launch) / launch time / peak; "
+                        "it exceeds 1 because one launch performs two iterations with the iterate in between kept in registers and "
+                        "physically moves %d floats per %s, not %d.  The physical HBM fraction is frac_hbm_traffic = PMC traffic "
+                        "(FETCH_SIZE x 2 + WRITE_SIZE) / launch time / peak.  That the work is done: bit-exact against the CPU oracle at this "
+                        "very size and launch geometry (tests/test_gpu_fullsize.py)."
+                        % (afu, "pixel" if args.config == "c2" else "voxel", ipl if ipl else "1/2", 7 if args.config == "c2" else 9,
+                           "pixel" if args.config == "c2" else "voxel", 2 * afu))
+            achieved = alg_bytes / 1e9 / (k["avg_ms"] * 1e-3) if alg_bytes else None
+            traffic, traffic_src = traffic_bytes(kname, cfg["size_key"], k["chunk_cols"])
             phys = traffic / 1e9 / (k["avg_ms"] * 1e-3) if traffic else None
             out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
                                "frac_hbm_traffic": phys / HBM_PEAK_GBPS if phys else None,
                                "achieved_hbm_traffic": phys, "traffic_source": traffic_src,
-                               "note": "frac = ALGORITHMIC bytes (SURVEY 8d: 11 floats/pixel/iteration x %s iterations per launch) / launch time / peak; "
-                                       "it exceeds 1 because one launch performs two iterations with the iterate in between kept in registers and "
-                                       "physically moves 7 floats/pixel, not 22.  The physical HBM fraction is frac_hbm_traffic = PMC traffic "
-                                       "(FETCH_SIZE x 2 + WRITE_SIZE) / launch time / peak.  That the work is done: bit-exact against the CPU oracle at this "
-                                       "very size and launch geometry (tests/test_gpu_fullsize.py) and against single-iteration launches "
-                                       "(tests/test_gpu_solver.py::test_fullsize_4096_pair_launches_equal_single_launches)." % (ipl if ipl else "1/2"),
+                               "note": note,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k["avg_ms"],
                                "launches_timed": k["sampled"], "iterations_per_launch": ipl, "chunk_cols": k["chunk_cols"],
                                "sample_every": every,
-                               "kernel_moves_bytes_per_launch": 7 * 4 * n * n if ipl else None,
+                               "kernel_moves_bytes_per_launch": moves,
                                "all_kernels": {name: {"avg_launch_ms": v["avg_ms"], "launches": v["launches"], "launches_timed": v["sampled"],
-                                                      "iterations_per_launch": v["iterations_per_launch"], "chunk_cols": v["chunk_cols"]}
+                                                      "iterations_per_launch": v["iterations_per_launch"], "chunk_cols": v["chunk_cols"],
+                                                      "compulsory_bytes": c4_kernel_bytes(name, units) if args.config == "c4" else None}
                                                for name, v in kern.items()}}
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(n, threads)
+            if args.config == "c2":
+                out["cpu_baseline"] = cpu_baseline(n, threads)
+            elif args.config == "c3":
+                out["cpu_baseline"] = cpu_baseline_c3(tuple(args.volume), threads)
+            else:
+                out["cpu_baseline"] = cpu_baseline_c4(args.size, backend, threads)
     else:
         out = None
 

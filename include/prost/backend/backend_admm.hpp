@@ -38,6 +38,7 @@ class BackendADMM : public Backend<T> {
   virtual std::string path() const { return "admm:generic"; }
   T rho() const { return rho_; }
   size_t iteration() const { return iteration_; }
+  virtual void KernelTimes(std::vector<typename Backend<T>::KernelTime>& out);
   int last_cg_iterations();                 ///< iterations taken by the most recent CGLS solve (reads the device record)
 
  private:
@@ -73,6 +74,9 @@ class BackendADMM : public Backend<T> {
   prost_hip_fused_op fused_op_;
   bool fused_rounds_ = false;
   int cg_result_index_ = 0;      ///< record that holds the result of the most recent device solve
+  // kernel timing (bench roofline figure): the four launches of ONE round of a sampled solve are bracketed by events
+  std::vector<void*> ev_;        ///< pool, five events per sampled round
+  size_t ev_used_ = 0, solves_ = 0, rounds_launched_ = 0;
   T rho_, delta_;
   int arb_u_, arb_l_;
   size_t iteration_;

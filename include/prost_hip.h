@@ -518,6 +518,11 @@ typedef struct prost_hip_fused_op {
 int prost_hip_fused_op_supported(const prost_hip_fused_op* op, uint64_t m, uint64_t n);
 int prost_hip_cgls_round_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream);
 int prost_hip_cgls_round_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream);
+/* The same round with event markers: ev5[0..4] (events of prost_hip_event_create, entries may be NULL) are recorded on `stream`
+ * before the first launch and after each of the four, so that a caller can time the round's kernels one by one (measurement
+ * only: the markers cost launch pipelining). */
+int prost_hip_cgls_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream);
+int prost_hip_cgls_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream);
 /* blocking read-back of record `index` of a record array */
 int prost_hip_cgls_result_at(const void* state, int index, prost_hip_cgls_result_t* out, void* stream);
 /* The start of a solve the same way: INIT_X ; [INIT_R ; r += K t ; INIT_R2] ; [s += K^T (sqrt(Sigma) r) ; INIT_S], each bracket

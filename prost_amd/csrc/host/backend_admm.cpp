@@ -71,6 +71,8 @@ void BackendADMM<T>::Release() {
   if (cg_state_) { prost_hip_free(cg_state_); cg_state_ = nullptr; }
   if (cg_workspace_) { prost_hip_free(cg_workspace_); cg_workspace_ = nullptr; }
   if (cg_done_host_) { prost_hip_host_free(cg_done_host_); cg_done_host_ = nullptr; }
+  for (void* e : ev_) prost_hip_event_destroy(e);
+  ev_.clear(); ev_used_ = 0;
   x_half_.clear(); z_half_.clear(); x_proj_.clear(); z_proj_.clear(); x_dual_.clear(); z_dual_.clear(); temp1_.clear(); temp2_.clear(); temp3_.clear(); tmp_n_.clear(); tmp_m_.clear();
 }
 
@@ -220,11 +222,20 @@ void BackendADMM<T>::CglsDevice(const device_vector<T>& b, device_vector<T>& x, 
     // is written by round j
     CheckHip(Api<T>::cgls_init_fused(&d, &fused_op_, st), "cgls_init_fused");
     int queued = 0;
+    // kernel timing: the second round of one solve in `sample_every_` is bracketed kernel by kernel (at most 512 samples)
+    const bool sample = this->time_kernels_ && (solves_++ % (size_t)this->sample_every_) == 0 && ev_used_ + 5 <= 5 * 512;
     for (int k = 0; k < maxit; ++k) {
       if (*static_cast<volatile int*>(cg_done_host_) == d.epoch) break;
-      CheckHip(Api<T>::cgls_round(&d, &fused_op_, k, st), "cgls_round");
+      if (sample && k == (maxit > 1 ? 1 : 0)) {
+        while (ev_.size() < ev_used_ + 5) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
+        CheckHip(Api<T>::cgls_round_timed(&d, &fused_op_, k, ev_.data() + ev_used_, st), "cgls_round");
+        ev_used_ += 5;
+      } else {
+        CheckHip(Api<T>::cgls_round(&d, &fused_op_, k, st), "cgls_round");
+      }
       queued++;
     }
+    if (this->time_kernels_) rounds_launched_ += (size_t)queued;
     cg_result_index_ = queued;
     cg_iters_valid_ = false;
     return;
@@ -264,6 +275,26 @@ void BackendADMM<T>::CglsDevice(const device_vector<T>& b, device_vector<T>& x, 
     }
   }
   cg_iters_valid_ = false;
+}
+
+/// mean duration of the four kernels of a CG round over the rounds sampled since the last call (rounds that ran after the
+/// stopping test fired return at once and would show up as ~2 us launches: the sampled round is the second of a solve)
+template <typename T>
+void BackendADMM<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& out) {
+  out.clear();
+  if (ev_used_ == 0) return;
+  CheckHip(prost_hip_event_synchronize(ev_[ev_used_ - 1]), "event_synchronize");
+  static const char* const names[4] = {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"};
+  double sum[4] = {0, 0, 0, 0};
+  const size_t samples = ev_used_ / 5;
+  for (size_t s = 0; s < samples; s++)
+    for (int k = 0; k < 4; k++) {
+      float ms = 0;
+      CheckHip(prost_hip_event_elapsed_ms(ev_[5 * s + k], ev_[5 * s + k + 1], &ms), "event_elapsed");
+      sum[k] += ms;
+    }
+  for (int k = 0; k < 4; k++) out.push_back({names[k], sum[k] / (double)samples, samples, rounds_launched_, 0, 0});
+  ev_used_ = 0; rounds_launched_ = 0; solves_ = 0;
 }
 
 template <typename T>

@@ -55,6 +55,7 @@ template <typename T> struct Api;
     static constexpr auto admm_elem = prost_hip_admm_elem_##S;                    \
     static constexpr auto cgls_stage = prost_hip_cgls_stage_##S;                  \
     static constexpr auto cgls_round = prost_hip_cgls_round_##S;                  \
+    static constexpr auto cgls_round_timed = prost_hip_cgls_round_timed_##S;      \
     static constexpr auto cgls_init_fused = prost_hip_cgls_init_fused_##S;        \
     static constexpr auto admm_fused_stage = prost_hip_admm_fused_stage_##S;      \
     static constexpr auto admm_stage = prost_hip_admm_stage_##S;                  \

@@ -1,0 +1,73 @@
+"""bench.py as the driver invokes it, for every BASELINE config it measures (c2 headline, c3, c4), at reduced sizes: the ONE JSON
+line with the contract's keys, a `roofline` object whose kernel time was measured with HIP events inside the timed region, a
+`cpu_baseline` object from the oracle, the native path (no fallback) -- so that a schema or plumbing error does not wait for
+the round-end run.  The bench process is started from the fork server (a process that has touched the GPU must not spawn)."""
+import json
+import multiprocessing as mp
+import os
+import sys
+
+import pytest
+
+import multirank_workers as workers
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                 "roofline", "cpu_baseline")
+
+
+def _bench(*argv):
+    ctx = mp.get_context("forkserver")
+    out = ctx.Queue()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + list(argv)
+    p = ctx.Process(target=workers.run_command, args=(cmd, {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, ROOT, out))
+    p.start()
+    rc, stdout, stderr = out.get(timeout=900)
+    p.join(timeout=60)
+    assert rc == 0, stderr
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_contract(d, steps, warmup):
+    for k in CONTRACT_KEYS:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup and d["unit"] == "it/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"] and d["iterates_finite"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and r["launches_timed"] >= 1 and r["avg_launch_ms"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / 1e9 / (r["avg_launch_ms"] * 1e-3)) <= 1e-9 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["sample"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_bench_c2_reduced():
+    d = _bench("--steps", "20", "--warmup", "5", "--size", "512", "--prelude-iters", "50")
+    _check_contract(d, 20, 5)
+    assert d["config"]["name"] == "c2" and d["config"]["path"] == "pdhg:fused-grad2d" and d["metric"] == "PDHG iters/sec, ROF-TV 512^2 fp32"
+    assert d["roofline"]["kernel"].startswith("fused_iter2d") and d["roofline"]["algorithmic_bytes_per_launch"] in (11 * 4 * 512 * 512, 22 * 4 * 512 * 512)
+
+
+def test_bench_c3_reduced():
+    d = _bench("--config", "c3", "--steps", "20", "--warmup", "5", "--volume", "96", "64", "8", "--prelude-iters", "20")
+    _check_contract(d, 20, 5)
+    assert d["config"]["name"] == "c3" and d["config"]["path"] == "pdhg:fused-grad3d" and d["metric"] == "PDHG iters/sec, TV-3D 96x64x8 fp32"
+    vox = 96 * 64 * 8
+    assert d["roofline"]["kernel"].startswith("fused_iter3d") and d["roofline"]["algorithmic_bytes_per_launch"] in (14 * 4 * vox, 28 * 4 * vox)
+    assert abs(d["achieved_hbm_GBps"] - d["value"] * 14 * 4 * vox / 1e9) <= 1e-9 * d["achieved_hbm_GBps"]
+    assert d["cpu_baseline"]["voxel_iterations_per_s"] > 0
+
+
+def test_bench_c4_reduced():
+    d = _bench("--config", "c4", "--steps", "20", "--warmup", "5", "--size", "128", "--prelude-iters", "10")
+    _check_contract(d, 20, 5)
+    assert d["config"]["name"] == "c4" and d["config"]["path"] == "admm:generic" and d["metric"] == "ADMM iters/sec, TV-L1 flow-like 128^2 fp32"
+    r = d["roofline"]
+    assert set(r["all_kernels"]) == {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"}      # the four-launch CG round ran
+    assert r["kernel"] in r["all_kernels"] and r["algorithmic_bytes_per_launch"] == r["all_kernels"][r["kernel"]]["compulsory_bytes"]
+    assert d["achieved_hbm_GBps"] is None and d["cg_iterations_last_solve"] >= 1
