@@ -25,6 +25,7 @@
 // intermediate iterate is stored nowhere; the residual sums of the second iteration are available (RES).
 #include "fused_common.hpp"
 #include "reduce.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace prost_hip {
@@ -66,6 +67,19 @@ __device__ __forceinline__ void stx_o(T* __restrict__ base, unsigned byte_off, c
   stx_nt<T, VEC>(reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off), v);
 }
 
+// Progress counters of the FLAGS instance, accessed so that ONLY LDS traffic is ordered.  A workgroup-scope fence (and
+// __syncthreads()) also waits for the wavefront's global loads and stores (s_waitcnt vmcnt(0)); the exchange buffers live in LDS and
+// a wavefront's LDS operations are processed in order, so lgkmcnt is all that has to be waited for, and the "memory" clobbers keep
+// the compiler from moving LDS accesses across these points.  Same box, 2048 x 2048 x 64: 1.325 ms per iteration against 1.355 with
+// fences.  (The barrier of the residual instance stays __syncthreads(): with the asm barrier that instance spills 9 registers instead
+// of 4 and runs 2.0 instead of 1.72 ms per iteration.)
+__device__ __forceinline__ int lds_flag_read(const int* p) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_flag_write(int* p, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(size_t)p), "v"(v) : "memory"); }
+
 template <class T, int VEC, bool GB>
 struct ColX2 {
   T y1[VEC], y2[VEC], y3[VEC], x[VEC], b[GB ? VEC : 1];   // own plane
@@ -76,7 +90,13 @@ struct ColX2 {
 // RES: additionally the four residual sums of the SECOND iteration (primal_residual_transform / dual_residual_transform,
 // backend_pdhg.cu:73-120), term by term the expressions of fused_iter3d_kernel: K^T y^k at column c comes from stage A two
 // steps earlier, everything else is in registers when stages C and D run.  One partial (4 doubles) per workgroup.
-template <class T, int VEC, int GFN, bool GB, int WT, bool RES>
+// FLAGS: the workgroup barrier per column step is replaced by per-wavefront progress counters in LDS.  A wavefront needs, at
+// step k, only what the wavefronts of the two NEIGHBOURING planes published at step k - 1; with the exchange buffers three
+// slots deep (slot k % 3 is written at step k, slot (k - 1) % 3 read) it may start step k as soon as both neighbours have
+// finished step k - 1 -- which also guarantees that they are done reading the slot it overwrites (written at step k - 3, read
+// at their step k - 2).  A barrier makes every step as long as its slowest wavefront (16 of them, each waiting for seven
+// loads); with the counters a late load delays the neighbouring planes by one step and is absorbed further out.
+template <class T, int VEC, int GFN, bool GB, int WT, bool RES, bool FLAGS>
 __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                        const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2,
                                                                        double* __restrict__ partial) {
@@ -86,7 +106,9 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   constexpr int kRowsPerWave = (kWave - 2 * kHalo) * VEC;
   constexpr int kPix = kWave * VEC;
   constexpr int P = WT - 3;                            // planes a workgroup owns
-  __shared__ T s_x1[2][WT][kPix], s_y3[2][WT][kPix], s_x2[2][WT][kPix];
+  constexpr int kSlots = FLAGS ? 3 : 2;
+  __shared__ T s_x1[kSlots][WT][kPix], s_y3[kSlots][WT][kPix], s_x2[kSlots][WT][kPix];
+  __shared__ int s_step[FLAGS ? WT : 1];               // FLAGS: last step whose publishes wavefront w has finished
   // RES: K^T y^k of the own plane waits two steps between stages A and C, and the four sums are added up once per step --
   // both live in LDS (own lanes only, no synchronisation), the instance stays within the 128 VGPRs of 16 wavefronts per CU
   __shared__ T s_kt[RES ? 3 : 1][RES ? WT : 1][RES ? kPix : 1];
@@ -122,13 +144,28 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
 
   typedef ColX2<T, VEC, GB> Col;
-  const unsigned voff = (unsigned)(row0 * (long)sizeof(T));          // meaningful in active lanes only (the others do not access memory)
+  const unsigned voff = (unsigned)(row0 * (long)sizeof(T));          // meaningful in active lanes only (the others do not store)
+  // Loads are UNCONDITIONAL: a lane outside the image reads the strip's first rows, a column outside the chunk's range the nearest
+  // valid one, a missing neighbour plane the own plane -- values nobody uses (every use is guarded by the predicate that would have
+  // guarded the load), but a register set that is overwritten as a whole each step is dead before it, which is what lets the three
+  // sets rotate without copies or re-zeroing
+  // (the residual instance, which sits at the 128-register limit, keeps predicated loads into a zeroed set: kUncond = false)
+  constexpr bool kUncond = !RES;
+  const unsigned voff_ld = kUncond && !active ? 0u : voff;
+  const T* zxp = kUncond && !has_above ? xp : xp + Pn;
+  const T* y3mp = kUncond && !has_below ? y3p : y3p - Pn;
+  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
   auto load_col = [&](long c, Col& in) {
-    const size_t o = (size_t)c * (size_t)ny;                          // wave-uniform
-    ldx_o<T, VEC>(y1p + o, voff, in.y1); ldx_o<T, VEC>(y2p + o, voff, in.y2); ldx_o<T, VEC>(y3p + o, voff, in.y3); ldx_o<T, VEC>(xp + o, voff, in.x);
-    if constexpr (GB) ldx_o<T, VEC>(bp + o, voff, in.b);
-    if (has_above) ldx_o<T, VEC>(xp + Pn + o, voff, in.zx);
-    if (has_below) ldx_o<T, VEC>(y3p - Pn + o, voff, in.y3m);
+    if (!kUncond) {
+      in = Col{};
+      if (!(active && has_col(c))) return;
+    }
+    const long cc = !kUncond ? c : (c < 0 ? 0 : (c >= nx ? nx - 1 : c));
+    const size_t o = (size_t)cc * (size_t)ny;                         // wave-uniform
+    ldx_o<T, VEC>(y1p + o, voff_ld, in.y1); ldx_o<T, VEC>(y2p + o, voff_ld, in.y2); ldx_o<T, VEC>(y3p + o, voff_ld, in.y3); ldx_o<T, VEC>(xp + o, voff_ld, in.x);
+    if constexpr (GB) ldx_o<T, VEC>(bp + o, voff_ld, in.b);
+    if (kUncond || has_above) ldx_o<T, VEC>(zxp + o, voff_ld, in.zx);
+    if (kUncond || has_below) ldx_o<T, VEC>(y3mp + o, voff_ld, in.y3m);
   };
   // primal step at column c of this plane (backend_pdhg.cu:317-338 with block_gradient3d.cu:127-149 on a zero-filled result);
   // v1 / v2 / v3: the dual variable at column c, p1c: its first component at column c-1, v3m: its third component one plane below
@@ -250,7 +287,7 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     for (int j = 0; j < VEC; j++) v[j] = buf[w][j * kWave + lane];
   };
 
-  Col in1 = {}, in2 = {};                              // raw columns c+1 and c+2
+  Col in1 = {}, in2 = {}, pre = {};                    // raw columns c+1, c+2 and the one being prefetched (c+3)
   T b_c[GB ? VEC : 1];                                 // b of prox_g at column c (stage C)
   T x1_m[VEC], x1_0[VEC], x1_1[VEC], x1_2[VEC];        // x^(k+1) at columns c-1 .. c+2
   T xz1_m[VEC], xz1_0[VEC], xz1_1[VEC];                // x^(k+1) one plane above at columns c-1 .. c+1 (from LDS)
@@ -266,24 +303,33 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   }
 #pragma unroll
   for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = 0;
-  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
   if (active) {
     if (xa - 2 >= 0) ldx_o<T, VEC>(y1p + (size_t)(xa - 2) * (size_t)ny, voff, in2.y1);   // becomes in1.y1 for A(xa-1)
   }
-  Col pre = {};
-  if (active && has_col(xa - 1)) load_col(xa - 1, pre);
+  if (exists || !kUncond) load_col(xa - 1, pre);
 
   // nothing of the prologue may still be in flight when the loop starts: the compiler's wait-count insertion otherwise carries
   // the prologue's pending loads around the loop and drains vmcnt to 0 INSIDE every step -- which also waits for the column that
   // was just prefetched
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+  if (FLAGS) {
+    if (lane == 0) s_step[FLAGS ? wv : 0] = -1;
+    __syncthreads();
+  }
   int k3 = 0;                                          // slot of s_kt that stage A writes in this step
+  int step = 0, wr3 = 0;                               // FLAGS: step counter and its slot (step % 3)
+  // (tried: the loop unrolled three times with the three raw-column sets renamed instead of copied -- 28 moves less per step,
+  // 40-80 spilled registers at the 128 the instance may use)
   for (long c = xa - 3; c <= xb; c++) {
-    const int wr = (int)((c + 4) & 1), rd = wr ^ 1;
+    const int wr = FLAGS ? wr3 : (int)((c + 4) & 1), rd = FLAGS ? (wr3 == 0 ? 2 : wr3 - 1) : wr ^ 1;
+    if (FLAGS && step > 0) {
+      // wait for the neighbouring planes' wavefronts (whether or not their planes exist: every wavefront counts its steps)
+      if (wv >= 1) while (__builtin_amdgcn_readfirstlane(lds_flag_read(&s_step[FLAGS ? wv - 1 : 0])) < step - 1) __builtin_amdgcn_s_sleep(1);
+      if (wv + 1 < WT) while (__builtin_amdgcn_readfirstlane(lds_flag_read(&s_step[FLAGS ? wv + 1 : 0])) < step - 1) __builtin_amdgcn_s_sleep(1);
+    }
     // raw columns: in1 <- in2 <- pre, prefetch column c+3
     in1 = in2; in2 = pre;
-    pre = Col{};
-    if (active && has_col(c + 3)) load_col(c + 3, pre);
+    if (exists || !kUncond) load_col(c + 3, pre);
     // neighbour-plane values published in the previous step
     if (has_above && wv + 1 < WT) { fetch(s_x1[rd], wv + 1, xz1_1); fetch(s_x2[rd], wv + 1, xz2_m); }
     if (has_below && wv >= 1) fetch(s_y3[rd], wv - 1, ym3_0);
@@ -325,7 +371,12 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
         stx_o<T, VEC>(y_out + off, voff, o[0]); stx_o<T, VEC>(y_out + N + off, voff, o[1]); stx_o<T, VEC>(y_out + 2 * N + off, voff, o[2]);
       }
     }
-    __syncthreads();                                   // one barrier per column: the buffers written now are read in the next step
+    if (FLAGS) {
+      if (lane == 0) lds_flag_write(&s_step[FLAGS ? wv : 0], step);          // after this step's publishes (LDS is in order per wavefront)
+      step++; wr3 = wr3 == 2 ? 0 : wr3 + 1;
+    } else {
+      __syncthreads();                                 // one barrier per column: the buffers written now are read in the next step
+    }
     // shift the pipeline by one column
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
@@ -340,6 +391,7 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     k3 = k3 == 2 ? 0 : k3 + 1;
   }
   if (RES) {                                           // the last barrier of the loop has passed: the exchange buffers are free
+    if (FLAGS) __syncthreads();
     double* sred = reinterpret_cast<double*>(&s_x1[0][0][0]);
     double r_pd = s_acc[0][RES ? wv : 0][RES ? lane : 0], r_pv = s_acc[RES ? 1 : 0][RES ? wv : 0][RES ? lane : 0], r_dd = s_acc[RES ? 2 : 0][RES ? wv : 0][RES ? lane : 0],
            r_dv = s_acc[RES ? 3 : 0][RES ? wv : 0][RES ? lane : 0];
@@ -427,12 +479,15 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
   const unsigned grid = (unsigned)(strips * a.chunks * groups);
   if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused 3-D double iteration: grid exceeds the reduction workspace"); return 1; }
   double* partial = static_cast<double*>(ws);
-#define GO2(G, B, R) hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, G, B, WT, R>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+  static const bool flags = []() { const char* e = getenv("PROST_X2_SYNC"); return !(e && atoi(e) == 0); }();      // PROST_X2_SYNC=0: the barrier per step (A/B)
+#define GO3(G, B, R, F) hipLaunchKernelGGL((fused_iter3d_x2_kernel<T, V, G, B, WT, R, F>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+#define GO2(G, B, R) do { if (flags && !R) GO3(G, B, false, true); else GO3(G, B, R, false); } while (0)
 #define GO(B, R) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B, R); else GO2(PROST_FN_SQUARE, B, R); } while (0)
   if (d->g_coeff_ptr[1]) { if (out4) GO(true, true); else GO(true, false); }
   else { if (out4) GO(false, true); else GO(false, false); }
 #undef GO
 #undef GO2
+#undef GO3
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused 3-D double iteration kernel"); }
   if (out4) return launch_fold4(out4, partial, grid, s);
   return 0;
