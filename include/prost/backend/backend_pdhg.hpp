@@ -96,6 +96,11 @@ class BackendPDHG : public Backend<T> {
   bool pair3d_ = false, pair_mc_ = false;
   size_t pair_launches_ = 0;
   prost_hip_fused_desc desc_;
+  // the description the double-iteration kernels run on: desc_, or -- for a BINARY per-pixel coefficient a of prox_g (the
+  // inpainting mask of example_tv_inpaint.m:23) -- desc_ with a folded into the b stream (b_masked_, prost_hip_mask_merge)
+  prost_hip_fused_desc desc_pair_;
+  device_vector<T> b_masked_;
+  void TryMaskedPairShape();
   // state: fused keeps x, x_prev, y, y_prev only; generic adds kx, kx_prev, kty, kty_prev, temp
   device_vector<T> x_, y_, x_prev_, y_prev_, temp_, kx_, kty_, kx_prev_, kty_prev_;
   device_vector<T> y_spare_;   // third dual buffer: single-kernel residual iterations read y, y_prev and write y_new

@@ -262,7 +262,19 @@ typedef struct {
   size_t res_x0, res_x1;    /* residual sums only over image columns [res_x0, res_x1); res_x1 == 0: all  */
                             /* (column-sharded images: the halo columns of a slab are not counted;        */
                             /*  honoured by prost_hip_fused_iteration / _iteration2)                      */
+  int g_b_masked;           /* (ABI 4) g_coeff_ptr[1] is a MERGED stream made by prost_hip_mask_merge: b where the coefficient a of  */
+                            /* prox_g is 1, the mask sentinel where a is 0 -- a binary per-pixel a (the inpainting mask of           */
+                            /* example_tv_inpaint.m:23) folded into the b stream; g_coeff_ptr[0] must be NULL, g_coeff_val[0] = 1.  */
+                            /* Honoured by prost_hip_fused_iteration2 and prost_hip_fused_iteration_mc_x2 only.                      */
 } prost_hip_fused_desc;
+/* Folds a BINARY per-element coefficient a of ElemOperation1D (elem_operation_1d.hpp:42-44: a == 0 skips the function, the
+ * element passes through) into the b stream: bm[i] = a[i] == 0 ? sentinel : (b ? b[i] : b_val), sentinel = a quiet NaN with the
+ * payload 0xA5A5.. that arithmetic never produces (PROST_HIP_MASK_SENTINEL_*).  nonbinary (DEVICE counter, zeroed by the caller)
+ * is incremented for every a[i] outside {0, 1}: the merged stream is only valid when it stays 0. */
+#define PROST_HIP_MASK_SENTINEL_F32 0x7FC0A5A5u
+#define PROST_HIP_MASK_SENTINEL_F64 0x7FF8A5A5A5A5A5A5ull
+int prost_hip_mask_merge_f32(float* bm, const float* a, const float* b, double b_val, size_t n, unsigned long long* nonbinary, void* stream);
+int prost_hip_mask_merge_f64(double* bm, const double* a, const double* b, double b_val, size_t n, unsigned long long* nonbinary, void* stream);
 
 /* returns 1 if the fused passes support this description for dtype (0 f32, 1 f64) */
 int prost_hip_fused_supported(const prost_hip_fused_desc* desc, int dtype);

@@ -25,7 +25,7 @@ class FusedDesc(C.Structure):
     _fields_ = [("is3d", C.c_int), ("nx", C.c_size_t), ("ny", C.c_size_t), ("L", C.c_size_t),
                 ("g_fn", C.c_int), ("g_coeff_ptr", C.c_void_p * 7), ("g_coeff_val", C.c_double * 7),
                 ("f_fn", C.c_int), ("f_coeff_ptr", C.c_void_p * 7), ("f_coeff_val", C.c_double * 7),
-                ("T_val", C.c_double), ("S_val", C.c_double), ("res_x0", C.c_size_t), ("res_x1", C.c_size_t)]
+                ("T_val", C.c_double), ("S_val", C.c_double), ("res_x0", C.c_size_t), ("res_x1", C.c_size_t), ("g_b_masked", C.c_int)]
 
 
 class ArgSpec(C.Structure):

@@ -131,6 +131,10 @@ __device__ __forceinline__ T row_below(const T (&v)[VEC], const T* __restrict__ 
   return dn;
 }
 
+// the mask sentinel of a merged b stream (prost_hip_mask_merge): bit compare, one instruction
+__device__ __forceinline__ bool is_mask_sentinel(float b) { return __float_as_uint(b) == PROST_HIP_MASK_SENTINEL_F32; }
+__device__ __forceinline__ bool is_mask_sentinel(double b) { return (unsigned long long)__double_as_longlong(b) == PROST_HIP_MASK_SENTINEL_F64; }
+
 template <class T>
 inline FusedArgs<T> make_fused_args(const prost_hip_fused_desc* d) {
   FusedArgs<T> a;

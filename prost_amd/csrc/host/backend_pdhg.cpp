@@ -68,6 +68,7 @@ bool BackendPDHG<T>::TryFused() {
   if (!prob.uniform_right(tv) && !uniform(prob.scaling_right_host(), tv)) return false;
   if (!prob.uniform_left(sv) && !uniform(prob.scaling_left_host(), sv)) return false;
   desc_.res_x0 = owned_x0_; desc_.res_x1 = owned_x1_;
+  desc_.g_b_masked = 0;
   desc_.is3d = d3 ? 1 : 0; desc_.nx = bd.nx; desc_.ny = bd.ny; desc_.L = bd.L;
   desc_.g_fn = pg.fn; desc_.f_fn = pf.fn;
   for (int i = 0; i < 7; i++) {
@@ -76,6 +77,33 @@ bool BackendPDHG<T>::TryFused() {
   }
   desc_.T_val = (double)tv; desc_.S_val = (double)sv;
   return prost_hip_fused_supported(&desc_, dtype_id<T>()) == 1;
+}
+
+/// example_tv_inpaint.m:23 -- sum_1d('square', m, f, lmb) with a 0 / 1 mask m as coefficient a: ElemOperation1D skips the function
+/// where a == 0 (elem_operation_1d.hpp:42-44), so with d = e = 0 a masked pixel passes through and every other pixel is the ROF
+/// shape.  If a is binary (checked on the device, once) it is folded into the b stream -- sentinel where a == 0 -- and the
+/// double-iteration kernels run their straight-line instance on that stream; otherwise they are not used for this problem.
+template <typename T>
+void BackendPDHG<T>::TryMaskedPairShape() {
+  desc_pair_ = desc_;
+  if (!fused_ || desc_.is3d || !desc_.g_coeff_ptr[0] || desc_.g_fn != PROST_FN_SQUARE) return;
+  for (int k = 2; k < 7; k++) if (desc_.g_coeff_ptr[k]) return;
+  if (desc_.g_coeff_val[2] == 0.0 || desc_.g_coeff_val[3] != 0.0 || desc_.g_coeff_val[4] != 0.0) return;
+  const size_t n = this->problem_->ncols();
+  b_masked_.resize(n);
+  unsigned long long* counter = nullptr;
+  CheckHip(prost_hip_malloc((void**)&counter, sizeof(unsigned long long)), "malloc");
+  CheckHip(prost_hip_memset(counter, 0, sizeof(unsigned long long), CurrentStream()), "memset");
+  CheckHip(Api<T>::mask_merge(b_masked_.data(), static_cast<const T*>(desc_.g_coeff_ptr[0]), static_cast<const T*>(desc_.g_coeff_ptr[1]),
+                              desc_.g_coeff_val[1], n, counter, CurrentStream()), "mask_merge");
+  unsigned long long nonbinary = 1;
+  CheckHip(prost_hip_memcpy_d2h(&nonbinary, counter, sizeof(nonbinary), CurrentStream()), "memcpy_d2h");
+  CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
+  prost_hip_free(counter);
+  if (nonbinary != 0) { b_masked_.clear(); return; }
+  desc_pair_.g_coeff_ptr[0] = nullptr; desc_pair_.g_coeff_val[0] = 1.0;
+  desc_pair_.g_coeff_ptr[1] = b_masked_.data();
+  desc_pair_.g_b_masked = 1;
 }
 
 template <typename T>
@@ -114,7 +142,8 @@ void BackendPDHG<T>::Initialize() {
 
   x_.resize(n); x_prev_.resize(n); y_.resize(m); y_prev_.resize(m);
   if (!fused_) { kty_prev_.resize(n); kty_.resize(n); kx_.resize(m); kx_prev_.resize(m); temp_.resize(l); }
-  pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_profitable(&desc_, dtype_id<T>()) == 1;
+  TryMaskedPairShape();
+  pair_kernel_ = single_kernel_ && opts_.allow_pair_kernel && prost_hip_fused_iteration2_profitable(&desc_pair_, dtype_id<T>()) == 1;
   // (volumes of fewer than 4 planes leave 13 of the 16 wavefronts of a workgroup idle: 2048^2 x 2 runs 0.125 ms per iteration in pairs,
   // 0.086 ms in single launches; from 4 planes on the pairs win, 0.127 against 0.206 ms)
   pair3d_ = fused_ && desc_.is3d && desc_.L >= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel && prost_hip_fused_iteration3d_x2_supported(&desc_, dtype_id<T>()) == 1;
@@ -123,7 +152,7 @@ void BackendPDHG<T>::Initialize() {
   // (L = 2 at heights the gray-value pair kernel takes: PerformIterations launches that one, so only one of the two flags is set --
   // the kernel names and chunk lengths KernelTimes reports then belong to the kernel that ran)
   pair_mc_ = fused_ && !pair_kernel_ && !desc_.is3d && desc_.L >= 2 && desc_.L <= 4 && opts_.allow_single_kernel && opts_.allow_pair_kernel &&
-             prost_hip_fused_iteration_mc_x2_profitable(&desc_, dtype_id<T>()) == 1;
+             prost_hip_fused_iteration_mc_x2_profitable(&desc_pair_, dtype_id<T>()) == 1;
   // third buffers: where every residual iteration (single-kernel paths) or every other pair (pair_kernel_: stored intermediate
   // iterate) uses them they are allocated here; the 3-D / multi-channel pair paths without them need a third buffer only to
   // rebuild the previous iterate (RebuildPrevious: read-out, callbacks) and allocate it there -- 4 n + 4 m values less resident
@@ -174,7 +203,7 @@ void BackendPDHG<T>::Release() {
   if (ev_res_done_) { prost_hip_event_destroy(ev_res_done_); ev_res_done_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;
-  y_spare_.clear(); x_spare_.clear(); sol_z_.clear(); sol_w_.clear();
+  y_spare_.clear(); x_spare_.clear(); sol_z_.clear(); sol_w_.clear(); b_masked_.clear();
   x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
 }
 
@@ -260,14 +289,14 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
   const bool t = BeginSample(store_mid ? (residuals ? kKernelPairMidRes : kKernelPairMid) : (residuals ? kKernelPairRes : kKernelPair));
   if (!store_mid) {
-    CheckHip(Api<T>::fused_iteration2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
+    CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
                                       residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
     EndSample(t);
     x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
     y_.swap(y_prev_);
     prev_stale_ = true;
   } else {
-    CheckHip(Api<T>::fused_iteration2(&desc_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
+    CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
                                       theta, 0, residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
     EndSample(t);
     x_.swap(x_spare_);       // x_ = x^(k+2), x_prev_ = x^(k+1): the state two single launches leave
@@ -308,7 +337,7 @@ void BackendPDHG<T>::IterationPairMc(bool residuals) {
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
   const bool t = BeginSample(residuals ? kKernelPairRes : kKernelPair);
-  CheckHip(Api<T>::fused_iteration_mc_x2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
+  CheckHip(Api<T>::fused_iteration_mc_x2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
                                          residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration_mc_x2");
   EndSample(t);
   x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
@@ -640,9 +669,9 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
   for (int k = 0; k < kKernelKinds; k++) {
     if (!cnt[k]) continue;
-    const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes)
+    const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_pair_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes)
                      : (k == kKernelPair || k == kKernelPairRes) && pair3d_ ? prost_hip_fused_iteration3d_x2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes)
-                     : (k == kKernelPair || k == kKernelPairRes) && pair_mc_ ? prost_hip_fused_iteration_mc_x2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes) : 0;
+                     : (k == kKernelPair || k == kKernelPairRes) && pair_mc_ ? prost_hip_fused_iteration_mc_x2_chunk_cols(&desc_pair_, dtype_id<T>(), k == kKernelPairRes) : 0;
     out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k], cols});
   }
   samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;

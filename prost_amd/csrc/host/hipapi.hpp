@@ -53,6 +53,7 @@ template <typename T> struct Api;
     static constexpr auto nrm2 = prost_hip_nrm2_##S;                              \
     static constexpr auto axpy = prost_hip_axpy_##S;                              \
     static constexpr auto admm_elem = prost_hip_admm_elem_##S;                    \
+    static constexpr auto mask_merge = prost_hip_mask_merge_##S;                  \
     static constexpr auto cgls_stage = prost_hip_cgls_stage_##S;                  \
     static constexpr auto cgls_round = prost_hip_cgls_round_##S;                  \
     static constexpr auto cgls_round_timed = prost_hip_cgls_round_timed_##S;      \

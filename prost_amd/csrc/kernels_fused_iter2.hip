@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
   const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t N = (size_t)nx * (size_t)ny;
   constexpr bool kUniformG = (GMASK & 0x15) == 0;
+  constexpr bool kBMask = FAST && (GMASK & 0x80) != 0;     // bit 7: the per-pixel b carries the mask sentinel (binary coefficient a folded in)
   constexpr bool kRes = (MODE & 2) != 0;
   constexpr bool kMid = (MODE & 1) != 0;
   typedef Col2<T, VEC, GMASK> Col;
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
                     const T (&gc)[Col::NG][VEC], const IterParams<T>& P, T (&xn)[VEC], T (&kt)[VEC]) {
     constexpr bool I = decltype(inner)::value;
     const T tauT = P.tau * a.Tval;
-    T parg[VEC];
+    T parg[VEC], parg0[kBMask ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
@@ -156,6 +157,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       kt[j] = kty;
       const T arg = xin[j] - tauT * kty;
       if (FAST) {
+        if (kBMask) parg0[j] = arg;
         parg[j] = arg - (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
       } else {
         T cf[7];
@@ -178,6 +180,12 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       }
 #pragma unroll
       for (int j = 0; j < VEC; j++) xn[j] = r[j] + (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
+      if (kBMask) {
+        // merged b stream (prost_hip_mask_merge): where the coefficient a of prox_g is 0 the element passes through,
+        // (arg - tau d) / (1 + tau e) = arg for d = e = 0 (elem_operation_1d.hpp:42-44); elsewhere a = 1, the code above
+#pragma unroll
+        for (int j = 0; j < VEC; j++) if (is_mask_sentinel(gc[slot_ofb(GMASK, 1)][j])) xn[j] = parg0[kBMask ? j : 0];
+      }
     }
   };
   // primal_residual_transform (backend_pdhg.cu:97-120) of one pixel, both components
@@ -395,6 +403,7 @@ static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
 // (measured abs / ind_leq0 at 4096^2: 0.79 vs 0.16 ms per iteration), so callers should not pair there.
 static bool iter2_fast_shape(const prost_hip_fused_desc* d) {
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
+  if (d->g_b_masked && (!d->g_coeff_ptr[1] || d->g_fn != PROST_FN_SQUARE)) return false;     // the merged stream IS the per-pixel b; square data term
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k] && k != 1) return false;
   return d->g_coeff_val[0] == 1.0 && d->g_coeff_val[2] != 0.0 && d->g_coeff_val[3] == 0.0 && d->g_coeff_val[4] == 0.0 &&
          d->f_coeff_val[0] == 1.0 && d->f_coeff_val[3] == 0.0 && d->f_coeff_val[4] == 0.0;
@@ -459,6 +468,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k]) mask |= 1 << k;
   // straight-line instance for the ROF shape: square / ind_leq0 with scalar a = 1, d = 0, e = 0 on both
   // sides (so a (v - d tau) = v and the fp64 denominators are exactly 1), b of prox_g per pixel
+  if (d->g_b_masked && !iter2_fast_shape(d)) { set_error("fused double iteration: a merged b stream needs the straight-line square shape"); return 1; }
   const bool fast = iter2_fast_shape(d) && p[0].ug.a_one && p[0].ug.den_one && !p[0].ug.degenerate && p[0].uf.a_one && p[0].uf.den_one &&
                     p[1].ug.den_one && p[1].uf.den_one;
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
@@ -474,6 +484,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
 #define GO3(G, F, M, PFv, FASTv, MODEv) do { if (rag) GO4(G, F, M, PFv, FASTv, MODEv, true); else if (no_ring) GO4(G, F, M, PFv, FASTv, MODEv, false); else GO4(G, F, M, (FASTv ? 0 : PFv), FASTv, MODEv, false); } while (0)
 #define GO(G, F, M, PFv, FASTv) do { if (mode == 0) GO3(G, F, M, PFv, FASTv, 0); else if (mode == 1) GO3(G, F, M, PFv, FASTv, 1); else if (mode == 2) GO3(G, F, M, PFv, FASTv, 2); else GO3(G, F, M, PFv, FASTv, 3); } while (0)
   if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 3, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 3, true); }
+  else if (fast && mask == 0x2 && d->g_b_masked) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x82, 3, true);      // inpainting: binary mask folded into b
   else if (fast && mask == 0x2) {
     GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 3, true);
   }

@@ -30,7 +30,7 @@ struct IterParamsMc {          // step sizes of one iteration + the host-evaluat
   UniformDiv sq;
 };
 
-template <class T, int VEC, bool GB>
+template <class T, int VEC, int GB>
 struct ColMcX2 {
   T y1[VEC], y2[VEC], x[VEC], b[GB ? VEC : 1];
 };
@@ -47,7 +47,8 @@ __device__ __forceinline__ void stm_o(T* __restrict__ base, unsigned byte_off, c
 // RES: additionally the four residual sums of the SECOND iteration (backend_pdhg.cu:73-120), term by term the expressions of
 // fused_iter2d_mc_kernel; K^T y^k of a column waits two steps between stages A and C in LDS, the sums are accumulated in LDS
 // (own lanes, no synchronisation) -- as in kernels_fused_iter3d_x2.hip.  One partial (4 doubles) per workgroup.
-template <class T, int VEC, int GFN, bool GB, int LW, bool RES>
+// GB: 0 scalar b of prox_g, 1 per-pixel b, 2 per-pixel b that carries the mask sentinel (prost_hip_mask_merge: binary a folded in)
+template <class T, int VEC, int GFN, int GB, int LW, bool RES>
 __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                                 const T* __restrict__ y, FusedArgs<T> a, IterParamsMc<T> p1,
                                                                                 IterParamsMc<T> p2, double* __restrict__ partial) {
@@ -90,7 +91,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
                     const IterParamsMc<T>& Pm, T (&xn)[VEC], T (&ktv)[VEC]) {
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
-    T parg[VEC];
+    T parg[VEC], parg0[GB == 2 ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
@@ -101,6 +102,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
       const T kty = (T)0 - (divx + divy);
       ktv[j] = kty;
       const T arg = xin[j] - tauT * kty;
+      if (GB == 2) parg0[GB == 2 ? j : 0] = arg;
       parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
     }
     T r[VEC];
@@ -111,6 +113,11 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     }
 #pragma unroll
     for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? bv[GB ? j : 0] : a.g_val[1]);
+    if (GB == 2) {
+      // merged b stream: where the binary coefficient a of prox_g is 0 the element passes through (elem_operation_1d.hpp:42-44 with d = e = 0)
+#pragma unroll
+      for (int j = 0; j < VEC; j++) if (is_mask_sentinel(bv[GB ? j : 0])) xn[j] = parg0[GB == 2 ? j : 0];
+    }
   };
   // first half of the dual step at column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77): the two dual arguments of this
   // channel, their squares published for the norm over all channels
@@ -302,6 +309,7 @@ static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
     if (k != 1 && d->g_coeff_ptr[k]) return false;
   }
   if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
+  if (d->g_b_masked && (!d->g_coeff_ptr[1] || d->g_fn != PROST_FN_SQUARE)) return false;
   if (d->g_coeff_val[0] != 1.0 || d->g_coeff_val[2] == 0.0 || d->g_coeff_val[3] != 0.0 || d->g_coeff_val[4] != 0.0) return false;
   if (d->f_coeff_val[0] != 1.0 || d->f_coeff_val[3] != 0.0 || d->f_coeff_val[4] != 0.0) return false;
   // (res_x0 / res_x1 -- the owned columns of a sharded slab -- restrict the residual sums of the RES instances)
@@ -368,7 +376,8 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
 #define GO3(G, B, LWv) do { if (out4) GO4(G, B, LWv, true); else GO4(G, B, LWv, false); } while (0)
 #define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)
 #define GO(B) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B); else GO2(PROST_FN_SQUARE, B); } while (0)
-  if (d->g_coeff_ptr[1]) GO(true); else GO(false);
+  if (d->g_coeff_ptr[1] && d->g_b_masked) GO2(PROST_FN_SQUARE, 2);       // inpainting: binary mask folded into b (square data term)
+  else if (d->g_coeff_ptr[1]) GO(1); else GO(0);
 #undef GO
 #undef GO2
 #undef GO3

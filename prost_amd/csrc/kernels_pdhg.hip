@@ -124,6 +124,31 @@ static int reduce_to(double* out2, void* ws, const EwIn<T, NIN>& in, size_t n, F
   return launch_fold(out2, partial, g, sqrt_first, st);
 }
 
+// bm = a == 0 ? sentinel : b ;  counts a outside {0, 1}   (prost_hip_mask_merge)
+template <class T>
+__global__ void __launch_bounds__(kBlock) mask_merge_kernel(T* __restrict__ bm, const T* __restrict__ a, const T* __restrict__ b, T b_val, size_t n,
+                                                            unsigned long long* nonbinary) {
+  unsigned long long bad = 0;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const T av = a[i];
+    if (av != (T)0 && av != (T)1) bad++;
+    T out = b ? b[i] : b_val;
+    if (av == (T)0) {
+      if constexpr (sizeof(T) == 4) out = __uint_as_float(PROST_HIP_MASK_SENTINEL_F32);
+      else out = __longlong_as_double((long long)PROST_HIP_MASK_SENTINEL_F64);
+    }
+    bm[i] = out;
+  }
+  if (bad) atomicAdd(nonbinary, bad);
+}
+template <class T>
+static int launch_mask_merge(T* bm, const T* a, const T* b, double b_val, size_t n, unsigned long long* nonbinary, void* stream) {
+  if (n == 0) return 0;
+  if (!bm || !a || !nonbinary) { set_error("mask_merge: bm, a and the counter are required"); return 1; }
+  hipLaunchKernelGGL((mask_merge_kernel<T>), dim3(grid_for(n, 4)), dim3(kBlock), 0, as_stream(stream), bm, a, b, (T)b_val, n, nonbinary);
+  PH_LAUNCH_END("mask merge kernel");
+}
+
 }  // namespace prost_hip
 
 using namespace prost_hip;
@@ -200,4 +225,6 @@ int prost_hip_admm_elem_f64(int op, double* o, const double* a, const double* b,
   return launch_admm<double>(op, o, a, b, c, d, alpha, beta, n, s);
 }
 
+int prost_hip_mask_merge_f32(float* bm, const float* a, const float* b, double b_val, size_t n, unsigned long long* nonbinary, void* s) { return launch_mask_merge<float>(bm, a, b, b_val, n, nonbinary, s); }
+int prost_hip_mask_merge_f64(double* bm, const double* a, const double* b, double b_val, size_t n, unsigned long long* nonbinary, void* s) { return launch_mask_merge<double>(bm, a, b, b_val, n, nonbinary, s); }
 }  // extern "C"

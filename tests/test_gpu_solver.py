@@ -207,6 +207,55 @@ def test_verbose_output_reaches_the_front_end_print_function():
     assert len(chunks) == n
 
 
+def inpaint_problem(nx, ny, L, mask, seed=3, lmb=7.0):
+    """matlab/examples/example_tv_inpaint.m:15-29: sum_1d('square', m, f, lmb) with the mask m as coefficient a, vectorial TV"""
+    f = synthetic.rof_image(nx, ny, L, seed)
+    u, q = prost.variable(nx * ny * L), prost.variable(2 * nx * ny * L)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d("square", mask, f, lmb))
+    prob.add_function(q, prost.function.sum_norm2(2 * L, False, "ind_leq0", 1, 1, 1))
+    prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, L))
+    return prob
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("nx,ny,L", [(37, 252, 1), (40, 128, 3), (33, 66, 2), (24, 130, 1)])
+def test_inpainting_mask_runs_the_double_iteration_kernels_bit_exact(precision, dtype, nx, ny, L):
+    """example_tv_inpaint.m:23: a 0 / 1 mask as coefficient a of the square data term (elem_operation_1d.hpp:42-44: a == 0 skips the
+    function).  A binary a is folded into the b stream (prost_hip_mask_merge) and the two-iterations-per-launch kernels run their
+    straight-line instance on it (gray: fused_iter2d_x2_kernel, 2-4 channels: fused_iter2d_mc_x2_kernel): iterates == single
+    launches == oracle, bit for bit, residual iterations and the rebuilt previous iterate (z, w) included.  A mask with other
+    values keeps the single launches (and still equals the oracle)."""
+    prost.set_precision(precision)
+    rng = np.random.default_rng(12)
+    n = nx * ny * L
+    binary = (rng.random(n) < 0.7).astype(np.float64)
+    binary[:ny] = 0.0                                     # a whole masked column, every channel's first
+    soft = binary.copy(); soft[rng.integers(0, n, 50)] = 0.5
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    for mask, expect_pairs in ((binary, True), (soft, False)):
+        prob = inpaint_problem(nx, ny, L, mask)
+        for step, res_iter in (("alg2", 10), ("boyd", 3)):
+            st = {}
+            for pair in (True, False):
+                b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.3)
+                b[1]["allow_pair_kernel"] = pair
+                s = prost.Solver(prob, b, o)
+                info = s.iterate(47, time_kernels=True, sample_every=1)
+                st[pair] = s.state(); s.destroy()
+                assert st[pair]["path"] == "pdhg:fused-grad2d"
+                paired = any("x2_kernel" in k for k in info["kernels"])
+                assert paired == (pair and expect_pairs), (pair, expect_pairs, list(info["kernels"]))
+            ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.3), o, 47, dtype)
+            for v in "xyzw":
+                assert np.array_equal(st[True][v], st[False][v]), (v, "pair vs single")
+                assert np.array_equal(st[True][v], ost[v]), (v, "vs oracle", float(np.abs(st[True][v] - ost[v]).max()))
+            for v in ("tau", "sigma"):
+                assert st[True][v] == st[False][v] == ost[v]
+        # masked pixels of a column nobody constrains stay what the TV term alone makes of them: the data term never touched them
+    prost.set_precision("double")
+
+
 @pytest.mark.parametrize("solve_dual", [False, True])
 def test_solve_streams_the_same_result_it_hands_to_callbacks(solve_dual):
     """Without an intermediate-solution callback prost.solve takes x, y, z, w straight from the device
