@@ -62,6 +62,11 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
   const unsigned total = gridDim.x, chunks = a.chunks;
   const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;          // XCD-aware tile order (kernels_fused_iter.hip)
   const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
+  // (tried in round 3: vertically adjacent strips as consecutive tiles -- they march over the same columns at the same time, so the
+  // rows their halo lanes share and the cache lines their boundaries straddle (a strip is 248 floats = 7.75 lines per column) meet
+  // in the XCD's L2.  FETCH_SIZE per launch drops from 177.0 to 155.4 thousand KiB (groups of 2 / 4 strips: 169.6 / 164.9), the
+  // total traffic from 564 to 522 MB -- and the launch gets SLOWER, 0.108 against 0.105 ms on the same box: at 5.4 TB/s the kernel
+  // is bound by what a wavefront has in flight, not by the bytes; the chunks of one strip stay consecutive.)
   const unsigned strip = tile / chunks, chunk = tile % chunks;
   const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
   const bool active = row0 >= 0 && row0 < ny;

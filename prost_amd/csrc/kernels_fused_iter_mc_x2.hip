@@ -80,10 +80,23 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   const unsigned voff = (unsigned)(row0 * (long)sizeof(T));          // meaningful in active lanes only
 
   typedef ColMcX2<T, VEC, GB> Col;
+  // kUncond (the plain instance): loads are UNCONDITIONAL -- a lane outside the image reads the strip's first rows, a column outside
+  // the chunk's range the nearest valid one; nobody uses those values (every use is guarded by the predicate that would have guarded
+  // the load), but a register set that is overwritten as a whole each step needs no re-zeroing and no branch around the loads
+  // (kernels_fused_iter3d_x2.hip: 10 % there; here, with three wavefronts per workgroup, within the noise -- as is an LDS-only
+  // barrier, "s_waitcnt lgkmcnt(0); s_barrier", in place of __syncthreads(): 0.205-0.210 ms per iteration at 4096^2 RGB either way)
+  constexpr bool kUncond = !RES;
+  const unsigned voff_ld = kUncond && !active ? 0u : voff;
+  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
   auto load_col = [&](long c, Col& in) {
-    const size_t o = (size_t)c * (size_t)ny;                          // wave-uniform
-    ldm_o<T, VEC>(y1p + o, voff, in.y1); ldm_o<T, VEC>(y2p + o, voff, in.y2); ldm_o<T, VEC>(xp + o, voff, in.x);
-    if constexpr (GB) ldm_o<T, VEC>(bp + o, voff, in.b);
+    if (!kUncond) {
+      in = Col{};
+      if (!(active && has_col(c))) return;
+    }
+    const long cc = !kUncond ? c : (c < 0 ? 0 : (c >= nx ? nx - 1 : c));
+    const size_t o = (size_t)cc * (size_t)ny;                         // wave-uniform
+    ldm_o<T, VEC>(y1p + o, voff_ld, in.y1); ldm_o<T, VEC>(y2p + o, voff_ld, in.y2); ldm_o<T, VEC>(xp + o, voff_ld, in.x);
+    if constexpr (GB != 0) ldm_o<T, VEC>(bp + o, voff_ld, in.b);
   };
   // primal step of this channel at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 on a zero-filled result);
   // v1 / v2: the dual variable at column c, p1c: its first component at column c-1
@@ -213,18 +226,16 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   }
 #pragma unroll
   for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = 0;
-  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
   if (active && xa - 2 >= 0) ldm_o<T, VEC>(y1p + (size_t)(xa - 2) * (size_t)ny, voff, in2.y1);   // becomes in1.y1 for A(xa-1)
   Col pre = {};
-  if (active && has_col(xa - 1)) load_col(xa - 1, pre);
+  load_col(xa - 1, pre);
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): nothing of the prologue in flight when the loop starts (see kernels_fused_iter3d_x2.hip)
 
   int k3 = 0;                                          // slot of s_kt that stage A writes in this step
   for (long c = xa - 3; c <= xb; c++) {
     const int buf = (int)((c + 4) & 1);
     in1 = in2; in2 = pre;
-    pre = Col{};
-    if (active && has_col(c + 3)) load_col(c + 3, pre);
+    load_col(c + 3, pre);
     const long ca = c + 2, cb = c + 1, cd = c - 1;
     const bool runA = ca >= (xa - 1 > 0 ? xa - 1 : 0) && ca < nx && ca <= xb + 1;
     const bool runB = cb >= (xa - 1 > 0 ? xa - 1 : 0) && cb < nx && cb <= xb;

@@ -5,6 +5,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from prost_amd import _hip as hip
+if os.environ.get("PROST_HIP_LIB"):          # A/B runs of kernel variants on one box
+    hip.LIB_PATH = os.environ["PROST_HIP_LIB"]
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 mode = sys.argv[2] if len(sys.argv) > 2 else "iter"
