@@ -532,7 +532,8 @@ int prost_hip_cgls_round_f32(const prost_hip_cgls_desc* d, const prost_hip_fused
 int prost_hip_cgls_round_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream);
 /* The same round with event markers: ev5[0..4] (events of prost_hip_event_create, entries may be NULL) are recorded on `stream`
  * before the first launch and after each of the four, so that a caller can time the round's kernels one by one (measurement
- * only: the markers cost launch pipelining). */
+ * only: the markers cost launch pipelining); ev5[5] is recorded right after ev5[4] -- the interval between those two holds no
+ * kernel and measures what a marker adds to each bracketed interval (the array has SIX entries). */
 int prost_hip_cgls_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream);
 int prost_hip_cgls_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream);
 /* blocking read-back of record `index` of a record array */

@@ -1290,6 +1290,7 @@ static int cgls_round(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op
   if (c.vn) hipLaunchKernelGGL((cg_step_p2_kernel<T, V>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
   else hipLaunchKernelGGL((cg_step_p2_kernel<T, 1>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
   mark(4);
+  mark(5);                      // ev5[4] -> ev5[5]: two markers with nothing in between = what a marker adds to each bracketed interval
   PH_LAUNCH_END("cgls round");
 }
 
