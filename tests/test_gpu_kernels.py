@@ -277,14 +277,14 @@ def test_cgls_stages_at_the_c_abi(hip, dtype, m, n, tol, zero_start):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", ["c4", "side_by_side_3d", "uncovered_rows"])
+@pytest.mark.parametrize("shape", ["c4", "side_by_side_3d", "side_by_side_3d_vec", "uncovered_rows"])
 def test_cgls_fused_rounds_at_the_c_abi(hip, dtype, shape):
     """prost_hip_cgls_round_*: a CG round in four launches -- the operator (CSR and gradient blocks, evaluated by the thread that
     owns the output element, blocks in order) applied inside the kernels, alpha / beta / the stopping test formed by the
     consuming kernels, one scalar record per round -- against (a) the numpy restatement of cgls.hpp on the assembled scipy
     matrix and (b) the staged rounds of prost_hip_cgls_stage_* with the separate operator kernels: same iteration counts,
     same x to round-off (only the grouping of the partial sums differs).
-    c4: K = [W; grad2d] as in BASELINE config 4; side_by_side_3d: K = [A B; grad3d 0]; uncovered_rows: rows no block writes."""
+    c4: K = [W; grad2d] as in BASELINE config 4; side_by_side_3d(_vec): K = [A B; grad3d 0]; uncovered_rows: rows no block writes."""
     import scipy.sparse as sp
     from reference_matrices import spmat_gradient2d, spmat_gradient3d
     rng = np.random.default_rng(5)
@@ -310,8 +310,8 @@ def test_cgls_fused_rounds_at_the_c_abi(hip, dtype, shape):
         W = sp.hstack([sp.diags(rng.uniform(-0.5, 0.5, npx)), sp.diags(rng.uniform(-0.5, 0.5, npx))])
         csr_block(W, 0, 0); grad_block(nx, ny, 2, False, npx, 0)
         m, n = npx + 4 * npx, 2 * npx
-    elif shape == "side_by_side_3d":
-        nx, ny, L = 9, 14, 5
+    elif shape.startswith("side_by_side_3d"):
+        nx, ny, L = (6, 8, 4) if shape.endswith("_vec") else (9, 14, 5)      # _vec: every boundary on a multiple of 4 -> 16 bytes of rows per lane
         npx = nx * ny * L
         csr_block(sp.random(300, npx, density=0.004, random_state=1), 0, 0)
         csr_block(sp.random(300, 120, density=0.03, random_state=2), 0, npx)
