@@ -28,3 +28,28 @@ def test_example_tvl1_removes_salt_and_pepper_noise():
     result, err_noisy, err_denoised = ex.main(nx=96, ny=64, nc=1, max_iters=20000, verbose=False)
     assert result["result"] in ("Converged.", "Reached maximum iterations.")
     assert err_denoised < 0.5 * err_noisy
+
+
+def test_example_tv_inpaint_fills_the_holes_with_pair_launches():
+    """example_tv_inpaint.m: the mask as coefficient a of the data term.  The solve runs two iterations per launch (binary mask folded
+    into the data stream), converges, keeps the known pixels close to the data and gives the oracle's solution and energy."""
+    import oracle
+    import tv_inpaint as ex
+    prost.set_gpu(0)
+    prost.set_precision("double")
+    result, energy, m, f, u = ex.main(nx=60, ny=48, nc=3, max_iters=30000, verbose=False, tol=1e-6)
+    assert result["result"] == "Converged." and int(result["pair_launches"]) > int(result["iters"]) // 3
+    assert np.isfinite(u).all() and np.abs((u - f)[m > 0]).mean() < 0.1
+    # the same description through the CPU oracle (restatement of the reference path)
+    rng = np.random.default_rng(42)
+    from prost_amd import synthetic
+    nx, ny, nc = 60, 48, 3
+    uu, qq = prost.variable(nx * ny * nc), prost.variable(2 * nx * ny * nc)
+    prob = prost.min_max_problem([uu], [qq])
+    prob.add_function(uu, prost.function.sum_1d("square", m, f, 7))
+    prob.add_function(qq, prost.function.sum_norm2(2 * nc, False, "ind_leq0", 1, 1, 1))
+    prob.add_dual_pair(uu, qq, prost.block.gradient2d(nx, ny, nc))
+    o = prost.options(max_iters=30000, num_cback_calls=250, verbose=False, tol_rel_primal=1e-6, tol_rel_dual=1e-6, tol_abs_dual=1e-6, tol_abs_primal=1e-6)
+    ro = oracle.solve(prob, prost.backend.pdhg(stepsize="boyd", residual_iter=10), o, np.float64)
+    assert ro["iters"] == result["iters"]
+    assert np.array_equal(np.asarray(ro["x"]).reshape(-1), u)
