@@ -27,9 +27,10 @@ class BackendPDHG : public Backend<T> {
     bool allow_single_kernel;  ///< MI355X addition: one kernel per non-residual iteration (7 instead of 11 floats/pixel)
     bool allow_pair_kernel;    ///< MI355X addition: two iterations per launch where nobody observes the one in between
     bool allow_arg_fusion;     ///< MI355X addition (generic path): proxes form their argument on the fly, no argument pass
+    bool allow_speculation;    ///< MI355X addition: the next pair launch is enqueued BEFORE the host waits for the residual sums (alg1 / alg2)
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
-                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true) {}
+                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_speculation(true) {}
   };
 
   explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), pair_kernel_(false), res_dev_(nullptr),
@@ -53,8 +54,8 @@ class BackendPDHG : public Backend<T> {
   /// Initialize(); needs the single-kernel path (gradient2d, L <= 2).
   void SetOwnedColumns(size_t x0, size_t x1) { owned_x0_ = x0; owned_x1_ = x1; }
   /// device pointers of the current iterate, for halo exchange between slabs: x (n), y (m)
-  T* x_data() { return x_.data(); }
-  T* y_data() { return y_.data(); }
+  T* x_data() { spec_valid_ = false; return x_.data(); }      // (the caller may write the iterate: a speculative launch from the old one is forgotten)
+  T* y_data() { spec_valid_ = false; return y_.data(); }
   bool single_kernel_path() const { return single_kernel_; }
   virtual size_t pair_launches() const { return pair_launches_; }
   /// one kernel per iteration with residual sums restricted to owned columns: gradient2d with L <= 2 or L = 3 / 4 channels
@@ -86,6 +87,19 @@ class BackendPDHG : public Backend<T> {
   void IterationPairMc(bool residuals);   // the same for gradient2d with 2-4 channels (prost_hip_fused_iteration_mc_x2): k + 2 is not a residual iteration
   void IterationPair3D(bool residuals);   // the same for gradient3d (prost_hip_fused_iteration3d_x2): k + 2 is not a residual iteration
   void RebuildPrevious();                 // x_prev_ / y_prev_ := x^(k-1) / y^(k-1) after a pair that did not store them
+  // Speculative next launch.  With alg1 / alg2 nothing on the device depends on the residual sums, but Solver::Solve reads them after
+  // every residual iteration: the host wait + the latency of the next launch leave the device idle ~15 us per residual iteration
+  // (2.8 % at the headline size).  When the sums are asked for, the pair launch that would follow (iterations k, k+1, plain) is
+  // enqueued FIRST, into the spare buffers, and the host waits for the residual launch's event only.  If the solver goes on with a
+  // budget >= 2 the results are adopted by exchanging buffers (no launch); anything else -- the solver stops, somebody reads or
+  // writes the state -- just forgets them: the iterates the solver can observe are never touched by the speculation.
+  bool CanSpeculate() const;
+  void Speculate();
+  void DropSpeculation() { spec_valid_ = false; }
+  bool spec_valid_ = false;
+  size_t spec_iteration_ = 0;
+  T spec_tau_[3] = {0, 0, 0}, spec_sigma_[3] = {0, 0, 0}, spec_theta_[3] = {0, 0, 0};   // step sizes of iterations k, k+1 and after the pair
+  void* ev_res_local_ = nullptr;          // recorded right after a residual launch (no communicator): what the host waits for
   bool is_residual_iteration(size_t k) const { return k == 0 || (k % (size_t)opts_.residual_iter) == 0; }   // backend_pdhg.cu:389
   void FinishResiduals();                 // all-reduce + D2H enqueued; resolved at once only for residual-driven step rules
   void ResolveResiduals();                // wait, sqrt, step-size rules (backend_pdhg.cu:433-476)

@@ -113,6 +113,7 @@ void BackendPDHG<T>::Initialize() {
   iteration_ = 0;
   pair_launches_ = 0;
   prev_stale_ = false;
+  spec_valid_ = false;
   residuals_pending_ = false;
   tau_ = (T)opts_.tau0;
   sigma_ = (T)opts_.sigma0;
@@ -201,6 +202,8 @@ void BackendPDHG<T>::Release() {
   if (side_stream_) { prost_hip_stream_synchronize(side_stream_); prost_hip_stream_destroy(side_stream_); side_stream_ = nullptr; }
   if (ev_res_ready_) { prost_hip_event_destroy(ev_res_ready_); ev_res_ready_ = nullptr; }
   if (ev_res_done_) { prost_hip_event_destroy(ev_res_done_); ev_res_done_ = nullptr; }
+  if (ev_res_local_) { prost_hip_event_destroy(ev_res_local_); ev_res_local_ = nullptr; }
+  spec_valid_ = false;
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;
   y_spare_.clear(); x_spare_.clear(); sol_z_.clear(); sol_w_.clear(); b_masked_.clear();
@@ -227,6 +230,20 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   // z, w of the last read-out (n + m values; the reference keeps no such copies): large ones are released when the iteration
   // goes on, small ones stay for the next callback
   if (!sol_z_.empty() && (sol_z_.size() + sol_w_.size()) * sizeof(T) > ((size_t)1 << 30)) { sol_z_.clear(); sol_w_.clear(); }
+  if (spec_valid_) {
+    spec_valid_ = false;
+    if (budget >= 2 && k == spec_iteration_) {
+      // the pair (k, k+1) already ran, into the spare buffers: exchange them in, exactly the state IterationPair leaves
+      x_prev_.swap(x_spare_); x_.swap(x_prev_);          // x_ = x^(k+2), x_prev_ = x^k (the pair's input), spare = what x_prev_ held
+      y_prev_.swap(y_spare_); y_.swap(y_prev_);
+      prev_stale_ = true;
+      stale_tau_ = spec_tau_[0]; stale_sigma_ = spec_sigma_[0]; stale_theta_ = spec_theta_[0];
+      tau_ = spec_tau_[2]; sigma_ = spec_sigma_[2]; theta_ = spec_theta_[2];
+      iteration_ += 2;
+      pair_launches_++;
+      return 2;
+    }
+  }
   if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
     IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
     pair_launches_++;
@@ -352,6 +369,7 @@ void BackendPDHG<T>::IterationPairMc(bool residuals) {
 /// single-iteration launch with the step sizes of iteration k rebuilds x^(k+1), y^(k+1) bit for bit.
 template <typename T>
 void BackendPDHG<T>::RebuildPrevious() {
+  spec_valid_ = false;               // (the spare buffers are about to be written, or the state to be looked at)
   if (!prev_stale_) return;
   last_end_ = kNoEvent;
   if (x_spare_.size() != x_.size()) x_spare_.resize(x_.size());
@@ -542,8 +560,41 @@ void BackendPDHG<T>::FinishResiduals() {
       CheckHip(prost_hip_memcpy_d2h(res_host_, res_dev_, 4 * sizeof(double), s), "memcpy_d2h");
     }
   }
+  else if (opts_.allow_speculation && pair_kernel_) {
+    if (!ev_res_local_) CheckHip(prost_hip_event_create(&ev_res_local_), "event_create");
+    CheckHip(prost_hip_event_record(ev_res_local_, s), "event_record");
+  }
   residuals_pending_ = true;
   if (opts_.stepsize_variant == kPDHGStepsResidualGoldstein || opts_.stepsize_variant == kPDHGStepsResidualBoyd) ResolveResiduals();
+}
+
+template <typename T>
+bool BackendPDHG<T>::CanSpeculate() const {
+  if (!opts_.allow_speculation || !pair_kernel_ || this->comm_ || owned_x1_ != 0 || !ev_res_local_ || spec_valid_) return false;
+  if (opts_.stepsize_variant != kPDHGStepsAlg1 && opts_.stepsize_variant != kPDHGStepsAlg2) return false;
+  const size_t k = iteration_;
+  // a PLAIN pair must be what PerformIterations(budget >= 2) would launch next: no residual sums, no stored intermediate iterate
+  if (k < 2 || is_residual_iteration(k) || is_residual_iteration(k + 1) || is_residual_iteration(k + 2)) return false;
+  return x_spare_.size() == x_.size() && y_spare_.size() == y_.size();
+}
+
+template <typename T>
+void BackendPDHG<T>::Speculate() {
+  double tau[2], sigma[2], theta[2];
+  const T t0 = tau_, s0 = sigma_, th0 = theta_;
+  spec_tau_[0] = tau_; spec_sigma_[0] = sigma_; spec_theta_[0] = theta_;
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  spec_tau_[1] = tau_; spec_sigma_[1] = sigma_; spec_theta_[1] = theta_;
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  spec_tau_[2] = tau_; spec_sigma_[2] = sigma_; spec_theta_[2] = theta_;
+  tau_ = t0; sigma_ = s0; theta_ = th0;                  // nothing observable changes until the results are adopted
+  for (int i = 0; i < 2; i++) { tau[i] = (double)spec_tau_[i]; sigma[i] = (double)spec_sigma_[i]; theta[i] = (double)spec_theta_[i]; }
+  const bool t = BeginSample(kKernelPair);
+  CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
+                                    nullptr, nullptr, CurrentStream()), "fused_iteration2");
+  EndSample(t);
+  spec_iteration_ = iteration_;
+  spec_valid_ = true;
 }
 
 template <typename T>
@@ -551,6 +602,10 @@ void BackendPDHG<T>::ResolveResiduals() {
   if (!residuals_pending_) return;
   residuals_pending_ = false;
   if (resolve_on_side_) { CheckHip(prost_hip_event_synchronize(ev_res_done_), "event_synchronize"); resolve_on_side_ = false; }
+  else if (CanSpeculate()) {
+    Speculate();                                         // the device goes on with the next pair while the host looks at the sums
+    CheckHip(prost_hip_event_synchronize(ev_res_local_), "event_synchronize");
+  }
   else CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   // the reference reduces in T and takes std::sqrt of the T sums (:433-436)

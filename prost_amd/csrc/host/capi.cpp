@@ -335,6 +335,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       if (prost_value_field(d, "allow_fused")) o.allow_fused = GetScalarFromField(d, "allow_fused") > 0.;
       if (prost_value_field(d, "allow_single_kernel")) o.allow_single_kernel = GetScalarFromField(d, "allow_single_kernel") > 0.;
       if (prost_value_field(d, "allow_pair_kernel")) o.allow_pair_kernel = GetScalarFromField(d, "allow_pair_kernel") > 0.;
+      if (prost_value_field(d, "allow_speculation")) o.allow_speculation = GetScalarFromField(d, "allow_speculation") > 0.;
       if (prost_value_field(d, "allow_arg_fusion")) o.allow_arg_fusion = GetScalarFromField(d, "allow_arg_fusion") > 0.;
       return new BackendPDHG<T>(o);
     };

@@ -42,7 +42,7 @@ def run_product(prob, backend, opts, iters):
 
 def run_oracle(prob, backend, opts, iters, dtype):
     prob.finalize()
-    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds")}]
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel")}]
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
     s.initialize()
     s.iterate(iters)
@@ -205,6 +205,59 @@ def test_verbose_output_reaches_the_front_end_print_function():
     n = len(chunks)
     prost.solve(prob, b, prost.options(max_iters=10, num_cback_calls=0, verbose=False))
     assert len(chunks) == n
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", ["alg2", "alg1"])
+@pytest.mark.parametrize("residual_iter", [4, 5, 10])
+def test_speculative_next_launch_is_invisible(precision, dtype, step, residual_iter):
+    """With alg1 / alg2 the pair launch that follows a residual iteration is enqueued BEFORE the host waits for the residual sums
+    (into spare buffers) and adopted by a buffer exchange if the solver goes on, forgotten otherwise.  Whatever the caller does in
+    between -- checked iteration (the loop of prost.solve), reading the state (z, w need the rebuilt previous iterate, which uses
+    the same spare buffers), unchecked iteration, a solve that stops on its tolerance -- the results equal those of a solver that
+    never speculates, and the oracle's."""
+    prost.set_precision(precision)
+    prob, u, q, f = synthetic.rof_problem(44, 252, 1, seed=9)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    runs = {}
+    for spec in (True, False):
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.4)
+        b[1]["allow_speculation"] = spec
+        s = prost.Solver(prob, b, o)
+        trace = []
+        s.iterate(residual_iter + 1, checked=True)               # ends right after a residual iteration: a speculative pair is in flight
+        trace.append(s.state())                                   # ... and is forgotten here (the read-out rebuilds the previous iterate)
+        s.iterate(3 * residual_iter + 1, checked=True)            # several adoptions in a row
+        s.iterate(3)                                              # unchecked: nobody asks for residuals
+        trace.append(s.state(vectors=False)["primal_res"])        # accessor only: speculates, then ...
+        s.iterate(1, checked=True)                                # ... a budget of one: forgotten again
+        s.iterate(2 * residual_iter, checked=True)
+        trace.append(s.state())
+        s.destroy()
+        runs[spec] = trace
+    for a, b_ in zip(runs[True], runs[False]):
+        if isinstance(a, dict):
+            for v in "xyzw":
+                assert np.array_equal(a[v], b_[v]), v
+            for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res"):
+                assert a[v] == b_[v], v
+        else:
+            assert a == b_
+    total = int(runs[True][-1]["iteration"])
+    ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.4), o, total, dtype)
+    for v in "xyzw":
+        assert np.array_equal(runs[True][-1][v], ost[v]), v
+    # a solve that stops on its tolerance: same iteration, same result with and without
+    o2 = prost.options(max_iters=5000, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=1e-3, tol_abs_dual=1e-3)
+    res = {}
+    for spec in (True, False):
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.4)
+        b[1]["allow_speculation"] = spec
+        res[spec] = prost.solve(prob, b, o2)
+    assert res[True]["result"] == res[False]["result"] == "Converged." and res[True]["iters"] == res[False]["iters"]
+    for v in "xyzw":
+        assert np.array_equal(np.asarray(res[True][v]), np.asarray(res[False][v])), v
+    prost.set_precision("double")
 
 
 def inpaint_problem(nx, ny, L, mask, seed=3, lmb=7.0):
