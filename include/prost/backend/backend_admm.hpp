@@ -75,7 +75,7 @@ class BackendADMM : public Backend<T> {
   bool fused_rounds_ = false;
   int cg_result_index_ = 0;      ///< record that holds the result of the most recent device solve
   // kernel timing (bench roofline figure): the four launches of ONE round of a sampled solve are bracketed by events
-  std::vector<void*> ev_;        ///< pool, six events per sampled round (four kernels + one empty interval)
+  std::vector<void*> ev_;        ///< pool, eight events per sampled round (begin / end of its four kernels)
   size_t ev_used_ = 0, solves_ = 0, rounds_launched_ = 0;
   T rho_, delta_;
   int arb_u_, arb_l_;

@@ -57,6 +57,12 @@ int prost_hip_stream_create(void** stream);
 int prost_hip_stream_destroy(void* stream);
 int prost_hip_stream_synchronize(void* stream);
 int prost_hip_device_synchronize(void);
+/* Kernel timing without stream markers: the NEXT iteration-kernel launch of the calling thread (the fused PDHG iteration kernels
+ * and the kernels of prost_hip_cgls_round) stamps `start` / `stop` (events of prost_hip_event_create) with the kernel's own begin
+ * and end (hipExtLaunchKernel), so prost_hip_event_elapsed_ms(start, stop) is the kernel's duration as a profiler reports it and no
+ * barrier packet sits between consecutive launches.  (NULL, NULL) withdraws events no launch has taken.  Launches that record
+ * nothing else (reduction folds, generic kernels) do not take the events. */
+int prost_hip_next_launch_events(void* start, void* stop);
 /* HIP graphs: the launches enqueued on `stream` between begin and end are recorded instead of executed;
  * end returns an executable graph that replays them with one host call (launch-bound inner loops). */
 int prost_hip_stream_begin_capture(void* stream);
@@ -530,12 +536,11 @@ typedef struct prost_hip_fused_op {
 int prost_hip_fused_op_supported(const prost_hip_fused_op* op, uint64_t m, uint64_t n);
 int prost_hip_cgls_round_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream);
 int prost_hip_cgls_round_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream);
-/* The same round with event markers: ev5[0..4] (events of prost_hip_event_create, entries may be NULL) are recorded on `stream`
- * before the first launch and after each of the four, so that a caller can time the round's kernels one by one (measurement
- * only: the markers cost launch pipelining); ev5[5] is recorded right after ev5[4] -- the interval between those two holds no
- * kernel and measures what a marker adds to each bracketed interval (the array has SIX entries). */
-int prost_hip_cgls_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream);
-int prost_hip_cgls_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream);
+/* The same round with per-kernel timing: kernel k of the round (0: the forward operator stage, 1: STEP_XR2, 2: the adjoint operator
+ * stage, 3: STEP_P2) stamps ev8[2 k] / ev8[2 k + 1] (events of prost_hip_event_create; a NULL pair skips that kernel) with its
+ * own begin / end, as prost_hip_next_launch_events does: no marker packets between the launches. */
+int prost_hip_cgls_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev8, void* stream);
+int prost_hip_cgls_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev8, void* stream);
 /* blocking read-back of record `index` of a record array */
 int prost_hip_cgls_result_at(const void* state, int index, prost_hip_cgls_result_t* out, void* stream);
 /* The start of a solve the same way: INIT_X ; [INIT_R ; r += K t ; INIT_R2] ; [s += K^T (sqrt(Sigma) r) ; INIT_S], each bracket

@@ -38,6 +38,25 @@ constexpr int kBlock = 256;        // 4 waves, one per SIMD
 constexpr int kMaxGridStride = 1 << 20;
 constexpr int kReduceBlocks = 8192;        // partial slots in the reduction workspace (pairs of doubles)
 
+// Kernel timing without stream markers (prost_hip_next_launch_events): the next PH_LAUNCH of the calling thread hands the two events
+// to hipExtLaunchKernelGGL, which stamps them with the kernel's OWN begin / end -- hipEventElapsedTime between them is the kernel's
+// duration as rocprofv3 reports it.  hipEventRecord brackets are barrier packets: they break the back-to-back dispatch of
+// consecutive launches (~4 us each) and measure the dispatch gap along with the kernel (a 22 us kernel read 14 % long).
+extern thread_local hipEvent_t g_launch_ev_start, g_launch_ev_stop;
+}  // namespace prost_hip
+#include <hip/hip_ext.h>
+#define PH_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                        \
+  do {                                                                                                                              \
+    if (::prost_hip::g_launch_ev_start) {                                                                                           \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ::prost_hip::g_launch_ev_start, ::prost_hip::g_launch_ev_stop, 0,   \
+                            __VA_ARGS__);                                                                                           \
+      ::prost_hip::g_launch_ev_start = nullptr; ::prost_hip::g_launch_ev_stop = nullptr;                                            \
+    } else {                                                                                                                        \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                                          \
+    }                                                                                                                               \
+  } while (0)
+namespace prost_hip {
+
 inline unsigned grid_for(size_t n, int per_thread = 1) {
   size_t b = (n + (size_t)kBlock * per_thread - 1) / ((size_t)kBlock * per_thread);
   if (b < 1) b = 1;

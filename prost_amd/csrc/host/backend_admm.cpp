@@ -223,13 +223,13 @@ void BackendADMM<T>::CglsDevice(const device_vector<T>& b, device_vector<T>& x, 
     CheckHip(Api<T>::cgls_init_fused(&d, &fused_op_, st), "cgls_init_fused");
     int queued = 0;
     // kernel timing: the second round of one solve in `sample_every_` is bracketed kernel by kernel (at most 512 samples)
-    const bool sample = this->time_kernels_ && (solves_++ % (size_t)this->sample_every_) == 0 && ev_used_ + 6 <= 6 * 512;
+    const bool sample = this->time_kernels_ && (solves_++ % (size_t)this->sample_every_) == 0 && ev_used_ + 8 <= 8 * 512;
     for (int k = 0; k < maxit; ++k) {
       if (*static_cast<volatile int*>(cg_done_host_) == d.epoch) break;
       if (sample && k == (maxit > 1 ? 1 : 0)) {
-        while (ev_.size() < ev_used_ + 6) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
+        while (ev_.size() < ev_used_ + 8) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
         CheckHip(Api<T>::cgls_round_timed(&d, &fused_op_, k, ev_.data() + ev_used_, st), "cgls_round");
-        ev_used_ += 6;
+        ev_used_ += 8;
       } else {
         CheckHip(Api<T>::cgls_round(&d, &fused_op_, k, st), "cgls_round");
       }
@@ -286,18 +286,13 @@ void BackendADMM<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   CheckHip(prost_hip_event_synchronize(ev_[ev_used_ - 1]), "event_synchronize");
   static const char* const names[4] = {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"};
   double sum[4] = {0, 0, 0, 0};
-  const size_t samples = ev_used_ / 6;
-  for (size_t s = 0; s < samples; s++) {
-    // the marker between two kernels of a round breaks their back-to-back dispatch: each bracketed interval holds the kernel plus
-    // what the marker costs, measured by the empty interval ev[4] -> ev[5] of the same round and taken off
-    float empty = 0;
-    CheckHip(prost_hip_event_elapsed_ms(ev_[6 * s + 4], ev_[6 * s + 5], &empty), "event_elapsed");
-    for (int k = 0; k < 4; k++) {
+  const size_t samples = ev_used_ / 8;
+  for (size_t s = 0; s < samples; s++)
+    for (int k = 0; k < 4; k++) {                       // the kernel's own begin / end stamps (hipExtLaunchKernel): no marker in between
       float ms = 0;
-      CheckHip(prost_hip_event_elapsed_ms(ev_[6 * s + k], ev_[6 * s + k + 1], &ms), "event_elapsed");
-      sum[k] += ms > empty ? ms - empty : 0.0;
+      CheckHip(prost_hip_event_elapsed_ms(ev_[8 * s + 2 * k], ev_[8 * s + 2 * k + 1], &ms), "event_elapsed");
+      sum[k] += ms;
     }
-  }
   for (int k = 0; k < 4; k++) out.push_back({names[k], sum[k] / (double)samples, samples, rounds_launched_, 0, 0});
   ev_used_ = 0; rounds_launched_ = 0; solves_ = 0;
 }

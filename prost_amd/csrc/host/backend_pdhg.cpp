@@ -270,29 +270,28 @@ int BackendPDHG<T>::PerformIterations(int budget) {
 template <typename T>
 size_t BackendPDHG<T>::NewEvent() {
   if (ev_used_ == ev_.size()) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
-  CheckHip(prost_hip_event_record(ev_[ev_used_], CurrentStream()), "event_record");
   return ev_used_++;
 }
 
-/// Event pair around a launch.  When EVERY launch is sampled (short runs) consecutive launches share their boundary
-/// event -- a marker costs about 4 us of launch pipelining, so this halves the price; the chain is broken wherever
-/// something else sits between two launches (fold / all-reduce after a residual launch, a host wait, a rebuild launch).
+/// Timing of a launch: the next iteration-kernel launch stamps an event pair with the kernel's OWN begin / end
+/// (prost_hip_next_launch_events -> hipExtLaunchKernel).  Up to round 2 the launch was bracketed by hipEventRecord markers on the
+/// stream: barrier packets that break the back-to-back dispatch of consecutive launches (~4 us each -- 3 % of a 20-step run with
+/// every launch bracketed) and measure the dispatch gap along with the kernel.
 template <typename T>
 bool BackendPDHG<T>::BeginSample(int kind) {
-  // (an untimed launch breaks the chain of shared boundary events; the pool is bounded: at most kMaxSamples launches are
-  // bracketed between two KernelTimes calls, later ones run unmarked)
-  if (!this->time_kernels_ || samples_.size() >= kMaxSamples) { last_end_ = kNoEvent; return false; }
-  // one launch in `sample_every_`: the markers must not serialise the stream of a long run
-  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) { last_end_ = kNoEvent; return false; }
-  const size_t start = (this->sample_every_ == 1 && last_end_ != kNoEvent) ? last_end_ : NewEvent();
-  samples_.push_back({kind, start, kNoEvent});
+  // (at most kMaxSamples launches are timed between two KernelTimes calls, later ones run untimed)
+  if (!this->time_kernels_ || samples_.size() >= kMaxSamples) return false;
+  // one launch in `sample_every_`
+  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) return false;
+  const size_t start = NewEvent(), end = NewEvent();
+  CheckHip(prost_hip_next_launch_events(ev_[start], ev_[end]), "next_launch_events");
+  samples_.push_back({kind, start, end});
   return true;
 }
 
 template <typename T>
 void BackendPDHG<T>::EndSample(bool sampled) {
-  if (!sampled) return;
-  samples_.back().end = last_end_ = NewEvent();
+  if (sampled) CheckHip(prost_hip_next_launch_events(nullptr, nullptr), "next_launch_events");     // (a launch that did not take them)
 }
 
 template <typename T>

@@ -1241,8 +1241,8 @@ template <class T, bool ADJ, class E>
 static void launch_op(const prost_hip_fused_op* op, const E& e, const T* in, size_t count, bool vec, unsigned grid, const CgState* cur, double* ws, hipStream_t st) {
   constexpr int V = VecOf<T>::N;
   const FusedOpDev dev = make_op(op);
-  if (vec) hipLaunchKernelGGL((op_stage_kernel<T, V, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
-  else hipLaunchKernelGGL((op_stage_kernel<T, 1, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
+  if (vec) PH_LAUNCH((op_stage_kernel<T, V, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
+  else PH_LAUNCH((op_stage_kernel<T, 1, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
 }
 
 template <class T>
@@ -1259,7 +1259,7 @@ struct CgPtrs {
 };
 
 template <class T>
-static int cgls_round(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream, void* const* ev5 = nullptr) {
+static int cgls_round(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream, void* const* ev8 = nullptr) {
   if (!d || !d->state || !d->workspace) { set_error("cgls_round: state and workspace are required"); return 1; }
   if (round < 0) { set_error("cgls_round: negative round"); return 1; }
   if (!fused_op_ok(op, d->m, d->n)) { set_error("cgls_round: unsupported operator description (prost_hip_fused_op_supported)"); return 1; }
@@ -1274,23 +1274,22 @@ static int cgls_round(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op
   CgState* nxt = static_cast<CgState*>(d->state) + round + 1;
   double* ws = static_cast<double*>(d->workspace);
   const double eps = (double)std::numeric_limits<T>::epsilon();
-  auto mark = [&](int k) { if (ev5 && ev5[k]) (void)hipEventRecord((hipEvent_t)ev5[k], st); };
+  // ev8: kernel k of the round stamps ev8[2 k] / ev8[2 k + 1] with its own begin / end (PH_LAUNCH, common.hpp)
+  auto mark = [&](int k) { if (ev8 && ev8[2 * k] && ev8[2 * k + 1]) { g_launch_ev_start = (hipEvent_t)ev8[2 * k]; g_launch_ev_stop = (hipEvent_t)ev8[2 * k + 1]; } };
   mark(0);
   launch_op<T, false>(op, EpiFwdQ<T>{c.q, c.sigma}, c.t, c.m, c.vop, gq, cur, ws, st);
   mark(1);
   const StepXR<T> fx{c.x, c.p, nullptr, c.tau, c.r, c.q, c.sigma, c.t, (T)(-d->shift), (T)0, (T)0};
   const RoundScalars ax{d->shift, eps, gq, gp, nullptr};
-  if (c.vn && c.vm) hipLaunchKernelGGL((cg_step_xr2_kernel<T, V>), dim3(gx), dim3(kBlock), 0, st, fx, c.n, c.m, cur, nxt, ws, ax);
-  else hipLaunchKernelGGL((cg_step_xr2_kernel<T, 1>), dim3(gx), dim3(kBlock), 0, st, fx, c.n, c.m, cur, nxt, ws, ax);
+  if (c.vn && c.vm) PH_LAUNCH((cg_step_xr2_kernel<T, V>), dim3(gx), dim3(kBlock), 0, st, fx, c.n, c.m, cur, nxt, ws, ax);
+  else PH_LAUNCH((cg_step_xr2_kernel<T, 1>), dim3(gx), dim3(kBlock), 0, st, fx, c.n, c.m, cur, nxt, ws, ax);
   mark(2);
   launch_op<T, true>(op, EpiAdjS<T>{c.s, c.tau, c.x, (T)(-d->shift)}, c.t, c.n, c.vop, gs, cur, ws, st);
   mark(3);
   const StepP<T> fp{c.p, c.s, c.t, c.tau, (T)0};
   const RoundScalars ap{d->shift, eps, gs, gx, d->host_done};
-  if (c.vn) hipLaunchKernelGGL((cg_step_p2_kernel<T, V>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
-  else hipLaunchKernelGGL((cg_step_p2_kernel<T, 1>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
-  mark(4);
-  mark(5);                      // ev5[4] -> ev5[5]: two markers with nothing in between = what a marker adds to each bracketed interval
+  if (c.vn) PH_LAUNCH((cg_step_p2_kernel<T, V>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
+  else PH_LAUNCH((cg_step_p2_kernel<T, 1>), dim3(gpp), dim3(kBlock), 0, st, fp, c.n, cur, nxt, ws, ap);
   PH_LAUNCH_END("cgls round");
 }
 
@@ -1377,8 +1376,8 @@ int prost_hip_normest_stage_f64(int stage, const prost_hip_normest_desc* d, void
 int prost_hip_fused_op_supported(const prost_hip_fused_op* op, uint64_t m, uint64_t n) { return fused_op_ok(op, m, n) ? 1 : 0; }
 int prost_hip_cgls_round_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream) { return cgls_round<float>(d, op, round, stream); }
 int prost_hip_cgls_round_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* stream) { return cgls_round<double>(d, op, round, stream); }
-int prost_hip_cgls_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream) { return cgls_round<float>(d, op, round, stream, ev5); }
-int prost_hip_cgls_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev5, void* stream) { return cgls_round<double>(d, op, round, stream, ev5); }
+int prost_hip_cgls_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev8, void* stream) { return cgls_round<float>(d, op, round, stream, ev8); }
+int prost_hip_cgls_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev8, void* stream) { return cgls_round<double>(d, op, round, stream, ev8); }
 int prost_hip_cgls_init_fused_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream) { return cgls_init_fused<float>(d, op, stream); }
 int prost_hip_cgls_init_fused_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream) { return cgls_init_fused<double>(d, op, stream); }
 int prost_hip_admm_fused_stage_f32(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream) { return admm_fused_stage<float>(stage, d, op, stream); }

@@ -333,7 +333,7 @@ static int run_primal(const prost_hip_fused_desc* d, T* x_new, const T* x, const
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k] && k != 1) coeff_vec_other = true;
   // straight-line instance: square with scalar a = 1, c != 0, d = e = 0 (b scalar or per pixel)
   const bool fast = d->g_fn == PROST_FN_SQUARE && !coeff_vec_other && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0;
-#define GO(VECv, GFNv, RESv, FASTv) hipLaunchKernelGGL((fused_primal2d_kernel<T, VECv, GFNv, RESv, FASTv>), grid, block, 0, s, x_new, x, y, y_prev, a, (T)tau, ug.sq, use_kty != 0, use_kty_prev != 0, partial)
+#define GO(VECv, GFNv, RESv, FASTv) PH_LAUNCH((fused_primal2d_kernel<T, VECv, GFNv, RESv, FASTv>), grid, block, 0, s, x_new, x, y, y_prev, a, (T)tau, ug.sq, use_kty != 0, use_kty_prev != 0, partial)
   if (vec) {
     if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_SQUARE, true, true); else GO(VecOf<T>::N, PROST_FN_SQUARE, false, true); }
     else if (d->g_fn == PROST_FN_SQUARE) { if (out2) GO(VecOf<T>::N, PROST_FN_SQUARE, true, false); else GO(VecOf<T>::N, PROST_FN_SQUARE, false, false); }
@@ -362,7 +362,7 @@ static int run_dual_l(const prost_hip_fused_desc* d, T* y_new, const T* y, const
   for (int k = 0; k < 7; k++) if (d->f_coeff_ptr[k]) f_vec = true;
   // straight-line instance: ind_leq0 with scalar coefficients a = 1, d = e = 0
   const bool fast = d->f_fn == PROST_FN_IND_LEQ0 && !f_vec && a.f_val[0] == (T)1 && a.f_val[3] == (T)0 && a.f_val[4] == (T)0;
-#define GO(VECv, FFNv, RESv, FASTv) hipLaunchKernelGGL((fused_dual2d_kernel<T, VECv, LCH, FFNv, RESv, FASTv>), grid, block, 0, s, y_new, y, xn, xo, a, (T)sigma, (T)theta, use_kx_prev != 0, partial)
+#define GO(VECv, FFNv, RESv, FASTv) PH_LAUNCH((fused_dual2d_kernel<T, VECv, LCH, FFNv, RESv, FASTv>), grid, block, 0, s, y_new, y, xn, xo, a, (T)sigma, (T)theta, use_kx_prev != 0, partial)
   if (vec) {
     if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_IND_LEQ0, true, true); else GO(VecOf<T>::N, PROST_FN_IND_LEQ0, false, true); }
     else if (d->f_fn == PROST_FN_IND_LEQ0) { if (out2) GO(VecOf<T>::N, PROST_FN_IND_LEQ0, true, false); else GO(VecOf<T>::N, PROST_FN_IND_LEQ0, false, false); }

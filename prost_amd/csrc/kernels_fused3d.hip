@@ -259,7 +259,7 @@ int run_primal3d(const prost_hip_fused_desc* d, T* x_new, const T* x, const T* y
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const bool g_uniform = !d->g_coeff_ptr[0] && !d->g_coeff_ptr[2] && !d->g_coeff_ptr[4];
   const bool fast = d->g_fn == PROST_FN_SQUARE;
-#define GO(VECv, GFNv, RESv) hipLaunchKernelGGL((fused_primal3d_kernel<T, VECv, GFNv, RESv>), grid, block, 0, s, x_new, x, y, y_prev, a, ug, g_uniform, (T)tau, use_kty != 0, use_kty_prev != 0, partial)
+#define GO(VECv, GFNv, RESv) PH_LAUNCH((fused_primal3d_kernel<T, VECv, GFNv, RESv>), grid, block, 0, s, x_new, x, y, y_prev, a, ug, g_uniform, (T)tau, use_kty != 0, use_kty_prev != 0, partial)
   if (vec) {
     if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_SQUARE, true); else GO(VecOf<T>::N, PROST_FN_SQUARE, false); }
     else { if (out2) GO(VecOf<T>::N, -1, true); else GO(VecOf<T>::N, -1, false); }
@@ -289,7 +289,7 @@ int run_dual3d(const prost_hip_fused_desc* d, T* y_new, const T* y, const T* xn,
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   const bool f_uniform = !d->f_coeff_ptr[0] && !d->f_coeff_ptr[2] && !d->f_coeff_ptr[4];
   const bool fast = d->f_fn == PROST_FN_IND_LEQ0;
-#define GO(VECv, FFNv, RESv) hipLaunchKernelGGL((fused_dual3d_kernel<T, VECv, FFNv, RESv>), grid, block, 0, s, y_new, y, xn, xo, a, uf, f_uniform, (T)sigma, (T)theta, use_kx_prev != 0, partial)
+#define GO(VECv, FFNv, RESv) PH_LAUNCH((fused_dual3d_kernel<T, VECv, FFNv, RESv>), grid, block, 0, s, y_new, y, xn, xo, a, uf, f_uniform, (T)sigma, (T)theta, use_kx_prev != 0, partial)
   if (vec) {
     if (fast) { if (out2) GO(VecOf<T>::N, PROST_FN_IND_LEQ0, true); else GO(VecOf<T>::N, PROST_FN_IND_LEQ0, false); }
     else { if (out2) GO(VecOf<T>::N, -1, true); else GO(VecOf<T>::N, -1, false); }

@@ -369,7 +369,7 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   bool fast = (d->g_fn == PROST_FN_SQUARE || (d->g_fn == PROST_FN_ABS && d->L == 1 && mask == 0x2)) && d->f_fn == PROST_FN_IND_LEQ0 &&
               (mask == 0x2 || (mask == 0 && d->L == 1)) &&
               ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO2(LCHv, G, F, M, R, RAGv, FASTv) hipLaunchKernelGGL((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO2(LCHv, G, F, M, R, RAGv, FASTv) PH_LAUNCH((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
 #define GO(LCHv, G, F, M, R, FASTv) do { if (rag) GO2(LCHv, G, F, M, R, true, FASTv); else GO2(LCHv, G, F, M, R, false, FASTv); } while (0)
 #define GO_RES(LCHv, G, F, M, FASTv) do { if (out4) GO(LCHv, G, F, M, true, FASTv); else GO(LCHv, G, F, M, false, FASTv); } while (0)
   // measured (4096^2 fp32): non-temporal stores +4 %, non-temporal loads -15 %, no register prefetch -8 %

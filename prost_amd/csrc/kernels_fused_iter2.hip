@@ -481,7 +481,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
   const bool rag = d->ny % V != 0;
   double* partial = static_cast<double*>(ws);
-#define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) hipLaunchKernelGGL((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
+#define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) PH_LAUNCH((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
 // straight-line instances of heights that are a multiple of the vector width prefetch through the LDS ring (PF = 0); ragged
 // heights (4-byte aligned column starts) keep the register ring
 // (PROST_ITER2_NO_RING=1 forces the register ring everywhere: A/B measurements)

@@ -234,7 +234,7 @@ static int run_iter3d_pw(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO2(G, F, B, FASTv, WTv) hipLaunchKernelGGL((fused_iter3d_pw_kernel<T, V, G, F, B, FASTv, WTv>), dim3(grid), dim3(kWave * WTv), 0, s, x_new, y_new, x, y, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0)
+#define GO2(G, F, B, FASTv, WTv) PH_LAUNCH((fused_iter3d_pw_kernel<T, V, G, F, B, FASTv, WTv>), dim3(grid), dim3(kWave * WTv), 0, s, x_new, y_new, x, y, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0)
 #define GO(G, F, B, FASTv) do { if (wt == 8) GO2(G, F, B, FASTv, 8); else GO2(G, F, B, FASTv, 4); } while (0)
   if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
   else { if (gb) GO(-1, -1, true, false); else GO(-1, -1, false, false); }

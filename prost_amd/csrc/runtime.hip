@@ -12,6 +12,8 @@ namespace prost_hip {
 
 static thread_local std::string g_last_error;
 
+thread_local hipEvent_t g_launch_ev_start = nullptr, g_launch_ev_stop = nullptr;
+
 void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(hipError_t e, const char* what) {
   g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -62,6 +64,11 @@ int prost_hip_event_destroy(void* e) { if (e) PH_CHECK(hipEventDestroy((hipEvent
 int prost_hip_event_record(void* e, void* s) { PH_CHECK(hipEventRecord((hipEvent_t)e, as_stream(s))); return 0; }
 int prost_hip_stream_wait_event(void* s, void* e) { PH_CHECK(hipStreamWaitEvent(as_stream(s), (hipEvent_t)e, 0)); return 0; }
 int prost_hip_event_synchronize(void* e) { PH_CHECK(hipEventSynchronize((hipEvent_t)e)); return 0; }
+int prost_hip_next_launch_events(void* start, void* stop) {
+  if ((start == nullptr) != (stop == nullptr)) { set_error("prost_hip_next_launch_events: both events or none"); return 1; }
+  g_launch_ev_start = (hipEvent_t)start; g_launch_ev_stop = (hipEvent_t)stop;
+  return 0;
+}
 int prost_hip_event_elapsed_ms(void* a, void* b, float* ms) { PH_CHECK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b)); return 0; }
 // ---- graphs: a captured launch sequence replayed with one host call ----
 int prost_hip_stream_begin_capture(void* s) { PH_CHECK(hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeThreadLocal)); return 0; }
