@@ -77,7 +77,7 @@ class Backend {
   };
   /// mean milliseconds per launch of every kernel kind sampled since the last call
   virtual void KernelTimes(std::vector<KernelTime>& out) { out.clear(); }
-  /// short description of the execution path ("pdhg:fused-grad2d", "pdhg:generic", "admm:generic")
+  /// short description of the execution path ("pdhg:fused-grad2d", "pdhg:generic", "admm:fused-op", "admm:generic")
   virtual std::string path() const = 0;
 
  protected:

@@ -35,7 +35,8 @@ class BackendADMM : public Backend<T> {
   virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
   virtual size_t gpu_mem_amount() const;
-  virtual std::string path() const { return "admm:generic"; }
+  /// "admm:fused-op": CG rounds of four launches with the operator inside the stage kernels; "admm:generic": staged rounds
+  virtual std::string path() const { return fused_rounds_ ? "admm:fused-op" : "admm:generic"; }
   T rho() const { return rho_; }
   size_t iteration() const { return iteration_; }
   virtual void KernelTimes(std::vector<typename Backend<T>::KernelTime>& out);

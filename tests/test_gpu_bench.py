@@ -66,7 +66,7 @@ def test_bench_c3_reduced():
 def test_bench_c4_reduced():
     d = _bench("--config", "c4", "--steps", "20", "--warmup", "5", "--size", "128", "--prelude-iters", "10")
     _check_contract(d, 20, 5)
-    assert d["config"]["name"] == "c4" and d["config"]["path"] == "admm:generic" and d["metric"] == "ADMM iters/sec, TV-L1 flow-like 128^2 fp32"
+    assert d["config"]["name"] == "c4" and d["config"]["path"] == "admm:fused-op" and d["metric"] == "ADMM iters/sec, TV-L1 flow-like 128^2 fp32"
     r = d["roofline"]
     assert set(r["all_kernels"]) == {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"}      # the four-launch CG round ran
     assert r["kernel"] in r["all_kernels"] and r["algorithmic_bytes_per_launch"] == r["all_kernels"][r["kernel"]]["compulsory_bytes"]

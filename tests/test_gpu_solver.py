@@ -437,13 +437,44 @@ def test_admm_matches_oracle(precision, dtype, device_cg, fused_rounds):
     tol = 2e-4 if dtype == np.float32 else 1e-9
     for k in (1, 5, 20):
         st = run_product(prob, b, o, k)
-        assert st["path"] == "admm:generic"
+        assert st["path"] == ("admm:fused-op" if fused_rounds else "admm:generic")
         ost = run_oracle(prob, b, o, k, dtype)
         assert_same_iterates(st, ost, exact=False, tol=tol)
         assert np.isclose(st["rho"], ost["rho"], rtol=1e-6)
         assert st["cg_iterations"] == ost["cg_iterations"]
         for name in ("primal_res", "dual_res"):
             assert np.isclose(st[name], ost[name], rtol=1e-3, atol=1e-5), name
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("nx,ny,L", [(10, 16, 6), (9, 13, 5)])
+def test_admm_fused_rounds_on_a_gradient3d_operator_match_the_oracle(precision, dtype, nx, ny, L):
+    """the four-launch CG rounds with a gradient3d stencil inside the stage kernels (16 bytes of rows per lane where every
+    boundary allows it: 16 rows; one row per lane otherwise: 13 rows), volumetric TV through ADMM: min_u lmb/2 |u - f|^2 + |g|_{2,1}
+    s.t. g = grad3d u -- against the oracle, and the staged rounds as the A/B"""
+    prost.set_precision(precision)
+    n = nx * ny * L
+    f = synthetic.rof_image(nx, ny, L, 5)
+    u, g = prost.variable(n), prost.variable(3 * n)
+    prob = prost.min_problem([u], [g])
+    prob.add_function(u, prost.function.sum_1d("square", 1, f, 8.0))
+    prob.add_function(g, prost.function.sum_norm2(3, False, "abs"))
+    prob.add_constraint(u, g, prost.block.gradient3d(nx, ny, L))
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    tol = 2e-4 if dtype == np.float32 else 1e-9
+    st = {}
+    for fused_rounds in (True, False):
+        b = prost.backend.admm(rho0=3, residual_iter=2)
+        b[1]["fused_rounds"] = fused_rounds
+        st[fused_rounds] = run_product(prob, b, o, 12)
+    ost = run_oracle(prob, prost.backend.admm(rho0=3, residual_iter=2), o, 12, dtype)
+    for k, s_ in st.items():
+        assert s_["path"] == ("admm:fused-op" if k else "admm:generic")
+        assert_same_iterates(s_, ost, exact=False, tol=tol)
+        assert s_["cg_iterations"] == ost["cg_iterations"], k
+        assert np.isclose(s_["rho"], ost["rho"], rtol=1e-6)
+    assert_same_iterates(st[True], st[False], exact=False, tol=tol / 4)
+    prost.set_precision("double")
 
 
 def test_admm_and_pdhg_agree_at_convergence_on_the_c4_shape():
@@ -459,7 +490,7 @@ def test_admm_and_pdhg_agree_at_convergence_on_the_c4_shape():
     out = {}
     for name, b, its in (("admm", prost.backend.admm(rho0=1), 1500), ("pdhg", prost.backend.pdhg(stepsize="boyd", residual_iter=10), 4000)):
         st = run_product(prob, b, o, its)
-        assert st["path"] == ("admm:generic" if name == "admm" else "pdhg:generic"), st["path"]
+        assert st["path"] == ("admm:fused-op" if name == "admm" else "pdhg:generic"), st["path"]
         out[name] = (energy(st["x"]), st["x"].sum(), st["x"])
     (ea, sa, xa), (ep, sp_, xp) = out["admm"], out["pdhg"]
     assert abs(ea - ep) / ep < 1e-3, (ea, ep)
