@@ -390,6 +390,7 @@ def main():
 
     prost.set_gpu(local_rank)
     prost.set_precision("single")
+    rccl_fallback = False
     if host_transport:
         prost.comm_init_host(lambda a: dist.all_reduce(torch.from_numpy(a)), world)
     elif multi:
@@ -398,7 +399,25 @@ def main():
         if rank == 0:
             ident.copy_(torch.from_numpy(prost.comm_unique_id()))
         dist.broadcast(ident, src=0)
-        prost.comm_init(ident.cpu().numpy(), rank, world)
+        failure = os.environ.get("PROST_BENCH_INJECT_RCCL_FAILURE")          # tests only: the branch below on a box where RCCL works
+        try:
+            if failure:
+                raise RuntimeError(failure)
+            prost.comm_init(ident.cpu().numpy(), rank, world)
+        except Exception as e:                                                # noqa: BLE001 -- whatever the native call raised is reported below
+            failure = str(e)
+        failed = torch.tensor([1.0 if failure else 0.0], device="cuda")
+        dist.all_reduce(failed)
+        if failed.item() > 0:
+            # a second RCCL communicator beside torch's could not be set up on this node: the four residual sums still have to be
+            # global, so they go through the host-callback transport over a gloo group instead (16 bytes per residual check) --
+            # said loudly here and in the JSON line (config.residual_allreduce), never silently
+            sys.stderr.write("bench.py: rank %d: native RCCL communicator failed (%s); residual all-reduce through the host-callback "
+                             "transport over gloo\n" % (rank, failure or "on another rank"))
+            prost.comm_destroy()
+            gloo = dist.new_group(backend="gloo")
+            prost.comm_init_host(lambda a: dist.all_reduce(torch.from_numpy(a), group=gloo), world)
+            rccl_fallback = True
     comm_info = prost.comm_info() if multi else {"nranks": 0, "transport": "none"}
     if multi and int(comm_info["nranks"]) != world:
         raise SystemExit("bench.py: the communicator counts %d ranks, WORLD_SIZE is %d" % (int(comm_info["nranks"]), world))
@@ -486,7 +505,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "path": path, "problems": world, "rccl_nranks": int(comm_info["nranks"]) if comm_info["transport"] == "rccl" else None,
-                       "comm_nranks": int(comm_info["nranks"]), "residual_allreduce": "host-callback (gloo)" if host_transport else "rccl" if multi else "none",
+                       "comm_nranks": int(comm_info["nranks"]), "residual_allreduce": "host-callback (gloo)" if host_transport else "host-callback (gloo) after the native RCCL communicator failed" if rccl_fallback else "rccl" if multi else "none",
                        "timed_loop": "Solver::IterateChecked = the loop of prost.solve (stopping test after every observable iteration; "
                                      "tolerances 0, so it never fires)"},
             "iterate_only_it_per_s": world * args.steps / elapsed_iterate,

@@ -152,3 +152,23 @@ def test_bench_two_ranks_under_torchrun_on_one_gpu(hip):
     assert d["config"]["residual_allreduce"] == "host-callback (gloo)"
     assert d["value"] > 0 and d["iterates_finite"] and d["roofline"]["launches_timed"] >= 5
     assert "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("inject", [None, "injected by the test"])
+def test_bench_native_rccl_communicator_and_its_fallback(hip, inject):
+    """the RCCL leg of bench.py on the one GPU there is (PROST_BENCH_FORCE_DIST=1: torch's nccl group + the solver's own RCCL
+    communicator with one rank + the residual all-reduce through it), and what happens when that second communicator cannot be
+    set up: the sums go through the host-callback transport over a gloo group and the JSON line says so"""
+    env = {"PROST_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_PORT": str(_free_port())}
+    if inject:
+        env["PROST_BENCH_INJECT_RCCL_FAILURE"] = inject
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--size", "1024", "--prelude-iters", "100", "--no-cpu-baseline"]
+    rc, stdout, stderr = _run_bench(cmd, env)
+    assert rc == 0, stderr
+    d = json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["iterates_finite"] and d["config"]["comm_nranks"] == 1
+    if inject:
+        assert d["config"]["residual_allreduce"].startswith("host-callback (gloo) after") and d["config"]["rccl_nranks"] is None
+        assert "native RCCL communicator failed (injected by the test)" in stderr
+    else:
+        assert d["config"]["residual_allreduce"] == "rccl" and d["config"]["rccl_nranks"] == 1
