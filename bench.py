@@ -450,9 +450,10 @@ def main():
     if prelude_iters > 0:
         solver.iterate(prelude_iters)
     prelude_ms = (time.perf_counter() - t_pre) * 1e3
-    # short runs bracket every launch with events (>= 5 samples of the dominant kernel at --steps 20), long runs one in eight
-    # (the markers cost launch pipelining)
-    every = args.sample_every or (1 if args.steps <= 40 else 2 if args.steps <= 80 else 4 if args.steps <= 160 else 8)
+    # launches bracketed with events: a bracketed launch does not overlap its neighbours' ramp-up / drain (measured at --steps 20,
+    # same box: every launch 17 130 it/s, one in three 17 750, none 18 050), so runs of 16 .. 40 steps time one launch in three
+    # (3 samples of the dominant kernel at --steps 20), shorter ones every launch, long ones one in eight
+    every = args.sample_every or (1 if args.steps < 16 else 3 if args.steps <= 40 else 4 if args.steps <= 160 else 8)
 
     solver.iterate(args.warmup, checked=True)
     barrier()

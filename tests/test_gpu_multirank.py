@@ -150,7 +150,7 @@ def test_bench_two_ranks_under_torchrun_on_one_gpu(hip):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["config"]["problems"] == 2
     assert d["config"]["residual_allreduce"] == "host-callback (gloo)"
-    assert d["value"] > 0 and d["iterates_finite"] and d["roofline"]["launches_timed"] >= 5
+    assert d["value"] > 0 and d["iterates_finite"] and d["roofline"]["launches_timed"] >= 3
     assert "cpu_baseline" not in d
 
 
