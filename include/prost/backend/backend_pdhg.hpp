@@ -58,6 +58,8 @@ class BackendPDHG : public Backend<T> {
   T* y_data() { spec_valid_ = false; return y_.data(); }
   bool single_kernel_path() const { return single_kernel_; }
   virtual size_t pair_launches() const { return pair_launches_; }
+  size_t speculative_launches() const { return spec_launched_; }
+  size_t speculative_adopted() const { return spec_adopted_; }
   /// one kernel per iteration with residual sums restricted to owned columns: gradient2d with L <= 2 or L = 3 / 4 channels
   bool sharded_path() const { return single_kernel_ || single_mc_; }
   size_t fused_channels() const { return fused_ ? desc_.L : 0; }
@@ -97,6 +99,7 @@ class BackendPDHG : public Backend<T> {
   void Speculate();
   void DropSpeculation() { spec_valid_ = false; }
   bool spec_valid_ = false;
+  size_t spec_launched_ = 0, spec_adopted_ = 0;          // statistics: speculative pair launches / those whose results were exchanged in
   size_t spec_iteration_ = 0;
   T spec_tau_[3] = {0, 0, 0}, spec_sigma_[3] = {0, 0, 0}, spec_theta_[3] = {0, 0, 0};   // step sizes of iterations k, k+1 and after the pair
   void* ev_res_local_ = nullptr;          // recorded right after a residual launch (no communicator): what the host waits for

@@ -136,7 +136,8 @@ int prost_comm_set_host_p2p(prost_p2p_cb fn, void* user);
  *   solver_copy_columns(dst_handle, dst_col, src_handle, src_col, ncols, ny): the same transfer between two
  *       solvers of one process
  *   solver_state(handle[, with_vectors = 1]) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,
- *                                   dual_var_norm,eps_primal,eps_dual,iteration,path}; with_vectors = 0 leaves out x,y,z,w
+ *                                   dual_var_norm,eps_primal,eps_dual,iteration,cg_iterations,path,pair_launches,
+ *                                   speculative_launches,speculative_adopted}; with_vectors = 0 leaves out x,y,z,w
  *   solver_compare(handle_a, handle_b) -> 4x2 matrix, rows x, y, x_prev, y_prev: {elements that differ in value,
  *       sum |a - b|}, formed on the device (verification of states too large to read back; pdhg only)
  *   solver_read(handle, 'x'|'y'|'x_prev'|'y_prev', offsets, count) -> count x numel(offsets) matrix: `count`

@@ -112,6 +112,7 @@ void BackendPDHG<T>::Initialize() {
 
   iteration_ = 0;
   pair_launches_ = 0;
+  spec_launched_ = spec_adopted_ = 0;
   prev_stale_ = false;
   spec_valid_ = false;
   residuals_pending_ = false;
@@ -241,6 +242,7 @@ int BackendPDHG<T>::PerformIterations(int budget) {
       tau_ = spec_tau_[2]; sigma_ = spec_sigma_[2]; theta_ = spec_theta_[2];
       iteration_ += 2;
       pair_launches_++;
+      spec_adopted_++;
       return 2;
     }
   }
@@ -569,7 +571,9 @@ void BackendPDHG<T>::FinishResiduals() {
 
 template <typename T>
 bool BackendPDHG<T>::CanSpeculate() const {
-  if (!opts_.allow_speculation || !pair_kernel_ || this->comm_ || owned_x1_ != 0 || !ev_res_local_ || spec_valid_) return false;
+  // (what the host is about to wait for: the event behind the residual launch, or -- with a communicator -- the one behind the
+  // all-reduce on the side stream)
+  if (!opts_.allow_speculation || !pair_kernel_ || owned_x1_ != 0 || !(resolve_on_side_ || (ev_res_local_ && !this->comm_)) || spec_valid_) return false;
   if (opts_.stepsize_variant != kPDHGStepsAlg1 && opts_.stepsize_variant != kPDHGStepsAlg2) return false;
   const size_t k = iteration_;
   // a PLAIN pair must be what PerformIterations(budget >= 2) would launch next: no residual sums, no stored intermediate iterate
@@ -594,13 +598,19 @@ void BackendPDHG<T>::Speculate() {
   EndSample(t);
   spec_iteration_ = iteration_;
   spec_valid_ = true;
+  spec_launched_++;
 }
 
 template <typename T>
 void BackendPDHG<T>::ResolveResiduals() {
   if (!residuals_pending_) return;
   residuals_pending_ = false;
-  if (resolve_on_side_) { CheckHip(prost_hip_event_synchronize(ev_res_done_), "event_synchronize"); resolve_on_side_ = false; }
+  if (resolve_on_side_) {
+    // (with a communicator the sums are being all-reduced on the side stream: the iteration stream is free for the next pair meanwhile)
+    if (CanSpeculate()) Speculate();
+    CheckHip(prost_hip_event_synchronize(ev_res_done_), "event_synchronize");
+    resolve_on_side_ = false;
+  }
   else if (CanSpeculate()) {
     Speculate();                                         // the device goes on with the next pair while the host looks at the sums
     CheckHip(prost_hip_event_synchronize(ev_res_local_), "event_synchronize");

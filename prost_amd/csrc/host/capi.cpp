@@ -812,8 +812,11 @@ void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** pl
     prost_value_struct_set(out, "z", vec_value_t(h.solver->cur_primal_constr_sol()));
     prost_value_struct_set(out, "w", vec_value_t(h.solver->cur_dual_constr_sol()));
   }
-  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0;
-  if (auto* p = dynamic_cast<BackendPDHG<T>*>(h.backend.get())) { tau = p->tau(); sigma = p->sigma(); theta = p->theta(); it = (double)p->iteration(); }
+  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0, spec_l = 0, spec_a = 0;
+  if (auto* p = dynamic_cast<BackendPDHG<T>*>(h.backend.get())) {
+    tau = p->tau(); sigma = p->sigma(); theta = p->theta(); it = (double)p->iteration();
+    spec_l = (double)p->speculative_launches(); spec_a = (double)p->speculative_adopted();
+  }
   if (auto* a = dynamic_cast<BackendADMM<T>*>(h.backend.get())) { rho = a->rho(); it = (double)a->iteration(); cg_its = a->last_cg_iterations(); }
   const char* names[] = {"tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual"};
   const double vals[] = {tau, sigma, theta, rho, it, (double)h.backend->primal_residual(), (double)h.backend->dual_residual(),
@@ -821,6 +824,9 @@ void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** pl
   for (int i = 0; i < 11; i++) prost_value_struct_set(out, names[i], prost_value_scalar(vals[i]));
   prost_value_struct_set(out, "cg_iterations", prost_value_scalar(cg_its));
   prost_value_struct_set(out, "path", prost_value_string(h.backend->path().c_str()));
+  prost_value_struct_set(out, "pair_launches", prost_value_scalar((double)h.backend->pair_launches()));
+  prost_value_struct_set(out, "speculative_launches", prost_value_scalar(spec_l));
+  prost_value_struct_set(out, "speculative_adopted", prost_value_scalar(spec_a));
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 void cmd_solver_state(CMD_ARGS) {

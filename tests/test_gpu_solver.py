@@ -210,13 +210,26 @@ def test_verbose_output_reaches_the_front_end_print_function():
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("step", ["alg2", "alg1"])
 @pytest.mark.parametrize("residual_iter", [4, 5, 10])
-def test_speculative_next_launch_is_invisible(precision, dtype, step, residual_iter):
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_speculative_next_launch_is_invisible(precision, dtype, step, residual_iter, with_comm):
     """With alg1 / alg2 the pair launch that follows a residual iteration is enqueued BEFORE the host waits for the residual sums
     (into spare buffers) and adopted by a buffer exchange if the solver goes on, forgotten otherwise.  Whatever the caller does in
     between -- checked iteration (the loop of prost.solve), reading the state (z, w need the rebuilt previous iterate, which uses
     the same spare buffers), unchecked iteration, a solve that stops on its tolerance -- the results equal those of a solver that
-    never speculates, and the oracle's."""
+    never speculates, and the oracle's.  with_comm: a (one-rank, host-callback) communicator is attached -- the sums are all-reduced on
+    the side stream and the speculative pair runs beside the collective instead of beside the host's look at the sums."""
     prost.set_precision(precision)
+    if with_comm:
+        prost.comm_init_host(lambda a: None, 1)
+    try:
+        _speculation_body(dtype, step, residual_iter)
+    finally:
+        if with_comm:
+            prost.comm_destroy()
+        prost.set_precision("double")
+
+
+def _speculation_body(dtype, step, residual_iter):
     prob, u, q, f = synthetic.rof_problem(44, 252, 1, seed=9)
     o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
     runs = {}
@@ -235,11 +248,14 @@ def test_speculative_next_launch_is_invisible(precision, dtype, step, residual_i
         trace.append(s.state())
         s.destroy()
         runs[spec] = trace
+        # that it happened: several speculative launches, most of them adopted (one forgotten at each read-out / budget of one)
+        launched, adopted = trace[-1]["speculative_launches"], trace[-1]["speculative_adopted"]
+        assert (launched >= 5 and 3 <= adopted < launched) if spec else launched == adopted == 0, (launched, adopted)
     for a, b_ in zip(runs[True], runs[False]):
         if isinstance(a, dict):
             for v in "xyzw":
                 assert np.array_equal(a[v], b_[v]), v
-            for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res"):
+            for v in ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "pair_launches"):
                 assert a[v] == b_[v], v
         else:
             assert a == b_
@@ -257,7 +273,6 @@ def test_speculative_next_launch_is_invisible(precision, dtype, step, residual_i
     assert res[True]["result"] == res[False]["result"] == "Converged." and res[True]["iters"] == res[False]["iters"]
     for v in "xyzw":
         assert np.array_equal(np.asarray(res[True][v]), np.asarray(res[False][v])), v
-    prost.set_precision("double")
 
 
 def inpaint_problem(nx, ny, L, mask, seed=3, lmb=7.0):
