@@ -872,3 +872,21 @@ def test_pair_kernel_convergence_stop_is_identical(prec, dtype, step):
     assert out[True]["iters"] == out[False]["iters"] and out[True]["iters"] < 5000 and out[True]["result"] == out[False]["result"]
     for v in "xyzw":
         assert np.array_equal(np.asarray(out[True][v]), np.asarray(out[False][v])), v
+
+
+@pytest.mark.parametrize("mode,cases", [("fused", 250), ("generic", 1200)])
+def test_randomised_differential_run_against_the_oracle(mode, cases):
+    """tools/fuzz_parity.py.  fused: random shapes / geometries / step rules / precisions / iteration counts of the fused PDHG paths
+    (gray, 2-4 channels, volumes; ROF, TV-L1, inpainting), default launch schedule.  generic: random compositions of sparse /
+    gradient / diags / identity / zero blocks over one or two primal and up to three dual variables with functions of the sum_1d /
+    sum_norm2 family (per-element coefficients, conjugates), min-max and constrained form, PDHG and ADMM.  PDHG bit for bit against
+    the oracle, ADMM within its tolerance -- apart from the classes the tool's header explains and counts (residual-threshold ties,
+    initial steps rescaled by a norm estimate that differs in the last places, sparse rows long enough for cooperative sums)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "--mode", mode, "--cases", str(cases), "--seed", "3", "--budget-s", "150"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    summary = [l for l in r.stdout.splitlines() if l.startswith("fuzz_parity:")]
+    assert r.returncode == 0 and summary, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " 0 failures" in summary[0], summary[0]
