@@ -104,12 +104,43 @@ def _coeffs(rng, count, fun):
     return a, b, cc, d, e, alpha, beta
 
 
+def _wrapper_function(rng, count, desc, what):
+    """the remaining builders of +prost/+function: projections per group (halfspace, second-order cone, sum-to-one, simplex, quadratic
+    epigraph) and the wrappers around any function (transform, permute)"""
+    dims = [d for d in (2, 3, 4, 6) if count % d == 0]
+    kind = str(rng.choice(["transform", "permute"] + (["halfspace", "soc", "ind_sum", "simplex", "epi_quad"] if dims else [])))
+    if desc is not None:
+        desc.append("%s: %s" % (what, kind))
+    if kind == "transform":
+        inner = prost.function.sum_1d(str(rng.choice(("abs", "square", "ind_box01", "huber"))), 1, float(rng.uniform(-1, 1)), float(rng.uniform(0.5, 2)), 0, 0, 0.5)
+        return prost.function.transform(inner, float(rng.uniform(0.5, 2)), float(rng.uniform(-1, 1)), float(rng.uniform(0.5, 2)), float(rng.uniform(-0.5, 0.5)),
+                                        float(rng.uniform(0, 1)))
+    if kind == "permute":
+        inner = prost.function.sum_1d(str(rng.choice(("abs", "square", "ind_geq0"))), 1, rng.uniform(-1, 1, count), rng.uniform(0.5, 2, count))
+        return prost.function.permute(inner, rng.permutation(count))
+    dim = int(rng.choice(dims))
+    n, il = count // dim, bool(rng.integers(0, 2))
+    if kind == "halfspace":
+        return prost.function.sum_ind_halfspace(dim, il, rng.uniform(-1, 1, dim if rng.random() < 0.5 else count), rng.uniform(-1, 1, 1 if rng.random() < 0.5 else n))
+    if kind == "soc":
+        return prost.function.sum_ind_soc(dim, il, 1.0)
+    if kind == "ind_sum":
+        return prost.function.sum_ind_sum(dim, il)
+    if kind == "simplex":
+        return prost.function.sum_ind_simplex(dim, il)
+    if desc is not None:
+        desc.append("transcendental")                              # helper.hpp:44-105: pow / acos / cos -- the device's and the host's differ in the last place
+    return prost.function.sum_ind_epi_quad(dim, il, rng.uniform(0.5, 2, 1 if rng.random() < 0.5 else n), rng.uniform(-1, 1, (dim - 1) * n), rng.uniform(-1, 1, 1 if rng.random() < 0.5 else n))
+
+
 CONTINUOUS_FUNS = ("zero", "abs", "square", "ind_leq0", "ind_geq0", "ind_eq0", "ind_box01", "max_pos0", "huber")
 
 
 def _function(rng, count, desc=None, what="", continuous=False):
     """continuous: only operations without jumps (no l0 / truncations; norm2 operations with b = d = 0, whose result tends to zero
     with the norm -- elem_operation_norm2.hpp:56-85 returns zero AT a zero norm whatever b and d say)"""
+    if not continuous and rng.random() < 0.2:
+        return _wrapper_function(rng, count, desc, what)
     fun = str(rng.choice(CONTINUOUS_FUNS if continuous else EXACT_FUNS))
     r = rng.random()
     if desc is not None:
@@ -137,10 +168,14 @@ def build_generic(c):
     psizes = [n] + ([int(rng.choice([n, int(rng.integers(1, 50))]))] if rng.random() < 0.4 else [])
     rows = []
     for _ in range(int(rng.integers(1, 4))):
-        t = str(rng.choice(["grad2d", "grad3d", "sparse", "sparse", "diags", "identity"]))
-        rows.append((t, {"grad2d": 2 * n, "grad3d": 3 * n, "identity": n}.get(t, int(rng.integers(1, 70)))))
+        t = str(rng.choice(["grad2d", "grad3d", "sparse", "sparse", "diags", "identity", "kron_id", "id_kron"]))
+        if t in ("kron_id", "id_kron"):                             # kron(K, I_d) / kron(I_d, K) with K of (mk x n / d): d must divide n
+            dl = int(rng.choice([d for d in (1, 2, 3, 4, 5, 6) if n % d == 0]))
+            rows.append((t, int(rng.integers(1, 9)) * dl, dl))
+        else:
+            rows.append((t, {"grad2d": 2 * n, "grad3d": 3 * n, "identity": n}.get(t, int(rng.integers(1, 70)))))
     pv = [prost.variable(k) for k in psizes]
-    dv = [prost.variable(m) for _, m in rows]
+    dv = [prost.variable(r[1]) for r in rows]
     prob = prost.min_max_problem(pv, dv) if c["form"] == "minmax" else prost.min_problem(pv, dv)
     add = prob.add_dual_pair if c["form"] == "minmax" else prob.add_constraint
 
@@ -159,8 +194,15 @@ def build_generic(c):
     desc = c.setdefault("_desc", [])
     del desc[:]
     desc.append("image %dx%dx%d primal %s rows %s" % (nx, ny, L, psizes, rows))
-    for j, (t, m) in enumerate(rows):
-        if t == "grad2d":
+    for j, row in enumerate(rows):
+        t, m = row[0], row[1]
+        if t in ("kron_id", "id_kron"):
+            dl = row[2]
+            Ks = sp.random(m // dl, n // dl, density=min(1.0, 3.0 / max(m // dl, n // dl)), random_state=int(rng.integers(0, 2 ** 31)), format="csc")
+            if Ks.nnz == 0:
+                Ks = sp.csc_matrix(([0.75], ([0], [0])), shape=(m // dl, n // dl))
+            add(pv[0], dv[j], (prost.block.sparse_kron_id if t == "kron_id" else prost.block.id_kron_sparse)(Ks, dl)); covered[0] = True
+        elif t == "grad2d":
             add(pv[0], dv[j], prost.block.gradient2d(nx, ny, L, bool(rng.integers(0, 2)) if L > 1 else False)); covered[0] = True
         elif t == "grad3d":
             add(pv[0], dv[j], prost.block.gradient3d(nx, ny, L, False)); covered[0] = True
@@ -184,7 +226,8 @@ def build_generic(c):
     for i, k in enumerate(psizes):
         if rng.random() < 0.85:
             prob.add_function(pv[i], _function(rng, k, desc, "primal %d" % i, c["backend"] == "admm"))
-    for j, (_, m) in enumerate(rows):
+    for j, row in enumerate(rows):
+        m = row[1]
         if rng.random() < 0.85:
             prob.add_function(dv[j], _function(rng, m, desc, "dual %d" % j, c["backend"] == "admm"))
     return prob
@@ -289,10 +332,10 @@ def main():
                 done += 1
                 if d:
                     fails += 1
-                    print("FAIL %s: %s" % ({k: v for k, v in c.items() if not k.startswith("_")}, d), flush=True)
+                    print("FAIL %s: %s%s" % ({k: v for k, v in c.items() if not k.startswith("_")}, d, "  [" + " ; ".join(c["_desc"]) + "]" if c.get("_desc") else ""), flush=True)
                 continue
             d = differs(st, ost)
-            if d and c.get("long_rows"):
+            if d and (c.get("long_rows") or "transcendental" in c.get("_desc", ())):
                 # (sums in another order: within the tolerance, or -- a residual threshold or a discontinuous operation downstream -- anywhere)
                 inexact += 1
                 diverged += 0 if close(st, ost, dtype) else 1
@@ -324,9 +367,9 @@ def main():
         done += 1
         if d:
             fails += 1
-            print("FAIL %s: %s" % ({k: v for k, v in c.items() if not k.startswith("_")}, d), flush=True)
+            print("FAIL %s: %s%s" % ({k: v for k, v in c.items() if not k.startswith("_")}, d, "  [" + " ; ".join(c["_desc"]) + "]" if c.get("_desc") else ""), flush=True)
     prost.set_precision("double")
-    print("fuzz_parity: %d cases in %.0f s, %d failures, %d threshold ties, %d with rescaled initial steps (setup; %d of them not within the tolerance afterwards), %d divergent compositions skipped, %d with long sparse rows compared with a tolerance, %d ADMM cases as sensitive in the oracle itself, paths %s"
+    print("fuzz_parity: %d cases in %.0f s, %d failures, %d threshold ties, %d with rescaled initial steps (setup; %d of them not within the tolerance afterwards), %d divergent compositions skipped, %d with long sparse rows or a transcendental projection compared with a tolerance, %d ADMM cases as sensitive in the oracle itself, paths %s"
           % (done, time.time() - t0, fails, ties, setups, diverged, skipped, inexact, sensitive, paths))
     return 1 if fails else 0
 
