@@ -286,6 +286,9 @@ def solve(prob, backend, opts):
     prob.finalize()
     result = command("solve_problem", [prob.data, prob.nrows, prob.ncols, backend, _opts_struct(opts)],
                      nlhs=1, struct_fields=_RESULT_FIELDS)[0]
+    for k in ("x", "y", "z", "w"):                       # (a one-element vector comes back as a scalar)
+        if k in result:
+            result[k] = np.atleast_1d(result[k])
     prob.fill_variables(result)
     return result
 

@@ -890,3 +890,19 @@ def test_randomised_differential_run_against_the_oracle(mode, cases):
     summary = [l for l in r.stdout.splitlines() if l.startswith("fuzz_parity:")]
     assert r.returncode == 0 and summary, r.stdout[-3000:] + r.stderr[-2000:]
     assert " 0 failures" in summary[0], summary[0]
+
+
+def test_solve_with_a_one_element_variable():
+    """a dual variable of ONE element (found by tools/fuzz_parity.py): the result vector of length one used to come back as a scalar,
+    which prob.fill_variables could not slice"""
+    prost.set_precision("double")
+    n = 12
+    u, q = prost.variable(n), prost.variable(1)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d("square", 1, np.linspace(0, 1, n), 2.0))
+    prob.add_function(q, prost.function.sum_1d("ind_box01"))
+    prob.add_dual_pair(u, q, prost.block.diags(1, n, [1.0, -1.0], [0, 1]))
+    r = prost.solve(prob, prost.backend.pdhg(stepsize="alg1"), prost.options(max_iters=30, num_cback_calls=0, verbose=False))
+    assert r["y"].shape == (1,) and q.val.shape == (1,) and u.val.shape == (n,)
+    ro = oracle.solve(prob, prost.backend.pdhg(stepsize="alg1"), prost.options(max_iters=30, num_cback_calls=0, verbose=False), np.float64)
+    assert r["iters"] == ro["iters"] and np.array_equal(r["x"], ro["x"]) and np.array_equal(r["y"], ro["y"])

@@ -40,6 +40,11 @@ def draw(rng):
          "residual_iter": int(rng.choice([1, 2, 3, 4, 5, 10])), "iters": int(rng.integers(1, 48)), "lmb": float(rng.choice([0.5, 3.0, 10.0, 40.0])),
          "gamma": float(rng.choice([0.05, 0.4, 0.5, 2.0])), "seed": int(rng.integers(0, 1000)), "checked": bool(rng.integers(0, 2))}
     c["scale_steps"] = bool(rng.random() < 0.5)           # False: no operator-norm estimate, the initial steps are exactly tau0 / sigma0
+    # a complete prost.solve instead of a fixed number of iterations: callback schedule (solver.cu:130-135, :153, :178), stopping
+    # test, warm start (x0 / y0), the read-outs in between
+    if rng.random() < 0.3:
+        c["solve"] = {"max_iters": int(rng.integers(1, 70)), "num_cback_calls": int(rng.choice([0, 1, 2, 3, 7, 20])),
+                      "tol": float(rng.choice([0.0, 0.0, 3e-2, 1e-2, 3e-3])), "warm": bool(rng.random() < 0.3)}
     c["ny"] = int(rng.choice(HEIGHTS)) if rng.random() < 0.8 else int(rng.integers(1, 600))
     if kind == "vol":
         c["ny"] = min(c["ny"], 260)
@@ -80,6 +85,9 @@ def draw_generic(rng):
          "form": str(rng.choice(["minmax", "minmax", "min"]))}
     c["scale_steps"] = bool(rng.random() < 0.2)
     c["backend"] = "pdhg" if c["form"] == "minmax" else str(rng.choice(["pdhg", "admm"]))
+    if c["backend"] == "pdhg" and rng.random() < 0.2:
+        c["solve"] = {"max_iters": int(rng.integers(1, 50)), "num_cback_calls": int(rng.choice([0, 1, 2, 3, 7, 20])),
+                      "tol": float(rng.choice([0.0, 0.0, 3e-2, 1e-2])), "warm": bool(rng.random() < 0.3)}
     c["step"] = str(rng.choice(["alg1", "alg2", "goldstein", "boyd"])) if c["backend"] == "pdhg" else "admm"
     return c
 
@@ -233,6 +241,48 @@ def build_generic(c):
     return prob
 
 
+def solve_opts(c, prob, trace):
+    so = c["solve"]
+    r = np.random.default_rng(c["seed"] + 99)
+    def cb(it, x, y):
+        trace.append((int(it), np.array(x, copy=True), np.array(y, copy=True)))
+        return False
+    o = prost.options(max_iters=so["max_iters"], num_cback_calls=so["num_cback_calls"], verbose=False, tol_rel_primal=so["tol"], tol_rel_dual=so["tol"],
+                      tol_abs_primal=so["tol"], tol_abs_dual=so["tol"], interm_cb=cb)
+    if so["warm"]:
+        o["x0"] = r.uniform(0, 1, prob.ncols); o["y0"] = r.uniform(-0.3, 0.3, prob.nrows)
+    return o
+
+
+def compare_solve(c, prob, backend, dtype):
+    """prost.solve against oracle.Solver.solve: result string, iteration count, x / y / z / w, and every intermediate callback
+    (iteration number and the iterates it was handed)"""
+    tp, to = [], []
+    res = prost.solve(prob, backend, solve_opts(c, prob, tp))
+    prob.finalize()
+    oo = solve_opts(c, prob, to)
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in NOT_ORACLE}]
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, oo, dtype)
+    s.initialize()
+    sc = s.scalars()
+    msg, iters = s.solve()
+    ost = s.state()
+    c["_steps0_oracle"] = (sc["tau"], sc["sigma"]); c["_steps0"] = c["_steps0_oracle"]
+    if not all(np.isfinite(ost[v]).all() for v in "xyzw") or not all(np.isfinite(t[1]).all() and np.isfinite(t[2]).all() for t in to):
+        return "skip", res.get("path")                     # a random composition that diverges
+    if msg != res["result"] or int(iters) != int(res["iters"]):
+        return "solve: %r after %r iterations vs %r after %r" % (res["result"], res["iters"], msg, iters), res.get("path")
+    if [t[0] for t in tp] != [t[0] for t in to]:
+        return "solve: callbacks at %s vs %s" % ([t[0] for t in tp], [t[0] for t in to]), res.get("path")
+    for (i, x, y), (_, ox, oy) in zip(tp, to):
+        if not (np.array_equal(np.ravel(x), np.ravel(ox)) and np.array_equal(np.ravel(y), np.ravel(oy))):
+            return "solve: iterates handed to the callback at iteration %d differ (x %.3g, y %.3g)" % (i, float(np.abs(np.ravel(x) - np.ravel(ox)).max()), float(np.abs(np.ravel(y) - np.ravel(oy)).max())), res.get("path")
+    for v in "xyzw":
+        if not np.array_equal(np.ravel(np.asarray(res[v])), ost[v]):
+            return "solve: final %s (max |d| %.3g)" % (v, float(np.abs(np.ravel(np.asarray(res[v])) - ost[v]).max())), res.get("path")
+    return None, res.get("path")
+
+
 def product(prob, backend, opts, c):
     s = prost.Solver(prob, backend, opts)
     st0 = s.state(vectors=False)
@@ -289,7 +339,7 @@ def main():
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     prost.set_gpu(0)
-    t0, done, fails, ties, setups, skipped, inexact, diverged, sensitive, paths = time.time(), 0, 0, 0, 0, 0, 0, 0, 0, {}
+    t0, done, fails, ties, setups, skipped, inexact, diverged, sensitive, solves, paths = time.time(), 0, 0, 0, 0, 0, 0, 0, 0, 0, {}
     for i in range(args.cases):
         if time.time() - t0 > args.budget_s:
             break
@@ -303,6 +353,23 @@ def main():
             b = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=c["scale_steps"])
         try:
             prob = build(c) if args.mode == "fused" else build_generic(c)
+            if "solve" in c and (c.get("long_rows") or "transcendental" in c.get("_desc", ())):
+                del c["solve"]                                            # (tolerance classes: compared after a fixed number of iterations below)
+            if "solve" in c:
+                if c["step"] in ("goldstein", "boyd") or c["scale_steps"]:
+                    c["step"] = "alg2" if c["seed"] % 2 else "alg1"       # (exact comparison of a whole solve: no residual-driven steps, no norm estimate)
+                    c["scale_steps"] = False
+                    b = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=False)
+                d, path = compare_solve(c, prob, b, dtype)
+                paths[path] = paths.get(path, 0) + 1
+                if d == "skip":
+                    skipped += 1
+                    continue
+                done += 1; solves += 1
+                if d:
+                    fails += 1
+                    print("FAIL %s: %s" % ({k: v for k, v in c.items() if not k.startswith("_")}, d), flush=True)
+                continue
             st = product(prob, b, o, c)
             paths[st["path"]] = paths.get(st["path"], 0) + 1
             ost = reference(prob, b, o, c, dtype)
@@ -369,8 +436,8 @@ def main():
             fails += 1
             print("FAIL %s: %s%s" % ({k: v for k, v in c.items() if not k.startswith("_")}, d, "  [" + " ; ".join(c["_desc"]) + "]" if c.get("_desc") else ""), flush=True)
     prost.set_precision("double")
-    print("fuzz_parity: %d cases in %.0f s, %d failures, %d threshold ties, %d with rescaled initial steps (setup; %d of them not within the tolerance afterwards), %d divergent compositions skipped, %d with long sparse rows or a transcendental projection compared with a tolerance, %d ADMM cases as sensitive in the oracle itself, paths %s"
-          % (done, time.time() - t0, fails, ties, setups, diverged, skipped, inexact, sensitive, paths))
+    print("fuzz_parity: %d cases (%d of them complete solves with callbacks) in %.0f s, %d failures, %d threshold ties, %d with rescaled initial steps (setup; %d of them not within the tolerance afterwards), %d divergent compositions skipped, %d with long sparse rows or a transcendental projection compared with a tolerance, %d ADMM cases as sensitive in the oracle itself, paths %s"
+          % (done, solves, time.time() - t0, fails, ties, setups, diverged, skipped, inexact, sensitive, paths))
     return 1 if fails else 0
 
 
