@@ -72,6 +72,59 @@ def build(c):
     return prob
 
 
+# ---- mode "large": launch geometries at sizes the oracle is too slow for --------------------------------------------------------
+def run_large(args, rng):
+    """Random LARGE shapes (up to ~40 M elements per vector: several row strips, hundreds of column chunks, planes beyond 2^31 bytes
+    are left to tests/test_gpu_fullsize.py), both precisions, 9-14 iterations with residual_iter 2-5 so that every launch kind of the
+    schedule runs (plain and residual pairs, single launches, two passes): the fused path against the generic nine-vector path of
+    the same solver, every element of x, y and the previous iterate, compared ON THE DEVICE (solver_compare)."""
+    t0, done, fails = time.time(), 0, 0
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    while done < args.cases and time.time() - t0 < args.budget_s:
+        kind = str(rng.choice(["gray", "gray", "mc", "vol"]))
+        c = {"kind": kind, "precision": str(rng.choice(["single", "double"])), "step": str(rng.choice(["alg1", "alg2"])), "residual_iter": int(rng.choice([2, 3, 4, 5])),
+             "iters": int(rng.integers(9, 15)), "lmb": float(rng.choice([3.0, 10.0])), "gamma": 0.5, "seed": int(rng.integers(0, 1000)),
+             "data": str(rng.choice(["square", "abs"] if kind == "vol" else ["square", "square", "abs", "mask"]))}
+        if kind == "vol":
+            c["L"] = int(rng.choice([2, 7, 13, 14, 26, 27, 40, 64, 100]))
+            budget = 30e6 / c["L"]
+            c["ny"] = int(rng.choice([124, 125, 126, 248, 250, 252, 500, 1000, int(rng.integers(60, 1200))]))
+            c["nx"] = int(max(8, min(rng.integers(8, 2000), budget // c["ny"])))
+        else:
+            c["L"] = 1 if kind == "gray" else int(rng.choice([2, 3, 4]))
+            budget = 40e6 / c["L"]
+            c["ny"] = int(rng.choice([248, 252, 256, 496, 504, 1000, 1008, 1012, 2048, 4096, 4094, 5000, int(rng.integers(200, 6000))]))
+            c["nx"] = int(max(8, min(rng.integers(8, 6000), budget // c["ny"])))
+        prost.set_precision(c["precision"])
+        d = None
+        try:
+            prob = build(c)
+            sol = []
+            for fused in (True, False):
+                b = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=False)
+                b[1]["allow_fused"] = fused
+                s = prost.Solver(prob, b, o)
+                s.iterate(c["iters"] // 2, checked=True); s.iterate(c["iters"] - c["iters"] // 2)
+                sol.append(s)
+            cmp_ = sol[0].compare(sol[1])
+            st = sol[0].state(vectors=False)
+            if any(v[0] != 0 for v in cmp_.values()):
+                d = "fused vs generic on the device: %s" % cmp_
+            elif not (np.isfinite(st["primal_res"]) and np.isfinite(st["dual_res"])):
+                d = "non-finite residuals"
+            for s in sol:
+                s.destroy()
+        except Exception as e:                                      # noqa: BLE001
+            d = "exception: %s" % e
+        done += 1
+        if d:
+            fails += 1
+            print("FAIL %s: %s" % (c, d), flush=True)
+    prost.set_precision("double")
+    print("fuzz_parity: %d large cases in %.0f s, %d failures" % (done, time.time() - t0, fails))
+    return 1 if fails else 0
+
+
 # ---- mode "generic": random compositions of the operator blocks and elementwise functions ---------------------------------------
 EXACT_FUNS = ("zero", "abs", "square", "ind_leq0", "ind_geq0", "ind_eq0", "ind_box01", "max_pos0", "l0", "huber", "trunclin", "truncquad")
 
@@ -335,10 +388,12 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=600.0)
-    ap.add_argument("--mode", choices=["fused", "generic"], default="fused")
+    ap.add_argument("--mode", choices=["fused", "generic", "large"], default="fused")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     prost.set_gpu(0)
+    if args.mode == "large":
+        return run_large(args, rng)
     t0, done, fails, ties, setups, skipped, inexact, diverged, sensitive, solves, paths = time.time(), 0, 0, 0, 0, 0, 0, 0, 0, 0, {}
     for i in range(args.cases):
         if time.time() - t0 > args.budget_s:
