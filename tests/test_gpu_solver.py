@@ -874,7 +874,7 @@ def test_pair_kernel_convergence_stop_is_identical(prec, dtype, step):
         assert np.array_equal(np.asarray(out[True][v]), np.asarray(out[False][v])), v
 
 
-@pytest.mark.parametrize("mode,cases", [("fused", 250), ("generic", 1200), ("large", 60)])
+@pytest.mark.parametrize("mode,cases", [("fused", 250), ("generic", 1200), ("large", 60), ("sharded", 150)])
 def test_randomised_differential_run_against_the_oracle(mode, cases):
     """tools/fuzz_parity.py.  fused: random shapes / geometries / step rules / precisions / iteration counts of the fused PDHG paths
     (gray, 2-4 channels, volumes; ROF, TV-L1, inpainting), default launch schedule.  generic: random compositions of sparse /
@@ -882,7 +882,8 @@ def test_randomised_differential_run_against_the_oracle(mode, cases):
     sum_norm2 family (per-element coefficients, conjugates), min-max and constrained form, PDHG and ADMM.  PDHG bit for bit against
     the oracle, ADMM within its tolerance -- apart from the classes the tool's header explains and counts (residual-threshold ties,
     initial steps rescaled by a norm estimate that differs in the last places, sparse rows long enough for cooperative sums).
-    large: shapes of up to 40 M elements (several row strips, hundreds of column chunks), fused path == generic path on the device."""
+    large: shapes of up to 40 M elements (several row strips, hundreds of column chunks), fused path == generic path on the device.
+    sharded: one image over 2-5 column slabs with random halo widths, owned columns == the oracle's whole-image iterates."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -125,6 +125,59 @@ def run_large(args, rng):
     return 1 if fails else 0
 
 
+# ---- mode "sharded": one image over column slabs ---------------------------------------------------------------------------------
+def run_sharded(args, rng):
+    """prost_amd.distributed.ColumnShardedSolver, slabs in one process: random image / channel count / number of
+    slabs / halo width / iteration count; the owned columns of every slab against the oracle's iterates of the WHOLE image, bit for bit."""
+    from prost_amd import distributed
+    t0, done, fails = time.time(), 0, 0
+    opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
+    while done < args.cases and time.time() - t0 < args.budget_s:
+        world, halo, L = int(rng.integers(2, 6)), int(rng.integers(3, 15)), int(rng.choice([1, 1, 2, 3, 4]))
+        c = {"world": world, "halo": halo, "L": L, "ny": int(rng.choice(HEIGHTS[8:])), "nx": int(rng.integers(world * (halo + 2), world * (halo + 2) + 120)),
+             "iters": int(rng.integers(1, 60)), "precision": str(rng.choice(["single", "double"])), "residual_iter": int(rng.choice([1, 2, 5, 10])),
+             "step": str(rng.choice(["alg1", "alg2"])), "seed": int(rng.integers(0, 1000))}
+        prost.set_precision(c["precision"])
+        dtype = np.float32 if c["precision"] == "single" else np.float64
+        if L >= 3:                                                  # the 3 / 4-channel one-kernel path takes whole 16-byte row groups only
+            c["ny"] += -c["ny"] % (4 if dtype == np.float32 else 2)
+        nx, ny = c["nx"], c["ny"]
+        d = None
+        try:
+            f = np.asarray(synthetic.rof_image(nx, ny, L, c["seed"])).ravel()
+
+            def make(lo, hi):
+                fs = np.concatenate([f[l * nx * ny + lo * ny: l * nx * ny + hi * ny] for l in range(L)])
+                return synthetic.rof_problem(hi - lo, ny, L, f=fs)[0]
+            backend = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=0.5)
+            whole = make(0, nx)
+            whole.finalize()
+            orc = oracle.Solver(whole.data, whole.nrows, whole.ncols, [backend[0], dict(backend[1], scale_steps_operator=False)], opts, dtype)
+            orc.initialize(); orc.iterate(c["iters"])
+            ost = orc.state()
+            slabs = [distributed.ColumnShardedSolver(make, nx, ny, backend, opts, r, world, halo, transport="local") for r in range(world)]
+            for s_ in slabs:
+                s_.transport = slabs
+            distributed.iterate_group(slabs, c["iters"])
+            own = lambda v, planes, c0, c1: np.concatenate([v[k * nx * ny + c0 * ny: k * nx * ny + c1 * ny] for k in planes])
+            for s_ in slabs:
+                st = s_.owned_state()
+                for name, got, want in (("x", st["x"], own(ost["x"], range(L), s_.c0, s_.c1)), ("y1", st["y1"], own(ost["y"], range(L), s_.c0, s_.c1)),
+                                        ("y2", st["y2"], own(ost["y"], range(L, 2 * L), s_.c0, s_.c1))):
+                    if d is None and not np.array_equal(got, want):
+                        d = "slab %d columns [%d, %d): %s differs (max |d| %.3g)" % (s_.rank, s_.c0, s_.c1, name, float(np.abs(got - want).max()))
+                s_.destroy()
+        except Exception as e:                                      # noqa: BLE001
+            d = "exception: %s" % e
+        done += 1
+        if d:
+            fails += 1
+            print("FAIL %s: %s" % (c, d), flush=True)
+    prost.set_precision("double")
+    print("fuzz_parity: %d sharded cases in %.0f s, %d failures" % (done, time.time() - t0, fails))
+    return 1 if fails else 0
+
+
 # ---- mode "generic": random compositions of the operator blocks and elementwise functions ---------------------------------------
 EXACT_FUNS = ("zero", "abs", "square", "ind_leq0", "ind_geq0", "ind_eq0", "ind_box01", "max_pos0", "l0", "huber", "trunclin", "truncquad")
 
@@ -388,12 +441,14 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=600.0)
-    ap.add_argument("--mode", choices=["fused", "generic", "large"], default="fused")
+    ap.add_argument("--mode", choices=["fused", "generic", "large", "sharded"], default="fused")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     prost.set_gpu(0)
     if args.mode == "large":
         return run_large(args, rng)
+    if args.mode == "sharded":
+        return run_sharded(args, rng)
     t0, done, fails, ties, setups, skipped, inexact, diverged, sensitive, solves, paths = time.time(), 0, 0, 0, 0, 0, 0, 0, 0, 0, {}
     for i in range(args.cases):
         if time.time() - t0 > args.budget_s:
