@@ -65,6 +65,14 @@ class BlockSparse : public Block<T> {
   virtual T row_sum(size_t row, T alpha) const;
   virtual T col_sum(size_t col, T alpha) const;
   virtual size_t gpu_mem_amount() const;
+  /// MI355X addition (on by default): a matrix whose rows repeat a few (column - row, value) sequences -- a stencil written out as a
+  /// sparse matrix -- is applied from one 16-bit pattern number per row + a small table instead of its CSR arrays; same sums, same order
+  static void SetPatternCompression(bool on);
+  static bool pattern_compression();
+  /// which of K / K^T are applied from row patterns (after Initialize()), and how many patterns each has
+  bool patterns_forward() const { return pat_.on; }
+  bool patterns_adjoint() const { return pat_t_.on; }
+  size_t pattern_count(bool adjoint) const { return (adjoint ? pat_t_ : pat_).count; }
   virtual bool describe(BlockDesc& d) const {
     if (val_.size() != nnz_ || nnz_ == 0) return false;      // before Initialize()
     d.kind = BlockDesc::kSparse; d.nnz = nnz_;
@@ -84,6 +92,14 @@ class BlockSparse : public Block<T> {
   std::vector<T> host_val_, host_val_t_;
   device_vector<int32_t> ind_, ind_t_, ptr_, ptr_t_;
   device_vector<T> val_, val_t_;
+  struct RowPatterns {
+    bool on = false;
+    size_t count = 0;
+    device_vector<uint16_t> ids;              ///< pattern number of every row
+    device_vector<int32_t> pptr, rel;         ///< entries pptr[id] .. pptr[id + 1] - 1 of the table: column - row ...
+    device_vector<T> val;                     ///< ... and value
+  };
+  RowPatterns pat_, pat_t_;
 };
 
 /// kron(K, I_d) (id_first == false, block_sparse_kron_id.cu) or kron(I_d, K) (id_first == true,

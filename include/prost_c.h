@@ -137,7 +137,7 @@ int prost_comm_set_host_p2p(prost_p2p_cb fn, void* user);
  *       solvers of one process
  *   solver_state(handle[, with_vectors = 1]) -> struct {x,y,z,w,tau,sigma,theta,rho,primal_res,dual_res,primal_var_norm,
  *                                   dual_var_norm,eps_primal,eps_dual,iteration,cg_iterations,path,pair_launches,
- *                                   speculative_launches,speculative_adopted}; with_vectors = 0 leaves out x,y,z,w
+ *                                   speculative_launches,speculative_adopted,sparse_pattern_products}; with_vectors = 0 leaves out x,y,z,w
  *   solver_compare(handle_a, handle_b) -> 4x2 matrix, rows x, y, x_prev, y_prev: {elements that differ in value,
  *       sum |a - b|}, formed on the device (verification of states too large to read back; pdhg only)
  *   solver_read(handle, 'x'|'y'|'x_prev'|'y_prev', offsets, count) -> count x numel(offsets) matrix: `count`
@@ -149,7 +149,8 @@ int prost_comm_set_host_p2p(prost_p2p_cb fn, void* user);
  *       themselves in Factory<T>::block_reg() / prox_reg() / backend_reg() from static initialisers (custom.cpp:11-28;
  *       the reference compiles such sources into the MEX file, cmake/CustomSources.cmake.example:1-26)
  *   registered -> struct {prox, block, backend}: cells of the registered names
- *   set_quirks(struct {diags_adjoint_grid, dual_negate_float})
+ *   set_quirks(struct {diags_adjoint_grid, dual_negate_float, fuse_moreau, sparse_patterns}) -- the first two switch reference
+ *       bug-compatibility on; the last two (default on) switch MI355X-side fusions off for A/B runs
  */
 
 #ifdef __cplusplus

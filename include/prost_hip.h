@@ -30,7 +30,7 @@ extern "C" {
  * 4: prost_hip_selftest_math writes EIGHT counters (it wrote five up to an early v3 header: a caller built against that
  *    header passes a too short buffer -- check prost_hip_abi_version() >= 4 before relying on the 8-slot layout);
  *    additions: comm_count, comm_is_host, comm_host_configure (point-to-point on the host-callback transport),
- *    fused operator entry points of the ADMM graph projection */
+ *    fused operator entry points of the ADMM graph projection, mask_merge, next_launch_events, pattern_spmv */
 #define PROST_HIP_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------------------------ */
@@ -112,6 +112,12 @@ int prost_hip_csr_spmv_acc_f64(double* res, const double* rhs, size_t nrows, siz
 /* res = K rhs (non-accumulating form: the zero fill of Block::EvalLocal folded into the product) */
 int prost_hip_csr_spmv_f32(float* res, const float* rhs, size_t nrows, size_t nnz, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 int prost_hip_csr_spmv_f64(double* res, const double* rhs, size_t nrows, size_t nnz, const double* val, const int32_t* ptr, const int32_t* ind, void* stream);
+/* res (+)= A rhs for a matrix whose rows repeat a few (column - row, value) sequences -- stencils written out as sparse matrices
+ * (spmat_gradient2d.m, blur operators): ids[row] (16-bit) selects entries pptr[id] .. pptr[id + 1] - 1 of the
+ * table (rel = column - row, pval = value), summed in that order: the bits of prost_hip_csr_spmv* for rows of <= 6 entries on
+ * average.  2 bytes per row instead of 8 per entry + 4 per row.  acc = 1 accumulates (block_sparse.cu:156-168), 0 writes. */
+int prost_hip_pattern_spmv_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int acc, void* stream);
+int prost_hip_pattern_spmv_f64(double* res, const double* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int acc, void* stream);
 /* res += kron(K, I_d) rhs (BlockSparseKronIdKernel, src/linop/block_sparse_kron_id.cu:26-49) and
  * res += kron(I_d, K) rhs (BlockIdKronSparseKernel, src/linop/block_id_kron_sparse.cu:26-52); K (nrows x ncols)
  * in CSR with int32 indices and FLOAT values for both T (:36, :79).  The adjoint is the same call

@@ -828,6 +828,12 @@ void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** pl
   prost_value_struct_set(out, "pair_launches", prost_value_scalar((double)h.backend->pair_launches()));
   prost_value_struct_set(out, "speculative_launches", prost_value_scalar(spec_l));
   prost_value_struct_set(out, "speculative_adopted", prost_value_scalar(spec_a));
+  {   // sparse blocks applied from row patterns instead of their CSR arrays (forward + adjoint products counted separately)
+    double pat = 0;
+    for (const auto& blk : h.problem->linop()->blocks())
+      if (auto* sb = dynamic_cast<BlockSparse<T>*>(blk.get())) pat += (sb->patterns_forward() ? 1 : 0) + (sb->patterns_adjoint() ? 1 : 0);
+    prost_value_struct_set(out, "sparse_pattern_products", prost_value_scalar(pat));
+  }
   if (nlhs >= 1) plhs[0] = out; else prost_value_free(out);
 }
 void cmd_solver_state(CMD_ARGS) {
@@ -1080,6 +1086,7 @@ void cmd_set_quirks(CMD_ARGS) {
   if (nrhs < 1) throw Exception("set_quirks: struct required.");
   if (prost_value_field(prhs[0], "diags_adjoint_grid")) BlockDiags<double>::SetReferenceGridQuirk(GetScalarFromField(prhs[0], "diags_adjoint_grid") > 0);
   if (prost_value_field(prhs[0], "fuse_moreau")) { const bool on = GetScalarFromField(prhs[0], "fuse_moreau") > 0; ProxMoreau<float>::SetFuseElemOperations(on); ProxMoreau<double>::SetFuseElemOperations(on); }
+  if (prost_value_field(prhs[0], "sparse_patterns")) BlockSparse<double>::SetPatternCompression(GetScalarFromField(prhs[0], "sparse_patterns") > 0);
   if (prost_value_field(prhs[0], "dual_negate_float")) DualLinearOperator<double>::SetReferenceNegateQuirk(GetScalarFromField(prhs[0], "dual_negate_float") > 0);
 }
 

@@ -86,6 +86,7 @@ template class device_vector<float>;
 template class device_vector<double>;
 template class device_vector<int32_t>;
 template class device_vector<int64_t>;
+template class device_vector<uint16_t>;
 
 // ---- linspace: num values + a trailing `end` (reference src/common.cu:33-46) ----
 template <typename T>

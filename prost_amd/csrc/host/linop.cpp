@@ -2,6 +2,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
+#include <unordered_map>
 
 #include "hipapi.hpp"
 #include "prost/linop/blocks.hpp"
@@ -50,13 +52,85 @@ BlockSparse<T>* BlockSparse<T>::CreateFromCSC(size_t row, size_t col, int m, int
              b->host_ind_.data(), b->host_ptr_.data());
   return b;
 }
+// Rows of a CSR matrix as repeated (column - row, value) sequences.  Returns false -- the matrix stays CSR -- when it is small (< 256
+// rows), when its rows are not made of few sequences (more than a quarter of up to 4096 sampled rows differ; > 4096 sequences in all, or
+// a table of > 65536 entries), or on a signature collision.
+namespace {
+bool g_sparse_patterns = true;
+template <typename T>
+struct HostRowPatterns { std::vector<uint16_t> ids; std::vector<int32_t> pptr, rel; std::vector<T> val; };
+template <typename T>
+bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind, const std::vector<T>& val, HostRowPatterns<T>& out) {
+  constexpr size_t kMinRows = 256, kMaxPatterns = 4096, kMaxTable = (size_t)1 << 16;
+  if (nrows < kMinRows || ptr.size() != nrows + 1) return false;
+  const size_t kSample = std::min<size_t>(4096, nrows), kMaxSampled = kSample / 4;
+  std::vector<uint64_t> sig(nrows);
+  ParallelFor(nrows, [&](size_t lo, size_t hi) {
+    for (size_t r = lo; r < hi; r++) {
+      uint64_t h = 1469598103934665603ull ^ (uint64_t)(ptr[r + 1] - ptr[r]);
+      for (int32_t j = ptr[r]; j < ptr[r + 1]; j++) {
+        uint64_t bits = 0;
+        std::memcpy(&bits, &val[j], sizeof(T));
+        h = (h ^ (uint64_t)(uint32_t)(ind[j] - (int32_t)r)) * 1099511628211ull; h ^= h >> 29;
+        h = (h ^ bits) * 1099511628211ull; h ^= h >> 31;
+      }
+      sig[r] = h;
+    }
+  });
+  {   // unstructured matrices leave here after a look at 4096 evenly spaced rows
+    std::vector<uint64_t> smp(kSample);
+    for (size_t i = 0; i < kSample; i++) smp[i] = sig[i * (nrows / kSample)];
+    std::sort(smp.begin(), smp.end());
+    if ((size_t)(std::unique(smp.begin(), smp.end()) - smp.begin()) > kMaxSampled) return false;
+  }
+  std::unordered_map<uint64_t, uint32_t> seen;
+  std::vector<size_t> rep;                                           // a row of every pattern
+  out.ids.assign((nrows + 3) / 4 * 4, 0);
+  out.pptr.assign(1, 0); out.rel.clear(); out.val.clear();
+  for (size_t r = 0; r < nrows; r++) {
+    auto it = seen.find(sig[r]);
+    if (it == seen.end()) {
+      if (seen.size() >= kMaxPatterns || out.rel.size() + (size_t)(ptr[r + 1] - ptr[r]) > kMaxTable) return false;
+      it = seen.emplace(sig[r], (uint32_t)rep.size()).first;
+      rep.push_back(r);
+      for (int32_t j = ptr[r]; j < ptr[r + 1]; j++) { out.rel.push_back(ind[j] - (int32_t)r); out.val.push_back(val[j]); }
+      out.pptr.push_back((int32_t)out.rel.size());
+    } else {
+      const size_t q = rep[it->second];                              // equal signatures: equal rows, or a collision (then: CSR)
+      const int32_t len = ptr[r + 1] - ptr[r];
+      if (len != ptr[q + 1] - ptr[q]) return false;
+      for (int32_t j = 0; j < len; j++)
+        if (ind[ptr[r] + j] - (int32_t)r != ind[ptr[q] + j] - (int32_t)q || std::memcmp(&val[ptr[r] + j], &val[ptr[q] + j], sizeof(T)) != 0) return false;
+    }
+    out.ids[r] = (uint16_t)it->second;
+  }
+  return true;
+}
+}  // namespace
+template <typename T> void BlockSparse<T>::SetPatternCompression(bool on) { g_sparse_patterns = on; }
+template <typename T> bool BlockSparse<T>::pattern_compression() { return g_sparse_patterns; }
+
 template <typename T>
 void BlockSparse<T>::Initialize() {
   ind_ = host_ind_; ptr_ = host_ptr_; val_ = host_val_;
   ind_t_ = host_ind_t_; ptr_t_ = host_ptr_t_; val_t_ = host_val_t_;
+  pat_.on = pat_t_.on = false;
+  if (!g_sparse_patterns) return;
+  auto build = [&](RowPatterns& p, size_t nrows, const std::vector<int32_t>& hp, const std::vector<int32_t>& hi, const std::vector<T>& hv) {
+    HostRowPatterns<T> h;
+    if (!BuildRowPatterns<T>(nrows, hp, hi, hv, h)) return;
+    p.ids = h.ids; p.pptr = h.pptr; p.rel = h.rel; p.val = h.val;
+    p.count = h.pptr.size() - 1;
+    p.on = true;
+  };
+  build(pat_, this->nrows(), host_ptr_, host_ind_, host_val_);
+  build(pat_t_, this->ncols(), host_ptr_t_, host_ind_t_, host_val_t_);
 }
 template <typename T>
-void BlockSparse<T>::Release() { ind_.clear(); ptr_.clear(); val_.clear(); ind_t_.clear(); ptr_t_.clear(); val_t_.clear(); }
+void BlockSparse<T>::Release() {
+  ind_.clear(); ptr_.clear(); val_.clear(); ind_t_.clear(); ptr_t_.clear(); val_t_.clear();
+  for (RowPatterns* p : {&pat_, &pat_t_}) { p->on = false; p->ids.clear(); p->pptr.clear(); p->rel.clear(); p->val.clear(); }
+}
 template <typename T>
 T BlockSparse<T>::row_sum(size_t row, T alpha) const {
   T sum = 0;
@@ -71,26 +145,32 @@ T BlockSparse<T>::col_sum(size_t col, T alpha) const {
 }
 template <typename T>
 size_t BlockSparse<T>::gpu_mem_amount() const {
-  return 2 * nnz_ * sizeof(int32_t) + (this->nrows() + this->ncols() + 2) * sizeof(int32_t) + 2 * nnz_ * sizeof(T);
+  size_t bytes = 2 * nnz_ * sizeof(int32_t) + (this->nrows() + this->ncols() + 2) * sizeof(int32_t) + 2 * nnz_ * sizeof(T);
+  for (const RowPatterns* p : {&pat_, &pat_t_}) bytes += p->ids.size() * sizeof(uint16_t) + (p->pptr.size() + p->rel.size()) * sizeof(int32_t) + p->val.size() * sizeof(T);
+  return bytes;
 }
 template <typename T>
 void BlockSparse<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) {
   if (val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), 1, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
   if (val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), 1, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalLocal(T* r, T*, const T* x, const T*) {
   if (val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), 0, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) {
   if (val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), 0, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv");
 }
 template class BlockSparse<float>;

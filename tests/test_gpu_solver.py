@@ -908,3 +908,66 @@ def test_solve_with_a_one_element_variable():
     assert r["y"].shape == (1,) and q.val.shape == (1,) and u.val.shape == (n,)
     ro = oracle.solve(prob, prost.backend.pdhg(stepsize="alg1"), prost.options(max_iters=30, num_cback_calls=0, verbose=False), np.float64)
     assert r["iters"] == ro["iters"] and np.array_equal(r["x"], ro["x"]) and np.array_equal(r["y"], ro["y"])
+
+
+def _stencil_matrices():
+    """sparse matrices that ARE stencils: the gradient of the reference's examples (spmat_gradient2d.m), its 3-D form, a 3 x 3 blur
+    with zero boundary (as example_deblurring.m builds one), and a matrix without structure as the negative control"""
+    rng = np.random.default_rng(5)
+    nx, ny = 40, 130
+    blur = sp.kron(sp.diags([0.25, 0.5, 0.25], [-1, 0, 1], shape=(nx, nx)), sp.diags([0.2, 0.6, 0.2], [-1, 0, 1], shape=(ny, ny))).tocsc()
+    return [("gradient2d", spmat_gradient2d(nx, ny, 1), 2), ("gradient2d rgb", spmat_gradient2d(24, 70, 3), 2), ("gradient3d", spmat_gradient3d(12, 30, 14), 2),
+            ("blur", blur, 2), ("random", sp.random(5200, 4100, density=3.0 / 4100, random_state=3, format="csc"), 0)]
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_stencils_written_out_as_sparse_matrices_run_from_row_patterns(precision, dtype):
+    """BlockSparse::Initialize recognises rows that repeat a few (column - row, value) sequences and applies such a matrix from one
+    16-bit pattern number per row + a table (prost_hip_pattern_spmv_*): the products and a PDHG solve equal the CSR path's
+    (set_quirks(sparse_patterns=0)) and the oracle's bit for bit; a matrix without structure stays CSR."""
+    prost.set_precision(precision)
+    rng = np.random.default_rng(1)
+    try:
+        for name, K, expect in _stencil_matrices():
+            K = sp.csc_matrix(K)
+            m, n = K.shape
+            u, q = prost.variable(n), prost.variable(m)
+            res = {}
+            for on in (1, 0):
+                prost.set_quirks(sparse_patterns=on)
+                prob = prost.min_max_problem([u], [q])
+                prob.add_function(u, prost.function.sum_1d("square", 1, np.linspace(0, 1, n), 4.0))
+                prob.add_function(q, prost.function.sum_1d("ind_box01", 0.5, -0.5))
+                prob.add_dual_pair(u, q, prost.block.sparse(K))
+                prob.finalize()
+                b = prost.backend.pdhg(stepsize="alg2", residual_iter=5, alg2_gamma=0.3, scale_steps_operator=False)
+                o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+                s = prost.Solver(prob, b, o)
+                s.iterate(23)
+                res[on] = s.state()
+                s.destroy()
+                if on:
+                    assert res[on]["sparse_pattern_products"] == expect, (name, res[on]["sparse_pattern_products"])
+                    ost = run_oracle(prob, b, o, 23, dtype)
+                else:
+                    assert res[on]["sparse_pattern_products"] == 0
+            # (rows of more than 6 entries on average: the CSR kernels sum with cooperating lanes, the patterns -- like the oracle --
+            # sequentially: equal to rounding there, bit for bit otherwise)
+            long_rows = K.nnz > 6 * min(m, n)
+            for v in "xyzw":
+                if long_rows:
+                    assert np.allclose(res[1][v], res[0][v], rtol=0, atol=1e-4 if dtype == np.float32 else 1e-12), (name, v)
+                else:
+                    assert np.array_equal(res[1][v], res[0][v]), (name, v)
+                assert np.array_equal(res[1][v], ost[v]), (name, v, "oracle")
+            # the products themselves, accumulating and not, through eval_linop
+            for tr in (False, True):
+                rhs = rng.uniform(-1, 1, m if tr else n)
+                prost.set_quirks(sparse_patterns=1)
+                a = np.asarray(prost.eval_linop(prob.data["linop"], rhs, tr)[0]).ravel()
+                prost.set_quirks(sparse_patterns=0)
+                b_ = np.asarray(prost.eval_linop(prob.data["linop"], rhs, tr)[0]).ravel()
+                assert np.array_equal(a, oracle.eval_linop(prob.data["linop"], rhs, tr, dtype)[0].ravel()), (name, tr)
+                assert np.allclose(a, b_, rtol=0, atol=1e-5 if dtype == np.float32 else 1e-13) if long_rows else np.array_equal(a, b_), (name, tr)
+    finally:
+        prost.set_quirks(sparse_patterns=1)

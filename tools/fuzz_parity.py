@@ -24,6 +24,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 
 import oracle
@@ -277,12 +278,17 @@ def _function(rng, count, desc=None, what="", continuous=False):
 def build_generic(c):
     import scipy.sparse as sp
     rng = np.random.default_rng(c["seed"])
-    nx, ny, L = int(rng.integers(2, 12)), int(rng.integers(2, 12)), int(rng.choice([1, 1, 2, 3]))
+    big = rng.random() < 0.3                                        # (sparse blocks of >= 256 rows can run from row patterns)
+    nx, ny, L = int(rng.integers(2, 30 if big else 12)), int(rng.integers(2, 30 if big else 12)), int(rng.choice([1, 1, 2, 3]))
     n = nx * ny * L
     psizes = [n] + ([int(rng.choice([n, int(rng.integers(1, 50))]))] if rng.random() < 0.4 else [])
     rows = []
     for _ in range(int(rng.integers(1, 4))):
-        t = str(rng.choice(["grad2d", "grad3d", "sparse", "sparse", "diags", "identity", "kron_id", "id_kron"]))
+        t = str(rng.choice(["grad2d", "grad3d", "sparse", "sparse", "diags", "identity", "kron_id", "id_kron", "stencil"]))
+        if t == "stencil":                                          # a stencil written out as a sparse matrix: applied from row patterns (>= 256 rows)
+            st = str(rng.choice(["g2", "g3", "band"]))
+            rows.append((t, {"g2": 2 * n, "g3": 3 * n, "band": n}[st], st))
+            continue
         if t in ("kron_id", "id_kron"):                             # kron(K, I_d) / kron(I_d, K) with K of (mk x n / d): d must divide n
             dl = int(rng.choice([d for d in (1, 2, 3, 4, 5, 6) if n % d == 0]))
             rows.append((t, int(rng.integers(1, 9)) * dl, dl))
@@ -316,6 +322,16 @@ def build_generic(c):
             if Ks.nnz == 0:
                 Ks = sp.csc_matrix(([0.75], ([0], [0])), shape=(m // dl, n // dl))
             add(pv[0], dv[j], (prost.block.sparse_kron_id if t == "kron_id" else prost.block.id_kron_sparse)(Ks, dl)); covered[0] = True
+        elif t == "stencil":
+            from reference_matrices import spmat_gradient2d, spmat_gradient3d
+            if row[2] == "g2":
+                Km = spmat_gradient2d(nx, ny, L)
+            elif row[2] == "g3":
+                Km = spmat_gradient3d(nx, ny, L)
+            else:
+                offs = sorted(set(int(v) for v in rng.integers(-ny - 1, ny + 2, int(rng.integers(1, 5)))))
+                Km = sp.diags([float(v) for v in rng.uniform(-1, 1, len(offs))], offs, shape=(n, n))
+            add(pv[0], dv[j], prost.block.sparse(sp.csc_matrix(Km))); covered[0] = True
         elif t == "grad2d":
             add(pv[0], dv[j], prost.block.gradient2d(nx, ny, L, bool(rng.integers(0, 2)) if L > 1 else False)); covered[0] = True
         elif t == "grad3d":
