@@ -113,7 +113,7 @@ int prost_hip_csr_spmv_acc_f64(double* res, const double* rhs, size_t nrows, siz
 int prost_hip_csr_spmv_f32(float* res, const float* rhs, size_t nrows, size_t nnz, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 int prost_hip_csr_spmv_f64(double* res, const double* rhs, size_t nrows, size_t nnz, const double* val, const int32_t* ptr, const int32_t* ind, void* stream);
 /* res (+)= A rhs for a matrix whose rows repeat a few (column - row, value) sequences -- stencils written out as sparse matrices
- * (spmat_gradient2d.m, blur operators): ids[row] (16-bit) selects entries pptr[id] .. pptr[id + 1] - 1 of the
+ * (spmat_gradient2d.m, blur operators): ids[row] (16-bit, the array 8-byte aligned and padded to a multiple of 4 rows) selects entries pptr[id] .. pptr[id + 1] - 1 of the
  * table (rel = column - row, pval = value), summed in that order: the bits of prost_hip_csr_spmv* for rows of <= 6 entries on
  * average.  2 bytes per row instead of 8 per entry + 4 per row.  acc = 1 accumulates (block_sparse.cu:156-168), 0 writes. */
 int prost_hip_pattern_spmv_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int acc, void* stream);

@@ -382,53 +382,85 @@ static int launch_diags(bool adj, T* res, const T* rhs, size_t nrows, size_t nco
 // (sequentially, the order of the oracle's restatement of csrmv), so the result equals that of csr_spmv_kernel<T, 1, .> bit for
 // bit.
 // ------------------------------------------------------------------------------------------
+// four consecutive elements at an address that is only element-aligned (gfx950 serves such 16-byte accesses): (row + rel) is
+// whatever the stencil says
+template <class T> struct Quad;
+template <> struct Quad<float> { typedef float V __attribute__((ext_vector_type(4), aligned(4))); };
+template <> struct Quad<double> { typedef double V __attribute__((ext_vector_type(4), aligned(8))); };
+
 template <class T, bool ACC>
 __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nrows, const uint16_t* __restrict__ ids,
                                                               const int32_t* __restrict__ pptr, const int32_t* __restrict__ rel, const T* __restrict__ pval) {
-  // a wavefront takes R groups of 64 consecutive rows (lane = row within the group: every access of the wavefront is one contiguous
-  // piece).  Nearly always all 64 R rows have ONE pattern: its table entries are then wave-uniform (scalar loads), and an entry
-  // costs one coalesced load of rhs per group.  Mixed wavefronts (the seams of the stencil, the last rows) walk the table per lane.
-  constexpr int R = 4;                                                   // (8: 10.0k against 10.5k iterations/s on the 2048^2 sparse-gradient ROF)
+  // A lane takes 4 consecutive rows, a wavefront G groups of 256 rows.  Nearly always all of them have ONE pattern: its table
+  // entries are then wave-uniform (scalar loads) and an entry costs one 16 / 32-byte load of rhs per lane and group.  Mixed
+  // wavefronts (the seams of the stencil, the last rows) walk the table per row.
+  constexpr int R = 4, G = 2;
+  typedef typename Quad<T>::V QV;
   const int lane = threadIdx.x & (kWave - 1);
   const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kWave, nwaves = (size_t)gridDim.x * kBlock / kWave;
-  for (size_t base = wave * (size_t)(kWave * R); base < nrows; base += nwaves * (size_t)(kWave * R)) {
-    unsigned id[R];
+  constexpr size_t kRowsPerWave = (size_t)kWave * R * G;
+  for (size_t base = wave * kRowsPerWave; base < nrows; base += nwaves * kRowsPerWave) {
+    unsigned id[G][R];
     bool same = true;
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-      const size_t row = base + (size_t)j * kWave + lane;
-      id[j] = row < nrows ? (unsigned)ids[row] : 0xFFFFFFFFu;            // rows past the end: no pattern (and no uniform wavefront)
+    for (int g = 0; g < G; g++) {
+      const size_t row0 = base + ((size_t)g * kWave + lane) * R;
+      if (row0 + R <= nrows) {
+        const uint2 w = *reinterpret_cast<const uint2*>(ids + row0);        // row0 is a multiple of 4 and ids 8-byte aligned
+        id[g][0] = w.x & 0xFFFFu; id[g][1] = w.x >> 16; id[g][2] = w.y & 0xFFFFu; id[g][3] = w.y >> 16;
+      } else {
+#pragma unroll
+        for (int j = 0; j < R; j++) id[g][j] = row0 + j < nrows ? (unsigned)ids[row0 + j] : 0xFFFFFFFFu;   // past the end: no pattern, no uniform wavefront
+      }
     }
-    const unsigned id0 = (unsigned)__builtin_amdgcn_readfirstlane((int)id[0]);
+    const unsigned id0 = (unsigned)__builtin_amdgcn_readfirstlane((int)id[0][0]);
 #pragma unroll
-    for (int j = 0; j < R; j++) same = same && id[j] == id0;
-    T out[R];
+    for (int g = 0; g < G; g++)
 #pragma unroll
-    for (int j = 0; j < R; j++) out[j] = 0;
+      for (int j = 0; j < R; j++) same = same && id[g][j] == id0;
+    T out[G][R];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+      for (int j = 0; j < R; j++) out[g][j] = 0;
     if (__builtin_amdgcn_ballot_w64(!same) == 0) {
       const int32_t b = pptr[id0], e = pptr[id0 + 1];
-      const T* x0 = rhs + base + lane;
       for (int32_t k = b; k < e; k++) {
         const long r = (long)rel[k];
         const T v = pval[k];
 #pragma unroll
-        for (int j = 0; j < R; j++) out[j] += v * x0[(long)(j * kWave) + r];
+        for (int g = 0; g < G; g++) {
+          const QV x = *reinterpret_cast<const QV*>(rhs + (long)(base + ((size_t)g * kWave + lane) * R) + r);
+#pragma unroll
+          for (int j = 0; j < R; j++) out[g][j] += v * x[j];
+        }
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < R; j++) {
-        if (id[j] == 0xFFFFFFFFu) continue;
-        const long row = (long)(base + (size_t)j * kWave + lane);
-        const int32_t b = pptr[id[j]], e = pptr[id[j] + 1];
-        T sum = 0;
-        for (int32_t k = b; k < e; k++) sum += pval[k] * rhs[row + rel[k]];
-        out[j] = sum;
-      }
+      for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          if (id[g][j] == 0xFFFFFFFFu) continue;
+          const long row = (long)(base + ((size_t)g * kWave + lane) * R + j);
+          const int32_t b = pptr[id[g][j]], e = pptr[id[g][j] + 1];
+          T sum = 0;
+          for (int32_t k = b; k < e; k++) sum += pval[k] * rhs[row + rel[k]];
+          out[g][j] = sum;
+        }
     }
 #pragma unroll
-    for (int j = 0; j < R; j++) {
-      const size_t row = base + (size_t)j * kWave + lane;
-      if (row < nrows) res[row] = (ACC ? res[row] : (T)0) + out[j];
+    for (int g = 0; g < G; g++) {
+      const size_t row0 = base + ((size_t)g * kWave + lane) * R;
+      if (row0 + R <= nrows) {
+        QV o;
+        if (ACC) o = *reinterpret_cast<const QV*>(res + row0);
+#pragma unroll
+        for (int j = 0; j < R; j++) o[j] = (ACC ? o[j] : (T)0) + out[g][j];
+        *reinterpret_cast<QV*>(res + row0) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < R; j++) if (row0 + j < nrows) res[row0 + j] = (ACC ? res[row0 + j] : (T)0) + out[g][j];
+      }
     }
   }
 }
@@ -436,8 +468,9 @@ template <class T>
 static int launch_pattern(T* res, const T* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const T* pval, int acc, void* stream) {
   if (nrows == 0) return 0;
   if (!res || !rhs || !ids || !pptr || !rel || !pval) { set_error("pattern spmv: null pointer"); return 1; }
+  if (reinterpret_cast<uintptr_t>(ids) % 8 != 0) { set_error("pattern spmv: the pattern numbers must be 8-byte aligned"); return 1; }
   hipStream_t s = as_stream(stream);
-  const unsigned grid = grid_for((nrows + 3) / 4);
+  const unsigned grid = grid_for((nrows + 7) / 8);
   if (acc) hipLaunchKernelGGL((pattern_spmv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
   else hipLaunchKernelGGL((pattern_spmv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
   PH_LAUNCH_END("pattern spmv kernel");

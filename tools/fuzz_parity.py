@@ -545,7 +545,14 @@ def main():
                     d = "initial tau %r vs %r; then %s" % (t0p, t0o, d)
             if d and c["step"] in ("goldstein", "boyd") and args.mode == "generic":
                 # no second product path to ask: a residual threshold that decided differently shows in the step sizes
-                if st["tau"] != ost["tau"] or st["sigma"] != ost["sigma"]:
+                tie = st["tau"] != ost["tau"] or st["sigma"] != ost["sigma"]
+                if not tie:
+                    # (boyd can divide and later multiply by the same factor: equal steps at the end, different ones on the way) -- the same
+                    # composition under alg1, whose steps do not look at the residuals, must then be exact
+                    b1 = prost.backend.pdhg(stepsize="alg1", residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=c["scale_steps"])
+                    p1 = build_generic(c)
+                    tie = differs(product(p1, b1, o, c), reference(p1, b1, o, c, dtype)) is None
+                if tie:
                     ties += 1
                     d = None
             elif d and c["step"] in ("goldstein", "boyd"):
