@@ -544,8 +544,7 @@ shared_ptr<SolverHandle<T>> build_solver(const prost_value* problem, size_t nrow
   { StageTimer t("Solver::Initialize (total)"); h->solver->Initialize(); }
   if (own_frac != 1.0) {
     auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get());
-    if (!pd->sharded_path()) throw Exception("Column sharding needs a one-kernel gradient2d path (one gradient2d block with L <= 4 channels; with 3 or 4 channels "
-                                              "the image height must be a whole number of 16-byte row groups: a multiple of 4 rows in single, of 2 in double precision).");
+    if (!pd->sharded_path()) throw Exception("Column sharding needs a one-kernel gradient2d path (one gradient2d block with L <= 4 channels).");
   }
   return h;
 }

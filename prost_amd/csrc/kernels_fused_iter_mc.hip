@@ -229,25 +229,25 @@ static bool iter_mc_ok(const prost_hip_fused_desc* d) {
   if (!d || d->is3d || (d->L != 3 && d->L != 4)) return false;
   if (d->nx == 0 || d->ny == 0) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
-  if (d->ny % VecOf<T>::N != 0) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;
     if (k != 1 && d->g_coeff_ptr[k]) return false;
   }
   if (d->g_coeff_ptr[1] && !aligned16(d->g_coeff_ptr[1])) return false;
-  const size_t strips = (d->ny + (size_t)(kWave - 1) * VecOf<T>::N - 1) / ((size_t)(kWave - 1) * VecOf<T>::N);
+  // (heights that are not a whole number of 16-byte row groups run the one-row-per-lane instance: round 3)
+  const size_t vec = d->ny % VecOf<T>::N == 0 ? VecOf<T>::N : 1;
+  const size_t strips = (d->ny + (size_t)(kWave - 1) * vec - 1) / ((size_t)(kWave - 1) * vec);
   if (strips * d->L > (size_t)kReduceBlocks / 2) return false;     // residual launches: one partial per wavefront must fit the workspace
   return strips * d->nx < (size_t)1 << 31;
 }
 
-template <class T>
-static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
+template <class T, int V>
+static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
                        int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream) {
   if (!iter_mc_ok<T>(d)) { set_error("fused multi-channel iteration: unsupported description (see prost_hip_fused_iteration_mc_supported)"); return 1; }
   if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y) || !aligned16(y_prev)) { set_error("fused multi-channel iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_new == x || y_new == y || (out4 && y_new == y_prev)) { set_error("fused multi-channel iteration: outputs must not alias inputs"); return 1; }
   if (out4 && (!ws || !y_prev)) { set_error("fused multi-channel iteration: residuals need the reduction workspace and y_prev"); return 1; }
-  constexpr int V = VecOf<T>::N;
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t strips = (d->ny + (size_t)(kWave - 1) * V - 1) / ((size_t)(kWave - 1) * V);
   // measured 4096^2 x 3 fp32: 6 columns 0.302 ms, 12: 0.306, 18: 0.314, 36: 0.329 (shorter chunks = more workgroups in flight
@@ -280,6 +280,14 @@ static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const 
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel iteration kernel"); }
   if (out4) return launch_fold4(out4, partial, grid * (unsigned)d->L, s);
   return 0;
+}
+
+// 16 bytes of rows per lane where the height is a whole number of such groups, one row per lane otherwise
+template <class T>
+static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
+                       int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream) {
+  if (d && d->ny % VecOf<T>::N != 0) return run_iter_mc_v<T, 1>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, out4, ws, stream);
+  return run_iter_mc_v<T, VecOf<T>::N>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, out4, ws, stream);
 }
 
 }  // namespace prost_hip

@@ -140,8 +140,6 @@ def run_sharded(args, rng):
              "step": str(rng.choice(["alg1", "alg2"])), "seed": int(rng.integers(0, 1000))}
         prost.set_precision(c["precision"])
         dtype = np.float32 if c["precision"] == "single" else np.float64
-        if L >= 3:                                                  # the 3 / 4-channel one-kernel path takes whole 16-byte row groups only
-            c["ny"] += -c["ny"] % (4 if dtype == np.float32 else 2)
         nx, ny = c["nx"], c["ny"]
         d = None
         try:
