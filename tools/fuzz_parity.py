@@ -85,7 +85,7 @@ def run_large(args, rng):
         kind = str(rng.choice(["gray", "gray", "mc", "vol"]))
         c = {"kind": kind, "precision": str(rng.choice(["single", "double"])), "step": str(rng.choice(["alg1", "alg2"])), "residual_iter": int(rng.choice([2, 3, 4, 5])),
              "iters": int(rng.integers(9, 15)), "lmb": float(rng.choice([3.0, 10.0])), "gamma": 0.5, "seed": int(rng.integers(0, 1000)),
-             "data": str(rng.choice(["square", "abs"] if kind == "vol" else ["square", "square", "abs", "mask"]))}
+             "data": str(rng.choice(["square", "abs"] if kind == "vol" else ["square", "square", "abs", "mask"])), "scale_steps": bool(rng.integers(0, 2))}
         if kind == "vol":
             c["L"] = int(rng.choice([2, 7, 13, 14, 26, 27, 40, 64, 100]))
             budget = 30e6 / c["L"]
@@ -102,7 +102,9 @@ def run_large(args, rng):
             prob = build(c)
             sol = []
             for fused in (True, False):
-                b = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=False)
+                # (scale_steps: both paths estimate the operator norm with the same kernels -- the stencil form of the power iteration --,
+                # so the rescaled steps are the same bits on both sides)
+                b = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=c["scale_steps"])
                 b[1]["allow_fused"] = fused
                 s = prost.Solver(prob, b, o)
                 s.iterate(c["iters"] // 2, checked=True); s.iterate(c["iters"] - c["iters"] // 2)
