@@ -64,6 +64,8 @@ class BlockSparse : public Block<T> {
   virtual void Release();
   virtual T row_sum(size_t row, T alpha) const;
   virtual T col_sum(size_t col, T alpha) const;
+  virtual void row_sums(T* out, T alpha) const;              ///< all rows at once, on all host cores (same sums as row_sum)
+  virtual void col_sums(T* out, T alpha) const;
   virtual size_t gpu_mem_amount() const;
   /// MI355X addition (on by default): a matrix whose rows repeat a few (column - row, value) sequences -- a stencil written out as a
   /// sparse matrix -- is applied from one 16-bit pattern number per row + a small table instead of its CSR arrays; same sums, same order
@@ -74,7 +76,7 @@ class BlockSparse : public Block<T> {
   bool patterns_adjoint() const { return pat_t_.on; }
   size_t pattern_count(bool adjoint) const { return (adjoint ? pat_t_ : pat_).count; }
   virtual bool describe(BlockDesc& d) const {
-    if (val_.size() != nnz_ || nnz_ == 0) return false;      // before Initialize()
+    if (val_.size() != nnz_ || val_t_.size() != nnz_ || nnz_ == 0) return false;      // before Initialize(), or applied from row patterns (no CSR arrays on the device)
     d.kind = BlockDesc::kSparse; d.nnz = nnz_;
     d.val = val_.data(); d.ptr = ptr_.data(); d.ind = ind_.data();
     d.val_t = val_t_.data(); d.ptr_t = ptr_t_.data(); d.ind_t = ind_t_.data();

@@ -22,6 +22,7 @@ def gradient3d(nx, ny, L, label_first=False):
 def sparse(K):
     import scipy.sparse as sp
     K = sp.csc_matrix(K, dtype=np.float64)
+    K.eliminate_zeros()                 # a MATLAB sparse matrix holds no explicit zeros (scipy constructions such as diags / kron do)
     K.sort_indices()
     sz = [K.shape[0], K.shape[1]]
     return lambda row, col, nrows, ncols: [["sparse", row, col, [K]], sz]
@@ -30,6 +31,7 @@ def sparse(K):
 def _kron(name, K, diaglength):
     import scipy.sparse as sp
     K = sp.csc_matrix(K, dtype=np.float64)
+    K.eliminate_zeros()
     K.sort_indices()
     d = int(diaglength)
     sz = [K.shape[0] * d, K.shape[1] * d]

@@ -112,19 +112,19 @@ template <typename T> bool BlockSparse<T>::pattern_compression() { return g_spar
 
 template <typename T>
 void BlockSparse<T>::Initialize() {
-  ind_ = host_ind_; ptr_ = host_ptr_; val_ = host_val_;
-  ind_t_ = host_ind_t_; ptr_t_ = host_ptr_t_; val_t_ = host_val_t_;
   pat_.on = pat_t_.on = false;
-  if (!g_sparse_patterns) return;
   auto build = [&](RowPatterns& p, size_t nrows, const std::vector<int32_t>& hp, const std::vector<int32_t>& hi, const std::vector<T>& hv) {
     HostRowPatterns<T> h;
-    if (!BuildRowPatterns<T>(nrows, hp, hi, hv, h)) return;
+    if (!g_sparse_patterns || !BuildRowPatterns<T>(nrows, hp, hi, hv, h)) return;
     p.ids = h.ids; p.pptr = h.pptr; p.rel = h.rel; p.val = h.val;
     p.count = h.pptr.size() - 1;
     p.on = true;
   };
   build(pat_, this->nrows(), host_ptr_, host_ind_, host_val_);
   build(pat_t_, this->ncols(), host_ptr_t_, host_ind_t_, host_val_t_);
+  // the CSR arrays of a product that runs from row patterns stay on the host (a 4096^2 gradient: 0.5 GB of upload each)
+  if (!pat_.on) { ind_ = host_ind_; ptr_ = host_ptr_; val_ = host_val_; }
+  if (!pat_t_.on) { ind_t_ = host_ind_t_; ptr_t_ = host_ptr_t_; val_t_ = host_val_t_; }
 }
 template <typename T>
 void BlockSparse<T>::Release() {
@@ -143,33 +143,49 @@ T BlockSparse<T>::col_sum(size_t col, T alpha) const {
   for (int32_t i = host_ptr_t_[col]; i < host_ptr_t_[col + 1]; i++) sum += std::pow(std::abs(host_val_t_[i]), alpha);
   return sum;
 }
+// |v|^alpha: alpha == 1 (the default scaling, both for rows and for columns: 2 - alpha == 1) needs no pow -- pow(x, 1) == x
+template <typename T>
+static void csr_abs_pow_sums(T* out, size_t n, const std::vector<int32_t>& ptr, const std::vector<T>& val, T alpha) {
+  ParallelFor(n, [&](size_t lo, size_t hi) {
+    for (size_t r = lo; r < hi; r++) {
+      T sum = 0;
+      if (alpha == (T)1) { for (int32_t i = ptr[r]; i < ptr[r + 1]; i++) sum += std::abs(val[i]); }
+      else { for (int32_t i = ptr[r]; i < ptr[r + 1]; i++) sum += std::pow(std::abs(val[i]), alpha); }
+      out[r] += sum;
+    }
+  });
+}
+template <typename T> void BlockSparse<T>::row_sums(T* out, T alpha) const { csr_abs_pow_sums<T>(out, this->nrows(), host_ptr_, host_val_, alpha); }
+template <typename T> void BlockSparse<T>::col_sums(T* out, T alpha) const { csr_abs_pow_sums<T>(out, this->ncols(), host_ptr_t_, host_val_t_, alpha); }
 template <typename T>
 size_t BlockSparse<T>::gpu_mem_amount() const {
-  size_t bytes = 2 * nnz_ * sizeof(int32_t) + (this->nrows() + this->ncols() + 2) * sizeof(int32_t) + 2 * nnz_ * sizeof(T);
+  size_t bytes = 0;
+  if (!pat_.on) bytes += nnz_ * (sizeof(int32_t) + sizeof(T)) + (this->nrows() + 1) * sizeof(int32_t);
+  if (!pat_t_.on) bytes += nnz_ * (sizeof(int32_t) + sizeof(T)) + (this->ncols() + 1) * sizeof(int32_t);
   for (const RowPatterns* p : {&pat_, &pat_t_}) bytes += p->ids.size() * sizeof(uint16_t) + (p->pptr.size() + p->rel.size()) * sizeof(int32_t) + p->val.size() * sizeof(T);
   return bytes;
 }
 template <typename T>
 void BlockSparse<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) {
-  if (val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (!pat_.on && val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
   if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), 1, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
-  if (val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (!pat_t_.on && val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
   if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), 1, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalLocal(T* r, T*, const T* x, const T*) {
-  if (val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (!pat_.on && val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
   if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), 0, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) {
-  if (val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
+  if (!pat_t_.on && val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
   if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), 0, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv");
 }

@@ -353,6 +353,11 @@ def build_generic(c):
     for i in range(len(pv)):
         if not covered[i]:
             add(pv[i], dv[0], sparse_block(rows[0][1], psizes[i]))
+    # (stencil matrices built with scipy carry explicit zeros: they count as entries, and a mean row length > 6 of K or of its stored
+    # transpose selects the cooperating-lane CSR kernels where the matrix is too small for row patterns)
+    for blk in prob.data["linop"]:
+        if blk[0] == "sparse" and blk[3][0].nnz > 6 * min(blk[3][0].shape):
+            c["long_rows"] = True
     for i, k in enumerate(psizes):
         if rng.random() < 0.85:
             prob.add_function(pv[i], _function(rng, k, desc, "primal %d" % i, c["backend"] == "admm"))
