@@ -2,7 +2,9 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 
 #include "hipapi.hpp"
@@ -83,27 +85,49 @@ bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::
     std::sort(smp.begin(), smp.end());
     if ((size_t)(std::unique(smp.begin(), smp.end()) - smp.begin()) > kMaxSampled) return false;
   }
-  std::unordered_map<uint64_t, uint32_t> seen;
-  std::vector<size_t> rep;                                           // a row of every pattern
-  out.ids.assign((nrows + 3) / 4 * 4, 0);
-  out.pptr.assign(1, 0); out.rel.clear(); out.val.clear();
-  for (size_t r = 0; r < nrows; r++) {
-    auto it = seen.find(sig[r]);
-    if (it == seen.end()) {
-      if (seen.size() >= kMaxPatterns || out.rel.size() + (size_t)(ptr[r + 1] - ptr[r]) > kMaxTable) return false;
-      it = seen.emplace(sig[r], (uint32_t)rep.size()).first;
-      rep.push_back(r);
-      for (int32_t j = ptr[r]; j < ptr[r + 1]; j++) { out.rel.push_back(ind[j] - (int32_t)r); out.val.push_back(val[j]); }
-      out.pptr.push_back((int32_t)out.rel.size());
-    } else {
-      const size_t q = rep[it->second];                              // equal signatures: equal rows, or a collision (then: CSR)
-      const int32_t len = ptr[r + 1] - ptr[r];
-      if (len != ptr[q + 1] - ptr[q]) return false;
-      for (int32_t j = 0; j < len; j++)
-        if (ind[ptr[r] + j] - (int32_t)r != ind[ptr[q] + j] - (int32_t)q || std::memcmp(&val[ptr[r] + j], &val[ptr[q] + j], sizeof(T)) != 0) return false;
+  // distinct signatures and the first row of each (per sub-range, merged), numbered in row order; then every row looks its number
+  // up and is compared with the first row of its pattern, entry by entry (equal signatures of different rows: the matrix stays CSR)
+  std::unordered_map<uint64_t, size_t> first;
+  std::mutex merge;
+  std::atomic<bool> ok(true);
+  ParallelFor(nrows, [&](size_t lo, size_t hi) {
+    std::unordered_map<uint64_t, size_t> local;
+    for (size_t r = lo; r < hi && ok.load(std::memory_order_relaxed); r++) {
+      if (local.emplace(sig[r], r).second && local.size() > kMaxPatterns) ok = false;
     }
-    out.ids[r] = (uint16_t)it->second;
+    std::lock_guard<std::mutex> g(merge);
+    for (const auto& kv : local) { auto it = first.emplace(kv.first, kv.second).first; if (kv.second < it->second) it->second = kv.second; }
+  });
+  if (!ok || first.size() > kMaxPatterns) return false;
+  std::vector<std::pair<size_t, uint64_t>> order;
+  order.reserve(first.size());
+  for (const auto& kv : first) order.emplace_back(kv.second, kv.first);
+  std::sort(order.begin(), order.end());
+  std::unordered_map<uint64_t, uint32_t> number;
+  std::vector<size_t> rep(order.size());
+  out.pptr.assign(1, 0); out.rel.clear(); out.val.clear();
+  for (size_t k = 0; k < order.size(); k++) {
+    const size_t r = order[k].first;
+    number.emplace(order[k].second, (uint32_t)k);
+    rep[k] = r;
+    for (int32_t j = ptr[r]; j < ptr[r + 1]; j++) { out.rel.push_back(ind[j] - (int32_t)r); out.val.push_back(val[j]); }
+    out.pptr.push_back((int32_t)out.rel.size());
+    if (out.rel.size() > kMaxTable) return false;
   }
+  out.ids.assign((nrows + 3) / 4 * 4, 0);
+  ParallelFor(nrows, [&](size_t lo, size_t hi) {
+    for (size_t r = lo; r < hi; r++) {
+      const uint32_t id = number.find(sig[r])->second;
+      const size_t q = rep[id];
+      const int32_t len = ptr[r + 1] - ptr[r];
+      bool same = len == ptr[q + 1] - ptr[q];
+      for (int32_t j = 0; same && j < len; j++)
+        same = ind[ptr[r] + j] - (int32_t)r == ind[ptr[q] + j] - (int32_t)q && std::memcmp(&val[ptr[r] + j], &val[ptr[q] + j], sizeof(T)) == 0;
+      if (!same) { ok = false; return; }
+      out.ids[r] = (uint16_t)id;
+    }
+  });
+  if (!ok) return false;
   return true;
 }
 }  // namespace
