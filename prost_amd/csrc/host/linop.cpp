@@ -114,6 +114,7 @@ bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::
     out.pptr.push_back((int32_t)out.rel.size());
     if (out.rel.size() > kMaxTable) return false;
   }
+  if (out.rel.empty()) return false;                                  // a matrix without entries: nothing to tabulate
   out.ids.assign((nrows + 3) / 4 * 4, 0);
   ParallelFor(nrows, [&](size_t lo, size_t hi) {
     for (size_t r = lo; r < hi; r++) {

@@ -971,3 +971,25 @@ def test_stencils_written_out_as_sparse_matrices_run_from_row_patterns(precision
                 assert np.allclose(a, b_, rtol=0, atol=1e-5 if dtype == np.float32 else 1e-13) if long_rows else np.array_equal(a, b_), (name, tr)
     finally:
         prost.set_quirks(sparse_patterns=1)
+
+
+def test_sparse_blocks_without_entries_and_with_empty_rows():
+    """edge cases of the row-pattern recognition: a block.sparse of a matrix without a single entry (no table to build: stays CSR), and a
+    large stencil matrix most of whose rows are empty (one pattern of length zero beside the others)"""
+    prost.set_precision("double")
+    n = 600
+    rhs = np.linspace(-1, 1, n)
+    empty = sp.csc_matrix((n, n))
+    got = np.asarray(prost.eval_linop(prost.block.sparse(empty)(0, 0, n, n)[0:1], rhs, False)[0]).ravel()
+    assert np.array_equal(got, np.zeros(n))
+    K = sp.lil_matrix((n, n))
+    for r in range(0, n, 7):
+        K[r, r] = 2.0
+        if r + 3 < n:
+            K[r, r + 3] = -0.5
+    K = sp.csc_matrix(K)
+    lin = prost.block.sparse(K)(0, 0, n, n)[0:1]
+    for tr in (False, True):
+        got = np.asarray(prost.eval_linop(lin, rhs, tr)[0]).ravel()
+        assert np.array_equal(got, oracle.eval_linop(lin, rhs, tr, np.float64)[0].ravel()), tr
+        assert np.allclose(got, (K.T if tr else K) @ rhs, rtol=0, atol=1e-15)
