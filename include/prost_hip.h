@@ -394,8 +394,8 @@ int prost_hip_fused_iteration3d_x2_f64(const prost_hip_fused_desc* desc, double*
 /* ONE kernel per iteration for gradient2d problems with L = 3 or 4 channels (kernels_fused_iter_mc.hip): the channels
  * run on the wavefronts of one workgroup and meet in LDS for the norm over the 2 L gradient components of a pixel
  * (sum_norm2(2 * nc, ...) of example_rof_primaldual.m).  Same contract as prost_hip_fused_iteration3d (incl. the
- * residual variant: y_prev, res_out4, workspace): outputs must not alias inputs, ny a multiple of the vector width,
- * scalar coefficients except b of prox_g. */
+ * residual variant: y_prev, res_out4, workspace): outputs must not alias inputs, scalar coefficients except b of prox_g;
+ * heights that are not a whole number of 16-byte row groups run a one-row-per-lane instance. */
 int prost_hip_fused_iteration_mc_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
 int prost_hip_fused_iteration_mc_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
                                      double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,

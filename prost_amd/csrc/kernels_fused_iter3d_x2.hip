@@ -446,7 +446,7 @@ static int compute_units() {
   return n;
 }
 
-// One workgroup per compute unit is resident (16 wavefronts x 126 VGPRs) and all workgroups take equally long, so a launch lasts
+// One workgroup per compute unit is resident (16 wavefronts x 121-128 VGPRs) and all workgroups take equally long, so a launch lasts
 // (rounds of workgroups) x (column steps of a workgroup): pick the number of column chunks that minimises
 // ceil(strips * groups * chunks / CUs) * (columns per chunk + 4 warm-up steps).  2048 x 2048 x 64 on 256 CUs: 17 x 5 x 3 = 255
 // workgroups, ONE round of 687 steps (64-column chunks: 11 rounds of 68 steps = 748).
