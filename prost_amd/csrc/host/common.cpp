@@ -104,9 +104,57 @@ template std::list<double> linspace<size_t>(size_t, size_t, int);
 template std::list<double> linspace<int>(int, int, int);
 
 // ---- CSR (n x m) -> CSC by counting sort on the column index (reference src/common.cu:55-82) ----
+// Large matrices: the rows are cut into sub-ranges that are counted and scattered on all host cores.  A sub-range of a banded
+// matrix (the stencils and warps this is used for) touches a narrow column range, so its private counters are small; a matrix whose
+// sub-ranges together span more than four times the columns takes the sequential sort below.  Entries of a column keep the order
+// of their rows either way (the sort is stable), so both forms produce the same arrays.
+template <typename T>
+static bool csr2csc_parallel(int n, int m, int nz, const T* a, const int32_t* col_idx, const int32_t* row_start, T* csc_a, int32_t* row_idx,
+                             int32_t* col_start) {
+  const size_t parts = ParallelChunks((size_t)n);
+  if (nz < (1 << 22) || parts < 2) return false;
+  struct Part { size_t r0 = 0, r1 = 0; int32_t cmin = 0, cmax = -1; std::vector<int32_t> cnt; };
+  std::vector<Part> part(parts);
+  for (size_t t = 0; t < parts; t++) ParallelChunkRange((size_t)n, t, part[t].r0, part[t].r1);
+  // (ParallelFor(n, ...) hands out exactly these sub-ranges: the one that starts at `lo` is found by its first row)
+  auto part_of = [&](size_t lo) -> Part& { for (Part& p : part) if (p.r0 == lo) return p; return part[0]; };
+  ParallelFor((size_t)n, [&](size_t lo, size_t) {
+    Part& p = part_of(lo);
+    int32_t cmin = m, cmax = -1;
+    for (int32_t j = row_start[p.r0]; j < row_start[p.r1]; j++) { cmin = std::min(cmin, col_idx[j]); cmax = std::max(cmax, col_idx[j]); }
+    p.cmin = cmin; p.cmax = cmax;
+  });
+  size_t span = 0;
+  for (const Part& p : part) if (p.cmax >= p.cmin) span += (size_t)(p.cmax - p.cmin + 1);
+  if (span > 4 * (size_t)m + 1024) return false;
+  ParallelFor((size_t)n, [&](size_t lo, size_t) {
+    Part& p = part_of(lo);
+    if (p.cmax < p.cmin) return;
+    p.cnt.assign((size_t)(p.cmax - p.cmin + 1), 0);
+    for (int32_t j = row_start[p.r0]; j < row_start[p.r1]; j++) p.cnt[col_idx[j] - p.cmin]++;
+  });
+  // column starts, and for every sub-range the position of its first entry of every column it touches (cnt is reused for that)
+  std::vector<int32_t> run(m + 1, 0);
+  for (const Part& p : part) for (size_t k = 0; k < p.cnt.size(); k++) run[p.cmin + k + 1] += p.cnt[k];
+  for (int c = 0; c < m; c++) run[c + 1] += run[c];
+  for (int c = 0; c <= m; c++) col_start[c] = run[c];
+  for (Part& p : part) for (size_t k = 0; k < p.cnt.size(); k++) { const int32_t c = p.cnt[k]; p.cnt[k] = run[p.cmin + k]; run[p.cmin + k] += c; }
+  ParallelFor((size_t)n, [&](size_t lo, size_t) {
+    Part& p = part_of(lo);
+    for (size_t r = p.r0; r < p.r1; r++)
+      for (int32_t j = row_start[r]; j < row_start[r + 1]; j++) {
+        const int32_t dst = p.cnt[col_idx[j] - p.cmin]++;
+        row_idx[dst] = (int32_t)r;
+        if (a) csc_a[dst] = a[j];
+      }
+  });
+  (void)nz;
+  return true;
+}
 template <typename T>
 void csr2csc(int n, int m, int nz, const T* a, const int32_t* col_idx, const int32_t* row_start, T* csc_a,
              int32_t* row_idx, int32_t* col_start) {
+  if (csr2csc_parallel<T>(n, m, nz, a, col_idx, row_start, csc_a, row_idx, col_start)) return;
   std::vector<int32_t> fill(m + 1, 0);
   for (int i = 0; i < nz; i++) fill[col_idx[i] + 1]++;
   for (int c = 0; c < m; c++) fill[c + 1] += fill[c];

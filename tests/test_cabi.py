@@ -289,3 +289,34 @@ def test_support_predicates_and_launch_geometry_of_the_double_iteration_kernels(
     assert L.prost_hip_fused_supported(C.byref(desc(1, 64, 4096, 513)), 0) == 0
     assert L.prost_hip_fused_supported(C.byref(desc(1, 64, 4096, 2049)), 0) == 0
     assert L.prost_hip_fused_iteration3d_x2_supported(C.byref(desc(1, 64, 4096, 2049)), 0) == 0
+
+
+def test_host_csr2csc_parallel_and_sequential_forms_agree_with_scipy():
+    """prost::csr2csc (host library; reference src/common.cu:55-82) straight through its C++ symbol: from 4 M entries on it counts and
+    scatters row sub-ranges on all host cores where they touch narrow column ranges (banded matrices) and runs the reference's
+    sequential counting sort otherwise -- arrays identical to scipy's sorted CSC in both forms.  (Matrices built from COO triplets:
+    scipy.sparse.random with a legacy seed permutes rows x columns positions, 13 TiB at these shapes.)"""
+    import ctypes as C
+    import scipy.sparse as sp
+    from reference_matrices import spmat_gradient2d
+    lib = C.CDLL(os.path.join(ROOT, "prost_amd", "lib", "libprost.so"), mode=C.RTLD_GLOBAL)
+    f = getattr(lib, "_ZN5prost7csr2cscIdEEviiiPKT_PKiS5_PS1_PiS7_")
+    f.restype = None
+    rng = np.random.default_rng(1)
+
+    def check(A):
+        A = sp.csr_matrix(A); A.sort_indices()
+        n, m = A.shape
+        val, ind, ptr = (np.ascontiguousarray(A.data, dtype=np.float64), np.ascontiguousarray(A.indices, dtype=np.int32), np.ascontiguousarray(A.indptr, dtype=np.int32))
+        oval, oind, optr = np.zeros(A.nnz), np.zeros(A.nnz, dtype=np.int32), np.zeros(m + 1, dtype=np.int32)
+        f(C.c_int(n), C.c_int(m), C.c_int(A.nnz), *[a.ctypes.data_as(C.c_void_p) for a in (val, ind, ptr, oval, oind, optr)])
+        B = sp.csc_matrix(A); B.sort_indices()
+        assert np.array_equal(optr, B.indptr) and np.array_equal(oind, B.indices) and np.array_equal(oval, B.data)
+
+    band = sp.csr_matrix(spmat_gradient2d(1100, 1100, 1))
+    band.data = band.data * rng.uniform(0.5, 1.5, band.nnz)
+    check(band); check(band.T)                                                   # parallel form (narrow column ranges)
+    nz = 4_500_000
+    check(sp.coo_matrix((rng.uniform(-1, 1, nz), (rng.integers(0, 1_500_000, nz), rng.integers(0, 1_200_000, nz))), shape=(1_500_000, 1_200_000)))   # sequential form
+    check(sp.coo_matrix((rng.uniform(-1, 1, nz), (rng.integers(0, 30, nz) * 40000 + rng.integers(0, 3, nz), rng.integers(0, 900_000, nz))), shape=(1_300_000, 900_000)))  # empty rows, dense stripes
+    check(sp.random(300, 200, density=0.05, random_state=1))                     # small: sequential

@@ -993,3 +993,26 @@ def test_sparse_blocks_without_entries_and_with_empty_rows():
         got = np.asarray(prost.eval_linop(lin, rhs, tr)[0]).ravel()
         assert np.array_equal(got, oracle.eval_linop(lin, rhs, tr, np.float64)[0].ravel()), tr
         assert np.allclose(got, (K.T if tr else K) @ rhs, rtol=0, atol=1e-15)
+
+
+def test_large_sparse_blocks_transposed_on_all_host_cores():
+    """BlockSparse::CreateFromCSC transposes the CSC arrays it is handed (csr2csc, reference src/common.cu:55-82).  From 4 M entries on
+    the counting sort runs on all host cores where the row sub-ranges touch narrow column ranges (banded matrices: stencils, warps) and
+    sequentially otherwise (an unstructured matrix): both against the oracle's sequential transposition, through the forward product
+    (which reads the transposed arrays) and the preconditioner sums."""
+    prost.set_precision("double")
+    rng = np.random.default_rng(3)
+    n = 1100
+    band = sp.csc_matrix(spmat_gradient2d(n, n, 1))
+    band.data = band.data * rng.uniform(0.5, 1.5, band.nnz)          # per-entry values: no row patterns, the CSR arrays themselves are applied
+    # (NOT scipy.sparse.random: with a legacy seed it draws the positions through a permutation of all rows x columns -- 13 TiB here)
+    nnz_r = 5_000_000
+    rand = sp.coo_matrix((rng.uniform(-1, 1, nnz_r), (rng.integers(0, 1_500_000, nnz_r), rng.integers(0, 1_200_000, nnz_r))), shape=(1_500_000, 1_200_000)).tocsc()
+    for name, K in (("banded", band), ("unstructured", rand)):
+        assert K.nnz > (1 << 22), (name, K.nnz)
+        lin = prost.block.sparse(K)(0, 0, K.shape[0], K.shape[1])[0:1]
+        rhs = rng.uniform(-1, 1, K.shape[1])
+        got, rowsum, colsum, _ = prost.eval_linop(lin, rhs, False)
+        want, orow, ocol = oracle.eval_linop(lin, rhs, False, np.float64)
+        assert np.array_equal(np.asarray(got).ravel(), want.ravel()), name
+        assert np.array_equal(np.asarray(rowsum).ravel(), orow.ravel()) and np.array_equal(np.asarray(colsum).ravel(), ocol.ravel()), name
