@@ -60,6 +60,9 @@ class BlockSparse : public Block<T> {
   /// arrays in MATLAB CSC form: ptr = Jc (ncols+1), ind = Ir (nnz) (block_sparse.cu:34-68)
   static BlockSparse<T>* CreateFromCSC(size_t row, size_t col, int m, int n, int nnz, const std::vector<T>& val,
                                        const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind);
+  /// the same, taking the arrays over instead of copying them (a 4096^2 gradient handed over as a matrix: 0.8 GB)
+  static BlockSparse<T>* CreateFromCSC(size_t row, size_t col, int m, int n, int nnz, std::vector<T>&& val, std::vector<int32_t>&& ptr,
+                                       std::vector<int32_t>&& ind);
   virtual void Initialize();
   virtual void Release();
   virtual T row_sum(size_t row, T alpha) const;

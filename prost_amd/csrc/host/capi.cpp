@@ -293,9 +293,12 @@ std::map<std::string, typename Factory<T>::BlockFactory>& Factory<T>::block_reg(
       const prost_value* pm = cell_at(d, 0);
       if (pm->kind != PROST_VALUE_SPARSE) throw Exception("Matrix must be sparse!");
       const int nrows = (int)pm->rows, ncols = (int)pm->cols, nnz = (int)pm->jc[ncols];
-      std::vector<T> val(pm->data.begin(), pm->data.begin() + nnz);
-      std::vector<int32_t> ptr(pm->jc.begin(), pm->jc.end()), ind(pm->ir.begin(), pm->ir.begin() + nnz);   // int64 -> int32 narrowing as the reference
-      return BlockSparse<T>::CreateFromCSC(row, col, nrows, ncols, nnz, val, ptr, ind);
+      // double -> T and int64 -> int32 (narrowing as the reference) on all host cores, the arrays handed over without another copy
+      std::vector<T> val((size_t)nnz);
+      std::vector<int32_t> ptr(pm->jc.begin(), pm->jc.end()), ind((size_t)nnz);
+      const double* src_v = pm->data.data(); const int64_t* src_i = pm->ir.data();
+      ParallelFor((size_t)nnz, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) { val[k] = (T)src_v[k]; ind[k] = (int32_t)src_i[k]; } });
+      return BlockSparse<T>::CreateFromCSC(row, col, nrows, ncols, nnz, std::move(val), std::move(ptr), std::move(ind));
     };
     for (int id_first = 0; id_first < 2; id_first++)                                          // factory.cpp:657-755
       reg[id_first ? "id_kron_sparse" : "sparse_kron_id"] = [id_first](size_t row, size_t col, const prost_value* d) -> Block<T>* {

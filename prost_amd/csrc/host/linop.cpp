@@ -45,10 +45,15 @@ GRAD_IMPL(BlockGradient3D, grad3d_fwd, grad3d_adj, 6)
 template <typename T>
 BlockSparse<T>* BlockSparse<T>::CreateFromCSC(size_t row, size_t col, int m, int n, int nnz, const std::vector<T>& val,
                                               const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind) {
+  return CreateFromCSC(row, col, m, n, nnz, std::vector<T>(val), std::vector<int32_t>(ptr), std::vector<int32_t>(ind));
+}
+template <typename T>
+BlockSparse<T>* BlockSparse<T>::CreateFromCSC(size_t row, size_t col, int m, int n, int nnz, std::vector<T>&& val, std::vector<int32_t>&& ptr,
+                                              std::vector<int32_t>&& ind) {
   BlockSparse<T>* b = new BlockSparse<T>(row, col, m, n);
   b->nnz_ = nnz;
   // the CSC arrays of K are the CSR arrays of K^T; K itself in CSR comes from one transposition
-  b->host_ind_t_ = ind; b->host_ptr_t_ = ptr; b->host_val_t_ = val;
+  b->host_ind_t_ = std::move(ind); b->host_ptr_t_ = std::move(ptr); b->host_val_t_ = std::move(val);
   b->host_ind_.resize(nnz); b->host_val_.resize(nnz); b->host_ptr_.resize(m + 1);
   csr2csc<T>(n, m, nnz, b->host_val_t_.data(), b->host_ind_t_.data(), b->host_ptr_t_.data(), b->host_val_.data(),
              b->host_ind_.data(), b->host_ptr_.data());

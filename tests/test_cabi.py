@@ -299,7 +299,8 @@ def test_host_csr2csc_parallel_and_sequential_forms_agree_with_scipy():
     import ctypes as C
     import scipy.sparse as sp
     from reference_matrices import spmat_gradient2d
-    lib = C.CDLL(os.path.join(ROOT, "prost_amd", "lib", "libprost.so"), mode=C.RTLD_GLOBAL)
+    # (loaded with local symbol scope: the real reference build of tests/test_oracle_pinning.py defines the same C++ names)
+    lib = C.CDLL(os.path.join(ROOT, "prost_amd", "lib", "libprost.so"))
     f = getattr(lib, "_ZN5prost7csr2cscIdEEviiiPKT_PKiS5_PS1_PiS7_")
     f.restype = None
     rng = np.random.default_rng(1)
