@@ -29,15 +29,22 @@ Before the W warm-up steps an untimed clock-ramp prelude runs 1500 of the same i
 driver's `--steps 20 --warmup 5` would otherwise measure the ramp.  The JSON line carries
   roofline     : dominant kernel = fused_iter2d_x2_kernel, one launch = TWO whole iterations with the
                  iterate in between kept in registers.
-                 `achieved` / `frac`: ALGORITHMIC bytes (2 x 11 floats/pixel) / mean launch time
-                 measured with HIP events on the solver's stream inside the timed region.  The kernel moves
-                 only 7 floats/pixel per launch, so this figure can exceed 1: it is measured against what the
-                 reference's two-pass algorithm must move, not against what this kernel moves.
+                 `achieved` / `frac`: COMPULSORY bytes of the kernel that ran -- every operand it has to read or
+                 write once: 7 floats/pixel per two-iteration launch (read x, f, y1, y2; write x, y1, y2), 9 per
+                 voxel in 3-D -- / mean launch time measured with HIP events on the solver's stream inside the
+                 timed region / 8 TB/s: a fraction in (0, 1] by construction.
                  `traffic` / `frac_hbm_traffic`: the PHYSICAL figure -- HBM bytes per launch from the PMC
                  counters (profiles/traffic_table.json: FETCH_SIZE doubled per MI355X_MICROARCH.md +
-                 WRITE_SIZE, separate --pmc passes), looked up by kernel instance, image size and chunk
-                 length of the launch that was timed (null if that geometry was never profiled), divided by
-                 the same launch time and the 8 TB/s peak.
+                 WRITE_SIZE, separate --pmc passes), looked up by kernel instance, precision, image size and
+                 chunk length of the launch that was timed (null if that geometry was never profiled), divided
+                 by the same launch time and the peak.  traffic / compulsory = the kernel's over-fetch.
+                 `algorithmic_equiv_frac`: SURVEY 8(d)'s two-pass byte model (11 floats/pixel/iteration x the
+                 iterations of the launch) over the same time and peak.  It exceeds 1: the launch keeps the
+                 iterate between its two iterations on chip, so the two-pass model is no lower bound for it;
+                 it says how fast a two-pass implementation would have to stream to keep up.
+                 Runs of <= 40 steps stamp EVERY launch (launches_timed >= 8 at the driver's --steps 20); a
+                 stamped launch does not overlap its neighbours, which costs such a run ~4 % of `value`
+                 (`iterate_only_it_per_s` is measured without stamps).
   cpu_baseline : the CPU oracle (port of the reference path) timed on this host's cores on a bounded
                  sample of the same workload; `reference_build` = the REAL reference's CPU build
                  (oracle/_ref, single-threaded thrust host backend) timed beside the port at 1024^2
@@ -59,19 +66,36 @@ HBM_PEAK_GBPS = 8000.0
 TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "traffic_table.json")
 
 
-def traffic_bytes(kernel, size, chunk_cols):
+def traffic_bytes(kernel, size, chunk_cols, dtype="f32"):
     """HBM bytes per launch of `kernel` (name as KernelTimes reports it) at image side `size` with `chunk_cols` columns
     per wavefront, from the PMC passes recorded in profiles/traffic_table.json (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md + WRITE_SIZE, KiB).  None when this launch geometry was never profiled."""
+    MI355X_MICROARCH.md + WRITE_SIZE, KiB; rows without a "dtype" are fp32).  None when this launch geometry was never profiled."""
     try:
         with open(TRAFFIC_TABLE) as fh:
             rows = json.load(fh)["launches"]
     except (OSError, ValueError, KeyError):
         return None, None
     for r in rows:
-        if r["kernel"] == kernel and r["size"] == size and r["chunk_cols"] == chunk_cols:
+        if r["kernel"] == kernel and r["size"] == size and r["chunk_cols"] == chunk_cols and r.get("dtype", "f32") == dtype:
             return (2 * r["fetch_size_kib"] + r["write_size_kib"]) * 1024, r.get("source")
     return None, None
+
+
+def compulsory_floats(kname, volume):
+    """values per pixel / voxel a launch of `kname` (as KernelTimes names it) has to move through HBM once: operands read
+    + results written ("algorithmic bytes / unit" column)"""
+    g = 3 if volume else 2                                   # gradient components = dual values per pixel
+    pair = 2 + 2 * g + 1                                     # read x, f, y ; write x, y : 7 / 9
+    table = {"x2_kernel": pair, "x2_kernel+residuals": pair, "x2_kernel+mid": pair + 1 + g, "x2_kernel+mid+residuals": pair + 1 + g,
+             "kernel": pair, "kernel+residuals": pair + g + (1 if volume else 0)}        # residual single launch: + y_prev (+ x_prev in 3-D)
+    if "primal" in kname:
+        return 3 + g                                         # read x, y, f ; write x : 5 / 6
+    if "dual" in kname:
+        return 2 + 2 * g                                     # read y, x_new, x_old ; write y : 6 / 8
+    for suffix, v in sorted(table.items(), key=lambda kv: -len(kv[0])):
+        if kname.endswith(suffix):
+            return v
+    return None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -102,7 +126,7 @@ def c4_problem(N):
     return prob
 
 
-def make_config(name, size, volume, seed):
+def make_config(name, size, volume, seed, fp="fp32"):
     """-> dict(prob, backend, metric, workload, units (pixels / voxels of one problem), alg_floats_per_unit (per iteration; None where
     SURVEY 8d defines no per-iteration figure), size_key (traffic-table key), prelude (default clock-ramp iterations))"""
     import prost_amd as prost
@@ -110,7 +134,7 @@ def make_config(name, size, volume, seed):
     if name == "c2":
         prob, u, q, f = synthetic.rof_problem(size, size, lmb=LAMBDA, seed=seed)
         return dict(prob=prob, backend=prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA),
-                    metric="PDHG iters/sec, ROF-TV %d^2 fp32" % size, units=size * size, alg_floats_per_unit=ALG_FLOATS_PER_PIXEL, size_key=size,
+                    metric="PDHG iters/sec, ROF-TV %d^2 %s" % (size, fp), units=size * size, alg_floats_per_unit=ALG_FLOATS_PER_PIXEL, size_key=size,
                     workload="ROF-TV denoising %dx%d grayscale (gradient2d + sum_1d square + sum_norm2 ind_leq0), PDHG alg2, residual_iter=10, "
                              "lambda=10; one independent problem per GPU" % (size, size), prelude=1500,
                     tiny=lambda: synthetic.rof_problem(64, 64, lmb=LAMBDA, seed=1)[0])
@@ -118,12 +142,12 @@ def make_config(name, size, volume, seed):
         nx, ny, L = volume
         prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, lmb=LAMBDA, seed=seed)
         return dict(prob=prob, backend=prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA),
-                    metric="PDHG iters/sec, TV-3D %dx%dx%d fp32" % (nx, ny, L), units=nx * ny * L, alg_floats_per_unit=14, size_key="%dx%dx%d" % (nx, ny, L),
+                    metric="PDHG iters/sec, TV-3D %dx%dx%d %s" % (nx, ny, L, fp), units=nx * ny * L, alg_floats_per_unit=14, size_key="%dx%dx%d" % (nx, ny, L),
                     workload="volumetric TV %dx%dx%d (gradient3d + sum_1d square + sum_norm2(3) ind_leq0), PDHG alg2, residual_iter=10, lambda=10; "
                              "one independent problem per GPU" % (nx, ny, L), prelude=60,
                     tiny=lambda: synthetic.tv3d_problem(32, 32, 8, lmb=LAMBDA, seed=1)[0])
     if name == "c4":
-        return dict(prob=c4_problem(size), backend=prost.backend.admm(rho0=1), metric="ADMM iters/sec, TV-L1 flow-like %d^2 fp32" % size,
+        return dict(prob=c4_problem(size), backend=prost.backend.admm(rho0=1), metric="ADMM iters/sec, TV-L1 flow-like %d^2 %s" % (size, fp),
                     units=size * size, alg_floats_per_unit=None, size_key=size,
                     workload="TV-L1 flow-like %dx%d (block.sparse W = [diag(Ix) diag(Iy)] + gradient2d L=2, sum_1d abs + sum_norm2(4) abs), ADMM rho0=1 with the "
                              "reference defaults (cg_max_iter=10, residual_iter=1); a step = one ADMM iteration = one graph projection (CGLS) + two proxes; "
@@ -147,7 +171,7 @@ def c4_kernel_bytes(kname, n_px, itemsize=4):
     return None
 
 
-def cpu_baseline_c3(volume, max_threads):
+def cpu_baseline_c3(volume, max_threads, np_dtype=None):
     """oracle (OpenMP port of the reference path) on a CROP of the volume: 256 x 256 x L voxels of the same synthetic data generator, the
     same backend options (scale_steps_operator off: the port's power iteration alone would take a minute; for gradient operators the
     rescale never fires), about 10 s of iterations; reported in voxel-iterations/s and as the equivalent full-volume rate"""
@@ -164,7 +188,7 @@ def cpu_baseline_c3(volume, max_threads):
     opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
     threads = min(16, max_threads)
     oracle.set_num_threads(threads)
-    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np.float32)
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np_dtype or np.float32)
     s.initialize()
     s.iterate(2)
     iters, t0 = 0, time.time()
@@ -181,7 +205,7 @@ def cpu_baseline_c3(volume, max_threads):
                       "threads; value = the crop's voxel-iteration rate divided by the %dx%dx%d voxels of the full volume" % (iters, cx, cy, L, threads, nx, ny, L)}
 
 
-def cpu_baseline_c4(size, backend, max_threads):
+def cpu_baseline_c4(size, backend, max_threads, np_dtype=None):
     """oracle ADMM (restatement of backend_admm.cu + cgls.hpp; parity-unpinned by the reference) on the SAME problem,
     about 10 s of outer iterations"""
     import numpy as np
@@ -193,7 +217,7 @@ def cpu_baseline_c4(size, backend, max_threads):
     opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
     threads = min(16, max_threads)
     oracle.set_num_threads(threads)
-    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np.float32)
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np_dtype or np.float32)
     s.initialize()
     s.iterate(1)
     iters, t0 = 0, time.time()
@@ -208,7 +232,7 @@ def cpu_baseline_c4(size, backend, max_threads):
                       % (iters, size, size, threads)}
 
 
-def cpu_baseline(n_img, max_threads):
+def cpu_baseline(n_img, max_threads, np_dtype=None):
     """Oracle (CPU restatement of the reference path, OpenMP) on a bounded sample: the same 4096^2
     ROF problem, a handful of iterations (about 10-30 s of CPU work).  The thread count is the best
     of a short probe over {8, 16, 32, 64} <= cores: the path is memory-bound and over-subscribing
@@ -218,12 +242,14 @@ def cpu_baseline(n_img, max_threads):
     import oracle
     import prost_amd as prost
     from prost_amd import synthetic
+    np_dtype = np_dtype or np.float32
+    fp = "fp32" if np_dtype == np.float32 else "fp64"
     prob, u, q, f = synthetic.rof_problem(n_img, n_img, seed=42)
     prob.finalize()
     backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA)
     opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0,
                          tol_abs_primal=0, tol_abs_dual=0)
-    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np.float32)
+    s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np_dtype)
     s.initialize()
     best, best_rate = 1, 0.0
     for t in [c for c in (8, 16, 32, 64) if c <= max_threads] or [1]:
@@ -248,10 +274,10 @@ def cpu_baseline(n_img, max_threads):
     s.iterate(3)
     single = 3 / (time.time() - t1)
     out = {"value": iters / el, "unit": "it/s", "cores": best, "kind": "port", "single_thread_value": single,
-           "sample": "%d PDHG iterations of the same %dx%d fp32 ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads "
-                     "(best of a probe over 8/16/32/64 threads on %d logical cores)" % (iters, n_img, n_img, best, max_threads)}
+           "sample": "%d PDHG iterations of the same %dx%d %s ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads "
+                     "(best of a probe over 8/16/32/64 threads on %d logical cores)" % (iters, n_img, n_img, fp, best, max_threads)}
     del s
-    out["reference_build"] = reference_build_rate(backend, opts)
+    out["reference_build"] = reference_build_rate(backend, opts) if np_dtype == np.float32 else None
     return out
 
 
@@ -314,6 +340,8 @@ def launch_ranks(n_ranks):
         sys.stderr.write("\n".join(other) + "\n")
     if p.returncode != 0 or not lines:
         sys.stderr.write("bench.py: the %d-rank child job failed (exit code %d)\n" % (n_ranks, p.returncode))
+        if lines:                      # e.g. a run that fell back from RCCL: its line says "value": null and why
+            print(lines[-1], flush=True)
         raise SystemExit(p.returncode or 1)
     d = json.loads(lines[-1])
     if d.get("n_gpus") != n_ranks:
@@ -335,6 +363,11 @@ def main():
     ap.add_argument("--volume", type=int, nargs=3, default=[2048, 2048, 64], metavar=("NX", "NY", "L"), help="c3: the volume (default 2048 2048 64)")
     ap.add_argument("--prelude-iters", type=int, default=None, help="untimed clock-ramp prelude before the warm-up steps: this many of the same iterations (0: none; default ~100 ms worth)")
     ap.add_argument("--sample-every", type=int, default=0, help="bracket one launch in this many with HIP events (0: chosen from --steps)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic type: f32 = the BASELINE metric (default); f64 = the precision the "
+                    "reference front end ships with (config.hpp:7)")
+    ap.add_argument("--stepsize", default=None, choices=["alg1", "alg2", "goldstein", "boyd"], help="pdhg configs: step-size rule (default alg2, the "
+                    "example's; boyd with --residual-iter 1 = the reference's DEFAULT backend options, pdhg.m:4-14)")
+    ap.add_argument("--residual-iter", type=int, default=None, help="pdhg configs: residual_iter (default 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
     ap.add_argument("--no-pair", action="store_true", help="one kernel launch per iteration (allow_pair_kernel = false); not the default configuration")
@@ -383,19 +416,20 @@ def main():
         # PROST_BENCH_FORCE_DIST without a launcher: a one-rank rendezvous on the loopback interface
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
             os.environ.setdefault(k, v)
-        if host_transport:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # torch.distributed is only the RENDEZVOUS here -- it broadcasts the 128-byte ncclUniqueId, runs the barriers around the
+        # timed region and MAX-reduces three timing doubles, all on CPU tensors over gloo.  The ONLY RCCL communicator of a rank
+        # is the solver's own (prost.comm_init -> ncclCommInitRank), the one the residual all-reduce runs on and the one
+        # config.rccl_nranks counts.  (Round 3 created torch's nccl process group beside it: two communicators per rank.)
+        dist.init_process_group(backend="gloo")
 
     prost.set_gpu(local_rank)
-    prost.set_precision("single")
+    prost.set_precision("single" if args.dtype == "f32" else "double")
     rccl_fallback = False
     if host_transport:
         prost.comm_init_host(lambda a: dist.all_reduce(torch.from_numpy(a)), world)
     elif multi:
-        # RCCL communicator owned by the native solver: rank 0 creates the id, torch broadcasts it
-        ident = torch.zeros(128, dtype=torch.float64, device="cuda")
+        # RCCL communicator owned by the native solver: rank 0 creates the id, gloo broadcasts it
+        ident = torch.zeros(128, dtype=torch.float64)
         if rank == 0:
             ident.copy_(torch.from_numpy(prost.comm_unique_id()))
         dist.broadcast(ident, src=0)
@@ -403,28 +437,38 @@ def main():
         try:
             if failure:
                 raise RuntimeError(failure)
-            prost.comm_init(ident.cpu().numpy(), rank, world)
+            prost.comm_init(ident.numpy(), rank, world)
         except Exception as e:                                                # noqa: BLE001 -- whatever the native call raised is reported below
             failure = str(e)
-        failed = torch.tensor([1.0 if failure else 0.0], device="cuda")
+        failed = torch.tensor([1.0 if failure else 0.0])
         dist.all_reduce(failed)
         if failed.item() > 0:
-            # a second RCCL communicator beside torch's could not be set up on this node: the four residual sums still have to be
-            # global, so they go through the host-callback transport over a gloo group instead (16 bytes per residual check) --
-            # said loudly here and in the JSON line (config.residual_allreduce), never silently
+            # the RCCL communicator could not be set up on this node.  The run goes on over the host-callback transport (gloo, 32
+            # bytes per residual check) so that the log still shows where the job stands -- but it is NOT the configuration that
+            # was asked for: the JSON line then carries "value": null (the rate goes to "value_without_rccl") and
+            # "rccl_nranks": null, and the process exits non-zero.  PROST_BENCH_TRANSPORT=host asks for that transport
+            # explicitly (tests on one GPU).
             sys.stderr.write("bench.py: rank %d: native RCCL communicator failed (%s); residual all-reduce through the host-callback "
-                             "transport over gloo\n" % (rank, failure or "on another rank"))
+                             "transport over gloo -- this run does not count as an RCCL run\n" % (rank, failure or "on another rank"))
             prost.comm_destroy()
-            gloo = dist.new_group(backend="gloo")
-            prost.comm_init_host(lambda a: dist.all_reduce(torch.from_numpy(a), group=gloo), world)
+            prost.comm_init_host(lambda a: dist.all_reduce(torch.from_numpy(a)), world)
             rccl_fallback = True
     comm_info = prost.comm_info() if multi else {"nranks": 0, "transport": "none"}
     if multi and int(comm_info["nranks"]) != world:
         raise SystemExit("bench.py: the communicator counts %d ranks, WORLD_SIZE is %d" % (int(comm_info["nranks"]), world))
 
     n = args.size
-    cfg = make_config(args.config, args.size, tuple(args.volume), 42 + rank)
+    itemsize = 4 if args.dtype == "f32" else 8
+    cfg = make_config(args.config, args.size, tuple(args.volume), 42 + rank, "fp32" if args.dtype == "f32" else "fp64")
     prob, backend = cfg["prob"], cfg["backend"]
+    if args.stepsize is not None or args.residual_iter is not None:
+        if backend[0] != "pdhg":
+            raise SystemExit("bench.py: --stepsize / --residual-iter apply to the pdhg configs")
+        if args.stepsize is not None:
+            backend[1]["stepsize"] = args.stepsize
+        if args.residual_iter is not None:
+            backend[1]["residual_iter"] = args.residual_iter
+        cfg["workload"] = cfg["workload"].replace("PDHG alg2, residual_iter=10", "PDHG %s, residual_iter=%d" % (backend[1]["stepsize"], backend[1]["residual_iter"]))
     if args.no_pair:
         if backend[0] != "pdhg":
             raise SystemExit("bench.py: --no-pair applies to the pdhg configs")
@@ -450,10 +494,11 @@ def main():
     if prelude_iters > 0:
         solver.iterate(prelude_iters)
     prelude_ms = (time.perf_counter() - t_pre) * 1e3
-    # launches bracketed with events: a bracketed launch does not overlap its neighbours' ramp-up / drain (measured at --steps 20,
-    # same box: every launch 17 130 it/s, one in three 17 750, none 18 050), so runs of 16 .. 40 steps time one launch in three
-    # (3 samples of the dominant kernel at --steps 20), shorter ones every launch, long ones one in eight
-    every = args.sample_every or (1 if args.steps < 16 else 3 if args.steps <= 40 else 4 if args.steps <= 160 else 8)
+    # launches stamped with events (hipExtLaunchKernel: the kernel's own begin / end): a stamped launch does not overlap its
+    # neighbours' ramp-up / drain (measured at --steps 20, same box: every launch 17 130 it/s, one in three 17 750, none 18 050).
+    # Runs of <= 40 steps stamp EVERY launch all the same: the driver's --steps 20 is 10 launches, and a roofline fraction resting on
+    # three samples cannot resolve the spread between boxes (round-3 review); longer runs one in four / one in eight
+    every = args.sample_every or (1 if args.steps <= 40 else 4 if args.steps <= 160 else 8)
 
     solver.iterate(args.warmup, checked=True)
     barrier()
@@ -471,7 +516,7 @@ def main():
     # the timed region proper: the K iterations between the two stream synchronisations INSIDE the native command
     # (info["ms"]); `elapsed` additionally holds the Python -> C marshalling of the call on both sides (~35 us, 3 % of a
     # 20-step run) and is reported as wall_ms_python_side
-    t = torch.tensor([info["ms"] * 1e-3, elapsed_iterate, elapsed], dtype=torch.float64, device="cpu" if host_transport else "cuda")
+    t = torch.tensor([info["ms"] * 1e-3, elapsed_iterate, elapsed], dtype=torch.float64)          # CPU tensor: gloo
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, elapsed_iterate, elapsed_py = float(t[0].item()), float(t[1].item()), float(t[2].item())
@@ -490,10 +535,10 @@ def main():
     if rank == 0:
         value = world * args.steps / elapsed
         afu = cfg["alg_floats_per_unit"]
-        bytes_per_iter = afu * 4 * units if afu else None
+        bytes_per_iter = afu * itemsize * units if afu else None
         out = {
             "metric": cfg["metric"],
-            "value": value,
+            "value": None if rccl_fallback else value,
             "unit": "it/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -502,21 +547,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "path": path, "problems": world, "rccl_nranks": int(comm_info["nranks"]) if comm_info["transport"] == "rccl" else None,
                        "comm_nranks": int(comm_info["nranks"]), "residual_allreduce": "host-callback (gloo)" if host_transport else "host-callback (gloo) after the native RCCL communicator failed" if rccl_fallback else "rccl" if multi else "none",
+                       "rendezvous": "gloo (CPU tensors: unique id, barriers, timing reduction); the solver's communicator is the only RCCL communicator of a rank" if multi else "none",
+                       "stepsize": backend[1].get("stepsize"), "residual_iter": backend[1].get("residual_iter"),
                        "timed_loop": "Solver::IterateChecked = the loop of prost.solve (stopping test after every observable iteration; "
                                      "tolerances 0, so it never fires)"},
             "iterate_only_it_per_s": world * args.steps / elapsed_iterate,
             "wall_ms_python_side": 1e3 * elapsed_py,     # barrier -> command -> barrier as seen from Python
             "prelude_iterations": prelude_iters,
             "prelude_ms": prelude_ms,
+            # BASELINE's "achieved HBM GB/s" as SURVEY 8(d) defines it: it/s x the two-pass model's bytes per iteration (738.2 MB at
+            # 4096^2 fp32) -- an EQUIVALENT rate (what a two-pass implementation would have to stream), above the 8 TB/s peak for
+            # launches that block two iterations in time; the physical figures are roofline.frac / roofline.frac_hbm_traffic
             "achieved_hbm_GBps": value * bytes_per_iter / 1e9 if bytes_per_iter else None,
-            "hbm_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world) if bytes_per_iter else None,
+            "algorithmic_equiv_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world) if bytes_per_iter else None,
             "iterates_finite": finite,
         }
+        if rccl_fallback:
+            out["value_without_rccl"] = value
+            out["error"] = "the native RCCL communicator could not be created; the run used the host-callback transport over gloo and does not count"
         if args.config == "c4":
             out["cg_iterations_last_solve"] = st.get("cg_iterations")
         kern = info.get("kernels", {})
@@ -527,14 +580,17 @@ def main():
             ipl = k["iterations_per_launch"]
             if args.config == "c4":
                 # ADMM: the kernels of the CG round, each against its own compulsory bytes (generic kernels)
-                alg_bytes = c4_kernel_bytes(kname, units)
-                moves = alg_bytes
+                comp_bytes = c4_kernel_bytes(kname, units, itemsize)
+                alg_bytes = None
                 note = ("ADMM has no per-iteration byte figure in SURVEY 8d; frac = COMPULSORY bytes of the dominant kernel of the CG round (every operand read "
                         "or written once, CSR arrays included: %s) / its launch time / peak.  The working set of a solve (~160 MB at 1024^2) exceeds the 32 MB of "
                         "L2, so the round's kernels stream from HBM / Infinity Cache: the path is bandwidth-bound kernel by kernel, not launch-bound -- "
                         "profiles/r03_c4_admm_kernel_stats.csv shows the device busy back to back." % kname)
             else:
-                # algorithmic bytes per launch = SURVEY 8(d)'s floats/unit/iteration x the iterations one launch performs
+                unit_name = "pixel" if args.config == "c2" else "voxel"
+                cf = compulsory_floats(kname, args.config == "c3")
+                comp_bytes = cf * itemsize * units if cf else None
+                # SURVEY 8(d)'s two-pass model: floats/unit/iteration x the iterations one launch performs
                 # (two-pass kernels: the pass's own share, 5 primal / 6 dual of 11 in 2-D, 6 / 8 of 14 in 3-D)
                 if ipl:
                     floats = afu * ipl
@@ -542,39 +598,46 @@ def main():
                     floats = 8 if "dual" in kname else 6
                 else:
                     floats = DUAL_PASS_FLOATS if "dual" in kname else ALG_FLOATS_PER_PIXEL - DUAL_PASS_FLOATS
-                alg_bytes = floats * 4 * units
-                moves = (7 if args.config == "c2" else 9) * 4 * units if ipl else None
-                note = ("frac = ALGORITHMIC bytes (SURVEY 8d: %d floats/%s/iteration x %s iterations per launch) / launch time / peak; "
-                        "it exceeds 1 because one launch performs two iterations with the iterate in between kept in registers and "
-                        "physically moves %d floats per %s, not %d.  The physical HBM fraction is frac_hbm_traffic = PMC traffic "
-                        "(FETCH_SIZE x 2 + WRITE_SIZE) / launch time / peak.  That the work is done: bit-exact against the CPU oracle at this "
-                        "very size and launch geometry (tests/test_gpu_fullsize.py)."
-                        % (afu, "pixel" if args.config == "c2" else "voxel", ipl if ipl else "1/2", 7 if args.config == "c2" else 9,
-                           "pixel" if args.config == "c2" else "voxel", 2 * afu))
-            achieved = alg_bytes / 1e9 / (k["avg_ms"] * 1e-3) if alg_bytes else None
-            traffic, traffic_src = traffic_bytes(kname, cfg["size_key"], k["chunk_cols"])
-            phys = traffic / 1e9 / (k["avg_ms"] * 1e-3) if traffic else None
+                alg_bytes = floats * itemsize * units
+                note = ("frac = COMPULSORY bytes of the kernel that ran (%s values per %s per launch: every operand read once, every result written once; "
+                        "one launch = %s iteration(s), the iterate in between never leaves the registers) / launch time / peak: <= 1 by construction.  "
+                        "frac_hbm_traffic = the same with the PMC traffic (FETCH_SIZE x 2 + WRITE_SIZE) in place of the compulsory bytes; traffic / compulsory = "
+                        "the kernel's over-fetch (warm-up columns of a chunk, halo lanes).  algorithmic_equiv_frac = SURVEY 8d's two-pass model (%d values per %s "
+                        "and iteration x the iterations of the launch) over the same time: above 1 because the two-pass model is no lower bound for a launch "
+                        "that blocks two iterations in time.  That the work is done: bit-exact against the CPU oracle at this very size and launch geometry "
+                        "(tests/test_gpu_fullsize.py)." % (cf, unit_name, ipl if ipl else "1/2", afu, unit_name))
+            t_s = k["avg_ms"] * 1e-3
+            achieved = comp_bytes / 1e9 / t_s if comp_bytes else None
+            traffic, traffic_src = traffic_bytes(kname, cfg["size_key"], k["chunk_cols"], args.dtype)
+            phys = traffic / 1e9 / t_s if traffic else None
+            alg = alg_bytes / 1e9 / t_s if alg_bytes else None
             out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
                                "frac_hbm_traffic": phys / HBM_PEAK_GBPS if phys else None,
                                "achieved_hbm_traffic": phys, "traffic_source": traffic_src,
+                               "traffic_over_compulsory": traffic / comp_bytes if traffic and comp_bytes else None,
+                               "algorithmic_equiv_frac": alg / HBM_PEAK_GBPS if alg else None,
+                               "algorithmic_equiv_GBps": alg,
                                "note": note,
-                               "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k["avg_ms"],
+                               "compulsory_bytes_per_launch": comp_bytes, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k["avg_ms"],
                                "launches_timed": k["sampled"], "iterations_per_launch": ipl, "chunk_cols": k["chunk_cols"],
                                "sample_every": every,
-                               "kernel_moves_bytes_per_launch": moves,
                                "all_kernels": {name: {"avg_launch_ms": v["avg_ms"], "launches": v["launches"], "launches_timed": v["sampled"],
                                                       "iterations_per_launch": v["iterations_per_launch"], "chunk_cols": v["chunk_cols"],
-                                                      "compulsory_bytes": c4_kernel_bytes(name, units) if args.config == "c4" else None}
+                                                      "compulsory_bytes": c4_kernel_bytes(name, units, itemsize) if args.config == "c4"
+                                                      else (compulsory_floats(name, args.config == "c3") or 0) * itemsize * units or None}
                                                for name, v in kern.items()}}
+            if comp_bytes and ipl:
+                # whole-job rate x compulsory bytes per iteration of the dominant kernel / peak: <= roofline.frac (launch gaps, residual launches)
+                out["hbm_roofline_frac"] = (value / world) * (comp_bytes / ipl) / 1e9 / HBM_PEAK_GBPS
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
             if args.config == "c2":
-                out["cpu_baseline"] = cpu_baseline(n, threads)
+                out["cpu_baseline"] = cpu_baseline(n, threads, np.float32 if args.dtype == "f32" else np.float64)
             elif args.config == "c3":
-                out["cpu_baseline"] = cpu_baseline_c3(tuple(args.volume), threads)
+                out["cpu_baseline"] = cpu_baseline_c3(tuple(args.volume), threads, np.float32 if args.dtype == "f32" else np.float64)
             else:
-                out["cpu_baseline"] = cpu_baseline_c4(args.size, backend, threads)
+                out["cpu_baseline"] = cpu_baseline_c4(args.size, backend, threads, np.float32 if args.dtype == "f32" else np.float64)
     else:
         out = None
 
@@ -592,6 +655,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    if rccl_fallback:
+        raise SystemExit(3)          # every rank: the launcher (and through it a parent bench.py) reports the failure
 
 
 if __name__ == "__main__":

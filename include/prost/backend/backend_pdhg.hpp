@@ -154,6 +154,15 @@ class BackendPDHG : public Backend<T> {
   enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelPairMid, kKernelPairRes, kKernelPairMidRes, kKernelKinds };
   bool BeginSample(int kind);
   void EndSample(bool sampled);
+  /// a launch that threw between BeginSample and EndSample: the armed event pair is withdrawn (no later launch of this thread
+  /// takes it) and the sample that was never recorded is dropped
+  void AbortSample(bool sampled);
+  /// BeginSample / launch / EndSample with that clean-up on the exception path
+  template <class F> void TimedLaunch(int kind, F&& launch) {
+    const bool sampled = BeginSample(kind);
+    try { launch(); } catch (...) { AbortSample(sampled); throw; }
+    EndSample(sampled);
+  }
   static constexpr size_t kNoEvent = ~(size_t)0;
   static constexpr size_t kMaxSamples = 16384;
   struct Sample { int kind; size_t start, end; };   // indices into ev_

@@ -5,9 +5,11 @@
 // argument is the prost_value tree of include/prost_c.h instead of an mxArray.
 #ifndef PROST_FACTORY_HPP_
 #define PROST_FACTORY_HPP_
+#include <array>
 #include <functional>
 #include <map>
 #include <string>
+#include <vector>
 
 #include "prost/prost.hpp"
 #include "prost_c.h"
@@ -41,6 +43,24 @@ std::vector<double> GetVector(const prost_value* v);
 double GetScalarFromCell(const prost_value* cell, size_t index);
 double GetScalarFromField(const prost_value* s, const std::string& name);
 std::string GetString(const prost_value* v);
+/// element `index` of a cell array (mxGetCell with the bounds check of factory.cpp:238-246)
+inline const prost_value* GetCell(const prost_value* cell, size_t index) {
+  if (!cell || prost_value_kind(cell) != PROST_VALUE_CELL || index >= prost_value_count(cell) || !prost_value_cell_get(cell, index))
+    throw Exception("Out-of-bounds access into cell-array.");
+  return prost_value_cell_get(cell, index);
+}
+/// a cell array of COEFFS_COUNT vectors -> std::array of std::vector<T>, every entry 1 or `count` values (factory.cpp:196-216):
+/// the coefficient argument of ProxElemOperation<T, ELEM_OPERATION> (prox_elem_operation.hpp)
+template <typename T, size_t COEFFS_COUNT>
+void GetCoefficients(std::array<std::vector<T>, COEFFS_COUNT>& coeffs, const prost_value* cell_arr, size_t count) {
+  if (!cell_arr || prost_value_kind(cell_arr) != PROST_VALUE_CELL || prost_value_count(cell_arr) < COEFFS_COUNT)
+    throw Exception("Cell array of coefficients is too small.");
+  for (size_t i = 0; i < COEFFS_COUNT; i++) {
+    const std::vector<double> v = GetVector(prost_value_cell_get(cell_arr, i));
+    coeffs[i].assign(v.begin(), v.end());
+    if (coeffs[i].size() != 1 && coeffs[i].size() != count) throw Exception("Size of coefficients should be either 1 or count.");
+  }
+}
 
 }  // namespace prost
 #endif

@@ -11,11 +11,13 @@ namespace prost {
 /// The reference instantiates ProxElemOperation<T, ElemOperation1D|Norm2<T, Function1D*>> 176
 /// times (prox_elem_operation.cu:44-256); here the elem operation and the scalar function are
 /// run-time ids (PROST_OP_*, PROST_FN_* of prost_hip.h) dispatched wave-uniformly in one kernel.
+/// (The reference's template itself -- ProxElemOperation<T, ELEM_OPERATION> for user-written
+/// operations -- is prost/prox/prox_elem_operation.hpp.)
 template <typename T>
-class ProxElemOperation : public ProxSeparableSum<T> {
+class ProxElemDispatch : public ProxSeparableSum<T> {
  public:
   /// op: PROST_OP_1D (dim forced to 1, elem_operation_1d.hpp:30) or PROST_OP_NORM2
-  ProxElemOperation(int op, int fn, size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps,
+  ProxElemDispatch(int op, int fn, size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps,
                     const std::array<std::vector<T>, 7>& coeffs);
   virtual void Initialize();      // uploads per-element coefficient vectors (prox_elem_operation.inl:200-222)
   virtual void Release();

@@ -201,9 +201,23 @@ def _struct_fields(v, names, owner=None):
     return out
 
 
+# first exception raised inside a host-transport callback (they run on a HIP runtime thread, in stream order: ctypes can only
+# print an exception there).  The callback poisons what it was asked to produce (NaN sums / untouched halo bytes would otherwise
+# flow on silently) and the NEXT command raises it.
+_callback_error = []
+
+
+def _raise_callback_error():
+    if _callback_error:
+        e = _callback_error[0]
+        del _callback_error[:]
+        raise ProstError("host-transport callback failed: %s: %s" % (type(e).__name__, e)) from e
+
+
 def command(cmd, args=(), nlhs=0, struct_fields=None):
     """prost_(cmd, args...) -- returns a list of nlhs converted results."""
     L = lib()
+    _raise_callback_error()
     keep = []
     vals = [to_value(a, keep) for a in args]
     prhs = (C.c_void_p * max(len(vals), 1))(*vals)
@@ -211,7 +225,9 @@ def command(cmd, args=(), nlhs=0, struct_fields=None):
     try:
         rc = L.prost_command(cmd.encode(), nlhs, plhs, len(vals), prhs)
         if rc != 0:
+            del _callback_error[:]
             raise ProstError(L.prost_last_error().decode())
+        _raise_callback_error()            # (a callback that failed DURING this command: its results are not to be trusted)
         out = []
         for i in range(nlhs):
             if not plhs[i]:
@@ -425,15 +441,27 @@ def comm_init_host(allreduce, world, p2p=None):
     transfers of one halo exchange and returns when they are complete (gloo: isend / irecv on every entry, then wait) --
     what ncclSend / ncclRecv inside one group do on the RCCL transport (solver_halo_exchange, solver_iterate_sharded)."""
     def _cb(user, ptr, count, fn=allreduce):
-        fn(np.ctypeslib.as_array(ptr, (count,)))
+        a = np.ctypeslib.as_array(ptr, (count,))
+        try:
+            fn(a)
+        except BaseException as e:          # noqa: BLE001 -- a peer that died, a gloo timeout: must not vanish on the runtime thread
+            a[:] = np.nan                   # the global sums are not global: residuals (and every step size derived from them) become NaN
+            _callback_error.append(e)
     cb = ALLREDUCE_CB(_cb)
     _host_allreduce_keep.append(cb)
     if lib().prost_comm_init_host(cb, None, int(world)) != 0:
         raise ProstError(lib().prost_last_error().decode())
     if p2p is not None:
         def _p2p(user, nops, is_send, peers, bufs, nbytes, fn=p2p):
-            fn([(bool(is_send[i]), int(peers[i]), np.ctypeslib.as_array(C.cast(bufs[i], C.POINTER(C.c_uint8)), (nbytes[i],)))
-                for i in range(nops)])
+            ops = [(bool(is_send[i]), int(peers[i]), np.ctypeslib.as_array(C.cast(bufs[i], C.POINTER(C.c_uint8)), (nbytes[i],)))
+                   for i in range(nops)]
+            try:
+                fn(ops)
+            except BaseException as e:      # noqa: BLE001
+                for snd, _, buf in ops:     # halo columns that never arrived: NaN bit patterns instead of stale staging bytes
+                    if not snd:
+                        buf[:] = 0xFF
+                _callback_error.append(e)
         pcb = P2P_CB(_p2p)
         _host_allreduce_keep.append(pcb)
         if lib().prost_comm_set_host_p2p(pcb, None) != 0:

@@ -21,7 +21,7 @@ def gradient3d(nx, ny, L, label_first=False):
 
 def sparse(K):
     import scipy.sparse as sp
-    K = sp.csc_matrix(K, dtype=np.float64)
+    K = sp.csc_matrix(K, dtype=np.float64, copy=True)      # (copy: the two calls below work in place and K may BE the caller's matrix)
     K.eliminate_zeros()                 # a MATLAB sparse matrix holds no explicit zeros (scipy constructions such as diags / kron do)
     K.sort_indices()
     sz = [K.shape[0], K.shape[1]]
@@ -30,7 +30,7 @@ def sparse(K):
 
 def _kron(name, K, diaglength):
     import scipy.sparse as sp
-    K = sp.csc_matrix(K, dtype=np.float64)
+    K = sp.csc_matrix(K, dtype=np.float64, copy=True)
     K.eliminate_zeros()
     K.sort_indices()
     d = int(diaglength)

@@ -8,29 +8,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "prost/prox/elemop/function_1d.hpp"
 #include "prost_hip.h"
 
 namespace prost_hip {
 
-template <class T> __device__ __forceinline__ T t_abs(T v) { return v < 0 ? -v : v; }
-template <> __device__ __forceinline__ float t_abs<float>(float v) { return fabsf(v); }
-template <> __device__ __forceinline__ double t_abs<double>(double v) { return fabs(v); }
-__device__ __forceinline__ float t_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double t_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float t_sqrt(float v) { return sqrtf(v); }
-__device__ __forceinline__ double t_sqrt(double v) { return sqrt(v); }
-__device__ __forceinline__ float t_pow(float a, float b) { return powf(a, b); }
-__device__ __forceinline__ double t_pow(double a, double b) { return pow(a, b); }
-__device__ __forceinline__ float t_sin(float v) { return sinf(v); }
-__device__ __forceinline__ double t_sin(double v) { return sin(v); }
-__device__ __forceinline__ float t_cos(float v) { return cosf(v); }
-__device__ __forceinline__ double t_cos(double v) { return cos(v); }
-__device__ __forceinline__ float t_acos(float v) { return acosf(v); }
-__device__ __forceinline__ double t_acos(double v) { return acos(v); }
-
-// x / d with the exact shortcut for d == 1
-__device__ __forceinline__ double div1(double x, double d) { return d == 1.0 ? x : x / d; }
-__device__ __forceinline__ float div1(float x, float d) { return d == 1.0f ? x : x / d; }
+// t_abs / t_sqrt / t_pow ..., div1 and the scalar maps f1d_* live in the public header (plugin authors compose them too)
+using namespace prost::elemop;
 
 // ---- exact (float)((double)x / D) for a wave-uniform divisor D ------------------------------
 // The reference's fp32 build divides in double wherever a double literal appears (e.g.
@@ -257,59 +241,6 @@ __device__ __forceinline__ void norm2_leq0_fast(const T (&nv)[VEC], const T (&av
 }
 constexpr float kTinyIsZeroRadius = 9.5367431640625e-07f;     // 2^-20
 
-// ---- Function1D* (include/prost/prox/elemop/function_1d.hpp) --------------------------------
-template <class T> __device__ __forceinline__ T f1d_abs(T x0, T tau) {            // :47-60
-  if (x0 >= tau) return x0 - tau;
-  if (x0 <= -tau) return x0 + tau;
-  return (T)0;
-}
-template <class T> __device__ __forceinline__ T f1d_square(T x0, T tau) {         // :63-72
-  return (T)div1((double)x0, 1. + (double)tau);
-}
-template <class T> __device__ __forceinline__ T f1d_l0(T x0, T tau) {             // :146-158
-  return (x0 * x0 > 2 * tau) ? x0 : (T)0;
-}
-template <class T> __device__ inline T lq_newton(T t0, T alpha, T q, T eps) {     // :173-191
-  T t = t0, delta = 0;
-  int guard = 0;   // the reference loop has no bound; 200 Newton steps is far past convergence
-  do {
-    const T power = t_pow(t, q);
-    const T dF1 = t - 1 + alpha * q * power / t;
-    const T dF2 = 1 + alpha * q * (q - 1) * power / (t * t);
-    delta = dF1 / dF2;
-    t = t - delta;
-  } while (delta > eps && ++guard < 200);
-  return t;
-}
-template <class T> __device__ inline T lq_half(T alpha) {                          // :195-202
-  const T sqrt3 = t_sqrt((T)3);
-  const T PI_half = (T)1.5707963267948966192313216916397514420985846996875529;
-  const T s = 2 * (t_sin((T)((t_acos((T)(alpha * 3 * sqrt3 / 4)) + PI_half) / 3))) / sqrt3;
-  return s * s;
-}
-template <class T> __device__ __forceinline__ T lq_eps();
-template <> __device__ __forceinline__ float lq_eps<float>() { return (float)1e-5; }   // :263-267
-template <> __device__ __forceinline__ double lq_eps<double>() { return 1e-11; }        // :270-274
-
-template <class T> __device__ inline T f1d_lq(T x0, T tau, T alpha, T beta) {      // :205-260
-  if (alpha == 1) return f1d_abs(x0, tau);
-  if (alpha == 0) return f1d_l0(x0, tau);
-  T t = 0;
-  if (t_abs(x0) > 0) {
-    T factor = tau * t_pow(t_abs(x0), (T)(alpha - 2));
-    if (alpha < 1) {
-      const T t2 = 2 * (alpha - 1) / (alpha - 2);
-      if ((double)factor < 0.5 * (double)(1 - (t2 - 1) * (t2 - 1)) / (double)t_pow(t2, alpha)) {
-        if ((double)alpha == 0.5) t = lq_half<T>(factor);
-        else t = lq_newton<T>((T)1, factor, alpha, lq_eps<T>());
-      }
-    } else {
-      t = lq_newton<T>((T)1, factor, alpha, lq_eps<T>());
-    }
-  }
-  return t * t_abs(x0);
-}
-
 // fn is wave-uniform: a scalar branch, or resolved at compile time when FN >= 0
 template <class T, int FN = -1>
 __device__ __forceinline__ T f1d_apply(int fn_rt, T x0, T tau, T alpha, T beta) {
@@ -318,30 +249,17 @@ __device__ __forceinline__ T f1d_apply(int fn_rt, T x0, T tau, T alpha, T beta) 
     case PROST_FN_ZERO: return x0;                                                   // :34-44
     case PROST_FN_ABS: return f1d_abs(x0, tau);
     case PROST_FN_SQUARE: return f1d_square(x0, tau);
-    case PROST_FN_IND_LEQ0: return x0 > (T)0 ? (T)0 : x0;                             // :75-87
-    case PROST_FN_IND_GEQ0: return x0 < (T)0 ? (T)0 : x0;                             // :90-102
+    case PROST_FN_IND_LEQ0: return f1d_ind_leq0(x0);
+    case PROST_FN_IND_GEQ0: return f1d_ind_geq0(x0);
     case PROST_FN_IND_EQ0: return (T)0;                                               // :105-114
-    case PROST_FN_IND_BOX01: return x0 > (T)1 ? (T)1 : (x0 < (T)0 ? (T)0 : x0);       // :117-131
-    case PROST_FN_MAX_POS0: return x0 > tau ? x0 - tau : (x0 < (T)0 ? x0 : (T)0);     // :134-148
+    case PROST_FN_IND_BOX01: return f1d_ind_box01(x0);
+    case PROST_FN_MAX_POS0: return f1d_max_pos0(x0, tau);
     case PROST_FN_L0: return f1d_l0(x0, tau);
-    case PROST_FN_HUBER: {                                                            // :161-171
-      T r = (T)(((double)(x0 / tau)) / (1. + (double)(alpha / tau)));
-      const T ar = t_abs(r);
-      r /= ((T)1 > ar ? (T)1 : ar);
-      return x0 - tau * r;
-    }
+    case PROST_FN_HUBER: return f1d_huber(x0, tau, alpha);
     case PROST_FN_LQ: return f1d_lq(x0, tau, alpha, beta);
     case PROST_FN_LQ_PLUS_EPS: return (T)0;                                           // :294-306
-    case PROST_FN_TRUNCQUAD: {                                                        // :277-291
-      const T x_sq = f1d_square<T>(x0, 2 * tau * alpha);
-      const T en_sq = alpha * x_sq * x_sq + (x_sq - x0) * (x_sq - x0) / (2 * tau);
-      return en_sq < beta ? x_sq : x0;
-    }
-    case PROST_FN_TRUNCLIN: {                                                         // :309-323
-      const T x_sh = f1d_abs<T>(x0, tau * alpha);
-      const T en_sh = (x_sh - x0) * (x_sh - x0) / (2 * tau) + alpha * t_abs(x_sh);
-      return en_sh < beta ? x_sh : x0;
-    }
+    case PROST_FN_TRUNCQUAD: return f1d_truncquad(x0, tau, alpha, beta);
+    case PROST_FN_TRUNCLIN: return f1d_trunclin(x0, tau, alpha, beta);
   }
   return x0;
 }

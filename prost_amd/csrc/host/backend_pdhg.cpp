@@ -54,6 +54,7 @@ bool BackendPDHG<T>::TryFused() {
   BlockDesc bd;
   auto blk = linop->blocks()[0];
   if (!blk->describe(bd) || bd.label_first) return false;
+  if (bd.kind != BlockDesc::kGradient2D && bd.kind != BlockDesc::kGradient3D) return false;      // (sparse blocks describe themselves too: kSparse)
   if (blk->row() != 0 || blk->col() != 0 || blk->nrows() != prob.nrows() || blk->ncols() != prob.ncols()) return false;
   ProxDesc pg, pf;
   if (!prox_g_[0]->describe(pg) || !prox_fstar_[0]->describe(pf)) return false;
@@ -297,6 +298,13 @@ void BackendPDHG<T>::EndSample(bool sampled) {
 }
 
 template <typename T>
+void BackendPDHG<T>::AbortSample(bool sampled) {
+  if (!sampled) return;
+  prost_hip_next_launch_events(nullptr, nullptr);          // (no CheckHip: an exception is already on its way)
+  if (!samples_.empty()) { samples_.pop_back(); if (ev_used_ >= 2) ev_used_ -= 2; }
+}
+
+template <typename T>
 void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
   void* s = CurrentStream();
   double tau[2], sigma[2], theta[2];
@@ -305,18 +313,19 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
-  const bool t = BeginSample(store_mid ? (residuals ? kKernelPairMidRes : kKernelPairMid) : (residuals ? kKernelPairRes : kKernelPair));
+  TimedLaunch(store_mid ? (residuals ? kKernelPairMidRes : kKernelPairMid) : (residuals ? kKernelPairRes : kKernelPair), [&] {
+    if (!store_mid)
+      CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
+                                        residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
+    else
+      CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
+                                        theta, 0, residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
+  });
   if (!store_mid) {
-    CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
-                                      residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
-    EndSample(t);
     x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
     y_.swap(y_prev_);
     prev_stale_ = true;
   } else {
-    CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
-                                      theta, 0, residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
-    EndSample(t);
     x_.swap(x_spare_);       // x_ = x^(k+2), x_prev_ = x^(k+1): the state two single launches leave
     y_.swap(y_spare_);
     prev_stale_ = false;
@@ -334,10 +343,10 @@ void BackendPDHG<T>::IterationPair3D(bool residuals) {
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
-  const bool t = BeginSample(residuals ? kKernelPairRes : kKernelPair);
-  CheckHip(Api<T>::fused_iteration3d_x2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
-                                        residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration3d_x2");
-  EndSample(t);
+  TimedLaunch(residuals ? kKernelPairRes : kKernelPair, [&] {
+    CheckHip(Api<T>::fused_iteration3d_x2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
+                                          residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration3d_x2");
+  });
   x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
   y_.swap(y_prev_);
   prev_stale_ = true;
@@ -354,10 +363,10 @@ void BackendPDHG<T>::IterationPairMc(bool residuals) {
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of iteration k+1 (:483-488)
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
-  const bool t = BeginSample(residuals ? kKernelPairRes : kKernelPair);
-  CheckHip(Api<T>::fused_iteration_mc_x2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
-                                         residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration_mc_x2");
-  EndSample(t);
+  TimedLaunch(residuals ? kKernelPairRes : kKernelPair, [&] {
+    CheckHip(Api<T>::fused_iteration_mc_x2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
+                                           residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration_mc_x2");
+  });
   x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
   y_.swap(y_prev_);
   prev_stale_ = true;
@@ -406,11 +415,11 @@ void BackendPDHG<T>::IterationFused(bool res) {
     // iterations add the y_prev stream and the four residual sums).  y_new cannot overwrite
     // y_prev_ on residual iterations (the kernel still reads it), so it goes to y_spare_.
     T* y_out = res ? y_spare_.data() : y_prev_.data();
-    const bool t = BeginSample(res ? kKernelIterRes : kKernelIter);
-    CheckHip(Api<T>::fused_iteration(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_,
-                                     (double)sigma_, (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0,
-                                     iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration");
-    EndSample(t);
+    TimedLaunch(res ? kKernelIterRes : kKernelIter, [&] {
+      CheckHip(Api<T>::fused_iteration(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_,
+                                       (double)sigma_, (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0,
+                                       iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration");
+    });
     x_.swap(x_prev_);
     if (res) { y_prev_.swap(y_spare_); }     // y_prev_ now holds y^(k+1); swapped into y_ below
     y_.swap(y_prev_);
@@ -426,15 +435,15 @@ void BackendPDHG<T>::IterationFused(bool res) {
     // non-residual iteration does not read; on residual iterations y_new goes to y_spare_ (the kernel still reads y_prev_).
     if (res) RebuildPrevious();      // the residual kernel streams y^(k-1)
     T* y_out = res ? y_spare_.data() : y_prev_.data();
-    const bool t3 = BeginSample(res ? kKernelIterRes : kKernelIter);
-    if (single3d_pw_ && !res)        // planes across the wavefronts of a workgroup: x_new of the plane above comes through LDS
-      CheckHip(Api<T>::fused_iteration3d_pw(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
-                                            iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, 0, s), "fused_iteration3d_pw");
-    else
-    CheckHip(Api<T>::fused_iteration3d(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
-                                       (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
-                                       res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration3d");
-    EndSample(t3);
+    TimedLaunch(res ? kKernelIterRes : kKernelIter, [&] {
+      if (single3d_pw_ && !res)        // planes across the wavefronts of a workgroup: x_new of the plane above comes through LDS
+        CheckHip(Api<T>::fused_iteration3d_pw(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
+                                              iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, 0, s), "fused_iteration3d_pw");
+      else
+      CheckHip(Api<T>::fused_iteration3d(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
+                                         (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
+                                         res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration3d");
+    });
     x_.swap(x_prev_);
     if (res) y_prev_.swap(y_spare_);
     y_.swap(y_prev_);
@@ -449,11 +458,11 @@ void BackendPDHG<T>::IterationFused(bool res) {
     // pixel and channel; residual iterations add the y_prev stream and the four sums, y_new then goes to y_spare_)
     if (res) RebuildPrevious();      // the residual kernel streams y^(k-1)
     T* y_out = res ? y_spare_.data() : y_prev_.data();
-    const bool tm = BeginSample(res ? kKernelIterRes : kKernelIter);
-    CheckHip(Api<T>::fused_iteration_mc(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
-                                        (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
-                                        res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration_mc");
-    EndSample(tm);
+    TimedLaunch(res ? kKernelIterRes : kKernelIter, [&] {
+      CheckHip(Api<T>::fused_iteration_mc(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
+                                          (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
+                                          res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration_mc");
+    });
     x_.swap(x_prev_);
     if (res) y_prev_.swap(y_spare_);
     y_.swap(y_prev_);
@@ -465,16 +474,16 @@ void BackendPDHG<T>::IterationFused(bool res) {
   }
   if (res) RebuildPrevious();        // the residual primal pass streams y^(k-1)
   prev_stale_ = false;
-  bool t = BeginSample(kKernelPrimal);
-  CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
-                                iteration_ >= 2 ? 1 : 0, res ? res_target() + 2 : nullptr, workspace_, s), "fused_primal");
-  EndSample(t);
+  TimedLaunch(kKernelPrimal, [&] {
+    CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
+                                  iteration_ >= 2 ? 1 : 0, res ? res_target() + 2 : nullptr, workspace_, s), "fused_primal");
+  });
   x_.swap(x_prev_);                        // x_ = x^(k+1), x_prev_ = x^k       (:334)
   // kx_prev_ of the reference is K x^k except at k = 0 (zero vector, :216)
-  t = BeginSample(kKernelDual);
-  CheckHip(Api<T>::fused_dual(&desc_, y_prev_.data(), y_.data(), x_.data(), x_prev_.data(), (double)sigma_, (double)theta_,
-                              iteration_ >= 1 ? 1 : 0, res ? res_target() : nullptr, workspace_, s), "fused_dual");
-  EndSample(t);
+  TimedLaunch(kKernelDual, [&] {
+    CheckHip(Api<T>::fused_dual(&desc_, y_prev_.data(), y_.data(), x_.data(), x_prev_.data(), (double)sigma_, (double)theta_,
+                                iteration_ >= 1 ? 1 : 0, res ? res_target() : nullptr, workspace_, s), "fused_dual");
+  });
   y_.swap(y_prev_);                        // y_ = y^(k+1), y_prev_ = y^k       (:366)
   if (res) FinishResiduals();
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
@@ -592,13 +601,14 @@ void BackendPDHG<T>::Speculate() {
   spec_tau_[2] = tau_; spec_sigma_[2] = sigma_; spec_theta_[2] = theta_;
   tau_ = t0; sigma_ = s0; theta_ = th0;                  // nothing observable changes until the results are adopted
   for (int i = 0; i < 2; i++) { tau[i] = (double)spec_tau_[i]; sigma[i] = (double)spec_sigma_[i]; theta[i] = (double)spec_theta_[i]; }
-  const bool t = BeginSample(kKernelPair);
-  CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
-                                    nullptr, nullptr, CurrentStream()), "fused_iteration2");
-  EndSample(t);
+  TimedLaunch(kKernelPair, [&] {
+    CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
+                                      nullptr, nullptr, CurrentStream()), "fused_iteration2");
+  });
   spec_iteration_ = iteration_;
   spec_valid_ = true;
-  spec_launched_++;
+  spec_launched_++;            // (KernelTimes counts this launch under the pair kernel whether or not it is adopted: it ran; pair_launches_
+                               //  counts adopted ones; solver_state reports speculative_launches / speculative_adopted)
 }
 
 template <typename T>
@@ -706,10 +716,19 @@ bool BackendPDHG<T>::current_solution_device(const T*& primal_x, const T*& prima
   return true;
 }
 
+/// What is RESIDENT after Initialize(): the iterate buffers, the third (spare) buffers of the kernels that ping-pong through
+/// them, and the merged mask / b stream of the inpainting shape.  Not resident until somebody reads the solution or the previous
+/// iterate (current_solution with z / w, callbacks, solver_compare, the end of the run): z and w (n + m values, kept while small),
+/// the three operator products they are formed from (n + 2 m, temporary) and -- on the pair paths that do not keep third buffers
+/// (3-D, multi-channel) -- the n + m values RebuildPrevious needs: at most 3 n + 4 m values on top of this figure, ~4.3 GB at
+/// 2048 x 2048 x 64 fp32 against 8.6 GB resident.
 template <typename T>
 size_t BackendPDHG<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
-  if (fused_) return (2 * (n + m) + (single_kernel_ || single3d_ || single_mc_ || pair3d_ || pair_mc_ ? m : 0) + (pair_kernel_ || pair3d_ || pair_mc_ ? n : 0)) * sizeof(T);
+  if (x_.size() == n && n > 0)          // after Initialize(): what the vectors really hold
+    return (x_.size() + x_prev_.size() + x_spare_.size() + y_.size() + y_prev_.size() + y_spare_.size() + b_masked_.size() + kty_.size() + kty_prev_.size() +
+            kx_.size() + kx_prev_.size() + temp_.size() + sol_z_.size() + sol_w_.size()) * sizeof(T);
+  if (fused_) return 2 * (n + m) * sizeof(T);
   return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511
 }
 

@@ -194,7 +194,7 @@ static Prox<T>* make_elem(int op, int fn, size_t idx, size_t size, bool diagstep
   const bool interleaved = GetScalarFromCell(data, 2) > 0.;
   std::array<std::vector<T>, 7> coeffs;
   get_coefficients<T>(coeffs, cell_at(data, 3), op == PROST_OP_1D ? size : count);     // factory.cpp:326-327 / :341-342
-  return new ProxElemOperation<T>(op, fn, idx, count, dim, interleaved, diagsteps, coeffs);
+  return new ProxElemDispatch<T>(op, fn, idx, count, dim, interleaved, diagsteps, coeffs);
 }
 
 template <typename T>

@@ -31,29 +31,29 @@ template class Prox<double>;
 
 // ---- elementwise 1d / norm2 ----
 template <typename T>
-ProxElemOperation<T>::ProxElemOperation(int op, int fn, size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps,
+ProxElemDispatch<T>::ProxElemDispatch(int op, int fn, size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps,
                                         const std::array<std::vector<T>, 7>& coeffs)
     : ProxSeparableSum<T>(index, count, op == PROST_OP_1D ? 1 : dim, interleaved, diagsteps), op_(op), fn_(fn), coeffs_(coeffs) {
   for (int i = 0; i < 7; i++)
     if (coeffs_[i].empty()) throw Exception("Empty vector passed.");
 }
 template <typename T>
-void ProxElemOperation<T>::Initialize() {
+void ProxElemDispatch<T>::Initialize() {
   for (int i = 0; i < 7; i++)
     if (coeffs_[i].size() > 1) {
       if (coeffs_[i].size() < this->count_) throw Exception("Size of coefficients should be either 1 or count.");
       d_coeffs_[i] = coeffs_[i];
     }
 }
-template <typename T> void ProxElemOperation<T>::Release() { for (int i = 0; i < 7; i++) d_coeffs_[i].clear(); }
+template <typename T> void ProxElemDispatch<T>::Release() { for (int i = 0; i < 7; i++) d_coeffs_[i].clear(); }
 template <typename T>
-size_t ProxElemOperation<T>::gpu_mem_amount() const {
+size_t ProxElemDispatch<T>::gpu_mem_amount() const {
   size_t mem = 0;
   for (int i = 0; i < 7; i++) if (coeffs_[i].size() > 1) mem += this->count_ * sizeof(T);
   return mem;
 }
 template <typename T>
-bool ProxElemOperation<T>::describe(ProxDesc& d) const {
+bool ProxElemDispatch<T>::describe(ProxDesc& d) const {
   d.kind = op_ == PROST_OP_1D ? ProxDesc::kElem1D : ProxDesc::kElemNorm2;
   d.fn = fn_; d.count = this->count_; d.dim = this->dim_; d.interleaved = this->interleaved_;
   for (int i = 0; i < 7; i++) {
@@ -66,7 +66,7 @@ bool ProxElemOperation<T>::describe(ProxDesc& d) const {
 }
 /// device pointer (per-element coefficient) or scalar value of each of the seven coefficients, as the kernels take them
 template <typename T>
-void ProxElemOperation<T>::CoeffArgs(const T* (&ptrs)[7], double (&vals)[7]) const {
+void ProxElemDispatch<T>::CoeffArgs(const T* (&ptrs)[7], double (&vals)[7]) const {
   for (int i = 0; i < 7; i++) {
     if (coeffs_[i].size() > 1) {
       if (d_coeffs_[i].size() != coeffs_[i].size()) throw Exception("ProxElemOperation used before Initialize().");
@@ -75,21 +75,21 @@ void ProxElemOperation<T>::CoeffArgs(const T* (&ptrs)[7], double (&vals)[7]) con
   }
 }
 template <typename T>
-void ProxElemOperation<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T* tau_diag, const T*, T tau, bool invert_tau) {
+void ProxElemDispatch<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T* tau_diag, const T*, T tau, bool invert_tau) {
   const T* ptrs[7]; double vals[7];
   CoeffArgs(ptrs, vals);
   CheckHip(Api<T>::prox_elem(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
                              this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem");
 }
 template <typename T>
-void ProxElemOperation<T>::EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau) {
+void ProxElemDispatch<T>::EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau) {
   const T* ptrs[7]; double vals[7];
   CoeffArgs(ptrs, vals);
   CheckHip(Api<T>::prox_elem_moreau(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
                                     this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem_moreau");
 }
 template <typename T>
-void ProxElemOperation<T>::EvalSourceLocal(bool moreau, device_vector<T>& result, const typename Prox<T>::ArgSource& src,
+void ProxElemDispatch<T>::EvalSourceLocal(bool moreau, device_vector<T>& result, const typename Prox<T>::ArgSource& src,
                                            const device_vector<T>& tau_diag, T tau, bool invert_tau) {
   const T* ptrs[7]; double vals[7];
   CoeffArgs(ptrs, vals);
@@ -100,8 +100,8 @@ void ProxElemOperation<T>::EvalSourceLocal(bool moreau, device_vector<T>& result
   CheckHip(Api<T>::prox_elem_arg(op_, fn_, moreau ? 1 : 0, result.data() + this->index_, &a, tau_diag.data() + this->index_, (double)tau,
                                  invert_tau ? 1 : 0, this->count_, this->dim_, this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem_arg");
 }
-template class ProxElemOperation<float>;
-template class ProxElemOperation<double>;
+template class ProxElemDispatch<float>;
+template class ProxElemDispatch<double>;
 
 // ---- Moreau ----
 template <typename T> void ProxMoreau<T>::Initialize() { scaled_arg_.resize(this->size_); conjugate_->Initialize(); }
@@ -112,7 +112,7 @@ template <typename T>
 void ProxMoreau<T>::EvalLocal(T* res, T* res_end, const T* arg, const T* arg_end, const T* tau_diag, const T* tau_end, T tau, bool invert_tau) {
   const size_t n = this->size_;
   if (g_moreau_fuse && res != arg) {
-    if (auto* e = dynamic_cast<ProxElemOperation<T>*>(conjugate_.get())) {        // pre-scale, elem operation and post-scale in one kernel
+    if (auto* e = dynamic_cast<ProxElemDispatch<T>*>(conjugate_.get())) {        // pre-scale, elem operation and post-scale in one kernel
       e->EvalMoreauLocal(res, arg, tau_diag, tau, invert_tau);
       return;
     }
@@ -123,10 +123,10 @@ void ProxMoreau<T>::EvalLocal(T* res, T* res_end, const T* arg, const T* arg_end
   (void)arg_end;
 }
 template <typename T>
-bool ProxMoreau<T>::supports_arg_source() const { return g_moreau_fuse && dynamic_cast<ProxElemOperation<T>*>(conjugate_.get()) != nullptr; }
+bool ProxMoreau<T>::supports_arg_source() const { return g_moreau_fuse && dynamic_cast<ProxElemDispatch<T>*>(conjugate_.get()) != nullptr; }
 template <typename T>
 void ProxMoreau<T>::EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau) {
-  auto* e = dynamic_cast<ProxElemOperation<T>*>(conjugate_.get());
+  auto* e = dynamic_cast<ProxElemDispatch<T>*>(conjugate_.get());
   if (!e) throw Exception("ProxMoreau: only a conjugated elem operation evaluates from an argument source.");
   e->EvalSourceLocal(true, result, src, tau_diag, tau, invert_tau);
 }

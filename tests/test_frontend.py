@@ -142,3 +142,28 @@ def test_mex_gateway_source_compiles_against_the_mex_api_declarations():
     # the declarations header stays declarations: no function bodies
     decl = open(os.path.join(root, "tests", "mex_decl.h")).read()
     assert "{" not in decl.split('extern "C" {', 1)[1].rsplit("}", 1)[0]
+
+
+def test_sparse_block_builders_do_not_touch_the_callers_matrix():
+    """block.sparse / sparse_kron_id canonicalise a COPY (eliminate_zeros / sort_indices work in place, and csc_matrix(K) of a
+    float64 CSC matrix is K itself)"""
+    import scipy.sparse as sp
+    K = sp.csc_matrix((np.array([1.0, 0.0, 2.0, 3.0]), np.array([1, 0, 0, 1]), np.array([0, 2, 4])), shape=(2, 2))
+    data, indices, nnz = K.data.copy(), K.indices.copy(), K.nnz
+    cell, sz = prost.block.sparse(K)(0, 0, 2, 2)
+    assert K.nnz == nnz and np.array_equal(K.data, data) and np.array_equal(K.indices, indices)
+    assert cell[3][0].nnz == 3 and cell[3][0].has_sorted_indices
+    prost.block.sparse_kron_id(K, 2)(0, 0, 4, 4)
+    assert K.nnz == nnz and np.array_equal(K.indices, indices)
+
+
+def test_host_transport_callback_failures_surface_in_the_next_command():
+    """an exception inside the host all-reduce / point-to-point callback (a ctypes callback on a HIP runtime thread: it could only
+    be printed) is recorded, poisons what the callback was to produce and is raised by the next command"""
+    from prost_amd import _capi
+    del _capi._callback_error[:]
+    _capi._callback_error.append(RuntimeError("peer 1 went away"))
+    with pytest.raises(prost.ProstError, match="host-transport callback failed: RuntimeError: peer 1 went away"):
+        prost.get_precision() if hasattr(prost, "get_precision") else _capi.command("get_precision", (), 1)
+    assert not _capi._callback_error
+    _capi.command("get_precision", (), 1)       # raised once

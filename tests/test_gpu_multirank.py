@@ -156,19 +156,27 @@ def test_bench_two_ranks_under_torchrun_on_one_gpu(hip):
 
 @pytest.mark.parametrize("inject", [None, "injected by the test"])
 def test_bench_native_rccl_communicator_and_its_fallback(hip, inject):
-    """the RCCL leg of bench.py on the one GPU there is (PROST_BENCH_FORCE_DIST=1: torch's nccl group + the solver's own RCCL
-    communicator with one rank + the residual all-reduce through it), and what happens when that second communicator cannot be
-    set up: the sums go through the host-callback transport over a gloo group and the JSON line says so"""
-    env = {"PROST_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_PORT": str(_free_port())}
+    """the RCCL leg of bench.py on the one GPU there is (PROST_BENCH_FORCE_DIST=1): the rendezvous runs over gloo on CPU tensors, so
+    the solver's own communicator is the ONLY RCCL communicator of the rank (RCCL's own log shows exactly one initialisation) and
+    the residual all-reduce runs through it.  When that communicator cannot be set up the run goes on over the host-callback
+    transport, loudly -- and does not count: "value" and "rccl_nranks" are null in the line, the process exits non-zero."""
+    env = {"PROST_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_PORT": str(_free_port()), "NCCL_DEBUG": "INFO"}
     if inject:
         env["PROST_BENCH_INJECT_RCCL_FAILURE"] = inject
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--size", "1024", "--prelude-iters", "100", "--no-cpu-baseline"]
     rc, stdout, stderr = _run_bench(cmd, env)
-    assert rc == 0, stderr
-    d = json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["iterates_finite"] and d["config"]["comm_nranks"] == 1
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (rc, stderr[-2000:])
+    d = json.loads(lines[-1])
+    inits = [l for l in (stdout + stderr).splitlines() if "Init COMPLETE" in l]
+    assert d["n_gpus"] == 1 and d["iterates_finite"] and d["config"]["comm_nranks"] == 1 and d["config"]["rendezvous"].startswith("gloo")
     if inject:
-        assert d["config"]["residual_allreduce"].startswith("host-callback (gloo) after") and d["config"]["rccl_nranks"] is None
+        assert rc == 3, (rc, stderr[-2000:])
+        assert d["value"] is None and d["value_without_rccl"] > 0 and d["config"]["rccl_nranks"] is None and "RCCL" in d["error"]
+        assert d["config"]["residual_allreduce"].startswith("host-callback (gloo) after")
         assert "native RCCL communicator failed (injected by the test)" in stderr
+        assert len(inits) == 0, inits                      # nothing created an RCCL communicator behind the solver's back
     else:
-        assert d["config"]["residual_allreduce"] == "rccl" and d["config"]["rccl_nranks"] == 1
+        assert rc == 0, stderr[-2000:]
+        assert d["value"] > 0 and d["config"]["residual_allreduce"] == "rccl" and d["config"]["rccl_nranks"] == 1
+        assert len(inits) == 1, inits                      # ONE communicator per rank: the solver's

@@ -140,3 +140,220 @@ def test_pdhg_with_plugin_block_and_prox_matches_the_oracle(hip, plugin, prec, d
         assert np.array_equal(np.asarray(got["x"]), np.asarray(exp["x"]))
     finally:
         prost.set_precision("double")
+
+
+# ---- the ELEM_OPERATION surface: user-written functors through prost::ProxElemOperation<T, OP> (tests/plugins/elem_operations.hip) ----
+
+def _coeffs(*vals):
+    return [np.atleast_1d(np.asarray(v, dtype=np.float64)).ravel() for v in vals]
+
+
+def plugin_norm2(name, dim, interleaved, *coeffs):
+    """front-end builder in the style of sum_norm2.m:83-86, naming a plugin operation"""
+    return lambda idx, count: [name, idx, count, False, [count // dim, dim, bool(interleaved), _coeffs(*coeffs)]]
+
+
+def plugin_1d(name, *coeffs):
+    """sum_1d.m:79-80"""
+    return lambda idx, count: [name, idx, count, True, [count, 1, False, _coeffs(*coeffs)]]
+
+
+def plugin_groups(name, dim, interleaved):
+    """sum_ind_simplex.m:7-9: no coefficients"""
+    return lambda idx, count: [name, idx, count, False, [count // dim, dim, bool(interleaved)]]
+
+
+def _coefficient_sets(rng, count, dtype):
+    """(a, b, c, d, e, alpha, beta): scalars; per-group vectors; the a == 0 branch of the 1-D operation"""
+    r = lambda lo, hi: (lo + (hi - lo) * rng.random(count)).astype(dtype).astype(np.float64)
+    return [(1.0, 0.0, 1.0, 0.0, 0.0, 0.25, 0.0),
+            (1.5, 0.3, 2.0, -0.2, 0.4, 0.7, 0.1),
+            (r(0.5, 2), r(-1, 1), r(0.5, 3), 0.1, r(0, 1), r(0.1, 2), 0.0),
+            (0.0, 0.3, 2.0, -0.2, 0.4, 0.7, 0.1)]
+
+
+def test_elem_operation_headers_are_what_the_reference_exports():
+    """CPU: the plugin-facing headers exist under the reference's paths and declare the reference's names (SURVEY 8b bullet 2;
+    prox_elem_operation.hpp:32-117, elem_operation.hpp:30-40, vector.hpp:32-63, shared_mem.hpp:28-62)"""
+    inc = os.path.join(os.path.dirname(HERE), "include", "prost", "prox")
+    for rel, names in {"prox_elem_operation.hpp": ["class ProxElemOperation", "struct ElemOpCoefficients", "kCoeffsCount == 0", "kCoeffsCount != 0"],
+                       "prox_elem_operation.inl": ["ProxElemOperationKernel", "CurrentStream()"],
+                       "vector.hpp": ["class Vector", "operator[]"],
+                       "shared_mem.hpp": ["class SharedMem", "operator[]"],
+                       "elemop/elem_operation.hpp": ["struct ElemOperation", "kCoeffsCount", "kDim", "SharedMemType", "GetSharedMemCount"],
+                       "elemop/elem_operation_1d.hpp": ["struct ElemOperation1D"],
+                       "elemop/elem_operation_norm2.hpp": ["struct ElemOperationNorm2"],
+                       "elemop/function_1d.hpp": ["Function1DHuber", "Function1DLq", "Function1DTruncLinear"]}.items():
+        text = open(os.path.join(inc, rel)).read()
+        for n in names:
+            assert n in text, (rel, n)
+
+
+def test_elem_operation_plugin_registers_its_operations(plugin):
+    for prec in ("single", "double"):
+        prost.set_precision(prec)
+        reg = prost.registered()["prox"]
+        for n in ["test:op:norm2_huber", "test:op:abs_1d", "test:op:simplex_lds", "test:op:partial"] + \
+                 ["test:tpl:%s:%s" % (k, f) for k in ("1d", "norm2") for f in prost.function.FUNCTIONS_1D]:
+            assert n in reg, n
+    prost.set_precision("double")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_user_written_elem_operations_equal_the_library_and_the_oracle(hip, plugin, prec, dtype):
+    """eval_prox of functor operations compiled OUT OF TREE through ProxElemOperation<T, OP> == the library's
+    elem_operation:norm2:huber / elem_operation:1d:abs == the oracle, bit for bit: dims 1 / 2 / 3 / 7 (register-tile
+    instances for dim <= 4, the one-group-per-lane kernel beyond), both layouts, counts with and without a 16-byte tail,
+    scalar and per-group coefficients, and through conjugate() -- which evaluates the operation with invert_tau = true."""
+    prost.set_gpu(0)
+    prost.set_precision(prec)
+    try:
+        rng = np.random.default_rng(17)
+        for count in (1024, 1003, 3):
+            for dim, interleaved in [(1, False), (2, False), (2, True), (3, False), (3, True), (4, True), (7, False), (7, True)]:
+                n = count * dim
+                arg = (2 * rng.standard_normal(n)).astype(dtype).astype(np.float64)
+                if interleaved:
+                    arg[:dim] = 0                       # a zero-norm group
+                else:
+                    arg[0::count][:dim] = 0
+                Tau = (0.5 + rng.random(n)).astype(dtype).astype(np.float64)
+                for cs in _coefficient_sets(rng, count, dtype)[:3]:
+                    for wrap in (lambda f: f, prost.function.conjugate):
+                        got, _ = prost.eval_prox(wrap(plugin_norm2("test:op:norm2_huber", dim, interleaved, *cs)), arg, 0.4, Tau)
+                        lib, _ = prost.eval_prox(wrap(prost.function.sum_norm2(dim, interleaved, "huber", *cs)), arg, 0.4, Tau)
+                        orc = oracle.eval_prox(wrap(prost.function.sum_norm2(dim, interleaved, "huber", *cs)), arg, 0.4, Tau, dtype)
+                        assert np.array_equal(got, lib), (count, dim, interleaved)
+                        assert np.array_equal(got, orc), (count, dim, interleaved, float(np.abs(got - orc).max()))
+            arg = (2 * rng.standard_normal(count)).astype(dtype).astype(np.float64)
+            Tau = (0.5 + rng.random(count)).astype(dtype).astype(np.float64)
+            for cs in _coefficient_sets(rng, count, dtype):
+                for wrap in (lambda f: f, prost.function.conjugate):
+                    got, _ = prost.eval_prox(wrap(plugin_1d("test:op:abs_1d", *cs)), arg, 0.4, Tau)
+                    orc = oracle.eval_prox(wrap(prost.function.sum_1d("abs", *cs)), arg, 0.4, Tau, dtype)
+                    assert np.array_equal(got, orc), (count, float(np.abs(got - orc).max()))
+    finally:
+        prost.set_precision("double")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_elem_operation_with_a_shared_memory_slice_and_partial_results(hip, plugin, prec, dtype):
+    """SharedMem: a simplex projection that sorts in its per-thread LDS slice (GetSharedMemCount(dim) = dim entries of T)
+    == the oracle's elem_operation:ind_simplex, bit for bit, up to dim 40 (40 KiB of LDS per workgroup in fp64);
+    kPartialResult: an operation that writes res[0] only leaves the other components of the result as they were."""
+    prost.set_gpu(0)
+    prost.set_precision(prec)
+    try:
+        rng = np.random.default_rng(5)
+        for count in (515, 64):
+            for dim, interleaved in [(2, False), (3, True), (4, False), (7, True), (33, False), (40, True)]:
+                arg = rng.standard_normal(count * dim).astype(dtype).astype(np.float64)
+                Tau = np.ones(count * dim)
+                got, _ = prost.eval_prox(plugin_groups("test:op:simplex_lds", dim, interleaved), arg, 1.0, Tau)
+                orc = oracle.eval_prox(prost.function.sum_ind_simplex(dim, interleaved), arg, 1.0, Tau, dtype)
+                assert np.array_equal(got, orc), (count, dim, interleaved, float(np.abs(got - orc).max()))
+                grp = got.reshape(count, dim) if interleaved else got.reshape(dim, count).T
+                assert np.allclose(grp.sum(axis=1), 1, atol=1e-5 if dtype == np.float32 else 1e-12) and (grp >= 0).all()
+        count, dim = 1000, 3
+        arg = rng.standard_normal(count * dim).astype(dtype).astype(np.float64)
+        got, _ = prost.eval_prox(plugin_groups("test:op:partial", dim, False), arg, 1.0, np.ones(count * dim))
+        assert np.array_equal(got[:count], 2 * arg[:count]) and np.array_equal(got[count:], np.zeros(2 * count))   # eval_prox zero-fills the result vector
+    finally:
+        prost.set_precision("double")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,dtype,tol", [("single", np.float32, 5e-5), ("double", np.float64, 1e-10)])
+def test_public_operation_templates_equal_the_built_in_operations(hip, plugin, prec, dtype, tol):
+    """ElemOperation1D / ElemOperationNorm2 over the 14 public Function1D* functors, instantiated out of tree, == the
+    library's run-time dispatched operations of the same names == the oracle (bit for bit; lq: Newton on pow(), stated)"""
+    prost.set_gpu(0)
+    prost.set_precision(prec)
+    try:
+        rng = np.random.default_rng(23)
+        count = 777
+        for fn in prost.function.FUNCTIONS_1D:
+            for cs in _coefficient_sets(rng, count, dtype)[1:3]:
+                if fn == "lq":                  # q = 1/2: the analytic branch (function_1d.hpp:195-202), as tests/test_gpu_kernels.py::test_prox_elem
+                    cs = cs[:5] + (0.5 if np.isscalar(cs[5]) else np.full(count, 0.5), cs[6])
+                arg = (2 * rng.standard_normal(count)).astype(dtype).astype(np.float64)
+                Tau = (0.5 + rng.random(count)).astype(dtype).astype(np.float64)
+                got, _ = prost.eval_prox(plugin_1d("test:tpl:1d:" + fn, *cs), arg, 0.4, Tau)
+                lib, _ = prost.eval_prox(prost.function.sum_1d(fn, *cs), arg, 0.4, Tau)
+                orc = oracle.eval_prox(prost.function.sum_1d(fn, *cs), arg, 0.4, Tau, dtype)
+                assert np.array_equal(got, lib), fn            # device against device: the same header, the same bits
+                if fn == "lq":                                  # device against host libm (pow / sin / acos)
+                    assert np.allclose(got, orc, rtol=tol, atol=tol), float(np.abs(got - orc).max())
+                else:
+                    assert np.array_equal(got, orc), fn
+                for dim, interleaved in [(2, False), (3, True), (7, False)]:
+                    arg = (2 * rng.standard_normal(count * dim)).astype(dtype).astype(np.float64)
+                    Tau = (0.5 + rng.random(count * dim)).astype(dtype).astype(np.float64)
+                    got, _ = prost.eval_prox(plugin_norm2("test:tpl:norm2:" + fn, dim, interleaved, *cs), arg, 0.4, Tau)
+                    lib, _ = prost.eval_prox(prost.function.sum_norm2(dim, interleaved, fn, *cs), arg, 0.4, Tau)
+                    orc = oracle.eval_prox(prost.function.sum_norm2(dim, interleaved, fn, *cs), arg, 0.4, Tau, dtype)
+                    assert np.array_equal(got, lib), (fn, dim, interleaved)
+                    if fn == "lq":
+                        assert np.allclose(got, orc, rtol=tol, atol=tol), float(np.abs(got - orc).max())
+                    else:
+                        assert np.array_equal(got, orc), (fn, dim, interleaved)
+    finally:
+        prost.set_precision("double")
+
+
+def _huber_tv_problem(nx, ny, f, lmb, alpha, plugin_ops, conj):
+    """TV-L1-like saddle-point problem with a Huber function on the dual variable q of the gradient; a 3-entry auxiliary
+    pair (w, r) comes first in both vectors, so q starts at offset 3 of the dual vector: the operation's operands are not
+    16-byte aligned."""
+    n = nx * ny
+    u, w = prost.variable(n), prost.variable(3)
+    r, q = prost.variable(3), prost.variable(2 * n)
+    prob = prost.min_max_problem([u, w], [r, q])
+    one = plugin_1d("test:op:abs_1d", 1, f, lmb) if plugin_ops else prost.function.sum_1d("abs", 1, f, lmb)
+    prob.add_function(u, one)
+    hub = plugin_norm2("test:op:norm2_huber", 2, False, 1, 0, 1, 0, 0, alpha, 0) if plugin_ops else \
+        prost.function.sum_norm2(2, False, "huber", 1, 0, 1, 0, 0, alpha, 0)
+    prob.add_function(q, prost.function.conjugate(hub) if conj else hub)
+    prob.add_function(r, prost.function.sum_1d("square", 1, 0, 1))
+    prob.add_dual_pair(w, r, prost.block.identity(3))
+    prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, 1))
+    return prob
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+@pytest.mark.parametrize("conj", [False, True])
+def test_pdhg_solve_with_user_written_elem_operations_matches_the_oracle(hip, plugin, prec, dtype, conj):
+    """a PDHG run whose prox_g and prox_fstar are functor operations compiled out of tree (the dual one at an offset of 3
+    entries: unaligned operands -> the VEC = 1 instances) == the oracle running elem_operation:1d:abs /
+    elem_operation:norm2:huber in their place: x, y, z, w after 1, 7, 30 iterations bit for bit, and a complete solve
+    stops at the same iteration with the same result"""
+    prost.set_gpu(0)
+    prost.set_precision(prec)
+    try:
+        nx, ny = 20, 34
+        f = synthetic.rof_image(nx, ny, 1, 3)
+        b = prost.backend.pdhg(stepsize="boyd", residual_iter=3)
+        o = prost.options(max_iters=60, num_cback_calls=0, verbose=False)
+        prob = _huber_tv_problem(nx, ny, f, 2.0, 0.05, True, conj)
+        ref = _huber_tv_problem(nx, ny, f, 2.0, 0.05, False, conj)
+        ref.finalize()
+        for k in (1, 7, 30):
+            s = prost.Solver(prob, b, o)
+            s.iterate(k)
+            st = s.state()
+            s.destroy()
+            orc = oracle.Solver(ref.data, ref.nrows, ref.ncols, b, o, dtype)
+            orc.initialize()
+            orc.iterate(k)
+            ost = orc.state()
+            for v in "xyzw":
+                assert np.array_equal(st[v], ost[v]), (k, v, float(np.abs(st[v] - ost[v]).max()))
+        o2 = prost.options(max_iters=2000, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=1e-3, tol_abs_dual=1e-3)
+        got, exp = prost.solve(prob, b, o2), oracle.solve(ref, b, o2, dtype)
+        assert got["result"] == exp["result"] and got["iters"] == exp["iters"]
+        assert np.array_equal(np.asarray(got["x"]), np.asarray(exp["x"]))
+    finally:
+        prost.set_precision("double")
