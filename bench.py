@@ -469,6 +469,8 @@ def main():
         if args.residual_iter is not None:
             backend[1]["residual_iter"] = args.residual_iter
         cfg["workload"] = cfg["workload"].replace("PDHG alg2, residual_iter=10", "PDHG %s, residual_iter=%d" % (backend[1]["stepsize"], backend[1]["residual_iter"]))
+    if os.environ.get("PROST_BENCH_DEVICE_RULES") == "0" and backend[0] == "pdhg":
+        backend[1]["allow_device_rules"] = False          # A/B: goldstein / boyd with the rule on the host (a wait per residual iteration)
     if args.no_pair:
         if backend[0] != "pdhg":
             raise SystemExit("bench.py: --no-pair applies to the pdhg configs")

@@ -29,6 +29,11 @@ class Backend {
   /// PerformIteration() leave (including whatever current_solution() needs of iteration k-1).
   /// Residual iterations update the residuals as usual.  Default: one iteration.
   virtual int PerformIterations(int budget) { (void)budget; PerformIteration(); return 1; }
+  /// MI355X addition.  true: the caller runs the loop of Solver::Solve -- it tests primal_residual() < eps_primal() &&
+  /// dual_residual() < eps_dual() after every PerformIterations call and stops when the test holds (solver.cu:141-150).  A backend
+  /// that evaluates the same test on the device may then end a PerformIterations(budget) call EARLY, at the first residual iteration
+  /// at which it holds, returning the iterations run up to and including that one.  false (default): every iteration asked for runs.
+  virtual void SetStopOnConvergence(bool on) { (void)on; }
   virtual void Release() = 0;
 
   virtual void current_solution(std::vector<T>& primal_sol, std::vector<T>& dual_sol) = 0;

@@ -28,9 +28,11 @@ class BackendPDHG : public Backend<T> {
     bool allow_pair_kernel;    ///< MI355X addition: two iterations per launch where nobody observes the one in between
     bool allow_arg_fusion;     ///< MI355X addition (generic path): proxes form their argument on the fly, no argument pass
     bool allow_speculation;    ///< MI355X addition: the next pair launch is enqueued BEFORE the host waits for the residual sums (alg1 / alg2)
+    bool allow_device_rules;   ///< MI355X addition: goldstein / boyd and the stopping test evaluated on the device, one host wait per BATCH of iterations
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
-                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_speculation(true) {}
+                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_speculation(true),
+                allow_device_rules(true) {}
   };
 
   explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), pair_kernel_(false), res_dev_(nullptr),
@@ -41,6 +43,9 @@ class BackendPDHG : public Backend<T> {
   virtual void Initialize();
   virtual void PerformIteration();
   virtual int PerformIterations(int budget);
+  virtual void SetStopOnConvergence(bool on) { stop_on_convergence_ = on; }
+  /// batches of iterations that ran with the step-size rule and the stopping test on the device (diagnostics)
+  size_t device_rule_batches() const { return dev_batches_; }
   virtual void Release();
   virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
@@ -108,7 +113,29 @@ class BackendPDHG : public Backend<T> {
   void ResolveResiduals();                // wait, sqrt, step-size rules (backend_pdhg.cu:433-476)
   void UpdateAlg2();                      // :483-488
 
+  // ---- step-size rule and stopping test on the device (goldstein / boyd on the one-kernel 2-D paths) ------------------------------
+  // The reference adapts tau / sigma on the host from residual norms it copies back at every residual iteration (backend_pdhg.cu:
+  // 433-476) -- with its default options (pdhg.m:4-14: boyd, residual_iter = 1) once per ITERATION.  Here a BATCH of up to
+  // kDeviceBatch iterations is enqueued without looking at the device: behind the reduction of the four sums (and the all-reduce) a
+  // one-thread kernel evaluates the rule and the solver's stopping test (kernels_pdhg_rule.hip), the iteration kernels read their
+  // step sizes from its device record, and once the test has fired the remaining launches of the batch return at once.  The host
+  // waits ONCE, at the end of the batch, adopts the scalars from the pinned mirror and -- if the batch stopped early -- puts the
+  // buffer roles back to what they were after the stopping iteration.
+  static constexpr int kDeviceBatch = 240;
+  bool dev_rules_ = false;                 // this problem / option set runs that way (Initialize)
+  bool in_device_batch_ = false;
+  bool stop_on_convergence_ = false;
+  bool batch_last_launch_evaluated_ = false;
+  size_t dev_batches_ = 0;
+  void* rule_rec_ = nullptr;               // device: PdhgRecord<T>
+  prost_hip_pdhg_rule_state* rule_mirror_ = nullptr;   // pinned host
+  struct BatchMark { size_t iteration_after, pair_launches; T *x, *xp, *y, *yp; bool prev_stale; };
+  std::vector<BatchMark> batch_marks_;     // one per residual iteration of the running batch: the state to return to if it stopped there
+  int PerformIterationsDevice(int budget);
+  void RestoreRoles(const BatchMark& m);
+
   Options opts_;
+  bool from_matrix_ = false;               // the fused path runs on a block that is gradient2d written out as a sparse matrix (TryFused)
   bool fused_, single_kernel_, pair_kernel_;
   bool pair3d_ = false, pair_mc_ = false;
   size_t pair_launches_ = 0;

@@ -62,6 +62,12 @@ class Block {
 
   virtual size_t gpu_mem_amount() const = 0;
   virtual bool describe(BlockDesc&) const { return false; }
+  /// MI355X addition.  true: this block's OPERATOR is gradient2d(nx, ny, L) (block_gradient2d.cu:26-139: planar output, forward
+  /// differences, zero rows at the far borders) although the block is of another kind -- e.g. the sparse matrix
+  /// spmat_gradient2d(nx, ny, L) the reference's examples hand over (example_rof_primal.m:10, :28).  d.kind / nx / ny / L are
+  /// filled in.  The block's row / column sums stay its own: a backend that runs stencil kernels for it must take the
+  /// preconditioners from the problem, not from the stencil block's constants (block_gradient2d.cu:154-163).
+  virtual bool stencil_shape(BlockDesc&) const { return false; }
 
  protected:
   virtual void EvalLocalAdd(T* res_begin, T* res_end, const T* rhs_begin, const T* rhs_end) = 0;

@@ -78,6 +78,13 @@ class BlockSparse : public Block<T> {
   bool patterns_forward() const { return pat_.on; }
   bool patterns_adjoint() const { return pat_t_.on; }
   size_t pattern_count(bool adjoint) const { return (adjoint ? pat_t_ : pat_).count; }
+  /// the matrix IS spmat_gradient2d(nx, ny, L) (matlab/+prost/+test/private/spmat_gradient2d.m:7-14), entry for entry (Initialize())
+  virtual bool stencil_shape(BlockDesc& d) const {
+    if (!grad_nx_) return false;
+    d.kind = BlockDesc::kGradient2D; d.nx = grad_nx_; d.ny = grad_ny_; d.L = grad_L_; d.label_first = false;
+    return true;
+  }
+  static void SetStencilRecognition(bool on);
   virtual bool describe(BlockDesc& d) const {
     if (val_.size() != nnz_ || val_t_.size() != nnz_ || nnz_ == 0) return false;      // before Initialize(), or applied from row patterns (no CSR arrays on the device)
     d.kind = BlockDesc::kSparse; d.nnz = nnz_;
@@ -93,6 +100,8 @@ class BlockSparse : public Block<T> {
   virtual void EvalLocal(T*, T*, const T*, const T*);            ///< non-accumulating product in one pass (no separate zero fill)
   virtual void EvalAdjointLocal(T*, T*, const T*, const T*);
   size_t nnz_;
+  size_t grad_nx_ = 0, grad_ny_ = 0, grad_L_ = 0;      ///< non-zero: K == spmat_gradient2d(grad_nx_, grad_ny_, grad_L_)
+  void DetectGradient2D();
   std::vector<int32_t> host_ind_, host_ind_t_, host_ptr_, host_ptr_t_;
   std::vector<T> host_val_, host_val_t_;
   device_vector<int32_t> ind_, ind_t_, ptr_, ptr_t_;

@@ -6,7 +6,7 @@
 // coefficients gathered per thread, `ELEM_OPERATION op(coeffs, dim, sh_mem); op(res, arg, tau_diag, tau, invert_tau)`.
 // The same contract here, laid out for CDNA4:
 //
-//   * TILE path (dim <= 4, the operation writes every res[i]).  A lane owns VEC = 16 / sizeof(T) consecutive element
+//   * TILE path (dim <= 8, the operation writes every res[i]).  A lane owns VEC = 16 / sizeof(T) consecutive element
 //     groups and keeps their arg / tau_diag / res components in a private tile that the Vector views index with
 //     compile-time constants -- i.e. registers.  Planar layout: per component ONE 16-byte load per lane (a wavefront
 //     reads 1 KiB contiguous per instruction); interleaved layout: the lane's VEC * dim values are contiguous and move
@@ -205,7 +205,11 @@ void Launch(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau, siz
     done = TryTile<T, OP, 1>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream) ||
            TryTile<T, OP, 2>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream) ||
            TryTile<T, OP, 3>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream) ||
-           TryTile<T, OP, 4>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream);
+           TryTile<T, OP, 4>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream) ||
+           TryTile<T, OP, 5>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream) ||
+           TryTile<T, OP, 6>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream) ||
+           TryTile<T, OP, 7>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream) ||
+           TryTile<T, OP, 8>(dim, interleaved, res, arg, tau_diag, tau, invert_tau, count, coeffs, lds_bytes, stream);
   }
   if (!done) {
     auto kernel = ProxElemOperationKernel<T, OP>;

@@ -149,8 +149,9 @@ int prost_comm_set_host_p2p(prost_p2p_cb fn, void* user);
  *       themselves in Factory<T>::block_reg() / prox_reg() / backend_reg() from static initialisers (custom.cpp:11-28;
  *       the reference compiles such sources into the MEX file, cmake/CustomSources.cmake.example:1-26)
  *   registered -> struct {prox, block, backend}: cells of the registered names
- *   set_quirks(struct {diags_adjoint_grid, dual_negate_float, fuse_moreau, sparse_patterns}) -- the first two switch reference
- *       bug-compatibility on; the last two (default on) switch MI355X-side fusions off for A/B runs
+ *   set_quirks(struct {diags_adjoint_grid, dual_negate_float, fuse_moreau, sparse_patterns, sparse_stencils}) -- the first two switch reference
+ *       bug-compatibility on; the others (default on) switch MI355X-side fusions off for A/B runs (sparse_stencils: a sparse block that IS
+ *       spmat_gradient2d(nx, ny, 1) runs the fused gradient kernels with the preconditioners of the matrix)
  */
 
 #ifdef __cplusplus

@@ -30,8 +30,9 @@ extern "C" {
  * 4: prost_hip_selftest_math writes EIGHT counters (it wrote five up to an early v3 header: a caller built against that
  *    header passes a too short buffer -- check prost_hip_abi_version() >= 4 before relying on the 8-slot layout);
  *    additions: comm_count, comm_is_host, comm_host_configure (point-to-point on the host-callback transport),
- *    fused operator entry points of the ADMM graph projection, mask_merge, next_launch_events, pattern_spmv */
-#define PROST_HIP_ABI_VERSION 4
+ *    fused operator entry points of the ADMM graph projection, mask_merge, next_launch_events, pattern_spmv
+ * 5: additions only -- device-resident step-size rules (pdhg_rule_*, fused_iteration_rec, fused_iteration2_rec) */
+#define PROST_HIP_ABI_VERSION 5
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
@@ -278,6 +279,12 @@ typedef struct {
                             /* prox_g is 1, the mask sentinel where a is 0 -- a binary per-pixel a (the inpainting mask of           */
                             /* example_tv_inpaint.m:23) folded into the b stream; g_coeff_ptr[0] must be NULL, g_coeff_val[0] = 1.  */
                             /* Honoured by prost_hip_fused_iteration2 and prost_hip_fused_iteration_mc_x2 only.                      */
+  int var_T;                /* (ABI 5) the primal preconditioner is NOT uniform: the operator was handed over as the sparse matrix    */
+  double T_cls[3];          /* spmat_gradient2d(nx, ny, 1) (example_rof_primal.m:10, :28) and Tau_j = 1 / (column sum of |K|) as        */
+                            /* problem.cu:262-287 forms it -- T_cls[0..2] for pixels with 2, 3, 4 stencil entries in their column         */
+                            /* (corner, edge, interior; count = 4 - [x == 0] - [x == nx - 1] - [y == 0] - [y == ny - 1]), T_val = T_cls[2]. */
+                            /* Sigma stays uniform (the all-zero rows of the matrix inherit 1/2, problem.cu:267-286).  Honoured by        */
+                            /* prost_hip_fused_iteration / _iteration2 (L == 1); every other fused entry point refuses such a description. */
 } prost_hip_fused_desc;
 /* Folds a BINARY per-element coefficient a of ElemOperation1D (elem_operation_1d.hpp:42-44: a == 0 skips the function, the
  * element passes through) into the b stream: bm[i] = a[i] == 0 ? sentinel : (b ? b[i] : b_val), sentinel = a quiet NaN with the
@@ -342,6 +349,66 @@ int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int 
 /* columns per wavefront (chunk length) a launch with cols_per_block <= 0 uses for this description; 0 if unsupported.
  * Measurement key: the HBM traffic of a launch depends on it (3 warm-up columns are re-read per chunk). */
 int prost_hip_fused_iteration2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals);
+
+/* ---- device-resident step sizes for the residual-driven rules (ABI 5; kernels_pdhg_rule.hip) --------------------------------
+ * Replaces the host side of BackendPDHG::UpdateResidualsAndStepsizes (backend_pdhg.cu:433-476: sqrt of the four sums, eps_primal /
+ * eps_dual of backend.hpp:71-74, Goldstein's rule :443-460, Boyd's rule :462-476) and the stopping test of Solver::Solve
+ * (solver.cu:141-150) by a one-thread kernel behind the reduction of the sums: same arithmetic, same precision (T = the _f32 /
+ * _f64 suffix), same order.  `record` is DEVICE memory of prost_hip_pdhg_rule_record_bytes() bytes, owned by the caller.
+ *   _begin : (re)initialises the record from the host's state -- the rule options, the description's scalar prox coefficients, tau,
+ *            sigma, theta, Goldstein's alpha, Boyd's l / u -- and clears the stop word.  stop_on_convergence != 0: a rule
+ *            evaluation whose stopping test fires raises the stop word; every prost_hip_fused_iteration*_rec launch and rule
+ *            evaluation enqueued after it returns at once (the iterate stays that of the stopping iteration).
+ *   _apply : one evaluation on sums4 = {primal diff^2, primal var^2, dual diff^2, dual var^2} (device or pinned host doubles, as
+ *            prost_hip_fused_iteration* and the all-reduce leave them) for the residual iteration with index `iteration`
+ *            (BackendPDHG::iteration_ when the reference calls UpdateResidualsAndStepsizes).
+ *   mirror : optional PINNED HOST struct that receives every scalar after the evaluation; valid once the stream has been
+ *            synchronised.  Nothing here waits for the device.
+ * prost_hip_fused_iteration_rec / _iteration2_rec: the launches of prost_hip_fused_iteration / _iteration2 with tau, sigma, theta
+ * (and the prox terms derived from them) read from the record by the kernel instead of passed by value; both iterations of a
+ * double-iteration launch use the record's current values.  Need scalar e = 0 on both proxes for the straight-line instances. */
+#define PROST_PDHG_RULE_NONE 0        /* alg1: nothing to adapt, residuals / stopping test only */
+#define PROST_PDHG_RULE_GOLDSTEIN 2
+#define PROST_PDHG_RULE_BOYD 3
+typedef struct prost_hip_pdhg_rule_opts {
+  int variant;                                  /* PROST_PDHG_RULE_* */
+  double arg_nu, arg_delta, arb_delta, arb_tau; /* pdhg.m:4-14 */
+  double tol_abs_primal, tol_abs_dual, tol_rel_primal, tol_rel_dual;   /* options.m */
+  double sqrt_rows, sqrt_cols;                  /* sqrt of the (global) numbers of dual / primal variables, formed in double on the host */
+} prost_hip_pdhg_rule_opts;
+typedef struct prost_hip_pdhg_rule_state {
+  double tau, sigma, theta;                     /* after the last evaluation */
+  double prev_tau, prev_sigma, prev_theta;      /* before it */
+  double arg_alpha;
+  long long arb_l, arb_u;
+  double sums[4];
+  double primal_res, dual_res, primal_var, dual_var, eps_primal, eps_dual;
+  unsigned long long evaluations;               /* since _begin */
+  unsigned long long last_iteration;            /* `iteration` of the last evaluation */
+  long long stopped;                            /* the stopping test fired (stop_on_convergence) ... */
+  unsigned long long stop_iteration;            /* ... at the residual iteration with this index */
+} prost_hip_pdhg_rule_state;
+size_t prost_hip_pdhg_rule_record_bytes(void);
+int prost_hip_pdhg_rule_begin_f32(void* record, const prost_hip_pdhg_rule_opts* opts, const prost_hip_fused_desc* desc, double tau, double sigma, double theta,
+                                  double arg_alpha, int arb_l, int arb_u, int stop_on_convergence, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_pdhg_rule_begin_f64(void* record, const prost_hip_pdhg_rule_opts* opts, const prost_hip_fused_desc* desc, double tau, double sigma, double theta,
+                                  double arg_alpha, int arb_l, int arb_u, int stop_on_convergence, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_pdhg_rule_apply_f32(void* record, const double* sums4, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_pdhg_rule_apply_f64(void* record, const double* sums4, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+/* apply_rule != 0 (res_out4 != NULL): the kernel that folds the four sums also evaluates the rule on them -- what _apply does, one launch
+ * less per residual iteration; for residual iterations whose sums need no all-reduce.  `iteration`, `mirror`: as for _apply. */
+int prost_hip_fused_iteration_rec_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
+                                      void* record, int use_kty, int use_kx_prev, int use_kty_prev, int cols_per_block, double* res_out4, void* workspace,
+                                      int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iteration_rec_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev,
+                                      void* record, int use_kty, int use_kx_prev, int use_kty_prev, int cols_per_block, double* res_out4, void* workspace,
+                                      int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iteration2_rec_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y, float* x_mid, float* y_mid,
+                                       void* record, int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
+                                       prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iteration2_rec_f64(const prost_hip_fused_desc* desc, double* x_out, double* y_out, const double* x, const double* y, double* x_mid, double* y_mid,
+                                       void* record, int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
+                                       prost_hip_pdhg_rule_state* mirror, void* stream);
 
 /* The same iteration with the PLANES ACROSS THE WAVEFRONTS of a workgroup (kernels_fused_iter3d_pw.hip): `waves` - 1
  * consecutive planes per workgroup exchange x_new through LDS, one helper wavefront recomputes the plane above the

@@ -114,6 +114,37 @@ struct FusedArgs {
   const T* f_ptr[7]; T f_val[7];
   T Tval, Sval;
   size_t rx0, rx1;            // columns whose residual terms are counted (single-kernel / pair kernels)
+  int varT;                   // position-dependent primal preconditioner (prost_hip_fused_desc.var_T): Tcls by stencil entries per column
+  T Tcls[3];
+};
+
+// step sizes of one iteration + the element-independent prox terms that go with them (device_math.hpp: UniformProx)
+template <class T>
+struct IterParams {
+  T tau, sigma, theta;
+  UniformProx<T> ug, uf;
+};
+
+// Device-resident step sizes for the residual-driven rules (goldstein, boyd; kernels_pdhg_rule.hip).  The reference forms
+// the four residual norms on the host and adapts tau / sigma there (backend_pdhg.cu:433-476) -- a device-to-host round trip
+// per residual iteration, i.e. per iteration under its default options (pdhg.m:4-14: boyd, residual_iter = 1).  Here the rule
+// is evaluated by a one-thread kernel behind the reduction of the sums; it leaves the parameters of the NEXT iterations in `p`,
+// which the iteration kernels read through scalar loads (a wave-uniform record, fetched once per wavefront), and raises `stop`
+// when the solver's stopping test fires: every later iteration kernel and rule evaluation of the same batch then returns at
+// once, so the host can enqueue a batch of iterations without looking at the device in between.
+template <class T>
+struct PdhgRecord {
+  IterParams<T> p;
+  int stop;                          // the stopping test of solver.cu:141-150 fired (only raised when stop_on_convergence)
+  int stop_on_convergence;
+  int variant;                       // PROST_PDHG_RULE_*
+  int arb_l, arb_u;
+  T arg_alpha, arg_nu, arg_delta, arb_delta, arb_tau;
+  T tol_abs_primal, tol_abs_dual, tol_rel_primal, tol_rel_dual;
+  double sqrt_rows, sqrt_cols;       // sqrt of the GLOBAL sizes (backend.hpp:71-74)
+  T g_val[7], f_val[7], Tval, Sval;  // what make_uniform_prox needs beside the step size
+  unsigned long long evaluations;    // rule evaluations since prost_hip_pdhg_rule_begin
+  unsigned long long stop_iteration;
 };
 
 // value of the row above the first row of this lane (row0 - 1): neighbour lane's last element
@@ -146,6 +177,8 @@ inline FusedArgs<T> make_fused_args(const prost_hip_fused_desc* d) {
   a.Tval = (T)d->T_val; a.Sval = (T)d->S_val;
   a.rx0 = d->res_x1 ? d->res_x0 : 0; a.rx1 = d->res_x1 ? d->res_x1 : d->nx;
   a.cols_per_block = 16;
+  a.varT = d->var_T ? 1 : 0;
+  for (int k = 0; k < 3; k++) a.Tcls[k] = (T)d->T_cls[k];
   return a;
 }
 
@@ -156,6 +189,10 @@ template <class T> int run_dual3d(const prost_hip_fused_desc* d, T* y_new, const
 
 // folds nslots x 4 doubles (one partial per wavefront) in a fixed order -> out4 (kernels_fused_iter.hip)
 int launch_fold4(double* out4, const double* partial, unsigned nslots, hipStream_t s);
+// ... with the step-size rule and the stopping test of the device record `rec` (PdhgRecord<T>) applied to the sums in the same launch
+struct RuleTail { int apply; unsigned long long iteration; prost_hip_pdhg_rule_state* mirror; };
+template <class T>
+int launch_fold4_rule(double* out4, const double* partial, unsigned nslots, void* rec, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, hipStream_t s);
 
 inline bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 

@@ -27,6 +27,7 @@ BackendPDHG<T>::~BackendPDHG() { Release(); }
 template <typename T>
 std::string BackendPDHG<T>::path() const {
   if (!fused_) return "pdhg:generic";
+  if (from_matrix_) return "pdhg:fused-grad2d(sparse)";        // the stencil kernels on a gradient handed over as a sparse matrix
   return desc_.is3d ? "pdhg:fused-grad3d" : "pdhg:fused-grad2d";
 }
 
@@ -53,8 +54,14 @@ bool BackendPDHG<T>::TryFused() {
   if (linop->blocks().size() != 1 || prox_g_.size() != 1 || prox_fstar_.size() != 1) return false;
   BlockDesc bd;
   auto blk = linop->blocks()[0];
-  if (!blk->describe(bd) || bd.label_first) return false;
-  if (bd.kind != BlockDesc::kGradient2D && bd.kind != BlockDesc::kGradient3D) return false;      // (sparse blocks describe themselves too: kSparse)
+  // a block whose OPERATOR is gradient2d although it was handed over as a sparse matrix (example_rof_primal.m:10, :28): the stencil
+  // kernels apply, with the preconditioners that matrix really has (checked against the problem's vectors below)
+  bool as_matrix = false;
+  from_matrix_ = false;
+  if (blk->describe(bd) && (bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D)) {}
+  else if (blk->stencil_shape(bd) && bd.kind == BlockDesc::kGradient2D && bd.L == 1) as_matrix = true;
+  else return false;
+  if (bd.label_first) return false;
   if (blk->row() != 0 || blk->col() != 0 || blk->nrows() != prob.nrows() || blk->ncols() != prob.ncols()) return false;
   ProxDesc pg, pf;
   if (!prox_g_[0]->describe(pg) || !prox_fstar_[0]->describe(pf)) return false;
@@ -66,8 +73,30 @@ bool BackendPDHG<T>::TryFused() {
   const size_t comps = d3 ? 3 : 2 * bd.L;
   if (pf.count != pixels || pf.dim != comps) return false;
   T tv, sv;
-  if (!prob.uniform_right(tv) && !uniform(prob.scaling_right_host(), tv)) return false;
+  desc_.var_T = 0; desc_.T_cls[0] = desc_.T_cls[1] = desc_.T_cls[2] = 0;
   if (!prob.uniform_left(sv) && !uniform(prob.scaling_left_host(), sv)) return false;
+  if (as_matrix) {
+    // Tau_j = 1 / (column sum of |K|) (problem.cu:262-287): 4 stencil entries in the column of an interior pixel, 3 on an edge, 2 in a
+    // corner.  The three values are READ from the problem's vector and every entry is compared with the value of its class.
+    if (owned_x1_ != 0 || bd.nx < 4 || bd.ny < 4) return false;
+    const std::vector<T>& tr = prob.scaling_right_host();
+    const size_t nx = bd.nx, ny = bd.ny;
+    if (tr.size() != nx * ny) return false;
+    const T cls[3] = {tr[0], tr[1], tr[ny + 1]};            // corner, edge, interior
+    std::atomic<bool> same(true);
+    ParallelFor(nx, [&](size_t b, size_t e) {
+      for (size_t x = b; x < e && same.load(std::memory_order_relaxed); x++)
+        for (size_t y = 0; y < ny; y++) {
+          const int cnt = 4 - (x == 0) - (x == nx - 1) - (y == 0) - (y == ny - 1);
+          if (tr[x * ny + y] != cls[cnt - 2]) { same.store(false); return; }
+        }
+    });
+    if (!same.load()) return false;
+    tv = cls[2];
+    desc_.var_T = (cls[0] != cls[2] || cls[1] != cls[2]) ? 1 : 0;
+    for (int i = 0; i < 3; i++) desc_.T_cls[i] = (double)cls[i];
+  }
+  else if (!prob.uniform_right(tv) && !uniform(prob.scaling_right_host(), tv)) return false;
   desc_.res_x0 = owned_x0_; desc_.res_x1 = owned_x1_;
   desc_.g_b_masked = 0;
   desc_.is3d = d3 ? 1 : 0; desc_.nx = bd.nx; desc_.ny = bd.ny; desc_.L = bd.L;
@@ -77,6 +106,9 @@ bool BackendPDHG<T>::TryFused() {
     desc_.f_coeff_ptr[i] = pf.coeff_ptr[i]; desc_.f_coeff_val[i] = pf.coeff_val[i];
   }
   desc_.T_val = (double)tv; desc_.S_val = (double)sv;
+  // (position-dependent Tau: the one-kernel iteration is the only fused form; the two-pass kernels refuse it)
+  from_matrix_ = as_matrix;
+  if (desc_.var_T) return opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
   return prost_hip_fused_supported(&desc_, dtype_id<T>()) == 1;
 }
 
@@ -175,6 +207,17 @@ void BackendPDHG<T>::Initialize() {
     CheckHip(prost_hip_event_create(&ev_res_done_), "event_create");
   }
 
+  // goldstein / boyd on the one-kernel 2-D path: rule + stopping test on the device (header).  Needs every step-size dependent prox
+  // term to be a scalar (a, c, e of prox_g; prox_f* has scalars only on this path) and e = 0 on both sides (the kernels' dispatch
+  // must not depend on the step size); column-sharded slabs exchange halos between iterations and keep the host loop.
+  dev_rules_ = single_kernel_ && !pair_mc_ && desc_.L == 1 && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
+               !desc_.g_coeff_ptr[4] && desc_.g_coeff_val[4] == 0.0 && desc_.f_coeff_val[4] == 0.0;
+  in_device_batch_ = false; dev_batches_ = 0;
+  if (dev_rules_) {
+    CheckHip(prost_hip_malloc(&rule_rec_, prost_hip_pdhg_rule_record_bytes()), "malloc");
+    CheckHip(prost_hip_host_alloc((void**)&rule_mirror_, sizeof(prost_hip_pdhg_rule_state)), "host_alloc");
+  }
+
   this->primal_var_norm_ = this->dual_var_norm_ = this->primal_residual_ = this->dual_residual_ = 0;
 
   if (opts_.scale_steps_operator) {                        // backend_pdhg.cu:274-286
@@ -201,6 +244,9 @@ void BackendPDHG<T>::Release() {
   if (res_dev_) { prost_hip_free(res_dev_); res_dev_ = nullptr; }
   if (res_host_) { prost_hip_host_free(res_host_); res_host_ = nullptr; }
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
+  if (rule_rec_) { prost_hip_free(rule_rec_); rule_rec_ = nullptr; }
+  if (rule_mirror_) { prost_hip_host_free(rule_mirror_); rule_mirror_ = nullptr; }
+  batch_marks_.clear();
   if (side_stream_) { prost_hip_stream_synchronize(side_stream_); prost_hip_stream_destroy(side_stream_); side_stream_ = nullptr; }
   if (ev_res_ready_) { prost_hip_event_destroy(ev_res_ready_); ev_res_ready_ = nullptr; }
   if (ev_res_done_) { prost_hip_event_destroy(ev_res_done_); ev_res_done_ = nullptr; }
@@ -247,6 +293,13 @@ int BackendPDHG<T>::PerformIterations(int budget) {
       return 2;
     }
   }
+  // residual-driven rules on the device: a batch of iterations, ONE host wait at its end (two- and one-iteration budgets -- a user
+  // stop callback polls after every launch -- keep the host loop: the batch's set-up kernel would cost more than the wait)
+  // (a caller that goes on after the stopping test already holds gets the host loop's answer -- one iteration -- not a batch that
+  // stops at its first residual iteration)
+  if (dev_rules_ && budget >= 3 && k >= 2 &&
+      !(stop_on_convergence_ && this->primal_residual_ < this->eps_primal() && this->dual_residual_ < this->eps_dual()))
+    return PerformIterationsDevice(budget);
   if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
     IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
     pair_launches_++;
@@ -268,6 +321,88 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   }
   PerformIteration();
   return 1;
+}
+
+template <typename T>
+void BackendPDHG<T>::RestoreRoles(const BatchMark& m) {
+  auto place = [](device_vector<T>& dst, T* want, device_vector<T>& o1, device_vector<T>& o2) {
+    if (dst.data() == want) return;
+    if (o1.data() == want) dst.swap(o1); else if (o2.data() == want) dst.swap(o2);
+    else throw Exception("BackendPDHG: lost track of an iterate buffer.");
+  };
+  place(x_, m.x, x_prev_, x_spare_); place(x_prev_, m.xp, x_spare_, x_spare_);
+  place(y_, m.y, y_prev_, y_spare_); place(y_prev_, m.yp, y_spare_, y_spare_);
+  prev_stale_ = m.prev_stale;
+  iteration_ = m.iteration_after;
+  pair_launches_ = m.pair_launches;
+}
+
+/// up to kDeviceBatch iterations with the step-size rule and the stopping test on the device; returns the iterations that RAN (fewer
+/// than asked for when the stopping test fired: the state is then that of the stopping iteration, as if the host loop had stopped there)
+template <typename T>
+int BackendPDHG<T>::PerformIterationsDevice(int budget) {
+  void* s = CurrentStream();
+  // A full batch is a whole number of residual periods (and even): the launch pattern -- pairs whose SECOND iteration is the residual
+  // one -- then continues across the batch boundary instead of starting over with a single launch, a stored-mid pair and a single
+  // residual launch per batch (measured at 4096^2, boyd, residual_iter 10, batches of 128: -3 %).
+  const int period = opts_.residual_iter % 2 == 0 ? opts_.residual_iter : 2 * opts_.residual_iter;
+  const int full = period <= kDeviceBatch ? (kDeviceBatch / period) * period : kDeviceBatch;
+  const int n = std::min(budget, full);
+  const size_t k0 = iteration_;
+  prost_hip_pdhg_rule_opts o;
+  o.variant = opts_.stepsize_variant == kPDHGStepsResidualGoldstein ? PROST_PDHG_RULE_GOLDSTEIN : PROST_PDHG_RULE_BOYD;
+  o.arg_nu = (double)opts_.arg_nu; o.arg_delta = (double)opts_.arg_delta; o.arb_delta = (double)opts_.arb_delta; o.arb_tau = (double)opts_.arb_tau;
+  o.tol_abs_primal = (double)this->solver_opts_.tol_abs_primal; o.tol_abs_dual = (double)this->solver_opts_.tol_abs_dual;
+  o.tol_rel_primal = (double)this->solver_opts_.tol_rel_primal; o.tol_rel_dual = (double)this->solver_opts_.tol_rel_dual;
+  o.sqrt_rows = std::sqrt((double)(this->global_nrows_ ? this->global_nrows_ : this->problem_->nrows()));      // backend.hpp:71-74
+  o.sqrt_cols = std::sqrt((double)(this->global_ncols_ ? this->global_ncols_ : this->problem_->ncols()));
+  ResolveResiduals();                      // (sums of the host loop still in flight: the rule's input state must be final)
+  spec_valid_ = false;
+  CheckHip(Api<T>::pdhg_rule_begin(rule_rec_, &o, &desc_, (double)tau_, (double)sigma_, (double)theta_, (double)arg_alpha_, arb_l_, arb_u_,
+                                   stop_on_convergence_ ? 1 : 0, rule_mirror_, s), "pdhg_rule_begin");
+  batch_marks_.clear();
+  batch_last_launch_evaluated_ = false;
+  in_device_batch_ = true;
+  try {
+    for (int done = 0; done < n;) {
+      const size_t k = iteration_;
+      batch_last_launch_evaluated_ = false;
+      if (pair_kernel_ && n - done >= 2 && !is_residual_iteration(k)) {
+        pair_launches_++;            // (counted first: the mark a residual launch leaves holds the count INCLUDING itself)
+        IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
+        done += 2;
+      } else {
+        IterationFused(is_residual_iteration(k));
+        done += 1;
+      }
+    }
+  } catch (...) { in_device_batch_ = false; throw; }
+  in_device_batch_ = false;
+  dev_batches_++;
+  CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");          // the batch's ONE host wait
+  CheckHip(prost_hip_check_last_error(), "PDHG iteration");
+  const prost_hip_pdhg_rule_state& m = *rule_mirror_;
+  if (m.evaluations > 0) {
+    this->primal_residual_ = (T)m.primal_res; this->primal_var_norm_ = (T)m.primal_var;
+    this->dual_residual_ = (T)m.dual_res; this->dual_var_norm_ = (T)m.dual_var;
+    for (int i = 0; i < 4; i++) res_host_[i] = m.sums[i];
+    arg_alpha_ = (T)m.arg_alpha; arb_l_ = (int)m.arb_l; arb_u_ = (int)m.arb_u;
+  }
+  tau_ = (T)m.tau; sigma_ = (T)m.sigma; theta_ = (T)m.theta;
+  bool last_evaluated = batch_last_launch_evaluated_;
+  if (m.stopped) {
+    // the launches after the stopping iteration returned at once: back to the buffer roles that iteration left
+    const BatchMark* mark = nullptr;
+    for (const BatchMark& b : batch_marks_) if (b.iteration_after == (size_t)m.stop_iteration + 1) mark = &b;
+    if (!mark) throw Exception("BackendPDHG: the device stopped at an iteration the batch did not contain.");
+    RestoreRoles(*mark);
+    last_evaluated = true;
+  }
+  // step sizes of the last launch that ran (RebuildPrevious re-runs its first iteration): the values before its rule evaluation
+  if (last_evaluated) { stale_tau_ = (T)m.prev_tau; stale_sigma_ = (T)m.prev_sigma; stale_theta_ = (T)m.prev_theta; }
+  else { stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_; }
+  batch_marks_.clear();
+  return (int)(iteration_ - k0);
 }
 
 template <typename T>
@@ -314,7 +449,12 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
   TimedLaunch(store_mid ? (residuals ? kKernelPairMidRes : kKernelPairMid) : (residuals ? kKernelPairRes : kKernelPair), [&] {
-    if (!store_mid)
+    if (in_device_batch_)            // step sizes from the device record (both iterations: no rule evaluation falls between them)
+      CheckHip(Api<T>::fused_iteration2_rec(&desc_pair_, store_mid ? x_spare_.data() : x_prev_.data(), store_mid ? y_spare_.data() : y_prev_.data(), x_.data(),
+                                            y_.data(), store_mid ? x_prev_.data() : nullptr, store_mid ? y_prev_.data() : nullptr, rule_rec_, 0,
+                                            residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, this->comm_ ? 0 : 1,
+                                            (unsigned long long)iteration_, rule_mirror_, s), "fused_iteration2_rec");
+    else if (!store_mid)
       CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
                                         residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
     else
@@ -416,6 +556,11 @@ void BackendPDHG<T>::IterationFused(bool res) {
     // y_prev_ on residual iterations (the kernel still reads it), so it goes to y_spare_.
     T* y_out = res ? y_spare_.data() : y_prev_.data();
     TimedLaunch(res ? kKernelIterRes : kKernelIter, [&] {
+      if (in_device_batch_)
+        CheckHip(Api<T>::fused_iteration_rec(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, rule_rec_,
+                                             iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr,
+                                             res ? workspace_ : nullptr, this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_, s), "fused_iteration_rec");
+      else
       CheckHip(Api<T>::fused_iteration(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_,
                                        (double)sigma_, (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0,
                                        iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration");
@@ -536,6 +681,7 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
 /// made to wait for it (device-side) before the buffer is overwritten.
 template <typename T>
 double* BackendPDHG<T>::res_target() {
+  if (in_device_batch_) return res_dev_;            // consumed on the device (all-reduce, rule kernel)
   if (!this->comm_) return res_host_;
   if (side_inflight_) {
     CheckHip(prost_hip_stream_wait_event(CurrentStream(), ev_res_done_), "stream_wait_event");
@@ -553,6 +699,18 @@ template <typename T>
 void BackendPDHG<T>::FinishResiduals() {
   void* s = CurrentStream();
   last_end_ = kNoEvent;            // kernel timing: the fold (and what follows here) sits between this launch and the next
+  if (in_device_batch_) {
+    // the sums stay on the device.  Without a communicator the kernel that folded them has already evaluated the rule and the stopping
+    // test (fold4_rule_kernel); with one they pass the all-reduce first and a one-thread kernel follows.  Scalars are mirrored to pinned
+    // host memory either way.
+    if (this->comm_) {
+      CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
+      CheckHip(Api<T>::pdhg_rule_apply(rule_rec_, res_dev_, (unsigned long long)iteration_, rule_mirror_, s), "pdhg_rule_apply");
+    }
+    batch_marks_.push_back({iteration_ + 1, pair_launches_, x_.data(), x_prev_.data(), y_.data(), y_prev_.data(), prev_stale_});
+    batch_last_launch_evaluated_ = true;
+    return;
+  }
   // without a communicator the reduction kernels wrote the four sums straight into the pinned host buffer
   // (device-visible): no D2H copy, a stream synchronisation is all that is needed before reading them
   if (this->comm_) {

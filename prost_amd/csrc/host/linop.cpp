@@ -137,6 +137,42 @@ bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::
   return true;
 }
 }  // namespace
+static bool g_stencil_recognition = true;
+template <typename T> void BlockSparse<T>::SetStencilRecognition(bool on) { g_stencil_recognition = on; }
+
+/// Is K, entry for entry, spmat_gradient2d(nx, ny, L) -- rows [0, L n): forward differences along x (-1 at the pixel, +1 one column
+/// on, nothing in the last column), rows [L n, 2 L n): along y (-1, +1 one row down, nothing in the last row), n = nx ny, label l in
+/// columns [l n, (l + 1) n) (spmat_gradient2d.m:7-14)?  ny is read off row 0, n off the first empty row, then every row is checked.
+template <typename T>
+void BlockSparse<T>::DetectGradient2D() {
+  grad_nx_ = grad_ny_ = grad_L_ = 0;
+  const size_t m = this->nrows(), n = this->ncols();
+  if (!g_stencil_recognition || m != 2 * n || n < 4 || host_ptr_.size() != m + 1) return;
+  if (host_ptr_[1] - host_ptr_[0] != 2 || host_ind_[0] != 0 || host_val_[0] != (T)-1 || host_val_[1] != (T)1) return;
+  const size_t ny = (size_t)host_ind_[1];
+  if (ny < 2 || ny >= n) return;
+  size_t first_empty = n;
+  for (size_t r = 0; r < n; r++) if (host_ptr_[r + 1] == host_ptr_[r]) { first_empty = r; break; }
+  const size_t img = first_empty + ny;
+  if (first_empty == n || img > n || n % img != 0 || img % ny != 0 || img / ny < 2) return;
+  std::atomic<bool> ok(true);
+  auto row_is = [&](size_t r, size_t c0, bool two) {
+    const int32_t b = host_ptr_[r], e = host_ptr_[r + 1];
+    if (!two) return e == b;
+    return e - b == 2 && (size_t)host_ind_[b] == c0 && host_val_[b] == (T)-1 && host_val_[b + 1] == (T)1;
+  };
+  ParallelFor(n, [&](size_t lo, size_t hi) {
+    for (size_t q = lo; q < hi && ok.load(std::memory_order_relaxed); q++) {
+      const size_t p = q % img;
+      const bool dx = p < img - ny, dy = p % ny < ny - 1;
+      if (!row_is(q, q, dx) || (dx && (size_t)host_ind_[host_ptr_[q] + 1] != q + ny) ||
+          !row_is(n + q, q, dy) || (dy && (size_t)host_ind_[host_ptr_[n + q] + 1] != q + 1)) { ok = false; return; }
+    }
+  });
+  if (!ok) return;
+  grad_ny_ = ny; grad_nx_ = img / ny; grad_L_ = n / img;
+}
+
 template <typename T> void BlockSparse<T>::SetPatternCompression(bool on) { g_sparse_patterns = on; }
 template <typename T> bool BlockSparse<T>::pattern_compression() { return g_sparse_patterns; }
 
@@ -150,6 +186,7 @@ void BlockSparse<T>::Initialize() {
     p.count = h.pptr.size() - 1;
     p.on = true;
   };
+  DetectGradient2D();
   build(pat_, this->nrows(), host_ptr_, host_ind_, host_val_);
   build(pat_t_, this->ncols(), host_ptr_t_, host_ind_t_, host_val_t_);
   // the CSR arrays of a product that runs from row patterns stay on the host (a 4096^2 gradient: 0.5 GB of upload each)

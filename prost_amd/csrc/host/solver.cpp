@@ -57,12 +57,14 @@ void Solver<T>::Initialize() {
 template <typename T>
 void Solver<T>::Iterate(int iters) {
   // the state is observable after the last iteration only: the backend may fuse the ones before it
+  backend_->SetStopOnConvergence(false);
   for (int i = 0; i < iters;) i += backend_->PerformIterations(iters - i);
   iterations_done_ += iters;
 }
 
 template <typename T>
 bool Solver<T>::IterateChecked(int iters) {
+  backend_->SetStopOnConvergence(true);
   for (int i = 0; i < iters;) {
     const int done = backend_->PerformIterations(iters - i);
     i += done;
@@ -90,6 +92,7 @@ typename Solver<T>::ConvergenceResult Solver<T>::Solve() {
   if (opts_.num_cback_calls >= 2) cb_iters = linspace(0, opts_.max_iters - 1, opts_.num_cback_calls);
   else cb_iters.push_back(1e8);
 
+  backend_->SetStopOnConvergence(true);
   for (int i = 0; i < opts_.max_iters; i++) {
     // The loop body below looks at the backend after EVERY iteration in the reference (solver.cu:137-
     // 196), but only three things can change its outcome: the residuals (which only residual

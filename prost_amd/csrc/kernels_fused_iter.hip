@@ -17,7 +17,7 @@
 // lane keeps >= 8 x 16 B requests in flight.
 // RES = true (residual iterations) additionally streams y_prev (2 floats/pixel) and accumulates the
 // four residual sums of backend_pdhg.cu:392-431 (one partial of 4 doubles per wavefront).
-#include "fused_common.hpp"
+#include "pdhg_rule.hpp"
 #include "reduce.hpp"
 
 
@@ -38,13 +38,21 @@ struct ColIn {            // everything loaded for one column
 // RAG: the image height is not a multiple of VEC (fused_common.hpp, ldv_n / stv_n)
 // FAST: straight-line instance for the ROF shape (host-checked: prox_g square with scalar a = 1, d = e = 0,
 // prox_f* ind_leq0 with scalar a = 1, d = e = 0), same forms as kernels_fused_iter2.hip
-template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, bool RAG, bool FAST>
+// VART: the primal preconditioner depends on the position (FusedArgs::varT: the gradient handed over as the sparse matrix
+// spmat_gradient2d, Tau_j = 1 / column sum).  Interior pixels (4 stencil entries in their column) run the code of the uniform
+// instance with Tval = Tcls[2]; pixels of the first / last column and row -- 3 or 2 entries -- evaluate the reference's own
+// expression with their Tau_j (elem_1d: ElemOperation1D as written) and the residual terms with their sqrt(Tau_j).  LCH == 1.
+template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, bool RAG, bool FAST, bool VART>
 __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
                                                              const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma, T theta,
                                                              UniformProx<T> ug, UniformProx<T> uf,
                                                              bool use_kty, bool use_kx_prev, bool use_kty_prev,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, const PdhgRecord<T>* __restrict__ rec) {
+  if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
+    if (rec->stop) return;
+    tau = rec->p.tau; sigma = rec->p.sigma; theta = rec->p.theta; ug = rec->p.ug; uf = rec->p.uf;
+  }
   const size_t nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x;
   constexpr int kRowsPerWave = (kWave - 1) * VEC;
@@ -110,6 +118,8 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
       T upp = 0;
       if (RES) { upp = lane_up(in.p2[RES ? l : 0][RES ? VEC - 1 : 0]); if (lane == 0) upp = in.upp[RES ? l : 0]; }
       T ktyv[VEC], parg[VEC];
+      T argv[VART ? VEC : 1], tTv[VART ? VEC : 1], sTv[VART ? VEC : 1];
+      bool edgev[VART ? VEC : 1];
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         const size_t row = row0 + j;
@@ -119,15 +129,25 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         if (have_prev) divx -= prev.y1[l][j];
         const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
         ktyv[j] = kty;
-        const T arg = in.x[l][j] - tauT * kty;
+        T tT = tauT;
+        bool edge = false;
+        if (VART) {                // stencil entries in this pixel's column of K: 4 inside, 3 on an edge, 2 in a corner
+          const int cnt = 4 - (c == 0 ? 1 : 0) - (c == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
+          edge = cnt != 4;
+          const T Tj = cnt == 4 ? a.Tval : (cnt == 3 ? a.Tcls[1] : a.Tcls[0]);
+          tT = tau * Tj;
+          edgev[VART ? j : 0] = edge; tTv[VART ? j : 0] = tT; sTv[VART ? j : 0] = edge ? t_sqrt(Tj) : sqT;
+        }
+        const T arg = in.x[l][j] - tT * kty;
+        if (VART) argv[VART ? j : 0] = arg;
         if (FAST) {
           parg[j] = arg - (((GMASK >> 1) & 1) ? in.gc[l][slot_of(GMASK, 1)][j] : a.g_val[1]);
         } else {
           T cf[7];
 #pragma unroll
           for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? in.gc[l][slot_of(GMASK, k)][j] : a.g_val[k];
-          if (kUniformG) xn[l][j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
-          else xn[l][j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, cf);
+          if (kUniformG && !edge) xn[l][j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
+          else xn[l][j] = elem_1d<T, GFN>(a.g_fn, arg, tT, cf);
         }
       }
       if (FAST) {      // a (v - d tau) = v, fp64 denominator 1: F_prox(v - b; step) + b (square: exact division, one
@@ -139,6 +159,17 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         }
 #pragma unroll
         for (int j = 0; j < VEC; j++) xn[l][j] = r[j] + (((GMASK >> 1) & 1) ? in.gc[l][slot_of(GMASK, 1)][j] : a.g_val[1]);
+        if (VART) {            // pixels with their own Tau_j: ElemOperation1D as the reference writes it (the uniform terms do not apply)
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            if (edgev[VART ? j : 0]) {
+              T cf[7];
+#pragma unroll
+              for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? in.gc[l][slot_of(GMASK, k)][j] : a.g_val[k];
+              xn[l][j] = elem_1d<T, GFN>(a.g_fn, argv[VART ? j : 0], tTv[VART ? j : 0], cf);
+            }
+          }
+        }
       }
       if (RES) {                                            // dual_residual_transform (backend_pdhg.cu:73-94)
 #pragma unroll
@@ -150,8 +181,9 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
           T dpx = (c < nx - 1) ? in.p1[ll][jj] : (T)0;
           if (have_prev) dpx -= prev.p1[ll][jj];
           const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
-          const T w_hat = div_tauT.div(in.x[l][j] - xn[l][j]) - sqT * ktyp;
-          const T diff = w_hat + sqT * ktyv[j];
+          const T sT = VART ? sTv[VART ? j : 0] : sqT;
+          const T w_hat = (VART && edgev[VART ? j : 0]) ? (in.x[l][j] - xn[l][j]) / (tau * sT) - sT * ktyp : div_tauT.div(in.x[l][j] - xn[l][j]) - sqT * ktyp;
+          const T diff = w_hat + sT * ktyv[j];
           if (owner && owned && j < nvalid && c >= a.rx0 && c < a.rx1) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
         }
       }
@@ -299,6 +331,40 @@ __global__ void __launch_bounds__(kBlock) fold4_kernel(double* __restrict__ out4
   }
 }
 
+// the same fold with the step-size rule and the stopping test as its epilogue (pdhg_rule.hpp): one launch less per residual iteration
+// where no all-reduce has to run between the sums and the rule
+template <class T>
+__global__ void __launch_bounds__(kBlock) fold4_rule_kernel(double* __restrict__ out4, const double* __restrict__ partial, unsigned nslots,
+                                                            PdhgRecord<T>* rec, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror) {
+  if (rec->stop) return;                 // the launch that would have produced the partials returned at once
+  double v[4] = {0, 0, 0, 0};
+  for (unsigned i = threadIdx.x; i < nslots; i += kBlock)
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] += partial[4 * (size_t)i + k];
+  __shared__ double s[4][kBlock / kWave];
+  __shared__ double tot[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) v[k] = wave_sum(v[k]);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) for (int k = 0; k < 4; k++) s[k][wave] = v[k];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int w = 0; w < kBlock / kWave; w++) t += s[threadIdx.x][w];
+    out4[threadIdx.x] = t;
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) rule_apply_device(rec, tot, iteration, mirror);
+}
+template <class T>
+int launch_fold4_rule(double* out4, const double* partial, unsigned nslots, void* rec, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, hipStream_t s) {
+  hipLaunchKernelGGL(fold4_rule_kernel<T>, dim3(1), dim3(kBlock), 0, s, out4, partial, nslots, static_cast<PdhgRecord<T>*>(rec), iteration, mirror);
+  PH_LAUNCH_END("fold4 + rule kernel");
+}
+template int launch_fold4_rule<float>(double*, const double*, unsigned, void*, unsigned long long, prost_hip_pdhg_rule_state*, hipStream_t);
+template int launch_fold4_rule<double>(double*, const double*, unsigned, void*, unsigned long long, prost_hip_pdhg_rule_state*, hipStream_t);
+
 int launch_fold4(double* out4, const double* partial, unsigned nslots, hipStream_t s) {
   hipLaunchKernelGGL(fold4_kernel, dim3(1), dim3(kBlock), 0, s, out4, partial, nslots);
   PH_LAUNCH_END("fold4 kernel");
@@ -307,6 +373,7 @@ int launch_fold4(double* out4, const double* partial, unsigned nslots, hipStream
 static bool iter_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   if (!d || d->is3d) return false;
   if (d->nx < 2 || d->ny < 2 || d->L < 1 || d->L > 2) return false;
+  if (d->var_T && d->L != 1) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   const int V = dtype == 0 ? 4 : 2;
   for (int k = 0; k < 7; k++) {
@@ -322,7 +389,7 @@ static bool iter_desc_ok(const prost_hip_fused_desc* d, int dtype) {
 template <class T>
 static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau,
                     double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws,
-                    void* stream) {
+                    void* stream, void* record = nullptr, const RuleTail* tail = nullptr) {
   constexpr int V = VecOf<T>::N;
   if (!iter_desc_ok(d, sizeof(T) == 4 ? 0 : 1) || !aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y) ||
       !aligned16(y_prev)) {
@@ -361,6 +428,10 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   int mask = 0;
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k]) mask |= 1 << k;
   const bool rag = d->ny % V != 0;
+  const PdhgRecord<T>* rec = static_cast<const PdhgRecord<T>*>(record);
+  // with a device record the step sizes are not known here and the dispatch below may only depend on the coefficients: e = 0 on
+  // both sides makes the fp64 denominators exactly 1 for every step size (what the straight-line instances assume)
+  if (rec) { tau = sigma = theta = 1.0; }
   // host-side evaluation of everything element-independent, in the kernels' own expression order
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
@@ -369,7 +440,9 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   bool fast = (d->g_fn == PROST_FN_SQUARE || (d->g_fn == PROST_FN_ABS && d->L == 1 && mask == 0x2)) && d->f_fn == PROST_FN_IND_LEQ0 &&
               (mask == 0x2 || (mask == 0 && d->L == 1)) &&
               ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO2(LCHv, G, F, M, R, RAGv, FASTv) PH_LAUNCH((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+  if (rec && (a.g_val[4] != (T)0 || a.f_val[4] != (T)0 || d->g_coeff_ptr[4])) fast = false;
+#define GO3(LCHv, G, F, M, R, RAGv, FASTv, VARTv) PH_LAUNCH((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv, VARTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
+#define GO2(LCHv, G, F, M, R, RAGv, FASTv) do { if (LCHv == 1 && a.varT) GO3(1, G, F, M, R, RAGv, FASTv, true); else GO3(LCHv, G, F, M, R, RAGv, FASTv, false); } while (0)
 #define GO(LCHv, G, F, M, R, FASTv) do { if (rag) GO2(LCHv, G, F, M, R, true, FASTv); else GO2(LCHv, G, F, M, R, false, FASTv); } while (0)
 #define GO_RES(LCHv, G, F, M, FASTv) do { if (out4) GO(LCHv, G, F, M, true, FASTv); else GO(LCHv, G, F, M, false, FASTv); } while (0)
   // measured (4096^2 fp32): non-temporal stores +4 %, non-temporal loads -15 %, no register prefetch -8 %
@@ -385,7 +458,9 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
 #undef GO_RES
 #undef GO
 #undef GO2
+#undef GO3
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused iteration kernel"); }
+  if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid.x, record, tail->iteration, tail->mirror, s);
   if (out4) {
     hipLaunchKernelGGL(fold4_kernel, dim3(1), dim3(kBlock), 0, s, out4, partial, grid.x);
     PH_LAUNCH_END("fold4 kernel");
@@ -408,5 +483,19 @@ int prost_hip_fused_iteration_f64(const prost_hip_fused_desc* d, double* x_new, 
                                   double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols_per_block,
                                   double* res_out4, void* workspace, void* s) {
   return run_iter<double>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols_per_block, res_out4, workspace, s);
+}
+int prost_hip_fused_iteration_rec_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
+                                      void* record, int use_kty, int use_kx_prev, int use_kty_prev, int cols_per_block, double* res_out4, void* workspace,
+                                      int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* s) {
+  if (!record) { set_error("fused iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter<float>(d, x_new, y_new, x, y, y_prev, 1, 1, 1, use_kty, use_kx_prev, use_kty_prev, cols_per_block, res_out4, workspace, s, record, &tail);
+}
+int prost_hip_fused_iteration_rec_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev,
+                                      void* record, int use_kty, int use_kx_prev, int use_kty_prev, int cols_per_block, double* res_out4, void* workspace,
+                                      int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* s) {
+  if (!record) { set_error("fused iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter<double>(d, x_new, y_new, x, y, y_prev, 1, 1, 1, use_kty, use_kx_prev, use_kty_prev, cols_per_block, res_out4, workspace, s, record, &tail);
 }
 }  // extern "C"

@@ -28,12 +28,6 @@ namespace prost_hip {
 constexpr int popcount7b(int m) { int c = 0; for (int k = 0; k < 7; k++) c += (m >> k) & 1; return c; }
 constexpr int slot_ofb(int m, int k) { int c = 0; for (int i = 0; i < k; i++) c += (m >> i) & 1; return c; }
 
-template <class T>
-struct IterParams {           // step sizes of one iteration + the host-evaluated uniform prox terms
-  T tau, sigma, theta;
-  UniformProx<T> ug, uf;
-};
-
 // PF == 0 selects the LDS prefetch ring (see the kernel): resident wavefronts per SIMD of that instance
 constexpr int kRingWaves = 4;
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -50,12 +44,19 @@ struct Col2 {
 // everything they need (y^k, y^(k+1), y^(k+2), x^(k+1), x^(k+2), K^T y^k, K^T y^(k+1), K x^(k+1),
 // K x^(k+2)) is in registers, no extra HBM traffic.
 // PF: columns of loads kept in flight per wave (3 for the straight-line instances at 3 waves/SIMD, 1 otherwise)
-template <class T, int VEC, int GFN, int FFN, int GMASK, int PF, bool FAST, int MODE, bool RAG>
+// VART: position-dependent primal preconditioner (FusedArgs::varT; see fused_iter2d_kernel): the interior instance of a column step
+// (`inner`) is untouched -- every pixel it sees has 4 stencil entries in its column, Tval = Tcls[2] -- and the boundary instance
+// re-evaluates the pixels of the first / last column and row with their own Tau_j through the reference's expression (elem_1d).
+template <class T, int VEC, int GFN, int FFN, int GMASK, int PF, bool FAST, int MODE, bool RAG, bool VART>
 __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRingWaves) : (MODE & 2) ? 2 : (PF > 1 || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
                                                                 FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2,
-                                                                double* __restrict__ partial) {
+                                                                double* __restrict__ partial, const PdhgRecord<T>* __restrict__ rec) {
+  if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
+    if (rec->stop) return;
+    p1 = rec->p; p2 = rec->p;      // a rule evaluation never falls between the two iterations of a launch
+  }
   const long nx = (long)a.nx, ny = (long)a.ny;
   const int lane = threadIdx.x;
   constexpr int kRowsPerWave = (kWave - 2) * VEC;
@@ -150,7 +151,10 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
                     const T (&gc)[Col::NG][VEC], const IterParams<T>& P, T (&xn)[VEC], T (&kt)[VEC]) {
     constexpr bool I = decltype(inner)::value;
     const T tauT = P.tau * a.Tval;
+    constexpr bool kEdges = VART && !I;          // this instance may see pixels with fewer than 4 stencil entries in their column
     T parg[VEC], parg0[kBMask ? VEC : 1];
+    T argv[kEdges ? VEC : 1], tTv[kEdges ? VEC : 1];
+    bool edgev[kEdges ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
@@ -160,7 +164,16 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       if (I || c > 0) divx -= y1p[j];
       const T kty = (T)0 - (divx + divy);
       kt[j] = kty;
-      const T arg = xin[j] - tauT * kty;
+      T tT = tauT;
+      bool edge = false;
+      if (kEdges) {
+        const int cnt = 4 - (c == 0 ? 1 : 0) - (c == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
+        edge = cnt != 4;
+        tT = P.tau * (cnt == 4 ? a.Tval : (cnt == 3 ? a.Tcls[1] : a.Tcls[0]));
+        edgev[kEdges ? j : 0] = edge; tTv[kEdges ? j : 0] = tT;
+      }
+      const T arg = xin[j] - tT * kty;
+      if (kEdges) argv[kEdges ? j : 0] = arg;
       if (FAST) {
         if (kBMask) parg0[j] = arg;
         parg[j] = arg - (((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1]);
@@ -168,8 +181,8 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
         T cf[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? gc[slot_ofb(GMASK, k)][j] : a.g_val[k];
-        if (kUniformG) xn[j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, P.ug);
-        else xn[j] = elem_1d<T, GFN>(a.g_fn, arg, tauT, cf);
+        if (kUniformG && !edge) xn[j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, P.ug);
+        else xn[j] = elem_1d<T, GFN>(a.g_fn, arg, tT, cf);
       }
     }
     if (FAST) {
@@ -190,6 +203,17 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
         // (arg - tau d) / (1 + tau e) = arg for d = e = 0 (elem_operation_1d.hpp:42-44); elsewhere a = 1, the code above
 #pragma unroll
         for (int j = 0; j < VEC; j++) if (is_mask_sentinel(gc[slot_ofb(GMASK, 1)][j])) xn[j] = parg0[kBMask ? j : 0];
+      }
+      if (kEdges) {             // pixels with their own Tau_j: ElemOperation1D as the reference writes it
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          if (edgev[kEdges ? j : 0]) {
+            T cf[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? gc[slot_ofb(GMASK, k)][j] : a.g_val[k];
+            xn[j] = elem_1d<T, GFN>(a.g_fn, argv[kEdges ? j : 0], tTv[kEdges ? j : 0], cf);
+          }
+        }
       }
     }
   };
@@ -327,20 +351,33 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
         stv_o<T, VEC, true, RAG>(x_out, off_of(cb), x2_1, nvalid);
         if (kMid) stv_o<T, VEC, true, RAG>(x_mid, off_of(cb), x1_1, nvalid);
         if (kRes && (size_t)cb >= a.rx0 && (size_t)cb < a.rx1) {   // dual_residual_transform (backend_pdhg.cu:73-94)
+          constexpr bool kEdges = VART && !decltype(inner)::value;
+          T sTv[kEdges ? VEC : 1], iTv[kEdges ? VEC : 1];             // sqrt(Tau_j), 1 / (tau sqrt(Tau_j)) of this column's pixels
+          if (kEdges) {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+              const long row = row0 + j;
+              const int cnt = 4 - (cb == 0 ? 1 : 0) - (cb == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
+              const T sT = cnt == 4 ? sqT : t_sqrt(cnt == 3 ? a.Tcls[1] : a.Tcls[0]);
+              sTv[kEdges ? j : 0] = sT; iTv[kEdges ? j : 0] = cnt == 4 ? inv_tauT : (T)1 / (p2.tau * sT);
+            }
+          }
           if (FAST) {                             // tolerance-compared sums: plain fp32 with fused multiply-adds (see dual)
             T sdd = 0, sdv = 0;
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-              const T w_hat = t_fma(-sqT, kt_1[j], (x1_1[j] - x2_1[j]) * inv_tauT);
-              const T diff = t_fma(sqT, kt_c[j], w_hat);
+              const T sT = kEdges ? sTv[kEdges ? j : 0] : sqT, iT = kEdges ? iTv[kEdges ? j : 0] : inv_tauT;
+              const T w_hat = t_fma(-sT, kt_1[j], (x1_1[j] - x2_1[j]) * iT);
+              const T diff = t_fma(sT, kt_c[j], w_hat);
               if (j < nvalid) { sdd = t_fma(diff, diff, sdd); sdv = t_fma(w_hat, w_hat, sdv); }
             }
             r_dd += (double)sdd; r_dv += (double)sdv;
           } else {
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-              const T w_hat = div_tauT.div(x1_1[j] - x2_1[j]) - sqT * kt_1[j];
-              const T diff = w_hat + sqT * kt_c[j];
+              const T sT = kEdges ? sTv[kEdges ? j : 0] : sqT;
+              const T w_hat = (kEdges && sT != sqT) ? (x1_1[j] - x2_1[j]) / (p2.tau * sT) - sT * kt_1[j] : div_tauT.div(x1_1[j] - x2_1[j]) - sqT * kt_1[j];
+              const T diff = w_hat + sT * kt_c[j];
               if (j < nvalid) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
             }
           }
@@ -409,6 +446,7 @@ static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
 static bool iter2_fast_shape(const prost_hip_fused_desc* d) {
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   if (d->g_b_masked && (!d->g_coeff_ptr[1] || d->g_fn != PROST_FN_SQUARE)) return false;     // the merged stream IS the per-pixel b; square data term
+  if (d->var_T && (d->g_fn != PROST_FN_SQUARE || !d->g_coeff_ptr[1] || d->g_b_masked)) return false;   // position-dependent Tau: one instance (ROF, per-pixel b)
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k] && k != 1) return false;
   return d->g_coeff_val[0] == 1.0 && d->g_coeff_val[2] != 0.0 && d->g_coeff_val[3] == 0.0 && d->g_coeff_val[4] == 0.0 &&
          d->f_coeff_val[0] == 1.0 && d->f_coeff_val[3] == 0.0 && d->f_coeff_val[4] == 0.0;
@@ -449,7 +487,7 @@ static int iter2_chunk_cols(const prost_hip_fused_desc* d, int V, bool res, int 
 
 template <class T>
 static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, T* x_mid, T* y_mid, const double* tau,
-                     const double* sigma, const double* theta, int cols, double* out4, void* ws, void* stream) {
+                     const double* sigma, const double* theta, int cols, double* out4, void* ws, void* stream, void* record = nullptr, const RuleTail* tail = nullptr) {
   constexpr int V = VecOf<T>::N;
   if (!iter2_desc_ok(d, sizeof(T) == 4 ? 0 : 1) || !aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) {
     set_error("fused double iteration: unsupported description"); return 1;
@@ -463,6 +501,12 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   a.cols_per_block = cols;
   a.chunks = (unsigned)((d->nx + cols - 1) / cols);
   if (strips * a.chunks > 0x7fffffffull) { set_error("fused double iteration: grid too large"); return 1; }
+  const PdhgRecord<T>* rec = static_cast<const PdhgRecord<T>*>(record);
+  // with a device record the step sizes are not known here: the dispatch below may only depend on the coefficients.  e = 0 on
+  // both sides makes the fp64 denominators exactly 1 for EVERY step size, which is what the straight-line instances assume
+  const double one2[2] = {1.0, 1.0};
+  if (rec) { tau = sigma = theta = one2; }
+  if (rec && (d->g_coeff_val[4] != 0.0 || d->f_coeff_val[4] != 0.0 || d->g_coeff_ptr[4])) { set_error("fused double iteration: device-resident step sizes need e = 0"); return 1; }
   IterParams<T> p[2];
   for (int i = 0; i < 2; i++) {
     p[i].tau = (T)tau[i]; p[i].sigma = (T)sigma[i]; p[i].theta = (T)theta[i];
@@ -481,7 +525,10 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
   const bool rag = d->ny % V != 0;
   double* partial = static_cast<double*>(ws);
-#define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) PH_LAUNCH((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial)
+#define GO5(G, F, M, PFv, FASTv, MODEv, RAGv, VARTv) PH_LAUNCH((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv, VARTv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial, rec)
+// position-dependent Tau (FusedArgs::varT): instances exist for the straight-line ROF shape with a per-pixel b (square, mask 0x2) -- the
+// shape callers pair on (prost_hip_fused_iteration2_profitable); the others are refused
+#define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) do { if (a.varT) { if constexpr (FASTv && G == PROST_FN_SQUARE && M == 0x2) GO5(G, F, M, PFv, FASTv, MODEv, RAGv, true); else { set_error("fused double iteration: no position-dependent Tau instance for this shape"); return 1; } } else GO5(G, F, M, PFv, FASTv, MODEv, RAGv, false); } while (0)
 // straight-line instances of heights that are a multiple of the vector width prefetch through the LDS ring (PF = 0); ragged
 // heights (4-byte aligned column starts) keep the register ring
 // (PROST_ITER2_NO_RING=1 forces the register ring everywhere: A/B measurements)
@@ -500,7 +547,9 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
 #undef GO
 #undef GO3
 #undef GO4
+#undef GO5
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused double iteration kernel"); }
+  if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid.x, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid.x, s);
   return 0;
 }
@@ -522,5 +571,19 @@ int prost_hip_fused_iteration2_f32(const prost_hip_fused_desc* d, float* x_out, 
 int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, double* x_mid, double* y_mid,
                                    const double* tau, const double* sigma, const double* theta, int cols_per_block, double* res_out4, void* workspace, void* s) {
   return run_iter2<double>(d, x_out, y_out, x, y, x_mid, y_mid, tau, sigma, theta, cols_per_block, res_out4, workspace, s);
+}
+int prost_hip_fused_iteration2_rec_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, float* x_mid, float* y_mid,
+                                       void* record, int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
+                                       prost_hip_pdhg_rule_state* mirror, void* s) {
+  if (!record) { set_error("fused double iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter2<float>(d, x_out, y_out, x, y, x_mid, y_mid, nullptr, nullptr, nullptr, cols_per_block, res_out4, workspace, s, record, &tail);
+}
+int prost_hip_fused_iteration2_rec_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, double* x_mid, double* y_mid,
+                                       void* record, int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
+                                       prost_hip_pdhg_rule_state* mirror, void* s) {
+  if (!record) { set_error("fused double iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter2<double>(d, x_out, y_out, x, y, x_mid, y_mid, nullptr, nullptr, nullptr, cols_per_block, res_out4, workspace, s, record, &tail);
 }
 }  // extern "C"

@@ -74,6 +74,33 @@ def pdhg():
     np.savez_compressed(os.path.join(OUT, "pdhg_rof_16x12x2.npz"), **out)
 
 
+def pdhg64():
+    """the 64 x 64 gray-value ROF problem, residual_iter in {1, 10}, all four step rules; x and y after 2, 10 and 50
+    iterations (z, w follow from them and are covered at 16 x 12 x 2), fp32 for every rule, fp64 for alg2 and boyd"""
+    out = {}
+    nx = ny = 64
+    f = synthetic.rof_image(nx, ny, 1, seed=11)
+    out["f"] = f.astype(np.float32)
+    f = out["f"].astype(np.float64)
+    for dt in (np.float32, np.float64):
+        for step in ("alg1", "alg2", "goldstein", "boyd"):
+            if dt == np.float64 and step not in ("alg2", "boyd"):
+                continue
+            for res_iter in (1, 10):
+                prob, u, q, _ = synthetic.rof_problem(nx, ny, 1, f=f)
+                prob.finalize()
+                b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5)
+                o = prost.options(max_iters=50, num_cback_calls=0, verbose=False)
+                R = ref.RefProblem(prob.data, prob.nrows, prob.ncols, dt)
+                for k in (2, 10, 50):
+                    r = R.pdhg(b[1], o, k)
+                    key = "%s_%s_r%d_k%d" % (np.dtype(dt).name, step, res_iter, k)
+                    out[key + "_x"] = r["x"].astype(dt)
+                    out[key + "_y"] = r["y"].astype(dt)
+                    out[key + "_scal"] = np.array([r[n] for n in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual")])
+    np.savez_compressed(os.path.join(OUT, "pdhg_rof_64x64.npz"), **out)
+
+
 def misc():
     import scipy.sparse as sp
     out = {}
@@ -98,9 +125,9 @@ def misc():
 
 if __name__ == "__main__":
     assert ref.available() or ref.build(), "oracle/_ref is not built and /root/reference is absent"
-    elementwise()
-    pdhg()
-    misc()
+    which = sys.argv[1:] or ["elementwise", "pdhg", "pdhg64", "misc"]
+    for name in which:
+        {"elementwise": elementwise, "pdhg": pdhg, "pdhg64": pdhg64, "misc": misc}[name]()
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):
             print(fn, os.path.getsize(os.path.join(OUT, fn)) // 1024, "KiB")

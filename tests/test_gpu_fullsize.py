@@ -253,3 +253,49 @@ def test_c2_4096_boyd_pair_and_single_launches_take_the_same_decisions():
         assert np.isclose(sa[v], sb[v], rtol=1e-5), v
     for s in solvers.values():
         s.destroy()
+
+
+@pytest.mark.parametrize("step,residual_iter", [("alg2", 10), ("boyd", 5)])
+def test_rof_1024_solved_to_tolerance_stops_where_the_oracle_stops(step, residual_iter):
+    """ROF 1024^2 fp32 solved to the tolerance of example_rof_primaldual.m (1e-4 on all four) against the ORACLE: (a) the trace of a
+    run observed at every residual iteration -- tau, sigma identical (every decision of boyd's rule: the product evaluates it on the
+    device, from residual sums its pair kernel forms in fp32 with FMAs), residual norms and eps to the stated tolerance -- and (b) a
+    complete prost.solve: result string, stopping iteration, x, y, z, w bit for bit.  This is the check that the tolerance-compared
+    residual sums never flip a decision on the way to convergence at a size where they add up 10^6 terms."""
+    n = 1024
+    tol = dict(tol_rel_primal=1e-4, tol_rel_dual=1e-4, tol_abs_primal=1e-4, tol_abs_dual=1e-4)
+    prob, u, q, f = synthetic.rof_problem(n, n, lmb=10.0)
+    b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.5)
+    o = prost.options(max_iters=10000, num_cback_calls=0, verbose=False, **tol)
+    oracle.set_num_threads(16)
+    prob.finalize()
+    orc = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float32)
+    orc.initialize()
+    s = prost.Solver(prob, b, o)
+    changes, k, converged = set(), 0, False
+    worst = 0.0
+    while k < 4000 and not converged:
+        # up to and including the next residual iteration (0, R, 2R, ...): observed right after the rule / the stopping test ran
+        step_k = 1 if k == 0 else residual_iter
+        converged = bool(s.iterate(step_k, checked=True)["converged"])
+        orc.iterate(step_k)
+        k += step_k
+        st, osc = s.state(vectors=False), orc.scalars()
+        assert st["iteration"] == osc["iteration"] == k
+        assert st["tau"] == osc["tau"] and st["sigma"] == osc["sigma"] and st["theta"] == osc["theta"], (k, st["tau"], osc["tau"], st["sigma"], osc["sigma"])
+        changes.add((st["tau"], st["sigma"]))
+        for name in ("primal_res", "dual_res", "eps_primal", "eps_dual"):
+            rel = abs(st[name] - osc[name]) / max(abs(osc[name]), 1e-30)
+            worst = max(worst, rel)
+            assert rel < 2e-3, (k, name, st[name], osc[name])          # near convergence the sums are differences of nearly equal numbers (DESIGN 2)
+        o_conv = osc["primal_res"] < osc["eps_primal"] and osc["dual_res"] < osc["eps_dual"]
+        assert converged == bool(o_conv), (k, st["primal_res"], st["eps_primal"], st["dual_res"], st["eps_dual"], osc)
+    assert converged and 50 < k < 4000, k
+    assert len(changes) >= (3 if step == "boyd" else 10), len(changes)
+    s.destroy()
+    del orc
+    got = prost.solve(prob, b, o)
+    exp = oracle.solve(prob, b, o, np.float32)
+    assert got["result"] == exp["result"] == "Converged." and int(got["iters"]) == int(exp["iters"]) == k, (got["iters"], exp["iters"], k)
+    for v in "xyzw":
+        assert np.array_equal(np.asarray(got[v]), np.asarray(exp[v])), v

@@ -42,7 +42,7 @@ def run_product(prob, backend, opts, iters):
 
 def run_oracle(prob, backend, opts, iters, dtype):
     prob.finalize()
-    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel")}]
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_device_rules")}]
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
     s.initialize()
     s.iterate(iters)
@@ -82,6 +82,28 @@ def test_pdhg_iterates_match_oracle(precision, dtype, step, fused):
                 assert st[name] == ost[name], name
             for name in ("primal_res", "dual_res", "dual_var_norm", "eps_primal", "eps_dual"):
                 assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
+
+
+@pytest.mark.parametrize("precision,dtype,step", [("single", np.float32, "alg1"), ("single", np.float32, "alg2"), ("single", np.float32, "goldstein"),
+                                                  ("single", np.float32, "boyd"), ("double", np.float64, "alg2"), ("double", np.float64, "boyd")])
+def test_pdhg_matches_reference_golden_fixture_64x64(precision, dtype, step):
+    """product (pair / single launches of the gray-value kernels; goldstein / boyd with the rule on the device) vs
+    tests/golden/pdhg_rof_64x64.npz: x and y of the REAL reference backend after 2, 10 and 50 iterations, residual_iter 1 and 10"""
+    prost.set_precision(precision)
+    g = np.load(os.path.join(GOLD, "pdhg_rof_64x64.npz"))
+    name = np.dtype(dtype).name
+    for res_iter in (1, 10):
+        prob, u, q, _ = synthetic.rof_problem(64, 64, 1, f=g["f"].astype(np.float64))
+        b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5)
+        o = prost.options(max_iters=50, num_cback_calls=0, verbose=False)
+        for k in (2, 10, 50):
+            st = run_product(prob, b, o, k)
+            key = "%s_%s_r%d_k%d" % (name, step, res_iter, k)
+            for v in "xy":
+                assert np.array_equal(st[v].astype(dtype), g[key + "_" + v]), (key, v)
+            exp = g[key + "_scal"]
+            got = np.array([st[n] for n in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual")])
+            assert np.allclose(got, exp, rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-4 if dtype == np.float32 else 1e-11), (key, got, exp)
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
@@ -1016,3 +1038,206 @@ def test_large_sparse_blocks_transposed_on_all_host_cores():
         want, orow, ocol = oracle.eval_linop(lin, rhs, False, np.float64)
         assert np.array_equal(np.asarray(got).ravel(), want.ravel()), name
         assert np.array_equal(np.asarray(rowsum).ravel(), orow.ravel()) and np.array_equal(np.asarray(colsum).ravel(), ocol.ravel()), name
+
+
+# ---------------------------------------------------------------------------------------------
+# residual-driven step rules and the stopping test on the device (kernels_pdhg_rule.hip)
+# ---------------------------------------------------------------------------------------------
+RULE_SCALARS = ("tau", "sigma", "theta", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual")
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", ["goldstein", "boyd"])
+@pytest.mark.parametrize("residual_iter", [1, 3, 10])
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_device_resident_step_rules_are_invisible(precision, dtype, step, residual_iter, with_comm):
+    """goldstein / boyd (boyd with residual_iter = 1 is the reference's DEFAULT, pdhg.m:4-14) on the one-kernel 2-D path: batches of
+    iterations run with the rule and the stopping test evaluated ON THE DEVICE, one host wait per batch.  Whatever the caller does --
+    unchecked iteration, the loop of prost.solve, reading the state in the middle, batches cut by the budget, more than one batch
+    (> 240 iterations) -- iterates, every step-size decision (tau, sigma after each stretch), residual norms and iteration counts
+    equal those of the host-side rule EXACTLY, and the iterates equal the oracle's bit for bit.  Tolerances are chosen so that the
+    rules' comparisons flip during the run.  with_comm: a (one-rank, host-callback) communicator -- the sums pass the all-reduce
+    before the rule kernel reads them."""
+    prost.set_precision(precision)
+    if with_comm:
+        prost.comm_init_host(lambda a: None, 1)
+    try:
+        prob, u, q, f = synthetic.rof_problem(44, 252, 1, seed=9)
+        o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=2e-2, tol_rel_dual=2e-2, tol_abs_primal=0, tol_abs_dual=0)
+        runs = {}
+        for dev in (True, False):
+            b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+            b[1]["allow_device_rules"] = dev
+            s = prost.Solver(prob, b, o)
+            trace = []
+            s.iterate(7)                                  # iterations 0, 1 on the host loop, then one short batch
+            trace.append(s.state())
+            s.iterate(500)                                # three batches (240 + 240 + 20)
+            trace.append(s.state(vectors=False))
+            s.iterate(2)                                  # a budget below the batch threshold: host loop
+            s.iterate(31)
+            trace.append(s.state())
+            s.destroy()
+            runs[dev] = trace
+            assert (trace[-1]["device_rule_batches"] >= 4) if dev else trace[-1]["device_rule_batches"] == 0, trace[-1]["device_rule_batches"]
+        changed = set()
+        for a, b_ in zip(runs[True], runs[False]):
+            for v in RULE_SCALARS + ("pair_launches",):
+                assert a[v] == b_[v], (v, a[v], b_[v])
+            changed.add((a["tau"], a["sigma"]))
+            if "x" in a:
+                for v in "xyzw":
+                    assert np.array_equal(a[v], b_[v]), v
+        assert len(changed) >= 2, changed                 # the rule did fire between the read-outs
+        if not with_comm:
+            ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter), o, 540, dtype)
+            assert_same_iterates(runs[True][-1], ost)
+            assert runs[True][-1]["tau"] == ost["tau"] and runs[True][-1]["sigma"] == ost["sigma"]
+    finally:
+        if with_comm:
+            prost.comm_destroy()
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", ["goldstein", "boyd"])
+@pytest.mark.parametrize("residual_iter,cbacks", [(1, 0), (4, 7), (10, 0)])
+def test_device_resident_stopping_test_stops_where_the_host_loop_stops(precision, dtype, step, residual_iter, cbacks):
+    """complete prost.solve runs that stop on their tolerance in the MIDDLE of a device batch: result, iteration count and x, y, z, w
+    equal the host-side rule's and the oracle's (solver.cu:141-150 evaluated by the rule kernel; the launches enqueued behind the
+    stopping iteration return at once and the buffer roles are put back).  cbacks: scheduled observations cut the batches short."""
+    prost.set_precision(precision)
+    prob, u, q, f = synthetic.rof_problem(60, 124, 1, seed=4)
+    for tol in (1e-2, 2e-3):
+        o = prost.options(max_iters=3000, num_cback_calls=cbacks, verbose=False, tol_rel_primal=tol, tol_rel_dual=tol, tol_abs_primal=tol, tol_abs_dual=tol)
+        res = {}
+        for dev in (True, False):
+            b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+            b[1]["allow_device_rules"] = dev
+            res[dev] = prost.solve(prob, b, o)
+        exp = oracle.solve(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter), o, dtype)
+        assert res[True]["result"] == res[False]["result"] == exp["result"] == "Converged.", (res[True]["result"], exp["result"])
+        assert int(res[True]["iters"]) == int(res[False]["iters"]) == int(exp["iters"]), (res[True]["iters"], res[False]["iters"], exp["iters"])
+        assert int(res[True]["iters"]) >= 5            # (the batches start at iteration 2)
+        for v in "xyzw":
+            assert np.array_equal(np.asarray(res[True][v]), np.asarray(res[False][v])), v
+            assert np.array_equal(np.asarray(res[True][v]), np.asarray(exp[v])), v
+    # the checked loop, entered again after it has stopped: one more iteration and the same answer, like the host loop
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=3e-2, tol_rel_dual=3e-2, tol_abs_primal=3e-2, tol_abs_dual=3e-2)
+    its = {}
+    for dev in (True, False):
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+        b[1]["allow_device_rules"] = dev
+        s = prost.Solver(prob, b, o)
+        seq = [s.iterate(1000, checked=True)["converged"], s.state(vectors=False)["iteration"]]
+        seq += [s.iterate(1000, checked=True)["converged"], s.state(vectors=False)["iteration"]]
+        s.iterate(40)                                          # unchecked: runs all 40 whatever the residuals say
+        seq.append(s.state(vectors=False)["iteration"])
+        st = s.state()
+        s.destroy()
+        its[dev] = (seq, st)
+    assert its[True][0] == its[False][0] and its[True][0][0] and its[True][0][2] and its[True][0][3] == its[True][0][1] + 1, its[True][0]
+    assert its[True][0][4] == its[True][0][3] + 40
+    for v in "xyzw":
+        assert np.array_equal(its[True][1][v], its[False][1][v]), v
+
+
+# ---------------------------------------------------------------------------------------------
+# gradients handed over as sparse matrices on the fused kernels (position-dependent Tau)
+# ---------------------------------------------------------------------------------------------
+def _rof_sparse_gradient(nx, ny, f, lmb, as_block=False, data="square"):
+    """example_rof_primal.m / example_rof_primaldual.m with the gradient written as prost.block.sparse(spmat_gradient2d(nx, ny, 1))"""
+    n = nx * ny
+    u, q = prost.variable(n), prost.variable(2 * n)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d(data, 1, f, lmb))
+    prob.add_function(q, prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1))
+    prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, 1) if as_block else prost.block.sparse(spmat_gradient2d(nx, ny, 1)))
+    return prob
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", STEPS)
+def test_gradient_handed_over_as_a_sparse_matrix_runs_the_fused_kernels(precision, dtype, step):
+    """prost.block.sparse(spmat_gradient2d(nx, ny, 1)) -- the way example_rof_primal.m:10,28, example_nonconvex_rof.m:13,45 and
+    example_deblurring.m:10,37 write the operator -- is recognised entry for entry and runs the one-kernel / two-iterations-per-launch
+    gradient kernels with the preconditioners THAT MATRIX has (Tau_j = 1 / column sum: 1/4 inside, 1/3 on the edges, 1/2 in the corners;
+    problem.cu:262-287), not the constants of block.gradient2d (block_gradient2d.cu:154-163).  x, y, z, w, the step sizes and the
+    preconditioner vectors equal the ORACLE's -- which runs the matrix as block.sparse -- bit for bit, and the generic path's
+    (set_quirks(sparse_stencils=0)); the same description with block.gradient2d gives different iterates (so the test would notice
+    the wrong preconditioners).  Heights on and off the vector width, pair and single launches, residual iterations."""
+    prost.set_precision(precision)
+    try:
+        for (nx, ny), res_iter in (((40, 64), 3), ((33, 30), 1), ((16, 1028), 10), ((21, 263), 4)):
+            f = synthetic.rof_image(nx, ny, 1, seed=5)
+            prob = _rof_sparse_gradient(nx, ny, f, 8.0)
+            b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5)
+            o = prost.options(max_iters=100, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=0, tol_abs_dual=0)
+            info = prost.problem_info(prob)
+            tr = np.asarray(info["scaling_right"]).reshape(nx, ny)
+            assert set(np.round(1 / tr.ravel()).astype(int)) == {2, 3, 4} and np.all(np.asarray(info["scaling_left"]) == 0.5)
+            for k in (1, 2, 11, 50):
+                st = run_product(prob, b, o, k)
+                assert st["path"] == "pdhg:fused-grad2d(sparse)", st["path"]
+                ost = run_oracle(prob, b, o, k, dtype)
+                assert_same_iterates(st, ost)
+                for name in ("tau", "sigma", "theta"):
+                    assert st[name] == ost[name], name
+                for name in ("primal_res", "dual_res", "dual_var_norm", "eps_primal", "eps_dual"):
+                    assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
+            if step in ("alg2", "boyd"):
+                assert st["pair_launches"] > 0 or ny % (4 if dtype == np.float32 else 2), (nx, ny, st["pair_launches"])
+            prost.set_quirks(sparse_stencils=0)
+            gen = run_product(prob, b, o, 50)
+            prost.set_quirks(sparse_stencils=1)
+            assert gen["path"] == "pdhg:generic"
+            assert_same_iterates(st, gen)
+            blk = run_product(_rof_sparse_gradient(nx, ny, f, 8.0, as_block=True), b, o, 50)
+            assert blk["path"] == "pdhg:fused-grad2d" and not np.array_equal(blk["x"], st["x"])
+        # a complete solve stops where the oracle stops
+        prob = _rof_sparse_gradient(48, 60, synthetic.rof_image(48, 60, 1, seed=2), 8.0)
+        b = prost.backend.pdhg(stepsize=step, residual_iter=2, alg2_gamma=0.5)
+        o = prost.options(max_iters=4000, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=1e-3, tol_abs_dual=1e-3)
+        got, exp = prost.solve(prob, b, o), oracle.solve(prob, b, o, dtype)
+        assert got["result"] == exp["result"] == "Converged." and int(got["iters"]) == int(exp["iters"]) and got["path"] == "pdhg:fused-grad2d(sparse)"
+        for v in "xyzw":
+            assert np.array_equal(np.asarray(got[v]), np.asarray(exp[v])), v
+    finally:
+        prost.set_quirks(sparse_stencils=1)
+
+
+def test_matrices_that_are_not_quite_the_gradient_stay_on_the_generic_path():
+    """the recognition compares every entry: two labels (another zero-row structure), a perturbed value, a missing entry, the TV-L1 data
+    term (no position-dependent instance of the pair kernel: single launches), the inpainting mask (per-pixel a) -- all still equal
+    the oracle; the first three on the generic path"""
+    prost.set_precision("single")
+    nx, ny = 24, 40
+    n = nx * ny
+    f = synthetic.rof_image(nx, ny, 1, seed=7)
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=5, alg2_gamma=0.5)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    K = sp.csc_matrix(spmat_gradient2d(nx, ny, 1))
+    K2 = K.copy(); K2.data[7] = 1.5
+    K3 = K.tolil(); K3[3, 3] = 0; K3 = sp.csc_matrix(K3)
+    for name, M, rows, cols in (("two labels", spmat_gradient2d(nx, ny // 2, 2), 2 * n, n), ("perturbed", K2, 2 * n, n), ("missing", K3, 2 * n, n)):
+        u, q = prost.variable(cols), prost.variable(rows)
+        prob = prost.min_max_problem([u], [q])
+        prob.add_function(u, prost.function.sum_1d("square", 1, f, 8.0))
+        prob.add_function(q, prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1))
+        prob.add_dual_pair(u, q, prost.block.sparse(M))
+        st = run_product(prob, b, o, 20)
+        assert st["path"] == "pdhg:generic", (name, st["path"])
+        assert_same_iterates(st, run_oracle(prob, b, o, 20, np.float32))
+    for data in ("abs",):
+        prob = _rof_sparse_gradient(nx, ny, f, 0.7, data=data)
+        st = run_product(prob, b, o, 33)
+        assert st["path"] == "pdhg:fused-grad2d(sparse)" and st["pair_launches"] == 0
+        assert_same_iterates(st, run_oracle(prob, b, o, 33, np.float32))
+    mask = (np.arange(n) % 3 != 0).astype(np.float64)
+    u, q = prost.variable(n), prost.variable(2 * n)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d("square", mask, f, 8.0))
+    prob.add_function(q, prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1))
+    prob.add_dual_pair(u, q, prost.block.sparse(K))
+    st = run_product(prob, b, o, 33)
+    assert st["path"] == "pdhg:fused-grad2d(sparse)"
+    assert_same_iterates(st, run_oracle(prob, b, o, 33, np.float32))

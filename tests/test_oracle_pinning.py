@@ -81,6 +81,31 @@ def test_pdhg_iterates_golden(dtype, step, res_iter):
     assert np.isclose(s.problem.normest(), g[name + "_normest"][0], rtol=1e-6)
 
 
+@pytest.mark.parametrize("dtype,step", [(np.float32, "alg1"), (np.float32, "alg2"), (np.float32, "goldstein"), (np.float32, "boyd"),
+                                        (np.float64, "alg2"), (np.float64, "boyd")])
+@pytest.mark.parametrize("res_iter", [1, 10])
+def test_pdhg_iterates_golden_64x64(dtype, step, res_iter):
+    """64 x 64 gray-value ROF, residual_iter in {1, 10}: oracle == the REAL reference's backend_pdhg.cu
+    (tests/golden/pdhg_rof_64x64.npz, made by make_golden.py from oracle/_ref), x and y bit for bit after 2, 10 and 50 iterations"""
+    g = np.load(os.path.join(GOLD, "pdhg_rof_64x64.npz"))
+    prob, u, q, _ = synthetic.rof_problem(64, 64, 1, f=g["f"].astype(np.float64))
+    prob.finalize()
+    b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5)
+    o = prost.options(max_iters=50, num_cback_calls=0, verbose=False)
+    name = np.dtype(dtype).name
+    for k in (2, 10, 50):
+        s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, dtype)
+        s.initialize()
+        s.iterate(k)
+        st, sc = s.state(), s.scalars()
+        key = "%s_%s_r%d_k%d" % (name, step, res_iter, k)
+        for v in "xy":
+            assert np.array_equal(st[v].astype(dtype), g[key + "_" + v]), (key, v)
+        exp = g[key + "_scal"]
+        got = np.array([sc[n] for n in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual")])
+        assert np.allclose(got, exp, rtol=5e-6 if dtype == np.float32 else 1e-13, atol=1e-4 if dtype == np.float32 else 1e-12), (key, got, exp)
+
+
 def test_misc_golden():
     g = np.load(os.path.join(GOLD, "misc.npz"))
     v, ri, cs = oracle.csr2csc(23, 31, g["csr_val"], g["csr_ind"], g["csr_ptr"])

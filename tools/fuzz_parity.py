@@ -32,7 +32,7 @@ import prost_amd as prost
 from prost_amd import synthetic
 
 HEIGHTS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 30, 62, 63, 64, 66, 124, 126, 128, 130, 247, 248, 249, 250, 252, 253, 256, 260, 496, 500, 504, 508, 510, 1000, 1028]
-NOT_ORACLE = ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_single_kernel")
+NOT_ORACLE = ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_single_kernel", "allow_device_rules")
 
 
 def draw(rng):
