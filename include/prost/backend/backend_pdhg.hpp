@@ -128,7 +128,8 @@ class BackendPDHG : public Backend<T> {
   bool batch_last_launch_evaluated_ = false;
   size_t dev_batches_ = 0;
   void* rule_rec_ = nullptr;               // device: PdhgRecord<T>
-  prost_hip_pdhg_rule_state* rule_mirror_ = nullptr;   // pinned host
+  prost_hip_pdhg_rule_state* rule_mirror_ = nullptr;   // pinned host: the scalars of the last evaluation, fetched at the end of a batch ...
+  prost_hip_pdhg_rule_state* rule_mirror_dev_ = nullptr;   // ... from the device copy the rule kernels write
   struct BatchMark { size_t iteration_after, pair_launches; T *x, *xp, *y, *yp; bool prev_stale; };
   std::vector<BatchMark> batch_marks_;     // one per residual iteration of the running batch: the state to return to if it stopped there
   int PerformIterationsDevice(int budget);

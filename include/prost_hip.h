@@ -284,7 +284,7 @@ typedef struct {
                             /* problem.cu:262-287 forms it -- T_cls[0..2] for pixels with 2, 3, 4 stencil entries in their column         */
                             /* (corner, edge, interior; count = 4 - [x == 0] - [x == nx - 1] - [y == 0] - [y == ny - 1]), T_val = T_cls[2]. */
                             /* Sigma stays uniform (the all-zero rows of the matrix inherit 1/2, problem.cu:267-286).  Honoured by        */
-                            /* prost_hip_fused_iteration / _iteration2 (L == 1); every other fused entry point refuses such a description. */
+                            /* prost_hip_fused_iteration (L <= 2), _iteration2 (L == 1, ROF shape), _iteration_mc (L = 3, 4); the others refuse it.   */
 } prost_hip_fused_desc;
 /* Folds a BINARY per-element coefficient a of ElemOperation1D (elem_operation_1d.hpp:42-44: a == 0 skips the function, the
  * element passes through) into the b stream: bm[i] = a[i] == 0 ? sentinel : (b ? b[i] : b_val), sentinel = a quiet NaN with the
@@ -362,8 +362,9 @@ int prost_hip_fused_iteration2_chunk_cols(const prost_hip_fused_desc* desc, int 
  *   _apply : one evaluation on sums4 = {primal diff^2, primal var^2, dual diff^2, dual var^2} (device or pinned host doubles, as
  *            prost_hip_fused_iteration* and the all-reduce leave them) for the residual iteration with index `iteration`
  *            (BackendPDHG::iteration_ when the reference calls UpdateResidualsAndStepsizes).
- *   mirror : optional PINNED HOST struct that receives every scalar after the evaluation; valid once the stream has been
- *            synchronised.  Nothing here waits for the device.
+ *   mirror : optional struct (device memory, or pinned host memory the device can write) that receives every scalar after the
+ *            evaluation; valid once the stream has been synchronised (and the struct copied, if it lives on the device).  Nothing
+ *            here waits for the device.
  * prost_hip_fused_iteration_rec / _iteration2_rec: the launches of prost_hip_fused_iteration / _iteration2 with tau, sigma, theta
  * (and the prox terms derived from them) read from the record by the kernel instead of passed by value; both iterations of a
  * double-iteration launch use the record's current values.  Need scalar e = 0 on both proxes for the straight-line instances. */

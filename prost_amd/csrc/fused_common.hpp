@@ -119,10 +119,25 @@ struct FusedArgs {
 };
 
 // step sizes of one iteration + the element-independent prox terms that go with them (device_math.hpp: UniformProx)
+// the step-size dependent terms of prox_g for the pixels whose Tau_j differs from the interior's (FusedArgs::varT): the step
+// c a^2 tau Tau_j and the divisor 1 + step of Function1DSquare with its reciprocal, per class (2 / 3 stencil entries per column)
+template <class T>
+struct EdgeTerms {
+  UniformDiv sq;
+  T step;
+};
+template <class T>
+__host__ __device__ inline EdgeTerms<T> make_edge_terms(const T* g_val, T tauT) {
+  const UniformProx<T> u = make_uniform_prox<T>(g_val, tauT);
+  EdgeTerms<T> e;
+  e.sq = u.sq; e.step = u.step;
+  return e;
+}
 template <class T>
 struct IterParams {
   T tau, sigma, theta;
   UniformProx<T> ug, uf;
+  EdgeTerms<T> ec[2];          // varT only: classes Tcls[0] (corner), Tcls[1] (edge)
 };
 
 // Device-resident step sizes for the residual-driven rules (goldstein, boyd; kernels_pdhg_rule.hip).  The reference forms
@@ -143,6 +158,8 @@ struct PdhgRecord {
   T tol_abs_primal, tol_abs_dual, tol_rel_primal, tol_rel_dual;
   double sqrt_rows, sqrt_cols;       // sqrt of the GLOBAL sizes (backend.hpp:71-74)
   T g_val[7], f_val[7], Tval, Sval;  // what make_uniform_prox needs beside the step size
+  int varT;                          // FusedArgs::varT and the two other classes of Tau_j
+  T Tcls[2];
   unsigned long long evaluations;    // rule evaluations since prost_hip_pdhg_rule_begin
   unsigned long long stop_iteration;
 };

@@ -59,7 +59,7 @@ bool BackendPDHG<T>::TryFused() {
   bool as_matrix = false;
   from_matrix_ = false;
   if (blk->describe(bd) && (bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D)) {}
-  else if (blk->stencil_shape(bd) && bd.kind == BlockDesc::kGradient2D && bd.L == 1) as_matrix = true;
+  else if (blk->stencil_shape(bd) && bd.kind == BlockDesc::kGradient2D && bd.L >= 1 && bd.L <= 4) as_matrix = true;
   else return false;
   if (bd.label_first) return false;
   if (blk->row() != 0 || blk->col() != 0 || blk->nrows() != prob.nrows() || blk->ncols() != prob.ncols()) return false;
@@ -81,15 +81,17 @@ bool BackendPDHG<T>::TryFused() {
     if (owned_x1_ != 0 || bd.nx < 4 || bd.ny < 4) return false;
     const std::vector<T>& tr = prob.scaling_right_host();
     const size_t nx = bd.nx, ny = bd.ny;
-    if (tr.size() != nx * ny) return false;
+    if (tr.size() != nx * ny * bd.L) return false;
     const T cls[3] = {tr[0], tr[1], tr[ny + 1]};            // corner, edge, interior
     std::atomic<bool> same(true);
-    ParallelFor(nx, [&](size_t b, size_t e) {
-      for (size_t x = b; x < e && same.load(std::memory_order_relaxed); x++)
+    ParallelFor(nx * bd.L, [&](size_t b, size_t e) {         // (every channel repeats the one-channel matrix)
+      for (size_t xl = b; xl < e && same.load(std::memory_order_relaxed); xl++) {
+        const size_t x = xl % nx;
         for (size_t y = 0; y < ny; y++) {
           const int cnt = 4 - (x == 0) - (x == nx - 1) - (y == 0) - (y == ny - 1);
-          if (tr[x * ny + y] != cls[cnt - 2]) { same.store(false); return; }
+          if (tr[xl * ny + y] != cls[cnt - 2]) { same.store(false); return; }
         }
+      }
     });
     if (!same.load()) return false;
     tv = cls[2];
@@ -108,7 +110,8 @@ bool BackendPDHG<T>::TryFused() {
   desc_.T_val = (double)tv; desc_.S_val = (double)sv;
   // (position-dependent Tau: the one-kernel iteration is the only fused form; the two-pass kernels refuse it)
   from_matrix_ = as_matrix;
-  if (desc_.var_T) return opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
+  if (desc_.var_T) return opts_.allow_single_kernel && (prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1 ||
+                                                        prost_hip_fused_iteration_mc_supported(&desc_, dtype_id<T>()) == 1);
   return prost_hip_fused_supported(&desc_, dtype_id<T>()) == 1;
 }
 
@@ -216,6 +219,9 @@ void BackendPDHG<T>::Initialize() {
   if (dev_rules_) {
     CheckHip(prost_hip_malloc(&rule_rec_, prost_hip_pdhg_rule_record_bytes()), "malloc");
     CheckHip(prost_hip_host_alloc((void**)&rule_mirror_, sizeof(prost_hip_pdhg_rule_state)), "host_alloc");
+    // (the rule kernels write their scalars to a DEVICE copy, fetched once per batch: ~20 stores over PCIe per residual iteration
+    // cost the one-thread epilogue ~4 us -- a fifth of an iteration at 1024^2)
+    CheckHip(prost_hip_malloc((void**)&rule_mirror_dev_, sizeof(prost_hip_pdhg_rule_state)), "malloc");
   }
 
   this->primal_var_norm_ = this->dual_var_norm_ = this->primal_residual_ = this->dual_residual_ = 0;
@@ -246,6 +252,7 @@ void BackendPDHG<T>::Release() {
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
   if (rule_rec_) { prost_hip_free(rule_rec_); rule_rec_ = nullptr; }
   if (rule_mirror_) { prost_hip_host_free(rule_mirror_); rule_mirror_ = nullptr; }
+  if (rule_mirror_dev_) { prost_hip_free(rule_mirror_dev_); rule_mirror_dev_ = nullptr; }
   batch_marks_.clear();
   if (side_stream_) { prost_hip_stream_synchronize(side_stream_); prost_hip_stream_destroy(side_stream_); side_stream_ = nullptr; }
   if (ev_res_ready_) { prost_hip_event_destroy(ev_res_ready_); ev_res_ready_ = nullptr; }
@@ -359,7 +366,7 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
   ResolveResiduals();                      // (sums of the host loop still in flight: the rule's input state must be final)
   spec_valid_ = false;
   CheckHip(Api<T>::pdhg_rule_begin(rule_rec_, &o, &desc_, (double)tau_, (double)sigma_, (double)theta_, (double)arg_alpha_, arb_l_, arb_u_,
-                                   stop_on_convergence_ ? 1 : 0, rule_mirror_, s), "pdhg_rule_begin");
+                                   stop_on_convergence_ ? 1 : 0, rule_mirror_dev_, s), "pdhg_rule_begin");
   batch_marks_.clear();
   batch_last_launch_evaluated_ = false;
   in_device_batch_ = true;
@@ -379,6 +386,7 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
   } catch (...) { in_device_batch_ = false; throw; }
   in_device_batch_ = false;
   dev_batches_++;
+  CheckHip(prost_hip_memcpy_d2h(rule_mirror_, rule_mirror_dev_, sizeof(prost_hip_pdhg_rule_state), s), "memcpy_d2h");
   CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");          // the batch's ONE host wait
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   const prost_hip_pdhg_rule_state& m = *rule_mirror_;
@@ -453,7 +461,7 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
       CheckHip(Api<T>::fused_iteration2_rec(&desc_pair_, store_mid ? x_spare_.data() : x_prev_.data(), store_mid ? y_spare_.data() : y_prev_.data(), x_.data(),
                                             y_.data(), store_mid ? x_prev_.data() : nullptr, store_mid ? y_prev_.data() : nullptr, rule_rec_, 0,
                                             residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, this->comm_ ? 0 : 1,
-                                            (unsigned long long)iteration_, rule_mirror_, s), "fused_iteration2_rec");
+                                            (unsigned long long)iteration_, rule_mirror_dev_, s), "fused_iteration2_rec");
     else if (!store_mid)
       CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
                                         residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
@@ -559,7 +567,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
       if (in_device_batch_)
         CheckHip(Api<T>::fused_iteration_rec(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, rule_rec_,
                                              iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr,
-                                             res ? workspace_ : nullptr, this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_, s), "fused_iteration_rec");
+                                             res ? workspace_ : nullptr, this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_dev_, s), "fused_iteration_rec");
       else
       CheckHip(Api<T>::fused_iteration(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_,
                                        (double)sigma_, (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0,
@@ -705,7 +713,7 @@ void BackendPDHG<T>::FinishResiduals() {
     // host memory either way.
     if (this->comm_) {
       CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
-      CheckHip(Api<T>::pdhg_rule_apply(rule_rec_, res_dev_, (unsigned long long)iteration_, rule_mirror_, s), "pdhg_rule_apply");
+      CheckHip(Api<T>::pdhg_rule_apply(rule_rec_, res_dev_, (unsigned long long)iteration_, rule_mirror_dev_, s), "pdhg_rule_apply");
     }
     batch_marks_.push_back({iteration_ + 1, pair_launches_, x_.data(), x_prev_.data(), y_.data(), y_prev_.data(), prev_stale_});
     batch_last_launch_evaluated_ = true;

@@ -41,17 +41,19 @@ struct ColIn {            // everything loaded for one column
 // VART: the primal preconditioner depends on the position (FusedArgs::varT: the gradient handed over as the sparse matrix
 // spmat_gradient2d, Tau_j = 1 / column sum).  Interior pixels (4 stencil entries in their column) run the code of the uniform
 // instance with Tval = Tcls[2]; pixels of the first / last column and row -- 3 or 2 entries -- evaluate the reference's own
-// expression with their Tau_j (elem_1d: ElemOperation1D as written) and the residual terms with their sqrt(Tau_j).  LCH == 1.
+// expression with their Tau_j (elem_1d: ElemOperation1D as written; the straight-line instances: the divisor 1 + step_j of the pixel's
+// class, EdgeTerms) and the residual terms with their sqrt(Tau_j).  The same for every channel.
 template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, bool RAG, bool FAST, bool VART>
 __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
                                                              const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma, T theta,
-                                                             UniformProx<T> ug, UniformProx<T> uf,
+                                                             UniformProx<T> ug, UniformProx<T> uf, EdgeTerms<T> ec0, EdgeTerms<T> ec1,
                                                              bool use_kty, bool use_kx_prev, bool use_kty_prev,
                                                              double* __restrict__ partial, const PdhgRecord<T>* __restrict__ rec) {
   if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
     if (rec->stop) return;
     tau = rec->p.tau; sigma = rec->p.sigma; theta = rec->p.theta; ug = rec->p.ug; uf = rec->p.uf;
+    if (VART) { ec0 = rec->p.ec[0]; ec1 = rec->p.ec[1]; }
   }
   const size_t nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x;
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
       if (RES) { upp = lane_up(in.p2[RES ? l : 0][RES ? VEC - 1 : 0]); if (lane == 0) upp = in.upp[RES ? l : 0]; }
       T ktyv[VEC], parg[VEC];
       T argv[VART ? VEC : 1], tTv[VART ? VEC : 1], sTv[VART ? VEC : 1];
-      bool edgev[VART ? VEC : 1];
+      bool edgev[VART ? VEC : 1], cornerv[VART ? VEC : 1];
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         const size_t row = row0 + j;
@@ -127,7 +129,18 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         if (row > 0) divy -= (j > 0 ? in.y2[l][j > 0 ? j - 1 : 0] : up);
         T divx = (c < nx - 1) ? in.y1[l][j] : (T)0;
         if (have_prev) divx -= prev.y1[l][j];
-        const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+        T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+        if (VART && use_kty) {
+          // K^T y as the MATRIX's transpose sums it -- a CSR row of the stored transpose (csr_spmv: sum = 0; sum += val * x in column
+          // order, i.e. d/dx rows before d/dy rows, the left / upper neighbour's +1 before the pixel's own -1): the association the
+          // oracle's block.sparse uses, so that this path stays bit for bit with it (the stencil form above rounds differently)
+          T s = 0;
+          if (have_prev) s += prev.y1[l][j];
+          if (c < nx - 1) s -= in.y1[l][j];
+          if (row > 0) s += (j > 0 ? in.y2[l][j > 0 ? j - 1 : 0] : up);
+          if (row < ny - 1) s -= in.y2[l][j];
+          kty = s;
+        }
         ktyv[j] = kty;
         T tT = tauT;
         bool edge = false;
@@ -136,7 +149,7 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
           edge = cnt != 4;
           const T Tj = cnt == 4 ? a.Tval : (cnt == 3 ? a.Tcls[1] : a.Tcls[0]);
           tT = tau * Tj;
-          edgev[VART ? j : 0] = edge; tTv[VART ? j : 0] = tT; sTv[VART ? j : 0] = edge ? t_sqrt(Tj) : sqT;
+          edgev[VART ? j : 0] = edge; cornerv[VART ? j : 0] = cnt == 2; tTv[VART ? j : 0] = tT; sTv[VART ? j : 0] = edge ? t_sqrt(Tj) : sqT;
         }
         const T arg = in.x[l][j] - tT * kty;
         if (VART) argv[VART ? j : 0] = arg;
@@ -159,14 +172,22 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
         }
 #pragma unroll
         for (int j = 0; j < VEC; j++) xn[l][j] = r[j] + (((GMASK >> 1) & 1) ? in.gc[l][slot_of(GMASK, 1)][j] : a.g_val[1]);
-        if (VART) {            // pixels with their own Tau_j: ElemOperation1D as the reference writes it (the uniform terms do not apply)
+        if (VART) {
+          // pixels with their own Tau_j: the same F_prox(v - b; step_j) + b with the step / the divisor 1 + step_j of the pixel's class
+          // (EdgeTerms, formed once per launch) -- bit for bit what elem_1d evaluates for a = 1, d = e = 0
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
             if (edgev[VART ? j : 0]) {
-              T cf[7];
-#pragma unroll
-              for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? in.gc[l][slot_of(GMASK, k)][j] : a.g_val[k];
-              xn[l][j] = elem_1d<T, GFN>(a.g_fn, argv[VART ? j : 0], tTv[VART ? j : 0], cf);
+              const bool cn = cornerv[VART ? j : 0];
+              const T bj = ((GMASK >> 1) & 1) ? in.gc[l][slot_of(GMASK, 1)][j] : a.g_val[1];
+              const T pj = argv[VART ? j : 0] - bj;
+              T rj;
+              if (GFN == PROST_FN_SQUARE) {
+                UniformDiv dv;
+                dv.D = cn ? ec0.sq.D : ec1.sq.D; dv.rD = cn ? ec0.sq.rD : ec1.sq.rD;
+                rj = div_to_float_exact(pj, dv);
+              } else rj = f1d_apply<T, GFN>(a.g_fn, pj, cn ? ec0.step : ec1.step, a.g_val[5], a.g_val[6]);
+              xn[l][j] = rj + bj;
             }
           }
         }
@@ -180,7 +201,15 @@ __global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_n
           if (row > 0) dpy -= (j > 0 ? in.p2[ll][RES && j > 0 ? j - 1 : 0] : upp);
           T dpx = (c < nx - 1) ? in.p1[ll][jj] : (T)0;
           if (have_prev) dpx -= prev.p1[ll][jj];
-          const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
+          T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
+          if (VART && use_kty_prev) {          // the same sum in the matrix's order (see the primal step)
+            T s = 0;
+            if (have_prev) s += prev.p1[ll][jj];
+            if (c < nx - 1) s -= in.p1[ll][jj];
+            if (row > 0) s += (j > 0 ? in.p2[ll][RES && j > 0 ? j - 1 : 0] : upp);
+            if (row < ny - 1) s -= in.p2[ll][jj];
+            ktyp = s;
+          }
           const T sT = VART ? sTv[VART ? j : 0] : sqT;
           const T w_hat = (VART && edgev[VART ? j : 0]) ? (in.x[l][j] - xn[l][j]) / (tau * sT) - sT * ktyp : div_tauT.div(in.x[l][j] - xn[l][j]) - sqT * ktyp;
           const T diff = w_hat + sT * ktyv[j];
@@ -373,7 +402,6 @@ int launch_fold4(double* out4, const double* partial, unsigned nslots, hipStream
 static bool iter_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   if (!d || d->is3d) return false;
   if (d->nx < 2 || d->ny < 2 || d->L < 1 || d->L > 2) return false;
-  if (d->var_T && d->L != 1) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   const int V = dtype == 0 ? 4 : 2;
   for (int k = 0; k < 7; k++) {
@@ -435,14 +463,15 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   // host-side evaluation of everything element-independent, in the kernels' own expression order
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
+  const EdgeTerms<T> ec0 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[0]) : EdgeTerms<T>(), ec1 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[1]) : EdgeTerms<T>();
   // straight-line instance for the ROF shape (square / ind_leq0 with scalar a = 1, d = e = 0 on both sides); run-time
   // dispatched otherwise
   bool fast = (d->g_fn == PROST_FN_SQUARE || (d->g_fn == PROST_FN_ABS && d->L == 1 && mask == 0x2)) && d->f_fn == PROST_FN_IND_LEQ0 &&
               (mask == 0x2 || (mask == 0 && d->L == 1)) &&
               ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
   if (rec && (a.g_val[4] != (T)0 || a.f_val[4] != (T)0 || d->g_coeff_ptr[4])) fast = false;
-#define GO3(LCHv, G, F, M, R, RAGv, FASTv, VARTv) PH_LAUNCH((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv, VARTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
-#define GO2(LCHv, G, F, M, R, RAGv, FASTv) do { if (LCHv == 1 && a.varT) GO3(1, G, F, M, R, RAGv, FASTv, true); else GO3(LCHv, G, F, M, R, RAGv, FASTv, false); } while (0)
+#define GO3(LCHv, G, F, M, R, RAGv, FASTv, VARTv) PH_LAUNCH((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv, VARTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
+#define GO2(LCHv, G, F, M, R, RAGv, FASTv) do { if (a.varT) GO3(LCHv, G, F, M, R, RAGv, FASTv, true); else GO3(LCHv, G, F, M, R, RAGv, FASTv, false); } while (0)
 #define GO(LCHv, G, F, M, R, FASTv) do { if (rag) GO2(LCHv, G, F, M, R, true, FASTv); else GO2(LCHv, G, F, M, R, false, FASTv); } while (0)
 #define GO_RES(LCHv, G, F, M, FASTv) do { if (out4) GO(LCHv, G, F, M, true, FASTv); else GO(LCHv, G, F, M, false, FASTv); } while (0)
   // measured (4096^2 fp32): non-temporal stores +4 %, non-temporal loads -15 %, no register prefetch -8 %

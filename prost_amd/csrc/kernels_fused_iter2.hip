@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     constexpr bool kEdges = VART && !I;          // this instance may see pixels with fewer than 4 stencil entries in their column
     T parg[VEC], parg0[kBMask ? VEC : 1];
     T argv[kEdges ? VEC : 1], tTv[kEdges ? VEC : 1];
-    bool edgev[kEdges ? VEC : 1];
+    bool edgev[kEdges ? VEC : 1], cornerv[kEdges ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const long row = row0 + j;
@@ -162,7 +162,15 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       if (I || row > 0) divy -= (j > 0) ? y2c[(j + VEC - 1) % VEC] : up;
       T divx = (I || c < nx - 1) ? y1c[j] : (T)0;
       if (I || c > 0) divx -= y1p[j];
-      const T kty = (T)0 - (divx + divy);
+      T kty = (T)0 - (divx + divy);
+      if (VART) {                // K^T y in the order of the matrix's transposed CSR row (kernels_fused_iter.hip: fused_iter2d_kernel)
+        T s = 0;
+        if (I || c > 0) s += y1p[j];
+        if (I || c < nx - 1) s -= y1c[j];
+        if (I || row > 0) s += (j > 0) ? y2c[(j + VEC - 1) % VEC] : up;
+        if (I || row < ny - 1) s -= y2c[j];
+        kty = s;
+      }
       kt[j] = kty;
       T tT = tauT;
       bool edge = false;
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
         const int cnt = 4 - (c == 0 ? 1 : 0) - (c == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
         edge = cnt != 4;
         tT = P.tau * (cnt == 4 ? a.Tval : (cnt == 3 ? a.Tcls[1] : a.Tcls[0]));
-        edgev[kEdges ? j : 0] = edge; tTv[kEdges ? j : 0] = tT;
+        edgev[kEdges ? j : 0] = edge; cornerv[kEdges ? j : 0] = cnt == 2; tTv[kEdges ? j : 0] = tT;
       }
       const T arg = xin[j] - tT * kty;
       if (kEdges) argv[kEdges ? j : 0] = arg;
@@ -204,14 +212,25 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
 #pragma unroll
         for (int j = 0; j < VEC; j++) if (is_mask_sentinel(gc[slot_ofb(GMASK, 1)][j])) xn[j] = parg0[kBMask ? j : 0];
       }
-      if (kEdges) {             // pixels with their own Tau_j: ElemOperation1D as the reference writes it
+      if (kEdges) {
+        // pixels with their own Tau_j.  Straight-line square shape: the same F_prox(v - b; step_j) + b with the divisor 1 + step_j of the
+        // pixel's class (two classes, their reciprocals formed once per launch: IterParams::ec) -- (float)((double)(v - b) / D_j) exactly
+        // as elem_1d evaluates it; any other shape: ElemOperation1D as the reference writes it.
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
           if (edgev[kEdges ? j : 0]) {
-            T cf[7];
+            if (GFN == PROST_FN_SQUARE && !kBMask) {
+              const bool cn = cornerv[kEdges ? j : 0];
+              UniformDiv dv;
+              dv.D = cn ? P.ec[0].sq.D : P.ec[1].sq.D; dv.rD = cn ? P.ec[0].sq.rD : P.ec[1].sq.rD;
+              const T bj = ((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1];
+              xn[j] = div_to_float_exact(argv[kEdges ? j : 0] - bj, dv) + bj;
+            } else {
+              T cf[7];
 #pragma unroll
-            for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? gc[slot_ofb(GMASK, k)][j] : a.g_val[k];
-            xn[j] = elem_1d<T, GFN>(a.g_fn, argv[kEdges ? j : 0], tTv[kEdges ? j : 0], cf);
+              for (int k = 0; k < 7; k++) cf[k] = ((GMASK >> k) & 1) ? gc[slot_ofb(GMASK, k)][j] : a.g_val[k];
+              xn[j] = elem_1d<T, GFN>(a.g_fn, argv[kEdges ? j : 0], tTv[kEdges ? j : 0], cf);
+            }
           }
         }
       }
@@ -512,6 +531,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
     p[i].tau = (T)tau[i]; p[i].sigma = (T)sigma[i]; p[i].theta = (T)theta[i];
     p[i].ug = make_uniform_prox<T>(a.g_val, (T)tau[i] * a.Tval);
     p[i].uf = make_uniform_prox<T>(a.f_val, (T)sigma[i] * a.Sval);
+    for (int k = 0; k < 2; k++) p[i].ec[k] = a.varT ? make_edge_terms<T>(a.g_val, (T)tau[i] * a.Tcls[k]) : EdgeTerms<T>();
   }
   int mask = 0;
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k]) mask |= 1 << k;

@@ -29,11 +29,13 @@ struct ColMc {
 
 // GB: coefficient b of prox_g is a per-pixel vector; every other coefficient of prox_g and all of prox_f* are scalars.
 // FAST: straight-line ROF instance (square / ind_leq0 with scalar a = 1, d = e = 0), forms of device_math.hpp.
-template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, int LW, bool RES>
+// VART: position-dependent primal preconditioner (FusedArgs::varT; see fused_iter2d_kernel in kernels_fused_iter.hip) -- the same for
+// every channel: spmat_gradient2d(nx, ny, L) repeats the one-channel matrix L times.
+template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, int LW, bool RES, bool VART>
 __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restrict__ x_new, T* __restrict__ y_new, const T* __restrict__ x,
                                                                     const T* __restrict__ y, const T* __restrict__ y_prev, FusedArgs<T> a, T tau,
-                                                                    T sigma, T theta, UniformProx<T> ug, UniformProx<T> uf, bool use_kty,
-                                                                    bool use_kx_prev, bool use_kty_prev, double* __restrict__ partial) {
+                                                                    T sigma, T theta, UniformProx<T> ug, UniformProx<T> uf, EdgeTerms<T> ec0, EdgeTerms<T> ec1,
+                                                                    bool use_kty, bool use_kx_prev, bool use_kty_prev, double* __restrict__ partial) {
   constexpr int kRowsPerWave = (kWave - 1) * VEC;
   constexpr int kPix = kWave * VEC;
   __shared__ T s_sq[2][2 * LW][kPix];
@@ -75,6 +77,8 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
     T up = lane_up(in.y2[VEC - 1]);
     if (lane == 0) up = in.up;
     T parg[VEC], ktyv[RES ? VEC : 1];
+    T argv[VART ? VEC : 1], sTv[VART ? VEC : 1];
+    bool edgev[VART ? VEC : 1], cornerv[VART ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const size_t row = row0 + j;
@@ -82,9 +86,27 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       if (row > 0) divy -= (j > 0 ? in.y2[j > 0 ? j - 1 : 0] : up);
       T divx = (c < nx - 1) ? in.y1[j] : (T)0;
       if (have_prev) divx -= p1[j];
-      const T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+      T kty = use_kty ? (T)0 - (divx + divy) : (T)0;
+      if (VART && use_kty) {         // K^T y in the order of the matrix's transposed CSR row (kernels_fused_iter.hip)
+        T s = 0;
+        if (have_prev) s += p1[j];
+        if (c < nx - 1) s -= in.y1[j];
+        if (row > 0) s += (j > 0 ? in.y2[j > 0 ? j - 1 : 0] : up);
+        if (row < ny - 1) s -= in.y2[j];
+        kty = s;
+      }
       if (RES) ktyv[RES ? j : 0] = kty;
-      const T arg = in.x[j] - tauT * kty;
+      T tT = tauT;
+      bool edge = false;
+      if (VART) {                  // stencil entries in this pixel's column of K: 4 inside, 3 on an edge, 2 in a corner
+        const int cnt = 4 - (c == 0 ? 1 : 0) - (c == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
+        edge = cnt != 4;
+        const T Tj = cnt == 4 ? a.Tval : (cnt == 3 ? a.Tcls[1] : a.Tcls[0]);
+        tT = tau * Tj;
+        edgev[VART ? j : 0] = edge; cornerv[VART ? j : 0] = cnt == 2; sTv[VART ? j : 0] = edge ? t_sqrt(Tj) : sqT;
+      }
+      const T arg = in.x[j] - tT * kty;
+      if (VART) argv[VART ? j : 0] = arg;
       if (FAST) {
         parg[j] = arg - (GB ? in.b[GB ? j : 0] : a.g_val[1]);
       } else {
@@ -92,7 +114,8 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
 #pragma unroll
         for (int k = 0; k < 7; k++) cf[k] = a.g_val[k];
         if (GB) cf[1] = in.b[GB ? j : 0];
-        xn[j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
+        if (!edge) xn[j] = elem_1d_u<T, GFN>(a.g_fn, arg, cf, ug);
+        else xn[j] = elem_1d<T, GFN>(a.g_fn, arg, tT, cf);
       }
     }
     if (FAST) {
@@ -100,6 +123,18 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       div_to_float_exact_vec<VEC>(parg, ug.sq, r);
 #pragma unroll
       for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? in.b[GB ? j : 0] : a.g_val[1]);
+      if (VART) {                  // pixels with their own Tau_j: the divisor 1 + step_j of their class (EdgeTerms)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          if (edgev[VART ? j : 0]) {
+            const bool cn = cornerv[VART ? j : 0];
+            UniformDiv dv;
+            dv.D = cn ? ec0.sq.D : ec1.sq.D; dv.rD = cn ? ec0.sq.rD : ec1.sq.rD;
+            const T bj = GB ? in.b[GB ? j : 0] : a.g_val[1];
+            xn[j] = div_to_float_exact(argv[VART ? j : 0] - bj, dv) + bj;
+          }
+        }
+      }
     }
     if (RES) {                                              // dual_residual_transform (backend_pdhg.cu:73-94)
       T upp = lane_up(in.p2[RES ? VEC - 1 : 0]);
@@ -112,9 +147,18 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
         if (row > 0) dpy -= (j > 0 ? in.p2[RES && j > 0 ? j - 1 : 0] : upp);
         T dpx = (c < nx - 1) ? in.p1[jj] : (T)0;
         if (have_prev) dpx -= pp1[jj];
-        const T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
-        const T w_hat = div_tauT.div(in.x[j] - xn[j]) - sqT * ktyp;
-        const T diff = w_hat + sqT * ktyv[jj];
+        T ktyp = use_kty_prev ? (T)0 - (dpx + dpy) : (T)0;
+        if (VART && use_kty_prev) {
+          T s = 0;
+          if (have_prev) s += pp1[jj];
+          if (c < nx - 1) s -= in.p1[jj];
+          if (row > 0) s += (j > 0 ? in.p2[RES && j > 0 ? j - 1 : 0] : upp);
+          if (row < ny - 1) s -= in.p2[jj];
+          ktyp = s;
+        }
+        const T sT = VART ? sTv[VART ? j : 0] : sqT;
+        const T w_hat = (VART && edgev[VART ? j : 0]) ? (in.x[j] - xn[j]) / (tau * sT) - sT * ktyp : div_tauT.div(in.x[j] - xn[j]) - sqT * ktyp;
+        const T diff = w_hat + sT * ktyv[jj];
         if (owner && counted && c >= a.rx0 && c < a.rx1) { r_dd += (double)(diff * diff); r_dv += (double)(w_hat * w_hat); }
       }
     }
@@ -226,7 +270,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
 
 template <class T>
 static bool iter_mc_ok(const prost_hip_fused_desc* d) {
-  if (!d || d->is3d || d->var_T || (d->L != 3 && d->L != 4)) return false;
+  if (!d || d->is3d || (d->L != 3 && d->L != 4)) return false;
   if (d->nx == 0 || d->ny == 0) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   for (int k = 0; k < 7; k++) {
@@ -269,7 +313,9 @@ static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO3(G, F, B, FASTv, LWv, R) PH_LAUNCH((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+  const EdgeTerms<T> ec0 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[0]) : EdgeTerms<T>(), ec1 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[1]) : EdgeTerms<T>();
+#define GO4(G, F, B, FASTv, LWv, R, VARTv) PH_LAUNCH((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv, R, VARTv>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO3(G, F, B, FASTv, LWv, R) do { if (a.varT) GO4(G, F, B, FASTv, LWv, R, true); else GO4(G, F, B, FASTv, LWv, R, false); } while (0)
 #define GO2(G, F, B, FASTv, LWv) do { if (out4) GO3(G, F, B, FASTv, LWv, true); else GO3(G, F, B, FASTv, LWv, false); } while (0)
 #define GO(G, F, B, FASTv) do { if (d->L == 3) GO2(G, F, B, FASTv, 3); else GO2(G, F, B, FASTv, 4); } while (0)
   if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
@@ -277,6 +323,7 @@ static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
 #undef GO
 #undef GO2
 #undef GO3
+#undef GO4
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel iteration kernel"); }
   if (out4) return launch_fold4(out4, partial, grid * (unsigned)d->L, s);
   return 0;
