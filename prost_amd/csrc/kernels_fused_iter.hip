@@ -43,8 +43,10 @@ struct ColIn {            // everything loaded for one column
 // instance with Tval = Tcls[2]; pixels of the first / last column and row -- 3 or 2 entries -- evaluate the reference's own
 // expression with their Tau_j (elem_1d: ElemOperation1D as written; the straight-line instances: the divisor 1 + step_j of the pixel's
 // class, EdgeTerms) and the residual terms with their sqrt(Tau_j).  The same for every channel.
+// (launch bounds: the residual instance with position-dependent Tau would take 169-171 VGPRs -- two resident wavefronts per SIMD
+// where the uniform instance, at 165-167, has three; it is held to three)
 template <class T, int VEC, int LCH, int GFN, int FFN, int GMASK, bool RES, bool RAG, bool FAST, bool VART>
-__global__ void __launch_bounds__(kWave) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
+__global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 : 1) fused_iter2d_kernel(T* __restrict__ x_new, T* __restrict__ y_new,
                                                              const T* __restrict__ x, const T* __restrict__ y,
                                                              const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma, T theta,
                                                              UniformProx<T> ug, UniformProx<T> uf, EdgeTerms<T> ec0, EdgeTerms<T> ec1,
@@ -402,6 +404,7 @@ int launch_fold4(double* out4, const double* partial, unsigned nslots, hipStream
 static bool iter_desc_ok(const prost_hip_fused_desc* d, int dtype) {
   if (!d || d->is3d) return false;
   if (d->nx < 2 || d->ny < 2 || d->L < 1 || d->L > 2) return false;
+  if (d->var_T && (d->nx < 4 || d->ny < 4)) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   const int V = dtype == 0 ? 4 : 2;
   for (int k = 0; k < 7; k++) {

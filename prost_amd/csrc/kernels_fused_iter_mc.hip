@@ -272,6 +272,7 @@ template <class T>
 static bool iter_mc_ok(const prost_hip_fused_desc* d) {
   if (!d || d->is3d || (d->L != 3 && d->L != 4)) return false;
   if (d->nx == 0 || d->ny == 0) return false;
+  if (d->var_T && (d->nx < 4 || d->ny < 4)) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   for (int k = 0; k < 7; k++) {
     if (d->f_coeff_ptr[k]) return false;

@@ -11,6 +11,8 @@
 //   test:op:simplex_lds   projection onto the unit simplex, sorting in the per-thread LDS slice (SharedMem, dim entries of T,
 //                         no coefficients);   library: elem_operation:ind_simplex
 //   test:op:partial       writes res[0] only (kPartialResult): the other components keep their old content
+//   test:tpl:ind_sum / test:tpl:ind_simplex   the PUBLIC ElemOperationIndSum / ElemOperationIndSimplex (elemop/*.hpp), instantiated out of
+//                         tree;   library: elem_operation:ind_sum / elem_operation:ind_simplex
 //   test:tpl:1d:<fn> / test:tpl:norm2:<fn>   the PUBLIC templates ElemOperation1D / ElemOperationNorm2 over the 14 public
 //                         Function1D* functors (elemop/*.hpp), instantiated out of tree;   library: elem_operation:1d|norm2:<fn>
 #include <hip/hip_runtime.h>
@@ -18,6 +20,8 @@
 #include "prost/factory.hpp"
 #include "prost/prox/elemop/elem_operation.hpp"
 #include "prost/prox/elemop/elem_operation_1d.hpp"
+#include "prost/prox/elemop/elem_operation_ind_simplex.hpp"
+#include "prost/prox/elemop/elem_operation_ind_sum.hpp"
 #include "prost/prox/elemop/elem_operation_norm2.hpp"
 #include "prost/prox/prox_elem_operation.inl"
 
@@ -155,6 +159,8 @@ void RegisterAll() {
   reg["test:op:abs_1d"] = CreateWithCoeffs<T, Abs1D<T>>;
   reg["test:op:simplex_lds"] = CreateNoCoeffs<T, SimplexLds<T>>;
   reg["test:op:partial"] = CreateNoCoeffs<T, FirstComponentOnly<T>>;
+  reg["test:tpl:ind_sum"] = CreateNoCoeffs<T, prost::ElemOperationIndSum<T>>;
+  reg["test:tpl:ind_simplex"] = CreateNoCoeffs<T, prost::ElemOperationIndSimplex<T>>;
   RegisterTemplates<T, prost::Function1DZero>("zero");
   RegisterTemplates<T, prost::Function1DAbs>("abs");
   RegisterTemplates<T, prost::Function1DSquare>("square");

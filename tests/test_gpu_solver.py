@@ -1193,8 +1193,8 @@ def test_gradient_handed_over_as_a_sparse_matrix_runs_the_fused_kernels(precisio
                     assert st[name] == ost[name], name
                 for name in ("primal_res", "dual_res", "dual_var_norm", "eps_primal", "eps_dual"):
                     assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
-            if step in ("alg2", "boyd"):
-                assert st["pair_launches"] > 0 or ny % (4 if dtype == np.float32 else 2), (nx, ny, st["pair_launches"])
+            if step in ("alg2", "boyd") and res_iter >= 3:
+                assert st["pair_launches"] > 0, (nx, ny, st["pair_launches"])
             prost.set_quirks(sparse_stencils=0)
             gen = run_product(prob, b, o, 50)
             prost.set_quirks(sparse_stencils=1)

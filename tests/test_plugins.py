@@ -183,6 +183,8 @@ def test_elem_operation_headers_are_what_the_reference_exports():
                        "elemop/elem_operation.hpp": ["struct ElemOperation", "kCoeffsCount", "kDim", "SharedMemType", "GetSharedMemCount"],
                        "elemop/elem_operation_1d.hpp": ["struct ElemOperation1D"],
                        "elemop/elem_operation_norm2.hpp": ["struct ElemOperationNorm2"],
+                       "elemop/elem_operation_ind_sum.hpp": ["struct ElemOperationIndSum"],
+                       "elemop/elem_operation_ind_simplex.hpp": ["struct ElemOperationIndSimplex", "GetSharedMemCount"],
                        "elemop/function_1d.hpp": ["Function1DHuber", "Function1DLq", "Function1DTruncLinear"]}.items():
         text = open(os.path.join(inc, rel)).read()
         for n in names:
@@ -256,6 +258,16 @@ def test_elem_operation_with_a_shared_memory_slice_and_partial_results(hip, plug
                 assert np.array_equal(got, orc), (count, dim, interleaved, float(np.abs(got - orc).max()))
                 grp = got.reshape(count, dim) if interleaved else got.reshape(dim, count).T
                 assert np.allclose(grp.sum(axis=1), 1, atol=1e-5 if dtype == np.float32 else 1e-12) and (grp >= 0).all()
+        # the PUBLIC ElemOperationIndSum / ElemOperationIndSimplex templates, instantiated out of tree, == the built-in operations
+        for count in (1001, 64):
+            for dim, interleaved in [(2, False), (3, True), (5, False), (8, True), (19, False)]:
+                arg = rng.standard_normal(count * dim).astype(dtype).astype(np.float64)
+                Tau = np.ones(count * dim)
+                for name, builtin in (("test:tpl:ind_sum", prost.function.sum_ind_sum), ("test:tpl:ind_simplex", prost.function.sum_ind_simplex)):
+                    got, _ = prost.eval_prox(plugin_groups(name, dim, interleaved), arg, 1.0, Tau)
+                    lib, _ = prost.eval_prox(builtin(dim, interleaved), arg, 1.0, Tau)
+                    orc = oracle.eval_prox(builtin(dim, interleaved), arg, 1.0, Tau, dtype)
+                    assert np.array_equal(got, lib) and np.array_equal(got, orc), (name, count, dim, interleaved)
         count, dim = 1000, 3
         arg = rng.standard_normal(count * dim).astype(dtype).astype(np.float64)
         got, _ = prost.eval_prox(plugin_groups("test:op:partial", dim, False), arg, 1.0, np.ones(count * dim))
