@@ -213,7 +213,10 @@ void BackendPDHG<T>::Initialize() {
   // goldstein / boyd on the one-kernel 2-D path: rule + stopping test on the device (header).  Needs every step-size dependent prox
   // term to be a scalar (a, c, e of prox_g; prox_f* has scalars only on this path) and e = 0 on both sides (the kernels' dispatch
   // must not depend on the step size); column-sharded slabs exchange halos between iterations and keep the host loop.
-  dev_rules_ = single_kernel_ && !pair_mc_ && desc_.L == 1 && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
+  // (gray values, and 2-4 channels with the channels in one lane / on the wavefronts of a workgroup: every kernel of those paths
+  // reads the record -- prost_hip_fused_iteration_rec, _iteration_mc_rec, _iteration2_rec, _iteration_mc_x2_rec)
+  const bool rec_kernels = single_kernel_ || single_mc_;
+  dev_rules_ = rec_kernels && !desc_.is3d && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
                !desc_.g_coeff_ptr[4] && desc_.g_coeff_val[4] == 0.0 && desc_.f_coeff_val[4] == 0.0;
   in_device_batch_ = false; dev_batches_ = 0;
   if (dev_rules_) {
@@ -378,6 +381,10 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
         pair_launches_++;            // (counted first: the mark a residual launch leaves holds the count INCLUDING itself)
         IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
         done += 2;
+      } else if (pair_mc_ && n - done >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {     // (no stored intermediate iterate)
+        pair_launches_++;
+        IterationPairMc(is_residual_iteration(k + 1));
+        done += 2;
       } else {
         IterationFused(is_residual_iteration(k));
         done += 1;
@@ -512,6 +519,11 @@ void BackendPDHG<T>::IterationPairMc(bool residuals) {
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
   TimedLaunch(residuals ? kKernelPairRes : kKernelPair, [&] {
+    if (in_device_batch_)
+      CheckHip(Api<T>::fused_iteration_mc_x2_rec(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), rule_rec_, 0, residuals ? res_target() : nullptr,
+                                                 residuals ? workspace_ : nullptr, this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_dev_, CurrentStream()),
+               "fused_iteration_mc_x2_rec");
+    else
     CheckHip(Api<T>::fused_iteration_mc_x2(&desc_pair_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
                                            residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration_mc_x2");
   });
@@ -612,6 +624,11 @@ void BackendPDHG<T>::IterationFused(bool res) {
     if (res) RebuildPrevious();      // the residual kernel streams y^(k-1)
     T* y_out = res ? y_spare_.data() : y_prev_.data();
     TimedLaunch(res ? kKernelIterRes : kKernelIter, [&] {
+      if (in_device_batch_)
+        CheckHip(Api<T>::fused_iteration_mc_rec(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, rule_rec_,
+                                                iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr,
+                                                res ? workspace_ : nullptr, this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_dev_, s), "fused_iteration_mc_rec");
+      else
       CheckHip(Api<T>::fused_iteration_mc(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, (double)tau_, (double)sigma_,
                                           (double)theta_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0,
                                           res ? res_target() : nullptr, res ? workspace_ : nullptr, s), "fused_iteration_mc");

@@ -46,6 +46,8 @@ template <typename T> struct Api;
     static constexpr auto fused_iteration = prost_hip_fused_iteration_##S;        \
     static constexpr auto fused_iteration2 = prost_hip_fused_iteration2_##S;      \
     static constexpr auto fused_iteration_rec = prost_hip_fused_iteration_rec_##S; \
+    static constexpr auto fused_iteration_mc_rec = prost_hip_fused_iteration_mc_rec_##S; \
+    static constexpr auto fused_iteration_mc_x2_rec = prost_hip_fused_iteration_mc_x2_rec_##S; \
     static constexpr auto fused_iteration2_rec = prost_hip_fused_iteration2_rec_##S; \
     static constexpr auto pdhg_rule_begin = prost_hip_pdhg_rule_begin_##S;        \
     static constexpr auto pdhg_rule_apply = prost_hip_pdhg_rule_apply_##S;        \

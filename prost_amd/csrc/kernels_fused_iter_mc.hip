@@ -35,7 +35,13 @@ template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, int LW, bool R
 __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restrict__ x_new, T* __restrict__ y_new, const T* __restrict__ x,
                                                                     const T* __restrict__ y, const T* __restrict__ y_prev, FusedArgs<T> a, T tau,
                                                                     T sigma, T theta, UniformProx<T> ug, UniformProx<T> uf, EdgeTerms<T> ec0, EdgeTerms<T> ec1,
-                                                                    bool use_kty, bool use_kx_prev, bool use_kty_prev, double* __restrict__ partial) {
+                                                                    bool use_kty, bool use_kx_prev, bool use_kty_prev, double* __restrict__ partial,
+                                                                    const PdhgRecord<T>* __restrict__ rec) {
+  if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
+    if (rec->stop) return;
+    tau = rec->p.tau; sigma = rec->p.sigma; theta = rec->p.theta; ug = rec->p.ug; uf = rec->p.uf;
+    if (VART) { ec0 = rec->p.ec[0]; ec1 = rec->p.ec[1]; }
+  }
   constexpr int kRowsPerWave = (kWave - 1) * VEC;
   constexpr int kPix = kWave * VEC;
   __shared__ T s_sq[2][2 * LW][kPix];
@@ -288,7 +294,7 @@ static bool iter_mc_ok(const prost_hip_fused_desc* d) {
 
 template <class T, int V>
 static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
-                       int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream) {
+                       int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream, void* record = nullptr, const RuleTail* tail = nullptr) {
   if (!iter_mc_ok<T>(d)) { set_error("fused multi-channel iteration: unsupported description (see prost_hip_fused_iteration_mc_supported)"); return 1; }
   if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y) || !aligned16(y_prev)) { set_error("fused multi-channel iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_new == x || y_new == y || (out4 && y_new == y_prev)) { set_error("fused multi-channel iteration: outputs must not alias inputs"); return 1; }
@@ -307,15 +313,18 @@ static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
   a.cols_per_block = (unsigned)c;
   a.chunks = (unsigned)((d->nx + c - 1) / c);
   const unsigned grid = (unsigned)(strips * a.chunks);
+  const PdhgRecord<T>* rec = static_cast<const PdhgRecord<T>*>(record);
+  if (rec) { tau = sigma = theta = 1.0; }      // the dispatch below may only depend on the coefficients (kernels_fused_iter.hip: run_iter)
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   hipStream_t s = as_stream(stream);
   double* partial = static_cast<double*>(ws);
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
-  const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
+  bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
+  if (rec && (a.g_val[4] != (T)0 || a.f_val[4] != (T)0)) fast = false;
   const EdgeTerms<T> ec0 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[0]) : EdgeTerms<T>(), ec1 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[1]) : EdgeTerms<T>();
-#define GO4(G, F, B, FASTv, LWv, R, VARTv) PH_LAUNCH((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv, R, VARTv>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO4(G, F, B, FASTv, LWv, R, VARTv) PH_LAUNCH((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv, R, VARTv>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
 #define GO3(G, F, B, FASTv, LWv, R) do { if (a.varT) GO4(G, F, B, FASTv, LWv, R, true); else GO4(G, F, B, FASTv, LWv, R, false); } while (0)
 #define GO2(G, F, B, FASTv, LWv) do { if (out4) GO3(G, F, B, FASTv, LWv, true); else GO3(G, F, B, FASTv, LWv, false); } while (0)
 #define GO(G, F, B, FASTv) do { if (d->L == 3) GO2(G, F, B, FASTv, 3); else GO2(G, F, B, FASTv, 4); } while (0)
@@ -326,6 +335,7 @@ static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
 #undef GO3
 #undef GO4
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel iteration kernel"); }
+  if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid * (unsigned)d->L, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid * (unsigned)d->L, s);
   return 0;
 }
@@ -333,9 +343,9 @@ static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
 // 16 bytes of rows per lane where the height is a whole number of such groups, one row per lane otherwise
 template <class T>
 static int run_iter_mc(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
-                       int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream) {
-  if (d && d->ny % VecOf<T>::N != 0) return run_iter_mc_v<T, 1>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, out4, ws, stream);
-  return run_iter_mc_v<T, VecOf<T>::N>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, out4, ws, stream);
+                       int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream, void* record = nullptr, const RuleTail* tail = nullptr) {
+  if (d && d->ny % VecOf<T>::N != 0) return run_iter_mc_v<T, 1>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, out4, ws, stream, record, tail);
+  return run_iter_mc_v<T, VecOf<T>::N>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, out4, ws, stream, record, tail);
 }
 
 }  // namespace prost_hip
@@ -353,5 +363,19 @@ int prost_hip_fused_iteration_mc_f64(const prost_hip_fused_desc* d, double* x_ne
                                      double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace,
                                      void* stream) {
   return run_iter_mc<double>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream);
+}
+int prost_hip_fused_iteration_mc_rec_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
+                                         void* record, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace,
+                                         int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused multi-channel iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter_mc<float>(d, x_new, y_new, x, y, y_prev, 1, 1, 1, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream, record, &tail);
+}
+int prost_hip_fused_iteration_mc_rec_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev,
+                                         void* record, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace,
+                                         int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused multi-channel iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter_mc<double>(d, x_new, y_new, x, y, y_prev, 1, 1, 1, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream, record, &tail);
 }
 }  // extern "C"

@@ -51,7 +51,13 @@ __device__ __forceinline__ void stm_o(T* __restrict__ base, unsigned byte_off, c
 template <class T, int VEC, int GFN, int GB, int LW, bool RES>
 __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                                 const T* __restrict__ y, FusedArgs<T> a, IterParamsMc<T> p1,
-                                                                                IterParamsMc<T> p2, double* __restrict__ partial) {
+                                                                                IterParamsMc<T> p2, double* __restrict__ partial,
+                                                                                const PdhgRecord<T>* __restrict__ rec) {
+  if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
+    if (rec->stop) return;
+    p1.tau = rec->p.tau; p1.sigma = rec->p.sigma; p1.theta = rec->p.theta; p1.step = rec->p.ug.step; p1.sq = rec->p.ug.sq;
+    p2 = p1;                       // a rule evaluation never falls between the two iterations of a launch
+  }
   // two iterations need two valid rows beyond the owned ones on either side: one halo lane of >= 2 rows, or two halo lanes of one row
   // (heights that are not a multiple of 16 bytes of rows: 1 row per lane)
   constexpr int kHalo = VEC >= 2 ? 1 : 2;
@@ -357,7 +363,10 @@ static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int col
 
 template <class T>
 static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
-                          const double* theta, int cols, double* out4, void* ws, void* stream) {
+                          const double* theta, int cols, double* out4, void* ws, void* stream, void* record = nullptr, const RuleTail* tail = nullptr) {
+  const PdhgRecord<T>* rec = static_cast<const PdhgRecord<T>*>(record);
+  const double one2[2] = {1.0, 1.0};
+  if (rec) { tau = sigma = theta = one2; }          // (the shape checks below do not depend on the step sizes: e = 0 is part of the supported shape)
   constexpr int kDtype = std::is_same<T, float>::value ? 0 : 1;
   if (!iter_mc_x2_ok(d, kDtype)) { set_error("fused multi-channel double iteration: unsupported description (see prost_hip_fused_iteration_mc_x2_supported)"); return 1; }
   if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused multi-channel double iteration: vectors must be 16-byte aligned"); return 1; }
@@ -382,7 +391,7 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
   if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused multi-channel double iteration: grid exceeds the reduction workspace"); return 1; }
   double* partial = static_cast<double*>(ws);
   const bool full = mc_x2_vec(kDtype, d->ny) > 1;
-#define GO5(VV, G, B, LWv, R) PH_LAUNCH((fused_iter2d_mc_x2_kernel<T, VV, G, B, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+#define GO5(VV, G, B, LWv, R) PH_LAUNCH((fused_iter2d_mc_x2_kernel<T, VV, G, B, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, rec)
 #define GO4(G, B, LWv, R) do { if (full) GO5(VecOf<T>::N, G, B, LWv, R); else GO5(1, G, B, LWv, R); } while (0)
 #define GO3(G, B, LWv) do { if (out4) GO4(G, B, LWv, true); else GO4(G, B, LWv, false); } while (0)
 #define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)
@@ -395,6 +404,7 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
 #undef GO4
 #undef GO5
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel double iteration kernel"); }
+  if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid, s);
   return 0;
 }
@@ -424,5 +434,17 @@ int prost_hip_fused_iteration_mc_x2_f32(const prost_hip_fused_desc* d, float* x_
 int prost_hip_fused_iteration_mc_x2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
                                         const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
   return run_iter_mc_x2<double>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
+}
+int prost_hip_fused_iteration_mc_x2_rec_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, void* record, int cols,
+                                            double* res_out4, void* workspace, int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused multi-channel double iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter_mc_x2<float>(d, x_out, y_out, x, y, nullptr, nullptr, nullptr, cols, res_out4, workspace, stream, record, &tail);
+}
+int prost_hip_fused_iteration_mc_x2_rec_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, void* record, int cols,
+                                            double* res_out4, void* workspace, int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused multi-channel double iteration: no step-size record"); return 1; }
+  const RuleTail tail = {apply_rule, iteration, mirror};
+  return run_iter_mc_x2<double>(d, x_out, y_out, x, y, nullptr, nullptr, nullptr, cols, res_out4, workspace, stream, record, &tail);
 }
 }  // extern "C"

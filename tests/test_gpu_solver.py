@@ -1108,6 +1108,44 @@ def test_device_resident_step_rules_are_invisible(precision, dtype, step, residu
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("step", ["goldstein", "boyd"])
+@pytest.mark.parametrize("L,nx,ny,residual_iter", [(3, 24, 60, 1), (4, 20, 33, 3), (2, 30, 64, 10), (3, 40, 124, 1), (3, 36, 252, 10)])
+def test_device_resident_step_rules_with_colour_channels(precision, dtype, step, L, nx, ny, residual_iter):
+    """2-4 channels (the reference's examples read RGB images): the single-iteration kernels -- channels in one lane for 2, on the
+    wavefronts of a workgroup for 3 / 4 -- and their double-iteration kernel read the step sizes from the device record as well.  Same checks as for gray
+    values: identical to the host-side rule in every scalar and iterate, identical to the oracle, a complete solve stops at the same
+    iteration."""
+    prost.set_precision(precision)
+    prob, u, q, f = synthetic.rof_problem(nx, ny, L, seed=12)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=2e-2, tol_rel_dual=2e-2, tol_abs_primal=0, tol_abs_dual=0)
+    runs = {}
+    for dev in (True, False):
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+        b[1]["allow_device_rules"] = dev
+        s = prost.Solver(prob, b, o)
+        s.iterate(9)
+        a = s.state()
+        s.iterate(300)
+        runs[dev] = (a, s.state())
+        s.destroy()
+        assert (runs[dev][1]["device_rule_batches"] >= 3) if dev else runs[dev][1]["device_rule_batches"] == 0
+    for a, b_ in zip(runs[True], runs[False]):
+        for v in RULE_SCALARS:
+            assert a[v] == b_[v], (v, a[v], b_[v])
+        for v in "xyzw":
+            assert np.array_equal(a[v], b_[v]), v
+    ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter), o, 309, dtype)
+    assert_same_iterates(runs[True][1], ost)
+    assert runs[True][1]["tau"] == ost["tau"] and runs[True][1]["sigma"] == ost["sigma"]
+    o2 = prost.options(max_iters=3000, num_cback_calls=0, verbose=False, tol_rel_primal=5e-3, tol_rel_dual=5e-3, tol_abs_primal=5e-3, tol_abs_dual=5e-3)
+    b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+    got, exp = prost.solve(prob, b, o2), oracle.solve(prob, b, o2, dtype)
+    assert got["result"] == exp["result"] == "Converged." and int(got["iters"]) == int(exp["iters"]), (got["iters"], exp["iters"])
+    for v in "xyzw":
+        assert np.array_equal(np.asarray(got[v]), np.asarray(exp[v])), v
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", ["goldstein", "boyd"])
 @pytest.mark.parametrize("residual_iter,cbacks", [(1, 0), (4, 7), (10, 0)])
 def test_device_resident_stopping_test_stops_where_the_host_loop_stops(precision, dtype, step, residual_iter, cbacks):
     """complete prost.solve runs that stop on their tolerance in the MIDDLE of a device batch: result, iteration count and x, y, z, w

@@ -145,6 +145,8 @@ def test_pdhg_with_plugin_block_and_prox_matches_the_oracle(hip, plugin, prec, d
 # ---- the ELEM_OPERATION surface: user-written functors through prost::ProxElemOperation<T, OP> (tests/plugins/elem_operations.hip) ----
 
 def _coeffs(*vals):
+    """a, b, c, d, e, alpha, beta with the defaults of sum_1d.m:35-77 / sum_norm2.m for the ones left out"""
+    vals = tuple(vals) + (1, 0, 1, 0, 0, 0, 0)[len(vals):]
     return [np.atleast_1d(np.asarray(v, dtype=np.float64)).ravel() for v in vals]
 
 
