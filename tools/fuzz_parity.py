@@ -54,6 +54,10 @@ def draw(rng):
     else:
         c["nx"] = int(rng.integers(1, 80)); c["L"] = 1 if kind == "gray" else int(rng.choice([2, 3, 4]))
         c["data"] = str(rng.choice(["square", "square", "abs", "mask"]))
+        # the gradient handed over as prost.block.sparse(spmat_gradient2d(nx, ny, L)) -- the way the reference's examples write it: recognised
+        # entry for entry and run on the same kernels with the position-dependent preconditioners of that matrix (other iterates than
+        # with block.gradient2d; the oracle runs the matrix as block.sparse)
+        c["as_matrix"] = bool(rng.random() < 0.3)
     return c
 
 
@@ -61,15 +65,19 @@ def build(c):
     nx, ny, L = c["nx"], c["ny"], c["L"]
     if c["kind"] == "vol":
         return synthetic.tv3d_problem(nx, ny, L, lmb=c["lmb"], seed=c["seed"], data_term=c["data"])[0]
-    if c["data"] != "mask":
+    if c["data"] != "mask" and not c.get("as_matrix"):
         return synthetic.rof_problem(nx, ny, L, lmb=c["lmb"], seed=c["seed"], data_term=c["data"])[0]
     f = synthetic.rof_image(nx, ny, L, c["seed"])
     mask = (synthetic.hash32(c["seed"] + 7, np.arange(nx * ny * L, dtype=np.uint64)) % 3 != 0).astype(np.float64)
     u, q = prost.variable(nx * ny * L), prost.variable(2 * nx * ny * L)
     prob = prost.min_max_problem([u], [q])
-    prob.add_function(u, prost.function.sum_1d("square", mask, f, c["lmb"]))
+    prob.add_function(u, prost.function.sum_1d("square", mask, f, c["lmb"]) if c["data"] == "mask" else prost.function.sum_1d(c["data"], 1, f, c["lmb"]))
     prob.add_function(q, prost.function.sum_norm2(2 * L, False, "ind_leq0", 1, 1, 1))
-    prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, L))
+    if c.get("as_matrix"):
+        from reference_matrices import spmat_gradient2d
+        prob.add_dual_pair(u, q, prost.block.sparse(spmat_gradient2d(nx, ny, L)))
+    else:
+        prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, L))
     return prob
 
 
