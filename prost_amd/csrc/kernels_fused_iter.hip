@@ -343,12 +343,29 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
   }
 }
 
+// a thread's share of the partials (slots t, t + kBlock, ...), added in that order; the loads of four slots are issued before the
+// first add (a load-add loop pays one L2 latency per slot: 15 of them in front of the one workgroup at 4096^2) -- same order, same bits
+__device__ __forceinline__ void fold4_accumulate(const double* __restrict__ partial, unsigned nslots, double (&v)[4]) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2* p2 = reinterpret_cast<const d2*>(partial);               // a slot = 4 doubles = two 16-byte loads (workspace: 256-byte aligned)
+  for (unsigned i = threadIdx.x; i < nslots; i += 4 * kBlock) {
+    d2 a[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const unsigned s = i + (unsigned)u * kBlock;
+      if (s < nslots) { a[u][0] = p2[2 * (size_t)s]; a[u][1] = p2[2 * (size_t)s + 1]; }
+      else { a[u][0] = d2{0, 0}; a[u][1] = d2{0, 0}; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + (unsigned)u * kBlock < nslots) { v[0] += a[u][0][0]; v[1] += a[u][0][1]; v[2] += a[u][1][0]; v[3] += a[u][1][1]; }
+  }
+}
+
 // folds nslots x 4 doubles in a fixed order (one workgroup) -> out4
 __global__ void __launch_bounds__(kBlock) fold4_kernel(double* __restrict__ out4, const double* __restrict__ partial, unsigned nslots) {
   double v[4] = {0, 0, 0, 0};
-  for (unsigned i = threadIdx.x; i < nslots; i += kBlock)
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] += partial[4 * (size_t)i + k];
+  fold4_accumulate(partial, nslots, v);
   __shared__ double s[4][kBlock / kWave];
 #pragma unroll
   for (int k = 0; k < 4; k++) v[k] = wave_sum(v[k]);
@@ -369,9 +386,7 @@ __global__ void __launch_bounds__(kBlock) fold4_rule_kernel(double* __restrict__
                                                             PdhgRecord<T>* rec, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror) {
   if (rec->stop) return;                 // the launch that would have produced the partials returned at once
   double v[4] = {0, 0, 0, 0};
-  for (unsigned i = threadIdx.x; i < nslots; i += kBlock)
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] += partial[4 * (size_t)i + k];
+  fold4_accumulate(partial, nslots, v);
   __shared__ double s[4][kBlock / kWave];
   __shared__ double tot[4];
 #pragma unroll
