@@ -25,6 +25,7 @@
 
 namespace prost_hip {
 
+typedef int idx_t;            // column / row index inside the kernels
 constexpr int popcount7b(int m) { int c = 0; for (int k = 0; k < 7; k++) c += (m >> k) & 1; return c; }
 constexpr int slot_ofb(int m, int k) { int c = 0; for (int i = 0; i < k; i++) c += (m >> i) & 1; return c; }
 
@@ -57,7 +58,10 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     if (rec->stop) return;
     p1 = rec->p; p2 = rec->p;      // a rule evaluation never falls between the two iterations of a launch
   }
-  const long nx = (long)a.nx, ny = (long)a.ny;
+  // 32-bit indices: columns and rows are < 2^31 (iter2_desc_ok: one plane is < 4 GiB), and the scalar unit compares 32-bit values
+  // itself -- 64-bit orderings are vector instructions
+  const idx_t nx = (idx_t)a.nx, ny = (idx_t)a.ny;
+  const idx_t rx0 = (idx_t)a.rx0, rx1 = a.rx1 > (size_t)0x7fffffff ? (idx_t)0x7fffffff : (idx_t)a.rx1;
   const int lane = threadIdx.x;
   constexpr int kRowsPerWave = (kWave - 2) * VEC;
   const unsigned total = gridDim.x, chunks = a.chunks;
@@ -69,13 +73,13 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
   // total traffic from 564 to 522 MB -- and the launch gets SLOWER, 0.108 against 0.105 ms on the same box: at 5.4 TB/s the kernel
   // is bound by what a wavefront has in flight, not by the bytes; the chunks of one strip stay consecutive.)
   const unsigned strip = tile / chunks, chunk = tile % chunks;
-  const long row0 = (long)strip * kRowsPerWave + ((long)lane - 1) * VEC;
+  const idx_t row0 = (idx_t)strip * kRowsPerWave + ((idx_t)lane - 1) * VEC;
   const bool active = row0 >= 0 && row0 < ny;
   const bool owner = active && lane > 0 && lane < kWave - 1;
   // RAG: the image height is not a multiple of VEC (fused_common.hpp, ldv_n / stv_n)
-  const int nvalid = !RAG ? VEC : (active ? (ny - row0 < (long)VEC ? (int)(ny - row0) : VEC) : 0);   // rows of this lane inside the image
-  const long xa = (long)chunk * a.cols_per_block;
-  const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const int nvalid = !RAG ? VEC : (active ? (ny - row0 < (idx_t)VEC ? (int)(ny - row0) : VEC) : 0);   // rows of this lane inside the image
+  const idx_t xa = (idx_t)chunk * a.cols_per_block;
+  const idx_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t N = (size_t)nx * (size_t)ny;
   constexpr bool kUniformG = (GMASK & 0x15) == 0;
   constexpr bool kBMask = FAST && (GMASK & 0x80) != 0;     // bit 7: the per-pixel b carries the mask sentinel (binary coefficient a folded in)
@@ -89,7 +93,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
   // one 32-bit byte offset per lane serves every plane (x, y1, y2, coefficients, outputs): the plane
   // bases are wave-uniform (SGPR pairs), so the loads/stores use the saddr + 32-bit voffset form and
   // no 64-bit per-lane address arithmetic is left in the loop (host guarantees N * sizeof(T) < 4 GiB)
-  auto off_of = [&](long c) { return (unsigned)((c * ny + row0) * (long)sizeof(T)); };
+  auto off_of = [&](idx_t c) { return ((unsigned)c * (unsigned)ny + (unsigned)row0) * (unsigned)sizeof(T); };   // mod 2^32: exact for every (column, row) inside the image
   // ---- PF == 0: prefetch through an LDS ring instead of a register ring --------------------------------------------------
   // The register version keeps the columns c+1 .. c+2+PF of the four input streams in VGPRs (80 registers at PF = 3) and
   // moves them one slot per step (64 v_mov per column).  Here a column is fetched by four LDS-DMA loads
@@ -105,7 +109,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
   const T* const y2base = y + N;
   T* const y2out = y_out + N;
   T* const y2mid = kMid ? y_mid + N : nullptr;
-  auto load_col = [&](long c, Col& in) {
+  auto load_col = [&](idx_t c, Col& in) {
     const unsigned o = off_of(c);
     ldv_o<T, VEC, RAG>(y, o, in.y1, nvalid); ldv_o<T, VEC, RAG>(y2base, o, in.y2, nvalid); ldv_o<T, VEC, RAG>(x, o, in.x, nvalid);
 #pragma unroll
@@ -119,8 +123,8 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       }
     }
   };
-  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
-  auto ring_issue = [&](long k) {                                // column k -> slot k & 1
+  auto has_col = [&](idx_t k) { return k >= 0 && k < nx && k <= xb + 1; };
+  auto ring_issue = [&](idx_t k) {                                // column k -> slot k & 1
     if (active) {
       const unsigned o = off_of(k);
       char* slot = ring_mem + (k & 1) * 4096;
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       if ((GMASK >> 1) & 1) __builtin_amdgcn_global_load_lds((glb_void_t*)(reinterpret_cast<const char*>(a.g_ptr[1]) + o), (lds_void_t*)(slot + 3072), 16, 0, 0);
     }
   };
-  auto ring_fetch = [&](long k, bool next_in_flight, Col& in) {
+  auto ring_fetch = [&](idx_t k, bool next_in_flight, Col& in) {
     typedef typename VecOf<T>::native V4;
     if (next_in_flight) { if (NB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -147,7 +151,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
   // primal step at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 inlined)
   // `inner` (a compile-time tag): every row of the wave and the columns c-1 .. c+1 are strictly inside
   // the image, so the boundary selects of the gradient stencil drop out (identical values otherwise)
-  auto primal = [&](auto inner, long c, const T (&y1c)[VEC], const T (&y2c)[VEC], T up, const T (&y1p)[VEC], const T (&xin)[VEC],
+  auto primal = [&](auto inner, idx_t c, const T (&y1c)[VEC], const T (&y2c)[VEC], T up, const T (&y1p)[VEC], const T (&xin)[VEC],
                     const T (&gc)[Col::NG][VEC], const IterParams<T>& P, T (&xn)[VEC], T (&kt)[VEC]) {
     constexpr bool I = decltype(inner)::value;
     const T tauT = P.tau * a.Tval;
@@ -157,7 +161,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     bool edgev[kEdges ? VEC : 1], cornerv[kEdges ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const long row = row0 + j;
+      const idx_t row = row0 + j;
       T divy = (I || row < ny - 1) ? y2c[j] : (T)0;
       if (I || row > 0) divy -= (j > 0) ? y2c[(j + VEC - 1) % VEC] : up;
       T divx = (I || c < nx - 1) ? y1c[j] : (T)0;
@@ -250,18 +254,18 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     r_pd += (double)(d2 * d2); r_pv += (double)(z2 * z2);
   };
   // dual step at column c (backend_pdhg.cu:341-370 with block_gradient2d.cu:61-77 inlined)
-  auto dual = [&](auto inner, long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+  auto dual = [&](auto inner, idx_t c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
                   const T (&y1c)[VEC], const T (&y2c)[VEC], const IterParams<T>& P, T (&o1)[VEC], T (&o2)[VEC], bool acc) {
     constexpr bool I = decltype(inner)::value;
     const T sigS = P.sigma * a.Sval, theta = P.theta;
     const bool has_next = I || c + 1 < nx;
-    const bool counted = (size_t)c >= a.rx0 && (size_t)c < a.rx1;       // residual terms of this column count (column-sharded images)
+    const bool counted = c >= rx0 && c < rx1;       // residual terms of this column count (column-sharded images)
     const T bel_n = lane_down(xn_c[0]);                         // lane 63: no source, its last row is halo
     const T bel_o = lane_down(xo_c[0]);
     T av[2][VEC], nv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const long row = row0 + j;
+      const idx_t row = row0 + j;
       const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
       const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
       const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
         T spd = 0, spv = 0;
 #pragma unroll
         for (int j = 0; j < VEC; j++) {
-          const long row = row0 + j;
+          const idx_t row = row0 + j;
           const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
           const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;     // K x^(k+2) again: cheaper than keeping it in registers
           const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
@@ -345,13 +349,13 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     for (int k = 0; k < PF - 1; k++) if (xa + k < nx && xa + k <= xb + 1) load_col(xa + k, ahead[k]);
   }
   // every lane active and no lane on the first / last image row: the whole strip is interior
-  const bool strip_inner = (long)strip * kRowsPerWave - VEC >= 1 && (long)strip * kRowsPerWave + (long)(kWave - 1) * VEC < ny - 1;
-  auto step = [&](auto inner, long c) {
+  const bool strip_inner = (idx_t)strip * kRowsPerWave - VEC >= 1 && (idx_t)strip * kRowsPerWave + (idx_t)(kWave - 1) * VEC < ny - 1;
+  auto step = [&](auto inner, idx_t c) {
     Col pre = {};
-    constexpr long kAhead = 2 + PF;
+    constexpr idx_t kAhead = 2 + PF;
     const bool has_pre = !kRing && c + kAhead < nx && c + kAhead <= xb + 1;
     if (active && has_pre) load_col(c + kAhead, pre);
-    const long ca = c + 2, cb = c + 1;
+    const idx_t ca = c + 2, cb = c + 1;
     if (kRing) {
       in1 = in2;
       if (has_col(ca)) ring_fetch(ca, has_col(ca + 1), in2); else in2 = Col{};
@@ -369,13 +373,13 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       if (owner && cb < xb) {
         stv_o<T, VEC, true, RAG>(x_out, off_of(cb), x2_1, nvalid);
         if (kMid) stv_o<T, VEC, true, RAG>(x_mid, off_of(cb), x1_1, nvalid);
-        if (kRes && (size_t)cb >= a.rx0 && (size_t)cb < a.rx1) {   // dual_residual_transform (backend_pdhg.cu:73-94)
+        if (kRes && cb >= rx0 && cb < rx1) {   // dual_residual_transform (backend_pdhg.cu:73-94)
           constexpr bool kEdges = VART && !decltype(inner)::value;
           T sTv[kEdges ? VEC : 1], iTv[kEdges ? VEC : 1];             // sqrt(Tau_j), 1 / (tau sqrt(Tau_j)) of this column's pixels
           if (kEdges) {
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
-              const long row = row0 + j;
+              const idx_t row = row0 + j;
               const int cnt = 4 - (cb == 0 ? 1 : 0) - (cb == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
               const T sT = cnt == 4 ? sqT : t_sqrt(cnt == 3 ? a.Tcls[1] : a.Tcls[0]);
               sTv[kEdges ? j : 0] = sT; iTv[kEdges ? j : 0] = cnt == 4 ? inv_tauT : (T)1 / (p2.tau * sT);
@@ -428,7 +432,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       kt_1[j] = kt_2[j];
     }
   };
-  for (long c = xa - 3; c < xb; c++) {
+  for (idx_t c = xa - 3; c < xb; c++) {
     // the stencils of this step touch columns c-1 .. c+3 (stage D reads column c+1, stage A column
     // c+1 .. c+2 and their left neighbours): all strictly inside, all four stages running
     if (strip_inner && c >= xa && c >= 2 && c + 3 < nx - 1) step(std::true_type(), c);

@@ -115,7 +115,12 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   // both live in LDS (own lanes only, no synchronisation), the instance stays within the 128 VGPRs of 16 wavefronts per CU
   __shared__ T s_kt[RES ? 3 : 1][RES ? WT : 1][RES ? kPix : 1];
   __shared__ double s_acc[RES ? 4 : 1][RES ? WT : 1][RES ? kWave : 1];
-  const long nx = (long)a.nx, ny = (long)a.ny, L = (long)a.L;
+  // column / row / plane indices: 32-bit in the plain instance -- the scalar unit orders 32-bit values itself, 64-bit orderings are
+  // vector instructions (2048 x 2048 x 64, same box: 1.279 -> 1.233 ms per iteration).  The residual instance keeps 64-bit indices:
+  // with 32-bit ones it spills 11 registers (none with these; 1.60 -> 2.06 ms); its counter form (RES with FLAGS) spills 12 either way
+  // and runs 2.14 ms.
+  typedef typename std::conditional<RES, long, int>::type idx_t;
+  const idx_t nx = (idx_t)a.nx, ny = (idx_t)a.ny, L = (idx_t)a.L;
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // wave-uniform: plane, roles and base pointers live in SGPRs
   const unsigned groups = (unsigned)((L + P - 1) / P);
@@ -127,18 +132,18 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   // the strip fastest, and 9 % more time with the strip slowest)
   const unsigned strips_n = total / (groups * chunks);
   const unsigned grp = tile % groups, strip = (tile / groups) % strips_n, chunk = tile / (strips_n * groups);
-  const long pl = (long)grp * P - 1 + wv;              // this wavefront's plane (may lie outside the volume: idle, still takes part in the barriers)
+  const idx_t pl = (idx_t)grp * P - 1 + wv;              // this wavefront's plane (may lie outside the volume: idle, still takes part in the barriers)
   const bool exists = pl >= 0 && pl < L;
-  const long l = exists ? pl : 0;
+  const idx_t l = exists ? pl : 0;
   const bool do_y1 = exists && wv <= P + 1;
   const bool do_x2 = exists && wv >= 1 && wv <= P + 1;
   const bool do_y2 = exists && wv >= 1 && wv <= P;
   const bool has_above = exists && l + 1 < L, has_below = exists && l > 0;
-  const long row0 = (long)strip * kRowsPerWave + ((long)lane - kHalo) * VEC;
+  const idx_t row0 = (idx_t)strip * kRowsPerWave + ((idx_t)lane - kHalo) * VEC;
   const bool active = exists && row0 >= 0 && row0 < ny;
   const bool owner = active && lane >= kHalo && lane < kWave - kHalo;
-  const long xa = (long)chunk * a.cols_per_block;
-  const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const idx_t xa = (idx_t)chunk * a.cols_per_block;
+  const idx_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t Pn = (size_t)nx * (size_t)ny, N = Pn * (size_t)L, plane = (size_t)l * Pn;
   const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
   const T* y1p = y + plane; const T* y2p = y + N + plane; const T* y3p = y + 2 * N + plane;
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
 
   typedef ColX2<T, VEC, GB> Col;
-  const unsigned voff = (unsigned)(row0 * (long)sizeof(T));          // meaningful in active lanes only (the others do not store)
+  const unsigned voff = (unsigned)(row0 * (idx_t)sizeof(T));          // meaningful in active lanes only (the others do not store)
   // Loads are UNCONDITIONAL: a lane outside the image reads the strip's first rows, a column outside the chunk's range the nearest
   // valid one, a missing neighbour plane the own plane -- values nobody uses (every use is guarded by the predicate that would have
   // guarded the load), but a register set that is overwritten as a whole each step is dead before it, which is what lets the three
@@ -156,13 +161,13 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   const unsigned voff_ld = kUncond && !active ? 0u : voff;
   const T* zxp = kUncond && !has_above ? xp : xp + Pn;
   const T* y3mp = kUncond && !has_below ? y3p : y3p - Pn;
-  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
-  auto load_col = [&](long c, Col& in) {
+  auto has_col = [&](idx_t k) { return k >= 0 && k < nx && k <= xb + 1; };
+  auto load_col = [&](idx_t c, Col& in) {
     if (!kUncond) {
       in = Col{};
       if (!(active && has_col(c))) return;
     }
-    const long cc = !kUncond ? c : (c < 0 ? 0 : (c >= nx ? nx - 1 : c));
+    const idx_t cc = !kUncond ? c : (c < 0 ? 0 : (c >= nx ? nx - 1 : c));
     const size_t o = (size_t)cc * (size_t)ny;                         // wave-uniform
     ldx_o<T, VEC>(y1p + o, voff_ld, in.y1); ldx_o<T, VEC>(y2p + o, voff_ld, in.y2); ldx_o<T, VEC>(y3p + o, voff_ld, in.y3); ldx_o<T, VEC>(xp + o, voff_ld, in.x);
     if constexpr (GB) ldx_o<T, VEC>(bp + o, voff_ld, in.b);
@@ -171,14 +176,14 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   };
   // primal step at column c of this plane (backend_pdhg.cu:317-338 with block_gradient3d.cu:127-149 on a zero-filled result);
   // v1 / v2 / v3: the dual variable at column c, p1c: its first component at column c-1, v3m: its third component one plane below
-  auto primal = [&](long c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&p1c)[VEC], const T (&v3m)[VEC],
+  auto primal = [&](idx_t c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&p1c)[VEC], const T (&v3m)[VEC],
                     const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1], const IterParams3<T>& Pm, T (&xn)[VEC], T (&ktv)[VEC]) {
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
     T parg[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const long row = row0 + j;
+      const idx_t row = row0 + j;
       T divy = (row < ny - 1) ? v2[j] : (T)0;
       if (row > 0) divy -= (j > 0 ? v2[j > 0 ? j - 1 : 0] : up);
       T divx = (c < nx - 1) ? v1[j] : (T)0;
@@ -202,9 +207,9 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? bv[GB ? j : 0] : a.g_val[1]);
   };
   // K x (new iterate) and K x_prev (old iterate) of pixel j at column c (block_gradient3d.cu:62-80)
-  auto gradients = [&](long c, int j, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+  auto gradients = [&](idx_t c, int j, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
                        const T (&xo_z)[VEC], T bel_n, T bel_o, T (&kx)[3], T (&kp)[3]) {
-    const long row = row0 + j;
+    const idx_t row = row0 + j;
     const bool has_next = c + 1 < nx;
     const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
     const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   };
   // dual step at column c of this plane (backend_pdhg.cu:341-370): xn_* the new primal iterate at columns c / c+1 / one plane
   // above, xo_* the old one, v* the dual variable at column c
-  auto dual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+  auto dual = [&](idx_t c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
                   const T (&xo_z)[VEC], const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const IterParams3<T>& Pm,
                   T (&out)[3][VEC]) {
     const T sigS = Pm.sigma * a.Sval, theta = Pm.theta;
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     if (owner) { accumulate(2, dd); accumulate(3, dv); }
   };
   // primal_residual_transform (backend_pdhg.cu:97-120) at the column of stage D: v* = y^(k+1), out = y^(k+2)
-  auto primal_residual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
+  auto primal_residual = [&](idx_t c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xn_z)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC],
                              const T (&xo_z)[VEC], const T (&v1)[VEC], const T (&v2)[VEC], const T (&v3)[VEC], const T (&out)[3][VEC]) {
     const T theta = p2.theta;
     const T bel_n = lane_down(xn_c[0]);
@@ -322,7 +327,10 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   int step = 0, wr3 = 0;                               // FLAGS: step counter and its slot (step % 3)
   // (tried: the loop unrolled three times with the three raw-column sets renamed instead of copied -- 28 moves less per step,
   // 40-80 spilled registers at the 128 the instance may use)
-  for (long c = xa - 3; c <= xb; c++) {
+  // (tried in round 4: a second instance of the column step for the steady state -- columns c-1 .. c+3 inside the chunk's range and
+  // strictly inside the image, so no column select is left in the stencils and every stage condition is the wavefront's role alone:
+  // 16 selects and a dozen scalar compares less per step, but the two copies together no longer fit 128 VGPRs (15 spilled))
+  for (idx_t c = xa - 3; c <= xb; c++) {
     const int wr = FLAGS ? wr3 : (int)((c + 4) & 1), rd = FLAGS ? (wr3 == 0 ? 2 : wr3 - 1) : wr ^ 1;
     if (FLAGS && step > 0) {
       // wait for the neighbouring planes' wavefronts (whether or not their planes exist: every wavefront counts its steps)
@@ -335,7 +343,7 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     // neighbour-plane values published in the previous step
     if (has_above && wv + 1 < WT) { fetch(s_x1[rd], wv + 1, xz1_1); fetch(s_x2[rd], wv + 1, xz2_m); }
     if (has_below && wv >= 1) fetch(s_y3[rd], wv - 1, ym3_0);
-    const long ca = c + 2, cb = c + 1, cd = c - 1;
+    const idx_t ca = c + 2, cb = c + 1, cd = c - 1;
     if (exists && ca >= (xa - 1 > 0 ? xa - 1 : 0) && ca < nx && ca <= xb + 1) {                    // stage A
       T kt_a[VEC];
       primal(ca, in2.y1, in2.y2, in2.y3, in1.y1, in2.y3m, in2.x, in2.b, p1, x1_2, kt_a);

@@ -66,24 +66,27 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   __shared__ T s_sq[2][2][2 * LW][kPix];               // [buffer][stage B / D][component][pixel]
   __shared__ T s_kt[RES ? 3 : 1][RES ? LW : 1][RES ? kPix : 1];
   __shared__ double s_acc[RES ? 4 : 1][RES ? LW : 1][RES ? kWave : 1];
-  const long nx = (long)a.nx, ny = (long)a.ny;
+  // column / row indices: 32-bit in the plain instances (wave-uniform orderings are then scalar instructions; 64-bit ones are vector
+  // compares), 64-bit in the residual instances, which need 6-8 registers more with 32-bit indices (two of them spill)
+  typedef typename std::conditional<RES, long, int>::type idx_t;
+  const idx_t nx = (idx_t)a.nx, ny = (idx_t)a.ny;
   const int lane = threadIdx.x & (kWave - 1);
   const int ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // wave-uniform: base pointers live in SGPRs
   const unsigned total = gridDim.x, chunks = a.chunks;
   const unsigned xcd = blockIdx.x % 8u, q = blockIdx.x / 8u;            // XCD-aware tile order, see kernels_fused_iter.hip
   const unsigned tile = xcd * (total / 8u) + (xcd < total % 8u ? xcd : total % 8u) + q;
   const unsigned strip = tile / chunks, chunk = tile % chunks;
-  const long row0 = (long)strip * kRowsPerWave + ((long)lane - kHalo) * VEC;
+  const idx_t row0 = (idx_t)strip * kRowsPerWave + ((idx_t)lane - kHalo) * VEC;
   const bool active = row0 >= 0 && row0 < ny;
   const bool owner = active && lane >= kHalo && lane < kWave - kHalo;
-  const long xa = (long)chunk * a.cols_per_block;
-  const long xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
+  const idx_t xa = (idx_t)chunk * a.cols_per_block;
+  const idx_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t P = (size_t)nx * (size_t)ny, N = P * LW, plane = (size_t)ch * P;
   const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
   const T* y1p = y + plane; const T* y2p = y + N + plane;
   const T* xp = x + plane;
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
-  const unsigned voff = (unsigned)(row0 * (long)sizeof(T));          // meaningful in active lanes only
+  const unsigned voff = (unsigned)(row0 * (idx_t)sizeof(T));          // meaningful in active lanes only
 
   typedef ColMcX2<T, VEC, GB> Col;
   // kUncond (the plain instance): loads are UNCONDITIONAL -- a lane outside the image reads the strip's first rows, a column outside
@@ -93,27 +96,27 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   // barrier, "s_waitcnt lgkmcnt(0); s_barrier", in place of __syncthreads(): 0.205-0.210 ms per iteration at 4096^2 RGB either way)
   constexpr bool kUncond = !RES;
   const unsigned voff_ld = kUncond && !active ? 0u : voff;
-  auto has_col = [&](long k) { return k >= 0 && k < nx && k <= xb + 1; };
-  auto load_col = [&](long c, Col& in) {
+  auto has_col = [&](idx_t k) { return k >= 0 && k < nx && k <= xb + 1; };
+  auto load_col = [&](idx_t c, Col& in) {
     if (!kUncond) {
       in = Col{};
       if (!(active && has_col(c))) return;
     }
-    const long cc = !kUncond ? c : (c < 0 ? 0 : (c >= nx ? nx - 1 : c));
+    const idx_t cc = !kUncond ? c : (c < 0 ? 0 : (c >= nx ? nx - 1 : c));
     const size_t o = (size_t)cc * (size_t)ny;                         // wave-uniform
     ldm_o<T, VEC>(y1p + o, voff_ld, in.y1); ldm_o<T, VEC>(y2p + o, voff_ld, in.y2); ldm_o<T, VEC>(xp + o, voff_ld, in.x);
     if constexpr (GB != 0) ldm_o<T, VEC>(bp + o, voff_ld, in.b);
   };
   // primal step of this channel at column c (backend_pdhg.cu:317-338 with block_gradient2d.cu:122-138 on a zero-filled result);
   // v1 / v2: the dual variable at column c, p1c: its first component at column c-1
-  auto primal = [&](long c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&p1c)[VEC], const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1],
+  auto primal = [&](idx_t c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&p1c)[VEC], const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1],
                     const IterParamsMc<T>& Pm, T (&xn)[VEC], T (&ktv)[VEC]) {
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
     T parg[VEC], parg0[GB == 2 ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const long row = row0 + j;
+      const idx_t row = row0 + j;
       T divy = (row < ny - 1) ? v2[j] : (T)0;
       if (row > 0) divy -= (j > 0 ? v2[j > 0 ? j - 1 : 0] : up);
       T divx = (c < nx - 1) ? v1[j] : (T)0;
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   };
   // first half of the dual step at column c (backend_pdhg.cu:341-370, block_gradient2d.cu:61-77): the two dual arguments of this
   // channel, their squares published for the norm over all channels
-  auto dual_args = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC], const T (&v1)[VEC],
+  auto dual_args = [&](idx_t c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC], const T (&v1)[VEC],
                        const T (&v2)[VEC], const IterParamsMc<T>& Pm, T (&av)[2][VEC], T (&sq)[2 * LW][kPix]) {
     const T sigS = Pm.sigma * a.Sval, theta = Pm.theta;
     const bool has_next = c + 1 < nx;
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     const T bel_o = lane_down(xo_c[0]);
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const long row = row0 + j;
+      const idx_t row = row0 + j;
       const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
       const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
       const T kx0 = has_next ? xn_n[j] - xn_c[j] : (T)0;
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     if (owner) { accumulate(2, dd); accumulate(3, dv); }
   };
   // primal_residual_transform (backend_pdhg.cu:97-120) at the column of stage D: v* = y^(k+1), out = y^(k+2); K x, K x_prev formed again
-  auto primal_residual = [&](long c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC], const T (&v1)[VEC],
+  auto primal_residual = [&](idx_t c, const T (&xn_c)[VEC], const T (&xn_n)[VEC], const T (&xo_c)[VEC], const T (&xo_n)[VEC], const T (&v1)[VEC],
                              const T (&v2)[VEC], const T (&out)[2][VEC]) {
     const T theta = p2.theta;
     const bool has_next = c + 1 < nx;
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     double pd = 0, pv = 0;
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const long row = row0 + j;
+      const idx_t row = row0 + j;
       const T below_n = (j < VEC - 1) ? xn_c[j < VEC - 1 ? j + 1 : 0] : bel_n;
       const T below_o = (j < VEC - 1) ? xo_c[j < VEC - 1 ? j + 1 : 0] : bel_o;
       const T kx[2] = {has_next ? xn_n[j] - xn_c[j] : (T)0, (row < ny - 1) ? below_n - xn_c[j] : (T)0};
@@ -238,11 +241,11 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): nothing of the prologue in flight when the loop starts (see kernels_fused_iter3d_x2.hip)
 
   int k3 = 0;                                          // slot of s_kt that stage A writes in this step
-  for (long c = xa - 3; c <= xb; c++) {
+  for (idx_t c = xa - 3; c <= xb; c++) {
     const int buf = (int)((c + 4) & 1);
     in1 = in2; in2 = pre;
     load_col(c + 3, pre);
-    const long ca = c + 2, cb = c + 1, cd = c - 1;
+    const idx_t ca = c + 2, cb = c + 1, cd = c - 1;
     const bool runA = ca >= (xa - 1 > 0 ? xa - 1 : 0) && ca < nx && ca <= xb + 1;
     const bool runB = cb >= (xa - 1 > 0 ? xa - 1 : 0) && cb < nx && cb <= xb;
     const bool runC = c >= xa && c < nx && c <= xb;
