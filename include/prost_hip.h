@@ -58,11 +58,12 @@ int prost_hip_stream_create(void** stream);
 int prost_hip_stream_destroy(void* stream);
 int prost_hip_stream_synchronize(void* stream);
 int prost_hip_device_synchronize(void);
-/* Kernel timing without stream markers: the NEXT iteration-kernel launch of the calling thread (the fused PDHG iteration kernels
- * and the kernels of prost_hip_cgls_round) stamps `start` / `stop` (events of prost_hip_event_create) with the kernel's own begin
- * and end (hipExtLaunchKernel), so prost_hip_event_elapsed_ms(start, stop) is the kernel's duration as a profiler reports it and no
- * barrier packet sits between consecutive launches.  (NULL, NULL) withdraws events no launch has taken.  Launches that record
- * nothing else (reduction folds, generic kernels) do not take the events. */
+/* Kernel timing: the NEXT iteration-kernel launch of the calling thread (the fused PDHG iteration kernels and the kernels of
+ * prost_hip_cgls_round) takes `start` / `stop` (events of prost_hip_event_create) into hipExtLaunchKernel.  `stop` is bound to the
+ * kernel's own command (its end; free).  `start` may be NULL: a start event is a marker packet of its own in front of the kernel
+ * (~4 us: it breaks the back-to-back dispatch of a chain), so a caller that stamps every launch of a chain passes stop events only
+ * and reads prost_hip_event_elapsed_ms(stop of the previous launch, stop of this one).  (NULL, NULL) withdraws events no launch has
+ * taken.  Launches that record nothing else (reduction folds, generic kernels) do not take the events. */
 int prost_hip_next_launch_events(void* start, void* stop);
 /* HIP graphs: the launches enqueued on `stream` between begin and end are recorded instead of executed;
  * end returns an executable graph that replays them with one host call (launch-bound inner loops). */
@@ -71,6 +72,9 @@ int prost_hip_stream_end_capture(void* stream, void** graph_exec);
 int prost_hip_graph_launch(void* graph_exec, void* stream);
 int prost_hip_graph_destroy(void* graph_exec);
 int prost_hip_event_create(void** event);
+/* an event for kernel timing only (prost_hip_next_launch_events): created without the system-scope release a default event adds to the
+ * end of the command it is bound to -- nothing the host reads from memory may be ordered by it */
+int prost_hip_event_create_timing(void** event);
 int prost_hip_event_destroy(void* event);
 int prost_hip_event_record(void* event, void* stream);
 int prost_hip_event_synchronize(void* event);

@@ -38,16 +38,20 @@ constexpr int kBlock = 256;        // 4 waves, one per SIMD
 constexpr int kMaxGridStride = 1 << 20;
 constexpr int kReduceBlocks = 8192;        // partial slots in the reduction workspace (pairs of doubles)
 
-// Kernel timing without stream markers (prost_hip_next_launch_events): the next PH_LAUNCH of the calling thread hands the two events
-// to hipExtLaunchKernelGGL, which stamps them with the kernel's OWN begin / end -- hipEventElapsedTime between them is the kernel's
-// duration as rocprofv3 reports it.  hipEventRecord brackets are barrier packets: they break the back-to-back dispatch of
-// consecutive launches (~4 us each) and measure the dispatch gap along with the kernel (a 22 us kernel read 14 % long).
+// Kernel timing (prost_hip_next_launch_events): the next PH_LAUNCH of the calling thread hands the events to hipExtLaunchKernelGGL.
+// The STOP event is bound to the kernel's own command: it costs nothing and carries the kernel's end.  A START event is a marker of
+// its own in front of the kernel -- a barrier packet that breaks the back-to-back dispatch of consecutive launches: a chain of 200
+// launches of a 75 us kernel runs 75.5 us per launch plain or with stop events only, 80.1 us with start + stop pairs (78.9 with
+// hipEventDisableSystemFence events; tools/stamp_probe.hip, profiles/r04_stamp_probe.txt).  Callers that time EVERY launch of a chain
+// therefore pass stop events only and take the distance between the ends of consecutive launches; a start event is for a launch
+// whose predecessor on the stream is not a stamped one.  (hipEventRecord brackets cost two such packets per launch and measure the
+// dispatch gap along with the kernel: a 22 us kernel read 14 % long.)
 extern thread_local hipEvent_t g_launch_ev_start, g_launch_ev_stop;
 }  // namespace prost_hip
 #include <hip/hip_ext.h>
 #define PH_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                        \
   do {                                                                                                                              \
-    if (::prost_hip::g_launch_ev_start) {                                                                                           \
+    if (::prost_hip::g_launch_ev_stop) {                                                                                            \
       hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ::prost_hip::g_launch_ev_start, ::prost_hip::g_launch_ev_stop, 0,   \
                             __VA_ARGS__);                                                                                           \
       ::prost_hip::g_launch_ev_start = nullptr; ::prost_hip::g_launch_ev_stop = nullptr;                                            \

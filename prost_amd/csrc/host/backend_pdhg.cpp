@@ -203,6 +203,8 @@ void BackendPDHG<T>::Initialize() {
   CheckHip(prost_hip_host_alloc((void**)&res_host_, 4 * sizeof(double)), "host_alloc");
   CheckHip(prost_hip_malloc(&workspace_, prost_hip_reduce_workspace_bytes()), "malloc");
   side_inflight_ = resolve_on_side_ = false;
+  // kernel timing: a first batch of events now, so that a short timed run does not create them (a few microseconds each) between its launches
+  while (ev_.size() < 64) { void* e; CheckHip(prost_hip_event_create_timing(&e), "event_create"); ev_.push_back(e); }
   const bool deferred_rule = opts_.stepsize_variant != kPDHGStepsResidualGoldstein && opts_.stepsize_variant != kPDHGStepsResidualBoyd;
   if (this->comm_ && deferred_rule && owned_x1_ == 0) {     // column-sharded slabs also exchange halos on this communicator: keep one stream there
     CheckHip(prost_hip_stream_create(&side_stream_), "stream_create");
@@ -395,6 +397,7 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
   dev_batches_++;
   CheckHip(prost_hip_memcpy_d2h(rule_mirror_, rule_mirror_dev_, sizeof(prost_hip_pdhg_rule_state), s), "memcpy_d2h");
   CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");          // the batch's ONE host wait
+  last_end_ = kNoEvent;              // (kernel timing: the stream has drained)
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   const prost_hip_pdhg_rule_state& m = *rule_mirror_;
   if (m.evaluations > 0) {
@@ -422,23 +425,26 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
 
 template <typename T>
 size_t BackendPDHG<T>::NewEvent() {
-  if (ev_used_ == ev_.size()) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
+  if (ev_used_ == ev_.size()) { void* e; CheckHip(prost_hip_event_create_timing(&e), "event_create"); ev_.push_back(e); }
   return ev_used_++;
 }
 
-/// Timing of a launch: the next iteration-kernel launch stamps an event pair with the kernel's OWN begin / end
-/// (prost_hip_next_launch_events -> hipExtLaunchKernel).  Up to round 2 the launch was bracketed by hipEventRecord markers on the
-/// stream: barrier packets that break the back-to-back dispatch of consecutive launches (~4 us each -- 3 % of a 20-step run with
-/// every launch bracketed) and measure the dispatch gap along with the kernel.
+/// Timing of a launch (prost_hip_next_launch_events -> hipExtLaunchKernel).  Every sampled launch takes a STOP event, which is bound
+/// to the kernel's own command and costs nothing.  Its sample runs from the stop event of the PREVIOUS sampled launch when nothing
+/// else has been enqueued and the host has not waited since (last_end_): the distance between the ends of two consecutive kernels
+/// of an in-order stream -- the kernel plus the dispatch gap in front of it (~0.5 us).  Otherwise the launch also takes a START event,
+/// a marker packet in front of the kernel (~4 us lost in the chain; rounds 3-4 gave one to EVERY sampled launch: 5-6 % of a 20-step
+/// run with every launch timed; hipEventRecord brackets, round 2, cost two packets).
 template <typename T>
 bool BackendPDHG<T>::BeginSample(int kind) {
   // (at most kMaxSamples launches are timed between two KernelTimes calls, later ones run untimed)
-  if (!this->time_kernels_ || samples_.size() >= kMaxSamples) return false;
+  if (!this->time_kernels_ || samples_.size() >= kMaxSamples) { last_end_ = kNoEvent; return false; }
   // one launch in `sample_every_`
-  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) return false;
-  const size_t start = NewEvent(), end = NewEvent();
-  CheckHip(prost_hip_next_launch_events(ev_[start], ev_[end]), "next_launch_events");
-  samples_.push_back({kind, start, end});
+  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) { last_end_ = kNoEvent; return false; }
+  const size_t start = last_end_ != kNoEvent ? last_end_ : NewEvent(), end = NewEvent();
+  CheckHip(prost_hip_next_launch_events(last_end_ != kNoEvent ? nullptr : ev_[start], ev_[end]), "next_launch_events");
+  samples_.push_back({kind, start, end, last_end_ == kNoEvent});
+  last_end_ = end;
   return true;
 }
 
@@ -451,7 +457,8 @@ template <typename T>
 void BackendPDHG<T>::AbortSample(bool sampled) {
   if (!sampled) return;
   prost_hip_next_launch_events(nullptr, nullptr);          // (no CheckHip: an exception is already on its way)
-  if (!samples_.empty()) { samples_.pop_back(); if (ev_used_ >= 2) ev_used_ -= 2; }
+  if (!samples_.empty()) { ev_used_ -= samples_.back().own_start ? 2 : 1; samples_.pop_back(); }
+  last_end_ = kNoEvent;
 }
 
 template <typename T>
@@ -648,6 +655,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
     CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
                                   iteration_ >= 2 ? 1 : 0, res ? res_target() + 2 : nullptr, workspace_, s), "fused_primal");
   });
+  if (res) last_end_ = kNoEvent;           // (kernel timing: the fold of the primal pass's sums sits in front of the dual pass)
   x_.swap(x_prev_);                        // x_ = x^(k+1), x_prev_ = x^k       (:334)
   // kx_prev_ of the reference is K x^k except at k = 0 (zero vector, :216)
   TimedLaunch(kKernelDual, [&] {
@@ -801,14 +809,16 @@ void BackendPDHG<T>::ResolveResiduals() {
   if (resolve_on_side_) {
     // (with a communicator the sums are being all-reduced on the side stream: the iteration stream is free for the next pair meanwhile)
     if (CanSpeculate()) Speculate();
+    last_end_ = kNoEvent;            // (kernel timing: the host waits, the next launch does not follow its predecessor back to back)
     CheckHip(prost_hip_event_synchronize(ev_res_done_), "event_synchronize");
     resolve_on_side_ = false;
   }
   else if (CanSpeculate()) {
     Speculate();                                         // the device goes on with the next pair while the host looks at the sums
+    last_end_ = kNoEvent;
     CheckHip(prost_hip_event_synchronize(ev_res_local_), "event_synchronize");
   }
-  else CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
+  else { last_end_ = kNoEvent; CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize"); }
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   // the reference reduces in T and takes std::sqrt of the T sums (:433-436)
   this->primal_residual_ = std::sqrt((T)res_host_[0]);
@@ -877,6 +887,7 @@ void BackendPDHG<T>::ConstraintVariables() {
     CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), ktyp.data(), (double)tau_, n, s), "w_variable");
     CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx.data(), kxp.data(), (double)sigma_, (double)theta_, m, s), "z_variable");
     CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");             // the temporaries above go out of scope
+    last_end_ = kNoEvent;
   } else {
     CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), (double)tau_, n, s), "w_variable");   // :147-160
     CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "z_variable");   // :169-186

@@ -1,5 +1,6 @@
 // runtime.hip -- device / memory / stream / event plumbing of the C ABI, plus the RCCL
 // communicator used for the global stopping criterion of multi-GPU batches.
+#include <cstdlib>
 #include "common.hpp"
 
 #include <rccl/rccl.h>
@@ -60,12 +61,16 @@ int prost_hip_stream_destroy(void* s) { if (s) PH_CHECK(hipStreamDestroy(as_stre
 int prost_hip_stream_synchronize(void* s) { PH_CHECK(hipStreamSynchronize(as_stream(s))); return 0; }
 int prost_hip_device_synchronize(void) { PH_CHECK(hipDeviceSynchronize()); return 0; }
 int prost_hip_event_create(void** e) { hipEvent_t ev; PH_CHECK(hipEventCreate(&ev)); *e = ev; return 0; }
+int prost_hip_event_create_timing(void** e) {
+  static const bool fence = []() { const char* v = getenv("PROST_TIMING_EVENTS_FENCE"); return v && atoi(v) != 0; }();      // A/B
+  hipEvent_t ev; PH_CHECK(hipEventCreateWithFlags(&ev, fence ? hipEventDefault : hipEventDisableSystemFence)); *e = ev; return 0;
+}
 int prost_hip_event_destroy(void* e) { if (e) PH_CHECK(hipEventDestroy((hipEvent_t)e)); return 0; }
 int prost_hip_event_record(void* e, void* s) { PH_CHECK(hipEventRecord((hipEvent_t)e, as_stream(s))); return 0; }
 int prost_hip_stream_wait_event(void* s, void* e) { PH_CHECK(hipStreamWaitEvent(as_stream(s), (hipEvent_t)e, 0)); return 0; }
 int prost_hip_event_synchronize(void* e) { PH_CHECK(hipEventSynchronize((hipEvent_t)e)); return 0; }
 int prost_hip_next_launch_events(void* start, void* stop) {
-  if ((start == nullptr) != (stop == nullptr)) { set_error("prost_hip_next_launch_events: both events or none"); return 1; }
+  if (start != nullptr && stop == nullptr) { set_error("prost_hip_next_launch_events: a start event needs a stop event"); return 1; }
   g_launch_ev_start = (hipEvent_t)start; g_launch_ev_stop = (hipEvent_t)stop;
   return 0;
 }
