@@ -186,6 +186,8 @@ class BackendPDHG : public Backend<T> {
   /// takes it) and the sample that was never recorded is dropped
   void AbortSample(bool sampled);
   /// BeginSample / launch / EndSample with that clean-up on the exception path
+  bool DescribeProxG(ProxDesc& out);         // prox_g as one elem_operation:1d over the whole primal variable (pieces merged)
+  device_vector<T> merged_g_[7];             // coefficient vectors assembled from the pieces of prox_g
   template <class F> void TimedLaunch(int kind, F&& launch) {
     const bool sampled = BeginSample(kind);
     try { launch(); } catch (...) { AbortSample(sampled); throw; }

@@ -22,6 +22,7 @@ struct ProxDesc {
   bool interleaved = false;
   const void* coeff_ptr[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device, or null
   double coeff_val[7] = {0, 0, 0, 0, 0, 0, 0};
+  bool moreau = false;      // the prox is the Moreau wrap (prox_moreau.cu:98-134) of the described operation
 };
 
 template <typename T> class ProxTransform;

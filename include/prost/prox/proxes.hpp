@@ -54,6 +54,8 @@ class ProxMoreau : public Prox<T> {
   virtual size_t gpu_mem_amount() const { return this->size_ * sizeof(T) + conjugate_->gpu_mem_amount(); }
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { conjugate_->get_separable_structure(sep); }
   virtual bool supports_arg_source() const;
+  /// the wrapped operation's description with `moreau` set (a wrap of a wrap is not described)
+  virtual bool describe(ProxDesc& d) const;
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
   virtual void average_preconditioner(std::vector<T>& precond) { conjugate_->average_preconditioner(precond); }
   virtual bool average_uniform(T& value) const { return conjugate_->average_uniform(value); }

@@ -31,8 +31,9 @@ extern "C" {
  *    header passes a too short buffer -- check prost_hip_abi_version() >= 4 before relying on the 8-slot layout);
  *    additions: comm_count, comm_is_host, comm_host_configure (point-to-point on the host-callback transport),
  *    fused operator entry points of the ADMM graph projection, mask_merge, next_launch_events, pattern_spmv
- * 5: additions only -- device-resident step-size rules (pdhg_rule_*, fused_iteration_rec, fused_iteration2_rec) */
-#define PROST_HIP_ABI_VERSION 5
+ * 5: additions only -- device-resident step-size rules (pdhg_rule_*, fused_iteration_rec, fused_iteration2_rec)
+ * 6: prost_hip_fused_desc gained f_moreau (appended); additions: event_create_timing; next_launch_events takes (NULL, stop) */
+#define PROST_HIP_ABI_VERSION 6
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
@@ -289,6 +290,10 @@ typedef struct {
                             /* (corner, edge, interior; count = 4 - [x == 0] - [x == nx - 1] - [y == 0] - [y == ny - 1]), T_val = T_cls[2]. */
                             /* Sigma stays uniform (the all-zero rows of the matrix inherit 1/2, problem.cu:267-286).  Honoured by        */
                             /* prost_hip_fused_iteration (L <= 2), _iteration2 (L == 1, ROF shape), _iteration_mc (L = 3, 4); the others refuse it.   */
+  int f_moreau;             /* (ABI 6) prox_fstar is the Moreau wrap of the described elem_operation:norm2 (a problem written in the PRIMAL  */
+                            /* form, example_rof_primal.m:27: backend_pdhg.cu:255-266 derives prox_f* from prox_f; prox_moreau.cu:98-134):   */
+                            /* v = arg / (sigma Sigma), r = prox of the described function at v with the step 1 / (sigma Sigma),             */
+                            /* result = arg - sigma Sigma r.  Honoured by prost_hip_fused_iteration and _iteration_mc; the others refuse it. */
 } prost_hip_fused_desc;
 /* Folds a BINARY per-element coefficient a of ElemOperation1D (elem_operation_1d.hpp:42-44: a == 0 skips the function, the
  * element passes through) into the b stream: bm[i] = a[i] == 0 ? sentinel : (b ? b[i] : b_val), sentinel = a quiet NaN with the

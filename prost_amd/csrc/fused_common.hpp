@@ -116,7 +116,13 @@ struct FusedArgs {
   size_t rx0, rx1;            // columns whose residual terms are counted (single-kernel / pair kernels)
   int varT;                   // position-dependent primal preconditioner (prost_hip_fused_desc.var_T): Tcls by stencil entries per column
   T Tcls[3];
+  int fmor;                   // prox_fstar = Moreau wrap of the described norm2 operation (prost_hip_fused_desc.f_moreau)
 };
+
+// step size the dual elem operation sees: sigma Sigma, or -- inside a Moreau wrap, which calls it with the inverted flag --
+// 1 / (sigma Sigma) as ElemOperation forms it (elem_operation_1d.hpp:40: 1. / (tau_scal * tau_diag) in double, narrowed)
+template <class T>
+__host__ __device__ inline T dual_prox_step(T sigma, T Sval, int fmor) { return fmor ? (T)(1. / (double)(sigma * Sval)) : sigma * Sval; }
 
 // step sizes of one iteration + the element-independent prox terms that go with them (device_math.hpp: UniformProx)
 // the step-size dependent terms of prox_g for the pixels whose Tau_j differs from the interior's (FusedArgs::varT): the step
@@ -160,6 +166,7 @@ struct PdhgRecord {
   T g_val[7], f_val[7], Tval, Sval;  // what make_uniform_prox needs beside the step size
   int varT;                          // FusedArgs::varT and the two other classes of Tau_j
   T Tcls[2];
+  int fmor;                          // FusedArgs::fmor
   unsigned long long evaluations;    // rule evaluations since prost_hip_pdhg_rule_begin
   unsigned long long stop_iteration;
 };
@@ -196,6 +203,7 @@ inline FusedArgs<T> make_fused_args(const prost_hip_fused_desc* d) {
   a.cols_per_block = 16;
   a.varT = d->var_T ? 1 : 0;
   for (int k = 0; k < 3; k++) a.Tcls[k] = (T)d->T_cls[k];
+  a.fmor = d->f_moreau ? 1 : 0;
   return a;
 }
 

@@ -43,6 +43,45 @@ static bool uniform(const std::vector<T>& v, T& value) {
   return same.load();
 }
 
+/// prox_g as ONE elem_operation:1d over all primal entries.  The primal variable may carry several of them on consecutive
+/// sub-variables (example_rof_primal.m:19-26: u1, u2, u3 with slices of f as coefficient b): same function, each coefficient a scalar
+/// or a vector per piece.  A coefficient that is the same scalar in every piece stays a scalar; any other becomes ONE vector over the
+/// whole variable, assembled on the device from the pieces' vectors / scalars (merged_g_) -- what the kernels stream either way.
+template <typename T>
+bool BackendPDHG<T>::DescribeProxG(ProxDesc& out) {
+  const size_t n = this->problem_->ncols();
+  for (auto& v : merged_g_) v.clear();
+  if (prox_g_.size() == 1) return prox_g_[0]->describe(out) && prox_g_[0]->index() == 0 && prox_g_[0]->size() == n;
+  std::vector<std::pair<size_t, ProxDesc>> pieces;             // (index, description), sorted by index
+  for (auto& p : prox_g_) {
+    ProxDesc d;
+    if (!p->describe(d) || d.kind != ProxDesc::kElem1D || d.moreau || d.count != p->size()) return false;
+    pieces.push_back({p->index(), d});
+  }
+  std::sort(pieces.begin(), pieces.end(), [](const std::pair<size_t, ProxDesc>& a, const std::pair<size_t, ProxDesc>& b) { return a.first < b.first; });
+  size_t at = 0;
+  for (auto& pc : pieces) {
+    if (pc.first != at || pc.second.fn != pieces[0].second.fn) return false;
+    at += pc.second.count;
+  }
+  if (at != n) return false;
+  out = pieces[0].second;
+  out.count = n;
+  for (int k = 0; k < 7; k++) {
+    bool scalar = true;
+    for (auto& pc : pieces) scalar = scalar && !pc.second.coeff_ptr[k] && pc.second.coeff_val[k] == pieces[0].second.coeff_val[k];
+    if (scalar) { out.coeff_ptr[k] = nullptr; out.coeff_val[k] = pieces[0].second.coeff_val[k]; continue; }
+    merged_g_[k].resize(n);
+    for (auto& pc : pieces) {
+      T* dst = merged_g_[k].data() + pc.first;
+      if (pc.second.coeff_ptr[k]) CheckHip(prost_hip_memcpy_d2d(dst, pc.second.coeff_ptr[k], pc.second.count * sizeof(T), CurrentStream()), "memcpy_d2d");
+      else CheckHip(Api<T>::fill(dst, pc.second.coeff_val[k], pc.second.count, CurrentStream()), "fill");
+    }
+    out.coeff_ptr[k] = merged_g_[k].data(); out.coeff_val[k] = 0;
+  }
+  return true;
+}
+
 /// fused path applies iff: one gradient2d/3d block (not label_first) spanning the whole operator,
 /// one elem_operation:1d prox_g over all primal entries, one elem_operation:norm2 prox_f* whose
 /// groups are the planar gradient components of a pixel, uniform Sigma and Tau.
@@ -51,7 +90,7 @@ bool BackendPDHG<T>::TryFused() {
   if (!opts_.allow_fused) return false;
   auto& prob = *this->problem_;
   auto linop = prob.linop();
-  if (linop->blocks().size() != 1 || prox_g_.size() != 1 || prox_fstar_.size() != 1) return false;
+  if (linop->blocks().size() != 1 || prox_g_.empty() || prox_fstar_.size() != 1) return false;
   BlockDesc bd;
   auto blk = linop->blocks()[0];
   // a block whose OPERATOR is gradient2d although it was handed over as a sparse matrix (example_rof_primal.m:10, :28): the stencil
@@ -64,9 +103,9 @@ bool BackendPDHG<T>::TryFused() {
   if (bd.label_first) return false;
   if (blk->row() != 0 || blk->col() != 0 || blk->nrows() != prob.nrows() || blk->ncols() != prob.ncols()) return false;
   ProxDesc pg, pf;
-  if (!prox_g_[0]->describe(pg) || !prox_fstar_[0]->describe(pf)) return false;
-  if (pg.kind != ProxDesc::kElem1D || pf.kind != ProxDesc::kElemNorm2 || pf.interleaved) return false;
-  if (prox_g_[0]->index() != 0 || prox_g_[0]->size() != prob.ncols()) return false;
+  if (!DescribeProxG(pg) || !prox_fstar_[0]->describe(pf)) return false;
+  // prox_f* may be the Moreau wrap of prox_f (a problem written in the primal form, example_rof_primal.m:27): one-kernel iterations
+  if (pg.kind != ProxDesc::kElem1D || pg.moreau || pf.kind != ProxDesc::kElemNorm2 || pf.interleaved) return false;
   if (prox_fstar_[0]->index() != 0 || prox_fstar_[0]->size() != prob.nrows()) return false;
   const bool d3 = bd.kind == BlockDesc::kGradient3D;
   const size_t pixels = d3 ? bd.nx * bd.ny * bd.L : bd.nx * bd.ny;
@@ -102,15 +141,15 @@ bool BackendPDHG<T>::TryFused() {
   desc_.res_x0 = owned_x0_; desc_.res_x1 = owned_x1_;
   desc_.g_b_masked = 0;
   desc_.is3d = d3 ? 1 : 0; desc_.nx = bd.nx; desc_.ny = bd.ny; desc_.L = bd.L;
-  desc_.g_fn = pg.fn; desc_.f_fn = pf.fn;
+  desc_.g_fn = pg.fn; desc_.f_fn = pf.fn; desc_.f_moreau = pf.moreau ? 1 : 0;
   for (int i = 0; i < 7; i++) {
     desc_.g_coeff_ptr[i] = pg.coeff_ptr[i]; desc_.g_coeff_val[i] = pg.coeff_val[i];
     desc_.f_coeff_ptr[i] = pf.coeff_ptr[i]; desc_.f_coeff_val[i] = pf.coeff_val[i];
   }
   desc_.T_val = (double)tv; desc_.S_val = (double)sv;
-  // (position-dependent Tau: the one-kernel iteration is the only fused form; the two-pass kernels refuse it)
+  // (position-dependent Tau, Moreau-wrapped prox_f*: the one-kernel iteration is the only fused form; the two-pass kernels refuse them)
   from_matrix_ = as_matrix;
-  if (desc_.var_T) return opts_.allow_single_kernel && (prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1 ||
+  if (desc_.var_T || desc_.f_moreau) return opts_.allow_single_kernel && (prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1 ||
                                                         prost_hip_fused_iteration_mc_supported(&desc_, dtype_id<T>()) == 1);
   return prost_hip_fused_supported(&desc_, dtype_id<T>()) == 1;
 }
@@ -170,6 +209,7 @@ void BackendPDHG<T>::Initialize() {
   } else prox_fstar_ = this->problem_->prox_fstar();
 
   fused_ = TryFused();
+  if (!fused_) for (auto& v : merged_g_) v.clear();
   arg_fused_g_ = arg_fused_f_ = opts_.allow_arg_fusion;
   for (auto& p : prox_g_) arg_fused_g_ = arg_fused_g_ && p->supports_arg_source();
   for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
@@ -267,6 +307,7 @@ void BackendPDHG<T>::Release() {
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); samples_.clear(); ev_used_ = 0; last_end_ = kNoEvent;
   y_spare_.clear(); x_spare_.clear(); sol_z_.clear(); sol_w_.clear(); b_masked_.clear();
+  for (auto& v : merged_g_) v.clear();
   x_.clear(); y_.clear(); x_prev_.clear(); y_prev_.clear(); temp_.clear(); kx_.clear(); kty_.clear(); kx_prev_.clear(); kty_prev_.clear();
 }
 
@@ -920,7 +961,7 @@ template <typename T>
 size_t BackendPDHG<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
   if (x_.size() == n && n > 0)          // after Initialize(): what the vectors really hold
-    return (x_.size() + x_prev_.size() + x_spare_.size() + y_.size() + y_prev_.size() + y_spare_.size() + b_masked_.size() + kty_.size() + kty_prev_.size() +
+    return (x_.size() + x_prev_.size() + x_spare_.size() + y_.size() + y_prev_.size() + y_spare_.size() + b_masked_.size() + merged_g_[0].size() + merged_g_[1].size() + merged_g_[2].size() + merged_g_[3].size() + merged_g_[4].size() + merged_g_[5].size() + merged_g_[6].size() + kty_.size() + kty_prev_.size() +
             kx_.size() + kx_prev_.size() + temp_.size() + sol_z_.size() + sol_w_.size()) * sizeof(T);
   if (fused_) return 2 * (n + m) * sizeof(T);
   return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511

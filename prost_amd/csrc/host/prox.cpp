@@ -123,6 +123,12 @@ void ProxMoreau<T>::EvalLocal(T* res, T* res_end, const T* arg, const T* arg_end
   (void)arg_end;
 }
 template <typename T>
+bool ProxMoreau<T>::describe(ProxDesc& d) const {
+  if (!conjugate_->describe(d) || d.moreau) return false;
+  d.moreau = true;
+  return true;
+}
+template <typename T>
 bool ProxMoreau<T>::supports_arg_source() const { return g_moreau_fuse && dynamic_cast<ProxElemDispatch<T>*>(conjugate_.get()) != nullptr; }
 template <typename T>
 void ProxMoreau<T>::EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau) {

@@ -308,7 +308,7 @@ static int pick_cols(size_t nx, size_t row_blocks, size_t planes) {
 static bool desc_ok(const prost_hip_fused_desc* d) {
   if (!d) return false;
   if (d->is3d) return false;                              // gradient3d passes: see kernels_fused3d.hip
-  if (d->var_T) return false;                             // position-dependent Tau: the one-kernel iterations only
+  if (d->var_T || d->f_moreau) return false;              // position-dependent Tau, Moreau-wrapped prox_f*: the one-kernel iterations only
   if (d->nx == 0 || d->ny == 0 || d->L == 0 || d->L > (size_t)kMaxFusedChannels) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   const size_t rb = (d->ny + kBlock - 1) / kBlock;        // worst case VEC = 1

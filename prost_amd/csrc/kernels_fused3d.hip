@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(kBlock) fused_dual3d_kernel(T* __restrict__ y_
 
 // ------------------------------------------------------------------------------------------
 bool fused3d_desc_ok(const prost_hip_fused_desc* d) {
-  if (!d || !d->is3d || d->var_T) return false;
+  if (!d || !d->is3d || d->var_T || d->f_moreau) return false;
   if (d->nx == 0 || d->ny == 0 || d->L == 0 || d->L > 65535) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   const size_t rb = (d->ny + kBlock - 1) / kBlock;        // worst case VEC = 1

@@ -283,8 +283,14 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
           arg[l] = cur.y1[l][j] + sigS * ((1 + theta) * kx[l] - theta * kp[l]);
           arg[LCH + l] = cur.y2[l][j] + sigS * ((1 + theta) * kx[LCH + l] - theta * kp[LCH + l]);
         }
+        // prox_f* given as the Moreau wrap of prox_f (FusedArgs::fmor; prox_moreau.cu:98-134 with the dual call's invert_tau = false): the
+        // operation sees v = arg / (sigma Sigma) and the step 1 / (sigma Sigma) (uf holds its terms), the result is arg - sigma Sigma r
+        const bool fm = !FAST && a.fmor != 0;
+        T va[2 * LCH];
 #pragma unroll
-        for (int i = 0; i < 2 * LCH; i++) norm += arg[i] * arg[i];
+        for (int i = 0; i < 2 * LCH; i++) va[i] = fm ? arg[i] / sigS : arg[i];
+#pragma unroll
+        for (int i = 0; i < 2 * LCH; i++) norm += va[i] * va[i];
         if (RES) {
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) { kxv[RES ? i : 0][RES ? j : 0] = kx[i]; kpv[RES ? i : 0][RES ? j : 0] = kp[i]; }
@@ -297,10 +303,10 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
           norm = t_sqrt(norm);
           const T pr = scaled_prox_u<T, FFN>(a.f_fn, norm, a.f_val, uf);
 #pragma unroll
-          for (int i = 0; i < 2 * LCH; i++) out[i][j] = pr * arg[i] / norm;
+          for (int i = 0; i < 2 * LCH; i++) { const T r = pr * va[i] / norm; out[i][j] = fm ? arg[i] - sigS * r : r; }
         } else {
 #pragma unroll
-          for (int i = 0; i < 2 * LCH; i++) out[i][j] = 0;
+          for (int i = 0; i < 2 * LCH; i++) out[i][j] = fm ? arg[i] - sigS * (T)0 : (T)0;
         }
       }
       if constexpr (FAST) {
@@ -480,7 +486,7 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
   if (rec) { tau = sigma = theta = 1.0; }
   // host-side evaluation of everything element-independent, in the kernels' own expression order
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
-  const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
+  const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, dual_prox_step<T>((T)sigma, a.Sval, a.fmor));
   const EdgeTerms<T> ec0 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[0]) : EdgeTerms<T>(), ec1 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[1]) : EdgeTerms<T>();
   // straight-line instance for the ROF shape (square / ind_leq0 with scalar a = 1, d = e = 0 on both sides); run-time
   // dispatched otherwise
@@ -488,6 +494,7 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
               (mask == 0x2 || (mask == 0 && d->L == 1)) &&
               ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
   if (rec && (a.g_val[4] != (T)0 || a.f_val[4] != (T)0 || d->g_coeff_ptr[4])) fast = false;
+  if (a.fmor) fast = false;           // Moreau-wrapped prox_f*: the run-time dispatched instances
 #define GO3(LCHv, G, F, M, R, RAGv, FASTv, VARTv) PH_LAUNCH((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv, VARTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
 #define GO2(LCHv, G, F, M, R, RAGv, FASTv) do { if (a.varT) GO3(LCHv, G, F, M, R, RAGv, FASTv, true); else GO3(LCHv, G, F, M, R, RAGv, FASTv, false); } while (0)
 #define GO(LCHv, G, F, M, R, FASTv) do { if (rag) GO2(LCHv, G, F, M, R, true, FASTv); else GO2(LCHv, G, F, M, R, false, FASTv); } while (0)

@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
 }
 
 static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
-  if (!d || d->is3d || d->L != 1) return false;
+  if (!d || d->is3d || d->L != 1 || d->f_moreau) return false;
   if (d->nx < 4 || d->ny < 4) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4 : 8) >= 4294967296.0) return false;   // 32-bit byte offsets per plane

@@ -200,6 +200,8 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
     const T bel_n = lane_down(xn_c[0]);
     const T bel_o = lane_down(cur.x[0]);
     T av[2][VEC];
+    T vv[FAST ? 1 : 2][FAST ? 1 : VEC];                    // what the norm2 operation sees (the arguments, or their Moreau pre-scaled form)
+    const bool fm = !FAST && a.fmor != 0;
     T kxv[RES ? 2 : 1][RES ? VEC : 1], kpv[RES ? 2 : 1][RES ? VEC : 1];
     const int buf = (int)(c & 1);
 #pragma unroll
@@ -214,8 +216,12 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       av[0][j] = cur.y1[j] + sigS * ((1 + theta) * kx0 - theta * kp0);       // backend_pdhg.cu:54-70
       av[1][j] = cur.y2[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
       if (RES) { kxv[0][RES ? j : 0] = kx0; kxv[RES ? 1 : 0][RES ? j : 0] = kx1; kpv[0][RES ? j : 0] = kp0; kpv[RES ? 1 : 0][RES ? j : 0] = kp1; }
-      s_sq[buf][ch][j * kWave + lane] = av[0][j] * av[0][j];             // [j][lane]: conflict-free banks
-      s_sq[buf][LW + ch][j * kWave + lane] = av[1][j] * av[1][j];
+      // prox_f* given as the Moreau wrap of prox_f (FusedArgs::fmor; prox_moreau.cu:98-134 with the dual call's invert_tau = false): the
+      // operation sees v = arg / (sigma Sigma) and the step 1 / (sigma Sigma) (uf holds its terms), the result is arg - sigma Sigma r
+      if (!FAST) { vv[0][FAST ? 0 : j] = fm ? av[0][j] / sigS : av[0][j]; vv[FAST ? 0 : 1][FAST ? 0 : j] = fm ? av[1][j] / sigS : av[1][j]; }
+      const T w0 = FAST ? av[0][j] : vv[0][FAST ? 0 : j], w1 = FAST ? av[1][j] : vv[FAST ? 0 : 1][FAST ? 0 : j];
+      s_sq[buf][ch][j * kWave + lane] = w0 * w0;                         // [j][lane]: conflict-free banks
+      s_sq[buf][LW + ch][j * kWave + lane] = w1 * w1;
     }
     __syncthreads();                                        // every wavefront of the workgroup runs the same column loop
     T nv[VEC];
@@ -237,9 +243,10 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
             const T nrm = t_sqrt(nv[j]);
             const T pr = scaled_prox_u<T, FFN>(a.f_fn, nrm, a.f_val, uf);
 #pragma unroll
-            for (int i = 0; i < 2; i++) out[i][j] = pr * av[i][j] / nrm;
+            for (int i = 0; i < 2; i++) { const T r = pr * vv[FAST ? 0 : i][FAST ? 0 : j] / nrm; out[i][j] = fm ? av[i][j] - sigS * r : r; }
           } else {
-            out[0][j] = 0; out[1][j] = 0;
+#pragma unroll
+            for (int i = 0; i < 2; i++) out[i][j] = fm ? av[i][j] - sigS * (T)0 : (T)0;
           }
         }
       }
@@ -316,13 +323,14 @@ static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
   const PdhgRecord<T>* rec = static_cast<const PdhgRecord<T>*>(record);
   if (rec) { tau = sigma = theta = 1.0; }      // the dispatch below may only depend on the coefficients (kernels_fused_iter.hip: run_iter)
   const UniformProx<T> ug = make_uniform_prox<T>(a.g_val, (T)tau * a.Tval);
-  const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
+  const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, dual_prox_step<T>((T)sigma, a.Sval, a.fmor));
   hipStream_t s = as_stream(stream);
   double* partial = static_cast<double*>(ws);
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
   if (rec && (a.g_val[4] != (T)0 || a.f_val[4] != (T)0)) fast = false;
+  if (a.fmor) fast = false;           // Moreau-wrapped prox_f*: the run-time dispatched instances
   const EdgeTerms<T> ec0 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[0]) : EdgeTerms<T>(), ec1 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[1]) : EdgeTerms<T>();
 #define GO4(G, F, B, FASTv, LWv, R, VARTv) PH_LAUNCH((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv, R, VARTv>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
 #define GO3(G, F, B, FASTv, LWv, R) do { if (a.varT) GO4(G, F, B, FASTv, LWv, R, true); else GO4(G, F, B, FASTv, LWv, R, false); } while (0)

@@ -321,7 +321,7 @@ static int mc_x2_vec(int dtype, size_t ny) { const int full = dtype == 0 ? 4 : 2
 static size_t mc_x2_rows(int dtype, size_t ny) { const int v = mc_x2_vec(dtype, ny); return v >= 2 ? (size_t)(kWave - 2) * v : (size_t)(kWave - 4); }
 
 static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
-  if ((dtype != 0 && dtype != 1) || !d || d->is3d || d->var_T || d->L < 2 || d->L > 4) return false;
+  if ((dtype != 0 && dtype != 1) || !d || d->is3d || d->var_T || d->f_moreau || d->L < 2 || d->L > 4) return false;
   if (d->nx < 4 || d->ny < 4) return false;
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   for (int k = 0; k < 7; k++) {

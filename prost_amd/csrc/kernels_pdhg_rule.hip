@@ -27,7 +27,7 @@ __global__ void pdhg_rule_begin_kernel(PdhgRecord<T>* r, prost_hip_pdhg_rule_opt
   r->sqrt_rows = o.sqrt_rows; r->sqrt_cols = o.sqrt_cols;
   for (int k = 0; k < 7; k++) { r->g_val[k] = a.g_val[k]; r->f_val[k] = a.f_val[k]; }
   r->Tval = a.Tval; r->Sval = a.Sval;
-  r->varT = a.varT; r->Tcls[0] = a.Tcls[0]; r->Tcls[1] = a.Tcls[1];
+  r->varT = a.varT; r->Tcls[0] = a.Tcls[0]; r->Tcls[1] = a.Tcls[1]; r->fmor = a.fmor;
   r->p.ec[0] = EdgeTerms<T>(); r->p.ec[1] = EdgeTerms<T>();
   r->evaluations = 0; r->stop_iteration = 0;
   rule_fill_params(r, tau, sigma, theta);

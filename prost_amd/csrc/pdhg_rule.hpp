@@ -10,7 +10,7 @@ __device__ __forceinline__ void rule_fill_params(PdhgRecord<T>* r, T tau, T sigm
   r->p.tau = tau; r->p.sigma = sigma; r->p.theta = theta;
   // what run_iter / run_iter2 evaluate on the host for by-value step sizes (kernels_fused_iter.hip, kernels_fused_iter2.hip)
   r->p.ug = make_uniform_prox<T>(r->g_val, tau * r->Tval);
-  r->p.uf = make_uniform_prox<T>(r->f_val, sigma * r->Sval);
+  r->p.uf = make_uniform_prox<T>(r->f_val, dual_prox_step<T>(sigma, r->Sval, r->fmor));
   if (r->varT) { r->p.ec[0] = make_edge_terms<T>(r->g_val, tau * r->Tcls[0]); r->p.ec[1] = make_edge_terms<T>(r->g_val, tau * r->Tcls[1]); }
 }
 

@@ -21,6 +21,19 @@ def test_example_rof_primaldual_converges_by_its_own_gap_callback():
     assert img.shape == (3, 70, 48) and np.isfinite(img).all()
 
 
+def test_example_rof_primal_with_sub_variables_runs_fused_and_equals_the_generic_path():
+    """example_rof_primal.m as written (primal form, three sub-variables, sparse gradient, boyd / residual_iter = 1): the one-kernel
+    iterations with the rule on the device; the same run on the generic path stops at the same iteration with the same image"""
+    import rof_primal_sub_variables as ex
+    prost.set_gpu(0)
+    prost.set_precision("double")
+    result, gaps, img, _ = ex.main(nx=70, ny=48, nc=3, max_iters=10000, verbose=False)
+    assert result["result"] == "Converged." and result["path"] == "pdhg:fused-grad2d(sparse)"
+    assert len(gaps) >= 2 and abs(gaps[-1]) < abs(gaps[0]) and abs(gaps[-1]) < 1e-2
+    ref, _, img_ref, _ = ex.main(nx=70, ny=48, nc=3, max_iters=10000, verbose=False, backend_opts={"allow_fused": False})
+    assert ref["path"] == "pdhg:generic" and int(ref["iters"]) == int(result["iters"]) and np.array_equal(img, img_ref)
+
+
 def test_example_tvl1_removes_salt_and_pepper_noise():
     import tvl1_salt_and_pepper as ex
     prost.set_gpu(0)

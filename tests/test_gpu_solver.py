@@ -1274,6 +1274,68 @@ def test_colour_gradient_handed_over_as_a_sparse_matrix_runs_the_fused_kernels(p
                 assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
 
 
+def _rof_primal_as_the_example_writes_it(nx, ny, L, f, lmb, as_block=False, split=(100, 500)):
+    """example_rof_primal.m:15-28, line for line: the problem in its PRIMAL form (min_problem: prox_f on the constrained variable, from
+    which the PDHG backend derives prox_f* by Moreau's identity, backend_pdhg.cu:255-266), the data term spread over three
+    sub-variables with slices of f as coefficient b, the gradient as a sparse matrix"""
+    n = nx * ny * L
+    u, g = prost.variable(n), prost.variable(2 * n)
+    subs = [prost.sub_variable(u, size) for size in list(split) + [n - sum(split)]] if split else []      # :19-21, before min_problem
+    prob = prost.min_problem([u], [g])
+    if split:
+        at = 0
+        for sv in subs:
+            prob.add_function(sv, prost.function.sum_1d("square", 1, f[at:at + sv.dim], lmb, 0, 0))
+            at += sv.dim
+    else:
+        prob.add_function(u, prost.function.sum_1d("square", 1, f, lmb, 0, 0))
+    prob.add_function(g, prost.function.sum_norm2(2 * L, False, "abs", 1, 0, 1, 0, 0))
+    prob.add_constraint(u, g, prost.block.gradient2d(nx, ny, L) if as_block else prost.block.sparse(spmat_gradient2d(nx, ny, L)))
+    return prob
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("L", [1, 2, 3, 4])
+def test_rof_in_primal_form_with_sub_variables_runs_the_fused_kernels(precision, dtype, L):
+    """example_rof_primal.m as it is written -- min_problem, three sub-variables carrying the data term, sum_norm2('abs') on the
+    constrained variable (prox_f* = its Moreau wrap), block.sparse(spmat_gradient2d), boyd with residual_iter = 1 (:32-36) -- runs the
+    one-kernel iterations: the pieces of prox_g merged into one coefficient stream, the Moreau wrap evaluated inside the kernel with
+    the reference's expressions (prox_moreau.cu:98-134), the step-size rule on the device.  x, y, z, w and the step sizes == the ORACLE
+    running the generic description, bit for bit; other step rules, block.gradient2d and an unsplit data term as well."""
+    prost.set_precision(precision)
+    o = prost.options(max_iters=200, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=0, tol_abs_dual=0)
+    for (nx, ny), res_iter, step, as_block, split in (((30, 32), 1, "boyd", False, (100, 500)), ((25, 31), 1, "boyd", False, (100, 500)),
+                                                     ((20, 36), 3, "alg2", False, (7, 1)), ((18, 40), 2, "goldstein", True, (100, 500)),
+                                                     ((21, 33), 5, "alg1", False, None)):
+        f = synthetic.rof_image(nx, ny, L, seed=8)
+        prob = _rof_primal_as_the_example_writes_it(nx, ny, L, f, 10.0, as_block, split)
+        b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5, tau0=1, sigma0=1)
+        for k in (1, 2, 9, 40):
+            st = run_product(prob, b, o, k)
+            assert st["path"] == ("pdhg:fused-grad2d" if as_block else "pdhg:fused-grad2d(sparse)"), st["path"]
+            ost = run_oracle(prob, b, o, k, dtype)
+            assert_same_iterates(st, ost)
+            for name in ("tau", "sigma", "theta"):
+                assert st[name] == ost[name], (name, k)
+            for name in ("primal_res", "dual_res", "eps_primal", "eps_dual"):
+                assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
+        if step in ("boyd", "goldstein"):
+            assert st["device_rule_batches"] >= 1, st["device_rule_batches"]
+        b[1]["allow_fused"] = False
+        gen = run_product(prob, b, o, 40)
+        assert gen["path"] == "pdhg:generic"
+        assert_same_iterates(st, gen)
+    # a complete solve stops where the oracle stops
+    f = synthetic.rof_image(36, 40, L, seed=9)
+    prob = _rof_primal_as_the_example_writes_it(36, 40, L, f, 10.0)
+    b = prost.backend.pdhg(stepsize="boyd", residual_iter=1, alg2_gamma=0.5, tau0=1, sigma0=1)
+    o = prost.options(max_iters=6000, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=1e-3, tol_abs_dual=1e-3)
+    got, exp = prost.solve(prob, b, o), oracle.solve(prob, b, o, dtype)
+    assert got["result"] == exp["result"] == "Converged." and int(got["iters"]) == int(exp["iters"]) and got["path"] == "pdhg:fused-grad2d(sparse)"
+    for v in "xyzw":
+        assert np.array_equal(np.asarray(got[v]), np.asarray(exp[v])), v
+
+
 def test_matrices_that_are_not_quite_the_gradient_stay_on_the_generic_path():
     """the recognition compares every entry: five labels (more channels than the one-kernel iterations take), a perturbed value, a missing entry, the TV-L1 data
     term (no position-dependent instance of the pair kernel: single launches), the inpainting mask (per-pixel a) -- all still equal
