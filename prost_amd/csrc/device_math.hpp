@@ -333,6 +333,37 @@ __device__ __forceinline__ T elem_1d_u(int fn, T arg, const T* c, const UniformP
   return scaled_prox_u<T, FN>(fn, arg, c, u);
 }
 
+// ---- prox_f* as the Moreau wrap of a norm2 operation, straight-line ---------------------------
+// prox_moreau.cu:98-134 with the dual call's invert_tau = false, around ElemOperationNorm2<FN> whose coefficients are all
+// wave-uniform (elem_operation_norm2.hpp:40-88):   v = arg / s   (s = sigma Sigma; the caller forms it with SharedDivisor: the
+// correctly rounded quotient),   r = pr v / ||v|| with pr = the scaled prox of ||v|| at the step 1 / s (`u` holds its terms),
+// r = 0 where ||v|| = 0,   out = arg - s r.   nv = the squared norms of v as the reference accumulates them.  Norms in
+// [2^-96, 2^126] take the short correctly rounded square root; the quotient runs through one refined double reciprocal per pixel
+// (device_math.hpp: rcp_refined -- RN(n / d) for float n, d).  Same bits as the three expressions of the reference.
+template <class T, int FN, int NC, int VEC>
+__device__ __forceinline__ void norm2_moreau_post(const T (&nv)[VEC], const T (&vv)[NC][VEC], const T (&av)[NC][VEC], T s, const T* c, const UniformProx<T>& u,
+                                                  T (&out)[NC][VEC]) {
+#pragma unroll
+  for (int j = 0; j < VEC; j++) {
+    const bool nz = nv[j] > (T)0;
+    const T x = nz ? nv[j] : (T)1;
+    T nrm;
+    if constexpr (sizeof(T) == 4) {
+      const bool mid = x >= (T)1.2621774483536189e-29f && x <= (T)8.507059173023462e37f;       // [2^-96, 2^126]
+      nrm = __builtin_expect(mid, 1) ? sqrt_midrange(x) : t_sqrt(x);
+    } else nrm = t_sqrt(x);
+    const T pr = scaled_prox_u<T, FN>(FN, nrm, c, u);
+    if constexpr (sizeof(T) == 4) {
+      const double r = rcp_refined(nrm);
+#pragma unroll
+      for (int i = 0; i < NC; i++) { const T q = nz ? (T)mul_rcp((float)(pr * vv[i][j]), r) : (T)0; out[i][j] = av[i][j] - s * q; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NC; i++) { const T q = nz ? pr * vv[i][j] / nrm : (T)0; out[i][j] = av[i][j] - s * q; }
+    }
+  }
+}
+
 // ---- scaled prox with two host-decided shortcuts (generic kernels, per-element step sizes) -----
 // e_zero: coefficient e is the scalar 0  -> the fp64 denominator 1. + tau*e is exactly 1
 // a_one : coefficient a is the scalar 1  -> the final division by a is the identity

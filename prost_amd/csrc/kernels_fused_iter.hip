@@ -78,6 +78,10 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
   const T tauT = tau * a.Tval, sigS = sigma * a.Sval;
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
   const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
+  // straight-line instance whose prox_f* is the Moreau wrap of ElemOperationNorm2<FFN> (FFN = abs: a problem written in the primal
+  // form with the TV regulariser on the constrained variable, example_rof_primal.m:27): device_math.hpp, norm2_moreau_post
+  constexpr bool kFM = FAST && FFN != PROST_FN_IND_LEQ0;
+  const SharedDivisor<T> div_sS(kFM ? sigS : (T)1);                  // arg / (sigma Sigma), correctly rounded
   // Function1DSquare with scalar a, c, e: its fp64 divisor 1. + step is wave-uniform -> exact
   // reciprocal-based quotient instead of a ~35-instruction fp64 division per pixel (device_math.hpp)
   // scalar a, c, e of prox_g (always the case for prox_f* here): every element-independent part of
@@ -266,6 +270,7 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
     if (owner) {
       T out[2 * LCH][VEC];
       T av[FAST ? 2 * LCH : 1][FAST ? VEC : 1], nv[FAST ? VEC : 1];
+      T vv[kFM ? 2 * LCH : 1][kFM ? VEC : 1];           // straight-line Moreau instance: the pre-scaled arguments
       T kxv[RES ? 2 * LCH : 1][RES ? VEC : 1], kpv[RES ? 2 * LCH : 1][RES ? VEC : 1];
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
@@ -288,7 +293,7 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
         const bool fm = !FAST && a.fmor != 0;
         T va[2 * LCH];
 #pragma unroll
-        for (int i = 0; i < 2 * LCH; i++) va[i] = fm ? arg[i] / sigS : arg[i];
+        for (int i = 0; i < 2 * LCH; i++) va[i] = kFM ? div_sS.div(arg[i]) : (fm ? arg[i] / sigS : arg[i]);
 #pragma unroll
         for (int i = 0; i < 2 * LCH; i++) norm += va[i] * va[i];
         if (RES) {
@@ -299,6 +304,10 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
           nv[FAST ? j : 0] = norm;
 #pragma unroll
           for (int i = 0; i < 2 * LCH; i++) av[FAST ? i : 0][FAST ? j : 0] = arg[i];
+          if (kFM) {
+#pragma unroll
+            for (int i = 0; i < 2 * LCH; i++) vv[kFM ? i : 0][kFM ? j : 0] = va[i];
+          }
         } else if (norm > 0) {
           norm = t_sqrt(norm);
           const T pr = scaled_prox_u<T, FFN>(a.f_fn, norm, a.f_val, uf);
@@ -311,7 +320,8 @@ __global__ void __launch_bounds__(kWave, (RES && VART && FAST && LCH == 1) ? 3 :
       }
       if constexpr (FAST) {
         // out = pr v / ||v||, pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0: device_math.hpp
-        norm2_leq0_fast<T, 2 * LCH, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+        if constexpr (kFM) norm2_moreau_post<T, FFN, kFM ? 2 * LCH : 1, kFM ? VEC : 1>(nv, vv, av, sigS, a.f_val, uf, out);
+        else norm2_leq0_fast<T, 2 * LCH, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
       }
       if (RES && c >= a.rx0 && c < a.rx1) {                // primal_residual_transform (backend_pdhg.cu:97-120)
 #pragma unroll
@@ -494,20 +504,27 @@ static int run_iter(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* 
               (mask == 0x2 || (mask == 0 && d->L == 1)) &&
               ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
   if (rec && (a.g_val[4] != (T)0 || a.f_val[4] != (T)0 || d->g_coeff_ptr[4])) fast = false;
-  if (a.fmor) fast = false;           // Moreau-wrapped prox_f*: the run-time dispatched instances
+  // Moreau-wrapped prox_f*: a straight-line instance for ElemOperationNorm2<abs> behind the square data term with per-pixel b (any
+  // scalar coefficients: the operation's terms are in uf); the run-time dispatched instances otherwise
+  const bool fast_g = d->g_fn == PROST_FN_SQUARE && mask == 0x2 && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 &&
+                      !(rec && (a.g_val[4] != (T)0 || d->g_coeff_ptr[4]));
+  const bool fast_moreau = a.fmor && d->f_fn == PROST_FN_ABS && fast_g;
+  if (a.fmor) fast = false;
 #define GO3(LCHv, G, F, M, R, RAGv, FASTv, VARTv) PH_LAUNCH((fused_iter2d_kernel<T, V, LCHv, G, F, M, R, RAGv, FASTv, VARTv>), grid, block, 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
 #define GO2(LCHv, G, F, M, R, RAGv, FASTv) do { if (a.varT) GO3(LCHv, G, F, M, R, RAGv, FASTv, true); else GO3(LCHv, G, F, M, R, RAGv, FASTv, false); } while (0)
 #define GO(LCHv, G, F, M, R, FASTv) do { if (rag) GO2(LCHv, G, F, M, R, true, FASTv); else GO2(LCHv, G, F, M, R, false, FASTv); } while (0)
 #define GO_RES(LCHv, G, F, M, FASTv) do { if (out4) GO(LCHv, G, F, M, true, FASTv); else GO(LCHv, G, F, M, false, FASTv); } while (0)
   // measured (4096^2 fp32): non-temporal stores +4 %, non-temporal loads -15 %, no register prefetch -8 %
   if (d->L == 1) {
-    if (fast && d->g_fn == PROST_FN_ABS) GO_RES(1, PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, true);          // TV-L1 data term
+    if (fast_moreau) GO_RES(1, PROST_FN_SQUARE, PROST_FN_ABS, 0x2, true);                                // ROF in its primal form
+    else if (fast && d->g_fn == PROST_FN_ABS) GO_RES(1, PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, true);          // TV-L1 data term
     else if (fast && mask == 0x2) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true);
     else if (fast) GO_RES(1, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0, true);
     else if (mask == 0) GO_RES(1, -1, -1, 0, false);
     else GO_RES(1, -1, -1, 0x7F, false);
   } else {
-    if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true); else if (mask == 0) GO_RES(2, -1, -1, 0, false); else GO_RES(2, -1, -1, 0x7F, false);
+    if (fast_moreau) GO_RES(2, PROST_FN_SQUARE, PROST_FN_ABS, 0x2, true);
+    else if (fast) GO_RES(2, PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, true); else if (mask == 0) GO_RES(2, -1, -1, 0, false); else GO_RES(2, -1, -1, 0x7F, false);
   }
 #undef GO_RES
 #undef GO

@@ -58,6 +58,9 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
   const size_t xb = xa + a.cols_per_block < nx ? xa + a.cols_per_block : nx;
   const size_t P = nx * ny, N = P * LW, plane = (size_t)ch * P;
   const T tauT = tau * a.Tval, sigS = sigma * a.Sval;
+  // straight-line instance whose prox_f* is the Moreau wrap of ElemOperationNorm2<FFN> (kernels_fused_iter.hip; device_math.hpp: norm2_moreau_post)
+  constexpr bool kFM = FAST && FFN != PROST_FN_IND_LEQ0, kPlain = FAST && !kFM;
+  const SharedDivisor<T> div_sS(kFM ? sigS : (T)1);       // arg / (sigma Sigma), correctly rounded
   const T* y1 = y + plane; const T* y2 = y + N + plane;
   const T* xp = x + plane;
   const T* bp = GB ? a.g_ptr[1] + plane : nullptr;
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
     const T bel_n = lane_down(xn_c[0]);
     const T bel_o = lane_down(cur.x[0]);
     T av[2][VEC];
-    T vv[FAST ? 1 : 2][FAST ? 1 : VEC];                    // what the norm2 operation sees (the arguments, or their Moreau pre-scaled form)
+    T vv[kPlain ? 1 : 2][kPlain ? 1 : VEC];                // what the norm2 operation sees (the arguments, or their Moreau pre-scaled form)
     const bool fm = !FAST && a.fmor != 0;
     T kxv[RES ? 2 : 1][RES ? VEC : 1], kpv[RES ? 2 : 1][RES ? VEC : 1];
     const int buf = (int)(c & 1);
@@ -218,8 +221,9 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
       if (RES) { kxv[0][RES ? j : 0] = kx0; kxv[RES ? 1 : 0][RES ? j : 0] = kx1; kpv[0][RES ? j : 0] = kp0; kpv[RES ? 1 : 0][RES ? j : 0] = kp1; }
       // prox_f* given as the Moreau wrap of prox_f (FusedArgs::fmor; prox_moreau.cu:98-134 with the dual call's invert_tau = false): the
       // operation sees v = arg / (sigma Sigma) and the step 1 / (sigma Sigma) (uf holds its terms), the result is arg - sigma Sigma r
-      if (!FAST) { vv[0][FAST ? 0 : j] = fm ? av[0][j] / sigS : av[0][j]; vv[FAST ? 0 : 1][FAST ? 0 : j] = fm ? av[1][j] / sigS : av[1][j]; }
-      const T w0 = FAST ? av[0][j] : vv[0][FAST ? 0 : j], w1 = FAST ? av[1][j] : vv[FAST ? 0 : 1][FAST ? 0 : j];
+      if (kFM) { vv[0][kPlain ? 0 : j] = div_sS.div(av[0][j]); vv[kPlain ? 0 : 1][kPlain ? 0 : j] = div_sS.div(av[1][j]); }
+      else if (!FAST) { vv[0][kPlain ? 0 : j] = fm ? av[0][j] / sigS : av[0][j]; vv[kPlain ? 0 : 1][kPlain ? 0 : j] = fm ? av[1][j] / sigS : av[1][j]; }
+      const T w0 = kPlain ? av[0][j] : vv[0][kPlain ? 0 : j], w1 = kPlain ? av[1][j] : vv[kPlain ? 0 : 1][kPlain ? 0 : j];
       s_sq[buf][ch][j * kWave + lane] = w0 * w0;                         // [j][lane]: conflict-free banks
       s_sq[buf][LW + ch][j * kWave + lane] = w1 * w1;
     }
@@ -234,7 +238,9 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
     }
     if (owner) {
       T out[2][VEC];
-      if (FAST) {
+      if constexpr (kFM) {
+        norm2_moreau_post<T, FFN, 2, VEC>(nv, vv, av, sigS, a.f_val, uf, out);
+      } else if constexpr (FAST) {
         norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
       } else {
 #pragma unroll
@@ -243,7 +249,7 @@ __global__ void __launch_bounds__(kWave * LW) fused_iter2d_mc_kernel(T* __restri
             const T nrm = t_sqrt(nv[j]);
             const T pr = scaled_prox_u<T, FFN>(a.f_fn, nrm, a.f_val, uf);
 #pragma unroll
-            for (int i = 0; i < 2; i++) { const T r = pr * vv[FAST ? 0 : i][FAST ? 0 : j] / nrm; out[i][j] = fm ? av[i][j] - sigS * r : r; }
+            for (int i = 0; i < 2; i++) { const T r = pr * vv[kPlain ? 0 : i][kPlain ? 0 : j] / nrm; out[i][j] = fm ? av[i][j] - sigS * r : r; }
           } else {
 #pragma unroll
             for (int i = 0; i < 2; i++) out[i][j] = fm ? av[i][j] - sigS * (T)0 : (T)0;
@@ -330,13 +336,17 @@ static int run_iter_mc_v(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
   if (rec && (a.g_val[4] != (T)0 || a.f_val[4] != (T)0)) fast = false;
-  if (a.fmor) fast = false;           // Moreau-wrapped prox_f*: the run-time dispatched instances
+  // Moreau-wrapped prox_f*: a straight-line instance for ElemOperationNorm2<abs> behind the square data term with per-pixel b
+  // (kernels_fused_iter.hip: run_iter); the run-time dispatched instances otherwise
+  const bool fast_moreau = a.fmor && d->f_fn == PROST_FN_ABS && gb && gsq && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && !(rec && a.g_val[4] != (T)0);
+  if (a.fmor) fast = false;
   const EdgeTerms<T> ec0 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[0]) : EdgeTerms<T>(), ec1 = a.varT ? make_edge_terms<T>(a.g_val, (T)tau * a.Tcls[1]) : EdgeTerms<T>();
 #define GO4(G, F, B, FASTv, LWv, R, VARTv) PH_LAUNCH((fused_iter2d_mc_kernel<T, V, G, F, B, FASTv, LWv, R, VARTv>), dim3(grid), dim3(kWave * LWv), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, ec0, ec1, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
 #define GO3(G, F, B, FASTv, LWv, R) do { if (a.varT) GO4(G, F, B, FASTv, LWv, R, true); else GO4(G, F, B, FASTv, LWv, R, false); } while (0)
 #define GO2(G, F, B, FASTv, LWv) do { if (out4) GO3(G, F, B, FASTv, LWv, true); else GO3(G, F, B, FASTv, LWv, false); } while (0)
 #define GO(G, F, B, FASTv) do { if (d->L == 3) GO2(G, F, B, FASTv, 3); else GO2(G, F, B, FASTv, 4); } while (0)
-  if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
+  if (fast_moreau) GO(PROST_FN_SQUARE, PROST_FN_ABS, true, true);
+  else if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
   else { if (gb) GO(-1, -1, true, false); else GO(-1, -1, false, false); }
 #undef GO
 #undef GO2
