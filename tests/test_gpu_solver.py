@@ -1336,6 +1336,29 @@ def test_rof_in_primal_form_with_sub_variables_runs_the_fused_kernels(precision,
         assert np.array_equal(np.asarray(got[v]), np.asarray(exp[v])), v
 
 
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("L", [1, 3])
+def test_nonconvex_rof_example_runs_the_fused_kernels(precision, dtype, L):
+    """example_nonconvex_rof.m:16-51 as written: the regulariser given as conjugate(sum_norm2(..., 'truncquad', 1, 0, 1, 0, 0, alpha,
+    lambda)) on the dual variable (a Moreau wrap around the run-time dispatched norm2 operation), the gradient as a sparse matrix,
+    alg2 with residual_iter = -1.  One-kernel iterations; x, y, z, w == the oracle's generic evaluation bit for bit"""
+    prost.set_precision(precision)
+    nx, ny = 26, 36
+    n = nx * ny * L
+    f = synthetic.rof_image(nx, ny, L, seed=10)
+    u, q = prost.variable(n), prost.variable(2 * n)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d("square", 1, f, 1))
+    prob.add_function(q, prost.function.conjugate(prost.function.sum_norm2(2 * L, False, "truncquad", 1, 0, 1, 0, 0, 30, 0.05)))
+    prob.add_dual_pair(u, q, prost.block.sparse(spmat_gradient2d(nx, ny, L)))
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=-1, alg2_gamma=0.25)
+    o = prost.options(max_iters=2000, num_cback_calls=0, verbose=False)
+    for k in (1, 2, 15, 60):
+        st = run_product(prob, b, o, k)
+        assert st["path"] == "pdhg:fused-grad2d(sparse)", st["path"]
+        assert_same_iterates(st, run_oracle(prob, b, o, k, dtype))
+
+
 def test_matrices_that_are_not_quite_the_gradient_stay_on_the_generic_path():
     """the recognition compares every entry: five labels (more channels than the one-kernel iterations take), a perturbed value, a missing entry, the TV-L1 data
     term (no position-dependent instance of the pair kernel: single launches), the inpainting mask (per-pixel a) -- all still equal
