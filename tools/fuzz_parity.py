@@ -58,6 +58,14 @@ def draw(rng):
         # entry for entry and run on the same kernels with the position-dependent preconditioners of that matrix (other iterates than
         # with block.gradient2d; the oracle runs the matrix as block.sparse)
         c["as_matrix"] = bool(rng.random() < 0.3)
+        # the regulariser written on the PRIMAL side (round 4): example_rof_primal.m -- min_problem, sum_norm2('abs') on the constrained
+        # variable, the data term on up to four sub-variables -- or example_nonconvex_rof.m -- conjugate(sum_norm2(fn, ...)) on the dual
+        # variable; prox_f* is then a Moreau wrap, evaluated inside the one-kernel iterations
+        if c["data"] == "square" and rng.random() < 0.3:
+            n = c["nx"] * c["ny"] * c["L"]
+            cuts = sorted(set(int(v) for v in rng.integers(1, max(2, n), size=int(rng.integers(0, 4))) if 0 < v < n))
+            c["primal_form"] = {"cuts": cuts, "fn": "abs"} if rng.random() < 0.6 else {"conj": str(rng.choice(["abs", "huber", "truncquad", "l0"])), "alpha": float(rng.choice([0.3, 2.0, 30.0])),
+                                                                                            "beta": float(rng.choice([0.05, 1.0]))}
     return c
 
 
@@ -65,9 +73,30 @@ def build(c):
     nx, ny, L = c["nx"], c["ny"], c["L"]
     if c["kind"] == "vol":
         return synthetic.tv3d_problem(nx, ny, L, lmb=c["lmb"], seed=c["seed"], data_term=c["data"])[0]
-    if c["data"] != "mask" and not c.get("as_matrix"):
+    if c["data"] != "mask" and not c.get("as_matrix") and not c.get("primal_form"):
         return synthetic.rof_problem(nx, ny, L, lmb=c["lmb"], seed=c["seed"], data_term=c["data"])[0]
     f = synthetic.rof_image(nx, ny, L, c["seed"])
+    if c.get("primal_form"):
+        from reference_matrices import spmat_gradient2d
+        pf, n = c["primal_form"], nx * ny * L
+        block = prost.block.sparse(spmat_gradient2d(nx, ny, L)) if c.get("as_matrix") else prost.block.gradient2d(nx, ny, L)
+        u, g = prost.variable(n), prost.variable(2 * n)
+        if "conj" in pf:                                   # example_nonconvex_rof.m:20-45
+            prob = prost.min_max_problem([u], [g])
+            prob.add_function(u, prost.function.sum_1d("square", 1, f, c["lmb"]))
+            prob.add_function(g, prost.function.conjugate(prost.function.sum_norm2(2 * L, False, pf["conj"], 1, 0, 1, 0, 0, pf["alpha"], pf["beta"])))
+            prob.add_dual_pair(u, g, block)
+            return prob
+        bounds = [0] + pf["cuts"] + [n]                    # example_rof_primal.m:15-28
+        subs = [prost.sub_variable(u, bounds[i + 1] - bounds[i]) for i in range(len(bounds) - 1)] if pf["cuts"] else []
+        prob = prost.min_problem([u], [g])
+        for i, sv in enumerate(subs):
+            prob.add_function(sv, prost.function.sum_1d("square", 1, f[bounds[i]:bounds[i + 1]], c["lmb"], 0, 0))
+        if not subs:
+            prob.add_function(u, prost.function.sum_1d("square", 1, f, c["lmb"], 0, 0))
+        prob.add_function(g, prost.function.sum_norm2(2 * L, False, "abs", 1, 0, 1, 0, 0))
+        prob.add_constraint(u, g, block)
+        return prob
     mask = (synthetic.hash32(c["seed"] + 7, np.arange(nx * ny * L, dtype=np.uint64)) % 3 != 0).astype(np.float64)
     u, q = prost.variable(nx * ny * L), prost.variable(2 * nx * ny * L)
     prob = prost.min_max_problem([u], [q])
