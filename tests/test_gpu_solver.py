@@ -1336,6 +1336,36 @@ def test_rof_in_primal_form_with_sub_variables_runs_the_fused_kernels(precision,
         assert np.array_equal(np.asarray(got[v]), np.asarray(exp[v])), v
 
 
+def test_data_terms_on_sub_variables_that_do_not_merge_into_one_stream():
+    """pieces of prox_g on sub-variables: different scalar coefficients c become ONE per-pixel vector (gray values: the run-time
+    dispatched one-kernel instance reads it; three channels: no kernel takes a per-pixel c, the generic path runs); a scalar b next to
+    vector b's is filled in; different functions, or a piece that is not an elem_operation:1d, stay generic -- all equal the oracle"""
+    prost.set_precision("single")
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    b = prost.backend.pdhg(stepsize="boyd", residual_iter=2, tau0=1, sigma0=1)
+    for L, fns, lmbs, scalar_b, want in ((1, ("square",) * 3, (10.0, 4.0, 7.0), False, "pdhg:fused-grad2d"), (1, ("square",) * 3, (10.0,) * 3, True, "pdhg:fused-grad2d"),
+                                         (3, ("square",) * 3, (10.0, 4.0, 7.0), False, "pdhg:generic"), (1, ("square", "abs", "square"), (10.0,) * 3, False, "pdhg:generic"),
+                                         (1, ("square", "zero", "square"), (10.0,) * 3, False, "pdhg:generic")):
+        nx, ny = 22, 36
+        n = nx * ny * L
+        f = synthetic.rof_image(nx, ny, L, seed=11)
+        u, g = prost.variable(n), prost.variable(2 * n)
+        sizes = (130, 401, n - 531)
+        subs = [prost.sub_variable(u, k) for k in sizes]
+        prob = prost.min_problem([u], [g])
+        at = 0
+        for i, sv in enumerate(subs):
+            bcoef = 0.25 if (scalar_b and i == 1) else f[at:at + sv.dim]
+            prob.add_function(sv, prost.function.zero() if fns[i] == "zero" else prost.function.sum_1d(fns[i], 1, bcoef, lmbs[i], 0, 0))
+            at += sv.dim
+        prob.add_function(g, prost.function.sum_norm2(2 * L, False, "abs", 1, 0, 1, 0, 0))
+        prob.add_constraint(u, g, prost.block.gradient2d(nx, ny, L))
+        for k in (1, 12, 40):
+            st = run_product(prob, b, o, k)
+            assert st["path"] == want, (st["path"], want, fns, lmbs)
+            assert_same_iterates(st, run_oracle(prob, b, o, k, np.float32))
+
+
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("L", [1, 3])
 def test_nonconvex_rof_example_runs_the_fused_kernels(precision, dtype, L):
