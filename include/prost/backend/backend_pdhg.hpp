@@ -123,6 +123,7 @@ class BackendPDHG : public Backend<T> {
   // buffer roles back to what they were after the stopping iteration.
   static constexpr int kDeviceBatch = 240;
   bool dev_rules_ = false;                 // this problem / option set runs that way (Initialize)
+  bool dev_rules_generic_ = false;         // ... on the GENERIC path: every prox evaluates from an argument source with record-aware kernels
   bool in_device_batch_ = false;
   bool stop_on_convergence_ = false;
   bool batch_last_launch_evaluated_ = false;
@@ -130,7 +131,7 @@ class BackendPDHG : public Backend<T> {
   void* rule_rec_ = nullptr;               // device: PdhgRecord<T>
   prost_hip_pdhg_rule_state* rule_mirror_ = nullptr;   // pinned host: the scalars of the last evaluation, fetched at the end of a batch ...
   prost_hip_pdhg_rule_state* rule_mirror_dev_ = nullptr;   // ... from the device copy the rule kernels write
-  struct BatchMark { size_t iteration_after, pair_launches; T *x, *xp, *y, *yp; bool prev_stale; };
+  struct BatchMark { size_t iteration_after, pair_launches; T *x, *xp, *y, *yp; bool prev_stale; T *kx, *kxp, *kty, *ktyp; };   // (kx .. ktyp: generic path)
   std::vector<BatchMark> batch_marks_;     // one per residual iteration of the running batch: the state to return to if it stopped there
   int PerformIterationsDevice(int budget);
   void RestoreRoles(const BatchMark& m);

@@ -88,6 +88,10 @@ class Prox {
   };
   /// true if EvalFromSource is implemented; a backend only skips its argument pass when EVERY prox of the list is
   virtual bool supports_arg_source() const { return false; }
+  /// EvalFromSource launches only kernels that take their step sizes from the device-resident record of a batch of iterations
+  /// (prost_hip_use_step_record): the in-tree elem operations, their Moreau wraps and the identity.  A prox of a plugin that
+  /// implements EvalFromSource with kernels of its own keeps the default -- its problems run the host loop.
+  virtual bool takes_step_record() const { return false; }
   /// result[index:index+size) = prox(source[index:index+size); tau * tau_diag[...]); result must not alias source.v[0]
   virtual void EvalFromSource(device_vector<T>& result, const ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false) {
     (void)result; (void)src; (void)tau_diag; (void)tau; (void)invert_tau;

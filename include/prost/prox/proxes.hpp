@@ -28,6 +28,7 @@ class ProxElemDispatch : public ProxSeparableSum<T> {
   /// prox of the conjugate (Moreau) of this elem operation in one fused pass; same ranges as EvalLocal
   void EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau);
   virtual bool supports_arg_source() const { return true; }
+  virtual bool takes_step_record() const { return true; }
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false) {
     EvalSourceLocal(false, result, src, tau_diag, tau, invert_tau);
   }
@@ -54,6 +55,7 @@ class ProxMoreau : public Prox<T> {
   virtual size_t gpu_mem_amount() const { return this->size_ * sizeof(T) + conjugate_->gpu_mem_amount(); }
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { conjugate_->get_separable_structure(sep); }
   virtual bool supports_arg_source() const;
+  virtual bool takes_step_record() const { return supports_arg_source(); }
   /// the wrapped operation's description with `moreau` set (a wrap of a wrap is not described)
   virtual bool describe(ProxDesc& d) const;
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
@@ -73,6 +75,7 @@ class ProxZero : public Prox<T> {
   ProxZero(size_t index, size_t size) : Prox<T>(index, size, true) {}
   virtual size_t gpu_mem_amount() const { return 0; }
   virtual bool supports_arg_source() const { return true; }
+  virtual bool takes_step_record() const { return true; }
   /// the identity prox of a source IS the argument pass, written straight into the result
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
 

@@ -66,6 +66,12 @@ int prost_hip_device_synchronize(void);
  * and reads prost_hip_event_elapsed_ms(stop of the previous launch, stop of this one).  (NULL, NULL) withdraws events no launch has
  * taken.  Launches that record nothing else (reduction folds, generic kernels) do not take the events. */
 int prost_hip_next_launch_events(void* start, void* stop);
+/* Device-resident step sizes on the GENERIC PDHG path (ABI 6): while `record` (a record of prost_hip_pdhg_rule_begin) is set for the
+ * calling thread, prost_hip_prox_elem_arg in the PDHG_PRIMAL / PDHG_DUAL modes, prost_hip_pdhg_primal_arg / _dual_arg and
+ * prost_hip_pdhg_residual_primal / _dual read tau, sigma, theta from it ON THE DEVICE -- the values passed by the host are ignored --
+ * and the first three return at once when its stop flag is raised.  With prost_hip_pdhg_rule_apply behind the residual sums a
+ * batch of generic iterations runs without a host wait.  NULL withdraws it. */
+int prost_hip_use_step_record(void* record);
 /* HIP graphs: the launches enqueued on `stream` between begin and end are recorded instead of executed;
  * end returns an executable graph that replays them with one host call (launch-bound inner loops). */
 int prost_hip_stream_begin_capture(void* stream);

@@ -47,6 +47,8 @@ constexpr int kReduceBlocks = 8192;        // partial slots in the reduction wor
 // whose predecessor on the stream is not a stamped one.  (hipEventRecord brackets cost two such packets per launch and measure the
 // dispatch gap along with the kernel: a 22 us kernel read 14 % long.)
 extern thread_local hipEvent_t g_launch_ev_start, g_launch_ev_stop;
+// device-resident step-size record the generic PDHG kernels of the calling thread read their step sizes from (prost_hip_use_step_record)
+extern thread_local void* g_step_record;
 }  // namespace prost_hip
 #include <hip/hip_ext.h>
 #define PH_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                        \

@@ -17,10 +17,20 @@ struct EwIn {
   const T* p[NIN > 0 ? NIN : 1];
 };
 
+// Functors whose scalars may live in a device-resident step-size record (prost_hip_use_step_record; kernels_pdhg.hip) define
+// prepare() -- called once per thread before the first element: fetches the scalars (wave-uniform loads) -- and map kernels
+// additionally skip(): true makes the whole launch a no-op (the record's stop flag).  Other functors have neither.
+template <class F> __device__ __forceinline__ auto ew_prepare(F& f, int) -> decltype(f.prepare(), void()) { f.prepare(); }
+template <class F> __device__ __forceinline__ void ew_prepare(F&, long) {}
+template <class F> __device__ __forceinline__ auto ew_skip(const F& f, int) -> decltype(f.skip()) { return f.skip(); }
+template <class F> __device__ __forceinline__ bool ew_skip(const F&, long) { return false; }
+
 // out[i] = f(in[0][i], ..., in[NIN-1][i]); `out` may alias an input (all loads of an element
 // group precede its store)
 template <class T, int VEC, int NIN, class F>
 __global__ void __launch_bounds__(kBlock) ew_kernel(T* out, EwIn<T, NIN> in, size_t n, F f) {
+  if (ew_skip(f, 0)) return;
+  ew_prepare(f, 0);
   const size_t nv = n / VEC;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
     T v[NIN > 0 ? NIN : 1][VEC], o[VEC];
@@ -59,6 +69,7 @@ static int launch_ew(const char* name, T* out, const EwIn<T, NIN>& in, size_t n,
 // launch_fold.  The association order is fixed by (grid, VEC), hence run-to-run deterministic.
 template <class T, int VEC, int NIN, class F>
 __global__ void __launch_bounds__(kBlock) reduce2_kernel(double* __restrict__ partial, EwIn<T, NIN> in, size_t n, F f) {
+  ew_prepare(f, 0);
   const size_t nv = n / VEC;
   double sa = 0, sb = 0;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {

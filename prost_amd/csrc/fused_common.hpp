@@ -171,6 +171,9 @@ struct PdhgRecord {
   unsigned long long stop_iteration;
 };
 
+// the record the generic PDHG kernels launched by this thread take their step sizes from, or null (prost_hip_use_step_record)
+template <class T> inline const PdhgRecord<T>* step_record() { return static_cast<const PdhgRecord<T>*>(g_step_record); }
+
 // value of the row above the first row of this lane (row0 - 1): neighbour lane's last element
 template <class T, int VEC>
 __device__ __forceinline__ T row_above(const T (&v)[VEC], const T* __restrict__ col_base, size_t row0, bool active) {

@@ -260,8 +260,14 @@ void BackendPDHG<T>::Initialize() {
   const bool rec_kernels = single_kernel_ || single_mc_;
   dev_rules_ = rec_kernels && !desc_.is3d && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
                !desc_.g_coeff_ptr[4] && desc_.g_coeff_val[4] == 0.0 && desc_.f_coeff_val[4] == 0.0;
+  // the same on the GENERIC path (any operator): the proxes form their arguments on the fly with kernels that read tau, sigma, theta
+  // from the record (elem operations of any function and coefficients, their Moreau wraps, the identity), the residual reductions
+  // as well, and a one-thread kernel applies the rule behind them
+  dev_rules_generic_ = !fused_ && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && arg_fused_g_ && arg_fused_f_;
+  for (auto& p : prox_g_) dev_rules_generic_ = dev_rules_generic_ && p->takes_step_record();
+  for (auto& p : prox_fstar_) dev_rules_generic_ = dev_rules_generic_ && p->takes_step_record();
   in_device_batch_ = false; dev_batches_ = 0;
-  if (dev_rules_) {
+  if (dev_rules_ || dev_rules_generic_) {
     CheckHip(prost_hip_malloc(&rule_rec_, prost_hip_pdhg_rule_record_bytes()), "malloc");
     CheckHip(prost_hip_host_alloc((void**)&rule_mirror_, sizeof(prost_hip_pdhg_rule_state)), "host_alloc");
     // (the rule kernels write their scalars to a DEVICE copy, fetched once per batch: ~20 stores over PCIe per residual iteration
@@ -350,7 +356,7 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   // stop callback polls after every launch -- keep the host loop: the batch's set-up kernel would cost more than the wait)
   // (a caller that goes on after the stopping test already holds gets the host loop's answer -- one iteration -- not a batch that
   // stops at its first residual iteration)
-  if (dev_rules_ && budget >= 3 && k >= 2 &&
+  if ((dev_rules_ || dev_rules_generic_) && budget >= 3 && k >= 2 &&
       !(stop_on_convergence_ && this->primal_residual_ < this->eps_primal() && this->dual_residual_ < this->eps_dual()))
     return PerformIterationsDevice(budget);
   if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
@@ -385,6 +391,7 @@ void BackendPDHG<T>::RestoreRoles(const BatchMark& m) {
   };
   place(x_, m.x, x_prev_, x_spare_); place(x_prev_, m.xp, x_spare_, x_spare_);
   place(y_, m.y, y_prev_, y_spare_); place(y_prev_, m.yp, y_spare_, y_spare_);
+  if (!fused_) { place(kx_, m.kx, kx_prev_, kx_prev_); place(kty_, m.kty, kty_prev_, kty_prev_); }
   prev_stale_ = m.prev_stale;
   iteration_ = m.iteration_after;
   pair_launches_ = m.pair_launches;
@@ -411,16 +418,22 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
   o.sqrt_cols = std::sqrt((double)(this->global_ncols_ ? this->global_ncols_ : this->problem_->ncols()));
   ResolveResiduals();                      // (sums of the host loop still in flight: the rule's input state must be final)
   spec_valid_ = false;
-  CheckHip(Api<T>::pdhg_rule_begin(rule_rec_, &o, &desc_, (double)tau_, (double)sigma_, (double)theta_, (double)arg_alpha_, arb_l_, arb_u_,
+  prost_hip_fused_desc no_desc{};            // generic path: the record's prox terms are not read by any kernel
+  no_desc.T_val = no_desc.S_val = 1.0; no_desc.g_coeff_val[0] = no_desc.f_coeff_val[0] = 1.0;
+  CheckHip(Api<T>::pdhg_rule_begin(rule_rec_, &o, fused_ ? &desc_ : &no_desc, (double)tau_, (double)sigma_, (double)theta_, (double)arg_alpha_, arb_l_, arb_u_,
                                    stop_on_convergence_ ? 1 : 0, rule_mirror_dev_, s), "pdhg_rule_begin");
   batch_marks_.clear();
   batch_last_launch_evaluated_ = false;
   in_device_batch_ = true;
+  if (!fused_) CheckHip(prost_hip_use_step_record(rule_rec_), "use_step_record");
   try {
     for (int done = 0; done < n;) {
       const size_t k = iteration_;
       batch_last_launch_evaluated_ = false;
-      if (pair_kernel_ && n - done >= 2 && !is_residual_iteration(k)) {
+      if (!fused_) {
+        IterationGeneric(is_residual_iteration(k));
+        done += 1;
+      } else if (pair_kernel_ && n - done >= 2 && !is_residual_iteration(k)) {
         pair_launches_++;            // (counted first: the mark a residual launch leaves holds the count INCLUDING itself)
         IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
         done += 2;
@@ -433,8 +446,9 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
         done += 1;
       }
     }
-  } catch (...) { in_device_batch_ = false; throw; }
+  } catch (...) { in_device_batch_ = false; prost_hip_use_step_record(nullptr); throw; }
   in_device_batch_ = false;
+  if (!fused_) CheckHip(prost_hip_use_step_record(nullptr), "use_step_record");
   dev_batches_++;
   CheckHip(prost_hip_memcpy_d2h(rule_mirror_, rule_mirror_dev_, sizeof(prost_hip_pdhg_rule_state), s), "memcpy_d2h");
   CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");          // the batch's ONE host wait
@@ -777,11 +791,13 @@ void BackendPDHG<T>::FinishResiduals() {
     // the sums stay on the device.  Without a communicator the kernel that folded them has already evaluated the rule and the stopping
     // test (fold4_rule_kernel); with one they pass the all-reduce first and a one-thread kernel follows.  Scalars are mirrored to pinned
     // host memory either way.
-    if (this->comm_) {
-      CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
+    if (this->comm_ || !fused_) {             // (generic path: the sums come from the reduction kernels, the rule is a launch of its own)
+      if (this->comm_) CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
       CheckHip(Api<T>::pdhg_rule_apply(rule_rec_, res_dev_, (unsigned long long)iteration_, rule_mirror_dev_, s), "pdhg_rule_apply");
     }
-    batch_marks_.push_back({iteration_ + 1, pair_launches_, x_.data(), x_prev_.data(), y_.data(), y_prev_.data(), prev_stale_});
+    // (generic path: IterationGeneric exchanges kty_ / kty_prev_ AFTER this call -- the mark holds the roles the iteration leaves)
+    batch_marks_.push_back({iteration_ + 1, pair_launches_, x_.data(), x_prev_.data(), y_.data(), y_prev_.data(), prev_stale_,
+                            kx_.data(), kx_prev_.data(), kty_prev_.data(), kty_.data()});
     batch_last_launch_evaluated_ = true;
     return;
   }

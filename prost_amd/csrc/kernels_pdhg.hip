@@ -29,15 +29,26 @@ int launch_fold(double* out, const double* partial, unsigned nslots, bool sqrt_f
 
 // ---- per-element formulas (one functor each; the skeletons in elementwise.hpp vectorise them) ----
 // primal_proxarg_functor (backend_pdhg.cu:38-51): in = x, T, kty
-template <class T> struct PrimalArgF { T tau; __device__ T operator()(const T* a) const { return a[0] - tau * a[1] * a[2]; } };
+// `rec`: the device-resident step-size record of a batch of iterations (prost_hip_use_step_record; fused_common.hpp: PdhgRecord) --
+// the step sizes are then read from it on the device, the values passed by the host are ignored, and the map kernels return at once
+// when its stop flag is raised
+template <class T> struct PrimalArgF {
+  T tau; const PdhgRecord<T>* rec;
+  __device__ void prepare() { if (rec) tau = rec->p.tau; }
+  __device__ bool skip() const { return rec && rec->stop; }
+  __device__ T operator()(const T* a) const { return a[0] - tau * a[1] * a[2]; }
+};
 // dual_proxarg_functor (backend_pdhg.cu:54-70): in = y, S, kx, kx_prev
 template <class T> struct DualArgF {
-  T sigma, theta;
+  T sigma, theta; const PdhgRecord<T>* rec;
+  __device__ void prepare() { if (rec) { sigma = rec->p.sigma; theta = rec->p.theta; } }
+  __device__ bool skip() const { return rec && rec->stop; }
   __device__ T operator()(const T* a) const { return a[0] + sigma * a[1] * ((1 + theta) * a[2] - theta * a[3]); }
 };
 // primal_residual_transform (backend_pdhg.cu:97-120): in = y_prev, y, S, kx_prev, kx
 template <class T> struct ResidualPrimalF {
-  T sigma, theta;
+  T sigma, theta; const PdhgRecord<T>* rec;
+  __device__ void prepare() { if (rec) { sigma = rec->p.sigma; theta = rec->p.theta; } }
   __device__ void operator()(const T* v, double& a, double& b) const {
     const T sd = v[2];
     const T z_hat = (v[0] - v[1]) / (sigma * t_sqrt(sd)) + t_sqrt(sd) * ((1 + theta) * v[4] - theta * v[3]);
@@ -48,7 +59,8 @@ template <class T> struct ResidualPrimalF {
 };
 // dual_residual_transform (backend_pdhg.cu:73-94): in = x_prev, x, T, kty_prev, kty
 template <class T> struct ResidualDualF {
-  T tau;
+  T tau; const PdhgRecord<T>* rec;
+  __device__ void prepare() { if (rec) tau = rec->p.tau; }
   __device__ void operator()(const T* v, double& a, double& b) const {
     const T td = v[2];
     const T w_hat = (v[0] - v[1]) / (tau * t_sqrt(td)) - t_sqrt(td) * v[3];
@@ -158,29 +170,29 @@ extern "C" {
 size_t prost_hip_reduce_workspace_bytes(void) { return (size_t)kReduceBlocks * 2 * sizeof(double); }
 
 int prost_hip_pdhg_primal_arg_f32(float* t, const float* x, const float* T, const float* k, double tau, size_t n, void* s) {
-  return launch_ew<float, 3>("primal_arg", t, EwIn<float, 3>{{x, T, k}}, n, PrimalArgF<float>{(float)tau}, as_stream(s));
+  return launch_ew<float, 3>("primal_arg", t, EwIn<float, 3>{{x, T, k}}, n, PrimalArgF<float>{(float)tau, step_record<float>()}, as_stream(s));
 }
 int prost_hip_pdhg_primal_arg_f64(double* t, const double* x, const double* T, const double* k, double tau, size_t n, void* s) {
-  return launch_ew<double, 3>("primal_arg", t, EwIn<double, 3>{{x, T, k}}, n, PrimalArgF<double>{tau}, as_stream(s));
+  return launch_ew<double, 3>("primal_arg", t, EwIn<double, 3>{{x, T, k}}, n, PrimalArgF<double>{tau, step_record<double>()}, as_stream(s));
 }
 int prost_hip_pdhg_dual_arg_f32(float* t, const float* y, const float* S, const float* kx, const float* kxp, double sg, double th, size_t m, void* s) {
-  return launch_ew<float, 4>("dual_arg", t, EwIn<float, 4>{{y, S, kx, kxp}}, m, DualArgF<float>{(float)sg, (float)th}, as_stream(s));
+  return launch_ew<float, 4>("dual_arg", t, EwIn<float, 4>{{y, S, kx, kxp}}, m, DualArgF<float>{(float)sg, (float)th, step_record<float>()}, as_stream(s));
 }
 int prost_hip_pdhg_dual_arg_f64(double* t, const double* y, const double* S, const double* kx, const double* kxp, double sg, double th, size_t m, void* s) {
-  return launch_ew<double, 4>("dual_arg", t, EwIn<double, 4>{{y, S, kx, kxp}}, m, DualArgF<double>{sg, th}, as_stream(s));
+  return launch_ew<double, 4>("dual_arg", t, EwIn<double, 4>{{y, S, kx, kxp}}, m, DualArgF<double>{sg, th, step_record<double>()}, as_stream(s));
 }
 
 int prost_hip_pdhg_residual_primal_f32(double* out2, const float* yp, const float* y, const float* S, const float* kxp, const float* kx, double sg, double th, size_t m, void* ws, void* s) {
-  return reduce_to<float, 5>(out2, ws, EwIn<float, 5>{{yp, y, S, kxp, kx}}, m, ResidualPrimalF<float>{(float)sg, (float)th}, false, s);
+  return reduce_to<float, 5>(out2, ws, EwIn<float, 5>{{yp, y, S, kxp, kx}}, m, ResidualPrimalF<float>{(float)sg, (float)th, step_record<float>()}, false, s);
 }
 int prost_hip_pdhg_residual_primal_f64(double* out2, const double* yp, const double* y, const double* S, const double* kxp, const double* kx, double sg, double th, size_t m, void* ws, void* s) {
-  return reduce_to<double, 5>(out2, ws, EwIn<double, 5>{{yp, y, S, kxp, kx}}, m, ResidualPrimalF<double>{sg, th}, false, s);
+  return reduce_to<double, 5>(out2, ws, EwIn<double, 5>{{yp, y, S, kxp, kx}}, m, ResidualPrimalF<double>{sg, th, step_record<double>()}, false, s);
 }
 int prost_hip_pdhg_residual_dual_f32(double* out2, const float* xp, const float* x, const float* T, const float* kp, const float* k, double tau, size_t n, void* ws, void* s) {
-  return reduce_to<float, 5>(out2, ws, EwIn<float, 5>{{xp, x, T, kp, k}}, n, ResidualDualF<float>{(float)tau}, false, s);
+  return reduce_to<float, 5>(out2, ws, EwIn<float, 5>{{xp, x, T, kp, k}}, n, ResidualDualF<float>{(float)tau, step_record<float>()}, false, s);
 }
 int prost_hip_pdhg_residual_dual_f64(double* out2, const double* xp, const double* x, const double* T, const double* kp, const double* k, double tau, size_t n, void* ws, void* s) {
-  return reduce_to<double, 5>(out2, ws, EwIn<double, 5>{{xp, x, T, kp, k}}, n, ResidualDualF<double>{tau}, false, s);
+  return reduce_to<double, 5>(out2, ws, EwIn<double, 5>{{xp, x, T, kp, k}}, n, ResidualDualF<double>{tau, step_record<double>()}, false, s);
 }
 
 int prost_hip_pdhg_w_variable_f32(float* w, const float* xp, const float* x, const float* T, const float* kp, double tau, size_t n, void* s) {

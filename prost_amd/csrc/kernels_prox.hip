@@ -23,7 +23,19 @@ template <class T>
 struct ArgSrc {
   const T* v0; const T* v1; const T* v2; const T* v3;      // ARG 0: v0 = arg.  1: x, T, K^T y.  2: y, Sigma, K x, K x_prev
   T s0, s1;                                                //                   1: tau          2: sigma, theta
+  // ARG 1 / 2 inside a batch of iterations with device-resident step sizes (prost_hip_use_step_record): s0, s1 and the prox's own
+  // step size are read from the record on the device, and the launch is a no-op once the record's stop flag is raised
+  const PdhgRecord<T>* rec;
 };
+template <class T, int ARG>
+__device__ __forceinline__ bool steps_from_record(ArgSrc<T>& a, T& tau_scal) {
+  if (ARG == 0 || !a.rec) return true;
+  if (a.rec->stop) return false;
+  a.s0 = ARG == 1 ? a.rec->p.tau : a.rec->p.sigma;
+  a.s1 = a.rec->p.theta;
+  tau_scal = a.s0;
+  return true;
+}
 template <class T, int ARG>
 __device__ __forceinline__ T arg_formula(const ArgSrc<T>& a, T p0, T p1, T p2, T p3) {
   if (ARG == 1) return p0 - a.s0 * p1 * p2;
@@ -55,6 +67,7 @@ template <class T, int OP, bool MOREAU, int ARG>
 __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, ArgSrc<T> arg,
                                                            const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                            size_t count, size_t dim, bool interleaved, int fn, Coeffs<T> cf) {
+  if (!steps_from_record<T, ARG>(arg, tau_scal)) return;
   const bool inner_inv = MOREAU ? !invert_tau : invert_tau;      // step flag the elem operation sees
   for (size_t tx = (size_t)blockIdx.x * kBlock + threadIdx.x; tx < count; tx += (size_t)gridDim.x * kBlock) {
     T c[7];
@@ -101,6 +114,7 @@ template <class T, int OP, int DIM, bool MOREAU, int ARG>
 __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ res, ArgSrc<T> arg,
                                                                const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                                size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one) {
+  if (!steps_from_record<T, ARG>(arg, tau_scal)) return;
   constexpr int VEC = VecOf<T>::N;
   constexpr int D = DIM > 0 ? DIM : 1;
   for (size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * VEC; t0 < count; t0 += (size_t)gridDim.x * kBlock * VEC) {
@@ -241,7 +255,7 @@ static int launch_prox_elem(int op, int fn, T* res, const ArgSrc<T>& arg, const 
 template <class T, bool MOREAU>
 static int launch_prox_elem(int op, int fn, T* res, const T* arg, const T* tau_diag, double tau, int invert, size_t count,
                             size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
-  return launch_prox_elem<T, MOREAU, 0>(op, fn, res, ArgSrc<T>{arg, nullptr, nullptr, nullptr, (T)0, (T)0}, tau_diag, tau, invert, count, dim, interleaved,
+  return launch_prox_elem<T, MOREAU, 0>(op, fn, res, ArgSrc<T>{arg, nullptr, nullptr, nullptr, (T)0, (T)0, nullptr}, tau_diag, tau, invert, count, dim, interleaved,
                                         coeff_ptr, coeff_val, stream);
 }
 
@@ -250,7 +264,7 @@ static int launch_prox_elem_arg(int op, int fn, int moreau, T* res, const prost_
                                 size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
   if (!a) { set_error("prox_elem_arg: argument source required"); return 1; }
   const ArgSrc<T> src{static_cast<const T*>(a->v[0]), static_cast<const T*>(a->v[1]), static_cast<const T*>(a->v[2]), static_cast<const T*>(a->v[3]),
-                      (T)a->s[0], (T)a->s[1]};
+                      (T)a->s[0], (T)a->s[1], a->mode == PROST_ARG_PLAIN ? nullptr : step_record<T>()};
   if (src.v0 == res) { set_error("prox_elem_arg: the result must not alias the argument source"); return 1; }
 #define GO(M, A) return launch_prox_elem<T, M, A>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream)
   switch (a->mode) {

@@ -14,6 +14,7 @@ namespace prost_hip {
 static thread_local std::string g_last_error;
 
 thread_local hipEvent_t g_launch_ev_start = nullptr, g_launch_ev_stop = nullptr;
+thread_local void* g_step_record = nullptr;
 
 void set_error(const std::string& msg) { g_last_error = msg; }
 int fail(hipError_t e, const char* what) {
@@ -69,6 +70,7 @@ int prost_hip_event_destroy(void* e) { if (e) PH_CHECK(hipEventDestroy((hipEvent
 int prost_hip_event_record(void* e, void* s) { PH_CHECK(hipEventRecord((hipEvent_t)e, as_stream(s))); return 0; }
 int prost_hip_stream_wait_event(void* s, void* e) { PH_CHECK(hipStreamWaitEvent(as_stream(s), (hipEvent_t)e, 0)); return 0; }
 int prost_hip_event_synchronize(void* e) { PH_CHECK(hipEventSynchronize((hipEvent_t)e)); return 0; }
+int prost_hip_use_step_record(void* record) { g_step_record = record; return 0; }
 int prost_hip_next_launch_events(void* start, void* stop) {
   if (start != nullptr && stop == nullptr) { set_error("prost_hip_next_launch_events: a start event needs a stop event"); return 1; }
   g_launch_ev_start = (hipEvent_t)start; g_launch_ev_stop = (hipEvent_t)stop;

@@ -1188,6 +1188,98 @@ def test_device_resident_stopping_test_stops_where_the_host_loop_stops(precision
         assert np.array_equal(its[True][1][v], its[False][1][v]), v
 
 
+def _deblurring_like_problem(nx, ny, seed, primal_form=True):
+    """example_deblurring.m:29-37 in small: min_problem with TWO constraint blocks on u -- a sparse blur operator B (two-tap average along y) with
+    a square data term on v = B u and the sparse gradient with the TV norm on g = grad u -- no function on u itself (the identity
+    prox); primal_form = False: the same operator as a min_max problem with the dual functions written directly"""
+    import scipy.sparse as sp
+    n = nx * ny
+    rng = np.random.default_rng(seed)
+    # (two taps per row and per column: rows this short are summed sequentially by the CSR kernels, like the oracle -- bit for bit;
+    # longer rows are summed by several lanes and compare with a tolerance, tests/test_gpu_kernels.py::test_csr_spmv)
+    B = sp.kron(sp.identity(nx), sp.diags([np.full(ny, 0.5), np.full(ny - 1, 0.5)], [0, 1])).tocsr()
+    f = synthetic.rof_image(nx, ny, 1, seed=seed)
+    fb = B @ f + 0.02 * rng.standard_normal(n)
+    u, v, g = prost.variable(n), prost.variable(n), prost.variable(2 * n)
+    if primal_form:
+        prob = prost.min_problem([u], [v, g])
+        prob.add_function(v, prost.function.sum_1d("square", 1, fb, 20.0, 0, 0))
+        prob.add_function(g, prost.function.sum_norm2(2, False, "abs", 1, 0, 1, 0, 0))
+        prob.add_constraint(u, v, prost.block.sparse(B))
+        prob.add_constraint(u, g, prost.block.sparse(spmat_gradient2d(nx, ny, 1)))
+    else:
+        prob = prost.min_max_problem([u], [v, g])
+        prob.add_function(v, prost.function.conjugate(prost.function.sum_1d("square", 1, fb, 20.0, 0, 0)))
+        prob.add_function(g, prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1))
+        prob.add_dual_pair(u, v, prost.block.sparse(B))
+        prob.add_dual_pair(u, g, prost.block.gradient2d(nx, ny, 1))
+    return prob
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", ["goldstein", "boyd"])
+@pytest.mark.parametrize("residual_iter,primal_form", [(1, True), (3, False), (10, True)])
+def test_device_resident_step_rules_on_the_generic_path(precision, dtype, step, residual_iter, primal_form):
+    """the residual-driven rules on the device for ANY operator (round 4): example_deblurring.m's shape -- two constraint blocks, the
+    identity prox on u, Moreau-wrapped elem operations on the constrained variables, boyd with residual_iter = 1 (:40-41) -- runs the
+    generic kernels in batches with ONE host wait: the proxes and the residual reductions read tau, sigma, theta from the device record
+    (prost_hip_use_step_record), a one-thread kernel applies the rule and the stopping test behind the sums.  Iterates, step sizes,
+    residual norms and iteration counts equal the host-side rule's EXACTLY at every read-out and the oracle's iterates bit for bit;
+    a complete solve stops in the middle of a batch at the oracle's iteration."""
+    prost.set_precision(precision)
+    prob = _deblurring_like_problem(26, 40, 3, primal_form)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=2e-2, tol_rel_dual=2e-2, tol_abs_primal=0, tol_abs_dual=0)
+    runs = {}
+    for dev in (True, False):
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+        b[1]["allow_device_rules"] = dev
+        s = prost.Solver(prob, b, o)
+        trace = []
+        s.iterate(7)
+        trace.append(s.state())
+        s.iterate(500)
+        trace.append(s.state(vectors=False))
+        s.iterate(2)
+        s.iterate(31)
+        trace.append(s.state())
+        s.destroy()
+        runs[dev] = trace
+        assert trace[-1]["path"] == "pdhg:generic"
+        assert (trace[-1]["device_rule_batches"] >= 4) if dev else trace[-1]["device_rule_batches"] == 0, trace[-1]["device_rule_batches"]
+    changed = set()
+    for a, b_ in zip(runs[True], runs[False]):
+        for v in RULE_SCALARS:
+            assert a[v] == b_[v], (v, a[v], b_[v])
+        changed.add((a["tau"], a["sigma"]))
+        if "x" in a:
+            for v in "xyzw":
+                assert np.array_equal(a[v], b_[v]), v
+    assert len(changed) >= 2, changed
+    # against the oracle: the residual SUMS are reduced in another order than the oracle's (compared with a tolerance everywhere), so a
+    # comparison of the rule that sits on a tie may fall the other way -- then both product paths follow the same other branch (checked
+    # above).  Exact equality is asserted where the step sizes say that no tie was hit, and must hold for the example's own shape.
+    ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter), o, 540, dtype)
+    same_branches = runs[True][-1]["tau"] == ost["tau"] and runs[True][-1]["sigma"] == ost["sigma"]
+    assert same_branches or not primal_form
+    if same_branches:
+        assert_same_iterates(runs[True][-1], ost)
+    for tol in (2e-2, 5e-3):
+        o2 = prost.options(max_iters=4000, num_cback_calls=3, verbose=False, tol_rel_primal=tol, tol_rel_dual=tol, tol_abs_primal=tol, tol_abs_dual=tol)
+        res = {}
+        for dev in (True, False):
+            b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+            b[1]["allow_device_rules"] = dev
+            res[dev] = prost.solve(prob, b, o2)
+        exp = oracle.solve(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter), o2, dtype)
+        assert res[True]["result"] == res[False]["result"] and int(res[True]["iters"]) == int(res[False]["iters"]), (res[True]["iters"], res[False]["iters"])
+        for v in "xyzw":
+            assert np.array_equal(np.asarray(res[True][v]), np.asarray(res[False][v])), v
+        if same_branches:
+            assert res[True]["result"] == exp["result"] and int(res[True]["iters"]) == int(exp["iters"]), (res[True]["iters"], exp["iters"])
+            for v in "xyzw":
+                assert np.array_equal(np.asarray(res[True][v]), np.asarray(exp[v])), v
+
+
 # ---------------------------------------------------------------------------------------------
 # gradients handed over as sparse matrices on the fused kernels (position-dependent Tau)
 # ---------------------------------------------------------------------------------------------
