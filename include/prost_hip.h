@@ -404,6 +404,15 @@ typedef struct prost_hip_pdhg_rule_state {
   long long stopped;                            /* the stopping test fired (stop_on_convergence) ... */
   unsigned long long stop_iteration;            /* ... at the residual iteration with this index */
 } prost_hip_pdhg_rule_state;
+/* Both residual reductions of an iteration in ONE launch and their folds -- with the rule and the stopping test of `record` behind
+ * them when apply_rule is set -- in a second: sums4 = {primal diff^2, primal var^2, dual diff^2, dual var^2}, bit for bit what
+ * prost_hip_pdhg_residual_primal + _dual give (same partials, same fold order).  record may be NULL when apply_rule is 0. */
+int prost_hip_pdhg_residuals_f32(double* sums4, const float* y_prev, const float* y, const float* S, const float* kx_prev, const float* kx, double sigma, double theta, size_t m,
+                                 const float* x_prev, const float* x, const float* T, const float* kty_prev, const float* kty, double tau, size_t n, void* workspace, void* record,
+                                 int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_pdhg_residuals_f64(double* sums4, const double* y_prev, const double* y, const double* S, const double* kx_prev, const double* kx, double sigma, double theta, size_t m,
+                                 const double* x_prev, const double* x, const double* T, const double* kty_prev, const double* kty, double tau, size_t n, void* workspace, void* record,
+                                 int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
 size_t prost_hip_pdhg_rule_record_bytes(void);
 int prost_hip_pdhg_rule_begin_f32(void* record, const prost_hip_pdhg_rule_opts* opts, const prost_hip_fused_desc* desc, double tau, double sigma, double theta,
                                   double arg_alpha, int arb_l, int arb_u, int stop_on_convergence, prost_hip_pdhg_rule_state* mirror, void* stream);

@@ -753,8 +753,12 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
     for (auto& p : prox_fstar_) p->Eval(y_, temp_, Sl, sigma_);
   }
   if (res) {                                                                                                   // :392-431
-    CheckHip(Api<T>::pdhg_residual_primal(res_target(), y_prev_.data(), y_.data(), Sl.data(), kx_prev_.data(), kx_.data(), (double)sigma_, (double)theta_, m, workspace_, s), "residual_primal");
-    CheckHip(Api<T>::pdhg_residual_dual(res_target() + 2, x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), kty_.data(), (double)tau_, n, workspace_, s), "residual_dual");
+    // both reductions in one launch, their folds -- and inside a device batch without a communicator the rule -- in a second
+    // (same sums, bit for bit, as pdhg_residual_primal + pdhg_residual_dual: five launches)
+    const bool rule_here = in_device_batch_ && !this->comm_;
+    CheckHip(Api<T>::pdhg_residuals(res_target(), y_prev_.data(), y_.data(), Sl.data(), kx_prev_.data(), kx_.data(), (double)sigma_, (double)theta_, m, x_prev_.data(), x_.data(),
+                                    Tr.data(), kty_prev_.data(), kty_.data(), (double)tau_, n, workspace_, rule_here ? rule_rec_ : nullptr, rule_here ? 1 : 0,
+                                    (unsigned long long)iteration_, rule_here ? rule_mirror_dev_ : nullptr, s), "pdhg_residuals");
     FinishResiduals();
   }
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
@@ -791,8 +795,8 @@ void BackendPDHG<T>::FinishResiduals() {
     // the sums stay on the device.  Without a communicator the kernel that folded them has already evaluated the rule and the stopping
     // test (fold4_rule_kernel); with one they pass the all-reduce first and a one-thread kernel follows.  Scalars are mirrored to pinned
     // host memory either way.
-    if (this->comm_ || !fused_) {             // (generic path: the sums come from the reduction kernels, the rule is a launch of its own)
-      if (this->comm_) CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
+    if (this->comm_) {
+      CheckHip(prost_hip_allreduce_sum_f64(this->comm_, res_dev_, 4, s), "allreduce");
       CheckHip(Api<T>::pdhg_rule_apply(rule_rec_, res_dev_, (unsigned long long)iteration_, rule_mirror_dev_, s), "pdhg_rule_apply");
     }
     // (generic path: IterationGeneric exchanges kty_ / kty_prev_ AFTER this call -- the mark holds the roles the iteration leaves)

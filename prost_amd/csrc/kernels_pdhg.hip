@@ -1,6 +1,7 @@
 // kernels_pdhg.hip -- generic (unfused) PDHG / ADMM / CGLS vector kernels for gfx950.
 // Streaming elementwise work: grid-stride loops, consecutive lanes on consecutive addresses.
 #include "elementwise.hpp"
+#include "pdhg_rule.hpp"
 
 namespace prost_hip {
 
@@ -25,6 +26,36 @@ __global__ void __launch_bounds__(kBlock) fold_partials_kernel(double* __restric
 int launch_fold(double* out, const double* partial, unsigned nslots, bool sqrt_first, hipStream_t s) {
   hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(kBlock), 0, s, out, partial, nslots, sqrt_first);
   PH_LAUNCH_END("fold partials");
+}
+
+// stage 2 of TWO reductions in one launch: (out4[0], out4[1]) from partial1 and (out4[2], out4[3]) from partial2, each in the order
+// of fold_partials_kernel -- and, on request, the step-size rule and the stopping test of the device record behind them
+// (pdhg_rule.hpp): the five launches of a residual iteration on the generic path (two reductions, two folds, the rule) become two
+template <class T>
+__global__ void __launch_bounds__(kBlock) fold_pair_rule_kernel(double* __restrict__ out4, const double* __restrict__ partial1, unsigned n1,
+                                                                const double* __restrict__ partial2, unsigned n2, PdhgRecord<T>* rec, int apply_rule,
+                                                                unsigned long long iteration, prost_hip_pdhg_rule_state* mirror) {
+  __shared__ double s_a[kBlock / kWave], s_b[kBlock / kWave];
+  __shared__ double tot[4];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  for (int h = 0; h < 2; h++) {
+    const double* partial = h == 0 ? partial1 : partial2;
+    const unsigned nslots = h == 0 ? n1 : n2;
+    double a = 0, b = 0;
+    for (unsigned i = threadIdx.x; i < nslots; i += kBlock) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) { s_a[wave] = a; s_b[wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double ta = 0, tb = 0;
+      for (int w = 0; w < kBlock / kWave; w++) { ta += s_a[w]; tb += s_b[w]; }
+      out4[2 * h] = ta; out4[2 * h + 1] = tb;
+      tot[2 * h] = ta; tot[2 * h + 1] = tb;
+    }
+    __syncthreads();
+  }
+  if (apply_rule && rec && threadIdx.x == 0) rule_apply_device<T>(rec, tot, iteration, mirror);
 }
 
 // ---- per-element formulas (one functor each; the skeletons in elementwise.hpp vectorise them) ----
@@ -161,6 +192,44 @@ static int launch_mask_merge(T* bm, const T* a, const T* b, double b_val, size_t
   PH_LAUNCH_END("mask merge kernel");
 }
 
+template <class T>
+__global__ void rule_after_sums_kernel(PdhgRecord<T>* rec, const double* sums4, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror) {
+  rule_apply_device<T>(rec, sums4, iteration, mirror);
+}
+
+template <class T>
+static int run_residuals(double* out4, const T* yp, const T* y, const T* S, const T* kxp, const T* kx, double sg, double th, size_t m, const T* xp, const T* x,
+                         const T* Tr, const T* kp, const T* k, double tau, size_t n, void* ws, void* record, int apply_rule, unsigned long long iteration,
+                         prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!out4 || !ws) { set_error("pdhg_residuals: output and workspace required"); return 1; }
+  if (apply_rule && !record) { set_error("pdhg_residuals: the rule needs a record"); return 1; }
+  constexpr int V = VecOf<T>::N;
+  const EwIn<T, 5> in1{{yp, y, S, kxp, kx}}, in2{{xp, x, Tr, kp, k}};
+  bool v1, v2;
+  const unsigned g1 = reduce2_geometry<T, 5>(in1, m, v1), g2 = reduce2_geometry<T, 5>(in2, n, v2);
+  if (m == 0 || n == 0 || (size_t)g1 + g2 > (size_t)kReduceBlocks) {
+    // (a size without entries, or more workgroups than one workspace holds: the separate launches)
+    if (int rc = reduce_to<T, 5>(out4, ws, in1, m, ResidualPrimalF<T>{(T)sg, (T)th, step_record<T>()}, false, stream)) return rc;
+    if (int rc = reduce_to<T, 5>(out4 + 2, ws, in2, n, ResidualDualF<T>{(T)tau, step_record<T>()}, false, stream)) return rc;
+    if (apply_rule) {
+      hipLaunchKernelGGL(rule_after_sums_kernel<T>, dim3(1), dim3(1), 0, as_stream(stream), static_cast<PdhgRecord<T>*>(record), out4, iteration, mirror);
+      PH_LAUNCH_END("pdhg rule kernel");
+    }
+    return 0;
+  }
+  hipStream_t st = as_stream(stream);
+  double* p1 = static_cast<double*>(ws);
+  double* p2 = p1 + 2 * (size_t)g1;
+  const ResidualPrimalF<T> f1{(T)sg, (T)th, step_record<T>()};
+  const ResidualDualF<T> f2{(T)tau, step_record<T>()};
+#define GO(A, B) hipLaunchKernelGGL((reduce2_pair_kernel<T, A, B, 5, 5, ResidualPrimalF<T>, ResidualDualF<T>>), dim3(g1 + g2), dim3(kBlock), 0, st, p1, in1, m, f1, g1, p2, in2, n, f2)
+  if (v1 && v2) GO(V, V); else if (v1) GO(V, 1); else if (v2) GO(1, V); else GO(1, 1);
+#undef GO
+  { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "residual reduction kernel"); }
+  hipLaunchKernelGGL(fold_pair_rule_kernel<T>, dim3(1), dim3(kBlock), 0, st, out4, p1, g1, p2, g2, static_cast<PdhgRecord<T>*>(record), apply_rule, iteration, mirror);
+  PH_LAUNCH_END("residual fold kernel");
+}
+
 }  // namespace prost_hip
 
 using namespace prost_hip;
@@ -193,6 +262,17 @@ int prost_hip_pdhg_residual_dual_f32(double* out2, const float* xp, const float*
 }
 int prost_hip_pdhg_residual_dual_f64(double* out2, const double* xp, const double* x, const double* T, const double* kp, const double* k, double tau, size_t n, void* ws, void* s) {
   return reduce_to<double, 5>(out2, ws, EwIn<double, 5>{{xp, x, T, kp, k}}, n, ResidualDualF<double>{tau, step_record<double>()}, false, s);
+}
+
+int prost_hip_pdhg_residuals_f32(double* out4, const float* yp, const float* y, const float* S, const float* kxp, const float* kx, double sg, double th, size_t m,
+                                 const float* xp, const float* x, const float* T, const float* kp, const float* k, double tau, size_t n, void* ws, void* record,
+                                 int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* s) {
+  return run_residuals<float>(out4, yp, y, S, kxp, kx, sg, th, m, xp, x, T, kp, k, tau, n, ws, record, apply_rule, iteration, mirror, s);
+}
+int prost_hip_pdhg_residuals_f64(double* out4, const double* yp, const double* y, const double* S, const double* kxp, const double* kx, double sg, double th, size_t m,
+                                 const double* xp, const double* x, const double* T, const double* kp, const double* k, double tau, size_t n, void* ws, void* record,
+                                 int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* s) {
+  return run_residuals<double>(out4, yp, y, S, kxp, kx, sg, th, m, xp, x, T, kp, k, tau, n, ws, record, apply_rule, iteration, mirror, s);
 }
 
 int prost_hip_pdhg_w_variable_f32(float* w, const float* xp, const float* x, const float* T, const float* kp, double tau, size_t n, void* s) {
