@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="image side (default 4096 for c2, 1024 for c4)")
     ap.add_argument("--volume", type=int, nargs=3, default=[2048, 2048, 64], metavar=("NX", "NY", "L"), help="c3: the volume (default 2048 2048 64)")
     ap.add_argument("--prelude-iters", type=int, default=None, help="untimed clock-ramp prelude before the warm-up steps: this many of the same iterations (0: none; default ~100 ms worth)")
-    ap.add_argument("--sample-every", type=int, default=0, help="stamp one launch in this many with HIP events (default: every launch)")
+    ap.add_argument("--sample-every", type=int, default=0, help="stamp one launch in this many with HIP events (0: chosen from --steps)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"], help="arithmetic type: f32 = the BASELINE metric (default); f64 = the precision the "
                     "reference front end ships with (config.hpp:7)")
     ap.add_argument("--stepsize", default=None, choices=["alg1", "alg2", "goldstein", "boyd"], help="pdhg configs: step-size rule (default alg2, the "
@@ -496,13 +496,13 @@ def main():
     if prelude_iters > 0:
         solver.iterate(prelude_iters)
     prelude_ms = (time.perf_counter() - t_pre) * 1e3
-    # EVERY launch of the timed region is stamped (hipExtLaunchKernel) with a stop event, which is bound to the kernel's own command
-    # and costs nothing; a sample is the distance between the ends of two consecutive launches of the in-order stream (kernel +
-    # ~0.5 us of dispatch gap).  Only a launch whose predecessor on the stream is not a stamped iteration kernel (the first one, the
-    # one after a residual fold) also takes a start event -- a marker packet of its own, ~4 us lost in the chain.  Up to round 4 every
-    # sampled launch carried such a start event: --steps 20 with all 10 launches stamped ran 17 130-17 500 it/s against 18 050-18 900
-    # unstamped on the same box (tools/stamp_probe.hip, profiles/r04_stamp_probe.txt: 80.1 against 75.5 us per launch of a chain).
-    every = args.sample_every or 1
+    # launches stamped with events (hipExtLaunchKernel: a start marker in front of the kernel, a stop event bound to the kernel's own
+    # command -- the kernel's duration as rocprofv3 reports it).  The marker costs the chain ~3.4 us per stamped launch
+    # (tools/stamp_probe.hip, profiles/r04_stamp_probe.txt; events without the system fence), ~3 % of `value` when every launch of the
+    # driver's --steps 20 is stamped -- which it is: 8 + 2 samples, a roofline fraction resting on three cannot resolve the spread
+    # between boxes (round-3 review).  Longer runs stamp one launch in four / eight.  (Stop events alone are free but give the launch
+    # PERIOD, ~4 us more than the kernel's duration: backend_pdhg.cpp, BeginSample.)
+    every = args.sample_every or (1 if args.steps <= 40 else 4 if args.steps <= 160 else 8)
 
     solver.iterate(args.warmup, checked=True)
     barrier()

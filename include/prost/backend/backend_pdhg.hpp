@@ -196,7 +196,7 @@ class BackendPDHG : public Backend<T> {
   }
   static constexpr size_t kNoEvent = ~(size_t)0;
   static constexpr size_t kMaxSamples = 16384;
-  struct Sample { int kind; size_t start, end; bool own_start; };   // indices into ev_; own_start: a start event of its own (not the previous launch's end)
+  struct Sample { int kind; size_t start, end; };   // indices into ev_
   size_t NewEvent();               // records the next event of the pool on the solver's stream
   std::vector<void*> ev_;          // event pool
   size_t ev_used_ = 0;

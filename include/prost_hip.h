@@ -60,11 +60,12 @@ int prost_hip_stream_destroy(void* stream);
 int prost_hip_stream_synchronize(void* stream);
 int prost_hip_device_synchronize(void);
 /* Kernel timing: the NEXT iteration-kernel launch of the calling thread (the fused PDHG iteration kernels and the kernels of
- * prost_hip_cgls_round) takes `start` / `stop` (events of prost_hip_event_create) into hipExtLaunchKernel.  `stop` is bound to the
- * kernel's own command (its end; free).  `start` may be NULL: a start event is a marker packet of its own in front of the kernel
- * (~4 us: it breaks the back-to-back dispatch of a chain), so a caller that stamps every launch of a chain passes stop events only
- * and reads prost_hip_event_elapsed_ms(stop of the previous launch, stop of this one).  (NULL, NULL) withdraws events no launch has
- * taken.  Launches that record nothing else (reduction folds, generic kernels) do not take the events. */
+ * prost_hip_cgls_round) takes `start` / `stop` (events of prost_hip_event_create / _create_timing) into hipExtLaunchKernel.  `stop` is
+ * bound to the kernel's own command (its end; free); `start` is a marker packet of its own in front of the kernel (~3.4-4.6 us lost in
+ * a back-to-back chain), and prost_hip_event_elapsed_ms(start, stop) is the kernel's duration as a profiler reports it.  `start` may be
+ * NULL: the distance between the stop events of two consecutive launches is then the launch PERIOD (kernel + the idle time between
+ * dependent launches).  (NULL, NULL) withdraws events no launch has taken.  Launches that record nothing else (reduction folds,
+ * generic kernels) do not take the events. */
 int prost_hip_next_launch_events(void* start, void* stop);
 /* Device-resident step sizes on the GENERIC PDHG path (ABI 6): while `record` (a record of prost_hip_pdhg_rule_begin) is set for the
  * calling thread, prost_hip_prox_elem_arg in the PDHG_PRIMAL / PDHG_DUAL modes, prost_hip_pdhg_primal_arg / _dual_arg and

@@ -41,11 +41,11 @@ constexpr int kReduceBlocks = 8192;        // partial slots in the reduction wor
 // Kernel timing (prost_hip_next_launch_events): the next PH_LAUNCH of the calling thread hands the events to hipExtLaunchKernelGGL.
 // The STOP event is bound to the kernel's own command: it costs nothing and carries the kernel's end.  A START event is a marker of
 // its own in front of the kernel -- a barrier packet that breaks the back-to-back dispatch of consecutive launches: a chain of 200
-// launches of a 75 us kernel runs 75.5 us per launch plain or with stop events only, 80.1 us with start + stop pairs (78.9 with
-// hipEventDisableSystemFence events; tools/stamp_probe.hip, profiles/r04_stamp_probe.txt).  Callers that time EVERY launch of a chain
-// therefore pass stop events only and take the distance between the ends of consecutive launches; a start event is for a launch
-// whose predecessor on the stream is not a stamped one.  (hipEventRecord brackets cost two such packets per launch and measure the
-// dispatch gap along with the kernel: a 22 us kernel read 14 % long.)
+// launches of a 75 us kernel runs 75.0 us per launch plain or with stop events only, 79.8 us with start + stop pairs (78.7 with
+// hipEventDisableSystemFence events; tools/stamp_probe.hip, profiles/r04_stamp_probe.txt).  start -> stop is the kernel's duration;
+// the distance between the stop events of consecutive launches is the launch period (it contains the idle time between dependent
+// launches).  (hipEventRecord brackets cost two such packets per launch and measure the dispatch gap along with the kernel: a 22 us
+// kernel read 14 % long.)
 extern thread_local hipEvent_t g_launch_ev_start, g_launch_ev_stop;
 // device-resident step-size record the generic PDHG kernels of the calling thread read their step sizes from (prost_hip_use_step_record)
 extern thread_local void* g_step_record;

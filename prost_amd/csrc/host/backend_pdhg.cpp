@@ -452,7 +452,6 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
   dev_batches_++;
   CheckHip(prost_hip_memcpy_d2h(rule_mirror_, rule_mirror_dev_, sizeof(prost_hip_pdhg_rule_state), s), "memcpy_d2h");
   CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");          // the batch's ONE host wait
-  last_end_ = kNoEvent;              // (kernel timing: the stream has drained)
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   const prost_hip_pdhg_rule_state& m = *rule_mirror_;
   if (m.evaluations > 0) {
@@ -484,22 +483,23 @@ size_t BackendPDHG<T>::NewEvent() {
   return ev_used_++;
 }
 
-/// Timing of a launch (prost_hip_next_launch_events -> hipExtLaunchKernel).  Every sampled launch takes a STOP event, which is bound
-/// to the kernel's own command and costs nothing.  Its sample runs from the stop event of the PREVIOUS sampled launch when nothing
-/// else has been enqueued and the host has not waited since (last_end_): the distance between the ends of two consecutive kernels
-/// of an in-order stream -- the kernel plus the dispatch gap in front of it (~0.5 us).  Otherwise the launch also takes a START event,
-/// a marker packet in front of the kernel (~4 us lost in the chain; rounds 3-4 gave one to EVERY sampled launch: 5-6 % of a 20-step
-/// run with every launch timed; hipEventRecord brackets, round 2, cost two packets).
+/// Timing of a launch (prost_hip_next_launch_events -> hipExtLaunchKernel): a sampled launch takes a START event -- a marker packet in
+/// front of the kernel -- and a STOP event bound to the kernel's own command; the elapsed time between them is the kernel's duration
+/// as rocprofv3 reports it (profiles/: within 1 %).  The marker costs the chain ~3.4 us per sampled launch with events created
+/// without the system fence (4.6 us with default events; tools/stamp_probe.hip).  Tried in round 4: stop events only, a sample being
+/// the distance between the ENDS of consecutive launches -- free, but that distance is the launch PERIOD: it contains the ~4 us the
+/// device idles between two dependent launches of this kernel (barrier, cache write-back / invalidate, dispatch of 3 876 workgroups),
+/// which is not part of the kernel's duration: 104.1 us against the 99.9 us rocprofv3 reports for the same run.  (hipEventRecord
+/// brackets, round 2, cost two marker packets per launch and read the gap along with the kernel.)
 template <typename T>
 bool BackendPDHG<T>::BeginSample(int kind) {
   // (at most kMaxSamples launches are timed between two KernelTimes calls, later ones run untimed)
-  if (!this->time_kernels_ || samples_.size() >= kMaxSamples) { last_end_ = kNoEvent; return false; }
+  if (!this->time_kernels_ || samples_.size() >= kMaxSamples) return false;
   // one launch in `sample_every_`
-  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) { last_end_ = kNoEvent; return false; }
-  const size_t start = last_end_ != kNoEvent ? last_end_ : NewEvent(), end = NewEvent();
-  CheckHip(prost_hip_next_launch_events(last_end_ != kNoEvent ? nullptr : ev_[start], ev_[end]), "next_launch_events");
-  samples_.push_back({kind, start, end, last_end_ == kNoEvent});
-  last_end_ = end;
+  if (this->sample_every_ > 1 ? (launches_[kind]++ % (size_t)this->sample_every_) != 1 : (launches_[kind]++, false)) return false;
+  const size_t start = NewEvent(), end = NewEvent();
+  CheckHip(prost_hip_next_launch_events(ev_[start], ev_[end]), "next_launch_events");
+  samples_.push_back({kind, start, end});
   return true;
 }
 
@@ -512,8 +512,7 @@ template <typename T>
 void BackendPDHG<T>::AbortSample(bool sampled) {
   if (!sampled) return;
   prost_hip_next_launch_events(nullptr, nullptr);          // (no CheckHip: an exception is already on its way)
-  if (!samples_.empty()) { ev_used_ -= samples_.back().own_start ? 2 : 1; samples_.pop_back(); }
-  last_end_ = kNoEvent;
+  if (!samples_.empty()) { samples_.pop_back(); if (ev_used_ >= 2) ev_used_ -= 2; }
 }
 
 template <typename T>
@@ -710,7 +709,6 @@ void BackendPDHG<T>::IterationFused(bool res) {
     CheckHip(Api<T>::fused_primal(&desc_, x_prev_.data(), x_.data(), y_.data(), y_prev_.data(), (double)tau_, iteration_ >= 1 ? 1 : 0,
                                   iteration_ >= 2 ? 1 : 0, res ? res_target() + 2 : nullptr, workspace_, s), "fused_primal");
   });
-  if (res) last_end_ = kNoEvent;           // (kernel timing: the fold of the primal pass's sums sits in front of the dual pass)
   x_.swap(x_prev_);                        // x_ = x^(k+1), x_prev_ = x^k       (:334)
   // kx_prev_ of the reference is K x^k except at k = 0 (zero vector, :216)
   TimedLaunch(kKernelDual, [&] {
@@ -870,16 +868,14 @@ void BackendPDHG<T>::ResolveResiduals() {
   if (resolve_on_side_) {
     // (with a communicator the sums are being all-reduced on the side stream: the iteration stream is free for the next pair meanwhile)
     if (CanSpeculate()) Speculate();
-    last_end_ = kNoEvent;            // (kernel timing: the host waits, the next launch does not follow its predecessor back to back)
     CheckHip(prost_hip_event_synchronize(ev_res_done_), "event_synchronize");
     resolve_on_side_ = false;
   }
   else if (CanSpeculate()) {
     Speculate();                                         // the device goes on with the next pair while the host looks at the sums
-    last_end_ = kNoEvent;
     CheckHip(prost_hip_event_synchronize(ev_res_local_), "event_synchronize");
   }
-  else { last_end_ = kNoEvent; CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize"); }
+  else CheckHip(prost_hip_stream_synchronize(CurrentStream()), "stream_synchronize");
   CheckHip(prost_hip_check_last_error(), "PDHG iteration");
   // the reference reduces in T and takes std::sqrt of the T sums (:433-436)
   this->primal_residual_ = std::sqrt((T)res_host_[0]);
@@ -948,7 +944,6 @@ void BackendPDHG<T>::ConstraintVariables() {
     CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), ktyp.data(), (double)tau_, n, s), "w_variable");
     CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx.data(), kxp.data(), (double)sigma_, (double)theta_, m, s), "z_variable");
     CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");             // the temporaries above go out of scope
-    last_end_ = kNoEvent;
   } else {
     CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), (double)tau_, n, s), "w_variable");   // :147-160
     CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "z_variable");   // :169-186

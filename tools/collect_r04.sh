@@ -30,13 +30,18 @@ for dt in f32 f64; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O -o pmc_fetch_$dt -- python3 $R/bench.py --dtype $dt --steps 60 --warmup 10 --prelude-iters 0 --no-cpu-baseline > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O -o pmc_write_$dt -- python3 $R/bench.py --dtype $dt --steps 60 --warmup 10 --prelude-iters 0 --no-cpu-baseline > /dev/null 2>&1
 done
+# C3: kernel stats, traffic and the instruction mix of the 3-D pair kernel
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats_c3 -- python3 $R/bench.py --config c3 --no-cpu-baseline > $O/bench_c3_under_rocprof.json 2>/dev/null
+for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O -o pmc_c3_$c -- python3 $R/bench.py --config c3 --steps 40 --warmup 10 --prelude-iters 0 --no-cpu-baseline > /dev/null 2>&1
+done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O -o pmc_fetch_sparse -- python3 $R/tools/sparse_rof_rate.py 4096 60 1 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O -o pmc_write_sparse -- python3 $R/tools/sparse_rof_rate.py 4096 60 1 > /dev/null 2>&1
 cd $R
 python3 - <<PY > $O/pmc_summary.txt
 # mean counter value per launch, FULL-SIZE launches only (smaller grids = the code-object warm-up on a tiny problem)
 import csv, collections, glob
-for tag in ("pmc_fetch_f32", "pmc_write_f32", "pmc_fetch_f64", "pmc_write_f64", "pmc_fetch_sparse", "pmc_write_sparse"):
+for tag in ("pmc_fetch_f32", "pmc_write_f32", "pmc_fetch_f64", "pmc_write_f64", "pmc_fetch_sparse", "pmc_write_sparse", "pmc_c3_FETCH_SIZE", "pmc_c3_WRITE_SIZE", "pmc_c3_SQ_INSTS_VALU", "pmc_c3_SQ_INSTS_SALU", "pmc_c3_SQ_INSTS_BRANCH"):
     files = glob.glob("$O/**/%s_counter_collection.csv" % tag, recursive=True)
     rows = [r for f in files[:1] for r in csv.DictReader(open(f)) if "fused" in r["Kernel_Name"]]
     big = collections.defaultdict(int)
@@ -62,3 +67,8 @@ try:
     print('$f'.split('/')[-1], 'value', round(d['value']), 'iterate_only', round(d['iterate_only_it_per_s']), 'kernel', r.get('kernel'), 'avg_ms', r.get('avg_launch_ms'), 'timed', r.get('launches_timed'), 'frac', r.get('frac'), 'phys', r.get('frac_hbm_traffic'), 'cols', r.get('chunk_cols'))
 except Exception as e: print('$f', 'ERR', e)"; done
 cat $O/sparse_rof_under_rocprof.txt $O/sparse_rof_generic_under_rocprof.txt
+# ---- the examples as written, the generic path under the default options, what a stamp costs
+{ python3 tools/rof_primal_rate.py 700 464 3 3000; python3 tools/rof_primal_rate.py 700 464 1 3000; python3 tools/rof_primal_rate.py 2048 2048 3 1000; python3 tools/rof_primal_rate.py 2048 2048 1 1000; } 2>/dev/null | tee $O/rof_primal_example_rates.txt
+{ python3 tools/generic_rule_rate.py 256 256 3000; python3 tools/generic_rule_rate.py 700 464 3000; python3 tools/generic_rule_rate.py 1024 1024 2000; python3 tools/generic_rule_rate.py 2048 2048 600; } 2>/dev/null | tee $O/generic_device_rules.txt
+{ python3 tools/sparse_rof_rate.py 2048 2000 1; python3 tools/sparse_rof_rate.py 2048 2000 2; python3 tools/sparse_rof_rate.py 4096 600 1; python3 tools/sparse_rof_rate.py 2048 2000 1 boyd 1; } 2>/dev/null | tee $O/sparse_rof_rates.txt
+tools/bin/stamp_probe | tee $O/stamp_probe.txt
