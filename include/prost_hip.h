@@ -539,7 +539,8 @@ int prost_hip_fused_iteration2_f64(const prost_hip_fused_desc* desc, double* x_o
  * Draws `n` pseudo-random cases (all exponents, subnormal / overflowing quotients, zeros) from `seed` and
  * writes the number of bit mismatches against the compiler's IEEE expansions to the DEVICE array
  * mismatches8 = {division, sqrt, exact division, subtraction, control, division with the product rounded through
- * fma(n, r, +0) against n / d + 0, min0(t) against t > 0 ? 0 : t, unused}; `control` counts the cases where
+ * fma(n, r, +0) against n / d + 0, min0(t) against t > 0 ? 0 : t, the fp64 quotient / square-root forms against `/` and sqrt
+ * (ABI 6; unused before)}; `control` counts the cases where
  * the plain single-precision reciprocal product differs from n / d and must come out > 0. */
 int prost_hip_selftest_math(unsigned long long* mismatches8, uint64_t n, uint64_t seed, void* stream);
 /* Verification entry: comparison of two device vectors without a read-back (the 2048 x 2048 x 64 state is

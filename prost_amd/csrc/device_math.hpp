@@ -16,6 +16,32 @@ namespace prost_hip {
 // t_abs / t_sqrt / t_pow ..., div1 and the scalar maps f1d_* live in the public header (plugin authors compose them too)
 using namespace prost::elemop;
 
+// ---- fp64: the compiler's own IEEE expansions of `/` and sqrt without their range handling -----------------
+// hipcc expands a / b into v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 fma), the quotient estimate, its
+// residual, v_div_fmas, v_div_fixup: 11 fp64-rate instructions PER QUOTIENT, and does not share the reciprocal between quotients
+// with the same divisor; sqrt is v_rsq_f64 + 2 products + 7 fma inside a range scaling (compare, 2 x ldexp, class test, 4 selects).
+// The forms below are those sequences minus v_div_scale / v_div_fmas' scaling / v_div_fixup resp. the range scaling: the SAME bits
+// wherever the dropped steps are the identity -- operands and results well inside the exponent range, checked by the callers
+// (f64_mid: |v| in [2^-500, 2^500]; quotients of two such values are normal) -- i.e. the correctly rounded quotient / root
+// (kernels_selftest.hip compares them with `/` and sqrt on the device).  The reciprocal of a divisor is formed ONCE:
+// 5 instructions, then 3 per quotient; a wave-uniform divisor pays the 5 once per launch.
+__device__ __forceinline__ bool f64_mid(double v) {
+  const unsigned e = ((unsigned)((unsigned long long)__double_as_longlong(v) >> 52)) & 0x7FFu;
+  return e - (1023u - 500u) <= 1000u;
+}
+__device__ __forceinline__ double rcp_newton2(double d) {           // the reciprocal as a / d's expansion refines it
+  double y = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return y;
+}
+__device__ __forceinline__ double div_mid(double n, double d, double y) {   // n / d for f64_mid n (or 0), d; y = rcp_newton2(d)
+  const double q0 = n * y;
+  const double r = __builtin_fma(-d, q0, n);
+  return __builtin_fma(r, y, q0);
+}
 // ---- exact (float)((double)x / D) for a wave-uniform divisor D ------------------------------
 // The reference's fp32 build divides in double wherever a double literal appears (e.g.
 // Function1DSquare: x0 / (1. + tau)).  A hardware fp64 division is ~35 VALU instructions; with a
@@ -42,7 +68,11 @@ __device__ __forceinline__ float div_to_float_exact(float x, const UniformDiv& u
   if (__builtin_expect((near_tie || !normal_float) && q1 != 0.0, 0)) return (float)(xd / u.D);
   return (float)q1;
 }
-__device__ __forceinline__ double div_to_float_exact(double x, const UniformDiv& u) { return u.D == 1.0 ? x : x / u.D; }
+__device__ __forceinline__ double div_to_float_exact(double x, const UniformDiv& u) {
+  if (u.D == 1.0) return x;
+  const double y = rcp_newton2(u.D);                              // (wave-uniform: hoisted out of the callers' loops)
+  return (f64_mid(u.D) && (f64_mid(x) || x == 0.0)) ? div_mid(x, u.D, y) : x / u.D;
+}
 // The same for VEC values with straight-line code, the guards evaluated as WAVE MASKS (the compares write SGPR pairs,
 // the OR runs on the scalar unit: no v_cndmask / v_or per element) and without the residual correction step: q0 = RN(x * rD) with rD = RN(1/D) is within
 // 2^-52 |q| < 2 ulp(double) of x / D, the reference's RN_double(x / D) within 1/2 ulp, so the two doubles differ by at
@@ -76,10 +106,20 @@ __device__ __forceinline__ void div_to_float_exact_vec(const float (&x)[VEC], co
     }
   }
 }
+// fp64: the short quotient for every element, the range guard as a wave mask, the full division for the whole wave if any lane needs it
 template <int VEC>
 __device__ __forceinline__ void div_to_float_exact_vec(const double (&x)[VEC], const UniformDiv& u, double (&out)[VEC]) {
+  const double y = rcp_newton2(u.D);
+  unsigned long long odd = __builtin_amdgcn_ballot_w64(!f64_mid(u.D));
 #pragma unroll
-  for (int j = 0; j < VEC; j++) out[j] = x[j] / u.D;
+  for (int j = 0; j < VEC; j++) {
+    out[j] = div_mid(x[j], u.D, y);
+    odd |= __builtin_amdgcn_ballot_w64(!(f64_mid(x[j]) || x[j] == 0.0));
+  }
+  if (__builtin_expect(odd != 0, 0)) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) out[j] = x[j] / u.D;
+  }
 }
 
 // ---- correctly rounded fp32 division / square root with fewer instructions ---------------------
@@ -150,9 +190,10 @@ template <> struct SharedDivisor<float> {
   __device__ __forceinline__ float div(float n) const { return mul_rcp(n, r); }
 };
 template <> struct SharedDivisor<double> {
-  double d;
-  __device__ __forceinline__ explicit SharedDivisor(double d_) : d(d_) {}
-  __device__ __forceinline__ double div(double n) const { return n / d; }
+  double d, y;
+  bool mid;
+  __device__ __forceinline__ explicit SharedDivisor(double d_) : d(d_), y(rcp_newton2(d_)), mid(f64_mid(d_)) {}
+  __device__ __forceinline__ double div(double n) const { return (mid && (f64_mid(n) || n == 0.0)) ? div_mid(n, d, y) : n / d; }
 };
 // ---- the same quotient in single precision only -------------------------------------------------
 // fp64 instructions and the f32 <-> f64 conversions issue at half the fp32 rate on this part (16 vs 32 lanes per
@@ -190,7 +231,19 @@ __device__ __forceinline__ float sqrt_midrange(float x) {
   s = r_up > 0.0f ? s_up : s;
   return s;
 }
-__device__ __forceinline__ double sqrt_midrange(double x) { return sqrt(x); }
+// sqrt(x) for x in [2^-500, 2^500] (f64_mid): the compiler's expansion without its range scaling and its zero / infinity select
+__device__ __forceinline__ double sqrt_midrange(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
 
 // ---- the dual step's prox of the ROF / TV shapes, straight-line --------------------------------
 // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked; elem_operation_norm2.hpp:40-88,
@@ -227,7 +280,31 @@ __device__ __forceinline__ void norm2_leq0_fast(const T (&nv)[VEC], const T (&av
 #pragma unroll
       for (int i = 0; i < NC; i++) out[i][j] = mul_rcp_pz(pr * av[i][j], r);
     }
-  } else {                                                   // general expansions, still branch-free (the fp64 instantiation)
+  } else {
+    if constexpr (sizeof(T) == 8) {
+      // fp64: the short square root, ONE refined reciprocal per pixel and three instructions per quotient (f64_mid forms above) --
+      // same bits as the expansions below wherever the squared norm and the numerators are zero or well inside the exponent
+      // range; a wave in which any lane is not (the guard is a wave mask) takes the expansions
+      unsigned long long odd = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const bool nz = nv[j] > 0;
+        const double x = nz ? (double)nv[j] : 1.0;
+        odd |= __builtin_amdgcn_ballot_w64(!f64_mid(x));
+        const double nrm = sqrt_midrange(x);
+        const double t = nrm - (double)b;
+        const double pr = (t > 0.0 ? 0.0 : t) + (double)b;
+        const double y = rcp_newton2(nrm);
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          const double num = pr * (double)av[i][j];
+          odd |= __builtin_amdgcn_ballot_w64(!(f64_mid(num) || num == 0.0));
+          out[i][j] = nz ? (T)div_mid(num, nrm, y) : (T)0;
+        }
+      }
+      if (__builtin_expect(odd == 0, 1)) return;
+    }
+    // general expansions, still branch-free
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const bool nz = nv[j] > 0;
@@ -351,15 +428,22 @@ __device__ __forceinline__ void norm2_moreau_post(const T (&nv)[VEC], const T (&
     if constexpr (sizeof(T) == 4) {
       const bool mid = x >= (T)1.2621774483536189e-29f && x <= (T)8.507059173023462e37f;       // [2^-96, 2^126]
       nrm = __builtin_expect(mid, 1) ? sqrt_midrange(x) : t_sqrt(x);
-    } else nrm = t_sqrt(x);
+    } else nrm = f64_mid((double)x) ? (T)sqrt_midrange((double)x) : t_sqrt(x);
     const T pr = scaled_prox_u<T, FN>(FN, nrm, c, u);
     if constexpr (sizeof(T) == 4) {
       const double r = rcp_refined(nrm);
 #pragma unroll
       for (int i = 0; i < NC; i++) { const T q = nz ? (T)mul_rcp((float)(pr * vv[i][j]), r) : (T)0; out[i][j] = av[i][j] - s * q; }
     } else {
+      // (fp64: the short reciprocal form where the operands allow it -- per lane here: this instance is not the hot one)
+      const double y = rcp_newton2((double)nrm);
 #pragma unroll
-      for (int i = 0; i < NC; i++) { const T q = nz ? pr * vv[i][j] / nrm : (T)0; out[i][j] = av[i][j] - s * q; }
+      for (int i = 0; i < NC; i++) {
+        const double num = (double)(pr * vv[i][j]);
+        const T qd = (f64_mid((double)nrm) && (f64_mid(num) || num == 0.0)) ? (T)div_mid(num, (double)nrm, y) : pr * vv[i][j] / nrm;
+        const T q = nz ? qd : (T)0;
+        out[i][j] = av[i][j] - s * q;
+      }
     }
   }
 }

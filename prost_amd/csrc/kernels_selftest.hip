@@ -21,7 +21,7 @@ __device__ __forceinline__ float rnd_float(uint64_t key, int elo, int ehi) {
 }
 
 __global__ void __launch_bounds__(kBlock) selftest_kernel(unsigned long long* bad, uint64_t n, uint64_t seed) {
-  unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0;
+  unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     const uint64_t k = seed * 0x100000001b3ull + i * 4;
     // (0) division through the refined double reciprocal: any normal denominator, numerators over the
@@ -54,6 +54,34 @@ __global__ void __launch_bounds__(kBlock) selftest_kernel(unsigned long long* ba
     const float er = (float)((double)xv / u.D);
     b2 += __float_as_uint(out4[0]) != __float_as_uint(er);
     b2 += __float_as_uint(div_to_float_exact(xv, u)) != __float_as_uint(er);
+    // (7) fp64: the short quotient and square root of device_math.hpp == `/` and sqrt for operands in their stated range
+    //     (|v| in [2^-500, 2^500], numerators also 0), the vector form and SharedDivisor over the WHOLE range (their guards)
+    {
+      const uint64_t m1 = ((uint64_t)mix32(k + 11) << 32) | mix32(k + 12), m2 = ((uint64_t)mix32(k + 13) << 32) | mix32(k + 14);
+      const int full = (int)((i / 5) % 4) == 3;                      // one case in four: exponents over the whole double range
+      const int e1 = full ? (int)(mix32(k + 15) % 2046u) + 1 : 1023 - 500 + (int)(mix32(k + 15) % 1001u);
+      const int e2 = full ? (int)(mix32(k + 16) % 2046u) + 1 : 1023 - 500 + (int)(mix32(k + 16) % 1001u);
+      double dn = __longlong_as_double((long long)((m1 & 0x800FFFFFFFFFFFFFull) | ((uint64_t)e1 << 52)));
+      const double dd = __longlong_as_double((long long)((m2 & 0x800FFFFFFFFFFFFFull) | ((uint64_t)e2 << 52)));
+      if (sel == 2) dn = 0.0; else if (sel == 3) dn = -dd;
+      const double qr64 = dn / dd;
+      if (!full) {
+        const double q64 = div_mid(dn, dd, rcp_newton2(dd));
+        b7 += (__double_as_longlong(q64) != __double_as_longlong(qr64)) && !(dn == 0.0 && q64 == 0.0 && qr64 == 0.0);
+        const double ax = fabs(dd);
+        b7 += __double_as_longlong(sqrt_midrange(ax)) != __double_as_longlong(sqrt(ax));
+      }
+      const SharedDivisor<double> sd(dd);
+      const double qs = sd.div(dn);
+      b7 += (__double_as_longlong(qs) != __double_as_longlong(qr64)) && !(qs == 0.0 && qr64 == 0.0) && !(qs != qs && qr64 != qr64);
+      const UniformDiv u64 = make_uniform_div(fabs(dd));
+      double in1[1] = {dn}, out1[1];
+      div_to_float_exact_vec<1>(in1, u64, out1);
+      const double qv = dn / u64.D;
+      b7 += (__double_as_longlong(out1[0]) != __double_as_longlong(qv)) && !(out1[0] == 0.0 && qv == 0.0) && !(out1[0] != out1[0] && qv != qv);
+      const double q1 = div_to_float_exact(dn, u64);
+      b7 += (__double_as_longlong(q1) != __double_as_longlong(qv)) && !(q1 == 0.0 && qv == 0.0) && !(q1 != q1 && qv != qv);
+    }
     // (3) float subtraction == double subtraction rounded to float (exponent gaps up to the full range)
     const float a = rnd_float(k + 1, -126, 127), c = rnd_float(k + 2, -126, 127);
     const float sf = a - c, sd = (float)((double)a - (double)c);
@@ -66,6 +94,7 @@ __global__ void __launch_bounds__(kBlock) selftest_kernel(unsigned long long* ba
   if (b4) atomicAdd(bad + 4, b4);
   if (b5) atomicAdd(bad + 5, b5);
   if (b6) atomicAdd(bad + 6, b6);
+  if (b7) atomicAdd(bad + 7, b7);
 }
 
 }  // namespace prost_hip

@@ -703,13 +703,14 @@ def test_double_iteration_kernel_special_values(hip, dtype):
 
 def test_short_division_and_sqrt_forms(hip):
     """device_math.hpp's short correctly rounded forms (used by the two-iterations kernel) against the
-    compiler's IEEE expansions on 2^31 pseudo-random cases per form, evaluated on the device."""
+    compiler's IEEE expansions on 2^31 pseudo-random cases per form, evaluated on the device (round 4: the fp64 quotient with a
+    shared refined reciprocal and the fp64 square root without range scaling as well -- slot 7)."""
     bad = hip.DeviceArray.zeros(8, np.uint64)
     total = np.zeros(8, dtype=np.uint64)
     for seed in range(8):
         hip.check(hip.lib().prost_hip_selftest_math(bad.ptr, C.c_uint64(1 << 28), C.c_uint64(seed), None))
         total += bad.to_host()
-    names = ("division", "sqrt", "exact_division", "subtraction", "control", "division_plus_zero", "min0", "unused")
+    names = ("division", "sqrt", "exact_division", "subtraction", "control", "division_plus_zero", "min0", "fp64_division_and_sqrt")
     assert total[:4].tolist() == [0, 0, 0, 0] and total[5:].tolist() == [0, 0, 0], dict(zip(names, total.tolist()))
     assert total[4] > 1000, "control: the harness must see the approximate reciprocal fail"
     print("selftest control mismatches:", int(total[4]), "of", 8 << 28)
