@@ -1216,6 +1216,36 @@ def _deblurring_like_problem(nx, ny, seed, primal_form=True):
     return prob
 
 
+@pytest.mark.parametrize("step", ["goldstein", "boyd"])
+def test_device_resident_step_rules_on_the_generic_path_with_a_communicator(step):
+    """the same batches when the four sums pass an all-reduce first (a one-rank host-callback communicator): the reduction launch
+    does not apply the rule, the all-reduce and the one-thread rule kernel follow -- identical to the host-side rule in every scalar
+    and iterate"""
+    prost.set_precision("single")
+    prob = _deblurring_like_problem(26, 40, 3, True)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=2e-2, tol_rel_dual=2e-2, tol_abs_primal=0, tol_abs_dual=0)
+    prost.comm_init_host(lambda a: None, 1)
+    try:
+        runs = {}
+        for dev in (True, False):
+            b = prost.backend.pdhg(stepsize=step, residual_iter=1)
+            b[1]["allow_device_rules"] = dev
+            s = prost.Solver(prob, b, o)
+            s.iterate(9)
+            a = s.state()
+            s.iterate(300)
+            runs[dev] = (a, s.state())
+            s.destroy()
+            assert (runs[dev][1]["device_rule_batches"] >= 3) if dev else runs[dev][1]["device_rule_batches"] == 0
+        for a, b_ in zip(runs[True], runs[False]):
+            for v in RULE_SCALARS:
+                assert a[v] == b_[v], (v, a[v], b_[v])
+            for v in "xyzw":
+                assert np.array_equal(a[v], b_[v]), v
+    finally:
+        prost.comm_destroy()
+
+
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("step", ["goldstein", "boyd"])
 @pytest.mark.parametrize("residual_iter,primal_form", [(1, True), (3, False), (10, True)])
