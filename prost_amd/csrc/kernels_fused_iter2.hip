@@ -88,6 +88,9 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
   typedef Col2<T, VEC, GMASK> Col;
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
   const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;
+  // straight-line instance whose prox_f* is the Moreau wrap of ElemOperationNorm2<FFN> (FFN = abs: ROF written in its primal form,
+  // example_rof_primal.m:27; kernels_fused_iter.hip, device_math.hpp: norm2_moreau_post)
+  constexpr bool kFM = FAST && FFN != PROST_FN_IND_LEQ0;
   double r_pd = 0, r_pv = 0, r_dd = 0, r_dv = 0;       // primal diff^2, primal var^2, dual diff^2, dual var^2
 
   // one 32-bit byte offset per lane serves every plane (x, y1, y2, coefficients, outputs): the plane
@@ -263,6 +266,8 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     const T bel_n = lane_down(xn_c[0]);                         // lane 63: no source, its last row is halo
     const T bel_o = lane_down(xo_c[0]);
     T av[2][VEC], nv[VEC];
+    T vv[kFM ? 2 : 1][kFM ? VEC : 1];          // kFM: the pre-scaled arguments v = arg / (sigma Sigma)
+    const SharedDivisor<T> div_sS(kFM ? sigS : (T)1);
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const idx_t row = row0 + j;
@@ -274,10 +279,12 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       const T kp2 = (I || row < ny - 1) ? below_o - xo_c[j] : (T)0;
       const T arg1 = y1c[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
       const T arg2 = y2c[j] + sigS * ((1 + theta) * kx2 - theta * kp2);
+      const T w1 = kFM ? div_sS.div(arg1) : arg1, w2 = kFM ? div_sS.div(arg2) : arg2;
       T norm = 0;
-      norm += arg1 * arg1;
-      norm += arg2 * arg2;
+      norm += w1 * w1;
+      norm += w2 * w2;
       if (FAST) {
+        if (kFM) { vv[0][kFM ? j : 0] = w1; vv[kFM ? 1 : 0][kFM ? j : 0] = w2; }
         av[0][j] = arg1; av[1][j] = arg2; nv[j] = norm;
       } else if (norm > 0) {
         norm = t_sqrt(norm);
@@ -293,7 +300,8 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
       // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked): out = pr v / ||v||,
       // pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0 -- straight-line for the VEC pixels (device_math.hpp)
       T out[2][VEC];
-      norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+      if constexpr (kFM) norm2_moreau_post<T, FFN, kFM ? 2 : 1, kFM ? VEC : 1>(nv, vv, av, sigS, a.f_val, P.uf, out);
+      else norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
 #pragma unroll
       for (int j = 0; j < VEC; j++) { o1[j] = out[0][j]; o2[j] = out[1][j]; }
       if (kRes && acc && owner && counted) {
@@ -448,7 +456,8 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
 }
 
 static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
-  if (!d || d->is3d || d->L != 1 || d->f_moreau) return false;
+  if (!d || d->is3d || d->L != 1) return false;
+  if (d->f_moreau && !(d->f_fn == PROST_FN_ABS && d->g_fn == PROST_FN_SQUARE && d->g_coeff_ptr[1] && !d->g_b_masked)) return false;   // Moreau-wrapped prox_f*: one straight-line instance
   if (d->nx < 4 || d->ny < 4) return false;
   if (d->g_fn < 0 || d->g_fn >= PROST_FN_COUNT || d->f_fn < 0 || d->f_fn >= PROST_FN_COUNT) return false;
   if ((double)d->nx * (double)d->ny * (dtype == 0 ? 4 : 8) >= 4294967296.0) return false;   // 32-bit byte offsets per plane
@@ -467,7 +476,7 @@ static bool iter2_desc_ok(const prost_hip_fused_desc* d, int dtype) {
 // 4-stage pipeline needs > 240 VGPRs: correct (tests) but ~5x slower than two single launches
 // (measured abs / ind_leq0 at 4096^2: 0.79 vs 0.16 ms per iteration), so callers should not pair there.
 static bool iter2_fast_shape(const prost_hip_fused_desc* d) {
-  if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
+  if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != (d->f_moreau ? PROST_FN_ABS : PROST_FN_IND_LEQ0)) return false;
   if (d->g_b_masked && (!d->g_coeff_ptr[1] || d->g_fn != PROST_FN_SQUARE)) return false;     // the merged stream IS the per-pixel b; square data term
   if (d->var_T && (d->g_fn != PROST_FN_SQUARE || !d->g_coeff_ptr[1] || d->g_b_masked)) return false;   // position-dependent Tau: one instance (ROF, per-pixel b)
   for (int k = 0; k < 7; k++) if (d->g_coeff_ptr[k] && k != 1) return false;
@@ -534,7 +543,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   for (int i = 0; i < 2; i++) {
     p[i].tau = (T)tau[i]; p[i].sigma = (T)sigma[i]; p[i].theta = (T)theta[i];
     p[i].ug = make_uniform_prox<T>(a.g_val, (T)tau[i] * a.Tval);
-    p[i].uf = make_uniform_prox<T>(a.f_val, (T)sigma[i] * a.Sval);
+    p[i].uf = make_uniform_prox<T>(a.f_val, dual_prox_step<T>((T)sigma[i], a.Sval, a.fmor));
     for (int k = 0; k < 2; k++) p[i].ec[k] = a.varT ? make_edge_terms<T>(a.g_val, (T)tau[i] * a.Tcls[k]) : EdgeTerms<T>();
   }
   int mask = 0;
@@ -544,6 +553,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   if (d->g_b_masked && !iter2_fast_shape(d)) { set_error("fused double iteration: a merged b stream needs the straight-line square shape"); return 1; }
   const bool fast = iter2_fast_shape(d) && p[0].ug.a_one && p[0].ug.den_one && !p[0].ug.degenerate && p[0].uf.a_one && p[0].uf.den_one &&
                     p[1].ug.den_one && p[1].uf.den_one;
+  if (a.fmor && !(fast && mask == 0x2)) { set_error("fused double iteration: a Moreau-wrapped prox_f* runs the straight-line square / abs instance only"); return 1; }
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
   hipStream_t s = as_stream(stream);
   const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
@@ -561,6 +571,7 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
 #define GO(G, F, M, PFv, FASTv) do { if (mode == 0) GO3(G, F, M, PFv, FASTv, 0); else if (mode == 1) GO3(G, F, M, PFv, FASTv, 1); else if (mode == 2) GO3(G, F, M, PFv, FASTv, 2); else GO3(G, F, M, PFv, FASTv, 3); } while (0)
   if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 3, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 3, true); }
   else if (fast && mask == 0x2 && d->g_b_masked) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x82, 3, true);      // inpainting: binary mask folded into b
+  else if (fast && mask == 0x2 && a.fmor) GO(PROST_FN_SQUARE, PROST_FN_ABS, 0x2, 3, true);          // ROF in its primal form (Moreau-wrapped TV norm)
   else if (fast && mask == 0x2) {
     GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x2, 3, true);
   }

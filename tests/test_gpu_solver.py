@@ -1428,7 +1428,8 @@ def test_rof_in_primal_form_with_sub_variables_runs_the_fused_kernels(precision,
     o = prost.options(max_iters=200, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=0, tol_abs_dual=0)
     for (nx, ny), res_iter, step, as_block, split in (((30, 32), 1, "boyd", False, (100, 500)), ((25, 31), 1, "boyd", False, (100, 500)),
                                                      ((20, 36), 3, "alg2", False, (7, 1)), ((18, 40), 2, "goldstein", True, (100, 500)),
-                                                     ((21, 33), 5, "alg1", False, None)):
+                                                     ((21, 33), 5, "alg1", False, None), ((16, 504), 10, "alg2", False, (100, 500)),
+                                                     ((12, 250), 4, "boyd", True, (100, 500))):
         f = synthetic.rof_image(nx, ny, L, seed=8)
         prob = _rof_primal_as_the_example_writes_it(nx, ny, L, f, 10.0, as_block, split)
         b = prost.backend.pdhg(stepsize=step, residual_iter=res_iter, alg2_gamma=0.5, tau0=1, sigma0=1)
@@ -1443,6 +1444,8 @@ def test_rof_in_primal_form_with_sub_variables_runs_the_fused_kernels(precision,
                 assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
         if step in ("boyd", "goldstein"):
             assert st["device_rule_batches"] >= 1, st["device_rule_batches"]
+        if L == 1 and step == "alg2":
+            assert st["pair_launches"] > 0, st["pair_launches"]           # two iterations per launch: the pair kernel's Moreau instance
         b[1]["allow_fused"] = False
         gen = run_product(prob, b, o, 40)
         assert gen["path"] == "pdhg:generic"
