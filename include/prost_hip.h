@@ -300,7 +300,8 @@ typedef struct {
   int f_moreau;             /* (ABI 6) prox_fstar is the Moreau wrap of the described elem_operation:norm2 (a problem written in the PRIMAL  */
                             /* form, example_rof_primal.m:27: backend_pdhg.cu:255-266 derives prox_f* from prox_f; prox_moreau.cu:98-134):   */
                             /* v = arg / (sigma Sigma), r = prox of the described function at v with the step 1 / (sigma Sigma),             */
-                            /* result = arg - sigma Sigma r.  Honoured by prost_hip_fused_iteration and _iteration_mc; the others refuse it. */
+                            /* result = arg - sigma Sigma r.  Honoured by prost_hip_fused_iteration, _iteration_mc and (square data term with per-pixel b,        */
+                            /* 'abs') _iteration2; the others refuse it. */
 } prost_hip_fused_desc;
 /* Folds a BINARY per-element coefficient a of ElemOperation1D (elem_operation_1d.hpp:42-44: a == 0 skips the function, the
  * element passes through) into the b stream: bm[i] = a[i] == 0 ? sentinel : (b ? b[i] : b_val), sentinel = a quiet NaN with the
