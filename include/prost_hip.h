@@ -296,7 +296,7 @@ typedef struct {
                             /* problem.cu:262-287 forms it -- T_cls[0..2] for pixels with 2, 3, 4 stencil entries in their column         */
                             /* (corner, edge, interior; count = 4 - [x == 0] - [x == nx - 1] - [y == 0] - [y == ny - 1]), T_val = T_cls[2]. */
                             /* Sigma stays uniform (the all-zero rows of the matrix inherit 1/2, problem.cu:267-286).  Honoured by        */
-                            /* prost_hip_fused_iteration (L <= 2), _iteration2 (L == 1, ROF shape), _iteration_mc (L = 3, 4); the others refuse it.   */
+                            /* prost_hip_fused_iteration (L <= 2), _iteration2 (L == 1, ROF shape), _iteration_mc (L = 3, 4), _iteration_mc_x2 (ROF shape); the others refuse it. */
   int f_moreau;             /* (ABI 6) prox_fstar is the Moreau wrap of the described elem_operation:norm2 (a problem written in the PRIMAL  */
                             /* form, example_rof_primal.m:27: backend_pdhg.cu:255-266 derives prox_f* from prox_f; prox_moreau.cu:98-134):   */
                             /* v = arg / (sigma Sigma), r = prox of the described function at v with the step 1 / (sigma Sigma),             */

@@ -28,6 +28,7 @@ struct IterParamsMc {          // step sizes of one iteration + the host-evaluat
   T tau, sigma, theta;
   T step;
   UniformDiv sq;
+  EdgeTerms<T> ec[2];          // GB = 3 (position-dependent Tau): the terms of the classes Tcls[0] (corner), Tcls[1] (edge)
 };
 
 template <class T, int VEC, int GB>
@@ -47,7 +48,10 @@ __device__ __forceinline__ void stm_o(T* __restrict__ base, unsigned byte_off, c
 // RES: additionally the four residual sums of the SECOND iteration (backend_pdhg.cu:73-120), term by term the expressions of
 // fused_iter2d_mc_kernel; K^T y^k of a column waits two steps between stages A and C in LDS, the sums are accumulated in LDS
 // (own lanes, no synchronisation) -- as in kernels_fused_iter3d_x2.hip.  One partial (4 doubles) per workgroup.
-// GB: 0 scalar b of prox_g, 1 per-pixel b, 2 per-pixel b that carries the mask sentinel (prost_hip_mask_merge: binary a folded in)
+// GB: 0 scalar b of prox_g, 1 per-pixel b, 2 per-pixel b that carries the mask sentinel (prost_hip_mask_merge: binary a folded in),
+// 3 per-pixel b AND the position-dependent primal preconditioner of a gradient handed over as a sparse matrix (FusedArgs::varT; square
+// data term) -- the expressions of fused_iter2d_mc_kernel<..., VART>: K^T y in the order of the matrix's transposed CSR row, the pixels of
+// the first / last row and column with the step and the divisor of their class
 template <class T, int VEC, int GFN, int GB, int LW, bool RES>
 __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                                 const T* __restrict__ y, FusedArgs<T> a, IterParamsMc<T> p1,
@@ -56,6 +60,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
     if (rec->stop) return;
     p1.tau = rec->p.tau; p1.sigma = rec->p.sigma; p1.theta = rec->p.theta; p1.step = rec->p.ug.step; p1.sq = rec->p.ug.sq;
+    if (GB == 3) { p1.ec[0] = rec->p.ec[0]; p1.ec[1] = rec->p.ec[1]; }
     p2 = p1;                       // a rule evaluation never falls between the two iterations of a launch
   }
   // two iterations need two valid rows beyond the owned ones on either side: one halo lane of >= 2 rows, or two halo lanes of one row
@@ -111,9 +116,12 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   // v1 / v2: the dual variable at column c, p1c: its first component at column c-1
   auto primal = [&](idx_t c, const T (&v1)[VEC], const T (&v2)[VEC], const T (&p1c)[VEC], const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1],
                     const IterParamsMc<T>& Pm, T (&xn)[VEC], T (&ktv)[VEC]) {
+    constexpr bool VART = GB == 3;
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
     T parg[VEC], parg0[GB == 2 ? VEC : 1];
+    T argv[VART ? VEC : 1];
+    bool edgev[VART ? VEC : 1], cornerv[VART ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const idx_t row = row0 + j;
@@ -121,9 +129,22 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
       if (row > 0) divy -= (j > 0 ? v2[j > 0 ? j - 1 : 0] : up);
       T divx = (c < nx - 1) ? v1[j] : (T)0;
       if (c > 0) divx -= p1c[j];
-      const T kty = (T)0 - (divx + divy);
+      T kty = (T)0 - (divx + divy);
+      T tT = tauT;
+      if (VART) {
+        T s = 0;                     // K^T y in the order of the matrix's transposed CSR row (kernels_fused_iter.hip: fused_iter2d_kernel)
+        if (c > 0) s += p1c[j];
+        if (c < nx - 1) s -= v1[j];
+        if (row > 0) s += (j > 0 ? v2[j > 0 ? j - 1 : 0] : up);
+        if (row < ny - 1) s -= v2[j];
+        kty = s;
+        const int cnt = 4 - (c == 0 ? 1 : 0) - (c == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
+        edgev[VART ? j : 0] = cnt != 4; cornerv[VART ? j : 0] = cnt == 2;
+        tT = Pm.tau * (cnt == 4 ? a.Tval : (cnt == 3 ? a.Tcls[1] : a.Tcls[0]));
+      }
       ktv[j] = kty;
-      const T arg = xin[j] - tauT * kty;
+      const T arg = xin[j] - tT * kty;
+      if (VART) argv[VART ? j : 0] = arg;
       if (GB == 2) parg0[GB == 2 ? j : 0] = arg;
       parg[j] = arg - (GB ? bv[GB ? j : 0] : a.g_val[1]);
     }
@@ -135,6 +156,18 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     }
 #pragma unroll
     for (int j = 0; j < VEC; j++) xn[j] = r[j] + (GB ? bv[GB ? j : 0] : a.g_val[1]);
+    if (VART) {                      // pixels with their own Tau_j: the divisor 1 + step_j of their class (IterParamsMc::ec)
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        if (edgev[VART ? j : 0]) {
+          const bool cn = cornerv[VART ? j : 0];
+          UniformDiv dv;
+          dv.D = cn ? Pm.ec[0].sq.D : Pm.ec[1].sq.D; dv.rD = cn ? Pm.ec[0].sq.rD : Pm.ec[1].sq.rD;
+          const T bj = bv[GB ? j : 0];
+          xn[j] = div_to_float_exact(argv[VART ? j : 0] - bj, dv) + bj;
+        }
+      }
+    }
     if (GB == 2) {
       // merged b stream: where the binary coefficient a of prox_g is 0 the element passes through (elem_operation_1d.hpp:42-44 with d = e = 0)
 #pragma unroll
@@ -186,12 +219,20 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
   }
   auto accumulate = [&](int k, double v) { s_acc[RES ? k : 0][RES ? ch : 0][RES ? lane : 0] += v; };
   // dual_residual_transform (backend_pdhg.cu:73-94) at the column of stage C: xo / xn = x^(k+1) / x^(k+2), kt_prev = K^T y^k, kt = K^T y^(k+1)
-  auto dual_residual = [&](const T (&xo)[VEC], const T (&xn)[VEC], const T (&kt_prev)[VEC], const T (&kt)[VEC]) {
+  auto dual_residual = [&](idx_t c, const T (&xo)[VEC], const T (&xn)[VEC], const T (&kt_prev)[VEC], const T (&kt)[VEC]) {
     double dd = 0, dv = 0;
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const T w_hat = div_tauT.div(xo[j] - xn[j]) - sqT * kt_prev[j];
-      const T diff = w_hat + sqT * kt[j];
+      T sT = sqT;
+      bool edge = false;
+      if (GB == 3) {                 // sqrt(Tau_j) of this pixel's class
+        const idx_t row = row0 + j;
+        const int cnt = 4 - (c == 0 ? 1 : 0) - (c == nx - 1 ? 1 : 0) - (row == 0 ? 1 : 0) - (row == ny - 1 ? 1 : 0);
+        edge = cnt != 4;
+        if (edge) sT = t_sqrt(cnt == 3 ? a.Tcls[1] : a.Tcls[0]);
+      }
+      const T w_hat = edge ? (xo[j] - xn[j]) / (p2.tau * sT) - sT * kt_prev[j] : div_tauT.div(xo[j] - xn[j]) - sqT * kt_prev[j];
+      const T diff = w_hat + sT * kt[j];
       dd += (double)(diff * diff); dv += (double)(w_hat * w_hat);
     }
     if (owner) { accumulate(2, dd); accumulate(3, dv); }
@@ -267,7 +308,7 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
         T kt_0[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; j++) kt_0[j] = s_kt[RES ? (k3 + 1) % 3 : 0][RES ? ch : 0][RES ? j * kWave + lane : 0];     // written two steps ago
-        dual_residual(x1_0, x2_0, kt_0, kt_c);
+        dual_residual(c, x1_0, x2_0, kt_0, kt_c);
       }
     }
     if (runD) dual_args(cd, x2_m, x2_0, x1_m, x1_0, ya_m, yb_m, p2, avD, s_sq[buf][1]);            // stage D, first half
@@ -321,7 +362,8 @@ static int mc_x2_vec(int dtype, size_t ny) { const int full = dtype == 0 ? 4 : 2
 static size_t mc_x2_rows(int dtype, size_t ny) { const int v = mc_x2_vec(dtype, ny); return v >= 2 ? (size_t)(kWave - 2) * v : (size_t)(kWave - 4); }
 
 static bool iter_mc_x2_ok(const prost_hip_fused_desc* d, int dtype) {
-  if ((dtype != 0 && dtype != 1) || !d || d->is3d || d->var_T || d->f_moreau || d->L < 2 || d->L > 4) return false;
+  if ((dtype != 0 && dtype != 1) || !d || d->is3d || d->f_moreau || d->L < 2 || d->L > 4) return false;
+  if (d->var_T && (d->g_fn != PROST_FN_SQUARE || !d->g_coeff_ptr[1] || d->g_b_masked)) return false;   // position-dependent Tau: square data term with per-pixel b
   if (d->nx < 4 || d->ny < 4) return false;
   if ((d->g_fn != PROST_FN_SQUARE && d->g_fn != PROST_FN_ABS) || d->f_fn != PROST_FN_IND_LEQ0) return false;
   for (int k = 0; k < 7; k++) {
@@ -383,6 +425,7 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
     const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma[i] * a.Sval);
     if (!ug.a_one || !ug.den_one || ug.degenerate || !uf.a_one || !uf.den_one) { set_error("fused multi-channel double iteration: not the straight-line ROF / TV-L1 shape"); return 1; }
     p[i].sq = ug.sq; p[i].step = ug.step;
+    for (int k = 0; k < 2; k++) p[i].ec[k] = a.varT ? make_edge_terms<T>(a.g_val, (T)tau[i] * a.Tcls[k]) : EdgeTerms<T>();
   }
   const size_t rows = mc_x2_rows(kDtype, d->ny);
   const size_t strips = (d->ny + rows - 1) / rows;
@@ -399,7 +442,8 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
 #define GO3(G, B, LWv) do { if (out4) GO4(G, B, LWv, true); else GO4(G, B, LWv, false); } while (0)
 #define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)
 #define GO(B) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B); else GO2(PROST_FN_SQUARE, B); } while (0)
-  if (d->g_coeff_ptr[1] && d->g_b_masked) GO2(PROST_FN_SQUARE, 2);       // inpainting: binary mask folded into b (square data term)
+  if (a.varT) GO2(PROST_FN_SQUARE, 3);                                    // the gradient handed over as a sparse matrix (iter_mc_x2_ok: square, per-pixel b)
+  else if (d->g_coeff_ptr[1] && d->g_b_masked) GO2(PROST_FN_SQUARE, 2);  // inpainting: binary mask folded into b (square data term)
   else if (d->g_coeff_ptr[1]) GO(1); else GO(0);
 #undef GO
 #undef GO2

@@ -1378,8 +1378,8 @@ def test_gradient_handed_over_as_a_sparse_matrix_runs_the_fused_kernels(precisio
 @pytest.mark.parametrize("L", [2, 3, 4])
 def test_colour_gradient_handed_over_as_a_sparse_matrix_runs_the_fused_kernels(precision, dtype, L):
     """spmat_gradient2d(nx, ny, nc) with nc = 2, 3, 4 channels (the examples read RGB images: example_rof_primal.m:3-10): the one-kernel
-    iterations (channels in one lane for 2, on the wavefronts of a workgroup for 3 / 4) with the position-dependent Tau of the matrix;
-    iterates == the oracle running block.sparse, bit for bit, residual iterations included"""
+    iterations (channels in one lane for 2, on the wavefronts of a workgroup for 3 / 4) and the multi-channel double-iteration kernel
+    with the position-dependent Tau of the matrix; iterates == the oracle running block.sparse, bit for bit, residual iterations included"""
     prost.set_precision(precision)
     for (nx, ny), res_iter, step in (((24, 64), 3, "alg2"), ((17, 30), 1, "boyd"), ((12, 260), 10, "goldstein")):
         f = synthetic.rof_image(nx, ny, L, seed=6)
@@ -1394,6 +1394,8 @@ def test_colour_gradient_handed_over_as_a_sparse_matrix_runs_the_fused_kernels(p
             assert st["tau"] == ost["tau"] and st["sigma"] == ost["sigma"]
             for name in ("primal_res", "dual_res", "eps_primal", "eps_dual"):
                 assert np.isclose(st[name], ost[name], rtol=1e-5, atol=1e-6), (name, st[name], ost[name])
+        if res_iter >= 3:
+            assert st["pair_launches"] > 0, (L, step, st["pair_launches"])     # two iterations per launch: the multi-channel pair kernel's instance for these matrices
 
 
 def _rof_primal_as_the_example_writes_it(nx, ny, L, f, lmb, as_block=False, split=(100, 500)):
