@@ -131,6 +131,11 @@ int prost_hip_csr_spmv_f64(double* res, const double* rhs, size_t nrows, size_t 
  * average.  2 bytes per row instead of 8 per entry + 4 per row.  acc = 1 accumulates (block_sparse.cu:156-168), 0 writes. */
 int prost_hip_pattern_spmv_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int acc, void* stream);
 int prost_hip_pattern_spmv_f64(double* res, const double* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int acc, void* stream);
+/* (ABI 6) the same with the table's sizes (npatterns + 1 offsets in pptr, nentries entries): a table of <= 256 patterns and <= 1024
+ * entries is staged in LDS by every workgroup -- two dependent memory round trips less per wavefront, which is what small products
+ * (<= 2^22 rows) consist of; same arithmetic, same bits */
+int prost_hip_pattern_spmv_tab_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int npatterns, int nentries, int acc, void* stream);
+int prost_hip_pattern_spmv_tab_f64(double* res, const double* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int npatterns, int nentries, int acc, void* stream);
 /* res += kron(K, I_d) rhs (BlockSparseKronIdKernel, src/linop/block_sparse_kron_id.cu:26-49) and
  * res += kron(I_d, K) rhs (BlockIdKronSparseKernel, src/linop/block_id_kron_sparse.cu:26-52); K (nrows x ncols)
  * in CSR with int32 indices and FLOAT values for both T (:36, :79).  The adjoint is the same call

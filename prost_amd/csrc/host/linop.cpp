@@ -235,25 +235,25 @@ size_t BlockSparse<T>::gpu_mem_amount() const {
 template <typename T>
 void BlockSparse<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) {
   if (!pat_.on && val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), 1, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), (int)pat_.pptr.size() - 1, (int)pat_.rel.size(), 1, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
   if (!pat_t_.on && val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), 1, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), (int)pat_t_.pptr.size() - 1, (int)pat_t_.rel.size(), 1, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalLocal(T* r, T*, const T* x, const T*) {
   if (!pat_.on && val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), 0, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), (int)pat_.pptr.size() - 1, (int)pat_.rel.size(), 0, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) {
   if (!pat_t_.on && val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), 0, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), (int)pat_t_.pptr.size() - 1, (int)pat_t_.rel.size(), 0, CurrentStream()), "pattern_spmv"); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv");
 }
 template class BlockSparse<float>;

@@ -388,9 +388,32 @@ template <class T> struct Quad;
 template <> struct Quad<float> { typedef float V __attribute__((ext_vector_type(4), aligned(4))); };
 template <> struct Quad<double> { typedef double V __attribute__((ext_vector_type(4), aligned(8))); };
 
-template <class T, bool ACC>
+// TAB: the pattern table (at most kTabPatterns patterns, kTabEntries entries) is staged in LDS by the workgroup while the pattern
+// numbers of its rows are on their way, and read from there: the chain of dependent memory round trips of a wavefront is numbers ->
+// operands -> store instead of numbers -> table offsets -> table entries -> operands -> store.  That chain IS the run time of the
+// small products of the generic path (256^2 .. 1024^2: one or two waves per SIMD, ~10 us per launch of which ~4.5 us are the launch
+// itself); the arithmetic and its order are unchanged.
+constexpr int kTabPatterns = 256, kTabEntries = 1024;
+__device__ __forceinline__ float uniform_value(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_value(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)b), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <class T, bool ACC, bool TAB>
 __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nrows, const uint16_t* __restrict__ ids,
-                                                              const int32_t* __restrict__ pptr, const int32_t* __restrict__ rel, const T* __restrict__ pval) {
+                                                              const int32_t* __restrict__ pptr_g, const int32_t* __restrict__ rel_g, const T* __restrict__ pval_g,
+                                                              int npatterns, int nentries) {
+  __shared__ int32_t s_pptr[TAB ? kTabPatterns + 1 : 1];
+  __shared__ int32_t s_rel[TAB ? kTabEntries : 1];
+  __shared__ T s_val[TAB ? kTabEntries : 1];
+  if (TAB) {
+    for (int i = threadIdx.x; i <= npatterns; i += kBlock) s_pptr[TAB ? i : 0] = pptr_g[i];
+    for (int i = threadIdx.x; i < nentries; i += kBlock) { s_rel[TAB ? i : 0] = rel_g[i]; s_val[TAB ? i : 0] = pval_g[i]; }
+  }
+  const int32_t* pptr = TAB ? s_pptr : pptr_g;
+  const int32_t* rel = TAB ? s_rel : rel_g;
+  const T* pval = TAB ? s_val : pval_g;
   // A lane takes 4 consecutive rows, a wavefront G groups of 256 rows.  Nearly always all of them have ONE pattern: its table
   // entries are then wave-uniform (scalar loads) and an entry costs one 16 / 32-byte load of rhs per lane and group.  Mixed
   // wavefronts (the seams of the stencil, the last rows) walk the table per row.
@@ -399,9 +422,8 @@ __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ re
   const int lane = threadIdx.x & (kWave - 1);
   const size_t wave = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kWave, nwaves = (size_t)gridDim.x * kBlock / kWave;
   constexpr size_t kRowsPerWave = (size_t)kWave * R * G;
-  for (size_t base = wave * kRowsPerWave; base < nrows; base += nwaves * kRowsPerWave) {
-    unsigned id[G][R];
-    bool same = true;
+  unsigned id[G][R];
+  auto load_ids = [&](size_t base) {
 #pragma unroll
     for (int g = 0; g < G; g++) {
       const size_t row0 = base + ((size_t)g * kWave + lane) * R;
@@ -413,6 +435,12 @@ __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ re
         for (int j = 0; j < R; j++) id[g][j] = row0 + j < nrows ? (unsigned)ids[row0 + j] : 0xFFFFFFFFu;   // past the end: no pattern, no uniform wavefront
       }
     }
+  };
+  size_t base = wave * kRowsPerWave;
+  if (base < nrows) load_ids(base);                     // requested before the table is waited for
+  if (TAB) __syncthreads();                             // the table is in LDS (every wavefront of the workgroup arrives here)
+  while (base < nrows) {
+    bool same = true;
     const unsigned id0 = (unsigned)__builtin_amdgcn_readfirstlane((int)id[0][0]);
 #pragma unroll
     for (int g = 0; g < G; g++)
@@ -424,10 +452,11 @@ __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ re
 #pragma unroll
       for (int j = 0; j < R; j++) out[g][j] = 0;
     if (__builtin_amdgcn_ballot_w64(!same) == 0) {
-      const int32_t b = pptr[id0], e = pptr[id0 + 1];
+      // (wave-uniform table entries: scalar loads from global memory, broadcast reads + readfirstlane from LDS)
+      const int32_t b = TAB ? __builtin_amdgcn_readfirstlane(pptr[id0]) : pptr[id0], e = TAB ? __builtin_amdgcn_readfirstlane(pptr[id0 + 1]) : pptr[id0 + 1];
       for (int32_t k = b; k < e; k++) {
-        const long r = (long)rel[k];
-        const T v = pval[k];
+        const long r = (long)(TAB ? __builtin_amdgcn_readfirstlane(rel[k]) : rel[k]);
+        const T v = TAB ? uniform_value(pval[k]) : pval[k];
 #pragma unroll
         for (int g = 0; g < G; g++) {
           const QV x = *reinterpret_cast<const QV*>(rhs + (long)(base + ((size_t)g * kWave + lane) * R) + r);
@@ -462,17 +491,27 @@ __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ re
         for (int j = 0; j < R; j++) if (row0 + j < nrows) res[row0 + j] = (ACC ? res[row0 + j] : (T)0) + out[g][j];
       }
     }
+    base += nwaves * kRowsPerWave;
+    if (base < nrows) load_ids(base);
   }
 }
 template <class T>
-static int launch_pattern(T* res, const T* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const T* pval, int acc, void* stream) {
+static int launch_pattern(T* res, const T* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const T* pval, int acc, void* stream,
+                          int npatterns = 0, int nentries = 0) {
   if (nrows == 0) return 0;
   if (!res || !rhs || !ids || !pptr || !rel || !pval) { set_error("pattern spmv: null pointer"); return 1; }
   if (reinterpret_cast<uintptr_t>(ids) % 8 != 0) { set_error("pattern spmv: the pattern numbers must be 8-byte aligned"); return 1; }
   hipStream_t s = as_stream(stream);
   const unsigned grid = grid_for((nrows + 7) / 8);
-  if (acc) hipLaunchKernelGGL((pattern_spmv_kernel<T, true>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
-  else hipLaunchKernelGGL((pattern_spmv_kernel<T, false>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
+  // the table staged in LDS where its size is known and fits (prost_hip_pattern_spmv_tab) and the product is small enough for the
+  // dependent round trips to matter (beyond ~2^22 rows it streams at the memory rate either way)
+  const bool tab = npatterns > 0 && npatterns <= kTabPatterns && nentries > 0 && nentries <= kTabEntries && nrows <= ((size_t)1 << 22);
+  if (tab) {
+    if (acc) hipLaunchKernelGGL((pattern_spmv_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, npatterns, nentries);
+    else hipLaunchKernelGGL((pattern_spmv_kernel<T, false, true>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, npatterns, nentries);
+  }
+  else if (acc) hipLaunchKernelGGL((pattern_spmv_kernel<T, true, false>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, 0, 0);
+  else hipLaunchKernelGGL((pattern_spmv_kernel<T, false, false>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, 0, 0);
   PH_LAUNCH_END("pattern spmv kernel");
 }
 
@@ -581,6 +620,8 @@ int prost_hip_csr_spmv_f32(float* r, const float* x, size_t nrows, size_t nnz, c
 int prost_hip_csr_spmv_f64(double* r, const double* x, size_t nrows, size_t nnz, const double* v, const int32_t* p, const int32_t* i, void* s) { return launch_csr<double, false>(r, x, nrows, nnz, v, p, i, s); }
 int prost_hip_pattern_spmv_f32(float* r, const float* x, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int acc, void* s) { return launch_pattern<float>(r, x, nrows, ids, pptr, rel, pval, acc, s); }
 int prost_hip_pattern_spmv_f64(double* r, const double* x, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int acc, void* s) { return launch_pattern<double>(r, x, nrows, ids, pptr, rel, pval, acc, s); }
+int prost_hip_pattern_spmv_tab_f32(float* r, const float* x, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int npatterns, int nentries, int acc, void* s) { return launch_pattern<float>(r, x, nrows, ids, pptr, rel, pval, acc, s, npatterns, nentries); }
+int prost_hip_pattern_spmv_tab_f64(double* r, const double* x, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int npatterns, int nentries, int acc, void* s) { return launch_pattern<double>(r, x, nrows, ids, pptr, rel, pval, acc, s, npatterns, nentries); }
 
 int prost_hip_sparse_kron_id_acc_f32(float* r, const float* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(false, r, x, d, nrows, 0, v, p, i, s); }
 int prost_hip_sparse_kron_id_acc_f64(double* r, const double* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(false, r, x, d, nrows, 0, v, p, i, s); }
