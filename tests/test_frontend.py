@@ -167,3 +167,23 @@ def test_host_transport_callback_failures_surface_in_the_next_command():
         prost.get_precision() if hasattr(prost, "get_precision") else _capi.command("get_precision", (), 1)
     assert not _capi._callback_error
     _capi.command("get_precision", (), 1)       # raised once
+
+
+def test_example_rof_primal_description_matches_the_matlab_script():
+    """examples/rof_primal_sub_variables.py builds what example_rof_primal.m:15-36 builds: a min_problem whose primal variable carries
+    three sum_1d pieces on consecutive sub-variables (100, 500, the rest; slices of f as coefficient b), the norm2 'abs' regulariser on
+    the constrained variable, one sparse block, boyd / residual_iter = 1 (no GPU needed for the description)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import rof_primal_sub_variables as ex
+    nx, ny, nc = 40, 30, 3
+    prob, backend, u, f, grad, lmb = ex.describe(nx, ny, nc)
+    prob.finalize()
+    n = nx * ny * nc
+    assert prob.ncols == n and prob.nrows == 2 * n
+    pieces = prob.data["prox_g"]
+    assert len(pieces) == 3 and not prob.data["prox_fstar"] and len(prob.data["prox_f"]) == 1
+    assert [(p[1], p[2]) for p in pieces] == [(0, 100), (100, 500), (600, n - 600)]
+    assert [b[0] for b in prob.data["linop"]] == ["sparse"] and grad.shape == (2 * n, n)
+    assert backend[0] == "pdhg" and backend[1]["stepsize"] == "boyd" and backend[1]["residual_iter"] == 1
+
