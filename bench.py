@@ -81,20 +81,42 @@ def traffic_bytes(kernel, size, chunk_cols, dtype="f32"):
     return None, None
 
 
+def kernel_kind(kname):
+    """-> (family, suffix) of a name KernelTimes emits (backend_pdhg.cpp, KernelTimes): family in {"primal", "dual", "iter", "iter_x2"},
+    suffix in {"", "+mid", "+residuals", "+mid+residuals"}.  The family is read from the kernel's own name token
+    (fused_<family><2d|3d>[_mc][_x2]_kernel), never from a substring of the whole name: "resi-dual-s" is not a dual pass."""
+    base, plus, tail = kname.partition("+")
+    suffix = plus + tail
+    if suffix not in ("", "+mid", "+residuals", "+mid+residuals"):
+        return None, None
+    if not (base.startswith("fused_") and base.endswith("_kernel")):
+        return None, None
+    core = base[len("fused_"):-len("_kernel")]              # primal2d, dual3d, iter2d, iter2d_mc, iter2d_x2, iter2d_mc_x2, iter3d_x2 ...
+    if core in ("primal2d", "primal3d"):
+        return ("primal", suffix) if suffix == "" else (None, None)
+    if core in ("dual2d", "dual3d"):
+        return ("dual", suffix) if suffix == "" else (None, None)
+    if core in ("iter2d", "iter3d", "iter2d_mc"):
+        return ("iter", suffix) if suffix in ("", "+residuals") else (None, None)
+    if core in ("iter2d_x2", "iter3d_x2", "iter2d_mc_x2"):
+        return "iter_x2", suffix
+    return None, None
+
+
 def compulsory_floats(kname, volume):
     """values per pixel / voxel a launch of `kname` (as KernelTimes names it) has to move through HBM once: operands read
-    + results written ("algorithmic bytes / unit" column)"""
+    + results written ("algorithmic bytes / unit" column).  None for a name this table does not know."""
     g = 3 if volume else 2                                   # gradient components = dual values per pixel
     pair = 2 + 2 * g + 1                                     # read x, f, y ; write x, y : 7 / 9
-    table = {"x2_kernel": pair, "x2_kernel+residuals": pair, "x2_kernel+mid": pair + 1 + g, "x2_kernel+mid+residuals": pair + 1 + g,
-             "kernel": pair, "kernel+residuals": pair + g + (1 if volume else 0)}        # residual single launch: + y_prev (+ x_prev in 3-D)
-    if "primal" in kname:
+    family, suffix = kernel_kind(kname)
+    if family == "primal":
         return 3 + g                                         # read x, y, f ; write x : 5 / 6
-    if "dual" in kname:
+    if family == "dual":
         return 2 + 2 * g                                     # read y, x_new, x_old ; write y : 6 / 8
-    for suffix, v in sorted(table.items(), key=lambda kv: -len(kv[0])):
-        if kname.endswith(suffix):
-            return v
+    if family == "iter":                                     # residual single launch: + y_prev (+ x_prev in 3-D): 9 / 13
+        return pair if suffix == "" else pair + g + (1 if volume else 0)
+    if family == "iter_x2":                                  # +mid: the iterate in between is stored as well (x, y): 10 / 13
+        return pair + (1 + g if "+mid" in suffix else 0)
     return None
 
 
@@ -186,23 +208,23 @@ def cpu_baseline_c3(volume, max_threads, np_dtype=None):
     prob.finalize()
     backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA, scale_steps_operator=False)
     opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
-    threads = min(16, max_threads)
-    oracle.set_num_threads(threads)
+    oracle.set_num_threads(min(64, max_threads))
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np_dtype or np.float32)
     s.initialize()
-    s.iterate(2)
+    threads, rates = cpu_probe_threads(s, max_threads)
     iters, t0 = 0, time.time()
     while True:
         s.iterate(5)
         iters += 5
         el = time.time() - t0
-        if el > 10.0 or iters >= 400:
+        if el > 8.0 or iters >= 2000:
             break
+    oracle.bind_threads(False)
     rate = iters / el
     return {"value": rate * cx * cy * L / (nx * ny * L), "unit": "it/s", "cores": threads, "kind": "port",
-            "voxel_iterations_per_s": rate * cx * cy * L, "crop_it_per_s": rate,
-            "sample": "%d PDHG iterations of a %dx%dx%d crop of the volume (same generator, same options), oracle/prost_oracle.cpp with %d OpenMP "
-                      "threads; value = the crop's voxel-iteration rate divided by the %dx%dx%d voxels of the full volume" % (iters, cx, cy, L, threads, nx, ny, L)}
+            "voxel_iterations_per_s": rate * cx * cy * L, "crop_it_per_s": rate, "threads_probed": {str(k): v for k, v in sorted(rates.items())},
+            "sample": "%d PDHG iterations of a %dx%dx%d crop of the volume (same generator, same options), oracle/prost_oracle.cpp with %d pinned OpenMP "
+                      "threads (best of a probe up to all logical CPUs, vectors first-touched per thread); value = the crop's voxel-iteration rate divided by the %dx%dx%d voxels of the full volume" % (iters, cx, cy, L, threads, nx, ny, L)}
 
 
 def cpu_baseline_c4(size, backend, max_threads, np_dtype=None):
@@ -215,28 +237,58 @@ def cpu_baseline_c4(size, backend, max_threads, np_dtype=None):
     prob = c4_problem(size)
     prob.finalize()
     opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
-    threads = min(16, max_threads)
-    oracle.set_num_threads(threads)
+    oracle.set_num_threads(min(64, max_threads))
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np_dtype or np.float32)
     s.initialize()
-    s.iterate(1)
+    threads, rates = cpu_probe_threads(s, max_threads, iters=1)
     iters, t0 = 0, time.time()
     while True:
         s.iterate(2)
         iters += 2
         el = time.time() - t0
-        if el > 10.0 or iters >= 200:
+        if el > 8.0 or iters >= 400:
             break
-    return {"value": iters / el, "unit": "it/s", "cores": threads, "kind": "port",
-            "sample": "%d ADMM iterations (10 CG iterations each) of the same %dx%d fp32 problem, oracle/prost_oracle.cpp with %d OpenMP threads"
-                      % (iters, size, size, threads)}
+    oracle.bind_threads(False)
+    return {"value": iters / el, "unit": "it/s", "cores": threads, "kind": "port", "threads_probed": {str(k): v for k, v in sorted(rates.items())},
+            "sample": "%d ADMM iterations (10 CG iterations each) of the same %dx%d fp32 problem, oracle/prost_oracle.cpp with %d pinned OpenMP threads (best of a probe up to all "
+                      "logical CPUs, vectors first-touched per thread)" % (iters, size, size, threads)}
+
+
+def cpu_thread_candidates(max_threads):
+    """thread counts the CPU baselines probe: powers of two from 8 up to the logical CPUs of the host, and the host's count itself"""
+    c = [t for t in (8, 16, 32, 64, 128, 256, 512) if t <= max_threads]
+    if max_threads not in c:
+        c.append(max_threads)
+    return c or [1]
+
+
+def cpu_probe_threads(s, max_threads, iters=2):
+    """best thread count for the oracle solver `s`: for every candidate the team is pinned (one thread per physical core first,
+    topology order: oracle.bind_threads) and every large vector is first-touched again by the thread that streams it
+    (Solver.rehome -- round 4 left all pages on the node of the thread that allocated them, which is what capped the port at
+    ~30 it/s on a two-socket host).  -> (threads, {threads: it/s}); the solver is left re-homed and bound for the best count."""
+    import oracle
+    rates = {}
+    for t in cpu_thread_candidates(max_threads):
+        oracle.set_num_threads(t)
+        oracle.bind_threads(True)
+        s.rehome()
+        s.iterate(1)
+        t0 = time.time()
+        s.iterate(iters)
+        rates[t] = iters / (time.time() - t0)
+        oracle.bind_threads(False)
+    best = max(rates, key=rates.get)
+    oracle.set_num_threads(best)
+    oracle.bind_threads(True)
+    s.rehome()
+    return best, rates
 
 
 def cpu_baseline(n_img, max_threads, np_dtype=None):
     """Oracle (CPU restatement of the reference path, OpenMP) on a bounded sample: the same 4096^2
     ROF problem, a handful of iterations (about 10-30 s of CPU work).  The thread count is the best
-    of a short probe over {8, 16, 32, 64} <= cores: the path is memory-bound and over-subscribing
-    the two sockets is slower than 16-32 threads (measured 256 threads: 1.3 it/s, 16 threads: 32 it/s)."""
+    of a probe over 8 ... all logical CPUs, threads pinned and the state first-touched per thread (cpu_probe_threads)."""
     import numpy as np
 
     import oracle
@@ -249,35 +301,41 @@ def cpu_baseline(n_img, max_threads, np_dtype=None):
     backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * LAMBDA)
     opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0,
                          tol_abs_primal=0, tol_abs_dual=0)
+    oracle.set_num_threads(min(max_threads, 64))          # setup (normest's power iteration) on many cores
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np_dtype)
     s.initialize()
-    best, best_rate = 1, 0.0
-    for t in [c for c in (8, 16, 32, 64) if c <= max_threads] or [1]:
-        oracle.set_num_threads(t)
-        s.iterate(1)
-        t0 = time.time()
-        s.iterate(2)
-        rate = 2 / (time.time() - t0)
-        if rate > best_rate:
-            best, best_rate = t, rate
-    oracle.set_num_threads(best)
+    best, rates = cpu_probe_threads(s, max_threads)
     iters, t0 = 0, time.time()
     while True:
         s.iterate(10)
         iters += 10
         el = time.time() - t0
-        if el > 10.0 or iters >= 400:
+        if el > 8.0 or iters >= 2000:
             break
-    # the same port on ONE thread (SURVEY 8d asks for both): a few iterations are enough at ~1 it/s
+    oracle.bind_threads(False)
+    # the same port on ONE thread (SURVEY 8d asks for both): a few iterations are enough at ~3 it/s
     oracle.set_num_threads(1)
     t1 = time.time()
     s.iterate(3)
     single = 3 / (time.time() - t1)
     out = {"value": iters / el, "unit": "it/s", "cores": best, "kind": "port", "single_thread_value": single,
-           "sample": "%d PDHG iterations of the same %dx%d %s ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads "
-                     "(best of a probe over 8/16/32/64 threads on %d logical cores)" % (iters, n_img, n_img, fp, best, max_threads)}
+           "threads_probed": {str(k): v for k, v in sorted(rates.items())}, "logical_cpus": max_threads,
+           "sample": "%d PDHG iterations of the same %dx%d %s ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads pinned one per "
+                     "core in topology order, every vector first-touched by the thread that streams it (best of a probe over %s threads on %d "
+                     "logical CPUs)" % (iters, n_img, n_img, fp, best, "/".join(str(t) for t in sorted(rates)), max_threads)}
     del s
-    out["reference_build"] = reference_build_rate(backend, opts) if np_dtype == np.float32 else None
+    rb = reference_build_rate(backend, opts) if np_dtype == np.float32 else None
+    out["reference_build"] = rb
+    if rb and "value" in rb:
+        # the REAL reference's CPU path is single-threaded (thrust host backend); its rate at the bench size, assuming it scales with the
+        # pixel count as the port does between the two sizes, and how the port compares with it on one thread at the size both ran
+        scale = (rb["size"] / float(n_img)) ** 2
+        out["reference_build_scaled_to_bench_size"] = rb["value"] * scale
+        out["port_over_reference_one_thread"] = rb["port_one_thread_same_size"] / rb["value"]
+        out["note"] = ("one thread, %dx%d: the port runs %.2f x the rate of the reference's own CPU build (the reference instantiates its kernel per "
+                       "function and is compiled by clang; the port is g++ -O2 with the same expressions); the reference build scaled by pixel "
+                       "count to %dx%d: %.2f it/s on one thread (it has no multi-threaded CPU path)"
+                       % (rb["size"], rb["size"], out["port_over_reference_one_thread"], n_img, n_img, out["reference_build_scaled_to_bench_size"]))
     return out
 
 
@@ -310,7 +368,7 @@ def reference_build_rate(backend, opts, n_ref=1024):
         t0 = time.time()
         s.iterate(20)
         rate_port = 20.0 / (time.time() - t0)
-        return {"value": rate_ref, "unit": "it/s", "cores": 1, "kind": "reference", "port_one_thread_same_size": rate_port,
+        return {"value": rate_ref, "unit": "it/s", "cores": 1, "kind": "reference", "port_one_thread_same_size": rate_port, "size": n_ref,
                 "sample": "20 PDHG iterations of the fp32 ROF problem at %dx%d (difference of a 22- and a 2-iteration run: setup removed), "
                           "oracle/_ref/libprost_ref.so = the reference's own backend_pdhg.cu / problem.cu / prox functors, thrust host backend"
                           % (n_ref, n_ref)}
@@ -599,9 +657,9 @@ def main():
                 if ipl:
                     floats = afu * ipl
                 elif args.config == "c3":
-                    floats = 8 if "dual" in kname else 6
+                    floats = 8 if kernel_kind(kname)[0] == "dual" else 6
                 else:
-                    floats = DUAL_PASS_FLOATS if "dual" in kname else ALG_FLOATS_PER_PIXEL - DUAL_PASS_FLOATS
+                    floats = DUAL_PASS_FLOATS if kernel_kind(kname)[0] == "dual" else ALG_FLOATS_PER_PIXEL - DUAL_PASS_FLOATS
                 alg_bytes = floats * itemsize * units
                 note = ("frac = COMPULSORY bytes of the kernel that ran (%s values per %s per launch: every operand read once, every result written once; "
                         "one launch = %s iteration(s), the iterate in between never leaves the registers) / launch time / peak: <= 1 by construction.  "

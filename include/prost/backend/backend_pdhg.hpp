@@ -131,9 +131,11 @@ class BackendPDHG : public Backend<T> {
   void* rule_rec_ = nullptr;               // device: PdhgRecord<T>
   prost_hip_pdhg_rule_state* rule_mirror_ = nullptr;   // pinned host: the scalars of the last evaluation, fetched at the end of a batch ...
   prost_hip_pdhg_rule_state* rule_mirror_dev_ = nullptr;   // ... from the device copy the rule kernels write
-  struct BatchMark { size_t iteration_after, pair_launches; T *x, *xp, *y, *yp; bool prev_stale; T *kx, *kxp, *kty, *ktyp; };   // (kx .. ktyp: generic path)
+  struct BatchMark { size_t iteration_after, pair_launches; T *x, *xp, *y, *yp; bool prev_stale; T *kx, *kxp, *kty, *ktyp;   // (kx .. ktyp: generic path)
+                     size_t samples = 0, ev_used = 0, launches[8] = {0}; };            // kernel timing as it stood after this launch (kKernelKinds == 8)
   std::vector<BatchMark> batch_marks_;     // one per residual iteration of the running batch: the state to return to if it stopped there
   int PerformIterationsDevice(int budget);
+  bool failed_ = false;                    // a device-resident batch threw half-way: the iterate on the device is undefined from then on
   void RestoreRoles(const BatchMark& m);
 
   Options opts_;

@@ -33,6 +33,11 @@ struct ElemOperation {
   /// res[i] unwritten on purpose (so that the old content survives) shadows this with `true` and runs on the
   /// one-group-per-lane path over HBM, whose stores are exactly the operation's own.
   static const bool kPartialResult = false;
+  /// MI355X addition, the opt-in counterpart.  By default the register-tile path first loads the old content of `res` into
+  /// the tile, so an operation ported from the reference that skips some res[i] without saying so still behaves as it
+  /// does there (the reference's kernel writes through views over global memory: what is not written stays).  An
+  /// operation that assigns EVERY component of `res` on every path shadows this with `true` and saves that read.
+  static const bool kWritesAllComponents = false;
 };
 
 }  // namespace prost

@@ -33,6 +33,7 @@ __host__ __device__ __forceinline__ T ScaledProx(T v, T tau, const T* c) {
 
 template <typename T, class FUN_1D>
 struct ElemOperation1D : public ElemOperation<1, 7> {
+  static const bool kWritesAllComponents = true;      // every res[i] is assigned on every path: the tile path need not preload res
   __host__ __device__ ElemOperation1D(T* coeffs, size_t /*dim*/, SharedMem<SharedMemType, GetSharedMemCount>& /*shared_mem*/) : coeffs_(coeffs) {}
 
   __host__ __device__ __forceinline__ void operator()(Vector<T>& res, const Vector<const T>& arg, const Vector<const T>& tau_diag, T tau_scal,

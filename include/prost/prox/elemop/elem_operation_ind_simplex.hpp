@@ -13,6 +13,7 @@ namespace prost {
 
 template <typename T>
 struct ElemOperationIndSimplex : public ElemOperation<0, 0, T> {
+  static const bool kWritesAllComponents = true;      // every res[i] is assigned on every path: the tile path need not preload res
   struct GetSharedMemCount {
     __host__ __device__ size_t operator()(size_t dim) { return dim; }
   };

@@ -11,6 +11,7 @@ namespace prost {
 
 template <typename T>
 struct ElemOperationIndSum : public ElemOperation<0, 0, T> {
+  static const bool kWritesAllComponents = true;      // every res[i] is assigned on every path: the tile path need not preload res
   __host__ __device__ ElemOperationIndSum(size_t dim, SharedMem<typename ElemOperationIndSum::SharedMemType, typename ElemOperationIndSum::GetSharedMemCount>& /*shared_mem*/)
       : dim_(dim) {}
 

@@ -13,6 +13,7 @@ namespace prost {
 
 template <typename T, class FUN_1D>
 struct ElemOperationNorm2 : public ElemOperation<0, 7> {
+  static const bool kWritesAllComponents = true;      // every res[i] is assigned on every path: the tile path need not preload res
   __host__ __device__ ElemOperationNorm2(T* coeffs, size_t dim, SharedMem<SharedMemType, GetSharedMemCount>& /*shared_mem*/)
       : coeffs_(coeffs), dim_(dim) {}
 

@@ -96,6 +96,16 @@ __global__ void __launch_bounds__(kLanes) ProxElemOperationTileKernel(T* d_res, 
       LoadPack<T, VEC>(d_tau + e0 + count * i, t + i * VEC);
     }
   }
+  if constexpr (!OP::kWritesAllComponents) {
+    // safe default: components the operation does not assign keep their old content, as with the reference's views over global memory
+    if (INTERLEAVED) {
+#pragma unroll
+      for (int k = 0; k < DIM; k++) LoadPack<T, VEC>(d_res + e0 * DIM + k * VEC, r + k * VEC);
+    } else {
+#pragma unroll
+      for (int i = 0; i < DIM; i++) LoadPack<T, VEC>(d_res + e0 + count * i, r + i * VEC);
+    }
+  }
   T cv[NC][VEC];
   if constexpr (OP::kCoeffsCount != 0) {
 #pragma unroll

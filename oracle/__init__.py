@@ -80,6 +80,8 @@ def lib():
         L.orc_linspace.argtypes = [dbl, dbl, i32, vp]
         L.orc_set_num_threads.argtypes = [i32]
         L.orc_set_num_threads.restype = None
+        L.orc_bind_threads.argtypes = [i32]
+        L.orc_bind_threads.restype = i32
         L.orc_problem_create.argtypes = [i32, sz, sz]
         L.orc_problem_create.restype = vp
         L.orc_problem_destroy.argtypes = [vp]
@@ -137,6 +139,7 @@ def lib():
         L.orc_solver_set_allreduce.argtypes = [vp, ALLREDUCE_CB, vp, sz, sz]
         L.orc_solver_initialize.argtypes = [vp]
         L.orc_solver_iterate.argtypes = [vp, i32]
+        L.orc_solver_rehome.argtypes = [vp]
         L.orc_solver_solve.argtypes = [vp, vp, vp]
         L.orc_solver_get.argtypes = [vp, vp, vp, vp, vp]
         L.orc_solver_scalars.argtypes = [vp, vp]
@@ -168,6 +171,12 @@ def _p(a):
 
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
+
+
+def bind_threads(on=True):
+    """timing runs: pin the OpenMP threads of the current team width to one CPU each (physical cores first, topology order);
+    on=False restores the process mask.  Solvers initialised AFTER set_num_threads(n > 1) first-touch their vectors per thread."""
+    return int(lib().orc_bind_threads(1 if on else 0))
 
 
 # ------------------------------------------------------------------------------------------
@@ -520,6 +529,10 @@ class Solver:
 
     def iterate(self, iters=1):
         _chk(lib().orc_solver_iterate(self.h, iters))
+
+    def rehome(self):
+        """timing runs: first-touch every large vector again, each range by the thread that streams it (set_num_threads / bind_threads first)"""
+        _chk(lib().orc_solver_rehome(self.h))
 
     def solve(self):
         r, k = C.c_int(), C.c_int()

@@ -25,10 +25,15 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #ifdef _OPENMP
 #include <omp.h>
+#endif
+#ifdef __linux__
+#include <sched.h>
+#include <fstream>
 #endif
 
 namespace {
@@ -44,6 +49,84 @@ struct OrcError : std::runtime_error { using std::runtime_error::runtime_error; 
 #define PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(g_threads) if(g_threads > 1)")
 
 typedef long long ssz;
+
+// ---------------------------------------------------------------------------------
+// Multi-threaded TIMING runs only (bench.py's cpu_baseline; results do not depend on it):
+// where the pages of the big vectors live and which cores the OpenMP threads run on.
+// A 2-socket host streams 10x faster from node-local memory; std::vector::assign touches
+// every page from the calling thread, i.e. puts the whole state on one node.
+// ---------------------------------------------------------------------------------
+// re-home a filled vector: the thread that will stream range [t n / T, (t+1) n / T) under PAR_FOR's static schedule
+// touches it first
+template <class V> void numa_rehome(V& v) {
+  typedef typename V::value_type E;
+  if (g_threads <= 1 || v.size() < ((size_t)1 << 18)) return;
+  V w; w.reserve(v.size());
+  E* p = w.data(); const E* src = v.data(); const ssz n = (ssz)v.size();
+  PAR_FOR
+  for (ssz i = 0; i < n; i++) p[i] = src[i];          // first touch (raw reserved storage; E is trivially copyable)
+  w.assign(v.begin(), v.end());                        // sets the size; the pages stay where they are
+  v.swap(w);
+}
+
+#ifdef __linux__
+// logical CPUs of this process's affinity mask: one hardware thread per physical core first (cores in (package, core id) order),
+// then their SMT siblings in the same order; *cores = number of physical cores
+std::vector<int> cpu_order(int* cores) {
+  cpu_set_t mask; CPU_ZERO(&mask);
+  *cores = 0;
+  if (sched_getaffinity(0, sizeof(mask), &mask) != 0) return {};
+  struct Ent { int pkg, core, cpu; };
+  std::vector<Ent> all;
+  for (int c = 0; c < CPU_SETSIZE; c++) {
+    if (!CPU_ISSET(c, &mask)) continue;
+    int pkg = 0, core = c;
+    { std::ifstream f("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/physical_package_id"); if (f) f >> pkg; }
+    { std::ifstream f("/sys/devices/system/cpu/cpu" + std::to_string(c) + "/topology/core_id"); if (f) f >> core; }
+    all.push_back({pkg, core, c});
+  }
+  std::sort(all.begin(), all.end(), [](const Ent& a, const Ent& b) { return std::tie(a.pkg, a.core, a.cpu) < std::tie(b.pkg, b.core, b.cpu); });
+  std::vector<int> first, rest;
+  for (size_t i = 0; i < all.size(); i++) {
+    const bool sibling = i > 0 && all[i].pkg == all[i - 1].pkg && all[i].core == all[i - 1].core;
+    (sibling ? rest : first).push_back(all[i].cpu);
+  }
+  *cores = (int)first.size();
+  first.insert(first.end(), rest.begin(), rest.end());
+  return first;
+}
+cpu_set_t g_saved_mask; bool g_mask_saved = false;
+// on = 1: pin OpenMP thread t of a g_threads-wide team to ONE CPU -- T <= physical cores: spread evenly over the cores in topology
+// order (neighbouring static-schedule ranges on neighbouring cores of one node); more: fill the SMT siblings too; more threads than
+// CPUs: wrap.  on = 0: every thread of the team (and the caller) gets the mask back that the process had.  -> threads bound
+int bind_threads(int on) {
+  if (!g_mask_saved) { CPU_ZERO(&g_saved_mask); if (sched_getaffinity(0, sizeof(g_saved_mask), &g_saved_mask) != 0) return 0; g_mask_saved = true; }
+  const cpu_set_t saved = g_saved_mask;
+  sched_setaffinity(0, sizeof(saved), &saved);
+  int cores = 0;
+  const std::vector<int> order = on ? cpu_order(&cores) : std::vector<int>();
+  const int T = g_threads, C = (int)order.size();
+  int bound = 0;
+#pragma omp parallel num_threads(g_threads) reduction(+ : bound)
+  {
+    if (!on || C == 0) sched_setaffinity(0, sizeof(saved), &saved);
+    else {
+#ifdef _OPENMP
+      const int t = omp_get_thread_num();
+#else
+      const int t = 0;
+#endif
+      const int span = T <= cores ? cores : C;                       // the CPUs this team spreads over
+      const int slot = (int)(((long long)t * span) / T) % C;
+      cpu_set_t one; CPU_ZERO(&one); CPU_SET(order[slot], &one);
+      if (sched_setaffinity(0, sizeof(one), &one) == 0) bound += 1;
+    }
+  }
+  return bound;
+}
+#else
+int bind_threads(int) { return 0; }
+#endif
 
 // ---------------------------------------------------------------------------------
 // glibc rand() (TYPE_3, r[i] = r[i-3] + r[i-31]); normest seeds from std::rand()
@@ -107,7 +190,7 @@ template <class T> inline T lq_eps();
 template <> inline float lq_eps<float>() { return (float)1e-5; }     // :263-267
 template <> inline double lq_eps<double>() { return 1e-11; }          // :270-274
 
-template <class T> inline T fn_apply(int fn, T x0, T tau, T alpha, T beta) {
+template <class T> __attribute__((always_inline)) inline T fn_apply(int fn, T x0, T tau, T alpha, T beta) {
   switch (fn) {
     case ORC_FN_ZERO: return x0;                                        // :34-44
     case ORC_FN_ABS: return fn_abs(x0, tau);
@@ -172,7 +255,7 @@ struct View {
 
 // ElemOperation1D::operator()  (elem_operation_1d.hpp:36-59)
 template <class T>
-inline void elem_1d(int fn, T* res, const T* arg, const T* tau_diag, T tau_scal, bool invert_tau,
+__attribute__((always_inline)) inline void elem_1d(int fn, T* res, const T* arg, const T* tau_diag, T tau_scal, bool invert_tau,
                     const T* c, const View& v) {
   const size_t i0 = v.at(0);
   T tau = invert_tau ? (T)(1. / (double)(tau_scal * tau_diag[i0])) : (tau_scal * tau_diag[i0]);
@@ -187,7 +270,7 @@ inline void elem_1d(int fn, T* res, const T* arg, const T* tau_diag, T tau_scal,
 
 // ElemOperationNorm2::operator()  (elem_operation_norm2.hpp:40-88)
 template <class T>
-inline void elem_norm2(int fn, T* res, const T* arg, const T* tau_diag, T tau_scal, bool invert_tau,
+__attribute__((always_inline)) inline void elem_norm2(int fn, T* res, const T* arg, const T* tau_diag, T tau_scal, bool invert_tau,
                        const T* c, const View& v) {
   T norm = 0;
   for (size_t i = 0; i < v.dim; i++) { const T val = arg[v.at(i)]; norm += val * val; }
@@ -204,20 +287,45 @@ inline void elem_norm2(int fn, T* res, const T* arg, const T* tau_diag, T tau_sc
   }
 }
 
-// ProxElemOperationKernel (prox_elem_operation.inl:59-94): one "thread" per tx
+// ProxElemOperationKernel (prox_elem_operation.inl:59-94): one "thread" per tx.  The reference instantiates the kernel per
+// (operation, function) pair (prox_elem_operation.inl:96-198); so does this loop -- FN, OP, the layout and small dims are
+// compile-time constants, which lets the compiler fold the function switch and unroll the component loops (same expressions,
+// same results; only the speed of the CPU baseline depends on it).
+template <class T, int FN, int OP, int DIM, bool IL>
+void prox_elem_loop(T* res, const T* arg, const T* tau_diag, T tau, bool invert, size_t count, size_t dim_rt,
+                    const T* const* cptr, const T* cval) {
+  const size_t dim = DIM > 0 ? (size_t)DIM : dim_rt;
+  PAR_FOR
+  for (ssz t = 0; t < (ssz)count; t++) {
+    View v{count, dim, IL, (size_t)t};
+    T c[7];
+    for (int i = 0; i < 7; i++) c[i] = cptr[i] ? cptr[i][t] : cval[i];
+    if (OP == ORC_OP_1D) elem_1d<T>(FN, res, arg, tau_diag, tau, invert, c, v);
+    else elem_norm2<T>(FN, res, arg, tau_diag, tau, invert, c, v);
+  }
+}
+template <class T, int FN>
+void prox_elem_fn(int op, T* res, const T* arg, const T* tau_diag, T tau, bool invert, size_t count, size_t dim, bool interleaved,
+                  const T* const* cptr, const T* cval) {
+  if (op == ORC_OP_1D) { prox_elem_loop<T, FN, ORC_OP_1D, 1, false>(res, arg, tau_diag, tau, invert, count, 1, cptr, cval); return; }
+#define ORC_N2(D) (interleaved ? prox_elem_loop<T, FN, ORC_OP_NORM2, D, true>(res, arg, tau_diag, tau, invert, count, dim, cptr, cval) \
+                               : prox_elem_loop<T, FN, ORC_OP_NORM2, D, false>(res, arg, tau_diag, tau, invert, count, dim, cptr, cval))
+  switch (dim) { case 2: ORC_N2(2); break; case 3: ORC_N2(3); break; case 4: ORC_N2(4); break; default: ORC_N2(0); }
+#undef ORC_N2
+}
+template <class T, int... FN>
+void prox_elem_dispatch(std::integer_sequence<int, FN...>, int op, int fn, T* res, const T* arg, const T* tau_diag, T tau, bool invert,
+                        size_t count, size_t dim, bool interleaved, const T* const* cptr, const T* cval) {
+  typedef void (*Fn)(int, T*, const T*, const T*, T, bool, size_t, size_t, bool, const T* const*, const T*);
+  static const Fn table[] = {&prox_elem_fn<T, FN>...};
+  table[fn](op, res, arg, tau_diag, tau, invert, count, dim, interleaved, cptr, cval);
+}
 template <class T>
 void prox_elem_run(int op, int fn, T* res, const T* arg, const T* tau_diag, T tau, bool invert,
                    size_t count, size_t dim, bool interleaved, const T* const* cptr, const T* cval) {
   if (fn < 0 || fn >= ORC_FN_COUNT) throw OrcError("unknown function id");
   if (op == ORC_OP_1D) dim = 1;   // kDim = 1 for ElemOperation1D (elem_operation_1d.hpp:30)
-  PAR_FOR
-  for (ssz t = 0; t < (ssz)count; t++) {
-    View v{count, dim, interleaved, (size_t)t};
-    T c[7];
-    for (int i = 0; i < 7; i++) c[i] = cptr[i] ? cptr[i][t] : cval[i];
-    if (op == ORC_OP_1D) elem_1d<T>(fn, res, arg, tau_diag, tau, invert, c, v);
-    else elem_norm2<T>(fn, res, arg, tau_diag, tau, invert, c, v);
-  }
+  prox_elem_dispatch<T>(std::make_integer_sequence<int, ORC_FN_COUNT>(), op, fn, res, arg, tau_diag, tau, invert, count, dim, interleaved, cptr, cval);
 }
 
 // helper::ProjectEpiQuadNd (include/prost/prox/helper.hpp:44-105); x0 may alias x
@@ -280,33 +388,35 @@ void epi_quad_run(T* res, const T* arg, size_t count, size_t dim,
 // ---------------------------------------------------------------------------------
 // Linear operator blocks
 // ---------------------------------------------------------------------------------
-// BlockGradient2DKernel / Adjoint (src/linop/block_gradient2d.cu:26-78, :81-139)
+// BlockGradient2DKernel / Adjoint (src/linop/block_gradient2d.cu:26-78, :81-139).  The kernel decodes (x, y, l) from the thread
+// index; here the same elements are visited by nested loops (no division per element), the contiguous index innermost.
 template <class T>
 void grad2d_run(bool adjoint, T* res, const T* rhs, size_t nx, size_t ny, size_t L, bool lf) {
   const size_t N = nx * ny * L;
+  const size_t sy = lf ? L : 1, sx = lf ? ny * L : ny, sl = lf ? 1 : nx * ny;
+  const size_t n_out = lf ? ny : L, n_in = lf ? L : ny;          // label_first: l fastest; else y fastest
   PAR_FOR
   for (ssz xs = 0; xs < (ssz)nx; xs++) {
     const size_t x = (size_t)xs;
-    for (size_t yt = 0; yt < ny * L; yt++) {
-      size_t y, l;
-      if (lf) { l = yt % L; y = yt / L; } else { y = yt % ny; l = yt / ny; }
-      size_t idx, sy, sx;   // strides of y- and x-neighbours
-      if (lf) { idx = l + y * L + x * ny * L; sy = L; sx = ny * L; }
-      else { idx = y + x * ny + l * nx * ny; sy = 1; sx = ny; }
-      if (!adjoint) {
-        const T val_pt = rhs[idx];
-        T gx, gy;
-        if (y < ny - 1) gy = rhs[idx + sy] - val_pt; else gy = 0;
-        if (x < nx - 1) gx = rhs[idx + sx] - val_pt; else gx = 0;
-        res[idx] += gx;
-        res[idx + N] += gy;
-      } else {
-        T divx, divy;
-        if (y < ny - 1) divy = rhs[idx + N]; else divy = 0;
-        if (y > 0) divy -= rhs[idx + N - sy];
-        if (x < nx - 1) divx = rhs[idx]; else divx = 0;
-        if (x > 0) divx -= rhs[idx - sx];
-        res[idx] -= (divx + divy);
+    for (size_t o = 0; o < n_out; o++) {
+      for (size_t in = 0; in < n_in; in++) {
+        const size_t y = lf ? o : in, l = lf ? in : o;
+        const size_t idx = y * sy + x * sx + l * sl;
+        if (!adjoint) {
+          const T val_pt = rhs[idx];
+          T gx, gy;
+          if (y < ny - 1) gy = rhs[idx + sy] - val_pt; else gy = 0;
+          if (x < nx - 1) gx = rhs[idx + sx] - val_pt; else gx = 0;
+          res[idx] += gx;
+          res[idx + N] += gy;
+        } else {
+          T divx, divy;
+          if (y < ny - 1) divy = rhs[idx + N]; else divy = 0;
+          if (y > 0) divy -= rhs[idx + N - sy];
+          if (x < nx - 1) divx = rhs[idx]; else divx = 0;
+          if (x > 0) divx -= rhs[idx - sx];
+          res[idx] -= (divx + divy);
+        }
       }
     }
   }
@@ -316,33 +426,34 @@ void grad2d_run(bool adjoint, T* res, const T* rhs, size_t nx, size_t ny, size_t
 template <class T>
 void grad3d_run(bool adjoint, T* res, const T* rhs, size_t nx, size_t ny, size_t L, bool lf) {
   const size_t N = nx * ny * L;
+  const size_t sy = lf ? L : 1, sx = lf ? ny * L : ny, sl = lf ? 1 : nx * ny;
+  const size_t n_out = lf ? ny : L, n_in = lf ? L : ny;
   PAR_FOR
   for (ssz xs = 0; xs < (ssz)nx; xs++) {
     const size_t x = (size_t)xs;
-    for (size_t yt = 0; yt < ny * L; yt++) {
-      size_t y, l;
-      if (lf) { l = yt % L; y = yt / L; } else { y = yt % ny; l = yt / ny; }
-      size_t idx, sy, sx, sl;
-      if (lf) { idx = l + y * L + x * ny * L; sy = L; sx = ny * L; sl = 1; }
-      else { idx = y + x * ny + l * nx * ny; sy = 1; sx = ny; sl = nx * ny; }
-      if (!adjoint) {
-        T gx = 0, gy = 0, gl = 0;
-        const T val_pt = rhs[idx];
-        if (y < ny - 1) gy = rhs[idx + sy] - val_pt;
-        if (x < nx - 1) gx = rhs[idx + sx] - val_pt;
-        if (l < L - 1) gl = rhs[idx + sl] - val_pt; else gl = -val_pt;   // dirichlet :73-76
-        res[idx] += gx;
-        res[idx + N] += gy;
-        res[idx + 2 * N] += gl;
-      } else {
-        T divx = 0, divy = 0, divl = 0;
-        if (y < ny - 1) divy = rhs[idx + N]; else divy = 0;
-        if (y > 0) divy -= rhs[idx + N - sy];
-        if (x < nx - 1) divx = rhs[idx]; else divx = 0;
-        if (x > 0) divx -= rhs[idx - sx];
-        divl = rhs[idx + 2 * N];
-        if (l > 0) divl -= rhs[idx + 2 * N - sl];
-        res[idx] -= (divx + divy + divl);
+    for (size_t o = 0; o < n_out; o++) {
+      for (size_t in = 0; in < n_in; in++) {
+        const size_t y = lf ? o : in, l = lf ? in : o;
+        const size_t idx = y * sy + x * sx + l * sl;
+        if (!adjoint) {
+          T gx = 0, gy = 0, gl = 0;
+          const T val_pt = rhs[idx];
+          if (y < ny - 1) gy = rhs[idx + sy] - val_pt;
+          if (x < nx - 1) gx = rhs[idx + sx] - val_pt;
+          if (l < L - 1) gl = rhs[idx + sl] - val_pt; else gl = -val_pt;   // dirichlet :73-76
+          res[idx] += gx;
+          res[idx + N] += gy;
+          res[idx + 2 * N] += gl;
+        } else {
+          T divx = 0, divy = 0, divl = 0;
+          if (y < ny - 1) divy = rhs[idx + N]; else divy = 0;
+          if (y > 0) divy -= rhs[idx + N - sy];
+          if (x < nx - 1) divx = rhs[idx]; else divx = 0;
+          if (x > 0) divx -= rhs[idx - sx];
+          divl = rhs[idx + 2 * N];
+          if (l > 0) divl -= rhs[idx + 2 * N - sl];
+          res[idx] -= (divx + divy + divl);
+        }
       }
     }
   }
@@ -439,6 +550,7 @@ struct Block {
   int nnz = 0;
   std::vector<T> val, val_t; std::vector<int32_t> ptr, ind, ptr_t, ind_t;   // K (CSR), K^T (CSR)
   std::vector<float> fval, fval_t; size_t diaglength = 0; int mat_nrows = 0, mat_ncols = 0;   // Kronecker blocks
+  void rehome() { numa_rehome(val); numa_rehome(val_t); numa_rehome(ptr); numa_rehome(ind); numa_rehome(ptr_t); numa_rehome(ind_t); numa_rehome(fval); numa_rehome(fval_t); }
 
   void add(T* res, const T* rhs) const {              // EvalLocalAdd
     switch (kind) {
@@ -642,6 +754,11 @@ struct Prox {
   std::vector<size_t> inds, inds2; size_t count2 = 0, dim2 = 0; T sum = 0, sum2 = 0; bool two = false;   // ProxIndSum
   T alpha = 1;                                  // ProxIndSOC
 
+  void rehome() {
+    for (auto& cv : coeffs) numa_rehome(cv);
+    numa_rehome(a); numa_rehome(b); numa_rehome(c); numa_rehome(scaled_arg); numa_rehome(scaled_tau);
+    if (child) child->rehome();
+  }
   // Prox::Initialize chain (prox_moreau.cu:73-87, prox_ind_epi_quad.cu:137-169)
   void initialize() {
     if (kind == PK_MOREAU) { scaled_arg.assign(size, 0); child->initialize(); }
@@ -972,6 +1089,7 @@ struct SolverBase {
   virtual ~SolverBase() {}
   virtual void initialize() = 0;
   virtual void iterate(int iters) = 0;
+  virtual void rehome() = 0;          // timing runs: re-place the pages of every large vector for the current thread team
   virtual void solve(int* result, int* iters_done) = 0;
   virtual void get(double* x, double* z, double* y, double* w) = 0;
   virtual void scalars(double* out) = 0;
@@ -1055,6 +1173,19 @@ struct Solver : SolverBase {
     }
     if (!x0.empty()) { if (x0.size() == n) { x = x0; x_prev = x0; } else throw OrcError("Initial primal solution has wrong size."); }
     if (!y0.empty()) { if (y0.size() == m) { y = y0; y_prev = y0; } else throw OrcError("Initial dual solution has wrong size."); }
+    rehome_problem();
+    for (auto* v : {&x, &y, &x_prev, &y_prev, &temp, &kx, &kty, &kx_prev, &kty_prev}) numa_rehome(*v);
+  }
+  void rehome() override {
+    rehome_problem();
+    for (auto* v : {&x, &y, &x_prev, &y_prev, &temp, &kx, &kty, &kx_prev, &kty_prev, &x_half, &z_half, &x_proj, &z_proj, &x_dual, &z_dual, &temp1, &temp2, &temp3}) numa_rehome(*v);
+  }
+  // multi-threaded timing runs: every large vector first-touched by the thread that streams it (numa_rehome); no effect on results
+  void rehome_problem() {
+    if (g_threads <= 1) return;
+    numa_rehome(prob->left); numa_rehome(prob->right);
+    for (auto& b : prob->blocks) b.rehome();
+    for (auto* l : {&prob->prox_g, &prob->prox_f, &prob->prox_gstar, &prob->prox_fstar, &pg, &pfs}) for (auto& pr : *l) pr->rehome();
   }
 
   // BackendPDHG::PerformIteration (backend_pdhg.cu:313-381)
@@ -1175,6 +1306,8 @@ struct Solver : SolverBase {
     delta = (T)ao.arb_delta; rho = (T)ao.rho0; iteration = 0; arb_u = arb_l = 0;
     // the reference leaves the residual members uninitialised here;
     // the oracle zero-initialises them (members default to 0).
+    rehome_problem();
+    for (auto* v : {&x_half, &z_half, &x_proj, &z_proj, &x_dual, &z_dual, &temp1, &temp2, &temp3}) numa_rehome(*v);
   }
 
   // GemvPrecondK (backend_admm.cu:199-272): y := alpha*op(S^1/2 K T^1/2) x + beta*y
@@ -1412,6 +1545,7 @@ extern "C" {
 
 const char* orc_last_error(void) { return g_err.c_str(); }
 void orc_set_num_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_bind_threads(int on) { return bind_threads(on); }
 
 int orc_grad2d(int dtype, int adjoint, void* res, const void* rhs, size_t nx, size_t ny, size_t L, int lf) {
   ORC_TRY
@@ -1706,6 +1840,7 @@ int orc_solver_set_allreduce(orc_solver* s, orc_allreduce_cb cb, void* user, siz
 }
 int orc_solver_initialize(orc_solver* s) { ORC_TRY s->s->initialize(); ORC_CATCH }
 int orc_solver_iterate(orc_solver* s, int iters) { ORC_TRY s->s->iterate(iters); ORC_CATCH }
+int orc_solver_rehome(orc_solver* s) { ORC_TRY s->s->rehome(); ORC_CATCH }
 int orc_solver_solve(orc_solver* s, int* result, int* iters_done) { ORC_TRY s->s->solve(result, iters_done); ORC_CATCH }
 int orc_solver_get(orc_solver* s, double* x, double* z, double* y, double* w) { ORC_TRY s->s->get(x, z, y, w); ORC_CATCH }
 int orc_solver_scalars(orc_solver* s, double* out) { ORC_TRY s->s->scalars(out); ORC_CATCH }

@@ -32,6 +32,9 @@ extern "C" {
 
 const char* orc_last_error(void);
 void orc_set_num_threads(int n);   /* OpenMP threads for the hot loops (default 1) */
+/* timing runs: on = 1 pins the threads of the team to one CPU each (physical cores first, topology order), on = 0 restores the
+   process mask; returns the number of threads bound.  Solvers initialised with > 1 thread first-touch their vectors per thread. */
+int orc_bind_threads(int on);
 
 /* ---- function ids (reference: matlab/+prost/private/factory.cpp:21-48) ---- */
 enum {
@@ -164,6 +167,7 @@ int orc_solver_set_callbacks(orc_solver*, orc_interm_cb, orc_stop_cb, void* user
 int orc_solver_set_allreduce(orc_solver*, orc_allreduce_cb, void* user, size_t global_nrows, size_t global_ncols);
 int orc_solver_initialize(orc_solver*);              /* solver.cu:68-120 */
 int orc_solver_iterate(orc_solver*, int iters);      /* PerformIteration x iters, no tests */
+int orc_solver_rehome(orc_solver*);                  /* timing runs: first-touch every large vector again for the current thread team */
 /* solver.cu:123-209 ; *result: 0 converged, 1 max iters, 2 stopped by user */
 int orc_solver_solve(orc_solver*, int* result, int* iters_done);
 /* current_solution (x n, z m, y m, w n) as doubles; any pointer may be NULL */

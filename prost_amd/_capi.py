@@ -207,6 +207,9 @@ def _struct_fields(v, names, owner=None):
 _callback_error = []
 
 
+_TEARDOWN_COMMANDS = frozenset(["release", "comm_destroy", "solver_destroy"])
+
+
 def _raise_callback_error():
     if _callback_error:
         e = _callback_error[0]
@@ -217,7 +220,12 @@ def _raise_callback_error():
 def command(cmd, args=(), nlhs=0, struct_fields=None):
     """prost_(cmd, args...) -- returns a list of nlhs converted results."""
     L = lib()
-    _raise_callback_error()
+    # A host-transport callback failure left over from an earlier command aborts the next command that would CONSUME results.  Teardown
+    # commands run first and raise the stored error afterwards: clean-up after a dead peer or a gloo timeout must not leak the native
+    # solver / communicator (nor need to be issued twice).
+    teardown = cmd in _TEARDOWN_COMMANDS
+    if not teardown:
+        _raise_callback_error()
     keep = []
     vals = [to_value(a, keep) for a in args]
     prhs = (C.c_void_p * max(len(vals), 1))(*vals)

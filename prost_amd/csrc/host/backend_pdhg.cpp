@@ -186,6 +186,7 @@ void BackendPDHG<T>::Initialize() {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols(), l = std::max(m, n);
 
   iteration_ = 0;
+  failed_ = false;
   pair_launches_ = 0;
   spec_launched_ = spec_adopted_ = 0;
   prev_stale_ = false;
@@ -333,6 +334,7 @@ void BackendPDHG<T>::PerformIteration() {
 /// store the intermediate iterate itself.
 template <typename T>
 int BackendPDHG<T>::PerformIterations(int budget) {
+  if (failed_) throw Exception("BackendPDHG: an earlier batch of device-resident iterations failed half-way; the state on the device is undefined. Create a new solver.");
   const size_t k = iteration_;
   // z, w of the last read-out (n + m values; the reference keeps no such copies): large ones are released when the iteration
   // goes on, small ones stay for the next callback
@@ -395,6 +397,11 @@ void BackendPDHG<T>::RestoreRoles(const BatchMark& m) {
   prev_stale_ = m.prev_stale;
   iteration_ = m.iteration_after;
   pair_launches_ = m.pair_launches;
+  // the launches behind the stopping iteration did no work: their (near-zero) samples and launch counts are withdrawn
+  if (samples_.size() > m.samples) samples_.resize(m.samples);
+  if (ev_used_ > m.ev_used) ev_used_ = m.ev_used;
+  for (int kk = 0; kk < kKernelKinds; kk++) launches_[kk] = m.launches[kk];
+  last_end_ = kNoEvent;
 }
 
 /// up to kDeviceBatch iterations with the step-size rule and the stopping test on the device; returns the iterations that RAN (fewer
@@ -446,7 +453,15 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
         done += 1;
       }
     }
-  } catch (...) { in_device_batch_ = false; prost_hip_use_step_record(nullptr); throw; }
+  } catch (...) {
+    // Launches of this batch are already enqueued: iteration_, the buffer roles and pair_launches_ have advanced with them while tau_ /
+    // sigma_ / theta_ and the residual fields still hold the values from the start of the batch (the true ones exist only in the device
+    // record, behind kernels that may have failed).  Nothing consistent can be handed out from here: the backend is marked failed
+    // and every later iteration / read-out throws instead of pairing iterates with the wrong step sizes.
+    in_device_batch_ = false; prost_hip_use_step_record(nullptr);
+    batch_marks_.clear(); spec_valid_ = false; failed_ = true;
+    throw;
+  }
   in_device_batch_ = false;
   if (!fused_) CheckHip(prost_hip_use_step_record(nullptr), "use_step_record");
   dev_batches_++;
@@ -800,6 +815,11 @@ void BackendPDHG<T>::FinishResiduals() {
     // (generic path: IterationGeneric exchanges kty_ / kty_prev_ AFTER this call -- the mark holds the roles the iteration leaves)
     batch_marks_.push_back({iteration_ + 1, pair_launches_, x_.data(), x_prev_.data(), y_.data(), y_prev_.data(), prev_stale_,
                             kx_.data(), kx_prev_.data(), kty_prev_.data(), kty_.data()});
+    // kernel timing: launches enqueued behind a stopping iteration return at once -- their samples must not enter the averages
+    // (RestoreRoles drops everything recorded after the mark it returns to)
+    static_assert(kKernelKinds == 8, "BatchMark::launches holds one counter per kernel kind");
+    batch_marks_.back().samples = samples_.size(); batch_marks_.back().ev_used = ev_used_;
+    for (int kk = 0; kk < kKernelKinds; kk++) batch_marks_.back().launches[kk] = launches_[kk];
     batch_last_launch_evaluated_ = true;
     return;
   }
@@ -922,12 +942,14 @@ void BackendPDHG<T>::UpdateAlg2() {                           // :483-488, compu
 
 template <typename T>
 void BackendPDHG<T>::current_solution(std::vector<T>& primal, std::vector<T>& dual) {
+  if (failed_) throw Exception("BackendPDHG: an earlier batch of device-resident iterations failed half-way; the state on the device is undefined. Create a new solver.");
   x_.copy_to(primal);
   y_.copy_to(dual);
 }
 
 template <typename T>
 void BackendPDHG<T>::ConstraintVariables() {
+  if (failed_) throw Exception("BackendPDHG: an earlier batch of device-resident iterations failed half-way; the state on the device is undefined. Create a new solver.");
   void* s = CurrentStream();
   const size_t n = this->problem_->ncols(), m = this->problem_->nrows();
   const device_vector<T>& Tr = this->problem_->scaling_right();

@@ -11,6 +11,7 @@
 //   test:op:simplex_lds   projection onto the unit simplex, sorting in the per-thread LDS slice (SharedMem, dim entries of T,
 //                         no coefficients);   library: elem_operation:ind_simplex
 //   test:op:partial       writes res[0] only (kPartialResult): the other components keep their old content
+//   test:op:partial_undeclared  the same operation WITHOUT the declaration (a straight port): the register-tile path preloads res
 //   test:tpl:ind_sum / test:tpl:ind_simplex   the PUBLIC ElemOperationIndSum / ElemOperationIndSimplex (elemop/*.hpp), instantiated out of
 //                         tree;   library: elem_operation:ind_sum / elem_operation:ind_simplex
 //   test:tpl:1d:<fn> / test:tpl:norm2:<fn>   the PUBLIC templates ElemOperation1D / ElemOperationNorm2 over the 14 public
@@ -33,6 +34,7 @@ using prost::Vector;
 // ---- user-written norm2 + Huber, the formulas as a user would type them from the paper / the reference's sources ----
 template <typename T>
 struct Norm2Huber : public prost::ElemOperation<0, 7> {
+  static const bool kWritesAllComponents = true;          // opt-in: every component is assigned below, the tile path skips the preload of res
   __host__ __device__ Norm2Huber(T* coeffs, size_t dim, SharedMem<SharedMemType, GetSharedMemCount>& shared_mem) : coeffs_(coeffs), dim_(dim) {}
 
   inline __host__ __device__ void operator()(Vector<T>& res, const Vector<const T>& arg, const Vector<const T>& tau_diag, T tau_scal, bool invert_tau) {
@@ -131,6 +133,16 @@ struct FirstComponentOnly : public prost::ElemOperation<0, 0> {
   }
 };
 
+// ---- the same omission WITHOUT the declaration: what a straight port from the reference looks like (its kernel preserves the old
+// content of res; here the register-tile path must, too -- kWritesAllComponents defaults to false) ----
+template <typename T>
+struct FirstComponentOnlyUndeclared : public prost::ElemOperation<0, 0> {
+  __host__ __device__ FirstComponentOnlyUndeclared(size_t dim, SharedMem<SharedMemType, GetSharedMemCount>& shared_mem) {}
+  inline __host__ __device__ void operator()(Vector<T>& res, const Vector<const T>& arg, const Vector<const T>& tau_diag, T tau_scal, bool invert_tau) {
+    res[0] = 2 * arg[0];
+  }
+};
+
 // ---- factories: data = {count, dim, interleaved[, {coefficients}]} like sum_1d.m:79-80 / sum_norm2.m:85-86 ----
 template <typename T, class OP>
 prost::Prox<T>* CreateWithCoeffs(size_t idx, size_t size, bool diagsteps, const prost_value* data) {
@@ -159,6 +171,7 @@ void RegisterAll() {
   reg["test:op:abs_1d"] = CreateWithCoeffs<T, Abs1D<T>>;
   reg["test:op:simplex_lds"] = CreateNoCoeffs<T, SimplexLds<T>>;
   reg["test:op:partial"] = CreateNoCoeffs<T, FirstComponentOnly<T>>;
+  reg["test:op:partial_undeclared"] = CreateNoCoeffs<T, FirstComponentOnlyUndeclared<T>>;
   reg["test:tpl:ind_sum"] = CreateNoCoeffs<T, prost::ElemOperationIndSum<T>>;
   reg["test:tpl:ind_simplex"] = CreateNoCoeffs<T, prost::ElemOperationIndSimplex<T>>;
   RegisterTemplates<T, prost::Function1DZero>("zero");

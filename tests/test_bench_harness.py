@@ -1,0 +1,56 @@
+"""CPU tests of bench.py's bookkeeping (no GPU): the byte model per kernel name.
+
+Every name `BackendPDHG::KernelTimes` can emit (prost_amd/csrc/host/backend_pdhg.cpp, the `names[]` table) must map to the
+compulsory values per pixel / voxel DESIGN.md section 3 states for that launch.  Round 4 matched kernel kinds by the substring
+"dual", which also sits in "resi-dual-s": every `+residuals` launch was priced as a dual pass.
+"""
+import os
+import re
+
+import pytest
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (name, volume) -> values per pixel / voxel and launch
+EXPECTED = {
+    ("fused_primal2d_kernel", False): 5, ("fused_dual2d_kernel", False): 6,
+    ("fused_primal3d_kernel", True): 6, ("fused_dual3d_kernel", True): 8,
+    ("fused_iter2d_kernel", False): 7, ("fused_iter2d_mc_kernel", False): 7, ("fused_iter3d_kernel", True): 9,
+    ("fused_iter2d_kernel+residuals", False): 9, ("fused_iter3d_kernel+residuals", True): 13,
+    ("fused_iter2d_x2_kernel", False): 7, ("fused_iter2d_mc_x2_kernel", False): 7, ("fused_iter3d_x2_kernel", True): 9,
+    ("fused_iter2d_x2_kernel+mid", False): 10,
+    ("fused_iter2d_x2_kernel+residuals", False): 7, ("fused_iter2d_mc_x2_kernel+residuals", False): 7,
+    ("fused_iter3d_x2_kernel+residuals", True): 9,
+    ("fused_iter2d_x2_kernel+mid+residuals", False): 10,
+}
+
+
+@pytest.mark.parametrize("key", sorted(EXPECTED))
+def test_compulsory_floats_of_every_kernel_name(key):
+    name, volume = key
+    assert bench.compulsory_floats(name, volume) == EXPECTED[key]
+
+
+def test_every_name_the_backend_can_emit_is_priced():
+    """the names[] table of KernelTimes, read from the source: nothing the backend reports is left without a byte figure, and no
+    `+residuals` name is taken for a dual pass"""
+    src = open(os.path.join(ROOT, "prost_amd", "csrc", "host", "backend_pdhg.cpp")).read()
+    block = src[src.index("const char* names[kKernelKinds]"):]
+    block = block[:block.index("};")]
+    names = set(re.findall(r'"(fused_[a-z0-9_+]+)"', block))
+    assert len(names) >= 15, names
+    for name in names:
+        volume = "3d" in name
+        assert (name, volume) in EXPECTED, "tests/test_bench_harness.py does not know %s" % name
+        assert bench.compulsory_floats(name, volume) == EXPECTED[(name, volume)], name
+        family, suffix = bench.kernel_kind(name)
+        assert family in ("primal", "dual", "iter", "iter_x2")
+        if "residuals" in name:
+            assert family not in ("primal", "dual"), name
+
+
+def test_unknown_names_are_not_priced():
+    for name in ("cg_step_xr2_kernel", "fused_dual2d_kernel+residuals", "residuals", "fused_iter2d_kernel+mid", "something_dual"):
+        assert bench.compulsory_floats(name, False) is None

@@ -169,6 +169,34 @@ def test_host_transport_callback_failures_surface_in_the_next_command():
     _capi.command("get_precision", (), 1)       # raised once
 
 
+def test_teardown_commands_run_before_a_pending_callback_error_is_raised(monkeypatch):
+    """clean-up after a dead peer must not leak the native solver / communicator: release, comm_destroy and solver_destroy EXECUTE and
+    only then raise the stored callback error (every other command raises it without running)"""
+    from prost_amd import _capi
+    ran = []
+
+    class FakeLib:
+        def prost_command(self, cmd, nlhs, plhs, nrhs, prhs):
+            ran.append(cmd.decode())
+            return 0
+
+        def prost_value_free(self, v):
+            pass
+
+    monkeypatch.setattr(_capi, "lib", lambda: FakeLib())
+    for cmd in ("release", "comm_destroy", "solver_destroy"):
+        del _capi._callback_error[:]
+        _capi._callback_error.append(RuntimeError("peer 1 went away"))
+        with pytest.raises(prost.ProstError, match="peer 1 went away"):
+            _capi.command(cmd, (), 0)
+        assert ran[-1] == cmd and not _capi._callback_error          # ran first, raised afterwards, once
+    _capi._callback_error.append(RuntimeError("peer 1 went away"))
+    n = len(ran)
+    with pytest.raises(prost.ProstError):
+        _capi.command("solver_iterate", (), 0)
+    assert len(ran) == n                                            # a consuming command does not run
+
+
 def test_example_rof_primal_description_matches_the_matlab_script():
     """examples/rof_primal_sub_variables.py builds what example_rof_primal.m:15-36 builds: a min_problem whose primal variable carries
     three sum_1d pieces on consecutive sub-variables (100, 500, the rest; slices of f as coefficient b), the norm2 'abs' regulariser on

@@ -274,6 +274,14 @@ def test_elem_operation_with_a_shared_memory_slice_and_partial_results(hip, plug
         arg = rng.standard_normal(count * dim).astype(dtype).astype(np.float64)
         got, _ = prost.eval_prox(plugin_groups("test:op:partial", dim, False), arg, 1.0, np.ones(count * dim))
         assert np.array_equal(got[:count], 2 * arg[:count]) and np.array_equal(got[count:], np.zeros(2 * count))   # eval_prox zero-fills the result vector
+        # the same operation WITHOUT the kPartialResult declaration (a straight port from the reference): it runs the register-tile
+        # path, which preloads res unless the operation opts out (kWritesAllComponents) -- unwritten components keep their content
+        for dim, interleaved, count in [(3, False, 1000), (3, True, 1000), (2, False, 4099), (4, True, 64)]:
+            arg = rng.standard_normal(count * dim).astype(dtype).astype(np.float64)
+            got, _ = prost.eval_prox(plugin_groups("test:op:partial_undeclared", dim, interleaved), arg, 1.0, np.ones(count * dim))
+            grp = got.reshape(count, dim) if interleaved else got.reshape(dim, count).T
+            agr = arg.reshape(count, dim) if interleaved else arg.reshape(dim, count).T
+            assert np.array_equal(grp[:, 0], 2 * agr[:, 0]) and np.array_equal(grp[:, 1:], np.zeros((count, dim - 1))), (dim, interleaved, count)
     finally:
         prost.set_precision("double")
 
