@@ -178,19 +178,44 @@ def make_config(name, size, volume, seed, fp="fp32"):
     raise SystemExit("bench.py: unknown --config %r (c2, c3, c4)" % name)
 
 
+# C4: values per PIXEL every kernel of an ADMM outer iteration has to move once (n = 2 px primal entries, m = 5 px rows: W's row + 4
+# gradient rows; W as CSR: 2 values + 2 column indices + 1 row start per pixel, W^T: 2 + 2 + 2), DESIGN.md section 3.  Indices count as
+# values of 4 bytes; with fp64 the vector entries double, the index arrays do not (itemsize-weighted below).
+C4_KERNEL_VALUES = {
+    # name: (vector values per pixel, 4-byte index words per pixel)
+    "cg_pixel_pq_kernel": (16, 0),            # p, s, tau (6), W (2), Sigma on W's rows (1) -> p, q (7); first round of a solve: 12
+    "cg_pixel_xrs_kernel": (28, 0),           # r, q (10), Sigma_W (1), x, p, tau (6), W (2) -> r, x, s (9)
+    "cg_step_xr2_kernel": (18, 0),            # x, p, tau -> x ; r, q, sigma -> r, t
+    "op_stage_kernel<EpiFwdQ>": (14, 3),      # t (2) through W (2 + indices) and the stencil ; sigma (5) -> q (5)
+    "op_stage_kernel<EpiAdjS>": (13, 4),      # t (5) through W^T (2 + indices) and the stencil ; x, tau (4) -> s (2)
+    "cg_step_p2_kernel": (10, 0),             # p, s, tau -> p, t
+}
+# the stages of an outer iteration outside the CG rounds (prost_hip_admm_fused_stage / prost_hip_cgls_init_fused), the same way
+C4_OUTER_VALUES = {"AdmmPreX": (16, 0), "EpiPreZK": (29, 3), "InitX": (8, 0), "EpiInitRK": (24, 3), "EpiInitSK": (17, 4), "AdmmPostX2": (14, 0),
+                   "EpiPostZK": (29, 3), "prox_f": (16, 0), "EpiResZK": (29, 3), "EpiResXK": (15, 4)}
+
+
 def c4_kernel_bytes(kname, n_px, itemsize=4):
-    """compulsory bytes of the four kernels of a CG round at the C4 shape (n = 2 px primal, m = 5 px rows, W: 2 px entries, two per
-    row; W^T one per row): every vector the kernel has to read or write once, CSR arrays included (generic kernels)"""
-    n, m, nnz = 2 * n_px, 5 * n_px, 2 * n_px
-    if kname == "cg_step_xr2_kernel":            # x, p, tau -> x ; r, q, sigma -> r, t
-        return (4 * n + 5 * m) * itemsize
-    if kname == "op_stage_kernel<EpiFwdQ>":      # t (n) through W (val, ind, row starts) and the stencil ; sigma -> q
-        return (n + 2 * m) * itemsize + nnz * (itemsize + 4) + (n_px + 1) * 4
-    if kname == "op_stage_kernel<EpiAdjS>":      # t (m) through W^T and the stencil ; x, tau -> s
-        return (m + 3 * n) * itemsize + nnz * (itemsize + 4) + (n + 1) * 4
-    if kname == "cg_step_p2_kernel":             # p, s, tau -> p, t
-        return 5 * n * itemsize
-    return None
+    """compulsory bytes of one launch of a kernel of the CG round at the C4 shape (generic kernels: every vector the
+    kernel has to read or write once, CSR arrays included)"""
+    v = C4_KERNEL_VALUES.get(kname)
+    return (v[0] * itemsize + v[1] * 4) * n_px if v else None
+
+
+def c4_iteration_bytes(path, cg_rounds, n_px, itemsize=4):
+    """compulsory bytes of ONE ADMM outer iteration at the C4 shape: the stages outside the solve + `cg_rounds` CG rounds of the path
+    that ran (two launches per round: admm:pixel-op; four: admm:fused-op).  None for a path this table does not describe."""
+    words = lambda t: t[0] * itemsize + t[1] * 4
+    outer = sum(words(t) for t in C4_OUTER_VALUES.values())
+    if path == "admm:pixel-op":
+        rnd = words(C4_KERNEL_VALUES["cg_pixel_pq_kernel"]) + words(C4_KERNEL_VALUES["cg_pixel_xrs_kernel"])
+        first = rnd - 4 * itemsize                                  # the first launch A of a solve reads no s and writes no p
+    elif path == "admm:fused-op":
+        rnd = sum(words(C4_KERNEL_VALUES[k]) for k in ("op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"))
+        first = rnd
+    else:
+        return None
+    return int((outer + first + max(int(cg_rounds) - 1, 0) * rnd) * n_px) if cg_rounds and cg_rounds >= 1 else int(outer * n_px)
 
 
 def cpu_baseline_c3(volume, max_threads, np_dtype=None):
@@ -254,8 +279,30 @@ def cpu_baseline_c4(size, backend, max_threads, np_dtype=None):
                       "logical CPUs, vectors first-touched per thread)" % (iters, size, size, threads)}
 
 
+def cpu_quota_cores():
+    """CPU time this process may use per second, in cores, from the cgroup (v2 cpu.max, v1 cfs_quota / cfs_period); None: unlimited.
+    The GPU boxes of this pool show 256 logical CPUs and a quota of 16 cores: more runnable threads than that are throttled."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_thread_candidates(max_threads):
-    """thread counts the CPU baselines probe: powers of two from 8 up to the logical CPUs of the host, and the host's count itself"""
+    """thread counts the CPU baselines probe: powers of two from 8 up to the logical CPUs of the host and the host's count itself --
+    or, under a cgroup CPU quota of q cores, q / 2, q, 3 q / 2 and 2 q (spinning OpenMP threads beyond the quota are throttled)"""
+    quota = cpu_quota_cores()
+    if quota and quota < max_threads:
+        q = max(1, int(round(quota)))
+        c = sorted({t for t in (max(1, q // 2), q, (3 * q) // 2, 2 * q) if 1 <= t <= max_threads})
+        return c
     c = [t for t in (8, 16, 32, 64, 128, 256, 512) if t <= max_threads]
     if max_threads not in c:
         c.append(max_threads)
@@ -319,10 +366,11 @@ def cpu_baseline(n_img, max_threads, np_dtype=None):
     s.iterate(3)
     single = 3 / (time.time() - t1)
     out = {"value": iters / el, "unit": "it/s", "cores": best, "kind": "port", "single_thread_value": single,
-           "threads_probed": {str(k): v for k, v in sorted(rates.items())}, "logical_cpus": max_threads,
+           "threads_probed": {str(k): v for k, v in sorted(rates.items())}, "logical_cpus": max_threads, "cpu_quota_cores": cpu_quota_cores(),
            "sample": "%d PDHG iterations of the same %dx%d %s ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads pinned one per "
                      "core in topology order, every vector first-touched by the thread that streams it (best of a probe over %s threads on %d "
-                     "logical CPUs)" % (iters, n_img, n_img, fp, best, "/".join(str(t) for t in sorted(rates)), max_threads)}
+                     "logical CPUs%s)" % (iters, n_img, n_img, fp, best, "/".join(str(t) for t in sorted(rates)), max_threads,
+                                          "; the container's cgroup CPU quota is %.0f cores" % cpu_quota_cores() if cpu_quota_cores() else "")}
     del s
     rb = reference_build_rate(backend, opts) if np_dtype == np.float32 else None
     out["reference_build"] = rb
@@ -645,9 +693,10 @@ def main():
                 comp_bytes = c4_kernel_bytes(kname, units, itemsize)
                 alg_bytes = None
                 note = ("ADMM has no per-iteration byte figure in SURVEY 8d; frac = COMPULSORY bytes of the dominant kernel of the CG round (every operand read "
-                        "or written once, CSR arrays included: %s) / its launch time / peak.  The working set of a solve (~160 MB at 1024^2) exceeds the 32 MB of "
-                        "L2, so the round's kernels stream from HBM / Infinity Cache: the path is bandwidth-bound kernel by kernel, not launch-bound -- "
-                        "profiles/r03_c4_admm_kernel_stats.csv shows the device busy back to back." % kname)
+                        "or written once, index arrays included: %s) / its launch time / peak.  compulsory_bytes_per_iteration = the same count over EVERY "
+                        "kernel of an outer iteration (the stages outside the solve + the CG rounds of the last solve); frac_iteration = value x those bytes "
+                        "/ peak: the whole-iteration figure, launch gaps and the host loop included.  The working set of a solve (~160 MB at 1024^2) exceeds "
+                        "the 32 MB of L2, so the kernels stream from HBM / Infinity Cache." % kname)
             else:
                 unit_name = "pixel" if args.config == "c2" else "voxel"
                 cf = compulsory_floats(kname, args.config == "c3")
@@ -689,6 +738,11 @@ def main():
                                                       "compulsory_bytes": c4_kernel_bytes(name, units, itemsize) if args.config == "c4"
                                                       else (compulsory_floats(name, args.config == "c3") or 0) * itemsize * units or None}
                                                for name, v in kern.items()}}
+            if args.config == "c4":
+                it_bytes = c4_iteration_bytes(path, st.get("cg_iterations") or 0, units, itemsize)
+                out["roofline"]["compulsory_bytes_per_iteration"] = it_bytes
+                out["roofline"]["frac_iteration"] = (value / world) * it_bytes / 1e9 / HBM_PEAK_GBPS if it_bytes else None
+                out["roofline"]["cg_rounds_per_iteration"] = st.get("cg_iterations")
             if comp_bytes and ipl:
                 # whole-job rate x compulsory bytes per iteration of the dominant kernel / peak: <= roofline.frac (launch gaps, residual launches)
                 out["hbm_roofline_frac"] = (value / world) * (comp_bytes / ipl) / 1e9 / HBM_PEAK_GBPS

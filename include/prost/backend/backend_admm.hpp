@@ -21,9 +21,11 @@ class BackendADMM : public Backend<T> {
                              ///< measured 10-25 % SLOWER than the direct launches on ROCm 7.2
     bool fused_rounds;       ///< CG rounds of four launches with the operator applied inside them (needs device_cg and an operator of
                              ///< CSR / gradient blocks); false: the staged rounds with LinearOperator::Eval between the stages
+    bool pixel_rounds;       ///< CG rounds of TWO launches for operators [D ; gradient2d] with D coupling the channels of one pixel (needs
+                             ///< fused_rounds); false: the four-launch rounds
     bool device_cg;          ///< fused passes + CG scalars resident on the device (default); false = the reference's launch sequence, one blocking nrm2 per scalar
     Options() : rho0(1), alpha(1.7), cg_tol_pow(1.3), cg_tol_min(1e-5), cg_tol_max(1e-8), cg_max_iter(10), residual_iter(1),
-                arb_delta(1.05), arb_tau(0.8), arb_gamma(1.01), cg_graph(false), fused_rounds(true), device_cg(true) {}
+                arb_delta(1.05), arb_tau(0.8), arb_gamma(1.01), cg_graph(false), fused_rounds(true), pixel_rounds(true), device_cg(true) {}
   };
   explicit BackendADMM(const Options& opts)
       : opts_(opts), scal_dev_(nullptr), scal_host_(nullptr), workspace_(nullptr), cg_state_(nullptr), cg_workspace_(nullptr), cg_done_host_(nullptr) {}
@@ -35,8 +37,9 @@ class BackendADMM : public Backend<T> {
   virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
   virtual size_t gpu_mem_amount() const;
-  /// "admm:fused-op": CG rounds of four launches with the operator inside the stage kernels; "admm:generic": staged rounds
-  virtual std::string path() const { return fused_rounds_ ? "admm:fused-op" : "admm:generic"; }
+  /// "admm:pixel-op": CG rounds of two launches (operators [D ; gradient2d]); "admm:fused-op": CG rounds of four launches with the
+  /// operator inside the stage kernels; "admm:generic": staged rounds
+  virtual std::string path() const { return pixel_rounds_ ? "admm:pixel-op" : fused_rounds_ ? "admm:fused-op" : "admm:generic"; }
   T rho() const { return rho_; }
   size_t iteration() const { return iteration_; }
   virtual void KernelTimes(std::vector<typename Backend<T>::KernelTime>& out);
@@ -74,6 +77,10 @@ class BackendADMM : public Backend<T> {
   // per round; fused_op_.nblocks == 0: the operator has other blocks (plugins, diags, Kronecker, ...) -> staged rounds
   prost_hip_fused_op fused_op_;
   bool fused_rounds_ = false;
+  // CG rounds in two launches (prost_hip_cgls_pixel_round_*): the operator as [D ; gradient2d], second buffers for p and r
+  prost_hip_pixel_op pixel_op_;
+  bool pixel_rounds_ = false;
+  device_vector<T> cg_p_alt_, cg_r_alt_;
   int cg_result_index_ = 0;      ///< record that holds the result of the most recent device solve
   // kernel timing (bench roofline figure): the four launches of ONE round of a sampled solve are bracketed by events
   std::vector<void*> ev_;        ///< pool, eight events per sampled round (begin / end of its four kernels)

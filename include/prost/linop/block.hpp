@@ -27,6 +27,9 @@ struct BlockDesc {
   size_t nnz = 0;
   const void* val = nullptr; const int32_t* ptr = nullptr; const int32_t* ind = nullptr;
   const void* val_t = nullptr; const int32_t* ptr_t = nullptr; const int32_t* ind_t = nullptr;
+  // kSparse: L > 0 iff the matrix couples the L channels of ONE pixel -- nrows x (L nrows), row i holds exactly L entries, at
+  // columns i + c nrows, c = 0 .. L-1 (e.g. [diag(Ix) diag(Iy)]): val is then also the row-major table w[i L + c]
+  size_t pointwise_planes = 0;
 };
 
 template <typename T>

@@ -90,6 +90,7 @@ class BlockSparse : public Block<T> {
     d.kind = BlockDesc::kSparse; d.nnz = nnz_;
     d.val = val_.data(); d.ptr = ptr_.data(); d.ind = ind_.data();
     d.val_t = val_t_.data(); d.ptr_t = ptr_t_.data(); d.ind_t = ind_t_.data();
+    d.pointwise_planes = pointwise_planes_;
     return true;
   }
 
@@ -102,6 +103,8 @@ class BlockSparse : public Block<T> {
   size_t nnz_;
   size_t grad_nx_ = 0, grad_ny_ = 0, grad_L_ = 0;      ///< non-zero: K == spmat_gradient2d(grad_nx_, grad_ny_, grad_L_)
   void DetectGradient2D();
+  size_t pointwise_planes_ = 0;                        ///< non-zero: row i has its entries at columns i + c nrows, c < pointwise_planes_ (Initialize())
+  void DetectPointwise();
   std::vector<int32_t> host_ind_, host_ind_t_, host_ptr_, host_ptr_t_;
   std::vector<T> host_val_, host_val_t_;
   device_vector<int32_t> ind_, ind_t_, ptr_, ptr_t_;

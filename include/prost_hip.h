@@ -636,7 +636,8 @@ int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void*
  * `state` is an ARRAY of records here (prost_hip_cgls_state_bytes() each): the INIT stages of prost_hip_cgls_stage write
  * record 0, round j reads record j and writes record j + 1 (rounds after the stopping test fired only hand the record on), so
  * a solve of at most R rounds needs R + 1 records and its result is record R (prost_hip_cgls_result_at).  Same per-element
- * expressions and roundings as the staged round; the partial sums are grouped differently (sums in double).
+ * expressions and roundings as the staged round; the sums are order-independent (reduce.hpp: exact to 2^-100, rounded once), so
+ * every CG scalar equals the staged round's.
  * CSR blocks: one thread per row, sequential sum -- what prost_hip_csr_spmv does for rows of up to 6 entries on average.
  * Gradient blocks: planar layout (label_first = false). */
 enum { PROST_OP_CSR = 1, PROST_OP_GRAD2D = 2, PROST_OP_GRAD3D = 3 };
@@ -661,6 +662,40 @@ int prost_hip_cgls_round_f64(const prost_hip_cgls_desc* d, const prost_hip_fused
  * own begin / end, as prost_hip_next_launch_events does: no marker packets between the launches. */
 int prost_hip_cgls_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev8, void* stream);
 int prost_hip_cgls_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, int round, void* const* ev8, void* stream);
+/* A CG round in TWO launches for operators K = [D ; gradient2d(nx, ny, L)] (or [gradient2d ; D], or the gradient alone): D is an
+ * (nx ny) x (L nx ny) sparse block whose row i holds exactly L entries, at columns i + c nx ny, c = 0 .. L-1 -- a matrix that couples
+ * the channels of ONE pixel, e.g. the warp matrix [diag(Ix) diag(Iy)] of a TV-L1 flow model.  A thread owns 4 consecutive pixels of an
+ * image column (2 in fp64) with all their rows and columns of K; what a stage needs from neighbouring pixels it recomputes from their
+ * operands, so the vector updates of cgls.hpp:311-351 fold into the operator stages (block_sparse.cu:146-211, block_gradient2d.cu:26-139,
+ * backend_admm.cu:199-272):
+ *   launch A: beta, stopping test (of the previous round) ; p = beta p + s ; q = sqrt(Sigma) K sqrt(Tau) p ; |p|^2, |q|^2
+ *   launch B: alpha ; x += alpha p ; r -= alpha q ; s = sqrt(Tau) (-shift x / sqrt(Tau) + K^T sqrt(Sigma) r) ; |x|^2, |s|^2
+ * Same records as prost_hip_cgls_round (record 0 from prost_hip_cgls_init_fused; launch A of round j writes record j); after the
+ * last queued round `last`, prost_hip_cgls_pixel_close writes record last + 1 (the evaluation launch A of the next round would
+ * make), so prost_hip_cgls_result_at(state, rounds queued) reads what the other paths leave there.  p and r alternate between the
+ * descriptor's buffers and p_alt / r_alt (n and m elements); d->t is not used.  Every vector is bit-identical to the four-launch
+ * round's: same per-element expressions in the same order, order-independent sums. */
+typedef struct prost_hip_pixel_op {
+  uint64_t nx, ny;
+  int L;                    /* channels, 1 .. 3 */
+  int has_d;                /* 0: K is the gradient block alone (m = 2 L nx ny) */
+  int d_first;              /* D stands BEFORE the gradient block in the operator's block list: K^T t is accumulated block by block in list
+                             * order (LinearOperator::EvalAdjoint, linearoperator.cu:152-170), whatever the row order is */
+  uint64_t d_row, g_row;    /* first row of D (nx ny rows) and of the gradient block (2 L nx ny rows): {0, nx ny} or {2 L nx ny, 0} */
+  const void* w;            /* D's values, row-major: w[i L + c] = D(i, i + c nx ny) -- the value array of D's CSR form (T) */
+  void* p_alt; void* r_alt; /* second buffers for p (n elements) and r (m elements) */
+  double sigma_grad;        /* Sigma on the gradient rows: ONE value (the caller checks that d->sigma is constant there; a gradient
+                             * block's row sums are, block_gradient2d.cu:154-158) -- d->sigma is read on D's rows only */
+} prost_hip_pixel_op;
+/* 1 if the two-launch rounds take this operator (host-only check); dtype 0: fp32 (ny % 4 == 0), 1: fp64 (ny % 2 == 0) */
+int prost_hip_pixel_op_supported(const prost_hip_pixel_op* op, uint64_t m, uint64_t n, int dtype);
+int prost_hip_cgls_pixel_round_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* stream);
+int prost_hip_cgls_pixel_round_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* stream);
+/* with per-kernel timing: launch A stamps ev4[0] / ev4[1], launch B ev4[2] / ev4[3] (as prost_hip_cgls_round_timed) */
+int prost_hip_cgls_pixel_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4, void* stream);
+int prost_hip_cgls_pixel_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4, void* stream);
+int prost_hip_cgls_pixel_close_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round, void* stream);
+int prost_hip_cgls_pixel_close_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round, void* stream);
 /* blocking read-back of record `index` of a record array */
 int prost_hip_cgls_result_at(const void* state, int index, prost_hip_cgls_result_t* out, void* stream);
 /* The start of a solve the same way: INIT_X ; [INIT_R ; r += K t ; INIT_R2] ; [s += K^T (sqrt(Sigma) r) ; INIT_S], each bracket

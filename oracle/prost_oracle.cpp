@@ -129,6 +129,34 @@ int bind_threads(int) { return 0; }
 #endif
 
 // ---------------------------------------------------------------------------------
+// Sums whose ORDER the reference leaves unspecified -- thrust::transform_reduce on the device (cgls.hpp:152-170 NormSquared,
+// problem.cu:456-486 inside normest) and cublas<t>nrm2 (backend_admm.cu:40-50) reduce by trees nobody documents; the host build
+// of thrust happens to go left to right.  The CG scalars alpha / beta, the relative stopping test of cgls.hpp:326-360 and the
+// rescale of the initial step sizes by normest are knife-edge functions of those sums, so "some order" is not a contract two
+// implementations can share.  The oracle therefore takes the one value every order approximates: the EXACT sum of the terms,
+// rounded once -- accumulated as an unevaluated pair hi + lo (Knuth's TwoSum keeps the rounding error of every addition; the
+// pair is exact to ~2^-100 of the sum).  prost_amd/csrc/reduce.hpp accumulates the same way in every kernel variant, which is
+// what makes ADMM / CGLS and normest comparable bit for bit.  The value stays within the rounding error of any summation
+// order; the pins of DESIGN.md section 2 (normest against the compiled reference: rel 1e-6) are unchanged.
+// Needs -ffp-contract=off (oracle/Makefile).
+// ---------------------------------------------------------------------------------
+struct ExactSum {
+  double hi = 0., lo = 0.;
+  inline void add(double t) {
+    const double s = hi + t;
+    const double bb = s - hi;
+    const double e = (hi - (s - bb)) + (t - bb);
+    hi = s; lo += e;
+  }
+  inline double value() const { return hi + lo; }
+};
+template <class T> inline double exact_sum_sq(const T* v, size_t n) {
+  ExactSum a;
+  for (size_t i = 0; i < n; i++) a.add((double)v[i] * (double)v[i]);
+  return a.value();
+}
+
+// ---------------------------------------------------------------------------------
 // glibc rand() (TYPE_3, r[i] = r[i-3] + r[i-31]); normest seeds from std::rand()
 // with srand never called (problem.cu:435) -> seed 1 in a fresh process.
 // ---------------------------------------------------------------------------------
@@ -1067,13 +1095,12 @@ struct Problem : ProblemBase {
       for (size_t i = 0; i < n; i++) x_temp[i] = std::sqrt(right[i]) * x[i];
       linop_eval(Ax_temp.data(), x_temp.data());
       for (size_t i = 0; i < m; i++) Ax[i] = std::sqrt(left[i]) * Ax_temp[i];
-      T s = 0; for (size_t i = 0; i < m; i++) s = s + Ax[i] * Ax[i];
-      T norm_Ax = std::sqrt(s);
+      // (the reference reduces in T with thrust, order unspecified on the device: ExactSum, then narrowed to T)
+      T norm_Ax = (T)std::sqrt(exact_sum_sq(Ax.data(), m));
       for (size_t i = 0; i < m; i++) Ax_temp[i] = std::sqrt(left[i]) * Ax[i];
       linop_eval_adjoint(x_temp.data(), Ax_temp.data());
       for (size_t i = 0; i < n; i++) x[i] = std::sqrt(right[i]) * x_temp[i];
-      s = 0; for (size_t i = 0; i < n; i++) s = s + x[i] * x[i];
-      T norm_x = std::sqrt(s);
+      T norm_x = (T)std::sqrt(exact_sum_sq(x.data(), n));
       norm = norm_x / norm_Ax;
       if ((double)std::abs(norm_prev - norm) < (double)(tol * norm)) break;
       for (size_t i = 0; i < n; i++) x[i] = x[i] / norm_x;
@@ -1327,17 +1354,11 @@ struct Solver : SolverBase {
     }
   }
   // cgls nrm2: thrust transform_reduce in double (cgls.hpp:152-170)
-  static double nrm2d(const std::vector<T>& v, size_t n) {
-    double s = 0.; for (size_t i = 0; i < n; i++) s = s + (double)v[i] * (double)v[i];
-    return std::sqrt(s);
-  }
+  static double nrm2d(const std::vector<T>& v, size_t n) { return std::sqrt(exact_sum_sq(v.data(), n)); }     // order-independent: ExactSum
   // cublas<t>nrm2 stand-in for the ADMM residuals (backend_admm.cu:40-50): cuBLAS is not
   // under /root/reference; restated as sqrt of the sum of squares accumulated in double,
   // narrowed to T for T=float as the reference does (result_float).
-  static double blas_nrm2(const std::vector<T>& v, size_t n) {
-    double s = 0.; for (size_t i = 0; i < n; i++) s += (double)v[i] * (double)v[i];
-    return (double)(T)std::sqrt(s);
-  }
+  static double blas_nrm2(const std::vector<T>& v, size_t n) { return (double)(T)std::sqrt(exact_sum_sq(v.data(), n)); }
   // cgls::Solve (include/prost/cgls.hpp:222-371)
   int cgls_solve(int m, int n, const std::vector<T>& b, std::vector<T>& xs, double shift, double tol, int maxit,
                  std::vector<T>& p, std::vector<T>& q, std::vector<T>& r, std::vector<T>& s, int& iterations) {

@@ -2,6 +2,7 @@
 // (behaviour of the reference's src/backend/backend_admm.cu and include/prost/cgls.hpp; the
 // cuBLAS nrm2/axpy and thrust functors are the prost_hip_nrm2 / _axpy / _admm_elem kernels).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <limits>
 
@@ -45,6 +46,7 @@ void BackendADMM<T>::Initialize() {
   CheckHip(prost_hip_malloc(&cg_state_, records * prost_hip_cgls_state_bytes()), "malloc");
   CheckHip(prost_hip_memset(cg_state_, 0, records * prost_hip_cgls_state_bytes(), CurrentStream()), "memset");
   fused_rounds_ = false;
+  pixel_rounds_ = false;
   fused_op_.nblocks = 0;
   cg_result_index_ = 0;
   if (opts_.device_cg && opts_.fused_rounds && !opts_.cg_graph) DescribeOperator();
@@ -73,7 +75,7 @@ void BackendADMM<T>::Release() {
   if (cg_done_host_) { prost_hip_host_free(cg_done_host_); cg_done_host_ = nullptr; }
   for (void* e : ev_) prost_hip_event_destroy(e);
   ev_.clear(); ev_used_ = 0;
-  x_half_.clear(); z_half_.clear(); x_proj_.clear(); z_proj_.clear(); x_dual_.clear(); z_dual_.clear(); temp1_.clear(); temp2_.clear(); temp3_.clear(); tmp_n_.clear(); tmp_m_.clear();
+  x_half_.clear(); z_half_.clear(); x_proj_.clear(); z_proj_.clear(); x_dual_.clear(); z_dual_.clear(); temp1_.clear(); temp2_.clear(); temp3_.clear(); tmp_n_.clear(); tmp_m_.clear(); cg_p_alt_.clear(); cg_r_alt_.clear();
 }
 
 template <typename T>
@@ -190,6 +192,43 @@ void BackendADMM<T>::DescribeOperator() {
   if (prost_hip_fused_op_supported(&op, this->problem_->nrows(), this->problem_->ncols()) != 1) return;
   fused_op_ = op;
   fused_rounds_ = true;
+  // K = [D ; gradient2d(nx, ny, L)] (either order) with D coupling the L channels of one pixel, or the gradient alone: the CG rounds
+  // of two launches (prost_hip_cgls_pixel_round_*)
+  if (!opts_.pixel_rounds || blocks.size() > 2) return;
+  const prost_hip_op_block* grad = nullptr; const prost_hip_op_block* dblk = nullptr;
+  size_t planes = 0;
+  for (size_t i = 0; i < blocks.size(); i++) {
+    BlockDesc bd;
+    blocks[i]->describe(bd);
+    if (op.block[i].kind == PROST_OP_GRAD2D && !grad) grad = &op.block[i];
+    else if (op.block[i].kind == PROST_OP_CSR && bd.pointwise_planes > 0 && !dblk) { dblk = &op.block[i]; planes = bd.pointwise_planes; }
+    else return;
+  }
+  if (!grad || grad->col != 0 || grad->L < 1 || grad->L > 3) return;
+  prost_hip_pixel_op po;
+  po.nx = grad->nx; po.ny = grad->ny; po.L = (int)grad->L; po.has_d = dblk ? 1 : 0;
+  po.d_first = dblk && dblk < grad ? 1 : 0;                 // position in the block LIST (the order K^T t is accumulated in)
+  po.g_row = grad->row; po.d_row = dblk ? dblk->row : 0; po.w = dblk ? dblk->val : nullptr;
+  po.p_alt = po.r_alt = nullptr;
+  if (dblk && (dblk->col != 0 || planes != grad->L || dblk->nrows != grad->nx * grad->ny)) return;
+  // Sigma must be ONE value on the gradient rows (it is for the alpha-preconditioners: every row of a gradient block sums to 2,
+  // block_gradient2d.cu:154-158; user-supplied scaling vectors may differ): the rounds read it as a scalar
+  {
+    const std::vector<T>& sl = this->problem_->scaling_left_host();
+    const size_t g0 = (size_t)grad->row, g1 = g0 + (size_t)grad->nrows;
+    if (sl.size() < g1) return;
+    const T v0 = sl[g0];
+    std::atomic<bool> same(true);
+    ParallelFor(g1 - g0, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) if (sl[g0 + i] != v0) { same.store(false); return; } });
+    if (!same.load()) return;
+    po.sigma_grad = (double)v0;
+  }
+  if (prost_hip_pixel_op_supported(&po, this->problem_->nrows(), this->problem_->ncols(), sizeof(T) == 4 ? 0 : 1) != 1) return;
+  cg_p_alt_.resize(this->problem_->ncols());
+  cg_r_alt_.resize(this->problem_->nrows());
+  po.p_alt = cg_p_alt_.data(); po.r_alt = cg_r_alt_.data();
+  pixel_op_ = po;
+  pixel_rounds_ = true;
 }
 
 /// The same solve with the CG scalars resident on the device (prost_hip_cgls_stage_*): no host round
@@ -228,13 +267,22 @@ void BackendADMM<T>::CglsDevice(const device_vector<T>& b, device_vector<T>& x, 
       if (*static_cast<volatile int*>(cg_done_host_) == d.epoch) break;
       if (sample && k == (maxit > 1 ? 1 : 0)) {
         while (ev_.size() < ev_used_ + 8) { void* e; CheckHip(prost_hip_event_create(&e), "event_create"); ev_.push_back(e); }
-        CheckHip(Api<T>::cgls_round_timed(&d, &fused_op_, k, ev_.data() + ev_used_, st), "cgls_round");
+        if (pixel_rounds_) {
+          // two launches per round: events 0-3 of the group of eight are used, 4-7 stay unrecorded (KernelTimes reads two kernels)
+          CheckHip(Api<T>::cgls_pixel_round_timed(&d, &pixel_op_, k, ev_.data() + ev_used_, st), "cgls_pixel_round");
+        } else {
+          CheckHip(Api<T>::cgls_round_timed(&d, &fused_op_, k, ev_.data() + ev_used_, st), "cgls_round");
+        }
         ev_used_ += 8;
+      } else if (pixel_rounds_) {
+        CheckHip(Api<T>::cgls_pixel_round(&d, &pixel_op_, k, st), "cgls_pixel_round");
       } else {
         CheckHip(Api<T>::cgls_round(&d, &fused_op_, k, st), "cgls_round");
       }
       queued++;
     }
+    // the last queued round's beta / stopping test -> record `queued` (the four-launch rounds write it themselves)
+    if (pixel_rounds_ && queued > 0) CheckHip(Api<T>::cgls_pixel_close(&d, &pixel_op_, queued - 1, st), "cgls_pixel_close");
     if (this->time_kernels_) rounds_launched_ += (size_t)queued;
     cg_result_index_ = queued;
     cg_iters_valid_ = false;
@@ -283,17 +331,20 @@ template <typename T>
 void BackendADMM<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& out) {
   out.clear();
   if (ev_used_ == 0) return;
-  CheckHip(prost_hip_event_synchronize(ev_[ev_used_ - 1]), "event_synchronize");
-  static const char* const names[4] = {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"};
+  CheckHip(prost_hip_event_synchronize(ev_[pixel_rounds_ ? ev_used_ - 5 : ev_used_ - 1]), "event_synchronize");      // the last RECORDED event of the last group
+  static const char* const names4[4] = {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"};
+  static const char* const names2[4] = {"cg_pixel_pq_kernel", "cg_pixel_xrs_kernel", "", ""};
+  const char* const* names = pixel_rounds_ ? names2 : names4;
+  const int kernels = pixel_rounds_ ? 2 : 4;
   double sum[4] = {0, 0, 0, 0};
   const size_t samples = ev_used_ / 8;
   for (size_t s = 0; s < samples; s++)
-    for (int k = 0; k < 4; k++) {                       // the kernel's own begin / end stamps (hipExtLaunchKernel): no marker in between
+    for (int k = 0; k < kernels; k++) {                       // the kernel's own begin / end stamps (hipExtLaunchKernel): no marker in between
       float ms = 0;
       CheckHip(prost_hip_event_elapsed_ms(ev_[8 * s + 2 * k], ev_[8 * s + 2 * k + 1], &ms), "event_elapsed");
       sum[k] += ms;
     }
-  for (int k = 0; k < 4; k++) out.push_back({names[k], sum[k] / (double)samples, samples, rounds_launched_, 0, 0});
+  for (int k = 0; k < kernels; k++) out.push_back({names[k], sum[k] / (double)samples, samples, rounds_launched_, 0, 0});
   ev_used_ = 0; rounds_launched_ = 0; solves_ = 0;
 }
 
@@ -503,7 +554,7 @@ void BackendADMM<T>::current_solution(std::vector<T>& primal_x, std::vector<T>& 
 template <typename T>
 size_t BackendADMM<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
-  return (4 * (n + m) + std::max(m, n)) * sizeof(T);
+  return (4 * (n + m) + std::max(m, n)) * sizeof(T) + (cg_p_alt_.size() + cg_r_alt_.size()) * sizeof(T);      // (+ the second p / r buffers of the two-launch rounds)
 }
 
 template class BackendADMM<float>;

@@ -353,6 +353,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       if (prost_value_field(d, "device_cg")) o.device_cg = GetScalarFromField(d, "device_cg") > 0.;
       if (prost_value_field(d, "cg_graph")) o.cg_graph = GetScalarFromField(d, "cg_graph") > 0.;
       if (prost_value_field(d, "fused_rounds")) o.fused_rounds = GetScalarFromField(d, "fused_rounds") > 0.;
+      if (prost_value_field(d, "pixel_rounds")) o.pixel_rounds = GetScalarFromField(d, "pixel_rounds") > 0.;
       return new BackendADMM<T>(o);
     };
   }

@@ -66,6 +66,9 @@ template <typename T> struct Api;
     static constexpr auto cgls_round = prost_hip_cgls_round_##S;                  \
     static constexpr auto cgls_round_timed = prost_hip_cgls_round_timed_##S;      \
     static constexpr auto cgls_init_fused = prost_hip_cgls_init_fused_##S;        \
+    static constexpr auto cgls_pixel_round = prost_hip_cgls_pixel_round_##S;      \
+    static constexpr auto cgls_pixel_round_timed = prost_hip_cgls_pixel_round_timed_##S; \
+    static constexpr auto cgls_pixel_close = prost_hip_cgls_pixel_close_##S;      \
     static constexpr auto admm_fused_stage = prost_hip_admm_fused_stage_##S;      \
     static constexpr auto admm_stage = prost_hip_admm_stage_##S;                  \
     static constexpr auto normest_stage = prost_hip_normest_stage_##S;            \

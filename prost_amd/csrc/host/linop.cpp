@@ -187,11 +187,32 @@ void BlockSparse<T>::Initialize() {
     p.on = true;
   };
   DetectGradient2D();
+  DetectPointwise();
   build(pat_, this->nrows(), host_ptr_, host_ind_, host_val_);
   build(pat_t_, this->ncols(), host_ptr_t_, host_ind_t_, host_val_t_);
   // the CSR arrays of a product that runs from row patterns stay on the host (a 4096^2 gradient: 0.5 GB of upload each)
   if (!pat_.on) { ind_ = host_ind_; ptr_ = host_ptr_; val_ = host_val_; }
   if (!pat_t_.on) { ind_t_ = host_ind_t_; ptr_t_ = host_ptr_t_; val_t_ = host_val_t_; }
+}
+/// K couples the channels of one pixel: nrows x (L nrows), row i = L entries at columns i, i + nrows, ..., i + (L - 1) nrows -- the
+/// shape of [diag(Ix) diag(Iy)] (a warp / data-term matrix of a multi-channel model).  The two-launch CG rounds of the ADMM backend
+/// (prost_hip_cgls_pixel_round) read such a block as a per-pixel table of L values.
+template <typename T>
+void BlockSparse<T>::DetectPointwise() {
+  pointwise_planes_ = 0;
+  const size_t m = this->nrows(), n = this->ncols();
+  if (m == 0 || n % m != 0 || host_ptr_.size() != m + 1) return;
+  const size_t L = n / m;
+  if (L < 1 || L > 4 || nnz_ != L * m) return;
+  std::atomic<bool> ok(true);
+  ParallelFor(m, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi && ok.load(std::memory_order_relaxed); i++) {
+      if ((size_t)host_ptr_[i] != i * L || (size_t)host_ptr_[i + 1] != (i + 1) * L) { ok.store(false); return; }
+      for (size_t c = 0; c < L; c++)
+        if ((size_t)host_ind_[i * L + c] != i + c * m) { ok.store(false); return; }
+    }
+  });
+  if (ok.load()) pointwise_planes_ = L;
 }
 template <typename T>
 void BlockSparse<T>::Release() {

@@ -34,13 +34,15 @@ struct CgState {
 };
 
 enum { kRegionX = 0, kRegionS, kRegionP, kRegionQ, kRegions };          // partial-sum regions of the workspace
-__host__ __device__ inline double* region(double* ws, int r) { return ws + (size_t)r * 2 * kReduceBlocks; }
+// a region holds one slot per workgroup: (hi, lo) of ONE sum, compact (stride 2: kernels with a single sum), or
+// (a.hi, a.lo, b.hi, b.lo) (stride 4: the staged kernels and the residual stages, which carry two sums) -- reduce.hpp, dd_t
+__host__ __device__ inline double* region(double* ws, int r) { return ws + (size_t)r * 4 * kReduceBlocks; }
 
 template <class T, int VEC, class F>
 __global__ void __launch_bounds__(kBlock) cg_stage_kernel(F f, size_t n0, size_t n1, const CgState* st, double* ws) {
   if (F::kSkipWhenDone && st->done) return;
   f.load(st);
-  double sa = 0, sb = 0;
+  dd_t sa{0.0, 0.0}, sb{0.0, 0.0};
   const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x, stride = (size_t)gridDim.x * kBlock;
   {
     const size_t nv = n0 / VEC;
@@ -53,86 +55,53 @@ __global__ void __launch_bounds__(kBlock) cg_stage_kernel(F f, size_t n0, size_t
     if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < n1 - nv * VEC) f.template range1<1>(nv * VEC + threadIdx.x, sa, sb);
   }
   if (F::kRegion >= 0) {
-    block_sum2_store(sa, sb, region(ws, F::kRegion), blockIdx.x);
-    if (F::kRegion2 >= 0 && threadIdx.x == 0) region(ws, F::kRegion2)[2 * blockIdx.x] = region(ws, F::kRegion)[2 * blockIdx.x];
+    block_dd_store2(sa, sb, region(ws, F::kRegion), blockIdx.x);
+    if (F::kRegion2 >= 0 && threadIdx.x == 0) {
+      region(ws, F::kRegion2)[4 * blockIdx.x] = region(ws, F::kRegion)[4 * blockIdx.x];
+      region(ws, F::kRegion2)[4 * blockIdx.x + 1] = region(ws, F::kRegion)[4 * blockIdx.x + 1];
+    }
   }
 }
 
-// one workgroup: sum of the first component of `g` partial pairs, fixed association order
-// (loads in batches of eight per thread, all issued before the first add: a loop of load-add-load-add pays one cache latency
-// per iteration, and every workgroup of the consuming kernels sits in this fold before it can start)
-__device__ __forceinline__ double fold_strided(const double* __restrict__ part, unsigned g, unsigned stride) {
-  double a = 0;
-  for (unsigned base = threadIdx.x; base < g; base += 8 * kBlock) {
-    double v[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const unsigned i = base + k * kBlock; v[k] = i < g ? part[(size_t)stride * i] : 0.0; }
-#pragma unroll
-    for (int k = 0; k < 8; k++) a += v[k];
-  }
-  return a;
-}
-__device__ __forceinline__ double fold_region(const double* part, unsigned g, unsigned stride = 2) {
-  __shared__ double s_w[kBlock / kWave];
-  double a = fold_strided(part, g, stride);
-  a = wave_sum(a);
-  __syncthreads();
-  if ((threadIdx.x & (kWave - 1)) == 0) s_w[threadIdx.x / kWave] = a;
-  __syncthreads();
-  double t = 0;
-#pragma unroll
-  for (int w = 0; w < kBlock / kWave; w++) t += s_w[w];
-  return t;
-}
-
-// the same for two COMPACT arrays (one double per workgroup) at once: one pass, both sets of loads in flight together, one pair
-// of barriers; association order per array as in fold_region
-__device__ __forceinline__ void fold_region2(const double* __restrict__ pa, unsigned ga, const double* __restrict__ pb, unsigned gb, double& ra, double& rb) {
-  __shared__ double s_a[kBlock / kWave], s_b[kBlock / kWave];
-  double a = 0, b = 0;
+// two folds at once (reduce.hpp, fold_dd): both sets of loads in flight together, one pair of barriers; every thread of every
+// workgroup of every kernel obtains the same two doubles (order-independent sums)
+__device__ __forceinline__ void fold_dd2(const double* __restrict__ pa, unsigned ga, unsigned sa_, const double* __restrict__ pb, unsigned gb, unsigned sb_,
+                                         double& ra, double& rb) {
+  __shared__ dd_t s_fa[kBlock / kWave], s_fb[kBlock / kWave];
+  dd_t a{0.0, 0.0}, b{0.0, 0.0};
   const unsigned gmax = ga > gb ? ga : gb;
-  for (unsigned base = threadIdx.x; base < gmax; base += 8 * kBlock) {
-    double va[8], vb[8];
+  for (unsigned base = threadIdx.x; base < gmax; base += 4 * kBlock) {
+    double ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const unsigned i = base + k * kBlock; va[k] = i < ga ? pa[i] : 0.0; vb[k] = i < gb ? pb[i] : 0.0; }
+    for (int k = 0; k < 4; k++) {
+      const unsigned i = base + k * kBlock;
+      ah[k] = i < ga ? pa[(size_t)sa_ * i] : 0.0; al[k] = i < ga ? pa[(size_t)sa_ * i + 1] : 0.0;
+      bh[k] = i < gb ? pb[(size_t)sb_ * i] : 0.0; bl[k] = i < gb ? pb[(size_t)sb_ * i + 1] : 0.0;
+    }
 #pragma unroll
-    for (int k = 0; k < 8; k++) { a += va[k]; b += vb[k]; }
+    for (int k = 0; k < 4; k++) { a = dd_add(a, dd_t{ah[k], al[k]}); b = dd_add(b, dd_t{bh[k], bl[k]}); }
   }
-  a = wave_sum(a);
-  b = wave_sum(b);
+  a = wave_sum_dd(a);
+  b = wave_sum_dd(b);
   __syncthreads();
-  if ((threadIdx.x & (kWave - 1)) == 0) { s_a[threadIdx.x / kWave] = a; s_b[threadIdx.x / kWave] = b; }
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_fa[threadIdx.x / kWave] = a; s_fb[threadIdx.x / kWave] = b; }
   __syncthreads();
-  double ta = 0, tb = 0;
+  dd_t ta = s_fa[0], tb = s_fb[0];
 #pragma unroll
-  for (int w = 0; w < kBlock / kWave; w++) { ta += s_a[w]; tb += s_b[w]; }
-  ra = ta; rb = tb;
-}
-
-// one double per workgroup, compact (the sums the fused rounds fold in every workgroup of the next kernel)
-__device__ __forceinline__ void block_sum1_store(double a, double* __restrict__ partial, unsigned slot) {
-  __shared__ double s_c[kBlock / kWave];
-  a = wave_sum(a);
-  if ((threadIdx.x & (kWave - 1)) == 0) s_c[threadIdx.x / kWave] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / kWave; w++) t += s_c[w];
-    partial[slot] = t;
-  }
+  for (int w = 1; w < kBlock / kWave; w++) { ta = dd_add(ta, s_fa[w]); tb = dd_add(tb, s_fb[w]); }
+  ra = ta.hi; rb = tb.hi;
 }
 
 enum { kScalarsInitX = 0, kScalarsInitS, kScalarsAlpha, kScalarsBeta };
-struct ScalarArgs { double shift, tol, eps; unsigned g0, g1; int* host_done; int epoch; unsigned stride; };   // stride 2: partial pairs, 1: compact
+struct ScalarArgs { double shift, tol, eps; unsigned g0, g1; int* host_done; int epoch; unsigned stride; };   // stride (doubles per slot) 4: two-sum slots, 2: compact
 
 // the scalar recurrences of cgls.hpp, in double, values narrowed to T where the reference narrows them
 template <class T, int WHICH>
 __global__ void __launch_bounds__(kBlock) cg_scalar_kernel(CgState* stp, const double* ws, ScalarArgs a) {
   if (WHICH >= kScalarsAlpha && stp->done) return;
-  const double s0 = fold_region(region(const_cast<double*>(ws), WHICH == kScalarsInitX ? kRegionX : WHICH == kScalarsAlpha ? kRegionQ : kRegionS), a.g0, a.stride);
-  const double s1 = WHICH == kScalarsAlpha ? fold_region(region(const_cast<double*>(ws), kRegionP), a.g1)
-                  : WHICH == kScalarsBeta ? fold_region(region(const_cast<double*>(ws), kRegionX), a.g1) : 0.;
+  const double s0 = fold_dd(region(const_cast<double*>(ws), WHICH == kScalarsInitX ? kRegionX : WHICH == kScalarsAlpha ? kRegionQ : kRegionS), a.g0, a.stride);
+  const double s1 = WHICH == kScalarsAlpha ? fold_dd(region(const_cast<double*>(ws), kRegionP), a.g1, 4)
+                  : WHICH == kScalarsBeta ? fold_dd(region(const_cast<double*>(ws), kRegionX), a.g1, 4) : 0.;
   if (threadIdx.x != 0) return;
   CgState& st = *stp;
   if (WHICH == kScalarsInitX) {                        // cgls.hpp:243-249, :281-282
@@ -174,7 +143,7 @@ template <class T> struct InitX {
   static constexpr int kRegion = kRegionX, kRegion2 = -1;
   const T* x; const T* tau; T* t; T* s; T negshift;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T xv[V], dv[V], tv[V], sv[V];
     ldv<T, V>(x + i, xv); ldv<T, V>(tau + i, dv);
 #pragma unroll
@@ -182,11 +151,11 @@ template <class T> struct InitX {
       const T sq = t_sqrt(dv[j]);
       tv[j] = sq * xv[j];
       sv[j] = (negshift / ((T)1 * sq)) * xv[j];
-      sa += (double)xv[j] * (double)xv[j];
+      dd_acc(sa, (double)xv[j] * (double)xv[j]);
     }
     stv<T, V>(t + i, tv); stv<T, V>(s + i, sv);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // INIT_R (m):  r = (1 / (-1 sqrt(Sigma))) b   [gemv2 of r = b - A x on the copy r = b]
 template <class T> struct InitR {
@@ -194,14 +163,14 @@ template <class T> struct InitR {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* b; const T* sigma; T* r;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T bv[V], dv[V], rv[V];
     ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) rv[j] = ((T)1 / ((T)-1 * t_sqrt(dv[j]))) * bv[j];
     stv<T, V>(r + i, rv);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // INIT_R2 (m), after r += K t:  r = normx > 0 ? -1 sqrt(Sigma) r : b  (the reference skips the product for
 //              x = 0, cgls.hpp:250);  t = sqrt(Sigma) r  [gemv1 of s = A'r - shift x]
@@ -210,7 +179,7 @@ template <class T> struct InitR2 {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* b; const T* sigma; T* r; T* t; bool nonzero;
   __device__ void load(const CgState* st) { nonzero = st->normx > 0.; }
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T bv[V], dv[V], rv[V], tv[V];
     ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv); ldv<T, V>(r + i, rv);
 #pragma unroll
@@ -221,7 +190,7 @@ template <class T> struct InitR2 {
     }
     stv<T, V>(r + i, rv); stv<T, V>(t + i, tv);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // INIT_S (n), after s += K^T t:  s = 1 sqrt(Tau) s;  p = s;  t = sqrt(Tau) p [gemv1 of q = A p];
 //              partials of |s|^2 = |p|^2  (cgls.hpp:263-283)
@@ -230,7 +199,7 @@ template <class T> struct InitS {
   static constexpr int kRegion = kRegionS, kRegion2 = kRegionP;
   T* s; T* p; T* t; const T* tau;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T sv[V], dv[V], tv[V];
     ldv<T, V>(s + i, sv); ldv<T, V>(tau + i, dv);
 #pragma unroll
@@ -238,11 +207,11 @@ template <class T> struct InitS {
       const T sq = t_sqrt(dv[j]);
       sv[j] = (T)1 * sq * sv[j];
       tv[j] = sq * sv[j];
-      sa += (double)sv[j] * (double)sv[j];
+      dd_acc(sa, (double)sv[j] * (double)sv[j]);
     }
     stv<T, V>(s + i, sv); stv<T, V>(p + i, sv); stv<T, V>(t + i, tv);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // STEP_Q (m), after q = K t:  q = 1 sqrt(Sigma) q;  partials of |q|^2  (cgls.hpp:287-296)
 template <class T> struct StepQ {
@@ -250,17 +219,17 @@ template <class T> struct StepQ {
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
   T* q; const T* sigma;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T qv[V], dv[V];
     ldv<T, V>(q + i, qv); ldv<T, V>(sigma + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) {
       qv[j] = (T)1 * t_sqrt(dv[j]) * qv[j];
-      sa += (double)qv[j] * (double)qv[j];
+      dd_acc(sa, (double)qv[j] * (double)qv[j]);
     }
     stv<T, V>(q + i, qv);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // STEP_XR:  (n) x = alpha p + x;  s = (-shift / (1 sqrt(Tau))) x;  partials of |x|^2
 //           (m) r = -alpha q + r;  t = sqrt(Sigma) r      (cgls.hpp:311-325, :352-354)
@@ -270,19 +239,19 @@ template <class T> struct StepXR {
   T* x; const T* p; T* s; const T* tau; T* r; const T* q; const T* sigma; T* t; T negshift;     // s == nullptr: the consumer forms it from x
   T alpha, neg_alpha;
   __device__ void load(const CgState* st) { alpha = (T)st->alpha; neg_alpha = (T)st->neg_alpha; }
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T xv[V], pv[V], dv[V], sv[V];
     ldv<T, V>(x + i, xv); ldv<T, V>(p + i, pv); ldv<T, V>(tau + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) {
       xv[j] = alpha * pv[j] + xv[j];
       sv[j] = (negshift / ((T)1 * t_sqrt(dv[j]))) * xv[j];
-      sa += (double)xv[j] * (double)xv[j];
+      dd_acc(sa, (double)xv[j] * (double)xv[j]);
     }
     stv<T, V>(x + i, xv);
     if (s) stv<T, V>(s + i, sv);
   }
-  template <int V> __device__ void range1(size_t i, double&, double&) const {
+  template <int V> __device__ void range1(size_t i, dd_t&, dd_t&) const {
     T rv[V], qv[V], dv[V], tv[V];
     ldv<T, V>(r + i, rv); ldv<T, V>(q + i, qv); ldv<T, V>(sigma + i, dv);
 #pragma unroll
@@ -299,17 +268,17 @@ template <class T> struct StepS {
   static constexpr int kRegion = kRegionS, kRegion2 = -1;
   T* s; const T* tau;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T sv[V], dv[V];
     ldv<T, V>(s + i, sv); ldv<T, V>(tau + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) {
       sv[j] = (T)1 * t_sqrt(dv[j]) * sv[j];
-      sa += (double)sv[j] * (double)sv[j];
+      dd_acc(sa, (double)sv[j] * (double)sv[j]);
     }
     stv<T, V>(s + i, sv);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // STEP_P (n):  p = beta p + s;  t = sqrt(Tau) p [gemv1 of the next q = A p];  partials of |p|^2  (cgls.hpp:341-351, :287-296)
 template <class T> struct StepP {
@@ -317,18 +286,18 @@ template <class T> struct StepP {
   static constexpr int kRegion = kRegionP, kRegion2 = -1;
   T* p; const T* s; T* t; const T* tau; T beta;
   __device__ void load(const CgState* st) { beta = (T)st->beta; }
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T pv[V], sv[V], dv[V], tv[V];
     ldv<T, V>(p + i, pv); ldv<T, V>(s + i, sv); ldv<T, V>(tau + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) {
       pv[j] = beta * pv[j] + sv[j];
       tv[j] = t_sqrt(dv[j]) * pv[j];
-      sa += (double)pv[j] * (double)pv[j];
+      dd_acc(sa, (double)pv[j] * (double)pv[j]);
     }
     stv<T, V>(p + i, pv); stv<T, V>(t + i, tv);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 
 // ---- ADMM outer iteration (BackendADMM::PerformIteration, backend_admm.cu:355-665) ---------------
@@ -343,7 +312,7 @@ template <class T> struct AdmmPreX {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* x_half; T* x_proj; const T* x_dual; const T* tau; T* temp1; T* temp3; T alpha;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T a[V], b[V], c[V], d[V], w[V], o[V], t[V];
     ldv<T, V>(x_half + i, a); ldv<T, V>(x_proj + i, b); ldv<T, V>(x_dual + i, c); ldv<T, V>(tau + i, d); ldv<T, V>(temp3 + i, w);
 #pragma unroll
@@ -354,7 +323,7 @@ template <class T> struct AdmmPreX {
     }
     stv<T, V>(temp1 + i, o); stv<T, V>(x_proj + i, w); stv<T, V>(temp3 + i, t);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // PRE_Z (m):  temp2 = sqrt(Sigma) (z_half + z_dual)                              temp2_functor :70-81
 //             z_dual = (1 / (-1 sqrt(Sigma))) temp2                              gemv_functor2 of z_dual = temp2 - A temp1 (:399)
@@ -363,7 +332,7 @@ template <class T> struct AdmmPreZ {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* z_half; T* z_dual; const T* sigma; T* temp2;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T a[V], b[V], d[V], o[V], z[V];
     ldv<T, V>(z_half + i, a); ldv<T, V>(z_dual + i, b); ldv<T, V>(sigma + i, d);
 #pragma unroll
@@ -374,7 +343,7 @@ template <class T> struct AdmmPreZ {
     }
     stv<T, V>(temp2 + i, o); stv<T, V>(z_dual + i, z);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // PRE_Z2 (m), after z_dual += K temp3:  z_dual = -1 sqrt(Sigma) z_dual            gemv_functor3 of :399
 template <class T> struct AdmmPreZ2 {
@@ -382,14 +351,14 @@ template <class T> struct AdmmPreZ2 {
   static constexpr int kRegion = -1, kRegion2 = -1;
   T* z_dual; const T* sigma;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T z[V], d[V];
     ldv<T, V>(z_dual + i, z); ldv<T, V>(sigma + i, d);
 #pragma unroll
     for (int j = 0; j < V; j++) z[j] = (T)-1 * t_sqrt(d[j]) * z[j];
     stv<T, V>(z_dual + i, z);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // POST_X (n), after the CG solve:  temp3 = x_proj (:437);  x_proj = sqrt(Tau) (x_proj + temp1)   x_proj_functor :447-456
 template <class T> struct AdmmPostX {
@@ -397,14 +366,14 @@ template <class T> struct AdmmPostX {
   static constexpr int kRegion = -1, kRegion2 = -1;
   T* x_proj; const T* temp1; const T* tau; T* temp3;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T x[V], a[V], d[V], o[V];
     ldv<T, V>(x_proj + i, x); ldv<T, V>(temp1 + i, a); ldv<T, V>(tau + i, d);
 #pragma unroll
     for (int j = 0; j < V; j++) o[j] = t_sqrt(d[j]) * (x[j] + a[j]);
     stv<T, V>(temp3 + i, x); stv<T, V>(x_proj + i, o);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // POST_XZ, after z_proj = K x_proj:
 //   (n) x_dual = temp1 sqrt(Tau) - x_proj  x_dual_functor :464-477;  temp1 = x_proj - x_dual  (prox_g argument :499)
@@ -414,7 +383,7 @@ template <class T> struct AdmmPostXZ {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* x_proj; T* x_dual; T* temp1; const T* tau; const T* z_proj; T* z_dual; T* temp2; const T* sigma;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T a[V], b[V], d[V], u[V], o[V];
     ldv<T, V>(temp1 + i, a); ldv<T, V>(x_proj + i, b); ldv<T, V>(tau + i, d);
 #pragma unroll
@@ -424,7 +393,7 @@ template <class T> struct AdmmPostXZ {
     }
     stv<T, V>(x_dual + i, u); stv<T, V>(temp1 + i, o);
   }
-  template <int V> __device__ void range1(size_t i, double&, double&) const {
+  template <int V> __device__ void range1(size_t i, dd_t&, dd_t&) const {
     T a[V], b[V], d[V], u[V], o[V];
     ldv<T, V>(temp2 + i, a); ldv<T, V>(z_proj + i, b); ldv<T, V>(sigma + i, d);
 #pragma unroll
@@ -448,7 +417,7 @@ template <class T> struct AdmmResZ {
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
   T* kx; const T* z_half; const T* z_proj; const T* z_dual; const T* sigma; T rho;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double& sb) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t& sb) const {
     T k[V], h[V], pj[V], du[V], d[V], y[V];
     ldv<T, V>(kx + i, k); ldv<T, V>(z_half + i, h); ldv<T, V>(z_proj + i, pj); ldv<T, V>(z_dual + i, du); ldv<T, V>(sigma + i, d);
 #pragma unroll
@@ -456,13 +425,13 @@ template <class T> struct AdmmResZ {
       const T sq = t_sqrt(d[j]);
       const T pr = sq * ((T)1.0 * k[j] + (T)-1.0 * h[j]);      // temp2 = -z_half; temp2 += K x_half; scaled
       const T pv = sq * h[j];
-      sa += (double)pr * (double)pr;
-      sb += (double)pv * (double)pv;
+      dd_acc(sa, (double)pr * (double)pr);
+      dd_acc(sb, (double)pv * (double)pv);
       y[j] = get_dual<T>(rho, d[j], (T)1, h[j], pj[j], du[j]);
     }
     stv<T, V>(kx + i, y);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // RES_X (n), with kty = K^T y:  w = get_dual(x_half, x_proj, x_dual, Tau, -1);  |sqrt(Tau) w| (dual variable norm, :570-590)
 //             and |sqrt(Tau) (w + kty)| (dual residual, :596-616)
@@ -471,7 +440,7 @@ template <class T> struct AdmmResX {
   static constexpr int kRegion = kRegionP, kRegion2 = -1;
   const T* kty; const T* x_half; const T* x_proj; const T* x_dual; const T* tau; T rho;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double& sb) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t& sb) const {
     T k[V], h[V], pj[V], du[V], d[V];
     ldv<T, V>(kty + i, k); ldv<T, V>(x_half + i, h); ldv<T, V>(x_proj + i, pj); ldv<T, V>(x_dual + i, du); ldv<T, V>(tau + i, d);
 #pragma unroll
@@ -480,11 +449,11 @@ template <class T> struct AdmmResX {
       const T w = get_dual<T>(rho, d[j], (T)-1, h[j], pj[j], du[j]);
       const T dv = sq * w;
       const T dr = sq * ((T)1.0 * k[j] + w);
-      sa += (double)dr * (double)dr;
-      sb += (double)dv * (double)dv;
+      dd_acc(sa, (double)dr * (double)dr);
+      dd_acc(sb, (double)dv * (double)dv);
     }
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 
 // out4 = {sqrt(sum RES_Z a), sqrt(sum RES_Z b), sqrt(sum RES_X a), sqrt(sum RES_X b)}
@@ -492,7 +461,9 @@ template <class T> struct AdmmResX {
 __global__ void __launch_bounds__(kBlock) admm_residual_fold_kernel(double* out4, const double* ws, unsigned gz, unsigned gx) {
   const double* rz = region(const_cast<double*>(ws), kRegionQ);
   const double* rx = region(const_cast<double*>(ws), kRegionP);
-  const double a = fold_region(rz, gz), b = fold_region(rz + 1, gz), c = fold_region(rx, gx), d = fold_region(rx + 1, gx);
+  double a, b, c, d;                        // (two folds at a time: half the barriers of four separate ones)
+  fold_dd2(rz, gz, 4, rz + 2, gz, 4, a, b);
+  fold_dd2(rx, gx, 4, rx + 2, gx, 4, c, d);
   if (threadIdx.x == 0) { out4[0] = sqrt(a); out4[1] = sqrt(b); out4[2] = sqrt(c); out4[3] = sqrt(d); }
 }
 
@@ -505,14 +476,14 @@ template <class T> struct NormestA {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* x; const T* tau; T* x_temp; T norm_x; bool divide; const double* norm_from;
   __device__ void load(const CgState*) { if (norm_from) { norm_x = (T)*norm_from; divide = *norm_from != 0.0; } }
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T xv[V], dv[V], o[V];
     ldv<T, V>(x + i, xv); ldv<T, V>(tau + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) { const T t = divide ? xv[j] / norm_x : xv[j]; o[j] = t_sqrt(dv[j]) * t; }
     stv<T, V>(x_temp + i, o);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // NORMEST_B (m), after ax = K x_temp:  a = sqrt(Sigma) ax;  partials of |a|^2;  ax = sqrt(Sigma) a
 template <class T> struct NormestB {
@@ -520,19 +491,19 @@ template <class T> struct NormestB {
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
   T* ax; const T* sigma;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T v[V], dv[V];
     ldv<T, V>(ax + i, v); ldv<T, V>(sigma + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) {
       const T sq = t_sqrt(dv[j]);
       const T a = sq * v[j];
-      sa += (double)a * (double)a;
+      dd_acc(sa, (double)a * (double)a);
       v[j] = sq * a;
     }
     stv<T, V>(ax + i, v);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // NORMEST_C (n), after x_temp = K^T ax:  x = sqrt(Tau) x_temp;  partials of |x|^2
 template <class T> struct NormestC {
@@ -540,18 +511,18 @@ template <class T> struct NormestC {
   static constexpr int kRegion = kRegionP, kRegion2 = -1;
   T* x; const T* x_temp; const T* tau;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double& sa, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t& sa, dd_t&) const {
     T v[V], dv[V];
     ldv<T, V>(x_temp + i, v); ldv<T, V>(tau + i, dv);
 #pragma unroll
-    for (int j = 0; j < V; j++) { v[j] = t_sqrt(dv[j]) * v[j]; sa += (double)v[j] * (double)v[j]; }
+    for (int j = 0; j < V; j++) { v[j] = t_sqrt(dv[j]) * v[j]; dd_acc(sa, (double)v[j] * (double)v[j]); }
     stv<T, V>(x + i, v);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // out[0] = sqrt(sum of the first components of g partial pairs of region r); out may be pinned host memory
 __global__ void __launch_bounds__(kBlock) sqrt_fold_kernel(double* out, const double* ws, int r, unsigned g) {
-  const double a = fold_region(region(const_cast<double*>(ws), r), g);
+  const double a = fold_dd(region(const_cast<double*>(ws), r), g, 4);
   if (threadIdx.x == 0) out[0] = sqrt(a);
 }
 
@@ -573,7 +544,7 @@ static int launch_stage(const char* name, F f, size_t n0, size_t n1, bool vec, c
 }
 
 template <class T, int WHICH>
-static int launch_scalars(const prost_hip_cgls_desc* d, unsigned g0, unsigned g1, hipStream_t st, unsigned stride = 2) {
+static int launch_scalars(const prost_hip_cgls_desc* d, unsigned g0, unsigned g1, hipStream_t st, unsigned stride = 4) {
   ScalarArgs a{d->shift, d->tol, (double)std::numeric_limits<T>::epsilon(), g0, g1, d->host_done, d->epoch, stride};
   hipLaunchKernelGGL((cg_scalar_kernel<T, WHICH>), dim3(1), dim3(kBlock), 0, st, static_cast<CgState*>(d->state),
                      static_cast<const double*>(d->workspace), a);
@@ -877,7 +848,7 @@ template <class T, int VEC, bool ADJ, class E>
 __global__ void __launch_bounds__(kBlock) op_stage_kernel(FusedOpDev op, E e, const T* __restrict__ in, size_t count, const CgState* cur, double* ws) {
   if (E::kSkipWhenDone && cur->done) return;
   e.prologue(cur, ws);
-  double sa = 0, sb = 0;
+  dd_t sa{0.0, 0.0}, sb{0.0, 0.0};
   const unsigned lane = threadIdx.x & (kWave - 1);
   const size_t nv = VEC > 1 ? (count / ((size_t)VEC * kWave)) * kWave : count;          // vector groups in full wavefront steps
   for (size_t i0 = (size_t)blockIdx.x * kBlock + (threadIdx.x - lane); i0 < nv; i0 += (size_t)gridDim.x * kBlock) {
@@ -899,10 +870,13 @@ __global__ void __launch_bounds__(kBlock) op_stage_kernel(FusedOpDev op, E e, co
   }
   if (E::kRegion >= 0) {
     if (E::kPairs) {
-      block_sum2_store(sa, sb, region(ws, E::kRegion), blockIdx.x);
+      block_dd_store2(sa, sb, region(ws, E::kRegion), blockIdx.x);
     } else {
-      block_sum1_store(sa, region(ws, E::kRegion), blockIdx.x);
-      if (E::kRegion2 >= 0 && threadIdx.x == 0) region(ws, E::kRegion2)[blockIdx.x] = region(ws, E::kRegion)[blockIdx.x];
+      block_dd_store1(sa, region(ws, E::kRegion), blockIdx.x);
+      if (E::kRegion2 >= 0 && threadIdx.x == 0) {
+        region(ws, E::kRegion2)[2 * blockIdx.x] = region(ws, E::kRegion)[2 * blockIdx.x];
+        region(ws, E::kRegion2)[2 * blockIdx.x + 1] = region(ws, E::kRegion)[2 * blockIdx.x + 1];
+      }
     }
   }
 }
@@ -915,11 +889,11 @@ template <class T> struct EpiFwdQ {
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
   T* q; const T* sigma;
   __device__ void prologue(const CgState*, double*) {}
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double&) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t& sa, dd_t&) const {
     T dv[V], qv[V];
     ldv<T, V>(sigma + i, dv);
 #pragma unroll
-    for (int j = 0; j < V; j++) { qv[j] = (T)1 * t_sqrt(dv[j]) * kv[j]; sa += (double)qv[j] * (double)qv[j]; }
+    for (int j = 0; j < V; j++) { qv[j] = (T)1 * t_sqrt(dv[j]) * kv[j]; dd_acc(sa, (double)qv[j] * (double)qv[j]); }
     stv<T, V>(q + i, qv);
   }
 };
@@ -937,11 +911,11 @@ template <class T> struct EpiAdjS {
 #pragma unroll
     for (int j = 0; j < V; j++) v[j] = (negshift / ((T)1 * t_sqrt(dv[j]))) * xv[j];
   }
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double&) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t& sa, dd_t&) const {
     T dv[V], sv[V];
     ldv<T, V>(tau + i, dv);
 #pragma unroll
-    for (int j = 0; j < V; j++) { sv[j] = (T)1 * t_sqrt(dv[j]) * kv[j]; sa += (double)sv[j] * (double)sv[j]; }
+    for (int j = 0; j < V; j++) { sv[j] = (T)1 * t_sqrt(dv[j]) * kv[j]; dd_acc(sa, (double)sv[j] * (double)sv[j]); }
     stv<T, V>(s + i, sv);
   }
 };
@@ -953,7 +927,7 @@ template <class T> struct EpiInitRK {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* b; const T* sigma; T* r; T* tm; bool nonzero;
   __device__ void prologue(const CgState* st, double*) { nonzero = st->normx > 0.; }
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double&, double&) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t&, dd_t&) const {
     T bv[V], dv[V], rv[V], tv[V];
     ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv);
 #pragma unroll
@@ -976,7 +950,7 @@ template <class T> struct EpiInitSK {
   T* s; T* p; T* t; const T* tau;
   __device__ void prologue(const CgState*, double*) {}
   template <int V> __device__ void init(size_t i, T (&v)[V]) const { ldv<T, V>(s + i, v); }
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double&) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t& sa, dd_t&) const {
     T dv[V], sv[V], tv[V];
     ldv<T, V>(tau + i, dv);
 #pragma unroll
@@ -984,7 +958,7 @@ template <class T> struct EpiInitSK {
       const T sq = t_sqrt(dv[j]);
       sv[j] = (T)1 * sq * kv[j];
       tv[j] = sq * sv[j];
-      sa += (double)sv[j] * (double)sv[j];
+      dd_acc(sa, (double)sv[j] * (double)sv[j]);
     }
     stv<T, V>(s + i, sv); stv<T, V>(p + i, sv); stv<T, V>(t + i, tv);
   }
@@ -997,7 +971,7 @@ template <class T> struct EpiPreZK {
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* z_half; T* z_dual; const T* sigma; T* temp2;
   __device__ void prologue(const CgState*, double*) {}
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double&, double&) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t&, dd_t&) const {
     T a[V], bb[V], d[V], o[V], z[V];
     ldv<T, V>(z_half + i, a); ldv<T, V>(z_dual + i, bb); ldv<T, V>(sigma + i, d);
 #pragma unroll
@@ -1019,7 +993,7 @@ template <class T> struct EpiPostZK {
   static constexpr int kRegion = -1, kRegion2 = -1;
   T* z_proj; T* z_dual; T* temp2; const T* sigma;
   __device__ void prologue(const CgState*, double*) {}
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double&, double&) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t&, dd_t&) const {
     T a[V], d[V], u[V], o[V];
     ldv<T, V>(temp2 + i, a); ldv<T, V>(sigma + i, d);
 #pragma unroll
@@ -1037,7 +1011,7 @@ template <class T> struct AdmmPostX2 {
   static constexpr int kRegion = -1, kRegion2 = -1;
   T* x_proj; T* temp1; const T* tau; T* temp3; T* x_dual;
   __device__ void load(const CgState*) {}
-  template <int V> __device__ void range0(size_t i, double&, double&) const {
+  template <int V> __device__ void range0(size_t i, dd_t&, dd_t&) const {
     T x[V], a[V], d[V], o[V], u[V], w[V];
     ldv<T, V>(x_proj + i, x); ldv<T, V>(temp1 + i, a); ldv<T, V>(tau + i, d);
 #pragma unroll
@@ -1049,7 +1023,7 @@ template <class T> struct AdmmPostX2 {
     }
     stv<T, V>(temp3 + i, x); stv<T, V>(x_proj + i, o); stv<T, V>(x_dual + i, u); stv<T, V>(temp1 + i, w);
   }
-  template <int V> __device__ void range1(size_t, double&, double&) const {}
+  template <int V> __device__ void range1(size_t, dd_t&, dd_t&) const {}
 };
 // RES_ZK (m):  kx = K x_half ; RES_Z (primal residual / variable norm sums; y = get_dual(...) stored in kx)
 template <class T> struct EpiResZK {
@@ -1058,7 +1032,7 @@ template <class T> struct EpiResZK {
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
   T* kx; const T* z_half; const T* z_proj; const T* z_dual; const T* sigma; T rho;
   __device__ void prologue(const CgState*, double*) {}
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double& sb) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t& sa, dd_t& sb) const {
     T h[V], pj[V], du[V], d[V], y[V];
     ldv<T, V>(z_half + i, h); ldv<T, V>(z_proj + i, pj); ldv<T, V>(z_dual + i, du); ldv<T, V>(sigma + i, d);
 #pragma unroll
@@ -1066,8 +1040,8 @@ template <class T> struct EpiResZK {
       const T sq = t_sqrt(d[j]);
       const T pr = sq * ((T)1.0 * kv[j] + (T)-1.0 * h[j]);
       const T pv = sq * h[j];
-      sa += (double)pr * (double)pr;
-      sb += (double)pv * (double)pv;
+      dd_acc(sa, (double)pr * (double)pr);
+      dd_acc(sb, (double)pv * (double)pv);
       y[j] = get_dual<T>(rho, d[j], (T)1, h[j], pj[j], du[j]);
     }
     stv<T, V>(kx + i, y);
@@ -1084,7 +1058,7 @@ template <class T> struct EpiResXK {
 #pragma unroll
     for (int j = 0; j < V; j++) v[j] = 0;
   }
-  template <int V> __device__ void apply(size_t i, const T (&kv)[V], double& sa, double& sb) const {
+  template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t& sa, dd_t& sb) const {
     T h[V], pj[V], du[V], d[V];
     ldv<T, V>(x_half + i, h); ldv<T, V>(x_proj + i, pj); ldv<T, V>(x_dual + i, du); ldv<T, V>(tau + i, d);
 #pragma unroll
@@ -1093,8 +1067,8 @@ template <class T> struct EpiResXK {
       const T w = get_dual<T>(rho, d[j], (T)-1, h[j], pj[j], du[j]);
       const T dv = sq * w;
       const T dr = sq * ((T)1.0 * kv[j] + w);
-      sa += (double)dr * (double)dr;
-      sb += (double)dv * (double)dv;
+      dd_acc(sa, (double)dr * (double)dr);
+      dd_acc(sb, (double)dv * (double)dv);
     }
   }
 };
@@ -1112,7 +1086,7 @@ __global__ void __launch_bounds__(kBlock) cg_step_xr2_kernel(StepXR<T> f, size_t
   const bool first = tid < nvn;
   if (first) { ldv<T, VEC>(f.x + tid * VEC, xv); ldv<T, VEC>(f.p + tid * VEC, pv); ldv<T, VEC>(f.tau + tid * VEC, dv); }
   double s0, s1;
-  fold_region2(region(ws, kRegionQ), a.g_a, region(ws, kRegionP), a.g_b, s0, s1);
+  fold_dd2(region(ws, kRegionQ), a.g_a, 2, region(ws, kRegionP), a.g_b, 2, s0, s1);
   const double normq = sqrt(s0), normp = sqrt(s1);
   double dlt = normq * normq + a.shift * normp * normp;
   const int indefinite = dlt <= 0. ? 1 : 0;
@@ -1120,14 +1094,14 @@ __global__ void __launch_bounds__(kBlock) cg_step_xr2_kernel(StepXR<T> f, size_t
   f.alpha = (T)(cur->gamma / dlt);
   f.neg_alpha = (T)(-cur->gamma / dlt);
   if (blockIdx.x == 0 && threadIdx.x == 0) nxt->indefinite = cur->indefinite | indefinite;
-  double sa = 0, sb = 0;
+  dd_t sa{0.0, 0.0}, sb{0.0, 0.0};
   if (first) {                                       // StepXR::range0 on the prefetched operands
     T sv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       xv[j] = f.alpha * pv[j] + xv[j];
       sv[j] = (f.negshift / ((T)1 * t_sqrt(dv[j]))) * xv[j];
-      sa += (double)xv[j] * (double)xv[j];
+      dd_acc(sa, (double)xv[j] * (double)xv[j]);
     }
     stv<T, VEC>(f.x + tid * VEC, xv);
     if (f.s) stv<T, VEC>(f.s + tid * VEC, sv);
@@ -1139,7 +1113,7 @@ __global__ void __launch_bounds__(kBlock) cg_step_xr2_kernel(StepXR<T> f, size_t
     for (size_t i = tid; i < nv; i += stride) f.template range1<VEC>(i * VEC, sa, sb);
     if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < m - nv * VEC) f.template range1<1>(nv * VEC + threadIdx.x, sa, sb);
   }
-  block_sum1_store(sa, region(ws, kRegionX), blockIdx.x);
+  block_dd_store1(sa, region(ws, kRegionX), blockIdx.x);
 }
 // STEP_P with beta and the stopping test formed here from the partials of |s|^2 (g_a) and |x|^2 (g_b)   (cgls.hpp:326-360);
 // workgroup 0 writes the next record.  A round that finds the solve finished only hands the record on.
@@ -1157,7 +1131,7 @@ __global__ void __launch_bounds__(kBlock) cg_step_p2_kernel(StepP<T> f, size_t n
   const bool first = tid < nv;
   if (first) { ldv<T, VEC>(f.p + tid * VEC, pv); ldv<T, VEC>(f.s + tid * VEC, sv); ldv<T, VEC>(f.tau + tid * VEC, dv); }
   double s0, s1;
-  fold_region2(region(ws, kRegionS), a.g_a, region(ws, kRegionX), a.g_b, s0, s1);
+  fold_dd2(region(ws, kRegionS), a.g_a, 2, region(ws, kRegionX), a.g_b, 2, s0, s1);
   const double norms = sqrt(s0), gamma = norms * norms, normx = sqrt(s1);
   f.beta = (T)(gamma / cur->gamma);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1174,20 +1148,20 @@ __global__ void __launch_bounds__(kBlock) cg_step_p2_kernel(StepP<T> f, size_t n
     }
     *nxt = r;
   }
-  double sa = 0, sb = 0;
+  dd_t sa{0.0, 0.0}, sb{0.0, 0.0};
   if (first) {                                       // StepP::range0 on the prefetched operands
     T tv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       pv[j] = f.beta * pv[j] + sv[j];
       tv[j] = t_sqrt(dv[j]) * pv[j];
-      sa += (double)pv[j] * (double)pv[j];
+      dd_acc(sa, (double)pv[j] * (double)pv[j]);
     }
     stv<T, VEC>(f.p + tid * VEC, pv); stv<T, VEC>(f.t + tid * VEC, tv);
   }
   for (size_t i = tid + stride; i < nv; i += stride) f.template range0<VEC>(i * VEC, sa, sb);
   if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < n - nv * VEC) f.template range0<1>(nv * VEC + threadIdx.x, sa, sb);
-  block_sum1_store(sa, region(ws, kRegionP), blockIdx.x);
+  block_dd_store1(sa, region(ws, kRegionP), blockIdx.x);
 }
 
 static bool fused_op_ok(const prost_hip_fused_op* op, uint64_t m, uint64_t n) {
@@ -1309,7 +1283,7 @@ static int cgls_init_fused(const prost_hip_cgls_desc* d, const prost_hip_fused_o
   launch_op<T, false>(op, EpiInitRK<T>{c.b, c.sigma, c.r, c.q, false}, c.t, c.m, c.vop, op_grid(c.m, c.vop ? V : 1), cur, ws, st);
   const unsigned gs = fold_grid(c.n, c.vop ? V : 1, kOpBlocks);          // = the grid round 0 expects for |p|^2
   launch_op<T, true>(op, EpiInitSK<T>{c.s, c.p, c.t, c.tau}, c.q, c.n, c.vop, gs, cur, ws, st);
-  return launch_scalars<T, kScalarsInitS>(d, gs, 0, st, 1);
+  return launch_scalars<T, kScalarsInitS>(d, gs, 0, st, 2);
 }
 
 // ADMM outer iteration with the operator inside the stages (the caller runs the CG solve and the proxes in between):
@@ -1356,6 +1330,357 @@ static int admm_fused_stage(int stage, const prost_hip_admm_desc* d, const prost
   }
 }
 
+
+// ---- pixel-ordered CG rounds: TWO launches per round (round 5) ------------------------------------------------------------
+// For operators K = [D ; grad2d(nx, ny, L)] -- D couples the L channels of ONE pixel (row i of D has its L entries at columns
+// i + c nx ny: the warp matrix [diag(Ix) diag(Iy)] of the TV-L1 flow shape, BASELINE config 4), D optional -- a thread that owns
+// 4 consecutive pixels of an image column (2 in fp64) owns every row and every column of K that belongs to them: the D row, the
+// 2 L gradient rows, the L primal entries.  What a stage needs from NEIGHBOURING pixels (the forward differences of the updated
+// p at the right / lower neighbour, the backward differences of the updated r at the left / upper neighbour) it recomputes
+// from the neighbour's operands instead of waiting for another thread to publish it -- the loads are cache hits -- so the
+// vector updates of a round fold into the operator stages:
+//   launch A (PQ):   beta, stopping test from the partials of the previous round ; p = beta p + s ; q = sqrt(Sigma) K sqrt(Tau) p ;
+//                    |p|^2, |q|^2                                   [STEP_P2 + OP_FWD<FwdQ>;  t = sqrt(Tau) p is never stored]
+//   launch B (XRS):  alpha ; x += alpha p ; r -= alpha q ; s = sqrt(Tau) (-shift x / sqrt(Tau) + K^T sqrt(Sigma) r) ;
+//                    |x|^2, |s|^2                                   [STEP_XR2 + OP_ADJ<AdjS>; t = sqrt(Sigma) r is never stored]
+// p and r are written to a second buffer each (a neighbour may still read the old values): round j reads p from P[(j-1) % 2]
+// and leaves it in P[j % 2], reads r from R[j % 2] and leaves it in R[(j+1) % 2].  Per element every value is formed by the
+// expressions of the four-launch round above in the same order (csr_rows / op_fwd_rows / op_adj_cols / the epilogues / StepXR /
+// StepP), the sums are order-independent (reduce.hpp): x, p, q, r, s and every CG scalar are bit-identical to the four-launch
+// round and to the staged round.  Per pixel and round (L = 2): A reads p, s, tau (6), D's values (2), sigma (5), writes p, q (7);
+// B reads r, q (10), D's sigma (1), x, p, tau (6), D's values (2), writes r, x, s (9); A: sigma on D's rows only (1 instead of 5):
+// 44 values instead of ~80.  (Sigma on the gradient rows is ONE number: the caller checks it.)
+template <class T> struct PixArgs {
+  unsigned nx, ny;                     // image; ny % VEC == 0
+  size_t npx;                          // nx ny
+  size_t d_row, g_row;                 // first row of the D block / of the gradient block
+  const T* w;                          // D's values, row-major: w[i L + c] (the CSR value array of the block); nullptr-free when HAS_D
+  const T* sigma; const T* tau;          // sigma: read on D's rows only
+  T sig_g;                               // Sigma on the gradient rows: ONE value (a gradient block's row sums are constant, block_gradient2d.cu:154-158)
+  T* x; const T* p_in; T* p_out; T* s; T* q; const T* r_in; T* r_out;
+  T negshift;
+  unsigned tiles;                      // workgroups
+};
+struct PixGeom { size_t px0; unsigned x, y0; bool active; };
+template <int VEC>
+__device__ __forceinline__ PixGeom pix_geom(unsigned tiles, unsigned ny, size_t npx) {
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch); each XCD takes a contiguous range of tiles, so
+  // the neighbouring image columns a tile re-reads were fetched by the same XCD's L2 a moment ago
+  unsigned t = blockIdx.x;
+  if ((tiles & 7u) == 0) t = (blockIdx.x & 7u) * (tiles >> 3) + (blockIdx.x >> 3);
+  PixGeom g;
+  g.px0 = ((size_t)t * kBlock + threadIdx.x) * VEC;
+  g.active = g.px0 < npx;
+  const size_t c = g.active ? g.px0 : 0;
+  g.x = (unsigned)(c / ny); g.y0 = (unsigned)(c - (size_t)g.x * ny);
+  return g;
+}
+
+template <class T, int L, bool HAS_D, bool D_FIRST, bool FIRST>
+__global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_pq_kernel(PixArgs<T> a, const CgState* prev, CgState* cur, double* ws, RoundScalars sc) {
+  constexpr int V = VecOf<T>::N;
+  if (FIRST ? cur->done != 0 : prev->done != 0) {
+    if (!FIRST && blockIdx.x == 0 && threadIdx.x == 0) *cur = *prev;
+    return;
+  }
+  const PixGeom g = pix_geom<V>(a.tiles, a.ny, a.npx);
+  const unsigned nx = a.nx, ny = a.ny;
+  const bool right = g.active && g.x + 1 < nx, below = g.active && g.y0 + V < ny;
+  // operands requested before the fold: none of them depends on beta
+  T pc[L][V], sv[L][V], tc[L][V], pr[L][V], sr[L][V], tr[L][V], pb[L], sb_[L], tb[L];
+#pragma unroll
+  for (int c = 0; c < L; c++) {
+#pragma unroll
+    for (int j = 0; j < V; j++) { pc[c][j] = 0; sv[c][j] = 0; tc[c][j] = 1; pr[c][j] = 0; sr[c][j] = 0; tr[c][j] = 1; }
+    pb[c] = 0; sb_[c] = 0; tb[c] = 1;
+    const size_t e = (size_t)c * a.npx + g.px0;
+    if (g.active) { ldv<T, V>(a.p_in + e, pc[c]); ldv<T, V>(a.tau + e, tc[c]); if (!FIRST) ldv<T, V>(a.s + e, sv[c]); }
+    if (right) { ldv<T, V>(a.p_in + e + ny, pr[c]); ldv<T, V>(a.tau + e + ny, tr[c]); if (!FIRST) ldv<T, V>(a.s + e + ny, sr[c]); }
+    if (below) { pb[c] = a.p_in[e + V]; tb[c] = a.tau[e + V]; if (!FIRST) sb_[c] = a.s[e + V]; }
+  }
+  T wv[HAS_D ? V * L : 1], sgd[V];
+  if (g.active && HAS_D) {
+#pragma unroll
+    for (int k = 0; k < L; k++) ldv<T, V>(a.w + g.px0 * L + (size_t)k * V, *reinterpret_cast<T(*)[V]>(&wv[k * V]));
+    ldv<T, V>(a.sigma + a.d_row + g.px0, sgd);
+  }
+  const T sqg = t_sqrt(a.sig_g);                       // sqrt(Sigma) of every gradient row
+  T beta = 0;
+  if (!FIRST) {
+    // STEP_P2's head: beta and the stopping test from |s|^2, |x|^2 of the previous round (cgls.hpp:326-360); workgroup 0 records
+    double s0, s1;
+    fold_dd2(region(ws, kRegionS), sc.g_a, 2, region(ws, kRegionX), sc.g_b, 2, s0, s1);
+    const double norms = sqrt(s0), gamma = norms * norms, normx = sqrt(s1);
+    beta = (T)(gamma / prev->gamma);
+    const bool done = (norms <= prev->norms0 * prev->tol) || (normx * prev->tol >= 1.);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const int indefinite = cur->indefinite;          // written by the previous round's launch B
+      CgState r = *prev;
+      r.indefinite = indefinite;
+      r.norms = norms; r.gamma = gamma; r.beta = (double)beta; r.normx = normx;
+      r.xmax = prev->xmax > normx ? prev->xmax : normx;
+      if (done) {
+        r.done = 1;
+        if (sc.host_done) __hip_atomic_store(sc.host_done, prev->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        r.k = prev->k + 1;
+      }
+      *cur = r;
+    }
+    if (done) return;                                  // (the four-launch round still updates p here; nobody reads it afterwards)
+  }
+  dd_t sq{0.0, 0.0}, sp{0.0, 0.0};
+  if (g.active) {
+    // STEP_P: p = beta p + s ; t = sqrt(Tau) p -- own pixels (stored), right and lower neighbours (recomputed, not stored)
+    T t0[L][V], t_r[L][V], t_b[L];
+#pragma unroll
+    for (int c = 0; c < L; c++) {
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        if (!FIRST) { pc[c][j] = beta * pc[c][j] + sv[c][j]; pr[c][j] = beta * pr[c][j] + sr[c][j]; }
+        t0[c][j] = t_sqrt(tc[c][j]) * pc[c][j];
+        t_r[c][j] = t_sqrt(tr[c][j]) * pr[c][j];
+        dd_acc(sp, (double)pc[c][j] * (double)pc[c][j]);
+      }
+      if (!FIRST) pb[c] = beta * pb[c] + sb_[c];
+      t_b[c] = t_sqrt(tb[c]) * pb[c];
+      if (!FIRST) stv<T, V>(a.p_out + (size_t)c * a.npx + g.px0, pc[c]);
+    }
+    // OP_FWD<FwdQ>: the D row (csr_rows: entries in order), then the gradient rows (op_fwd_rows), each scaled by EpiFwdQ
+    if (HAS_D) {
+      T qd[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        T sum = 0;
+#pragma unroll
+        for (int c = 0; c < L; c++) sum += wv[j * L + c] * t0[c][j];
+        T kv = 0;
+        kv = kv + sum;
+        qd[j] = (T)1 * t_sqrt(sgd[j]) * kv;
+        dd_acc(sq, (double)qd[j] * (double)qd[j]);
+      }
+      stv<T, V>(a.q + a.d_row + g.px0, qd);
+    }
+#pragma unroll
+    for (int c = 0; c < L; c++) {
+      T qx[V], qy[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        const T gx = g.x < nx - 1 ? t_r[c][j] - t0[c][j] : (T)0;
+        const T dn = j + 1 < V ? t0[c][(j + 1) % V] : t_b[c];
+        const T gy = g.y0 + j < ny - 1 ? dn - t0[c][j] : (T)0;
+        T kx = 0, ky = 0;
+        kx = kx + gx; ky = ky + gy;
+        qx[j] = (T)1 * sqg * kx;
+        qy[j] = (T)1 * sqg * ky;
+        dd_acc(sq, (double)qx[j] * (double)qx[j]);
+        dd_acc(sq, (double)qy[j] * (double)qy[j]);
+      }
+      stv<T, V>(a.q + a.g_row + (size_t)c * a.npx + g.px0, qx);
+      stv<T, V>(a.q + a.g_row + (size_t)(L + c) * a.npx + g.px0, qy);
+    }
+  }
+  block_dd_store1(sq, region(ws, kRegionQ), blockIdx.x);
+  block_dd_store1(sp, region(ws, kRegionP), blockIdx.x);
+}
+
+template <class T, int L, bool HAS_D, bool D_FIRST>
+__global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_xrs_kernel(PixArgs<T> a, const CgState* cur, CgState* nxt, double* ws, RoundScalars sc) {
+  constexpr int V = VecOf<T>::N;
+  if (cur->done) return;
+  const PixGeom g = pix_geom<V>(a.tiles, a.ny, a.npx);
+  const unsigned nx = a.nx, ny = a.ny;
+  const bool left = g.active && g.x > 0, above = g.active && g.y0 > 0;
+  // operands requested before the fold (none depends on alpha): own rows of r, q, sigma; the d/dx rows of the left neighbour
+  // column; the d/dy row of the pixel above; x, p, tau, D's values
+  T rd[V], qd[V], gd[V];
+  T rx[L][V], qx[L][V], ry[L][V], qy[L][V], rl[L][V], ql[L][V], ra[L], qa[L];
+  T xv[L][V], pv[L][V], tv[L][V];
+  T wv[HAS_D ? V * L : 1];
+#pragma unroll
+  for (int j = 0; j < V; j++) { rd[j] = 0; qd[j] = 0; gd[j] = 1; }
+#pragma unroll
+  for (int c = 0; c < L; c++) {
+#pragma unroll
+    for (int j = 0; j < V; j++) { rl[c][j] = 0; ql[c][j] = 0; }
+    ra[c] = 0; qa[c] = 0;
+  }
+  if (g.active) {
+    if (HAS_D) {
+      const size_t e = a.d_row + g.px0;
+      ldv<T, V>(a.r_in + e, rd); ldv<T, V>(a.q + e, qd); ldv<T, V>(a.sigma + e, gd);
+#pragma unroll
+      for (int k = 0; k < L; k++) ldv<T, V>(a.w + g.px0 * L + (size_t)k * V, *reinterpret_cast<T(*)[V]>(&wv[k * V]));
+    }
+#pragma unroll
+    for (int c = 0; c < L; c++) {
+      const size_t ex = a.g_row + (size_t)c * a.npx + g.px0, ey = a.g_row + (size_t)(L + c) * a.npx + g.px0;
+      ldv<T, V>(a.r_in + ex, rx[c]); ldv<T, V>(a.q + ex, qx[c]);
+      ldv<T, V>(a.r_in + ey, ry[c]); ldv<T, V>(a.q + ey, qy[c]);
+      if (left) { ldv<T, V>(a.r_in + ex - ny, rl[c]); ldv<T, V>(a.q + ex - ny, ql[c]); }
+      if (above) { ra[c] = a.r_in[ey - 1]; qa[c] = a.q[ey - 1]; }
+    }
+  }
+  // STEP_XR2's head: alpha from |q|^2, |p|^2 (cgls.hpp:297-310)
+  double s0, s1;
+  fold_dd2(region(ws, kRegionQ), sc.g_a, 2, region(ws, kRegionP), sc.g_b, 2, s0, s1);
+  const double normq = sqrt(s0), normp = sqrt(s1);
+  double dlt = normq * normq + sc.shift * normp * normp;
+  const int indefinite = dlt <= 0. ? 1 : 0;
+  if (dlt == 0.) dlt = sc.eps;
+  const T alpha = (T)(cur->gamma / dlt), neg_alpha = (T)(-cur->gamma / dlt);
+  if (blockIdx.x == 0 && threadIdx.x == 0) nxt->indefinite = cur->indefinite | indefinite;
+  dd_t sx{0.0, 0.0}, ss{0.0, 0.0};
+  const T sqg = t_sqrt(a.sig_g);                       // sqrt(Sigma) of every gradient row
+  if (g.active) {
+    // second batch of operands (behind the fold's barriers: they arrive while r and t are formed; all at once would not fit 128 registers)
+#pragma unroll
+    for (int c = 0; c < L; c++) {
+      const size_t en = (size_t)c * a.npx + g.px0;
+      ldv<T, V>(a.x + en, xv[c]); ldv<T, V>(a.p_in + en, pv[c]); ldv<T, V>(a.tau + en, tv[c]);
+    }
+    // STEP_XR (m): r = -alpha q + r ; t = sqrt(Sigma) r -- own rows (stored), neighbour rows (recomputed, not stored)
+    T td[V];
+    if (HAS_D) {
+#pragma unroll
+      for (int j = 0; j < V; j++) { rd[j] = neg_alpha * qd[j] + rd[j]; td[j] = t_sqrt(gd[j]) * rd[j]; }
+      stv<T, V>(a.r_out + a.d_row + g.px0, rd);
+    }
+#pragma unroll
+    for (int c = 0; c < L; c++) {
+      T tx[V], ty[V], tl[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        rx[c][j] = neg_alpha * qx[c][j] + rx[c][j]; tx[j] = sqg * rx[c][j];
+        ry[c][j] = neg_alpha * qy[c][j] + ry[c][j]; ty[j] = sqg * ry[c][j];
+        rl[c][j] = neg_alpha * ql[c][j] + rl[c][j]; tl[j] = sqg * rl[c][j];
+      }
+      ra[c] = neg_alpha * qa[c] + ra[c];
+      const T t_above = sqg * ra[c];
+      stv<T, V>(a.r_out + a.g_row + (size_t)c * a.npx + g.px0, rx[c]);
+      stv<T, V>(a.r_out + a.g_row + (size_t)(L + c) * a.npx + g.px0, ry[c]);
+      // STEP_XR (n): x = alpha p + x ; OP_ADJ<AdjS>: v = s0 ; + D^T t ; - div t (blocks in operator order) ; s = 1 sqrt(Tau) v
+      T so[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) {
+        xv[c][j] = alpha * pv[c][j] + xv[c][j];
+        dd_acc(sx, (double)xv[c][j] * (double)xv[c][j]);
+        const T sq = t_sqrt(tv[c][j]);
+        T v = (a.negshift / ((T)1 * sq)) * xv[c][j];
+        T dsum = 0;
+        if (HAS_D) dsum += wv[j * L + c] * td[j];
+        T divy = g.y0 + j < ny - 1 ? ty[j] : (T)0;
+        if (g.y0 + j > 0) divy -= j > 0 ? ty[(j + V - 1) % V] : t_above;
+        T divx = g.x < nx - 1 ? tx[j] : (T)0;
+        if (g.x > 0) divx -= tl[j];
+        const T sdiv = divx + divy;
+        if (HAS_D && D_FIRST) { v = v + dsum; v = v - sdiv; }
+        else if (HAS_D) { v = v - sdiv; v = v + dsum; }
+        else v = v - sdiv;
+        so[j] = (T)1 * sq * v;
+        dd_acc(ss, (double)so[j] * (double)so[j]);
+      }
+      stv<T, V>(a.x + (size_t)c * a.npx + g.px0, xv[c]);
+      stv<T, V>(a.s + (size_t)c * a.npx + g.px0, so);
+    }
+  }
+  block_dd_store1(sx, region(ws, kRegionX), blockIdx.x);
+  block_dd_store1(ss, region(ws, kRegionS), blockIdx.x);
+}
+
+// the closing evaluation of a solve whose last queued round was round `last`: beta / stopping test of that round -> record last + 1
+// (what launch A of round last + 1 would record), so that the result record (iterations, flags, norms) is that of the other paths
+template <class T>
+__global__ void __launch_bounds__(kBlock) cg_pixel_close_kernel(const CgState* prev, CgState* cur, double* ws, RoundScalars sc) {
+  if (prev->done) { if (threadIdx.x == 0) *cur = *prev; return; }
+  double s0, s1;
+  fold_dd2(region(ws, kRegionS), sc.g_a, 2, region(ws, kRegionX), sc.g_b, 2, s0, s1);
+  if (threadIdx.x != 0) return;
+  const double norms = sqrt(s0), gamma = norms * norms, normx = sqrt(s1);
+  CgState r = *prev;
+  r.indefinite = cur->indefinite;
+  r.norms = norms; r.gamma = gamma; r.beta = (double)(T)(gamma / prev->gamma); r.normx = normx;
+  r.xmax = prev->xmax > normx ? prev->xmax : normx;
+  if ((norms <= prev->norms0 * prev->tol) || (normx * prev->tol >= 1.)) {
+    r.done = 1;
+    if (sc.host_done) __hip_atomic_store(sc.host_done, prev->epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    r.k = prev->k + 1;
+  }
+  *cur = r;
+}
+
+static bool pixel_op_ok(const prost_hip_pixel_op* op, uint64_t m, uint64_t n, unsigned V) {
+  if (!op || op->nx == 0 || op->ny == 0 || op->L < 1 || op->L > 3) return false;
+  const uint64_t npx = op->nx * op->ny;
+  if (op->ny % V || npx >= ((uint64_t)1 << 31)) return false;
+  if (n != (uint64_t)op->L * npx) return false;
+  if (op->has_d) {
+    if (!op->w || m != npx + 2 * (uint64_t)op->L * npx) return false;
+    const bool d_first = op->d_row == 0 && op->g_row == npx, g_first = op->g_row == 0 && op->d_row == 2 * (uint64_t)op->L * npx;
+    if (!d_first && !g_first) return false;
+  } else if (m != 2 * (uint64_t)op->L * npx || op->g_row != 0) {
+    return false;
+  }
+  return true;
+}
+
+template <class T>
+static int cgls_pixel_round(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, int close, void* stream, void* const* ev4) {
+  constexpr int V = VecOf<T>::N;
+  if (!d || !d->state || !d->workspace) { set_error("cgls_pixel_round: state and workspace are required"); return 1; }
+  if (round < 0) { set_error("cgls_pixel_round: negative round"); return 1; }
+  if (!pixel_op_ok(op, d->m, d->n, V) || !op->p_alt || !op->r_alt) { set_error("cgls_pixel_round: unsupported operator description (prost_hip_pixel_op_supported)"); return 1; }
+  T* P[2] = {static_cast<T*>(d->p), static_cast<T*>(op->p_alt)};
+  T* R[2] = {static_cast<T*>(d->r), static_cast<T*>(op->r_alt)};
+  for (const void* ptr : {(const void*)d->x, (const void*)d->q, (const void*)d->s, (const void*)d->sigma, (const void*)d->tau, (const void*)op->w, (const void*)P[0], (const void*)P[1], (const void*)R[0], (const void*)R[1]})
+    if (!aligned16(ptr)) { set_error("cgls_pixel_round: operands must be 16-byte aligned"); return 1; }
+  hipStream_t st = as_stream(stream);
+  const size_t npx = (size_t)(op->nx * op->ny);
+  const unsigned tiles = (unsigned)((npx / V + kBlock - 1) / kBlock);
+  if (tiles > (unsigned)kReduceBlocks) { set_error("cgls_pixel_round: image too large for the reduction workspace"); return 1; }
+  // the partial sums of round 0's |p|^2 and of the solve's first |s|^2 come from the kernels of prost_hip_cgls_init_fused, whose grids
+  // are what cgls_round computes for them; afterwards every region is written by `tiles` workgroups
+  CgState* rec = static_cast<CgState*>(d->state);
+  double* ws = static_cast<double*>(d->workspace);
+  const double eps = (double)std::numeric_limits<T>::epsilon();
+  PixArgs<T> a;
+  a.nx = (unsigned)op->nx; a.ny = (unsigned)op->ny; a.npx = npx; a.d_row = (size_t)op->d_row; a.g_row = (size_t)op->g_row;
+  a.w = static_cast<const T*>(op->w); a.sigma = static_cast<const T*>(d->sigma); a.tau = static_cast<const T*>(d->tau);
+  a.x = static_cast<T*>(d->x); a.s = static_cast<T*>(d->s); a.q = static_cast<T*>(d->q);
+  a.negshift = (T)(-d->shift); a.tiles = tiles; a.sig_g = (T)op->sigma_grad;
+  const bool has_d = op->has_d != 0, d_first = has_d && op->d_first != 0;
+  const int L = op->L;
+  auto mark = [&](int k) { if (ev4 && ev4[2 * k] && ev4[2 * k + 1]) { g_launch_ev_start = (hipEvent_t)ev4[2 * k]; g_launch_ev_stop = (hipEvent_t)ev4[2 * k + 1]; } };
+  if (close) {
+    const RoundScalars sc{d->shift, eps, tiles, tiles, d->host_done};
+    if (round < 1) { set_error("cgls_pixel_close: no round to close"); return 1; }
+    PH_LAUNCH((cg_pixel_close_kernel<T>), dim3(1), dim3(kBlock), 0, st, rec + round - 1, rec + round, ws, sc);
+    PH_LAUNCH_END("cgls pixel close");
+  }
+  // launch A of round j: beta / stopping test of round j - 1 -> record j ; p ; q
+  a.p_in = round == 0 ? P[0] : P[(round - 1) & 1]; a.p_out = P[round & 1];
+  a.r_in = R[round & 1]; a.r_out = R[(round + 1) & 1];
+  const RoundScalars sa{d->shift, eps, tiles, tiles, d->host_done};
+  mark(0);
+#define PIX_A(LL, HD, DF, FI) PH_LAUNCH((cg_pixel_pq_kernel<T, LL, HD, DF, FI>), dim3(tiles), dim3(kBlock), 0, st, a, round == 0 ? rec : rec + round - 1, rec + round, ws, sa)
+#define PIX_A_L(LL) do { if (round == 0) { if (!has_d) PIX_A(LL, false, false, true); else if (d_first) PIX_A(LL, true, true, true); else PIX_A(LL, true, false, true); } \
+                         else { if (!has_d) PIX_A(LL, false, false, false); else if (d_first) PIX_A(LL, true, true, false); else PIX_A(LL, true, false, false); } } while (0)
+  if (L == 1) PIX_A_L(1); else if (L == 2) PIX_A_L(2); else PIX_A_L(3);
+#undef PIX_A_L
+#undef PIX_A
+  // launch B of round j: alpha ; x, r ; s
+  a.p_in = P[round & 1];
+  const RoundScalars sb{d->shift, eps, tiles, tiles, nullptr};
+  mark(1);
+#define PIX_B(LL, HD, DF) PH_LAUNCH((cg_pixel_xrs_kernel<T, LL, HD, DF>), dim3(tiles), dim3(kBlock), 0, st, a, rec + round, rec + round + 1, ws, sb)
+#define PIX_B_L(LL) do { if (!has_d) PIX_B(LL, false, false); else if (d_first) PIX_B(LL, true, true); else PIX_B(LL, true, false); } while (0)
+  if (L == 1) PIX_B_L(1); else if (L == 2) PIX_B_L(2); else PIX_B_L(3);
+#undef PIX_B_L
+#undef PIX_B
+  PH_LAUNCH_END("cgls pixel round");
+}
+
 }  // namespace prost_hip
 
 using namespace prost_hip;
@@ -1363,7 +1688,7 @@ using namespace prost_hip;
 extern "C" {
 
 size_t prost_hip_cgls_state_bytes(void) { return sizeof(CgState); }
-size_t prost_hip_cgls_workspace_bytes(void) { return (size_t)kRegions * kReduceBlocks * 2 * sizeof(double); }
+size_t prost_hip_cgls_workspace_bytes(void) { return (size_t)kRegions * kReduceBlocks * 4 * sizeof(double); }
 int prost_hip_cgls_stage_f32(int stage, const prost_hip_cgls_desc* d, void* stream) { return cgls_stage<float>(stage, d, stream); }
 int prost_hip_cgls_stage_f64(int stage, const prost_hip_cgls_desc* d, void* stream) { return cgls_stage<double>(stage, d, stream); }
 
@@ -1382,6 +1707,14 @@ int prost_hip_cgls_init_fused_f32(const prost_hip_cgls_desc* d, const prost_hip_
 int prost_hip_cgls_init_fused_f64(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream) { return cgls_init_fused<double>(d, op, stream); }
 int prost_hip_admm_fused_stage_f32(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream) { return admm_fused_stage<float>(stage, d, op, stream); }
 int prost_hip_admm_fused_stage_f64(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream) { return admm_fused_stage<double>(stage, d, op, stream); }
+
+int prost_hip_pixel_op_supported(const prost_hip_pixel_op* op, uint64_t m, uint64_t n, int dtype) { return pixel_op_ok(op, m, n, dtype == 0 ? 4u : 2u) ? 1 : 0; }
+int prost_hip_cgls_pixel_round_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* stream) { return cgls_pixel_round<float>(d, op, round, 0, stream, nullptr); }
+int prost_hip_cgls_pixel_round_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* stream) { return cgls_pixel_round<double>(d, op, round, 0, stream, nullptr); }
+int prost_hip_cgls_pixel_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4, void* stream) { return cgls_pixel_round<float>(d, op, round, 0, stream, ev4); }
+int prost_hip_cgls_pixel_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4, void* stream) { return cgls_pixel_round<double>(d, op, round, 0, stream, ev4); }
+int prost_hip_cgls_pixel_close_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round, void* stream) { return cgls_pixel_round<float>(d, op, last_round + 1, 1, stream, nullptr); }
+int prost_hip_cgls_pixel_close_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round, void* stream) { return cgls_pixel_round<double>(d, op, last_round + 1, 1, stream, nullptr); }
 
 int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void* stream) { return prost_hip_cgls_result_at(state, 0, out, stream); }
 int prost_hip_cgls_result_at(const void* state, int index, prost_hip_cgls_result_t* out, void* stream) {

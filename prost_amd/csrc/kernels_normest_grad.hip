@@ -8,7 +8,8 @@
 // voxel through HBM (the neighbour loads are cache hits), 100 rounds at 2048 x 2048 x 64 in 0.06 s instead of 0.5 s.
 // Every intermediate value is formed by the expression, in the precision and in the order the separate kernels use
 // (x_temp = sqrt(tau) (x / |x|); a = sqrt(sigma) (K x_temp); sqrt(sigma) a; 0 - (divx + divy + divl); sqrt(tau) K^T ...), so x'
-// is bit-identical to the generic round; the two norms are sums of the same terms in double, in another order.
+// is bit-identical to the generic round; the two norms are order-independent sums of the same terms (reduce.hpp, dd_t): the
+// same doubles as the generic round's and the oracle's.
 #include "fused_common.hpp"
 #include "reduce.hpp"
 
@@ -25,7 +26,7 @@ __global__ void __launch_bounds__(kBlock) normest_grad_kernel(T* __restrict__ x_
   auto xt = [&](T v) { return sqT * (divide ? by_norm.div(v) : v); };          // x_temp of NORMEST_A
   const size_t slice = nx * ny;
   const size_t tiles = (size_t)strips * nx * L;
-  double sa = 0, sx = 0;
+  dd_t sa{0.0, 0.0}, sx{0.0, 0.0};      // order-independent sums (reduce.hpp): the norms equal the staged round's and the oracle's
   for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
     const size_t strip = t % strips, c = (t / strips) % nx, l = t / ((size_t)strips * nx);
     const size_t row0 = (strip * kBlock + threadIdx.x) * VEC;
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(kBlock) normest_grad_kernel(T* __restrict__ x_
       const T gx = c + 1 < nx ? xr[j] - val : (T)0, gxm = xc[j] - xl[j];            // gxm: at column c-1 (used only when c > 0)
       const T gy = row < ny - 1 ? dn - val : (T)0, gym = val - up;                  // gym: at row-1 (used only when row > 0)
       const T ax = sqS * gx, axm = sqS * gxm, ay = sqS * gy, aym = sqS * gym;
-      sa += (double)ax * (double)ax + (double)ay * (double)ay;
+      dd_acc(sa, (double)ax * (double)ax); dd_acc(sa, (double)ay * (double)ay);
       // K^T (grad_adj_vec_kernel): 0 - (divx + divy [+ divl])
       T divy = row < ny - 1 ? sqS * ay : (T)0;
       if (row > 0) divy -= sqS * aym;
@@ -63,34 +64,24 @@ __global__ void __launch_bounds__(kBlock) normest_grad_kernel(T* __restrict__ x_
       if (D3) {
         const T gl = l + 1 < L ? xu[j] - val : -val, glm = val - xd[j];             // Dirichlet above the last plane; glm: plane l-1
         const T al = sqS * gl, alm = sqS * glm;
-        sa += (double)al * (double)al;
+        dd_acc(sa, (double)al * (double)al);
         T divl = sqS * al;
         if (l > 0) divl -= sqS * alm;
         s = divx + divy + divl;
       }
       const T kty = (T)0 - s;
       o[j] = sqT * kty;                                                           // NORMEST_C
-      sx += (double)o[j] * (double)o[j];
+      dd_acc(sx, (double)o[j] * (double)o[j]);
     }
     stv<T, VEC>(x_out + l * slice + c * ny + row0, o);
   }
-  block_sum2_store(sa, sx, partial, blockIdx.x);
+  block_dd_store2(sa, sx, partial, blockIdx.x);
 }
 
-// out[0] = sqrt(sum of the first components), out[1] = sqrt(sum of the second ones) of g partial pairs, in a fixed order
+// out[0] = sqrt(first sum), out[1] = sqrt(second sum) of g two-sum slots (block_dd_store2)
 __global__ void __launch_bounds__(kBlock) normest_fold_kernel(double* out, const double* __restrict__ partial, unsigned g) {
-  double a = 0, b = 0;
-  for (unsigned i = threadIdx.x; i < g; i += kBlock) { a += partial[2 * (size_t)i]; b += partial[2 * (size_t)i + 1]; }
-  __shared__ double s_a[kBlock / kWave], s_b[kBlock / kWave];
-  a = wave_sum(a); b = wave_sum(b);
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  if (lane == 0) { s_a[wave] = a; s_b[wave] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double ta = 0, tb = 0;
-    for (int w = 0; w < kBlock / kWave; w++) { ta += s_a[w]; tb += s_b[w]; }
-    out[0] = sqrt(ta); out[1] = sqrt(tb);
-  }
+  const double ta = fold_dd(partial, g, 4), tb = fold_dd(partial + 2, g, 4);
+  if (threadIdx.x == 0) { out[0] = sqrt(ta); out[1] = sqrt(tb); }
 }
 
 template <class T>

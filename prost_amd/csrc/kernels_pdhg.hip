@@ -135,7 +135,12 @@ template <class T, int OP> struct AdmmF {
       case PROST_ADMM_GEMV1: return t_sqrt(a[0]) * a[1];                                         // a b
       case PROST_ADMM_GEMV2: return (beta / (alpha * t_sqrt(a[0]))) * a[1];                      // a b
       case PROST_ADMM_GEMV3: return alpha * t_sqrt(a[0]) * a[1];                                 // a b
-      case PROST_ADMM_GETDUAL: return -alpha * t_pow(a[3], beta) * (a[0] - a[1] + a[2]);         // a b c d
+      case PROST_ADMM_GETDUAL: {                                                                 // a b c d
+        // get_dual_functor (backend_admm.cu:181-196) is called with the exponents +1 and -1 only: pow(x, 1) = x and pow(x, -1) = 1 / x
+        // for a correctly rounded pow; the device's pow is not (a few results per thousand differ in the last place) -- kernels_cgls.hip, get_dual
+        const T pw = beta == (T)1 ? a[3] : beta == (T)-1 ? (T)1 / a[3] : t_pow(a[3], beta);
+        return -alpha * pw * (a[0] - a[1] + a[2]);
+      }
       case PROST_ADMM_SCALE: return alpha * a[0];                                                // a
       default: return a[0] / alpha;                                                              // PROST_ADMM_DIV: a
     }
@@ -165,6 +170,41 @@ static int reduce_to(double* out2, void* ws, const EwIn<T, NIN>& in, size_t n, F
   const unsigned g = launch_reduce2<T, NIN>(partial, in, n, f, st);
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "reduction kernel"); }
   return launch_fold(out2, partial, g, sqrt_first, st);
+}
+
+// |x|_2 with an order-independent sum (reduce.hpp, dd_t): the norms of cgls::Solve and of the ADMM residuals decide alpha, beta and
+// the stopping tests -- every implementation of the solve (host-side scalars, device-resident stages, fused rounds) and the
+// CPU oracle obtain the same double
+template <class T, int VEC>
+__global__ void __launch_bounds__(kBlock) nrm2_dd_kernel(const T* __restrict__ x, size_t n, double* __restrict__ partial) {
+  dd_t a{0.0, 0.0};
+  const size_t nv = n / VEC;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += (size_t)gridDim.x * kBlock) {
+    T v[VEC];
+    ldv<T, VEC>(x + i * VEC, v);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) dd_acc(a, (double)v[j] * (double)v[j]);
+  }
+  if (VEC > 1 && blockIdx.x == 0 && threadIdx.x < n - nv * VEC) { const T v = x[nv * VEC + threadIdx.x]; dd_acc(a, (double)v * (double)v); }
+  block_dd_store1(a, partial, blockIdx.x);
+}
+__global__ void __launch_bounds__(kBlock) nrm2_dd_fold_kernel(double* out, const double* partial, unsigned g) {
+  const double t = fold_dd(partial, g, 2);
+  if (threadIdx.x == 0) { out[0] = sqrt(t); out[1] = 0.0; }
+}
+template <class T>
+static int nrm2_dd(double* out, const T* x, size_t n, void* ws, void* stream) {
+  hipStream_t st = as_stream(stream);
+  if (n == 0) { PH_CHECK(hipMemsetAsync(out, 0, 2 * sizeof(double), st)); return 0; }
+  constexpr int V = VecOf<T>::N;
+  const bool vec = aligned16(x) && n >= (size_t)V;
+  unsigned g = grid_for(vec ? n / V : n, 2);
+  if (g > (unsigned)kReduceBlocks) g = (unsigned)kReduceBlocks;
+  double* partial = static_cast<double*>(ws);
+  if (vec) hipLaunchKernelGGL((nrm2_dd_kernel<T, V>), dim3(g), dim3(kBlock), 0, st, x, n, partial);
+  else hipLaunchKernelGGL((nrm2_dd_kernel<T, 1>), dim3(g), dim3(kBlock), 0, st, x, n, partial);
+  hipLaunchKernelGGL(nrm2_dd_fold_kernel, dim3(1), dim3(kBlock), 0, st, out, partial, g);
+  PH_LAUNCH_END("nrm2");
 }
 
 // bm = a == 0 ? sentinel : b ;  counts a outside {0, 1}   (prost_hip_mask_merge)
@@ -299,10 +339,10 @@ int prost_hip_compare_f64(double* out2, const double* a, const double* b, size_t
 
 // fold writes out[0] = sqrt(sum), out[1] = 0 -> `out` must have room for 2 doubles
 int prost_hip_nrm2_f32(double* out, const float* x, size_t n, void* ws, void* s) {
-  return reduce_to<float, 1>(out, ws, EwIn<float, 1>{{x}}, n, Nrm2F<float>{}, true, s);
+  return nrm2_dd<float>(out, x, n, ws, s);
 }
 int prost_hip_nrm2_f64(double* out, const double* x, size_t n, void* ws, void* s) {
-  return reduce_to<double, 1>(out, ws, EwIn<double, 1>{{x}}, n, Nrm2F<double>{}, true, s);
+  return nrm2_dd<double>(out, x, n, ws, s);
 }
 int prost_hip_axpy_f32(float* y, const float* x, double alpha, size_t n, void* s) {
   return launch_ew<float, 2>("axpy", y, EwIn<float, 2>{{x, y}}, n, AxpyF<float>{(float)alpha}, as_stream(s));

@@ -36,4 +36,101 @@ __device__ __forceinline__ void block_sum2_store(double a, double b, double* __r
 // optional sqrt of out[0]
 int launch_fold(double* out, const double* partial, unsigned nslots, bool sqrt_first, hipStream_t s);
 
+
+// ---- order-independent sums (round 5) ---------------------------------------------------------------------------
+// The CG scalars of the ADMM graph projection (cgls.hpp:152-170: thrust::transform_reduce in double) and the norms of
+// Problem::normest are reductions whose ORDER the reference leaves to thrust / cuBLAS.  alpha, beta and the relative stopping
+// test of cgls.hpp:326-360 are knife-edge functions of them: two kernels that add the same terms in another order end a solve
+// in different rounds now and then (profiles/r04_fuzz.log).  These sums are therefore carried as unevaluated pairs hi + lo
+// (Knuth's TwoSum: the rounding error of every addition is kept), per thread, through the wavefront / workgroup folds and
+// through the final fold: the result is the exact sum of the terms rounded ONCE (to within 2^-100 of the sum -- it can depend on
+// the order only where the exact sum lies that close to a rounding boundary), so every kernel variant -- staged rounds, fused
+// rounds, pixel-ordered rounds, any grid -- and the CPU oracle, which accumulates the same way, obtain the same double.
+// Needs -ffp-contract=off (the whole library is built that way): no FMA may be formed from these additions.
+struct dd_t { double hi, lo; };
+__host__ __device__ __forceinline__ void dd_acc(dd_t& a, double t) {          // a += t
+  const double s = a.hi + t;
+  const double bb = s - a.hi;
+  const double e = (a.hi - (s - bb)) + (t - bb);
+  a.hi = s;
+  a.lo += e;
+}
+__host__ __device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b) {              // a + b, renormalised (|lo| <= ulp(hi) / 2)
+  const double s = a.hi + b.hi;
+  const double bb = s - a.hi;
+  double e = (a.hi - (s - bb)) + (b.hi - bb);
+  e += a.lo + b.lo;
+  dd_t r;
+  r.hi = s + e;
+  r.lo = e - (r.hi - s);
+  return r;
+}
+__device__ __forceinline__ dd_t wave_sum_dd(dd_t v) {
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    dd_t w;
+    w.hi = __shfl_down(v.hi, o, kWave);
+    w.lo = __shfl_down(v.lo, o, kWave);
+    v = dd_add(v, w);
+  }
+  return v;
+}
+// call from every thread of a kBlock-thread workgroup; partial[2 slot], partial[2 slot + 1] = (hi, lo) of the workgroup's sum
+__device__ __forceinline__ void block_dd_store1(dd_t a, double* __restrict__ partial, unsigned slot) {
+  __shared__ dd_t s_d1[kBlock / kWave];
+  a = wave_sum_dd(a);
+  if ((threadIdx.x & (kWave - 1)) == 0) s_d1[threadIdx.x / kWave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dd_t t = s_d1[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; w++) t = dd_add(t, s_d1[w]);
+    partial[2 * slot] = t.hi;
+    partial[2 * slot + 1] = t.lo;
+  }
+  __syncthreads();                      // (s_d1 may be reused by a second call)
+}
+// two sums at once: partial[4 slot .. 4 slot + 3] = (a.hi, a.lo, b.hi, b.lo)
+__device__ __forceinline__ void block_dd_store2(dd_t a, dd_t b, double* __restrict__ partial, unsigned slot) {
+  __shared__ dd_t s_d2a[kBlock / kWave], s_d2b[kBlock / kWave];
+  a = wave_sum_dd(a);
+  b = wave_sum_dd(b);
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_d2a[threadIdx.x / kWave] = a; s_d2b[threadIdx.x / kWave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dd_t ta = s_d2a[0], tb = s_d2b[0];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; w++) { ta = dd_add(ta, s_d2a[w]); tb = dd_add(tb, s_d2b[w]); }
+    partial[4 * slot] = ta.hi; partial[4 * slot + 1] = ta.lo;
+    partial[4 * slot + 2] = tb.hi; partial[4 * slot + 3] = tb.lo;
+  }
+  __syncthreads();
+}
+// every thread of a kBlock-thread workgroup: the sum of g (hi, lo) partials, `stride` doubles apart (2: block_dd_store1 layout,
+// 4: one of the two sums of block_dd_store2), rounded to double -- the same value in every workgroup of every kernel.
+// Loads in batches of eight before the first add (a load-add loop pays one cache latency per iteration).
+__device__ __forceinline__ double fold_dd(const double* __restrict__ part, unsigned g, unsigned stride) {
+  __shared__ dd_t s_fd[kBlock / kWave];
+  dd_t a{0.0, 0.0};
+  for (unsigned base = threadIdx.x; base < g; base += 8 * kBlock) {
+    double vh[8], vl[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const unsigned i = base + k * kBlock;
+      vh[k] = i < g ? part[(size_t)stride * i] : 0.0;
+      vl[k] = i < g ? part[(size_t)stride * i + 1] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) a = dd_add(a, dd_t{vh[k], vl[k]});
+  }
+  a = wave_sum_dd(a);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) s_fd[threadIdx.x / kWave] = a;
+  __syncthreads();
+  dd_t t = s_fd[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / kWave; w++) t = dd_add(t, s_fd[w]);
+  return t.hi;
+}
+
 }  // namespace prost_hip

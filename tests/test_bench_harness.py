@@ -54,3 +54,20 @@ def test_every_name_the_backend_can_emit_is_priced():
 def test_unknown_names_are_not_priced():
     for name in ("cg_step_xr2_kernel", "fused_dual2d_kernel+residuals", "residuals", "fused_iter2d_kernel+mid", "something_dual"):
         assert bench.compulsory_floats(name, False) is None
+
+
+def test_c4_byte_model():
+    """C4 (ADMM): every kernel name BackendADMM::KernelTimes emits is priced, and the whole-iteration figure is the sum over the
+    stages outside the solve and the CG rounds of the path that ran"""
+    src = open(os.path.join(ROOT, "prost_amd", "csrc", "host", "backend_admm.cpp")).read()
+    for table in ("names4", "names2"):
+        block = src[src.index("static const char* const %s[4]" % table):]
+        block = block[:block.index("};")]
+        for name in re.findall(r'"([a-zA-Z0-9_<>]+)"', block):
+            assert bench.c4_kernel_bytes(name, 1024 * 1024) > 0, name
+    px = 1024 * 1024
+    outer = sum(v * 4 + i * 4 for v, i in bench.C4_OUTER_VALUES.values()) * px
+    assert bench.c4_iteration_bytes("admm:pixel-op", 10, px) == outer + (44 * 10 - 4) * 4 * px
+    assert bench.c4_iteration_bytes("admm:fused-op", 10, px) == outer + 10 * (55 * 4 + 7 * 4) * px
+    assert bench.c4_iteration_bytes("admm:generic", 10, px) is None
+    assert bench.c4_iteration_bytes("admm:pixel-op", 10, px, 8) > bench.c4_iteration_bytes("admm:pixel-op", 10, px, 4)

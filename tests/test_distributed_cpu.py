@@ -54,31 +54,49 @@ def _worker(rank, world, port, step, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("step", ["alg1", "boyd"])
-def test_global_residual_allreduce_gloo(step):
+@pytest.mark.parametrize("step,world", [("alg1", 2), ("boyd", 2), ("alg1", 8), ("boyd", 8)])
+def test_global_residual_allreduce_gloo(step, world):
+    """world 2 and world 8 (BASELINE config 5: eight independent problems, seeds 42 .. 49): every rank sees the same global scalars"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, step, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, step, out)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([out.get(timeout=120) for _ in procs])
+    res = sorted([out.get(timeout=300) for _ in procs])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, g0, l0, x0), (_, g1, l1, x1) = res
+    assert [r[0] for r in res] == list(range(world))
+    g0, l0 = res[0][1], res[0][2]
     # every rank sees the same global scalars and takes the same step-size decisions
-    for k in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "tau", "sigma"):
-        assert g0[k] == g1[k], k
-    assert x0 != x1                                    # different problems (seeds 42, 43)
+    for _, g, _, _ in res[1:]:
+        for k in ("primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "tau", "sigma"):
+            assert g0[k] == g[k], k
+    assert len({r[3] for r in res}) == world           # different problems (seeds 42 .. 42 + world - 1)
     if step == "alg1":
         # iterates do not depend on residuals: global^2 = sum of the local squares
         for k in ("primal_res", "dual_res", "dual_var_norm"):
-            assert np.isclose(g0[k] ** 2, l0[k] ** 2 + l1[k] ** 2, rtol=1e-12), k
+            assert np.isclose(g0[k] ** 2, sum(r[2][k] ** 2 for r in res), rtol=1e-12), k
         # eps uses the GLOBAL sizes: sqrt(sum m) * tol_abs + tol_rel * global norm
-        m = 2 * 2 * 20 * 16
+        m = world * 2 * 20 * 16
         assert np.isclose(g0["eps_primal"], np.sqrt(m) * 1e-4 + 1e-4 * g0["primal_var_norm"], rtol=1e-12)
+
+
+def test_bench_refuses_a_launcher_with_another_world_size():
+    """`bench.py --gpus 8` under a launcher that started another number of ranks must not report n_gpus = 8: it exits before anything
+    touches a GPU (this runs on the CPU box).  A --gpus below 1 is refused as well."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for ws in ("1", "2", "4"):
+        env = dict(os.environ, WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=120)
+        assert p.returncode != 0 and ("WORLD_SIZE = %s" % ws) in p.stderr and "--gpus 8" in p.stderr, (ws, p.stderr[-400:])
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "0"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "--gpus must be at least 1" in p.stderr
 
 
 def test_column_slabs_partition_the_image():

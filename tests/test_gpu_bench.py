@@ -82,11 +82,19 @@ def test_bench_c3_reduced():
     assert d["cpu_baseline"]["voxel_iterations_per_s"] > 0
 
 
+def bench_module():
+    import importlib
+    sys.path.insert(0, ROOT) if ROOT not in sys.path else None
+    return importlib.import_module("bench")
+
+
 def test_bench_c4_reduced():
     d = _bench("--config", "c4", "--steps", "20", "--warmup", "5", "--size", "128", "--prelude-iters", "10")
     _check_contract(d, 20, 5)
-    assert d["config"]["name"] == "c4" and d["config"]["path"] == "admm:fused-op" and d["metric"] == "ADMM iters/sec, TV-L1 flow-like 128^2 fp32"
+    assert d["config"]["name"] == "c4" and d["config"]["path"] == "admm:pixel-op" and d["metric"] == "ADMM iters/sec, TV-L1 flow-like 128^2 fp32"
     r = d["roofline"]
-    assert set(r["all_kernels"]) == {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"}      # the four-launch CG round ran
+    assert set(r["all_kernels"]) == {"cg_pixel_pq_kernel", "cg_pixel_xrs_kernel"}      # the two-launch CG round ran
+    px = 128 * 128
+    assert r["compulsory_bytes_per_iteration"] == bench_module().c4_iteration_bytes("admm:pixel-op", d["cg_iterations_last_solve"], px) and 0 < r["frac_iteration"] <= 1
     assert r["kernel"] in r["all_kernels"] and r["compulsory_bytes_per_launch"] == r["all_kernels"][r["kernel"]]["compulsory_bytes"]
     assert d["achieved_hbm_GBps"] is None and d["cg_iterations_last_solve"] >= 1

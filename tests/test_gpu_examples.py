@@ -66,3 +66,71 @@ def test_example_tv_inpaint_fills_the_holes_with_pair_launches():
     ro = oracle.solve(prob, prost.backend.pdhg(stepsize="boyd", residual_iter=10), o, np.float64)
     assert ro["iters"] == result["iters"]
     assert np.array_equal(np.asarray(ro["x"]).reshape(-1), u)
+
+
+def _compare_with_oracle(describe, args, prec, dtype, iters, solve_iters):
+    """iterates after `iters` iterations and a complete prost.solve (callback schedule, stopping test) against oracle.Solver /
+    oracle.solve on the SAME description"""
+    import oracle
+    prost.set_gpu(0)
+    prost.set_precision(prec)
+    try:
+        d = describe(*args)
+        prob, backend = d[0], d[1]
+        o = prost.options(max_iters=1000, num_cback_calls=0, verbose=False)
+        paths = set()
+        for k in iters:
+            s = prost.Solver(prob, backend, o)
+            s.iterate(k)
+            st = s.state()
+            s.destroy()
+            paths.add(st["path"])
+            prob.finalize()
+            orc = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, o, dtype)
+            orc.initialize()
+            orc.iterate(k)
+            ost = orc.state(); ost.update(orc.scalars())
+            for v in "xyzw":
+                assert np.array_equal(st[v], ost[v]), (k, v, float(np.abs(st[v] - ost[v]).max()))
+            assert st["tau"] == ost["tau"] and st["sigma"] == ost["sigma"], (k, st["tau"], ost["tau"])
+        d = describe(*args)
+        prob, backend, opts = d[0], d[1], dict(d[2])
+        opts["max_iters"] = solve_iters
+        res = prost.solve(prob, backend, opts)
+        d2 = describe(*args)
+        ro = oracle.solve(d2[0], d2[1], opts, dtype)
+        assert res["result"] == ro["result"] and int(res["iters"]) == int(ro["iters"]), (res["result"], res["iters"], ro["result"], ro["iters"])
+        for v in "xyzw":
+            assert np.array_equal(np.asarray(res[v]).reshape(-1), np.asarray(ro[v]).reshape(-1)), v
+        return paths, res
+    finally:
+        prost.set_precision("double")
+
+
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_example_multilabel_fast_as_written_matches_the_oracle(prec, dtype):
+    """example_multilabel_fast.m:21-54 as written: sparse gradient over 3 labels + the kron(ones(1, L), speye) sum row on a second dual
+    variable, ind_geq0 with a linear term, the zero function with a linear term, vectorial TV over 2 L components; boyd / residual_iter 10"""
+    import multilabel_fast as ex
+    paths, res = _compare_with_oracle(ex.describe, (28, 24), prec, dtype, (1, 2, 25), 400)
+    assert paths == {"pdhg:generic"}
+    lab = np.asarray(res["x"]).reshape(3, 28, 24)
+    assert np.isfinite(lab).all() and lab.min() >= 0
+
+
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_example_multilabel_tight_as_written_matches_the_oracle(prec, dtype):
+    """example_multilabel_tight.m:42-94 as written: two primal and three dual variables, gradient2d + two sparse_kron_id blocks + identity"""
+    import multilabel_tight as ex
+    paths, res = _compare_with_oracle(ex.describe, (20, 12), prec, dtype, (1, 2, 25), 400)
+    assert paths == {"pdhg:generic"}
+
+
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_example_deblurring_as_written_matches_the_oracle(prec, dtype):
+    """example_deblurring.m:10-41 as written: kron(speye(nc), convmtx2(kernel)) and spmat_gradient2d as sparse matrices on two constrained
+    variables (the blur matrix's rows hold up to klen entries: summed in CSR order), square data term with a per-element b, the default
+    backend options boyd / residual_iter 1"""
+    import deblurring as ex
+    paths, res = _compare_with_oracle(lambda nx, ny, nc: ex.describe(nx, ny, nc, klen=5), (24, 16, 2), prec, dtype, (1, 2, 31), 300)
+    assert paths == {"pdhg:generic"}

@@ -208,7 +208,7 @@ def test_c4_1024_admm_matches_oracle():
     s.iterate(k)
     st = s.state()
     s.destroy()
-    assert st["path"] == "admm:fused-op"
+    assert st["path"] == "admm:pixel-op"
     prob.finalize()
     oracle.set_num_threads(16)
     os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float32)

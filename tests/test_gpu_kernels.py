@@ -7,6 +7,8 @@ order) rel 1e-6.
 """
 import ctypes as C
 
+import math
+
 import numpy as np
 import pytest
 
@@ -206,7 +208,8 @@ def _cgls_reference(A, b, x, sig, tau, shift, tol, maxit, dtype):
         yv = (yv + (ATr @ t).astype(T)).astype(T)
         return (T(alpha) * sq_t * yv).astype(T)
     Aop = lambda v: gemv("n", 1, v, 0, np.zeros(A.shape[0], T))
-    nrm = lambda v: float(np.sqrt(np.sum(v.astype(np.float64) ** 2)))
+    # the norms of cgls.hpp are order-independent sums in the library (reduce.hpp): math.fsum is the exactly rounded sum of the same terms
+    nrm = lambda v: math.sqrt(math.fsum((v.astype(np.float64) ** 2).tolist()))
     x = x.copy(); r = b.copy()
     if nrm(x) > 0:
         r = gemv("n", -1, x, 1, r)

@@ -154,6 +154,29 @@ def test_bench_two_ranks_under_torchrun_on_one_gpu(hip):
     assert "cpu_baseline" not in d
 
 
+def test_bench_eight_ranks_on_one_gpu(hip):
+    """BASELINE config 5 as the driver will launch it on an 8-GPU node -- `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` --
+    with the eight ranks sharing the one GPU there is (PROST_BENCH_TRANSPORT=host: gloo under the native communicator's host-callback
+    transport): rendezvous of eight processes, eight independent problems (seeds 42 .. 49), global sizes in the stopping criterion,
+    barriers and MAX-reduced timing, ONE rank-0 JSON line with n_gpus = 8 and the aggregate rate, exit code 0.  Also without a launcher
+    (bench.py starts its eight ranks itself).  A functional run of the N = 8 code path, not a scaling figure."""
+    env = {"PROST_BENCH_TRANSPORT": "host", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "1"}
+    base = ["--gpus", "8", "--steps", "20", "--warmup", "5", "--size", "1024", "--prelude-iters", "40", "--no-cpu-baseline"]
+    for launcher in (True, False):
+        cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+               if launcher else [sys.executable]) + [os.path.join(ROOT, "bench.py")] + base
+        rc, stdout, stderr = _run_bench(cmd, env)
+        assert rc == 0, stderr[-3000:]
+        lines = [l for l in stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 8 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+        assert d["config"]["problems"] == 8 and d["config"]["comm_nranks"] == 8 and d["config"]["rccl_nranks"] is None
+        assert d["config"]["residual_allreduce"] == "host-callback (gloo)" and d["config"]["rendezvous"].startswith("gloo")
+        assert d["value"] > 0 and d["iterates_finite"] and abs(d["value"] - 8 * 20 / (d["ms_per_step"] * 20e-3)) <= 1e-6 * d["value"]
+        assert d["metric"] == "PDHG iters/sec, ROF-TV 1024^2 fp32" and "cpu_baseline" not in d
+
+
 @pytest.mark.parametrize("inject", [None, "injected by the test"])
 def test_bench_native_rccl_communicator_and_its_fallback(hip, inject):
     """the RCCL leg of bench.py on the one GPU there is (PROST_BENCH_FORCE_DIST=1): the rendezvous runs over gloo on CPU tensors, so

@@ -42,7 +42,7 @@ def run_product(prob, backend, opts, iters):
 
 def run_oracle(prob, backend, opts, iters, dtype):
     prob.finalize()
-    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_device_rules")}]
+    b = [backend[0], {k: v for k, v in backend[1].items() if k not in ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "pixel_rounds", "allow_speculation", "allow_pair_kernel", "allow_device_rules")}]
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, opts, dtype)
     s.initialize()
     s.iterate(iters)
@@ -474,13 +474,110 @@ def test_admm_matches_oracle(precision, dtype, device_cg, fused_rounds):
     tol = 2e-4 if dtype == np.float32 else 1e-9
     for k in (1, 5, 20):
         st = run_product(prob, b, o, k)
-        assert st["path"] == ("admm:fused-op" if fused_rounds else "admm:generic")
+        assert st["path"] == ("admm:pixel-op" if fused_rounds else "admm:generic")      # [W ; gradient2d(L = 2)]: the two-launch rounds
         ost = run_oracle(prob, b, o, k, dtype)
         assert_same_iterates(st, ost, exact=False, tol=tol)
         assert np.isclose(st["rho"], ost["rho"], rtol=1e-6)
         assert st["cg_iterations"] == ost["cg_iterations"]
         for name in ("primal_res", "dual_res"):
             assert np.isclose(st[name], ost[name], rtol=1e-3, atol=1e-5), name
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+def test_operator_norm_estimate_equals_the_oracle_bit_for_bit(precision, dtype):
+    """Problem::normest (problem.cu:429-500) divides the initial step sizes when the estimate is further than 0.1 from 1
+    (backend_pdhg.cu:274-286).  Its two norms per round are reductions the reference leaves to thrust; here and in the oracle they are
+    order-independent sums (reduce.hpp dd_t / ExactSum), so the estimate -- 100 rounds of a power iteration -- and the rescaled tau, sigma
+    are the SAME bits for any operator whose products are summed row by row (rounds 3-4: up to 138 ulp apart, iterates then only
+    tolerance-compared)."""
+    prost.set_precision(precision)
+    rng = np.random.default_rng(17)
+    cases = []
+    # a random sparse operator (short rows), a diagonal band operator, a two-column image gradient, the C4 operator [W ; gradient2d(L = 2)]
+    A = sp.random(60, 45, density=0.06, random_state=3, format="csc", dtype=np.float64); A.data = np.round(A.data * 8) / 4 + 0.25
+    u, v = prost.variable(45), prost.variable(60)
+    p1 = prost.min_max_problem([u], [v])
+    p1.add_function(u, prost.function.sum_1d("square", 1, rng.random(45), 2.0)); p1.add_function(v, prost.function.sum_1d("ind_box01"))
+    p1.add_dual_pair(u, v, prost.block.sparse(A))
+    cases.append(("sparse", p1))
+    u, v = prost.variable(50), prost.variable(50)
+    p2 = prost.min_max_problem([u], [v])
+    p2.add_function(u, prost.function.sum_1d("abs")); p2.add_function(v, prost.function.sum_1d("ind_box01"))
+    p2.add_dual_pair(u, v, prost.block.diags(50, 50, [1.5, -0.5, 2.0], [-1, 0, 3]))
+    cases.append(("diags", p2))
+    cases.append(("grad 2 columns", synthetic.rof_problem(2, 40, 1, seed=4)[0]))
+    cases.append(("grad 1x64x3", synthetic.rof_problem(1, 64, 3, seed=4)[0]))
+    cases.append(("c4", tvl1_like_problem(16, 12)))
+    fired = 0
+    for name, prob in cases:
+        o = prost.options(max_iters=20, num_cback_calls=0, verbose=False)
+        for fused in (True, False):
+            b = prost.backend.pdhg(stepsize="alg1", residual_iter=5, scale_steps_operator=True)
+            b[1]["allow_fused"] = fused
+            for k in (0, 7):
+                st = run_product(prob, b, o, k)
+                ost = run_oracle(prob, b, o, k, dtype)
+                assert st["tau"] == ost["tau"] and st["sigma"] == ost["sigma"], (name, fused, k, st["tau"], ost["tau"])
+                if k:
+                    assert_same_iterates(st, ost, exact=True)
+                fired += 1 if (k == 0 and st["tau"] != 1.0) else 0
+    assert fired >= 4          # (the rescale did fire: otherwise this test would compare 1 with 1)
+    prost.set_precision("double")
+
+
+def pixel_coupled_problem(nx, ny, L, has_d=True, d_first=True, seed=0):
+    """K = [D ; gradient2d(nx, ny, L)] (or the other order, or the gradient alone): D = [diag(w_0) ... diag(w_{L-1})] couples the L
+    channels of one pixel -- the C4 shape for L = 2"""
+    n = nx * ny
+    w = [synthetic.rof_image(nx, ny, 1, seed + c) - 0.5 for c in range(L)]
+    bvec = synthetic.rof_image(nx, ny, 1, seed + 7) - 0.5
+    u = prost.variable(L * n)
+    v, g = prost.variable(n), prost.variable(2 * L * n)
+    cons = ([v, g] if d_first else [g, v]) if has_d else [g]
+    prob = prost.min_problem([u], cons)
+    if has_d:
+        prob.add_function(v, prost.function.sum_1d("abs", 1, bvec, 5.0))
+        prob.add_constraint(u, v, prost.block.sparse(sp.hstack([sp.diags(wc) for wc in w]).tocsc()))
+    prob.add_function(g, prost.function.sum_norm2(2 * L, False, "abs"))
+    prob.add_constraint(u, g, prost.block.gradient2d(nx, ny, L))
+    return prob
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("nx,ny,L,has_d,d_first", [(16, 12, 2, True, True), (9, 20, 2, True, False), (7, 8, 1, True, True), (12, 16, 3, True, True),
+                                                    (11, 24, 2, False, True), (5, 1028, 1, False, True), (40, 264, 2, True, True)])
+def test_admm_cg_variants_agree_bit_for_bit(precision, dtype, nx, ny, L, has_d, d_first):
+    """One ADMM run, four implementations of the CGLS graph projection -- CG rounds of TWO launches (pixel-ordered, operators
+    [D ; gradient2d]), of FOUR launches (operator inside the stage kernels), the staged rounds around LinearOperator::Eval, and the
+    host-driven solve with one blocking nrm2 per scalar (the reference's sequence) -- form every vector element by the same
+    expressions and every CG scalar from order-independent sums (reduce.hpp): x, y, z, w, rho, the residual norms and the CG
+    iteration counts are IDENTICAL, and equal to the oracle's, which accumulates the same way (oracle/prost_oracle.cpp, ExactSum).
+    Round 4 compared these with 2e-4 / 2e-5: the sums were grouped differently per path (profiles/r04_fuzz.log: one solve in
+    ~30 000 ended in a different round)."""
+    prost.set_precision(precision)
+    prob = pixel_coupled_problem(nx, ny, L, has_d, d_first, seed=3)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    variants = {"pixel": dict(), "fused4": dict(pixel_rounds=False), "staged": dict(fused_rounds=False), "host": dict(device_cg=False)}
+    for iters in (1, 4, 13):
+        st = {}
+        for name, kw in variants.items():
+            b = prost.backend.admm(rho0=2, residual_iter=2)
+            b[1].update(kw)
+            st[name] = run_product(prob, b, o, iters)
+        assert st["pixel"]["path"] == "admm:pixel-op" and st["fused4"]["path"] == "admm:fused-op" and st["staged"]["path"] == "admm:generic"
+        ost = run_oracle(prob, prost.backend.admm(rho0=2, residual_iter=2), o, iters, dtype)
+        for name in variants:
+            for v in "xyzw":
+                assert np.array_equal(st[name][v], st["pixel"][v]), (iters, name, v, float(np.abs(st[name][v] - st["pixel"][v]).max()))
+            assert st[name]["cg_iterations"] == ost["cg_iterations"], (iters, name)
+            assert st[name]["rho"] == st["pixel"]["rho"]
+            for r_ in ("primal_res", "dual_res"):
+                assert st[name][r_] == st["pixel"][r_], (iters, name, r_)
+        assert_same_iterates(st["pixel"], ost, exact=True)
+        assert st["pixel"]["rho"] == ost["rho"]
+        for r_ in ("primal_res", "dual_res"):
+            assert st["pixel"][r_] == ost[r_], (iters, r_, st["pixel"][r_], ost[r_])
+    prost.set_precision("double")
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
@@ -527,7 +624,7 @@ def test_admm_and_pdhg_agree_at_convergence_on_the_c4_shape():
     out = {}
     for name, b, its in (("admm", prost.backend.admm(rho0=1), 1500), ("pdhg", prost.backend.pdhg(stepsize="boyd", residual_iter=10), 4000)):
         st = run_product(prob, b, o, its)
-        assert st["path"] == ("admm:fused-op" if name == "admm" else "pdhg:generic"), st["path"]
+        assert st["path"] == ("admm:pixel-op" if name == "admm" else "pdhg:generic"), st["path"]
         out[name] = (energy(st["x"]), st["x"].sum(), st["x"])
     (ea, sa, xa), (ep, sp_, xp) = out["admm"], out["pdhg"]
     assert abs(ea - ep) / ep < 1e-3, (ea, ep)

@@ -150,6 +150,69 @@ def _coeffs(*vals):
     return [np.atleast_1d(np.asarray(v, dtype=np.float64)).ravel() for v in vals]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_plugins_written_with_the_reference_iterator_signatures(hip, plugin, prec, dtype):
+    """include/prost/compat/thrust_ranges.hpp: a block and a prox whose EvalLocalAdd / EvalAdjointLocalAdd / EvalLocal take
+    thrust::device_vector<T>::iterator ranges and call thrust::transform on them -- the reference's plugin contract (block.hpp:66-77,
+    prox.hpp:117-126), bodies as a user of the reference writes them (tests/plugins/thrust_style_plugins.hip) -- evaluate like the
+    library's block.identity / sum_1d('abs') and like the oracle, in eval_linop / eval_prox and inside a PDHG solve"""
+    prost.set_gpu(0)
+    prost.set_precision(prec)
+    t_block = lambda n, scale: (lambda row, col, nrows, ncols: [["test:thrust:scaled_identity", row, col, [n, float(scale)]], [n, n]])
+    t_prox = lambda lmb: (lambda idx, count: ["test:thrust:soft_threshold", idx, count, True, [float(lmb)]])
+    try:
+        now = prost.registered()
+        assert "test:thrust:scaled_identity" in now["block"] and "test:thrust:soft_threshold" in now["prox"]
+        n, scale, lmb = 1003, 0.5, 0.75
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal(n).astype(dtype).astype(np.float64)
+        for transpose in (False, True):
+            got, rowsum, colsum, _ = prost.eval_linop([t_block(n, scale)(0, 0, n, n)[0]], x, transpose)
+            exp, erow, ecol, _ = prost.eval_linop([prost.block.diags(n, n, [scale], [0])(0, 0, n, n)[0]], x, transpose)
+            assert np.array_equal(got, exp) and np.array_equal(rowsum, erow) and np.array_equal(colsum, ecol)
+        Tau = (0.5 + rng.random(n)).astype(dtype).astype(np.float64)
+        arg = (2 * rng.standard_normal(n)).astype(dtype).astype(np.float64)
+        for conj in (False, True):
+            f_plug = prost.function.conjugate(t_prox(lmb)) if conj else t_prox(lmb)
+            f_lib = prost.function.sum_1d("abs", 1, 0, lmb)
+            f_lib = prost.function.conjugate(f_lib) if conj else f_lib
+            got, _ = prost.eval_prox(f_plug, arg, 0.4, Tau)
+            orc = oracle.eval_prox(f_lib, arg, 0.4, Tau, dtype)
+            assert np.array_equal(got, np.asarray(orc, dtype=np.float64)), conj
+        # inside a solve: [gradient2d ; thrust-style block], prox_fstar on the second dual variable = the thrust-style prox
+        nx, ny = 24, 36
+        f = synthetic.rof_image(nx, ny, 1, 11)
+
+        def problem(plug):
+            npx = nx * ny
+            u, q, r = prost.variable(npx), prost.variable(2 * npx), prost.variable(npx)
+            prob = prost.min_max_problem([u], [q, r])
+            prob.add_function(u, prost.function.sum_1d("square", 1, f, 10.0))
+            prob.add_function(q, prost.function.sum_norm2(2, False, "ind_leq0", 1, 1, 1))
+            prob.add_function(r, t_prox(0.3) if plug else prost.function.sum_1d("abs", 1, 0, 0.3))
+            prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, 1))
+            prob.add_dual_pair(u, r, t_block(npx, 0.5) if plug else prost.block.diags(npx, npx, [0.5], [0]))
+            return prob
+        b = prost.backend.pdhg(stepsize="boyd", residual_iter=4)
+        o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+        ref = problem(False)
+        ref.finalize()
+        for k in (1, 23):
+            s = prost.Solver(problem(True), b, o)
+            s.iterate(k)
+            st = s.state()
+            s.destroy()
+            orc = oracle.Solver(ref.data, ref.nrows, ref.ncols, b, o, dtype)
+            orc.initialize()
+            orc.iterate(k)
+            ost = orc.state()
+            for v in "xyzw":
+                assert np.array_equal(st[v], ost[v]), (k, v, float(np.abs(st[v] - ost[v]).max()))
+    finally:
+        prost.set_precision("double")
+
+
 def plugin_norm2(name, dim, interleaved, *coeffs):
     """front-end builder in the style of sum_norm2.m:83-86, naming a plugin operation"""
     return lambda idx, count: [name, idx, count, False, [count // dim, dim, bool(interleaved), _coeffs(*coeffs)]]
