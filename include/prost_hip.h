@@ -449,6 +449,23 @@ int prost_hip_fused_iteration_mc_x2_rec_f32(const prost_hip_fused_desc* desc, fl
 int prost_hip_fused_iteration_mc_x2_rec_f64(const prost_hip_fused_desc* desc, double* x_out, double* y_out, const double* x, const double* y, void* record, int cols,
                                             double* res_out4, void* workspace, int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror,
                                             void* stream);
+/* ... and of the gradient3d kernels (round 5): prost_hip_fused_iteration3d (block_gradient3d.cu:25-150 inside one PerformIteration),
+ * prost_hip_fused_iteration3d_pw (planes across the wavefronts of a workgroup; no residual sums) and prost_hip_fused_iteration3d_x2 (two
+ * iterations per launch, both with the record's step sizes; residual sums of the second) */
+int prost_hip_fused_iteration3d_rec_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev, void* record,
+                                        int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace, int apply_rule,
+                                        unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iteration3d_rec_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev, void* record,
+                                        int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace, int apply_rule,
+                                        unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iteration3d_pw_rec_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, void* record, int use_kty,
+                                           int use_kx_prev, int cols, int waves, void* stream);
+int prost_hip_fused_iteration3d_pw_rec_f64(const prost_hip_fused_desc* desc, double* x_new, double* y_new, const double* x, const double* y, void* record, int use_kty,
+                                           int use_kx_prev, int cols, int waves, void* stream);
+int prost_hip_fused_iteration3d_x2_rec_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y, void* record, int cols,
+                                           double* res_out4, void* workspace, int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iteration3d_x2_rec_f64(const prost_hip_fused_desc* desc, double* x_out, double* y_out, const double* x, const double* y, void* record, int cols,
+                                           double* res_out4, void* workspace, int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
 int prost_hip_fused_iteration2_rec_f32(const prost_hip_fused_desc* desc, float* x_out, float* y_out, const float* x, const float* y, float* x_mid, float* y_mid,
                                        void* record, int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
                                        prost_hip_pdhg_rule_state* mirror, void* stream);

@@ -258,8 +258,10 @@ void BackendPDHG<T>::Initialize() {
   // must not depend on the step size); column-sharded slabs exchange halos between iterations and keep the host loop.
   // (gray values, and 2-4 channels with the channels in one lane / on the wavefronts of a workgroup: every kernel of those paths
   // reads the record -- prost_hip_fused_iteration_rec, _iteration_mc_rec, _iteration2_rec, _iteration_mc_x2_rec)
-  const bool rec_kernels = single_kernel_ || single_mc_;
-  dev_rules_ = rec_kernels && !desc_.is3d && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
+  // (round 5: gradient3d as well -- prost_hip_fused_iteration3d_rec, _3d_pw_rec, _3d_x2_rec: the reference's default options on a
+  // volume cost a host round trip per iteration before)
+  const bool rec_kernels = single_kernel_ || single_mc_ || single3d_;
+  dev_rules_ = rec_kernels && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
                !desc_.g_coeff_ptr[4] && desc_.g_coeff_val[4] == 0.0 && desc_.f_coeff_val[4] == 0.0;
   // the same on the GENERIC path (any operator): the proxes form their arguments on the fly with kernels that read tau, sigma, theta
   // from the record (elem operations of any function and coefficients, their Moreau wraps, the identity), the residual reductions
@@ -448,6 +450,10 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
         pair_launches_++;
         IterationPairMc(is_residual_iteration(k + 1));
         done += 2;
+      } else if (pair3d_ && n - done >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {
+        pair_launches_++;
+        IterationPair3D(is_residual_iteration(k + 1));
+        done += 2;
       } else {
         IterationFused(is_residual_iteration(k));
         done += 1;
@@ -575,6 +581,11 @@ void BackendPDHG<T>::IterationPair3D(bool residuals) {
   iteration_++;
   tau[1] = (double)tau_; sigma[1] = (double)sigma_; theta[1] = (double)theta_;
   TimedLaunch(residuals ? kKernelPairRes : kKernelPair, [&] {
+    if (in_device_batch_)
+      CheckHip(Api<T>::fused_iteration3d_x2_rec(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), rule_rec_, 0, residuals ? res_target() : nullptr,
+                                                residuals ? workspace_ : nullptr, this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_dev_, CurrentStream()),
+               "fused_iteration3d_x2_rec");
+    else
     CheckHip(Api<T>::fused_iteration3d_x2(&desc_, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
                                           residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, CurrentStream()), "fused_iteration3d_x2");
   });
@@ -677,7 +688,14 @@ void BackendPDHG<T>::IterationFused(bool res) {
     if (res) RebuildPrevious();      // the residual kernel streams y^(k-1)
     T* y_out = res ? y_spare_.data() : y_prev_.data();
     TimedLaunch(res ? kKernelIterRes : kKernelIter, [&] {
-      if (single3d_pw_ && !res)        // planes across the wavefronts of a workgroup: x_new of the plane above comes through LDS
+      if (in_device_batch_ && single3d_pw_ && !res)
+        CheckHip(Api<T>::fused_iteration3d_pw_rec(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), rule_rec_, iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, 0, s),
+                 "fused_iteration3d_pw_rec");
+      else if (in_device_batch_)
+        CheckHip(Api<T>::fused_iteration3d_rec(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), res ? y_prev_.data() : nullptr, rule_rec_, iteration_ >= 1 ? 1 : 0,
+                                               iteration_ >= 1 ? 1 : 0, iteration_ >= 2 ? 1 : 0, 0, res ? res_target() : nullptr, res ? workspace_ : nullptr,
+                                               this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_dev_, s), "fused_iteration3d_rec");
+      else if (single3d_pw_ && !res)        // planes across the wavefronts of a workgroup: x_new of the plane above comes through LDS
         CheckHip(Api<T>::fused_iteration3d_pw(&desc_, x_prev_.data(), y_out, x_.data(), y_.data(), (double)tau_, (double)sigma_, (double)theta_,
                                               iteration_ >= 1 ? 1 : 0, iteration_ >= 1 ? 1 : 0, 0, 0, s), "fused_iteration3d_pw");
       else

@@ -48,6 +48,9 @@ template <typename T> struct Api;
     static constexpr auto fused_iteration_rec = prost_hip_fused_iteration_rec_##S; \
     static constexpr auto fused_iteration_mc_rec = prost_hip_fused_iteration_mc_rec_##S; \
     static constexpr auto fused_iteration_mc_x2_rec = prost_hip_fused_iteration_mc_x2_rec_##S; \
+    static constexpr auto fused_iteration3d_rec = prost_hip_fused_iteration3d_rec_##S; \
+    static constexpr auto fused_iteration3d_pw_rec = prost_hip_fused_iteration3d_pw_rec_##S; \
+    static constexpr auto fused_iteration3d_x2_rec = prost_hip_fused_iteration3d_x2_rec_##S; \
     static constexpr auto fused_iteration2_rec = prost_hip_fused_iteration2_rec_##S; \
     static constexpr auto pdhg_rule_begin = prost_hip_pdhg_rule_begin_##S;        \
     static constexpr auto pdhg_rule_apply = prost_hip_pdhg_rule_apply_##S;        \

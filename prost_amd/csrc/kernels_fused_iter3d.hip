@@ -40,7 +40,11 @@ template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, bool RES>
 __global__ void __launch_bounds__(kWave) fused_iter3d_kernel(T* __restrict__ x_new, T* __restrict__ y_new, const T* __restrict__ x,
                                                              const T* __restrict__ y, const T* __restrict__ y_prev, FusedArgs<T> a, T tau, T sigma,
                                                              T theta, UniformProx<T> ug, UniformProx<T> uf, bool use_kty, bool use_kx_prev,
-                                                             bool use_kty_prev, double* __restrict__ partial) {
+                                                             bool use_kty_prev, double* __restrict__ partial, const PdhgRecord<T>* __restrict__ rec) {
+  if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
+    if (rec->stop) return;
+    tau = rec->p.tau; sigma = rec->p.sigma; theta = rec->p.theta; ug = rec->p.ug; uf = rec->p.uf;
+  }
   const size_t nx = a.nx, ny = a.ny, L = a.L;
   const int lane = threadIdx.x;
   constexpr int kRowsPerWave = (kWave - 1) * VEC;
@@ -278,7 +282,8 @@ static bool iter3d_ok(const prost_hip_fused_desc* d) {
 
 template <class T>
 static int run_iter3d(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, const T* y_prev, double tau, double sigma, double theta,
-                      int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream) {
+                      int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* out4, void* ws, void* stream, void* record = nullptr,
+                      const RuleTail* tail = nullptr) {
   if (!iter3d_ok<T>(d)) { set_error("fused 3-D iteration: unsupported description (see prost_hip_fused_iteration3d_supported)"); return 1; }
   if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y) || !aligned16(y_prev)) { set_error("fused 3-D iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_new == x || y_new == y || (out4 && y_new == y_prev)) { set_error("fused 3-D iteration: outputs must not alias inputs (planes l-1 / l+1 are read by other wavefronts)"); return 1; }
@@ -300,10 +305,11 @@ static int run_iter3d(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T
   const UniformProx<T> uf = make_uniform_prox<T>(a.f_val, (T)sigma * a.Sval);
   hipStream_t s = as_stream(stream);
   double* partial = static_cast<double*>(ws);
+  const PdhgRecord<T>* rec = static_cast<const PdhgRecord<T>*>(record);
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO2(G, F, B, FASTv, R) PH_LAUNCH((fused_iter3d_kernel<T, V, G, F, B, FASTv, R>), dim3(grid), dim3(kWave), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial)
+#define GO2(G, F, B, FASTv, R) PH_LAUNCH((fused_iter3d_kernel<T, V, G, F, B, FASTv, R>), dim3(grid), dim3(kWave), 0, s, x_new, y_new, x, y, y_prev, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, use_kty_prev != 0, partial, rec)
 #define GO(G, F, B, FASTv) do { if (out4) GO2(G, F, B, FASTv, true); else GO2(G, F, B, FASTv, false); } while (0)
   if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
   else if (gsq && fle) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, false); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, false); }
@@ -311,6 +317,7 @@ static int run_iter3d(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T
 #undef GO
 #undef GO2
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused 3-D iteration kernel"); }
+  if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid, s);
   return 0;
 }
@@ -330,5 +337,22 @@ int prost_hip_fused_iteration3d_f64(const prost_hip_fused_desc* d, double* x_new
                                     double tau, double sigma, double theta, int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4,
                                     void* workspace, void* stream) {
   return run_iter3d<double>(d, x_new, y_new, x, y, y_prev, tau, sigma, theta, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream);
+}
+// the same launch with tau, sigma, theta and the prox terms derived from them read from the device record (prost_hip_pdhg_rule_begin; the
+// by-value structure flags -- which straight-line instance runs -- come from the description, they do not depend on the step sizes);
+// apply_rule: the fold of a residual launch also evaluates the step-size rule and the stopping test (no communicator)
+int prost_hip_fused_iteration3d_rec_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev, void* record,
+                                        int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace, int apply_rule,
+                                        unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused_iteration3d_rec: no record"); return 1; }
+  const RuleTail tail{apply_rule, iteration, mirror};
+  return run_iter3d<float>(d, x_new, y_new, x, y, y_prev, 1.0, 1.0, 1.0, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream, record, &tail);
+}
+int prost_hip_fused_iteration3d_rec_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, const double* y_prev, void* record,
+                                        int use_kty, int use_kx_prev, int use_kty_prev, int cols, double* res_out4, void* workspace, int apply_rule,
+                                        unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused_iteration3d_rec: no record"); return 1; }
+  const RuleTail tail{apply_rule, iteration, mirror};
+  return run_iter3d<double>(d, x_new, y_new, x, y, y_prev, 1.0, 1.0, 1.0, use_kty, use_kx_prev, use_kty_prev, cols, res_out4, workspace, stream, record, &tail);
 }
 }  // extern "C"

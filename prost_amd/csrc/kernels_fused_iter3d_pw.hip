@@ -25,7 +25,11 @@ struct ColPw {
 template <class T, int VEC, int GFN, int FFN, bool GB, bool FAST, int WT>
 __global__ void __launch_bounds__(kWave * WT) fused_iter3d_pw_kernel(T* __restrict__ x_new, T* __restrict__ y_new, const T* __restrict__ x,
                                                                     const T* __restrict__ y, FusedArgs<T> a, T tau, T sigma, T theta,
-                                                                    UniformProx<T> ug, UniformProx<T> uf, bool use_kty, bool use_kx_prev) {
+                                                                    UniformProx<T> ug, UniformProx<T> uf, bool use_kty, bool use_kx_prev, const PdhgRecord<T>* __restrict__ rec) {
+  if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): wave-uniform scalar loads
+    if (rec->stop) return;
+    tau = rec->p.tau; sigma = rec->p.sigma; theta = rec->p.theta; ug = rec->p.ug; uf = rec->p.uf;
+  }
   constexpr int kRowsPerWave = (kWave - 1) * VEC;
   constexpr int kPix = kWave * VEC;
   constexpr int kPlanes = WT - 1;                      // planes a workgroup produces
@@ -210,7 +214,7 @@ static bool iter3d_pw_ok(const prost_hip_fused_desc* d) {
 
 template <class T>
 static int run_iter3d_pw(const prost_hip_fused_desc* d, T* x_new, T* y_new, const T* x, const T* y, double tau, double sigma, double theta,
-                         int use_kty, int use_kx_prev, int cols, int waves, void* stream) {
+                         int use_kty, int use_kx_prev, int cols, int waves, void* stream, void* record = nullptr) {
   if (!iter3d_pw_ok<T>(d)) { set_error("fused 3-D iteration (planes across wavefronts): unsupported description"); return 1; }
   if (!aligned16(x_new) || !aligned16(y_new) || !aligned16(x) || !aligned16(y)) { set_error("fused 3-D iteration: vectors must be 16-byte aligned"); return 1; }
   if (x_new == x || y_new == y) { set_error("fused 3-D iteration: outputs must not alias inputs"); return 1; }
@@ -234,7 +238,7 @@ static int run_iter3d_pw(const prost_hip_fused_desc* d, T* x_new, T* y_new, cons
   const bool gb = d->g_coeff_ptr[1] != nullptr;
   const bool gsq = d->g_fn == PROST_FN_SQUARE, fle = d->f_fn == PROST_FN_IND_LEQ0;
   const bool fast = gsq && fle && ug.a_one && ug.den_one && !ug.degenerate && a.g_val[3] == (T)0 && uf.a_one && uf.den_one && a.f_val[3] == (T)0;
-#define GO2(G, F, B, FASTv, WTv) PH_LAUNCH((fused_iter3d_pw_kernel<T, V, G, F, B, FASTv, WTv>), dim3(grid), dim3(kWave * WTv), 0, s, x_new, y_new, x, y, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0)
+#define GO2(G, F, B, FASTv, WTv) PH_LAUNCH((fused_iter3d_pw_kernel<T, V, G, F, B, FASTv, WTv>), dim3(grid), dim3(kWave * WTv), 0, s, x_new, y_new, x, y, a, (T)tau, (T)sigma, (T)theta, ug, uf, use_kty != 0, use_kx_prev != 0, static_cast<const PdhgRecord<T>*>(record))
 #define GO(G, F, B, FASTv) do { if (wt == 8) GO2(G, F, B, FASTv, 8); else GO2(G, F, B, FASTv, 4); } while (0)
   if (fast) { if (gb) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, true, true); else GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, false, true); }
   else { if (gb) GO(-1, -1, true, false); else GO(-1, -1, false, false); }
@@ -256,5 +260,15 @@ int prost_hip_fused_iteration3d_pw_f32(const prost_hip_fused_desc* d, float* x_n
 int prost_hip_fused_iteration3d_pw_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, double tau, double sigma,
                                        double theta, int use_kty, int use_kx_prev, int cols, int waves, void* stream) {
   return run_iter3d_pw<double>(d, x_new, y_new, x, y, tau, sigma, theta, use_kty, use_kx_prev, cols, waves, stream);
+}
+int prost_hip_fused_iteration3d_pw_rec_f32(const prost_hip_fused_desc* d, float* x_new, float* y_new, const float* x, const float* y, void* record, int use_kty,
+                                           int use_kx_prev, int cols, int waves, void* stream) {
+  if (!record) { set_error("fused_iteration3d_pw_rec: no record"); return 1; }
+  return run_iter3d_pw<float>(d, x_new, y_new, x, y, 1.0, 1.0, 1.0, use_kty, use_kx_prev, cols, waves, stream, record);
+}
+int prost_hip_fused_iteration3d_pw_rec_f64(const prost_hip_fused_desc* d, double* x_new, double* y_new, const double* x, const double* y, void* record, int use_kty,
+                                           int use_kx_prev, int cols, int waves, void* stream) {
+  if (!record) { set_error("fused_iteration3d_pw_rec: no record"); return 1; }
+  return run_iter3d_pw<double>(d, x_new, y_new, x, y, 1.0, 1.0, 1.0, use_kty, use_kx_prev, cols, waves, stream, record);
 }
 }  // extern "C"

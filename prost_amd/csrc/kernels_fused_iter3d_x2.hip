@@ -101,7 +101,12 @@ struct ColX2 {
 template <class T, int VEC, int GFN, bool GB, int WT, bool RES, bool FLAGS>
 __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                        const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2,
-                                                                       double* __restrict__ partial) {
+                                                                       double* __restrict__ partial, const PdhgRecord<T>* __restrict__ rec) {
+  if (rec) {                       // device-resident step sizes (fused_common.hpp: PdhgRecord): both iterations of the launch run with the record's
+    if (rec->stop) return;         // values -- no rule evaluation falls between them (the residual sums, if any, are those of the second)
+    p1.tau = rec->p.tau; p1.sigma = rec->p.sigma; p1.theta = rec->p.theta; p1.step = rec->p.ug.step; p1.sq = rec->p.ug.sq;
+    p2 = p1;
+  }
   // two iterations need TWO valid rows beyond the owned ones on either side (x^(k+2) of a row needs y^(k+1) of the row above, that
   // x^(k+1) of the same row, that the raw y of the row above it): one halo lane of >= 2 rows, or two halo lanes of one row (fp64)
   constexpr int kHalo = VEC >= 2 ? 1 : 2;
@@ -478,7 +483,7 @@ static size_t x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int cols, 
 
 template <class T, int V, int WT>
 static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const IterParams3<T> (&p)[2], int cols,
-                            double* out4, void* ws, hipStream_t s) {
+                            double* out4, void* ws, hipStream_t s, void* record = nullptr, const RuleTail* tail = nullptr) {
   constexpr int P = WT - 3;
   FusedArgs<T> a = make_fused_args<T>(d);
   const size_t groups = (d->L + P - 1) / P;
@@ -490,7 +495,7 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
   if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused 3-D double iteration: grid exceeds the reduction workspace"); return 1; }
   double* partial = static_cast<double*>(ws);
   static const bool flags = []() { const char* e = getenv("PROST_X2_SYNC"); return !(e && atoi(e) == 0); }();      // PROST_X2_SYNC=0: the barrier per step (A/B)
-#define GO3(G, B, R, F) PH_LAUNCH((fused_iter3d_x2_kernel<T, V, G, B, WT, R, F>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial)
+#define GO3(G, B, R, F) PH_LAUNCH((fused_iter3d_x2_kernel<T, V, G, B, WT, R, F>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, static_cast<const PdhgRecord<T>*>(record))
 #define GO2(G, B, R) do { if (flags && !R) GO3(G, B, false, true); else GO3(G, B, R, false); } while (0)
 #define GO(B, R) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B, R); else GO2(PROST_FN_SQUARE, B, R); } while (0)
   if (d->g_coeff_ptr[1]) { if (out4) GO(true, true); else GO(true, false); }
@@ -499,13 +504,14 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
 #undef GO2
 #undef GO3
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused 3-D double iteration kernel"); }
+  if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid, s);
   return 0;
 }
 
 template <class T>
 static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
-                         const double* theta, int cols, double* out4, void* ws, void* stream) {
+                         const double* theta, int cols, double* out4, void* ws, void* stream, void* record = nullptr, const RuleTail* tail = nullptr) {
   constexpr int kDtype = std::is_same<T, float>::value ? 0 : 1;
   if (!iter3d_x2_ok(d, kDtype)) { set_error("fused 3-D double iteration: unsupported description (see prost_hip_fused_iteration3d_x2_supported)"); return 1; }
   if (!aligned16(x_out) || !aligned16(y_out) || !aligned16(x) || !aligned16(y)) { set_error("fused 3-D double iteration: vectors must be 16-byte aligned"); return 1; }
@@ -521,9 +527,9 @@ static int run_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, cons
     p[i].sq = ug.sq; p[i].step = ug.step;
   }
   if constexpr (std::is_same<T, float>::value) {
-    if (x2_vec(kDtype, d->ny) == 2) return launch_iter3d_x2<T, 2, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
+    if (x2_vec(kDtype, d->ny) == 2) return launch_iter3d_x2<T, 2, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream), record, tail);
   }
-  return launch_iter3d_x2<T, 1, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream));
+  return launch_iter3d_x2<T, 1, kX2Waves>(d, x_out, y_out, x, y, p, cols, out4, ws, as_stream(stream), record, tail);
 }
 
 }  // namespace prost_hip
@@ -542,5 +548,21 @@ int prost_hip_fused_iteration3d_x2_f32(const prost_hip_fused_desc* d, float* x_o
 int prost_hip_fused_iteration3d_x2_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, const double* tau,
                                        const double* sigma, const double* theta, int cols, double* res_out4, void* workspace, void* stream) {
   return run_iter3d_x2<double>(d, x_out, y_out, x, y, tau, sigma, theta, cols, res_out4, workspace, stream);
+}
+// both iterations with the step sizes of the device record (prost_hip_pdhg_rule_begin); apply_rule: the fold of the residual sums also
+// evaluates the step-size rule and the stopping test
+int prost_hip_fused_iteration3d_x2_rec_f32(const prost_hip_fused_desc* d, float* x_out, float* y_out, const float* x, const float* y, void* record, int cols,
+                                           double* res_out4, void* workspace, int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused_iteration3d_x2_rec: no record"); return 1; }
+  const double one[2] = {1.0, 1.0};
+  const RuleTail tail{apply_rule, iteration, mirror};
+  return run_iter3d_x2<float>(d, x_out, y_out, x, y, one, one, one, cols, res_out4, workspace, stream, record, &tail);
+}
+int prost_hip_fused_iteration3d_x2_rec_f64(const prost_hip_fused_desc* d, double* x_out, double* y_out, const double* x, const double* y, void* record, int cols,
+                                           double* res_out4, void* workspace, int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!record) { set_error("fused_iteration3d_x2_rec: no record"); return 1; }
+  const double one[2] = {1.0, 1.0};
+  const RuleTail tail{apply_rule, iteration, mirror};
+  return run_iter3d_x2<double>(d, x_out, y_out, x, y, one, one, one, cols, res_out4, workspace, stream, record, &tail);
 }
 }  // extern "C"

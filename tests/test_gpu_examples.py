@@ -68,9 +68,13 @@ def test_example_tv_inpaint_fills_the_holes_with_pair_launches():
     assert np.array_equal(np.asarray(ro["x"]).reshape(-1), u)
 
 
-def _compare_with_oracle(describe, args, prec, dtype, iters, solve_iters):
+def _compare_with_oracle(describe, args, prec, dtype, iters, solve_iters, tol=0.0):
     """iterates after `iters` iterations and a complete prost.solve (callback schedule, stopping test) against oracle.Solver /
-    oracle.solve on the SAME description"""
+    oracle.solve on the SAME description; tol > 0: relative to the vector's scale instead of bit for bit (operators with long sparse
+    rows, whose products cooperating lanes sum in another order than the oracle's row loop -- cuSPARSE defines none)"""
+    def same(a, b):
+        a, b = np.asarray(a).reshape(-1), np.asarray(b).reshape(-1)
+        return np.array_equal(a, b) if tol == 0 else float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max()))
     import oracle
     prost.set_gpu(0)
     prost.set_precision(prec)
@@ -91,17 +95,17 @@ def _compare_with_oracle(describe, args, prec, dtype, iters, solve_iters):
             orc.iterate(k)
             ost = orc.state(); ost.update(orc.scalars())
             for v in "xyzw":
-                assert np.array_equal(st[v], ost[v]), (k, v, float(np.abs(st[v] - ost[v]).max()))
-            assert st["tau"] == ost["tau"] and st["sigma"] == ost["sigma"], (k, st["tau"], ost["tau"])
+                assert same(st[v], ost[v]), (k, v, float(np.abs(st[v] - ost[v]).max()))
+            assert (st["tau"] == ost["tau"] and st["sigma"] == ost["sigma"]) if tol == 0 else np.isclose(st["tau"], ost["tau"], rtol=1e-6), (k, st["tau"], ost["tau"])
         d = describe(*args)
         prob, backend, opts = d[0], d[1], dict(d[2])
         opts["max_iters"] = solve_iters
         res = prost.solve(prob, backend, opts)
         d2 = describe(*args)
         ro = oracle.solve(d2[0], d2[1], opts, dtype)
-        assert res["result"] == ro["result"] and int(res["iters"]) == int(ro["iters"]), (res["result"], res["iters"], ro["result"], ro["iters"])
+        assert res["result"] == ro["result"] and (int(res["iters"]) == int(ro["iters"]) if tol == 0 else abs(int(res["iters"]) - int(ro["iters"])) <= 3), (res["result"], res["iters"], ro["result"], ro["iters"])
         for v in "xyzw":
-            assert np.array_equal(np.asarray(res[v]).reshape(-1), np.asarray(ro[v]).reshape(-1)), v
+            assert same(res[v], ro[v]) if tol == 0 else float(np.abs(np.asarray(res[v]).reshape(-1) - np.asarray(ro[v]).reshape(-1)).max()) <= 50 * tol * max(1.0, float(np.abs(np.asarray(ro[v])).max())), v
         return paths, res
     finally:
         prost.set_precision("double")
@@ -132,5 +136,8 @@ def test_example_deblurring_as_written_matches_the_oracle(prec, dtype):
     variables (the blur matrix's rows hold up to klen entries: summed in CSR order), square data term with a per-element b, the default
     backend options boyd / residual_iter 1"""
     import deblurring as ex
-    paths, res = _compare_with_oracle(lambda nx, ny, nc: ex.describe(nx, ny, nc, klen=5), (24, 16, 2), prec, dtype, (1, 2, 31), 300)
+    # the blur matrix's rows are longer than 6 entries on average: its products run on cooperating lanes (another association than the
+    # oracle's row loop) -- the long-row class of DESIGN.md section 2, compared with a tolerance; the stopping iteration may move by a few
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    paths, res = _compare_with_oracle(lambda nx, ny, nc: ex.describe(nx, ny, nc, klen=5), (24, 16, 2), prec, dtype, (1, 2, 31), 300, tol=tol)
     assert paths == {"pdhg:generic"}

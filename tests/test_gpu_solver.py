@@ -1243,6 +1243,47 @@ def test_device_resident_step_rules_with_colour_channels(precision, dtype, step,
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("step", ["goldstein", "boyd"])
+@pytest.mark.parametrize("nx,ny,L,residual_iter", [(12, 64, 6, 1), (10, 124, 5, 3), (9, 66, 16, 10), (14, 33, 4, 1), (8, 252, 14, 10)])
+def test_device_resident_step_rules_on_volumes(precision, dtype, step, nx, ny, L, residual_iter):
+    """gradient3d (round 5): the one-kernel iteration, its planes-across-wavefronts form and the double-iteration kernel read tau, sigma,
+    theta and the prox terms from the device record (prost_hip_fused_iteration3d_rec / _3d_pw_rec / _3d_x2_rec), the fold of a residual
+    launch applies the rule and the stopping test -- the reference's DEFAULT options (boyd, residual_iter 1) on a volume ran one host
+    round trip per iteration before.  Identical to the host-side rule in every scalar and iterate, identical to the oracle, a complete
+    solve stops at the same iteration.  (ny = 33: odd height, the two-pass kernels -- no record kernels there, the host loop stays.)"""
+    prost.set_precision(precision)
+    prob, u, q, f = synthetic.tv3d_problem(nx, ny, L, lmb=6.0, seed=12)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, tol_rel_primal=2e-2, tol_rel_dual=2e-2, tol_abs_primal=0, tol_abs_dual=0)
+    runs = {}
+    record_kernels = ny % (4 if dtype == np.float32 else 2) == 0
+    for dev in (True, False):
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+        b[1]["allow_device_rules"] = dev
+        s = prost.Solver(prob, b, o)
+        s.iterate(9)
+        a = s.state()
+        s.iterate(300)
+        runs[dev] = (a, s.state())
+        s.destroy()
+        assert runs[dev][1]["path"] == "pdhg:fused-grad3d"
+        assert (runs[dev][1]["device_rule_batches"] >= 3) if (dev and record_kernels) else runs[dev][1]["device_rule_batches"] == 0
+    for a, b_ in zip(runs[True], runs[False]):
+        for v in RULE_SCALARS:
+            assert a[v] == b_[v], (v, a[v], b_[v])
+        for v in "xyzw":
+            assert np.array_equal(a[v], b_[v]), v
+    ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter), o, 309, dtype)
+    assert_same_iterates(runs[True][1], ost)
+    assert runs[True][1]["tau"] == ost["tau"] and runs[True][1]["sigma"] == ost["sigma"]
+    o2 = prost.options(max_iters=3000, num_cback_calls=0, verbose=False, tol_rel_primal=5e-3, tol_rel_dual=5e-3, tol_abs_primal=5e-3, tol_abs_dual=5e-3)
+    b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+    got, exp = prost.solve(prob, b, o2), oracle.solve(prob, b, o2, dtype)
+    assert got["result"] == exp["result"] == "Converged." and int(got["iters"]) == int(exp["iters"]), (got["iters"], exp["iters"])
+    for v in "xyzw":
+        assert np.array_equal(np.asarray(got[v]), np.asarray(exp[v])), v
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step", ["goldstein", "boyd"])
 @pytest.mark.parametrize("residual_iter,cbacks", [(1, 0), (4, 7), (10, 0)])
 def test_device_resident_stopping_test_stops_where_the_host_loop_stops(precision, dtype, step, residual_iter, cbacks):
     """complete prost.solve runs that stop on their tolerance in the MIDDLE of a device batch: result, iteration count and x, y, z, w
