@@ -7,6 +7,7 @@
 // launch, prox_elem_operation.inl:128,187).
 #ifndef PROST_PROX_PROX_HPP_
 #define PROST_PROX_PROX_HPP_
+#include "prost_hip.h"
 #include "prost/common.hpp"
 #include "prost/device_vector.hpp"
 
@@ -85,7 +86,19 @@ class Prox {
     int mode;               ///< PROST_ARG_PDHG_PRIMAL (x, T, K^T y; tau) or PROST_ARG_PDHG_DUAL (y, Sigma, K x, K x_prev; sigma, theta)
     const T* v[4];
     T s[2];
+    // PROST_ARG_PDHG_PRIMAL_OP / _DUAL_OP (round 5): the operator product is formed on the fly as well (prost_hip_arg_spec) -- v[2] (and v[3]
+    // of the dual source) are then unused; v[3] of the primal source = K^T y_prev (read for the residual sums)
+    const prost_hip_fused_op* op = nullptr;
+    size_t op_rows = 0, op_cols = 0;
+    const T* w[2] = {nullptr, nullptr};     ///< whole vectors the product is taken of: y | x, x_prev
+    T* kty_out = nullptr;                   ///< primal source: K^T y is stored here (element 0 of the whole variable)
+    int use[2] = {1, 1};                    ///< 0: that product counts as the zero vector (iterations 0 / 1 of the reference)
+    double* res_ws = nullptr;               ///< residual sums: slots of 4 doubles; *res_slot is advanced by the slots a launch takes
+    unsigned* res_slot = nullptr;
+    unsigned res_slots_max = 0;             ///< slots ONE launch may take
   };
+  /// true if EvalFromSource also takes the operator sources (PROST_ARG_PDHG_PRIMAL_OP / _DUAL_OP)
+  virtual bool supports_op_source() const { return false; }
   /// true if EvalFromSource is implemented; a backend only skips its argument pass when EVERY prox of the list is
   virtual bool supports_arg_source() const { return false; }
   /// EvalFromSource launches only kernels that take their step sizes from the device-resident record of a batch of iterations

@@ -29,6 +29,8 @@ class ProxElemDispatch : public ProxSeparableSum<T> {
   void EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau);
   virtual bool supports_arg_source() const { return true; }
   virtual bool takes_step_record() const { return true; }
+  /// the operator sources run the 16-bytes-per-lane kernel only: planar layout (or the 1-D operation), range and count on 16-byte boundaries
+  virtual bool supports_op_source() const;
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false) {
     EvalSourceLocal(false, result, src, tau_diag, tau, invert_tau);
   }
@@ -56,6 +58,7 @@ class ProxMoreau : public Prox<T> {
   virtual void get_separable_structure(std::vector<std::tuple<size_t, size_t, size_t>>& sep) { conjugate_->get_separable_structure(sep); }
   virtual bool supports_arg_source() const;
   virtual bool takes_step_record() const { return supports_arg_source(); }
+  virtual bool supports_op_source() const { return supports_arg_source() && conjugate_->supports_op_source(); }
   /// the wrapped operation's description with `moreau` set (a wrap of a wrap is not described)
   virtual bool describe(ProxDesc& d) const;
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
@@ -76,6 +79,7 @@ class ProxZero : public Prox<T> {
   virtual size_t gpu_mem_amount() const { return 0; }
   virtual bool supports_arg_source() const { return true; }
   virtual bool takes_step_record() const { return true; }
+  virtual bool supports_op_source() const { const size_t v = 16 / sizeof(T); return this->size_ % v == 0 && this->index_ % v == 0; }
   /// the identity prox of a source IS the argument pass, written straight into the result
   virtual void EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false);
 

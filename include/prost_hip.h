@@ -32,8 +32,11 @@ extern "C" {
  *    additions: comm_count, comm_is_host, comm_host_configure (point-to-point on the host-callback transport),
  *    fused operator entry points of the ADMM graph projection, mask_merge, next_launch_events, pattern_spmv
  * 5: additions only -- device-resident step-size rules (pdhg_rule_*, fused_iteration_rec, fused_iteration2_rec)
- * 6: prost_hip_fused_desc gained f_moreau (appended); additions: event_create_timing; next_launch_events takes (NULL, stop) */
-#define PROST_HIP_ABI_VERSION 6
+ * 6: prost_hip_fused_desc gained f_moreau (appended); additions: event_create_timing; next_launch_events takes (NULL, stop)
+ * 7: prost_hip_op_block gained the row-pattern fields, prost_hip_arg_spec the operator source (both appended; callers that filled the
+ *    old layouts must zero the new members); prost_hip_cgls_workspace_bytes doubled (order-independent sums: (hi, lo) per partial);
+ *    additions: cgls_pixel_round / _close, pixel_op_supported, fused_iteration3d_rec / _3d_pw_rec / _3d_x2_rec, pdhg_fold_sums */
+#define PROST_HIP_ABI_VERSION 7
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
@@ -193,8 +196,26 @@ int prost_hip_prox_elem_moreau_f64(int op, int fn, double* res, const double* ar
  *                          (y, Sigma, K x, K x_prev; sigma, theta)
  * v[] are device pointers to the FIRST element of the prox's range in each vector; res must not alias v[0].
  * moreau != 0 evaluates the conjugate as prost_hip_prox_elem_moreau does. */
-typedef struct prost_hip_arg_spec { int mode; const void* v[4]; double s[2]; } prost_hip_arg_spec;
-enum { PROST_ARG_PLAIN = 0, PROST_ARG_PDHG_PRIMAL = 1, PROST_ARG_PDHG_DUAL = 2 };
+/* ABI 7, the operator sources: the same two arguments with the OPERATOR PRODUCT formed on the fly from the blocks of `op` (sparse blocks
+ * as CSR arrays or row patterns, gradient stencils; evaluated per element in the order LinearOperator::Eval / EvalAdjoint accumulate the
+ * blocks, linearoperator.cu:135-170 -- the bits of the separate passes), so K x and K^T y are never written:
+ *   PROST_ARG_PDHG_PRIMAL_OP  arg = v[0] - s[0] v[1] (K^T w[0])                         v[0] = x, v[1] = T (prox range); w[0] = y (WHOLE dual vector);
+ *                             v[3] = K^T y_prev of the range (read for the residual sums only), kty_out: K^T w[0] of the range is stored there
+ *   PROST_ARG_PDHG_DUAL_OP    arg = v[0] + s[0] v[1] ((1 + s[1]) K w[0] - s[1] K w[1])  v[0] = y, v[1] = Sigma (prox range); w[0] = x, w[1] = x_prev (WHOLE)
+ * base = index of the prox's first element in the whole variable; use[i] = 0 makes product i the zero vector (iterations 0 / 1 of the
+ * reference, backend_pdhg.cu:213-216).  res_ws != NULL: the launch also adds up the terms of the dual (PRIMAL_OP) / primal (DUAL_OP) residual
+ * of its elements (backend_pdhg.cu:73-120) -- one slot of 4 doubles per workgroup from slot res_slot on, at most res_slots_max workgroups;
+ * prost_hip_pdhg_fold_sums folds the slots of an iteration's launches.  Planar layout (or the 1-D operation), count a multiple of 16 bytes of
+ * elements, 16-byte aligned operands (prost_hip_prox_elem_arg_op_supported). */
+typedef struct prost_hip_arg_spec {
+  int mode; const void* v[4]; double s[2];
+  const struct prost_hip_fused_op* op; uint64_t op_rows, op_cols; uint64_t base; const void* w[2]; void* kty_out; int use[2];
+  double* res_ws; unsigned res_slot, res_slots_max;
+} prost_hip_arg_spec;
+enum { PROST_ARG_PLAIN = 0, PROST_ARG_PDHG_PRIMAL = 1, PROST_ARG_PDHG_DUAL = 2, PROST_ARG_PDHG_PRIMAL_OP = 3, PROST_ARG_PDHG_DUAL_OP = 4 };
+/* 1 if the operator sources take `op` (m rows, n columns): sparse / gradient blocks whose positions and sizes -- and a gradient's height
+ * and plane size -- are multiples of 16 bytes of elements (dtype 0: 4, 1: 2); host-only check */
+int prost_hip_prox_elem_arg_op_supported(const struct prost_hip_fused_op* op, uint64_t m, uint64_t n, int dtype);
 int prost_hip_prox_elem_arg_f32(int op, int fn, int moreau, float* res, const prost_hip_arg_spec* arg, const float* tau_diag, double tau, int invert_tau,
                                 size_t count, size_t dim, int interleaved, const float* const* coeff_ptr, const double* coeff_val, void* stream);
 int prost_hip_prox_elem_arg_f64(int op, int fn, int moreau, double* res, const prost_hip_arg_spec* arg, const double* tau_diag, double tau, int invert_tau,
@@ -427,6 +448,13 @@ int prost_hip_pdhg_rule_begin_f64(void* record, const prost_hip_pdhg_rule_opts* 
                                   double arg_alpha, int arb_l, int arb_u, int stop_on_convergence, prost_hip_pdhg_rule_state* mirror, void* stream);
 int prost_hip_pdhg_rule_apply_f32(void* record, const double* sums4, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
 int prost_hip_pdhg_rule_apply_f64(void* record, const double* sums4, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+/* The residual sums of an iteration whose prox launches added them up themselves (prost_hip_prox_elem_arg with an operator source and
+ * res_ws): out4 = {primal: sum diff^2, sum z_hat^2 ; dual: sum diff^2, sum w_hat^2} (backend_pdhg.cu:392-431) from n_primal / n_dual slots of 4
+ * doubles; record != NULL and apply_rule: the step-size rule and the stopping test follow in the same launch (prost_hip_pdhg_rule_apply). */
+int prost_hip_pdhg_fold_sums_f32(double* out4, const double* ws_primal, unsigned n_primal, const double* ws_dual, unsigned n_dual, void* record, int apply_rule,
+                                 unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_pdhg_fold_sums_f64(double* out4, const double* ws_primal, unsigned n_primal, const double* ws_dual, unsigned n_dual, void* record, int apply_rule,
+                                 unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
 /* apply_rule != 0 (res_out4 != NULL): the kernel that folds the four sums also evaluates the rule on them -- what _apply does, one launch
  * less per residual iteration; for residual iterations whose sums need no all-reduce.  `iteration`, `mirror`: as for _apply. */
 int prost_hip_fused_iteration_rec_f32(const prost_hip_fused_desc* desc, float* x_new, float* y_new, const float* x, const float* y, const float* y_prev,
@@ -664,7 +692,17 @@ typedef struct prost_hip_op_block {
   uint64_t nx, ny, L;                       /* gradient blocks */
   const void* val; const int32_t* ptr; const int32_t* ind;          /* CSR of K   (T values, nrows + 1 row starts) */
   const void* val_t; const int32_t* ptr_t; const int32_t* ind_t;    /* CSR of K^T (ncols + 1 row starts) */
+  /* ABI 7: a sparse block whose product runs from ROW PATTERNS (prost_hip_pattern_spmv: one 16-bit pattern number per row + a table of
+   * (column - row, value) sequences) instead of CSR arrays, for K and / or K^T; ids / ids_t NULL: the CSR arrays above */
+  const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval;
+  const uint16_t* ids_t; const int32_t* pptr_t; const int32_t* rel_t; const void* pval_t;
+  /* the DOMINANT pattern of K / K^T (the one most rows have: the interior of a stencil), copied out of the table -- dom_n entries
+   * (0: none given, or longer than PROST_HIP_OP_DOM_MAX): a kernel that applies the block inside another kernel requests the operands
+   * of this pattern while the pattern numbers of its rows are still on their way and keeps them if the numbers confirm it */
+  int dom_id, dom_n; int32_t dom_rel[12]; double dom_val[12];
+  int dom_id_t, dom_n_t; int32_t dom_rel_t[12]; double dom_val_t[12];
 } prost_hip_op_block;
+#define PROST_HIP_OP_DOM_MAX 12
 #define PROST_HIP_OP_MAX_BLOCKS 4
 typedef struct prost_hip_fused_op {
   int nblocks;

@@ -45,7 +45,11 @@ class OpBlock(C.Structure):
     """prost_hip_op_block"""
     _fields_ = [("kind", C.c_int), ("row", C.c_uint64), ("col", C.c_uint64), ("nrows", C.c_uint64), ("ncols", C.c_uint64),
                 ("nx", C.c_uint64), ("ny", C.c_uint64), ("L", C.c_uint64),
-                ("val", C.c_void_p), ("ptr", C.c_void_p), ("ind", C.c_void_p), ("val_t", C.c_void_p), ("ptr_t", C.c_void_p), ("ind_t", C.c_void_p)]
+                ("val", C.c_void_p), ("ptr", C.c_void_p), ("ind", C.c_void_p), ("val_t", C.c_void_p), ("ptr_t", C.c_void_p), ("ind_t", C.c_void_p),
+                ("ids", C.c_void_p), ("pptr", C.c_void_p), ("rel", C.c_void_p), ("pval", C.c_void_p),          # ABI 7: row patterns of K ...
+                ("ids_t", C.c_void_p), ("pptr_t", C.c_void_p), ("rel_t", C.c_void_p), ("pval_t", C.c_void_p),    # ... and of K^T (NULL: CSR)
+                ("dom_id", C.c_int), ("dom_n", C.c_int), ("dom_rel", C.c_int32 * 12), ("dom_val", C.c_double * 12),           # the dominant pattern (dom_n = 0: none)
+                ("dom_id_t", C.c_int), ("dom_n_t", C.c_int), ("dom_rel_t", C.c_int32 * 12), ("dom_val_t", C.c_double * 12)]
 
 
 class FusedOp(C.Structure):
@@ -73,8 +77,8 @@ def lib():
                            "(or make -C prost_amd/csrc)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.prost_hip_last_error.restype = C.c_char_p
-        if L.prost_hip_abi_version() != 6:
-            raise HipError("libprost_hip.so has ABI version %d, this binding needs 6: rebuild (make -C prost_amd/csrc)" % L.prost_hip_abi_version())
+        if L.prost_hip_abi_version() != 7:
+            raise HipError("libprost_hip.so has ABI version %d, this binding needs 7: rebuild (make -C prost_amd/csrc)" % L.prost_hip_abi_version())
         L.prost_hip_reduce_workspace_bytes.restype = C.c_size_t
         L.prost_hip_cgls_state_bytes.restype = C.c_size_t
         L.prost_hip_cgls_workspace_bytes.restype = C.c_size_t

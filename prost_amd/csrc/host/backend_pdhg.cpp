@@ -13,6 +13,7 @@
 #include <type_traits>
 #include <atomic>
 #include <cmath>
+#include <cstring>
 #include <iostream>
 
 #include "hipapi.hpp"
@@ -214,6 +215,12 @@ void BackendPDHG<T>::Initialize() {
   arg_fused_g_ = arg_fused_f_ = opts_.allow_arg_fusion;
   for (auto& p : prox_g_) arg_fused_g_ = arg_fused_g_ && p->supports_arg_source();
   for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
+  // the operator inside the prox kernels (round 5): every block a sparse matrix or a gradient stencil, every prox able to form K^T y /
+  // K x for its own elements (the in-tree elem operations, their Moreau wraps, the identity, on 16-byte boundaries)
+  op_fused_ = !fused_ && opts_.allow_op_fusion && arg_fused_g_ && arg_fused_f_ && owned_x1_ == 0 && DescribeGenericOperator();
+  for (auto& p : prox_g_) op_fused_ = op_fused_ && p->supports_op_source();
+  for (auto& p : prox_fstar_) op_fused_ = op_fused_ && p->supports_op_source();
+  if (op_fused_ && !op_workspace_) CheckHip(prost_hip_malloc(&op_workspace_, 2 * (size_t)kOpSumSlots * 4 * sizeof(double)), "malloc");
   single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
   single3d_ = fused_ && !single_kernel_ && opts_.allow_single_kernel && prost_hip_fused_iteration3d_supported(&desc_, dtype_id<T>()) == 1;
   single3d_pw_ = single3d_ && prost_hip_fused_iteration3d_pw_supported(&desc_, dtype_id<T>()) == 1;
@@ -304,6 +311,7 @@ void BackendPDHG<T>::Release() {
   if (res_dev_) { prost_hip_free(res_dev_); res_dev_ = nullptr; }
   if (res_host_) { prost_hip_host_free(res_host_); res_host_ = nullptr; }
   if (workspace_) { prost_hip_free(workspace_); workspace_ = nullptr; }
+  if (op_workspace_) { prost_hip_free(op_workspace_); op_workspace_ = nullptr; }
   if (rule_rec_) { prost_hip_free(rule_rec_); rule_rec_ = nullptr; }
   if (rule_mirror_) { prost_hip_host_free(rule_mirror_); rule_mirror_ = nullptr; }
   if (rule_mirror_dev_) { prost_hip_free(rule_mirror_dev_); rule_mirror_dev_ = nullptr; }
@@ -754,8 +762,88 @@ void BackendPDHG<T>::IterationFused(bool res) {
   iteration_++;
 }
 
+/// The operator as a table of sparse (CSR arrays or row patterns) and gradient blocks for the operator sources of the prox kernels
+/// (prost_hip_prox_elem_arg, PROST_ARG_PDHG_PRIMAL_OP / _DUAL_OP); plugin blocks, diags, Kronecker blocks, label_first gradients and a
+/// dualized operator keep the separate products.
+template <typename T>
+bool BackendPDHG<T>::DescribeGenericOperator() {
+  auto linop = this->problem_->linop();
+  if (dynamic_cast<DualLinearOperator<T>*>(linop.get())) return false;
+  const auto& blocks = linop->blocks();
+  if (blocks.empty() || blocks.size() > (size_t)PROST_HIP_OP_MAX_BLOCKS) return false;
+  prost_hip_fused_op op;
+  std::memset(&op, 0, sizeof(op));
+  for (const auto& b : blocks) {
+    BlockDesc bd;
+    if (!b->describe(bd)) return false;
+    prost_hip_op_block& o = op.block[op.nblocks++];
+    o.row = b->row(); o.col = b->col(); o.nrows = b->nrows(); o.ncols = b->ncols();
+    if (bd.kind == BlockDesc::kSparse) {
+      o.kind = PROST_OP_CSR;
+      o.val = bd.val; o.ptr = bd.ptr; o.ind = bd.ind; o.val_t = bd.val_t; o.ptr_t = bd.ptr_t; o.ind_t = bd.ind_t;
+      o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t;
+      o.dom_id = bd.dom_id; o.dom_n = bd.dom_n; o.dom_id_t = bd.dom_id_t; o.dom_n_t = bd.dom_n_t;
+      for (int k = 0; k < PROST_HIP_OP_DOM_MAX; k++) { o.dom_rel[k] = bd.dom_rel[k]; o.dom_val[k] = bd.dom_val[k]; o.dom_rel_t[k] = bd.dom_rel_t[k]; o.dom_val_t[k] = bd.dom_val_t[k]; }
+    } else if ((bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D) && !bd.label_first) {
+      o.kind = bd.kind == BlockDesc::kGradient2D ? PROST_OP_GRAD2D : PROST_OP_GRAD3D;
+      o.nx = bd.nx; o.ny = bd.ny; o.L = bd.L;
+    } else {
+      return false;
+    }
+  }
+  if (prost_hip_prox_elem_arg_op_supported(&op, this->problem_->nrows(), this->problem_->ncols(), dtype_id<T>()) != 1) return false;
+  gen_op_ = op;
+  return true;
+}
+
+/// One generic iteration with the operator INSIDE the prox kernels: the launches of prox_g form x - tau T K^T y for their own elements
+/// (and store K^T y, n values, for the next iteration's dual residual), the launches of prox_f* form y + sigma Sigma ((1 + theta) K x -
+/// theta K x_prev); on residual iterations they add up the residual terms as well and ONE more launch folds the sums (+ the rule inside a
+/// device batch).  K x is never written, the fill passes and the four operator launches are gone: deblurring's shape 9 -> 4 launches.
+/// Same expressions, same block order, same bits as IterationGeneric (the reference's zero vectors of iterations 0 / 1 included).
+template <typename T>
+void BackendPDHG<T>::IterationGenericOp(bool res) {
+  void* s = CurrentStream();
+  const size_t n = this->problem_->ncols(), m = this->problem_->nrows();
+  const device_vector<T>& Tr = this->problem_->scaling_right();
+  const device_vector<T>& Sl = this->problem_->scaling_left();
+  // the reduction workspace as slots of 4 doubles: primal sums (prox_f* launches) in the first half, dual sums (prox_g launches) in the second
+  const unsigned half = kOpSumSlots;
+  double* ws_p = static_cast<double*>(op_workspace_);
+  double* ws_d = ws_p + 4 * (size_t)half;
+  unsigned slot_p = 0, slot_d = 0;
+  kty_.swap(kty_prev_);                    // kty_prev_ = K^T y^(k-1) as the previous iteration stored it (zeros before); kty_ is written below
+  x_.swap(x_prev_);
+  {
+    typename Prox<T>::ArgSource src{PROST_ARG_PDHG_PRIMAL_OP, {x_prev_.data(), Tr.data(), nullptr, kty_prev_.data()}, {tau_, (T)0}};
+    src.op = &gen_op_; src.op_rows = m; src.op_cols = n;
+    src.w[0] = y_.data(); src.kty_out = kty_.data();
+    src.use[0] = iteration_ >= 1 ? 1 : 0;                    // kty_ is the zero vector in iteration 0 (backend_pdhg.cu:213)
+    if (res) { src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, half / (unsigned)std::max<size_t>(prox_g_.size(), 1)); }
+    for (auto& p : prox_g_) p->EvalFromSource(x_, src, Tr, tau_);
+  }
+  y_.swap(y_prev_);
+  {
+    typename Prox<T>::ArgSource src{PROST_ARG_PDHG_DUAL_OP, {y_prev_.data(), Sl.data(), nullptr, nullptr}, {sigma_, theta_}};
+    src.op = &gen_op_; src.op_rows = m; src.op_cols = n;
+    src.w[0] = x_.data(); src.w[1] = x_prev_.data();
+    src.use[1] = iteration_ >= 1 ? 1 : 0;                    // kx_prev_ is the zero vector in iteration 0 (:216)
+    if (res) { src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1)); }
+    for (auto& p : prox_fstar_) p->EvalFromSource(y_, src, Sl, sigma_);
+  }
+  if (res) {
+    const bool rule_here = in_device_batch_ && !this->comm_;
+    CheckHip(Api<T>::pdhg_fold_sums(res_target(), ws_p, slot_p, ws_d, slot_d, rule_here ? rule_rec_ : nullptr, rule_here ? 1 : 0, (unsigned long long)iteration_,
+                                    rule_here ? rule_mirror_dev_ : nullptr, s), "pdhg_fold_sums");
+    FinishResiduals();
+  }
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  iteration_++;
+}
+
 template <typename T>
 void BackendPDHG<T>::IterationGeneric(bool res) {
+  if (op_fused_) { IterationGenericOp(res); return; }
   void* s = CurrentStream();
   const size_t n = this->problem_->ncols(), m = this->problem_->nrows();
   const device_vector<T>& Tr = this->problem_->scaling_right();
@@ -831,8 +919,9 @@ void BackendPDHG<T>::FinishResiduals() {
       CheckHip(Api<T>::pdhg_rule_apply(rule_rec_, res_dev_, (unsigned long long)iteration_, rule_mirror_dev_, s), "pdhg_rule_apply");
     }
     // (generic path: IterationGeneric exchanges kty_ / kty_prev_ AFTER this call -- the mark holds the roles the iteration leaves)
+    // (operator inside the prox kernels: kty_ / kty_prev_ were exchanged at the START of the iteration and stay)
     batch_marks_.push_back({iteration_ + 1, pair_launches_, x_.data(), x_prev_.data(), y_.data(), y_prev_.data(), prev_stale_,
-                            kx_.data(), kx_prev_.data(), kty_prev_.data(), kty_.data()});
+                            kx_.data(), kx_prev_.data(), op_fused_ ? kty_.data() : kty_prev_.data(), op_fused_ ? kty_prev_.data() : kty_.data()});
     // kernel timing: launches enqueued behind a stopping iteration return at once -- their samples must not enter the averages
     // (RestoreRoles drops everything recorded after the mark it returns to)
     static_assert(kKernelKinds == 8, "BatchMark::launches holds one counter per kernel kind");
@@ -984,6 +1073,14 @@ void BackendPDHG<T>::ConstraintVariables() {
     CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), ktyp.data(), (double)tau_, n, s), "w_variable");
     CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx.data(), kxp.data(), (double)sigma_, (double)theta_, m, s), "z_variable");
     CheckHip(prost_hip_stream_synchronize(s), "stream_synchronize");             // the temporaries above go out of scope
+  } else if (op_fused_) {
+    // the operator products are not resident: K^T y^k is what the last primal launch stored (kty_; the zero vector after iteration 0, as
+    // the reference's kty_prev_), K x and K x_prev are formed now (kx_prev_: the zero vector after the first iteration)
+    this->problem_->linop()->Eval(kx_, x_);
+    if (iteration_ >= 2) this->problem_->linop()->Eval(kx_prev_, x_prev_);
+    else CheckHip(prost_hip_memset(kx_prev_.data(), 0, m * sizeof(T), s), "memset");
+    CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), kty_.data(), (double)tau_, n, s), "w_variable");
+    CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "z_variable");
   } else {
     CheckHip(Api<T>::pdhg_w_variable(sol_w_.data(), x_prev_.data(), x_.data(), Tr.data(), kty_prev_.data(), (double)tau_, n, s), "w_variable");   // :147-160
     CheckHip(Api<T>::pdhg_z_variable(sol_z_.data(), y_prev_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "z_variable");   // :169-186

@@ -55,6 +55,7 @@ template <typename T> struct Api;
     static constexpr auto pdhg_rule_begin = prost_hip_pdhg_rule_begin_##S;        \
     static constexpr auto pdhg_rule_apply = prost_hip_pdhg_rule_apply_##S;        \
     static constexpr auto pdhg_residuals = prost_hip_pdhg_residuals_##S;          \
+    static constexpr auto pdhg_fold_sums = prost_hip_pdhg_fold_sums_##S;          \
     static constexpr auto fused_iteration3d = prost_hip_fused_iteration3d_##S;    \
     static constexpr auto fused_iteration_mc = prost_hip_fused_iteration_mc_##S;  \
     static constexpr auto fused_iteration_mc_x2 = prost_hip_fused_iteration_mc_x2_##S; \

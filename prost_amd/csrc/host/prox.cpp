@@ -1,4 +1,5 @@
 // prox.cpp -- proximal operators of the prost host library (calls prost_hip.h only).
+#include <algorithm>
 #include <chrono>
 #include <sstream>
 
@@ -81,6 +82,28 @@ void ProxElemDispatch<T>::EvalLocal(T* res, T*, const T* arg, const T*, const T*
   CheckHip(Api<T>::prox_elem(op_, fn_, res, arg, tau_diag, (double)tau, invert_tau ? 1 : 0, this->count_, this->dim_,
                              this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem");
 }
+/// the device-side argument description of a prox that covers [index, index + size) of its variable (prost_hip_arg_spec)
+template <typename T>
+static void FillArgSpec(prost_hip_arg_spec& a, const typename Prox<T>::ArgSource& src, size_t index, size_t size) {
+  (void)size;
+  a.mode = src.mode;
+  for (int k = 0; k < 4; k++) a.v[k] = src.v[k] ? src.v[k] + index : nullptr;
+  a.s[0] = (double)src.s[0]; a.s[1] = (double)src.s[1];
+  a.op = src.op; a.op_rows = src.op_rows; a.op_cols = src.op_cols; a.base = index;
+  a.w[0] = src.w[0]; a.w[1] = src.w[1];                        // WHOLE vectors: the operator indexes them
+  a.kty_out = src.kty_out ? src.kty_out + index : nullptr;
+  a.use[0] = src.use[0]; a.use[1] = src.use[1];
+  a.res_ws = src.res_ws; a.res_slot = src.res_slot ? *src.res_slot : 0; a.res_slots_max = src.res_slots_max;
+}
+/// workgroups (= partial slots) the 16-bytes-per-lane kernel launches for `count` element groups under the cap of the source
+template <typename T>
+static unsigned ResSlotsOfLaunch(const typename Prox<T>::ArgSource& src, size_t count) {
+  const size_t v = 16 / sizeof(T), lanes = count / v;
+  size_t g = (lanes + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > (size_t)1 << 20) g = (size_t)1 << 20;
+  return (unsigned)std::min<size_t>(g, src.res_slots_max);
+}
 template <typename T>
 void ProxElemDispatch<T>::EvalMoreauLocal(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau) {
   const T* ptrs[7]; double vals[7];
@@ -94,11 +117,16 @@ void ProxElemDispatch<T>::EvalSourceLocal(bool moreau, device_vector<T>& result,
   const T* ptrs[7]; double vals[7];
   CoeffArgs(ptrs, vals);
   prost_hip_arg_spec a;
-  a.mode = src.mode;
-  for (int k = 0; k < 4; k++) a.v[k] = src.v[k] ? src.v[k] + this->index_ : nullptr;
-  a.s[0] = (double)src.s[0]; a.s[1] = (double)src.s[1];
+  FillArgSpec<T>(a, src, this->index_, this->size_);
   CheckHip(Api<T>::prox_elem_arg(op_, fn_, moreau ? 1 : 0, result.data() + this->index_, &a, tau_diag.data() + this->index_, (double)tau,
                                  invert_tau ? 1 : 0, this->count_, this->dim_, this->interleaved_ ? 1 : 0, ptrs, vals, CurrentStream()), "prox_elem_arg");
+  if (src.res_ws && src.res_slot) *src.res_slot += ResSlotsOfLaunch<T>(src, this->count_);
+}
+template <typename T>
+bool ProxElemDispatch<T>::supports_op_source() const {
+  const size_t v = 16 / sizeof(T);
+  const bool planar = op_ == PROST_OP_1D || !this->interleaved_ || this->dim_ == 1;
+  return planar && this->count_ % v == 0 && this->index_ % v == 0;
 }
 template class ProxElemDispatch<float>;
 template class ProxElemDispatch<double>;
@@ -148,6 +176,16 @@ void ProxZero<T>::EvalFromSource(device_vector<T>& result, const typename Prox<T
     CheckHip(Api<T>::pdhg_primal_arg(result.data() + i, src.v[0] + i, src.v[1] + i, src.v[2] + i, (double)src.s[0], this->size_, s), "primal_arg");
   else if (src.mode == PROST_ARG_PDHG_DUAL)
     CheckHip(Api<T>::pdhg_dual_arg(result.data() + i, src.v[0] + i, src.v[1] + i, src.v[2] + i, src.v[3] + i, (double)src.s[0], (double)src.s[1], this->size_, s), "dual_arg");
+  else if (src.mode == PROST_ARG_PDHG_PRIMAL_OP || src.mode == PROST_ARG_PDHG_DUAL_OP) {
+    // the identity as the 1-D operation of the zero function with a = c = 1, b = d = e = 0: ((1 (arg - 0 tau)) / 1 - 0 + 0) / 1 = arg, exactly
+    // (elem_operation_1d.hpp:45-58) -- the launch that forms the argument from the operator writes it straight into the result
+    prost_hip_arg_spec a;
+    FillArgSpec<T>(a, src, i, this->size_);
+    const T* ptrs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const double vals[7] = {1, 0, 1, 0, 0, 0, 0};
+    CheckHip(Api<T>::prox_elem_arg(PROST_OP_1D, PROST_FN_ZERO, 0, result.data() + i, &a, src.v[1] + i, (double)src.s[0], 0, this->size_, 1, 0, ptrs, vals, s), "prox_elem_arg");
+    if (src.res_ws && src.res_slot) *src.res_slot += ResSlotsOfLaunch<T>(src, this->size_);
+  }
   else throw Exception("ProxZero: unknown argument source.");
 }
 template <typename T>

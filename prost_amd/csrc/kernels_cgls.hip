@@ -23,6 +23,7 @@
 #include <limits>
 
 #include "elementwise.hpp"
+#include "fused_op.hpp"
 
 namespace prost_hip {
 
@@ -61,35 +62,6 @@ __global__ void __launch_bounds__(kBlock) cg_stage_kernel(F f, size_t n0, size_t
       region(ws, F::kRegion2)[4 * blockIdx.x + 1] = region(ws, F::kRegion)[4 * blockIdx.x + 1];
     }
   }
-}
-
-// two folds at once (reduce.hpp, fold_dd): both sets of loads in flight together, one pair of barriers; every thread of every
-// workgroup of every kernel obtains the same two doubles (order-independent sums)
-__device__ __forceinline__ void fold_dd2(const double* __restrict__ pa, unsigned ga, unsigned sa_, const double* __restrict__ pb, unsigned gb, unsigned sb_,
-                                         double& ra, double& rb) {
-  __shared__ dd_t s_fa[kBlock / kWave], s_fb[kBlock / kWave];
-  dd_t a{0.0, 0.0}, b{0.0, 0.0};
-  const unsigned gmax = ga > gb ? ga : gb;
-  for (unsigned base = threadIdx.x; base < gmax; base += 4 * kBlock) {
-    double ah[4], al[4], bh[4], bl[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const unsigned i = base + k * kBlock;
-      ah[k] = i < ga ? pa[(size_t)sa_ * i] : 0.0; al[k] = i < ga ? pa[(size_t)sa_ * i + 1] : 0.0;
-      bh[k] = i < gb ? pb[(size_t)sb_ * i] : 0.0; bl[k] = i < gb ? pb[(size_t)sb_ * i + 1] : 0.0;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { a = dd_add(a, dd_t{ah[k], al[k]}); b = dd_add(b, dd_t{bh[k], bl[k]}); }
-  }
-  a = wave_sum_dd(a);
-  b = wave_sum_dd(b);
-  __syncthreads();
-  if ((threadIdx.x & (kWave - 1)) == 0) { s_fa[threadIdx.x / kWave] = a; s_fb[threadIdx.x / kWave] = b; }
-  __syncthreads();
-  dd_t ta = s_fa[0], tb = s_fb[0];
-#pragma unroll
-  for (int w = 1; w < kBlock / kWave; w++) { ta = dd_add(ta, s_fa[w]); tb = dd_add(tb, s_fb[w]); }
-  ra = ta.hi; rb = tb.hi;
 }
 
 enum { kScalarsInitX = 0, kScalarsInitS, kScalarsAlpha, kScalarsBeta };
@@ -668,184 +640,13 @@ static int normest_stage(int stage, const prost_hip_normest_desc* d, void* strea
 //   * the scalar record is an ARRAY: round j reads record j and writes record j + 1, so no kernel reads a field that
 //     another workgroup of the same launch writes.
 // Round:  OP_FWD<FwdQ>  |  STEP_XR2 (alpha)  |  OP_ADJ<AdjS>  |  STEP_P2 (beta, stopping test)
-struct OpBlockDev {
-  int kind;
-  unsigned long long row, col, nrows, ncols, nx, ny, L;
-  const void* val; const int32_t* ptr; const int32_t* ind;
-  const void* val_t; const int32_t* ptr_t; const int32_t* ind_t;
-};
-struct FusedOpDev { int nblocks; OpBlockDev b[PROST_HIP_OP_MAX_BLOCKS]; };
-
-// a[j] belongs to element j * 64 + lane of a 64 VEC-element range; out[c] := element VEC * lane + c (all 64 lanes active)
-template <class T, int VEC>
-__device__ __forceinline__ void wave_untranspose(const T (&a)[VEC], T (&out)[VEC], unsigned lane) {
-  const unsigned src_j = (VEC * lane) / kWave;          // the same for the VEC elements of a lane: VEC divides 64
-#pragma unroll
-  for (int c = 0; c < VEC; c++) {
-    const int src_lane = (int)((VEC * lane + c) & (kWave - 1));
-    T v = 0;
-#pragma unroll
-    for (int j = 0; j < VEC; j++) { const T tmp = __shfl(a[j], src_lane, kWave); if ((unsigned)j == src_j) v = tmp; }
-    out[c] = v;
-  }
-}
-
-// sum[j] = (A rhs)_(r_j), j < VEC, for VEC rows of a CSR matrix -- ONE loop over the entry positions with the VEC rows side
-// by side, so that the loads of the VEC rows (row starts, then values / indices, then gathered operands: three dependent
-// levels) are in flight together instead of one row after the other.  Per row the entries are summed in order, as
-// csr_spmv_kernel<T, 1, .> does.
-template <class T, int VEC>
-__device__ __forceinline__ void csr_rows(const T* __restrict__ val, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ind,
-                                         const T* __restrict__ rhs, const size_t (&r)[VEC], T (&sum)[VEC]) {
-  int32_t b[VEC], e[VEC], len = 0;
-#pragma unroll
-  for (int j = 0; j < VEC; j++) { b[j] = ptr[r[j]]; e[j] = ptr[r[j] + 1]; }
-#pragma unroll
-  for (int j = 0; j < VEC; j++) { sum[j] = 0; len = e[j] - b[j] > len ? e[j] - b[j] : len; }
-  for (int32_t st = 0; st < len; st++) {
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      const int32_t k = b[j] + st;
-      if (k < e[j]) sum[j] += val[k] * rhs[ind[k]];
-    }
-  }
-}
-// the contribution of one CSR block (or its transpose) to the VEC elements starting at local index r0 of this lane; `wave0`: local
-// index of lane 0's first element, `whole`: the wavefront's 64 VEC elements all lie inside the block -- then the lanes take the rows
-// transposed (lane, lane + 64, ...: neighbouring lanes load neighbouring rows) and the sums are shuffled back
-template <class T, int VEC>
-__device__ __forceinline__ void csr_contrib(const T* __restrict__ val, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ind,
-                                            const T* __restrict__ rhs, size_t r0, size_t wave0, bool whole, T (&sum)[VEC]) {
-  size_t r[VEC];
-  if (VEC > 1 && whole) {
-    const unsigned lane = threadIdx.x & (kWave - 1);
-    T st[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) r[j] = wave0 + (size_t)j * kWave + lane;
-    csr_rows<T, VEC>(val, ptr, ind, rhs, r, st);
-    wave_untranspose<T, VEC>(st, sum, lane);
-  } else {
-#pragma unroll
-    for (int j = 0; j < VEC; j++) r[j] = r0 + j;
-    csr_rows<T, VEC>(val, ptr, ind, rhs, r, sum);
-  }
-}
-
-// kv[0..VEC) = (K rhs)_(i .. i+VEC).  VEC > 1: i, every block's row / col / nrows and every gradient block's ny and plane
-// size are multiples of VEC (host-checked), so the VEC rows lie in the same blocks, the same component plane and image column.
-// w0 = the i of lane 0 (wave-uniform); VEC > 1 callers guarantee that all 64 lanes are active.
-template <class T, int VEC>
-__device__ __forceinline__ void op_fwd_rows(const FusedOpDev& op, size_t i, size_t w0, const T* __restrict__ t, T (&kv)[VEC]) {
-#pragma unroll
-  for (int j = 0; j < VEC; j++) kv[j] = 0;
-  for (int b = 0; b < op.nblocks; b++) {
-    const OpBlockDev& B = op.b[b];
-    if (i < B.row || i >= B.row + B.nrows) continue;
-    const size_t r = i - B.row;
-    const T* rhs = t + B.col;
-    if (B.kind == PROST_OP_CSR) {
-      const bool whole = VEC > 1 && w0 >= B.row && w0 + (size_t)kWave * VEC <= B.row + B.nrows;
-      T sum[VEC];
-      csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, rhs, r, w0 - B.row, whole, sum);
-#pragma unroll
-      for (int j = 0; j < VEC; j++) kv[j] = kv[j] + sum[j];
-    } else {
-      const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, N = slice * (unsigned)B.L;
-      const unsigned r32 = (unsigned)r;
-      const unsigned c = r32 / N, idx = r32 - c * N;
-      T cur[VEC], g[VEC];
-      ldv<T, VEC>(rhs + idx, cur);
-      if (c == 0) {
-        const unsigned x = (idx / ny) % nx;
-        T nb[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; j++) nb[j] = 0;
-        if (x < nx - 1) ldv<T, VEC>(rhs + idx + ny, nb);
-#pragma unroll
-        for (int j = 0; j < VEC; j++) g[j] = x < nx - 1 ? nb[j] - cur[j] : (T)0;
-      } else if (c == 1) {
-        const unsigned y = idx % ny;
-        const T below = y + VEC < ny ? rhs[idx + VEC] : (T)0;
-#pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          const T dn = j + 1 < VEC ? cur[(j + 1) % VEC] : below;
-          g[j] = y + j < ny - 1 ? dn - cur[j] : (T)0;
-        }
-      } else {
-        const unsigned l = idx / slice;
-        T up[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; j++) up[j] = 0;
-        if (l < (unsigned)B.L - 1) ldv<T, VEC>(rhs + idx + slice, up);
-#pragma unroll
-        for (int j = 0; j < VEC; j++) g[j] = l < (unsigned)B.L - 1 ? up[j] - cur[j] : -cur[j];      // Dirichlet (block_gradient3d.cu:73-76)
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; j++) kv[j] = kv[j] + g[j];
-    }
-  }
-}
-// v[0..VEC) += (K^T rhs)_(j .. j+VEC), blocks in order (EvalAdjointAdd per block)
-template <class T, int VEC>
-__device__ __forceinline__ void op_adj_cols(const FusedOpDev& op, size_t jg, size_t w0, const T* __restrict__ t, T (&v)[VEC]) {
-  for (int b = 0; b < op.nblocks; b++) {
-    const OpBlockDev& B = op.b[b];
-    if (jg < B.col || jg >= B.col + B.ncols) continue;
-    const size_t cidx = jg - B.col;
-    const T* rhs = t + B.row;
-    if (B.kind == PROST_OP_CSR) {
-      const bool whole = VEC > 1 && w0 >= B.col && w0 + (size_t)kWave * VEC <= B.col + B.ncols;
-      T sum[VEC];
-      csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - B.col, whole, sum);
-#pragma unroll
-      for (int j = 0; j < VEC; j++) v[j] = v[j] + sum[j];
-    } else {
-      const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, idx = (unsigned)cidx;
-      const size_t N = (size_t)slice * B.L;
-      const unsigned y = idx % ny, x = (idx / ny) % nx;
-      T px[VEC], pxm[VEC], py[VEC];
-      ldv<T, VEC>(rhs + idx, px);
-      ldv<T, VEC>(rhs + N + idx, py);
-#pragma unroll
-      for (int j = 0; j < VEC; j++) pxm[j] = 0;
-      if (x > 0) ldv<T, VEC>(rhs + idx - ny, pxm);
-      const T above = y > 0 ? rhs[N + idx - 1] : (T)0;
-      T pl[VEC], plm[VEC];
-      unsigned l = 0;
-      if (B.kind == PROST_OP_GRAD3D) {
-        l = idx / slice;
-        ldv<T, VEC>(rhs + 2 * N + idx, pl);
-#pragma unroll
-        for (int j = 0; j < VEC; j++) plm[j] = 0;
-        if (l > 0) ldv<T, VEC>(rhs + 2 * N + idx - slice, plm);
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; j++) {
-        T divx, divy;
-        if (y + j < ny - 1) divy = py[j]; else divy = 0;
-        if (y + j > 0) divy -= j > 0 ? py[(j + VEC - 1) % VEC] : above;
-        if (x < nx - 1) divx = px[j]; else divx = 0;
-        if (x > 0) divx -= pxm[j];
-        T sdiv;
-        if (B.kind == PROST_OP_GRAD3D) {
-          T divl = pl[j];
-          if (l > 0) divl -= plm[j];
-          sdiv = divx + divy + divl;
-        } else {
-          sdiv = divx + divy;
-        }
-        v[j] = v[j] - sdiv;                     // adjoint is minus the divergence
-      }
-    }
-  }
-}
-
 // out = E(K in) / out = E(v0 + K^T in) with the stage functor E as epilogue; `count` output elements; E::kRegion >= 0: one
 // partial (pair) per workgroup.  E::prologue runs in every thread of every workgroup before the loop (block-wide folds).
 // A wavefront takes 64 VEC consecutive elements per step, lane l the VEC elements from (w0 + l) VEC; the last, partly filled
 // step of the range and the count % VEC tail run one element per lane.
 template <class T, int VEC, bool ADJ, class E>
-__global__ void __launch_bounds__(kBlock) op_stage_kernel(FusedOpDev op, E e, const T* __restrict__ in, size_t count, const CgState* cur, double* ws) {
+__global__ void __launch_bounds__(kBlock) op_stage_kernel(const FusedOpDev* __restrict__ opp, E e, const T* __restrict__ in, size_t count, const CgState* cur, double* ws) {
+  const FusedOpDev& op = *opp;
   if (E::kSkipWhenDone && cur->done) return;
   e.prologue(cur, ws);
   dd_t sa{0.0, 0.0}, sb{0.0, 0.0};
@@ -1164,45 +965,52 @@ __global__ void __launch_bounds__(kBlock) cg_step_p2_kernel(StepP<T> f, size_t n
   block_dd_store1(sa, region(ws, kRegionP), blockIdx.x);
 }
 
-static bool fused_op_ok(const prost_hip_fused_op* op, uint64_t m, uint64_t n) {
-  if (!op || op->nblocks < 1 || op->nblocks > PROST_HIP_OP_MAX_BLOCKS) return false;
-  for (int b = 0; b < op->nblocks; b++) {
-    const prost_hip_op_block& B = op->block[b];
-    if (B.nrows == 0 || B.ncols == 0 || B.row + B.nrows > m || B.col + B.ncols > n) return false;
-    if (B.kind == PROST_OP_CSR) {
-      if (!B.val || !B.ptr || !B.ind || !B.val_t || !B.ptr_t || !B.ind_t) return false;
-    } else if (B.kind == PROST_OP_GRAD2D || B.kind == PROST_OP_GRAD3D) {
-      const uint64_t N = B.nx * B.ny * B.L, comps = B.kind == PROST_OP_GRAD2D ? 2 : 3;
-      if (B.nx == 0 || B.ny == 0 || B.L == 0 || N != B.ncols || comps * N != B.nrows) return false;
-      if (comps * N >= ((uint64_t)1 << 32)) return false;                // 32-bit element offsets inside a block
-    } else {
-      return false;
-    }
-  }
-  return true;
-}
-// VEC rows / columns per thread need every block boundary, gradient height and plane size on a multiple of VEC
-static bool fused_op_vec_ok(const prost_hip_fused_op* op, unsigned V) {
-  for (int b = 0; b < op->nblocks; b++) {
-    const prost_hip_op_block& B = op->block[b];
-    if (B.row % V || B.col % V || B.nrows % V || B.ncols % V) return false;
-    if (B.kind != PROST_OP_CSR && (B.ny % V || (B.nx * B.ny * B.L) % V)) return false;
-  }
-  return true;
-}
-static FusedOpDev make_op(const prost_hip_fused_op* op) {
-  FusedOpDev o;
-  o.nblocks = op->nblocks;
-  for (int b = 0; b < op->nblocks; b++) {
-    const prost_hip_op_block& B = op->block[b];
-    o.b[b] = OpBlockDev{B.kind, B.row, B.col, B.nrows, B.ncols, B.nx, B.ny, B.L, B.val, B.ptr, B.ind, B.val_t, B.ptr_t, B.ind_t};
-  }
-  return o;
-}
 // Workgroups of a kernel whose partial sums every workgroup of the NEXT kernel folds itself.  A fold costs one memory latency
 // plus g / 256 loads per thread whatever g is (the partial array stays in L1 / L2), so the PRODUCING kernels may use as many
 // workgroups as the workspace has slots: the operator kernels -- chains of dependent loads (row start -> value, index ->
 // gathered operand) -- run one VEC-row group per thread; the streaming stages cap at kFoldBlocks workgroups.
+}  // namespace prost_hip
+#include <cstring>
+#include <mutex>
+#include <vector>
+namespace prost_hip {
+const FusedOpDev* device_op(const prost_hip_fused_op* op) {
+  static std::mutex mu;
+  struct Entry { FusedOpDev host; FusedOpDev* dev; int device; };
+  static std::vector<Entry> cache;
+  FusedOpDev h;
+  std::memset(&h, 0, sizeof(h));                      // (padding bytes: entries are compared with memcmp)
+  {
+    const FusedOpDev made = make_op(op);
+    h.nblocks = made.nblocks;
+    for (int b = 0; b < made.nblocks; b++) {
+      OpBlockDev& D = h.b[b]; const OpBlockDev& S = made.b[b];
+      D.kind = S.kind; D.row = S.row; D.col = S.col; D.nrows = S.nrows; D.ncols = S.ncols; D.nx = S.nx; D.ny = S.ny; D.L = S.L;
+      D.val = S.val; D.ptr = S.ptr; D.ind = S.ind; D.val_t = S.val_t; D.ptr_t = S.ptr_t; D.ind_t = S.ind_t;
+      D.ids = S.ids; D.pptr = S.pptr; D.rel = S.rel; D.pval = S.pval; D.ids_t = S.ids_t; D.pptr_t = S.pptr_t; D.rel_t = S.rel_t; D.pval_t = S.pval_t;
+      D.dom_id = S.dom_id; D.dom_n = S.dom_n; D.dom_id_t = S.dom_id_t; D.dom_n_t = S.dom_n_t;
+      for (int k = 0; k < PROST_HIP_OP_DOM_MAX; k++) {
+        D.dom_rel[k] = k < S.dom_n ? S.dom_rel[k] : 0; D.dom_val[k] = k < S.dom_n ? S.dom_val[k] : 0.0;
+        D.dom_rel_t[k] = k < S.dom_n_t ? S.dom_rel_t[k] : 0; D.dom_val_t[k] = k < S.dom_n_t ? S.dom_val_t[k] : 0.0;
+      }
+    }
+  }
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) { set_error("device_op: no current device"); return nullptr; }
+  std::lock_guard<std::mutex> g(mu);
+  for (const Entry& e : cache) if (e.device == device && std::memcmp(&e.host, &h, sizeof(h)) == 0) return e.dev;
+  if (cache.size() >= 64) {                            // (operators come and go with their solvers: start over rather than grow)
+    for (Entry& e : cache) (void)hipFree(e.dev);
+    cache.clear();
+  }
+  FusedOpDev* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(FusedOpDev)) != hipSuccess || hipMemcpy(d, &h, sizeof(FusedOpDev), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("device_op: cannot upload the operator table");
+    return nullptr;
+  }
+  cache.push_back(Entry{h, d, device});
+  return d;
+}
 constexpr unsigned kFoldBlocks = 2048;
 constexpr unsigned kOpBlocks = 2048;
 static unsigned fold_grid(size_t elements, unsigned per_thread, unsigned cap = kFoldBlocks) {
@@ -1214,7 +1022,8 @@ static unsigned op_grid(size_t elements, unsigned per_thread) { return fold_grid
 template <class T, bool ADJ, class E>
 static void launch_op(const prost_hip_fused_op* op, const E& e, const T* in, size_t count, bool vec, unsigned grid, const CgState* cur, double* ws, hipStream_t st) {
   constexpr int V = VecOf<T>::N;
-  const FusedOpDev dev = make_op(op);
+  const FusedOpDev* dev = device_op(op);
+  if (!dev) return;
   if (vec) PH_LAUNCH((op_stage_kernel<T, V, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
   else PH_LAUNCH((op_stage_kernel<T, 1, ADJ, E>), dim3(grid), dim3(kBlock), 0, st, dev, e, in, count, cur, ws);
 }
@@ -1237,6 +1046,7 @@ static int cgls_round(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op
   if (!d || !d->state || !d->workspace) { set_error("cgls_round: state and workspace are required"); return 1; }
   if (round < 0) { set_error("cgls_round: negative round"); return 1; }
   if (!fused_op_ok(op, d->m, d->n)) { set_error("cgls_round: unsupported operator description (prost_hip_fused_op_supported)"); return 1; }
+  if (!device_op(op)) return 1;                        // (uploads the block table on first sight; launch_op finds it in the cache)
   hipStream_t st = as_stream(stream);
   constexpr int V = VecOf<T>::N;
   const CgPtrs<T> c(d, op);
@@ -1273,6 +1083,7 @@ template <class T>
 static int cgls_init_fused(const prost_hip_cgls_desc* d, const prost_hip_fused_op* op, void* stream) {
   if (!d || !d->state || !d->workspace) { set_error("cgls_init_fused: state and workspace are required"); return 1; }
   if (!fused_op_ok(op, d->m, d->n)) { set_error("cgls_init_fused: unsupported operator description (prost_hip_fused_op_supported)"); return 1; }
+  if (!device_op(op)) return 1;                        // (uploads the block table on first sight; launch_op finds it in the cache)
   hipStream_t st = as_stream(stream);
   constexpr int V = VecOf<T>::N;
   const CgPtrs<T> c(d, op);
@@ -1294,6 +1105,7 @@ template <class T>
 static int admm_fused_stage(int stage, const prost_hip_admm_desc* d, const prost_hip_fused_op* op, void* stream) {
   if (!d || !d->workspace) { set_error("admm_fused_stage: workspace is required"); return 1; }
   if (!fused_op_ok(op, d->m, d->n)) { set_error("admm_fused_stage: unsupported operator description (prost_hip_fused_op_supported)"); return 1; }
+  if (!device_op(op)) return 1;                        // (uploads the block table on first sight; launch_op finds it in the cache)
   hipStream_t st = as_stream(stream);
   constexpr int V = VecOf<T>::N;
   T* x_half = static_cast<T*>(d->x_half); T* x_proj = static_cast<T*>(d->x_proj); T* x_dual = static_cast<T*>(d->x_dual);

@@ -2,6 +2,7 @@
 // Streaming elementwise work: grid-stride loops, consecutive lanes on consecutive addresses.
 #include "elementwise.hpp"
 #include "pdhg_rule.hpp"
+#include "reduce.hpp"
 
 namespace prost_hip {
 
@@ -56,6 +57,33 @@ __global__ void __launch_bounds__(kBlock) fold_pair_rule_kernel(double* __restri
     __syncthreads();
   }
   if (apply_rule && rec && threadIdx.x == 0) rule_apply_device<T>(rec, tot, iteration, mirror);
+}
+
+// the residual sums of an iteration whose prox launches added them up themselves (kernels_prox.hip, operator sources): slots of 4 doubles
+// (a.hi, a.lo, b.hi, b.lo; reduce.hpp) -- the primal sums from the launches of prox_f*, the dual sums from those of prox_g -- folded
+// order-independently, and on request the step-size rule and the stopping test behind them (pdhg_rule.hpp)
+template <class T>
+__global__ void __launch_bounds__(kBlock) fold_sums_rule_kernel(double* __restrict__ out4, const double* __restrict__ ws_primal, unsigned n_primal,
+                                                                const double* __restrict__ ws_dual, unsigned n_dual, PdhgRecord<T>* rec, int apply_rule,
+                                                                unsigned long long iteration, prost_hip_pdhg_rule_state* mirror) {
+  if (rec && rec->stop) return;
+  __shared__ double tot[4];
+  double a, b, c, d;
+  fold_dd2(ws_primal, n_primal, 4, ws_primal + 2, n_primal, 4, a, b);
+  fold_dd2(ws_dual, n_dual, 4, ws_dual + 2, n_dual, 4, c, d);
+  if (threadIdx.x == 0) {
+    out4[0] = a; out4[1] = b; out4[2] = c; out4[3] = d;
+    tot[0] = a; tot[1] = b; tot[2] = c; tot[3] = d;
+    if (apply_rule && rec) rule_apply_device<T>(rec, tot, iteration, mirror);
+  }
+}
+template <class T>
+static int fold_sums(double* out4, const double* ws_primal, unsigned n_primal, const double* ws_dual, unsigned n_dual, void* record, int apply_rule,
+                     unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream) {
+  if (!out4 || !ws_primal || !ws_dual) { set_error("pdhg_fold_sums: null argument"); return 1; }
+  hipLaunchKernelGGL(fold_sums_rule_kernel<T>, dim3(1), dim3(kBlock), 0, as_stream(stream), out4, ws_primal, n_primal, ws_dual, n_dual, static_cast<PdhgRecord<T>*>(record),
+                     apply_rule, iteration, mirror);
+  PH_LAUNCH_END("fold sums kernel");
 }
 
 // ---- per-element formulas (one functor each; the skeletons in elementwise.hpp vectorise them) ----
@@ -315,6 +343,14 @@ int prost_hip_pdhg_residuals_f64(double* out4, const double* yp, const double* y
   return run_residuals<double>(out4, yp, y, S, kxp, kx, sg, th, m, xp, x, T, kp, k, tau, n, ws, record, apply_rule, iteration, mirror, s);
 }
 
+int prost_hip_pdhg_fold_sums_f32(double* out4, const double* ws_primal, unsigned n_primal, const double* ws_dual, unsigned n_dual, void* record, int apply_rule,
+                                 unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* s) {
+  return fold_sums<float>(out4, ws_primal, n_primal, ws_dual, n_dual, record, apply_rule, iteration, mirror, s);
+}
+int prost_hip_pdhg_fold_sums_f64(double* out4, const double* ws_primal, unsigned n_primal, const double* ws_dual, unsigned n_dual, void* record, int apply_rule,
+                                 unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* s) {
+  return fold_sums<double>(out4, ws_primal, n_primal, ws_dual, n_dual, record, apply_rule, iteration, mirror, s);
+}
 int prost_hip_pdhg_w_variable_f32(float* w, const float* xp, const float* x, const float* T, const float* kp, double tau, size_t n, void* s) {
   return launch_ew<float, 4>("w_variable", w, EwIn<float, 4>{{xp, x, T, kp}}, n, WVarF<float>{(float)tau}, as_stream(s));
 }

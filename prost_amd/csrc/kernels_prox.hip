@@ -6,6 +6,8 @@
 // the 14-way dispatch is one scalar branch per wave (no per-function template explosion: the
 // reference instantiates 176 kernels, prox_elem_operation.cu:44-256; this file compiles 4).
 #include "elementwise.hpp"
+#include "fused_op.hpp"
+#include "reduce.hpp"
 
 namespace prost_hip {
 
@@ -27,19 +29,76 @@ struct ArgSrc {
   // step size are read from the record on the device, and the launch is a no-op once the record's stop flag is raised
   const PdhgRecord<T>* rec;
 };
+// ARG = 3 / 4 (round 5): the PDHG prox arguments of ARG 1 / 2 with the OPERATOR PRODUCT formed on the fly as well (fused_op.hpp): K^T y
+// (ARG 3) resp. K x and K x_prev (ARG 4) are evaluated, for the elements a lane owns, from the operator's blocks -- row patterns, CSR
+// rows, gradient stencils -- in the order LinearOperator::Eval / EvalAdjoint accumulate them, so the argument has the bits of the
+// separate passes and K x, K^T y are never written (the reference: fill + K + fill + K^T, two full vectors through memory per
+// iteration; backend_pdhg.cu:334-347, :370-380).  The same launch can add up the terms of the residuals
+// (primal_residual_transform / dual_residual_transform, backend_pdhg.cu:73-120) of its elements: every operand is in registers.
+template <class T> struct OpSrc {
+  const FusedOpDev* opp;       // the block table, in device memory (fused_op.hpp, device_op)
+  size_t base;                 // index of the prox's first element in the whole variable: a column of K (ARG 3) / a row (ARG 4)
+  const T* w0; const T* w1;    // ARG 3: w0 = y (whole dual vector) ; ARG 4: w0 = x, w1 = x_prev (whole primal vectors)
+  T* kty_out;                  // ARG 3: K^T y of the range is stored here (prox range; the NEXT iteration's dual residual reads it); may be null
+  int use0, use1;              // 0: that product counts as the zero vector (iterations 0 / 1 of the reference, backend_pdhg.cu:213-216)
+  double* res_ws;              // one (a.hi, a.lo, b.hi, b.lo) slot per workgroup, from slot res_slot on (reduce.hpp); null: no residual sums
+  unsigned res_slot;
+};
+struct NoOpSrc {};
+template <class T, int ARG> struct OpSrcOf { typedef NoOpSrc type; };
+template <class T> struct OpSrcOf<T, 3> { typedef OpSrc<T> type; };
+template <class T> struct OpSrcOf<T, 4> { typedef OpSrc<T> type; };
+// the operands an argument was formed from (ARG 3 / 4), kept for the residual terms
+template <class T, int VEC> struct ArgParts { T p0[VEC], p1[VEC], p2[VEC], p3[VEC]; };
+
 template <class T, int ARG>
 __device__ __forceinline__ bool steps_from_record(ArgSrc<T>& a, T& tau_scal) {
   if (ARG == 0 || !a.rec) return true;
   if (a.rec->stop) return false;
-  a.s0 = ARG == 1 ? a.rec->p.tau : a.rec->p.sigma;
+  a.s0 = (ARG == 1 || ARG == 3) ? a.rec->p.tau : a.rec->p.sigma;
   a.s1 = a.rec->p.theta;
   tau_scal = a.s0;
   return true;
 }
 template <class T, int ARG>
 __device__ __forceinline__ T arg_formula(const ArgSrc<T>& a, T p0, T p1, T p2, T p3) {
-  if (ARG == 1) return p0 - a.s0 * p1 * p2;
+  if (ARG == 1 || ARG == 3) return p0 - a.s0 * p1 * p2;
   return p0 + a.s0 * p1 * ((1 + a.s1) * p2 - a.s1 * p3);
+}
+// ARG 3 / 4: the argument of VEC consecutive elements from `off` on, its operands kept in `P`
+template <class T, int VEC, int ARG>
+__device__ __forceinline__ void load_arg_op(const ArgSrc<T>& a, const OpSrc<T>& os, size_t off, T (&out)[VEC], ArgParts<T, VEC>& P, bool store = true) {
+  ldv<T, VEC>(a.v0 + off, P.p0); ldv<T, VEC>(a.v1 + off, P.p1);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) { P.p2[j] = 0; P.p3[j] = 0; }
+  const size_t g = os.base + off;
+  if (ARG == 3) {
+    if (os.res_ws && a.v3) ldv<T, VEC>(a.v3 + off, P.p3);                          // K^T y_prev, stored by the previous iteration's launch
+    if (os.use0) op_adj_cols<T, VEC>(*os.opp, g, g, os.w0, P.p2, false);            // 0 + K^T y, block after block
+    if (store && os.kty_out) stv<T, VEC>(os.kty_out + off, P.p2);
+  } else {
+    if (os.use0) op_fwd_rows<T, VEC>(*os.opp, g, g, os.w0, P.p2, false);            // K x
+    if (os.use1) op_fwd_rows<T, VEC>(*os.opp, g, g, os.w1, P.p3, false);            // K x_prev
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; j++) out[j] = arg_formula<T, ARG>(a, P.p0[j], P.p1[j], P.p2[j], ARG == 4 ? P.p3[j] : (T)0);
+}
+// the residual terms of VEC elements whose prox result is `res` (ResidualPrimalF / ResidualDualF of kernels_pdhg.hip, term by term)
+template <class T, int VEC, int ARG>
+__device__ __forceinline__ void residual_terms(const ArgSrc<T>& a, const ArgParts<T, VEC>& P, const T (&res)[VEC], dd_t& sa, dd_t& sb) {
+#pragma unroll
+  for (int j = 0; j < VEC; j++) {
+    const T d = P.p1[j];
+    if (ARG == 4) {                                    // in = y_prev, y, Sigma, K x_prev, K x
+      const T z_hat = (P.p0[j] - res[j]) / (a.s0 * t_sqrt(d)) + t_sqrt(d) * ((1 + a.s1) * P.p2[j] - a.s1 * P.p3[j]);
+      const T diff = z_hat - t_sqrt(d) * P.p2[j];
+      dd_acc(sa, (double)(diff * diff)); dd_acc(sb, (double)(z_hat * z_hat));
+    } else {                                           // in = x_prev, x, T, K^T y_prev, K^T y
+      const T w_hat = (P.p0[j] - res[j]) / (a.s0 * t_sqrt(d)) - t_sqrt(d) * P.p3[j];
+      const T diff = w_hat + t_sqrt(d) * P.p2[j];
+      dd_acc(sa, (double)(diff * diff)); dd_acc(sb, (double)(w_hat * w_hat));
+    }
+  }
 }
 template <class T, int VEC, int ARG>
 __device__ __forceinline__ void load_arg(const ArgSrc<T>& a, size_t off, T (&out)[VEC]) {
@@ -113,10 +172,15 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
 template <class T, int OP, int DIM, bool MOREAU, int ARG>
 __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ res, ArgSrc<T> arg,
                                                                const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
-                                                               size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one) {
+                                                               size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one,
+                                                               typename OpSrcOf<T, ARG>::type os) {
   if (!steps_from_record<T, ARG>(arg, tau_scal)) return;
   constexpr int VEC = VecOf<T>::N;
   constexpr int D = DIM > 0 ? DIM : 1;
+  constexpr bool OPA = ARG >= 3;                       // operator product on the fly; residual sums on request
+  dd_t r_a{0.0, 0.0}, r_b{0.0, 0.0};
+  bool with_res = false;
+  if constexpr (OPA) with_res = os.res_ws != nullptr;
   for (size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * VEC; t0 < count; t0 += (size_t)gridDim.x * kBlock * VEC) {
     T c[7][VEC], td[VEC];
 #pragma unroll
@@ -131,7 +195,9 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
     const bool inner_inv = MOREAU ? !invert_tau : invert_tau;
     if (OP == PROST_OP_1D) {
       T a[VEC], out[VEC];
-      load_arg<T, VEC, ARG>(arg, t0, a);
+      ArgParts<T, OPA ? VEC : 1> parts;
+      if constexpr (OPA) load_arg_op<T, VEC, ARG>(arg, os, t0, a, parts);
+      else load_arg<T, VEC, ARG>(arg, t0, a);
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         T cc[7];
@@ -141,14 +207,17 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
         out[j] = MOREAU ? moreau_post<T>(a[j], r, tau_scal, td[j], invert_tau) : r;
       }
       stv<T, VEC>(res + t0, out);
+      if constexpr (OPA) { if (with_res) residual_terms<T, VEC, ARG>(arg, parts, out, r_a, r_b); }
     } else {
       T v[D][VEC], tdv[MOREAU ? D : 1][VEC], norm[VEC], scale[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; j++) norm[j] = 0;
+      ArgParts<T, OPA ? VEC : 1> parts[OPA ? D : 1];
       if (DIM > 0) {
 #pragma unroll
         for (int i = 0; i < D; i++) {
-          load_arg<T, VEC, ARG>(arg, t0 + (size_t)i * count, v[i]);
+          if constexpr (OPA) load_arg_op<T, VEC, ARG>(arg, os, t0 + (size_t)i * count, v[i], parts[i]);
+          else load_arg<T, VEC, ARG>(arg, t0 + (size_t)i * count, v[i]);
           if (MOREAU) {
             if (i == 0) {
 #pragma unroll
@@ -164,7 +233,8 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
       } else {
         for (size_t i = 0; i < dim; i++) {
           T w[VEC], tw[VEC];
-          load_arg<T, VEC, ARG>(arg, t0 + i * count, w);
+          if constexpr (OPA) load_arg_op<T, VEC, ARG>(arg, os, t0 + i * count, w, parts[0], false);
+          else load_arg<T, VEC, ARG>(arg, t0 + i * count, w);
           if (MOREAU) ldv<T, VEC>(tau_diag + t0 + i * count, tw);
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
@@ -198,11 +268,13 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
             out[j] = MOREAU ? moreau_post<T>(v[i][j], r, tau_scal, tdi, invert_tau) : r;
           }
           stv<T, VEC>(res + t0 + (size_t)i * count, out);
+          if constexpr (OPA) { if (with_res) residual_terms<T, VEC, ARG>(arg, parts[i], out, r_a, r_b); }
         }
       } else {
         for (size_t i = 0; i < dim; i++) {
           T w[VEC], tw[VEC], out[VEC];
-          load_arg<T, VEC, ARG>(arg, t0 + i * count, w);
+          if constexpr (OPA) load_arg_op<T, VEC, ARG>(arg, os, t0 + i * count, w, parts[0]);
+          else load_arg<T, VEC, ARG>(arg, t0 + i * count, w);
           if (MOREAU) ldv<T, VEC>(tau_diag + t0 + i * count, tw);
 #pragma unroll
           for (int j = 0; j < VEC; j++) {
@@ -212,15 +284,18 @@ __global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ r
             out[j] = MOREAU ? moreau_post<T>(w[j], r, tau_scal, tdi, invert_tau) : r;
           }
           stv<T, VEC>(res + t0 + i * count, out);
+          if constexpr (OPA) { if (with_res) residual_terms<T, VEC, ARG>(arg, parts[0], out, r_a, r_b); }
         }
       }
     }
   }
+  if constexpr (OPA) { if (with_res) block_dd_store2(r_a, r_b, os.res_ws, os.res_slot + blockIdx.x); }
 }
 
 template <class T, bool MOREAU, int ARG>
 static int launch_prox_elem(int op, int fn, T* res, const ArgSrc<T>& arg, const T* tau_diag, double tau, int invert, size_t count,
-                            size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream) {
+                            size_t dim, int interleaved, const T* const* coeff_ptr, const double* coeff_val, void* stream,
+                            const typename OpSrcOf<T, ARG>::type& os = typename OpSrcOf<T, ARG>::type(), unsigned max_grid = 0) {
   if (fn < 0 || fn >= PROST_FN_COUNT) { set_error("prox_elem: unknown function id"); return 1; }
   if (op != PROST_OP_1D && op != PROST_OP_NORM2) { set_error("prox_elem: unknown elem operation"); return 1; }
   if (count == 0) return 0;
@@ -229,13 +304,16 @@ static int launch_prox_elem(int op, int fn, T* res, const ArgSrc<T>& arg, const 
   hipStream_t s = as_stream(stream);
   constexpr int V = VecOf<T>::N;
   bool vec = (op == PROST_OP_1D || !interleaved || dim == 1) && count % V == 0 && aligned16(res) && aligned16(arg.v0) && aligned16(tau_diag);
-  if (ARG >= 1) vec = vec && aligned16(arg.v1) && aligned16(arg.v2);
-  if (ARG == 2) vec = vec && aligned16(arg.v3);
+  if (ARG >= 1) vec = vec && aligned16(arg.v1);
+  if (ARG == 1 || ARG == 2) vec = vec && aligned16(arg.v2);
+  if (ARG == 2 || ARG == 3) vec = vec && aligned16(arg.v3);
   for (int i = 0; i < 7; i++) vec = vec && aligned16(cf.ptr[i]);
   if (vec) {
     const bool e_zero = !cf.ptr[4] && cf.val[4] == (T)0, a_one = !cf.ptr[0] && cf.val[0] == (T)1;
-    dim3 g(grid_for(count / V)), b(kBlock);
-#define GO(OPv, DIMv) hipLaunchKernelGGL((prox_elem_vec_kernel<T, OPv, DIMv, MOREAU, ARG>), g, b, 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, fn, cf, e_zero, a_one)
+    unsigned gx = grid_for(count / V);
+    if (max_grid && gx > max_grid) gx = max_grid;          // (residual sums: one partial slot per workgroup)
+    dim3 g(gx), b(kBlock);
+#define GO(OPv, DIMv) hipLaunchKernelGGL((prox_elem_vec_kernel<T, OPv, DIMv, MOREAU, ARG>), g, b, 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, fn, cf, e_zero, a_one, os)
     if (op == PROST_OP_1D) GO(PROST_OP_1D, 1);
     else if (dim == 1) GO(PROST_OP_NORM2, 1);
     else if (dim == 2) GO(PROST_OP_NORM2, 2);
@@ -245,11 +323,14 @@ static int launch_prox_elem(int op, int fn, T* res, const ArgSrc<T>& arg, const 
 #undef GO
     PH_LAUNCH_END("prox_elem kernel");
   }
+  if constexpr (ARG >= 3) { set_error("prox_elem_arg: the operator sources need the planar layout (or the 1-D operation), a count that is a multiple of 16 bytes and 16-byte aligned operands (prost_hip_prox_elem_arg_op_supported)"); return 1; }
+  else {
   if (op == PROST_OP_1D)
     hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_1D, MOREAU, ARG>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, (size_t)1, interleaved != 0, fn, cf);
   else
     hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_NORM2, MOREAU, ARG>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, dim, interleaved != 0, fn, cf);
   PH_LAUNCH_END("prox_elem kernel");
+  }
 }
 
 template <class T, bool MOREAU>
@@ -271,9 +352,31 @@ static int launch_prox_elem_arg(int op, int fn, int moreau, T* res, const prost_
     case PROST_ARG_PLAIN: if (moreau) GO(true, 0); else GO(false, 0);
     case PROST_ARG_PDHG_PRIMAL: if (moreau) GO(true, 1); else GO(false, 1);
     case PROST_ARG_PDHG_DUAL: if (moreau) GO(true, 2); else GO(false, 2);
+    case PROST_ARG_PDHG_PRIMAL_OP: case PROST_ARG_PDHG_DUAL_OP: break;
     default: set_error("prox_elem_arg: unknown argument mode"); return 1;
   }
 #undef GO
+  // operator sources: K^T y / K x, K x_prev formed on the fly from the blocks of a->op (fused_op.hpp)
+  constexpr unsigned V = VecOf<T>::N;
+  const bool primal = a->mode == PROST_ARG_PDHG_PRIMAL_OP;
+  if (!a->op || !a->w[0] || (!primal && !a->w[1])) { set_error("prox_elem_arg: the operator sources need the operator and the whole vectors"); return 1; }
+  if (!fused_op_ok(a->op, a->op_rows, a->op_cols) || !fused_op_vec_ok(a->op, V) || a->base % V) { set_error("prox_elem_arg: unsupported operator description (prost_hip_prox_elem_arg_op_supported)"); return 1; }
+  if (a->base + count * (op == PROST_OP_1D ? 1 : dim) > (primal ? a->op_cols : a->op_rows)) { set_error("prox_elem_arg: the prox's range exceeds the operator"); return 1; }
+  OpSrc<T> os;
+  os.opp = device_op(a->op); os.base = (size_t)a->base;
+  if (!os.opp) return 1;
+  os.w0 = static_cast<const T*>(a->w[0]); os.w1 = static_cast<const T*>(a->w[1]);
+  os.kty_out = static_cast<T*>(a->kty_out); os.use0 = a->use[0]; os.use1 = a->use[1];
+  os.res_ws = a->res_ws; os.res_slot = a->res_slot;
+  if (os.res_ws && a->res_slots_max < 1) { set_error("prox_elem_arg: no partial slots for the residual sums"); return 1; }
+  if (os.kty_out && !aligned16(os.kty_out)) { set_error("prox_elem_arg: kty_out must be 16-byte aligned"); return 1; }
+  const unsigned cap = os.res_ws ? a->res_slots_max : 0;
+  if (primal) {
+    if (moreau) return launch_prox_elem<T, true, 3>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
+    return launch_prox_elem<T, false, 3>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
+  }
+  if (moreau) return launch_prox_elem<T, true, 4>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
+  return launch_prox_elem<T, false, 4>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -363,6 +466,9 @@ int prost_hip_prox_elem_moreau_f32(int op, int fn, float* res, const float* arg,
 }
 int prost_hip_prox_elem_moreau_f64(int op, int fn, double* res, const double* arg, const double* td, double tau, int inv, size_t count, size_t dim, int il, const double* const* cp, const double* cv, void* s) {
   return launch_prox_elem<double, true>(op, fn, res, arg, td, tau, inv, count, dim, il, cp, cv, s);
+}
+int prost_hip_prox_elem_arg_op_supported(const prost_hip_fused_op* op, uint64_t m, uint64_t n, int dtype) {
+  return fused_op_ok(op, m, n) && fused_op_vec_ok(op, dtype == 0 ? 4u : 2u) ? 1 : 0;
 }
 int prost_hip_prox_elem_arg_f32(int op, int fn, int moreau, float* res, const prost_hip_arg_spec* a, const float* td, double tau, int inv, size_t count, size_t dim, int il, const float* const* cp, const double* cv, void* s) {
   return launch_prox_elem_arg<float>(op, fn, moreau, res, a, td, tau, inv, count, dim, il, cp, cv, s);

@@ -133,4 +133,33 @@ __device__ __forceinline__ double fold_dd(const double* __restrict__ part, unsig
   return t.hi;
 }
 
+// two folds at once (fold_dd): both sets of loads in flight together, one pair of barriers; every thread of every
+// workgroup of every kernel obtains the same two doubles (order-independent sums)
+__device__ __forceinline__ void fold_dd2(const double* __restrict__ pa, unsigned ga, unsigned sa_, const double* __restrict__ pb, unsigned gb, unsigned sb_,
+                                         double& ra, double& rb) {
+  __shared__ dd_t s_fa[kBlock / kWave], s_fb[kBlock / kWave];
+  dd_t a{0.0, 0.0}, b{0.0, 0.0};
+  const unsigned gmax = ga > gb ? ga : gb;
+  for (unsigned base = threadIdx.x; base < gmax; base += 4 * kBlock) {
+    double ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned i = base + k * kBlock;
+      ah[k] = i < ga ? pa[(size_t)sa_ * i] : 0.0; al[k] = i < ga ? pa[(size_t)sa_ * i + 1] : 0.0;
+      bh[k] = i < gb ? pb[(size_t)sb_ * i] : 0.0; bl[k] = i < gb ? pb[(size_t)sb_ * i + 1] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a = dd_add(a, dd_t{ah[k], al[k]}); b = dd_add(b, dd_t{bh[k], bl[k]}); }
+  }
+  a = wave_sum_dd(a);
+  b = wave_sum_dd(b);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) { s_fa[threadIdx.x / kWave] = a; s_fb[threadIdx.x / kWave] = b; }
+  __syncthreads();
+  dd_t ta = s_fa[0], tb = s_fb[0];
+#pragma unroll
+  for (int w = 1; w < kBlock / kWave; w++) { ta = dd_add(ta, s_fa[w]); tb = dd_add(tb, s_fb[w]); }
+  ra = ta.hi; rb = tb.hi;
+}
+
 }  // namespace prost_hip

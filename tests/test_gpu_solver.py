@@ -525,6 +525,43 @@ def test_operator_norm_estimate_equals_the_oracle_bit_for_bit(precision, dtype):
     prost.set_precision("double")
 
 
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("step,residual_iter", [("boyd", 1), ("alg2", 4), ("goldstein", 3)])
+def test_generic_pdhg_with_the_operator_inside_the_prox_kernels(precision, dtype, step, residual_iter):
+    """allow_op_fusion (round 5, off by default: measured slower): the prox launches of the generic path form K^T y / K x
+    for their own elements from the operator's blocks -- row patterns, CSR rows, gradient stencils, in block order -- and add up the residual
+    terms themselves, so K x is never written and an iteration is 4 launches instead of 9.  Iterates, step sizes and decisions are those of
+    the separate products and of the oracle, bit for bit, on: example_deblurring.m's shape (two sparse constraint blocks, Moreau-wrapped
+    proxes, the identity on the primal side), example_multilabel_fast.m as written (sparse gradient over 3 labels + the sum row, norm2 over 6
+    components, linear terms), and [W ; gradient2d(L = 2)] with a stencil block; the reference's zero vectors of iterations 0 / 1, warm
+    starts and the read-out of z / w included; with the rule on the device and on the host."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import generic_rule_rate, multilabel_fast
+    prost.set_precision(precision)
+    rng = np.random.default_rng(5)
+    problems = [("deblurring-like", generic_rule_rate.problem(40, 36)), ("multilabel_fast", multilabel_fast.describe(28, 24)[0]), ("c4", tvl1_like_problem(24, 20))]
+    for name, prob in problems:
+        prob.finalize()
+        o = prost.options(max_iters=100, num_cback_calls=0, verbose=False, x0=rng.random(prob.ncols), y0=0.1 * rng.standard_normal(prob.nrows))
+        for iters in (1, 2, 23):
+            st = {}
+            for opf, dev in ((True, True), (True, False), (False, True)):
+                b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.2)
+                b[1]["allow_op_fusion"] = opf
+                b[1]["allow_device_rules"] = dev
+                st[(opf, dev)] = run_product(prob, b, o, iters)
+                assert st[(opf, dev)]["path"] == "pdhg:generic" and st[(opf, dev)]["operator_in_prox_kernels"] == (1.0 if opf else 0.0), (name, opf)
+            ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.2), o, iters, dtype)
+            for key, s_ in st.items():
+                assert_same_iterates(s_, ost, exact=True)
+                assert s_["tau"] == ost["tau"] and s_["sigma"] == ost["sigma"], (name, iters, key)
+                for r_ in ("primal_res", "dual_res"):
+                    assert np.isclose(s_[r_], ost[r_], rtol=1e-5, atol=1e-7), (name, iters, key, r_)
+    prost.set_precision("double")
+
+
 def pixel_coupled_problem(nx, ny, L, has_d=True, d_first=True, seed=0):
     """K = [D ; gradient2d(nx, ny, L)] (or the other order, or the gradient alone): D = [diag(w_0) ... diag(w_{L-1})] couples the L
     channels of one pixel -- the C4 shape for L = 2"""

@@ -35,15 +35,17 @@ def main(nx=700, ny=464, iters=3000, residual_iter=1):
     prost.set_gpu(0); prost.set_precision("single")
     o = prost.options(max_iters=10 ** 9, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
     prob = problem(nx, ny)
-    for name, dev in (("rule on the device", True), ("rule on the host", False)):
+    for name, dev, opf in (("operator in the prox kernels, rule on the device", True, True), ("operator in the prox kernels, rule on the host", False, True),
+                           ("separate products, rule on the device", True, False), ("separate products, rule on the host", False, False)):
         b = prost.backend.pdhg(stepsize="boyd", residual_iter=int(residual_iter))      # :40-41
         b[1]["allow_device_rules"] = dev
+        b[1]["allow_op_fusion"] = opf
         s = prost.Solver(prob, b, o)
         s.iterate(300)
         info = s.iterate(iters)
         st = s.state(vectors=False)
-        print("deblurring-like %dx%d fp32, boyd R=%d, %-18s: %.0f it/s (%.4f ms per iteration), path %s, device rule batches %s" % (
-            nx, ny, residual_iter, name, iters / (info["ms"] * 1e-3), info["ms"] / iters, st["path"], st.get("device_rule_batches")), flush=True)
+        print("deblurring-like %dx%d fp32, boyd R=%d, %-48s: %.0f it/s (%.4f ms per iteration), path %s, operator in prox kernels %s, device rule batches %s" % (
+            nx, ny, residual_iter, name, iters / (info["ms"] * 1e-3), info["ms"] / iters, st["path"], st.get("operator_in_prox_kernels"), st.get("device_rule_batches")), flush=True)
         s.destroy()
 
 
