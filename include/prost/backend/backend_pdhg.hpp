@@ -27,15 +27,16 @@ class BackendPDHG : public Backend<T> {
     bool allow_single_kernel;  ///< MI355X addition: one kernel per non-residual iteration (7 instead of 11 floats/pixel)
     bool allow_pair_kernel;    ///< MI355X addition: two iterations per launch where nobody observes the one in between
     bool allow_arg_fusion;     ///< MI355X addition (generic path): proxes form their argument on the fly, no argument pass
-    bool allow_op_fusion;      ///< MI355X addition (generic path, round 5; OFF by default): the proxes also form the operator products K^T y / K x on the
-                               ///< fly and add up the residual terms themselves (operators of sparse / gradient blocks): K x, K^T y never written, 4 launches
-                               ///< per iteration instead of 9 -- bit-identical, but measured SLOWER than the separate products at every size (DESIGN.md section 7:
-                               ///< each launch walks the block table through ~130 dependent memory operations per wavefront, 15-20 us against 5 us)
+    int allow_op_fusion;       ///< MI355X addition (generic path, round 5): the proxes also form the operator products K^T y / K x on the fly and add up
+                               ///< the residual terms themselves (operators of sparse / gradient blocks): K x, K^T y never written, 4 launches per iteration
+                               ///< instead of 9, bit-identical.  0: never; 1 (default): where every sparse block is a STENCIL written out row by row (row
+                               ///< patterns with a dominant pattern for K and K^T -- example_deblurring.m, example_multilabel_*.m) or a gradient block;
+                               ///< 2: wherever the kernels support the operator (random CSR blocks walk their rows lane by lane: not measured faster)
     bool allow_speculation;    ///< MI355X addition: the next pair launch is enqueued BEFORE the host waits for the residual sums (alg1 / alg2)
     bool allow_device_rules;   ///< MI355X addition: goldstein / boyd and the stopping test evaluated on the device, one host wait per BATCH of iterations
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
-                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_op_fusion(false), allow_speculation(true),
+                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_op_fusion(1), allow_speculation(true),
                 allow_device_rules(true) {}
   };
 
@@ -97,7 +98,7 @@ class BackendPDHG : public Backend<T> {
   void IterationFused(bool residual_iteration);
   void IterationGeneric(bool residual_iteration);
   void IterationGenericOp(bool residual_iteration);      ///< the same iteration with the operator inside the prox kernels (op_fused_)
-  bool DescribeGenericOperator();
+  bool DescribeGenericOperator(bool stencils_only);
   void IterationPair(bool store_mid, bool residuals);   // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
   void IterationPairMc(bool residuals);   // the same for gradient2d with 2-4 channels (prost_hip_fused_iteration_mc_x2): k + 2 is not a residual iteration
   void IterationPair3D(bool residuals);   // the same for gradient3d (prost_hip_fused_iteration3d_x2): k + 2 is not a residual iteration
@@ -180,6 +181,9 @@ class BackendPDHG : public Backend<T> {
   prost_hip_fused_op gen_op_;                          // the operator as a table of sparse / gradient blocks (op_fused_)
   void* op_workspace_ = nullptr;                       // residual sums of the prox launches: 2 x kOpSumSlots slots of 4 doubles (primal | dual)
   static constexpr unsigned kOpSumSlots = 8192;
+  /// workgroups of one residual launch: every workgroup ends with a block-wide fold of its sums, which 2048 workgroups (two rounds of the
+  /// machine at 4 wavefronts per SIMD) spread over 4+ element groups per lane at the sizes where it matters; 8192 -> 2048: 4576 -> 4911 it/s at 2048^2
+  static constexpr unsigned kOpLaunchSlots = 2048;
   double* res_target();
   // all-reduce of the sums on a side stream (alg1 / alg2 with a communicator): the iteration stream never waits for the other ranks
   void* side_stream_ = nullptr;

@@ -23,6 +23,16 @@ struct OpBlockDev {
 };
 struct FusedOpDev { int nblocks; OpBlockDev b[PROST_HIP_OP_MAX_BLOCKS]; };
 
+// The block table and the pattern tables are written by the host before the first launch and never by a kernel.  Kernels read them
+// through the CONSTANT address space: a wave-uniform load from there is a scalar load (batched, results in SGPRs) whatever the kernel has
+// stored before.  Through a generic pointer the compiler must assume that the kernel's own stores may alias the table (the grid-stride
+// loop stores results before it walks the table again) and emits per-lane VECTOR loads, each field waited for before the next is
+// requested: 8-10 dependent memory round trips per block and wavefront (measured: 100-120 us for a prox launch at 2048^2 that takes 35 with
+// scalar loads).
+#define PROST_CONSTANT __attribute__((address_space(4)))
+template <class U> __device__ __forceinline__ const PROST_CONSTANT U* as_constant(const U* p) { return (const PROST_CONSTANT U*)p; }
+template <class U> __device__ __forceinline__ const PROST_CONSTANT U* as_constant_of(const void* p) { return (const PROST_CONSTANT U*)p; }
+
 // a[j] belongs to element j * 64 + lane of a 64 VEC-element range; out[c] := element VEC * lane + c (all 64 lanes active)
 template <class T, int VEC>
 __device__ __forceinline__ void wave_untranspose(const T (&a)[VEC], T (&out)[VEC], unsigned lane) {
@@ -81,35 +91,45 @@ __device__ __forceinline__ void csr_contrib(const T* __restrict__ val, const int
 // sum[j] = (A rhs)_(r0 + j) for VEC consecutive rows of a pattern-compressed matrix: the entries of a row's pattern in order, as
 // pattern_spmv_kernel (out = 0 ; out += value * rhs[row + rel]) -- the bits of the CSR product.  Nearly always the VEC rows of a lane, and
 // the rows of the whole wavefront, have ONE pattern: its table entries are then wave-uniform (scalar loads) and an entry costs one load
-// of VEC consecutive operands per lane (element-aligned 16-byte accesses, which gfx950 serves); the seams of a stencil walk the table per
-// lane or per row.
+// of VEC consecutive operands per lane (element-aligned 16-byte accesses, which gfx950 serves); a wavefront on the seams of a
+// stencil takes one pass per pattern it holds.
 template <class T, int VEC> struct OpPack { typedef T V __attribute__((ext_vector_type(VEC), aligned(sizeof(T)))); };
 // `len`: number of operand elements behind rhs (the speculative loads of the dominant pattern are clamped into [0, len - VEC]: rows at
 // the seams of a stencil have other patterns, their speculative values are dropped)
-template <class T, int VEC>
-__device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, const int32_t* __restrict__ pptr, const int32_t* __restrict__ rel,
-                                             const T* __restrict__ pval, const T* __restrict__ rhs, size_t r0, T (&sum)[VEC],
-                                             int dom_id = -1, int dom_n = 0, const int32_t* dom_rel = nullptr, const double* dom_val = nullptr, size_t len = 0) {
+// NR right-hand sides at once (K x and K x_prev of the dual step): one walk over the pattern numbers and the table, the operand loads of
+// all of them in flight together.
+template <class T, int VEC, int NR>
+__device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, const PROST_CONSTANT int32_t* __restrict__ pptr, const PROST_CONSTANT int32_t* __restrict__ rel,
+                                             const PROST_CONSTANT T* __restrict__ pval, const T* const (&rhs)[NR], size_t r0, T (&sum)[NR][VEC],
+                                             int dom_id = -1, int dom_n = 0, const PROST_CONSTANT int32_t* dom_rel = nullptr, const PROST_CONSTANT double* dom_val = nullptr, size_t len = 0) {
   typedef typename OpPack<T, VEC>::V PV;
+  constexpr int kB = NR == 1 ? 6 : 4;                              // entries per batch: kB * NR operand loads of VEC elements in flight
   unsigned id[VEC];
+  if (VEC == 4) {                                                  // r0 is a multiple of 4 and the numbers start on an 8-byte boundary
+    const uint2 w = *reinterpret_cast<const uint2*>(ids + r0);
+    id[0] = w.x & 0xFFFFu; id[1 % VEC] = w.x >> 16; id[2 % VEC] = w.y & 0xFFFFu; id[3 % VEC] = w.y >> 16;
+  } else {
 #pragma unroll
-  for (int j = 0; j < VEC; j++) id[j] = ids[r0 + j];
+    for (int j = 0; j < VEC; j++) id[j] = ids[r0 + j];
+  }
 #pragma unroll
-  for (int j = 0; j < VEC; j++) sum[j] = 0;
+  for (int q = 0; q < NR; q++)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) sum[q][j] = 0;
   bool same = true;
 #pragma unroll
   for (int j = 1; j < VEC; j++) same = same && id[j] == id[0];
   if (VEC > 1 && dom_n > 0 && len >= (size_t)VEC) {
-    // the operands of the DOMINANT pattern are requested at once (table entries from the kernel arguments: no load), in flight together
+    // the operands of the DOMINANT pattern are requested at once (its entries sit in the block table: scalar loads), in flight together
     // with the pattern numbers above -- one memory round trip instead of four dependent ones (numbers -> table offsets -> entries -> operands)
-    constexpr int kB = 6;
-    PV x[kB];
+    PV x[NR][kB];
     const long hi = (long)len - VEC;
 #pragma unroll
     for (int u = 0; u < kB; u++) {
       long a = (long)r0 + (long)dom_rel[u < dom_n ? u : dom_n - 1];
       a = a < 0 ? 0 : (a > hi ? hi : a);
-      x[u] = *reinterpret_cast<const PV*>(rhs + a);
+#pragma unroll
+      for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + a);
     }
     const bool dom = same && id[0] == (unsigned)dom_id;
     if (__builtin_amdgcn_ballot_w64(!dom) == 0) {
@@ -118,18 +138,24 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
         if (u < dom_n) {
           const T v = (T)dom_val[u];
 #pragma unroll
-          for (int j = 0; j < VEC; j++) sum[j] += v * x[u][j];
+          for (int q = 0; q < NR; q++)
+#pragma unroll
+            for (int j = 0; j < VEC; j++) sum[q][j] += v * x[q][u][j];
         }
       }
       for (int k0 = kB; k0 < dom_n; k0 += kB) {          // (interior rows: every address is in range)
 #pragma unroll
-        for (int u = 0; u < kB; u++) x[u] = *reinterpret_cast<const PV*>(rhs + (long)r0 + (long)dom_rel[k0 + u < dom_n ? k0 + u : dom_n - 1]);
+        for (int u = 0; u < kB; u++)
+#pragma unroll
+          for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + (long)r0 + (long)dom_rel[k0 + u < dom_n ? k0 + u : dom_n - 1]);
 #pragma unroll
         for (int u = 0; u < kB; u++) {
           if (k0 + u < dom_n) {
             const T v = (T)dom_val[k0 + u];
 #pragma unroll
-            for (int j = 0; j < VEC; j++) sum[j] += v * x[u][j];
+            for (int q = 0; q < NR; q++)
+#pragma unroll
+              for (int j = 0; j < VEC; j++) sum[q][j] += v * x[q][u][j];
           }
         }
       }
@@ -137,55 +163,64 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
     }
   }
   if (VEC > 1) {
-    const unsigned id0 = (unsigned)__builtin_amdgcn_readfirstlane((int)id[0]);
-    const bool uniform = same && id[0] == id0;
-    if (__builtin_amdgcn_ballot_w64(!uniform) == 0) {               // every active lane of the wavefront: one pattern
-      // entries in batches of eight: the table entries of a batch first (scalar loads), then its eight operand loads in flight together,
-      // then the sums in entry order -- one memory round trip per batch instead of one per entry
-      const int32_t b = pptr[id0], e = pptr[id0 + 1];
-      for (int32_t k0 = b; k0 < e; k0 += 8) {
-        long r[8]; T v[8];
+    // One pass per DISTINCT pattern among the wavefront's rows (the seams of a stencil put two or three into a wavefront; a wavefront
+    // of one pattern that is not the dominant one takes one pass): the pattern number of a pass is wave-uniform, so its table entries are
+    // scalar loads and the operands of an entry are requested by all lanes together -- a lane whose VEC rows all have the pattern with
+    // one 16-byte load, a lane on the seam row by row.  Every row still sums the entries of ITS pattern in table order.
+    unsigned todo = (1u << VEC) - 1;                               // rows of this lane whose pattern has not had its pass
+    for (;;) {
+      unsigned cand = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int32_t k = k0 + u < e ? k0 + u : e - 1; r[u] = (long)rel[k]; v[u] = pval[k]; }
-        typename OpPack<T, VEC>::V x[8];
+      for (int j = VEC - 1; j >= 0; j--) cand = (todo >> j & 1) ? id[j] : cand;
+      const unsigned long long open = __builtin_amdgcn_ballot_w64(todo != 0);
+      if (open == 0) break;
+      const unsigned cur = (unsigned)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(open));
+      bool mine[VEC], all = true;
+      unsigned mask = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u++) x[u] = *reinterpret_cast<const typename OpPack<T, VEC>::V*>(rhs + (long)r0 + r[u]);
+      for (int j = 0; j < VEC; j++) { mine[j] = id[j] == cur; all = all && mine[j]; mask |= mine[j] ? 1u << j : 0u; }
+      todo &= ~mask;
+      const int32_t b = pptr[cur], e = pptr[cur + 1];
+      for (int32_t k0 = b; k0 < e; k0 += kB) {
+        long r[kB]; T v[kB];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < kB; u++) { const int32_t k = k0 + u < e ? k0 + u : e - 1; r[u] = (long)rel[k]; v[u] = pval[k]; }
+        PV x[NR][kB];
+        if (all) {
+#pragma unroll
+          for (int u = 0; u < kB; u++)
+#pragma unroll
+            for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + (long)r0 + r[u]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < kB; u++)
+#pragma unroll
+            for (int q = 0; q < NR; q++)
+#pragma unroll
+              for (int j = 0; j < VEC; j++) x[q][u][j] = rhs[q][mine[j] ? (long)(r0 + j) + r[u] : 0L];     // (element 0: always there, never used)
+        }
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
           if (k0 + u < e) {
 #pragma unroll
-            for (int j = 0; j < VEC; j++) sum[j] += v[u] * x[u][j];
+            for (int q = 0; q < NR; q++)
+#pragma unroll
+              for (int j = 0; j < VEC; j++) sum[q][j] = mine[j] ? sum[q][j] + v[u] * x[q][u][j] : sum[q][j];
           }
         }
       }
-      return;
     }
-    if (same) {                                                     // one pattern per lane
-      const int32_t b = pptr[id[0]], e = pptr[id[0] + 1];
-      for (int32_t k0 = b; k0 < e; k0 += 4) {
-        long r[4]; T v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int32_t k = k0 + u < e ? k0 + u : e - 1; r[u] = (long)rel[k]; v[u] = pval[k]; }
-        typename OpPack<T, VEC>::V x[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) x[u] = *reinterpret_cast<const typename OpPack<T, VEC>::V*>(rhs + (long)r0 + r[u]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          if (k0 + u < e) {
-#pragma unroll
-            for (int j = 0; j < VEC; j++) sum[j] += v[u] * x[u][j];
-          }
-        }
-      }
-      return;
-    }
+    return;
   }
 #pragma unroll
   for (int j = 0; j < VEC; j++) {
     const int32_t b = pptr[id[j]], e = pptr[id[j] + 1];
-    T s = 0;
-    for (int32_t k = b; k < e; k++) s += pval[k] * rhs[(long)(r0 + j) + (long)rel[k]];
-    sum[j] = s;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      T s = 0;
+      for (int32_t k = b; k < e; k++) s += pval[k] * rhs[q][(long)(r0 + j) + (long)rel[k]];
+      sum[q][j] = s;
+    }
   }
 }
 
@@ -194,73 +229,97 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
 // kv[0..VEC) = (K rhs)_(i .. i+VEC).  VEC > 1: i, every block's row / col / nrows and every gradient block's ny and plane
 // size are multiples of VEC (host-checked), so the VEC rows lie in the same blocks, the same component plane and image column.
 // w0 = the i of lane 0 (wave-uniform); VEC > 1 callers guarantee that all 64 lanes are active.
-template <class T, int VEC>
-__device__ __forceinline__ void op_fwd_rows(const FusedOpDev& op, size_t i, size_t w0, const T* __restrict__ t, T (&kv)[VEC], bool lanes_in_step = true) {
+template <class T, int VEC, int NR>
+__device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& op, size_t i, size_t w0, const T* const (&t)[NR], T (&kv)[NR][VEC], bool lanes_in_step = true) {
 #pragma unroll
-  for (int j = 0; j < VEC; j++) kv[j] = 0;
+  for (int q = 0; q < NR; q++)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) kv[q][j] = 0;
   for (int b = 0; b < op.nblocks; b++) {
-    const OpBlockDev& B = op.b[b];
+    const PROST_CONSTANT OpBlockDev& B = op.b[b];
     if (i < B.row || i >= B.row + B.nrows) continue;
     const size_t r = i - B.row;
-    const T* rhs = t + B.col;
     if (B.kind == PROST_OP_CSR) {
       const bool whole = VEC > 1 && lanes_in_step && w0 >= B.row && w0 + (size_t)kWave * VEC <= B.row + B.nrows;
-      T sum[VEC];
-      if (B.ids) pattern_rows<T, VEC>(B.ids, B.pptr, B.rel, static_cast<const T*>(B.pval), rhs, r, sum, B.dom_id, B.dom_n, B.dom_rel, B.dom_val, (size_t)B.ncols);
-      else csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, rhs, r, w0 - B.row, whole, sum);
+      T sum[NR][VEC];
+      if (B.ids) {
+        const T* rhs[NR];
 #pragma unroll
-      for (int j = 0; j < VEC; j++) kv[j] = kv[j] + sum[j];
+        for (int q = 0; q < NR; q++) rhs[q] = t[q] + B.col;
+        pattern_rows<T, VEC, NR>(B.ids, as_constant(B.pptr), as_constant(B.rel), as_constant_of<T>(B.pval), rhs, r, sum, B.dom_id, B.dom_n, B.dom_rel, B.dom_val, (size_t)B.ncols);
+      } else {
+#pragma unroll
+        for (int q = 0; q < NR; q++) csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, t[q] + B.col, r, w0 - B.row, whole, sum[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < NR; q++)
+#pragma unroll
+        for (int j = 0; j < VEC; j++) kv[q][j] = kv[q][j] + sum[q][j];
     } else {
       const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, N = slice * (unsigned)B.L;
       const unsigned r32 = (unsigned)r;
       const unsigned c = r32 / N, idx = r32 - c * N;
-      T cur[VEC], g[VEC];
-      ldv<T, VEC>(rhs + idx, cur);
-      if (c == 0) {
-        const unsigned x = (idx / ny) % nx;
-        T nb[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; j++) nb[j] = 0;
-        if (x < nx - 1) ldv<T, VEC>(rhs + idx + ny, nb);
+      for (int q = 0; q < NR; q++) {
+        const T* rhs = t[q] + B.col;
+        T cur[VEC], g[VEC];
+        ldv<T, VEC>(rhs + idx, cur);
+        if (c == 0) {
+          const unsigned x = (idx / ny) % nx;
+          T nb[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; j++) g[j] = x < nx - 1 ? nb[j] - cur[j] : (T)0;
-      } else if (c == 1) {
-        const unsigned y = idx % ny;
-        const T below = y + VEC < ny ? rhs[idx + VEC] : (T)0;
+          for (int j = 0; j < VEC; j++) nb[j] = 0;
+          if (x < nx - 1) ldv<T, VEC>(rhs + idx + ny, nb);
 #pragma unroll
-        for (int j = 0; j < VEC; j++) {
-          const T dn = j + 1 < VEC ? cur[(j + 1) % VEC] : below;
-          g[j] = y + j < ny - 1 ? dn - cur[j] : (T)0;
+          for (int j = 0; j < VEC; j++) g[j] = x < nx - 1 ? nb[j] - cur[j] : (T)0;
+        } else if (c == 1) {
+          const unsigned y = idx % ny;
+          const T below = y + VEC < ny ? rhs[idx + VEC] : (T)0;
+#pragma unroll
+          for (int j = 0; j < VEC; j++) {
+            const T dn = j + 1 < VEC ? cur[(j + 1) % VEC] : below;
+            g[j] = y + j < ny - 1 ? dn - cur[j] : (T)0;
+          }
+        } else {
+          const unsigned l = idx / slice;
+          T up[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; j++) up[j] = 0;
+          if (l < (unsigned)B.L - 1) ldv<T, VEC>(rhs + idx + slice, up);
+#pragma unroll
+          for (int j = 0; j < VEC; j++) g[j] = l < (unsigned)B.L - 1 ? up[j] - cur[j] : -cur[j];      // Dirichlet (block_gradient3d.cu:73-76)
         }
-      } else {
-        const unsigned l = idx / slice;
-        T up[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; j++) up[j] = 0;
-        if (l < (unsigned)B.L - 1) ldv<T, VEC>(rhs + idx + slice, up);
-#pragma unroll
-        for (int j = 0; j < VEC; j++) g[j] = l < (unsigned)B.L - 1 ? up[j] - cur[j] : -cur[j];      // Dirichlet (block_gradient3d.cu:73-76)
+        for (int j = 0; j < VEC; j++) kv[q][j] = kv[q][j] + g[j];
       }
-#pragma unroll
-      for (int j = 0; j < VEC; j++) kv[j] = kv[j] + g[j];
     }
   }
 }
+template <class T, int VEC>
+__device__ __forceinline__ void op_fwd_rows(const PROST_CONSTANT FusedOpDev& op, size_t i, size_t w0, const T* __restrict__ t, T (&kv)[VEC], bool lanes_in_step = true) {
+  const T* tt[1] = {t};
+  T k1[1][VEC];
+  op_fwd_rows_n<T, VEC, 1>(op, i, w0, tt, k1, lanes_in_step);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) kv[j] = k1[0][j];
+}
 // v[0..VEC) += (K^T rhs)_(j .. j+VEC), blocks in order (EvalAdjointAdd per block)
 template <class T, int VEC>
-__device__ __forceinline__ void op_adj_cols(const FusedOpDev& op, size_t jg, size_t w0, const T* __restrict__ t, T (&v)[VEC], bool lanes_in_step = true) {
+__device__ __forceinline__ void op_adj_cols(const PROST_CONSTANT FusedOpDev& op, size_t jg, size_t w0, const T* __restrict__ t, T (&v)[VEC], bool lanes_in_step = true) {
   for (int b = 0; b < op.nblocks; b++) {
-    const OpBlockDev& B = op.b[b];
+    const PROST_CONSTANT OpBlockDev& B = op.b[b];
     if (jg < B.col || jg >= B.col + B.ncols) continue;
     const size_t cidx = jg - B.col;
     const T* rhs = t + B.row;
     if (B.kind == PROST_OP_CSR) {
       const bool whole = VEC > 1 && lanes_in_step && w0 >= B.col && w0 + (size_t)kWave * VEC <= B.col + B.ncols;
-      T sum[VEC];
-      if (B.ids_t) pattern_rows<T, VEC>(B.ids_t, B.pptr_t, B.rel_t, static_cast<const T*>(B.pval_t), rhs, cidx, sum, B.dom_id_t, B.dom_n_t, B.dom_rel_t, B.dom_val_t, (size_t)B.nrows);
-      else csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - B.col, whole, sum);
+      T sum[1][VEC];
+      if (B.ids_t) {
+        const T* rr[1] = {rhs};
+        pattern_rows<T, VEC, 1>(B.ids_t, as_constant(B.pptr_t), as_constant(B.rel_t), as_constant_of<T>(B.pval_t), rr, cidx, sum, B.dom_id_t, B.dom_n_t, B.dom_rel_t, B.dom_val_t, (size_t)B.nrows);
+      } else csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - B.col, whole, sum[0]);
 #pragma unroll
-      for (int j = 0; j < VEC; j++) v[j] = v[j] + sum[j];
+      for (int j = 0; j < VEC; j++) v[j] = v[j] + sum[0][j];
     } else {
       const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, idx = (unsigned)cidx;
       const size_t N = (size_t)slice * B.L;

@@ -10,6 +10,7 @@
 // synchronisation of the loop (the reference synchronises after every prox and twice per
 // residual iteration).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <atomic>
 #include <cmath>
@@ -217,7 +218,7 @@ void BackendPDHG<T>::Initialize() {
   for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
   // the operator inside the prox kernels (round 5): every block a sparse matrix or a gradient stencil, every prox able to form K^T y /
   // K x for its own elements (the in-tree elem operations, their Moreau wraps, the identity, on 16-byte boundaries)
-  op_fused_ = !fused_ && opts_.allow_op_fusion && arg_fused_g_ && arg_fused_f_ && owned_x1_ == 0 && DescribeGenericOperator();
+  op_fused_ = !fused_ && opts_.allow_op_fusion > 0 && arg_fused_g_ && arg_fused_f_ && owned_x1_ == 0 && DescribeGenericOperator(opts_.allow_op_fusion == 1);
   for (auto& p : prox_g_) op_fused_ = op_fused_ && p->supports_op_source();
   for (auto& p : prox_fstar_) op_fused_ = op_fused_ && p->supports_op_source();
   if (op_fused_ && !op_workspace_) CheckHip(prost_hip_malloc(&op_workspace_, 2 * (size_t)kOpSumSlots * 4 * sizeof(double)), "malloc");
@@ -766,7 +767,7 @@ void BackendPDHG<T>::IterationFused(bool res) {
 /// (prost_hip_prox_elem_arg, PROST_ARG_PDHG_PRIMAL_OP / _DUAL_OP); plugin blocks, diags, Kronecker blocks, label_first gradients and a
 /// dualized operator keep the separate products.
 template <typename T>
-bool BackendPDHG<T>::DescribeGenericOperator() {
+bool BackendPDHG<T>::DescribeGenericOperator(bool stencils_only) {
   auto linop = this->problem_->linop();
   if (dynamic_cast<DualLinearOperator<T>*>(linop.get())) return false;
   const auto& blocks = linop->blocks();
@@ -780,6 +781,8 @@ bool BackendPDHG<T>::DescribeGenericOperator() {
     o.row = b->row(); o.col = b->col(); o.nrows = b->nrows(); o.ncols = b->ncols();
     if (bd.kind == BlockDesc::kSparse) {
       o.kind = PROST_OP_CSR;
+      // (a stencil: K and K^T run from row patterns and one pattern covers most rows -- its operands are requested speculatively)
+      if (stencils_only && !(bd.ids && bd.ids_t && bd.dom_n > 0 && bd.dom_n_t > 0)) return false;
       o.val = bd.val; o.ptr = bd.ptr; o.ind = bd.ind; o.val_t = bd.val_t; o.ptr_t = bd.ptr_t; o.ind_t = bd.ind_t;
       o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t;
       o.dom_id = bd.dom_id; o.dom_n = bd.dom_n; o.dom_id_t = bd.dom_id_t; o.dom_n_t = bd.dom_n_t;
@@ -819,7 +822,7 @@ void BackendPDHG<T>::IterationGenericOp(bool res) {
     src.op = &gen_op_; src.op_rows = m; src.op_cols = n;
     src.w[0] = y_.data(); src.kty_out = kty_.data();
     src.use[0] = iteration_ >= 1 ? 1 : 0;                    // kty_ is the zero vector in iteration 0 (backend_pdhg.cu:213)
-    if (res) { src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, half / (unsigned)std::max<size_t>(prox_g_.size(), 1)); }
+    if (res) { src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_g_.size(), 1))); }
     for (auto& p : prox_g_) p->EvalFromSource(x_, src, Tr, tau_);
   }
   y_.swap(y_prev_);
@@ -828,7 +831,7 @@ void BackendPDHG<T>::IterationGenericOp(bool res) {
     src.op = &gen_op_; src.op_rows = m; src.op_cols = n;
     src.w[0] = x_.data(); src.w[1] = x_prev_.data();
     src.use[1] = iteration_ >= 1 ? 1 : 0;                    // kx_prev_ is the zero vector in iteration 0 (:216)
-    if (res) { src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1)); }
+    if (res) { src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1))); }
     for (auto& p : prox_fstar_) p->EvalFromSource(y_, src, Sl, sigma_);
   }
   if (res) {

@@ -340,7 +340,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       if (prost_value_field(d, "allow_pair_kernel")) o.allow_pair_kernel = GetScalarFromField(d, "allow_pair_kernel") > 0.;
       if (prost_value_field(d, "allow_speculation")) o.allow_speculation = GetScalarFromField(d, "allow_speculation") > 0.;
       if (prost_value_field(d, "allow_arg_fusion")) o.allow_arg_fusion = GetScalarFromField(d, "allow_arg_fusion") > 0.;
-      if (prost_value_field(d, "allow_op_fusion")) o.allow_op_fusion = GetScalarFromField(d, "allow_op_fusion") > 0.;
+      if (prost_value_field(d, "allow_op_fusion")) o.allow_op_fusion = (int)GetScalarFromField(d, "allow_op_fusion");
       if (prost_value_field(d, "allow_device_rules")) o.allow_device_rules = GetScalarFromField(d, "allow_device_rules") > 0.;
       return new BackendPDHG<T>(o);
     };

@@ -646,7 +646,7 @@ static int normest_stage(int stage, const prost_hip_normest_desc* d, void* strea
 // step of the range and the count % VEC tail run one element per lane.
 template <class T, int VEC, bool ADJ, class E>
 __global__ void __launch_bounds__(kBlock) op_stage_kernel(const FusedOpDev* __restrict__ opp, E e, const T* __restrict__ in, size_t count, const CgState* cur, double* ws) {
-  const FusedOpDev& op = *opp;
+  const PROST_CONSTANT FusedOpDev& op = *as_constant(opp);
   if (E::kSkipWhenDone && cur->done) return;
   e.prologue(cur, ws);
   dd_t sa{0.0, 0.0}, sb{0.0, 0.0};

@@ -74,11 +74,19 @@ __device__ __forceinline__ void load_arg_op(const ArgSrc<T>& a, const OpSrc<T>& 
   const size_t g = os.base + off;
   if (ARG == 3) {
     if (os.res_ws && a.v3) ldv<T, VEC>(a.v3 + off, P.p3);                          // K^T y_prev, stored by the previous iteration's launch
-    if (os.use0) op_adj_cols<T, VEC>(*os.opp, g, g, os.w0, P.p2, false);            // 0 + K^T y, block after block
+    if (os.use0) op_adj_cols<T, VEC>(*as_constant(os.opp), g, g, os.w0, P.p2, false);            // 0 + K^T y, block after block
     if (store && os.kty_out) stv<T, VEC>(os.kty_out + off, P.p2);
   } else {
-    if (os.use0) op_fwd_rows<T, VEC>(*os.opp, g, g, os.w0, P.p2, false);            // K x
-    if (os.use1) op_fwd_rows<T, VEC>(*os.opp, g, g, os.w1, P.p3, false);            // K x_prev
+    if (os.use0 && os.use1) {                                                                  // K x and K x_prev in one walk over the blocks
+      const T* tt[2] = {os.w0, os.w1};
+      T kk[2][VEC];
+      op_fwd_rows_n<T, VEC, 2>(*as_constant(os.opp), g, g, tt, kk, false);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { P.p2[j] = kk[0][j]; P.p3[j] = kk[1][j]; }
+    } else {
+      if (os.use0) op_fwd_rows<T, VEC>(*as_constant(os.opp), g, g, os.w0, P.p2, false);          // K x
+      if (os.use1) op_fwd_rows<T, VEC>(*as_constant(os.opp), g, g, os.w1, P.p3, false);          // K x_prev
+    }
   }
 #pragma unroll
   for (int j = 0; j < VEC; j++) out[j] = arg_formula<T, ARG>(a, P.p0[j], P.p1[j], P.p2[j], ARG == 4 ? P.p3[j] : (T)0);
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
 // transaction and the per-element coefficient vectors are read with the same width.  DIM > 0 keeps
 // the components in registers; DIM == 0 (any dimension) makes a second pass over arg (L2 hits).
 template <class T, int OP, int DIM, bool MOREAU, int ARG>
-__global__ void __launch_bounds__(kBlock) prox_elem_vec_kernel(T* __restrict__ res, ArgSrc<T> arg,
+__global__ void __launch_bounds__(kBlock, ARG >= 3 && sizeof(T) == 4 && DIM <= 1 ? 4 : 1) prox_elem_vec_kernel(T* __restrict__ res, ArgSrc<T> arg,
                                                                const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                                size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one,
                                                                typename OpSrcOf<T, ARG>::type os) {

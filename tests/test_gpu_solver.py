@@ -528,7 +528,7 @@ def test_operator_norm_estimate_equals_the_oracle_bit_for_bit(precision, dtype):
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("step,residual_iter", [("boyd", 1), ("alg2", 4), ("goldstein", 3)])
 def test_generic_pdhg_with_the_operator_inside_the_prox_kernels(precision, dtype, step, residual_iter):
-    """allow_op_fusion (round 5, off by default: measured slower): the prox launches of the generic path form K^T y / K x
+    """allow_op_fusion (round 5; 1 = the default: operators of stencil / gradient blocks, 2: any supported operator): the prox launches of the generic path form K^T y / K x
     for their own elements from the operator's blocks -- row patterns, CSR rows, gradient stencils, in block order -- and add up the residual
     terms themselves, so K x is never written and an iteration is 4 launches instead of 9.  Iterates, step sizes and decisions are those of
     the separate products and of the oracle, bit for bit, on: example_deblurring.m's shape (two sparse constraint blocks, Moreau-wrapped
@@ -549,7 +549,7 @@ def test_generic_pdhg_with_the_operator_inside_the_prox_kernels(precision, dtype
             st = {}
             for opf, dev in ((True, True), (True, False), (False, True)):
                 b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.2)
-                b[1]["allow_op_fusion"] = opf
+                b[1]["allow_op_fusion"] = 2 if opf else 0
                 b[1]["allow_device_rules"] = dev
                 st[(opf, dev)] = run_product(prob, b, o, iters)
                 assert st[(opf, dev)]["path"] == "pdhg:generic" and st[(opf, dev)]["operator_in_prox_kernels"] == (1.0 if opf else 0.0), (name, opf)

@@ -54,3 +54,10 @@ try:
 except Exception as e: print('$f', 'ERR', e)"; done
 { python3 tools/generic_rule_rate.py 256 256 3000; python3 tools/generic_rule_rate.py 1024 1024 2000; python3 tools/generic_rule_rate.py 2048 2048 600; } 2>/dev/null | tee $O/generic_op_fusion_rates.txt
 find $O -name "*kernel_trace.csv" -size +1M -delete; find $O -name "*counter_collection.csv" -size +1M -delete
+# ---- where the generic path spends its time at 2048^2 (kernel stats over the four variants)
+cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats_generic2048 -- python3 $R/tools/generic_rule_rate.py 2048 2048 300 > /dev/null 2>&1; cd $R
+python3 -c "
+import csv
+for r in list(csv.DictReader(open('$O/stats_generic2048_kernel_stats.csv')))[:24]: print('  ', r['Name'][:150].replace('void prost_hip::',''), r['Calls'], r['AverageNs'], r['Percentage'])"
+find $O -name "*kernel_trace.csv" -size +1M -delete
+du -sh $R/gpurun_out

@@ -1,7 +1,7 @@
 """The reference's default backend options (boyd, residual_iter = 1) on the GENERIC path: example_deblurring.m's shape -- min_problem,
 two sparse constraint blocks on u (a blur operator with a square data term, the gradient with the TV norm), no function on u -- with
 the step-size rule on the device (batches of iterations, one host wait each) and on the host (one round trip per iteration).
-usage: generic_rule_rate.py [nx ny] [iters]"""
+usage: generic_rule_rate.py [nx ny] [iters] [residual_iter] [warmup] [variant mask: 1 op+device, 2 op+host, 4 separate+device, 8 separate+host]"""
 import os
 import sys
 
@@ -31,17 +31,20 @@ def problem(nx, ny, seed=3):
     return prob
 
 
-def main(nx=700, ny=464, iters=3000, residual_iter=1):
+def main(nx=700, ny=464, iters=3000, residual_iter=1, warmup=300, mask=15):
     prost.set_gpu(0); prost.set_precision("single")
     o = prost.options(max_iters=10 ** 9, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
     prob = problem(nx, ny)
     for name, dev, opf in (("operator in the prox kernels, rule on the device", True, True), ("operator in the prox kernels, rule on the host", False, True),
                            ("separate products, rule on the device", True, False), ("separate products, rule on the host", False, False)):
+        mask, skip = mask >> 1, not (mask & 1)
+        if skip:
+            continue
         b = prost.backend.pdhg(stepsize="boyd", residual_iter=int(residual_iter))      # :40-41
         b[1]["allow_device_rules"] = dev
-        b[1]["allow_op_fusion"] = opf
+        b[1]["allow_op_fusion"] = 1 if opf else 0
         s = prost.Solver(prob, b, o)
-        s.iterate(300)
+        s.iterate(warmup)
         info = s.iterate(iters)
         st = s.state(vectors=False)
         print("deblurring-like %dx%d fp32, boyd R=%d, %-48s: %.0f it/s (%.4f ms per iteration), path %s, operator in prox kernels %s, device rule batches %s" % (
@@ -50,4 +53,4 @@ def main(nx=700, ny=464, iters=3000, residual_iter=1):
 
 
 if __name__ == "__main__":
-    main(*[int(a) for a in sys.argv[1:5]])
+    main(*[int(a) for a in sys.argv[1:7]])
