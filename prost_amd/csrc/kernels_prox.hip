@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kBlock) prox_elem_kernel(T* __restrict__ res, 
 // transaction and the per-element coefficient vectors are read with the same width.  DIM > 0 keeps
 // the components in registers; DIM == 0 (any dimension) makes a second pass over arg (L2 hits).
 template <class T, int OP, int DIM, bool MOREAU, int ARG>
-__global__ void __launch_bounds__(kBlock, ARG >= 3 && sizeof(T) == 4 && DIM <= 1 ? 4 : 1) prox_elem_vec_kernel(T* __restrict__ res, ArgSrc<T> arg,
+__global__ void __launch_bounds__(kBlock, ARG >= 3 && sizeof(T) == 4 ? (DIM <= 1 ? 4 : DIM == 2 ? 3 : 1) : 1) prox_elem_vec_kernel(T* __restrict__ res, ArgSrc<T> arg,
                                                                const T* __restrict__ tau_diag, T tau_scal, bool invert_tau,
                                                                size_t count, size_t dim, int fn, Coeffs<T> cf, bool e_zero, bool a_one,
                                                                typename OpSrcOf<T, ARG>::type os) {
