@@ -179,6 +179,7 @@ class BackendPDHG : public Backend<T> {
   bool arg_fused_g_ = false, arg_fused_f_ = false;     // every prox of prox_g_ / prox_fstar_ evaluates from an argument source
   bool op_fused_ = false;                              // ... and from the operator sources: the generic iteration runs without K x / K^T y launches
   prost_hip_fused_op gen_op_;                          // the operator as a table of sparse / gradient blocks (op_fused_)
+  const T* view_tau_ = nullptr; const T* view_sigma_ = nullptr; const int* view_stop_ = nullptr;   // device addresses inside rule_rec_ (Prox::StepView)
   void* op_workspace_ = nullptr;                       // residual sums of the prox launches: 2 x kOpSumSlots slots of 4 doubles (primal | dual)
   static constexpr unsigned kOpSumSlots = 8192;
   /// workgroups of one residual launch: every workgroup ends with a block-wide fold of its sums, which 2048 workgroups (two rounds of the

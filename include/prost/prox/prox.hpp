@@ -105,6 +105,15 @@ class Prox {
   /// (prost_hip_use_step_record): the in-tree elem operations, their Moreau wraps and the identity.  A prox of a plugin that
   /// implements EvalFromSource with kernels of its own keeps the default -- its problems run the host loop.
   virtual bool takes_step_record() const { return false; }
+  /// MI355X addition (round 5): the step size as a DEVICE scalar.  Inside a batch of iterations whose step-size rule runs on the device
+  /// (goldstein / boyd without a host wait per iteration) the host does not know tau when it enqueues the prox.  A prox whose kernels can
+  /// read it from device memory returns true from takes_step_view() and implements EvalLocalStepView: `*view.step` is the scalar the
+  /// reference would have passed as `tau`, valid when the kernel RUNS; a non-zero `*view.stop` means the batch has ended (the stopping
+  /// test fired) and the kernel must leave `result` untouched.  ProxElemOperation<T, OP> (prox_elem_operation.inl) implements it for every
+  /// user-written operation; proxes that keep the default run the host loop, as the reference does.
+  struct StepView { const T* step; const int* stop; };
+  virtual bool takes_step_view() const { return false; }
+  void EvalWithStepView(device_vector<T>& result, const device_vector<T>& arg, const device_vector<T>& tau_diag, const StepView& view, bool invert_tau = false);
   /// result[index:index+size) = prox(source[index:index+size); tau * tau_diag[...]); result must not alias source.v[0]
   virtual void EvalFromSource(device_vector<T>& result, const ArgSource& src, const device_vector<T>& tau_diag, T tau, bool invert_tau = false) {
     (void)result; (void)src; (void)tau_diag; (void)tau; (void)invert_tau;
@@ -114,6 +123,12 @@ class Prox {
  protected:
   virtual void EvalLocal(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg,
                          const T* tau_end, T tau, bool invert_tau) = 0;
+  /// EvalLocal with the step size read on the device (StepView above); the default refuses
+  virtual void EvalLocalStepView(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg, const T* tau_end,
+                                 const StepView& view, bool invert_tau) {
+    (void)result_beg; (void)result_end; (void)arg_beg; (void)arg_end; (void)tau_beg; (void)tau_end; (void)view; (void)invert_tau;
+    throw Exception("This prox cannot take its step size from the device.");
+  }
   size_t index_, size_;
   bool diagsteps_;
 };

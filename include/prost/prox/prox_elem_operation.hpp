@@ -26,6 +26,9 @@
 
 namespace prost {
 
+template <typename T, class ELEM_OPERATION>
+struct ElemOpCoefficients;
+
 template <typename T, class ELEM_OPERATION, class ENABLE = void>
 class ProxElemOperation {};
 
@@ -36,10 +39,15 @@ class ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATIO
   ProxElemOperation(size_t index, size_t count, size_t dim, bool interleaved, bool diagsteps)
       : ProxSeparableSum<T>(index, count, (ELEM_OPERATION::kDim <= 0) ? dim : ELEM_OPERATION::kDim, interleaved, diagsteps) {}
   virtual size_t gpu_mem_amount() const { return 0; }
+  /// MI355X addition: the kernel reads the step size from device memory when asked to (prox.hpp: StepView) -- problems whose proxes are
+  /// user-written operations run goldstein / boyd without a host wait per iteration as well
+  virtual bool takes_step_view() const { return true; }
 
  protected:
   virtual void EvalLocal(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg, const T* tau_end,
                          T tau, bool invert_tau);
+  virtual void EvalLocalStepView(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg, const T* tau_end,
+                                 const typename Prox<T>::StepView& view, bool invert_tau);
 };
 
 /// operations with kCoeffsCount scalar-or-per-group coefficients (prox_elem_operation.hpp:64-110)
@@ -59,12 +67,16 @@ class ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATIO
       if (coeffs_[i].size() > 1) mem += this->count_ * sizeof(T);
     return mem;
   }
+  virtual bool takes_step_view() const { return true; }
 
  protected:
   virtual void EvalLocal(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg, const T* tau_end,
                          T tau, bool invert_tau);
+  virtual void EvalLocalStepView(T* result_beg, T* result_end, const T* arg_beg, const T* arg_end, const T* tau_beg, const T* tau_end,
+                                 const typename Prox<T>::StepView& view, bool invert_tau);
 
  private:
+  void KernelCoefficients(ElemOpCoefficients<T, ELEM_OPERATION>& coeffs) const;
   std::array<std::vector<T>, ELEM_OPERATION::kCoeffsCount> coeffs_;
   std::array<device_vector<T>, ELEM_OPERATION::kCoeffsCount> d_coeffs_;
 };

@@ -56,6 +56,20 @@ __device__ __forceinline__ void StorePack(T* p, const T* in) {
   *reinterpret_cast<Pack<T, N>*>(p) = q;
 }
 
+/// the scalar step of a launch: the host's value, or -- inside a batch of iterations whose step-size rule runs on the device (prox.hpp:
+/// StepView) -- a device scalar read when the kernel runs; a raised stop word ends the kernel before it touches the result
+template <typename T>
+struct StepArg {
+  T tau; const T* step; const int* stop;
+  __device__ __forceinline__ bool resolve(T& t) const {
+    t = tau;
+    if (step == nullptr) return true;
+    if (*stop != 0) return false;
+    t = *step;
+    return true;
+  }
+};
+
 /// constructs the operation the way the reference kernel does (prox_elem_operation.inl:53, :91) and applies it
 template <typename T, class OP>
 __device__ __forceinline__ void Apply(Vector<T>& res, const Vector<const T>& arg, const Vector<const T>& tau_diag, T tau, bool invert_tau,
@@ -73,11 +87,13 @@ __device__ __forceinline__ void Apply(Vector<T>& res, const Vector<const T>& arg
 
 // ---- TILE path: VEC element groups per lane in registers; groups [first, first + n) of `count`, n % VEC == 0 -------
 template <typename T, class OP, int DIM, int VEC, bool INTERLEAVED>
-__global__ void __launch_bounds__(kLanes) ProxElemOperationTileKernel(T* d_res, const T* d_arg, const T* d_tau, T tau, bool invert_tau,
+__global__ void __launch_bounds__(kLanes) ProxElemOperationTileKernel(T* d_res, const T* d_arg, const T* d_tau, StepArg<T> step, bool invert_tau,
                                                                       size_t count, size_t first, size_t n,
                                                                       ElemOpCoefficients<T, OP> coeffs) {
   const size_t lane = (size_t)blockIdx.x * kLanes + threadIdx.x;
   if (lane * VEC >= n) return;
+  T tau;
+  if (!step.resolve(tau)) return;
   const size_t e0 = first + lane * VEC;          // first group of this lane
   constexpr int NC = OP::kCoeffsCount ? (int)OP::kCoeffsCount : 1;
 
@@ -138,10 +154,12 @@ __global__ void __launch_bounds__(kLanes) ProxElemOperationTileKernel(T* d_res, 
 
 // ---- DIRECT path: one element group per lane, views over HBM (the reference's access pattern) ----------------------
 template <typename T, class OP>
-__global__ void __launch_bounds__(kLanes) ProxElemOperationKernel(T* d_res, const T* d_arg, const T* d_tau, T tau, bool invert_tau, size_t count,
+__global__ void __launch_bounds__(kLanes) ProxElemOperationKernel(T* d_res, const T* d_arg, const T* d_tau, StepArg<T> step, bool invert_tau, size_t count,
                                                                   size_t dim, ElemOpCoefficients<T, OP> coeffs, bool interleaved) {
   const size_t tx = (size_t)blockIdx.x * kLanes + threadIdx.x;
   if (tx >= count) return;
+  T tau;
+  if (!step.resolve(tau)) return;
   constexpr int NC = OP::kCoeffsCount ? (int)OP::kCoeffsCount : 1;
   Vector<T> res(count, dim, interleaved, tx, d_res);
   const Vector<const T> arg(count, dim, interleaved, tx, d_arg);
@@ -166,7 +184,7 @@ inline void CheckLaunch(const char* what) {
 }
 
 template <typename T, class OP, int DIM, int VEC, bool INTERLEAVED>
-void LaunchTile(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau, size_t count, size_t first, size_t n,
+void LaunchTile(T* res, const T* arg, const T* tau_diag, const StepArg<T>& tau, bool invert_tau, size_t count, size_t first, size_t n,
                 const ElemOpCoefficients<T, OP>& coeffs, size_t lds_bytes, hipStream_t stream) {
   if (n == 0) return;
   const size_t lanes = n / VEC;
@@ -176,7 +194,7 @@ void LaunchTile(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau,
 
 /// DIM-th instance of the tile path if the operation admits that dimension (kDim == 0: any)
 template <typename T, class OP, int DIM>
-bool TryTile(size_t dim, bool interleaved, T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau, size_t count,
+bool TryTile(size_t dim, bool interleaved, T* res, const T* arg, const T* tau_diag, const StepArg<T>& tau, bool invert_tau, size_t count,
              const ElemOpCoefficients<T, OP>& coeffs, size_t lds_bytes, hipStream_t stream) {
   if constexpr (OP::kDim != 0 && OP::kDim != DIM) {
     return false;
@@ -203,7 +221,7 @@ bool TryTile(size_t dim, bool interleaved, T* res, const T* arg, const T* tau_di
 /// what both EvalLocal specialisations do (prox_elem_operation.inl:96-198): grid over the element groups, dynamic LDS
 /// for the operation's per-thread scratch, launch, error check -- without the device synchronisation
 template <typename T, class OP>
-void Launch(T* res, const T* arg, const T* tau_diag, T tau, bool invert_tau, size_t count, size_t dim, bool interleaved,
+void Launch(T* res, const T* arg, const T* tau_diag, const StepArg<T>& tau, bool invert_tau, size_t count, size_t dim, bool interleaved,
             const ElemOpCoefficients<T, OP>& coeffs) {
   if (count == 0) return;
   hipStream_t stream = static_cast<hipStream_t>(CurrentStream());
@@ -241,14 +259,24 @@ void ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATION
   ElemOpCoefficients<T, ELEM_OPERATION> coeffs;
   coeffs.dev_p[0] = nullptr;
   coeffs.val[0] = 0;
-  elemop_kernel::Launch<T, ELEM_OPERATION>(result_beg, arg_beg, tau_beg, tau, invert_tau, this->count_, this->dim_, this->interleaved_, coeffs);
+  elemop_kernel::Launch<T, ELEM_OPERATION>(result_beg, arg_beg, tau_beg, elemop_kernel::StepArg<T>{tau, nullptr, nullptr}, invert_tau, this->count_, this->dim_,
+                                           this->interleaved_, coeffs);
+}
+template <typename T, class ELEM_OPERATION>
+void ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATION::kCoeffsCount == 0>::type>::EvalLocalStepView(
+    T* result_beg, T* /*result_end*/, const T* arg_beg, const T* /*arg_end*/, const T* tau_beg, const T* /*tau_end*/, const typename Prox<T>::StepView& view,
+    bool invert_tau) {
+  ElemOpCoefficients<T, ELEM_OPERATION> coeffs;
+  coeffs.dev_p[0] = nullptr;
+  coeffs.val[0] = 0;
+  elemop_kernel::Launch<T, ELEM_OPERATION>(result_beg, arg_beg, tau_beg, elemop_kernel::StepArg<T>{(T)0, view.step, view.stop}, invert_tau, this->count_, this->dim_,
+                                           this->interleaved_, coeffs);
 }
 
 // ---- kCoeffsCount != 0 (prox_elem_operation.inl:142-222) ----
 template <typename T, class ELEM_OPERATION>
-void ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATION::kCoeffsCount != 0>::type>::EvalLocal(
-    T* result_beg, T* /*result_end*/, const T* arg_beg, const T* /*arg_end*/, const T* tau_beg, const T* /*tau_end*/, T tau, bool invert_tau) {
-  ElemOpCoefficients<T, ELEM_OPERATION> coeffs;
+void ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATION::kCoeffsCount != 0>::type>::KernelCoefficients(
+    ElemOpCoefficients<T, ELEM_OPERATION>& coeffs) const {
   for (size_t i = 0; i < ELEM_OPERATION::kCoeffsCount; i++) {
     if (coeffs_[i].size() > 1) {
       if (d_coeffs_[i].size() != coeffs_[i].size()) throw Exception("ProxElemOperation used before Initialize().");
@@ -260,7 +288,23 @@ void ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATION
       coeffs.val[i] = coeffs_[i][0];
     }
   }
-  elemop_kernel::Launch<T, ELEM_OPERATION>(result_beg, arg_beg, tau_beg, tau, invert_tau, this->count_, this->dim_, this->interleaved_, coeffs);
+}
+template <typename T, class ELEM_OPERATION>
+void ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATION::kCoeffsCount != 0>::type>::EvalLocal(
+    T* result_beg, T* /*result_end*/, const T* arg_beg, const T* /*arg_end*/, const T* tau_beg, const T* /*tau_end*/, T tau, bool invert_tau) {
+  ElemOpCoefficients<T, ELEM_OPERATION> coeffs;
+  KernelCoefficients(coeffs);
+  elemop_kernel::Launch<T, ELEM_OPERATION>(result_beg, arg_beg, tau_beg, elemop_kernel::StepArg<T>{tau, nullptr, nullptr}, invert_tau, this->count_, this->dim_,
+                                           this->interleaved_, coeffs);
+}
+template <typename T, class ELEM_OPERATION>
+void ProxElemOperation<T, ELEM_OPERATION, typename std::enable_if<ELEM_OPERATION::kCoeffsCount != 0>::type>::EvalLocalStepView(
+    T* result_beg, T* /*result_end*/, const T* arg_beg, const T* /*arg_end*/, const T* tau_beg, const T* /*tau_end*/, const typename Prox<T>::StepView& view,
+    bool invert_tau) {
+  ElemOpCoefficients<T, ELEM_OPERATION> coeffs;
+  KernelCoefficients(coeffs);
+  elemop_kernel::Launch<T, ELEM_OPERATION>(result_beg, arg_beg, tau_beg, elemop_kernel::StepArg<T>{(T)0, view.step, view.stop}, invert_tau, this->count_, this->dim_,
+                                           this->interleaved_, coeffs);
 }
 
 template <typename T, class ELEM_OPERATION>

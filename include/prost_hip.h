@@ -36,7 +36,7 @@ extern "C" {
  * 7: prost_hip_op_block gained the row-pattern fields, prost_hip_arg_spec the operator source (both appended; callers that filled the
  *    old layouts must zero the new members); prost_hip_cgls_workspace_bytes doubled (order-independent sums: (hi, lo) per partial);
  *    additions: cgls_pixel_round / _close, pixel_op_supported, fused_iteration3d_rec / _3d_pw_rec / _3d_x2_rec, pdhg_fold_sums */
-#define PROST_HIP_ABI_VERSION 7
+#define PROST_HIP_ABI_VERSION 8
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
@@ -442,6 +442,11 @@ int prost_hip_pdhg_residuals_f64(double* sums4, const double* y_prev, const doub
                                  const double* x_prev, const double* x, const double* T, const double* kty_prev, const double* kty, double tau, size_t n, void* workspace, void* record,
                                  int apply_rule, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
 size_t prost_hip_pdhg_rule_record_bytes(void);
+/* ABI 8: the DEVICE addresses of the scalars a record of prost_hip_pdhg_rule_begin_f32 / _f64 (dtype 0 / 1) holds for the coming iterations --
+ * tau, sigma, theta (float or double) and the stop word (int, non-zero once the stopping test has fired) -- so that a kernel outside this
+ * library (a plugin prox, include/prost/prox/prox.hpp: StepView) can take its step size from the device inside a batch of iterations.
+ * Address arithmetic only: nothing is read or launched.  Any out pointer may be NULL. */
+int prost_hip_pdhg_record_view(const void* record, int dtype, const void** tau, const void** sigma, const void** theta, const int** stop);
 int prost_hip_pdhg_rule_begin_f32(void* record, const prost_hip_pdhg_rule_opts* opts, const prost_hip_fused_desc* desc, double tau, double sigma, double theta,
                                   double arg_alpha, int arb_l, int arb_u, int stop_on_convergence, prost_hip_pdhg_rule_state* mirror, void* stream);
 int prost_hip_pdhg_rule_begin_f64(void* record, const prost_hip_pdhg_rule_opts* opts, const prost_hip_fused_desc* desc, double tau, double sigma, double theta,
@@ -450,7 +455,8 @@ int prost_hip_pdhg_rule_apply_f32(void* record, const double* sums4, unsigned lo
 int prost_hip_pdhg_rule_apply_f64(void* record, const double* sums4, unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
 /* The residual sums of an iteration whose prox launches added them up themselves (prost_hip_prox_elem_arg with an operator source and
  * res_ws): out4 = {primal: sum diff^2, sum z_hat^2 ; dual: sum diff^2, sum w_hat^2} (backend_pdhg.cu:392-431) from n_primal / n_dual slots of 4
- * doubles; record != NULL and apply_rule: the step-size rule and the stopping test follow in the same launch (prost_hip_pdhg_rule_apply). */
+ * doubles (both arrays on 32-byte boundaries); record != NULL and apply_rule: the step-size rule and the stopping test follow in the same
+ * launch (prost_hip_pdhg_rule_apply). */
 int prost_hip_pdhg_fold_sums_f32(double* out4, const double* ws_primal, unsigned n_primal, const double* ws_dual, unsigned n_dual, void* record, int apply_rule,
                                  unsigned long long iteration, prost_hip_pdhg_rule_state* mirror, void* stream);
 int prost_hip_pdhg_fold_sums_f64(double* out4, const double* ws_primal, unsigned n_primal, const double* ws_dual, unsigned n_dual, void* record, int apply_rule,

@@ -274,12 +274,17 @@ void BackendPDHG<T>::Initialize() {
   // the same on the GENERIC path (any operator): the proxes form their arguments on the fly with kernels that read tau, sigma, theta
   // from the record (elem operations of any function and coefficients, their Moreau wraps, the identity), the residual reductions
   // as well, and a one-thread kernel applies the rule behind them
-  dev_rules_generic_ = !fused_ && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && arg_fused_g_ && arg_fused_f_;
-  for (auto& p : prox_g_) dev_rules_generic_ = dev_rules_generic_ && p->takes_step_record();
-  for (auto& p : prox_fstar_) dev_rules_generic_ = dev_rules_generic_ && p->takes_step_record();
+  // (round 5: a prox that needs its argument materialised -- a plugin's ProxElemOperation<T, OP> -- takes part when its kernel can read the
+  // step size from the device, Prox::takes_step_view; the argument pass in front of it reads the record like the fused ones)
+  dev_rules_generic_ = !fused_ && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule;
+  for (auto& p : prox_g_) dev_rules_generic_ = dev_rules_generic_ && (p->supports_arg_source() ? p->takes_step_record() : p->takes_step_view());
+  for (auto& p : prox_fstar_) dev_rules_generic_ = dev_rules_generic_ && (p->supports_arg_source() ? p->takes_step_record() : p->takes_step_view());
   in_device_batch_ = false; dev_batches_ = 0;
   if (dev_rules_ || dev_rules_generic_) {
     CheckHip(prost_hip_malloc(&rule_rec_, prost_hip_pdhg_rule_record_bytes()), "malloc");
+    const void *vt = nullptr, *vs = nullptr;
+    CheckHip(prost_hip_pdhg_record_view(rule_rec_, dtype_id<T>(), &vt, &vs, nullptr, &view_stop_), "pdhg_record_view");
+    view_tau_ = static_cast<const T*>(vt); view_sigma_ = static_cast<const T*>(vs);
     CheckHip(prost_hip_host_alloc((void**)&rule_mirror_, sizeof(prost_hip_pdhg_rule_state)), "host_alloc");
     // (the rule kernels write their scalars to a DEVICE copy, fetched once per batch: ~20 stores over PCIe per residual iteration
     // cost the one-thread epilogue ~4 us -- a fifth of an iteration at 1024^2)
@@ -854,6 +859,8 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   // When every prox of a list can form its argument on the fly (elem operations, their conjugates, the identity),
   // the argument pass of :317-331 / :349-364 is folded into the prox kernels: same expressions, one vector less
   // written and re-read per prox.
+  // (a list with both kinds -- in-tree operations next to a plugin's -- runs the argument pass once for the proxes that need it; inside a
+  // device batch those take the step size from the record through a StepView)
   if (arg_fused_g_) {
     x_.swap(x_prev_);
     const typename Prox<T>::ArgSource src{PROST_ARG_PDHG_PRIMAL, {x_prev_.data(), Tr.data(), kty_.data(), nullptr}, {tau_, (T)0}};
@@ -861,7 +868,12 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   } else {
     CheckHip(Api<T>::pdhg_primal_arg(temp_.data(), x_.data(), Tr.data(), kty_.data(), (double)tau_, n, s), "primal_arg");   // :317-331
     x_.swap(x_prev_);
-    for (auto& p : prox_g_) p->Eval(x_, temp_, Tr, tau_);
+    const typename Prox<T>::ArgSource src{PROST_ARG_PDHG_PRIMAL, {x_prev_.data(), Tr.data(), kty_.data(), nullptr}, {tau_, (T)0}};
+    for (auto& p : prox_g_) {
+      if (in_device_batch_ && p->supports_arg_source()) p->EvalFromSource(x_, src, Tr, tau_);
+      else if (in_device_batch_) p->EvalWithStepView(x_, temp_, Tr, typename Prox<T>::StepView{view_tau_, view_stop_});
+      else p->Eval(x_, temp_, Tr, tau_);
+    }
   }
   kx_.swap(kx_prev_);
   this->problem_->linop()->Eval(kx_, x_);
@@ -872,7 +884,12 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   } else {
     CheckHip(Api<T>::pdhg_dual_arg(temp_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "dual_arg");   // :349-364
     y_.swap(y_prev_);
-    for (auto& p : prox_fstar_) p->Eval(y_, temp_, Sl, sigma_);
+    const typename Prox<T>::ArgSource src{PROST_ARG_PDHG_DUAL, {y_prev_.data(), Sl.data(), kx_.data(), kx_prev_.data()}, {sigma_, theta_}};
+    for (auto& p : prox_fstar_) {
+      if (in_device_batch_ && p->supports_arg_source()) p->EvalFromSource(y_, src, Sl, sigma_);
+      else if (in_device_batch_) p->EvalWithStepView(y_, temp_, Sl, typename Prox<T>::StepView{view_sigma_, view_stop_});
+      else p->Eval(y_, temp_, Sl, sigma_);
+    }
   }
   if (res) {                                                                                                   // :392-431
     // both reductions in one launch, their folds -- and inside a device batch without a communicator the rule -- in a second

@@ -14,6 +14,11 @@ void Prox<T>::Eval(device_vector<T>& result, const device_vector<T>& arg, const 
             tau_diag.data() + index_, tau_diag.data() + index_ + size_, tau, invert_tau);
 }
 template <typename T>
+void Prox<T>::EvalWithStepView(device_vector<T>& result, const device_vector<T>& arg, const device_vector<T>& tau_diag, const StepView& view, bool invert_tau) {
+  EvalLocalStepView(result.data() + index_, result.data() + index_ + size_, arg.data() + index_, arg.data() + index_ + size_,
+                    tau_diag.data() + index_, tau_diag.data() + index_ + size_, view, invert_tau);
+}
+template <typename T>
 double Prox<T>::Eval(std::vector<T>& result, const std::vector<T>& arg, const std::vector<T>& tau_diag, T tau) {
   device_vector<T> d_arg; d_arg = arg;
   device_vector<T> d_tau; d_tau = tau_diag;

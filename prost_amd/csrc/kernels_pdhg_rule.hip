@@ -65,11 +65,24 @@ static int rule_apply(void* record, const double* sums4, unsigned long long iter
   PH_LAUNCH_END("pdhg rule kernel");
 }
 
+template <class T>
+static void record_view(const void* record, const void** tau, const void** sigma, const void** theta, const int** stop) {
+  const PdhgRecord<T>* r = static_cast<const PdhgRecord<T>*>(record);       // (device address: only offsets are formed)
+  if (tau) *tau = &r->p.tau;
+  if (sigma) *sigma = &r->p.sigma;
+  if (theta) *theta = &r->p.theta;
+  if (stop) *stop = &r->stop;
+}
 }  // namespace prost_hip
 
 using namespace prost_hip;
 
 extern "C" {
+int prost_hip_pdhg_record_view(const void* record, int dtype, const void** tau, const void** sigma, const void** theta, const int** stop) {
+  if (!record || (dtype != 0 && dtype != 1)) { set_error("pdhg_record_view: null record or unknown dtype"); return 1; }
+  if (dtype == 0) record_view<float>(record, tau, sigma, theta, stop); else record_view<double>(record, tau, sigma, theta, stop);
+  return 0;
+}
 size_t prost_hip_pdhg_rule_record_bytes(void) { return sizeof(PdhgRecord<double>) > sizeof(PdhgRecord<float>) ? sizeof(PdhgRecord<double>) : sizeof(PdhgRecord<float>); }
 int prost_hip_pdhg_rule_begin_f32(void* record, const prost_hip_pdhg_rule_opts* o, const prost_hip_fused_desc* d, double tau, double sigma, double theta, double arg_alpha,
                                   int arb_l, int arb_u, int stop_on_convergence, prost_hip_pdhg_rule_state* mirror, void* stream) {

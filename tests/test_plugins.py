@@ -442,3 +442,47 @@ def test_pdhg_solve_with_user_written_elem_operations_matches_the_oracle(hip, pl
         assert np.array_equal(np.asarray(got["x"]), np.asarray(exp["x"]))
     finally:
         prost.set_precision("double")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+@pytest.mark.parametrize("step,residual_iter", [("boyd", 1), ("boyd", 3), ("goldstein", 1)])
+def test_user_written_elem_operations_take_their_step_from_the_device(hip, plugin, prec, dtype, step, residual_iter):
+    """round 5 (Prox::StepView): the reference's DEFAULT options (boyd, residual_iter 1) on a problem whose proxes are functor operations
+    compiled out of tree -- next to in-tree ones in the same lists -- run the step-size rule and the stopping test on the device: the
+    argument passes and the plugin's kernels read tau / sigma from the record, no host wait per iteration.  Iterates and step sizes ==
+    the host rule's == the oracle's, bit for bit; a complete solve stops at the same iteration."""
+    prost.set_gpu(0)
+    prost.set_precision(prec)
+    try:
+        nx, ny = 20, 34
+        f = synthetic.rof_image(nx, ny, 1, 3)
+        prob = _huber_tv_problem(nx, ny, f, 2.0, 0.05, True, False)
+        ref = _huber_tv_problem(nx, ny, f, 2.0, 0.05, False, False)
+        ref.finalize()
+        o = prost.options(max_iters=80, num_cback_calls=0, verbose=False)
+        for k in (5, 9, 41):          # (budgets below 3 iterations keep the host loop)
+            st = {}
+            for dev in (True, False):
+                b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+                b[1]["allow_device_rules"] = dev
+                s = prost.Solver(prob, b, o)
+                s.iterate(k)
+                st[dev] = s.state()
+                s.destroy()
+            assert st[True]["device_rule_batches"] > 0 and st[False]["device_rule_batches"] == 0, (st[True]["device_rule_batches"], st[False]["device_rule_batches"])
+            orc = oracle.Solver(ref.data, ref.nrows, ref.ncols, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter), o, dtype)
+            orc.initialize()
+            orc.iterate(k)
+            ost, osc = orc.state(), orc.scalars()
+            for dev in (True, False):
+                for v in "xyzw":
+                    assert np.array_equal(st[dev][v], ost[v]), (k, dev, v, float(np.abs(st[dev][v] - ost[v]).max()))
+                assert st[dev]["tau"] == osc["tau"] and st[dev]["sigma"] == osc["sigma"], (k, dev)
+        o2 = prost.options(max_iters=2000, num_cback_calls=0, verbose=False, tol_rel_primal=1e-3, tol_rel_dual=1e-3, tol_abs_primal=1e-3, tol_abs_dual=1e-3)
+        b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter)
+        got, exp = prost.solve(prob, b, o2), oracle.solve(ref, b, o2, dtype)
+        assert got["result"] == exp["result"] and got["iters"] == exp["iters"]
+        assert np.array_equal(np.asarray(got["x"]), np.asarray(exp["x"]))
+    finally:
+        prost.set_precision("double")

@@ -32,7 +32,7 @@ import prost_amd as prost
 from prost_amd import synthetic
 
 HEIGHTS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 30, 62, 63, 64, 66, 124, 126, 128, 130, 247, 248, 249, 250, 252, 253, 256, 260, 496, 500, 504, 508, 510, 1000, 1028]
-NOT_ORACLE = ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_single_kernel", "allow_device_rules")
+NOT_ORACLE = ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_single_kernel", "allow_device_rules", "allow_op_fusion", "pixel_rounds")
 
 
 def draw(rng):
@@ -508,6 +508,7 @@ def main():
     if args.mode == "sharded":
         return run_sharded(args, rng)
     t0, done, fails, ties, setups, skipped, inexact, diverged, sensitive, solves, paths = time.time(), 0, 0, 0, 0, 0, 0, 0, 0, 0, {}
+    admm_exact = 0
     for i in range(args.cases):
         if time.time() - t0 > args.budget_s:
             break
@@ -519,6 +520,16 @@ def main():
             b = prost.backend.admm(rho0=float(np.random.default_rng(c["seed"]).choice([0.5, 1.0, 4.0])), residual_iter=c["residual_iter"])
         else:
             b = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=c["scale_steps"])
+        # product-only switches (round 5), drawn per case: the operator inside the prox launches (0 never / 1 stencil operators / 2 any CSR or
+        # gradient operator), the step rule on the device or on the host, ADMM's two-launch CG rounds
+        r5 = np.random.default_rng(c["seed"] + 505)
+        if c.get("backend") == "admm":
+            b[1]["pixel_rounds"] = bool(r5.random() < 0.7)
+        else:
+            b[1]["allow_op_fusion"] = int(r5.choice([0, 1, 2, 2]))
+            b[1]["allow_device_rules"] = bool(r5.random() < 0.7)
+        product_only = {k: b[1][k] for k in ("pixel_rounds", "allow_op_fusion", "allow_device_rules") if k in b[1]}
+        c["product_only"] = product_only
         try:
             prob = build(c) if args.mode == "fused" else build_generic(c)
             if "solve" in c and (c.get("long_rows") or "transcendental" in c.get("_desc", ())):
@@ -528,6 +539,7 @@ def main():
                     c["step"] = "alg2" if c["seed"] % 2 else "alg1"       # (exact comparison of a whole solve: no residual-driven steps, no norm estimate)
                     c["scale_steps"] = False
                     b = prost.backend.pdhg(stepsize=c["step"], residual_iter=c["residual_iter"], alg2_gamma=c["gamma"], scale_steps_operator=False)
+                    b[1].update(product_only)
                 d, path = compare_solve(c, prob, b, dtype)
                 paths[path] = paths.get(path, 0) + 1
                 if d == "skip":
@@ -552,6 +564,7 @@ def main():
                 # that tolerance times the conditioning of the random operator, not to 1e-9 as on the TV-L1 problem of the tests)
                 tol = 2e-4 if dtype == np.float32 else 2e-6
                 ok = close(st, ost, dtype, tol)
+                admm_exact += 1 if (all(np.array_equal(st[v], ost[v]) for v in "xyzw") and st["cg_iterations"] == ost["cg_iterations"]) else 0
                 if not ok and st["cg_iterations"] != ost["cg_iterations"] and close(st, ost, dtype, 10 * tol):
                     ties += 1
                     ok = True
@@ -608,8 +621,8 @@ def main():
             fails += 1
             print("FAIL %s: %s%s" % ({k: v for k, v in c.items() if not k.startswith("_")}, d, "  [" + " ; ".join(c["_desc"]) + "]" if c.get("_desc") else ""), flush=True)
     prost.set_precision("double")
-    print("fuzz_parity: %d cases (%d of them complete solves with callbacks) in %.0f s, %d failures, %d threshold ties, %d with rescaled initial steps (setup; %d of them not within the tolerance afterwards), %d divergent compositions skipped, %d with long sparse rows or a transcendental projection compared with a tolerance, %d ADMM cases as sensitive in the oracle itself, paths %s"
-          % (done, solves, time.time() - t0, fails, ties, setups, diverged, skipped, inexact, sensitive, paths))
+    print("fuzz_parity: %d cases (%d of them complete solves with callbacks) in %.0f s, %d failures, %d threshold ties, %d with rescaled initial steps (setup; %d of them not within the tolerance afterwards), %d divergent compositions skipped, %d with long sparse rows or a transcendental projection compared with a tolerance, %d ADMM cases as sensitive in the oracle itself, %d ADMM cases bit-identical to the oracle (iterates and CG iteration counts), paths %s"
+          % (done, solves, time.time() - t0, fails, ties, setups, diverged, skipped, inexact, sensitive, admm_exact, paths))
     return 1 if fails else 0
 
 
