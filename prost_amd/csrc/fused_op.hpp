@@ -116,9 +116,7 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
   for (int q = 0; q < NR; q++)
 #pragma unroll
     for (int j = 0; j < VEC; j++) sum[q][j] = 0;
-  bool same = true;
-#pragma unroll
-  for (int j = 1; j < VEC; j++) same = same && id[j] == id[0];
+  // (nothing below may look at id[] before the speculative operand loads are out: the first use is where the wavefront waits for the numbers)
   if (VEC > 1 && dom_n > 0 && len >= (size_t)VEC) {
     // the operands of the DOMINANT pattern are requested at once (its entries sit in the block table: scalar loads), in flight together
     // with the pattern numbers above -- one memory round trip instead of four dependent ones (numbers -> table offsets -> entries -> operands)
@@ -126,12 +124,14 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
     const long hi = (long)len - VEC;
 #pragma unroll
     for (int u = 0; u < kB; u++) {
-      long a = (long)r0 + (long)dom_rel[u < dom_n ? u : dom_n - 1];
+      long a = (long)r0 + (long)dom_rel[u];            // (kB <= PROST_HIP_OP_DOM_MAX; slots past dom_n hold 0: a valid address, value unused)
       a = a < 0 ? 0 : (a > hi ? hi : a);
 #pragma unroll
       for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + a);
     }
-    const bool dom = same && id[0] == (unsigned)dom_id;
+    bool dom = true;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) dom = dom && id[j] == (unsigned)dom_id;
     if (__builtin_amdgcn_ballot_w64(!dom) == 0) {
 #pragma unroll
       for (int u = 0; u < kB; u++) {
@@ -229,6 +229,22 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
 // kv[0..VEC) = (K rhs)_(i .. i+VEC).  VEC > 1: i, every block's row / col / nrows and every gradient block's ny and plane
 // size are multiples of VEC (host-checked), so the VEC rows lie in the same blocks, the same component plane and image column.
 // w0 = the i of lane 0 (wave-uniform); VEC > 1 callers guarantee that all 64 lanes are active.
+// The header of a block as ONE batch of scalar loads: the fields are requested together and pinned in SGPRs before the first branch looks
+// at one of them.  Left to itself the compiler sinks every load to its first use behind the branch in front of it -- load, wait, compare,
+// branch, load, wait ... six or seven scalar round trips per block and wavefront before the first operand is requested (the prox launches
+// of the generic path spent two thirds of a wavefront's life in s_waitcnt lgkmcnt(0)).
+struct OpHead { int kind; unsigned long long row, col, nrows, ncols, nx, ny, L; const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval; int dom_id, dom_n; };
+template <bool ADJ>
+__device__ __forceinline__ OpHead op_head(const PROST_CONSTANT OpBlockDev& B) {
+  OpHead h;
+  h.kind = B.kind; h.row = B.row; h.col = B.col; h.nrows = B.nrows; h.ncols = B.ncols; h.nx = B.nx; h.ny = B.ny; h.L = B.L;
+  h.ids = ADJ ? B.ids_t : B.ids; h.pptr = ADJ ? B.pptr_t : B.pptr; h.rel = ADJ ? B.rel_t : B.rel; h.pval = ADJ ? B.pval_t : B.pval;
+  h.dom_id = ADJ ? B.dom_id_t : B.dom_id; h.dom_n = ADJ ? B.dom_n_t : B.dom_n;
+  asm volatile("" : : "s"(h.kind), "s"(h.row), "s"(h.col), "s"(h.nrows), "s"(h.ncols), "s"(h.nx), "s"(h.ny), "s"(h.L), "s"(h.ids), "s"(h.pptr), "s"(h.rel),
+               "s"(h.pval), "s"(h.dom_id), "s"(h.dom_n));
+  return h;
+}
+
 template <class T, int VEC, int NR>
 __device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& op, size_t i, size_t w0, const T* const (&t)[NR], T (&kv)[NR][VEC], bool lanes_in_step = true) {
 #pragma unroll
@@ -237,31 +253,32 @@ __device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& o
     for (int j = 0; j < VEC; j++) kv[q][j] = 0;
   for (int b = 0; b < op.nblocks; b++) {
     const PROST_CONSTANT OpBlockDev& B = op.b[b];
-    if (i < B.row || i >= B.row + B.nrows) continue;
-    const size_t r = i - B.row;
-    if (B.kind == PROST_OP_CSR) {
-      const bool whole = VEC > 1 && lanes_in_step && w0 >= B.row && w0 + (size_t)kWave * VEC <= B.row + B.nrows;
+    const OpHead H = op_head<false>(B);
+    if ((i < H.row) | (i >= H.row + H.nrows)) continue;
+    const size_t r = i - H.row;
+    if (H.kind == PROST_OP_CSR) {
+      const bool whole = VEC > 1 && lanes_in_step && w0 >= H.row && w0 + (size_t)kWave * VEC <= H.row + H.nrows;
       T sum[NR][VEC];
-      if (B.ids) {
+      if (H.ids) {
         const T* rhs[NR];
 #pragma unroll
-        for (int q = 0; q < NR; q++) rhs[q] = t[q] + B.col;
-        pattern_rows<T, VEC, NR>(B.ids, as_constant(B.pptr), as_constant(B.rel), as_constant_of<T>(B.pval), rhs, r, sum, B.dom_id, B.dom_n, B.dom_rel, B.dom_val, (size_t)B.ncols);
+        for (int q = 0; q < NR; q++) rhs[q] = t[q] + H.col;
+        pattern_rows<T, VEC, NR>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rhs, r, sum, H.dom_id, H.dom_n, B.dom_rel, B.dom_val, (size_t)H.ncols);
       } else {
 #pragma unroll
-        for (int q = 0; q < NR; q++) csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, t[q] + B.col, r, w0 - B.row, whole, sum[q]);
+        for (int q = 0; q < NR; q++) csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, t[q] + H.col, r, w0 - H.row, whole, sum[q]);
       }
 #pragma unroll
       for (int q = 0; q < NR; q++)
 #pragma unroll
         for (int j = 0; j < VEC; j++) kv[q][j] = kv[q][j] + sum[q][j];
     } else {
-      const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, N = slice * (unsigned)B.L;
+      const unsigned nx = (unsigned)H.nx, ny = (unsigned)H.ny, slice = nx * ny, N = slice * (unsigned)H.L;
       const unsigned r32 = (unsigned)r;
       const unsigned c = r32 / N, idx = r32 - c * N;
 #pragma unroll
       for (int q = 0; q < NR; q++) {
-        const T* rhs = t[q] + B.col;
+        const T* rhs = t[q] + H.col;
         T cur[VEC], g[VEC];
         ldv<T, VEC>(rhs + idx, cur);
         if (c == 0) {
@@ -285,9 +302,9 @@ __device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& o
           T up[VEC];
 #pragma unroll
           for (int j = 0; j < VEC; j++) up[j] = 0;
-          if (l < (unsigned)B.L - 1) ldv<T, VEC>(rhs + idx + slice, up);
+          if (l < (unsigned)H.L - 1) ldv<T, VEC>(rhs + idx + slice, up);
 #pragma unroll
-          for (int j = 0; j < VEC; j++) g[j] = l < (unsigned)B.L - 1 ? up[j] - cur[j] : -cur[j];      // Dirichlet (block_gradient3d.cu:73-76)
+          for (int j = 0; j < VEC; j++) g[j] = l < (unsigned)H.L - 1 ? up[j] - cur[j] : -cur[j];      // Dirichlet (block_gradient3d.cu:73-76)
         }
 #pragma unroll
         for (int j = 0; j < VEC; j++) kv[q][j] = kv[q][j] + g[j];
@@ -308,21 +325,22 @@ template <class T, int VEC>
 __device__ __forceinline__ void op_adj_cols(const PROST_CONSTANT FusedOpDev& op, size_t jg, size_t w0, const T* __restrict__ t, T (&v)[VEC], bool lanes_in_step = true) {
   for (int b = 0; b < op.nblocks; b++) {
     const PROST_CONSTANT OpBlockDev& B = op.b[b];
-    if (jg < B.col || jg >= B.col + B.ncols) continue;
-    const size_t cidx = jg - B.col;
-    const T* rhs = t + B.row;
-    if (B.kind == PROST_OP_CSR) {
-      const bool whole = VEC > 1 && lanes_in_step && w0 >= B.col && w0 + (size_t)kWave * VEC <= B.col + B.ncols;
+    const OpHead H = op_head<true>(B);
+    if ((jg < H.col) | (jg >= H.col + H.ncols)) continue;
+    const size_t cidx = jg - H.col;
+    const T* rhs = t + H.row;
+    if (H.kind == PROST_OP_CSR) {
+      const bool whole = VEC > 1 && lanes_in_step && w0 >= H.col && w0 + (size_t)kWave * VEC <= H.col + H.ncols;
       T sum[1][VEC];
-      if (B.ids_t) {
+      if (H.ids) {
         const T* rr[1] = {rhs};
-        pattern_rows<T, VEC, 1>(B.ids_t, as_constant(B.pptr_t), as_constant(B.rel_t), as_constant_of<T>(B.pval_t), rr, cidx, sum, B.dom_id_t, B.dom_n_t, B.dom_rel_t, B.dom_val_t, (size_t)B.nrows);
-      } else csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - B.col, whole, sum[0]);
+        pattern_rows<T, VEC, 1>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rr, cidx, sum, H.dom_id, H.dom_n, B.dom_rel_t, B.dom_val_t, (size_t)H.nrows);
+      } else csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - H.col, whole, sum[0]);
 #pragma unroll
       for (int j = 0; j < VEC; j++) v[j] = v[j] + sum[0][j];
     } else {
-      const unsigned nx = (unsigned)B.nx, ny = (unsigned)B.ny, slice = nx * ny, idx = (unsigned)cidx;
-      const size_t N = (size_t)slice * B.L;
+      const unsigned nx = (unsigned)H.nx, ny = (unsigned)H.ny, slice = nx * ny, idx = (unsigned)cidx;
+      const size_t N = (size_t)slice * H.L;
       const unsigned y = idx % ny, x = (idx / ny) % nx;
       T px[VEC], pxm[VEC], py[VEC];
       ldv<T, VEC>(rhs + idx, px);
@@ -333,7 +351,7 @@ __device__ __forceinline__ void op_adj_cols(const PROST_CONSTANT FusedOpDev& op,
       const T above = y > 0 ? rhs[N + idx - 1] : (T)0;
       T pl[VEC], plm[VEC];
       unsigned l = 0;
-      if (B.kind == PROST_OP_GRAD3D) {
+      if (H.kind == PROST_OP_GRAD3D) {
         l = idx / slice;
         ldv<T, VEC>(rhs + 2 * N + idx, pl);
 #pragma unroll
@@ -348,7 +366,7 @@ __device__ __forceinline__ void op_adj_cols(const PROST_CONSTANT FusedOpDev& op,
         if (x < nx - 1) divx = px[j]; else divx = 0;
         if (x > 0) divx -= pxm[j];
         T sdiv;
-        if (B.kind == PROST_OP_GRAD3D) {
+        if (H.kind == PROST_OP_GRAD3D) {
           T divl = pl[j];
           if (l > 0) divl -= plm[j];
           sdiv = divx + divy + divl;
@@ -399,7 +417,10 @@ inline FusedOpDev make_op(const prost_hip_fused_op* op) {
     D.ids = B.ids; D.pptr = B.pptr; D.rel = B.rel; D.pval = B.pval; D.ids_t = B.ids_t; D.pptr_t = B.pptr_t; D.rel_t = B.rel_t; D.pval_t = B.pval_t;
     D.dom_id = B.dom_id; D.dom_n = B.ids && B.dom_n > 0 && B.dom_n <= PROST_HIP_OP_DOM_MAX ? B.dom_n : 0;
     D.dom_id_t = B.dom_id_t; D.dom_n_t = B.ids_t && B.dom_n_t > 0 && B.dom_n_t <= PROST_HIP_OP_DOM_MAX ? B.dom_n_t : 0;
-    for (int k = 0; k < PROST_HIP_OP_DOM_MAX; k++) { D.dom_rel[k] = B.dom_rel[k]; D.dom_val[k] = B.dom_val[k]; D.dom_rel_t[k] = B.dom_rel_t[k]; D.dom_val_t[k] = B.dom_val_t[k]; }
+    for (int k = 0; k < PROST_HIP_OP_DOM_MAX; k++) {        // (slots past the pattern's length: 0 -- the kernels request them unconditionally)
+      D.dom_rel[k] = k < D.dom_n ? B.dom_rel[k] : 0; D.dom_val[k] = k < D.dom_n ? B.dom_val[k] : 0.0;
+      D.dom_rel_t[k] = k < D.dom_n_t ? B.dom_rel_t[k] : 0; D.dom_val_t[k] = k < D.dom_n_t ? B.dom_val_t[k] : 0.0;
+    }
   }
   return o;
 }

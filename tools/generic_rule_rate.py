@@ -20,6 +20,11 @@ def problem(nx, ny, seed=3):
     k1 = sp.diags([np.ones(ny - 1), np.ones(ny), np.ones(ny - 1)], [-1, 0, 1]) / 3.0
     k2 = sp.diags([np.ones(nx - 1), np.ones(nx), np.ones(nx - 1)], [-1, 0, 1]) / 3.0
     B = sp.kron(k2, k1).tocsr()                                       # 3 x 3 box blur (example_deblurring.m:12-22 uses a motion kernel)
+    shape = os.environ.get("PROST_RATE_BLUR", "xy")                   # experiments: "x" = 3 taps across columns (offsets -ny, 0, ny: 16-byte aligned operands), "y" = 3 taps along a column
+    if shape == "x":
+        B = sp.kron(k2, sp.identity(ny)).tocsr()
+    elif shape == "y":
+        B = sp.kron(sp.identity(nx), k1).tocsr()
     f = synthetic.rof_image(nx, ny, 1, seed=seed)
     fb = B @ f + 0.02 * np.random.default_rng(seed).standard_normal(n)
     u, v, g = prost.variable(n), prost.variable(n), prost.variable(2 * n)
