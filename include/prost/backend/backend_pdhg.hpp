@@ -29,8 +29,8 @@ class BackendPDHG : public Backend<T> {
     bool allow_arg_fusion;     ///< MI355X addition (generic path): proxes form their argument on the fly, no argument pass
     int allow_op_fusion;       ///< MI355X addition (generic path, round 5): the proxes also form the operator products K^T y / K x on the fly and add up
                                ///< the residual terms themselves (operators of sparse / gradient blocks): K x, K^T y never written, 4 launches per iteration
-                               ///< instead of 9, bit-identical.  0: never; 1 (default): where every sparse block is a STENCIL written out row by row (row
-                               ///< patterns with a dominant pattern for K and K^T -- example_deblurring.m, example_multilabel_*.m) or a gradient block;
+                               ///< instead of 9, bit-identical.  0: never; 1 (default): problems of >= 2^19 elements (x and y) where every sparse block is a STENCIL written out row by row (row
+                               ///< patterns for K and K^T -- example_deblurring.m, example_multilabel_*.m) or a gradient block;
                                ///< 2: wherever the kernels support the operator (random CSR blocks walk their rows lane by lane: not measured faster)
     bool allow_speculation;    ///< MI355X addition: the next pair launch is enqueued BEFORE the host waits for the residual sums (alg1 / alg2)
     bool allow_device_rules;   ///< MI355X addition: goldstein / boyd and the stopping test evaluated on the device, one host wait per BATCH of iterations

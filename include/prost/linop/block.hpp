@@ -34,9 +34,6 @@ struct BlockDesc {
   // device -- ids / ids_t non-null then, and val .. ind / val_t .. ind_t null (each direction on its own)
   const uint16_t* ids = nullptr; const int32_t* pptr = nullptr; const int32_t* rel = nullptr; const void* pval = nullptr;
   const uint16_t* ids_t = nullptr; const int32_t* pptr_t = nullptr; const int32_t* rel_t = nullptr; const void* pval_t = nullptr;
-  // the pattern most rows have (the interior of a stencil), as host copies of its table entries; dom_n = 0: unknown / longer than 12 entries
-  int dom_id = -1, dom_n = 0; int32_t dom_rel[12] = {0}; double dom_val[12] = {0};
-  int dom_id_t = -1, dom_n_t = 0; int32_t dom_rel_t[12] = {0}; double dom_val_t[12] = {0};
 };
 
 template <typename T>

@@ -90,11 +90,9 @@ class BlockSparse : public Block<T> {
     if (!pat_.on && val_.size() != nnz_) return false;          // before Initialize()
     if (!pat_t_.on && val_t_.size() != nnz_) return false;
     d.kind = BlockDesc::kSparse; d.nnz = nnz_;
-    if (pat_.on) { d.ids = pat_.ids.data(); d.pptr = pat_.pptr.data(); d.rel = pat_.rel.data(); d.pval = pat_.val.data();
-                   d.dom_id = pat_.dom_id; d.dom_n = pat_.dom_n; for (int k = 0; k < 12; k++) { d.dom_rel[k] = pat_.dom_rel[k]; d.dom_val[k] = pat_.dom_val[k]; } }
+    if (pat_.on) { d.ids = pat_.ids.data(); d.pptr = pat_.pptr.data(); d.rel = pat_.rel.data(); d.pval = pat_.val.data(); }
     else { d.val = val_.data(); d.ptr = ptr_.data(); d.ind = ind_.data(); }
-    if (pat_t_.on) { d.ids_t = pat_t_.ids.data(); d.pptr_t = pat_t_.pptr.data(); d.rel_t = pat_t_.rel.data(); d.pval_t = pat_t_.val.data();
-                     d.dom_id_t = pat_t_.dom_id; d.dom_n_t = pat_t_.dom_n; for (int k = 0; k < 12; k++) { d.dom_rel_t[k] = pat_t_.dom_rel[k]; d.dom_val_t[k] = pat_t_.dom_val[k]; } }
+    if (pat_t_.on) { d.ids_t = pat_t_.ids.data(); d.pptr_t = pat_t_.pptr.data(); d.rel_t = pat_t_.rel.data(); d.pval_t = pat_t_.val.data(); }
     else { d.val_t = val_t_.data(); d.ptr_t = ptr_t_.data(); d.ind_t = ind_t_.data(); }
     d.pointwise_planes = pointwise_planes_;
     return true;
@@ -121,7 +119,6 @@ class BlockSparse : public Block<T> {
     device_vector<uint16_t> ids;              ///< pattern number of every row
     device_vector<int32_t> pptr, rel;         ///< entries pptr[id] .. pptr[id + 1] - 1 of the table: column - row ...
     device_vector<T> val;                     ///< ... and value
-    int dom_id = -1, dom_n = 0; int32_t dom_rel[12] = {0}; double dom_val[12] = {0};      ///< the pattern most rows have (host copy of its entries)
   };
   RowPatterns pat_, pat_t_;
 };

@@ -702,13 +702,7 @@ typedef struct prost_hip_op_block {
    * (column - row, value) sequences) instead of CSR arrays, for K and / or K^T; ids / ids_t NULL: the CSR arrays above */
   const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval;
   const uint16_t* ids_t; const int32_t* pptr_t; const int32_t* rel_t; const void* pval_t;
-  /* the DOMINANT pattern of K / K^T (the one most rows have: the interior of a stencil), copied out of the table -- dom_n entries
-   * (0: none given, or longer than PROST_HIP_OP_DOM_MAX): a kernel that applies the block inside another kernel requests the operands
-   * of this pattern while the pattern numbers of its rows are still on their way and keeps them if the numbers confirm it */
-  int dom_id, dom_n; int32_t dom_rel[12]; double dom_val[12];
-  int dom_id_t, dom_n_t; int32_t dom_rel_t[12]; double dom_val_t[12];
 } prost_hip_op_block;
-#define PROST_HIP_OP_DOM_MAX 12
 #define PROST_HIP_OP_MAX_BLOCKS 4
 typedef struct prost_hip_fused_op {
   int nblocks;

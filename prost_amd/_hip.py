@@ -47,9 +47,7 @@ class OpBlock(C.Structure):
                 ("nx", C.c_uint64), ("ny", C.c_uint64), ("L", C.c_uint64),
                 ("val", C.c_void_p), ("ptr", C.c_void_p), ("ind", C.c_void_p), ("val_t", C.c_void_p), ("ptr_t", C.c_void_p), ("ind_t", C.c_void_p),
                 ("ids", C.c_void_p), ("pptr", C.c_void_p), ("rel", C.c_void_p), ("pval", C.c_void_p),          # ABI 7: row patterns of K ...
-                ("ids_t", C.c_void_p), ("pptr_t", C.c_void_p), ("rel_t", C.c_void_p), ("pval_t", C.c_void_p),    # ... and of K^T (NULL: CSR)
-                ("dom_id", C.c_int), ("dom_n", C.c_int), ("dom_rel", C.c_int32 * 12), ("dom_val", C.c_double * 12),           # the dominant pattern (dom_n = 0: none)
-                ("dom_id_t", C.c_int), ("dom_n_t", C.c_int), ("dom_rel_t", C.c_int32 * 12), ("dom_val_t", C.c_double * 12)]
+                ("ids_t", C.c_void_p), ("pptr_t", C.c_void_p), ("rel_t", C.c_void_p), ("pval_t", C.c_void_p)]    # ... and of K^T (NULL: CSR)
 
 
 class FusedOp(C.Structure):

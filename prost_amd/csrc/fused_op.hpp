@@ -17,9 +17,6 @@ struct OpBlockDev {
   // (entries pptr[id] .. pptr[id + 1] - 1: column - row in rel, value in pval); ids / ids_t null: the CSR arrays above
   const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval;
   const uint16_t* ids_t; const int32_t* pptr_t; const int32_t* rel_t; const void* pval_t;
-  // the dominant pattern of K / K^T, copied out of the table (prost_hip_op_block): its operands are requested before the pattern numbers arrive
-  int dom_id, dom_n; int32_t dom_rel[PROST_HIP_OP_DOM_MAX]; double dom_val[PROST_HIP_OP_DOM_MAX];
-  int dom_id_t, dom_n_t; int32_t dom_rel_t[PROST_HIP_OP_DOM_MAX]; double dom_val_t[PROST_HIP_OP_DOM_MAX];
 };
 struct FusedOpDev { int nblocks; OpBlockDev b[PROST_HIP_OP_MAX_BLOCKS]; };
 
@@ -94,14 +91,9 @@ __device__ __forceinline__ void csr_contrib(const T* __restrict__ val, const int
 // of VEC consecutive operands per lane (element-aligned 16-byte accesses, which gfx950 serves); a wavefront on the seams of a
 // stencil takes one pass per pattern it holds.
 template <class T, int VEC> struct OpPack { typedef T V __attribute__((ext_vector_type(VEC), aligned(sizeof(T)))); };
-// `len`: number of operand elements behind rhs (the speculative loads of the dominant pattern are clamped into [0, len - VEC]: rows at
-// the seams of a stencil have other patterns, their speculative values are dropped)
-// NR right-hand sides at once (K x and K x_prev of the dual step): one walk over the pattern numbers and the table, the operand loads of
-// all of them in flight together.
 template <class T, int VEC, int NR>
 __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, const PROST_CONSTANT int32_t* __restrict__ pptr, const PROST_CONSTANT int32_t* __restrict__ rel,
-                                             const PROST_CONSTANT T* __restrict__ pval, const T* const (&rhs)[NR], size_t r0, T (&sum)[NR][VEC],
-                                             int dom_id = -1, int dom_n = 0, const PROST_CONSTANT int32_t* dom_rel = nullptr, const PROST_CONSTANT double* dom_val = nullptr, size_t len = 0) {
+                                             const PROST_CONSTANT T* __restrict__ pval, const T* const (&rhs)[NR], size_t r0, T (&sum)[NR][VEC]) {
   typedef typename OpPack<T, VEC>::V PV;
   constexpr int kB = NR == 1 ? 6 : 4;                              // entries per batch: kB * NR operand loads of VEC elements in flight
   unsigned id[VEC];
@@ -116,55 +108,9 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
   for (int q = 0; q < NR; q++)
 #pragma unroll
     for (int j = 0; j < VEC; j++) sum[q][j] = 0;
-  // (nothing below may look at id[] before the speculative operand loads are out: the first use is where the wavefront waits for the numbers)
-  if (VEC > 1 && dom_n > 0 && len >= (size_t)VEC) {
-    // the operands of the DOMINANT pattern are requested at once (its entries sit in the block table: scalar loads), in flight together
-    // with the pattern numbers above -- one memory round trip instead of four dependent ones (numbers -> table offsets -> entries -> operands)
-    PV x[NR][kB];
-    const long hi = (long)len - VEC;
-#pragma unroll
-    for (int u = 0; u < kB; u++) {
-      long a = (long)r0 + (long)dom_rel[u];            // (kB <= PROST_HIP_OP_DOM_MAX; slots past dom_n hold 0: a valid address, value unused)
-      a = a < 0 ? 0 : (a > hi ? hi : a);
-#pragma unroll
-      for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + a);
-    }
-    bool dom = true;
-#pragma unroll
-    for (int j = 0; j < VEC; j++) dom = dom && id[j] == (unsigned)dom_id;
-    if (__builtin_amdgcn_ballot_w64(!dom) == 0) {
-#pragma unroll
-      for (int u = 0; u < kB; u++) {
-        if (u < dom_n) {
-          const T v = (T)dom_val[u];
-#pragma unroll
-          for (int q = 0; q < NR; q++)
-#pragma unroll
-            for (int j = 0; j < VEC; j++) sum[q][j] += v * x[q][u][j];
-        }
-      }
-      for (int k0 = kB; k0 < dom_n; k0 += kB) {          // (interior rows: every address is in range)
-#pragma unroll
-        for (int u = 0; u < kB; u++)
-#pragma unroll
-          for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + (long)r0 + (long)dom_rel[k0 + u < dom_n ? k0 + u : dom_n - 1]);
-#pragma unroll
-        for (int u = 0; u < kB; u++) {
-          if (k0 + u < dom_n) {
-            const T v = (T)dom_val[k0 + u];
-#pragma unroll
-            for (int q = 0; q < NR; q++)
-#pragma unroll
-              for (int j = 0; j < VEC; j++) sum[q][j] += v * x[q][u][j];
-          }
-        }
-      }
-      return;
-    }
-  }
   if (VEC > 1) {
-    // One pass per DISTINCT pattern among the wavefront's rows (the seams of a stencil put two or three into a wavefront; a wavefront
-    // of one pattern that is not the dominant one takes one pass): the pattern number of a pass is wave-uniform, so its table entries are
+    // One pass per DISTINCT pattern among the wavefront's rows (one in the interior of a stencil, two or three on its seams): the pattern
+    // number of a pass is wave-uniform, so its table entries are
     // scalar loads and the operands of an entry are requested by all lanes together -- a lane whose VEC rows all have the pattern with
     // one 16-byte load, a lane on the seam row by row.  Every row still sums the entries of ITS pattern in table order.
     unsigned todo = (1u << VEC) - 1;                               // rows of this lane whose pattern has not had its pass
@@ -233,15 +179,14 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
 // at one of them.  Left to itself the compiler sinks every load to its first use behind the branch in front of it -- load, wait, compare,
 // branch, load, wait ... six or seven scalar round trips per block and wavefront before the first operand is requested (the prox launches
 // of the generic path spent two thirds of a wavefront's life in s_waitcnt lgkmcnt(0)).
-struct OpHead { int kind; unsigned long long row, col, nrows, ncols, nx, ny, L; const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval; int dom_id, dom_n; };
+struct OpHead { int kind; unsigned long long row, col, nrows, ncols, nx, ny, L; const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval; };
 template <bool ADJ>
 __device__ __forceinline__ OpHead op_head(const PROST_CONSTANT OpBlockDev& B) {
   OpHead h;
   h.kind = B.kind; h.row = B.row; h.col = B.col; h.nrows = B.nrows; h.ncols = B.ncols; h.nx = B.nx; h.ny = B.ny; h.L = B.L;
   h.ids = ADJ ? B.ids_t : B.ids; h.pptr = ADJ ? B.pptr_t : B.pptr; h.rel = ADJ ? B.rel_t : B.rel; h.pval = ADJ ? B.pval_t : B.pval;
-  h.dom_id = ADJ ? B.dom_id_t : B.dom_id; h.dom_n = ADJ ? B.dom_n_t : B.dom_n;
   asm volatile("" : : "s"(h.kind), "s"(h.row), "s"(h.col), "s"(h.nrows), "s"(h.ncols), "s"(h.nx), "s"(h.ny), "s"(h.L), "s"(h.ids), "s"(h.pptr), "s"(h.rel),
-               "s"(h.pval), "s"(h.dom_id), "s"(h.dom_n));
+               "s"(h.pval));
   return h;
 }
 
@@ -263,7 +208,7 @@ __device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& o
         const T* rhs[NR];
 #pragma unroll
         for (int q = 0; q < NR; q++) rhs[q] = t[q] + H.col;
-        pattern_rows<T, VEC, NR>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rhs, r, sum, H.dom_id, H.dom_n, B.dom_rel, B.dom_val, (size_t)H.ncols);
+        pattern_rows<T, VEC, NR>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rhs, r, sum);
       } else {
 #pragma unroll
         for (int q = 0; q < NR; q++) csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, t[q] + H.col, r, w0 - H.row, whole, sum[q]);
@@ -334,7 +279,7 @@ __device__ __forceinline__ void op_adj_cols(const PROST_CONSTANT FusedOpDev& op,
       T sum[1][VEC];
       if (H.ids) {
         const T* rr[1] = {rhs};
-        pattern_rows<T, VEC, 1>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rr, cidx, sum, H.dom_id, H.dom_n, B.dom_rel_t, B.dom_val_t, (size_t)H.nrows);
+        pattern_rows<T, VEC, 1>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rr, cidx, sum);
       } else csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - H.col, whole, sum[0]);
 #pragma unroll
       for (int j = 0; j < VEC; j++) v[j] = v[j] + sum[0][j];
@@ -415,12 +360,6 @@ inline FusedOpDev make_op(const prost_hip_fused_op* op) {
     D.kind = B.kind; D.row = B.row; D.col = B.col; D.nrows = B.nrows; D.ncols = B.ncols; D.nx = B.nx; D.ny = B.ny; D.L = B.L;
     D.val = B.val; D.ptr = B.ptr; D.ind = B.ind; D.val_t = B.val_t; D.ptr_t = B.ptr_t; D.ind_t = B.ind_t;
     D.ids = B.ids; D.pptr = B.pptr; D.rel = B.rel; D.pval = B.pval; D.ids_t = B.ids_t; D.pptr_t = B.pptr_t; D.rel_t = B.rel_t; D.pval_t = B.pval_t;
-    D.dom_id = B.dom_id; D.dom_n = B.ids && B.dom_n > 0 && B.dom_n <= PROST_HIP_OP_DOM_MAX ? B.dom_n : 0;
-    D.dom_id_t = B.dom_id_t; D.dom_n_t = B.ids_t && B.dom_n_t > 0 && B.dom_n_t <= PROST_HIP_OP_DOM_MAX ? B.dom_n_t : 0;
-    for (int k = 0; k < PROST_HIP_OP_DOM_MAX; k++) {        // (slots past the pattern's length: 0 -- the kernels request them unconditionally)
-      D.dom_rel[k] = k < D.dom_n ? B.dom_rel[k] : 0; D.dom_val[k] = k < D.dom_n ? B.dom_val[k] : 0.0;
-      D.dom_rel_t[k] = k < D.dom_n_t ? B.dom_rel_t[k] : 0; D.dom_val_t[k] = k < D.dom_n_t ? B.dom_val_t[k] : 0.0;
-    }
   }
   return o;
 }

@@ -185,19 +185,6 @@ void BlockSparse<T>::Initialize() {
     p.ids = h.ids; p.pptr = h.pptr; p.rel = h.rel; p.val = h.val;
     p.count = h.pptr.size() - 1;
     p.on = true;
-    // the pattern most rows have (a sample of the rows is enough: it only steers a speculative load)
-    p.dom_id = -1; p.dom_n = 0;
-    {
-      std::vector<size_t> cnt(p.count, 0);
-      const size_t step = std::max<size_t>(1, nrows / 65536);
-      for (size_t r = 0; r < nrows; r += step) cnt[h.ids[r]]++;
-      const size_t best = (size_t)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
-      const int len = h.pptr[best + 1] - h.pptr[best];
-      if (len > 0 && len <= 12) {
-        p.dom_id = (int)best; p.dom_n = len;
-        for (int k = 0; k < len; k++) { p.dom_rel[k] = h.rel[h.pptr[best] + k]; p.dom_val[k] = (double)h.val[h.pptr[best] + k]; }
-      }
-    }
   };
   DetectGradient2D();
   DetectPointwise();

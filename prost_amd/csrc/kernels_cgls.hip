@@ -22,6 +22,7 @@
 //   gemv_functor3  alpha sqrt(d) v        axpy           alpha x + y
 #include <limits>
 
+#include <cstdlib>
 #include "elementwise.hpp"
 #include "fused_op.hpp"
 
@@ -988,11 +989,6 @@ const FusedOpDev* device_op(const prost_hip_fused_op* op) {
       D.kind = S.kind; D.row = S.row; D.col = S.col; D.nrows = S.nrows; D.ncols = S.ncols; D.nx = S.nx; D.ny = S.ny; D.L = S.L;
       D.val = S.val; D.ptr = S.ptr; D.ind = S.ind; D.val_t = S.val_t; D.ptr_t = S.ptr_t; D.ind_t = S.ind_t;
       D.ids = S.ids; D.pptr = S.pptr; D.rel = S.rel; D.pval = S.pval; D.ids_t = S.ids_t; D.pptr_t = S.pptr_t; D.rel_t = S.rel_t; D.pval_t = S.pval_t;
-      D.dom_id = S.dom_id; D.dom_n = S.dom_n; D.dom_id_t = S.dom_id_t; D.dom_n_t = S.dom_n_t;
-      for (int k = 0; k < PROST_HIP_OP_DOM_MAX; k++) {
-        D.dom_rel[k] = k < S.dom_n ? S.dom_rel[k] : 0; D.dom_val[k] = k < S.dom_n ? S.dom_val[k] : 0.0;
-        D.dom_rel_t[k] = k < S.dom_n_t ? S.dom_rel_t[k] : 0; D.dom_val_t[k] = k < S.dom_n_t ? S.dom_val_t[k] : 0.0;
-      }
     }
   }
   int device = 0;

@@ -5,7 +5,9 @@
 // contiguous axis is y (resp. (y,l)).  Every kernel maps consecutive lanes to consecutive
 // addresses of that axis: a wave reads/writes 256 contiguous bytes (fp32) per access, and the
 // +-1 / +-ny neighbours of a lane are the same or the adjacent cache lines (served by L1/L2).
+#include <cstdlib>
 #include "elementwise.hpp"
+#include "fused_op.hpp"
 
 namespace prost_hip {
 
@@ -495,6 +497,32 @@ __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ re
     if (base < nrows) load_ids(base);
   }
 }
+// Round 5: the same product with the row walk of the fused kernels (fused_op.hpp: pattern_rows) -- a lane takes VEC consecutive rows, the
+// wavefront one pass per distinct pattern among its rows, the table read through the constant address space with scalar loads, the
+// operands of up to six entries in flight together.  Same sums in the same order as pattern_spmv_kernel.
+template <class T, bool ACC>
+__global__ void __launch_bounds__(kBlock) pattern_spmv_rows_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nrows, const uint16_t* __restrict__ ids,
+                                                                    const int32_t* __restrict__ pptr, const int32_t* __restrict__ rel, const T* __restrict__ pval) {
+  constexpr int V = VecOf<T>::N;
+  const size_t nvec = nrows / V;
+  const T* rr[1] = {rhs};
+  for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec; g += (size_t)gridDim.x * kBlock) {
+    const size_t r0 = g * V;
+    T sum[1][V], o[V];
+    if (ACC) ldv<T, V>(res + r0, o);
+    pattern_rows<T, V, 1>(ids, as_constant(pptr), as_constant(rel), as_constant(pval), rr, r0, sum);
+#pragma unroll
+    for (int j = 0; j < V; j++) o[j] = (ACC ? o[j] : (T)0) + sum[0][j];
+    stv<T, V>(res + r0, o);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < nrows - nvec * V) {              // the last nrows % V rows
+    const size_t r0 = nvec * V + threadIdx.x;
+    T sum[1][1];
+    pattern_rows<T, 1, 1>(ids, as_constant(pptr), as_constant(rel), as_constant(pval), rr, r0, sum);
+    res[r0] = (ACC ? res[r0] : (T)0) + sum[0][0];
+  }
+}
+
 template <class T>
 static int launch_pattern(T* res, const T* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const T* pval, int acc, void* stream,
                           int npatterns = 0, int nentries = 0) {
@@ -502,9 +530,21 @@ static int launch_pattern(T* res, const T* rhs, size_t nrows, const uint16_t* id
   if (!res || !rhs || !ids || !pptr || !rel || !pval) { set_error("pattern spmv: null pointer"); return 1; }
   if (reinterpret_cast<uintptr_t>(ids) % 8 != 0) { set_error("pattern spmv: the pattern numbers must be 8-byte aligned"); return 1; }
   hipStream_t s = as_stream(stream);
+  // round 5: 16 bytes of rows per lane, one pass per distinct pattern of a wavefront, scalar table loads (pattern_spmv_rows_kernel); same
+  // box, deblurring's shape with separate products: 256^2 17 992 -> 25 093, 1024^2 11 061 -> 14 344, 2048^2 4 557 -> 5 177 iterations/s.
+  // (Requesting the operands of the table's most frequent pattern before the pattern numbers arrive was tried on top of this and in
+  // the prox kernels that apply the operator: 3-7 % SLOWER at every size -- with scalar table loads the walk is cheap, the speculation is not)
+  if (reinterpret_cast<uintptr_t>(res) % 16 == 0) {
+    const size_t lanes = nrows / VecOf<T>::N;
+    size_t gx = (lanes + kBlock - 1) / kBlock;
+    if (gx < 1) gx = 1;
+    if (gx > 16384) gx = 16384;
+    if (acc) hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, true>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
+    else hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, false>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
+    PH_LAUNCH_END("pattern spmv rows kernel");
+  }
   const unsigned grid = grid_for((nrows + 7) / 8);
-  // the table staged in LDS where its size is known and fits (prost_hip_pattern_spmv_tab) and the product is small enough for the
-  // dependent round trips to matter (beyond ~2^22 rows it streams at the memory rate either way)
+  // (res not 16-byte aligned: the row-by-row kernel) the table staged in LDS where its size is known and fits (prost_hip_pattern_spmv_tab)
   const bool tab = npatterns > 0 && npatterns <= kTabPatterns && nentries > 0 && nentries <= kTabEntries && nrows <= ((size_t)1 << 22);
   if (tab) {
     if (acc) hipLaunchKernelGGL((pattern_spmv_kernel<T, true, true>), dim3(grid), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, npatterns, nentries);

@@ -47,7 +47,7 @@ def main(nx=700, ny=464, iters=3000, residual_iter=1, warmup=300, mask=15):
             continue
         b = prost.backend.pdhg(stepsize="boyd", residual_iter=int(residual_iter))      # :40-41
         b[1]["allow_device_rules"] = dev
-        b[1]["allow_op_fusion"] = 1 if opf else 0
+        b[1]["allow_op_fusion"] = 2 if opf else 0
         s = prost.Solver(prob, b, o)
         s.iterate(warmup)
         info = s.iterate(iters)
