@@ -27,16 +27,20 @@ class BackendPDHG : public Backend<T> {
     bool allow_single_kernel;  ///< MI355X addition: one kernel per non-residual iteration (7 instead of 11 floats/pixel)
     bool allow_pair_kernel;    ///< MI355X addition: two iterations per launch where nobody observes the one in between
     bool allow_arg_fusion;     ///< MI355X addition (generic path): proxes form their argument on the fly, no argument pass
-    int allow_op_fusion;       ///< MI355X addition (generic path, round 5): the proxes also form the operator products K^T y / K x on the fly and add up
-                               ///< the residual terms themselves (operators of sparse / gradient blocks): K x, K^T y never written, 4 launches per iteration
-                               ///< instead of 9, bit-identical.  0: never; 1 (default): problems of >= 2^19 elements (x and y) where every sparse block is a STENCIL written out row by row (row
-                               ///< patterns for K and K^T -- example_deblurring.m, example_multilabel_*.m) or a gradient block;
-                               ///< 2: wherever the kernels support the operator (random CSR blocks walk their rows lane by lane: not measured faster)
+    int allow_op_fusion;       ///< MI355X addition (generic path, round 5; default 0 = off): > 0: the proxes also form the operator products K^T y / K x on the
+                               ///< fly and add up the residual terms themselves (operators of sparse / gradient blocks; CSR blocks without row patterns: rows
+                               ///< of <= 6 entries on average): K x, K^T y never written, 4 launches per iteration instead of 9, bit-identical.  Off by default:
+                               ///< once the stand-alone pattern product had the same row walk, the separate products were as fast or faster at every size
+                               ///< measured
+    int residual_sums_in_prox; ///< MI355X addition (generic path, round 5): the prox launches that form their argument on the fly add up the residual terms
+                               ///< of their elements themselves (no separate reduction over eight vectors).  0: never; 1 (default): problems of >= 2^23
+                               ///< elements (x and y together: below that the two small reduction launches are cheaper than the sums' tail in every prox
+                               ///< launch); 2: always
     bool allow_speculation;    ///< MI355X addition: the next pair launch is enqueued BEFORE the host waits for the residual sums (alg1 / alg2)
     bool allow_device_rules;   ///< MI355X addition: goldstein / boyd and the stopping test evaluated on the device, one host wait per BATCH of iterations
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
-                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_op_fusion(1), allow_speculation(true),
+                allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_op_fusion(0), residual_sums_in_prox(1), allow_speculation(true),
                 allow_device_rules(true) {}
   };
 
@@ -53,6 +57,7 @@ class BackendPDHG : public Backend<T> {
   size_t device_rule_batches() const { return dev_batches_; }
   /// generic path: the operator products are formed inside the prox kernels (IterationGenericOp)
   bool operator_in_prox_kernels() const { return op_fused_; }
+  bool residual_sums_in_prox_launches() const { return res_in_prox_; }
   virtual void Release();
   virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
@@ -180,6 +185,7 @@ class BackendPDHG : public Backend<T> {
   bool op_fused_ = false;                              // ... and from the operator sources: the generic iteration runs without K x / K^T y launches
   prost_hip_fused_op gen_op_;                          // the operator as a table of sparse / gradient blocks (op_fused_)
   const T* view_tau_ = nullptr; const T* view_sigma_ = nullptr; const int* view_stop_ = nullptr;   // device addresses inside rule_rec_ (Prox::StepView)
+  bool res_in_prox_ = false;                           // separate products: the prox launches add up the residual terms themselves (ARG 5 / 6)
   void* op_workspace_ = nullptr;                       // residual sums of the prox launches: 2 x kOpSumSlots slots of 4 doubles (primal | dual)
   static constexpr unsigned kOpSumSlots = 8192;
   /// workgroups of one residual launch: every workgroup ends with a block-wide fold of its sums, which 2048 workgroups (two rounds of the

@@ -31,7 +31,9 @@ class FusedDesc(C.Structure):
 
 class ArgSpec(C.Structure):
     """prost_hip_arg_spec: how a prox obtains its argument (PROST_ARG_PLAIN / PDHG_PRIMAL / PDHG_DUAL)"""
-    _fields_ = [("mode", C.c_int), ("v", C.c_void_p * 4), ("s", C.c_double * 2)]
+    _fields_ = [("mode", C.c_int), ("v", C.c_void_p * 4), ("s", C.c_double * 2),
+                ("op", C.c_void_p), ("op_rows", C.c_uint64), ("op_cols", C.c_uint64), ("base", C.c_uint64), ("w", C.c_void_p * 2), ("kty_out", C.c_void_p),
+                ("use", C.c_int * 2), ("res_ws", C.c_void_p), ("res_slot", C.c_uint), ("res_slots_max", C.c_uint)]      # operator sources / residual sums: zero = none
 
 
 class CglsDesc(C.Structure):

@@ -218,14 +218,21 @@ void BackendPDHG<T>::Initialize() {
   for (auto& p : prox_fstar_) arg_fused_f_ = arg_fused_f_ && p->supports_arg_source();
   // the operator inside the prox kernels (round 5): every block a sparse matrix or a gradient stencil, every prox able to form K^T y /
   // K x for its own elements (the in-tree elem operations, their Moreau wraps, the identity, on 16-byte boundaries)
-  // (option 1, the default: stencil operators, and only where an iteration is not launch-bound -- below ~2^19 elements of x and y together the
-  // nine small launches of the separate products, ~4 us each, beat four launches that each walk the operator: deblurring's shape at 256^2
-  // 25.0 k against 22.5 k iterations/s, at 700 x 464 19.6 k against 20.5 k; option 2 applies the operator inside the prox launches at any size)
-  const bool big_enough = opts_.allow_op_fusion >= 2 || this->problem_->ncols() + this->problem_->nrows() >= ((size_t)1 << 19);
-  op_fused_ = !fused_ && opts_.allow_op_fusion > 0 && big_enough && arg_fused_g_ && arg_fused_f_ && owned_x1_ == 0 && DescribeGenericOperator(opts_.allow_op_fusion == 1);
+  // (off by default: with the row walk of round 5 in the stand-alone products as well, the separate products are as fast or faster --
+  // deblurring's shape 256^2 25.0 k against 22.5 k iterations/s, 1024^2 14.4 k against 14.9 k, 2048^2 5.7 k (residual sums in the prox
+  // launches) against 5.4 k; example_multilabel_fast.m 512^2 24.9 k against 21.2 k)
+  op_fused_ = !fused_ && opts_.allow_op_fusion > 0 && arg_fused_g_ && arg_fused_f_ && owned_x1_ == 0 && DescribeGenericOperator(false);
   for (auto& p : prox_g_) op_fused_ = op_fused_ && p->supports_op_source();
   for (auto& p : prox_fstar_) op_fused_ = op_fused_ && p->supports_op_source();
-  if (op_fused_ && !op_workspace_) CheckHip(prost_hip_malloc(&op_workspace_, 2 * (size_t)kOpSumSlots * 4 * sizeof(double)), "malloc");
+  // the residual sums inside the prox launches of the separate-products path too (round 5, ARG 5 / 6 of the prox kernels): every prox forms
+  // its argument on the fly with the 16-bytes-per-lane kernel -- the separate reduction re-read eight vectors per residual iteration
+  // (from 2^23 elements of x and y on: 2048^2 deblurring shape 5 137 -> 5 668 iterations/s; at 256^2 the sums' tail in every prox launch and the
+  // 1024-lane fold cost more than the two small reduction launches they replace: 25.0 k -> 21.0 k)
+  res_in_prox_ = !fused_ && !op_fused_ && arg_fused_g_ && arg_fused_f_ && owned_x1_ == 0 && opts_.allow_arg_fusion && opts_.residual_sums_in_prox > 0 &&
+                 (opts_.residual_sums_in_prox >= 2 || this->problem_->ncols() + this->problem_->nrows() >= ((size_t)1 << 23));
+  for (auto& p : prox_g_) res_in_prox_ = res_in_prox_ && p->supports_op_source();
+  for (auto& p : prox_fstar_) res_in_prox_ = res_in_prox_ && p->supports_op_source();
+  if ((op_fused_ || res_in_prox_) && !op_workspace_) CheckHip(prost_hip_malloc(&op_workspace_, 2 * (size_t)kOpSumSlots * 4 * sizeof(double)), "malloc");
   single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
   single3d_ = fused_ && !single_kernel_ && opts_.allow_single_kernel && prost_hip_fused_iteration3d_supported(&desc_, dtype_id<T>()) == 1;
   single3d_pw_ = single3d_ && prost_hip_fused_iteration3d_pw_supported(&desc_, dtype_id<T>()) == 1;
@@ -792,6 +799,10 @@ bool BackendPDHG<T>::DescribeGenericOperator(bool stencils_only) {
       o.kind = PROST_OP_CSR;
       // (a stencil written out row by row: K and K^T run from row patterns)
       if (stencils_only && !(bd.ids && bd.ids_t)) return false;
+      // (CSR rows without patterns are walked lane by lane inside the prox launches: beyond ~6 entries per row that is an order of magnitude
+      // slower than the stand-alone product with its cooperating lanes -- example_deblurring.m's 15-tap motion blur: 367 against 4 855
+      // iterations/s at 512 x 512 x 3 -- so such operators keep the separate products under every option)
+      if (!(bd.ids && bd.ids_t) && bd.nnz > 6 * std::min(b->nrows(), b->ncols())) return false;
       o.val = bd.val; o.ptr = bd.ptr; o.ind = bd.ind; o.val_t = bd.val_t; o.ptr_t = bd.ptr_t; o.ind_t = bd.ind_t;
       o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t;
     } else if ((bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D) && !bd.label_first) {
@@ -863,9 +874,18 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   // written and re-read per prox.
   // (a list with both kinds -- in-tree operations next to a plugin's -- runs the argument pass once for the proxes that need it; inside a
   // device batch those take the step size from the record through a StepView)
+  const bool res_here = res && res_in_prox_;
+  const unsigned half = kOpSumSlots;
+  double* ws_p = static_cast<double*>(op_workspace_);
+  double* ws_d = ws_p ? ws_p + 4 * (size_t)half : nullptr;
+  unsigned slot_p = 0, slot_d = 0;
   if (arg_fused_g_) {
     x_.swap(x_prev_);
-    const typename Prox<T>::ArgSource src{PROST_ARG_PDHG_PRIMAL, {x_prev_.data(), Tr.data(), kty_.data(), nullptr}, {tau_, (T)0}};
+    typename Prox<T>::ArgSource src{PROST_ARG_PDHG_PRIMAL, {x_prev_.data(), Tr.data(), kty_.data(), nullptr}, {tau_, (T)0}};
+    if (res_here) {                                    // dual residual terms: x_prev, x, T, K^T y^(k-1), K^T y^k
+      src.v[3] = kty_prev_.data();
+      src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_g_.size(), 1)));
+    }
     for (auto& p : prox_g_) p->EvalFromSource(x_, src, Tr, tau_);
   } else {
     CheckHip(Api<T>::pdhg_primal_arg(temp_.data(), x_.data(), Tr.data(), kty_.data(), (double)tau_, n, s), "primal_arg");   // :317-331
@@ -881,7 +901,10 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
   this->problem_->linop()->Eval(kx_, x_);
   if (arg_fused_f_) {
     y_.swap(y_prev_);
-    const typename Prox<T>::ArgSource src{PROST_ARG_PDHG_DUAL, {y_prev_.data(), Sl.data(), kx_.data(), kx_prev_.data()}, {sigma_, theta_}};
+    typename Prox<T>::ArgSource src{PROST_ARG_PDHG_DUAL, {y_prev_.data(), Sl.data(), kx_.data(), kx_prev_.data()}, {sigma_, theta_}};
+    if (res_here) {                                    // primal residual terms: y_prev, y, Sigma, K x_prev, K x
+      src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1)));
+    }
     for (auto& p : prox_fstar_) p->EvalFromSource(y_, src, Sl, sigma_);
   } else {
     CheckHip(Api<T>::pdhg_dual_arg(temp_.data(), y_.data(), Sl.data(), kx_.data(), kx_prev_.data(), (double)sigma_, (double)theta_, m, s), "dual_arg");   // :349-364
@@ -897,6 +920,10 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
     // both reductions in one launch, their folds -- and inside a device batch without a communicator the rule -- in a second
     // (same sums, bit for bit, as pdhg_residual_primal + pdhg_residual_dual: five launches)
     const bool rule_here = in_device_batch_ && !this->comm_;
+    if (res_here)
+      CheckHip(Api<T>::pdhg_fold_sums(res_target(), ws_p, slot_p, ws_d, slot_d, rule_here ? rule_rec_ : nullptr, rule_here ? 1 : 0, (unsigned long long)iteration_,
+                                      rule_here ? rule_mirror_dev_ : nullptr, s), "pdhg_fold_sums");
+    else
     CheckHip(Api<T>::pdhg_residuals(res_target(), y_prev_.data(), y_.data(), Sl.data(), kx_prev_.data(), kx_.data(), (double)sigma_, (double)theta_, m, x_prev_.data(), x_.data(),
                                     Tr.data(), kty_prev_.data(), kty_.data(), (double)tau_, n, workspace_, rule_here ? rule_rec_ : nullptr, rule_here ? 1 : 0,
                                     (unsigned long long)iteration_, rule_here ? rule_mirror_dev_ : nullptr, s), "pdhg_residuals");

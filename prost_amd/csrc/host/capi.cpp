@@ -341,6 +341,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       if (prost_value_field(d, "allow_speculation")) o.allow_speculation = GetScalarFromField(d, "allow_speculation") > 0.;
       if (prost_value_field(d, "allow_arg_fusion")) o.allow_arg_fusion = GetScalarFromField(d, "allow_arg_fusion") > 0.;
       if (prost_value_field(d, "allow_op_fusion")) o.allow_op_fusion = (int)GetScalarFromField(d, "allow_op_fusion");
+      if (prost_value_field(d, "residual_sums_in_prox")) o.residual_sums_in_prox = (int)GetScalarFromField(d, "residual_sums_in_prox");
       if (prost_value_field(d, "allow_device_rules")) o.allow_device_rules = GetScalarFromField(d, "allow_device_rules") > 0.;
       return new BackendPDHG<T>(o);
     };
@@ -818,12 +819,13 @@ void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** pl
     prost_value_struct_set(out, "z", vec_value_t(h.solver->cur_primal_constr_sol()));
     prost_value_struct_set(out, "w", vec_value_t(h.solver->cur_dual_constr_sol()));
   }
-  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0, spec_l = 0, spec_a = 0, dev_batches = 0, op_fused = 0;
+  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0, spec_l = 0, spec_a = 0, dev_batches = 0, op_fused = 0, res_prox = 0;
   if (auto* p = dynamic_cast<BackendPDHG<T>*>(h.backend.get())) {
     tau = p->tau(); sigma = p->sigma(); theta = p->theta(); it = (double)p->iteration();
     spec_l = (double)p->speculative_launches(); spec_a = (double)p->speculative_adopted();
     dev_batches = (double)p->device_rule_batches();
     op_fused = p->operator_in_prox_kernels() ? 1 : 0;
+    res_prox = p->residual_sums_in_prox_launches() ? 1 : 0;
   }
   if (auto* a = dynamic_cast<BackendADMM<T>*>(h.backend.get())) { rho = a->rho(); it = (double)a->iteration(); cg_its = a->last_cg_iterations(); }
   const char* names[] = {"tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res", "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual"};
@@ -837,6 +839,7 @@ void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** pl
   prost_value_struct_set(out, "speculative_adopted", prost_value_scalar(spec_a));
   prost_value_struct_set(out, "device_rule_batches", prost_value_scalar(dev_batches));
   prost_value_struct_set(out, "operator_in_prox_kernels", prost_value_scalar(op_fused));      // generic PDHG: K x / K^T y formed inside the prox launches
+  prost_value_struct_set(out, "residual_sums_in_prox_launches", prost_value_scalar(res_prox)); // generic PDHG, separate products: the prox launches add up the residual terms
   {   // sparse blocks applied from row patterns instead of their CSR arrays (forward + adjoint products counted separately)
     double pat = 0;
     for (const auto& blk : h.problem->linop()->blocks())

@@ -177,11 +177,12 @@ template <typename T>
 void ProxZero<T>::EvalFromSource(device_vector<T>& result, const typename Prox<T>::ArgSource& src, const device_vector<T>&, T, bool) {
   const size_t i = this->index_;
   void* s = CurrentStream();
-  if (src.mode == PROST_ARG_PDHG_PRIMAL)
+  const bool sums = src.res_ws != nullptr && (src.mode == PROST_ARG_PDHG_PRIMAL || src.mode == PROST_ARG_PDHG_DUAL);
+  if (src.mode == PROST_ARG_PDHG_PRIMAL && !sums)
     CheckHip(Api<T>::pdhg_primal_arg(result.data() + i, src.v[0] + i, src.v[1] + i, src.v[2] + i, (double)src.s[0], this->size_, s), "primal_arg");
-  else if (src.mode == PROST_ARG_PDHG_DUAL)
+  else if (src.mode == PROST_ARG_PDHG_DUAL && !sums)
     CheckHip(Api<T>::pdhg_dual_arg(result.data() + i, src.v[0] + i, src.v[1] + i, src.v[2] + i, src.v[3] + i, (double)src.s[0], (double)src.s[1], this->size_, s), "dual_arg");
-  else if (src.mode == PROST_ARG_PDHG_PRIMAL_OP || src.mode == PROST_ARG_PDHG_DUAL_OP) {
+  else if (sums || src.mode == PROST_ARG_PDHG_PRIMAL_OP || src.mode == PROST_ARG_PDHG_DUAL_OP) {
     // the identity as the 1-D operation of the zero function with a = c = 1, b = d = e = 0: ((1 (arg - 0 tau)) / 1 - 0 + 0) / 1 = arg, exactly
     // (elem_operation_1d.hpp:45-58) -- the launch that forms the argument from the operator writes it straight into the result
     prost_hip_arg_spec a;

@@ -48,6 +48,12 @@ struct NoOpSrc {};
 template <class T, int ARG> struct OpSrcOf { typedef NoOpSrc type; };
 template <class T> struct OpSrcOf<T, 3> { typedef OpSrc<T> type; };
 template <class T> struct OpSrcOf<T, 4> { typedef OpSrc<T> type; };
+// ARG = 5 / 6: ARG 1 / 2 (the products K^T y resp. K x, K x_prev read from memory) with the residual sums of ARG 3 / 4 -- the launch that has
+// x_prev, x, T, K^T y (resp. y_prev, y, Sigma, K x, K x_prev) in registers adds up the terms of dual_residual_transform / primal_residual_
+// transform itself; only K^T y_prev (ARG 5: a.v3) is read in addition.  The separate reduction re-read eight vectors per residual iteration.
+template <class T> struct OpSrcOf<T, 5> { typedef OpSrc<T> type; };
+template <class T> struct OpSrcOf<T, 6> { typedef OpSrc<T> type; };
+constexpr bool arg_is_primal(int ARG) { return ARG == 1 || ARG == 3 || ARG == 5; }
 // the operands an argument was formed from (ARG 3 / 4), kept for the residual terms
 template <class T, int VEC> struct ArgParts { T p0[VEC], p1[VEC], p2[VEC], p3[VEC]; };
 
@@ -55,14 +61,14 @@ template <class T, int ARG>
 __device__ __forceinline__ bool steps_from_record(ArgSrc<T>& a, T& tau_scal) {
   if (ARG == 0 || !a.rec) return true;
   if (a.rec->stop) return false;
-  a.s0 = (ARG == 1 || ARG == 3) ? a.rec->p.tau : a.rec->p.sigma;
+  a.s0 = arg_is_primal(ARG) ? a.rec->p.tau : a.rec->p.sigma;
   a.s1 = a.rec->p.theta;
   tau_scal = a.s0;
   return true;
 }
 template <class T, int ARG>
 __device__ __forceinline__ T arg_formula(const ArgSrc<T>& a, T p0, T p1, T p2, T p3) {
-  if (ARG == 1 || ARG == 3) return p0 - a.s0 * p1 * p2;
+  if (arg_is_primal(ARG)) return p0 - a.s0 * p1 * p2;
   return p0 + a.s0 * p1 * ((1 + a.s1) * p2 - a.s1 * p3);
 }
 // ARG 3 / 4: the argument of VEC consecutive elements from `off` on, its operands kept in `P`
@@ -72,7 +78,12 @@ __device__ __forceinline__ void load_arg_op(const ArgSrc<T>& a, const OpSrc<T>& 
 #pragma unroll
   for (int j = 0; j < VEC; j++) { P.p2[j] = 0; P.p3[j] = 0; }
   const size_t g = os.base + off;
-  if (ARG == 3) {
+  if (ARG == 5) {                                                                   // K^T y from memory; K^T y_prev only for the residual terms
+    ldv<T, VEC>(a.v2 + off, P.p2);
+    if (os.res_ws && a.v3) ldv<T, VEC>(a.v3 + off, P.p3);
+  } else if (ARG == 6) {                                                            // K x, K x_prev from memory
+    ldv<T, VEC>(a.v2 + off, P.p2); ldv<T, VEC>(a.v3 + off, P.p3);
+  } else if (ARG == 3) {
     if (os.res_ws && a.v3) ldv<T, VEC>(a.v3 + off, P.p3);                          // K^T y_prev, stored by the previous iteration's launch
     if (os.use0) op_adj_cols<T, VEC>(*as_constant(os.opp), g, g, os.w0, P.p2, false);            // 0 + K^T y, block after block
     if (store && os.kty_out) stv<T, VEC>(os.kty_out + off, P.p2);
@@ -89,7 +100,7 @@ __device__ __forceinline__ void load_arg_op(const ArgSrc<T>& a, const OpSrc<T>& 
     }
   }
 #pragma unroll
-  for (int j = 0; j < VEC; j++) out[j] = arg_formula<T, ARG>(a, P.p0[j], P.p1[j], P.p2[j], ARG == 4 ? P.p3[j] : (T)0);
+  for (int j = 0; j < VEC; j++) out[j] = arg_formula<T, ARG>(a, P.p0[j], P.p1[j], P.p2[j], !arg_is_primal(ARG) ? P.p3[j] : (T)0);
 }
 // the residual terms of VEC elements whose prox result is `res` (ResidualPrimalF / ResidualDualF of kernels_pdhg.hip, term by term)
 template <class T, int VEC, int ARG>
@@ -97,7 +108,7 @@ __device__ __forceinline__ void residual_terms(const ArgSrc<T>& a, const ArgPart
 #pragma unroll
   for (int j = 0; j < VEC; j++) {
     const T d = P.p1[j];
-    if (ARG == 4) {                                    // in = y_prev, y, Sigma, K x_prev, K x
+    if (!arg_is_primal(ARG)) {                         // in = y_prev, y, Sigma, K x_prev, K x
       const T z_hat = (P.p0[j] - res[j]) / (a.s0 * t_sqrt(d)) + t_sqrt(d) * ((1 + a.s1) * P.p2[j] - a.s1 * P.p3[j]);
       const T diff = z_hat - t_sqrt(d) * P.p2[j];
       dd_acc(sa, (double)(diff * diff)); dd_acc(sb, (double)(z_hat * z_hat));
@@ -313,8 +324,8 @@ static int launch_prox_elem(int op, int fn, T* res, const ArgSrc<T>& arg, const 
   constexpr int V = VecOf<T>::N;
   bool vec = (op == PROST_OP_1D || !interleaved || dim == 1) && count % V == 0 && aligned16(res) && aligned16(arg.v0) && aligned16(tau_diag);
   if (ARG >= 1) vec = vec && aligned16(arg.v1);
-  if (ARG == 1 || ARG == 2) vec = vec && aligned16(arg.v2);
-  if (ARG == 2 || ARG == 3) vec = vec && aligned16(arg.v3);
+  if (ARG == 1 || ARG == 2 || ARG == 5 || ARG == 6) vec = vec && aligned16(arg.v2);
+  if (ARG == 2 || ARG == 3 || ARG == 5 || ARG == 6) vec = vec && aligned16(arg.v3);
   for (int i = 0; i < 7; i++) vec = vec && aligned16(cf.ptr[i]);
   if (vec) {
     const bool e_zero = !cf.ptr[4] && cf.val[4] == (T)0, a_one = !cf.ptr[0] && cf.val[0] == (T)1;
@@ -331,7 +342,7 @@ static int launch_prox_elem(int op, int fn, T* res, const ArgSrc<T>& arg, const 
 #undef GO
     PH_LAUNCH_END("prox_elem kernel");
   }
-  if constexpr (ARG >= 3) { set_error("prox_elem_arg: the operator sources need the planar layout (or the 1-D operation), a count that is a multiple of 16 bytes and 16-byte aligned operands (prost_hip_prox_elem_arg_op_supported)"); return 1; }
+  if constexpr (ARG >= 3) { set_error("prox_elem_arg: the operator sources and the residual sums need the planar layout (or the 1-D operation), a count that is a multiple of 16 bytes and 16-byte aligned operands (prost_hip_prox_elem_arg_op_supported)"); return 1; }
   else {
   if (op == PROST_OP_1D)
     hipLaunchKernelGGL((prox_elem_kernel<T, PROST_OP_1D, MOREAU, ARG>), dim3(grid_for(count)), dim3(kBlock), 0, s, res, arg, tau_diag, (T)tau, invert != 0, count, (size_t)1, interleaved != 0, fn, cf);
@@ -355,6 +366,20 @@ static int launch_prox_elem_arg(int op, int fn, int moreau, T* res, const prost_
   const ArgSrc<T> src{static_cast<const T*>(a->v[0]), static_cast<const T*>(a->v[1]), static_cast<const T*>(a->v[2]), static_cast<const T*>(a->v[3]),
                       (T)a->s[0], (T)a->s[1], a->mode == PROST_ARG_PLAIN ? nullptr : step_record<T>()};
   if (src.v0 == res) { set_error("prox_elem_arg: the result must not alias the argument source"); return 1; }
+  if ((a->mode == PROST_ARG_PDHG_PRIMAL || a->mode == PROST_ARG_PDHG_DUAL) && a->res_ws) {
+    // the residual terms of this prox's elements are added up by the launch itself (ARG 5 / 6): 16-bytes-per-lane kernel only
+    if (a->res_slots_max < 1) { set_error("prox_elem_arg: no partial slots for the residual sums"); return 1; }
+    OpSrc<T> os;
+    os.opp = nullptr; os.base = 0; os.w0 = os.w1 = nullptr; os.kty_out = nullptr; os.use0 = os.use1 = 0;
+    os.res_ws = a->res_ws; os.res_slot = a->res_slot;
+    const unsigned cap = a->res_slots_max;
+    if (a->mode == PROST_ARG_PDHG_PRIMAL) {
+      if (moreau) return launch_prox_elem<T, true, 5>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
+      return launch_prox_elem<T, false, 5>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
+    }
+    if (moreau) return launch_prox_elem<T, true, 6>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
+    return launch_prox_elem<T, false, 6>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream, os, cap);
+  }
 #define GO(M, A) return launch_prox_elem<T, M, A>(op, fn, res, src, tau_diag, tau, invert, count, dim, interleaved, coeff_ptr, coeff_val, stream)
   switch (a->mode) {
     case PROST_ARG_PLAIN: if (moreau) GO(true, 0); else GO(false, 0);

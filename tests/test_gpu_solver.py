@@ -528,7 +528,7 @@ def test_operator_norm_estimate_equals_the_oracle_bit_for_bit(precision, dtype):
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("step,residual_iter", [("boyd", 1), ("alg2", 4), ("goldstein", 3)])
 def test_generic_pdhg_with_the_operator_inside_the_prox_kernels(precision, dtype, step, residual_iter):
-    """allow_op_fusion (round 5; 1 = the default: operators of stencil / gradient blocks, 2: any supported operator): the prox launches of the generic path form K^T y / K x
+    """allow_op_fusion (round 5; off by default) and residual_sums_in_prox (default: from 2^23 elements on): the prox launches of the generic path form K^T y / K x
     for their own elements from the operator's blocks -- row patterns, CSR rows, gradient stencils, in block order -- and add up the residual
     terms themselves, so K x is never written and an iteration is 4 launches instead of 9.  Iterates, step sizes and decisions are those of
     the separate products and of the oracle, bit for bit, on: example_deblurring.m's shape (two sparse constraint blocks, Moreau-wrapped
@@ -547,12 +547,16 @@ def test_generic_pdhg_with_the_operator_inside_the_prox_kernels(precision, dtype
         o = prost.options(max_iters=100, num_cback_calls=0, verbose=False, x0=rng.random(prob.ncols), y0=0.1 * rng.standard_normal(prob.nrows))
         for iters in (1, 2, 23):
             st = {}
-            for opf, dev in ((True, True), (True, False), (False, True)):
+            # (True, .): the operator inside the prox launches; ("sums", .): separate products, the prox launches add up the residual terms
+            # (residual_sums_in_prox = 2: always -- the default waits for 2^23 elements); (False, .): separate products and reductions
+            for opf, dev in ((True, True), (True, False), (False, True), ("sums", True), ("sums", False)):
                 b = prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.2)
-                b[1]["allow_op_fusion"] = 2 if opf else 0
+                b[1]["allow_op_fusion"] = 2 if opf is True else 0
+                b[1]["residual_sums_in_prox"] = 2 if opf == "sums" else 0
                 b[1]["allow_device_rules"] = dev
                 st[(opf, dev)] = run_product(prob, b, o, iters)
-                assert st[(opf, dev)]["path"] == "pdhg:generic" and st[(opf, dev)]["operator_in_prox_kernels"] == (1.0 if opf else 0.0), (name, opf)
+                assert st[(opf, dev)]["path"] == "pdhg:generic" and st[(opf, dev)]["operator_in_prox_kernels"] == (1.0 if opf is True else 0.0), (name, opf)
+                assert st[(opf, dev)]["residual_sums_in_prox_launches"] == (1.0 if opf == "sums" else 0.0), (name, opf)
             ost = run_oracle(prob, prost.backend.pdhg(stepsize=step, residual_iter=residual_iter, alg2_gamma=0.2), o, iters, dtype)
             for key, s_ in st.items():
                 assert_same_iterates(s_, ost, exact=True)
