@@ -140,6 +140,8 @@ class BlockKronSparse : public Block<T> {
   BlockKronSparse(size_t row, size_t col, size_t nrows, size_t ncols) : Block<T>(row, col, nrows, ncols) {}
   virtual void EvalLocalAdd(T*, T*, const T*, const T*);
   virtual void EvalAdjointLocalAdd(T*, T*, const T*, const T*);
+  virtual void EvalLocal(T*, T*, const T*, const T*);              ///< non-accumulating forms: no fill pass in front of the product
+  virtual void EvalAdjointLocal(T*, T*, const T*, const T*);
   bool id_first_ = false;
   size_t diaglength_ = 0, mat_nnz_ = 0, mat_nrows_ = 0, mat_ncols_ = 0;
   std::vector<int32_t> host_ind_, host_ind_t_, host_ptr_, host_ptr_t_;

@@ -50,6 +50,9 @@ class LinearOperator {
   std::vector<shared_ptr<Block<T>>> blocks_;
   size_t nrows_, ncols_;
   bool rows_exclusive_, cols_exclusive_;   // every row (column) written by exactly one block
+  /// MI355X addition: per block 0 = the first writer of its whole row (column) range, 1 = every row (column) of its range has been written by
+  /// earlier blocks; empty = no such plan (a block's range is partly new, or some row has no writer): fill + accumulate as the reference does
+  std::vector<char> row_plan_, col_plan_;
 
   template <typename U> friend class DualLinearOperator;
 };

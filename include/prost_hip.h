@@ -147,6 +147,11 @@ int prost_hip_sparse_kron_id_acc_f32(float* res, const float* rhs, size_t diagle
 int prost_hip_sparse_kron_id_acc_f64(double* res, const double* rhs, size_t diaglength, size_t nrows, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 int prost_hip_id_kron_sparse_acc_f32(float* res, const float* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 int prost_hip_id_kron_sparse_acc_f64(double* res, const double* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+/* (ABI 8) res = ... : the non-accumulating forms (the zero fill of Block::EvalLocal folded into the product) */
+int prost_hip_sparse_kron_id_f32(float* res, const float* rhs, size_t diaglength, size_t nrows, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_sparse_kron_id_f64(double* res, const double* rhs, size_t diaglength, size_t nrows, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_id_kron_sparse_f32(float* res, const float* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
+int prost_hip_id_kron_sparse_f64(double* res, const double* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr, const int32_t* ind, void* stream);
 /* x = beta * x (beta == 0 -> zero fill): thrust::fill / transform at linearoperator.cu:140-147 */
 /* x[i] = value (thrust::fill, linearoperator.cu:140-147; also used for preconditioners that are one constant: the
  * gradient blocks' row / column sums are, block_gradient2d.cu:154-163, so nothing is uploaded for them) */

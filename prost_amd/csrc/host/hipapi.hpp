@@ -21,6 +21,8 @@ template <typename T> struct Api;
     static constexpr auto scale = prost_hip_scale_##S;                            \
     static constexpr auto sparse_kron_id_acc = prost_hip_sparse_kron_id_acc_##S;  \
     static constexpr auto id_kron_sparse_acc = prost_hip_id_kron_sparse_acc_##S;  \
+    static constexpr auto sparse_kron_id = prost_hip_sparse_kron_id_##S;          \
+    static constexpr auto id_kron_sparse = prost_hip_id_kron_sparse_##S;          \
     static constexpr auto prox_elem = prost_hip_prox_elem_##S;                    \
     static constexpr auto prox_elem_moreau = prost_hip_prox_elem_moreau_##S;      \
     static constexpr auto prox_elem_arg = prost_hip_prox_elem_arg_##S;            \

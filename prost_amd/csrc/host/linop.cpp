@@ -329,6 +329,18 @@ void BlockKronSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
   if (id_first_) CheckHip(Api<T>::id_kron_sparse_acc(r, x, diaglength_, mat_ncols_, mat_nrows_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "id_kron_sparse_acc");
   else CheckHip(Api<T>::sparse_kron_id_acc(r, x, diaglength_, mat_ncols_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "sparse_kron_id_acc");
 }
+template <typename T>
+void BlockKronSparse<T>::EvalLocal(T* r, T*, const T* x, const T*) {
+  if (ptr_.size() != host_ptr_.size()) throw Exception("BlockKronSparse used before Initialize().");
+  if (id_first_) CheckHip(Api<T>::id_kron_sparse(r, x, diaglength_, mat_nrows_, mat_ncols_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "id_kron_sparse");
+  else CheckHip(Api<T>::sparse_kron_id(r, x, diaglength_, mat_nrows_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "sparse_kron_id");
+}
+template <typename T>
+void BlockKronSparse<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) {
+  if (ptr_t_.size() != host_ptr_t_.size()) throw Exception("BlockKronSparse used before Initialize().");
+  if (id_first_) CheckHip(Api<T>::id_kron_sparse(r, x, diaglength_, mat_ncols_, mat_nrows_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "id_kron_sparse");
+  else CheckHip(Api<T>::sparse_kron_id(r, x, diaglength_, mat_ncols_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "sparse_kron_id");
+}
 template class BlockKronSparse<float>;
 template class BlockKronSparse<double>;
 
@@ -420,6 +432,29 @@ void LinearOperator<T>::InitializeHost() {
   for (auto& b : blocks_) { rr.emplace_back(b->row(), b->nrows()); cc.emplace_back(b->col(), b->ncols()); }
   rows_exclusive_ = !blocks_.empty() && ranges_partition(rr, nrows_);
   cols_exclusive_ = !blocks_.empty() && ranges_partition(cc, ncols_);
+  // first writers and pure accumulators, in list order (the order LinearOperator::Eval accumulates in): a first writer runs its
+  // non-accumulating product (0 + sum: the bits of fill + accumulate), nobody fills
+  auto plan = [](const std::vector<std::pair<size_t, size_t>>& r, size_t total, std::vector<char>& out) {
+    out.clear();
+    std::vector<std::pair<size_t, size_t>> done;                      // disjoint [begin, end) ranges already written, sorted
+    std::vector<char> p;
+    for (const auto& q : r) {
+      const size_t b = q.first, e = q.first + q.second;
+      size_t covered = 0;
+      for (const auto& d : done) { const size_t lo = std::max(b, d.first), hi = std::min(e, d.second); if (lo < hi) covered += hi - lo; }
+      if (covered == 0) { p.push_back(0); done.emplace_back(b, e); }
+      else if (covered == e - b) p.push_back(1);
+      else return;                                                    // partly new: no plan
+      // (merge: keep `done` disjoint)
+      std::sort(done.begin(), done.end());
+      std::vector<std::pair<size_t, size_t>> m;
+      for (const auto& d : done) { if (!m.empty() && d.first <= m.back().second) m.back().second = std::max(m.back().second, d.second); else m.push_back(d); }
+      done.swap(m);
+    }
+    if (done.size() == 1 && done[0].first == 0 && done[0].second == total) out.swap(p);
+  };
+  plan(rr, nrows_, row_plan_);
+  plan(cc, ncols_, col_plan_);
 }
 template <typename T>
 void LinearOperator<T>::Initialize() {
@@ -445,6 +480,10 @@ void LinearOperator<T>::Eval(device_vector<T>& result, const device_vector<T>& r
     for (size_t i = 1; i < blocks_.size(); i++) blocks_[i]->EvalAdd(result.data(), rhs.data());
     return;
   }
+  if (beta == 0 && row_plan_.size() == blocks_.size() && !blocks_.empty() && result.size() == nrows_) {
+    for (size_t i = 0; i < blocks_.size(); i++) { if (row_plan_[i]) blocks_[i]->EvalAdd(result.data(), rhs.data()); else blocks_[i]->Eval(result.data(), rhs.data()); }
+    return;
+  }
   ApplyBeta(result, beta, false);
   for (auto& b : blocks_) b->EvalAdd(result.data(), rhs.data());
 }
@@ -457,6 +496,10 @@ void LinearOperator<T>::EvalAdjoint(device_vector<T>& result, const device_vecto
   if (beta == 0 && !blocks_.empty() && blocks_[0]->col() == 0 && blocks_[0]->ncols() == ncols_ && result.size() == ncols_) {
     blocks_[0]->EvalAdjoint(result.data(), rhs.data());
     for (size_t i = 1; i < blocks_.size(); i++) blocks_[i]->EvalAdjointAdd(result.data(), rhs.data());
+    return;
+  }
+  if (beta == 0 && col_plan_.size() == blocks_.size() && !blocks_.empty() && result.size() == ncols_) {
+    for (size_t i = 0; i < blocks_.size(); i++) { if (col_plan_[i]) blocks_[i]->EvalAdjointAdd(result.data(), rhs.data()); else blocks_[i]->EvalAdjoint(result.data(), rhs.data()); }
     return;
   }
   ApplyBeta(result, beta, false);

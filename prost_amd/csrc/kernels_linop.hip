@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(kBlock) csr_spmv_kernel(T* __restrict__ res, c
 template <class T, bool ACC>
 static int launch_csr(T* res, const T* rhs, size_t nrows, size_t nnz, const T* val, const int32_t* ptr, const int32_t* ind, void* stream) {
   if (nrows == 0) return 0;
-  const double mean = (double)nnz / (double)nrows;
+  const double mean = (double)nnz / (double)nrows;      // (example_deblurring.m's 35-tap rows, same box: 1 / 4 / 16 / 64 lanes per row = 593 / 3 969 / 4 853 / 2 319 iterations/s)
   hipStream_t s = as_stream(stream);
   if (mean <= 6.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 1, ACC>), dim3(grid_for(nrows)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
   else if (mean <= 24.0) hipLaunchKernelGGL((csr_spmv_kernel<T, 4, ACC>), dim3(grid_for(nrows * 4)), dim3(kBlock), 0, s, res, rhs, nrows, val, ptr, ind);
@@ -598,7 +598,7 @@ static int launch_csr(T* res, const T* rhs, size_t nrows, size_t nnz, const T* v
 // (ptr / ind / val are wave-uniform broadcasts) and read d-contiguous rhs entries -> fully coalesced.
 // kron(I, K): consecutive lanes own consecutive rows of one K copy (a gather, as in the reference).
 // ------------------------------------------------------------------------------------------
-template <class T, bool ID_FIRST>
+template <class T, bool ID_FIRST, bool ACC>
 __global__ void __launch_bounds__(kBlock) kron_spmv_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t diaglength, size_t nrows,
                                                            size_t ncols, const float* __restrict__ val, const int32_t* __restrict__ ptr,
                                                            const int32_t* __restrict__ ind) {
@@ -610,17 +610,19 @@ __global__ void __launch_bounds__(kBlock) kron_spmv_kernel(T* __restrict__ res, 
     T sum = 0;
     const int32_t stop = ptr[row + 1];
     for (int32_t i = ptr[row]; i < stop; i++) sum += val[i] * rhs[ID_FIRST ? (size_t)ind[i] + col_ofs : (size_t)ind[i] * diaglength + col_ofs];
-    res[tx] += sum;
+    res[tx] = (ACC ? res[tx] : (T)0) + sum;       // ACC = false: the zero fill + accumulate of Block::EvalLocal in one pass
   }
 }
 
 template <class T>
 static int launch_kron(bool id_first, T* res, const T* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr,
-                       const int32_t* ind, void* stream) {
+                       const int32_t* ind, void* stream, bool acc = true) {
   const size_t total = diaglength * nrows;
   if (total == 0) return 0;
-  if (id_first) hipLaunchKernelGGL((kron_spmv_kernel<T, true>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
-  else hipLaunchKernelGGL((kron_spmv_kernel<T, false>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
+  if (id_first && acc) hipLaunchKernelGGL((kron_spmv_kernel<T, true, true>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
+  else if (id_first) hipLaunchKernelGGL((kron_spmv_kernel<T, true, false>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
+  else if (acc) hipLaunchKernelGGL((kron_spmv_kernel<T, false, true>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
+  else hipLaunchKernelGGL((kron_spmv_kernel<T, false, false>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
   PH_LAUNCH_END("kronecker spmv kernel");
 }
 
@@ -667,6 +669,10 @@ int prost_hip_sparse_kron_id_acc_f32(float* r, const float* x, size_t d, size_t 
 int prost_hip_sparse_kron_id_acc_f64(double* r, const double* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(false, r, x, d, nrows, 0, v, p, i, s); }
 int prost_hip_id_kron_sparse_acc_f32(float* r, const float* x, size_t d, size_t nrows, size_t ncols, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(true, r, x, d, nrows, ncols, v, p, i, s); }
 int prost_hip_id_kron_sparse_acc_f64(double* r, const double* x, size_t d, size_t nrows, size_t ncols, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(true, r, x, d, nrows, ncols, v, p, i, s); }
+int prost_hip_sparse_kron_id_f32(float* r, const float* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(false, r, x, d, nrows, 0, v, p, i, s, false); }
+int prost_hip_sparse_kron_id_f64(double* r, const double* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(false, r, x, d, nrows, 0, v, p, i, s, false); }
+int prost_hip_id_kron_sparse_f32(float* r, const float* x, size_t d, size_t nrows, size_t ncols, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(true, r, x, d, nrows, ncols, v, p, i, s, false); }
+int prost_hip_id_kron_sparse_f64(double* r, const double* x, size_t d, size_t nrows, size_t ncols, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(true, r, x, d, nrows, ncols, v, p, i, s, false); }
 
 int prost_hip_scale_f32(float* x, size_t n, double beta, void* s) { return launch_scale<float>(x, n, beta, s); }
 int prost_hip_scale_f64(double* x, size_t n, double beta, void* s) { return launch_scale<double>(x, n, beta, s); }
