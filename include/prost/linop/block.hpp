@@ -34,6 +34,7 @@ struct BlockDesc {
   // device -- ids / ids_t non-null then, and val .. ind / val_t .. ind_t null (each direction on its own)
   const uint16_t* ids = nullptr; const int32_t* pptr = nullptr; const int32_t* rel = nullptr; const void* pval = nullptr;
   const uint16_t* ids_t = nullptr; const int32_t* pptr_t = nullptr; const int32_t* rel_t = nullptr; const void* pval_t = nullptr;
+  const int32_t* anchor = nullptr; const int32_t* anchor_t = nullptr;     ///< anchored pattern tables (offsets from anchor[row]); null: from the row number
 };
 
 template <typename T>

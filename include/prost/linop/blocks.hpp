@@ -90,9 +90,9 @@ class BlockSparse : public Block<T> {
     if (!pat_.on && val_.size() != nnz_) return false;          // before Initialize()
     if (!pat_t_.on && val_t_.size() != nnz_) return false;
     d.kind = BlockDesc::kSparse; d.nnz = nnz_;
-    if (pat_.on) { d.ids = pat_.ids.data(); d.pptr = pat_.pptr.data(); d.rel = pat_.rel.data(); d.pval = pat_.val.data(); }
+    if (pat_.on) { d.ids = pat_.ids.data(); d.pptr = pat_.pptr.data(); d.rel = pat_.rel.data(); d.pval = pat_.val.data(); d.anchor = pat_.anchor.size() ? pat_.anchor.data() : nullptr; }
     else { d.val = val_.data(); d.ptr = ptr_.data(); d.ind = ind_.data(); }
-    if (pat_t_.on) { d.ids_t = pat_t_.ids.data(); d.pptr_t = pat_t_.pptr.data(); d.rel_t = pat_t_.rel.data(); d.pval_t = pat_t_.val.data(); }
+    if (pat_t_.on) { d.ids_t = pat_t_.ids.data(); d.pptr_t = pat_t_.pptr.data(); d.rel_t = pat_t_.rel.data(); d.pval_t = pat_t_.val.data(); d.anchor_t = pat_t_.anchor.size() ? pat_t_.anchor.data() : nullptr; }
     else { d.val_t = val_t_.data(); d.ptr_t = ptr_t_.data(); d.ind_t = ind_t_.data(); }
     d.pointwise_planes = pointwise_planes_;
     return true;
@@ -119,8 +119,10 @@ class BlockSparse : public Block<T> {
     device_vector<uint16_t> ids;              ///< pattern number of every row
     device_vector<int32_t> pptr, rel;         ///< entries pptr[id] .. pptr[id + 1] - 1 of the table: column - row ...
     device_vector<T> val;                     ///< ... and value
+    device_vector<int32_t> anchor;            ///< anchored table (matrices between different geometries): offsets count from anchor[row]; empty: from the row number
   };
   RowPatterns pat_, pat_t_;
+  void PatternProduct(const RowPatterns& p, T* r, const T* x, size_t rows, int acc);
 };
 
 /// kron(K, I_d) (id_first == false, block_sparse_kron_id.cu) or kron(I_d, K) (id_first == true,

@@ -139,6 +139,15 @@ int prost_hip_pattern_spmv_f64(double* res, const double* rhs, size_t nrows, con
  * (<= 2^22 rows) consist of; same arithmetic, same bits */
 int prost_hip_pattern_spmv_tab_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int npatterns, int nentries, int acc, void* stream);
 int prost_hip_pattern_spmv_tab_f64(double* res, const double* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int npatterns, int nentries, int acc, void* stream);
+/* (ABI 8) ANCHORED row patterns: the table's offsets count from anchor[row] (int32, padded like ids to a multiple of 4 rows, 16-byte aligned) instead
+ * of from the row number: rows of equal SHAPE share a pattern also where the matrix maps between different geometries -- convmtx2's FULL
+ * convolution in example_deblurring.m:15-16 (the blurred image is larger than the sharp one: column - row drifts by ky - 1 per image
+ * column), restrictions / prolongations, rectangular crops.  Entry k of row r multiplies rhs[anchor[r] + rel[k]].  6 bytes per row instead
+ * of 8 per entry.  Same sums in the same order as prost_hip_csr_spmv with one lane per row. */
+int prost_hip_pattern_spmv_anchored_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* anchor, const int32_t* pptr, const int32_t* rel,
+                                        const float* pval, int npatterns, int nentries, int acc, void* stream);
+int prost_hip_pattern_spmv_anchored_f64(double* res, const double* rhs, size_t nrows, const uint16_t* ids, const int32_t* anchor, const int32_t* pptr, const int32_t* rel,
+                                        const double* pval, int npatterns, int nentries, int acc, void* stream);
 /* res += kron(K, I_d) rhs (BlockSparseKronIdKernel, src/linop/block_sparse_kron_id.cu:26-49) and
  * res += kron(I_d, K) rhs (BlockIdKronSparseKernel, src/linop/block_id_kron_sparse.cu:26-52); K (nrows x ncols)
  * in CSR with int32 indices and FLOAT values for both T (:36, :79).  The adjoint is the same call
@@ -707,6 +716,9 @@ typedef struct prost_hip_op_block {
    * (column - row, value) sequences) instead of CSR arrays, for K and / or K^T; ids / ids_t NULL: the CSR arrays above */
   const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval;
   const uint16_t* ids_t; const int32_t* pptr_t; const int32_t* rel_t; const void* pval_t;
+  /* (ABI 8) ANCHORED tables: the offsets of a pattern count from anchor[row] (the row's first column) instead of from the row number
+   * (prost_hip_pattern_spmv_anchored); NULL: offsets relative to the row */
+  const int32_t* anchor; const int32_t* anchor_t;
 } prost_hip_op_block;
 #define PROST_HIP_OP_MAX_BLOCKS 4
 typedef struct prost_hip_fused_op {

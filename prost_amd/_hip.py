@@ -49,7 +49,8 @@ class OpBlock(C.Structure):
                 ("nx", C.c_uint64), ("ny", C.c_uint64), ("L", C.c_uint64),
                 ("val", C.c_void_p), ("ptr", C.c_void_p), ("ind", C.c_void_p), ("val_t", C.c_void_p), ("ptr_t", C.c_void_p), ("ind_t", C.c_void_p),
                 ("ids", C.c_void_p), ("pptr", C.c_void_p), ("rel", C.c_void_p), ("pval", C.c_void_p),          # ABI 7: row patterns of K ...
-                ("ids_t", C.c_void_p), ("pptr_t", C.c_void_p), ("rel_t", C.c_void_p), ("pval_t", C.c_void_p)]    # ... and of K^T (NULL: CSR)
+                ("ids_t", C.c_void_p), ("pptr_t", C.c_void_p), ("rel_t", C.c_void_p), ("pval_t", C.c_void_p),    # ... and of K^T (NULL: CSR)
+                ("anchor", C.c_void_p), ("anchor_t", C.c_void_p)]                                                # ABI 8: anchored tables (NULL: offsets from the row number)
 
 
 class FusedOp(C.Structure):

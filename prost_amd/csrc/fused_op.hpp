@@ -17,6 +17,7 @@ struct OpBlockDev {
   // (entries pptr[id] .. pptr[id + 1] - 1: column - row in rel, value in pval); ids / ids_t null: the CSR arrays above
   const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval;
   const uint16_t* ids_t; const int32_t* pptr_t; const int32_t* rel_t; const void* pval_t;
+  const int32_t* anchor; const int32_t* anchor_t;      // anchored tables (pattern_rows); null: offsets count from the row number
 };
 struct FusedOpDev { int nblocks; OpBlockDev b[PROST_HIP_OP_MAX_BLOCKS]; };
 
@@ -93,7 +94,8 @@ __device__ __forceinline__ void csr_contrib(const T* __restrict__ val, const int
 template <class T, int VEC> struct OpPack { typedef T V __attribute__((ext_vector_type(VEC), aligned(sizeof(T)))); };
 template <class T, int VEC, int NR>
 __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, const PROST_CONSTANT int32_t* __restrict__ pptr, const PROST_CONSTANT int32_t* __restrict__ rel,
-                                             const PROST_CONSTANT T* __restrict__ pval, const T* const (&rhs)[NR], size_t r0, T (&sum)[NR][VEC]) {
+                                             const PROST_CONSTANT T* __restrict__ pval, const T* const (&rhs)[NR], size_t r0, T (&sum)[NR][VEC],
+                                             const int32_t* __restrict__ anchor = nullptr) {
   typedef typename OpPack<T, VEC>::V PV;
   constexpr int kB = NR == 1 ? 6 : 4;                              // entries per batch: kB * NR operand loads of VEC elements in flight
   unsigned id[VEC];
@@ -103,6 +105,25 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
   } else {
 #pragma unroll
     for (int j = 0; j < VEC; j++) id[j] = ids[r0 + j];
+  }
+  // ANCHORED tables (round 5; anchor != null): the offsets of a pattern count from anchor[row] -- the row's first column -- instead of from
+  // the row number, so matrices whose range and domain have different geometry (convmtx2's FULL convolution of example_deblurring.m: the
+  // output image is larger than the input, column - row drifts by 14 per image column) repeat their patterns as well.  Consecutive rows of
+  // an image column have consecutive anchors: the 16-byte operand loads stay, a lane whose anchors are not consecutive goes row by row.
+  long base[VEC];
+  bool consec = true;
+  if (anchor) {
+    int32_t an[VEC];
+    if (VEC == 4) { const int4 w = *reinterpret_cast<const int4*>(anchor + r0); an[0] = w.x; an[1 % VEC] = w.y; an[2 % VEC] = w.z; an[3 % VEC] = w.w; }
+    else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) an[j] = anchor[r0 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { base[j] = (long)an[j]; consec = consec && an[j] == an[0] + j; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) base[j] = (long)(r0 + j);
   }
 #pragma unroll
   for (int q = 0; q < NR; q++)
@@ -132,18 +153,18 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
 #pragma unroll
         for (int u = 0; u < kB; u++) { const int32_t k = k0 + u < e ? k0 + u : e - 1; r[u] = (long)rel[k]; v[u] = pval[k]; }
         PV x[NR][kB];
-        if (all) {
+        if (all && consec) {
 #pragma unroll
           for (int u = 0; u < kB; u++)
 #pragma unroll
-            for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + (long)r0 + r[u]);
+            for (int q = 0; q < NR; q++) x[q][u] = *reinterpret_cast<const PV*>(rhs[q] + base[0] + r[u]);
         } else {
 #pragma unroll
           for (int u = 0; u < kB; u++)
 #pragma unroll
             for (int q = 0; q < NR; q++)
 #pragma unroll
-              for (int j = 0; j < VEC; j++) x[q][u][j] = rhs[q][mine[j] ? (long)(r0 + j) + r[u] : 0L];     // (element 0: always there, never used)
+              for (int j = 0; j < VEC; j++) x[q][u][j] = rhs[q][mine[j] ? base[j] + r[u] : 0L];     // (element 0: always there, never used)
         }
 #pragma unroll
         for (int u = 0; u < kB; u++) {
@@ -164,7 +185,7 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       T s = 0;
-      for (int32_t k = b; k < e; k++) s += pval[k] * rhs[q][(long)(r0 + j) + (long)rel[k]];
+      for (int32_t k = b; k < e; k++) s += pval[k] * rhs[q][base[j] + (long)rel[k]];
       sum[q][j] = s;
     }
   }
@@ -179,14 +200,15 @@ __device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, c
 // at one of them.  Left to itself the compiler sinks every load to its first use behind the branch in front of it -- load, wait, compare,
 // branch, load, wait ... six or seven scalar round trips per block and wavefront before the first operand is requested (the prox launches
 // of the generic path spent two thirds of a wavefront's life in s_waitcnt lgkmcnt(0)).
-struct OpHead { int kind; unsigned long long row, col, nrows, ncols, nx, ny, L; const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval; };
+struct OpHead { int kind; unsigned long long row, col, nrows, ncols, nx, ny, L; const uint16_t* ids; const int32_t* pptr; const int32_t* rel; const void* pval; const int32_t* anchor; };
 template <bool ADJ>
 __device__ __forceinline__ OpHead op_head(const PROST_CONSTANT OpBlockDev& B) {
   OpHead h;
   h.kind = B.kind; h.row = B.row; h.col = B.col; h.nrows = B.nrows; h.ncols = B.ncols; h.nx = B.nx; h.ny = B.ny; h.L = B.L;
   h.ids = ADJ ? B.ids_t : B.ids; h.pptr = ADJ ? B.pptr_t : B.pptr; h.rel = ADJ ? B.rel_t : B.rel; h.pval = ADJ ? B.pval_t : B.pval;
+  h.anchor = ADJ ? B.anchor_t : B.anchor;
   asm volatile("" : : "s"(h.kind), "s"(h.row), "s"(h.col), "s"(h.nrows), "s"(h.ncols), "s"(h.nx), "s"(h.ny), "s"(h.L), "s"(h.ids), "s"(h.pptr), "s"(h.rel),
-               "s"(h.pval));
+               "s"(h.pval), "s"(h.anchor));
   return h;
 }
 
@@ -208,7 +230,7 @@ __device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& o
         const T* rhs[NR];
 #pragma unroll
         for (int q = 0; q < NR; q++) rhs[q] = t[q] + H.col;
-        pattern_rows<T, VEC, NR>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rhs, r, sum);
+        pattern_rows<T, VEC, NR>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rhs, r, sum, H.anchor);
       } else {
 #pragma unroll
         for (int q = 0; q < NR; q++) csr_contrib<T, VEC>(static_cast<const T*>(B.val), B.ptr, B.ind, t[q] + H.col, r, w0 - H.row, whole, sum[q]);
@@ -279,7 +301,7 @@ __device__ __forceinline__ void op_adj_cols(const PROST_CONSTANT FusedOpDev& op,
       T sum[1][VEC];
       if (H.ids) {
         const T* rr[1] = {rhs};
-        pattern_rows<T, VEC, 1>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rr, cidx, sum);
+        pattern_rows<T, VEC, 1>(H.ids, as_constant(H.pptr), as_constant(H.rel), as_constant_of<T>(H.pval), rr, cidx, sum, H.anchor);
       } else csr_contrib<T, VEC>(static_cast<const T*>(B.val_t), B.ptr_t, B.ind_t, rhs, cidx, w0 - H.col, whole, sum[0]);
 #pragma unroll
       for (int j = 0; j < VEC; j++) v[j] = v[j] + sum[0][j];
@@ -360,6 +382,7 @@ inline FusedOpDev make_op(const prost_hip_fused_op* op) {
     D.kind = B.kind; D.row = B.row; D.col = B.col; D.nrows = B.nrows; D.ncols = B.ncols; D.nx = B.nx; D.ny = B.ny; D.L = B.L;
     D.val = B.val; D.ptr = B.ptr; D.ind = B.ind; D.val_t = B.val_t; D.ptr_t = B.ptr_t; D.ind_t = B.ind_t;
     D.ids = B.ids; D.pptr = B.pptr; D.rel = B.rel; D.pval = B.pval; D.ids_t = B.ids_t; D.pptr_t = B.pptr_t; D.rel_t = B.rel_t; D.pval_t = B.pval_t;
+    D.anchor = B.ids ? B.anchor : nullptr; D.anchor_t = B.ids_t ? B.anchor_t : nullptr;
   }
   return o;
 }

@@ -178,12 +178,12 @@ void BackendADMM<T>::DescribeOperator() {
     o.row = b->row(); o.col = b->col(); o.nrows = b->nrows(); o.ncols = b->ncols();
     o.nx = o.ny = o.L = 0;
     o.val = o.val_t = nullptr; o.ptr = o.ind = o.ptr_t = o.ind_t = nullptr;
-    o.ids = o.ids_t = nullptr; o.pptr = o.rel = o.pptr_t = o.rel_t = nullptr; o.pval = o.pval_t = nullptr;
+    o.ids = o.ids_t = nullptr; o.pptr = o.rel = o.pptr_t = o.rel_t = nullptr; o.pval = o.pval_t = nullptr; o.anchor = o.anchor_t = nullptr;
     if (bd.kind == BlockDesc::kSparse) {
       if ((double)bd.nnz > 6.0 * (double)b->nrows() || (double)bd.nnz > 6.0 * (double)b->ncols()) return;
       o.kind = PROST_OP_CSR;
       o.val = bd.val; o.ptr = bd.ptr; o.ind = bd.ind; o.val_t = bd.val_t; o.ptr_t = bd.ptr_t; o.ind_t = bd.ind_t;
-      o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t;
+      o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t; o.anchor = bd.anchor; o.anchor_t = bd.anchor_t;
     } else if ((bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D) && !bd.label_first) {
       o.kind = bd.kind == BlockDesc::kGradient2D ? PROST_OP_GRAD2D : PROST_OP_GRAD3D;
       o.nx = bd.nx; o.ny = bd.ny; o.L = bd.L;

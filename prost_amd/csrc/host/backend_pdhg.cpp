@@ -804,7 +804,7 @@ bool BackendPDHG<T>::DescribeGenericOperator(bool stencils_only) {
       // iterations/s at 512 x 512 x 3 -- so such operators keep the separate products under every option)
       if (!(bd.ids && bd.ids_t) && bd.nnz > 6 * std::min(b->nrows(), b->ncols())) return false;
       o.val = bd.val; o.ptr = bd.ptr; o.ind = bd.ind; o.val_t = bd.val_t; o.ptr_t = bd.ptr_t; o.ind_t = bd.ind_t;
-      o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t;
+      o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t; o.anchor = bd.anchor; o.anchor_t = bd.anchor_t;
     } else if ((bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D) && !bd.label_first) {
       o.kind = bd.kind == BlockDesc::kGradient2D ? PROST_OP_GRAD2D : PROST_OP_GRAD3D;
       o.nx = bd.nx; o.ny = bd.ny; o.L = bd.L;

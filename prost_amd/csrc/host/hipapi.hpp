@@ -17,6 +17,7 @@ template <typename T> struct Api;
     static constexpr auto csr_spmv_acc = prost_hip_csr_spmv_acc_##S;              \
     static constexpr auto csr_spmv = prost_hip_csr_spmv_##S;                      \
     static constexpr auto pattern_spmv = prost_hip_pattern_spmv_tab_##S;          \
+    static constexpr auto pattern_spmv_anchored = prost_hip_pattern_spmv_anchored_##S; \
     static constexpr auto fill = prost_hip_fill_##S;                              \
     static constexpr auto scale = prost_hip_scale_##S;                            \
     static constexpr auto sparse_kron_id_acc = prost_hip_sparse_kron_id_acc_##S;  \

@@ -65,9 +65,11 @@ BlockSparse<T>* BlockSparse<T>::CreateFromCSC(size_t row, size_t col, int m, int
 namespace {
 bool g_sparse_patterns = true;
 template <typename T>
-struct HostRowPatterns { std::vector<uint16_t> ids; std::vector<int32_t> pptr, rel; std::vector<T> val; };
+struct HostRowPatterns { std::vector<uint16_t> ids; std::vector<int32_t> pptr, rel, anchor; std::vector<T> val; };
 template <typename T>
-bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind, const std::vector<T>& val, HostRowPatterns<T>& out) {
+bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::vector<int32_t>& ind, const std::vector<T>& val, HostRowPatterns<T>& out, bool anchored = false) {
+  // anchored: offsets count from the row's FIRST COLUMN instead of from the row number (matrices between different geometries)
+  auto base_of = [&](size_t r) -> int32_t { return anchored ? (ptr[r + 1] > ptr[r] ? ind[ptr[r]] : 0) : (int32_t)r; };
   constexpr size_t kMinRows = 256, kMaxPatterns = 4096, kMaxTable = (size_t)1 << 16;
   if (nrows < kMinRows || ptr.size() != nrows + 1) return false;
   const size_t kSample = std::min<size_t>(4096, nrows), kMaxSampled = kSample / 4;
@@ -78,7 +80,7 @@ bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::
       for (int32_t j = ptr[r]; j < ptr[r + 1]; j++) {
         uint64_t bits = 0;
         std::memcpy(&bits, &val[j], sizeof(T));
-        h = (h ^ (uint64_t)(uint32_t)(ind[j] - (int32_t)r)) * 1099511628211ull; h ^= h >> 29;
+        h = (h ^ (uint64_t)(uint32_t)(ind[j] - base_of(r))) * 1099511628211ull; h ^= h >> 29;
         h = (h ^ bits) * 1099511628211ull; h ^= h >> 31;
       }
       sig[r] = h;
@@ -115,7 +117,7 @@ bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::
     const size_t r = order[k].first;
     number.emplace(order[k].second, (uint32_t)k);
     rep[k] = r;
-    for (int32_t j = ptr[r]; j < ptr[r + 1]; j++) { out.rel.push_back(ind[j] - (int32_t)r); out.val.push_back(val[j]); }
+    for (int32_t j = ptr[r]; j < ptr[r + 1]; j++) { out.rel.push_back(ind[j] - base_of(r)); out.val.push_back(val[j]); }
     out.pptr.push_back((int32_t)out.rel.size());
     if (out.rel.size() > kMaxTable) return false;
   }
@@ -128,12 +130,18 @@ bool BuildRowPatterns(size_t nrows, const std::vector<int32_t>& ptr, const std::
       const int32_t len = ptr[r + 1] - ptr[r];
       bool same = len == ptr[q + 1] - ptr[q];
       for (int32_t j = 0; same && j < len; j++)
-        same = ind[ptr[r] + j] - (int32_t)r == ind[ptr[q] + j] - (int32_t)q && std::memcmp(&val[ptr[r] + j], &val[ptr[q] + j], sizeof(T)) == 0;
+        same = ind[ptr[r] + j] - base_of(r) == ind[ptr[q] + j] - base_of(q) && std::memcmp(&val[ptr[r] + j], &val[ptr[q] + j], sizeof(T)) == 0;
       if (!same) { ok = false; return; }
       out.ids[r] = (uint16_t)id;
     }
   });
   if (!ok) return false;
+  out.anchor.clear();
+  if (anchored) {
+    // an empty row continues the run of the row above it, so that the 4 rows of a lane keep consecutive anchors across it
+    out.anchor.assign((nrows + 3) / 4 * 4, 0);
+    for (size_t r = 0; r < nrows; r++) out.anchor[r] = ptr[r + 1] > ptr[r] ? ind[ptr[r]] : (r ? out.anchor[r - 1] + 1 : 0);
+  }
   return true;
 }
 }  // namespace
@@ -181,8 +189,12 @@ void BlockSparse<T>::Initialize() {
   pat_.on = pat_t_.on = false;
   auto build = [&](RowPatterns& p, size_t nrows, const std::vector<int32_t>& hp, const std::vector<int32_t>& hi, const std::vector<T>& hv) {
     HostRowPatterns<T> h;
-    if (!g_sparse_patterns || !BuildRowPatterns<T>(nrows, hp, hi, hv, h)) return;
+    // (offsets from the row number first -- 2 bytes per row; then from the row's first column -- 6 bytes per row, for matrices that map
+    // between different geometries: convmtx2 of example_deblurring.m)
+    if (!g_sparse_patterns || !(BuildRowPatterns<T>(nrows, hp, hi, hv, h) || BuildRowPatterns<T>(nrows, hp, hi, hv, h, true))) return;
     p.ids = h.ids; p.pptr = h.pptr; p.rel = h.rel; p.val = h.val;
+    p.anchor.clear();
+    if (!h.anchor.empty()) p.anchor = h.anchor;
     p.count = h.pptr.size() - 1;
     p.on = true;
   };
@@ -217,7 +229,7 @@ void BlockSparse<T>::DetectPointwise() {
 template <typename T>
 void BlockSparse<T>::Release() {
   ind_.clear(); ptr_.clear(); val_.clear(); ind_t_.clear(); ptr_t_.clear(); val_t_.clear();
-  for (RowPatterns* p : {&pat_, &pat_t_}) { p->on = false; p->ids.clear(); p->pptr.clear(); p->rel.clear(); p->val.clear(); }
+  for (RowPatterns* p : {&pat_, &pat_t_}) { p->on = false; p->ids.clear(); p->pptr.clear(); p->rel.clear(); p->val.clear(); p->anchor.clear(); }
 }
 template <typename T>
 T BlockSparse<T>::row_sum(size_t row, T alpha) const {
@@ -250,31 +262,38 @@ size_t BlockSparse<T>::gpu_mem_amount() const {
   size_t bytes = 0;
   if (!pat_.on) bytes += nnz_ * (sizeof(int32_t) + sizeof(T)) + (this->nrows() + 1) * sizeof(int32_t);
   if (!pat_t_.on) bytes += nnz_ * (sizeof(int32_t) + sizeof(T)) + (this->ncols() + 1) * sizeof(int32_t);
-  for (const RowPatterns* p : {&pat_, &pat_t_}) bytes += p->ids.size() * sizeof(uint16_t) + (p->pptr.size() + p->rel.size()) * sizeof(int32_t) + p->val.size() * sizeof(T);
+  for (const RowPatterns* p : {&pat_, &pat_t_}) bytes += p->ids.size() * sizeof(uint16_t) + (p->pptr.size() + p->rel.size() + p->anchor.size()) * sizeof(int32_t) + p->val.size() * sizeof(T);
   return bytes;
+}
+template <typename T>
+void BlockSparse<T>::PatternProduct(const RowPatterns& p, T* r, const T* x, size_t rows, int acc) {
+  if (p.anchor.size())
+    CheckHip(Api<T>::pattern_spmv_anchored(r, x, rows, p.ids.data(), p.anchor.data(), p.pptr.data(), p.rel.data(), p.val.data(), (int)p.pptr.size() - 1, (int)p.rel.size(), acc, CurrentStream()), "pattern_spmv_anchored");
+  else
+    CheckHip(Api<T>::pattern_spmv(r, x, rows, p.ids.data(), p.pptr.data(), p.rel.data(), p.val.data(), (int)p.pptr.size() - 1, (int)p.rel.size(), acc, CurrentStream()), "pattern_spmv");
 }
 template <typename T>
 void BlockSparse<T>::EvalLocalAdd(T* r, T*, const T* x, const T*) {
   if (!pat_.on && val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), (int)pat_.pptr.size() - 1, (int)pat_.rel.size(), 1, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_.on) { PatternProduct(pat_, r, x, this->nrows(), 1); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocalAdd(T* r, T*, const T* x, const T*) {
   if (!pat_t_.on && val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), (int)pat_t_.pptr.size() - 1, (int)pat_t_.rel.size(), 1, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_t_.on) { PatternProduct(pat_t_, r, x, this->ncols(), 1); return; }
   CheckHip(Api<T>::csr_spmv_acc(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv_acc");
 }
 template <typename T>
 void BlockSparse<T>::EvalLocal(T* r, T*, const T* x, const T*) {
   if (!pat_.on && val_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->nrows(), pat_.ids.data(), pat_.pptr.data(), pat_.rel.data(), pat_.val.data(), (int)pat_.pptr.size() - 1, (int)pat_.rel.size(), 0, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_.on) { PatternProduct(pat_, r, x, this->nrows(), 0); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->nrows(), nnz_, val_.data(), ptr_.data(), ind_.data(), CurrentStream()), "csr_spmv");
 }
 template <typename T>
 void BlockSparse<T>::EvalAdjointLocal(T* r, T*, const T* x, const T*) {
   if (!pat_t_.on && val_t_.size() != nnz_ && nnz_) throw Exception("BlockSparse used before Initialize().");
-  if (pat_t_.on) { CheckHip(Api<T>::pattern_spmv(r, x, this->ncols(), pat_t_.ids.data(), pat_t_.pptr.data(), pat_t_.rel.data(), pat_t_.val.data(), (int)pat_t_.pptr.size() - 1, (int)pat_t_.rel.size(), 0, CurrentStream()), "pattern_spmv"); return; }
+  if (pat_t_.on) { PatternProduct(pat_t_, r, x, this->ncols(), 0); return; }
   CheckHip(Api<T>::csr_spmv(r, x, this->ncols(), nnz_, val_t_.data(), ptr_t_.data(), ind_t_.data(), CurrentStream()), "csr_spmv");
 }
 template class BlockSparse<float>;

@@ -989,6 +989,7 @@ const FusedOpDev* device_op(const prost_hip_fused_op* op) {
       D.kind = S.kind; D.row = S.row; D.col = S.col; D.nrows = S.nrows; D.ncols = S.ncols; D.nx = S.nx; D.ny = S.ny; D.L = S.L;
       D.val = S.val; D.ptr = S.ptr; D.ind = S.ind; D.val_t = S.val_t; D.ptr_t = S.ptr_t; D.ind_t = S.ind_t;
       D.ids = S.ids; D.pptr = S.pptr; D.rel = S.rel; D.pval = S.pval; D.ids_t = S.ids_t; D.pptr_t = S.pptr_t; D.rel_t = S.rel_t; D.pval_t = S.pval_t;
+      D.anchor = S.anchor; D.anchor_t = S.anchor_t;
     }
   }
   int device = 0;

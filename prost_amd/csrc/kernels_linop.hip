@@ -500,17 +500,18 @@ __global__ void __launch_bounds__(kBlock) pattern_spmv_kernel(T* __restrict__ re
 // Round 5: the same product with the row walk of the fused kernels (fused_op.hpp: pattern_rows) -- a lane takes VEC consecutive rows, the
 // wavefront one pass per distinct pattern among its rows, the table read through the constant address space with scalar loads, the
 // operands of up to six entries in flight together.  Same sums in the same order as pattern_spmv_kernel.
-template <class T, bool ACC>
+template <class T, bool ACC, int VEC>
 __global__ void __launch_bounds__(kBlock) pattern_spmv_rows_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nrows, const uint16_t* __restrict__ ids,
-                                                                    const int32_t* __restrict__ pptr, const int32_t* __restrict__ rel, const T* __restrict__ pval) {
-  constexpr int V = VecOf<T>::N;
+                                                                    const int32_t* __restrict__ pptr, const int32_t* __restrict__ rel, const T* __restrict__ pval,
+                                                                    const int32_t* __restrict__ anchor) {
+  constexpr int V = VEC;
   const size_t nvec = nrows / V;
   const T* rr[1] = {rhs};
   for (size_t g = (size_t)blockIdx.x * kBlock + threadIdx.x; g < nvec; g += (size_t)gridDim.x * kBlock) {
     const size_t r0 = g * V;
     T sum[1][V], o[V];
     if (ACC) ldv<T, V>(res + r0, o);
-    pattern_rows<T, V, 1>(ids, as_constant(pptr), as_constant(rel), as_constant(pval), rr, r0, sum);
+    pattern_rows<T, V, 1>(ids, as_constant(pptr), as_constant(rel), as_constant(pval), rr, r0, sum, anchor);
 #pragma unroll
     for (int j = 0; j < V; j++) o[j] = (ACC ? o[j] : (T)0) + sum[0][j];
     stv<T, V>(res + r0, o);
@@ -518,14 +519,14 @@ __global__ void __launch_bounds__(kBlock) pattern_spmv_rows_kernel(T* __restrict
   if (blockIdx.x == 0 && threadIdx.x < nrows - nvec * V) {              // the last nrows % V rows
     const size_t r0 = nvec * V + threadIdx.x;
     T sum[1][1];
-    pattern_rows<T, 1, 1>(ids, as_constant(pptr), as_constant(rel), as_constant(pval), rr, r0, sum);
+    pattern_rows<T, 1, 1>(ids, as_constant(pptr), as_constant(rel), as_constant(pval), rr, r0, sum, anchor);
     res[r0] = (ACC ? res[r0] : (T)0) + sum[0][0];
   }
 }
 
 template <class T>
 static int launch_pattern(T* res, const T* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const T* pval, int acc, void* stream,
-                          int npatterns = 0, int nentries = 0) {
+                          int npatterns = 0, int nentries = 0, const int32_t* anchor = nullptr) {
   if (nrows == 0) return 0;
   if (!res || !rhs || !ids || !pptr || !rel || !pval) { set_error("pattern spmv: null pointer"); return 1; }
   if (reinterpret_cast<uintptr_t>(ids) % 8 != 0) { set_error("pattern spmv: the pattern numbers must be 8-byte aligned"); return 1; }
@@ -534,13 +535,21 @@ static int launch_pattern(T* res, const T* rhs, size_t nrows, const uint16_t* id
   // box, deblurring's shape with separate products: 256^2 17 992 -> 25 093, 1024^2 11 061 -> 14 344, 2048^2 4 557 -> 5 177 iterations/s.
   // (Requesting the operands of the table's most frequent pattern before the pattern numbers arrive was tried on top of this and in
   // the prox kernels that apply the operator: 3-7 % SLOWER at every size -- with scalar table loads the walk is cheap, the speculation is not)
+  if (anchor && reinterpret_cast<uintptr_t>(anchor) % 16 != 0) { set_error("pattern spmv: the anchors must be 16-byte aligned"); return 1; }
   if (reinterpret_cast<uintptr_t>(res) % 16 == 0) {
     const size_t lanes = nrows / VecOf<T>::N;
     size_t gx = (lanes + kBlock - 1) / kBlock;
     if (gx < 1) gx = 1;
     if (gx > 16384) gx = 16384;
-    if (acc) hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, true>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
-    else hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, false>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval);
+    if (acc) hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, true, VecOf<T>::N>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, anchor);
+    else hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, false, VecOf<T>::N>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, anchor);
+    PH_LAUNCH_END("pattern spmv rows kernel");
+  }
+  if (anchor) {                  // (res not 16-byte aligned: the same walk one row per lane)
+    size_t gx = (nrows + kBlock - 1) / kBlock;
+    if (gx > 65536) gx = 65536;
+    if (acc) hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, true, 1>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, anchor);
+    else hipLaunchKernelGGL((pattern_spmv_rows_kernel<T, false, 1>), dim3((unsigned)gx), dim3(kBlock), 0, s, res, rhs, nrows, ids, pptr, rel, pval, anchor);
     PH_LAUNCH_END("pattern spmv rows kernel");
   }
   const unsigned grid = grid_for((nrows + 7) / 8);
@@ -664,6 +673,16 @@ int prost_hip_pattern_spmv_f32(float* r, const float* x, size_t nrows, const uin
 int prost_hip_pattern_spmv_f64(double* r, const double* x, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int acc, void* s) { return launch_pattern<double>(r, x, nrows, ids, pptr, rel, pval, acc, s); }
 int prost_hip_pattern_spmv_tab_f32(float* r, const float* x, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int npatterns, int nentries, int acc, void* s) { return launch_pattern<float>(r, x, nrows, ids, pptr, rel, pval, acc, s, npatterns, nentries); }
 int prost_hip_pattern_spmv_tab_f64(double* r, const double* x, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int npatterns, int nentries, int acc, void* s) { return launch_pattern<double>(r, x, nrows, ids, pptr, rel, pval, acc, s, npatterns, nentries); }
+int prost_hip_pattern_spmv_anchored_f32(float* r, const float* x, size_t nrows, const uint16_t* ids, const int32_t* anchor, const int32_t* pptr, const int32_t* rel, const float* pval, int npatterns,
+                                        int nentries, int acc, void* s) {
+  if (!anchor) { set_error("pattern spmv: anchors required"); return 1; }
+  return launch_pattern<float>(r, x, nrows, ids, pptr, rel, pval, acc, s, npatterns, nentries, anchor);
+}
+int prost_hip_pattern_spmv_anchored_f64(double* r, const double* x, size_t nrows, const uint16_t* ids, const int32_t* anchor, const int32_t* pptr, const int32_t* rel, const double* pval, int npatterns,
+                                        int nentries, int acc, void* s) {
+  if (!anchor) { set_error("pattern spmv: anchors required"); return 1; }
+  return launch_pattern<double>(r, x, nrows, ids, pptr, rel, pval, acc, s, npatterns, nentries, anchor);
+}
 
 int prost_hip_sparse_kron_id_acc_f32(float* r, const float* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<float>(false, r, x, d, nrows, 0, v, p, i, s); }
 int prost_hip_sparse_kron_id_acc_f64(double* r, const double* x, size_t d, size_t nrows, const float* v, const int32_t* p, const int32_t* i, void* s) { return launch_kron<double>(false, r, x, d, nrows, 0, v, p, i, s); }

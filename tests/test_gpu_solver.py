@@ -1084,13 +1084,23 @@ def _stencil_matrices():
     rng = np.random.default_rng(5)
     nx, ny = 40, 130
     blur = sp.kron(sp.diags([0.25, 0.5, 0.25], [-1, 0, 1], shape=(nx, nx)), sp.diags([0.2, 0.6, 0.2], [-1, 0, 1], shape=(ny, ny))).tocsc()
+    # convmtx2's FULL convolution (example_deblurring.m:15-16): the output image is larger than the input, so column - row drifts from one image
+    # column to the next and only ANCHORED patterns (offsets from the row's first column, round 5) repeat; one and three channels
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import deblurring
+    kernel = np.array([[0.0, 0.1, 0.2], [0.05, 0.3, 0.0], [0.15, 0.0, 0.1], [0.0, 0.05, 0.05]])
+    conv = deblurring.convmtx2(kernel, 66, 30)
+    conv_motion = sp.kron(sp.eye(3), deblurring.convmtx2(deblurring.motion_kernel(9, 45.0), 48, 20)).tocsc()
     return [("gradient2d", spmat_gradient2d(nx, ny, 1), 2), ("gradient2d rgb", spmat_gradient2d(24, 70, 3), 2), ("gradient3d", spmat_gradient3d(12, 30, 14), 2),
-            ("blur", blur, 2), ("random", sp.random(5200, 4100, density=3.0 / 4100, random_state=3, format="csc"), 0)]
+            ("blur", blur, 2), ("full convolution", conv, 2), ("full convolution, motion kernel, rgb", conv_motion, 2),
+            ("random", sp.random(5200, 4100, density=3.0 / 4100, random_state=3, format="csc"), 0)]
 
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 def test_stencils_written_out_as_sparse_matrices_run_from_row_patterns(precision, dtype):
-    """BlockSparse::Initialize recognises rows that repeat a few (column - row, value) sequences and applies such a matrix from one
+    """BlockSparse::Initialize recognises rows that repeat a few (column - row, value) sequences -- or, for matrices between different
+    geometries, (column - first column of the row, value) sequences: anchored tables -- and applies such a matrix from one
     16-bit pattern number per row + a table (prost_hip_pattern_spmv_*): the products and a PDHG solve equal the CSR path's
     (set_quirks(sparse_patterns=0)) and the oracle's bit for bit; a matrix without structure stays CSR."""
     prost.set_precision(precision)
