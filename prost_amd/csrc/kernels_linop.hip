@@ -612,13 +612,18 @@ __global__ void __launch_bounds__(kBlock) kron_spmv_kernel(T* __restrict__ res, 
                                                            size_t ncols, const float* __restrict__ val, const int32_t* __restrict__ ptr,
                                                            const int32_t* __restrict__ ind) {
   const size_t total = diaglength * nrows;
+  // (K's arrays are never written by a kernel: read through the constant address space -- kron(K, I): the row is the same for the lanes of a
+  // wavefront wherever diaglength >= 64, its entries then come through scalar loads)
+  const PROST_CONSTANT float* cval = as_constant(val);
+  const PROST_CONSTANT int32_t* cptr = as_constant(ptr);
+  const PROST_CONSTANT int32_t* cind = as_constant(ind);
   for (size_t tx = (size_t)blockIdx.x * kBlock + threadIdx.x; tx < total; tx += (size_t)gridDim.x * kBlock) {
     size_t row, col_ofs;
     if (ID_FIRST) { row = tx % nrows; col_ofs = (tx / nrows) * ncols; }
     else { col_ofs = tx % diaglength; row = tx / diaglength; }
     T sum = 0;
-    const int32_t stop = ptr[row + 1];
-    for (int32_t i = ptr[row]; i < stop; i++) sum += val[i] * rhs[ID_FIRST ? (size_t)ind[i] + col_ofs : (size_t)ind[i] * diaglength + col_ofs];
+    const int32_t stop = cptr[row + 1];
+    for (int32_t i = cptr[row]; i < stop; i++) sum += cval[i] * rhs[ID_FIRST ? (size_t)cind[i] + col_ofs : (size_t)cind[i] * diaglength + col_ofs];
     res[tx] = (ACC ? res[tx] : (T)0) + sum;       // ACC = false: the zero fill + accumulate of Block::EvalLocal in one pass
   }
 }
