@@ -92,9 +92,9 @@ __device__ __forceinline__ void csr_contrib(const T* __restrict__ val, const int
 // of VEC consecutive operands per lane (element-aligned 16-byte accesses, which gfx950 serves); a wavefront on the seams of a
 // stencil takes one pass per pattern it holds.
 template <class T, int VEC> struct OpPack { typedef T V __attribute__((ext_vector_type(VEC), aligned(sizeof(T)))); };
-template <class T, int VEC, int NR>
-__device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, const PROST_CONSTANT int32_t* __restrict__ pptr, const PROST_CONSTANT int32_t* __restrict__ rel,
-                                             const PROST_CONSTANT T* __restrict__ pval, const T* const (&rhs)[NR], size_t r0, T (&sum)[NR][VEC],
+// (IP / VP: where the table lives -- the constant address space: scalar loads; or LDS, staged by the workgroup: broadcast reads)
+template <class T, int VEC, int NR, class IP, class VP>
+__device__ __forceinline__ void pattern_rows(const uint16_t* __restrict__ ids, IP pptr, IP rel, VP pval, const T* const (&rhs)[NR], size_t r0, T (&sum)[NR][VEC],
                                              const int32_t* __restrict__ anchor = nullptr) {
   typedef typename OpPack<T, VEC>::V PV;
   constexpr int kB = NR == 1 ? 6 : 4;                              // entries per batch: kB * NR operand loads of VEC elements in flight
