@@ -695,8 +695,9 @@ def main():
                 note = ("ADMM has no per-iteration byte figure in SURVEY 8d; frac = COMPULSORY bytes of the dominant kernel of the CG round (every operand read "
                         "or written once, index arrays included: %s) / its launch time / peak.  compulsory_bytes_per_iteration = the same count over EVERY "
                         "kernel of an outer iteration (the stages outside the solve + the CG rounds of the last solve); frac_iteration = value x those bytes "
-                        "/ peak: the whole-iteration figure, launch gaps and the host loop included.  The working set of a solve (~160 MB at 1024^2) exceeds "
-                        "the 32 MB of L2, so the kernels stream from HBM / Infinity Cache." % kname)
+                        "/ peak: the whole-iteration figure, launch gaps and the host loop included.  frac_hbm_traffic = the dominant kernel's PMC traffic "
+                        "(FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_table.json) / its launch time / peak.  The working set of a solve (~160 MB at 1024^2) "
+                        "exceeds the 32 MB of L2, so the kernels stream from HBM / Infinity Cache." % kname)
             else:
                 unit_name = "pixel" if args.config == "c2" else "voxel"
                 cf = compulsory_floats(kname, args.config == "c3")
