@@ -118,6 +118,57 @@ def test_csr_spmv(hip, dtype, density):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("acc", [0, 1])
+def test_pattern_spmv_with_anchored_tables_at_the_c_abi(hip, dtype, acc):
+    """prost_hip_pattern_spmv_anchored (round 5): a matrix between two geometries -- here the FULL 2-D convolution of a 41 x 23 image with a
+    3 x 4 kernel, rows padded with a few empty ones -- as one 16-bit pattern number + one int32 anchor (the row's first column) per row and a
+    table of (column - anchor, value) sequences built HERE with numpy; the product equals the row-by-row CSR sum of the oracle bit for bit,
+    accumulating and not, for an output that is 16-byte aligned (4 / 2 rows per lane) and one that is not (one row per lane)."""
+    import ctypes as C
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    ny, nx, kernel = 41, 23, rng.uniform(-1, 1, (3, 4)).astype(dtype)
+    kernel[1, 2] = 0
+    ky, kx = kernel.shape
+    ny2, nx2 = ny + ky - 1, nx + kx - 1
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    src = (yy + xx * ny).reshape(-1)
+    rows, cols, vals = [], [], []
+    for j in range(kx):
+        for i in range(ky):
+            if kernel[i, j] != 0:
+                rows.append(((yy + i) + (xx + j) * ny2).reshape(-1)); cols.append(src); vals.append(np.full(src.size, kernel[i, j]))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(ny2 * nx2 + 5, ny * nx)).astype(dtype)   # 5 empty rows at the end
+    A.sort_indices()
+    m, n = A.shape
+    ptr, ind, val = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data
+    # the table: patterns numbered in order of first appearance
+    table, ids, anchor = {}, np.zeros((m + 3) // 4 * 4, np.uint16), np.zeros((m + 3) // 4 * 4, np.int32)
+    pptr, rel, pval = [0], [], []
+    for r in range(m):
+        b, e = ptr[r], ptr[r + 1]
+        a0 = int(ind[b]) if e > b else (int(anchor[r - 1]) + 1 if r else 0)
+        key = (tuple((ind[b:e] - a0).tolist()), val[b:e].tobytes())
+        if key not in table:
+            table[key] = len(table)
+            rel.extend((ind[b:e] - a0).tolist()); pval.extend(val[b:e].tolist()); pptr.append(len(rel))
+        ids[r] = table[key]; anchor[r] = a0
+    assert len(table) < 200 and len(rel) < 1024
+    x = rng.standard_normal(n).astype(dtype)
+    base = rng.standard_normal(m).astype(dtype)
+    ref = oracle.csr_spmv_acc(base.copy() if acc else np.zeros(m, dtype), x, A.data, A.indptr, A.indices)
+    d_ids, d_anchor = dev(hip, ids), dev(hip, anchor)
+    d_pptr, d_rel, d_pval, d_x = dev(hip, np.asarray(pptr, np.int32)), dev(hip, np.asarray(rel, np.int32)), dev(hip, np.asarray(pval, dtype)), dev(hip, x)
+    for shift in (0, 1):                       # 1: the output starts one element into its buffer -- not 16-byte aligned
+        buf = np.zeros(m + 1, dtype); buf[shift:shift + m] = base
+        r = dev(hip, buf)
+        out = C.c_void_p(r.ptr.value + shift * np.dtype(dtype).itemsize)
+        hip.check(hip.fn("pattern_spmv_anchored", dtype)(out, d_x.ptr, hip.sz(m), d_ids.ptr, d_anchor.ptr, d_pptr.ptr, d_rel.ptr, d_pval.ptr, len(pptr) - 1, len(rel), acc, None))
+        got = r.to_host()[shift:shift + m]
+        assert np.array_equal(got, ref), (shift, float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("op", [0, 1])
 @pytest.mark.parametrize("fn", oracle.FUNCTIONS)
 def test_prox_elem(hip, dtype, op, fn):
