@@ -89,6 +89,8 @@ def kernel_kind(kname):
     suffix = plus + tail
     if suffix not in ("", "+mid", "+residuals", "+mid+residuals"):
         return None, None
+    if base.startswith("fused_iter2d_xk_kernel<") and base.endswith(">") and base[len("fused_iter2d_xk_kernel<"):-1].isdigit():
+        return ("iter_xk", suffix) if suffix in ("", "+residuals") else (None, None)      # K iterations per launch (tolerance-class arithmetic)
     if not (base.startswith("fused_") and base.endswith("_kernel")):
         return None, None
     core = base[len("fused_"):-len("_kernel")]              # primal2d, dual3d, iter2d, iter2d_mc, iter2d_x2, iter2d_mc_x2, iter3d_x2 ...
@@ -117,6 +119,8 @@ def compulsory_floats(kname, volume):
         return pair if suffix == "" else pair + g + (1 if volume else 0)
     if family == "iter_x2":                                  # +mid: the iterate in between is stored as well (x, y): 10 / 13
         return pair + (1 + g if "+mid" in suffix else 0)
+    if family == "iter_xk":                                  # K iterations per launch: the same 7 values, whatever K
+        return pair
     return None
 
 
@@ -476,6 +480,7 @@ def main():
     ap.add_argument("--residual-iter", type=int, default=None, help="pdhg configs: residual_iter (default 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
+    ap.add_argument("--no-fmad", action="store_true", help="c2 / f32: skip the second leg that runs the same steps with arithmetic='fmad' (value_fmad, roofline_fmad)")
     ap.add_argument("--no-pair", action="store_true", help="one kernel launch per iteration (allow_pair_kernel = false); not the default configuration")
     args = ap.parse_args()
 
@@ -583,25 +588,12 @@ def main():
         backend[1]["allow_pair_kernel"] = False
     opts = prost.options(max_iters=10 ** 9, num_cback_calls=0, verbose=False, tol_rel_primal=0, tol_rel_dual=0,
                          tol_abs_primal=0, tol_abs_dual=0)
-    # code objects are loaded on a kernel's first launch (milliseconds each): run the same kernel instances once on a
-    # tiny problem so that a short --warmup does not pay for that inside or right before the timed region
-    tiny = prost.Solver(cfg["tiny"](), backend, opts)
-    tiny.iterate(24)
-    tiny.destroy()
-    solver = prost.Solver(prob, backend, opts)          # uploads the data, allocates the state in HBM
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed clock-ramp prelude on the real problem: a FIXED number of the same iterations (about 90 ms at the headline
-    # size; every rank must run the same count -- the residual all-reduces pair up across ranks)
-    prelude_iters, t_pre = (cfg["prelude"] if args.prelude_iters is None else args.prelude_iters), time.perf_counter()
-    if prelude_iters > 0:
-        solver.iterate(prelude_iters)
-    prelude_ms = (time.perf_counter() - t_pre) * 1e3
     # launches stamped with events (hipExtLaunchKernel: a start marker in front of the kernel, a stop event bound to the kernel's own
     # command -- the kernel's duration as rocprofv3 reports it).  The marker costs the chain ~3.4 us per stamped launch
     # (tools/stamp_probe.hip, profiles/r04_stamp_probe.txt; events without the system fence), ~3 % of `value` when every launch of the
@@ -609,38 +601,65 @@ def main():
     # between boxes (round-3 review).  Longer runs stamp one launch in four / eight.  (Stop events alone are free but give the launch
     # PERIOD, ~4 us more than the kernel's duration: backend_pdhg.cpp, BeginSample.)
     every = args.sample_every or (1 if args.steps <= 40 else 4 if args.steps <= 160 else 8)
-
-    solver.iterate(args.warmup, checked=True)
-    barrier()
-    t0 = time.perf_counter()
-    info = solver.iterate(args.steps, time_kernels=not args.no_kernel_timing, sample_every=every, checked=True, defer_times=True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    info["kernels"] = solver.kernel_times()          # event pairs recorded inside the timed region, evaluated after it
-
-    # the bare iteration loop (Solver::Iterate: nobody waits for the residual sums), same K, untimed markers off
-    barrier()
-    elapsed_iterate = solver.iterate(args.steps)["ms"] * 1e-3
-    barrier()
-
-    # the timed region proper: the K iterations between the two stream synchronisations INSIDE the native command
-    # (info["ms"]); `elapsed` additionally holds the Python -> C marshalling of the call on both sides (~35 us, 3 % of a
-    # 20-step run) and is reported as wall_ms_python_side
-    t = torch.tensor([info["ms"] * 1e-3, elapsed_iterate, elapsed], dtype=torch.float64)          # CPU tensor: gloo
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, elapsed_iterate, elapsed_py = float(t[0].item()), float(t[1].item()), float(t[2].item())
     units = cfg["units"]
-    if args.config == "c3":
-        # the state is 8 GB at the full size: scalars only, finiteness on three 64 Ki-element windows of x and y read from the device
-        st = solver.state(vectors=False)
-        seg = min(65536, units)
-        probes = [np.asarray(solver.read(v, [0, (ln - seg) // 2, ln - seg], seg)) for v, ln in (("x", units), ("y", 3 * units))]
-        finite = bool(all(np.isfinite(p).all() for p in probes))
-    else:
-        st = solver.state()
-        finite = bool(np.isfinite(st["x"]).all() and np.isfinite(st["y"]).all())
+
+    def run_leg(backend):
+        """tiny warm-up of the code objects, the solver on the real problem, prelude, W warm-up steps, K timed steps (barrier +
+        synchronize on both sides), the bare iteration loop, the state: one measurement of one backend description"""
+        # code objects are loaded on a kernel's first launch (milliseconds each): run the same kernel instances once on a
+        # tiny problem so that a short --warmup does not pay for that inside or right before the timed region
+        tiny = prost.Solver(cfg["tiny"](), backend, opts)
+        tiny.iterate(24)
+        tiny.destroy()
+        solver = prost.Solver(prob, backend, opts)          # uploads the data, allocates the state in HBM
+        # untimed clock-ramp prelude on the real problem: a FIXED number of the same iterations (about 90 ms at the headline
+        # size; every rank must run the same count -- the residual all-reduces pair up across ranks)
+        prelude_iters, t_pre = (cfg["prelude"] if args.prelude_iters is None else args.prelude_iters), time.perf_counter()
+        if prelude_iters > 0:
+            solver.iterate(prelude_iters)
+        prelude_ms = (time.perf_counter() - t_pre) * 1e3
+        solver.iterate(args.warmup, checked=True)
+        barrier()
+        t0 = time.perf_counter()
+        info = solver.iterate(args.steps, time_kernels=not args.no_kernel_timing, sample_every=every, checked=True, defer_times=True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        info["kernels"] = solver.kernel_times()          # event pairs recorded inside the timed region, evaluated after it
+        # the bare iteration loop (Solver::Iterate: nobody waits for the residual sums), same K, untimed markers off
+        barrier()
+        elapsed_iterate = solver.iterate(args.steps)["ms"] * 1e-3
+        barrier()
+        # the timed region proper: the K iterations between the two stream synchronisations INSIDE the native command
+        # (info["ms"]); `elapsed` additionally holds the Python -> C marshalling of the call on both sides (~35 us, 3 % of a
+        # 20-step run) and is reported as wall_ms_python_side
+        t = torch.tensor([info["ms"] * 1e-3, elapsed_iterate, elapsed], dtype=torch.float64)          # CPU tensor: gloo
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if args.config == "c3":
+            # the state is 8 GB at the full size: scalars only, finiteness on three 64 Ki-element windows of x and y read from the device
+            st = solver.state(vectors=False)
+            seg = min(65536, units)
+            probes = [np.asarray(solver.read(v, [0, (ln - seg) // 2, ln - seg], seg)) for v, ln in (("x", units), ("y", 3 * units))]
+            finite = bool(all(np.isfinite(p).all() for p in probes))
+        else:
+            st = solver.state()
+            finite = bool(np.isfinite(st["x"]).all() and np.isfinite(st["y"]).all())
+            st = {k: v for k, v in st.items() if k not in ("x", "y", "z", "w")}
+        solver.destroy()
+        return {"elapsed": float(t[0].item()), "elapsed_iterate": float(t[1].item()), "elapsed_py": float(t[2].item()), "info": info, "st": st,
+                "finite": finite, "prelude_iters": prelude_iters, "prelude_ms": prelude_ms}
+
+    leg = run_leg(backend)
+    elapsed, elapsed_iterate, elapsed_py, info, st, finite = leg["elapsed"], leg["elapsed_iterate"], leg["elapsed_py"], leg["info"], leg["st"], leg["finite"]
+    prelude_iters, prelude_ms = leg["prelude_iters"], leg["prelude_ms"]
     path = st["path"]
+    # the tolerance-class leg (headline config, fp32): the same problem, the same loop, `arithmetic="fmad"` (DESIGN.md section 5;
+    # iterates within the tolerance of tests/test_gpu_fmad.py of the exact ones).  `value` above stays the exact run.
+    leg_fmad = None
+    if args.config == "c2" and args.dtype == "f32" and not args.no_fmad and not args.no_pair:
+        backend_fmad = [backend[0], dict(backend[1])]
+        backend_fmad[1]["arithmetic"] = "fmad"
+        leg_fmad = run_leg(backend_fmad)
 
     if rank == 0:
         value = world * args.steps / elapsed
@@ -672,8 +691,9 @@ def main():
             "prelude_ms": prelude_ms,
             # BASELINE's "achieved HBM GB/s" as SURVEY 8(d) defines it: it/s x the two-pass model's bytes per iteration (738.2 MB at
             # 4096^2 fp32) -- an EQUIVALENT rate (what a two-pass implementation would have to stream), above the 8 TB/s peak for
-            # launches that block two iterations in time; the physical figures are roofline.frac / roofline.frac_hbm_traffic
-            "achieved_hbm_GBps": value * bytes_per_iter / 1e9 if bytes_per_iter else None,
+            # launches that block several iterations in time, hence the name; the physical figures are roofline.achieved (compulsory
+            # bytes) and roofline.achieved_hbm_traffic (PMC traffic)
+            "two_pass_equiv_GBps": value * bytes_per_iter / 1e9 if bytes_per_iter else None,
             "algorithmic_equiv_roofline_frac": value * bytes_per_iter / 1e9 / (HBM_PEAK_GBPS * world) if bytes_per_iter else None,
             "iterates_finite": finite,
         }
@@ -682,13 +702,14 @@ def main():
             out["error"] = "the native RCCL communicator could not be created; the run used the host-callback transport over gloo and does not count"
         if args.config == "c4":
             out["cg_iterations_last_solve"] = st.get("cg_iterations")
-        kern = info.get("kernels", {})
-        if kern:
-            # dominant kernel = largest share of the timed region (mean launch time x launches)
+        def roofline_of(kern, value, st):
+            """the roofline object of one measurement: dominant kernel = largest share of the timed region (mean launch time x launches)"""
+            if not kern:
+                return None, None
             kname = max(kern, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"])
             k = kern[kname]
             ipl = k["iterations_per_launch"]
-            if args.config == "c4":
+            if args.config in ("c4", "c4w"):
                 # ADMM: the kernels of the CG round, each against its own compulsory bytes (SURVEY 8d, generic kernels)
                 comp_bytes = c4_kernel_bytes(kname, units, itemsize)
                 alg_bytes = None
@@ -696,8 +717,8 @@ def main():
                         "or written once, index arrays included: %s) / its launch time / peak.  compulsory_bytes_per_iteration = the same count over EVERY "
                         "kernel of an outer iteration (the stages outside the solve + the CG rounds of the last solve); frac_iteration = value x those bytes "
                         "/ peak: the whole-iteration figure, launch gaps and the host loop included.  frac_hbm_traffic = the dominant kernel's PMC traffic "
-                        "(FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_table.json) / its launch time / peak.  The working set of a solve (~160 MB at 1024^2) "
-                        "exceeds the 32 MB of L2, so the kernels stream from HBM / Infinity Cache." % kname)
+                        "(FETCH_SIZE x 2 + WRITE_SIZE, profiles/traffic_table.json) / its launch time / peak.  At 1024^2 the working set of a solve (~160 MB) "
+                        "fits the 256 MB Infinity Cache, so that traffic is not all HBM traffic; at 2048^2 (--size 2048) it streams from HBM." % kname)
             else:
                 unit_name = "pixel" if args.config == "c2" else "voxel"
                 cf = compulsory_floats(kname, args.config == "c3")
@@ -712,41 +733,70 @@ def main():
                     floats = DUAL_PASS_FLOATS if kernel_kind(kname)[0] == "dual" else ALG_FLOATS_PER_PIXEL - DUAL_PASS_FLOATS
                 alg_bytes = floats * itemsize * units
                 note = ("frac = COMPULSORY bytes of the kernel that ran (%s values per %s per launch: every operand read once, every result written once; "
-                        "one launch = %s iteration(s), the iterate in between never leaves the registers) / launch time / peak: <= 1 by construction.  "
+                        "one launch = %s iteration(s), the iterates in between never leave the registers) / launch time / peak: <= 1 by construction.  "
                         "frac_hbm_traffic = the same with the PMC traffic (FETCH_SIZE x 2 + WRITE_SIZE) in place of the compulsory bytes; traffic / compulsory = "
-                        "the kernel's over-fetch (warm-up columns of a chunk, halo lanes).  algorithmic_equiv_frac = SURVEY 8d's two-pass model (%d values per %s "
-                        "and iteration x the iterations of the launch) over the same time: above 1 because the two-pass model is no lower bound for a launch "
-                        "that blocks two iterations in time.  That the work is done: bit-exact against the CPU oracle at this very size and launch geometry "
-                        "(tests/test_gpu_fullsize.py)." % (cf, unit_name, ipl if ipl else "1/2", afu, unit_name))
+                        "the kernel's over-fetch (warm-up columns of a chunk, halo lanes, cache lines a strip boundary cuts).  algorithmic_equiv_frac = SURVEY "
+                        "8d's two-pass model (%d values per %s and iteration x the iterations of the launch) over the same time: above 1 because the two-pass "
+                        "model is no lower bound for a launch that blocks several iterations in time.  That the work is done: tests/test_gpu_fullsize.py "
+                        "(exact class: bit for bit against the CPU oracle at this very size and launch geometry), tests/test_gpu_fmad.py (tolerance class: "
+                        "within its stated bounds of that oracle at this size)." % (cf, unit_name, ipl if ipl else "1/2", afu, unit_name))
             t_s = k["avg_ms"] * 1e-3
             achieved = comp_bytes / 1e9 / t_s if comp_bytes else None
             traffic, traffic_src = traffic_bytes(kname, cfg["size_key"], k["chunk_cols"], args.dtype)
             phys = traffic / 1e9 / t_s if traffic else None
             alg = alg_bytes / 1e9 / t_s if alg_bytes else None
-            out["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
-                               "frac_hbm_traffic": phys / HBM_PEAK_GBPS if phys else None,
-                               "achieved_hbm_traffic": phys, "traffic_source": traffic_src,
-                               "traffic_over_compulsory": traffic / comp_bytes if traffic and comp_bytes else None,
-                               "algorithmic_equiv_frac": alg / HBM_PEAK_GBPS if alg else None,
-                               "algorithmic_equiv_GBps": alg,
-                               "note": note,
-                               "compulsory_bytes_per_launch": comp_bytes, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k["avg_ms"],
-                               "launches_timed": k["sampled"], "iterations_per_launch": ipl, "chunk_cols": k["chunk_cols"],
-                               "sample_every": every,
-                               "all_kernels": {name: {"avg_launch_ms": v["avg_ms"], "launches": v["launches"], "launches_timed": v["sampled"],
-                                                      "iterations_per_launch": v["iterations_per_launch"], "chunk_cols": v["chunk_cols"],
-                                                      "compulsory_bytes": c4_kernel_bytes(name, units, itemsize) if args.config == "c4"
-                                                      else (compulsory_floats(name, args.config == "c3") or 0) * itemsize * units or None}
-                                               for name, v in kern.items()}}
-            if args.config == "c4":
-                it_bytes = c4_iteration_bytes(path, st.get("cg_iterations") or 0, units, itemsize)
-                out["roofline"]["compulsory_bytes_per_iteration"] = it_bytes
-                out["roofline"]["frac_iteration"] = (value / world) * it_bytes / 1e9 / HBM_PEAK_GBPS if it_bytes else None
-                out["roofline"]["cg_rounds_per_iteration"] = st.get("cg_iterations")
-            if comp_bytes and ipl:
-                # whole-job rate x compulsory bytes per iteration of the dominant kernel / peak: <= roofline.frac (launch gaps, residual launches)
-                out["hbm_roofline_frac"] = (value / world) * (comp_bytes / ipl) / 1e9 / HBM_PEAK_GBPS
+            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": traffic,
+                    "frac_hbm_traffic": phys / HBM_PEAK_GBPS if phys else None,
+                    "achieved_hbm_traffic": phys, "traffic_source": traffic_src,
+                    "traffic_over_compulsory": traffic / comp_bytes if traffic and comp_bytes else None,
+                    "algorithmic_equiv_frac": alg / HBM_PEAK_GBPS if alg else None,
+                    "algorithmic_equiv_GBps": alg,
+                    "note": note,
+                    "compulsory_bytes_per_launch": comp_bytes, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": k["avg_ms"],
+                    "launches_timed": k["sampled"], "iterations_per_launch": ipl, "chunk_cols": k["chunk_cols"],
+                    "sample_every": every,
+                    "all_kernels": {name: {"avg_launch_ms": v["avg_ms"], "launches": v["launches"], "launches_timed": v["sampled"],
+                                           "iterations_per_launch": v["iterations_per_launch"], "chunk_cols": v["chunk_cols"],
+                                           "compulsory_bytes": c4_kernel_bytes(name, units, itemsize) if args.config in ("c4", "c4w")
+                                           else (compulsory_floats(name, args.config == "c3") or 0) * itemsize * units or None}
+                                    for name, v in kern.items()}}
+            if args.config in ("c4", "c4w"):
+                it_bytes = c4_iteration_bytes(st["path"], st.get("cg_iterations") or 0, units, itemsize)
+                roof["compulsory_bytes_per_iteration"] = it_bytes
+                roof["frac_iteration"] = (value / world) * it_bytes / 1e9 / HBM_PEAK_GBPS if it_bytes else None
+                roof["cg_rounds_per_iteration"] = st.get("cg_iterations")
+            # whole-job rate x the compulsory bytes per iteration of the launches that ran / peak: <= roofline.frac (launch gaps, residual
+            # launches, the host's wait for the sums).  Launches of different length (groups of 4, 4 and 2 per residual period) share
+            # one byte count, so the per-iteration figure comes from the launches themselves: bytes x launches / iterations
+            total_it = sum(v["launches"] * v["iterations_per_launch"] for v in kern.values())
+            total_bytes = sum(v["launches"] * ((compulsory_floats(name, args.config == "c3") or 0) * itemsize * units) for name, v in kern.items()) \
+                if args.config not in ("c4", "c4w") else 0
+            whole = (value / world) * (total_bytes / total_it) / 1e9 / HBM_PEAK_GBPS if total_it and total_bytes else None
+            return roof, whole
+
+        roof, whole = roofline_of(info.get("kernels", {}), value, st)
+        if roof:
+            out["roofline"] = roof
+        if whole:
+            out["hbm_roofline_frac"] = whole
+        if leg_fmad is not None:
+            v_f = world * args.steps / leg_fmad["elapsed"]
+            roof_f, whole_f = roofline_of(leg_fmad["info"].get("kernels", {}), v_f, leg_fmad["st"])
+            out["value_fmad"] = v_f
+            out["ms_per_step_fmad"] = 1e3 * leg_fmad["elapsed"] / args.steps
+            out["roofline_fmad"] = roof_f
+            out["fmad"] = {"arithmetic": leg_fmad["st"].get("arithmetic"), "path": leg_fmad["st"]["path"],
+                           "iterations_per_launch_max": leg_fmad["st"].get("iterations_per_launch_max"),
+                           "iterate_only_it_per_s": world * args.steps / leg_fmad["elapsed_iterate"], "iterates_finite": leg_fmad["finite"],
+                           "two_pass_equiv_GBps": v_f * bytes_per_iter / 1e9 if bytes_per_iter else None, "hbm_roofline_frac": whole_f,
+                           "speedup_over_exact": v_f / value,
+                           "tolerance": "tests/test_gpu_fmad.py: one iteration within 2 (x) / 4 (y) ulp at the vector's scale of the exact kernels; "
+                                        "iterates within 1e-5 k (relative to the vector's largest entry) of the CPU oracle after k iterations, "
+                                        "checked at k = 12 and 102 at this size; a solve to 1e-4 stops within one residual period of the exact one",
+                           "note": "the same problem and loop with backend.pdhg(..., arithmetic='fmad'): fused multiply-adds and fp32 reciprocal "
+                                   "instructions (what nvcc's default -fmad=true makes of the reference's kernels), up to 4 iterations per launch "
+                                   "(kernels_fused_iterk.hip).  `value` is the exact-arithmetic run, bit for bit with the CPU oracle."}
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
             if args.config == "c2":
@@ -758,7 +808,6 @@ def main():
     else:
         out = None
 
-    solver.destroy()
     if multi:
         prost.comm_destroy()
         dist.destroy_process_group()

@@ -38,10 +38,15 @@ class BackendPDHG : public Backend<T> {
                                ///< launch); 2: always
     bool allow_speculation;    ///< MI355X addition: the next pair launch is enqueued BEFORE the host waits for the residual sums (alg1 / alg2)
     bool allow_device_rules;   ///< MI355X addition: goldstein / boyd and the stopping test evaluated on the device, one host wait per BATCH of iterations
+    int arithmetic;            ///< MI355X addition (round 6): PROST_HIP_ARITH_EXACT (0, default): every iterate rounds like the reference's expressions
+                               ///< without contraction, bit for bit with the CPU oracle.  PROST_HIP_ARITH_FMAD (1): the fused iteration kernels may
+                               ///< contract multiply-adds (what nvcc's default does to the reference's kernels) and divide through fp32 reciprocal
+                               ///< instructions; where a K-iterations-per-launch kernel exists for the problem (fp32 gray-value ROF / TV-L1 shapes) up
+                               ///< to 4 iterations run per launch.  Iterates within a stated tolerance of the exact ones (tests/test_gpu_fmad.py).
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
                 allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_op_fusion(0), residual_sums_in_prox(1), allow_speculation(true),
-                allow_device_rules(true) {}
+                allow_device_rules(true), arithmetic(PROST_HIP_ARITH_EXACT) {}
   };
 
   explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), pair_kernel_(false), res_dev_(nullptr),
@@ -107,6 +112,19 @@ class BackendPDHG : public Backend<T> {
   void IterationPair(bool store_mid, bool residuals);   // iterations k and k+1 in one launch (prost_hip_fused_iteration2)
   void IterationPairMc(bool residuals);   // the same for gradient2d with 2-4 channels (prost_hip_fused_iteration_mc_x2): k + 2 is not a residual iteration
   void IterationPair3D(bool residuals);   // the same for gradient3d (prost_hip_fused_iteration3d_x2): k + 2 is not a residual iteration
+  /// tolerance-class arithmetic: iterations k .. k+g-1 in one launch (prost_hip_fused_iterationk, 2 <= g <= group_max_); only the last
+  /// one may be a residual iteration (its sums are formed in the kernel)
+  void IterationGroup(int g, bool residuals);
+  /// the launch PerformIterations would make at iteration k with this budget: 0 = no group launch, else its size; `residuals`: its
+  /// last iteration is a residual iteration
+  int GroupSize(size_t k, int budget, bool& residuals) const;
+ public:
+  static constexpr int kGroupMax = 4;
+  /// the arithmetic class the iteration kernels of this solve run in (PROST_HIP_ARITH_*) and the largest launch group (0: none)
+  int arithmetic() const { return group_max_ >= 2 || desc_pair_.arith == PROST_HIP_ARITH_FMAD ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT; }
+  int group_max() const { return group_max_; }
+ private:
+  int group_max_ = 0;
   void RebuildPrevious();                 // x_prev_ / y_prev_ := x^(k-1) / y^(k-1) after a pair that did not store them
   // Speculative next launch.  With alg1 / alg2 nothing on the device depends on the residual sums, but Solver::Solve reads them after
   // every residual iteration: the host wait + the latency of the next launch leave the device idle ~15 us per residual iteration
@@ -120,7 +138,8 @@ class BackendPDHG : public Backend<T> {
   bool spec_valid_ = false;
   size_t spec_launched_ = 0, spec_adopted_ = 0;          // statistics: speculative pair launches / those whose results were exchanged in
   size_t spec_iteration_ = 0;
-  T spec_tau_[3] = {0, 0, 0}, spec_sigma_[3] = {0, 0, 0}, spec_theta_[3] = {0, 0, 0};   // step sizes of iterations k, k+1 and after the pair
+  T spec_tau_[kGroupMax + 1] = {0}, spec_sigma_[kGroupMax + 1] = {0}, spec_theta_[kGroupMax + 1] = {0};   // step sizes of iterations k .. k+g-1 and after the launch
+  int spec_count_ = 2;                    // iterations of the speculative launch
   void* ev_res_local_ = nullptr;          // recorded right after a residual launch (no communicator): what the host waits for
   bool is_residual_iteration(size_t k) const { return k == 0 || (k % (size_t)opts_.residual_iter) == 0; }   // backend_pdhg.cu:389
   void FinishResiduals();                 // all-reduce + D2H enqueued; resolved at once only for residual-driven step rules
@@ -146,7 +165,8 @@ class BackendPDHG : public Backend<T> {
   prost_hip_pdhg_rule_state* rule_mirror_ = nullptr;   // pinned host: the scalars of the last evaluation, fetched at the end of a batch ...
   prost_hip_pdhg_rule_state* rule_mirror_dev_ = nullptr;   // ... from the device copy the rule kernels write
   struct BatchMark { size_t iteration_after, pair_launches; T *x, *xp, *y, *yp; bool prev_stale; T *kx, *kxp, *kty, *ktyp;   // (kx .. ktyp: generic path)
-                     size_t samples = 0, ev_used = 0, launches[8] = {0}; };            // kernel timing as it stood after this launch (kKernelKinds == 8)
+                     size_t samples = 0, ev_used = 0, launches[14] = {0};             // kernel timing as it stood after this launch (kKernelKinds == 14)
+                     int stale_count = 2; bool stale_group = false; };
   std::vector<BatchMark> batch_marks_;     // one per residual iteration of the running batch: the state to return to if it stopped there
   int PerformIterationsDevice(int budget);
   bool failed_ = false;                    // a device-resident batch threw half-way: the iterate on the device is undefined from then on
@@ -175,6 +195,11 @@ class BackendPDHG : public Backend<T> {
   bool residuals_pending_ = false;   // four sums enqueued (device -> pinned host), not yet waited for
   size_t owned_x0_ = 0, owned_x1_ = 0;
   T stale_tau_ = 0, stale_sigma_ = 0, stale_theta_ = 0;   // step sizes of that iteration k
+  // after a group launch: x_prev_ / y_prev_ hold the group's input x^k, y^k and x_ / y_ = x^(k+g); stale_count_ = g and the step sizes
+  // of iterations k+1 .. k+g-2 (iteration k: stale_tau_ ...) -- RebuildPrevious re-runs g - 1 iterations in the same arithmetic
+  int stale_count_ = 2;
+  bool stale_group_ = false;
+  T stale_tau_more_[kGroupMax] = {0}, stale_sigma_more_[kGroupMax] = {0}, stale_theta_more_[kGroupMax] = {0};
   double* res_dev_;        // 4 doubles: primal (diff^2, var^2), dual (diff^2, var^2)
   /// where the reduction kernels put the four sums: the pinned (device-visible) host buffer, or the device
   /// buffer when an RCCL all-reduce has to run on them first
@@ -205,7 +230,8 @@ class BackendPDHG : public Backend<T> {
   T arg_alpha_;
   std::vector<shared_ptr<Prox<T>>> prox_g_, prox_fstar_;
   // kernel timing: event pairs around one launch in eight of every kernel kind
-  enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelPairMid, kKernelPairRes, kKernelPairMidRes, kKernelKinds };
+  enum KernelKind { kKernelPrimal = 0, kKernelDual, kKernelIter, kKernelIterRes, kKernelPair, kKernelPairMid, kKernelPairRes, kKernelPairMidRes,
+                    kKernelGroup2, kKernelGroup3, kKernelGroup4, kKernelGroup2Res, kKernelGroup3Res, kKernelGroup4Res, kKernelKinds };
   bool BeginSample(int kind);
   void EndSample(bool sampled);
   /// a launch that threw between BeginSample and EndSample: the armed event pair is withdrawn (no later launch of this thread

@@ -35,8 +35,12 @@ extern "C" {
  * 6: prost_hip_fused_desc gained f_moreau (appended); additions: event_create_timing; next_launch_events takes (NULL, stop)
  * 7: prost_hip_op_block gained the row-pattern fields, prost_hip_arg_spec the operator source (both appended; callers that filled the
  *    old layouts must zero the new members); prost_hip_cgls_workspace_bytes doubled (order-independent sums: (hi, lo) per partial);
- *    additions: cgls_pixel_round / _close, pixel_op_supported, fused_iteration3d_rec / _3d_pw_rec / _3d_x2_rec, pdhg_fold_sums */
-#define PROST_HIP_ABI_VERSION 8
+ *    additions: cgls_pixel_round / _close, pixel_op_supported, fused_iteration3d_rec / _3d_pw_rec / _3d_x2_rec, pdhg_fold_sums
+ * 8: prost_hip_op_block gained anchor / anchor_t (appended; they must be NULL unless ids / ids_t are set -- callers that filled the old
+ *    layout must zero them); additions: pattern_spmv_anchored_*, pdhg_record_view, the non-accumulating Kronecker entry points
+ * 9: prost_hip_fused_desc gained arith (appended; callers that filled the old layout must zero it = PROST_HIP_ARITH_EXACT);
+ *    additions: fused_iteration2_arith, fused_iteration_mc_x2_arith, fused_iteration3d_x2_arith */
+#define PROST_HIP_ABI_VERSION 9
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
@@ -342,7 +346,16 @@ typedef struct {
                             /* v = arg / (sigma Sigma), r = prox of the described function at v with the step 1 / (sigma Sigma),             */
                             /* result = arg - sigma Sigma r.  Honoured by prost_hip_fused_iteration, _iteration_mc and (square data term with per-pixel b,        */
                             /* 'abs') _iteration2; the others refuse it. */
+  int arith;                /* (ABI 9) PROST_HIP_ARITH_*: the arithmetic class the iteration kernels may use.  EXACT (0): every result    */
+                            /* rounds like the reference's expressions evaluated WITHOUT contraction (the CPU oracle, bit for bit).        */
+                            /* FMAD (1): fused multiply-adds where a product feeds a sum (nvcc's default for the reference's kernels,      */
+                            /* src/CMakeLists.txt:12-24), quotients by 1 + step and by ||v|| through fp32 reciprocal / reciprocal square   */
+                            /* root instructions -- results within the tolerance of tests/test_gpu_fmad.py of the exact ones.  Honoured by */
+                            /* prost_hip_fused_iteration2, _iteration_mc_x2 and _iteration3d_x2 for fp32 ROF / TV-L1 shapes (see           */
+                            /* prost_hip_fused_iteration2_arith); every other entry point and shape computes exactly.                      */
 } prost_hip_fused_desc;
+#define PROST_HIP_ARITH_EXACT 0
+#define PROST_HIP_ARITH_FMAD 1
 /* Folds a BINARY per-element coefficient a of ElemOperation1D (elem_operation_1d.hpp:42-44: a == 0 skips the function, the
  * element passes through) into the b stream: bm[i] = a[i] == 0 ? sentinel : (b ? b[i] : b_val), sentinel = a quiet NaN with the
  * payload 0xA5A5.. that arithmetic never produces (PROST_HIP_MASK_SENTINEL_*).  nonbinary (DEVICE counter, zeroed by the caller)
@@ -406,6 +419,25 @@ int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int 
 /* columns per wavefront (chunk length) a launch with cols_per_block <= 0 uses for this description; 0 if unsupported.
  * Measurement key: the HBM traffic of a launch depends on it (3 warm-up columns are re-read per chunk). */
 int prost_hip_fused_iteration2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals);
+/* (ABI 9) PROST_HIP_ARITH_* of the instance a launch with this description runs: FMAD only where desc->arith asks for it AND a
+ * tolerance-class instance exists (fp32, straight-line ROF / TV-L1 shape, uniform Tau, ind_leq0 radius > 0), EXACT otherwise */
+int prost_hip_fused_iteration2_arith(const prost_hip_fused_desc* desc, int dtype);
+
+/* (ABI 9) K consecutive PerformIteration calls (:313-381; K = 1 .. 6, none of them observed from outside and none but the LAST a
+ * residual iteration) in ONE kernel, tolerance-class arithmetic only (desc->arith == PROST_HIP_ARITH_FMAD): the iterates in between
+ * stay in registers, the launch reads x^k, y^k and b once and writes x^(k+K), y^(k+K) -- 7 floats / pixel per K iterations.
+ * tau / sigma / theta: HOST arrays of K.  res_out4 != NULL: the four residual sums of the last iteration.  gradient2d, L == 1, fp32,
+ * heights that are a multiple of 4, prox_g = 1d:square | 1d:abs with scalar a = 1, d = e = 0, prox_f* = norm2:ind_leq0 with scalar
+ * a = 1, b > 0, d = e = 0.  A launch equals the corresponding sequence of prost_hip_fused_iteration2 launches of the same arithmetic
+ * class bit for bit.  _max: the largest K a description supports (0: none); _rec: step sizes from the device record (ABI 5). */
+int prost_hip_fused_iterationk_max(const prost_hip_fused_desc* desc, int dtype);
+int prost_hip_fused_iterationk_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int k, int with_residuals);
+int prost_hip_fused_iterationk_f32(const prost_hip_fused_desc* desc, int k, float* x_out, float* y_out, const float* x, const float* y,
+                                   const double* tau, const double* sigma, const double* theta, int cols_per_block, double* res_out4,
+                                   void* workspace, void* stream);
+int prost_hip_fused_iterationk_f64(const prost_hip_fused_desc* desc, int k, double* x_out, double* y_out, const double* x, const double* y,
+                                   const double* tau, const double* sigma, const double* theta, int cols_per_block, double* res_out4,
+                                   void* workspace, void* stream);      /* always fails: fp32 only (_max answers 0) */
 
 /* ---- device-resident step sizes for the residual-driven rules (ABI 5; kernels_pdhg_rule.hip) --------------------------------
  * Replaces the host side of BackendPDHG::UpdateResidualsAndStepsizes (backend_pdhg.cu:433-476: sqrt of the four sums, eps_primal /
@@ -519,6 +551,12 @@ int prost_hip_fused_iteration2_rec_f32(const prost_hip_fused_desc* desc, float* 
                                        prost_hip_pdhg_rule_state* mirror, void* stream);
 int prost_hip_fused_iteration2_rec_f64(const prost_hip_fused_desc* desc, double* x_out, double* y_out, const double* x, const double* y, double* x_mid, double* y_mid,
                                        void* record, int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
+                                       prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iterationk_rec_f32(const prost_hip_fused_desc* desc, int k, float* x_out, float* y_out, const float* x, const float* y, void* record,
+                                       int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
+                                       prost_hip_pdhg_rule_state* mirror, void* stream);
+int prost_hip_fused_iterationk_rec_f64(const prost_hip_fused_desc* desc, int k, double* x_out, double* y_out, const double* x, const double* y, void* record,
+                                       int cols_per_block, double* res_out4, void* workspace, int apply_rule, unsigned long long iteration,
                                        prost_hip_pdhg_rule_state* mirror, void* stream);
 
 /* The same iteration with the PLANES ACROSS THE WAVEFRONTS of a workgroup (kernels_fused_iter3d_pw.hip): `waves` - 1

@@ -26,7 +26,7 @@ class FusedDesc(C.Structure):
                 ("g_fn", C.c_int), ("g_coeff_ptr", C.c_void_p * 7), ("g_coeff_val", C.c_double * 7),
                 ("f_fn", C.c_int), ("f_coeff_ptr", C.c_void_p * 7), ("f_coeff_val", C.c_double * 7),
                 ("T_val", C.c_double), ("S_val", C.c_double), ("res_x0", C.c_size_t), ("res_x1", C.c_size_t), ("g_b_masked", C.c_int),
-                ("var_T", C.c_int), ("T_cls", C.c_double * 3), ("f_moreau", C.c_int)]
+                ("var_T", C.c_int), ("T_cls", C.c_double * 3), ("f_moreau", C.c_int), ("arith", C.c_int)]
 
 
 class ArgSpec(C.Structure):
@@ -78,8 +78,8 @@ def lib():
                            "(or make -C prost_amd/csrc)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.prost_hip_last_error.restype = C.c_char_p
-        if L.prost_hip_abi_version() != 8:
-            raise HipError("libprost_hip.so has ABI version %d, this binding needs 8: rebuild (make -C prost_amd/csrc)" % L.prost_hip_abi_version())
+        if L.prost_hip_abi_version() != 9:
+            raise HipError("libprost_hip.so has ABI version %d, this binding needs 9: rebuild (make -C prost_amd/csrc)" % L.prost_hip_abi_version())
         L.prost_hip_reduce_workspace_bytes.restype = C.c_size_t
         L.prost_hip_cgls_state_bytes.restype = C.c_size_t
         L.prost_hip_cgls_workspace_bytes.restype = C.c_size_t

@@ -166,6 +166,15 @@ __device__ __forceinline__ double mul_rcp_pz(double n, double r) { return n * r 
 // min(t, 0) for t that is not NaN (callers: the range-checked fast paths): == (t > 0 ? 0 : t) including t = +-0
 __device__ __forceinline__ float min0(float t) { return __builtin_fminf(t, 0.0f); }
 __device__ __forceinline__ double min0(double t) { return t > 0.0 ? 0.0 : t; }
+// ---- tolerance-class arithmetic (prost_hip_fused_desc.arith = PROST_HIP_ARITH_FMAD) -----------------------
+// one instruction each: v_min_f32 / v_max_f32 (operands are never NaN where these are used) and v_rsq_f32 (1 ulp; +inf for +0,
+// which the callers' min(b * rsq, 1) turns into the factor 1 on a zero vector)
+__device__ __forceinline__ float t_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float t_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double t_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double t_max(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float t_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double t_rsq(double x) { return 1.0 / __builtin_sqrt(x); }
 // value of the neighbouring lane of the 64-lane wavefront: ONE v_mov_b32 with a DPP wavefront shift instead of a
 // ds_bpermute (address VALU + LDS round trip).  lane_up: lane i reads lane i - 1 (lane 0 gets 0); lane_down: lane i
 // reads lane i + 1 (lane 63 gets 0).

@@ -117,6 +117,7 @@ struct FusedArgs {
   int varT;                   // position-dependent primal preconditioner (prost_hip_fused_desc.var_T): Tcls by stencil entries per column
   T Tcls[3];
   int fmor;                   // prox_fstar = Moreau wrap of the described norm2 operation (prost_hip_fused_desc.f_moreau)
+  unsigned strips;            // K-iteration kernel: row strips of the launch (tile order: vertical neighbours are consecutive tiles)
 };
 
 // step size the dual elem operation sees: sigma Sigma, or -- inside a Moreau wrap, which calls it with the inverted flag --
@@ -207,6 +208,7 @@ inline FusedArgs<T> make_fused_args(const prost_hip_fused_desc* d) {
   a.varT = d->var_T ? 1 : 0;
   for (int k = 0; k < 3; k++) a.Tcls[k] = (T)d->T_cls[k];
   a.fmor = d->f_moreau ? 1 : 0;
+  a.strips = 0;
   return a;
 }
 

@@ -30,6 +30,7 @@ template <typename T>
 std::string BackendPDHG<T>::path() const {
   if (!fused_) return "pdhg:generic";
   if (from_matrix_) return "pdhg:fused-grad2d(sparse)";        // the stencil kernels on a gradient handed over as a sparse matrix
+  if (group_max_ >= 2) return "pdhg:fused-grad2d+fmad";       // tolerance-class arithmetic, up to kGroupMax iterations per launch
   return desc_.is3d ? "pdhg:fused-grad3d" : "pdhg:fused-grad2d";
 }
 
@@ -255,6 +256,16 @@ void BackendPDHG<T>::Initialize() {
   // iterate) uses them they are allocated here; the 3-D / multi-channel pair paths without them need a third buffer only to
   // rebuild the previous iterate (RebuildPrevious: read-out, callbacks) and allocate it there -- 4 n + 4 m values less resident
   // at the 2048 x 2048 x 64 size until somebody reads the solution
+  // tolerance-class arithmetic (Options::arithmetic): where the K-iterations-per-launch kernel takes the description, groups of up to
+  // kGroupMax iterations replace the pairs; elsewhere the solve stays exact (exact results satisfy every tolerance)
+  group_max_ = 0; stale_group_ = false; stale_count_ = 2;
+  desc_.arith = desc_pair_.arith = PROST_HIP_ARITH_EXACT;
+  if (opts_.arithmetic == PROST_HIP_ARITH_FMAD && pair_kernel_ && owned_x1_ == 0) {
+    prost_hip_fused_desc probe = desc_pair_;
+    probe.arith = PROST_HIP_ARITH_FMAD;
+    const int kmax = prost_hip_fused_iterationk_max(&probe, dtype_id<T>());
+    if (kmax >= 2) { group_max_ = std::min(kmax, kGroupMax); desc_pair_.arith = PROST_HIP_ARITH_FMAD; }
+  }
   if (pair_kernel_) x_spare_.resize(n);
   if (single_kernel_ || single3d_ || single_mc_) y_spare_.resize(m);
 
@@ -368,17 +379,19 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   if (!sol_z_.empty() && (sol_z_.size() + sol_w_.size()) * sizeof(T) > ((size_t)1 << 30)) { sol_z_.clear(); sol_w_.clear(); }
   if (spec_valid_) {
     spec_valid_ = false;
-    if (budget >= 2 && k == spec_iteration_) {
-      // the pair (k, k+1) already ran, into the spare buffers: exchange them in, exactly the state IterationPair leaves
-      x_prev_.swap(x_spare_); x_.swap(x_prev_);          // x_ = x^(k+2), x_prev_ = x^k (the pair's input), spare = what x_prev_ held
+    if (budget >= spec_count_ && k == spec_iteration_) {
+      // the launch (k .. k+g-1) already ran, into the spare buffers: exchange them in, exactly the state IterationPair / IterationGroup leaves
+      x_prev_.swap(x_spare_); x_.swap(x_prev_);          // x_ = x^(k+g), x_prev_ = x^k (the launch's input), spare = what x_prev_ held
       y_prev_.swap(y_spare_); y_.swap(y_prev_);
       prev_stale_ = true;
       stale_tau_ = spec_tau_[0]; stale_sigma_ = spec_sigma_[0]; stale_theta_ = spec_theta_[0];
-      tau_ = spec_tau_[2]; sigma_ = spec_sigma_[2]; theta_ = spec_theta_[2];
-      iteration_ += 2;
+      stale_count_ = spec_count_; stale_group_ = group_max_ >= 2;
+      for (int i = 1; i < spec_count_; i++) { stale_tau_more_[i] = spec_tau_[i]; stale_sigma_more_[i] = spec_sigma_[i]; stale_theta_more_[i] = spec_theta_[i]; }
+      tau_ = spec_tau_[spec_count_]; sigma_ = spec_sigma_[spec_count_]; theta_ = spec_theta_[spec_count_];
+      iteration_ += (size_t)spec_count_;
       pair_launches_++;
       spec_adopted_++;
-      return 2;
+      return spec_count_;
     }
   }
   // residual-driven rules on the device: a batch of iterations, ONE host wait at its end (two- and one-iteration budgets -- a user
@@ -388,6 +401,15 @@ int BackendPDHG<T>::PerformIterations(int budget) {
   if ((dev_rules_ || dev_rules_generic_) && budget >= 3 && k >= 2 &&
       !(stop_on_convergence_ && this->primal_residual_ < this->eps_primal() && this->dual_residual_ < this->eps_dual()))
     return PerformIterationsDevice(budget);
+  {
+    bool res = false;
+    const int g = GroupSize(k, budget, res);
+    if (g >= 2) {
+      IterationGroup(g, res);
+      pair_launches_++;
+      return g;
+    }
+  }
   if (pair_kernel_ && budget >= 2 && k >= 2 && !is_residual_iteration(k)) {
     IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
     pair_launches_++;
@@ -422,6 +444,7 @@ void BackendPDHG<T>::RestoreRoles(const BatchMark& m) {
   place(y_, m.y, y_prev_, y_spare_); place(y_prev_, m.yp, y_spare_, y_spare_);
   if (!fused_) { place(kx_, m.kx, kx_prev_, kx_prev_); place(kty_, m.kty, kty_prev_, kty_prev_); }
   prev_stale_ = m.prev_stale;
+  stale_count_ = m.stale_count; stale_group_ = m.stale_group;
   iteration_ = m.iteration_after;
   pair_launches_ = m.pair_launches;
   // the launches behind the stopping iteration did no work: their (near-zero) samples and launch counts are withdrawn
@@ -467,6 +490,10 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
       if (!fused_) {
         IterationGeneric(is_residual_iteration(k));
         done += 1;
+      } else if (bool gres = false; int g = GroupSize(k, n - done, gres)) {
+        pair_launches_++;            // (counted first: the mark a residual launch leaves holds the count INCLUDING itself)
+        IterationGroup(g, gres);
+        done += g;
       } else if (pair_kernel_ && n - done >= 2 && !is_residual_iteration(k)) {
         pair_launches_++;            // (counted first: the mark a residual launch leaves holds the count INCLUDING itself)
         IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
@@ -519,6 +546,8 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
   // step sizes of the last launch that ran (RebuildPrevious re-runs its first iteration): the values before its rule evaluation
   if (last_evaluated) { stale_tau_ = (T)m.prev_tau; stale_sigma_ = (T)m.prev_sigma; stale_theta_ = (T)m.prev_theta; }
   else { stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_; }
+  // (every iteration of a launch inside a batch ran with the record's values of that moment)
+  for (int i = 0; i < kGroupMax; i++) { stale_tau_more_[i] = stale_tau_; stale_sigma_more_[i] = stale_sigma_; stale_theta_more_[i] = stale_theta_; }
   batch_marks_.clear();
   return (int)(iteration_ - k0);
 }
@@ -583,6 +612,7 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
       CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), x_prev_.data(), y_prev_.data(), tau, sigma,
                                         theta, 0, residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iteration2");
   });
+  stale_count_ = 2; stale_group_ = false;
   if (!store_mid) {
     x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
     y_.swap(y_prev_);
@@ -593,6 +623,54 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
     prev_stale_ = false;
   }
   if (residuals) FinishResiduals();                                    // iteration_ == k+1 here, as in the single path
+  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  iteration_++;
+}
+
+/// The launch PerformIterations makes at iteration k: a group never starts with a residual iteration (its sums need the iterate in
+/// front of it), never contains one except as its LAST iteration (the kernel forms the sums there), and never leaves the next residual
+/// iteration alone behind it (a single residual launch streams y^(k-1), which a group keeps in registers): with d = iterations up to and
+/// including the next residual one, g = min(budget, group_max_, d), one less if that would leave d - g == 1.
+template <typename T>
+int BackendPDHG<T>::GroupSize(size_t k, int budget, bool& residuals) const {
+  residuals = false;
+  if (group_max_ < 2 || budget < 2 || k < 2 || is_residual_iteration(k)) return 0;
+  const size_t ri = (size_t)opts_.residual_iter;
+  const size_t r = (k / ri + 1) * ri;                // the next residual iteration (> k)
+  const size_t d = r - k + 1;
+  int g = (int)std::min<size_t>(std::min<size_t>((size_t)budget, (size_t)group_max_), d);
+  if (d - (size_t)g == 1 && g > 2) g--;
+  residuals = k + (size_t)g - 1 == r;
+  return g;
+}
+
+template <typename T>
+void BackendPDHG<T>::IterationGroup(int g, bool residuals) {
+  void* s = CurrentStream();
+  double tau[kGroupMax], sigma[kGroupMax], theta[kGroupMax];
+  for (int i = 0; i < g; i++) {
+    tau[i] = (double)tau_; sigma[i] = (double)sigma_; theta[i] = (double)theta_;
+    if (i == 0) { stale_tau_ = tau_; stale_sigma_ = sigma_; stale_theta_ = theta_; }
+    else { stale_tau_more_[i] = tau_; stale_sigma_more_[i] = sigma_; stale_theta_more_[i] = theta_; }
+    if (i + 1 < g) {
+      if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();          // step sizes of the next iteration (:483-488)
+      iteration_++;
+    }
+  }
+  // iteration_ == k + g - 1 here, the index of the launch's last iteration, as FinishResiduals expects it
+  const int kind = (residuals ? kKernelGroup2Res : kKernelGroup2) + (g - 2);
+  TimedLaunch(kind, [&] {
+    if (in_device_batch_)            // step sizes from the device record (every iteration of the launch: no rule evaluation falls between them)
+      CheckHip(Api<T>::fused_iterationk_rec(&desc_pair_, g, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), rule_rec_, 0, residuals ? res_target() : nullptr,
+                                            residuals ? workspace_ : nullptr, this->comm_ ? 0 : 1, (unsigned long long)iteration_, rule_mirror_dev_, s), "fused_iterationk_rec");
+    else
+      CheckHip(Api<T>::fused_iterationk(&desc_pair_, g, x_prev_.data(), y_prev_.data(), x_.data(), y_.data(), tau, sigma, theta, 0,
+                                        residuals ? res_target() : nullptr, residuals ? workspace_ : nullptr, s), "fused_iterationk");
+  });
+  x_.swap(x_prev_);        // x_ = x^(k+g); x_prev_ / y_prev_ = x^k / y^k, the launch's inputs
+  y_.swap(y_prev_);
+  prev_stale_ = true; stale_count_ = g; stale_group_ = true;
+  if (residuals) FinishResiduals();
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
   iteration_++;
 }
@@ -616,7 +694,7 @@ void BackendPDHG<T>::IterationPair3D(bool residuals) {
   });
   x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
   y_.swap(y_prev_);
-  prev_stale_ = true;
+  prev_stale_ = true; stale_count_ = 2; stale_group_ = false;
   if (residuals) FinishResiduals();                                    // iteration_ == k+1 here, as in the single path
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
   iteration_++;
@@ -641,7 +719,7 @@ void BackendPDHG<T>::IterationPairMc(bool residuals) {
   });
   x_.swap(x_prev_);        // x_ = x^(k+2); x_prev_ / y_prev_ = x^k / y^k, the pair's inputs
   y_.swap(y_prev_);
-  prev_stale_ = true;
+  prev_stale_ = true; stale_count_ = 2; stale_group_ = false;
   if (residuals) FinishResiduals();                                    // iteration_ == k+1 here, as in the single path
   if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
   iteration_++;
@@ -656,6 +734,15 @@ void BackendPDHG<T>::RebuildPrevious() {
   last_end_ = kNoEvent;
   if (x_spare_.size() != x_.size()) x_spare_.resize(x_.size());
   if (y_spare_.size() != y_.size()) y_spare_.resize(y_.size());
+  if (stale_group_) {
+    // a group of stale_count_ iterations: the iterate in front of its last one is stale_count_ - 1 iterations behind the inputs, in the
+    // same arithmetic (a launch of K iterations equals any partition of it into shorter launches bit for bit)
+    double tau[kGroupMax], sigma[kGroupMax], theta[kGroupMax];
+    tau[0] = (double)stale_tau_; sigma[0] = (double)stale_sigma_; theta[0] = (double)stale_theta_;
+    for (int i = 1; i < stale_count_ - 1; i++) { tau[i] = (double)stale_tau_more_[i]; sigma[i] = (double)stale_sigma_more_[i]; theta[i] = (double)stale_theta_more_[i]; }
+    CheckHip(Api<T>::fused_iterationk(&desc_pair_, stale_count_ - 1, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), tau, sigma, theta, 0,
+                                      nullptr, nullptr, CurrentStream()), "fused_iterationk");
+  } else
   if (pair_mc_ && single_mc_)
     CheckHip(Api<T>::fused_iteration_mc(&desc_, x_spare_.data(), y_spare_.data(), x_prev_.data(), y_prev_.data(), nullptr, (double)stale_tau_,
                                         (double)stale_sigma_, (double)stale_theta_, 1, 1, 1, 0, nullptr, nullptr, CurrentStream()), "fused_iteration_mc");
@@ -973,8 +1060,9 @@ void BackendPDHG<T>::FinishResiduals() {
                             kx_.data(), kx_prev_.data(), op_fused_ ? kty_.data() : kty_prev_.data(), op_fused_ ? kty_prev_.data() : kty_.data()});
     // kernel timing: launches enqueued behind a stopping iteration return at once -- their samples must not enter the averages
     // (RestoreRoles drops everything recorded after the mark it returns to)
-    static_assert(kKernelKinds == 8, "BatchMark::launches holds one counter per kernel kind");
+    static_assert(kKernelKinds == 14, "BatchMark::launches holds one counter per kernel kind");
     batch_marks_.back().samples = samples_.size(); batch_marks_.back().ev_used = ev_used_;
+    batch_marks_.back().stale_count = stale_count_; batch_marks_.back().stale_group = stale_group_;
     for (int kk = 0; kk < kKernelKinds; kk++) batch_marks_.back().launches[kk] = launches_[kk];
     batch_last_launch_evaluated_ = true;
     return;
@@ -1011,6 +1099,13 @@ bool BackendPDHG<T>::CanSpeculate() const {
   if (!opts_.allow_speculation || !pair_kernel_ || owned_x1_ != 0 || !(resolve_on_side_ || (ev_res_local_ && !this->comm_)) || spec_valid_) return false;
   if (opts_.stepsize_variant != kPDHGStepsAlg1 && opts_.stepsize_variant != kPDHGStepsAlg2) return false;
   const size_t k = iteration_;
+  if (group_max_ >= 2) {
+    // a PLAIN group must be what PerformIterations would launch next with a large budget (a smaller budget drops the speculation)
+    bool res = false;
+    const int g = GroupSize(k, kGroupMax, res);
+    if (g < 2 || res) return false;
+    return x_spare_.size() == x_.size() && y_spare_.size() == y_.size();
+  }
   // a PLAIN pair must be what PerformIterations(budget >= 2) would launch next: no residual sums, no stored intermediate iterate
   if (k < 2 || is_residual_iteration(k) || is_residual_iteration(k + 1) || is_residual_iteration(k + 2)) return false;
   return x_spare_.size() == x_.size() && y_spare_.size() == y_.size();
@@ -1018,15 +1113,23 @@ bool BackendPDHG<T>::CanSpeculate() const {
 
 template <typename T>
 void BackendPDHG<T>::Speculate() {
-  double tau[2], sigma[2], theta[2];
+  double tau[kGroupMax], sigma[kGroupMax], theta[kGroupMax];
   const T t0 = tau_, s0 = sigma_, th0 = theta_;
-  spec_tau_[0] = tau_; spec_sigma_[0] = sigma_; spec_theta_[0] = theta_;
-  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
-  spec_tau_[1] = tau_; spec_sigma_[1] = sigma_; spec_theta_[1] = theta_;
-  if (opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
-  spec_tau_[2] = tau_; spec_sigma_[2] = sigma_; spec_theta_[2] = theta_;
+  bool res = false;
+  const int g = group_max_ >= 2 ? GroupSize(iteration_, kGroupMax, res) : 2;
+  spec_count_ = g;
+  for (int i = 0; i <= g; i++) {
+    spec_tau_[i] = tau_; spec_sigma_[i] = sigma_; spec_theta_[i] = theta_;
+    if (i < g && opts_.stepsize_variant == kPDHGStepsAlg2) UpdateAlg2();
+  }
   tau_ = t0; sigma_ = s0; theta_ = th0;                  // nothing observable changes until the results are adopted
-  for (int i = 0; i < 2; i++) { tau[i] = (double)spec_tau_[i]; sigma[i] = (double)spec_sigma_[i]; theta[i] = (double)spec_theta_[i]; }
+  for (int i = 0; i < g; i++) { tau[i] = (double)spec_tau_[i]; sigma[i] = (double)spec_sigma_[i]; theta[i] = (double)spec_theta_[i]; }
+  if (group_max_ >= 2)
+    TimedLaunch(kKernelGroup2 + (g - 2), [&] {
+      CheckHip(Api<T>::fused_iterationk(&desc_pair_, g, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), tau, sigma, theta, 0, nullptr, nullptr,
+                                        CurrentStream()), "fused_iterationk");
+    });
+  else
   TimedLaunch(kKernelPair, [&] {
     CheckHip(Api<T>::fused_iteration2(&desc_pair_, x_spare_.data(), y_spare_.data(), x_.data(), y_.data(), nullptr, nullptr, tau, sigma, theta, 0,
                                       nullptr, nullptr, CurrentStream()), "fused_iteration2");
@@ -1184,11 +1287,14 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
                                      d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", d3 ? "fused_iter3d_x2_kernel" : pair_mc_ ? "fused_iter2d_mc_x2_kernel" : "fused_iter2d_x2_kernel",
-                                     "fused_iter2d_x2_kernel+mid", d3 ? "fused_iter3d_x2_kernel+residuals" : pair_mc_ ? "fused_iter2d_mc_x2_kernel+residuals" : "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals"};
-  const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2};
+                                     "fused_iter2d_x2_kernel+mid", d3 ? "fused_iter3d_x2_kernel+residuals" : pair_mc_ ? "fused_iter2d_mc_x2_kernel+residuals" : "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals",
+                                     "fused_iter2d_xk_kernel<2>", "fused_iter2d_xk_kernel<3>", "fused_iter2d_xk_kernel<4>",
+                                     "fused_iter2d_xk_kernel<2>+residuals", "fused_iter2d_xk_kernel<3>+residuals", "fused_iter2d_xk_kernel<4>+residuals"};
+  const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 3, 4, 2, 3, 4};
   for (int k = 0; k < kKernelKinds; k++) {
     if (!cnt[k]) continue;
-    const int cols = k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_pair_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes)
+    const int cols = k >= kKernelGroup2 ? prost_hip_fused_iterationk_chunk_cols(&desc_pair_, dtype_id<T>(), iters[k], k >= kKernelGroup2Res)
+                     : k >= kKernelPair && pair_kernel_ ? prost_hip_fused_iteration2_chunk_cols(&desc_pair_, dtype_id<T>(), k == kKernelPairRes || k == kKernelPairMidRes)
                      : (k == kKernelPair || k == kKernelPairRes) && pair3d_ ? prost_hip_fused_iteration3d_x2_chunk_cols(&desc_, dtype_id<T>(), k == kKernelPairRes)
                      : (k == kKernelPair || k == kKernelPairRes) && pair_mc_ ? prost_hip_fused_iteration_mc_x2_chunk_cols(&desc_pair_, dtype_id<T>(), k == kKernelPairRes) : 0;
     out.push_back({names[k], sum[k] / cnt[k], cnt[k], launches_[k], iters[k], cols});

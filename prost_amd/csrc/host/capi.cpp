@@ -343,6 +343,12 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       if (prost_value_field(d, "allow_op_fusion")) o.allow_op_fusion = (int)GetScalarFromField(d, "allow_op_fusion");
       if (prost_value_field(d, "residual_sums_in_prox")) o.residual_sums_in_prox = (int)GetScalarFromField(d, "residual_sums_in_prox");
       if (prost_value_field(d, "allow_device_rules")) o.allow_device_rules = GetScalarFromField(d, "allow_device_rules") > 0.;
+      if (prost_value_field(d, "arithmetic")) {            // MI355X addition: 'exact' (default) | 'fmad' (tolerance class, BackendPDHG::Options::arithmetic)
+        const std::string ar = GetString(prost_value_field(d, "arithmetic"));
+        if (ar == "exact") o.arithmetic = PROST_HIP_ARITH_EXACT;
+        else if (ar == "fmad") o.arithmetic = PROST_HIP_ARITH_FMAD;
+        else throw Exception("Couldn't recognize arithmetic class. Valid options are {exact,fmad}.");
+      }
       return new BackendPDHG<T>(o);
     };
     reg["admm"] = [](const prost_value* d) -> Backend<T>* {                                   // factory.cpp:799-818
@@ -819,8 +825,9 @@ void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** pl
     prost_value_struct_set(out, "z", vec_value_t(h.solver->cur_primal_constr_sol()));
     prost_value_struct_set(out, "w", vec_value_t(h.solver->cur_dual_constr_sol()));
   }
-  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0, spec_l = 0, spec_a = 0, dev_batches = 0, op_fused = 0, res_prox = 0;
+  double tau = 0, sigma = 0, theta = 0, rho = 0, it = 0, cg_its = 0, spec_l = 0, spec_a = 0, dev_batches = 0, op_fused = 0, res_prox = 0, arith = 0, gmax = 0;
   if (auto* p = dynamic_cast<BackendPDHG<T>*>(h.backend.get())) {
+    arith = (double)p->arithmetic(); gmax = (double)p->group_max();
     tau = p->tau(); sigma = p->sigma(); theta = p->theta(); it = (double)p->iteration();
     spec_l = (double)p->speculative_launches(); spec_a = (double)p->speculative_adopted();
     dev_batches = (double)p->device_rule_batches();
@@ -838,6 +845,8 @@ void solver_state_t(SolverHandle<T>& h, bool vectors, int nlhs, prost_value** pl
   prost_value_struct_set(out, "speculative_launches", prost_value_scalar(spec_l));
   prost_value_struct_set(out, "speculative_adopted", prost_value_scalar(spec_a));
   prost_value_struct_set(out, "device_rule_batches", prost_value_scalar(dev_batches));
+  prost_value_struct_set(out, "arithmetic", prost_value_string(arith != 0 ? "fmad" : "exact"));   // the class the iteration kernels of this solve run in
+  prost_value_struct_set(out, "iterations_per_launch_max", prost_value_scalar(gmax));             // tolerance class: largest group of iterations in one launch (0: pairs / singles)
   prost_value_struct_set(out, "operator_in_prox_kernels", prost_value_scalar(op_fused));      // generic PDHG: K x / K^T y formed inside the prox launches
   prost_value_struct_set(out, "residual_sums_in_prox_launches", prost_value_scalar(res_prox)); // generic PDHG, separate products: the prox launches add up the residual terms
   {   // sparse blocks applied from row patterns instead of their CSR arrays (forward + adjoint products counted separately)

@@ -55,6 +55,8 @@ template <typename T> struct Api;
     static constexpr auto fused_iteration3d_pw_rec = prost_hip_fused_iteration3d_pw_rec_##S; \
     static constexpr auto fused_iteration3d_x2_rec = prost_hip_fused_iteration3d_x2_rec_##S; \
     static constexpr auto fused_iteration2_rec = prost_hip_fused_iteration2_rec_##S; \
+    static constexpr auto fused_iterationk = prost_hip_fused_iterationk_##S;      \
+    static constexpr auto fused_iterationk_rec = prost_hip_fused_iterationk_rec_##S; \
     static constexpr auto pdhg_rule_begin = prost_hip_pdhg_rule_begin_##S;        \
     static constexpr auto pdhg_rule_apply = prost_hip_pdhg_rule_apply_##S;        \
     static constexpr auto pdhg_residuals = prost_hip_pdhg_residuals_##S;          \

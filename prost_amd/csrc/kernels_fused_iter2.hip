@@ -48,7 +48,12 @@ struct Col2 {
 // VART: position-dependent primal preconditioner (FusedArgs::varT; see fused_iter2d_kernel): the interior instance of a column step
 // (`inner`) is untouched -- every pixel it sees has 4 stencil entries in its column, Tval = Tcls[2] -- and the boundary instance
 // re-evaluates the pixels of the first / last column and row with their own Tau_j through the reference's expression (elem_1d).
-template <class T, int VEC, int GFN, int FFN, int GMASK, int PF, bool FAST, int MODE, bool RAG, bool VART>
+// FMAD: the tolerance-class arithmetic (prost_hip_fused_desc.arith = PROST_HIP_ARITH_FMAD; straight-line ROF / TV-L1 shapes only): the
+// SAME expressions with fused multiply-adds where a product feeds a sum (what nvcc's default -fmad=true makes of the reference's
+// kernels, src/CMakeLists.txt:12-24), the quotient by the wave-uniform 1 + step as a product with its fp32 reciprocal and
+// pr v / ||v|| as v * min(b * rsq(||v||^2), 1) (v_rsq_f32, 1 ulp) -- no fp64 instruction, no conversion, no range guard.  Results are
+// within a stated tolerance of the exact instances (tests/test_gpu_fmad.py), not bit-identical to them.
+template <class T, int VEC, int GFN, int FFN, int GMASK, int PF, bool FAST, int MODE, bool RAG, bool VART, bool FMAD>
 __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRingWaves) : (MODE & 2) ? 2 : (PF > 1 || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
@@ -158,6 +163,28 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
                     const T (&gc)[Col::NG][VEC], const IterParams<T>& P, T (&xn)[VEC], T (&kt)[VEC]) {
     constexpr bool I = decltype(inner)::value;
     const T tauT = P.tau * a.Tval;
+    if constexpr (FMAD) {
+      // x - tau T K^T y = fma(tau T, div y, x);  Function1DSquare: (v - b) / (1 + step) + b = fma(v - b, 1 / (1 + step), b);
+      // Function1DAbs: soft threshold of v - b by step
+      const T rD = (T)P.ug.sq.rD, st = P.ug.step;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const idx_t row = row0 + j;
+        const T upj = (j > 0) ? y2c[(j + VEC - 1) % VEC] : up;
+        const T divy = ((I || row < ny - 1) ? y2c[j] : (T)0) - ((I || row > 0) ? upj : (T)0);
+        const T divx = ((I || c < nx - 1) ? y1c[j] : (T)0) - ((I || c > 0) ? y1p[j] : (T)0);
+        const T sdiv = divx + divy;
+        kt[j] = -sdiv;
+        const T arg = t_fma(tauT, sdiv, xin[j]);
+        const T bj = ((GMASK >> 1) & 1) ? gc[slot_ofb(GMASK, 1)][j] : a.g_val[1];
+        T r;
+        if (GFN == PROST_FN_SQUARE) r = t_fma(arg - bj, rD, bj);
+        else { const T v = arg - bj; r = (v - t_max(t_min(v, st), -st)) + bj; }
+        if (kBMask) r = is_mask_sentinel(bj) ? arg : r;
+        xn[j] = r;
+      }
+      return;
+    }
     constexpr bool kEdges = VART && !I;          // this instance may see pixels with fewer than 4 stencil entries in their column
     T parg[VEC], parg0[kBMask ? VEC : 1];
     T argv[kEdges ? VEC : 1], tTv[kEdges ? VEC : 1];
@@ -266,10 +293,29 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     const T bel_n = lane_down(xn_c[0]);                         // lane 63: no source, its last row is halo
     const T bel_o = lane_down(xo_c[0]);
     T av[2][VEC], nv[VEC];
+    if constexpr (FMAD) {
+      const T opt = 1 + theta, bq = a.f_val[1];
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const idx_t row = row0 + j;
+        const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
+        const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
+        const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+        const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
+        const T kp1 = has_next ? xo_n[j] - xo_c[j] : (T)0;
+        const T kp2 = (I || row < ny - 1) ? below_o - xo_c[j] : (T)0;
+        const T arg1 = t_fma(sigS, t_fma(opt, kx1, -(theta * kp1)), y1c[j]);
+        const T arg2 = t_fma(sigS, t_fma(opt, kx2, -(theta * kp2)), y2c[j]);
+        // ElemOperationNorm2<Function1DIndLeq0>, a = 1, d = e = 0, radius b > 0: pr v / ||v|| = v min(b / ||v||, 1); ||v|| = 0: b * inf -> 1, v = 0
+        const T sc = t_min(bq * t_rsq(t_fma(arg2, arg2, arg1 * arg1)), (T)1);
+        av[0][j] = arg1; av[1][j] = arg2;
+        o1[j] = arg1 * sc; o2[j] = arg2 * sc;
+      }
+    }
     T vv[kFM ? 2 : 1][kFM ? VEC : 1];          // kFM: the pre-scaled arguments v = arg / (sigma Sigma)
     const SharedDivisor<T> div_sS(kFM ? sigS : (T)1);
 #pragma unroll
-    for (int j = 0; j < VEC; j++) {
+    for (int j = 0; j < (FMAD ? 0 : VEC); j++) {
       const idx_t row = row0 + j;
       const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
       const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
@@ -299,11 +345,13 @@ __global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRi
     if (FAST) {
       // ElemOperationNorm2<Function1DIndLeq0> with scalar a = 1, d = 0, e = 0 (host-checked): out = pr v / ||v||,
       // pr = min(||v|| - b, 0) + b, 0 for ||v|| = 0 -- straight-line for the VEC pixels (device_math.hpp)
-      T out[2][VEC];
-      if constexpr (kFM) norm2_moreau_post<T, FFN, kFM ? 2 : 1, kFM ? VEC : 1>(nv, vv, av, sigS, a.f_val, P.uf, out);
-      else norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+      if constexpr (!FMAD) {
+        T out[2][VEC];
+        if constexpr (kFM) norm2_moreau_post<T, FFN, kFM ? 2 : 1, kFM ? VEC : 1>(nv, vv, av, sigS, a.f_val, P.uf, out);
+        else norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
 #pragma unroll
-      for (int j = 0; j < VEC; j++) { o1[j] = out[0][j]; o2[j] = out[1][j]; }
+        for (int j = 0; j < VEC; j++) { o1[j] = out[0][j]; o2[j] = out[1][j]; }
+      }
       if (kRes && acc && owner && counted) {
         // primal_residual_transform (backend_pdhg.cu:97-120): z_hat = (y_old - y_new) / (sigma sqrt(S)) + sqrt(S) ((1 + theta) K x_new
         // - theta K x_old).  With the prox argument above, arg = y_old + sigma S ((1 + theta) K x_new - theta K x_old), that is
@@ -484,6 +532,14 @@ static bool iter2_fast_shape(const prost_hip_fused_desc* d) {
          d->f_coeff_val[0] == 1.0 && d->f_coeff_val[3] == 0.0 && d->f_coeff_val[4] == 0.0;
 }
 
+// The tolerance-class instances (kernel template parameter FMAD) exist for fp32, uniform Tau, prox_f* = norm2:ind_leq0 with a radius
+// b > 0 written directly (no Moreau wrap).  A description that asks for them and is not of that shape runs the exact instances: exact
+// results satisfy every tolerance.
+static bool iter2_fmad_shape(const prost_hip_fused_desc* d, int dtype) {
+  return d->arith == PROST_HIP_ARITH_FMAD && dtype == 0 && iter2_fast_shape(d) && !d->var_T && !d->f_moreau && d->f_fn == PROST_FN_IND_LEQ0 &&
+         d->f_coeff_val[1] > 0.0;
+}
+
 // chunk length (columns per wavefront) of a launch; `res`: the launch also forms the residual sums
 static int iter2_chunk_cols(const prost_hip_fused_desc* d, int V, bool res, int cols) {
   const size_t strips = (d->ny + 62 * V - 1) / (62 * V);
@@ -554,15 +610,26 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
   const bool fast = iter2_fast_shape(d) && p[0].ug.a_one && p[0].ug.den_one && !p[0].ug.degenerate && p[0].uf.a_one && p[0].uf.den_one &&
                     p[1].ug.den_one && p[1].uf.den_one;
   if (a.fmor && !(fast && mask == 0x2)) { set_error("fused double iteration: a Moreau-wrapped prox_f* runs the straight-line square / abs instance only"); return 1; }
+  const bool fmad = fast && iter2_fmad_shape(d, sizeof(T) == 4 ? 0 : 1);
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
   hipStream_t s = as_stream(stream);
   const int mode = (out4 ? 2 : 0) | (x_mid ? 1 : 0);
   const bool rag = d->ny % V != 0;
   double* partial = static_cast<double*>(ws);
-#define GO5(G, F, M, PFv, FASTv, MODEv, RAGv, VARTv) PH_LAUNCH((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv, VARTv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial, rec)
+#define GO5(G, F, M, PFv, FASTv, MODEv, RAGv, VARTv, FMADv) \
+  PH_LAUNCH((fused_iter2d_x2_kernel<T, V, G, F, M, PFv, FASTv, MODEv, RAGv, VARTv, FMADv>), grid, block, 0, s, x_out, y_out, x, y, x_mid, y_mid, a, p[0], p[1], partial, rec)
 // position-dependent Tau (FusedArgs::varT): instances exist for the straight-line ROF shape with a per-pixel b (square, mask 0x2) -- the
 // shape callers pair on (prost_hip_fused_iteration2_profitable); the others are refused
-#define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) do { if (a.varT) { if constexpr (FASTv && G == PROST_FN_SQUARE && M == 0x2) GO5(G, F, M, PFv, FASTv, MODEv, RAGv, true); else { set_error("fused double iteration: no position-dependent Tau instance for this shape"); return 1; } } else GO5(G, F, M, PFv, FASTv, MODEv, RAGv, false); } while (0)
+// tolerance-class arithmetic (`fmad`, decided above): fp32 straight-line instances with prox_f* = norm2:ind_leq0
+#define GO4(G, F, M, PFv, FASTv, MODEv, RAGv) do { \
+    if (a.varT) { \
+      if constexpr (FASTv && G == PROST_FN_SQUARE && M == 0x2) GO5(G, F, M, PFv, FASTv, MODEv, RAGv, true, false); \
+      else { set_error("fused double iteration: no position-dependent Tau instance for this shape"); return 1; } \
+    } else if (fmad) { \
+      if constexpr (FASTv && F == PROST_FN_IND_LEQ0 && sizeof(T) == 4) GO5(G, F, M, PFv, FASTv, MODEv, RAGv, false, true); \
+      else { set_error("fused double iteration: no tolerance-class instance for this shape"); return 1; } \
+    } else GO5(G, F, M, PFv, FASTv, MODEv, RAGv, false, false); \
+  } while (0)
 // straight-line instances of heights that are a multiple of the vector width prefetch through the LDS ring (PF = 0); ragged
 // heights (4-byte aligned column starts) keep the register ring
 // (PROST_ITER2_NO_RING=1 forces the register ring everywhere: A/B measurements)
@@ -596,6 +663,9 @@ using namespace prost_hip;
 extern "C" {
 int prost_hip_fused_iteration2_supported(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) ? 1 : 0; }
 int prost_hip_fused_iteration2_profitable(const prost_hip_fused_desc* desc, int dtype) { return iter2_desc_ok(desc, dtype) && iter2_fast_shape(desc) ? 1 : 0; }
+int prost_hip_fused_iteration2_arith(const prost_hip_fused_desc* desc, int dtype) {
+  return iter2_desc_ok(desc, dtype) && iter2_fmad_shape(desc, dtype) ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT;
+}
 int prost_hip_fused_iteration2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals) {
   return iter2_desc_ok(desc, dtype) ? iter2_chunk_cols(desc, dtype == 0 ? 4 : 2, with_residuals != 0, 0) : 0;
 }

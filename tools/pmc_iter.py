@@ -24,6 +24,7 @@ for i, (g, fv) in enumerate(zip([1, 0, 10, 0, 0, 0, 0], [1, 1, 1, 0, 0, 0, 0])):
     d.g_coeff_val[i] = g; d.f_coeff_val[i] = fv
 d.g_coeff_ptr[1] = f.ptr.value
 d.T_val, d.S_val = 0.25, 0.5
+d.arith = int(os.environ.get("PROST_ARITH", "0"))
 r4 = hip.DeviceArray.zeros(4, np.float64)
 ws = hip.DeviceArray(hip.lib().prost_hip_reduce_workspace_bytes() // 8, np.float64)
 for i in range(reps):
@@ -34,6 +35,10 @@ for i in range(reps):
     elif mode == "iter2":
         t2 = (C.c_double * 2)(0.3, 0.29); s2 = (C.c_double * 2)(1.0, 1.03); th2 = (C.c_double * 2)(0.9, 0.91)
         hip.check(hip.fn("fused_iteration2", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, None, t2, s2, th2, cols, None, None, None))
+    elif mode.startswith("iterk"):        # iterk4 / iterk3res ...
+        K = int(mode[5]); tk = (C.c_double * 4)(0.3, 0.29, 0.28, 0.27); sk = (C.c_double * 4)(1.0, 1.03, 1.06, 1.09); thk = (C.c_double * 4)(0.9, 0.91, 0.92, 0.93)
+        res = mode.endswith("res")
+        hip.check(hip.lib().prost_hip_fused_iterationk_f32(C.byref(d), K, x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, tk, sk, thk, cols, r4.ptr if res else None, ws.ptr if res else None, None))
     elif mode == "iter":
         hip.check(hip.fn("fused_iteration", dtype)(C.byref(d), x[b].ptr, y[b].ptr, x[a].ptr, y[a].ptr, None, hip.dbl(0.3), hip.dbl(1.0), hip.dbl(0.9), 1, 1, 0, cols, None, None, None))
     else:
