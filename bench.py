@@ -81,6 +81,30 @@ def traffic_bytes(kernel, size, chunk_cols, dtype="f32"):
     return None, None
 
 
+def validate_line(out):
+    """what a reader of the JSON line alone may rely on: no rate called GB/s exceeds the part's HBM peak unless its NAME says it is an
+    equivalent figure (a model's bytes over the measured time), and every roofline fraction on compulsory bytes or traffic is <= 1.
+    Raises ValueError otherwise (bench.py calls this before it prints; tests/test_bench_harness.py feeds it lines)."""
+    peak = HBM_PEAK_GBPS * max(1, int(out.get("n_gpus") or 1))
+
+    def walk(d, where):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                walk(v, where + k + ".")
+                continue
+            if not isinstance(v, (int, float)) or isinstance(v, bool):
+                continue
+            name = where + k
+            if "equiv" in k:
+                continue
+            if (k.endswith("GBps") or (where.startswith("roofline") and k in ("achieved", "achieved_hbm_traffic"))) and v > peak:
+                raise ValueError("bench.py: %s = %.1f GB/s exceeds the HBM peak %.0f GB/s and its name does not say 'equiv'" % (name, v, peak))
+            if where.startswith("roofline") and k in ("frac", "frac_hbm_traffic") and v > 1.0:
+                raise ValueError("bench.py: %s = %.3f is above 1" % (name, v))
+    walk(out, "")
+    return out
+
+
 def kernel_kind(kname):
     """-> (family, suffix) of a name KernelTimes emits (backend_pdhg.cpp, KernelTimes): family in {"primal", "dual", "iter", "iter_x2"},
     suffix in {"", "+mid", "+residuals", "+mid+residuals"}.  The family is read from the kernel's own name token
@@ -304,8 +328,11 @@ def cpu_thread_candidates(max_threads):
     or, under a cgroup CPU quota of q cores, q / 2, q, 3 q / 2 and 2 q (spinning OpenMP threads beyond the quota are throttled)"""
     quota = cpu_quota_cores()
     if quota and quota < max_threads:
-        q = max(1, int(round(quota)))
-        c = sorted({t for t in (max(1, q // 2), q, (3 * q) // 2, 2 * q) if 1 <= t <= max_threads})
+        # never more threads than the quota pays for: a team above it runs in bursts (the throttle stops every thread for the rest of the
+        # period once the quota is spent), so a 2-iteration probe can read twice the rate the run then sustains (BENCH_r05: probe 48.9 it/s
+        # at 24 threads under a 16-core quota, the 8-second sample 29.3)
+        q = max(1, int(quota))
+        c = sorted({t for t in (max(1, q // 2), max(1, (3 * q) // 4), q) if 1 <= t <= max_threads})
         return c
     c = [t for t in (8, 16, 32, 64, 128, 256, 512) if t <= max_threads]
     if max_threads not in c:
@@ -313,7 +340,7 @@ def cpu_thread_candidates(max_threads):
     return c or [1]
 
 
-def cpu_probe_threads(s, max_threads, iters=2):
+def cpu_probe_threads(s, max_threads, iters=4):
     """best thread count for the oracle solver `s`: for every candidate the team is pinned (one thread per physical core first,
     topology order: oracle.bind_threads) and every large vector is first-touched again by the thread that streams it
     (Solver.rehome -- round 4 left all pages on the node of the thread that allocated them, which is what capped the port at
@@ -356,25 +383,32 @@ def cpu_baseline(n_img, max_threads, np_dtype=None):
     s = oracle.Solver(prob.data, prob.nrows, prob.ncols, backend, opts, np_dtype)
     s.initialize()
     best, rates = cpu_probe_threads(s, max_threads)
-    iters, t0 = 0, time.time()
-    while True:
-        s.iterate(10)
-        iters += 10
-        el = time.time() - t0
-        if el > 8.0 or iters >= 2000:
-            break
+    # three samples of ~3 s each; the reported value is their MEDIAN, min and max beside it (one sample of 8 s in round 5: two runs on
+    # one box differed by 40 %)
+    samples, iters = [], 0
+    for _ in range(3):
+        it_s, t0 = 0, time.time()
+        while True:
+            s.iterate(10)
+            it_s += 10
+            el = time.time() - t0
+            if el > 3.0 or it_s >= 1000:
+                break
+        samples.append(it_s / el)
+        iters += it_s
+    samples.sort()
     oracle.bind_threads(False)
     # the same port on ONE thread (SURVEY 8d asks for both): a few iterations are enough at ~3 it/s
     oracle.set_num_threads(1)
     t1 = time.time()
     s.iterate(3)
     single = 3 / (time.time() - t1)
-    out = {"value": iters / el, "unit": "it/s", "cores": best, "kind": "port", "single_thread_value": single,
+    out = {"value": samples[1], "value_min": samples[0], "value_max": samples[2], "unit": "it/s", "cores": best, "kind": "port", "single_thread_value": single,
            "threads_probed": {str(k): v for k, v in sorted(rates.items())}, "logical_cpus": max_threads, "cpu_quota_cores": cpu_quota_cores(),
-           "sample": "%d PDHG iterations of the same %dx%d %s ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads pinned one per "
-                     "core in topology order, every vector first-touched by the thread that streams it (best of a probe over %s threads on %d "
+           "sample": "median of 3 samples (%d PDHG iterations in all) of the same %dx%d %s ROF problem, oracle/prost_oracle.cpp, OpenMP with %d threads pinned "
+                     "one per core in topology order, every vector first-touched by the thread that streams it (best of a probe over %s threads on %d "
                      "logical CPUs%s)" % (iters, n_img, n_img, fp, best, "/".join(str(t) for t in sorted(rates)), max_threads,
-                                          "; the container's cgroup CPU quota is %.0f cores" % cpu_quota_cores() if cpu_quota_cores() else "")}
+                                          "; the container's cgroup CPU quota is %.0f cores and the probe stays within it" % cpu_quota_cores() if cpu_quota_cores() else "")}
     del s
     rb = reference_build_rate(backend, opts) if np_dtype == np.float32 else None
     out["reference_build"] = rb
@@ -480,7 +514,9 @@ def main():
     ap.add_argument("--residual-iter", type=int, default=None, help="pdhg configs: residual_iter (default 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record HIP events inside the timed region")
-    ap.add_argument("--no-fmad", action="store_true", help="c2 / f32: skip the second leg that runs the same steps with arithmetic='fmad' (value_fmad, roofline_fmad)")
+    ap.add_argument("--arithmetic", default="exact", choices=["exact", "fmad"], help="pdhg configs: the arithmetic class of the MAIN leg (`value`); default exact = "
+                    "bit for bit with the CPU oracle.  With the default, c2 / c3 in f32 run a second leg with 'fmad' and report it as value_fmad / roofline_fmad")
+    ap.add_argument("--no-fmad", action="store_true", help="c2, c3 / f32: skip the second leg that runs the same steps with arithmetic='fmad' (value_fmad, roofline_fmad)")
     ap.add_argument("--no-pair", action="store_true", help="one kernel launch per iteration (allow_pair_kernel = false); not the default configuration")
     args = ap.parse_args()
 
@@ -580,6 +616,10 @@ def main():
         if args.residual_iter is not None:
             backend[1]["residual_iter"] = args.residual_iter
         cfg["workload"] = cfg["workload"].replace("PDHG alg2, residual_iter=10", "PDHG %s, residual_iter=%d" % (backend[1]["stepsize"], backend[1]["residual_iter"]))
+    if args.arithmetic != "exact":
+        if backend[0] != "pdhg":
+            raise SystemExit("bench.py: --arithmetic applies to the pdhg configs")
+        backend[1]["arithmetic"] = args.arithmetic
     if os.environ.get("PROST_BENCH_DEVICE_RULES") == "0" and backend[0] == "pdhg":
         backend[1]["allow_device_rules"] = False          # A/B: goldstein / boyd with the rule on the host (a wait per residual iteration)
     if args.no_pair:
@@ -656,7 +696,7 @@ def main():
     # the tolerance-class leg (headline config, fp32): the same problem, the same loop, `arithmetic="fmad"` (DESIGN.md section 5;
     # iterates within the tolerance of tests/test_gpu_fmad.py of the exact ones).  `value` above stays the exact run.
     leg_fmad = None
-    if args.config == "c2" and args.dtype == "f32" and not args.no_fmad and not args.no_pair:
+    if args.config in ("c2", "c3") and args.dtype == "f32" and not args.no_fmad and not args.no_pair and args.arithmetic == "exact":
         backend_fmad = [backend[0], dict(backend[1])]
         backend_fmad[1]["arithmetic"] = "fmad"
         leg_fmad = run_leg(backend_fmad)
@@ -793,10 +833,11 @@ def main():
                            "speedup_over_exact": v_f / value,
                            "tolerance": "tests/test_gpu_fmad.py: one iteration within 2 (x) / 4 (y) ulp at the vector's scale of the exact kernels; "
                                         "iterates within 1e-5 k (relative to the vector's largest entry) of the CPU oracle after k iterations, "
-                                        "checked at k = 12 and 102 at this size; a solve to 1e-4 stops within one residual period of the exact one",
+                                        "checked at this size (c2: k = 12 and 102 on the whole image; c3: k = 12 on sub-volumes); a solve to 1e-4 "
+                                        "stops within one residual period of the exact one",
                            "note": "the same problem and loop with backend.pdhg(..., arithmetic='fmad'): fused multiply-adds and fp32 reciprocal "
-                                   "instructions (what nvcc's default -fmad=true makes of the reference's kernels), up to 4 iterations per launch "
-                                   "(kernels_fused_iterk.hip).  `value` is the exact-arithmetic run, bit for bit with the CPU oracle."}
+                                   "instructions (what nvcc's default -fmad=true makes of the reference's kernels)%s.  `value` is the "
+                                   "exact-arithmetic run, bit for bit with the CPU oracle." % (", up to 4 iterations per launch (kernels_fused_iterk.hip)" if args.config == "c2" else "")}
         if not args.no_cpu_baseline and world == 1:
             threads = os.cpu_count() or 1
             if args.config == "c2":
@@ -820,7 +861,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(json.dumps(validate_line(out)), flush=True)
     if rccl_fallback:
         raise SystemExit(3)          # every rank: the launcher (and through it a parent bench.py) reports the failure
 

@@ -121,7 +121,9 @@ class BackendPDHG : public Backend<T> {
  public:
   static constexpr int kGroupMax = 4;
   /// the arithmetic class the iteration kernels of this solve run in (PROST_HIP_ARITH_*) and the largest launch group (0: none)
-  int arithmetic() const { return group_max_ >= 2 || desc_pair_.arith == PROST_HIP_ARITH_FMAD ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT; }
+  int arithmetic() const {
+    return fused_ && (group_max_ >= 2 || desc_pair_.arith == PROST_HIP_ARITH_FMAD || desc_.arith == PROST_HIP_ARITH_FMAD) ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT;
+  }
   int group_max() const { return group_max_; }
  private:
   int group_max_ = 0;

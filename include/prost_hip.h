@@ -581,6 +581,8 @@ int prost_hip_fused_iteration_mc_x2_supported(const prost_hip_fused_desc* desc, 
 /* 1 iff the launch is also faster than two single launches (tiny images: one launch instead of two; large ones: half the HBM
  * traffic; in between -- about 384^2 to 700^2 RGB -- the single-iteration kernel is up to 9 % faster) */
 int prost_hip_fused_iteration_mc_x2_profitable(const prost_hip_fused_desc* desc, int dtype);
+/* (ABI 9) PROST_HIP_ARITH_* of the instance a launch with this description runs (FMAD: fp32, heights that are a multiple of 4, uniform Tau, ind_leq0 radius > 0) */
+int prost_hip_fused_iteration_mc_x2_arith(const prost_hip_fused_desc* desc, int dtype);
 int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals);
 /* res_out4 != NULL (needs `workspace`): also the four residual sums of the SECOND iteration, as prost_hip_fused_iteration_mc
  * writes them for that iteration (same terms, restricted to the owned columns res_x0 / res_x1; the summation order differs) */
@@ -599,6 +601,8 @@ int prost_hip_fused_iteration_mc_x2_f64(const prost_hip_fused_desc* desc, double
 int prost_hip_fused_iteration3d_x2_supported(const prost_hip_fused_desc* desc, int dtype /* 0 f32, 1 f64 */);
 /* columns per chunk a launch with cols <= 0 uses (0 if unsupported): chosen so that the rounds of workgroups on the
  * device's compute units times the column steps of a workgroup is minimal */
+/* (ABI 9) PROST_HIP_ARITH_* of the instance a launch with this description runs (FMAD: fp32, even heights, ind_leq0 radius > 0 and desc->arith asks for it) */
+int prost_hip_fused_iteration3d_x2_arith(const prost_hip_fused_desc* desc, int dtype);
 int prost_hip_fused_iteration3d_x2_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int with_residuals);
 /* res_out4 != NULL (needs `workspace`): also the four residual sums of the SECOND iteration, as
  * prost_hip_fused_iteration3d writes them for that iteration (same terms; the summation order differs) */

@@ -31,6 +31,7 @@ std::string BackendPDHG<T>::path() const {
   if (!fused_) return "pdhg:generic";
   if (from_matrix_) return "pdhg:fused-grad2d(sparse)";        // the stencil kernels on a gradient handed over as a sparse matrix
   if (group_max_ >= 2) return "pdhg:fused-grad2d+fmad";       // tolerance-class arithmetic, up to kGroupMax iterations per launch
+  if (arithmetic() == PROST_HIP_ARITH_FMAD) return desc_.is3d ? "pdhg:fused-grad3d+fmad" : "pdhg:fused-grad2d+fmad";      // ... in the pair launches
   return desc_.is3d ? "pdhg:fused-grad3d" : "pdhg:fused-grad2d";
 }
 
@@ -143,6 +144,7 @@ bool BackendPDHG<T>::TryFused() {
   else if (!prob.uniform_right(tv) && !uniform(prob.scaling_right_host(), tv)) return false;
   desc_.res_x0 = owned_x0_; desc_.res_x1 = owned_x1_;
   desc_.g_b_masked = 0;
+  desc_.arith = PROST_HIP_ARITH_EXACT;
   desc_.is3d = d3 ? 1 : 0; desc_.nx = bd.nx; desc_.ny = bd.ny; desc_.L = bd.L;
   desc_.g_fn = pg.fn; desc_.f_fn = pf.fn; desc_.f_moreau = pf.moreau ? 1 : 0;
   for (int i = 0; i < 7; i++) {
@@ -265,6 +267,17 @@ void BackendPDHG<T>::Initialize() {
     probe.arith = PROST_HIP_ARITH_FMAD;
     const int kmax = prost_hip_fused_iterationk_max(&probe, dtype_id<T>());
     if (kmax >= 2) { group_max_ = std::min(kmax, kGroupMax); desc_pair_.arith = PROST_HIP_ARITH_FMAD; }
+  }
+  // gradient3d volumes / 2-4 channels: the pair kernels have tolerance-class instances of their own (two iterations per launch as before)
+  if (opts_.arithmetic == PROST_HIP_ARITH_FMAD && pair3d_) {
+    prost_hip_fused_desc probe = desc_;
+    probe.arith = PROST_HIP_ARITH_FMAD;
+    if (prost_hip_fused_iteration3d_x2_arith(&probe, dtype_id<T>()) == PROST_HIP_ARITH_FMAD) desc_.arith = PROST_HIP_ARITH_FMAD;
+  }
+  if (opts_.arithmetic == PROST_HIP_ARITH_FMAD && pair_mc_) {
+    prost_hip_fused_desc probe = desc_pair_;
+    probe.arith = PROST_HIP_ARITH_FMAD;
+    if (prost_hip_fused_iteration_mc_x2_arith(&probe, dtype_id<T>()) == PROST_HIP_ARITH_FMAD) desc_pair_.arith = PROST_HIP_ARITH_FMAD;
   }
   if (pair_kernel_) x_spare_.resize(n);
   if (single_kernel_ || single3d_ || single_mc_) y_spare_.resize(m);

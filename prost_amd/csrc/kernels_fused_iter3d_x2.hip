@@ -98,7 +98,10 @@ struct ColX2 {
 // finished step k - 1 -- which also guarantees that they are done reading the slot it overwrites (written at step k - 3, read
 // at their step k - 2).  A barrier makes every step as long as its slowest wavefront (16 of them, each waiting for seven
 // loads); with the counters a late load delays the neighbouring planes by one step and is absorbed further out.
-template <class T, int VEC, int GFN, bool GB, int WT, bool RES, bool FLAGS>
+// FMAD: the tolerance-class arithmetic (prost_hip_fused_desc.arith = PROST_HIP_ARITH_FMAD, fp32): fused multiply-adds where a product feeds a
+// sum, the quotient by 1 + step as a product with its fp32 reciprocal, pr v / ||v|| as v min(b rsq(||v||^2), 1) -- see
+// kernels_fused_iter2.hip; results within the tolerance of tests/test_gpu_fmad.py of the exact instances, not bit-identical to them.
+template <class T, int VEC, int GFN, bool GB, int WT, bool RES, bool FLAGS, bool FMAD>
 __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                        const T* __restrict__ y, FusedArgs<T> a, IterParams3<T> p1, IterParams3<T> p2,
                                                                        double* __restrict__ partial, const PdhgRecord<T>* __restrict__ rec) {
@@ -185,6 +188,23 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
                     const T (&xin)[VEC], const T (&bv)[GB ? VEC : 1], const IterParams3<T>& Pm, T (&xn)[VEC], T (&ktv)[VEC]) {
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
+    if constexpr (FMAD) {
+      const T rD = (T)Pm.sq.rD;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const idx_t row = row0 + j;
+        const T divy = ((row < ny - 1) ? v2[j] : (T)0) - ((row > 0) ? (j > 0 ? v2[j > 0 ? j - 1 : 0] : up) : (T)0);
+        const T divx = ((c < nx - 1) ? v1[j] : (T)0) - ((c > 0) ? p1c[j] : (T)0);
+        const T divl = v3[j] - (has_below ? v3m[j] : (T)0);
+        const T sdiv = divx + divy + divl;
+        ktv[j] = -sdiv;
+        const T arg = t_fma(tauT, sdiv, xin[j]);
+        const T bj = GB ? bv[GB ? j : 0] : a.g_val[1];
+        if (GFN == PROST_FN_SQUARE) xn[j] = t_fma(arg - bj, rD, bj);
+        else { const T v = arg - bj; xn[j] = (v - t_max(t_min(v, Pm.step), -Pm.step)) + bj; }
+      }
+      return;
+    }
     T parg[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
@@ -239,6 +259,19 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
       T kx[3], kp[3];
       gradients(c, j, xn_c, xn_n, xn_z, xo_c, xo_n, xo_z, bel_n, bel_o, kx, kp);
       const T yv[3] = {v1[j], v2[j], v3[j]};
+      if constexpr (FMAD) {
+        const T opt = 1 + theta;
+        T nsq = 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const T arg = t_fma(sigS, t_fma(opt, kx[i], -(theta * kp[i])), yv[i]);
+          nsq = i == 0 ? arg * arg : t_fma(arg, arg, nsq);
+          av[i][j] = arg;
+        }
+        const T sc = t_min(a.f_val[1] * t_rsq(nsq), (T)1);        // radius b > 0 (host-checked); ||v|| = 0: b * inf -> factor 1 on a zero vector
+#pragma unroll
+        for (int i = 0; i < 3; i++) out[i][j] = av[i][j] * sc;
+      } else {
       T norm = 0;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
@@ -247,12 +280,14 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
         av[i][j] = arg;
       }
       nv[j] = norm;
+      }
     }
-    norm2_leq0_fast<T, 3, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+    if constexpr (!FMAD) norm2_leq0_fast<T, 3, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
   };
   // residual sums of the second iteration (RES): the terms of fused_iter3d_kernel
   const T sqT = t_sqrt(a.Tval), sqS = t_sqrt(a.Sval);
   const SharedDivisor<T> div_tauT(p2.tau * sqT), div_sigS(p2.sigma * sqS);   // wave-uniform: exact quotients through one double reciprocal each
+  const T inv_tauT = (T)1 / (p2.tau * sqT), inv_sigS = (T)1 / (p2.sigma * sqS);  // (FMAD: the tolerance-compared sums use these)
   if (RES) {
 #pragma unroll
     for (int k = 0; k < 4; k++) s_acc[RES ? k : 0][RES ? wv : 0][RES ? lane : 0] = 0;   // primal diff^2, primal var^2, dual diff^2, dual var^2
@@ -263,8 +298,8 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
     double dd = 0, dv = 0;
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      const T w_hat = div_tauT.div(xo[j] - xn[j]) - sqT * kt_prev[j];
-      const T diff = w_hat + sqT * kt[j];
+      const T w_hat = FMAD ? t_fma(-sqT, kt_prev[j], (xo[j] - xn[j]) * inv_tauT) : div_tauT.div(xo[j] - xn[j]) - sqT * kt_prev[j];
+      const T diff = FMAD ? t_fma(sqT, kt[j], w_hat) : w_hat + sqT * kt[j];
       dd += (double)(diff * diff); dv += (double)(w_hat * w_hat);
     }
     if (owner) { accumulate(2, dd); accumulate(3, dv); }
@@ -283,8 +318,9 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
       const T yv[3] = {v1[j], v2[j], v3[j]};
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        const T z_hat = div_sigS.div(yv[i] - out[i][j]) + sqS * ((1 + theta) * kx[i] - theta * kp[i]);
-        const T diff = z_hat - sqS * kx[i];
+        const T z_hat = FMAD ? t_fma(sqS, t_fma(1 + theta, kx[i], -(theta * kp[i])), (yv[i] - out[i][j]) * inv_sigS)
+                             : div_sigS.div(yv[i] - out[i][j]) + sqS * ((1 + theta) * kx[i] - theta * kp[i]);
+        const T diff = FMAD ? t_fma(-sqS, kx[i], z_hat) : z_hat - sqS * kx[i];
         pd += (double)(diff * diff); pv += (double)(z_hat * z_hat);
       }
     }
@@ -300,6 +336,9 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   };
 
   Col in1 = {}, in2 = {}, pre = {};                    // raw columns c+1, c+2 and the one being prefetched (c+3)
+  // (tried in round 6 with the tolerance-class instance, which needs 10-15 registers less: a SECOND column in flight (c+4).  As a third
+  // set copied down the chain nothing changes -- the copy itself waits for the newest loads (2.62 ms per launch either way at 2048 x
+  // 2048 x 64); as two sets that take turns in a twice-unrolled loop, 20-27 registers spill and the launch takes 4.64 ms.)
   T b_c[GB ? VEC : 1];                                 // b of prox_g at column c (stage C)
   T x1_m[VEC], x1_0[VEC], x1_1[VEC], x1_2[VEC];        // x^(k+1) at columns c-1 .. c+2
   T xz1_m[VEC], xz1_0[VEC], xz1_1[VEC];                // x^(k+1) one plane above at columns c-1 .. c+1 (from LDS)
@@ -335,16 +374,17 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
   // (tried in round 4: a second instance of the column step for the steady state -- columns c-1 .. c+3 inside the chunk's range and
   // strictly inside the image, so no column select is left in the stencils and every stage condition is the wavefront's role alone:
   // 16 selects and a dozen scalar compares less per step, but the two copies together no longer fit 128 VGPRs (15 spilled))
-  for (idx_t c = xa - 3; c <= xb; c++) {
+  // one column step; `cur` holds raw column c+2 and is refilled with the column that will be needed when its turn comes again
+  auto column_step = [&](idx_t c, Col& cur) {
     const int wr = FLAGS ? wr3 : (int)((c + 4) & 1), rd = FLAGS ? (wr3 == 0 ? 2 : wr3 - 1) : wr ^ 1;
     if (FLAGS && step > 0) {
       // wait for the neighbouring planes' wavefronts (whether or not their planes exist: every wavefront counts its steps)
       if (wv >= 1) while (__builtin_amdgcn_readfirstlane(lds_flag_read(&s_step[FLAGS ? wv - 1 : 0])) < step - 1) __builtin_amdgcn_s_sleep(1);
       if (wv + 1 < WT) while (__builtin_amdgcn_readfirstlane(lds_flag_read(&s_step[FLAGS ? wv + 1 : 0])) < step - 1) __builtin_amdgcn_s_sleep(1);
     }
-    // raw columns: in1 <- in2 <- pre, prefetch column c+3
-    in1 = in2; in2 = pre;
-    if (exists || !kUncond) load_col(c + 3, pre);
+    // raw columns: in1 <- in2 <- cur, prefetch column c+3
+    in1 = in2; in2 = cur;
+    if (exists || !kUncond) load_col(c + 3, cur);
     // neighbour-plane values published in the previous step
     if (has_above && wv + 1 < WT) { fetch(s_x1[rd], wv + 1, xz1_1); fetch(s_x2[rd], wv + 1, xz2_m); }
     if (has_below && wv >= 1) fetch(s_y3[rd], wv - 1, ym3_0);
@@ -404,7 +444,8 @@ __global__ void __launch_bounds__(kWave * WT, 1) fused_iter3d_x2_kernel(T* __res
 #pragma unroll
     for (int j = 0; j < (GB ? VEC : 1); j++) b_c[j] = in1.b[j];
     k3 = k3 == 2 ? 0 : k3 + 1;
-  }
+  };
+  for (idx_t c = xa - 3; c <= xb; c++) column_step(c, pre);
   if (RES) {                                           // the last barrier of the loop has passed: the exchange buffers are free
     if (FLAGS) __syncthreads();
     double* sred = reinterpret_cast<double*>(&s_x1[0][0][0]);
@@ -448,6 +489,11 @@ static bool iter3d_x2_ok(const prost_hip_fused_desc* d, int dtype) {
   // (residual launches write one partial per workgroup: with one chunk per tile the tiles alone must fit the reduction workspace)
   const size_t tiles = strips * ((d->L + kX2Waves - 4) / (kX2Waves - 3));
   return tiles <= (size_t)kReduceBlocks / 2 && tiles * d->nx < (size_t)1 << 31;
+}
+
+// tolerance-class instances: fp32, 2 rows per lane (even heights), ind_leq0 radius > 0; anything else computes exactly
+static bool iter3d_x2_fmad(const prost_hip_fused_desc* d, int dtype) {
+  return d->arith == PROST_HIP_ARITH_FMAD && dtype == 0 && iter3d_x2_ok(d, dtype) && x2_vec(dtype, d->ny) == 2 && d->f_coeff_val[1] > 0.0;
 }
 
 static int compute_units() {
@@ -495,7 +541,9 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
   if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused 3-D double iteration: grid exceeds the reduction workspace"); return 1; }
   double* partial = static_cast<double*>(ws);
   static const bool flags = []() { const char* e = getenv("PROST_X2_SYNC"); return !(e && atoi(e) == 0); }();      // PROST_X2_SYNC=0: the barrier per step (A/B)
-#define GO3(G, B, R, F) PH_LAUNCH((fused_iter3d_x2_kernel<T, V, G, B, WT, R, F>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, static_cast<const PdhgRecord<T>*>(record))
+  const bool fmad = iter3d_x2_fmad(d, std::is_same<T, float>::value ? 0 : 1);
+#define GO4(G, B, R, F, A) PH_LAUNCH((fused_iter3d_x2_kernel<T, V, G, B, WT, R, F, A>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, static_cast<const PdhgRecord<T>*>(record))
+#define GO3(G, B, R, F) do { bool done_ = false; if constexpr (std::is_same<T, float>::value && V == 2) { if (fmad) { GO4(G, B, R, F, true); done_ = true; } } if (!done_) GO4(G, B, R, F, false); } while (0)
 #define GO2(G, B, R) do { if (flags && !R) GO3(G, B, false, true); else GO3(G, B, R, false); } while (0)
 #define GO(B, R) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B, R); else GO2(PROST_FN_SQUARE, B, R); } while (0)
   if (d->g_coeff_ptr[1]) { if (out4) GO(true, true); else GO(true, false); }
@@ -503,6 +551,7 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
 #undef GO
 #undef GO2
 #undef GO3
+#undef GO4
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused 3-D double iteration kernel"); }
   if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid, s);
@@ -538,6 +587,7 @@ using namespace prost_hip;
 
 extern "C" {
 int prost_hip_fused_iteration3d_x2_supported(const prost_hip_fused_desc* d, int dtype) { return iter3d_x2_ok(d, dtype) ? 1 : 0; }
+int prost_hip_fused_iteration3d_x2_arith(const prost_hip_fused_desc* d, int dtype) { return iter3d_x2_fmad(d, dtype) ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT; }
 int prost_hip_fused_iteration3d_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int with_residuals) {
   return iter3d_x2_ok(d, dtype) ? (int)x2_chunk_cols(d, dtype, 0, with_residuals != 0) : 0;
 }

@@ -52,7 +52,8 @@ __device__ __forceinline__ void stm_o(T* __restrict__ base, unsigned byte_off, c
 // 3 per-pixel b AND the position-dependent primal preconditioner of a gradient handed over as a sparse matrix (FusedArgs::varT; square
 // data term) -- the expressions of fused_iter2d_mc_kernel<..., VART>: K^T y in the order of the matrix's transposed CSR row, the pixels of
 // the first / last row and column with the step and the divisor of their class
-template <class T, int VEC, int GFN, int GB, int LW, bool RES>
+// FMAD: the tolerance-class arithmetic (prost_hip_fused_desc.arith = PROST_HIP_ARITH_FMAD; fp32, GB <= 2): see kernels_fused_iter2.hip
+template <class T, int VEC, int GFN, int GB, int LW, bool RES, bool FMAD>
 __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out, const T* __restrict__ x,
                                                                                 const T* __restrict__ y, FusedArgs<T> a, IterParamsMc<T> p1,
                                                                                 IterParamsMc<T> p2, double* __restrict__ partial,
@@ -119,6 +120,25 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
     constexpr bool VART = GB == 3;
     const T tauT = Pm.tau * a.Tval;
     const T up = lane_up(v2[VEC - 1]);                 // lane 0: no source, its first row is halo
+    if constexpr (FMAD) {
+      const T rD = (T)Pm.sq.rD;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const idx_t row = row0 + j;
+        const T divy = ((row < ny - 1) ? v2[j] : (T)0) - ((row > 0) ? (j > 0 ? v2[j > 0 ? j - 1 : 0] : up) : (T)0);
+        const T divx = ((c < nx - 1) ? v1[j] : (T)0) - ((c > 0) ? p1c[j] : (T)0);
+        const T sdiv = divx + divy;
+        ktv[j] = -sdiv;
+        const T arg = t_fma(tauT, sdiv, xin[j]);
+        const T bj = GB ? bv[GB ? j : 0] : a.g_val[1];
+        T r;
+        if (GFN == PROST_FN_SQUARE) r = t_fma(arg - bj, rD, bj);
+        else { const T v = arg - bj; r = (v - t_max(t_min(v, Pm.step), -Pm.step)) + bj; }
+        if (GB == 2) r = is_mask_sentinel(bj) ? arg : r;
+        xn[j] = r;
+      }
+      return;
+    }
     T parg[VEC], parg0[GB == 2 ? VEC : 1];
     T argv[VART ? VEC : 1];
     bool edgev[VART ? VEC : 1], cornerv[VART ? VEC : 1];
@@ -191,8 +211,13 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
       const T kx1 = (row < ny - 1) ? below_n - xn_c[j] : (T)0;
       const T kp0 = has_next ? xo_n[j] - xo_c[j] : (T)0;
       const T kp1 = (row < ny - 1) ? below_o - xo_c[j] : (T)0;
+      if constexpr (FMAD) {
+        av[0][j] = t_fma(sigS, t_fma(1 + theta, kx0, -(theta * kp0)), v1[j]);
+        av[1][j] = t_fma(sigS, t_fma(1 + theta, kx1, -(theta * kp1)), v2[j]);
+      } else {
       av[0][j] = v1[j] + sigS * ((1 + theta) * kx0 - theta * kp0);              // backend_pdhg.cu:54-70
       av[1][j] = v2[j] + sigS * ((1 + theta) * kx1 - theta * kp1);
+      }
       sq[ch][j * kWave + lane] = av[0][j] * av[0][j];                           // [j][lane]: conflict-free banks
       sq[LW + ch][j * kWave + lane] = av[1][j] * av[1][j];
     }
@@ -206,8 +231,12 @@ __global__ void __launch_bounds__(kWave * LW, 3) fused_iter2d_mc_x2_kernel(T* __
 #pragma unroll
       for (int i = 0; i < 2 * LW; i++) norm += sq[i][j * kWave + lane];
       nv[j] = norm;
+      if constexpr (FMAD) {          // pr v / ||v|| = v min(b / ||v||, 1), radius b > 0 (host-checked); ||v|| = 0: b * inf -> factor 1 on a zero vector
+        const T sc = t_min(a.f_val[1] * t_rsq(norm), (T)1);
+        out[0][j] = av[0][j] * sc; out[1][j] = av[1][j] * sc;
+      }
     }
-    norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
+    if constexpr (!FMAD) norm2_leq0_fast<T, 2, VEC>(nv, av, a.f_val[1], tiny_is_zero, out);
   };
 
   // residual sums of the second iteration (RES): the terms of fused_iter2d_mc_kernel
@@ -406,6 +435,11 @@ static size_t mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int col
   return best_c < d->nx ? best_c : d->nx;
 }
 
+// tolerance-class instances: fp32, 4 rows per lane (heights that are a multiple of 4), uniform Tau, ind_leq0 radius > 0; anything else computes exactly
+static bool iter_mc_x2_fmad(const prost_hip_fused_desc* d, int dtype) {
+  return d->arith == PROST_HIP_ARITH_FMAD && dtype == 0 && iter_mc_x2_ok(d, dtype) && mc_x2_vec(dtype, d->ny) == 4 && !d->var_T && d->f_coeff_val[1] > 0.0;
+}
+
 template <class T>
 static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T* x, const T* y, const double* tau, const double* sigma,
                           const double* theta, int cols, double* out4, void* ws, void* stream, void* record = nullptr, const RuleTail* tail = nullptr) {
@@ -437,7 +471,9 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
   if (out4 && grid > (unsigned)kReduceBlocks / 2) { set_error("fused multi-channel double iteration: grid exceeds the reduction workspace"); return 1; }
   double* partial = static_cast<double*>(ws);
   const bool full = mc_x2_vec(kDtype, d->ny) > 1;
-#define GO5(VV, G, B, LWv, R) PH_LAUNCH((fused_iter2d_mc_x2_kernel<T, VV, G, B, LWv, R>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, rec)
+  const bool fmad = iter_mc_x2_fmad(d, kDtype);
+#define GO6(VV, G, B, LWv, R, A) PH_LAUNCH((fused_iter2d_mc_x2_kernel<T, VV, G, B, LWv, R, A>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, rec)
+#define GO5(VV, G, B, LWv, R) do { bool done_ = false; if constexpr (std::is_same<T, float>::value && VV == 4 && B != 3) { if (fmad) { GO6(VV, G, B, LWv, R, true); done_ = true; } } if (!done_) GO6(VV, G, B, LWv, R, false); } while (0)
 #define GO4(G, B, LWv, R) do { if (full) GO5(VecOf<T>::N, G, B, LWv, R); else GO5(1, G, B, LWv, R); } while (0)
 #define GO3(G, B, LWv) do { if (out4) GO4(G, B, LWv, true); else GO4(G, B, LWv, false); } while (0)
 #define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)
@@ -450,6 +486,7 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
 #undef GO3
 #undef GO4
 #undef GO5
+#undef GO6
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused multi-channel double iteration kernel"); }
   if (out4 && tail && tail->apply) return launch_fold4_rule<T>(out4, partial, grid, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid, s);
@@ -471,6 +508,7 @@ int prost_hip_fused_iteration_mc_x2_profitable(const prost_hip_fused_desc* d, in
   const double values = (double)d->nx * (double)d->ny * (double)d->L;
   return values <= 3.0e5 || values >= 1.5e6 ? 1 : 0;
 }
+int prost_hip_fused_iteration_mc_x2_arith(const prost_hip_fused_desc* d, int dtype) { return iter_mc_x2_fmad(d, dtype) ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT; }
 int prost_hip_fused_iteration_mc_x2_chunk_cols(const prost_hip_fused_desc* d, int dtype, int with_residuals) {
   return iter_mc_x2_ok(d, dtype) ? (int)mc_x2_chunk_cols(d, dtype, 0, with_residuals != 0) : 0;
 }

@@ -24,6 +24,9 @@ EXPECTED = {
     ("fused_iter2d_x2_kernel+residuals", False): 7, ("fused_iter2d_mc_x2_kernel+residuals", False): 7,
     ("fused_iter3d_x2_kernel+residuals", True): 9,
     ("fused_iter2d_x2_kernel+mid+residuals", False): 10,
+    # K iterations per launch (tolerance-class arithmetic): the same seven values whatever K
+    ("fused_iter2d_xk_kernel<2>", False): 7, ("fused_iter2d_xk_kernel<3>", False): 7, ("fused_iter2d_xk_kernel<4>", False): 7,
+    ("fused_iter2d_xk_kernel<2>+residuals", False): 7, ("fused_iter2d_xk_kernel<3>+residuals", False): 7, ("fused_iter2d_xk_kernel<4>+residuals", False): 7,
 }
 
 
@@ -39,20 +42,37 @@ def test_every_name_the_backend_can_emit_is_priced():
     src = open(os.path.join(ROOT, "prost_amd", "csrc", "host", "backend_pdhg.cpp")).read()
     block = src[src.index("const char* names[kKernelKinds]"):]
     block = block[:block.index("};")]
-    names = set(re.findall(r'"(fused_[a-z0-9_+]+)"', block))
-    assert len(names) >= 15, names
+    names = set(re.findall(r'"(fused_[a-z0-9_+<>]+)"', block))
+    assert len(names) >= 21, names
     for name in names:
         volume = "3d" in name
         assert (name, volume) in EXPECTED, "tests/test_bench_harness.py does not know %s" % name
         assert bench.compulsory_floats(name, volume) == EXPECTED[(name, volume)], name
         family, suffix = bench.kernel_kind(name)
-        assert family in ("primal", "dual", "iter", "iter_x2")
+        assert family in ("primal", "dual", "iter", "iter_x2", "iter_xk")
         if "residuals" in name:
             assert family not in ("primal", "dual"), name
 
 
+def test_no_rate_above_the_hbm_peak_unless_its_name_says_equivalent():
+    """round-5 review: a top-level `achieved_hbm_GBps` of 13 218 read as impossible.  The two-pass-equivalent figures carry 'equiv' in
+    their names; everything else called GB/s, and every roofline fraction, is checked against the peak before the line is printed"""
+    ok = {"n_gpus": 1, "value": 19000.0, "two_pass_equiv_GBps": 14026.0, "roofline": {"achieved": 4600.0, "achieved_hbm_traffic": 5500.0, "frac": 0.575, "frac_hbm_traffic": 0.69,
+                                                                                "algorithmic_equiv_GBps": 14400.0, "algorithmic_equiv_frac": 1.8, "peak": 8000.0},
+          "fmad": {"two_pass_equiv_GBps": 23000.0}, "roofline_fmad": {"achieved": 4500.0, "frac": 0.56}}
+    assert bench.validate_line(ok) is ok
+    for bad in ({"achieved_hbm_GBps": 13218.0}, {"roofline": {"achieved": 8100.0}}, {"roofline": {"frac": 1.01}}, {"roofline_fmad": {"achieved_hbm_traffic": 9000.0}},
+                {"fmad": {"some_GBps": 9000.0}}):
+        with pytest.raises(ValueError):
+            bench.validate_line(dict(ok, **bad))
+    assert bench.validate_line({"n_gpus": 8, "some_GBps": 40000.0})            # whole-job rates scale with the GPUs
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"achieved_hbm_GBps"' not in src and "validate_line(out)" in src
+
+
 def test_unknown_names_are_not_priced():
-    for name in ("cg_step_xr2_kernel", "fused_dual2d_kernel+residuals", "residuals", "fused_iter2d_kernel+mid", "something_dual"):
+    for name in ("cg_step_xr2_kernel", "fused_dual2d_kernel+residuals", "residuals", "fused_iter2d_kernel+mid", "something_dual", "fused_iter2d_xk_kernel<4>+mid",
+                 "fused_iter2d_xk_kernel<x>"):
         assert bench.compulsory_floats(name, False) is None
 
 

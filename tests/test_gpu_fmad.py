@@ -280,3 +280,85 @@ def test_shapes_without_a_tolerance_class_instance_run_exact():
         assert np.array_equal(st[v], ost[v]), v
     with pytest.raises(ValueError):
         prost.backend.pdhg(arithmetic="fast")
+
+
+@pytest.mark.parametrize("kind,dims", [("3d", (48, 40, 9)), ("3d", (128, 96, 20)), ("rgb", (96, 128, 3)), ("rgb", (200, 64, 2)), ("rgb", (64, 64, 4))])
+def test_volumes_and_colour_images_track_the_oracle(kind, dims):
+    """the tolerance-class instances of the 3-D and the multi-channel pair kernels (two iterations per launch as in the exact class)"""
+    nx, ny, L = dims
+    k = 42
+    f = synthetic.rof_image(nx, ny, L, 42)
+    prob = (synthetic.tv3d_problem(nx, ny, L, f=f) if kind == "3d" else synthetic.rof_problem(nx, ny, L, f=f))[0]
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5, arithmetic="fmad")
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    s = prost.Solver(prob, b, o)
+    info = s.iterate(k, time_kernels=True, sample_every=1)
+    st = s.state()
+    s.destroy()
+    assert st["arithmetic"] == "fmad" and st["path"] == ("pdhg:fused-grad3d+fmad" if kind == "3d" else "pdhg:fused-grad2d+fmad"), (st["arithmetic"], st["path"])
+    assert any("_x2_kernel" in nm for nm in info["kernels"]), info["kernels"]
+    bo = [b[0], {kk: v for kk, v in b[1].items() if kk != "arithmetic"}]
+    os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, bo, o, np.float32)
+    os_.initialize(); os_.iterate(k)
+    ost = os_.state(); sc = os_.scalars()
+    del os_
+    differs = False
+    for v in "xyzw":
+        rel = float(np.abs(st[v].astype(np.float64) - ost[v]).max()) / float(np.abs(ost[v]).max())
+        assert rel <= 1e-5 * k, (kind, dims, v, rel)
+        differs = differs or not np.array_equal(st[v], ost[v])
+    assert differs                                  # (the tolerance-class instance did run)
+    # (residual norms: a per-element residual of ~2e-4 is formed from terms of size 0.1 .. 1, so two roundings of the same iterate
+    # differ by ~5e-4 of it)
+    for v in ("primal_res", "dual_res"):
+        assert np.isclose(st[v], sc[v], rtol=2e-3), (v, st[v], sc[v])
+
+
+def _crop(f, nx, ny, L, x0, x1, y0, y1, l0, l1):
+    return np.ascontiguousarray(f.reshape(L, nx, ny)[l0:l1, x0:x1, y0:y1]).reshape(-1)
+
+
+def _read_block(solver, which, comps, nx, ny, L, x0, x1, y0, y1, l0, l1):
+    n = nx * ny * L
+    offs = [c * n + l * nx * ny + x * ny + y0 for c in range(comps) for l in range(l0, l1) for x in range(x0, x1)]
+    return solver.read(which, offs, y1 - y0).reshape(comps, l1 - l0, x1 - x0, y1 - y0)
+
+
+def test_c3_2048x2048x64_sub_volumes_track_the_oracle():
+    """BASELINE config 3 at its full size in the tolerance class: sub-volumes of the 2048 x 2048 x 64 run against oracle runs on the
+    cropped volume (tests/test_gpu_fullsize.py: after k iterations every voxel further than k from a crop's artificial faces depends
+    on the crop's data only)"""
+    nx, ny, L, k = 2048, 2048, 64, 12
+    f = synthetic.rof_image(nx, ny, L, 42)
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    prob = synthetic.tv3d_problem(nx, ny, L, f=f)[0]
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5, arithmetic="fmad")
+    s = prost.Solver(prob, b, o)
+    del prob
+    info = s.iterate(k, time_kernels=True)
+    scal = s.state(vectors=False)
+    assert scal["path"] == "pdhg:fused-grad3d+fmad" and scal["iteration"] == k
+    assert any(nm.startswith("fused_iter3d_x2_kernel") for nm in info["kernels"]), info["kernels"]
+    oracle.set_num_threads(16)
+    margin = k + 1
+    bo = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+    for (x0, x1, y0, y1, l0, l1) in [(nx - 44, nx, ny - 72, ny, L - 36, L), (1000, 1044, 1990, 2048, 20, 56)]:
+        cx, cy, cl = x1 - x0, y1 - y0, l1 - l0
+        cprob = synthetic.tv3d_problem(cx, cy, cl, f=_crop(f, nx, ny, L, x0, x1, y0, y1, l0, l1))[0]
+        cprob.finalize()
+        osv = oracle.Solver(cprob.data, cprob.nrows, cprob.ncols, bo, o, np.float32)
+        osv.initialize(); osv.iterate(k)
+        ost = osv.state()
+        lo = lambda a0: 0 if a0 == 0 else margin
+        hi = lambda a1, full, c: c if a1 == full else c - margin
+        sx, sy, sl = slice(lo(x0), hi(x1, nx, cx)), slice(lo(y0), hi(y1, ny, cy)), slice(lo(l0), hi(l1, L, cl))
+        got_x = _read_block(s, "x", 1, nx, ny, L, x0, x1, y0, y1, l0, l1)[:, sl, sx, sy]
+        got_y = _read_block(s, "y", 3, nx, ny, L, x0, x1, y0, y1, l0, l1)[:, sl, sx, sy]
+        exp_x = ost["x"].reshape(1, cl, cx, cy)[:, sl, sx, sy]
+        exp_y = ost["y"].reshape(3, cl, cx, cy)[:, sl, sx, sy]
+        assert got_x.size > 4000
+        for name, g, e in (("x", got_x, exp_x), ("y", got_y, exp_y)):
+            rel = float(np.abs(g.astype(np.float64) - e).max()) / float(np.abs(e).max())
+            assert rel <= 1e-5 * k, (name, (x0, y0, l0), rel)
+            assert not np.array_equal(g, e)
+    s.destroy()
