@@ -66,7 +66,7 @@ HBM_PEAK_GBPS = 8000.0
 TRAFFIC_TABLE = os.path.join(ROOT, "profiles", "traffic_table.json")
 
 
-def traffic_bytes(kernel, size, chunk_cols, dtype="f32"):
+def traffic_bytes(kernel, size, chunk_cols, dtype="f32", config=None):
     """HBM bytes per launch of `kernel` (name as KernelTimes reports it) at image side `size` with `chunk_cols` columns
     per wavefront, from the PMC passes recorded in profiles/traffic_table.json (FETCH_SIZE doubled per
     MI355X_MICROARCH.md + WRITE_SIZE, KiB; rows without a "dtype" are fp32).  None when this launch geometry was never profiled."""
@@ -76,7 +76,7 @@ def traffic_bytes(kernel, size, chunk_cols, dtype="f32"):
     except (OSError, ValueError, KeyError):
         return None, None
     for r in rows:
-        if r["kernel"] == kernel and r["size"] == size and r["chunk_cols"] == chunk_cols and r.get("dtype", "f32") == dtype:
+        if r["kernel"] == kernel and r["size"] == size and r["chunk_cols"] == chunk_cols and r.get("dtype", "f32") == dtype and r.get("config", "c4" if config == "c4" else None) == config:
             return (2 * r["fetch_size_kib"] + r["write_size_kib"]) * 1024, r.get("source")
     return None, None
 
@@ -154,26 +154,11 @@ def compulsory_floats(kname, volume):
 ZERO_TOL = dict(tol_rel_primal=0, tol_rel_dual=0, tol_abs_primal=0, tol_abs_dual=0)
 
 
-def c4_problem(N):
-    """SURVEY 8(d) C4: primal u in R^(2n); v = W u with W = [diag(Ix) diag(Iy)] (block.sparse, 2 nnz per row), g = gradient2d(N, N, 2) u;
-    f(v) = sum_1d('abs', 1, b, lambda), f(g) = sum_norm2(4, false, 'abs'); min_problem"""
-    import scipy.sparse as sp
-
-    import prost_amd as prost
+def c4_problem(N, warp=False):
+    """SURVEY 8(d) C4 (warp=False: W = [diag(Ix) diag(Iy)]) / its gather-type sibling c4w (warp=True: 4 non-zeros per row at displaced
+    columns): prost_amd/synthetic.py, tvl1_flow_problem"""
     from prost_amd import synthetic
-    n = N * N
-    Ix = synthetic.rof_image(N, N, 1, 1) - 0.5
-    Iy = synthetic.rof_image(N, N, 1, 2) - 0.5
-    bvec = synthetic.rof_image(N, N, 1, 3) - 0.5
-    W = sp.hstack([sp.diags(Ix), sp.diags(Iy)]).tocsc()
-    u = prost.variable(2 * n)
-    v, g = prost.variable(n), prost.variable(4 * n)
-    prob = prost.min_problem([u], [v, g])
-    prob.add_function(v, prost.function.sum_1d("abs", 1, bvec, 5.0))
-    prob.add_function(g, prost.function.sum_norm2(4, False, "abs"))
-    prob.add_constraint(u, v, prost.block.sparse(W))
-    prob.add_constraint(u, g, prost.block.gradient2d(N, N, 2))
-    return prob
+    return synthetic.tvl1_flow_problem(N, warp)
 
 
 def make_config(name, size, volume, seed, fp="fp32"):
@@ -203,7 +188,14 @@ def make_config(name, size, volume, seed, fp="fp32"):
                              "reference defaults (cg_max_iter=10, residual_iter=1); a step = one ADMM iteration = one graph projection (CGLS) + two proxes; "
                              "one independent problem per GPU" % (size, size), prelude=100,
                     tiny=lambda: c4_problem(32))
-    raise SystemExit("bench.py: unknown --config %r (c2, c3, c4)" % name)
+    if name == "c4w":
+        return dict(prob=c4_problem(size, True), backend=prost.backend.admm(rho0=1), metric="ADMM iters/sec, TV-L1 optical flow (warp matrix) %d^2 %s" % (size, fp),
+                    units=size * size, alg_floats_per_unit=None, size_key=size,
+                    workload="TV-L1 optical flow %dx%d (block.sparse warp matrix W: n x 2n, 4 non-zeros per row at columns displaced by a smooth flow of up to 5 "
+                             "pixels, general CSR + gradient2d L=2, sum_1d abs + sum_norm2(4) abs), ADMM rho0=1 with the reference's defaults (cg_max_iter=10); "
+                             "BASELINE.json configs[3] as worded" % (size, size), prelude=100,
+                    tiny=lambda: c4_problem(32, True))
+    raise SystemExit("bench.py: unknown --config %r (c2, c3, c4, c4w)" % name)
 
 
 # C4: values per PIXEL every kernel of an ADMM outer iteration has to move once (n = 2 px primal entries, m = 5 px rows: W's row + 4
@@ -223,23 +215,36 @@ C4_OUTER_VALUES = {"AdmmPreX": (16, 0), "EpiPreZK": (29, 3), "InitX": (8, 0), "E
                    "EpiPostZK": (29, 3), "prox_f": (16, 0), "EpiResZK": (29, 3), "EpiResXK": (15, 4)}
 
 
-def c4_kernel_bytes(kname, n_px, itemsize=4):
+def c4_values(table, name, w_nnz=2):
+    """(vector values, index words) per pixel of a stage at a W with `w_nnz` non-zeros per row: the tables above are written for C4's two;
+    every stage that applies W or W^T (Epi...K / EpiFwd / EpiAdj: the names with index words) reads w_nnz - 2 more values and as many more
+    column indices per pixel"""
+    v = table.get(name)
+    if v is None:
+        return None
+    extra = (w_nnz - 2) if v[1] > 0 else 0
+    return (v[0] + extra, v[1] + extra)
+
+
+def c4_kernel_bytes(kname, n_px, itemsize=4, w_nnz=2):
     """compulsory bytes of one launch of a kernel of the CG round at the C4 shape (generic kernels: every vector the
     kernel has to read or write once, CSR arrays included)"""
-    v = C4_KERNEL_VALUES.get(kname)
+    v = c4_values(C4_KERNEL_VALUES, kname, w_nnz)
     return (v[0] * itemsize + v[1] * 4) * n_px if v else None
 
 
-def c4_iteration_bytes(path, cg_rounds, n_px, itemsize=4):
+def c4_iteration_bytes(path, cg_rounds, n_px, itemsize=4, w_nnz=2):
     """compulsory bytes of ONE ADMM outer iteration at the C4 shape: the stages outside the solve + `cg_rounds` CG rounds of the path
     that ran (two launches per round: admm:pixel-op; four: admm:fused-op).  None for a path this table does not describe."""
     words = lambda t: t[0] * itemsize + t[1] * 4
-    outer = sum(words(t) for t in C4_OUTER_VALUES.values())
+    outer = sum(words(c4_values(C4_OUTER_VALUES, k, w_nnz)) for k in C4_OUTER_VALUES)
     if path == "admm:pixel-op":
+        if w_nnz != 2:
+            return None
         rnd = words(C4_KERNEL_VALUES["cg_pixel_pq_kernel"]) + words(C4_KERNEL_VALUES["cg_pixel_xrs_kernel"])
         first = rnd - 4 * itemsize                                  # the first launch A of a solve reads no s and writes no p
     elif path == "admm:fused-op":
-        rnd = sum(words(C4_KERNEL_VALUES[k]) for k in ("op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"))
+        rnd = sum(words(c4_values(C4_KERNEL_VALUES, k, w_nnz)) for k in ("op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"))
         first = rnd
     else:
         return None
@@ -280,14 +285,14 @@ def cpu_baseline_c3(volume, max_threads, np_dtype=None):
                       "threads (best of a probe up to all logical CPUs, vectors first-touched per thread); value = the crop's voxel-iteration rate divided by the %dx%dx%d voxels of the full volume" % (iters, cx, cy, L, threads, nx, ny, L)}
 
 
-def cpu_baseline_c4(size, backend, max_threads, np_dtype=None):
+def cpu_baseline_c4(size, backend, max_threads, np_dtype=None, warp=False):
     """oracle ADMM (restatement of backend_admm.cu + cgls.hpp; parity-unpinned by the reference) on the SAME problem,
     about 10 s of outer iterations"""
     import numpy as np
 
     import oracle
     import prost_amd as prost
-    prob = c4_problem(size)
+    prob = c4_problem(size, warp)
     prob.finalize()
     opts = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
     oracle.set_num_threads(min(64, max_threads))
@@ -500,7 +505,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 1000 + 5000 iterations = 0.4 s of GPU time.  The part needs ~10 ms of load to reach its steady clocks:
     # with --warmup 20 --steps 500 (a 35 ms run) the pair kernel measures 0.124 ms per launch, in steady state 0.115 ms
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"], help="BASELINE config (default c2 = the headline: ROF-TV 4096^2)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c4w"], help="BASELINE config (default c2 = the headline: ROF-TV 4096^2)")
     ap.add_argument("--steps", type=int, default=None, help="timed iterations (default: 5000 for c2, 200 for c3, 1000 for c4)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up iterations (default: 1000 / 20 / 100)")
     ap.add_argument("--size", type=int, default=None, help="image side (default 4096 for c2, 1024 for c4)")
@@ -522,7 +527,7 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be at least 1")
-    dflt = {"c2": (5000, 1000, N_IMG), "c3": (200, 20, None), "c4": (1000, 100, 1024)}[args.config]
+    dflt = {"c2": (5000, 1000, N_IMG), "c3": (200, 20, None), "c4": (1000, 100, 1024), "c4w": (1000, 100, 1024)}[args.config]
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup
     args.size = dflt[2] if args.size is None else args.size
@@ -740,8 +745,13 @@ def main():
         if rccl_fallback:
             out["value_without_rccl"] = value
             out["error"] = "the native RCCL communicator could not be created; the run used the host-callback transport over gloo and does not count"
-        if args.config == "c4":
+        if args.config in ("c4", "c4w"):
             out["cg_iterations_last_solve"] = st.get("cg_iterations")
+            # nothing the reference holds pins ADMM / CGLS: backend_admm.cu needs cuBLAS (nrm2, axpy) and cuSPARSE (csrmv) to compile, neither
+            # exists here; the oracle's ADMM is a restatement checked by properties only
+            out["oracle_pin"] = "unpinned (the reference's backend_admm.cu / cgls.hpp need cuBLAS / cuSPARSE; the CPU oracle's ADMM is a restatement)"
+        w_nnz = 4 if args.config == "c4w" else 2
+
         def roofline_of(kern, value, st):
             """the roofline object of one measurement: dominant kernel = largest share of the timed region (mean launch time x launches)"""
             if not kern:
@@ -751,7 +761,7 @@ def main():
             ipl = k["iterations_per_launch"]
             if args.config in ("c4", "c4w"):
                 # ADMM: the kernels of the CG round, each against its own compulsory bytes (generic kernels)
-                comp_bytes = c4_kernel_bytes(kname, units, itemsize)
+                comp_bytes = c4_kernel_bytes(kname, units, itemsize, w_nnz)
                 alg_bytes = None
                 note = ("ADMM has no per-iteration byte figure in SURVEY 8d; frac = COMPULSORY bytes of the dominant kernel of the CG round (every operand read "
                         "or written once, index arrays included: %s) / its launch time / peak.  compulsory_bytes_per_iteration = the same count over EVERY "
@@ -782,7 +792,7 @@ def main():
                         "within its stated bounds of that oracle at this size)." % (cf, unit_name, ipl if ipl else "1/2", afu, unit_name))
             t_s = k["avg_ms"] * 1e-3
             achieved = comp_bytes / 1e9 / t_s if comp_bytes else None
-            traffic, traffic_src = traffic_bytes(kname, cfg["size_key"], k["chunk_cols"], args.dtype)
+            traffic, traffic_src = traffic_bytes(kname, cfg["size_key"], k["chunk_cols"], args.dtype, args.config if args.config in ("c4", "c4w") else None)
             phys = traffic / 1e9 / t_s if traffic else None
             alg = alg_bytes / 1e9 / t_s if alg_bytes else None
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -798,11 +808,11 @@ def main():
                     "sample_every": every,
                     "all_kernels": {name: {"avg_launch_ms": v["avg_ms"], "launches": v["launches"], "launches_timed": v["sampled"],
                                            "iterations_per_launch": v["iterations_per_launch"], "chunk_cols": v["chunk_cols"],
-                                           "compulsory_bytes": c4_kernel_bytes(name, units, itemsize) if args.config in ("c4", "c4w")
+                                           "compulsory_bytes": c4_kernel_bytes(name, units, itemsize, w_nnz) if args.config in ("c4", "c4w")
                                            else (compulsory_floats(name, args.config == "c3") or 0) * itemsize * units or None}
                                     for name, v in kern.items()}}
             if args.config in ("c4", "c4w"):
-                it_bytes = c4_iteration_bytes(st["path"], st.get("cg_iterations") or 0, units, itemsize)
+                it_bytes = c4_iteration_bytes(st["path"], st.get("cg_iterations") or 0, units, itemsize, w_nnz)
                 roof["compulsory_bytes_per_iteration"] = it_bytes
                 roof["frac_iteration"] = (value / world) * it_bytes / 1e9 / HBM_PEAK_GBPS if it_bytes else None
                 roof["cg_rounds_per_iteration"] = st.get("cg_iterations")
@@ -845,7 +855,7 @@ def main():
             elif args.config == "c3":
                 out["cpu_baseline"] = cpu_baseline_c3(tuple(args.volume), threads, np.float32 if args.dtype == "f32" else np.float64)
             else:
-                out["cpu_baseline"] = cpu_baseline_c4(args.size, backend, threads, np.float32 if args.dtype == "f32" else np.float64)
+                out["cpu_baseline"] = cpu_baseline_c4(args.size, backend, threads, np.float32 if args.dtype == "f32" else np.float64, args.config == "c4w")
     else:
         out = None
 

@@ -1423,6 +1423,10 @@ static bool pixel_op_ok(const prost_hip_pixel_op* op, uint64_t m, uint64_t n, un
   if (!op || op->nx == 0 || op->ny == 0 || op->L < 1 || op->L > 3) return false;
   const uint64_t npx = op->nx * op->ny;
   if (op->ny % V || npx >= ((uint64_t)1 << 31)) return false;
+  // one workgroup per tile of kBlock x V pixels writes a partial into the reduction workspace (cgls_pixel_round): images beyond
+  // kReduceBlocks tiles (8.4 M pixels in fp32, 4.2 M in fp64 -- 4096^2) are refused HERE, so that BackendADMM::DescribeOperator falls
+  // back to the four-launch rounds (whose fold grids are capped) instead of picking a path whose every solve then fails
+  if ((npx / V + kBlock - 1) / kBlock > (uint64_t)kReduceBlocks) return false;
   if (n != (uint64_t)op->L * npx) return false;
   if (op->has_d) {
     if (!op->w || m != npx + 2 * (uint64_t)op->L * npx) return false;

@@ -62,3 +62,56 @@ def tv3d_problem(nx, ny, L, lmb=10.0, seed=42, f=None, data_term="square"):
     prob.add_function(q, function.sum_norm2(3, False, "ind_leq0", 1, 1, 1))
     prob.add_dual_pair(u, q, block.gradient3d(nx, ny, L))
     return prob, u, q, f
+
+
+def warp_matrix(N, seed_base=0):
+    """A gather-type warp matrix W (n x 2n, n = N^2, exactly 4 non-zeros per row at DISPLACED columns): the linearised brightness-constancy
+    term of TV-L1 optical flow, rho(u) = Ix(p + d) u1(p + d) + Iy(p + d) u2(p + d) - b, evaluated at the position p + d(p) a smooth
+    warm-start flow d (|d| <= 5 pixels) points to, with LINEAR interpolation between the two neighbouring pixels along the flow's
+    dominant axis per channel:  row p holds  Ix(q0) (1 - a), Ix(q1) a  at the columns of channel 1 and  Iy(r0) (1 - c), Iy(r1) c  at
+    the columns of channel 2, q0 / q1 the two x-neighbours of the warped position (y rounded), r0 / r1 its two y-neighbours (x rounded).
+    A general CSR block for block_sparse.cu:146-211 (the reference has no optical-flow example; example_tvl1.m:26-43 is the nearest
+    problem).  -> scipy CSC matrix; Ix, Iy from the counter-hash generator (rof_image seeds 1, 2), column-major pixels (idx = y + x N)."""
+    import scipy.sparse as sp
+    n = N * N
+    Ix = rof_image(N, N, 1, seed_base + 1) - 0.5
+    Iy = rof_image(N, N, 1, seed_base + 2) - 0.5
+    idx = np.arange(n)
+    py, px = idx % N, idx // N
+    dx = 4.5 * np.sin(2 * np.pi * 1.5 * px / N) * np.cos(2 * np.pi * py / N)
+    dy = 4.5 * np.cos(2 * np.pi * px / N) * np.sin(2 * np.pi * 2.0 * py / N)
+    qx = np.clip(px + dx, 0, N - 1); qy = np.clip(py + dy, 0, N - 1)
+    x0 = np.minimum(np.floor(qx).astype(np.int64), N - 2); ax = qx - x0
+    y0 = np.minimum(np.floor(qy).astype(np.int64), N - 2); ay = qy - y0
+    xr = np.rint(qx).astype(np.int64); yr = np.rint(qy).astype(np.int64)
+    c1a, c1b = yr + x0 * N, yr + (x0 + 1) * N                  # channel 1: the two x-neighbours at the rounded row
+    c2a, c2b = y0 + xr * N, (y0 + 1) + xr * N                  # channel 2: the two y-neighbours at the rounded column
+    rows = np.concatenate([idx, idx, idx, idx])
+    cols = np.concatenate([c1a, c1b, n + c2a, n + c2b])
+    # (weights kept away from exact zeros: every row has exactly 4 stored entries)
+    vals = np.concatenate([Ix[c1a] * np.maximum(1 - ax, 1e-3), Ix[c1b] * np.maximum(ax, 1e-3), Iy[c2a] * np.maximum(1 - ay, 1e-3), Iy[c2b] * np.maximum(ay, 1e-3)])
+    vals = np.where(vals == 0, 1e-3, vals)
+    return sp.csc_matrix((vals, (rows, cols)), shape=(n, 2 * n))
+
+
+def tvl1_flow_problem(N, warp=False):
+    """BASELINE config 4: primal u in R^(2n); v = W u, g = gradient2d(N, N, 2) u; f(v) = sum_1d('abs', 1, b, 5), f(g) = sum_norm2(4, false,
+    'abs'); min_problem.  warp=False: W = [diag(Ix) diag(Iy)] (SURVEY 8d C4, 2 non-zeros per row on the pixel's own columns);
+    warp=True: the gather-type warp matrix above (4 non-zeros per row at displaced columns)"""
+    import scipy.sparse as sp
+    from . import block, function
+    from .problem import variable, min_problem
+    n = N * N
+    bvec = rof_image(N, N, 1, 3) - 0.5
+    if warp:
+        W = warp_matrix(N)
+    else:
+        W = sp.hstack([sp.diags(rof_image(N, N, 1, 1) - 0.5), sp.diags(rof_image(N, N, 1, 2) - 0.5)]).tocsc()
+    u = variable(2 * n)
+    v, g = variable(n), variable(4 * n)
+    prob = min_problem([u], [v, g])
+    prob.add_function(v, function.sum_1d("abs", 1, bvec, 5.0))
+    prob.add_function(g, function.sum_norm2(4, False, "abs"))
+    prob.add_constraint(u, v, block.sparse(W))
+    prob.add_constraint(u, g, block.gradient2d(N, N, 2))
+    return prob

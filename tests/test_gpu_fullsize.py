@@ -223,6 +223,50 @@ def test_c4_1024_admm_matches_oracle():
     assert np.isclose(st["rho"], ost["rho"], rtol=1e-6)
 
 
+def _admm_vs_oracle(prob, k, path, threads=16):
+    b = prost.backend.admm(rho0=1)
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    s = prost.Solver(prob, b, o)
+    s.iterate(k)
+    st = s.state()
+    s.destroy()
+    assert st["path"] == path, st["path"]
+    prob.finalize()
+    oracle.set_num_threads(threads)
+    os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, b, o, np.float32)
+    os_.initialize()
+    os_.iterate(k)
+    ost = os_.state()
+    ost.update(os_.scalars())
+    del os_
+    for v in "xyzw":
+        scale = max(1.0, float(np.abs(ost[v]).max()))
+        assert float(np.abs(st[v] - ost[v]).max()) <= 2e-4 * scale, (v, float(np.abs(st[v] - ost[v]).max()), scale)
+    assert st["cg_iterations"] == ost["cg_iterations"]
+    assert np.isclose(st["rho"], ost["rho"], rtol=1e-6)
+
+
+def test_c4w_1024_admm_on_a_warp_matrix_matches_oracle():
+    """BASELINE.json configs[3] as worded -- "block_sparse WARP MATRIX + gradient2d" -- at 1024^2: W gathers the two flow channels at
+    columns displaced by a smooth flow of up to 5 pixels (4 non-zeros per row, general CSR: synthetic.warp_matrix; the reference applies
+    it with cusparse csrmv, block_sparse.cu:146-211).  No pixel-diagonal structure, so the CG rounds are the four-launch ones with the
+    operator inside the stage kernels (admm:fused-op); product against oracle.Solver after 5 outer iterations at the tolerance of row
+    a5 (2e-4 of the vector's scale, equal CG iteration counts).  ADMM / CGLS parity is unpinned by the reference."""
+    W = synthetic.warp_matrix(64).tocsr()
+    assert (np.diff(W.indptr) == 4).all() and W.shape == (64 * 64, 2 * 64 * 64)
+    far = np.abs((W.indices % (64 * 64)) - np.repeat(np.arange(64 * 64), 4))
+    assert far.max() >= 4 * 64                     # entries several image columns away from the row's own pixel: a gather, not a diagonal
+    _admm_vs_oracle(synthetic.tvl1_flow_problem(1024, warp=True), 5, "admm:fused-op")
+
+
+def test_c4_2048_streams_from_hbm_and_4096_falls_back_to_the_four_launch_rounds():
+    """C4 beyond the Infinity Cache: at 2048^2 the two-launch pixel rounds (a solve's working set is 640 MB); at 4096^2 one partial per
+    pixel tile no longer fits the reduction workspace, prost_hip_pixel_op_supported answers no and the solve runs the four-launch rounds
+    (round-5 advice: the pixel path was chosen there and every solve failed)"""
+    _admm_vs_oracle(synthetic.tvl1_flow_problem(2048), 3, "admm:pixel-op")
+    _admm_vs_oracle(synthetic.tvl1_flow_problem(4096), 2, "admm:fused-op")
+
+
 def test_c2_4096_boyd_pair_and_single_launches_take_the_same_decisions():
     """residual-driven steps (boyd) at 4096^2, 30 iterations, residual_iter 5, tolerances 1e-2 (so that the rule's
     comparisons `residual < eps` flip during the run: no change at iterations 0 and 5, tau /= 1.05 from iteration 10 on, where
