@@ -25,6 +25,21 @@ def spmat_gradient2d(nx, ny, nc):
     return sp.vstack([sp.kron(sp.identity(nc), gx), sp.kron(sp.identity(nc), gy)]).tocsr()
 
 
+def describe(nx=700, ny=464, nc=3, max_iters=10000, num_cback_calls=250):
+    """the problem description, backend and options of example_rof_primaldual.m:15-46 as written, without the gap callback (which can
+    stop the run): -> (prob, backend, opts)"""
+    f = synthetic.rof_image(nx, ny, nc, seed=1).astype(np.float64)
+    lmb = 10
+    u = prost.variable(nx * ny * nc)
+    q = prost.variable(2 * nx * ny * nc)
+    prob = prost.min_max_problem([u], [q])
+    prob.add_function(u, prost.function.sum_1d("square", 1, f, lmb))
+    prob.add_function(q, prost.function.sum_norm2(2 * nc, False, "ind_leq0", 1, 1, 1))
+    prob.add_dual_pair(u, q, prost.block.gradient2d(nx, ny, nc))
+    backend = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.05 * lmb)
+    return prob, backend, prost.options(max_iters=max_iters, num_cback_calls=num_cback_calls, verbose=False)
+
+
 def main(nx=700, ny=464, nc=3, max_iters=10000, verbose=True):
     f = synthetic.rof_image(nx, ny, nc, seed=1).astype(np.float64)           # :3-6  f in [0, 1], y fastest, then x, then channel
     grad = spmat_gradient2d(nx, ny, nc)                                       # :10

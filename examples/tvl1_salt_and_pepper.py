@@ -12,7 +12,8 @@ import prost_amd as prost
 from prost_amd import synthetic
 
 
-def main(nx=512, ny=384, nc=1, max_iters=50000, verbose=True):
+def describe(nx=512, ny=384, nc=1, max_iters=50000):
+    """the problem description, backend and options of example_tvl1.m:21-53 as written -> (prob, backend, opts, u, f, clean)"""
     rng = np.random.default_rng(42)                                           # :1
     clean = synthetic.rof_image(nx, ny, nc, seed=2).astype(np.float64)        # :5-8
     f = clean.copy()
@@ -32,6 +33,11 @@ def main(nx=512, ny=384, nc=1, max_iters=50000, verbose=True):
     backend = prost.backend.pdhg(stepsize="boyd", residual_iter=10)           # :42-43
     opts = prost.options(max_iters=max_iters, num_cback_calls=250, verbose=False, tol_rel_primal=1e-7, tol_rel_dual=1e-7,
                          tol_abs_dual=1e-7, tol_abs_primal=1e-7)             # :47-53
+    return prob, backend, opts, u, f, clean
+
+
+def main(nx=512, ny=384, nc=1, max_iters=50000, verbose=True):
+    prob, backend, opts, u, f, clean = describe(nx, ny, nc, max_iters)
     t0 = time.perf_counter()
     result = prost.solve(prob, backend, opts)                                 # :56
     elapsed = time.perf_counter() - t0

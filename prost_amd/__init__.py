@@ -7,11 +7,11 @@ the HIP kernel C ABI libprost_hip.so) through the command table of include/prost
 (`solve_problem`, `eval_linop`, `eval_prox`, ... -- matlab/+prost/private/prost.cpp:305-313).
 """
 from . import backend, block, function  # noqa: F401
-from .problem import (min_max_problem, min_problem, options, problem, sub_variable,  # noqa: F401
-                      variable)
+from .problem import (get_all_variables, min_max_problem, min_problem, options, problem,  # noqa: F401
+                      sub_variable, variable)
 
 __all__ = ["backend", "block", "function", "variable", "sub_variable", "problem", "min_max_problem",
-           "min_problem", "options", "solve", "eval_linop", "eval_prox", "init", "release", "set_gpu",
+           "min_problem", "options", "get_all_variables", "solve", "eval_linop", "eval_prox", "init", "release", "set_gpu",
            "list_gpus", "set_precision", "get_precision"]
 
 

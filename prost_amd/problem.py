@@ -206,6 +206,17 @@ class min_problem(problem):
         return self
 
 
+def get_all_variables(result, p_vars, pc_vars, d_vars, dc_vars):
+    """matlab/+prost/get_all_variables.m:19-49: slices result x / z / y / w into the given primal, constrained-primal, dual and
+    constrained-dual variables, in order (sub-variables are not set, as in the reference)"""
+    import numpy as np
+    for key, vs in (("x", p_vars), ("z", pc_vars), ("y", d_vars), ("w", dc_vars)):
+        idx = 0
+        for v in vs:
+            v.val = np.asarray(result[key]).reshape(-1)[idx:idx + v.dim]
+            idx += v.dim
+
+
 def options(**kw):
     """options.m:4-14"""
     p = dict(tol_rel_primal=1e-4, tol_rel_dual=1e-4, tol_abs_primal=1e-4, tol_abs_dual=1e-4,

@@ -141,3 +141,61 @@ def test_example_deblurring_as_written_matches_the_oracle(prec, dtype):
     # order -- the oracle's -- and the example is bit for bit like the other two.)
     paths, res = _compare_with_oracle(lambda nx, ny, nc: ex.describe(nx, ny, nc, klen=5), (24, 16, 2), prec, dtype, (1, 2, 31), 300, tol=0.0)
     assert paths == {"pdhg:generic"}
+
+
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_example_tvl1_as_written_matches_the_oracle(prec, dtype):
+    """example_tvl1.m:21-53 as written (abs data term, vectorial TV through block.gradient2d, boyd / residual_iter 10, tolerances 1e-7): iterates
+    after 1, 2 and 25 iterations and the complete solve -- callback schedule, stopping iteration, x, y, z, w -- bit for bit with the oracle
+    (round 5 checked only that the noise goes down)"""
+    import tvl1_salt_and_pepper as ex
+    paths, res = _compare_with_oracle(lambda nx, ny, nc: ex.describe(nx, ny, nc)[:3], (48, 32, 1), prec, dtype, (1, 2, 25), 600)
+    assert paths == {"pdhg:fused-grad2d"}
+    paths, res = _compare_with_oracle(lambda nx, ny, nc: ex.describe(nx, ny, nc)[:3], (36, 28, 3), prec, dtype, (1, 25), 300)
+    assert paths == {"pdhg:fused-grad2d"}
+
+
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_example_rof_primaldual_as_written_matches_the_oracle(prec, dtype):
+    """example_rof_primaldual.m:15-46 as written (RGB: sum_norm2(6, ...), alg2 with gamma = 0.05 lmb, residual_iter 10, 250 callback
+    calls) without the gap callback that may end the run early: bit for bit with the oracle"""
+    import rof_rgb_gap_callback as ex
+    paths, res = _compare_with_oracle(ex.describe, (40, 28, 3), prec, dtype, (1, 2, 25), 500)
+    assert paths == {"pdhg:fused-grad2d"}
+
+
+@pytest.mark.parametrize("prec,dtype", [("single", np.float32), ("double", np.float64)])
+def test_example_rof_dual_as_written_matches_the_oracle(prec, dtype):
+    """example_rof_dual.m:10-41 as written: the DUAL problem as a prost.min_problem over q with the constraint w = -grad' q handed over as
+    a sparse block, goldstein / residual_iter 100; the image is the dual variable of that problem"""
+    import rof_dual as ex
+    paths, res = _compare_with_oracle(lambda nx, ny, nc: ex.describe(nx, ny, nc)[:3], (28, 20, 2), prec, dtype, (1, 2, 25), 450)
+    assert paths == {"pdhg:generic"}
+
+
+def test_example_rof_dual_runs_with_its_gap_callback_and_reads_the_image_from_the_dual_variables():
+    import rof_dual as ex
+    prost.set_gpu(0)
+    prost.set_precision("double")
+    result, gaps, img, f = ex.main(nx=40, ny=32, nc=2, max_iters=6000, verbose=False)
+    assert result["result"] in ("Stopped by user.", "Converged.", "Reached maximum iterations.")
+    assert gaps and abs(gaps[-1]) < abs(gaps[0])
+    assert img.shape == (2, 40, 32) and np.isfinite(img).all()
+    # the denoised image stays close to the data (lmb = 0.3 is a strong regulariser: within the data's range, smoother than it)
+    assert float(np.abs(img.reshape(-1) - f).mean()) < 0.5 and img.std() < f.std()
+
+
+def test_example_multilabel_callback_reads_the_labelling_and_never_stops_the_run():
+    """example_multilabel_callback.m as the interm_cb of example_multilabel_fast.m:60-63"""
+    import multilabel_callback as cb
+    import multilabel_fast as ex
+    prost.set_gpu(0)
+    prost.set_precision("double")
+    nx, ny, L = 24, 20, 3
+    prob, backend, opts, u, f, im = ex.describe(nx, ny, max_iters=200, num_cback_calls=4)
+    seen = []
+    opts["interm_cb"] = lambda it, x, y: cb.multilabel_callback(it, x, y, ny, nx, L, im, show=lambda it_, im_, lab: seen.append((it_, lab.copy())))
+    res = prost.solve(prob, backend, opts)
+    assert res["result"] == "Reached maximum iterations." and int(res["iters"]) == 200          # the callback returns false: never "Stopped by user."
+    assert len(seen) >= 4 and all(lab.shape == (L, nx, ny) and np.isfinite(lab).all() for _, lab in seen)
+    assert np.array_equal(seen[-1][1].reshape(-1), np.asarray(res["x"]).reshape(-1)[:nx * ny * L])
