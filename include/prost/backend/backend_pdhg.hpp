@@ -6,6 +6,8 @@
 //   generic  any blocks / proxes: the reference's sequence on the generic kernels
 #ifndef PROST_BACKEND_PDHG_HPP_
 #define PROST_BACKEND_PDHG_HPP_
+#include <functional>
+
 #include "prost/backend/backend.hpp"
 #include "prost_hip.h"
 
@@ -75,6 +77,16 @@ class BackendPDHG : public Backend<T> {
   /// [x0, x1) of this backend's problem count in the residual sums (x1 == 0: all).  Call before
   /// Initialize(); needs the single-kernel path (gradient2d, L <= 2).
   void SetOwnedColumns(size_t x0, size_t x1) { owned_x0_ = x0; owned_x1_ = x1; }
+  /// Column-sharded slabs with the residual-driven rules on the device (round 6): `hook` ENQUEUES the halo exchange on the solver's stream
+  /// (RCCL send / recv: device-side, no host wait) and is called inside a device-resident batch whenever `period` iterations have run
+  /// since the last exchange; no launch of a batch spans an exchange.  Order of what a batch enqueues per residual iteration:
+  /// iteration kernel (+ partial sums) -> fold -> all-reduce of the four sums -> rule kernel -> [exchange when due] -> next iteration kernel.
+  /// Without a hook the caller exchanges between its PerformIterations calls (solver_iterate_sharded's host loop).
+  void SetExchangeHook(std::function<void()> hook, size_t period, size_t since) { exchange_hook_ = std::move(hook); exchange_period_ = period; since_exchange_ = since; }
+  void ClearExchangeHook() { exchange_hook_ = nullptr; }
+  size_t since_exchange() const { return since_exchange_; }
+  /// the residual-driven rule runs on the device for this problem / option set (batches of iterations, one host wait each)
+  bool device_rules() const { return dev_rules_ || dev_rules_generic_; }
   /// device pointers of the current iterate, for halo exchange between slabs: x (n), y (m)
   T* x_data() { spec_valid_ = false; return x_.data(); }      // (the caller may write the iterate: a speculative launch from the old one is forgotten)
   T* y_data() { spec_valid_ = false; return y_.data(); }
@@ -171,6 +183,9 @@ class BackendPDHG : public Backend<T> {
                      int stale_count = 2; bool stale_group = false; };
   std::vector<BatchMark> batch_marks_;     // one per residual iteration of the running batch: the state to return to if it stopped there
   int PerformIterationsDevice(int budget);
+  int PerformIterationsInner(int budget);
+  std::function<void()> exchange_hook_;   // slabs: enqueues the halo exchange (SetExchangeHook)
+  size_t exchange_period_ = 0, since_exchange_ = 0;
   bool failed_ = false;                    // a device-resident batch threw half-way: the iterate on the device is undefined from then on
   void RestoreRoles(const BatchMark& m);
 

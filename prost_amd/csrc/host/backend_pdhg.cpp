@@ -304,7 +304,10 @@ void BackendPDHG<T>::Initialize() {
   // (round 5: gradient3d as well -- prost_hip_fused_iteration3d_rec, _3d_pw_rec, _3d_x2_rec: the reference's default options on a
   // volume cost a host round trip per iteration before)
   const bool rec_kernels = single_kernel_ || single_mc_ || single3d_;
-  dev_rules_ = rec_kernels && opts_.allow_device_rules && owned_x1_ == 0 && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
+  // (column-sharded slabs exchange halos between iterations: on the RCCL transport the exchange is device-side work on the solver's
+  // stream, enqueued by the exchange hook inside the batch; on the host-callback transport it needs the host and the host loop stays)
+  const bool slab_ok = owned_x1_ == 0 || (this->comm_ && prost_hip_comm_is_host(this->comm_) == 0);
+  dev_rules_ = rec_kernels && opts_.allow_device_rules && slab_ok && !deferred_rule && !desc_.g_coeff_ptr[0] && !desc_.g_coeff_ptr[2] &&
                !desc_.g_coeff_ptr[4] && desc_.g_coeff_val[4] == 0.0 && desc_.f_coeff_val[4] == 0.0;
   // the same on the GENERIC path (any operator): the proxes form their arguments on the fly with kernels that read tau, sigma, theta
   // from the record (elem operations of any function and coefficients, their Moreau wraps, the identity), the residual reductions
@@ -385,6 +388,22 @@ void BackendPDHG<T>::PerformIteration() {
 /// store the intermediate iterate itself.
 template <typename T>
 int BackendPDHG<T>::PerformIterations(int budget) {
+  // slabs with an exchange hook: a device-resident batch calls the hook itself (PerformIterationsDevice); every other path exchanges here
+  // when it is due and never runs across the next exchange
+  const bool hooked = exchange_hook_ && exchange_period_ > 0;
+  const bool batch = (dev_rules_ || dev_rules_generic_) && budget >= 3 && iteration_ >= 2 &&
+                     !(stop_on_convergence_ && this->primal_residual_ < this->eps_primal() && this->dual_residual_ < this->eps_dual());
+  if (hooked && !batch) {
+    if (since_exchange_ >= exchange_period_) { exchange_hook_(); since_exchange_ = 0; }
+    budget = (int)std::min<size_t>((size_t)budget, exchange_period_ - since_exchange_);
+  }
+  const int ran = PerformIterationsInner(budget);
+  if (hooked && !batch) since_exchange_ += (size_t)ran;
+  return ran;
+}
+
+template <typename T>
+int BackendPDHG<T>::PerformIterationsInner(int budget) {
   if (failed_) throw Exception("BackendPDHG: an earlier batch of device-resident iterations failed half-way; the state on the device is undefined. Create a new solver.");
   const size_t k = iteration_;
   // z, w of the last read-out (n + m values; the reference keeps no such copies): large ones are released when the iteration
@@ -500,29 +519,33 @@ int BackendPDHG<T>::PerformIterationsDevice(int budget) {
     for (int done = 0; done < n;) {
       const size_t k = iteration_;
       batch_last_launch_evaluated_ = false;
+      // slabs: the halo exchange when it is due (device-side, on this stream), and no launch across the next one
+      if (exchange_hook_ && exchange_period_ > 0 && since_exchange_ >= exchange_period_) { exchange_hook_(); since_exchange_ = 0; }
+      const int room = exchange_hook_ && exchange_period_ > 0 ? (int)std::min<size_t>((size_t)(n - done), exchange_period_ - since_exchange_) : n - done;
+      int ran = 1;
       if (!fused_) {
         IterationGeneric(is_residual_iteration(k));
-        done += 1;
-      } else if (bool gres = false; int g = GroupSize(k, n - done, gres)) {
+      } else if (bool gres = false; int g = GroupSize(k, room, gres)) {
         pair_launches_++;            // (counted first: the mark a residual launch leaves holds the count INCLUDING itself)
         IterationGroup(g, gres);
-        done += g;
-      } else if (pair_kernel_ && n - done >= 2 && !is_residual_iteration(k)) {
+        ran = g;
+      } else if (pair_kernel_ && room >= 2 && !is_residual_iteration(k)) {
         pair_launches_++;            // (counted first: the mark a residual launch leaves holds the count INCLUDING itself)
         IterationPair(is_residual_iteration(k + 2), is_residual_iteration(k + 1));
-        done += 2;
-      } else if (pair_mc_ && n - done >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {     // (no stored intermediate iterate)
+        ran = 2;
+      } else if (pair_mc_ && room >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {     // (no stored intermediate iterate)
         pair_launches_++;
         IterationPairMc(is_residual_iteration(k + 1));
-        done += 2;
-      } else if (pair3d_ && n - done >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {
+        ran = 2;
+      } else if (pair3d_ && room >= 2 && k >= 2 && !is_residual_iteration(k) && !is_residual_iteration(k + 2)) {
         pair_launches_++;
         IterationPair3D(is_residual_iteration(k + 1));
-        done += 2;
+        ran = 2;
       } else {
         IterationFused(is_residual_iteration(k));
-        done += 1;
       }
+      done += ran;
+      since_exchange_ += (size_t)ran;
     }
   } catch (...) {
     // Launches of this batch are already enqueued: iteration_, the buffer roles and pair_launches_ have advanced with them while tau_ /

@@ -916,6 +916,19 @@ static size_t iterate_sharded_t(AnyHandle& a, int iters, size_t ny, size_t H, si
   auto h = std::static_pointer_cast<SolverHandle<T>>(a.h);
   if (H < 3) throw Exception("solver_iterate_sharded: the halo must be at least 3 columns.");
   const size_t period = H - 2;
+  // residual-driven rule on the device and a device-side transport (RCCL): the whole call is ONE sequence of enqueues -- the backend
+  // calls the exchange from inside its batches (BackendPDHG::SetExchangeHook), the host waits once per batch of up to 240 iterations
+  if (g_comm && !prost_hip_comm_is_host(g_comm) && (left >= 0 || right >= 0)) {
+    if (auto* pd = dynamic_cast<BackendPDHG<T>*>(h->backend.get())) {
+      if (pd->device_rules()) {
+        pd->SetExchangeHook([&a, ny, H, HL, HR, left, right]() { halo_exchange_t<T>(a, ny, H, HL, HR, left, right); }, period, since);
+        try { h->solver->Iterate(iters); } catch (...) { pd->ClearExchangeHook(); throw; }
+        since = pd->since_exchange();
+        pd->ClearExchangeHook();
+        return since;
+      }
+    }
+  }
   for (int done = 0; done < iters;) {
     if (since >= period) { halo_exchange_t<T>(a, ny, H, HL, HR, left, right); since = 0; }
     const int k = (int)std::min<size_t>((size_t)(iters - done), period - since);
