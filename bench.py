@@ -282,7 +282,8 @@ def cpu_baseline_c3(volume, max_threads, np_dtype=None):
     return {"value": rate * cx * cy * L / (nx * ny * L), "unit": "it/s", "cores": threads, "kind": "port",
             "voxel_iterations_per_s": rate * cx * cy * L, "crop_it_per_s": rate, "threads_probed": {str(k): v for k, v in sorted(rates.items())},
             "sample": "%d PDHG iterations of a %dx%dx%d crop of the volume (same generator, same options), oracle/prost_oracle.cpp with %d pinned OpenMP "
-                      "threads (best of a probe up to all logical CPUs, vectors first-touched per thread); value = the crop's voxel-iteration rate divided by the %dx%dx%d voxels of the full volume" % (iters, cx, cy, L, threads, nx, ny, L)}
+                      "threads (best of a probe up to all logical CPUs, vectors first-touched per thread); value = the crop's voxel-iteration rate divided by "
+                      "the %dx%dx%d voxels of the full volume" % (iters, cx, cy, L, threads, nx, ny, L)}
 
 
 def cpu_baseline_c4(size, backend, max_threads, np_dtype=None, warp=False):
@@ -725,7 +726,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "path": path, "problems": world, "rccl_nranks": int(comm_info["nranks"]) if comm_info["transport"] == "rccl" else None,
-                       "comm_nranks": int(comm_info["nranks"]), "residual_allreduce": "host-callback (gloo)" if host_transport else "host-callback (gloo) after the native RCCL communicator failed" if rccl_fallback else "rccl" if multi else "none",
+                       "comm_nranks": int(comm_info["nranks"]),
+                       "residual_allreduce": "host-callback (gloo)" if host_transport else "host-callback (gloo) after the native RCCL communicator failed" if rccl_fallback
+                       else "rccl" if multi else "none",
                        "rendezvous": "gloo (CPU tensors: unique id, barriers, timing reduction); the solver's communicator is the only RCCL communicator of a rank" if multi else "none",
                        "stepsize": backend[1].get("stepsize"), "residual_iter": backend[1].get("residual_iter"),
                        "timed_loop": "Solver::IterateChecked = the loop of prost.solve (stopping test after every observable iteration; "

@@ -141,8 +141,10 @@ int prost_hip_pattern_spmv_f64(double* res, const double* rhs, size_t nrows, con
 /* (ABI 6) the same with the table's sizes (npatterns + 1 offsets in pptr, nentries entries): a table of <= 256 patterns and <= 1024
  * entries is staged in LDS by every workgroup -- two dependent memory round trips less per wavefront, which is what small products
  * (<= 2^22 rows) consist of; same arithmetic, same bits */
-int prost_hip_pattern_spmv_tab_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const float* pval, int npatterns, int nentries, int acc, void* stream);
-int prost_hip_pattern_spmv_tab_f64(double* res, const double* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel, const double* pval, int npatterns, int nentries, int acc, void* stream);
+int prost_hip_pattern_spmv_tab_f32(float* res, const float* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel,
+    const float* pval, int npatterns, int nentries, int acc, void* stream);
+int prost_hip_pattern_spmv_tab_f64(double* res, const double* rhs, size_t nrows, const uint16_t* ids, const int32_t* pptr, const int32_t* rel,
+    const double* pval, int npatterns, int nentries, int acc, void* stream);
 /* (ABI 8) ANCHORED row patterns: the table's offsets count from anchor[row] (int32, padded like ids to a multiple of 4 rows, 16-byte aligned) instead
  * of from the row number: rows of equal SHAPE share a pattern also where the matrix maps between different geometries -- convmtx2's FULL
  * convolution in example_deblurring.m:15-16 (the blurred image is larger than the sharp one: column - row drifts by ky - 1 per image
@@ -299,10 +301,13 @@ int prost_hip_pdhg_dual_arg_f64(double* temp, const double* y, const double* S, 
  * out2[0] = sum diff^2, out2[1] = sum var^2 (DEVICE doubles).  Terms are evaluated in T as the
  * reference does; the accumulation is in double (the reference's order is unspecified). */
 size_t prost_hip_reduce_workspace_bytes(void);
-int prost_hip_pdhg_residual_primal_f32(double* out2, const float* y_prev, const float* y, const float* S, const float* kx_prev, const float* kx, double sigma, double theta, size_t m, void* workspace, void* stream);
-int prost_hip_pdhg_residual_primal_f64(double* out2, const double* y_prev, const double* y, const double* S, const double* kx_prev, const double* kx, double sigma, double theta, size_t m, void* workspace, void* stream);
+int prost_hip_pdhg_residual_primal_f32(double* out2, const float* y_prev, const float* y, const float* S, const float* kx_prev, const float* kx,
+    double sigma, double theta, size_t m, void* workspace, void* stream);
+int prost_hip_pdhg_residual_primal_f64(double* out2, const double* y_prev, const double* y, const double* S, const double* kx_prev, const double* kx,
+    double sigma, double theta, size_t m, void* workspace, void* stream);
 int prost_hip_pdhg_residual_dual_f32(double* out2, const float* x_prev, const float* x, const float* T, const float* kty_prev, const float* kty, double tau, size_t n, void* workspace, void* stream);
-int prost_hip_pdhg_residual_dual_f64(double* out2, const double* x_prev, const double* x, const double* T, const double* kty_prev, const double* kty, double tau, size_t n, void* workspace, void* stream);
+int prost_hip_pdhg_residual_dual_f64(double* out2, const double* x_prev, const double* x, const double* T, const double* kty_prev, const double* kty,
+    double tau, size_t n, void* workspace, void* stream);
 /* compute_w_variable_functor / compute_z_variable_functor (:147-186, used :524-560) */
 int prost_hip_pdhg_w_variable_f32(float* w, const float* x_prev, const float* x, const float* T, const float* kty_prev, double tau, size_t n, void* stream);
 int prost_hip_pdhg_w_variable_f64(double* w, const double* x_prev, const double* x, const double* T, const double* kty_prev, double tau, size_t n, void* stream);

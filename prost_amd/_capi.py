@@ -267,7 +267,8 @@ def command(cmd, args=(), nlhs=0, struct_fields=None):
 _RESULT_FIELDS = ("x", "y", "z", "w", "result", "iters", "path", "pair_launches")
 _STATE_FIELDS = ("x", "y", "z", "w", "tau", "sigma", "theta", "rho", "iteration", "primal_res", "dual_res",
                  "primal_var_norm", "dual_var_norm", "eps_primal", "eps_dual", "cg_iterations", "path", "pair_launches",
-                 "speculative_launches", "speculative_adopted", "device_rule_batches", "arithmetic", "iterations_per_launch_max", "operator_in_prox_kernels", "residual_sums_in_prox_launches", "sparse_pattern_products")
+                 "speculative_launches", "speculative_adopted", "device_rule_batches", "arithmetic", "iterations_per_launch_max", "operator_in_prox_kernels",
+                 "residual_sums_in_prox_launches", "sparse_pattern_products")
 
 
 def _opts_struct(opts):

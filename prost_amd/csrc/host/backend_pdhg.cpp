@@ -927,7 +927,8 @@ bool BackendPDHG<T>::DescribeGenericOperator(bool stencils_only) {
       // iterations/s at 512 x 512 x 3 -- so such operators keep the separate products under every option)
       if (!(bd.ids && bd.ids_t) && bd.nnz > 6 * std::min(b->nrows(), b->ncols())) return false;
       o.val = bd.val; o.ptr = bd.ptr; o.ind = bd.ind; o.val_t = bd.val_t; o.ptr_t = bd.ptr_t; o.ind_t = bd.ind_t;
-      o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t; o.anchor = bd.anchor; o.anchor_t = bd.anchor_t;
+      o.ids = bd.ids; o.pptr = bd.pptr; o.rel = bd.rel; o.pval = bd.pval; o.ids_t = bd.ids_t; o.pptr_t = bd.pptr_t; o.rel_t = bd.rel_t; o.pval_t = bd.pval_t;
+      o.anchor = bd.anchor; o.anchor_t = bd.anchor_t;
     } else if ((bd.kind == BlockDesc::kGradient2D || bd.kind == BlockDesc::kGradient3D) && !bd.label_first) {
       o.kind = bd.kind == BlockDesc::kGradient2D ? PROST_OP_GRAD2D : PROST_OP_GRAD3D;
       o.nx = bd.nx; o.ny = bd.ny; o.L = bd.L;
@@ -1301,7 +1302,8 @@ template <typename T>
 size_t BackendPDHG<T>::gpu_mem_amount() const {
   const size_t m = this->problem_->nrows(), n = this->problem_->ncols();
   if (x_.size() == n && n > 0)          // after Initialize(): what the vectors really hold
-    return (x_.size() + x_prev_.size() + x_spare_.size() + y_.size() + y_prev_.size() + y_spare_.size() + b_masked_.size() + merged_g_[0].size() + merged_g_[1].size() + merged_g_[2].size() + merged_g_[3].size() + merged_g_[4].size() + merged_g_[5].size() + merged_g_[6].size() + kty_.size() + kty_prev_.size() +
+    return (x_.size() + x_prev_.size() + x_spare_.size() + y_.size() + y_prev_.size() + y_spare_.size() + b_masked_.size() + merged_g_[0].size() + merged_g_[1].size() +
+            merged_g_[2].size() + merged_g_[3].size() + merged_g_[4].size() + merged_g_[5].size() + merged_g_[6].size() + kty_.size() + kty_prev_.size() +
             kx_.size() + kx_prev_.size() + temp_.size() + sol_z_.size() + sol_w_.size()) * sizeof(T);
   if (fused_) return 2 * (n + m) * sizeof(T);
   return (4 * (n + m) + std::max(n, m)) * sizeof(T);           // backend_pdhg.cu:504-511
@@ -1322,8 +1324,11 @@ void BackendPDHG<T>::KernelTimes(std::vector<typename Backend<T>::KernelTime>& o
   }
   const bool d3 = desc_.is3d != 0;
   const char* names[kKernelKinds] = {d3 ? "fused_primal3d_kernel" : "fused_primal2d_kernel", d3 ? "fused_dual3d_kernel" : "fused_dual2d_kernel",
-                                     d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel", d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals", d3 ? "fused_iter3d_x2_kernel" : pair_mc_ ? "fused_iter2d_mc_x2_kernel" : "fused_iter2d_x2_kernel",
-                                     "fused_iter2d_x2_kernel+mid", d3 ? "fused_iter3d_x2_kernel+residuals" : pair_mc_ ? "fused_iter2d_mc_x2_kernel+residuals" : "fused_iter2d_x2_kernel+residuals", "fused_iter2d_x2_kernel+mid+residuals",
+                                     d3 ? "fused_iter3d_kernel" : single_mc_ ? "fused_iter2d_mc_kernel" : "fused_iter2d_kernel",
+                                     d3 ? "fused_iter3d_kernel+residuals" : "fused_iter2d_kernel+residuals",
+                                     d3 ? "fused_iter3d_x2_kernel" : pair_mc_ ? "fused_iter2d_mc_x2_kernel" : "fused_iter2d_x2_kernel", "fused_iter2d_x2_kernel+mid",
+                                     d3 ? "fused_iter3d_x2_kernel+residuals" : pair_mc_ ? "fused_iter2d_mc_x2_kernel+residuals" : "fused_iter2d_x2_kernel+residuals",
+                                     "fused_iter2d_x2_kernel+mid+residuals",
                                      "fused_iter2d_xk_kernel<2>", "fused_iter2d_xk_kernel<3>", "fused_iter2d_xk_kernel<4>",
                                      "fused_iter2d_xk_kernel<2>+residuals", "fused_iter2d_xk_kernel<3>+residuals", "fused_iter2d_xk_kernel<4>+residuals"};
   const int iters[kKernelKinds] = {0, 0, 1, 1, 2, 2, 2, 2, 2, 3, 4, 2, 3, 4};

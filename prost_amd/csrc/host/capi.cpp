@@ -1119,7 +1119,8 @@ void cmd_set_quirks(CMD_ARGS) {
   (void)nlhs; (void)plhs;
   if (nrhs < 1) throw Exception("set_quirks: struct required.");
   if (prost_value_field(prhs[0], "diags_adjoint_grid")) BlockDiags<double>::SetReferenceGridQuirk(GetScalarFromField(prhs[0], "diags_adjoint_grid") > 0);
-  if (prost_value_field(prhs[0], "fuse_moreau")) { const bool on = GetScalarFromField(prhs[0], "fuse_moreau") > 0; ProxMoreau<float>::SetFuseElemOperations(on); ProxMoreau<double>::SetFuseElemOperations(on); }
+  if (prost_value_field(prhs[0], "fuse_moreau")) { const bool on = GetScalarFromField(prhs[0],
+      "fuse_moreau") > 0; ProxMoreau<float>::SetFuseElemOperations(on); ProxMoreau<double>::SetFuseElemOperations(on); }
   if (prost_value_field(prhs[0], "sparse_patterns")) BlockSparse<double>::SetPatternCompression(GetScalarFromField(prhs[0], "sparse_patterns") > 0);
   if (prost_value_field(prhs[0], "sparse_stencils")) BlockSparse<double>::SetStencilRecognition(GetScalarFromField(prhs[0], "sparse_stencils") > 0);
   if (prost_value_field(prhs[0], "dual_negate_float")) DualLinearOperator<double>::SetReferenceNegateQuirk(GetScalarFromField(prhs[0], "dual_negate_float") > 0);
@@ -1151,7 +1152,8 @@ const std::map<std::string, cmd_fn>& cmd_reg() {
       {"eval_prox", cmd_eval_prox}, {"list_gpus", cmd_list_gpus}, {"set_gpu", cmd_set_gpu},
       {"set_precision", cmd_set_precision}, {"get_precision", cmd_get_precision}, {"problem_info", cmd_problem_info}, {"glibc_rand_unit", cmd_glibc_rand_unit},
       {"solver_create", cmd_solver_create}, {"solver_iterate", cmd_solver_iterate}, {"solver_kernel_times", cmd_solver_kernel_times}, {"solver_state", cmd_solver_state},
-      {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_iterate_sharded", cmd_solver_iterate_sharded}, {"solver_copy_columns", cmd_solver_copy_columns},
+      {"solver_destroy", cmd_solver_destroy}, {"solver_halo_exchange", cmd_solver_halo_exchange}, {"solver_iterate_sharded",
+          cmd_solver_iterate_sharded}, {"solver_copy_columns", cmd_solver_copy_columns},
       {"solver_compare", cmd_solver_compare}, {"solver_read", cmd_solver_read}, {"comm_unique_id", cmd_comm_unique_id}, {"comm_init", cmd_comm_init},
       {"comm_destroy", cmd_comm_destroy}, {"comm_info", cmd_comm_info}, {"set_quirks", cmd_set_quirks}, {"load_plugin", cmd_load_plugin}, {"registered", cmd_registered}};
   return reg;

@@ -1446,7 +1446,8 @@ static int cgls_pixel_round(const prost_hip_cgls_desc* d, const prost_hip_pixel_
   if (!pixel_op_ok(op, d->m, d->n, V) || !op->p_alt || !op->r_alt) { set_error("cgls_pixel_round: unsupported operator description (prost_hip_pixel_op_supported)"); return 1; }
   T* P[2] = {static_cast<T*>(d->p), static_cast<T*>(op->p_alt)};
   T* R[2] = {static_cast<T*>(d->r), static_cast<T*>(op->r_alt)};
-  for (const void* ptr : {(const void*)d->x, (const void*)d->q, (const void*)d->s, (const void*)d->sigma, (const void*)d->tau, (const void*)op->w, (const void*)P[0], (const void*)P[1], (const void*)R[0], (const void*)R[1]})
+  for (const void* ptr : {(const void*)d->x, (const void*)d->q, (const void*)d->s, (const void*)d->sigma, (const void*)d->tau, (const void*)op->w,
+      (const void*)P[0], (const void*)P[1], (const void*)R[0], (const void*)R[1]})
     if (!aligned16(ptr)) { set_error("cgls_pixel_round: operands must be 16-byte aligned"); return 1; }
   hipStream_t st = as_stream(stream);
   const size_t npx = (size_t)(op->nx * op->ny);
@@ -1524,10 +1525,14 @@ int prost_hip_admm_fused_stage_f64(int stage, const prost_hip_admm_desc* d, cons
 int prost_hip_pixel_op_supported(const prost_hip_pixel_op* op, uint64_t m, uint64_t n, int dtype) { return pixel_op_ok(op, m, n, dtype == 0 ? 4u : 2u) ? 1 : 0; }
 int prost_hip_cgls_pixel_round_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* stream) { return cgls_pixel_round<float>(d, op, round, 0, stream, nullptr); }
 int prost_hip_cgls_pixel_round_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* stream) { return cgls_pixel_round<double>(d, op, round, 0, stream, nullptr); }
-int prost_hip_cgls_pixel_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4, void* stream) { return cgls_pixel_round<float>(d, op, round, 0, stream, ev4); }
-int prost_hip_cgls_pixel_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4, void* stream) { return cgls_pixel_round<double>(d, op, round, 0, stream, ev4); }
-int prost_hip_cgls_pixel_close_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round, void* stream) { return cgls_pixel_round<float>(d, op, last_round + 1, 1, stream, nullptr); }
-int prost_hip_cgls_pixel_close_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round, void* stream) { return cgls_pixel_round<double>(d, op, last_round + 1, 1, stream, nullptr); }
+int prost_hip_cgls_pixel_round_timed_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4,
+    void* stream) { return cgls_pixel_round<float>(d, op, round, 0, stream, ev4); }
+int prost_hip_cgls_pixel_round_timed_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int round, void* const* ev4,
+    void* stream) { return cgls_pixel_round<double>(d, op, round, 0, stream, ev4); }
+int prost_hip_cgls_pixel_close_f32(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round,
+    void* stream) { return cgls_pixel_round<float>(d, op, last_round + 1, 1, stream, nullptr); }
+int prost_hip_cgls_pixel_close_f64(const prost_hip_cgls_desc* d, const prost_hip_pixel_op* op, int last_round,
+    void* stream) { return cgls_pixel_round<double>(d, op, last_round + 1, 1, stream, nullptr); }
 
 int prost_hip_cgls_result(const void* state, prost_hip_cgls_result_t* out, void* stream) { return prost_hip_cgls_result_at(state, 0, out, stream); }
 int prost_hip_cgls_result_at(const void* state, int index, prost_hip_cgls_result_t* out, void* stream) {

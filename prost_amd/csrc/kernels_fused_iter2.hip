@@ -54,7 +54,8 @@ struct Col2 {
 // pr v / ||v|| as v * min(b * rsq(||v||^2), 1) (v_rsq_f32, 1 ulp) -- no fp64 instruction, no conversion, no range guard.  Results are
 // within a stated tolerance of the exact instances (tests/test_gpu_fmad.py), not bit-identical to them.
 template <class T, int VEC, int GFN, int FFN, int GMASK, int PF, bool FAST, int MODE, bool RAG, bool VART, bool FMAD>
-__global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRingWaves) : (MODE & 2) ? 2 : (PF > 1 || MODE == 1 ? 3 : 4)) : 1) fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
+__global__ void __launch_bounds__(kWave, FAST ? (PF == 0 ? ((MODE & 2) ? 3 : kRingWaves) : (MODE & 2) ? 2 : (PF > 1 || MODE == 1 ? 3 : 4)) : 1)
+    fused_iter2d_x2_kernel(T* __restrict__ x_out, T* __restrict__ y_out,
                                                                 const T* __restrict__ x, const T* __restrict__ y,
                                                                 T* __restrict__ x_mid, T* __restrict__ y_mid,
                                                                 FusedArgs<T> a, IterParams<T> p1, IterParams<T> p2,
@@ -634,8 +635,10 @@ static int run_iter2(const prost_hip_fused_desc* d, T* x_out, T* y_out, const T*
 // heights (4-byte aligned column starts) keep the register ring
 // (PROST_ITER2_NO_RING=1 forces the register ring everywhere: A/B measurements)
   static const bool no_ring = []() { const char* e = getenv("PROST_ITER2_NO_RING"); return e && atoi(e) != 0; }();
-#define GO3(G, F, M, PFv, FASTv, MODEv) do { if (rag) GO4(G, F, M, PFv, FASTv, MODEv, true); else if (no_ring) GO4(G, F, M, PFv, FASTv, MODEv, false); else GO4(G, F, M, (FASTv ? 0 : PFv), FASTv, MODEv, false); } while (0)
-#define GO(G, F, M, PFv, FASTv) do { if (mode == 0) GO3(G, F, M, PFv, FASTv, 0); else if (mode == 1) GO3(G, F, M, PFv, FASTv, 1); else if (mode == 2) GO3(G, F, M, PFv, FASTv, 2); else GO3(G, F, M, PFv, FASTv, 3); } while (0)
+#define GO3(G, F, M, PFv, FASTv, MODEv) do { if (rag) GO4(G, F, M, PFv, FASTv, MODEv, true); else if (no_ring) GO4(G, F, M, PFv, FASTv, MODEv, false); \
+    else GO4(G, F, M, (FASTv ? 0 : PFv), FASTv, MODEv, false); } while (0)
+#define GO(G, F, M, PFv, FASTv) do { if (mode == 0) GO3(G, F, M, PFv, FASTv, 0); else if (mode == 1) GO3(G, F, M, PFv, FASTv, 1); \
+    else if (mode == 2) GO3(G, F, M, PFv, FASTv, 2); else GO3(G, F, M, PFv, FASTv, 3); } while (0)
   if (fast && d->g_fn == PROST_FN_ABS) { if (mask == 0x2) GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0x2, 3, true); else GO(PROST_FN_ABS, PROST_FN_IND_LEQ0, 0, 3, true); }
   else if (fast && mask == 0x2 && d->g_b_masked) GO(PROST_FN_SQUARE, PROST_FN_IND_LEQ0, 0x82, 3, true);      // inpainting: binary mask folded into b
   else if (fast && mask == 0x2 && a.fmor) GO(PROST_FN_SQUARE, PROST_FN_ABS, 0x2, 3, true);          // ROF in its primal form (Moreau-wrapped TV norm)

@@ -542,8 +542,10 @@ static int launch_iter3d_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, c
   double* partial = static_cast<double*>(ws);
   static const bool flags = []() { const char* e = getenv("PROST_X2_SYNC"); return !(e && atoi(e) == 0); }();      // PROST_X2_SYNC=0: the barrier per step (A/B)
   const bool fmad = iter3d_x2_fmad(d, std::is_same<T, float>::value ? 0 : 1);
-#define GO4(G, B, R, F, A) PH_LAUNCH((fused_iter3d_x2_kernel<T, V, G, B, WT, R, F, A>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, static_cast<const PdhgRecord<T>*>(record))
-#define GO3(G, B, R, F) do { bool done_ = false; if constexpr (std::is_same<T, float>::value && V == 2) { if (fmad) { GO4(G, B, R, F, true); done_ = true; } } if (!done_) GO4(G, B, R, F, false); } while (0)
+#define GO4(G, B, R, F, A) PH_LAUNCH((fused_iter3d_x2_kernel<T, V, G, B, WT, R, F, A>), dim3(grid), dim3(kWave * WT), 0, s, x_out, y_out, x, y, a, p[0], \
+    p[1], partial, static_cast<const PdhgRecord<T>*>(record))
+#define GO3(G, B, R, F) do { bool done_ = false; if constexpr (std::is_same<T, float>::value && V == 2) { if (fmad) { GO4(G, B, R, F, true); done_ = true; \
+    } } if (!done_) GO4(G, B, R, F, false); } while (0)
 #define GO2(G, B, R) do { if (flags && !R) GO3(G, B, false, true); else GO3(G, B, R, false); } while (0)
 #define GO(B, R) do { if (d->g_fn == PROST_FN_ABS) GO2(PROST_FN_ABS, B, R); else GO2(PROST_FN_SQUARE, B, R); } while (0)
   if (d->g_coeff_ptr[1]) { if (out4) GO(true, true); else GO(true, false); }

@@ -473,7 +473,8 @@ static int run_iter_mc_x2(const prost_hip_fused_desc* d, T* x_out, T* y_out, con
   const bool full = mc_x2_vec(kDtype, d->ny) > 1;
   const bool fmad = iter_mc_x2_fmad(d, kDtype);
 #define GO6(VV, G, B, LWv, R, A) PH_LAUNCH((fused_iter2d_mc_x2_kernel<T, VV, G, B, LWv, R, A>), dim3(grid), dim3(kWave * LWv), 0, s, x_out, y_out, x, y, a, p[0], p[1], partial, rec)
-#define GO5(VV, G, B, LWv, R) do { bool done_ = false; if constexpr (std::is_same<T, float>::value && VV == 4 && B != 3) { if (fmad) { GO6(VV, G, B, LWv, R, true); done_ = true; } } if (!done_) GO6(VV, G, B, LWv, R, false); } while (0)
+#define GO5(VV, G, B, LWv, R) do { bool done_ = false; if constexpr (std::is_same<T, float>::value && VV == 4 && B != 3) { if (fmad) { GO6(VV, G, B, LWv, \
+    R, true); done_ = true; } } if (!done_) GO6(VV, G, B, LWv, R, false); } while (0)
 #define GO4(G, B, LWv, R) do { if (full) GO5(VecOf<T>::N, G, B, LWv, R); else GO5(1, G, B, LWv, R); } while (0)
 #define GO3(G, B, LWv) do { if (out4) GO4(G, B, LWv, true); else GO4(G, B, LWv, false); } while (0)
 #define GO2(G, B) do { if (d->L == 2) GO3(G, B, 2); else if (d->L == 3) GO3(G, B, 3); else GO3(G, B, 4); } while (0)

@@ -103,9 +103,11 @@ def _compare_with_oracle(describe, args, prec, dtype, iters, solve_iters, tol=0.
         res = prost.solve(prob, backend, opts)
         d2 = describe(*args)
         ro = oracle.solve(d2[0], d2[1], opts, dtype)
-        assert res["result"] == ro["result"] and (int(res["iters"]) == int(ro["iters"]) if tol == 0 else abs(int(res["iters"]) - int(ro["iters"])) <= 3), (res["result"], res["iters"], ro["result"], ro["iters"])
+        assert res["result"] == ro["result"] and (int(res["iters"]) == int(ro["iters"]) if tol == 0 else abs(int(res["iters"]) - int(ro["iters"])) <= 3), \
+            (res["result"], res["iters"], ro["result"], ro["iters"])
         for v in "xyzw":
-            assert same(res[v], ro[v]) if tol == 0 else float(np.abs(np.asarray(res[v]).reshape(-1) - np.asarray(ro[v]).reshape(-1)).max()) <= 50 * tol * max(1.0, float(np.abs(np.asarray(ro[v])).max())), v
+            got, exp = np.asarray(res[v]).reshape(-1), np.asarray(ro[v]).reshape(-1)
+            assert same(got, exp) if tol == 0 else float(np.abs(got - exp).max()) <= 50 * tol * max(1.0, float(np.abs(exp).max())), v
         return paths, res
     finally:
         prost.set_precision("double")

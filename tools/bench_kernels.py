@@ -93,17 +93,24 @@ def main():
     cnt = n // 3
     report("prox_epi_quad dim 3", timeit(lambda: hip.check(f("prox_epi_quad")(A[1].ptr, A[0].ptr, sz(cnt), sz(3), None, dbl(1.0), A[2].ptr, None, dbl(0.5), None))), (3 + 3 + 2) * cnt * 4)
     ptrs = (C.c_void_p * 7)(); vals = (C.c_double * 7)(1, 0, 10, 0, 0, 0, 0); ptrs[1] = A[3].ptr.value
-    report("prox_elem 1d:square, b per element", timeit(lambda: hip.check(f("prox_elem")(0, hip.FN_ID["square"], A[1].ptr, A[0].ptr, A[2].ptr, dbl(0.3), 0, sz(n), sz(1), 0, ptrs, vals, None))), 4 * n * 4)
+    report("prox_elem 1d:square, b per element",
+           timeit(lambda: hip.check(f("prox_elem")(0, hip.FN_ID["square"], A[1].ptr, A[0].ptr, A[2].ptr, dbl(0.3), 0, sz(n), sz(1), 0, ptrs, vals, None))), 4 * n * 4)
     p0 = (C.c_void_p * 7)(); v1 = (C.c_double * 7)(1, 0.1, 1, 0, 0, 0, 0)
-    report("prox_elem 1d:abs, scalar coefficients", timeit(lambda: hip.check(f("prox_elem")(0, hip.FN_ID["abs"], A[1].ptr, A[0].ptr, A[2].ptr, dbl(0.3), 0, sz(n), sz(1), 0, p0, v1, None))), 3 * n * 4)
+    report("prox_elem 1d:abs, scalar coefficients",
+           timeit(lambda: hip.check(f("prox_elem")(0, hip.FN_ID["abs"], A[1].ptr, A[0].ptr, A[2].ptr, dbl(0.3), 0, sz(n), sz(1), 0, p0, v1, None))), 3 * n * 4)
     v2 = (C.c_double * 7)(1, 1, 1, 0, 0, 0, 0)
-    report("prox_elem norm2:ind_leq0 dim 2 planar", timeit(lambda: hip.check(f("prox_elem")(1, hip.FN_ID["ind_leq0"], B[1].ptr, B[0].ptr, B[2].ptr, dbl(0.3), 0, sz(n), sz(2), 0, p0, v2, None))), (4 * n + n) * 4)
+    report("prox_elem norm2:ind_leq0 dim 2 planar",
+           timeit(lambda: hip.check(f("prox_elem")(1, hip.FN_ID["ind_leq0"], B[1].ptr, B[0].ptr, B[2].ptr, dbl(0.3), 0, sz(n), sz(2), 0, p0, v2, None))), (4 * n + n) * 4)
     report("moreau_prescale", timeit(lambda: hip.check(f("moreau_prescale")(A[1].ptr, A[0].ptr, A[2].ptr, dbl(0.3), 0, sz(n), None))), 3 * n * 4)
     report("moreau_postscale", timeit(lambda: hip.check(f("moreau_postscale")(A[1].ptr, A[0].ptr, A[2].ptr, dbl(0.3), 0, sz(n), None))), 4 * n * 4)
     report("pdhg_primal_arg", timeit(lambda: hip.check(f("pdhg_primal_arg")(A[1].ptr, A[0].ptr, A[2].ptr, A[3].ptr, dbl(0.3), sz(n), None))), 4 * n * 4)
-    report("pdhg_dual_arg (m = 2n)", timeit(lambda: hip.check(f("pdhg_dual_arg")(B[3].ptr, B[0].ptr, B[1].ptr, B[2].ptr, B[4].ptr, dbl(0.3), dbl(0.9), sz(2 * n), None))), 5 * 2 * n * 4)
-    report("pdhg_residual_primal (m = 2n)", timeit(lambda: hip.check(f("pdhg_residual_primal")(out2.ptr, B[0].ptr, B[1].ptr, B[2].ptr, B[3].ptr, B[4].ptr, dbl(0.3), dbl(0.9), sz(2 * n), ws.ptr, None))), 5 * 2 * n * 4)
-    report("pdhg_residual_dual (n)", timeit(lambda: hip.check(f("pdhg_residual_dual")(out2.ptr, A[0].ptr, A[1].ptr, A[2].ptr, A[3].ptr, A[4].ptr, dbl(0.3), sz(n), ws.ptr, None))), 5 * n * 4)
+    report("pdhg_dual_arg (m = 2n)",
+           timeit(lambda: hip.check(f("pdhg_dual_arg")(B[3].ptr, B[0].ptr, B[1].ptr, B[2].ptr, B[4].ptr, dbl(0.3), dbl(0.9), sz(2 * n), None))), 5 * 2 * n * 4)
+    report("pdhg_residual_primal (m = 2n)",
+           timeit(lambda: hip.check(f("pdhg_residual_primal")(out2.ptr, B[0].ptr, B[1].ptr, B[2].ptr, B[3].ptr, B[4].ptr, dbl(0.3), dbl(0.9), sz(2 * n), ws.ptr, None))),
+           5 * 2 * n * 4)
+    report("pdhg_residual_dual (n)",
+           timeit(lambda: hip.check(f("pdhg_residual_dual")(out2.ptr, A[0].ptr, A[1].ptr, A[2].ptr, A[3].ptr, A[4].ptr, dbl(0.3), sz(n), ws.ptr, None))), 5 * n * 4)
     report("nrm2 (m = 2n)", timeit(lambda: hip.check(f("nrm2")(out2.ptr, B[0].ptr, sz(2 * n), ws.ptr, None))), 2 * n * 4)
     report("axpy (m = 2n)", timeit(lambda: hip.check(f("axpy")(B[1].ptr, B[0].ptr, dbl(0.5), sz(2 * n), None))), 3 * 2 * n * 4)
     report("admm_elem TEMP1 (n)", timeit(lambda: hip.check(f("admm_elem")(0, A[1].ptr, A[0].ptr, A[2].ptr, A[3].ptr, A[4].ptr, dbl(1.7), dbl(0), sz(n), None))), 5 * n * 4)

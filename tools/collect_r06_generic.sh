@@ -36,10 +36,12 @@ for k, (calls, us, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
         fe = d["FETCH_SIZE"] / len(disp[k]["FETCH_SIZE"]); wr = d["WRITE_SIZE"] / len(disp[k]["WRITE_SIZE"])
         mb = (2 * fe + wr) * 1024 / 1e6
         print("   traffic: FETCH_SIZE %.0f KiB (x2) + WRITE_SIZE %.0f KiB = %.1f MB per launch -> %.0f GB/s = %.3f of 8 TB/s" % (fe, wr, mb, mb / 1e3 / (us * 1e-6), mb / 1e3 / (us * 1e-6) / 8000))
-    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"):
+    for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
+              "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"):
         if c in d:
             v = d[c] / len(disp[k][c])
-            extra = "  (%.0f %% of the wave cycles)" % (100 * v / (d["SQ_WAVE_CYCLES"] / len(disp[k]["SQ_WAVE_CYCLES"]))) if c in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") and d.get("SQ_WAVE_CYCLES") else ""
+            share = c in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") and d.get("SQ_WAVE_CYCLES")
+            extra = "  (%.0f %% of the wave cycles)" % (100 * v / (d["SQ_WAVE_CYCLES"] / len(disp[k]["SQ_WAVE_CYCLES"]))) if share else ""
             print("   %-22s %12.6g%s" % (c, v, extra))
 PY
 cat $O/generic_rate_under_rocprof.txt | tail -2

@@ -155,7 +155,9 @@ def main_k(N=4096, iters=200):
         e = len(ks) % 2
         return x[e].to_host().copy(), y[e].to_host().copy(), r4.to_host().copy()
     ref12 = run_seq([-2] * 6, True)
-    for name, ks in (("6 x K=2", [2] * 6), ("4 x K=3", [3] * 4), ("3 x K=4", [4] * 3), ("K=4,3,3,2", [4, 3, 3, 2]), ("K=5,5,2", [5, 5, 2]), ("2 x K=6", [6, 6]), ("K=6 cols 5", None), ("K=5 cols 100", None), ("K=2 cols 7", None), ("K=4 cols 5", None), ("K=3 cols 1000", None)):
+    cases = (("6 x K=2", [2] * 6), ("4 x K=3", [3] * 4), ("3 x K=4", [4] * 3), ("K=4,3,3,2", [4, 3, 3, 2]), ("K=5,5,2", [5, 5, 2]), ("2 x K=6", [6, 6]),
+             ("K=6 cols 5", None), ("K=5 cols 100", None), ("K=2 cols 7", None), ("K=4 cols 5", None), ("K=3 cols 1000", None))
+    for name, ks in cases:
         if ks is None:
             k = int(name[2]); got = run_seq([k] * (12 // k) + ([12 % k] if 12 % k else []), True, cols=int(name.split()[-1]))
         else:
