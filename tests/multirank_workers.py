@@ -139,4 +139,4 @@ def run_command(cmd, env, cwd, out):
     e = dict(os.environ)
     e.update(env)
     p = subprocess.run(cmd, env=e, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    out.put((p.returncode, p.stdout[-6000:], p.stderr[-3000:]))
+    out.put((p.returncode, p.stdout[-60000:], p.stderr[-3000:]))      # (the bench line alone is ~10 000 characters)

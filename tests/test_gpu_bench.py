@@ -58,6 +58,11 @@ def test_bench_c2_reduced():
     assert d["roofline"]["kernel"].startswith("fused_iter2d") and d["roofline"]["algorithmic_bytes_per_launch"] in (11 * 4 * 512 * 512, 22 * 4 * 512 * 512)
     assert d["roofline"]["compulsory_bytes_per_launch"] == 7 * 4 * 512 * 512 and d["roofline"]["iterations_per_launch"] == 2
     assert d["config"]["stepsize"] == "alg2" and d["config"]["residual_iter"] == 10
+    # the tolerance-class leg beside the exact one (round 6): same problem, same loop, K iterations per launch
+    assert d["value_fmad"] > 0 and d["fmad"]["arithmetic"] == "fmad" and d["fmad"]["path"] == "pdhg:fused-grad2d+fmad" and d["fmad"]["iterates_finite"]
+    rf = d["roofline_fmad"]
+    assert rf["kernel"].startswith("fused_iter2d_xk_kernel<") and rf["compulsory_bytes_per_launch"] == 7 * 4 * 512 * 512 and 0 < rf["frac"] <= 1
+    assert any(k.endswith("+residuals") for k in rf["all_kernels"]) and "two_pass_equiv_GBps" in d and "achieved_hbm_GBps" not in d
 
 
 def test_bench_c2_reduced_fp64_and_the_reference_default_options():
@@ -78,7 +83,7 @@ def test_bench_c3_reduced():
     vox = 96 * 64 * 8
     assert d["roofline"]["kernel"].startswith("fused_iter3d") and d["roofline"]["algorithmic_bytes_per_launch"] in (14 * 4 * vox, 28 * 4 * vox)
     assert d["roofline"]["compulsory_bytes_per_launch"] in (9 * 4 * vox, 13 * 4 * vox)
-    assert abs(d["achieved_hbm_GBps"] - d["value"] * 14 * 4 * vox / 1e9) <= 1e-9 * d["achieved_hbm_GBps"]
+    assert abs(d["two_pass_equiv_GBps"] - d["value"] * 14 * 4 * vox / 1e9) <= 1e-9 * d["two_pass_equiv_GBps"]
     assert d["cpu_baseline"]["voxel_iterations_per_s"] > 0
 
 
@@ -97,4 +102,20 @@ def test_bench_c4_reduced():
     px = 128 * 128
     assert r["compulsory_bytes_per_iteration"] == bench_module().c4_iteration_bytes("admm:pixel-op", d["cg_iterations_last_solve"], px) and 0 < r["frac_iteration"] <= 1
     assert r["kernel"] in r["all_kernels"] and r["compulsory_bytes_per_launch"] == r["all_kernels"][r["kernel"]]["compulsory_bytes"]
-    assert d["achieved_hbm_GBps"] is None and d["cg_iterations_last_solve"] >= 1
+    assert d["two_pass_equiv_GBps"] is None and d["cg_iterations_last_solve"] >= 1
+    assert d["oracle_pin"].startswith("unpinned")
+
+
+def test_bench_c4w_reduced():
+    """BASELINE.json configs[3] as worded (warp matrix): the four-launch CG rounds with the operator inside the stage kernels"""
+    d = _bench("--config", "c4w", "--steps", "20", "--warmup", "5", "--size", "128", "--prelude-iters", "10")
+    _check_contract(d, 20, 5)
+    assert d["config"]["name"] == "c4w" and d["config"]["path"] == "admm:fused-op" and "warp matrix" in d["config"]["workload"]
+    r = d["roofline"]
+    assert set(r["all_kernels"]) == {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"}
+    px = 128 * 128
+    bm = bench_module()
+    assert r["compulsory_bytes_per_iteration"] == bm.c4_iteration_bytes("admm:fused-op", d["cg_iterations_last_solve"], px, 4, 4) and 0 < r["frac_iteration"] <= 1
+    # 4 non-zeros per row: two more values and two more column indices per pixel than C4's W in every stage that applies it
+    assert bm.c4_kernel_bytes("op_stage_kernel<EpiFwdQ>", px, 4, 4) == bm.c4_kernel_bytes("op_stage_kernel<EpiFwdQ>", px, 4, 2) + 16 * px
+    assert d["oracle_pin"].startswith("unpinned")
