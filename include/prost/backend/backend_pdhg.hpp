@@ -45,10 +45,11 @@ class BackendPDHG : public Backend<T> {
                                ///< contract multiply-adds (what nvcc's default does to the reference's kernels) and divide through fp32 reciprocal
                                ///< instructions; where a K-iterations-per-launch kernel exists for the problem (fp32 gray-value ROF / TV-L1 shapes) up
                                ///< to 4 iterations run per launch.  Iterates within a stated tolerance of the exact ones (tests/test_gpu_fmad.py).
+    int group_max;             ///< MI355X addition (round 6): iterations per launch of the K-iteration kernel; 0 = the class's default, 1 = never (pairs)
     Options() : tau0(1), sigma0(1), residual_iter(1), scale_steps_operator(true), alg2_gamma(0), arg_alpha0(0.5),
                 arg_nu(0.95), arg_delta(1.5), arb_delta(1.05), arb_tau(0.8), stepsize_variant(kPDHGStepsResidualBoyd),
                 allow_fused(true), allow_single_kernel(true), allow_pair_kernel(true), allow_arg_fusion(true), allow_op_fusion(0), residual_sums_in_prox(1), allow_speculation(true),
-                allow_device_rules(true), arithmetic(PROST_HIP_ARITH_EXACT) {}
+                allow_device_rules(true), arithmetic(PROST_HIP_ARITH_EXACT), group_max(0) {}
   };
 
   explicit BackendPDHG(const Options& opts) : opts_(opts), fused_(false), single_kernel_(false), pair_kernel_(false), res_dev_(nullptr),
@@ -134,7 +135,7 @@ class BackendPDHG : public Backend<T> {
   static constexpr int kGroupMax = 4;
   /// the arithmetic class the iteration kernels of this solve run in (PROST_HIP_ARITH_*) and the largest launch group (0: none)
   int arithmetic() const {
-    return fused_ && (group_max_ >= 2 || desc_pair_.arith == PROST_HIP_ARITH_FMAD || desc_.arith == PROST_HIP_ARITH_FMAD) ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT;
+    return fused_ && (desc_pair_.arith == PROST_HIP_ARITH_FMAD || desc_.arith == PROST_HIP_ARITH_FMAD) ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT;
   }
   int group_max() const { return group_max_; }
  private:

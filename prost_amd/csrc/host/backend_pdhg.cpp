@@ -30,7 +30,6 @@ template <typename T>
 std::string BackendPDHG<T>::path() const {
   if (!fused_) return "pdhg:generic";
   if (from_matrix_) return "pdhg:fused-grad2d(sparse)";        // the stencil kernels on a gradient handed over as a sparse matrix
-  if (group_max_ >= 2) return "pdhg:fused-grad2d+fmad";       // tolerance-class arithmetic, up to kGroupMax iterations per launch
   if (arithmetic() == PROST_HIP_ARITH_FMAD) return desc_.is3d ? "pdhg:fused-grad3d+fmad" : "pdhg:fused-grad2d+fmad";      // ... in the pair launches
   return desc_.is3d ? "pdhg:fused-grad3d" : "pdhg:fused-grad2d";
 }
@@ -262,11 +261,15 @@ void BackendPDHG<T>::Initialize() {
   // kGroupMax iterations replace the pairs; elsewhere the solve stays exact (exact results satisfy every tolerance)
   group_max_ = 0; stale_group_ = false; stale_count_ = 2;
   desc_.arith = desc_pair_.arith = PROST_HIP_ARITH_EXACT;
-  if (opts_.arithmetic == PROST_HIP_ARITH_FMAD && pair_kernel_ && owned_x1_ == 0) {
+  if (pair_kernel_ && owned_x1_ == 0 && opts_.group_max != 1) {
     prost_hip_fused_desc probe = desc_pair_;
-    probe.arith = PROST_HIP_ARITH_FMAD;
+    probe.arith = opts_.arithmetic == PROST_HIP_ARITH_FMAD ? PROST_HIP_ARITH_FMAD : PROST_HIP_ARITH_EXACT;
     const int kmax = prost_hip_fused_iterationk_max(&probe, dtype_id<T>());
-    if (kmax >= 2) { group_max_ = std::min(kmax, kGroupMax); desc_pair_.arith = PROST_HIP_ARITH_FMAD; }
+    // tolerance class: groups of up to kGroupMax.  Exact class: the K-iteration kernel with the exact forms equals the pair kernel and the
+    // oracle bit for bit, but its launches are bound by instruction issue (~48 us per iteration whatever K: 4096^2, K = 2 / 3 / 4: 0.106 /
+    // 0.145 / 0.204 ms per launch), so groups buy nothing there: pairs stay the default, Options::group_max > 1 asks for groups (tests)
+    const int want = opts_.group_max > 1 ? opts_.group_max : (probe.arith == PROST_HIP_ARITH_FMAD ? kGroupMax : 1);
+    if (kmax >= 2 && want >= 2) { group_max_ = std::min(std::min(kmax, kGroupMax), want); desc_pair_.arith = probe.arith; }
   }
   // gradient3d volumes / 2-4 channels: the pair kernels have tolerance-class instances of their own (two iterations per launch as before)
   if (opts_.arithmetic == PROST_HIP_ARITH_FMAD && pair3d_) {

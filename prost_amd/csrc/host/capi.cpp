@@ -343,6 +343,7 @@ std::map<std::string, typename Factory<T>::BackendFactory>& Factory<T>::backend_
       if (prost_value_field(d, "allow_op_fusion")) o.allow_op_fusion = (int)GetScalarFromField(d, "allow_op_fusion");
       if (prost_value_field(d, "residual_sums_in_prox")) o.residual_sums_in_prox = (int)GetScalarFromField(d, "residual_sums_in_prox");
       if (prost_value_field(d, "allow_device_rules")) o.allow_device_rules = GetScalarFromField(d, "allow_device_rules") > 0.;
+      if (prost_value_field(d, "group_max")) o.group_max = (int)GetScalarFromField(d, "group_max");
       if (prost_value_field(d, "arithmetic")) {            // MI355X addition: 'exact' (default) | 'fmad' (tolerance class, BackendPDHG::Options::arithmetic)
         const std::string ar = GetString(prost_value_field(d, "arithmetic"));
         if (ar == "exact") o.arithmetic = PROST_HIP_ARITH_EXACT;

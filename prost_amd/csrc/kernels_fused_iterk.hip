@@ -42,6 +42,7 @@ typedef const __attribute__((address_space(1))) void glb_void_k;
 
 struct LevelStep {
   float tauT, rD, step, sigS, theta, opt;       // tau T, 1 / (1 + step), step = c a^2 tau T, sigma S, theta, 1 + theta
+  UniformDiv sq;                                // exact class: the divisor 1. + step of Function1DSquare and its reciprocal, in double
 };
 template <int K>
 struct StepsK {
@@ -69,7 +70,13 @@ __device__ __forceinline__ void ring_wait(bool steady, bool full) {
 
 // GFN: Function1DSquare or Function1DAbs (scalar a = 1, d = e = 0, c != 0), BPTR: b of prox_g per pixel, RES: the four residual
 // sums of the LAST iteration, R: ring slots, WAVES: resident wavefronts per SIMD the register budget is cut for
-template <int K, int GFN, bool BPTR, bool RES, int R, int WAVES>
+// EXACT: the arithmetic of the exact class -- the expressions of kernels_fused_iter2.hip's straight-line instances, operation for
+// operation (no contraction, the correctly rounded quotient and root forms of device_math.hpp): a launch then equals the CPU oracle bit for
+// bit, like the pair kernel -- which pins the pipeline itself (stage order, halo lanes, ring, chunk edges) to the oracle, independently of
+// the tolerance-class arithmetic.  The exact forms are bound by instruction issue (~71 VALU per pixel-iteration against ~17): measured at
+// 4096^2, K = 2 / 3 / 4: 0.106 / 0.145 / 0.204 ms per launch = 53 / 48 / 51 us per iteration, no better than the pair kernel, so the host
+// keeps pairs for the exact class (BackendPDHG::Options::group_max asks for groups explicitly).
+template <int K, int GFN, bool BPTR, bool RES, int R, int WAVES, bool EXACT>
 __global__ void __launch_bounds__(kWave, WAVES)
     fused_iter2d_xk_kernel(float* __restrict__ x_out, float* __restrict__ y_out, const float* __restrict__ x, const float* __restrict__ y,
                            FusedArgs<float> a, StepsK<K> sp, double* __restrict__ partial, const PdhgRecord<float>* __restrict__ rec) {
@@ -81,7 +88,7 @@ __global__ void __launch_bounds__(kWave, WAVES)
     if (rec->stop) return;
     LevelStep s;
     s.tauT = rec->p.tau * a.Tval; s.rD = (float)rec->p.ug.sq.rD; s.step = rec->p.ug.step; s.sigS = rec->p.sigma * a.Sval;
-    s.theta = rec->p.theta; s.opt = 1 + rec->p.theta;
+    s.theta = rec->p.theta; s.opt = 1 + rec->p.theta; s.sq = rec->p.ug.sq;
 #pragma unroll
     for (int l = 0; l < K; l++) sp.s[l] = s;
     sp.tau_last = rec->p.tau; sp.sigma_last = rec->p.sigma;
@@ -108,6 +115,7 @@ __global__ void __launch_bounds__(kWave, WAVES)
   T* const y2out = y_out + N;
   const T* const bptr = BPTR ? a.g_ptr[1] : nullptr;
   const T bval = a.g_val[1], bq = a.f_val[1];
+  const bool tiny_is_zero = a.f_val[1] >= (T)kTinyIsZeroRadius;     // device_math.hpp: norm2_leq0_fast
   auto off_of = [&](idx_t c) { return ((unsigned)c * (unsigned)ny + (unsigned)row0) * (unsigned)sizeof(T); };
   // loaded columns: xa - K + 1 .. xb + K - 1 (the y_1 of column xa - K is read directly into registers)
   auto has_col = [&](idx_t k) { return k >= 0 && k < nx && k >= xa - K + 1 && k <= xb + K - 1; };
@@ -172,6 +180,7 @@ __global__ void __launch_bounds__(kWave, WAVES)
                     const T (&bc)[VEC], T (&xn)[VEC], T (&kt)[RES ? VEC : 1], bool want_kt) {
     constexpr bool I = decltype(inner)::value;
     const T up = lane_up(y2c[VEC - 1]);            // lane 0: no source, its first row is halo
+    T parg[EXACT ? VEC : 1];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const idx_t row = row0 + j;
@@ -179,10 +188,27 @@ __global__ void __launch_bounds__(kWave, WAVES)
       const T divy = ((I || row < ny - 1) ? y2c[j] : (T)0) - ((I || row > 0) ? upj : (T)0);
       const T divx = ((I || c < nx - 1) ? y1c[j] : (T)0) - ((I || c > 0) ? y1p[j] : (T)0);
       const T sdiv = divx + divy;
-      if (RES && want_kt) kt[RES ? j : 0] = -sdiv;
-      const T arg = t_fma(P.tauT, sdiv, xin[j]);
-      if (GFN == PROST_FN_SQUARE) xn[j] = t_fma(arg - bc[j], P.rD, bc[j]);
-      else { const T v = arg - bc[j]; xn[j] = (v - t_max(t_min(v, P.step), -P.step)) + bc[j]; }
+      if constexpr (EXACT) {        // backend_pdhg.cu:317-338 as kernels_fused_iter2.hip evaluates it: K^T y = 0 - (div), x - tau T K^T y, v - b
+        const T kty = (T)0 - sdiv;
+        if (RES && want_kt) kt[RES ? j : 0] = kty;
+        const T arg = xin[j] - P.tauT * kty;
+        parg[EXACT ? j : 0] = arg - bc[j];
+      } else {
+        if (RES && want_kt) kt[RES ? j : 0] = -sdiv;
+        const T arg = t_fma(P.tauT, sdiv, xin[j]);
+        if (GFN == PROST_FN_SQUARE) xn[j] = t_fma(arg - bc[j], P.rD, bc[j]);
+        else { const T v = arg - bc[j]; xn[j] = (v - t_max(t_min(v, P.step), -P.step)) + bc[j]; }
+      }
+    }
+    if constexpr (EXACT) {          // ElemOperation1D<F>, scalar a = 1, d = e = 0: F_prox(v - b; step) + b (Function1DSquare: the exact division)
+      T r[VEC];
+      if (GFN == PROST_FN_SQUARE) div_to_float_exact_vec<VEC>(parg, P.sq, r);
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) r[j] = f1d_apply<T, GFN>(GFN, parg[EXACT ? j : 0], P.step, a.g_val[5], a.g_val[6]);
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; j++) xn[j] = r[j] + bc[j];
     }
   };
   // dual step of level l at column c: y^l = prox_f*(y^(l-1) + sigma S K ((1 + theta) x^l - theta x^(l-1)))
@@ -193,8 +219,43 @@ __global__ void __launch_bounds__(kWave, WAVES)
     const T bel_n = lane_down(xn_c[0]);            // lane 63: no source, its last row is halo
     const T bel_o = lane_down(xo_c[0]);
     T spd = 0, spv = 0;
+    if constexpr (EXACT) {
+      // backend_pdhg.cu:341-370 as kernels_fused_iter2.hip evaluates it; ElemOperationNorm2<Function1DIndLeq0> through norm2_leq0_fast
+      T av[2][VEC], nv[VEC], out[2][VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; j++) {
+      for (int j = 0; j < VEC; j++) {
+        const idx_t row = row0 + j;
+        const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
+        const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
+        const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+        const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
+        const T kp1 = has_next ? xo_n[j] - xo_c[j] : (T)0;
+        const T kp2 = (I || row < ny - 1) ? below_o - xo_c[j] : (T)0;
+        const T arg1 = y1c[j] + P.sigS * (P.opt * kx1 - P.theta * kp1);
+        const T arg2 = y2c[j] + P.sigS * (P.opt * kx2 - P.theta * kp2);
+        T norm = 0;
+        norm += arg1 * arg1;
+        norm += arg2 * arg2;
+        av[0][j] = arg1; av[1][j] = arg2; nv[j] = norm;
+      }
+      norm2_leq0_fast<T, 2, VEC>(nv, av, bq, tiny_is_zero, out);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) { o1[j] = out[0][j]; o2[j] = out[1][j]; }
+      if (RES && acc) {             // the tolerance-compared sums: fp32 with fused multiply-adds, as in the pair kernel's straight-line instances
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+          const idx_t row = row0 + j;
+          const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
+          const T kx1 = has_next ? xn_n[j] - xn_c[j] : (T)0;
+          const T kx2 = (I || row < ny - 1) ? below_n - xn_c[j] : (T)0;
+          const T z1 = (av[0][j] - o1[j]) * inv_sigS, z2 = (av[1][j] - o2[j]) * inv_sigS;
+          const T d1 = t_fma(-sqS, kx1, z1), d2 = t_fma(-sqS, kx2, z2);
+          spd = t_fma(d1, d1, spd); spd = t_fma(d2, d2, spd); spv = t_fma(z1, z1, spv); spv = t_fma(z2, z2, spv);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < (EXACT ? 0 : VEC); j++) {
       const idx_t row = row0 + j;
       const T below_n = (j < VEC - 1) ? xn_c[(j + 1) % VEC] : bel_n;
       const T below_o = (j < VEC - 1) ? xo_c[(j + 1) % VEC] : bel_o;
@@ -307,7 +368,7 @@ __global__ void __launch_bounds__(kWave, WAVES)
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 static bool iterk_shape_ok(const prost_hip_fused_desc* d, int dtype) {
-  if (!d || dtype != 0 || d->arith != PROST_HIP_ARITH_FMAD) return false;
+  if (!d || dtype != 0 || (d->arith != PROST_HIP_ARITH_FMAD && d->arith != PROST_HIP_ARITH_EXACT)) return false;
   if (d->is3d || d->L != 1 || d->var_T || d->f_moreau || d->g_b_masked) return false;
   if (d->nx < 8 || d->ny < 8 || d->ny % 4 != 0) return false;
   if ((double)d->nx * (double)d->ny * 4 >= 4294967296.0) return false;
@@ -319,7 +380,7 @@ static bool iterk_shape_ok(const prost_hip_fused_desc* d, int dtype) {
   if (!aligned16(d->g_coeff_ptr[1])) return false;
   if ((d->ny + 56 * 4 - 1) / (56 * 4) > (size_t)kReduceBlocks / 2) return false;
   return d->g_coeff_val[0] == 1.0 && d->g_coeff_val[2] != 0.0 && d->g_coeff_val[3] == 0.0 && d->g_coeff_val[4] == 0.0 &&
-         d->f_coeff_val[0] == 1.0 && d->f_coeff_val[1] > 0.0 && d->f_coeff_val[3] == 0.0 && d->f_coeff_val[4] == 0.0;
+         d->f_coeff_val[0] == 1.0 && (d->f_coeff_val[1] > 0.0 || d->arith == PROST_HIP_ARITH_EXACT) && d->f_coeff_val[3] == 0.0 && d->f_coeff_val[4] == 0.0;
 }
 
 // ring slots and resident wavefronts per SIMD of the instances (160 KB of LDS per CU: 4 SIMDs x WAVES x R x NB KB must fit)
@@ -331,6 +392,7 @@ template <> struct IterKGeom<4> { static constexpr int R = 4, W = 2; };
 template <> struct IterKGeom<5> { static constexpr int R = 4, W = 2; };
 template <> struct IterKGeom<6> { static constexpr int R = 4, W = 2; };
 constexpr int kIterKMax = 6;
+constexpr int kIterKMaxExact = 4;      // exact class: instances up to K = 4 (register budget of the correctly rounded forms)
 static int iterk_rows_per_wave(int K) { return (kWave - 2 * ((K + 3) / 4)) * 4; }
 static int iterk_waves(int K) { return K <= 2 ? IterKGeom<2>::W : K == 3 ? IterKGeom<3>::W : 2; }
 
@@ -384,6 +446,7 @@ static int run_iterk(const prost_hip_fused_desc* d, float* x_out, float* y_out, 
     const UniformProx<float> ug = make_uniform_prox<float>(a.g_val, t * a.Tval);
     if (!record && !(ug.a_one && ug.den_one && !ug.degenerate)) { set_error("fused K-iteration launch: not the straight-line shape"); return 1; }
     sp.s[l].tauT = t * a.Tval; sp.s[l].rD = (float)ug.sq.rD; sp.s[l].step = ug.step; sp.s[l].sigS = s * a.Sval; sp.s[l].theta = th; sp.s[l].opt = 1 + th;
+    sp.s[l].sq = ug.sq;
   }
   sp.tau_last = record ? 1.0f : (float)tau[K - 1]; sp.sigma_last = record ? 1.0f : (float)sigma[K - 1];
   dim3 grid((unsigned)(strips * a.chunks)), block(kWave);
@@ -392,8 +455,11 @@ static int run_iterk(const prost_hip_fused_desc* d, float* x_out, float* y_out, 
   const PdhgRecord<float>* rec = static_cast<const PdhgRecord<float>*>(record);
   constexpr int R = IterKGeom<K>::R, W = IterKGeom<K>::W;
   static const int geom = iterk_override("PROST_ITERK_GEOM", 0);
-#define GOK(G, BP, RS) PH_LAUNCH((fused_iter2d_xk_kernel<K, G, BP, RS, R, (RS && W > 2 ? W - 1 : W)>), grid, block, 0, s, x_out, y_out, x, y, a, sp, partial, rec)
-#define GOKW(G, BP, RS) PH_LAUNCH((fused_iter2d_xk_kernel<K, G, BP, RS, 8, 1>), grid, block, 0, s, x_out, y_out, x, y, a, sp, partial, rec)
+  const bool exact = d->arith == PROST_HIP_ARITH_EXACT;
+#define GOKA(G, BP, RS, EX) PH_LAUNCH((fused_iter2d_xk_kernel<K, G, BP, RS, R, (RS && W > 2 ? W - 1 : W), EX>), grid, block, 0, s, x_out, y_out, x, y, a, sp, partial, rec)
+#define GOK(G, BP, RS) do { if (exact) { if constexpr (K <= kIterKMaxExact) GOKA(G, BP, RS, true); else { set_error("fused K-iteration launch: the exact class runs K <= 4"); return 1; } } \
+    else GOKA(G, BP, RS, false); } while (0)
+#define GOKW(G, BP, RS) PH_LAUNCH((fused_iter2d_xk_kernel<K, G, BP, RS, 8, 1, false>), grid, block, 0, s, x_out, y_out, x, y, a, sp, partial, rec)
 #define GOK2(G, BP) do { \
     bool done = false; \
     if constexpr (K == 4 && G == PROST_FN_SQUARE && BP) { if (geom == 1) { done = true; if (out4) GOKW(G, BP, true); else GOKW(G, BP, false); } } \
@@ -405,6 +471,7 @@ static int run_iterk(const prost_hip_fused_desc* d, float* x_out, float* y_out, 
 #undef GOK2
 #undef GOKW
 #undef GOK
+#undef GOKA
   { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(e_, "fused K-iteration kernel"); }
   if (out4 && tail && tail->apply) return launch_fold4_rule<float>(out4, partial, grid.x, record, tail->iteration, tail->mirror, s);
   if (out4) return launch_fold4(out4, partial, grid.x, s);
@@ -430,9 +497,11 @@ static int run_iterk_any(int K, const prost_hip_fused_desc* d, float* x_out, flo
 using namespace prost_hip;
 
 extern "C" {
-int prost_hip_fused_iterationk_max(const prost_hip_fused_desc* desc, int dtype) { return iterk_shape_ok(desc, dtype) ? kIterKMax : 0; }
+int prost_hip_fused_iterationk_max(const prost_hip_fused_desc* desc, int dtype) {
+  return !iterk_shape_ok(desc, dtype) ? 0 : desc->arith == PROST_HIP_ARITH_EXACT ? kIterKMaxExact : kIterKMax;
+}
 int prost_hip_fused_iterationk_chunk_cols(const prost_hip_fused_desc* desc, int dtype, int k, int with_residuals) {
-  return iterk_shape_ok(desc, dtype) && k >= 1 && k <= kIterKMax ? iterk_chunk_cols(desc, k, with_residuals != 0, 0) : 0;
+  return iterk_shape_ok(desc, dtype) && k >= 1 && k <= (desc->arith == PROST_HIP_ARITH_EXACT ? kIterKMaxExact : kIterKMax) ? iterk_chunk_cols(desc, k, with_residuals != 0, 0) : 0;
 }
 int prost_hip_fused_iterationk_f32(const prost_hip_fused_desc* d, int k, float* x_out, float* y_out, const float* x, const float* y, const double* tau,
                                    const double* sigma, const double* theta, int cols_per_block, double* res_out4, void* workspace, void* s) {

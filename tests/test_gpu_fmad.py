@@ -112,7 +112,7 @@ def test_a_launch_of_k_iterations_equals_every_partition_bit_for_bit(hip, nx, ny
     tolerance-class PAIR kernel (kernels_fused_iter2.hip, template parameter FMAD) -- two independently written kernels"""
     p = _Rof(hip, nx, ny, gfn, bpp)
     assert hip.lib().prost_hip_fused_iterationk_max(C.byref(p.desc(1)), 0) == 6
-    assert hip.lib().prost_hip_fused_iterationk_max(C.byref(p.desc(0)), 0) == 0            # exact descriptions never run it
+    assert hip.lib().prost_hip_fused_iterationk_max(C.byref(p.desc(0)), 0) == 4            # the exact class: K <= 4 (its own test below)
     assert hip.lib().prost_hip_fused_iterationk_max(C.byref(p.desc(1)), 1) == 0            # fp64: no tolerance-class instances
     ref = p.run([-2] * 6, res_last=True)
     assert np.isfinite(ref[0]).all() and np.isfinite(ref[1]).all()
@@ -362,3 +362,43 @@ def test_c3_2048x2048x64_sub_volumes_track_the_oracle():
             assert rel <= 1e-5 * k, (name, (x0, y0, l0), rel)
             assert not np.array_equal(g, e)
     s.destroy()
+
+
+@pytest.mark.parametrize("nx,ny,gfn,bpp", [(1024, 1024, "square", True), (333, 520, "abs", True), (40, 64, "square", False)])
+def test_the_k_iteration_kernel_in_the_exact_class_equals_the_exact_pair_kernel_bit_for_bit(hip, nx, ny, gfn, bpp):
+    """the pipeline of kernels_fused_iterk.hip (stage order, halo lanes, LDS ring, chunk edges) with the EXACT forms: equal to the exact pair
+    kernel -- which equals the CPU oracle (tests/test_gpu_fullsize.py) -- for K = 1 .. 4 and every partition"""
+    p = _Rof(hip, nx, ny, gfn, bpp)
+    assert hip.lib().prost_hip_fused_iterationk_max(C.byref(p.desc(0)), 0) == 4
+    ref = p.run([-2] * 6, arith=0, res_last=True)
+    for ks, cols in (([2] * 6, 0), ([3] * 4, 0), ([4] * 3, 0), ([4, 3, 3, 2], 0), ([1, 4, 1, 4, 2], 0), ([4] * 3, 5), ([3] * 4, 1000)):
+        got = p.run(ks, arith=0, cols=cols, res_last=ks[-1] >= 2)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (ks, cols)
+        if ks[-1] >= 2:
+            assert np.allclose(got[2], ref[2], rtol=1e-12), (ks, cols)
+    d = p.desc(0)
+    assert hip.lib().prost_hip_fused_iterationk_f32(C.byref(d), 5, p.x[1].ptr, p.y[1].ptr, p.x[0].ptr, p.y[0].ptr, _arr(TAUS, 0, 5), _arr(SIGMAS, 0, 5), _arr(THETAS, 0, 5), 0,
+                                                    None, None, None) != 0          # the exact class runs K <= 4
+
+
+def test_exact_groups_through_the_solver_equal_the_oracle_bit_for_bit():
+    """Options::group_max = 3 in the exact class (pairs are its default): the group scheduling, the rebuilt previous iterate and the
+    residual launches against oracle.Solver, every bit of x, y, z, w"""
+    n, k = 1024, 47
+    prob, u, q, f = synthetic.rof_problem(n, n)
+    b = prost.backend.pdhg(stepsize="alg2", residual_iter=10, alg2_gamma=0.5)
+    b[1]["group_max"] = 3
+    o = prost.options(max_iters=10 ** 6, num_cback_calls=0, verbose=False, **ZERO_TOL)
+    s = prost.Solver(prob, b, o)
+    info = s.iterate(k, time_kernels=True, sample_every=1)
+    st = s.state()
+    s.destroy()
+    assert st["arithmetic"] == "exact" and st["path"] == "pdhg:fused-grad2d" and st["iterations_per_launch_max"] == 3
+    assert "fused_iter2d_xk_kernel<3>" in info["kernels"], info["kernels"]
+    bo = [b[0], {kk: v for kk, v in b[1].items() if kk != "group_max"}]
+    os_ = oracle.Solver(prob.data, prob.nrows, prob.ncols, bo, o, np.float32)
+    os_.initialize(); os_.iterate(k)
+    ost = os_.state()
+    del os_
+    for v in "xyzw":
+        assert np.array_equal(st[v], ost[v]), (v, int((st[v] != ost[v]).sum()))

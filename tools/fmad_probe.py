@@ -122,7 +122,7 @@ def main_k(N=4096, iters=200):
         d.g_coeff_val[i] = gv[i]; d.f_coeff_val[i] = fv[i]
     d.g_coeff_ptr[1] = f.ptr.value
     d.T_val, d.S_val = 0.25, 0.5
-    d.arith = 1
+    d.arith = int(os.environ.get("PROST_ARITH", "1"))          # 0: the exact class (K <= 4), 1: the tolerance class
     L_ = hip.lib()
     I2 = hip.fn("fused_iteration2", dtype)
     IK = L_.prost_hip_fused_iterationk_f32
@@ -157,6 +157,8 @@ def main_k(N=4096, iters=200):
     ref12 = run_seq([-2] * 6, True)
     cases = (("6 x K=2", [2] * 6), ("4 x K=3", [3] * 4), ("3 x K=4", [4] * 3), ("K=4,3,3,2", [4, 3, 3, 2]), ("K=5,5,2", [5, 5, 2]), ("2 x K=6", [6, 6]),
              ("K=6 cols 5", None), ("K=5 cols 100", None), ("K=2 cols 7", None), ("K=4 cols 5", None), ("K=3 cols 1000", None))
+    kmax = L_.prost_hip_fused_iterationk_max(C.byref(d), 0)
+    cases = tuple(c for c in cases if (max(c[1]) if c[1] else int(c[0][2])) <= kmax)
     for name, ks in cases:
         if ks is None:
             k = int(name[2]); got = run_seq([k] * (12 // k) + ([12 % k] if 12 % k else []), True, cols=int(name.split()[-1]))
@@ -176,7 +178,7 @@ def main_k(N=4096, iters=200):
         ms = C.c_float(); hip.check(L_.prost_hip_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
         return ms.value / iters
     reset()
-    for k in (2, 3, 4, 5, 6):
+    for k in [k for k in (2, 3, 4, 5, 6) if k <= kmax]:
         for mode in (0, 2):
             for cols in (0, 18, 24, 30, 36, 42, 48, 72):
                 def runk(cnt):
