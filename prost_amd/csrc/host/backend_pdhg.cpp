@@ -234,7 +234,19 @@ void BackendPDHG<T>::Initialize() {
                  (opts_.residual_sums_in_prox >= 2 || this->problem_->ncols() + this->problem_->nrows() >= ((size_t)1 << 23));
   for (auto& p : prox_g_) res_in_prox_ = res_in_prox_ && p->supports_op_source();
   for (auto& p : prox_fstar_) res_in_prox_ = res_in_prox_ && p->supports_op_source();
-  if ((op_fused_ || res_in_prox_) && !op_workspace_) CheckHip(prost_hip_malloc(&op_workspace_, 2 * (size_t)kOpSumSlots * 4 * sizeof(double)), "malloc");
+  // every prox launch of a side writes its partial sums into its own run of slots of that side's half of the workspace: more proxes than
+  // slots, or a prox without elements (it launches nothing, its slots would stay unwritten), keep the separate reductions
+  {
+    bool slots_ok = prox_g_.size() <= kOpSumSlots / 4 && prox_fstar_.size() <= kOpSumSlots / 4;
+    for (auto& p : prox_g_) slots_ok = slots_ok && p->size() > 0;
+    for (auto& p : prox_fstar_) slots_ok = slots_ok && p->size() > 0;
+    op_fused_ = op_fused_ && slots_ok;
+    res_in_prox_ = res_in_prox_ && slots_ok;
+  }
+  if ((op_fused_ || res_in_prox_) && !op_workspace_) {
+    CheckHip(prost_hip_malloc(&op_workspace_, 2 * (size_t)kOpSumSlots * 4 * sizeof(double)), "malloc");
+    CheckHip(prost_hip_memset(op_workspace_, 0, 2 * (size_t)kOpSumSlots * 4 * sizeof(double), CurrentStream()), "memset");
+  }
   single_kernel_ = fused_ && opts_.allow_single_kernel && prost_hip_fused_iteration_supported(&desc_, dtype_id<T>()) == 1;
   single3d_ = fused_ && !single_kernel_ && opts_.allow_single_kernel && prost_hip_fused_iteration3d_supported(&desc_, dtype_id<T>()) == 1;
   single3d_pw_ = single3d_ && prost_hip_fused_iteration3d_pw_supported(&desc_, dtype_id<T>()) == 1;

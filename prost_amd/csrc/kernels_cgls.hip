@@ -996,10 +996,11 @@ const FusedOpDev* device_op(const prost_hip_fused_op* op) {
   if (hipGetDevice(&device) != hipSuccess) { set_error("device_op: no current device"); return nullptr; }
   std::lock_guard<std::mutex> g(mu);
   for (const Entry& e : cache) if (e.device == device && std::memcmp(&e.host, &h, sizeof(h)) == 0) return e.dev;
-  if (cache.size() >= 64) {                            // (operators come and go with their solvers: start over rather than grow)
-    for (Entry& e : cache) (void)hipFree(e.dev);
-    cache.clear();
-  }
+  // Tables are never freed: the pointer is handed out after the mutex is released, so another thread (the ranks of a multi-rank test
+  // live in one process) may be about to launch with any cached table, and a table may belong to another device than the current one.
+  // They are ~2 KB each; a process that has seen 4096 distinct operators stops caching the oldest half of the list instead (the
+  // tables themselves stay allocated).
+  if (cache.size() >= 4096) cache.erase(cache.begin(), cache.begin() + 2048);
   FusedOpDev* d = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(FusedOpDev)) != hipSuccess || hipMemcpy(d, &h, sizeof(FusedOpDev), hipMemcpyHostToDevice) != hipSuccess) {
     set_error("device_op: cannot upload the operator table");
