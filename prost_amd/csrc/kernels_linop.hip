@@ -204,6 +204,110 @@ __global__ void __launch_bounds__(kBlock) grad_adj_vec_kernel(T* __restrict__ re
   }
 }
 
+// ---- label-first layout (idx = l + y L + x ny L), 2-D, 16 bytes per lane ------------------------------------------------------
+// (round 6: the scalar kernel above reached 0.41-0.44 of the HBM peak on this layout, 4-byte accesses.)  A column x is one contiguous
+// run of R = ny L values, t = l + y L; the y-neighbour of t is t + L, the x-neighbour t + R.  A lane owns VEC consecutive t: the
+// x-neighbours are the vector it loads for the next column anyway, the y-neighbours one more 16-byte access at a 4-byte aligned address
+// (gfx950 serves those; the lanes at the end of the run, whose access would leave it, read element by element).  Arithmetic per element
+// is that of the scalar kernel: bit-identical.
+template <class T, int VEC>
+__device__ __forceinline__ void ldv_at(const T* p, T (&v)[VEC]) {          // 16 bytes at any sizeof(T)-aligned address
+  typedef typename UVecOf<T>::type V;
+  const V t = *reinterpret_cast<const V*>(p);
+#pragma unroll
+  for (int j = 0; j < VEC; j++) v[j] = t[j];
+}
+template <class T, int VEC, bool ACC>
+__global__ void __launch_bounds__(kBlock) grad_fwd_lf_vec_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nx, size_t ny, size_t L, unsigned strips,
+                                                                 int cols) {
+  const unsigned strip = blockIdx.x % strips, chunk = blockIdx.x / strips;
+  const size_t R = ny * L, N = nx * R;
+  const size_t t0 = ((size_t)strip * kBlock + threadIdx.x) * VEC;
+  if (t0 >= R) return;
+  const size_t x0 = (size_t)chunk * cols, x1 = x0 + cols < nx ? x0 + cols : nx;
+  T cur[VEC], nxt[VEC], dn[VEC];
+  ldv<T, VEC>(rhs + x0 * R + t0, cur);
+  for (size_t x = x0; x < x1; x++) {
+    const size_t idx = x * R + t0;
+    const bool has_next = x + 1 < nx;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { nxt[j] = 0; dn[j] = 0; }
+    if (has_next) ldv<T, VEC>(rhs + idx + R, nxt);
+    if (t0 + VEC - 1 + L < R) ldv_at<T, VEC>(rhs + idx + L, dn);
+    else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) if (t0 + j + L < R) dn[j] = rhs[idx + j + L];
+    }
+    T gx[VEC], gy[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const T val = cur[j];
+      gy[j] = (t0 + j + L < R) ? dn[j] - val : (T)0;            // y < ny - 1
+      gx[j] = has_next ? nxt[j] - val : (T)0;
+    }
+    if (ACC) {
+      T o[VEC];
+      ldv<T, VEC>(res + idx, o);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) gx[j] = o[j] + gx[j];
+      ldv<T, VEC>(res + idx + N, o);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) gy[j] = o[j] + gy[j];
+    }
+    stv<T, VEC>(res + idx, gx);
+    stv<T, VEC>(res + idx + N, gy);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
+  }
+}
+template <class T, int VEC, bool ACC>
+__global__ void __launch_bounds__(kBlock) grad_adj_lf_vec_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t nx, size_t ny, size_t L, unsigned strips,
+                                                                 int cols) {
+  const unsigned strip = blockIdx.x % strips, chunk = blockIdx.x / strips;
+  const size_t R = ny * L, N = nx * R;
+  const size_t t0 = ((size_t)strip * kBlock + threadIdx.x) * VEC;
+  if (t0 >= R) return;
+  const size_t x0 = (size_t)chunk * cols, x1 = x0 + cols < nx ? x0 + cols : nx;
+  T prev[VEC], px[VEC], py[VEC], pu[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; j++) prev[j] = 0;
+  if (x0 > 0) ldv<T, VEC>(rhs + (x0 - 1) * R + t0, prev);
+  for (size_t x = x0; x < x1; x++) {
+    const size_t idx = x * R + t0;
+    ldv<T, VEC>(rhs + idx, px);
+    ldv<T, VEC>(rhs + N + idx, py);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) pu[j] = 0;
+    if (t0 >= L) ldv_at<T, VEC>(rhs + N + idx - L, pu);
+    else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) if (t0 + j >= L) pu[j] = rhs[N + idx + j - L];
+    }
+    T o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      T divx, divy;
+      if (t0 + j + L < R) divy = py[j]; else divy = 0;          // y < ny - 1
+      if (t0 + j >= L) divy -= pu[j];                            // y > 0
+      if (x < nx - 1) divx = px[j]; else divx = 0;
+      if (x > 0) divx -= prev[j];
+      o[j] = divx + divy;
+    }
+    if (ACC) {
+      T r[VEC];
+      ldv<T, VEC>(res + idx, r);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) o[j] = r[j] - o[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) o[j] = (T)0 - o[j];
+    }
+    stv<T, VEC>(res + idx, o);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) prev[j] = px[j];
+  }
+}
+
 // columns per workgroup: non-power-of-two chunks keep concurrently running workgroups on
 // different HBM channels (see kernels_fused_iter.hip); shrink until the grid fills 256 CUs x 4
 static int pick_grad_cols(size_t nx, size_t strips, size_t L) {
@@ -225,6 +329,19 @@ static int launch_grad(bool adjoint, T* res, const T* rhs, size_t nx, size_t ny,
       if (!adjoint) { if (acc) GOV(grad_fwd_vec_kernel, true); else GOV(grad_fwd_vec_kernel, false); }
       else { if (acc) GOV(grad_adj_vec_kernel, true); else GOV(grad_adj_vec_kernel, false); }
 #undef GOV
+      PH_LAUNCH_END("gradient kernel");
+    }
+  }
+  if (lf && !D3 && (ny * L) % V == 0 && aligned16(res) && aligned16(rhs)) {
+    const size_t R = ny * L, strips = (R + (size_t)kBlock * V - 1) / ((size_t)kBlock * V);
+    const int cols = pick_grad_cols(nx, strips, 1);
+    const size_t blocks = strips * ((nx + cols - 1) / cols);
+    if (blocks < (1ull << 31)) {
+      hipStream_t s = as_stream(stream);
+#define GOL(K, ACCv) hipLaunchKernelGGL((K<T, V, ACCv>), dim3((unsigned)blocks), dim3(kBlock), 0, s, res, rhs, nx, ny, L, (unsigned)strips, cols)
+      if (!adjoint) { if (acc) GOL(grad_fwd_lf_vec_kernel, true); else GOL(grad_fwd_lf_vec_kernel, false); }
+      else { if (acc) GOL(grad_adj_lf_vec_kernel, true); else GOL(grad_adj_lf_vec_kernel, false); }
+#undef GOL
       PH_LAUNCH_END("gradient kernel");
     }
   }

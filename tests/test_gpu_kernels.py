@@ -49,7 +49,10 @@ def ulp_diff(a, b):
 
 
 GRAD_SHAPES = [(7, 5, 1, False), (7, 5, 3, False), (7, 5, 3, True), (1, 9, 1, False), (9, 1, 1, False),
-               (33, 130, 2, False), (307, 229, 8, False), (64, 300, 2, True)]
+               (33, 130, 2, False), (307, 229, 8, False), (64, 300, 2, True),
+               # label-first runs of ny L values: the 16-bytes-per-lane kernels of round 6 (ny L a multiple of 4 / 2), more than one strip,
+               # L larger than a lane's 4 values, one column, one row
+               (9, 8, 3, True), (70, 1030, 4, True), (5, 12, 7, True), (1, 16, 1, True), (6, 1, 4, True), (3, 2, 2, True)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
