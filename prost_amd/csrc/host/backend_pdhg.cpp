@@ -682,6 +682,12 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
 /// front of it), never contains one except as its LAST iteration (the kernel forms the sums there), and never leaves the next residual
 /// iteration alone behind it (a single residual launch streams y^(k-1), which a group keeps in registers): with d = iterations up to and
 /// including the next residual one, g = min(budget, group_max_, d), one less if that would leave d - g == 1.
+/// workgroups of one residual launch of the generic path (kOpLaunchSlots; PROST_OP_LAUNCH_SLOTS overrides it for measurements)
+static unsigned OpLaunchSlots() {
+  static const unsigned v = []() { const char* e = getenv("PROST_OP_LAUNCH_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 2048u; }();
+  return v;
+}
+
 template <typename T>
 int BackendPDHG<T>::GroupSize(size_t k, int budget, bool& residuals) const {
   residuals = false;
@@ -979,7 +985,7 @@ void BackendPDHG<T>::IterationGenericOp(bool res) {
     src.op = &gen_op_; src.op_rows = m; src.op_cols = n;
     src.w[0] = y_.data(); src.kty_out = kty_.data();
     src.use[0] = iteration_ >= 1 ? 1 : 0;                    // kty_ is the zero vector in iteration 0 (backend_pdhg.cu:213)
-    if (res) { src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_g_.size(), 1))); }
+    if (res) { src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(OpLaunchSlots(), half / (unsigned)std::max<size_t>(prox_g_.size(), 1))); }
     for (auto& p : prox_g_) p->EvalFromSource(x_, src, Tr, tau_);
   }
   y_.swap(y_prev_);
@@ -988,7 +994,7 @@ void BackendPDHG<T>::IterationGenericOp(bool res) {
     src.op = &gen_op_; src.op_rows = m; src.op_cols = n;
     src.w[0] = x_.data(); src.w[1] = x_prev_.data();
     src.use[1] = iteration_ >= 1 ? 1 : 0;                    // kx_prev_ is the zero vector in iteration 0 (:216)
-    if (res) { src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1))); }
+    if (res) { src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(OpLaunchSlots(), half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1))); }
     for (auto& p : prox_fstar_) p->EvalFromSource(y_, src, Sl, sigma_);
   }
   if (res) {
@@ -1023,7 +1029,7 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
     typename Prox<T>::ArgSource src{PROST_ARG_PDHG_PRIMAL, {x_prev_.data(), Tr.data(), kty_.data(), nullptr}, {tau_, (T)0}};
     if (res_here) {                                    // dual residual terms: x_prev, x, T, K^T y^(k-1), K^T y^k
       src.v[3] = kty_prev_.data();
-      src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_g_.size(), 1)));
+      src.res_ws = ws_d; src.res_slot = &slot_d; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(OpLaunchSlots(), half / (unsigned)std::max<size_t>(prox_g_.size(), 1)));
     }
     for (auto& p : prox_g_) p->EvalFromSource(x_, src, Tr, tau_);
   } else {
@@ -1042,7 +1048,7 @@ void BackendPDHG<T>::IterationGeneric(bool res) {
     y_.swap(y_prev_);
     typename Prox<T>::ArgSource src{PROST_ARG_PDHG_DUAL, {y_prev_.data(), Sl.data(), kx_.data(), kx_prev_.data()}, {sigma_, theta_}};
     if (res_here) {                                    // primal residual terms: y_prev, y, Sigma, K x_prev, K x
-      src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(kOpLaunchSlots, half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1)));
+      src.res_ws = ws_p; src.res_slot = &slot_p; src.res_slots_max = std::max<unsigned>(1, std::min<unsigned>(OpLaunchSlots(), half / (unsigned)std::max<size_t>(prox_fstar_.size(), 1)));
     }
     for (auto& p : prox_fstar_) p->EvalFromSource(y_, src, Sl, sigma_);
   } else {
