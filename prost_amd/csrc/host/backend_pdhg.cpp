@@ -681,7 +681,7 @@ void BackendPDHG<T>::IterationPair(bool store_mid, bool residuals) {
 /// The launch PerformIterations makes at iteration k: a group never starts with a residual iteration (its sums need the iterate in
 /// front of it), never contains one except as its LAST iteration (the kernel forms the sums there), and never leaves the next residual
 /// iteration alone behind it (a single residual launch streams y^(k-1), which a group keeps in registers): with d = iterations up to and
-/// including the next residual one, g = min(budget, group_max_, d), one less if that would leave d - g == 1.
+/// including the next residual one, g = min(budget, group_max_, d), shortened while that would leave d - g == 1 or 2.
 /// workgroups of one residual launch of the generic path (kOpLaunchSlots; PROST_OP_LAUNCH_SLOTS overrides it for measurements)
 static unsigned OpLaunchSlots() {
   static const unsigned v = []() { const char* e = getenv("PROST_OP_LAUNCH_SLOTS"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 2048u; }();
@@ -696,7 +696,10 @@ int BackendPDHG<T>::GroupSize(size_t k, int budget, bool& residuals) const {
   const size_t r = (k / ri + 1) * ri;                // the next residual iteration (> k)
   const size_t d = r - k + 1;
   int g = (int)std::min<size_t>(std::min<size_t>((size_t)budget, (size_t)group_max_), d);
-  if (d - (size_t)g == 1 && g > 2) g--;
+  // never leave one iteration behind (see above), and not two either where a shorter launch now avoids it: the two-iteration launch
+  // with the sums is the slowest instance per iteration (4096^2: 0.101-0.127 ms between boxes against 0.104 for three), so a period of
+  // ten runs as 4 + 3 + 3, not 4 + 4 + 2
+  while (g > 2 && d - (size_t)g >= 1 && d - (size_t)g <= 2) g--;
   residuals = k + (size_t)g - 1 == r;
   return g;
 }

@@ -404,18 +404,16 @@ static int iterk_override(const char* name, int dflt) {
 static int iterk_chunk_cols(const prost_hip_fused_desc* d, int K, bool res, int cols) {
   const size_t rpw = (size_t)iterk_rows_per_wave(K), strips = (d->ny + rpw - 1) / rpw;
   if (cols <= 0) {
-    // the longest chunk (2K - 2 extra columns are loaded per chunk) that still fills >= 90 % of the wave slots in one round
-    const size_t slots = 256 * 4 * (size_t)iterk_waves(K);
-    cols = 0;
-    for (int c : {72, 60, 48, 42, 36, 30, 24, 18, 12, 9}) if (strips * ((d->nx + c - 1) / c) * 10 >= slots * 9) { cols = c; break; }
-    if (cols == 0) {
-      double best = 1e30;
-      for (int c : {18, 12, 9, 6, 4, 3, 2}) {
-        const double waves = (double)(strips * ((d->nx + c - 1) / c));
-        const double cost = (c + 2 * K - 0.5) * (waves > (double)slots ? waves / (double)slots : 1.0);
-        if (cost < best) { best = cost; cols = c; }
-      }
-    }
+    // The shortest chunk whose workgroups all run in ONE round with two wavefronts per SIMD (2048 on the chip).  Shorter chunks mean a
+    // second, mostly empty round (3072^2, K = 4: 2223 workgroups of 18 columns 0.080 ms, 1664 of 24 columns 0.067 ms; 2048^2: 2052 of
+    // 9 columns 0.045, 1539 of 12 columns 0.042); longer ones leave SIMDs idle and load 2K - 2 extra columns for less (4096^2, K = 4:
+    // 36 columns 0.104, 42 columns 0.112, 72 columns 0.170 ms).  The K = 2 / 3 instances could hold 4 / 3 waves per SIMD, but two already
+    // cover the latency: 4096^2, K = 2 with the sums: 36 columns 0.101-0.127 ms between boxes, 18 columns 0.112-0.140.  Images past
+    // 2048 workgroups of 72 columns (8192^2) run several rounds whatever the length: 72 (K = 2: 0.457 against 0.503 ms at 36).
+    static const int fill = iterk_override("PROST_ITERK_FILL_WAVES", 2);
+    const size_t slots = 256 * 4 * (size_t)(iterk_waves(K) < fill ? iterk_waves(K) : fill);
+    cols = 72;
+    for (int c : {2, 3, 4, 6, 9, 12, 18, 24, 30, 36, 42, 48, 60, 72}) if (strips * ((d->nx + c - 1) / c) <= slots) { cols = c; break; }
     static const char* const names[] = {"", "PROST_ITERK1_COLS", "PROST_ITERK2_COLS", "PROST_ITERK3_COLS", "PROST_ITERK4_COLS", "PROST_ITERK5_COLS", "PROST_ITERK6_COLS"};
     cols = iterk_override(names[K], cols);
   }

@@ -766,11 +766,148 @@ __global__ void __launch_bounds__(kBlock) kron_spmv_kernel(T* __restrict__ res, 
   }
 }
 
+// kron(K, I_d), 16 bytes per lane (round 6; the kernel above: 0.18 of the HBM peak on compulsory bytes at K 12 x 16, d = 2^20 -- a 64-bit
+// division per element, 4-byte accesses, and every operand segment re-read from memory once per row that refers to it).  A lane owns V
+// consecutive offsets o of the identity and walks the rows of a row chunk (blockIdx.y): K's row is wave-uniform (scalar loads), the operand
+// segments of one row chunk are re-read by the SAME lanes shortly after one another (cache hits).  Per output the products are added in CSR
+// order into a sum that starts at zero, as above: bit-identical.
+template <class T, bool ACC>
+__global__ void __launch_bounds__(kBlock) kron_id_vec_kernel(T* __restrict__ res, const T* __restrict__ rhs, unsigned dvec, size_t diaglength,
+                                                             unsigned nrows, unsigned rows_per_chunk, const float* __restrict__ val,
+                                                             const int32_t* __restrict__ ptr, const int32_t* __restrict__ ind) {
+  constexpr int V = 16 / sizeof(T);
+  typedef T TV __attribute__((ext_vector_type(V)));
+  const PROST_CONSTANT float* cval = as_constant(val);
+  const PROST_CONSTANT int32_t* cptr = as_constant(ptr);
+  const PROST_CONSTANT int32_t* cind = as_constant(ind);
+  const unsigned r0 = blockIdx.y * rows_per_chunk, r1 = r0 + rows_per_chunk < nrows ? r0 + rows_per_chunk : nrows;
+  for (unsigned ov = blockIdx.x * kBlock + threadIdx.x; ov < dvec; ov += gridDim.x * kBlock) {
+    const size_t o = (size_t)ov * V;
+    int32_t i = cptr[r0];
+    for (unsigned r = r0; r < r1; r++) {
+      const int32_t stop = cptr[r + 1];
+      T sum[V];
+#pragma unroll
+      for (int j = 0; j < V; j++) sum[j] = 0;
+      for (; i < stop; i++) {
+        const T v = (T)cval[i];
+        const TV xv = *reinterpret_cast<const TV*>(rhs + (size_t)cind[i] * diaglength + o);
+#pragma unroll
+        for (int j = 0; j < V; j++) sum[j] += v * xv[j];
+      }
+      TV* out = reinterpret_cast<TV*>(res + (size_t)r * diaglength + o);
+      TV t;
+      if (ACC) t = *out;
+#pragma unroll
+      for (int j = 0; j < V; j++) t[j] = (ACC ? t[j] : (T)0) + sum[j];
+      *out = t;
+    }
+  }
+}
+
+// kron(I_d, K) through LDS (round 6; the kernel above: 0.15 of the HBM peak at K 12 x 16 -- per-lane chains ptr -> ind / val -> operand through
+// memory, a 64-bit division per element, 4-byte gathers).  A workgroup takes kCopies consecutive copies of K at a time: their operand range
+// [j0 ncols, (j0 + kCopies) ncols) and their output range are CONTIGUOUS, so the operands enter LDS with 16-byte loads and every lane
+// writes V consecutive outputs; K itself (ptr, ind, val) is staged in LDS once per workgroup when it fits (kKronMaxNnz / kKronMaxRows), else
+// read through the constant address space.  Same products in the same order per output: bit-identical.
+constexpr int kKronTile = 4096;        // operand elements per tile (16 KB fp32, 32 KB fp64)
+constexpr int kKronMaxNnz = 2048;
+constexpr int kKronMaxRows = 1024;
+template <class T, bool ACC>
+__global__ void __launch_bounds__(kBlock) id_kron_lds_kernel(T* __restrict__ res, const T* __restrict__ rhs, size_t diaglength, unsigned nrows,
+                                                             unsigned ncols, unsigned copies, const float* __restrict__ val,
+                                                             const int32_t* __restrict__ ptr, const int32_t* __restrict__ ind) {
+  constexpr int V = 16 / sizeof(T);
+  typedef T TV __attribute__((ext_vector_type(V)));
+  __shared__ __attribute__((aligned(16))) T s_rhs[kKronTile];
+  __shared__ float s_val[kKronMaxNnz];
+  __shared__ int32_t s_ind[kKronMaxNnz];
+  __shared__ int32_t s_ptr[kKronMaxRows + 1];
+  const PROST_CONSTANT float* cval = as_constant(val);
+  const PROST_CONSTANT int32_t* cptr = as_constant(ptr);
+  const PROST_CONSTANT int32_t* cind = as_constant(ind);
+  const int32_t nnz = cptr[nrows];
+  const bool staged = nnz <= kKronMaxNnz;                                       // workgroup-uniform
+  for (unsigned k = threadIdx.x; k <= nrows; k += kBlock) s_ptr[k] = cptr[k];
+  if (staged)
+    for (int32_t k = threadIdx.x; k < nnz; k += kBlock) { s_val[k] = cval[k]; s_ind[k] = cind[k]; }
+  // the V outputs of a lane within a tile: t = V (threadIdx.x + kBlock k) + e  ->  copy t / nrows, row t % nrows, advanced without divisions
+  const unsigned step_q = (V * kBlock) / nrows, step_m = (V * kBlock) % nrows;
+  const unsigned q0 = (V * threadIdx.x) / nrows, m0 = (V * threadIdx.x) % nrows;
+  const size_t tiles = (diaglength + copies - 1) / copies;
+  for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const size_t j0 = tile * copies;
+    const unsigned nc = diaglength - j0 < copies ? (unsigned)(diaglength - j0) : copies;
+    const unsigned n_in = nc * ncols, n_out = nc * nrows;
+    const T* __restrict__ src = rhs + j0 * ncols;
+    T* __restrict__ dst = res + j0 * nrows;
+    __syncthreads();                                                            // the previous tile's reads of s_rhs (and the staging of K)
+    for (unsigned k = V * threadIdx.x; k < n_in; k += V * kBlock) {
+      if (k + V <= n_in) *reinterpret_cast<TV*>(s_rhs + k) = *reinterpret_cast<const TV*>(src + k);
+      else for (unsigned e = k; e < n_in; e++) s_rhs[e] = src[e];
+    }
+    __syncthreads();
+    unsigned q = q0, m = m0;
+    for (unsigned t = V * threadIdx.x; t < n_out; t += V * kBlock) {
+      T sum[V];
+      unsigned qe = q, me = m;
+#pragma unroll
+      for (int e = 0; e < V; e++) {
+        sum[e] = 0;
+        if (t + e < n_out) {
+          const T* __restrict__ xs = s_rhs + qe * ncols;
+          if (staged) { for (int32_t i = s_ptr[me], stop = s_ptr[me + 1]; i < stop; i++) sum[e] += (T)s_val[i] * xs[s_ind[i]]; }
+          else { for (int32_t i = s_ptr[me], stop = s_ptr[me + 1]; i < stop; i++) sum[e] += (T)cval[i] * xs[cind[i]]; }
+        }
+        if (++me == nrows) { me = 0; qe++; }
+      }
+      if (t + V <= n_out) {
+        TV* out = reinterpret_cast<TV*>(dst + t);
+        TV o;
+        if (ACC) o = *out;
+#pragma unroll
+        for (int e = 0; e < V; e++) o[e] = (ACC ? o[e] : (T)0) + sum[e];
+        *out = o;
+      } else {
+        for (unsigned e = 0; t + e < n_out; e++) dst[t + e] = (ACC ? dst[t + e] : (T)0) + sum[e];
+      }
+      q += step_q; m += step_m;
+      if (m >= nrows) { m -= nrows; q++; }
+    }
+  }
+}
+
 template <class T>
 static int launch_kron(bool id_first, T* res, const T* rhs, size_t diaglength, size_t nrows, size_t ncols, const float* val, const int32_t* ptr,
                        const int32_t* ind, void* stream, bool acc = true) {
   const size_t total = diaglength * nrows;
   if (total == 0) return 0;
+  constexpr size_t V = 16 / sizeof(T);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(rhs)) & 15u) == 0;
+  static const bool plain_only = getenv("PROST_KRON_PLAIN") != nullptr;       // A/B switch (tools/bench_kernels.py)
+  if (!plain_only && !id_first && aligned && diaglength % V == 0 && diaglength / V < (1u << 31) && nrows < (1u << 31)) {
+    const unsigned dvec = (unsigned)(diaglength / V);
+    const unsigned gx = grid_for(dvec);
+    // enough workgroups to fill the chip when the identity is short: the rows are cut into chunks (blockIdx.y)
+    unsigned gy = gx >= 2048u ? 1u : (2048u + gx - 1) / gx;
+    if (gy > nrows) gy = (unsigned)nrows;
+    if (gy > 65535u) gy = 65535u;
+    const unsigned rpc = (unsigned)((nrows + gy - 1) / gy);
+    gy = (unsigned)((nrows + rpc - 1) / rpc);
+    if (acc) hipLaunchKernelGGL((kron_id_vec_kernel<T, true>), dim3(gx, gy), dim3(kBlock), 0, as_stream(stream), res, rhs, dvec, diaglength, (unsigned)nrows, rpc, val, ptr, ind);
+    else hipLaunchKernelGGL((kron_id_vec_kernel<T, false>), dim3(gx, gy), dim3(kBlock), 0, as_stream(stream), res, rhs, dvec, diaglength, (unsigned)nrows, rpc, val, ptr, ind);
+    PH_LAUNCH_END("kronecker spmv kernel (identity last, 16 bytes per lane)");
+  }
+  const size_t widest = nrows > ncols ? nrows : ncols;
+  if (!plain_only && id_first && aligned && nrows >= 1 && ncols >= 1 && widest <= (size_t)kKronMaxRows) {
+    // copies per tile: a multiple of 4 (tile starts stay 16-byte aligned whatever nrows / ncols are) that fills the operand tile
+    const unsigned copies = (unsigned)((size_t)kKronTile / widest) & ~3u;
+    const size_t tiles = (diaglength + copies - 1) / copies;
+    const unsigned grid = (unsigned)(tiles < (size_t)kMaxGridStride ? tiles : (size_t)kMaxGridStride);
+    if (acc) hipLaunchKernelGGL((id_kron_lds_kernel<T, true>), dim3(grid), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, (unsigned)nrows, (unsigned)ncols, copies, val, ptr, ind);
+    else hipLaunchKernelGGL((id_kron_lds_kernel<T, false>), dim3(grid), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, (unsigned)nrows, (unsigned)ncols, copies, val, ptr, ind);
+    PH_LAUNCH_END("kronecker spmv kernel (identity first, LDS tiles)");
+  }
   if (id_first && acc) hipLaunchKernelGGL((kron_spmv_kernel<T, true, true>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
   else if (id_first) hipLaunchKernelGGL((kron_spmv_kernel<T, true, false>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);
   else if (acc) hipLaunchKernelGGL((kron_spmv_kernel<T, false, true>), dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, nrows, ncols, val, ptr, ind);

@@ -149,7 +149,11 @@ def test_kronecker_blocks(prec, dtype, name):
     import scipy.sparse as sp
     prost.set_precision(prec)
     rng = np.random.default_rng(32)
-    for (diaglength, nrows, ncols, dens) in ((64 * 12, 81, 64, 0.01), (5, 3, 4, 0.6), (1, 9, 7, 0.3), (700, 2, 2, 1.0)):
+    # (the last five: 16 bytes per lane with a ragged last tile; K too large for the LDS copy of its arrays (3000 non-zeros), then for the
+    #  tiled kernel altogether (1100 rows); a single row; an identity shorter than a vector)
+    shapes = ((64 * 12, 81, 64, 0.01), (5, 3, 4, 0.6), (1, 9, 7, 0.3), (700, 2, 2, 1.0), (4100, 5, 3, 0.5), (40, 300, 200, 0.05), (8, 1100, 30, 0.01),
+              (1028, 1, 6, 0.7), (2, 12, 16, 0.2))
+    for (diaglength, nrows, ncols, dens) in shapes:
         K_mat = sp.random(nrows, ncols, dens, random_state=5, format="csc")
         bf = getattr(prost.block, name)(K_mat, diaglength)
         m, n = nrows * diaglength, ncols * diaglength

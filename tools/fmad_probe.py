@@ -178,9 +178,9 @@ def main_k(N=4096, iters=200):
         ms = C.c_float(); hip.check(L_.prost_hip_event_elapsed_ms(ev[0], ev[1], C.byref(ms)))
         return ms.value / iters
     reset()
-    for k in [k for k in (2, 3, 4, 5, 6) if k <= kmax]:
+    for k in [k for k in (int(c) for c in os.environ.get("PROBE_KS", "2,3,4,5,6").split(",")) if k <= kmax]:
         for mode in (0, 2):
-            for cols in (0, 18, 24, 30, 36, 42, 48, 72):
+            for cols in tuple(int(c) for c in os.environ.get("PROBE_COLS", "0,18,24,30,36,42,48,72").split(",")):
                 def runk(cnt):
                     for i in range(cnt):
                         a, b = i % 2, (i + 1) % 2
