@@ -835,18 +835,36 @@ __global__ void __launch_bounds__(kBlock) id_kron_lds_kernel(T* __restrict__ res
   const unsigned step_q = (V * kBlock) / nrows, step_m = (V * kBlock) % nrows;
   const unsigned q0 = (V * threadIdx.x) / nrows, m0 = (V * threadIdx.x) % nrows;
   const size_t tiles = (diaglength + copies - 1) / copies;
+  // the operands of a tile travel global -> registers -> LDS, and the loads of the NEXT tile are issued before the products of the current
+  // one, so they are in flight during them (loaded, then computed with nothing in flight: 0.34 of the HBM peak at S 12 x 16)
+  constexpr int NP = kKronTile / (V * kBlock);
+  TV pre[NP];
+  auto fetch = [&](size_t tl) {
+    const size_t j0 = tl * copies;
+    const unsigned nc = diaglength - j0 < copies ? (unsigned)(diaglength - j0) : copies;
+    const unsigned n_in = nc * ncols;
+    const T* __restrict__ src = rhs + j0 * ncols;
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const unsigned k = V * (threadIdx.x + p * kBlock);
+      if (k + V <= n_in) pre[p] = *reinterpret_cast<const TV*>(src + k);
+      else {
+#pragma unroll
+        for (int e = 0; e < V; e++) pre[p][e] = k + e < n_in ? src[k + e] : (T)0;
+      }
+    }
+  };
+  if (blockIdx.x < tiles) fetch(blockIdx.x);
   for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const size_t j0 = tile * copies;
     const unsigned nc = diaglength - j0 < copies ? (unsigned)(diaglength - j0) : copies;
-    const unsigned n_in = nc * ncols, n_out = nc * nrows;
-    const T* __restrict__ src = rhs + j0 * ncols;
+    const unsigned n_out = nc * nrows;
     T* __restrict__ dst = res + j0 * nrows;
     __syncthreads();                                                            // the previous tile's reads of s_rhs (and the staging of K)
-    for (unsigned k = V * threadIdx.x; k < n_in; k += V * kBlock) {
-      if (k + V <= n_in) *reinterpret_cast<TV*>(s_rhs + k) = *reinterpret_cast<const TV*>(src + k);
-      else for (unsigned e = k; e < n_in; e++) s_rhs[e] = src[e];
-    }
+#pragma unroll
+    for (int p = 0; p < NP; p++) *reinterpret_cast<TV*>(s_rhs + V * (threadIdx.x + p * kBlock)) = pre[p];
     __syncthreads();
+    if (tile + gridDim.x < tiles) fetch(tile + gridDim.x);
     unsigned q = q0, m = m0;
     for (unsigned t = V * threadIdx.x; t < n_out; t += V * kBlock) {
       T sum[V];
@@ -903,7 +921,7 @@ static int launch_kron(bool id_first, T* res, const T* rhs, size_t diaglength, s
     // copies per tile: a multiple of 4 (tile starts stay 16-byte aligned whatever nrows / ncols are) that fills the operand tile
     const unsigned copies = (unsigned)((size_t)kKronTile / widest) & ~3u;
     const size_t tiles = (diaglength + copies - 1) / copies;
-    const unsigned grid = (unsigned)(tiles < (size_t)kMaxGridStride ? tiles : (size_t)kMaxGridStride);
+    const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);       // resident workgroups (4 per CU) that walk the tiles, the next one's loads in flight
     if (acc) hipLaunchKernelGGL((id_kron_lds_kernel<T, true>), dim3(grid), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, (unsigned)nrows, (unsigned)ncols, copies, val, ptr, ind);
     else hipLaunchKernelGGL((id_kron_lds_kernel<T, false>), dim3(grid), dim3(kBlock), 0, as_stream(stream), res, rhs, diaglength, (unsigned)nrows, (unsigned)ncols, copies, val, ptr, ind);
     PH_LAUNCH_END("kronecker spmv kernel (identity first, LDS tiles)");

@@ -32,7 +32,7 @@ import prost_amd as prost
 from prost_amd import synthetic
 
 HEIGHTS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 30, 62, 63, 64, 66, 124, 126, 128, 130, 247, 248, 249, 250, 252, 253, 256, 260, 496, 500, 504, 508, 510, 1000, 1028]
-NOT_ORACLE = ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_single_kernel", "allow_device_rules", "allow_op_fusion", "pixel_rounds", "residual_sums_in_prox")
+NOT_ORACLE = ("allow_fused", "device_cg", "allow_arg_fusion", "cg_graph", "fused_rounds", "allow_speculation", "allow_pair_kernel", "allow_single_kernel", "allow_device_rules", "allow_op_fusion", "pixel_rounds", "residual_sums_in_prox", "group_max")
 
 
 def draw(rng):
@@ -529,7 +529,10 @@ def main():
             b[1]["allow_op_fusion"] = int(r5.choice([0, 0, 2, 2]))
             b[1]["residual_sums_in_prox"] = int(r5.choice([0, 1, 2, 2]))
             b[1]["allow_device_rules"] = bool(r5.random() < 0.7)
-        product_only = {k: b[1][k] for k in ("pixel_rounds", "allow_op_fusion", "residual_sums_in_prox", "allow_device_rules") if k in b[1]}
+            # round 6: up to four iterations per launch in the EXACT class (kernels_fused_iterk.hip with the exact forms; the shapes it does not
+            # take keep their pair / single launches): every partition of the iterations must give the oracle's iterates bit for bit
+            b[1]["group_max"] = int(r5.choice([1, 1, 2, 3, 4]))
+        product_only = {k: b[1][k] for k in ("pixel_rounds", "allow_op_fusion", "residual_sums_in_prox", "allow_device_rules", "group_max") if k in b[1]}
         c["product_only"] = product_only
         try:
             prob = build(c) if args.mode == "fused" else build_generic(c)
