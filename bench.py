@@ -222,6 +222,10 @@ def c4_values(table, name, w_nnz=2):
     v = table.get(name)
     if v is None:
         return None
+    if name.startswith("cg_pixel") and w_nnz != 2:
+        # a general CSR W on the two-launch rounds (round 6): its values and column indices + the row starts of W (launch A: one per pixel) or of
+        # W^T (launch B: one per primal entry, two per pixel); the operands gathered at displaced pixels are re-reads of vectors counted once
+        return (v[0] - 2 + w_nnz, w_nnz + (1 if "pq" in name else 2))
     extra = (w_nnz - 2) if v[1] > 0 else 0
     return (v[0] + extra, v[1] + extra)
 
@@ -239,9 +243,7 @@ def c4_iteration_bytes(path, cg_rounds, n_px, itemsize=4, w_nnz=2):
     words = lambda t: t[0] * itemsize + t[1] * 4
     outer = sum(words(c4_values(C4_OUTER_VALUES, k, w_nnz)) for k in C4_OUTER_VALUES)
     if path == "admm:pixel-op":
-        if w_nnz != 2:
-            return None
-        rnd = words(C4_KERNEL_VALUES["cg_pixel_pq_kernel"]) + words(C4_KERNEL_VALUES["cg_pixel_xrs_kernel"])
+        rnd = words(c4_values(C4_KERNEL_VALUES, "cg_pixel_pq_kernel", w_nnz)) + words(c4_values(C4_KERNEL_VALUES, "cg_pixel_xrs_kernel", w_nnz))
         first = rnd - 4 * itemsize                                  # the first launch A of a solve reads no s and writes no p
     elif path == "admm:fused-op":
         rnd = sum(words(c4_values(C4_KERNEL_VALUES, k, w_nnz)) for k in ("op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"))

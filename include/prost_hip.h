@@ -39,8 +39,9 @@ extern "C" {
  * 8: prost_hip_op_block gained anchor / anchor_t (appended; they must be NULL unless ids / ids_t are set -- callers that filled the old
  *    layout must zero them); additions: pattern_spmv_anchored_*, pdhg_record_view, the non-accumulating Kronecker entry points
  * 9: prost_hip_fused_desc gained arith (appended; callers that filled the old layout must zero it = PROST_HIP_ARITH_EXACT);
- *    additions: fused_iteration2_arith, fused_iteration_mc_x2_arith, fused_iteration3d_x2_arith */
-#define PROST_HIP_ABI_VERSION 9
+ *    additions: fused_iteration2_arith, fused_iteration_mc_x2_arith, fused_iteration3d_x2_arith, fused_iterationk_* (K iterations per launch)
+ * 10: prost_hip_pixel_op gained d_csr and the CSR arrays of D and D^T (appended; callers that filled the old layout must zero them) */
+#define PROST_HIP_ABI_VERSION 10
 
 /* ------------------------------------------------------------------------------------------ */
 /* runtime plumbing (replaces cudaSetDevice/cudaDeviceReset/thrust::device_vector allocation:  */
@@ -805,6 +806,14 @@ typedef struct prost_hip_pixel_op {
   void* p_alt; void* r_alt; /* second buffers for p (n elements) and r (m elements) */
   double sigma_grad;        /* Sigma on the gradient rows: ONE value (the caller checks that d->sigma is constant there; a gradient
                              * block's row sums are, block_gradient2d.cu:154-158) -- d->sigma is read on D's rows only */
+  /* ABI 10: D as ANY CSR block of nx ny rows over the L nx ny primal entries (block_sparse.cu:146-211: a warp matrix whose rows gather at
+   * displaced pixels).  d_csr = 1 (with has_d = 1): the rows of D come from d_val / d_ptr / d_ind, its columns from the CSR arrays of D^T
+   * (values of the solve's type, 32-bit indices, device memory; w is not read).  The thread that owns a pixel owns D's row of that pixel
+   * and the L primal entries of that pixel; the operand of every entry -- sqrt(Tau) p, sqrt(Sigma) r of ANOTHER pixel, updated in this
+   * very launch -- is recomputed from that pixel's stored operands.  Same expressions in the same order as the four-launch round. */
+  int d_csr;
+  const void* d_val; const int32_t* d_ptr; const int32_t* d_ind;
+  const void* dt_val; const int32_t* dt_ptr; const int32_t* dt_ind;
 } prost_hip_pixel_op;
 /* 1 if the two-launch rounds take this operator (host-only check); dtype 0: fp32 (ny % 4 == 0), 1: fp64 (ny % 2 == 0) */
 int prost_hip_pixel_op_supported(const prost_hip_pixel_op* op, uint64_t m, uint64_t n, int dtype);

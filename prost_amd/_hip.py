@@ -78,8 +78,8 @@ def lib():
                            "(or make -C prost_amd/csrc)" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.prost_hip_last_error.restype = C.c_char_p
-        if L.prost_hip_abi_version() != 9:
-            raise HipError("libprost_hip.so has ABI version %d, this binding needs 9: rebuild (make -C prost_amd/csrc)" % L.prost_hip_abi_version())
+        if L.prost_hip_abi_version() != 10:
+            raise HipError("libprost_hip.so has ABI version %d, this binding needs 10: rebuild (make -C prost_amd/csrc)" % L.prost_hip_abi_version())
         L.prost_hip_reduce_workspace_bytes.restype = C.c_size_t
         L.prost_hip_cgls_state_bytes.restype = C.c_size_t
         L.prost_hip_cgls_workspace_bytes.restype = C.c_size_t

@@ -212,12 +212,16 @@ __device__ __forceinline__ OpHead op_head(const PROST_CONSTANT OpBlockDev& B) {
   return h;
 }
 
-template <class T, int VEC, int NR>
+// ZERO = false: kv holds the vector the product is ADDED to (LinearOperator::Eval with accumulate: EvalAdd per block, in block order, onto
+// what is there -- (v + K_1 t) + K_2 t, not v + (K_1 t + K_2 t): the two differ in the last place where two blocks share rows)
+template <class T, int VEC, int NR, bool ZERO = true>
 __device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& op, size_t i, size_t w0, const T* const (&t)[NR], T (&kv)[NR][VEC], bool lanes_in_step = true) {
+  if (ZERO) {
 #pragma unroll
-  for (int q = 0; q < NR; q++)
+    for (int q = 0; q < NR; q++)
 #pragma unroll
-    for (int j = 0; j < VEC; j++) kv[q][j] = 0;
+      for (int j = 0; j < VEC; j++) kv[q][j] = 0;
+  }
   for (int b = 0; b < op.nblocks; b++) {
     const PROST_CONSTANT OpBlockDev& B = op.b[b];
     const OpHead H = op_head<false>(B);
@@ -279,11 +283,15 @@ __device__ __forceinline__ void op_fwd_rows_n(const PROST_CONSTANT FusedOpDev& o
     }
   }
 }
-template <class T, int VEC>
+template <class T, int VEC, bool ZERO = true>
 __device__ __forceinline__ void op_fwd_rows(const PROST_CONSTANT FusedOpDev& op, size_t i, size_t w0, const T* __restrict__ t, T (&kv)[VEC], bool lanes_in_step = true) {
   const T* tt[1] = {t};
   T k1[1][VEC];
-  op_fwd_rows_n<T, VEC, 1>(op, i, w0, tt, k1, lanes_in_step);
+  if (!ZERO) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) k1[0][j] = kv[j];
+  }
+  op_fwd_rows_n<T, VEC, 1, ZERO>(op, i, w0, tt, k1, lanes_in_step);
 #pragma unroll
   for (int j = 0; j < VEC; j++) kv[j] = k1[0][j];
 }

@@ -3,6 +3,7 @@
 // cuBLAS nrm2/axpy and thrust functors are the prost_hip_nrm2 / _axpy / _admm_elem kernels).
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <cmath>
 #include <limits>
 
@@ -204,15 +205,25 @@ void BackendADMM<T>::DescribeOperator() {
     blocks[i]->describe(bd);
     if (op.block[i].kind == PROST_OP_GRAD2D && !grad) grad = &op.block[i];
     else if (op.block[i].kind == PROST_OP_CSR && bd.pointwise_planes > 0 && bd.val && !dblk) { dblk = &op.block[i]; planes = bd.pointwise_planes; }
+    // round 6: any CSR block with one row per pixel (a warp matrix that gathers at displaced pixels) -- both directions as plain CSR arrays
+    else if (op.block[i].kind == PROST_OP_CSR && bd.val && bd.ptr && bd.ind && bd.val_t && bd.ptr_t && bd.ind_t && !dblk) { dblk = &op.block[i]; planes = 0; }
     else return;
   }
   if (!grad || grad->col != 0 || grad->L < 1 || grad->L > 3) return;
   prost_hip_pixel_op po;
+  std::memset(&po, 0, sizeof(po));
   po.nx = grad->nx; po.ny = grad->ny; po.L = (int)grad->L; po.has_d = dblk ? 1 : 0;
   po.d_first = dblk && dblk < grad ? 1 : 0;                 // position in the block LIST (the order K^T t is accumulated in)
   po.g_row = grad->row; po.d_row = dblk ? dblk->row : 0; po.w = dblk ? dblk->val : nullptr;
   po.p_alt = po.r_alt = nullptr;
-  if (dblk && (dblk->col != 0 || planes != grad->L || dblk->nrows != grad->nx * grad->ny)) return;
+  if (dblk && (dblk->col != 0 || dblk->nrows != grad->nx * grad->ny)) return;
+  if (dblk && planes == 0) {
+    if (dblk->ncols != grad->L * grad->nx * grad->ny) return;
+    po.d_csr = 1; po.w = nullptr;
+    po.d_val = dblk->val; po.d_ptr = dblk->ptr; po.d_ind = dblk->ind; po.dt_val = dblk->val_t; po.dt_ptr = dblk->ptr_t; po.dt_ind = dblk->ind_t;
+  } else if (dblk && planes != grad->L) {
+    return;
+  }
   // Sigma must be ONE value on the gradient rows (it is for the alpha-preconditioners: every row of a gradient block sums to 2,
   // block_gradient2d.cu:154-158; user-supplied scaling vectors may differ): the rounds read it as a scalar
   {

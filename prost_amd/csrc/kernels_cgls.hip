@@ -658,6 +658,7 @@ __global__ void __launch_bounds__(kBlock) op_stage_kernel(const FusedOpDev* __re
     T kv[VEC];
     if (VEC > 1 || i < count) {
       if constexpr (ADJ) { e.template init<VEC>(i, kv); op_adj_cols<T, VEC>(op, i, i0 * VEC, in, kv); }
+      else if constexpr (E::kFwdInit) { e.template init<VEC>(i, kv); op_fwd_rows<T, VEC, false>(op, i, i0 * VEC, in, kv); }
       else op_fwd_rows<T, VEC>(op, i, i0 * VEC, in, kv);
       e.template apply<VEC>(i, kv, sa, sb);
     }
@@ -666,6 +667,7 @@ __global__ void __launch_bounds__(kBlock) op_stage_kernel(const FusedOpDev* __re
     for (size_t i = nv * VEC + (size_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (size_t)gridDim.x * kBlock) {
       T kv[1];
       if constexpr (ADJ) { e.template init<1>(i, kv); op_adj_cols<T, 1>(op, i, i, in, kv); }
+      else if constexpr (E::kFwdInit) { e.template init<1>(i, kv); op_fwd_rows<T, 1, false>(op, i, i, in, kv); }
       else op_fwd_rows<T, 1>(op, i, i, in, kv);
       e.template apply<1>(i, kv, sa, sb);
     }
@@ -686,6 +688,7 @@ __global__ void __launch_bounds__(kBlock) op_stage_kernel(const FusedOpDev* __re
 // ---- epilogues (the stage structs above, fed with the product instead of reading it back) ----
 // FWD_Q (m):  q = 1 sqrt(Sigma) (K t);  |q|^2                                   [K->Eval(q, t, 0) ; STEP_Q]
 template <class T> struct EpiFwdQ {
+  static constexpr bool kFwdInit = false;
   static constexpr bool kPairs = false;
   static constexpr bool kSkipWhenDone = true;
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
@@ -702,6 +705,7 @@ template <class T> struct EpiFwdQ {
 // ADJ_S (n):  s = 1 sqrt(Tau) (s0 + K^T t) with s0 = (-shift / (1 sqrt(Tau))) x formed here (STEP_XR's expression: the vector
 //             STEP_XR would write and this kernel read back);  |s|^2            [K->EvalAdjoint(s, t, 1) ; STEP_S]
 template <class T> struct EpiAdjS {
+  static constexpr bool kFwdInit = false;
   static constexpr bool kPairs = false;
   static constexpr bool kSkipWhenDone = true;
   static constexpr int kRegion = kRegionS, kRegion2 = -1;
@@ -723,20 +727,27 @@ template <class T> struct EpiAdjS {
 };
 // INIT_RK (m):  r = (1 / (-1 sqrt(Sigma))) b ; r += K t ; r = normx > 0 ? -1 sqrt(Sigma) r : b ; tm = sqrt(Sigma) r
 //               [INIT_R ; K->Eval(r, t, 1) ; INIT_R2 -- tm goes to its own buffer: t is being read by other threads]
+// (the product is ADDED to r block by block, in block order -- kFwdInit: the rows start from INIT_R's value, not from zero)
 template <class T> struct EpiInitRK {
+  static constexpr bool kFwdInit = true;
   static constexpr bool kPairs = false;
   static constexpr bool kSkipWhenDone = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* b; const T* sigma; T* r; T* tm; bool nonzero;
   __device__ void prologue(const CgState* st, double*) { nonzero = st->normx > 0.; }
+  template <int V> __device__ void init(size_t i, T (&v)[V]) const {
+    T bv[V], dv[V];
+    ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv);
+#pragma unroll
+    for (int j = 0; j < V; j++) v[j] = ((T)1 / ((T)-1 * t_sqrt(dv[j]))) * bv[j];
+  }
   template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t&, dd_t&) const {
     T bv[V], dv[V], rv[V], tv[V];
     ldv<T, V>(b + i, bv); ldv<T, V>(sigma + i, dv);
 #pragma unroll
     for (int j = 0; j < V; j++) {
       const T sq = t_sqrt(dv[j]);
-      T rr = ((T)1 / ((T)-1 * sq)) * bv[j];
-      rr = rr + kv[j];
+      T rr = kv[j];
       rr = nonzero ? (T)-1 * sq * rr : bv[j];
       rv[j] = rr;
       tv[j] = sq * rr;
@@ -746,6 +757,7 @@ template <class T> struct EpiInitRK {
 };
 // INIT_SK (n):  s = 1 sqrt(Tau) (s + K^T tm) ; p = s ; t = sqrt(Tau) p ; |s|^2 = |p|^2       [K->EvalAdjoint(s, tm, 1) ; INIT_S]
 template <class T> struct EpiInitSK {
+  static constexpr bool kFwdInit = false;
   static constexpr bool kPairs = false;
   static constexpr bool kSkipWhenDone = false;
   static constexpr int kRegion = kRegionS, kRegion2 = kRegionP;
@@ -768,11 +780,21 @@ template <class T> struct EpiInitSK {
 // PRE_ZK (m):  temp2 = sqrt(Sigma) (z_half + z_dual) ; z_dual = (1 / (-1 sqrt(Sigma))) temp2 ; z_dual += K temp3 ;
 //              z_dual = -1 sqrt(Sigma) z_dual                                    [PRE_Z ; K->Eval(z_dual, temp3, 1) ; PRE_Z2]
 template <class T> struct EpiPreZK {
+  static constexpr bool kFwdInit = true;             // the product is added to PRE_Z's z_dual block by block
   static constexpr bool kPairs = false;
   static constexpr bool kSkipWhenDone = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
   const T* z_half; T* z_dual; const T* sigma; T* temp2;
   __device__ void prologue(const CgState*, double*) {}
+  template <int V> __device__ void init(size_t i, T (&v)[V]) const {
+    T a[V], bb[V], d[V];
+    ldv<T, V>(z_half + i, a); ldv<T, V>(z_dual + i, bb); ldv<T, V>(sigma + i, d);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const T sq = t_sqrt(d[j]);
+      v[j] = ((T)1 / ((T)-1 * sq)) * (sq * (a[j] + bb[j]));
+    }
+  }
   template <int V> __device__ void apply(size_t i, const T (&kv)[V], dd_t&, dd_t&) const {
     T a[V], bb[V], d[V], o[V], z[V];
     ldv<T, V>(z_half + i, a); ldv<T, V>(z_dual + i, bb); ldv<T, V>(sigma + i, d);
@@ -780,9 +802,7 @@ template <class T> struct EpiPreZK {
     for (int j = 0; j < V; j++) {
       const T sq = t_sqrt(d[j]);
       o[j] = sq * (a[j] + bb[j]);
-      T zz = ((T)1 / ((T)-1 * sq)) * o[j];
-      zz = zz + kv[j];
-      z[j] = (T)-1 * sq * zz;
+      z[j] = (T)-1 * sq * kv[j];
     }
     stv<T, V>(temp2 + i, o); stv<T, V>(z_dual + i, z);
   }
@@ -790,6 +810,7 @@ template <class T> struct EpiPreZK {
 // POST_ZK (m):  z_proj = K x_proj ; z_dual = temp2 / sqrt(Sigma) - z_proj ; temp2 = z_proj - z_dual
 //               [K->Eval(z_proj, x_proj) ; the m half of POST_XZ]
 template <class T> struct EpiPostZK {
+  static constexpr bool kFwdInit = false;
   static constexpr bool kPairs = false;
   static constexpr bool kSkipWhenDone = false;
   static constexpr int kRegion = -1, kRegion2 = -1;
@@ -829,6 +850,7 @@ template <class T> struct AdmmPostX2 {
 };
 // RES_ZK (m):  kx = K x_half ; RES_Z (primal residual / variable norm sums; y = get_dual(...) stored in kx)
 template <class T> struct EpiResZK {
+  static constexpr bool kFwdInit = false;
   static constexpr bool kPairs = true;
   static constexpr bool kSkipWhenDone = false;
   static constexpr int kRegion = kRegionQ, kRegion2 = -1;
@@ -851,6 +873,7 @@ template <class T> struct EpiResZK {
 };
 // RES_XK (n):  kty = K^T y (not stored) ; RES_X (dual residual / variable norm sums)
 template <class T> struct EpiResXK {
+  static constexpr bool kFwdInit = false;
   static constexpr bool kPairs = true;
   static constexpr bool kSkipWhenDone = false;
   static constexpr int kRegion = kRegionP, kRegion2 = -1;
@@ -1165,6 +1188,10 @@ template <class T> struct PixArgs {
   size_t npx;                          // nx ny
   size_t d_row, g_row;                 // first row of the D block / of the gradient block
   const T* w;                          // D's values, row-major: w[i L + c] (the CSR value array of the block); nullptr-free when HAS_D
+  // D_CSR (round 6): D is ANY CSR block of nx ny rows over the L nx ny primal entries (a warp matrix that gathers at displaced pixels):
+  // its CSR arrays for the rows, those of D^T for the columns
+  const T* d_val; const int32_t* d_ptr; const int32_t* d_ind;
+  const T* dt_val; const int32_t* dt_ptr; const int32_t* dt_ind;
   const T* sigma; const T* tau;          // sigma: read on D's rows only
   T sig_g;                               // Sigma on the gradient rows: ONE value (a gradient block's row sums are constant, block_gradient2d.cu:154-158)
   T* x; const T* p_in; T* p_out; T* s; T* q; const T* r_in; T* r_out;
@@ -1186,7 +1213,40 @@ __device__ __forceinline__ PixGeom pix_geom(unsigned tiles, unsigned ny, size_t 
   return g;
 }
 
-template <class T, int L, bool HAS_D, bool D_FIRST, bool FIRST>
+// sum[j] = sum_k val[k] f(ind[k]) over the CSR rows row0 .. row0 + V - 1 of this lane, entries in order (csr_rows of fused_op.hpp with the
+// operand FORMED per entry: the vector the four-launch round would have stored is recomputed from its operands at the gathered position).
+// `whole` (wave-uniform: the wavefront's 64 V rows from wave0 on all exist): the lanes take the rows TRANSPOSED -- lane, lane + 64, ... --
+// so that neighbouring lanes read neighbouring row starts, entries and (for a warp) neighbouring gathered operands, and the sums are
+// shuffled back to the lanes that own the rows (csr_contrib's scheme).  Taking a lane's own V rows instead costs 4-8 cache lines per
+// lane and load: the first version of these instances ran launch A in 107 us at 1024^2 against 48 us for the two launches it replaces.
+template <class T, int V, class F>
+__device__ __forceinline__ void csr_rows_formed(const T* __restrict__ val, const int32_t* __restrict__ ptr, const int32_t* __restrict__ ind, size_t row0, size_t wave0,
+                                                bool whole, F f, T (&sum)[V]) {
+  const unsigned lane = threadIdx.x & (kWave - 1);
+  size_t r[V];
+#pragma unroll
+  for (int j = 0; j < V; j++) r[j] = whole ? wave0 + (size_t)j * kWave + lane : row0 + j;
+  int32_t b[V], e[V], len = 0;
+#pragma unroll
+  for (int j = 0; j < V; j++) { b[j] = ptr[r[j]]; e[j] = ptr[r[j] + 1]; }
+  T acc[V];
+#pragma unroll
+  for (int j = 0; j < V; j++) { acc[j] = 0; len = e[j] - b[j] > len ? e[j] - b[j] : len; }
+  for (int32_t st = 0; st < len; st++) {
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+      const int32_t k = b[j] + st;
+      if (k < e[j]) acc[j] += val[k] * f((size_t)ind[k]);
+    }
+  }
+  if (V > 1 && whole) wave_untranspose<T, V>(acc, sum, lane);
+  else {
+#pragma unroll
+    for (int j = 0; j < V; j++) sum[j] = acc[j];
+  }
+}
+
+template <class T, int L, bool HAS_D, bool D_FIRST, bool FIRST, bool D_CSR = false>
 __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_pq_kernel(PixArgs<T> a, const CgState* prev, CgState* cur, double* ws, RoundScalars sc) {
   constexpr int V = VecOf<T>::N;
   if (FIRST ? cur->done != 0 : prev->done != 0) {
@@ -1208,10 +1268,12 @@ __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_pq_kernel(P
     if (right) { ldv<T, V>(a.p_in + e + ny, pr[c]); ldv<T, V>(a.tau + e + ny, tr[c]); if (!FIRST) ldv<T, V>(a.s + e + ny, sr[c]); }
     if (below) { pb[c] = a.p_in[e + V]; tb[c] = a.tau[e + V]; if (!FIRST) sb_[c] = a.s[e + V]; }
   }
-  T wv[HAS_D ? V * L : 1], sgd[V];
+  T wv[HAS_D && !D_CSR ? V * L : 1], sgd[V];
   if (g.active && HAS_D) {
+    if constexpr (!D_CSR) {
 #pragma unroll
-    for (int k = 0; k < L; k++) ldv<T, V>(a.w + g.px0 * L + (size_t)k * V, *reinterpret_cast<T(*)[V]>(&wv[k * V]));
+      for (int k = 0; k < L; k++) ldv<T, V>(a.w + g.px0 * L + (size_t)k * V, *reinterpret_cast<T(*)[V]>(&wv[k * V]));
+    }
     ldv<T, V>(a.sigma + a.d_row + g.px0, sgd);
   }
   const T sqg = t_sqrt(a.sig_g);                       // sqrt(Sigma) of every gradient row
@@ -1258,12 +1320,24 @@ __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_pq_kernel(P
     }
     // OP_FWD<FwdQ>: the D row (csr_rows: entries in order), then the gradient rows (op_fwd_rows), each scaled by EpiFwdQ
     if (HAS_D) {
-      T qd[V];
+      T qd[V], dsum[V];
+      if constexpr (D_CSR) {
+        // t = sqrt(Tau) p at the gathered primal entry, p updated as above (STEP_P's expressions; the stored p of that entry is written by its owner)
+        const size_t wave0 = ((size_t)(g.px0 / V) - (threadIdx.x & (kWave - 1))) * V;          // first pixel of the wavefront
+        csr_rows_formed<T, V>(a.d_val, a.d_ptr, a.d_ind, g.px0, wave0, wave0 + (size_t)kWave * V <= a.npx, [&](size_t col) {
+          T pv = a.p_in[col];
+          if (!FIRST) pv = beta * pv + a.s[col];
+          return t_sqrt(a.tau[col]) * pv;
+        }, dsum);
+      }
 #pragma unroll
       for (int j = 0; j < V; j++) {
         T sum = 0;
+        if constexpr (D_CSR) sum = dsum[j];
+        else {
 #pragma unroll
-        for (int c = 0; c < L; c++) sum += wv[j * L + c] * t0[c][j];
+          for (int c = 0; c < L; c++) sum += wv[j * L + c] * t0[c][j];
+        }
         T kv = 0;
         kv = kv + sum;
         qd[j] = (T)1 * t_sqrt(sgd[j]) * kv;
@@ -1294,7 +1368,7 @@ __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_pq_kernel(P
   block_dd_store1(sp, region(ws, kRegionP), blockIdx.x);
 }
 
-template <class T, int L, bool HAS_D, bool D_FIRST>
+template <class T, int L, bool HAS_D, bool D_FIRST, bool D_CSR = false>
 __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_xrs_kernel(PixArgs<T> a, const CgState* cur, CgState* nxt, double* ws, RoundScalars sc) {
   constexpr int V = VecOf<T>::N;
   if (cur->done) return;
@@ -1306,7 +1380,7 @@ __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_xrs_kernel(
   T rd[V], qd[V], gd[V];
   T rx[L][V], qx[L][V], ry[L][V], qy[L][V], rl[L][V], ql[L][V], ra[L], qa[L];
   T xv[L][V], pv[L][V], tv[L][V];
-  T wv[HAS_D ? V * L : 1];
+  T wv[HAS_D && !D_CSR ? V * L : 1];
 #pragma unroll
   for (int j = 0; j < V; j++) { rd[j] = 0; qd[j] = 0; gd[j] = 1; }
 #pragma unroll
@@ -1319,8 +1393,10 @@ __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_xrs_kernel(
     if (HAS_D) {
       const size_t e = a.d_row + g.px0;
       ldv<T, V>(a.r_in + e, rd); ldv<T, V>(a.q + e, qd); ldv<T, V>(a.sigma + e, gd);
+      if constexpr (!D_CSR) {
 #pragma unroll
-      for (int k = 0; k < L; k++) ldv<T, V>(a.w + g.px0 * L + (size_t)k * V, *reinterpret_cast<T(*)[V]>(&wv[k * V]));
+        for (int k = 0; k < L; k++) ldv<T, V>(a.w + g.px0 * L + (size_t)k * V, *reinterpret_cast<T(*)[V]>(&wv[k * V]));
+      }
     }
 #pragma unroll
     for (int c = 0; c < L; c++) {
@@ -1370,7 +1446,15 @@ __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_xrs_kernel(
       stv<T, V>(a.r_out + a.g_row + (size_t)c * a.npx + g.px0, rx[c]);
       stv<T, V>(a.r_out + a.g_row + (size_t)(L + c) * a.npx + g.px0, ry[c]);
       // STEP_XR (n): x = alpha p + x ; OP_ADJ<AdjS>: v = s0 ; + D^T t ; - div t (blocks in operator order) ; s = 1 sqrt(Tau) v
-      T so[V];
+      T so[V], dcol[V];
+      if constexpr (HAS_D && D_CSR) {
+        // t = sqrt(Sigma) r at the gathered D row, r updated as above (STEP_XR's expressions; the stored r of that row is written by its owner)
+        const size_t wave0 = ((size_t)(g.px0 / V) - (threadIdx.x & (kWave - 1))) * V;          // first pixel of the wavefront
+        csr_rows_formed<T, V>(a.dt_val, a.dt_ptr, a.dt_ind, (size_t)c * a.npx + g.px0, (size_t)c * a.npx + wave0, wave0 + (size_t)kWave * V <= a.npx, [&](size_t row) {
+          const size_t e = a.d_row + row;
+          return t_sqrt(a.sigma[e]) * (neg_alpha * a.q[e] + a.r_in[e]);
+        }, dcol);
+      }
 #pragma unroll
       for (int j = 0; j < V; j++) {
         xv[c][j] = alpha * pv[c][j] + xv[c][j];
@@ -1378,7 +1462,8 @@ __global__ void __launch_bounds__(kBlock, (L <= 2 ? 4 : 2)) cg_pixel_xrs_kernel(
         const T sq = t_sqrt(tv[c][j]);
         T v = (a.negshift / ((T)1 * sq)) * xv[c][j];
         T dsum = 0;
-        if (HAS_D) dsum += wv[j * L + c] * td[j];
+        if constexpr (HAS_D && D_CSR) dsum = dcol[j];
+        else if (HAS_D) dsum += wv[j * L + c] * td[j];
         T divy = g.y0 + j < ny - 1 ? ty[j] : (T)0;
         if (g.y0 + j > 0) divy -= j > 0 ? ty[(j + V - 1) % V] : t_above;
         T divx = g.x < nx - 1 ? tx[j] : (T)0;
@@ -1429,8 +1514,9 @@ static bool pixel_op_ok(const prost_hip_pixel_op* op, uint64_t m, uint64_t n, un
   // back to the four-launch rounds (whose fold grids are capped) instead of picking a path whose every solve then fails
   if ((npx / V + kBlock - 1) / kBlock > (uint64_t)kReduceBlocks) return false;
   if (n != (uint64_t)op->L * npx) return false;
+  if (op->d_csr && (!op->has_d || !op->d_val || !op->d_ptr || !op->d_ind || !op->dt_val || !op->dt_ptr || !op->dt_ind)) return false;
   if (op->has_d) {
-    if (!op->w || m != npx + 2 * (uint64_t)op->L * npx) return false;
+    if ((!op->d_csr && !op->w) || m != npx + 2 * (uint64_t)op->L * npx) return false;
     const bool d_first = op->d_row == 0 && op->g_row == npx, g_first = op->g_row == 0 && op->d_row == 2 * (uint64_t)op->L * npx;
     if (!d_first && !g_first) return false;
   } else if (m != 2 * (uint64_t)op->L * npx || op->g_row != 0) {
@@ -1447,7 +1533,7 @@ static int cgls_pixel_round(const prost_hip_cgls_desc* d, const prost_hip_pixel_
   if (!pixel_op_ok(op, d->m, d->n, V) || !op->p_alt || !op->r_alt) { set_error("cgls_pixel_round: unsupported operator description (prost_hip_pixel_op_supported)"); return 1; }
   T* P[2] = {static_cast<T*>(d->p), static_cast<T*>(op->p_alt)};
   T* R[2] = {static_cast<T*>(d->r), static_cast<T*>(op->r_alt)};
-  for (const void* ptr : {(const void*)d->x, (const void*)d->q, (const void*)d->s, (const void*)d->sigma, (const void*)d->tau, (const void*)op->w,
+  for (const void* ptr : {(const void*)d->x, (const void*)d->q, (const void*)d->s, (const void*)d->sigma, (const void*)d->tau, op->d_csr ? (const void*)d->x : (const void*)op->w,
       (const void*)P[0], (const void*)P[1], (const void*)R[0], (const void*)R[1]})
     if (!aligned16(ptr)) { set_error("cgls_pixel_round: operands must be 16-byte aligned"); return 1; }
   hipStream_t st = as_stream(stream);
@@ -1462,6 +1548,9 @@ static int cgls_pixel_round(const prost_hip_cgls_desc* d, const prost_hip_pixel_
   PixArgs<T> a;
   a.nx = (unsigned)op->nx; a.ny = (unsigned)op->ny; a.npx = npx; a.d_row = (size_t)op->d_row; a.g_row = (size_t)op->g_row;
   a.w = static_cast<const T*>(op->w); a.sigma = static_cast<const T*>(d->sigma); a.tau = static_cast<const T*>(d->tau);
+  a.d_val = static_cast<const T*>(op->d_val); a.d_ptr = op->d_ptr; a.d_ind = op->d_ind;
+  a.dt_val = static_cast<const T*>(op->dt_val); a.dt_ptr = op->dt_ptr; a.dt_ind = op->dt_ind;
+  const bool d_csr = op->has_d != 0 && op->d_csr != 0;
   a.x = static_cast<T*>(d->x); a.s = static_cast<T*>(d->s); a.q = static_cast<T*>(d->q);
   a.negshift = (T)(-d->shift); a.tiles = tiles; a.sig_g = (T)op->sigma_grad;
   const bool has_d = op->has_d != 0, d_first = has_d && op->d_first != 0;
@@ -1478,18 +1567,21 @@ static int cgls_pixel_round(const prost_hip_cgls_desc* d, const prost_hip_pixel_
   a.r_in = R[round & 1]; a.r_out = R[(round + 1) & 1];
   const RoundScalars sa{d->shift, eps, tiles, tiles, d->host_done};
   mark(0);
-#define PIX_A(LL, HD, DF, FI) PH_LAUNCH((cg_pixel_pq_kernel<T, LL, HD, DF, FI>), dim3(tiles), dim3(kBlock), 0, st, a, round == 0 ? rec : rec + round - 1, rec + round, ws, sa)
-#define PIX_A_L(LL) do { if (round == 0) { if (!has_d) PIX_A(LL, false, false, true); else if (d_first) PIX_A(LL, true, true, true); else PIX_A(LL, true, false, true); } \
-                         else { if (!has_d) PIX_A(LL, false, false, false); else if (d_first) PIX_A(LL, true, true, false); else PIX_A(LL, true, false, false); } } while (0)
+#define PIX_A(LL, HD, DF, FI, DC) PH_LAUNCH((cg_pixel_pq_kernel<T, LL, HD, DF, FI, DC>), dim3(tiles), dim3(kBlock), 0, st, a, round == 0 ? rec : rec + round - 1, rec + round, ws, sa)
+#define PIX_A_D(LL, FI) do { if (!has_d) PIX_A(LL, false, false, FI, false); else if (d_csr) { if (d_first) PIX_A(LL, true, true, FI, true); else PIX_A(LL, true, false, FI, true); } \
+                             else if (d_first) PIX_A(LL, true, true, FI, false); else PIX_A(LL, true, false, FI, false); } while (0)
+#define PIX_A_L(LL) do { if (round == 0) PIX_A_D(LL, true); else PIX_A_D(LL, false); } while (0)
   if (L == 1) PIX_A_L(1); else if (L == 2) PIX_A_L(2); else PIX_A_L(3);
 #undef PIX_A_L
+#undef PIX_A_D
 #undef PIX_A
   // launch B of round j: alpha ; x, r ; s
   a.p_in = P[round & 1];
   const RoundScalars sb{d->shift, eps, tiles, tiles, nullptr};
   mark(1);
-#define PIX_B(LL, HD, DF) PH_LAUNCH((cg_pixel_xrs_kernel<T, LL, HD, DF>), dim3(tiles), dim3(kBlock), 0, st, a, rec + round, rec + round + 1, ws, sb)
-#define PIX_B_L(LL) do { if (!has_d) PIX_B(LL, false, false); else if (d_first) PIX_B(LL, true, true); else PIX_B(LL, true, false); } while (0)
+#define PIX_B(LL, HD, DF, DC) PH_LAUNCH((cg_pixel_xrs_kernel<T, LL, HD, DF, DC>), dim3(tiles), dim3(kBlock), 0, st, a, rec + round, rec + round + 1, ws, sb)
+#define PIX_B_L(LL) do { if (!has_d) PIX_B(LL, false, false, false); else if (d_csr) { if (d_first) PIX_B(LL, true, true, true); else PIX_B(LL, true, false, true); } \
+                         else if (d_first) PIX_B(LL, true, true, false); else PIX_B(LL, true, false, false); } while (0)
   if (L == 1) PIX_B_L(1); else if (L == 2) PIX_B_L(2); else PIX_B_L(3);
 #undef PIX_B_L
 #undef PIX_B

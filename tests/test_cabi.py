@@ -27,7 +27,7 @@ def test_kernel_library_exports_every_declared_symbol():
     L = _hip.lib()
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
-    assert L.prost_hip_abi_version() == 9
+    assert L.prost_hip_abi_version() == 10
     assert L.prost_hip_reduce_workspace_bytes() >= 4096
 
 

@@ -107,15 +107,17 @@ def test_bench_c4_reduced():
 
 
 def test_bench_c4w_reduced():
-    """BASELINE.json configs[3] as worded (warp matrix): the four-launch CG rounds with the operator inside the stage kernels"""
+    """BASELINE.json configs[3] as worded (warp matrix): the two-launch CG rounds with the rows of W gathered (round 6; four launches before)"""
     d = _bench("--config", "c4w", "--steps", "20", "--warmup", "5", "--size", "128", "--prelude-iters", "10")
     _check_contract(d, 20, 5)
-    assert d["config"]["name"] == "c4w" and d["config"]["path"] == "admm:fused-op" and "warp matrix" in d["config"]["workload"]
+    assert d["config"]["name"] == "c4w" and d["config"]["path"] == "admm:pixel-op" and "warp matrix" in d["config"]["workload"]
     r = d["roofline"]
-    assert set(r["all_kernels"]) == {"op_stage_kernel<EpiFwdQ>", "cg_step_xr2_kernel", "op_stage_kernel<EpiAdjS>", "cg_step_p2_kernel"}
+    assert set(r["all_kernels"]) == {"cg_pixel_pq_kernel", "cg_pixel_xrs_kernel"}
     px = 128 * 128
     bm = bench_module()
-    assert r["compulsory_bytes_per_iteration"] == bm.c4_iteration_bytes("admm:fused-op", d["cg_iterations_last_solve"], px, 4, 4) and 0 < r["frac_iteration"] <= 1
+    assert r["compulsory_bytes_per_iteration"] == bm.c4_iteration_bytes("admm:pixel-op", d["cg_iterations_last_solve"], px, 4, 4) and 0 < r["frac_iteration"] <= 1
+    # launch A: W's 4 values + 4 column indices + 1 row start per pixel instead of the 2 values of a pixel-diagonal W
+    assert bm.c4_kernel_bytes("cg_pixel_pq_kernel", px, 4, 4) == bm.c4_kernel_bytes("cg_pixel_pq_kernel", px, 4, 2) + (2 * 4 + 5 * 4) * px
     # 4 non-zeros per row: two more values and two more column indices per pixel than C4's W in every stage that applies it
     assert bm.c4_kernel_bytes("op_stage_kernel<EpiFwdQ>", px, 4, 4) == bm.c4_kernel_bytes("op_stage_kernel<EpiFwdQ>", px, 4, 2) + 16 * px
     assert d["oracle_pin"].startswith("unpinned")

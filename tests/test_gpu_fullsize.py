@@ -249,14 +249,14 @@ def _admm_vs_oracle(prob, k, path, threads=16):
 def test_c4w_1024_admm_on_a_warp_matrix_matches_oracle():
     """BASELINE.json configs[3] as worded -- "block_sparse WARP MATRIX + gradient2d" -- at 1024^2: W gathers the two flow channels at
     columns displaced by a smooth flow of up to 5 pixels (4 non-zeros per row, general CSR: synthetic.warp_matrix; the reference applies
-    it with cusparse csrmv, block_sparse.cu:146-211).  No pixel-diagonal structure, so the CG rounds are the four-launch ones with the
-    operator inside the stage kernels (admm:fused-op); product against oracle.Solver after 5 outer iterations at the tolerance of row
-    a5 (2e-4 of the vector's scale, equal CG iteration counts).  ADMM / CGLS parity is unpinned by the reference."""
+    it with cusparse csrmv, block_sparse.cu:146-211).  One row of W per pixel, so the CG rounds are the two-launch ones with the operand
+    of every entry recomputed at the gathered pixel (admm:pixel-op, round 6); product against oracle.Solver after 5 outer iterations at
+    the tolerance of row a5 (2e-4 of the vector's scale, equal CG iteration counts).  ADMM / CGLS parity is unpinned by the reference."""
     W = synthetic.warp_matrix(64).tocsr()
     assert (np.diff(W.indptr) == 4).all() and W.shape == (64 * 64, 2 * 64 * 64)
     far = np.abs((W.indices % (64 * 64)) - np.repeat(np.arange(64 * 64), 4))
     assert far.max() >= 4 * 64                     # entries several image columns away from the row's own pixel: a gather, not a diagonal
-    _admm_vs_oracle(synthetic.tvl1_flow_problem(1024, warp=True), 5, "admm:fused-op")
+    _admm_vs_oracle(synthetic.tvl1_flow_problem(1024, warp=True), 5, "admm:pixel-op")
 
 
 def test_c4_2048_streams_from_hbm_and_4096_falls_back_to_the_four_launch_rounds():

@@ -578,7 +578,19 @@ def pixel_coupled_problem(nx, ny, L, has_d=True, d_first=True, seed=0):
     v, g = prost.variable(n), prost.variable(2 * L * n)
     cons = ([v, g] if d_first else [g, v]) if has_d else [g]
     prob = prost.min_problem([u], cons)
-    if has_d:
+    if has_d == "csr":
+        # round 6: D as a general sparse block with one row per pixel -- 0 .. 4 entries per row anywhere in the L n columns (empty rows and
+        # empty columns included), the shape of a warp matrix that gathers at displaced pixels
+        rng = np.random.default_rng(seed + 11)
+        counts = rng.integers(0, 5, size=n)
+        rows = np.repeat(np.arange(n), counts)
+        near = np.clip(rows % n + rng.integers(-3 * ny, 3 * ny + 1, size=rows.size), 0, n - 1)
+        cols = near + n * rng.integers(0, L, size=rows.size)
+        D = sp.csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(n, L * n))     # (duplicates are summed: fewer entries)
+        D.eliminate_zeros()
+        prob.add_function(v, prost.function.sum_1d("abs", 1, bvec, 5.0))
+        prob.add_constraint(u, v, prost.block.sparse(D.tocsc()))
+    elif has_d:
         prob.add_function(v, prost.function.sum_1d("abs", 1, bvec, 5.0))
         prob.add_constraint(u, v, prost.block.sparse(sp.hstack([sp.diags(wc) for wc in w]).tocsc()))
     prob.add_function(g, prost.function.sum_norm2(2 * L, False, "abs"))
@@ -588,7 +600,9 @@ def pixel_coupled_problem(nx, ny, L, has_d=True, d_first=True, seed=0):
 
 @pytest.mark.parametrize("precision,dtype", PRECISIONS)
 @pytest.mark.parametrize("nx,ny,L,has_d,d_first", [(16, 12, 2, True, True), (9, 20, 2, True, False), (7, 8, 1, True, True), (12, 16, 3, True, True),
-                                                    (11, 24, 2, False, True), (5, 1028, 1, False, True), (40, 264, 2, True, True)])
+                                                    (11, 24, 2, False, True), (5, 1028, 1, False, True), (40, 264, 2, True, True),
+                                                    (16, 12, 2, "csr", True), (9, 20, 2, "csr", False), (7, 8, 1, "csr", True), (12, 16, 3, "csr", True),
+                                                    (40, 264, 2, "csr", True)])
 def test_admm_cg_variants_agree_bit_for_bit(precision, dtype, nx, ny, L, has_d, d_first):
     """One ADMM run, four implementations of the CGLS graph projection -- CG rounds of TWO launches (pixel-ordered, operators
     [D ; gradient2d]), of FOUR launches (operator inside the stage kernels), the staged rounds around LinearOperator::Eval, and the
@@ -619,7 +633,44 @@ def test_admm_cg_variants_agree_bit_for_bit(precision, dtype, nx, ny, L, has_d, 
         assert_same_iterates(st["pixel"], ost, exact=True)
         assert st["pixel"]["rho"] == ost["rho"]
         for r_ in ("primal_res", "dual_res"):
-            assert st["pixel"][r_] == ost[r_], (iters, r_, st["pixel"][r_], ost[r_])
+            # (fp64 on the random rows of "csr": the product's sums are double-double, the oracle's exact -- equal after rounding except for a
+            #  sum that lies within 2^-106 of a rounding boundary; seen once: 0.7075602990803983 against ...84)
+            slack = np.spacing(ost[r_]) if has_d == "csr" and dtype == np.float64 else 0.0
+            assert abs(st["pixel"][r_] - ost[r_]) <= slack, (iters, r_, st["pixel"][r_], ost[r_])
+    prost.set_precision("double")
+
+
+@pytest.mark.parametrize("precision,dtype", PRECISIONS)
+@pytest.mark.parametrize("m,n1,n2", [(2, 84, 6), (40, 24, 56), (300, 256, 192)])
+def test_admm_fused_rounds_with_two_blocks_on_the_same_rows_bit_for_bit(precision, dtype, m, n1, n2):
+    """K = [A B]: two sparse blocks on the SAME rows.  LinearOperator::Eval with accumulate adds block by block onto what is there --
+    r = (r0 + A t_1) + B t_2 -- and the operator-in-stage kernels must do the same (round 6: they formed r0 + (A t_1 + B t_2) in
+    INIT_RK / PRE_ZK, one unit in the last place apart; found by tools/fuzz_parity.py --mode generic on a 2-row operator whose CG
+    solves run on rounding noise and amplify it).  Four-launch rounds == staged rounds == oracle, bit for bit."""
+    prost.set_precision(precision)
+    rng = np.random.default_rng(17)
+    A = sp.random(m, n1, density=min(1.0, 3.0 / n1), random_state=3, format="csc") + sp.csc_matrix(([1.0], ([0], [0])), shape=(m, n1))
+    B = sp.random(m, n2, density=min(1.0, 3.0 / n2), random_state=4, format="csc") + sp.csc_matrix(([0.5], ([m - 1], [n2 - 1])), shape=(m, n2))
+    u1, u2, v = prost.variable(n1), prost.variable(n2), prost.variable(m)
+    prob = prost.min_problem([u1, u2], [v])
+    prob.add_function(u1, prost.function.sum_1d("square", 1, rng.standard_normal(n1), 2.0))
+    prob.add_function(u2, prost.function.sum_1d("abs", 1, rng.standard_normal(n2), 0.7))
+    prob.add_function(v, prost.function.sum_1d("huber", 1, rng.standard_normal(m), 1, 0, 0, 0.4))
+    prob.add_constraint(u1, v, prost.block.sparse(A.tocsc()))
+    prob.add_constraint(u2, v, prost.block.sparse(B.tocsc()))
+    o = prost.options(max_iters=100, num_cback_calls=0, verbose=False)
+    for iters in (2, 9):
+        st = {}
+        for fused_rounds in (True, False):
+            b = prost.backend.admm(rho0=1, residual_iter=4)
+            b[1]["fused_rounds"] = fused_rounds
+            b[1]["pixel_rounds"] = False
+            st[fused_rounds] = run_product(prob, b, o, iters)
+        assert st[True]["path"] == "admm:fused-op" and st[False]["path"] == "admm:generic"
+        ost = run_oracle(prob, prost.backend.admm(rho0=1, residual_iter=4), o, iters, dtype)
+        for k in (True, False):
+            assert_same_iterates(st[k], ost, exact=True)
+            assert st[k]["cg_iterations"] == ost["cg_iterations"] and st[k]["rho"] == ost["rho"], (iters, k)
     prost.set_precision("double")
 
 

@@ -1,7 +1,8 @@
 #!/bin/bash
 # On the GPU box: HBM traffic counters (separate --pmc passes, FETCH_SIZE / WRITE_SIZE) of the kernels round 6 added or re-measured:
 # the K-iteration kernel of the tolerance class at the headline size, the CG-round kernels of C4 at 2048^2 (beyond the Infinity Cache)
-# and of the warp-matrix config c4w.  usage: bash tools/collect_r06_pmc.sh   -> gpurun_out/r06/pmc_traffic_raw.txt
+# and of the warp-matrix config c4w.  usage: bash tools/collect_r06_pmc.sh [c4w]  -> gpurun_out/r06/pmc_traffic_raw.txt (c4w: only the c4w runs ->
+# pmc_traffic_c4w_raw.txt: the two-launch rounds with gathered rows, round 6)
 R=$PWD; O=$R/gpurun_out/r06; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 run() {   # tag, bench args...
@@ -30,6 +31,14 @@ for k, d in sorted(agg.items()):
 PY
   rm -rf /tmp/pmc_${tag}_FETCH_SIZE /tmp/pmc_${tag}_WRITE_SIZE
 }
+if [ "$1" = "c4w" ]; then
+{
+run c4w_1024 --config c4w --steps 20 --warmup 5
+run c4w_2048 --config c4w --size 2048 --steps 12 --warmup 3
+} > $O/pmc_traffic_c4w_raw.txt 2>&1
+cat $O/pmc_traffic_c4w_raw.txt
+exit 0
+fi
 {
 run c2_fmad --arithmetic fmad --steps 60 --warmup 10
 run c2_exact --no-fmad --steps 60 --warmup 10
