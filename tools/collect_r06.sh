@@ -21,7 +21,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats -- python3 $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats_driver -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats_c3 -- python3 $R/bench.py --config c3 --no-cpu-baseline > $O/bench_c3_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o stats_c4w -- python3 $R/bench.py --config c4w --no-cpu-baseline > $O/bench_c4w_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O -o kernels -- python3 $R/tools/bench_kernels.py > $O/kernels_raw.jsonl 2> $O/kernels.err
 cd $R
+python3 tools/annotate_kernels.py $O/kernels_raw.jsonl profiles/r06_kernels.jsonl > $O/kernels.jsonl
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 for f in $(find $O -name "*_kernel_stats.csv"); do echo $f; python3 -c "
 import csv
