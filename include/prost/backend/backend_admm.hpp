@@ -37,7 +37,8 @@ class BackendADMM : public Backend<T> {
   virtual void current_solution(std::vector<T>& primal, std::vector<T>& dual);
   virtual void current_solution(std::vector<T>& primal_x, std::vector<T>& primal_z, std::vector<T>& dual_y, std::vector<T>& dual_w);
   virtual size_t gpu_mem_amount() const;
-  /// "admm:pixel-op": CG rounds of two launches (operators [D ; gradient2d]); "admm:fused-op": CG rounds of four launches with the
+  /// "admm:pixel-op": CG rounds of two launches (operators [D ; gradient2d], D pixel-diagonal or any sparse block with one row per
+  /// pixel, e.g. a warp matrix); "admm:fused-op": CG rounds of four launches with the
   /// operator inside the stage kernels; "admm:generic": staged rounds
   virtual std::string path() const { return pixel_rounds_ ? "admm:pixel-op" : fused_rounds_ ? "admm:fused-op" : "admm:generic"; }
   T rho() const { return rho_; }

@@ -1183,6 +1183,10 @@ static int admm_fused_stage(int stage, const prost_hip_admm_desc* d, const prost
 // round and to the staged round.  Per pixel and round (L = 2): A reads p, s, tau (6), D's values (2), sigma (5), writes p, q (7);
 // B reads r, q (10), D's sigma (1), x, p, tau (6), D's values (2), writes r, x, s (9); A: sigma on D's rows only (1 instead of 5):
 // 44 values instead of ~80.  (Sigma on the gradient rows is ONE number: the caller checks it.)
+// D_CSR (round 6, prost_hip_pixel_op.d_csr): D is ANY sparse block with one row per pixel (a warp matrix: row i gathers the channels at
+// pixels displaced from i).  The owner of pixel i still owns D's row i (launch A) and the L columns of D^T at i (launch B); the operand
+// of an entry belongs to ANOTHER pixel and is recomputed from that pixel's stored operands like the stencil neighbours are -- three
+// gathered values per entry instead of one, t never stored (csr_rows_formed below).
 template <class T> struct PixArgs {
   unsigned nx, ny;                     // image; ny % VEC == 0
   size_t npx;                          // nx ny
